@@ -1,0 +1,55 @@
+"""Pins the oracle (oracle/rapsearch_port.c) against golden vectors captured from the reference.
+
+The reference's search engine is the closed RAPsearch2 v2.15 binary
+(/root/reference/microbe_census/microbe_census.py:369-389); tests/golden/make_golden.py ran it in
+the build container and committed its m8 output.  The oracle must reproduce those files byte for
+byte (md5 of all non-# lines), which pins every stage: 6-frame translation, SEG masking, seeding,
+ungapped/gapped extension, statistics, sum statistics, ranking and the 500-row cap.
+"""
+import gzip
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _trimmed_reads_fasta(case, tmp_path):
+    """Re-create the FASTA the reference fed to rapsearch (process_seqfile, microbe_census.py:328-367)."""
+    meta = json.load(open(os.path.join(GOLD, case + ".json")))
+    L = meta["args"]["read_length"]
+    out = tmp_path / (case + ".fa")
+    reads_gz = os.path.join(GOLD, case + ".reads.fa.gz")
+    if os.path.exists(reads_gz):
+        data = gzip.open(reads_gz, "rb").read()
+    else:  # FASTA input, every record long enough is kept and trimmed
+        recs, name, seq = [], None, []
+        with gzip.open(os.path.join(GOLD, "inputs", meta["seqfiles"][0]), "rt") as f:
+            for line in f:
+                if line[0] == ">":
+                    if name is not None:
+                        recs.append("".join(seq))
+                    name, seq = line, []
+                else:
+                    seq.append(line.strip())
+            recs.append("".join(seq))
+        keep = [s[:L] for s in recs if len(s) >= L][: meta["args"]["nreads"]]
+        data = "".join(">%d\n%s\n" % (i, s) for i, s in enumerate(keep)).encode()
+    assert hashlib.md5(data).hexdigest() == meta["reads_md5"]
+    out.write_bytes(data)
+    return str(out), meta
+
+
+@pytest.mark.parametrize("case", ["config1_example_fq", "unittest_metagenome"])
+def test_oracle_reproduces_reference_m8(case, oracle_bin, ref_dir, tmp_path):
+    fasta, meta = _trimmed_reads_fasta(case, tmp_path)
+    out = str(tmp_path / "out.m8")
+    subprocess.check_call([oracle_bin, os.path.join(ref_dir, "rapdb_2.15"), fasta, out])
+    got = open(out, "rb").read()
+    assert got.count(b"\n") == meta["m8_rows"]
+    assert hashlib.md5(got).hexdigest() == meta["m8_md5"]
+    want = gzip.open(os.path.join(GOLD, case + ".m8.gz"), "rb").read()
+    assert got == want
