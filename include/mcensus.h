@@ -1,0 +1,87 @@
+/* mcensus.h - C ABI of libmcensus_hip.so: the MI355X (gfx950) implementation of MicrobeCensus' hot path.
+ *
+ * The reference has no FFI: its hot path is a subprocess,
+ *     rapsearch -q tmp -d rapdb_2.15 -o tmp -z T -e 1 -t n -p f -b 0
+ * launched by search_seqs()            (/root/reference/microbe_census/microbe_census.py:369-389),
+ * whose tmp.m8 is parsed by parse_rapsearch()/classify_reads()          (microbe_census.py:391-460),
+ * and whose database comes from `prerapsearch -d markers.faa -n rapdb_2.15` (training/search_reads.py:57
+ * documents the flag set).  Each entry point below names the piece of that interface it replaces.
+ * Plain pointers and sizes only; every call returns 0 (or a count) on success and a negative value on
+ * error, with the message available from mc_last_error().  There is no CPU fallback: without a HIP device
+ * mc_open() fails.
+ */
+#ifndef MCENSUS_H
+#define MCENSUS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mc_handle mc_handle;
+
+/* One row of RAPsearch2's m8 output (the 12 columns parse_rapsearch reads, microbe_census.py:391-398),
+ * kept binary: query = read id, subject = marker index. */
+typedef struct mc_row {
+    int32_t query, subject;
+    double ident;
+    int32_t alnlen, mismatch, gapopen, qstart, qend, sstart, send;
+    double loge, bits;
+    int32_t score, nmatch;
+} mc_row;
+
+/* best_hits[read] = [family, aln, aln/target_len, score]   (classify_reads, microbe_census.py:450-453) */
+typedef struct mc_best_hit {
+    int32_t read, family, aln, target_len;
+    double bits;
+} mc_best_hit;
+
+typedef struct mc_stats {
+    int64_t reads, seed_tasks, gap_tasks, hsps, rows, reads_with_rows, classified;
+    float ms_translate, ms_seed, ms_eval, ms_gapped, ms_sort, ms_finish, ms_total;
+} mc_stats;
+
+const char *mc_last_error(void);
+int mc_device_count(void);
+
+/* Replaces `prerapsearch -d <fasta> -n <db>` + the DB load of rapsearch (CHashSearch::BuildDHash / Search):
+ * builds the reduced-alphabet 6-mer index of the marker proteins on the host and uploads it to `device`.
+ * marker_family[i] is the gene family index of marker i (gene_fam.map, microbe_census.py:438). */
+mc_handle *mc_open(const char *const *names, const char *const *seqs, int32_t nseq,
+                   const int32_t *marker_family, int32_t nfam, int32_t device);
+void mc_close(mc_handle *h);
+
+/* Host views of the index, for cross-checking against a prerapsearch-built database (tests only). */
+int mc_index_view(const mc_handle *h, const uint8_t **res_codes, const uint32_t **offsets, const uint32_t **bucket_starts,
+                  const uint32_t **postings, const uint16_t **keys, int64_t *nres, int64_t *npostings,
+                  uint32_t *freq_thr, double letter_p[10]);
+
+/* Per-run parameters: trimmed read length (args['read_length']), the -e threshold, and
+ * find_opt_pars(pars.map, L) (microbe_census.py:61-72) as arrays indexed by family. aln_stat: 0 hits, 1 cov, 2 aln. */
+int mc_set_run(mc_handle *h, int32_t read_len, double loge_thr, const double *min_cov, const double *min_score,
+               const int32_t *max_aaid, const int32_t *aln_stat);
+
+/* Replaces search_seqs() + classify_reads(): reads = nreads x read_len bytes (the trimmed sequences that
+ * process_seqfile writes, one after another, no separators).  Runs the whole device pipeline.
+ * first_read_id is added to the read index to form the query id. */
+int mc_search(mc_handle *h, const uint8_t *reads, int64_t nreads, int64_t first_read_id);
+
+/* Same pipeline on reads that are already resident in HBM (bench / streaming):
+ * mc_upload() copies a batch to the device, mc_run() executes the kernels on it (no host transfers of reads). */
+int mc_upload(mc_handle *h, const uint8_t *reads, int64_t nreads);
+int mc_run(mc_handle *h, int64_t first_read_id);
+
+/* Results of the last mc_search()/mc_run(), owned by the handle until the next call:
+ * rows in the reference's m8 order (ascending read id, then RAPsearch2's order within a read); best hits in
+ * ascending read id (only reads with a passing hit). */
+int64_t mc_result_rows(mc_handle *h, const mc_row **rows);
+int64_t mc_result_best_hits(mc_handle *h, const mc_best_hit **hits);
+int mc_result_stats(mc_handle *h, mc_stats *out);
+
+/* Writes the rows of the last run as RAPsearch2 m8 text (PrintRes formatting: %g columns, tab separated,
+ * no header lines) - what search_seqs() leaves in paths['tempfile']+'.m8'. append != 0 appends. */
+int mc_write_m8(mc_handle *h, const char *path, int append);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

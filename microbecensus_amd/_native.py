@@ -1,0 +1,182 @@
+"""ctypes binding of libmcensus_hip.so (include/mcensus.h).  No CPU fallback: if the HIP library is
+missing or no MI355X is visible, importing the engine fails loudly."""
+import ctypes as C
+import gzip
+import json
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmcensus_hip.so")
+DATA_DIR = os.path.join(_HERE, "data")
+
+
+class McRow(C.Structure):
+    _fields_ = [("query", C.c_int32), ("subject", C.c_int32), ("ident", C.c_double), ("alnlen", C.c_int32),
+                ("mismatch", C.c_int32), ("gapopen", C.c_int32), ("qstart", C.c_int32), ("qend", C.c_int32),
+                ("sstart", C.c_int32), ("send", C.c_int32), ("loge", C.c_double), ("bits", C.c_double),
+                ("score", C.c_int32), ("nmatch", C.c_int32)]
+
+
+class McBestHit(C.Structure):
+    _fields_ = [("read", C.c_int32), ("family", C.c_int32), ("aln", C.c_int32), ("target_len", C.c_int32),
+                ("bits", C.c_double)]
+
+
+class McStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("reads", "seed_tasks", "gap_tasks", "hsps", "rows", "reads_with_rows", "classified")] + \
+               [(n, C.c_float) for n in ("ms_translate", "ms_seed", "ms_eval", "ms_gapped", "ms_sort", "ms_finish", "ms_total")]
+
+
+ROW_DTYPE = np.dtype([("query", "<i4"), ("subject", "<i4"), ("ident", "<f8"), ("alnlen", "<i4"), ("mismatch", "<i4"),
+                      ("gapopen", "<i4"), ("qstart", "<i4"), ("qend", "<i4"), ("sstart", "<i4"), ("send", "<i4"),
+                      ("loge", "<f8"), ("bits", "<f8"), ("score", "<i4"), ("nmatch", "<i4")], align=True)
+BEST_DTYPE = np.dtype([("read", "<i4"), ("family", "<i4"), ("aln", "<i4"), ("target_len", "<i4"), ("bits", "<f8")], align=True)
+
+_lib = None
+
+
+def load_library():
+    """Load libmcensus_hip.so and declare the prototypes of include/mcensus.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.mc_last_error.restype = C.c_char_p
+    lib.mc_device_count.restype = C.c_int
+    lib.mc_open.restype = C.c_void_p
+    lib.mc_open.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32]
+    lib.mc_close.argtypes = [C.c_void_p]
+    lib.mc_index_view.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 5 + [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+    lib.mc_set_run.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.mc_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
+    lib.mc_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.mc_run.argtypes = [C.c_void_p, C.c_int64]
+    lib.mc_result_rows.restype = C.c_int64
+    lib.mc_result_rows.argtypes = [C.c_void_p, C.POINTER(C.POINTER(McRow))]
+    lib.mc_result_best_hits.restype = C.c_int64
+    lib.mc_result_best_hits.argtypes = [C.c_void_p, C.POINTER(C.POINTER(McBestHit))]
+    lib.mc_result_stats.argtypes = [C.c_void_p, C.POINTER(McStats)]
+    lib.mc_write_m8.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_index_view", "mc_set_run", "mc_search",
+                    "mc_upload", "mc_run", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8"]
+
+
+def load_markers(path=None):
+    """(names, seqs) of the canonical marker FASTA shipped as package data."""
+    path = path or os.path.join(DATA_DIR, "markers.faa.gz")
+    names, seqs = [], []
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rt") as f:
+        for line in f:
+            if line.startswith(">"):
+                names.append(line[1:].split()[0])
+                seqs.append([])
+            else:
+                seqs[-1].append(line.strip())
+    return names, ["".join(s) for s in seqs]
+
+
+def load_model(path=None):
+    with open(path or os.path.join(DATA_DIR, "model.json")) as f:
+        return json.load(f)
+
+
+ALN_STAT = {"hits": 0, "cov": 1, "aln": 2}
+
+
+class Engine:
+    """One MI355X: marker index resident in HBM + the search/classify pipeline."""
+
+    def __init__(self, device=0, names=None, seqs=None, marker_family=None, nfam=None):
+        lib = load_library()
+        if names is None:
+            names, seqs = load_markers()
+            model = load_model()
+            marker_family, nfam = model["marker_family"], len(model["families"])
+        self.lib, self.names, self.nfam = lib, names, nfam
+        n = len(names)
+        an = (C.c_char_p * n)(*[s.encode() for s in names])
+        asq = (C.c_char_p * n)(*[s.encode() for s in seqs])
+        fam = (C.c_int32 * n)(*marker_family)
+        self.h = lib.mc_open(an, asq, n, fam, nfam, device)
+        if not self.h:
+            raise RuntimeError("mc_open failed: %s" % lib.mc_last_error().decode())
+        self.read_len = None
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.lib.mc_last_error().decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mc_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_run(self, read_len, pars=None, families=None, loge_thr=1.0):
+        """pars: {family: [min_cov, max_aaid, min_score, aln_stat]} as find_opt_pars returns for this length."""
+        nf = self.nfam
+        cov = (C.c_double * nf)(*([0.0] * nf)); score = (C.c_double * nf)(*([0.0] * nf))
+        aaid = (C.c_int32 * nf)(*([100] * nf)); stat = (C.c_int32 * nf)(*([0] * nf))
+        if pars is not None:
+            for i, fam in enumerate(families):
+                p = pars[fam]
+                cov[i], aaid[i], score[i], stat[i] = float(p[0]), int(round(float(p[1]))), float(p[2]), ALN_STAT[p[3]]
+                assert float(p[1]) == aaid[i]
+        self._check(self.lib.mc_set_run(self.h, read_len, loge_thr, cov, score, aaid, stat), "mc_set_run")
+        self.read_len = read_len
+
+    def search(self, reads, first_read_id=0):
+        """reads: uint8 array (n, read_len) of bases.  Returns (rows, best_hits) as numpy structured arrays."""
+        reads = np.ascontiguousarray(reads, dtype=np.uint8)
+        assert reads.ndim == 2 and reads.shape[1] == self.read_len
+        self._check(self.lib.mc_search(self.h, reads.ctypes.data_as(C.c_void_p), reads.shape[0], first_read_id), "mc_search")
+        return self.results()
+
+    def upload(self, reads):
+        reads = np.ascontiguousarray(reads, dtype=np.uint8)
+        assert reads.ndim == 2 and reads.shape[1] == self.read_len
+        self._check(self.lib.mc_upload(self.h, reads.ctypes.data_as(C.c_void_p), reads.shape[0]), "mc_upload")
+
+    def run(self, first_read_id=0):
+        self._check(self.lib.mc_run(self.h, first_read_id), "mc_run")
+
+    def results(self):
+        pr = C.POINTER(McRow)(); pb = C.POINTER(McBestHit)()
+        n = self.lib.mc_result_rows(self.h, C.byref(pr)); m = self.lib.mc_result_best_hits(self.h, C.byref(pb))
+        rows = np.ctypeslib.as_array(C.cast(pr, C.POINTER(C.c_uint8)), shape=(n * C.sizeof(McRow),)).view(ROW_DTYPE).copy() if n else np.zeros(0, ROW_DTYPE)
+        best = np.ctypeslib.as_array(C.cast(pb, C.POINTER(C.c_uint8)), shape=(m * C.sizeof(McBestHit),)).view(BEST_DTYPE).copy() if m else np.zeros(0, BEST_DTYPE)
+        return rows, best
+
+    def stats(self):
+        s = McStats()
+        self._check(self.lib.mc_result_stats(self.h, C.byref(s)), "mc_result_stats")
+        return {k: getattr(s, k) for k, _ in McStats._fields_}
+
+    def write_m8(self, path, append=False):
+        self._check(self.lib.mc_write_m8(self.h, path.encode(), 1 if append else 0), "mc_write_m8")
+
+    def index_view(self):
+        p = [C.c_void_p() for _ in range(5)]
+        nres, npost, thr = C.c_int64(), C.c_int64(), C.c_uint32()
+        lp = (C.c_double * 10)()
+        self._check(self.lib.mc_index_view(self.h, *[C.byref(x) for x in p], C.byref(nres), C.byref(npost), C.byref(thr), lp), "mc_index_view")
+        nseq = len(self.names)
+
+        def arr(ptr, dtype, n):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dtype).itemsize,)).view(dtype).copy()
+        return {"res": arr(p[0], "u1", nres.value), "off": arr(p[1], "<u4", nseq + 1), "bstart": arr(p[2], "<u4", 1000001),
+                "post": arr(p[3], "<u4", npost.value), "keys": arr(p[4], "<u2", npost.value), "thr": thr.value, "letter_p": list(lp)}

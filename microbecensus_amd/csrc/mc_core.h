@@ -1,0 +1,593 @@
+// mc_core.h - per-thread algorithms of the MI355X translated-search path.
+//
+// Every function here is what ONE GPU thread (or one wave, where noted) executes; the HIP kernels in
+// mc_kernels.hip are thin launch wrappers around them.  The functions are MC_HD so that the very same
+// source can also be compiled by g++ into the test-only emulation harness (tests/emul/) that checks the
+// logic against the oracle on machines without a GPU.  The product never runs that harness.
+//
+// What is computed follows RAPsearch2 v2.15 as the reference drives it
+// (/root/reference/microbe_census/microbe_census.py:369-389: rapsearch -z T -e 1 -t n -p f -b 0); the
+// addresses quoted are inside /root/reference/microbe_census/bin/rapsearch_Linux_2.15 and are the same
+// ones oracle/rapsearch_port.c documents.  This file is an independent, GPU-shaped formulation:
+// dense 5-bit residue codes, a 32x32 int8 score tile, table-driven statistics, per-candidate task
+// records and stateless (trace-free) gapped extension.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MC_HD __host__ __device__ __forceinline__
+#define MC_HDN __host__ __device__
+#else
+#define MC_HD inline
+#define MC_HDN inline
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// constants
+// ---------------------------------------------------------------------------------------------
+#define MC_NBUCKET 1000000
+#define MC_INV 20          // dense code of every non-amino-acid residue (stop, unknown codon, SEG mask)
+#define MC_INVGRP 10       // reduced-alphabet group of MC_INV
+#define MC_MAXAA 170       // longest frame supported (read length <= 510)
+#define MC_SMAX 4096       // raw scores are tabulated up to here
+#define MC_MAX_M8 500      // rapsearch -v 500
+#define MC_LNFAC_N 400
+
+#define MC_GAP_OPEN 11
+#define MC_GAP_EXT 1
+#define MC_SEED_SCORE 11.0
+#define MC_SEED_IDENT 4
+
+// chronological key of a seed hit inside one read: frame(3) | pos(8) | phase(6) | posting(11)
+#define MC_CHRONO(frame, pos, phase, idx) ((((uint32_t)(frame)) << 25) | (((uint32_t)(pos)) << 17) | (((uint32_t)(phase)) << 11) | ((uint32_t)(idx)))
+
+struct McTables {
+    int8_t sub[32 * 32];       // BLOSUM62 on dense codes, -5 wherever MC_INV is involved (this+0x31c)
+    uint8_t grp[32];           // dense code -> murphy10 group (this+0x219)
+    uint8_t codon[64];         // 16*i(b0)+4*i(b1)+i(b2), T,C,A,G = 0..3 -> dense code (aa@0x688c00)
+    double entray[2][16];      // Seg::entropy_init@0x439090 for W = 12 / 8
+    double lterm[13][16];      // log((1/total)*c)*c, Seg::entropy_cal@0x438f70 general branch
+    double lnfac[MC_LNFAC_N];  // lnfac@0x688c40
+    double xdrop_ungapped, xdrop_gapped, gap_trigger;   // this+0x40388, +0x40398, +0x40378
+    // per run (query length m = read_len/3): BlastStat state after blastComputeLengthAdjustmentComp
+    double ell, mprime, nprime, logK;
+    double loge_thr;           // -e 1
+    double loge_r[MC_SMAX];    // CalRes 0x4077ec-0x407b8f: rounded log10(E) per raw score
+    double bits_r[MC_SMAX];    // CalRes 0x40783f-0x407850 / 0x407be8: rounded bit score per raw score
+    uint32_t freq_thr;         // .info median bucket size (Db+0x38)
+    double letter_p[10];       // Db+0x28
+};
+
+struct McIndex {
+    const uint8_t *res;        // dense residue codes of all marker sequences
+    const uint32_t *off;       // nseq+1
+    const uint32_t *bstart;    // MC_NBUCKET+1
+    const uint32_t *post;      // seqIdx<<11 | pos, in prerapsearch bucket order
+    const uint16_t *keys;      // 4 reduced residues after the 6-mer, 0xF past the sequence end
+    int32_t nseq;
+};
+
+// one seed hit waiting for evaluation (ExtendSeq2Set body for one posting)
+struct McSeedTask {
+    uint32_t read;             // read index inside the batch
+    uint32_t chrono;           // MC_CHRONO
+    uint32_t posting;
+    uint32_t seedlen_nkey;     // seedlen | nkey<<8
+};
+
+// seed hit whose ungapped score reached the gapped trigger (AlignSeqs 0x4134c8)
+struct McGapTask {
+    uint32_t read, chrono, sidx;
+    int16_t qp, dp, L, qfwd, qbwd;   // grown seed start (frame / subject), length, ungapped extents
+    int16_t score, nmatch;
+};
+
+// one HSP (STResult as CalRes@0x4077a0 fills it)
+struct McHsp {
+    uint32_t read, chrono;
+    int32_t sidx;
+    int16_t score, frame;
+    int16_t alnlen, mism, gaps, nmatch;
+    int16_t qaas, qaae, ds, de;
+    int16_t qnts, qnte;
+    double loge;               // may be replaced by sum statistics during finishing
+};
+
+// m8 row (PrintRes@0x409310, second loop)
+struct McRow {
+    int32_t query, subject;
+    double ident;
+    int32_t alnlen, mismatch, gapopen, qstart, qend, sstart, send;
+    double loge, bits;
+    int32_t score, frame;
+};
+
+// ---------------------------------------------------------------------------------------------
+// 6-frame translation (BuildQHash 0x40d079-0x40d433) - one thread per (read, frame)
+// ---------------------------------------------------------------------------------------------
+MC_HD int mc_nt_idx(uint8_t c) { return c == 'T' ? 0 : c == 'C' ? 1 : c == 'A' ? 2 : c == 'G' ? 3 : -1; }
+MC_HD int mc_nt_idx_rc(uint8_t c)
+{ // index of the complement; the std::map of Process knows ACGTU (+lower case, which never translates)
+    return c == 'A' ? 0 : c == 'G' ? 1 : (c == 'T' || c == 'U') ? 2 : c == 'C' ? 3 : -1;
+}
+
+MC_HD int mc_translate_frame(const McTables &T, const uint8_t *read, int len, int frame, uint8_t *prot)
+{
+    int o = frame % 3, n = (len - o) / 3, i;
+    if (n < 0) n = 0;
+    if (frame < 3) {
+        for (i = 0; i < n; i++) {
+            int a = mc_nt_idx(read[o + 3 * i]), b = mc_nt_idx(read[o + 3 * i + 1]), c = mc_nt_idx(read[o + 3 * i + 2]);
+            prot[i] = (a < 0 || b < 0 || c < 0) ? MC_INV : T.codon[16 * a + 4 * b + c];
+        }
+    } else {
+        for (i = 0; i < n; i++) {
+            int p = len - 1 - (o + 3 * i);
+            int a = mc_nt_idx_rc(read[p]), b = mc_nt_idx_rc(read[p - 1]), c = mc_nt_idx_rc(read[p - 2]);
+            prot[i] = (a < 0 || b < 0 || c < 0) ? MC_INV : T.codon[16 * a + 4 * b + c];
+        }
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SEG (Seg::*@0x438b50-0x43b140; window W, locut 2.2, hicut 2.5, maxtrim 100, downset 0, upset 1)
+// Residues are dense codes; MC_INV does not count towards the composition.  Positions of masked
+// residues are returned as a bit set.
+// ---------------------------------------------------------------------------------------------
+MC_HD void mc_seg_state(const uint8_t *comp, uint8_t *sv)
+{ // composition counts sorted descending, 0 terminated (Seg::stateon@0x4399b0)
+    int n = 0;
+    for (int i = 0; i < 20; i++) {
+        int v = comp[i];
+        if (v > 0) {
+            int j = n;
+            while (j > 0 && sv[j - 1] < v) { sv[j] = sv[j - 1]; j--; }
+            sv[j] = (uint8_t)v; n++;
+        }
+    }
+    sv[n] = 0;
+}
+MC_HD double mc_seg_entropy(const McTables &T, int W, const uint8_t *sv)
+{ // Seg::entropy_cal@0x438f70
+    int total = 0, i;
+    double ent = 0.0;
+    for (i = 0; sv[i]; i++) total += sv[i];
+    if (total == W) { const double *e = T.entray[W == 12 ? 0 : 1]; for (i = 0; sv[i]; i++) ent = ent + e[sv[i]]; return ent; }
+    if (total == 0) return 0.0;
+    for (i = 0; sv[i]; i++) ent = ent + T.lterm[total][sv[i]];
+    double inv = 1.0 / (double)total;
+    double r = inv * (-ent);
+    return r / 0.6931471805599453;
+}
+MC_HD void mc_seg_comp(const uint8_t *s, int n, uint8_t *comp)
+{
+    for (int i = 0; i < 20; i++) comp[i] = 0;
+    for (int i = 0; i < n; i++) if (s[i] < 20) comp[s[i]]++;
+}
+MC_HD double mc_seg_getprob(const McTables &T, const uint8_t *sv, int total)
+{ // Seg::getprob@0x4393d0 = lnperm + lnass - total*ln 20
+    double ans1 = T.lnfac[20];
+    if (sv[0] != 0) {
+        int tot = 20, cls = 1, svim1 = sv[0], svi = 0, i;
+        for (i = 0;; svim1 = svi) {
+            if (++i == 20) { ans1 = ans1 - T.lnfac[cls]; break; }
+            else if ((svi = sv[i]) == svim1) cls++;
+            else {
+                tot -= cls;
+                ans1 = ans1 - T.lnfac[cls];
+                if (svi == 0) { ans1 = ans1 - T.lnfac[tot]; break; }
+                cls = 1;
+            }
+        }
+    }
+    double ans2 = T.lnfac[total];
+    for (int i = 0; sv[i] != 0; i++) ans2 = ans2 - T.lnfac[sv[i]];
+    double t = (double)total * 2.995732273553991;
+    return (ans2 + ans1) - t;
+}
+MC_HD void mc_seg_trim(const McTables &T, const uint8_t *s, int n, int *leftend, int *rightend)
+{ // Seg::trim@0x439e20
+    int lend = 0, rend = n - 1, minlen = 1;
+    double minprob = 1.0;
+    uint8_t comp[20], sv[21];
+    if (n - 100 > minlen) minlen = n - 100;
+    for (int len = n; len > minlen; len--) {
+        mc_seg_comp(s, len, comp);
+        for (int i = 0;; i++) {
+            mc_seg_state(comp, sv);
+            double prob = mc_seg_getprob(T, sv, len);
+            if (prob < minprob) { minprob = prob; lend = i; rend = len + i - 1; }
+            if (i + 1 + len > n) break;
+            if (s[i] < 20) comp[s[i]]--;
+            if (s[i + len] < 20) comp[s[i + len]]++;
+        }
+    }
+    *leftend = *leftend + lend;
+    *rightend = *rightend - (n - rend - 1);
+}
+// Seg::segseq@0x43a9e0 with the recursion turned into a work list (the result is a set of positions,
+// so the order in which sub-ranges are handled does not matter).  H must hold n doubles.
+MC_HDN void mc_seg_mask(const McTables &T, const uint8_t *prot, int n, uint8_t *maskbits /* (MC_MAXAA+7)/8 */, double *H)
+{
+    int W = (n <= 11) ? 8 : 12;
+    int16_t stk_s[16], stk_n[16];
+    int sp = 0;
+    for (int i = 0; i < (MC_MAXAA + 7) / 8; i++) maskbits[i] = 0;
+    stk_s[0] = 0; stk_n[0] = (int16_t)n; sp = 1;
+    while (sp > 0) {
+        sp--;
+        int base = stk_s[sp], m = stk_n[sp];
+        const uint8_t *s = prot + base;
+        if (W > m) continue;
+        // Seg::seqent@0x43a2e0
+        {
+            uint8_t comp[20], sv[21];
+            int start = 0;
+            mc_seg_comp(s, W, comp);
+            mc_seg_state(comp, sv);
+            double ent = mc_seg_entropy(T, W, sv);
+            for (int i = 0; i <= m - 1; i++) {
+                H[i] = ent;
+                if (start + 1 + W <= m) {
+                    if (s[start] < 20) comp[s[start]]--;
+                    if (s[start + W] < 20) comp[s[start + W]]++;
+                    start++;
+                    mc_seg_state(comp, sv);
+                    ent = mc_seg_entropy(T, W, sv);
+                }
+            }
+        }
+        int last = m - 1, lowlim = 0;
+        for (int i = 0; i <= last; i++) {
+            if (H[i] <= 2.2 && H[i] != -1.0) {
+                int j, loi, hii, leftend, rightend;
+                for (j = i; j >= lowlim; j--) { if (H[j] > 2.5) break; }
+                loi = j + 1;
+                for (j = i; j <= last; j++) { if (H[j] > 2.5) break; }
+                hii = j - 1;
+                leftend = loi; rightend = hii;
+                mc_seg_trim(T, s + leftend, rightend - leftend + 1, &leftend, &rightend);
+                if (i < leftend) {
+                    int lend = loi, rend = leftend - 1;
+                    if (sp < 16) { stk_s[sp] = (int16_t)(base + lend); stk_n[sp] = (int16_t)(rend - lend + 1); sp++; }
+                }
+                for (j = leftend; j <= rightend; j++) maskbits[(base + j) >> 3] |= (uint8_t)(1u << ((base + j) & 7));
+                i = (hii < rightend) ? hii : rightend;
+                lowlim = i + 1;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// suffix keys (ExtendSeq2Set 0x413bd2-0x414aa1)
+// ---------------------------------------------------------------------------------------------
+MC_HD int mc_klen(uint32_t k)
+{
+    int low = (k & 0xf) != 0xf;
+    int l = ((k & 0xff) != 0xff) ? 3 + low : 2 + low;
+    l -= ((k & 0xfff) == 0xfff);
+    l -= (k == 0xffff);
+    return l;
+}
+MC_HD bool mc_key_lb_less(uint32_t dbk, uint32_t qk)
+{
+    int ld = mc_klen(dbk), lq = mc_klen(qk), n = ld < lq ? ld : lq;
+    if (n != 0) { int sh = (4 - n) * 4; int a = (int)(dbk >> sh), b = (int)(qk >> sh); if (a != b) return a < b; }
+    return ld < lq;
+}
+MC_HD bool mc_key_ub_less(uint32_t qk, uint32_t dbk)
+{
+    int ld = mc_klen(dbk), lq = mc_klen(qk), n = lq <= ld ? lq : ld;
+    if (n == 0) return lq < ld;
+    int sh = (4 - n) * 4; int a = (int)(qk >> sh), b = (int)(dbk >> sh);
+    if (a == b) return false;
+    return a < b;
+}
+// range of bucket `seed` whose key matches qk on the common prefix; returns ned-nst (0 = nothing)
+MC_HD int mc_key_range(const McIndex &X, int seed, uint32_t qk, int *nst_out)
+{
+    uint32_t b0 = X.bstart[seed];
+    int n = (int)(X.bstart[seed + 1] - b0);
+    const uint16_t *keys = X.keys + b0;
+    if (n == 0) return 0;
+    int lo = 0, len = n;
+    while (len > 0) { int half = len >> 1; if (mc_key_lb_less(keys[lo + half], qk)) { lo += half + 1; len -= half + 1; } else len = half; }
+    int nst = lo;
+    if (nst == n) return 0;
+    uint32_t dk = keys[nst];
+    int m = mc_klen(qk) < mc_klen(dk) ? mc_klen(qk) : mc_klen(dk);
+    if (m == 0) return 0;
+    int sh = (4 - m) * 4;
+    if ((dk >> sh) != (qk >> sh)) return 0;
+    lo = 0; len = n;
+    while (len > 0) { int half = len >> 1; if (mc_key_ub_less(qk, keys[lo + half])) len = half; else { lo += half + 1; len -= half + 1; } }
+    *nst_out = nst;
+    return lo - nst;
+}
+MC_HD uint32_t mc_pack_key(const uint8_t *g, int nkey)
+{
+    uint32_t qk = 0;
+    for (int i = 0; i < nkey; i++) qk |= (uint32_t)g[i] << (12 - 4 * i);
+    for (int i = nkey; i <= 3; i++) qk |= 0xfu << (12 - 4 * i);
+    return qk & 0xffff;
+}
+
+// ---------------------------------------------------------------------------------------------
+// seed enumeration for one frame (Searching@0x415050) - sequential over positions because of `prev`.
+// emit(seed_bucket, nst, count, seedlen, nkey, pos, phase) is called for every non-empty posting range.
+// phase: 0 exact; 1..30 = 1 + stride_index*10 + j; 31..40 = 31 + substituted first key residue.
+// ---------------------------------------------------------------------------------------------
+template <class Emit>
+MC_HDN void mc_enumerate_seeds(const McTables &T, const McIndex &X, const uint8_t *q, int qlen, Emit &emit)
+{
+    if (qlen <= 6) return;
+    int prev = 6;
+    for (int pos = 0; pos + 6 < qlen; pos++) {
+        int seed = 0, len = 6, used, g;
+        bool bad = false;
+        for (int k = 0; k < 6; k++) { g = T.grp[q[pos + k]]; if (g == MC_INVGRP) { bad = true; break; } seed = seed * 10 + g; }
+        if (bad) continue;
+        uint32_t freq = X.bstart[seed + 1] - X.bstart[seed];
+        if (freq > T.freq_thr) {
+            int rest = qlen - pos - 6, maxextra = (rest >= 2) ? 3 : rest + 1;
+            if (maxextra <= 1) len = 7;
+            else {
+                double thr = (double)T.freq_thr;
+                int extra = 1, idx = pos + 7;
+                g = T.grp[q[pos + 6]];
+                if (g == MC_INVGRP) continue;
+                double e = (double)freq * T.letter_p[g];
+                if (!(thr >= e)) {
+                    for (;;) {
+                        extra++;
+                        if (!(maxextra > extra)) break;
+                        g = T.grp[q[idx]];
+                        if (g == MC_INVGRP) { bad = true; break; }
+                        idx++;
+                        e = e * T.letter_p[g];
+                        if (thr >= e) break;
+                    }
+                    if (bad) continue;
+                }
+                len = 6 + extra;
+            }
+        }
+        used = (len >= prev - 1) ? len : prev - 1;
+        if (qlen < pos + used) continue;
+        uint8_t key[4];
+        for (int k = 6; k < used && k < 10; k++) key[k - 6] = T.grp[q[pos + k]];
+        if (freq != 0) {
+            int r = 0, nst = 0;
+            if (used > 6) r = mc_key_range(X, seed, mc_pack_key(key, used - 6), &nst);
+            else r = (int)freq;
+            if (r > 0) emit(seed, nst, r, used, used - 6, pos, 0);
+            prev = used;
+            if (r <= 0) prev = 6;
+        }
+        if (!(qlen < pos + 10)) {
+            bool ok = true;
+            for (int k = pos + used; k < pos + 10; k++) if (T.grp[q[k]] == MC_INVGRP) { ok = false; break; }
+            if (!ok) continue;
+            for (int k = 0; k < 4; k++) key[k] = T.grp[q[pos + 6 + k]];
+            uint32_t qk = mc_pack_key(key, 4);
+            const int strides[3] = {10, 1, 100};
+            for (int m = 0; m < 3; m++) {
+                int st = strides[m], start = seed - ((seed / st) % 10) * st;
+                for (int j = 0; j < 10; j++) {
+                    int v = start + j * st, nst = 0;
+                    if (v == seed) continue;
+                    int r = mc_key_range(X, v, qk, &nst);
+                    if (r > 0) emit(v, nst, r, 10, 4, pos, 1 + m * 10 + j);
+                }
+            }
+            int orig = key[0];
+            for (int k = 0; k < 10; k++) {
+                if (k == orig) continue;
+                key[0] = (uint8_t)k;
+                int nst = 0, r = mc_key_range(X, seed, mc_pack_key(key, 4), &nst);
+                if (r > 0) emit(seed, nst, r, 10, 4, pos, 31 + k);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// one seed hit: redundancy skip, seed score, growth, gate, ungapped X-drop (ExtendSeq2Set
+// 0x413e68-0x41422a + AlignSeqs 0x413370-0x4137a7).  Result: 0 = dropped, 1 = ungapped HSP complete
+// (out), 2 = needs gapped extension (gt).
+// ---------------------------------------------------------------------------------------------
+#define MC_SUB(T, a, b) ((int)(T).sub[((a) << 5) | (b)])
+
+MC_HDN int mc_eval_seed(const McTables &T, const McIndex &X, const uint8_t *q, int qlen, int frame, int qpos,
+                        uint32_t posting, int seedlen, int nkey, McGapTask *gt)
+{
+    int dpos = (int)(posting & 0x7ff), sidx = (int)(posting >> 11);
+    uint32_t o0 = X.off[sidx];
+    int dlen = (int)(X.off[sidx + 1] - o0);
+    const uint8_t *d = X.res + o0;
+    if (dpos + seedlen > dlen) return 0;
+    if (qpos != 0 && dpos != 0 && T.grp[q[qpos - 1]] == T.grp[d[dpos - 1]] && nkey != 4) return 0;
+    int score = 0, ident = 0, L = seedlen;
+    for (int k = 0; k < seedlen; k++) { int a = q[qpos + k], b = d[dpos + k]; score += MC_SUB(T, a, b); ident += (a == b); }
+    int lim = dlen - dpos; if (lim > qlen - qpos) lim = qlen - qpos;
+    while (lim > L && T.grp[q[qpos + L]] == T.grp[d[dpos + L]]) { int a = q[qpos + L], b = d[dpos + L]; score += MC_SUB(T, a, b); ident += (a == b); L++; }
+    int back = qpos < dpos ? qpos : dpos, qp = qpos, dp = dpos;
+    while (back > 0 && T.grp[q[qp - 1]] == T.grp[d[dp - 1]]) { qp--; dp--; back--; L++; int a = q[qp], b = d[dp]; score += MC_SUB(T, a, b); ident += (a == b); }
+    if (!((double)score >= MC_SEED_SCORE && ident >= MC_SEED_IDENT)) return 0;
+    int s0 = score, qfwd = 0, qbwd = 0, fgain = 0, bgain = 0;
+    { // forward
+        int n1 = qlen - qp - L, n2 = dlen - dp - L, bl = 0, bi = 0;
+        if (n1 != 0 && n2 != 0 && !(s0 < -20)) {
+            const uint8_t *p1 = q + qp + L, *p2 = d + dp + L;
+            int run = s0, best = s0, id = 0;
+            for (int i = 0;;) {
+                int a = p1[i], b = p2[i];
+                run += MC_SUB(T, a, b); id += (a == b); i++;
+                if (run > best) { best = run; bl = i; bi = id; }
+                if (!(n2 > i)) break;
+                if (n1 <= i) break;
+                if (run < -20) break;
+                if ((double)run < (double)best - T.xdrop_ungapped) break;
+            }
+            fgain = best - s0;
+        }
+        ident += bi; qfwd = bl;
+    }
+    { // backward, restarting from the seed score
+        int a = qp - 1, b = dp - 1, bl = 0, bi = 0;
+        if (a >= 0 && b >= 0 && !(s0 < -20)) {
+            int run = s0, best = s0, id = 0, cnt = 0;
+            for (;;) {
+                int x = q[a], y = d[b];
+                run += MC_SUB(T, x, y); id += (x == y); cnt++;
+                if (best < run) { best = run; bl = cnt; bi = id; }
+                a--; b--;
+                if (b < 0) break;
+                if (a < 0) break;
+                if (run < -20) break;
+                if ((double)run < (double)best - T.xdrop_ungapped) break;
+            }
+            bgain = best - s0;
+        }
+        ident += bi; qbwd = bl;
+    }
+    score = s0 + bgain + fgain;
+    gt->sidx = (uint32_t)sidx; gt->qp = (int16_t)qp; gt->dp = (int16_t)dp; gt->L = (int16_t)L;
+    gt->qfwd = (int16_t)qfwd; gt->qbwd = (int16_t)qbwd; gt->score = (int16_t)score; gt->nmatch = (int16_t)ident;
+    (void)frame;
+    return (!(T.gap_trigger > (double)score)) ? 2 : 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gapped X-drop extension without trace planes (AlignGapped@0x40a550).
+// The reference records three trace planes and walks back from the best cell; the only things it keeps
+// from that walk are: residues consumed, identities, the number of gap runs and of gap columns, and the
+// number of trace steps.  Those are carried forward here, per DP state, along exactly the predecessor
+// the trace would follow (same tie rules: 's' over E/e over D/d, open over extend on ties in the band,
+// strict '>' in the right-growth loop), packed as ident | steps<<10 | runs<<20 | gapcols<<26 ... (64 bit).
+// seq1/seq2 are addressed through (base, stride) so the left flank is walked backwards in place.
+// ---------------------------------------------------------------------------------------------
+struct McPath { uint16_t ident, steps, gapcols; uint8_t runs, cls; };   // cls: class of the last step 0 s, 1 E, 2 D, 3 none
+MC_HD McPath mc_path_zero() { McPath p; p.ident = 0; p.steps = 0; p.gapcols = 0; p.runs = 0; p.cls = 3; return p; }
+MC_HD McPath mc_path_gap(McPath p, int cls)
+{ // append one gap step of class cls (1 = E: consumes seq2, 2 = D: consumes seq1)
+    if (p.cls != cls) p.runs++;
+    p.cls = (uint8_t)cls; p.steps++; p.gapcols++;
+    return p;
+}
+
+struct McGapResult { int gain, c1, c2, ident, steps, runs, gapcols; };
+
+// workspace: H, D (int) and PH, PD (McPath), each n2+2 entries.
+//   PH[j] = step sequence (origin .. cell) the trace would follow from main[i][j]
+//   PD[j] = the same for the D plane of the cell
+MC_HDN McGapResult mc_align_gapped(const McTables &T, const uint8_t *s1, int st1, const uint8_t *s2, int st2, int n1, int n2,
+                                   int *H, int *D, McPath *PH, McPath *PD)
+{
+    const int open = MC_GAP_OPEN, ext = MC_GAP_EXT, first = MC_GAP_OPEN + MC_GAP_EXT;
+    McGapResult R; R.gain = 0; R.c1 = 0; R.c2 = 0; R.ident = 0; R.steps = 0; R.runs = 0; R.gapcols = 0;
+    int jEnd = (int)((T.xdrop_gapped - (double)open) / (double)ext);   // 0x40a693-0x40a6b9
+    int best = 0, bestI = 0, bestJ = 0, jStart = 1;
+    McPath bestP = mc_path_zero();
+    H[0] = 0; D[0] = -open; PH[0] = mc_path_zero(); PD[0] = mc_path_zero();
+    if (n2 > 0 && jEnd > 0) {                                          // row 0: 'E' then 'e' (0x40a6c1-0x40a770)
+        int r = -open;
+        McPath pe = mc_path_zero();
+        for (int j = 1;;) {
+            r -= ext; H[j] = r; D[j] = r - open;
+            pe = mc_path_gap(pe, 1);
+            PH[j] = pe; PD[j] = pe;
+            j++;
+            if (jEnd < j) break;
+            if (n2 < j) break;
+        }
+    }
+    if (n1 <= 0 || jEnd <= 1) return R;
+    for (int i = 1;;) {
+        // left border (i, jStart-1): the planes say 'D' in row 1 (continue from main[0][.]) and 'd' afterwards
+        int diag = H[jStart - 1];
+        McPath pdiag = PH[jStart - 1];
+        int hprev = H[jStart - 1] - first;
+        if (hprev < D[jStart - 1] - ext) hprev = D[jStart - 1] - ext;
+        McPath pborder = mc_path_gap((i == 1) ? PH[jStart - 1] : PD[jStart - 1], 2);
+        D[jStart - 1] = hprev; H[jStart - 1] = hprev;
+        PD[jStart - 1] = pborder; PH[jStart - 1] = pborder;
+        int E = hprev - open, h = 0;
+        McPath pE = pborder;       // E plane of the previous cell of this row
+        McPath phprev = pborder;   // main path of the previous cell of this row
+        bool grow = true, trim = true;
+        if (!(jStart > jEnd) && !(n2 < jStart)) {
+            for (int j = jStart;;) {                                   // 0x40a8e4-0x40a9f5
+                int a = hprev - first, b = E - ext, Dn;
+                McPath npE, npD;
+                if (a >= b) { E = a; npE = mc_path_gap(phprev, 1); }   // 'E': from main[i][j-1]
+                else { E = b; npE = mc_path_gap(pE, 1); }              // 'e': from the E plane of (i, j-1)
+                a = H[j] - first; b = D[j] - ext;
+                if (a >= b) { Dn = a; npD = mc_path_gap(PH[j], 2); }   // 'D': from main[i-1][j]
+                else { Dn = b; npD = mc_path_gap(PD[j], 2); }          // 'd': from the D plane of (i-1, j)
+                int x = s1[(i - 1) * st1], y = s2[(j - 1) * st2];
+                int s = diag + MC_SUB(T, x, y);
+                McPath np = pdiag; np.steps++; np.ident += (x == y); np.cls = 0;
+                h = s;
+                if (E > h) { h = E; np = npE; }
+                if (h < Dn) { h = Dn; np = npD; }
+                diag = H[j]; pdiag = PH[j];
+                H[j] = h; D[j] = Dn; PH[j] = np; PD[j] = npD;
+                pE = npE; phprev = np; hprev = h;
+                if (h > best) { best = h; bestI = i; bestJ = j; bestP = np; }
+                else if ((double)best - T.xdrop_gapped > (double)h && j > bestJ) {
+                    if (j >= jEnd) { jEnd = j; }                       // 0x40b48f: fall into the right growth
+                    else { jEnd = j; grow = false; trim = false; }     // 0x40a9f5: next row
+                    break;
+                }
+                j++;
+                if (n2 < j) break;
+                if (j > jEnd) break;
+            }
+        }
+        if (grow) {                                                    // 0x40ac45-0x40ad08
+            for (int j = jEnd + 1; !(n2 < j); j++) {
+                int a = hprev - first, b = E - ext;
+                McPath npE;
+                if (a > b) { E = a; npE = mc_path_gap(phprev, 1); }
+                else { E = b; npE = mc_path_gap(pE, 1); }
+                H[j] = E; D[j] = E - open; PH[j] = npE; PD[j] = npE;
+                pE = npE; phprev = npE;
+                if (E > best) { best = E; bestI = i; bestJ = j; bestP = npE; }
+                else if ((double)best - T.xdrop_gapped > (double)E) { jEnd = j; break; }
+                hprev = E;
+            }
+        }
+        if (trim && !(jStart > bestJ)) {                               // 0x40ad0c-0x40ad82
+            double lim = (double)best - T.xdrop_gapped;
+            if (lim > (double)H[bestJ]) jStart = bestJ;
+            else { int k = bestJ; for (;;) { k--; if (jStart > k) break; if (lim > (double)H[k]) { jStart = k; break; } } }
+        }
+        i++;
+        if (n1 < i) break;
+        if (!(jStart < jEnd)) break;
+    }
+    R.gain = best; R.c1 = bestI; R.c2 = bestJ;
+    if (best > 0) { R.ident = bestP.ident; R.steps = bestP.steps; R.runs = bestP.runs; R.gapcols = bestP.gapcols; }
+    return R;
+}
+
+// finalise one HSP (CalRes@0x4077a0 up to the keep test).  Returns false when the HSP is not kept.
+MC_HD bool mc_make_hsp(const McTables &T, int ntlen, int frame, const McGapTask &g, int qfwd, int dfwd, int qbwd, int dbwd,
+                       int score, int nmatch, int alnlen, int gapopens, int gaptotal, McHsp *h)
+{
+    if (score < 0 || score >= MC_SMAX) return false;
+    double le = T.loge_r[score];
+    if (!(score > 30) && !(T.loge_thr > le)) return false;
+    int qbeg = g.qp, dbeg = g.dp, L = g.L;
+    h->sidx = (int32_t)g.sidx; h->score = (int16_t)score; h->frame = (int16_t)frame; h->loge = le;
+    h->alnlen = (int16_t)alnlen; h->gaps = (int16_t)gapopens; h->mism = (int16_t)(alnlen - nmatch - gaptotal); h->nmatch = (int16_t)nmatch;
+    h->qaas = (int16_t)(qbeg - qbwd); h->qaae = (int16_t)(qbeg + qfwd - 1 + L);
+    h->ds = (int16_t)(dbeg - dbwd); h->de = (int16_t)(dbeg + dfwd - 1 + L);
+    if (frame <= 2) { h->qnts = (int16_t)((qbeg - qbwd) * 3 + frame + 1); h->qnte = (int16_t)((qbeg + qfwd + L) * 3 + frame); }
+    else { int s = ntlen - (qbeg - qbwd) * 3 - (frame - 3); h->qnts = (int16_t)s; h->qnte = (int16_t)(s + 1 - (qfwd + qbwd + L) * 3); }
+    return true;
+}

@@ -1,0 +1,300 @@
+// mc_finish.h - per-read ranking / linking / capping / classification: what ONE GPU thread does for one
+// read that produced HSPs.  Same conventions as mc_core.h (MC_HD code shared with the test-only emulation).
+//
+// Follows, for the read's HSPs: the multimap bookkeeping of CalRes (0x4082b0-0x408446: duplicate test
+// against the newest HSP of the same subject, otherwise "insert in front"), PrintRes@0x409310
+// (SumEvalue@0x408a50 per subject, std::sort by log E, 500-row cap, log E < threshold), the heap
+// permutation MergeRes@0x40e3b0 applies to rows whose printed log E is equal, and then MicrobeCensus'
+// classify_reads / alignment_filter / alignment_coverage (/root/reference/microbe_census/
+// microbe_census.py:400-460) on the surviving rows.
+#pragma once
+#include "mc_core.h"
+#include <math.h>
+
+struct McClassPars {               // find_opt_pars(pars.map, L)  microbe_census.py:61-72
+    double min_cov[32], min_score[32];
+    int32_t max_aaid[32];          // always an integer in pars.map: pid > max_aaid  <=>  100*nmatch > max_aaid*alnlen
+    int32_t aln_stat[32];          // 0 hits, 1 cov, 2 aln
+    int32_t nfam, read_len;
+};
+
+struct McBestHit {                 // best_hits[read] = [fam, aln, aln/target_len, score]  microbe_census.py:450-453
+    int32_t read, family, aln, target_len;
+    double bits;
+};
+
+// ------------------------------------------------------------------------------------------------
+// libstdc++ (GCC 4.4) std::sort on McHsp with a '<' key, exactly as the binary instantiates it
+// (__introsort_loop@0x42a570/0x42a0b0/0x42a310, __final_insertion_sort@0x4263f0, heap fallback).
+// key selector: 0 = loge, 1 = frame, 2 = qaas
+// ------------------------------------------------------------------------------------------------
+MC_HD bool mc_hless(const McHsp &a, const McHsp &b, int key)
+{
+    return key == 0 ? (a.loge < b.loge) : key == 1 ? (a.frame < b.frame) : (a.qaas < b.qaas);
+}
+MC_HDN void mc_adjust_heap(McHsp *first, long hole, long len, McHsp value, int key)
+{
+    long top = hole, sc = hole;
+    while (sc < (len - 1) / 2) {
+        sc = 2 * (sc + 1);
+        if (mc_hless(first[sc], first[sc - 1], key)) sc--;
+        first[hole] = first[sc]; hole = sc;
+    }
+    if ((len & 1) == 0 && sc == (len - 2) / 2) { sc = 2 * (sc + 1); first[hole] = first[sc - 1]; hole = sc - 1; }
+    long parent = (hole - 1) / 2;
+    while (hole > top && mc_hless(first[parent], value, key)) { first[hole] = first[parent]; hole = parent; parent = (hole - 1) / 2; }
+    first[hole] = value;
+}
+MC_HDN void mc_heapsort(McHsp *first, long n, int key)
+{
+    if (n >= 2) for (long parent = (n - 2) / 2;; parent--) { mc_adjust_heap(first, parent, n, first[parent], key); if (parent == 0) break; }
+    for (long m = n; m > 1;) { m--; McHsp v = first[m]; first[m] = first[0]; mc_adjust_heap(first, 0, m, v, key); }
+}
+MC_HDN void mc_unguarded_insert(McHsp *last, McHsp val, int key)
+{
+    McHsp *next = last - 1;
+    while (mc_hless(val, *next, key)) { *last = *next; last = next; --next; }
+    *last = val;
+}
+MC_HDN void mc_insertion_sort(McHsp *first, McHsp *last, int key)
+{
+    if (first == last) return;
+    for (McHsp *i = first + 1; i != last; ++i) {
+        McHsp val = *i;
+        if (mc_hless(val, *first, key)) { for (McHsp *p = i; p != first; --p) *p = *(p - 1); *first = val; }
+        else mc_unguarded_insert(i, val, key);
+    }
+}
+MC_HDN void mc_std_sort(McHsp *first, long n, int key)
+{
+    if (n <= 0) return;
+    long lg = 0;
+    for (long t = n; t > 1; t >>= 1) lg++;
+    // explicit stack of (first, last, depth): the recursion of __introsort_loop goes into the right part
+    long sf[64], sl[64], sd[64];
+    int sp = 0;
+    sf[0] = 0; sl[0] = n; sd[0] = 2 * lg; sp = 1;
+    while (sp > 0) {
+        sp--;
+        long f = sf[sp], l = sl[sp], depth = sd[sp];
+        while (l - f > 16) {
+            if (depth == 0) { mc_heapsort(first + f, l - f, key); break; }
+            --depth;
+            const McHsp &a = first[f], &b = first[f + (l - f) / 2], &c = first[l - 1];
+            McHsp pivot;
+            if (mc_hless(a, b, key)) { if (mc_hless(b, c, key)) pivot = b; else if (mc_hless(a, c, key)) pivot = c; else pivot = a; }
+            else if (mc_hless(a, c, key)) pivot = a;
+            else if (mc_hless(b, c, key)) pivot = c;
+            else pivot = b;
+            long lo = f, hi = l;
+            for (;;) {
+                while (mc_hless(first[lo], pivot, key)) ++lo;
+                --hi;
+                while (mc_hless(pivot, first[hi], key)) --hi;
+                if (!(lo < hi)) break;
+                McHsp t = first[lo]; first[lo] = first[hi]; first[hi] = t;
+                ++lo;
+            }
+            if (sp < 64) { sf[sp] = lo; sl[sp] = l; sd[sp] = depth; sp++; }
+            l = lo;
+        }
+    }
+    if (n > 16) { mc_insertion_sort(first, first + 16, key); for (McHsp *i = first + 16; i != first + n; ++i) mc_unguarded_insert(i, *i, key); }
+    else mc_insertion_sort(first, first + n, key);
+}
+MC_HDN void mc_stable_sort_loge(McHsp *first, long n)
+{ // std::stable_sort(CompEvalueObj): any stable sort produces the same permutation
+    for (long i = 1; i < n; ++i) {
+        McHsp val = first[i]; long j = i;
+        while (j > 0 && val.loge < first[j - 1].loge) { first[j] = first[j - 1]; --j; }
+        first[j] = val;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sum statistics (BlastStat::sumScore2Expect@0x438300 -> @0x437f90)
+// ------------------------------------------------------------------------------------------------
+MC_HD double mc_fac(int n) { int r = 1; while (n > 1) { r *= n; n--; } return (double)r; }
+MC_HDN double mc_sum_expect(const McTables &T, int n, const double *scores, int subj_len)
+{
+    double sum = 0.0;
+    for (int i = 0; i < n; i++) sum = sum + scores[i];
+    double a = 1.0 / 0.041, b = (double)subj_len - T.ell;
+    if (!(a > b)) a = b;
+    double t = log(0.041 * T.mprime * a);
+    double xsum = sum * 0.267 - t;
+    xsum = xsum - (double)(n - 1) * (T.logK + 7.824046010856292);
+    xsum = xsum - log(mc_fac(n));
+    double ex = exp(-xsum);
+    double pw = pow(xsum, (double)(n - 1));
+    double d = pow(0.1, (double)(n - 1)) * 0.9;
+    double r = T.nprime / (double)subj_len;
+    double x = ex * pw;
+    x = x / (mc_fac(n) * mc_fac(n - 1));
+    x = x / d;
+    return r * x;
+}
+
+// CHashSearch::SumEvalue@0x408a50 on v[st, ed); returns the new end (the range may shrink).
+// tmp must hold 2*(ed-st) entries.
+MC_HDN int mc_sum_evalue(const McTables &T, McHsp *v, int st, int ed, int subj_len, McHsp *tmp)
+{
+    McHsp *a = v + st;
+    int n = ed - st, part, nres = 0;
+    mc_std_sort(a, n, 1);
+    for (part = 0; part < n && !(a[part].frame > 2); part++) {}
+    if ((n - part) <= 1 && part <= 1) return ed;
+    McHsp *res = tmp, *chosen = tmp + n;
+    for (int pass = 0; pass < 2; pass++) {
+        McHsp *g = pass ? a + part : a;
+        int gn = pass ? n - part : part, nc = 0;
+        if (gn == 0) continue;
+        if (gn == 1) { if (T.loge_thr > g[0].loge) res[nres++] = g[0]; continue; }
+        mc_std_sort(g, gn, 2);
+        mc_stable_sort_loge(g, gn);
+        chosen[nc++] = g[0];
+        for (int i = 1; i < gn; i++) {
+            const McHsp &e = g[i];
+            int ov = (e.qaae + 1 - e.qaas) >> 1;
+            bool ok = true;
+            if (ov > 10) ov = 10;
+            if (e.loge >= 1.0 && !(e.score > 30)) continue;
+            for (int j = 0; j < nc; j++) {
+                const McHsp &c = chosen[j];
+                if (e.qaas <= c.qaae - ov) { if (e.qaae >= c.qaas + ov) { ok = false; break; } }
+                if (e.qaae - ov < c.qaas) continue;
+                if (c.qaae >= ov + e.qaas) { ok = false; break; }
+            }
+            if (ok) chosen[nc++] = e;
+        }
+        if (nc == 1) { if (T.loge_thr > chosen[0].loge) res[nres++] = chosen[0]; }
+        else {
+            double sc[5];
+            int k = nc < 5 ? nc : 5;
+            for (int i = 0; i < k; i++) sc[i] = (double)chosen[i].score;
+            double E = mc_sum_expect(T, k, sc, subj_len);
+            double le = (E == 0.0) ? -10000.0 : log(E) / 2.302585092994046;
+            if (T.loge_thr > le) for (int i = 0; i < nc; i++) { chosen[i].loge = le; res[nres++] = chosen[i]; }
+        }
+    }
+    if (nres > 0) { for (int i = 0; i < nres; i++) v[st + i] = res[i]; return st + nres; }
+    return ed;
+}
+
+// ------------------------------------------------------------------------------------------------
+// printed-log-E key: two rows tie in MergeRes when "%g" prints the same 6 significant digits
+// ------------------------------------------------------------------------------------------------
+MC_HDN double mc_round6(double x)
+{
+    const double p10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    if (x == 0.0 || x != x) return x;
+    double ax = x < 0 ? -x : x;
+    int e = 0;
+    if (ax >= 1.0) { while (e < 16 && ax >= p10[e + 1]) e++; }
+    else { while (e > -16 && ax < 1.0 / p10[-e]) e--; }
+    double scaled = (5 - e >= 0) ? ax * p10[5 - e] : ax / p10[e - 5];
+    double r = nearbyint(scaled);
+    if (r >= 1000000.0) { r = r / 10.0; e++; }
+    r = (5 - e >= 0) ? r / p10[5 - e] : r * p10[e - 5];
+    return x < 0 ? -r : r;
+}
+MC_HDN void mc_row_adjust_heap(McRow *a, double *k, long hole, long len, McRow v, double kv)
+{
+    long top = hole, sc = hole;
+    while (sc < (len - 1) / 2) {
+        sc = 2 * (sc + 1);
+        if (k[sc] < k[sc - 1]) sc--;
+        a[hole] = a[sc]; k[hole] = k[sc]; hole = sc;
+    }
+    if ((len & 1) == 0 && sc == (len - 2) / 2) { sc = 2 * (sc + 1); a[hole] = a[sc - 1]; k[hole] = k[sc - 1]; hole = sc - 1; }
+    long parent = (hole - 1) / 2;
+    while (hole > top && k[parent] < kv) { a[hole] = a[parent]; k[hole] = k[parent]; hole = parent; parent = (hole - 1) / 2; }
+    a[hole] = v; k[hole] = kv;
+}
+// std::partial_sort(first, first+n, first+n) keyed by the printed log E (MergeRes 0x40ed5e-0x40f007)
+MC_HDN void mc_merge_res_order(McRow *a, double *k, int n)
+{
+    if (n < 2) return;
+    for (long i = (n - 2) / 2;; i--) { mc_row_adjust_heap(a, k, i, n, a[i], k[i]); if (i == 0) break; }
+    for (long m = n; m > 1;) { m--; McRow v = a[m]; double kv = k[m]; a[m] = a[0]; k[m] = k[0]; mc_row_adjust_heap(a, k, 0, m, v, kv); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// alignment_coverage + alignment_filter (microbe_census.py:400-430) on one row, all in IEEE double
+// ------------------------------------------------------------------------------------------------
+MC_HD bool mc_row_passes(const McClassPars &P, const McRow &r, int fam, int target_len, int nmatch)
+{
+    double query_len = (double)P.read_len / 3.0;
+    double qs = (double)(r.qstart < r.qend ? r.qstart : r.qend), qe = (double)(r.qstart < r.qend ? r.qend : r.qstart);
+    double md = fmod(qs, 3.0);
+    double frame = (md == 1.0 || md == 2.0) ? md : 3.0;
+    double query_start = (qs + 3.0 - frame) / 3.0;
+    double query_stop = (qe + 1.0 - frame) / 3.0;
+    double t1 = (double)r.sstart + 1.0, t2 = (double)r.send + 1.0;
+    double t_start = t1 < t2 ? t1 : t2, t_stop = t1 < t2 ? t2 : t1;
+    double x1 = query_start - 1.0, x2 = t_start - 1.0;
+    double x = x1 < x2 ? x1 : x2;       // python min(a, b): b if b < a else a
+    double y = (double)r.alnlen;
+    double z1 = query_len - query_stop, z2 = (double)target_len - t_stop;
+    double z = z2 < z1 ? z2 : z1;
+    double maxaln = x + y + z;
+    double cov = (double)r.alnlen / maxaln;
+    if (cov < P.min_cov[fam]) return false;
+    if (r.bits < P.min_score[fam]) return false;
+    if (100 * nmatch > P.max_aaid[fam] * r.alnlen) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// One read.  in[0,n): its HSPs sorted by (subject, chrono).  v: n entries, tmp: 2n entries of scratch.
+// rows_out (may be null) receives the m8 rows (<= 500) in the order the reference prints them;
+// krows: 500 doubles of scratch.  Returns the number of rows; *best gets the classify_reads result
+// (best->family = -1 when no row passes the filters).
+// ------------------------------------------------------------------------------------------------
+MC_HDN int mc_finish_read(const McTables &T, const McIndex &X, const McClassPars &P, const int32_t *marker_family,
+                          int read_id, const McHsp *in, int n, McHsp *v, McHsp *tmp, McRow *rows, double *krows, McBestHit *best)
+{
+    int vn = 0;
+    for (int a = 0; a < n;) {
+        int b = a, sidx = in[a].sidx, st = vn;
+        while (b < n && in[b].sidx == sidx) b++;
+        // stack of this subject's HSPs, newest on top; a re-found HSP only replaces the top if it is better
+        for (int k = a; k < b; k++) {
+            const McHsp &h = in[k];
+            if (vn > st) {
+                McHsp &t = v[vn - 1];
+                if (t.frame == h.frame && t.qaas == h.qaas && t.ds == h.ds && t.qaae == h.qaae && t.de == h.de) {
+                    if (t.loge > h.loge) { t.score = h.score; t.loge = h.loge; t.alnlen = h.alnlen; t.mism = h.mism; t.gaps = h.gaps; t.nmatch = h.nmatch; t.qnts = h.qnts; t.qnte = h.qnte; }
+                    continue;
+                }
+            }
+            v[vn++] = h;
+        }
+        for (int i = st, j = vn - 1; i < j; i++, j--) { McHsp t = v[i]; v[i] = v[j]; v[j] = t; }   // multimap order: newest first
+        if (vn - st > 1) vn = mc_sum_evalue(T, v, st, vn, (int)(X.off[sidx + 1] - X.off[sidx]), tmp);
+        a = b;
+    }
+    mc_std_sort(v, vn, 0);
+    int nrows = 0;
+    best->read = read_id; best->family = -1; best->aln = 0; best->target_len = 0; best->bits = 0.0;
+    for (int i = 0; i < vn && i < MC_MAX_M8; i++) {
+        const McHsp &h = v[i];
+        if (!(h.loge < T.loge_thr)) break;
+        McRow &r = rows[nrows];
+        r.query = read_id; r.subject = h.sidx; r.ident = (double)h.nmatch * 100.0 / (double)h.alnlen;
+        r.alnlen = h.alnlen; r.mismatch = h.mism; r.gapopen = h.gaps; r.qstart = h.qnts; r.qend = h.qnte; r.sstart = h.ds; r.send = h.de;
+        r.loge = h.loge; r.bits = T.bits_r[h.score]; r.score = h.score; r.frame = h.nmatch;   // frame slot carries nmatch for the classifier
+        krows[nrows] = mc_round6(h.loge);
+        nrows++;
+    }
+    mc_merge_res_order(rows, krows, nrows);
+    for (int i = 0; i < nrows; i++) {
+        McRow &r = rows[i];
+        int fam = marker_family[r.subject], tl = (int)(X.off[r.subject + 1] - X.off[r.subject]);
+        int nmatch = r.frame;
+        if (mc_row_passes(P, r, fam, tl, nmatch)) {
+            if (best->family < 0 || best->bits < r.bits) { best->family = fam; best->aln = r.alnlen; best->target_len = tl; best->bits = r.bits; }
+        }
+    }
+    return nrows;
+}

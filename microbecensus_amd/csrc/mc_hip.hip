@@ -1,0 +1,487 @@
+// mc_hip.hip - HIP kernels (gfx950) and the C ABI of libmcensus_hip.so.
+//
+// Pipeline for one batch of reads resident in HBM (all stages on the handle's stream):
+//   k_translate_seg   1 thread / (read, frame)   6-frame translation + SEG masking      -> frames
+//   k_enumerate       1 thread / (read, frame)   reduced-alphabet seeds, bucket probes  -> seed tasks
+//   k_eval_seeds      1 thread / seed task       seed gate, growth, ungapped X-drop     -> HSPs | gap tasks
+//   k_gapped          1 thread / gap task        trace-free affine X-drop, both flanks  -> HSPs
+//   radix sort        (read, subject, chrono)    rocPRIM device sort of the HSP keys
+//   k_finish          1 thread / read with HSPs  linking, ranking, cap, classification   -> rows, best hits
+// The per-thread algorithms live in mc_core.h / mc_finish.h; see include/mcensus.h for what each entry
+// point replaces in the reference.
+#include <cstring>
+#include <cstdio>
+#include <cstdlib>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/mcensus.h"
+#include "mc_finish.h"
+#include "mc_index.h"
+
+static thread_local std::string g_err;
+extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
+
+#define HIPCK(call)                                                                                         \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess) {                                                                             \
+            g_err = std::string(#call) + ": " + hipGetErrorString(e_);                                       \
+            return -1;                                                                                      \
+        }                                                                                                   \
+    } while (0)
+
+enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_N = 8 };
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restrict__ T, const uint8_t *__restrict__ reads, int L,
+                                                       int64_t nreads, uint8_t *__restrict__ frames, int FP)
+{
+    int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= nreads * 6) return;
+    int64_t r = tid / 6;
+    int f = (int)(tid - r * 6);
+    uint8_t prot[MC_MAXAA + 2];
+    uint8_t mask[(MC_MAXAA + 7) / 8];
+    double H[MC_MAXAA + 2];
+    int n = mc_translate_frame(*T, reads + r * L, L, f, prot);
+    mc_seg_mask(*T, prot, n, mask, H);
+    uint8_t *out = frames + (r * 6 + f) * FP;
+    for (int i = 0; i < n; i++) out[i] = (mask[i >> 3] & (1 << (i & 7))) ? (uint8_t)MC_INV : prot[i];
+    for (int i = n; i < FP; i++) out[i] = MC_INV;
+}
+
+struct DevEmit {
+    McSeedTask *tasks; uint32_t *counters; uint32_t cap; uint32_t read; int frame; const McIndex *X;
+    __device__ void operator()(int bucket, int nst, int cnt, int seedlen, int nkey, int pos, int phase)
+    {
+        uint32_t base = atomicAdd(&counters[C_TASKS], (uint32_t)cnt);
+        if (base + (uint32_t)cnt > cap) { counters[C_OVERFLOW] = 1; return; }
+        uint32_t b0 = X->bstart[bucket];
+        for (int i = 0; i < cnt; i++) {
+            McSeedTask t;
+            t.read = read; t.chrono = MC_CHRONO(frame, pos, phase, nst + i); t.posting = X->post[b0 + nst + i];
+            t.seedlen_nkey = (uint32_t)seedlen | ((uint32_t)nkey << 8);
+            tasks[base + i] = t;
+        }
+    }
+};
+
+__global__ void __launch_bounds__(256) k_enumerate(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
+                                                   int64_t nreads, McSeedTask *tasks, uint32_t cap, uint32_t *counters)
+{
+    int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= nreads * 6) return;
+    int64_t r = tid / 6;
+    int f = (int)(tid - r * 6);
+    int qlen = (L - f % 3) / 3;
+    DevEmit e{tasks, counters, cap, (uint32_t)r, f, &X};
+    mc_enumerate_seeds(*T, X, frames + (r * 6 + f) * FP, qlen, e);
+}
+
+__global__ void __launch_bounds__(256) k_eval_seeds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
+                                                    const McSeedTask *__restrict__ tasks, uint32_t ntasks, McHsp *hsps, uint32_t cap_hsps,
+                                                    McGapTask *gaps, uint32_t cap_gaps, uint32_t *counters)
+{
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= ntasks) return;
+    McSeedTask t = tasks[tid];
+    int frame = (int)(t.chrono >> 25), pos = (int)((t.chrono >> 17) & 0xff);
+    int qlen = (L - frame % 3) / 3;
+    McGapTask g;
+    g.read = t.read; g.chrono = t.chrono;
+    int rc = mc_eval_seed(*T, X, frames + ((int64_t)t.read * 6 + frame) * FP, qlen, frame, pos, t.posting, (int)(t.seedlen_nkey & 0xff), (int)(t.seedlen_nkey >> 8), &g);
+    if (rc == 1) {
+        McHsp h;
+        h.read = t.read; h.chrono = t.chrono;
+        if (mc_make_hsp(*T, L, frame, g, g.qfwd, g.qfwd, g.qbwd, g.qbwd, g.score, g.nmatch, g.qfwd + g.L + g.qbwd, 0, 0, &h)) {
+            uint32_t k = atomicAdd(&counters[C_HSPS], 1u);
+            if (k < cap_hsps) hsps[k] = h; else counters[C_OVERFLOW] = 2;
+        }
+    } else if (rc == 2) {
+        uint32_t k = atomicAdd(&counters[C_GAPS], 1u);
+        if (k < cap_gaps) gaps[k] = g; else counters[C_OVERFLOW] = 3;
+    }
+}
+
+#define MC_GAP_W 1200   // workspace entries per thread (markers are <= 1183 aa, checked in mc_open)
+
+__global__ void __launch_bounds__(128) k_gapped(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
+                                                const McGapTask *__restrict__ gaps, uint32_t ngaps, McHsp *hsps, uint32_t cap_hsps, uint32_t *counters,
+                                                int *wsH, int *wsD, McPath *wsPH, McPath *wsPD)
+{
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    int *Hh = wsH + (size_t)tid * MC_GAP_W, *Dd = wsD + (size_t)tid * MC_GAP_W;
+    McPath *PH = wsPH + (size_t)tid * MC_GAP_W, *PD = wsPD + (size_t)tid * MC_GAP_W;
+    for (uint32_t k = tid; k < ngaps; k += nthreads) {
+        McGapTask g = gaps[k];
+        int frame = (int)(g.chrono >> 25);
+        int qlen = (L - frame % 3) / 3;
+        const uint8_t *q = frames + ((int64_t)g.read * 6 + frame) * FP;
+        const uint8_t *d = X.res + X.off[g.sidx];
+        int dlen = (int)(X.off[g.sidx + 1] - X.off[g.sidx]);
+        int score = g.score, nmatch = g.nmatch, qfwd = g.qfwd, dfwd = g.qfwd, qbwd = g.qbwd, dbwd = g.qbwd;
+        int alnlen = g.qfwd + g.L + g.qbwd, gapopens = 0, gaptotal = 0;
+        int qend = qfwd + g.qp + g.L, dend = dfwd + g.dp + g.L, dright = dlen - dend, qright = qlen - qend;
+        if (dright > 2 && qright > 2) {
+            McGapResult R = mc_align_gapped(*T, q + qend, 1, d + dend, 1, qright, dright, Hh, Dd, PH, PD);
+            if (R.gain > 0) { score += R.gain; nmatch += R.ident; qfwd += R.c1; dfwd += R.c2; alnlen += R.steps; gapopens += R.runs; gaptotal += R.gapcols; }
+        }
+        int dleft = g.dp - dbwd, qleft = g.qp - qbwd;
+        if (dleft > 2 && qleft > 2) {
+            McGapResult R = mc_align_gapped(*T, q + qleft - 1, -1, d + dleft - 1, -1, qleft, dleft, Hh, Dd, PH, PD);
+            if (R.gain > 0) { score += R.gain; nmatch += R.ident; qbwd += R.c1; dbwd += R.c2; alnlen += R.steps; gapopens += R.runs; gaptotal += R.gapcols; }
+        }
+        McHsp h;
+        h.read = g.read; h.chrono = g.chrono;
+        if (mc_make_hsp(*T, L, frame, g, qfwd, dfwd, qbwd, dbwd, score, nmatch, alnlen, gapopens, gaptotal, &h)) {
+            uint32_t o = atomicAdd(&counters[C_HSPS], 1u);
+            if (o < cap_hsps) hsps[o] = h; else counters[C_OVERFLOW] = 2;
+        }
+    }
+}
+
+__global__ void k_make_keys(const McHsp *__restrict__ hsps, uint32_t n, uint64_t *keys, uint32_t *idx)
+{
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n) return;
+    const McHsp &h = hsps[tid];
+    keys[tid] = ((uint64_t)h.read << 43) | ((uint64_t)(uint32_t)h.sidx << 28) | (uint64_t)h.chrono;
+    idx[tid] = tid;
+}
+__global__ void k_gather(const McHsp *__restrict__ hsps, const uint32_t *__restrict__ idx, uint32_t n, McHsp *out, uint32_t *heads, uint32_t *counters)
+{
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n) return;
+    McHsp h = hsps[idx[tid]];
+    out[tid] = h;
+    bool head = (tid == 0) || (hsps[idx[tid - 1]].read != h.read);
+    if (head) heads[atomicAdd(&counters[C_HEADS], 1u)] = tid;
+}
+
+struct McSegInfo { uint32_t read, row_off, nrows, pad; };
+
+__global__ void __launch_bounds__(64) k_finish(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
+                                               const McHsp *__restrict__ sorted, uint32_t nhsps, const uint32_t *__restrict__ heads, uint32_t nheads,
+                                               McHsp *v, McHsp *tmp, McRow *rowscratch, double *kscratch, int64_t first_read_id,
+                                               McRow *rows, uint32_t cap_rows, McSegInfo *seginfo, McBestHit *best, uint32_t *counters)
+{
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    McRow *myrows = rowscratch + (size_t)tid * MC_MAX_M8;
+    double *myk = kscratch + (size_t)tid * MC_MAX_M8;
+    for (uint32_t s = tid; s < nheads; s += nthreads) {
+        uint32_t a = heads[s], b = a;
+        uint32_t read = sorted[a].read;
+        while (b < nhsps && sorted[b].read == read) b++;
+        int n = (int)(b - a);
+        McBestHit bh;
+        int nr = mc_finish_read(*T, X, *P, fam, (int)((int64_t)read + first_read_id), sorted + a, n, v + a, tmp + 2 * (size_t)a, myrows, myk, &bh);
+        McSegInfo si; si.read = read; si.nrows = (uint32_t)nr; si.row_off = 0; si.pad = 0;
+        if (nr > 0) {
+            uint32_t off = atomicAdd(&counters[C_ROWS], (uint32_t)nr);
+            si.row_off = off;
+            if (off + (uint32_t)nr <= cap_rows) { for (int i = 0; i < nr; i++) rows[off + i] = myrows[i]; }
+            else counters[C_OVERFLOW] = 4;
+        }
+        seginfo[s] = si;
+        best[s] = bh;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------------
+struct mc_handle {
+    McHostIndex H;
+    std::vector<int32_t> fam;
+    int nfam = 0, device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    // device index + tables
+    uint8_t *d_res = nullptr; uint32_t *d_off = nullptr, *d_bstart = nullptr, *d_post = nullptr; uint16_t *d_keys = nullptr; int32_t *d_fam = nullptr;
+    McTables *d_T = nullptr; McClassPars *d_P = nullptr;
+    McTables hT; McClassPars hP;
+    int read_len = 0, FP = 0; bool run_set = false;
+    // batch buffers
+    int64_t cap_reads = 0, nreads = 0;
+    uint8_t *d_reads = nullptr, *d_frames = nullptr;
+    McSeedTask *d_tasks = nullptr; McGapTask *d_gaps = nullptr; McHsp *d_hsps = nullptr, *d_sorted = nullptr, *d_v = nullptr, *d_tmp = nullptr;
+    uint32_t cap_tasks = 0, cap_gaps = 0, cap_hsps = 0, cap_rows = 0;
+    uint64_t *d_k64 = nullptr, *d_k64o = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
+    uint32_t *d_counters = nullptr;
+    McRow *d_rows = nullptr, *d_rowscratch = nullptr; double *d_kscratch = nullptr; McSegInfo *d_seginfo = nullptr; McBestHit *d_best = nullptr;
+    int *d_gH = nullptr, *d_gD = nullptr; McPath *d_gPH = nullptr, *d_gPD = nullptr;
+    int gap_threads = 0, fin_threads = 0;
+    // host results
+    std::vector<mc_row> rows; std::vector<mc_best_hit> best; mc_stats stats;
+};
+
+static McIndex dev_index(const mc_handle *h)
+{
+    McIndex X; X.res = h->d_res; X.off = h->d_off; X.bstart = h->d_bstart; X.post = h->d_post; X.keys = h->d_keys; X.nseq = h->H.nseq;
+    return X;
+}
+
+template <class Tp> static int dalloc(Tp **p, size_t n)
+{
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    HIPCK(hipMalloc((void **)p, n * sizeof(Tp)));
+    return 0;
+}
+
+extern "C" int mc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" void mc_close(mc_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_frames, h->d_tasks, h->d_gaps, h->d_hsps,
+                    h->d_sorted, h->d_v, h->d_tmp, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, h->d_heads, h->d_sorttmp, h->d_counters, h->d_rows, h->d_rowscratch,
+                    h->d_kscratch, h->d_seginfo, h->d_best, h->d_gH, h->d_gD, h->d_gPH, h->d_gPD};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static int open_impl(mc_handle *h, const char *const *names, const char *const *seqs, int32_t nseq, const int32_t *marker_family, int32_t nfam, int32_t device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device available: libmcensus_hip has no CPU fallback"; return -1; }
+    if (device < 0 || device >= ndev) { g_err = "device index out of range"; return -1; }
+    if (nfam > 32) { g_err = "at most 32 gene families are supported"; return -1; }
+    std::string err;
+    if (!mc_build_index(h->H, names, seqs, nseq, err)) { g_err = err; return -1; }
+    for (int s = 0; s < nseq; s++) if ((int)(h->H.off[s + 1] - h->H.off[s]) > MC_GAP_W - 8) { g_err = "marker longer than the gapped-extension workspace"; return -1; }
+    h->fam.assign(marker_family, marker_family + nseq);
+    h->nfam = nfam; h->device = device;
+    HIPCK(hipSetDevice(device));
+    HIPCK(hipStreamCreate(&h->stream));
+    for (auto &e : h->ev) HIPCK(hipEventCreate(&e));
+    const McHostIndex &H = h->H;
+    if (dalloc(&h->d_res, H.res.size()) || dalloc(&h->d_off, H.off.size()) || dalloc(&h->d_bstart, H.bstart.size()) || dalloc(&h->d_post, H.post.size() + 1) ||
+        dalloc(&h->d_keys, H.keys.size() + 1) || dalloc(&h->d_fam, (size_t)nseq) || dalloc(&h->d_T, 1) || dalloc(&h->d_P, 1) || dalloc(&h->d_counters, C_N)) return -1;
+    HIPCK(hipMemcpy(h->d_res, H.res.data(), H.res.size(), hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(h->d_off, H.off.data(), H.off.size() * 4, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(h->d_bstart, H.bstart.data(), H.bstart.size() * 4, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(h->d_post, H.post.data(), H.post.size() * 4, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(h->d_keys, H.keys.data(), H.keys.size() * 2, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(h->d_fam, h->fam.data(), (size_t)nseq * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" mc_handle *mc_open(const char *const *names, const char *const *seqs, int32_t nseq, const int32_t *marker_family, int32_t nfam, int32_t device)
+{
+    mc_handle *h = new mc_handle();
+    if (open_impl(h, names, seqs, nseq, marker_family, nfam, device) != 0) { std::string e = g_err; mc_close(h); g_err = e; return nullptr; }
+    return h;
+}
+
+extern "C" int mc_index_view(const mc_handle *h, const uint8_t **res_codes, const uint32_t **offsets, const uint32_t **bucket_starts, const uint32_t **postings,
+                             const uint16_t **keys, int64_t *nres, int64_t *npostings, uint32_t *freq_thr, double letter_p[10])
+{
+    if (!h) { g_err = "null handle"; return -1; }
+    *res_codes = h->H.res_code.data(); *offsets = h->H.off.data(); *bucket_starts = h->H.bstart.data(); *postings = h->H.post.data(); *keys = h->H.keys.data();
+    *nres = h->H.nres; *npostings = (int64_t)h->H.post.size(); *freq_thr = h->H.freq_thr;
+    for (int i = 0; i < 10; i++) letter_p[i] = h->H.letter_p[i];
+    return 0;
+}
+
+extern "C" int mc_set_run(mc_handle *h, int32_t read_len, double loge_thr, const double *min_cov, const double *min_score, const int32_t *max_aaid, const int32_t *aln_stat)
+{
+    if (!h) { g_err = "null handle"; return -1; }
+    if (read_len < 18 || read_len > 3 * MC_MAXAA) { g_err = "read_len out of range (18..510)"; return -1; }
+    HIPCK(hipSetDevice(h->device));
+    mc_fill_tables(h->hT, h->H, read_len, loge_thr);
+    memset(&h->hP, 0, sizeof h->hP);
+    h->hP.nfam = h->nfam; h->hP.read_len = read_len;
+    for (int f = 0; f < h->nfam; f++) { h->hP.min_cov[f] = min_cov[f]; h->hP.min_score[f] = min_score[f]; h->hP.max_aaid[f] = max_aaid[f]; h->hP.aln_stat[f] = aln_stat[f]; }
+    HIPCK(hipMemcpy(h->d_T, &h->hT, sizeof(McTables), hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(h->d_P, &h->hP, sizeof(McClassPars), hipMemcpyHostToDevice));
+    h->read_len = read_len; h->FP = ((read_len / 3 + 2) + 3) & ~3; h->run_set = true;
+    h->cap_reads = 0;   // frame pitch may have changed
+    return 0;
+}
+
+static int ensure_capacity(mc_handle *h, int64_t nreads)
+{
+    if (nreads <= h->cap_reads) return 0;
+    int64_t cap = nreads;
+    if (cap > (1 << 21) - 1) { g_err = "batch larger than 2097151 reads"; return -1; }
+    h->cap_tasks = (uint32_t)std::min<int64_t>(cap * 160 + 65536, 0x7fffffff);
+    h->cap_gaps = (uint32_t)std::min<int64_t>(cap * 24 + 65536, 0x7fffffff);
+    h->cap_hsps = (uint32_t)std::min<int64_t>(cap * 64 + 65536, 0x7fffffff);
+    h->cap_rows = (uint32_t)std::min<int64_t>(cap * 32 + 65536, 0x7fffffff);
+    h->gap_threads = 64 * 1024; h->fin_threads = 16 * 1024;
+    if (dalloc(&h->d_reads, (size_t)cap * h->read_len) || dalloc(&h->d_frames, (size_t)cap * 6 * h->FP) || dalloc(&h->d_tasks, h->cap_tasks) ||
+        dalloc(&h->d_gaps, h->cap_gaps) || dalloc(&h->d_hsps, h->cap_hsps) || dalloc(&h->d_sorted, h->cap_hsps) || dalloc(&h->d_v, h->cap_hsps) ||
+        dalloc(&h->d_tmp, (size_t)h->cap_hsps * 2) || dalloc(&h->d_k64, h->cap_hsps) || dalloc(&h->d_k64o, h->cap_hsps) || dalloc(&h->d_idx, h->cap_hsps) ||
+        dalloc(&h->d_idxo, h->cap_hsps) || dalloc(&h->d_heads, (size_t)cap + 1) || dalloc(&h->d_rows, h->cap_rows) ||
+        dalloc(&h->d_rowscratch, (size_t)h->fin_threads * MC_MAX_M8) || dalloc(&h->d_kscratch, (size_t)h->fin_threads * MC_MAX_M8) ||
+        dalloc(&h->d_seginfo, (size_t)cap + 1) || dalloc(&h->d_best, (size_t)cap + 1) || dalloc(&h->d_gH, (size_t)h->gap_threads * MC_GAP_W) ||
+        dalloc(&h->d_gD, (size_t)h->gap_threads * MC_GAP_W) || dalloc(&h->d_gPH, (size_t)h->gap_threads * MC_GAP_W) || dalloc(&h->d_gPD, (size_t)h->gap_threads * MC_GAP_W))
+        return -1;
+    size_t bytes = 0;
+    HIPCK(rocprim::radix_sort_pairs(nullptr, bytes, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, (size_t)h->cap_hsps, 0, 64, h->stream));
+    if (h->d_sorttmp) { (void)hipFree(h->d_sorttmp); h->d_sorttmp = nullptr; }
+    HIPCK(hipMalloc(&h->d_sorttmp, bytes + 16));
+    h->sorttmp_bytes = bytes;
+    h->cap_reads = cap;
+    return 0;
+}
+
+extern "C" int mc_upload(mc_handle *h, const uint8_t *reads, int64_t nreads)
+{
+    if (!h || !h->run_set) { g_err = "mc_set_run() must be called first"; return -1; }
+    HIPCK(hipSetDevice(h->device));
+    if (ensure_capacity(h, nreads)) return -1;
+    HIPCK(hipMemcpyAsync(h->d_reads, reads, (size_t)nreads * h->read_len, hipMemcpyHostToDevice, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    h->nreads = nreads;
+    return 0;
+}
+
+static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
+
+extern "C" int mc_run(mc_handle *h, int64_t first_read_id)
+{
+    if (!h || !h->run_set) { g_err = "mc_set_run() must be called first"; return -1; }
+    HIPCK(hipSetDevice(h->device));
+    const int64_t n = h->nreads;
+    const int L = h->read_len, FP = h->FP;
+    hipStream_t st = h->stream;
+    McIndex X = dev_index(h);
+    uint32_t c[C_N];
+    memset(&h->stats, 0, sizeof h->stats);
+    h->rows.clear(); h->best.clear();
+    h->stats.reads = n;
+    if (n == 0) return 0;
+    HIPCK(hipMemsetAsync(h->d_counters, 0, sizeof(uint32_t) * C_N, st));
+    HIPCK(hipEventRecord(h->ev[0], st));
+    {
+        int64_t threads = n * 6;
+        k_translate_seg<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, h->d_reads, L, n, h->d_frames, FP);
+        HIPCK(hipEventRecord(h->ev[1], st));
+        k_enumerate<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, X, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, h->d_counters);
+        HIPCK(hipEventRecord(h->ev[2], st));
+    }
+    HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    if (c[C_OVERFLOW]) { g_err = "seed task buffer overflow"; return -2; }
+    uint32_t ntasks = c[C_TASKS];
+    if (ntasks) k_eval_seeds<<<dim3((ntasks + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_tasks, ntasks, h->d_hsps, h->cap_hsps, h->d_gaps, h->cap_gaps, h->d_counters);
+    HIPCK(hipEventRecord(h->ev[3], st));
+    HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    if (c[C_OVERFLOW]) { g_err = "HSP / gap task buffer overflow"; return -2; }
+    uint32_t ngaps = c[C_GAPS];
+    if (ngaps) {
+        int blocks = std::min<int>(h->gap_threads / 128, (int)((ngaps + 127) / 128));
+        k_gapped<<<dim3(blocks), dim3(128), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, ngaps, h->d_hsps, h->cap_hsps, h->d_counters, h->d_gH, h->d_gD, h->d_gPH, h->d_gPD);
+    }
+    HIPCK(hipEventRecord(h->ev[4], st));
+    HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    if (c[C_OVERFLOW]) { g_err = "HSP buffer overflow"; return -2; }
+    uint32_t nh = c[C_HSPS];
+    uint32_t nheads = 0, nrows = 0;
+    std::vector<McSegInfo> seg;
+    std::vector<McBestHit> bh;
+    std::vector<McRow> rows;
+    if (nh) {
+        k_make_keys<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(h->d_hsps, nh, h->d_k64, h->d_idx);
+        size_t bytes = h->sorttmp_bytes;
+        HIPCK(rocprim::radix_sort_pairs(h->d_sorttmp, bytes, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, (size_t)nh, 0, 64, st));
+        k_gather<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(h->d_hsps, h->d_idxo, nh, h->d_sorted, h->d_heads, h->d_counters);
+        HIPCK(hipEventRecord(h->ev[5], st));
+        HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
+        HIPCK(hipStreamSynchronize(st));
+        nheads = c[C_HEADS];
+        int blocks = std::min<int>(h->fin_threads / 64, (int)((nheads + 63) / 64));
+        k_finish<<<dim3(blocks), dim3(64), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp, h->d_rowscratch, h->d_kscratch,
+                                                      first_read_id, h->d_rows, h->cap_rows, h->d_seginfo, h->d_best, h->d_counters);
+        HIPCK(hipEventRecord(h->ev[6], st));
+        HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
+        HIPCK(hipStreamSynchronize(st));
+        if (c[C_OVERFLOW]) { g_err = "row buffer overflow"; return -2; }
+        nrows = c[C_ROWS];
+        seg.resize(nheads); bh.resize(nheads); rows.resize(nrows);
+        HIPCK(hipMemcpy(seg.data(), h->d_seginfo, sizeof(McSegInfo) * nheads, hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(bh.data(), h->d_best, sizeof(McBestHit) * nheads, hipMemcpyDeviceToHost));
+        if (nrows) HIPCK(hipMemcpy(rows.data(), h->d_rows, sizeof(McRow) * nrows, hipMemcpyDeviceToHost));
+    } else {
+        HIPCK(hipEventRecord(h->ev[5], st));
+        HIPCK(hipEventRecord(h->ev[6], st));
+        HIPCK(hipStreamSynchronize(st));
+    }
+    // assemble results in read order
+    std::vector<uint32_t> order(nheads);
+    for (uint32_t i = 0; i < nheads; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return seg[a].read < seg[b].read; });
+    h->rows.reserve(nrows);
+    int64_t with_rows = 0;
+    for (uint32_t oi : order) {
+        const McSegInfo &s = seg[oi];
+        if (s.nrows) with_rows++;
+        for (uint32_t i = 0; i < s.nrows; i++) {
+            const McRow &r = rows[s.row_off + i];
+            mc_row o; o.query = r.query; o.subject = r.subject; o.ident = r.ident; o.alnlen = r.alnlen; o.mismatch = r.mismatch; o.gapopen = r.gapopen;
+            o.qstart = r.qstart; o.qend = r.qend; o.sstart = r.sstart; o.send = r.send; o.loge = r.loge; o.bits = r.bits; o.score = r.score; o.nmatch = r.frame;
+            h->rows.push_back(o);
+        }
+        if (bh[oi].family >= 0) { mc_best_hit b; b.read = bh[oi].read; b.family = bh[oi].family; b.aln = bh[oi].aln; b.target_len = bh[oi].target_len; b.bits = bh[oi].bits; h->best.push_back(b); }
+    }
+    h->stats.seed_tasks = ntasks; h->stats.gap_tasks = ngaps; h->stats.hsps = nh; h->stats.rows = nrows; h->stats.reads_with_rows = with_rows; h->stats.classified = (int64_t)h->best.size();
+    h->stats.ms_translate = ev_ms(h->ev[0], h->ev[1]); h->stats.ms_seed = ev_ms(h->ev[1], h->ev[2]); h->stats.ms_eval = ev_ms(h->ev[2], h->ev[3]);
+    h->stats.ms_gapped = ev_ms(h->ev[3], h->ev[4]); h->stats.ms_sort = ev_ms(h->ev[4], h->ev[5]); h->stats.ms_finish = ev_ms(h->ev[5], h->ev[6]); h->stats.ms_total = ev_ms(h->ev[0], h->ev[6]);
+    return 0;
+}
+
+extern "C" int mc_search(mc_handle *h, const uint8_t *reads, int64_t nreads, int64_t first_read_id)
+{
+    if (!h || !h->run_set) { g_err = "mc_set_run() must be called first"; return -1; }
+    const int64_t B = 1 << 20;
+    std::vector<mc_row> all_rows; std::vector<mc_best_hit> all_best; mc_stats tot; memset(&tot, 0, sizeof tot);
+    for (int64_t off = 0; off < nreads || (nreads == 0 && off == 0); off += B) {
+        int64_t nb = std::min<int64_t>(B, nreads - off);
+        if (mc_upload(h, reads + off * h->read_len, nb)) return -1;
+        int rc = mc_run(h, first_read_id + off);
+        if (rc) return rc;
+        all_rows.insert(all_rows.end(), h->rows.begin(), h->rows.end());
+        all_best.insert(all_best.end(), h->best.begin(), h->best.end());
+        tot.reads += h->stats.reads; tot.seed_tasks += h->stats.seed_tasks; tot.gap_tasks += h->stats.gap_tasks; tot.hsps += h->stats.hsps; tot.rows += h->stats.rows;
+        tot.reads_with_rows += h->stats.reads_with_rows; tot.classified += h->stats.classified;
+        tot.ms_translate += h->stats.ms_translate; tot.ms_seed += h->stats.ms_seed; tot.ms_eval += h->stats.ms_eval; tot.ms_gapped += h->stats.ms_gapped;
+        tot.ms_sort += h->stats.ms_sort; tot.ms_finish += h->stats.ms_finish; tot.ms_total += h->stats.ms_total;
+        if (nreads == 0) break;
+    }
+    h->rows.swap(all_rows); h->best.swap(all_best); h->stats = tot;
+    return 0;
+}
+
+extern "C" int64_t mc_result_rows(mc_handle *h, const mc_row **rows) { if (!h) return -1; *rows = h->rows.data(); return (int64_t)h->rows.size(); }
+extern "C" int64_t mc_result_best_hits(mc_handle *h, const mc_best_hit **hits) { if (!h) return -1; *hits = h->best.data(); return (int64_t)h->best.size(); }
+extern "C" int mc_result_stats(mc_handle *h, mc_stats *out) { if (!h) return -1; *out = h->stats; return 0; }
+
+extern "C" int mc_write_m8(mc_handle *h, const char *path, int append)
+{
+    if (!h) { g_err = "null handle"; return -1; }
+    FILE *f = fopen(path, append ? "a" : "w");
+    if (!f) { g_err = std::string("cannot open ") + path; return -1; }
+    for (const mc_row &r : h->rows)
+        fprintf(f, "%d\t%s\t%g\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%g\t%g\n", r.query, h->H.names[r.subject].c_str(), r.ident, r.alnlen, r.mismatch, r.gapopen, r.qstart, r.qend,
+                r.sstart, r.send, r.loge, r.bits);
+    fclose(f);
+    return 0;
+}

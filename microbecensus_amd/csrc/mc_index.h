@@ -1,0 +1,247 @@
+// mc_index.h - host-side construction of the marker index and of the constant tables.
+//
+// Replaces prerapsearch (CHashSearch::BuildDHash@0x40fc20 in
+// /root/reference/microbe_census/bin/prerapsearch_Linux_2.15, same code as in rapsearch_Linux_2.15) and
+// the DB/statistics set-up of CHashSearch::Search@0x418750.  The index has to reproduce the posting ORDER
+// inside every bucket, because the order in which seed hits are met decides which of several equivalent
+// HSPs survives; prerapsearch orders a bucket with std::sort(CompDbObj) - an unstable sort - so the
+// libstdc++ (GCC 4.4) introsort is restated here.  tests/test_index.py checks the result entry by entry
+// against a prerapsearch-built database.
+#pragma once
+#include "mc_core.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+struct McHostIndex {
+    std::vector<std::string> names;
+    std::vector<uint8_t> res_code;     // RAPsearch2 codes (group<<4 | 1+k, 0xA0 invalid) - for cross-checks
+    std::vector<uint8_t> res;          // dense codes used on the device
+    std::vector<uint32_t> off, bstart, post;
+    std::vector<uint16_t> keys;
+    std::vector<uint32_t> bitmap;      // 1 bit per bucket: non-empty
+    uint32_t freq_thr;
+    double letter_p[10];
+    int64_t nres;
+    int nseq;
+};
+
+static const char *MC_AA_ORDER = "ARNDCQEGHILKMFPSTWYV";
+static const char *MC_GROUPS[10] = {"A", "KR", "EDNQ", "C", "G", "H", "ILVM", "FYW", "P", "S/T"};
+
+inline int mc_dense_of_char(unsigned char c)
+{
+    if (c >= 'a' && c <= 'z') c = (unsigned char)(c - 32);
+    const char *p = c ? strchr(MC_AA_ORDER, c) : NULL;
+    return p ? (int)(p - MC_AA_ORDER) : MC_INV;
+}
+inline int mc_group_of_dense(int d)
+{
+    if (d >= 20) return MC_INVGRP;
+    for (int g = 0; g < 10; g++) if (strchr(MC_GROUPS[g], MC_AA_ORDER[d])) return g;
+    return MC_INVGRP;
+}
+inline int mc_code_of_char(unsigned char c)
+{ // CHashSearch ctor 0x4169bd-0x416a62
+    if (c >= 'a' && c <= 'z') c = (unsigned char)(c - 32);
+    for (int g = 0; g < 10; g++) { const char *p = c ? strchr(MC_GROUPS[g], c) : NULL; if (p) return (g << 4) + 1 + (int)(p - MC_GROUPS[g]); }
+    return 0xA0;
+}
+
+// ---- libstdc++ 4.4 std::sort (pivot by value, threshold 16, heap fallback) -------------------------
+template <class V, class Less> void mc44_adjust_heap(V *first, long hole, long len, V value, Less lt)
+{
+    long top = hole, sc = hole;
+    while (sc < (len - 1) / 2) { sc = 2 * (sc + 1); if (lt(first[sc], first[sc - 1])) sc--; first[hole] = first[sc]; hole = sc; }
+    if ((len & 1) == 0 && sc == (len - 2) / 2) { sc = 2 * (sc + 1); first[hole] = first[sc - 1]; hole = sc - 1; }
+    long parent = (hole - 1) / 2;
+    while (hole > top && lt(first[parent], value)) { first[hole] = first[parent]; hole = parent; parent = (hole - 1) / 2; }
+    first[hole] = value;
+}
+template <class V, class Less> void mc44_introsort_loop(V *first, V *last, long depth, Less lt)
+{
+    while (last - first > 16) {
+        if (depth == 0) {
+            long n = last - first;
+            for (long parent = (n - 2) / 2;; parent--) { mc44_adjust_heap(first, parent, n, first[parent], lt); if (parent == 0) break; }
+            for (long m = n; m > 1;) { m--; V v = first[m]; first[m] = first[0]; mc44_adjust_heap(first, 0L, m, v, lt); }
+            return;
+        }
+        --depth;
+        V &a = *first, &b = *(first + (last - first) / 2), &c = *(last - 1);
+        V pivot = lt(a, b) ? (lt(b, c) ? b : (lt(a, c) ? c : a)) : (lt(a, c) ? a : (lt(b, c) ? c : b));
+        V *lo = first, *hi = last;
+        for (;;) {
+            while (lt(*lo, pivot)) ++lo;
+            --hi;
+            while (lt(pivot, *hi)) --hi;
+            if (!(lo < hi)) break;
+            V t = *lo; *lo = *hi; *hi = t;
+            ++lo;
+        }
+        mc44_introsort_loop(lo, last, depth, lt);
+        last = lo;
+    }
+}
+template <class V, class Less> void mc44_sort(V *first, V *last, Less lt)
+{
+    long n = last - first, lg = 0;
+    if (n <= 0) return;
+    for (long t = n; t > 1; t >>= 1) lg++;
+    mc44_introsort_loop(first, last, 2 * lg, lt);
+    V *stop = (n > 16) ? first + 16 : last;
+    for (V *i = first + 1; i < stop; ++i) {
+        V val = *i;
+        if (lt(val, *first)) { for (V *p = i; p != first; --p) *p = *(p - 1); *first = val; }
+        else { V *l = i, *nx = i - 1; while (lt(val, *nx)) { *l = *nx; l = nx; --nx; } *l = val; }
+    }
+    for (V *i = stop; i < last; ++i) { V val = *i, *l = i, *nx = i - 1; while (lt(val, *nx)) { *l = *nx; l = nx; --nx; } *l = val; }
+}
+
+struct McPostKey { uint32_t post; uint16_t key; };
+
+inline bool mc_build_index(McHostIndex &X, const char *const *names, const char *const *seqs, int nseq, std::string &err)
+{
+    X.nseq = nseq;
+    X.names.assign(names, names + nseq);
+    X.off.assign((size_t)nseq + 1, 0);
+    int64_t total = 0;
+    for (int s = 0; s < nseq; s++) {
+        size_t l = strlen(seqs[s]);
+        if (l >= 2048) { err = "marker sequence longer than 2047 residues: " + X.names[s]; return false; }
+        X.off[s] = (uint32_t)total; total += (int64_t)l;
+    }
+    X.off[nseq] = (uint32_t)total; X.nres = total;
+    X.res.resize((size_t)total); X.res_code.resize((size_t)total);
+    uint8_t grp_of_dense[32];
+    for (int d = 0; d < 32; d++) grp_of_dense[d] = (uint8_t)mc_group_of_dense(d);
+    int64_t gcount[11] = {0};
+    for (int s = 0; s < nseq; s++)
+        for (uint32_t i = X.off[s], k = 0; i < X.off[s + 1]; i++, k++) {
+            unsigned char c = (unsigned char)seqs[s][k];
+            X.res[i] = (uint8_t)mc_dense_of_char(c);
+            X.res_code[i] = (uint8_t)mc_code_of_char(c);
+            gcount[grp_of_dense[X.res[i]]]++;
+        }
+    // buckets: every window but the last of each sequence, 6 valid reduced residues
+    std::vector<uint32_t> count(MC_NBUCKET + 1, 0);
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1) {
+            X.bstart.assign(MC_NBUCKET + 1, 0);
+            for (int b = 0; b < MC_NBUCKET; b++) X.bstart[b + 1] = X.bstart[b] + count[b];
+            X.post.resize(X.bstart[MC_NBUCKET]);
+            std::fill(count.begin(), count.end(), 0);
+        }
+        for (int s = 0; s < nseq; s++) {
+            const uint8_t *r = &X.res[X.off[s]];
+            int len = (int)(X.off[s + 1] - X.off[s]);
+            for (int pos = 0; pos + 6 < len; pos++) {
+                int seed = 0; bool bad = false;
+                for (int k = 0; k < 6; k++) { int g = grp_of_dense[r[pos + k]]; if (g == MC_INVGRP) { bad = true; break; } seed = seed * 10 + g; }
+                if (bad) continue;
+                if (pass == 1) X.post[X.bstart[seed] + count[seed]] = ((uint32_t)s << 11) | (uint32_t)pos;
+                count[seed]++;
+            }
+        }
+    }
+    // suffix keys + bucket order (std::sort with CompDbObj, __introsort_loop@0x42f8d0)
+    X.keys.resize(X.post.size());
+    X.bitmap.assign((MC_NBUCKET + 31) / 32, 0);
+    std::vector<McPostKey> tmp;
+    auto key_of = [&](uint32_t p) -> uint16_t {
+        int s = (int)(p >> 11), pos = (int)(p & 0x7ff), len = (int)(X.off[s + 1] - X.off[s]);
+        int rem = len - pos - 6; if (rem > 4) rem = 4;
+        uint32_t k = 0;
+        for (int i = 0; i < 4; i++) k |= (uint32_t)(i < rem ? grp_of_dense[X.res[X.off[s] + pos + 6 + i]] : 0xF) << (12 - 4 * i);
+        return (uint16_t)k;
+    };
+    auto less = [](const McPostKey &a, const McPostKey &b) { return mc_key_lb_less(a.key, b.key); };
+    for (int b = 0; b < MC_NBUCKET; b++) {
+        uint32_t n = X.bstart[b + 1] - X.bstart[b];
+        if (!n) continue;
+        X.bitmap[b >> 5] |= 1u << (b & 31);
+        tmp.resize(n);
+        for (uint32_t i = 0; i < n; i++) { tmp[i].post = X.post[X.bstart[b] + i]; tmp[i].key = key_of(tmp[i].post); }
+        mc44_sort(tmp.data(), tmp.data() + n, less);
+        for (uint32_t i = 0; i < n; i++) { X.post[X.bstart[b] + i] = tmp[i].post; X.keys[X.bstart[b] + i] = tmp[i].key; }
+    }
+    // .info: median of ALL bucket sizes, reduced-letter frequencies
+    { std::vector<uint32_t> c(MC_NBUCKET); for (int b = 0; b < MC_NBUCKET; b++) c[b] = X.bstart[b + 1] - X.bstart[b]; std::nth_element(c.begin(), c.begin() + (MC_NBUCKET >> 1), c.end()); X.freq_thr = c[MC_NBUCKET >> 1]; }
+    { int64_t valid = 0; for (int g = 0; g < 10; g++) valid += gcount[g]; for (int g = 0; g < 10; g++) X.letter_p[g] = (double)gcount[g] / (double)valid; }
+    return true;
+}
+
+// ---- statistics / constant tables (BlastStat::*@0x437d50-0x438b40, Seg::initialize@0x439650) ----------
+inline int mc_length_adjustment(double n, double nseq, int qlen)
+{ // BlastStat::blastComputeLengthAdjustment@0x438410 (NCBI BLAST_ComputeLengthAdjustment, gapped set)
+    const double K = 0.041, beta = -30.0;
+    union { uint64_t u; double d; } ad; ad.u = 0x401c76e43aa79bbbULL;
+    double alpha_d_lambda = ad.d, logK = log(K), m = (double)qlen;
+    double ell, ell_min = 0.0, ell_max, ell_next = 0.0, ss, ell_bar, mb, c, mx = (m > n) ? m : n;
+    bool converged = false;
+    c = m * n - mx / K;
+    if (c < 0) return 0;
+    mb = m * nseq + n;
+    ell_max = 2 * c / (mb + sqrt(mb * mb + (-4.0) * nseq * c));
+    for (int i = 1; i <= 20; i++) {
+        ell = ell_next;
+        ss = (m - ell) * (n - nseq * ell);
+        ell_bar = alpha_d_lambda * (log(ss) + logK) + beta;
+        if (ell_bar >= ell) { ell_min = ell; if (ell_bar - ell_min <= 1.0) { converged = true; break; } if (ell_min == ell_max) break; }
+        else ell_max = ell;
+        if (ell_min <= ell_bar && ell_bar <= ell_max) ell_next = ell_bar;
+        else ell_next = (i == 1) ? ell_max : (ell_min + ell_max) * 0.5;
+    }
+    int adj = (int)ell_min;
+    if (converged) {
+        ell = ceil(ell_min);
+        if (ell <= ell_max) { ss = (m - ell) * (n - nseq * ell); if (alpha_d_lambda * (log(ss) + logK) + beta >= ell) adj = (int)ell; }
+    }
+    return adj;
+}
+
+inline void mc_fill_tables(McTables &T, const McHostIndex &X, int read_len, double loge_thr)
+{
+    static const int8_t B62[20][20] = {
+        {4, -1, -2, -2, 0, -1, -1, 0, -2, -1, -1, -1, -1, -2, -1, 1, 0, -3, -2, 0}, {-1, 5, 0, -2, -3, 1, 0, -2, 0, -3, -2, 2, -1, -3, -2, -1, -1, -3, -2, -3},
+        {-2, 0, 6, 1, -3, 0, 0, 0, 1, -3, -3, 0, -2, -3, -2, 1, 0, -4, -2, -3}, {-2, -2, 1, 6, -3, 0, 2, -1, -1, -3, -4, -1, -3, -3, -1, 0, -1, -4, -3, -3},
+        {0, -3, -3, -3, 9, -3, -4, -3, -3, -1, -1, -3, -1, -2, -3, -1, -1, -2, -2, -1}, {-1, 1, 0, 0, -3, 5, 2, -2, 0, -3, -2, 1, 0, -3, -1, 0, -1, -2, -1, -2},
+        {-1, 0, 0, 2, -4, 2, 5, -2, 0, -3, -3, 1, -2, -3, -1, 0, -1, -3, -2, -2}, {0, -2, 0, -1, -3, -2, -2, 6, -2, -4, -4, -2, -3, -3, -2, 0, -2, -2, -3, -3},
+        {-2, 0, 1, -1, -3, 0, 0, -2, 8, -3, -3, -1, -2, -1, -2, -1, -2, -2, 2, -3}, {-1, -3, -3, -3, -1, -3, -3, -4, -3, 4, 2, -3, 1, 0, -3, -2, -1, -3, -1, 3},
+        {-1, -2, -3, -4, -1, -2, -3, -4, -3, 2, 4, -2, 2, 0, -3, -2, -1, -2, -1, 1}, {-1, 2, 0, -1, -3, 1, 1, -2, -1, -3, -2, 5, -1, -3, -1, 0, -1, -3, -2, -2},
+        {-1, -1, -2, -3, -1, 0, -2, -3, -2, 1, 2, -1, 5, 0, -2, -1, -1, -1, -1, 1}, {-2, -3, -3, -3, -2, -3, -3, -3, -1, 0, 0, -3, 0, 6, -4, -2, -2, 1, 3, -1},
+        {-1, -2, -2, -1, -3, -1, -1, -2, -2, -3, -3, -1, -2, -4, 7, -1, -1, -4, -3, -2}, {1, -1, 1, 0, -1, 0, 0, 0, -1, -2, -2, 0, -1, -2, -1, 4, 1, -3, -2, -2},
+        {0, -1, 0, -1, -1, -1, -1, -2, -2, -1, -1, -1, -1, -2, -1, 1, 5, -2, -2, 0}, {-3, -3, -4, -4, -2, -2, -3, -2, -2, -3, -2, -3, -1, 1, -4, -3, -2, 11, 2, -3},
+        {-2, -2, -2, -3, -2, -1, -2, -3, 2, -1, -1, -2, -1, 3, -3, -2, -2, 2, 7, -1}, {0, -3, -3, -3, -1, -2, -2, -3, -3, 3, 1, -2, 1, -1, -2, -2, 0, -3, -1, 4}};
+    static const char *aa = "FFLLSSSSYY..CC.WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+    const double LN2 = 0.6931471805599453;
+    memset(&T, 0, sizeof T);
+    for (int a = 0; a < 32; a++) for (int b = 0; b < 32; b++) T.sub[(a << 5) | b] = (a < 20 && b < 20) ? B62[a][b] : -5;
+    for (int d = 0; d < 32; d++) T.grp[d] = (uint8_t)mc_group_of_dense(d);
+    for (int i = 0; i < 64; i++) T.codon[i] = (uint8_t)mc_dense_of_char((unsigned char)aa[i]);
+    for (int w = 0; w < 2; w++) { int W = w ? 8 : 12; T.entray[w][0] = 0.0; for (int i = 1; i <= W; i++) { double p = (double)i / (double)W; T.entray[w][i] = (-p) * log(p) / LN2; } }
+    for (int tot = 1; tot <= 12; tot++) { double inv = 1.0 / (double)tot; for (int c = 1; c <= tot; c++) { double x = (double)c; T.lterm[tot][c] = log(inv * x) * x; } }
+    { char buf[64]; for (int i = 0; i < MC_LNFAC_N; i++) { snprintf(buf, sizeof buf, "%.6f", lgamma((double)i + 1.0)); T.lnfac[i] = atof(buf); } }
+    T.gap_trigger = (25.0 * LN2 - 2.0099154790312257) / 0.318;
+    T.xdrop_ungapped = (7.0 * LN2 - 2.0099154790312257) / 0.318;
+    T.xdrop_gapped = (15.0 * LN2 - 3.1941832122778293) / 0.267;
+    T.loge_thr = loge_thr;
+    T.freq_thr = X.freq_thr;
+    for (int g = 0; g < 10; g++) T.letter_p[g] = X.letter_p[g];
+    int m = read_len / 3;
+    int adj = (m <= 10) ? 0 : mc_length_adjustment((double)X.nres, (double)X.nseq, m);
+    T.ell = (double)adj; T.mprime = (double)m - T.ell; T.nprime = (double)X.nres - (double)X.nseq * T.ell; T.logK = log(0.041);
+    for (int s = 0; s < MC_SMAX; s++) {
+        double t = 0.041 * T.nprime; t = t * T.mprime;
+        double x = exp((double)s * (-0.267)) * t; x = x / (1.0 - 0.1);
+        double le = (x == 0.0) ? -10000.0 : log(x) / 2.302585092994046;
+        le = (le > 0.0) ? floor(le * 100.0 + 0.5) / 100.0 : floor(le * 100.0 - 0.5) / 100.0;
+        T.loge_r[s] = le;
+        double bits = ((double)s * 0.267 - T.logK) / LN2;
+        T.bits_r[s] = floor(bits * 100.0 + 0.5) / 100.0;
+    }
+}

@@ -1,0 +1,129 @@
+// tests/emul/mc_emul.cpp - TEST-ONLY sequential emulation of the GPU pipeline.
+//
+// Compiles the per-thread device functions of microbecensus_amd/csrc (mc_core.h, mc_finish.h) with g++ and
+// runs them one "thread" at a time, stage by stage, exactly in the decomposition the HIP kernels use
+// (translate+SEG -> seed enumeration -> seed evaluation -> gapped extension -> sort by (read,subject,chrono)
+// -> per-read finishing).  It exists so the kernel logic can be checked against the oracle / golden m8 on
+// machines without a GPU.  It is not part of the product and is never loaded by microbecensus_amd.
+//
+//   mc_emul <markers.faa> <reads.fa> <out.m8> [rapdb-to-verify-index]
+#include "../../microbecensus_amd/csrc/mc_finish.h"
+#include "../../microbecensus_amd/csrc/mc_index.h"
+#include <algorithm>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+
+static bool read_fasta(const char *path, std::vector<std::string> &names, std::vector<std::string> &seqs)
+{
+    std::ifstream f(path);
+    if (!f) return false;
+    std::string line;
+    while (std::getline(f, line)) {
+        while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
+        if (line.empty()) continue;
+        if (line[0] == '>') { size_t e = line.find_first_of(" \t"); names.push_back(line.substr(1, e == std::string::npos ? e : e - 1)); seqs.push_back(""); }
+        else if (!seqs.empty()) seqs.back() += line;
+    }
+    return true;
+}
+
+struct Emit {
+    std::vector<McSeedTask> *out; uint32_t read; int frame; const McIndex *X;
+    void operator()(int bucket, int nst, int cnt, int seedlen, int nkey, int pos, int phase)
+    {
+        uint32_t b0 = X->bstart[bucket];
+        for (int i = 0; i < cnt; i++) {
+            McSeedTask t; t.read = read; t.chrono = MC_CHRONO(frame, pos, phase, nst + i); t.posting = X->post[b0 + nst + i];
+            t.seedlen_nkey = (uint32_t)seedlen | ((uint32_t)nkey << 8);
+            out->push_back(t);
+        }
+    }
+};
+
+int main(int argc, char **argv)
+{
+    if (argc < 4) { fprintf(stderr, "usage: %s markers.faa reads.fa out.m8 [rapdb]\n", argv[0]); return 2; }
+    std::vector<std::string> mn, ms, rn, rs;
+    if (!read_fasta(argv[1], mn, ms) || !read_fasta(argv[2], rn, rs)) { fprintf(stderr, "cannot read input\n"); return 1; }
+    std::vector<const char *> np, sp;
+    for (size_t i = 0; i < mn.size(); i++) { np.push_back(mn[i].c_str()); sp.push_back(ms[i].c_str()); }
+    McHostIndex H; std::string err;
+    if (!mc_build_index(H, np.data(), sp.data(), (int)mn.size(), err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    fprintf(stderr, "index: %d seqs %ld residues %zu postings thr %u\n", H.nseq, (long)H.nres, H.post.size(), H.freq_thr);
+    int read_len = rs.empty() ? 0 : (int)rs[0].size();
+    static McTables T;
+    mc_fill_tables(T, H, read_len, getenv("MC_LOGE_THR") ? atof(getenv("MC_LOGE_THR")) : 1.0);
+    McIndex X; X.res = H.res.data(); X.off = H.off.data(); X.bstart = H.bstart.data(); X.post = H.post.data(); X.keys = H.keys.data(); X.nseq = H.nseq;
+    McClassPars P; memset(&P, 0, sizeof P); P.nfam = 1; P.read_len = read_len;
+    std::vector<int32_t> fam(H.nseq, 0);
+
+    const int FP = MC_MAXAA + 2;
+    std::vector<uint8_t> frames((size_t)rs.size() * 6 * FP);
+    std::vector<int> flen(rs.size() * 6);
+    // stage 1: translate + SEG
+    for (size_t r = 0; r < rs.size(); r++)
+        for (int f = 0; f < 6; f++) {
+            uint8_t *p = &frames[(r * 6 + f) * FP];
+            if ((int)rs[r].size() != read_len) { fprintf(stderr, "reads must all have the same length\n"); return 1; }
+            int n = mc_translate_frame(T, (const uint8_t *)rs[r].data(), read_len, f, p);
+            uint8_t mask[(MC_MAXAA + 7) / 8]; double Hbuf[MC_MAXAA + 2];
+            mc_seg_mask(T, p, n, mask, Hbuf);
+            for (int i = 0; i < n; i++) if (mask[i >> 3] & (1 << (i & 7))) p[i] = MC_INV;
+            flen[r * 6 + f] = n;
+        }
+    // stage 2: seed enumeration
+    std::vector<McSeedTask> tasks;
+    for (size_t r = 0; r < rs.size(); r++)
+        for (int f = 0; f < 6; f++) { Emit e{&tasks, (uint32_t)r, f, &X}; mc_enumerate_seeds(T, X, &frames[(r * 6 + f) * FP], flen[r * 6 + f], e); }
+    fprintf(stderr, "seed tasks: %zu (%.1f / read)\n", tasks.size(), (double)tasks.size() / std::max<size_t>(1, rs.size()));
+    // stage 3: seed evaluation (+ ungapped) ; stage 4: gapped
+    std::vector<McHsp> hsps; std::vector<McGapTask> gaps;
+    for (const McSeedTask &t : tasks) {
+        int frame = (int)(t.chrono >> 25), pos = (int)((t.chrono >> 17) & 0xff);
+        McGapTask g; g.read = t.read; g.chrono = t.chrono;
+        int rc = mc_eval_seed(T, X, &frames[((size_t)t.read * 6 + frame) * FP], flen[(size_t)t.read * 6 + frame], frame, pos, t.posting, (int)(t.seedlen_nkey & 0xff), (int)(t.seedlen_nkey >> 8), &g);
+        if (rc == 1) { McHsp h; h.read = t.read; h.chrono = t.chrono; if (mc_make_hsp(T, read_len, frame, g, g.qfwd, g.qfwd, g.qbwd, g.qbwd, g.score, g.nmatch, g.qfwd + g.L + g.qbwd, 0, 0, &h)) hsps.push_back(h); }
+        else if (rc == 2) gaps.push_back(g);
+    }
+    fprintf(stderr, "ungapped hsps: %zu gapped tasks: %zu\n", hsps.size(), gaps.size());
+    std::vector<int> Hh(2100), Dd(2100); std::vector<McPath> PH(2100), PD(2100);
+    for (const McGapTask &g : gaps) {
+        int frame = (int)(g.chrono >> 25);
+        const uint8_t *q = &frames[((size_t)g.read * 6 + frame) * FP]; int qlen = flen[(size_t)g.read * 6 + frame];
+        const uint8_t *d = X.res + X.off[g.sidx]; int dlen = (int)(X.off[g.sidx + 1] - X.off[g.sidx]);
+        int score = g.score, nmatch = g.nmatch, qfwd = g.qfwd, dfwd = g.qfwd, qbwd = g.qbwd, dbwd = g.qbwd;
+        int alnlen = g.qfwd + g.L + g.qbwd, gapopens = 0, gaptotal = 0;
+        int qend = qfwd + g.qp + g.L, dend = dfwd + g.dp + g.L, dright = dlen - dend, qright = qlen - qend;
+        if (dright > 2 && qright > 2) {
+            McGapResult R = mc_align_gapped(T, q + qend, 1, d + dend, 1, qright, dright, Hh.data(), Dd.data(), PH.data(), PD.data());
+            if (R.gain > 0) { score += R.gain; nmatch += R.ident; qfwd += R.c1; dfwd += R.c2; alnlen += R.steps; gapopens += R.runs; gaptotal += R.gapcols; }
+        }
+        int dleft = g.dp - dbwd, qleft = g.qp - qbwd;
+        if (dleft > 2 && qleft > 2) {
+            McGapResult R = mc_align_gapped(T, q + qleft - 1, -1, d + dleft - 1, -1, qleft, dleft, Hh.data(), Dd.data(), PH.data(), PD.data());
+            if (R.gain > 0) { score += R.gain; nmatch += R.ident; qbwd += R.c1; dbwd += R.c2; alnlen += R.steps; gapopens += R.runs; gaptotal += R.gapcols; }
+        }
+        McHsp h; h.read = g.read; h.chrono = g.chrono;
+        if (mc_make_hsp(T, read_len, frame, g, qfwd, dfwd, qbwd, dbwd, score, nmatch, alnlen, gapopens, gaptotal, &h)) hsps.push_back(h);
+    }
+    // stage 5: sort by (read, subject, chrono)
+    std::sort(hsps.begin(), hsps.end(), [](const McHsp &a, const McHsp &b) { if (a.read != b.read) return a.read < b.read; if (a.sidx != b.sidx) return a.sidx < b.sidx; return a.chrono < b.chrono; });
+    fprintf(stderr, "hsps kept: %zu\n", hsps.size());
+    // stage 6: per-read finishing
+    FILE *o = fopen(argv[3], "w");
+    std::vector<McHsp> v, tmp; std::vector<McRow> rows(MC_MAX_M8); std::vector<double> kr(MC_MAX_M8);
+    for (size_t a = 0; a < hsps.size();) {
+        size_t b = a; while (b < hsps.size() && hsps[b].read == hsps[a].read) b++;
+        int n = (int)(b - a); v.resize(n); tmp.resize(2 * n);
+        McBestHit best;
+        int nr = mc_finish_read(T, X, P, fam.data(), (int)hsps[a].read, &hsps[a], n, v.data(), tmp.data(), rows.data(), kr.data(), &best);
+        for (int i = 0; i < nr; i++) {
+            const McRow &r = rows[i];
+            fprintf(o, "%s\t%s\t%g\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%g\t%g\n", rn[r.query].c_str(), H.names[r.subject].c_str(), r.ident, r.alnlen, r.mismatch, r.gapopen, r.qstart, r.qend, r.sstart, r.send, r.loge, r.bits);
+        }
+        a = b;
+    }
+    fclose(o);
+    return 0;
+}
