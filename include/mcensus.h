@@ -37,6 +37,7 @@ typedef struct mc_best_hit {
 
 typedef struct mc_stats {
     int64_t reads, seed_tasks, gap_tasks, hsps, rows, reads_with_rows, classified;
+    int64_t bucket_lookups, key_probes;   /* algorithmic traffic of the seed kernel: 8 B and 2 B reads */
     float ms_translate, ms_seed, ms_eval, ms_gapped, ms_sort, ms_finish, ms_total;
 } mc_stats;
 
@@ -68,7 +69,11 @@ int mc_search(mc_handle *h, const uint8_t *reads, int64_t nreads, int64_t first_
 /* Same pipeline on reads that are already resident in HBM (bench / streaming):
  * mc_upload() copies a batch to the device, mc_run() executes the kernels on it (no host transfers of reads). */
 int mc_upload(mc_handle *h, const uint8_t *reads, int64_t nreads);
+/* ... or adopts caller-owned device memory (e.g. a torch uint8 tensor) as the resident read set. */
+int mc_attach(mc_handle *h, const void *device_reads, int64_t nreads);
 int mc_run(mc_handle *h, int64_t first_read_id);
+/* runs the pipeline on reads [first, first+count) of the resident set (count <= 2097151). */
+int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id);
 
 /* Results of the last mc_search()/mc_run(), owned by the handle until the next call:
  * rows in the reference's m8 order (ascending read id, then RAPsearch2's order within a read); best hits in

@@ -25,7 +25,7 @@ class McBestHit(C.Structure):
 
 
 class McStats(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in ("reads", "seed_tasks", "gap_tasks", "hsps", "rows", "reads_with_rows", "classified")] + \
+    _fields_ = [(n, C.c_int64) for n in ("reads", "seed_tasks", "gap_tasks", "hsps", "rows", "reads_with_rows", "classified", "bucket_lookups", "key_probes")] + \
                [(n, C.c_float) for n in ("ms_translate", "ms_seed", "ms_eval", "ms_gapped", "ms_sort", "ms_finish", "ms_total")]
 
 
@@ -55,6 +55,8 @@ def load_library():
     lib.mc_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
     lib.mc_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.mc_run.argtypes = [C.c_void_p, C.c_int64]
+    lib.mc_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.mc_run_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
     lib.mc_result_rows.restype = C.c_int64
     lib.mc_result_rows.argtypes = [C.c_void_p, C.POINTER(C.POINTER(McRow))]
     lib.mc_result_best_hits.restype = C.c_int64
@@ -66,7 +68,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_index_view", "mc_set_run", "mc_search",
-                    "mc_upload", "mc_run", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8"]
+                    "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8"]
 
 
 def load_markers(path=None):
@@ -153,6 +155,13 @@ class Engine:
 
     def run(self, first_read_id=0):
         self._check(self.lib.mc_run(self.h, first_read_id), "mc_run")
+
+    def attach(self, device_ptr, nreads):
+        """Adopt caller-owned device memory (nreads x read_len bytes) as the resident read set."""
+        self._check(self.lib.mc_attach(self.h, C.c_void_p(device_ptr), nreads), "mc_attach")
+
+    def run_range(self, first, count, first_read_id=0):
+        self._check(self.lib.mc_run_range(self.h, first, count, first_read_id), "mc_run_range")
 
     def results(self):
         pr = C.POINTER(McRow)(); pb = C.POINTER(McBestHit)()

@@ -286,15 +286,18 @@ MC_HD bool mc_key_ub_less(uint32_t qk, uint32_t dbk)
     if (a == b) return false;
     return a < b;
 }
+struct McSeedCount { uint32_t lookups, keyprobes; };   // bucket-bound reads (8 B each) and suffix-key reads (2 B each)
+
 // range of bucket `seed` whose key matches qk on the common prefix; returns ned-nst (0 = nothing)
-MC_HD int mc_key_range(const McIndex &X, int seed, uint32_t qk, int *nst_out)
+MC_HD int mc_key_range(const McIndex &X, int seed, uint32_t qk, int *nst_out, McSeedCount *sc)
 {
     uint32_t b0 = X.bstart[seed];
     int n = (int)(X.bstart[seed + 1] - b0);
     const uint16_t *keys = X.keys + b0;
+    sc->lookups++;
     if (n == 0) return 0;
     int lo = 0, len = n;
-    while (len > 0) { int half = len >> 1; if (mc_key_lb_less(keys[lo + half], qk)) { lo += half + 1; len -= half + 1; } else len = half; }
+    while (len > 0) { int half = len >> 1; sc->keyprobes++; if (mc_key_lb_less(keys[lo + half], qk)) { lo += half + 1; len -= half + 1; } else len = half; }
     int nst = lo;
     if (nst == n) return 0;
     uint32_t dk = keys[nst];
@@ -303,7 +306,7 @@ MC_HD int mc_key_range(const McIndex &X, int seed, uint32_t qk, int *nst_out)
     int sh = (4 - m) * 4;
     if ((dk >> sh) != (qk >> sh)) return 0;
     lo = 0; len = n;
-    while (len > 0) { int half = len >> 1; if (mc_key_ub_less(qk, keys[lo + half])) len = half; else { lo += half + 1; len -= half + 1; } }
+    while (len > 0) { int half = len >> 1; sc->keyprobes++; if (mc_key_ub_less(qk, keys[lo + half])) len = half; else { lo += half + 1; len -= half + 1; } }
     *nst_out = nst;
     return lo - nst;
 }
@@ -321,7 +324,7 @@ MC_HD uint32_t mc_pack_key(const uint8_t *g, int nkey)
 // phase: 0 exact; 1..30 = 1 + stride_index*10 + j; 31..40 = 31 + substituted first key residue.
 // ---------------------------------------------------------------------------------------------
 template <class Emit>
-MC_HDN void mc_enumerate_seeds(const McTables &T, const McIndex &X, const uint8_t *q, int qlen, Emit &emit)
+MC_HDN void mc_enumerate_seeds(const McTables &T, const McIndex &X, const uint8_t *q, int qlen, Emit &emit, McSeedCount *sc)
 {
     if (qlen <= 6) return;
     int prev = 6;
@@ -331,6 +334,7 @@ MC_HDN void mc_enumerate_seeds(const McTables &T, const McIndex &X, const uint8_
         for (int k = 0; k < 6; k++) { g = T.grp[q[pos + k]]; if (g == MC_INVGRP) { bad = true; break; } seed = seed * 10 + g; }
         if (bad) continue;
         uint32_t freq = X.bstart[seed + 1] - X.bstart[seed];
+        sc->lookups++;
         if (freq > T.freq_thr) {
             int rest = qlen - pos - 6, maxextra = (rest >= 2) ? 3 : rest + 1;
             if (maxextra <= 1) len = 7;
@@ -361,7 +365,7 @@ MC_HDN void mc_enumerate_seeds(const McTables &T, const McIndex &X, const uint8_
         for (int k = 6; k < used && k < 10; k++) key[k - 6] = T.grp[q[pos + k]];
         if (freq != 0) {
             int r = 0, nst = 0;
-            if (used > 6) r = mc_key_range(X, seed, mc_pack_key(key, used - 6), &nst);
+            if (used > 6) r = mc_key_range(X, seed, mc_pack_key(key, used - 6), &nst, sc);
             else r = (int)freq;
             if (r > 0) emit(seed, nst, r, used, used - 6, pos, 0);
             prev = used;
@@ -379,7 +383,7 @@ MC_HDN void mc_enumerate_seeds(const McTables &T, const McIndex &X, const uint8_
                 for (int j = 0; j < 10; j++) {
                     int v = start + j * st, nst = 0;
                     if (v == seed) continue;
-                    int r = mc_key_range(X, v, qk, &nst);
+                    int r = mc_key_range(X, v, qk, &nst, sc);
                     if (r > 0) emit(v, nst, r, 10, 4, pos, 1 + m * 10 + j);
                 }
             }
@@ -387,7 +391,7 @@ MC_HDN void mc_enumerate_seeds(const McTables &T, const McIndex &X, const uint8_
             for (int k = 0; k < 10; k++) {
                 if (k == orig) continue;
                 key[0] = (uint8_t)k;
-                int nst = 0, r = mc_key_range(X, seed, mc_pack_key(key, 4), &nst);
+                int nst = 0, r = mc_key_range(X, seed, mc_pack_key(key, 4), &nst, sc);
                 if (r > 0) emit(seed, nst, r, 10, 4, pos, 31 + k);
             }
         }

@@ -36,6 +36,7 @@ extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
     } while (0)
 
 enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_N = 8 };
+enum { S_LOOKUPS = 0, S_KEYPROBES, S_N = 4 };   // 64-bit algorithmic-traffic counters of k_enumerate
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -74,7 +75,7 @@ struct DevEmit {
 };
 
 __global__ void __launch_bounds__(256) k_enumerate(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
-                                                   int64_t nreads, McSeedTask *tasks, uint32_t cap, uint32_t *counters)
+                                                   int64_t nreads, McSeedTask *tasks, uint32_t cap, uint32_t *counters, unsigned long long *stats)
 {
     int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= nreads * 6) return;
@@ -82,7 +83,9 @@ __global__ void __launch_bounds__(256) k_enumerate(const McTables *__restrict__ 
     int f = (int)(tid - r * 6);
     int qlen = (L - f % 3) / 3;
     DevEmit e{tasks, counters, cap, (uint32_t)r, f, &X};
-    mc_enumerate_seeds(*T, X, frames + (r * 6 + f) * FP, qlen, e);
+    McSeedCount sc; sc.lookups = 0; sc.keyprobes = 0;
+    mc_enumerate_seeds(*T, X, frames + (r * 6 + f) * FP, qlen, e, &sc);
+    if (stats) { atomicAdd(&stats[S_LOOKUPS], (unsigned long long)sc.lookups); atomicAdd(&stats[S_KEYPROBES], (unsigned long long)sc.keyprobes); }
 }
 
 __global__ void __launch_bounds__(256) k_eval_seeds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
@@ -209,8 +212,10 @@ struct mc_handle {
     McTables hT; McClassPars hP;
     int read_len = 0, FP = 0; bool run_set = false;
     // batch buffers
-    int64_t cap_reads = 0, nreads = 0;
+    int64_t cap_reads = 0, nreads = 0, cap_own = 0;
     uint8_t *d_reads = nullptr, *d_frames = nullptr;
+    const uint8_t *reads_dev = nullptr;   // resident read set (own buffer or attached caller memory)
+    unsigned long long *d_stats = nullptr;
     McSeedTask *d_tasks = nullptr; McGapTask *d_gaps = nullptr; McHsp *d_hsps = nullptr, *d_sorted = nullptr, *d_v = nullptr, *d_tmp = nullptr;
     uint32_t cap_tasks = 0, cap_gaps = 0, cap_hsps = 0, cap_rows = 0;
     uint64_t *d_k64 = nullptr, *d_k64o = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
@@ -248,7 +253,7 @@ extern "C" void mc_close(mc_handle *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_frames, h->d_tasks, h->d_gaps, h->d_hsps,
                     h->d_sorted, h->d_v, h->d_tmp, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, h->d_heads, h->d_sorttmp, h->d_counters, h->d_rows, h->d_rowscratch,
-                    h->d_kscratch, h->d_seginfo, h->d_best, h->d_gH, h->d_gD, h->d_gPH, h->d_gPD};
+                    h->d_kscratch, h->d_seginfo, h->d_best, h->d_gH, h->d_gD, h->d_gPH, h->d_gPD, h->d_stats};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -271,7 +276,7 @@ static int open_impl(mc_handle *h, const char *const *names, const char *const *
     for (auto &e : h->ev) HIPCK(hipEventCreate(&e));
     const McHostIndex &H = h->H;
     if (dalloc(&h->d_res, H.res.size()) || dalloc(&h->d_off, H.off.size()) || dalloc(&h->d_bstart, H.bstart.size()) || dalloc(&h->d_post, H.post.size() + 1) ||
-        dalloc(&h->d_keys, H.keys.size() + 1) || dalloc(&h->d_fam, (size_t)nseq) || dalloc(&h->d_T, 1) || dalloc(&h->d_P, 1) || dalloc(&h->d_counters, C_N)) return -1;
+        dalloc(&h->d_keys, H.keys.size() + 1) || dalloc(&h->d_fam, (size_t)nseq) || dalloc(&h->d_T, 1) || dalloc(&h->d_P, 1) || dalloc(&h->d_counters, C_N) || dalloc(&h->d_stats, S_N)) return -1;
     HIPCK(hipMemcpy(h->d_res, H.res.data(), H.res.size(), hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_off, H.off.data(), H.off.size() * 4, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_bstart, H.bstart.data(), H.bstart.size() * 4, hipMemcpyHostToDevice));
@@ -324,7 +329,7 @@ static int ensure_capacity(mc_handle *h, int64_t nreads)
     h->cap_hsps = (uint32_t)std::min<int64_t>(cap * 64 + 65536, 0x7fffffff);
     h->cap_rows = (uint32_t)std::min<int64_t>(cap * 32 + 65536, 0x7fffffff);
     h->gap_threads = 64 * 1024; h->fin_threads = 16 * 1024;
-    if (dalloc(&h->d_reads, (size_t)cap * h->read_len) || dalloc(&h->d_frames, (size_t)cap * 6 * h->FP) || dalloc(&h->d_tasks, h->cap_tasks) ||
+    if (dalloc(&h->d_frames, (size_t)cap * 6 * h->FP) || dalloc(&h->d_tasks, h->cap_tasks) ||
         dalloc(&h->d_gaps, h->cap_gaps) || dalloc(&h->d_hsps, h->cap_hsps) || dalloc(&h->d_sorted, h->cap_hsps) || dalloc(&h->d_v, h->cap_hsps) ||
         dalloc(&h->d_tmp, (size_t)h->cap_hsps * 2) || dalloc(&h->d_k64, h->cap_hsps) || dalloc(&h->d_k64o, h->cap_hsps) || dalloc(&h->d_idx, h->cap_hsps) ||
         dalloc(&h->d_idxo, h->cap_hsps) || dalloc(&h->d_heads, (size_t)cap + 1) || dalloc(&h->d_rows, h->cap_rows) ||
@@ -345,20 +350,30 @@ extern "C" int mc_upload(mc_handle *h, const uint8_t *reads, int64_t nreads)
 {
     if (!h || !h->run_set) { g_err = "mc_set_run() must be called first"; return -1; }
     HIPCK(hipSetDevice(h->device));
-    if (ensure_capacity(h, nreads)) return -1;
-    HIPCK(hipMemcpyAsync(h->d_reads, reads, (size_t)nreads * h->read_len, hipMemcpyHostToDevice, h->stream));
+    if (nreads > h->cap_own) { if (dalloc(&h->d_reads, (size_t)nreads * h->read_len + 16)) return -1; h->cap_own = nreads; }
+    if (nreads) HIPCK(hipMemcpyAsync(h->d_reads, reads, (size_t)nreads * h->read_len, hipMemcpyHostToDevice, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
-    h->nreads = nreads;
+    h->reads_dev = h->d_reads; h->nreads = nreads;
+    return 0;
+}
+
+extern "C" int mc_attach(mc_handle *h, const void *device_reads, int64_t nreads)
+{
+    if (!h || !h->run_set) { g_err = "mc_set_run() must be called first"; return -1; }
+    h->reads_dev = (const uint8_t *)device_reads; h->nreads = nreads;
     return 0;
 }
 
 static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 
-extern "C" int mc_run(mc_handle *h, int64_t first_read_id)
+extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id)
 {
     if (!h || !h->run_set) { g_err = "mc_set_run() must be called first"; return -1; }
+    if (first < 0 || count < 0 || first + count > h->nreads) { g_err = "range outside the resident read set"; return -1; }
     HIPCK(hipSetDevice(h->device));
-    const int64_t n = h->nreads;
+    if (ensure_capacity(h, count)) return -1;
+    const int64_t n = count;
+    const uint8_t *d_reads = h->reads_dev + first * h->read_len;
     const int L = h->read_len, FP = h->FP;
     hipStream_t st = h->stream;
     McIndex X = dev_index(h);
@@ -368,12 +383,13 @@ extern "C" int mc_run(mc_handle *h, int64_t first_read_id)
     h->stats.reads = n;
     if (n == 0) return 0;
     HIPCK(hipMemsetAsync(h->d_counters, 0, sizeof(uint32_t) * C_N, st));
+    HIPCK(hipMemsetAsync(h->d_stats, 0, sizeof(unsigned long long) * S_N, st));
     HIPCK(hipEventRecord(h->ev[0], st));
     {
         int64_t threads = n * 6;
-        k_translate_seg<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, h->d_reads, L, n, h->d_frames, FP);
+        k_translate_seg<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, d_reads, L, n, h->d_frames, FP);
         HIPCK(hipEventRecord(h->ev[1], st));
-        k_enumerate<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, X, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, h->d_counters);
+        k_enumerate<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, X, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, h->d_counters, h->d_stats);
         HIPCK(hipEventRecord(h->ev[2], st));
     }
     HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
@@ -442,26 +458,29 @@ extern "C" int mc_run(mc_handle *h, int64_t first_read_id)
         }
         if (bh[oi].family >= 0) { mc_best_hit b; b.read = bh[oi].read; b.family = bh[oi].family; b.aln = bh[oi].aln; b.target_len = bh[oi].target_len; b.bits = bh[oi].bits; h->best.push_back(b); }
     }
+    { unsigned long long ss[S_N]; HIPCK(hipMemcpy(ss, h->d_stats, sizeof ss, hipMemcpyDeviceToHost)); h->stats.bucket_lookups = (int64_t)ss[S_LOOKUPS]; h->stats.key_probes = (int64_t)ss[S_KEYPROBES]; }
     h->stats.seed_tasks = ntasks; h->stats.gap_tasks = ngaps; h->stats.hsps = nh; h->stats.rows = nrows; h->stats.reads_with_rows = with_rows; h->stats.classified = (int64_t)h->best.size();
     h->stats.ms_translate = ev_ms(h->ev[0], h->ev[1]); h->stats.ms_seed = ev_ms(h->ev[1], h->ev[2]); h->stats.ms_eval = ev_ms(h->ev[2], h->ev[3]);
     h->stats.ms_gapped = ev_ms(h->ev[3], h->ev[4]); h->stats.ms_sort = ev_ms(h->ev[4], h->ev[5]); h->stats.ms_finish = ev_ms(h->ev[5], h->ev[6]); h->stats.ms_total = ev_ms(h->ev[0], h->ev[6]);
     return 0;
 }
 
+extern "C" int mc_run(mc_handle *h, int64_t first_read_id) { return h ? mc_run_range(h, 0, h->nreads, first_read_id) : -1; }
+
 extern "C" int mc_search(mc_handle *h, const uint8_t *reads, int64_t nreads, int64_t first_read_id)
 {
     if (!h || !h->run_set) { g_err = "mc_set_run() must be called first"; return -1; }
     const int64_t B = 1 << 20;
     std::vector<mc_row> all_rows; std::vector<mc_best_hit> all_best; mc_stats tot; memset(&tot, 0, sizeof tot);
+    if (mc_upload(h, reads, nreads)) return -1;
     for (int64_t off = 0; off < nreads || (nreads == 0 && off == 0); off += B) {
         int64_t nb = std::min<int64_t>(B, nreads - off);
-        if (mc_upload(h, reads + off * h->read_len, nb)) return -1;
-        int rc = mc_run(h, first_read_id + off);
+        int rc = mc_run_range(h, off, nb, first_read_id + off);
         if (rc) return rc;
         all_rows.insert(all_rows.end(), h->rows.begin(), h->rows.end());
         all_best.insert(all_best.end(), h->best.begin(), h->best.end());
         tot.reads += h->stats.reads; tot.seed_tasks += h->stats.seed_tasks; tot.gap_tasks += h->stats.gap_tasks; tot.hsps += h->stats.hsps; tot.rows += h->stats.rows;
-        tot.reads_with_rows += h->stats.reads_with_rows; tot.classified += h->stats.classified;
+        tot.reads_with_rows += h->stats.reads_with_rows; tot.classified += h->stats.classified; tot.bucket_lookups += h->stats.bucket_lookups; tot.key_probes += h->stats.key_probes;
         tot.ms_translate += h->stats.ms_translate; tot.ms_seed += h->stats.ms_seed; tot.ms_eval += h->stats.ms_eval; tot.ms_gapped += h->stats.ms_gapped;
         tot.ms_sort += h->stats.ms_sort; tot.ms_finish += h->stats.ms_finish; tot.ms_total += h->stats.ms_total;
         if (nreads == 0) break;

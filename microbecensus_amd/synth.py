@@ -1,0 +1,107 @@
+"""Deterministic synthetic shotgun reads for benchmarks and size-independent tests.
+
+No reference code or data is involved beyond the marker proteins shipped as package data: a synthetic
+"community" of genomes is assembled from (a) marker proteins picked from the database and diverged at the
+amino-acid level and (b) random ORFs with the database's amino-acid composition, all back-translated with
+random synonymous codons, placed on either strand and separated by random spacers.  About 1 % of the genes
+are markers, which is what a bacterial genome carries of the 30 universal families.  Reads are sampled
+uniformly over the genomes, strand by fair coin, error free.
+
+The generator is counter based (splitmix64 of seed and index), so every value is a pure function of
+(seed, index): identical on every platform and cheap to vectorise with numpy.
+"""
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+CODONS = {
+    "A": ["GCT", "GCC", "GCA", "GCG"], "R": ["CGT", "CGC", "CGA", "CGG", "AGA", "AGG"], "N": ["AAT", "AAC"], "D": ["GAT", "GAC"],
+    "C": ["TGT", "TGC"], "Q": ["CAA", "CAG"], "E": ["GAA", "GAG"], "G": ["GGT", "GGC", "GGA", "GGG"], "H": ["CAT", "CAC"],
+    "I": ["ATT", "ATC", "ATA"], "L": ["TTA", "TTG", "CTT", "CTC", "CTA", "CTG"], "K": ["AAA", "AAG"], "M": ["ATG"], "F": ["TTT", "TTC"],
+    "P": ["CCT", "CCC", "CCA", "CCG"], "S": ["TCT", "TCC", "TCA", "TCG", "AGT", "AGC"], "T": ["ACT", "ACC", "ACA", "ACG"], "W": ["TGG"],
+    "Y": ["TAT", "TAC"], "V": ["GTT", "GTC", "GTA", "GTG"], "X": ["NNN"],
+}
+AA = "ARNDCQEGHILKMFPSTWYV"
+
+
+def splitmix64(x):
+    """Vectorised splitmix64 finaliser on uint64 arrays."""
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        return z ^ (z >> np.uint64(31))
+
+
+class Counter:
+    """Stream of uint64 values: value k = splitmix64(seed * K + k)."""
+
+    def __init__(self, seed):
+        self.base = np.uint64(splitmix64(np.array([seed], dtype=np.uint64))[0])
+        self.k = 0
+
+    def take(self, n):
+        with np.errstate(over="ignore"):
+            idx = (np.arange(self.k, self.k + n, dtype=np.uint64) * np.uint64(0xD1342543DE82EF95) + self.base) & _M64
+        self.k += n
+        return splitmix64(idx)
+
+    def uniform(self, n):
+        return (self.take(n) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+    def integers(self, n, hi):
+        return (self.take(n) % np.uint64(hi)).astype(np.int64)
+
+
+def build_genomes(marker_seqs, total_bp=8_000_000, seed=20261001, marker_gene_fraction=0.01, divergence=0.25):
+    """Returns one uint8 array of bases (all genomes concatenated)."""
+    rng = Counter(seed)
+    comp = np.zeros(20)
+    sample = "".join(marker_seqs[:: max(1, len(marker_seqs) // 500)])
+    for i, a in enumerate(AA):
+        comp[i] = sample.count(a)
+    cdf = np.cumsum(comp / comp.sum())
+    codon_tab = {a: [np.frombuffer(c.encode(), dtype=np.uint8) for c in cs] for a, cs in CODONS.items()}
+    rc_map = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGTN", b"TGCAN"):
+        rc_map[a] = b
+    parts, n = [], 0
+    while n < total_bp:
+        u = rng.uniform(4)
+        if u[0] < marker_gene_fraction:
+            prot = marker_seqs[int(u[1] * len(marker_seqs))].replace("X", "A")
+            sub = rng.uniform(len(prot))
+            repl = np.searchsorted(cdf, rng.uniform(len(prot)))
+            prot = "".join(AA[min(19, int(repl[i]))] if sub[i] < divergence else c for i, c in enumerate(prot))
+        else:
+            ln = 100 + int(u[1] * 500)
+            prot = "".join(AA[min(19, int(k))] for k in np.searchsorted(cdf, rng.uniform(ln)))
+        pick = rng.take(len(prot))
+        gene = np.concatenate([codon_tab[a][int(pick[i] % np.uint64(len(codon_tab[a])))] for i, a in enumerate(prot)])
+        if u[2] < 0.5:
+            gene = rc_map[gene[::-1]]
+        spacer = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(20 + int(u[3] * 120), 4)]
+        parts += [gene, spacer]
+        n += len(gene) + len(spacer)
+    return np.concatenate(parts)
+
+
+def sample_reads(genome, nreads, read_len, seed=1, chunk=1 << 20):
+    """(nreads, read_len) uint8 bases, uniform start, strand by fair coin, error free."""
+    rng = Counter(seed)
+    out = np.empty((nreads, read_len), dtype=np.uint8)
+    rc_map = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGTN", b"TGCAN"):
+        rc_map[a] = b
+    span = len(genome) - read_len
+    ar = np.arange(read_len, dtype=np.int64)
+    for s in range(0, nreads, chunk):
+        m = min(chunk, nreads - s)
+        start = rng.integers(m, span)
+        strand = rng.take(m) & np.uint64(1)
+        block = genome[start[:, None] + ar[None, :]]
+        rev = strand.astype(bool)
+        block[rev] = rc_map[block[rev][:, ::-1]]
+        out[s:s + m] = block
+    return out

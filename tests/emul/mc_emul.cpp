@@ -73,10 +73,10 @@ int main(int argc, char **argv)
             flen[r * 6 + f] = n;
         }
     // stage 2: seed enumeration
-    std::vector<McSeedTask> tasks;
+    std::vector<McSeedTask> tasks; uint64_t lookups = 0, keyprobes = 0;
     for (size_t r = 0; r < rs.size(); r++)
-        for (int f = 0; f < 6; f++) { Emit e{&tasks, (uint32_t)r, f, &X}; mc_enumerate_seeds(T, X, &frames[(r * 6 + f) * FP], flen[r * 6 + f], e); }
-    fprintf(stderr, "seed tasks: %zu (%.1f / read)\n", tasks.size(), (double)tasks.size() / std::max<size_t>(1, rs.size()));
+        for (int f = 0; f < 6; f++) { Emit e{&tasks, (uint32_t)r, f, &X}; McSeedCount sc{0, 0}; mc_enumerate_seeds(T, X, &frames[(r * 6 + f) * FP], flen[r * 6 + f], e, &sc); lookups += sc.lookups; keyprobes += sc.keyprobes; }
+    fprintf(stderr, "seed tasks: %zu (%.1f / read) lookups %.1f / read keyprobes %.1f / read\n", tasks.size(), (double)tasks.size() / std::max<size_t>(1, rs.size()), (double)lookups / std::max<size_t>(1, rs.size()), (double)keyprobes / std::max<size_t>(1, rs.size()));
     // stage 3: seed evaluation (+ ungapped) ; stage 4: gapped
     std::vector<McHsp> hsps; std::vector<McGapTask> gaps;
     for (const McSeedTask &t : tasks) {
