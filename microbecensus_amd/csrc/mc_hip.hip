@@ -324,10 +324,13 @@ static int ensure_capacity(mc_handle *h, int64_t nreads)
     if (nreads <= h->cap_reads) return 0;
     int64_t cap = nreads;
     if (cap > (1 << 21) - 1) { g_err = "batch larger than 2097151 reads"; return -1; }
-    h->cap_tasks = (uint32_t)std::min<int64_t>(cap * 160 + 65536, 0x7fffffff);
-    h->cap_gaps = (uint32_t)std::min<int64_t>(cap * 24 + 65536, 0x7fffffff);
-    h->cap_hsps = (uint32_t)std::min<int64_t>(cap * 64 + 65536, 0x7fffffff);
-    h->cap_rows = (uint32_t)std::min<int64_t>(cap * 32 + 65536, 0x7fffffff);
+    // pool sizes: generous multiples of what shotgun reads produce (45-60 seed hits, 10-17 kept HSPs, 1-3 gapped
+    // extensions per 100-150 bp read), scaled with the read length; a batch that still overflows is split by mc_search
+    const int64_t L = h->read_len;
+    h->cap_tasks = (uint32_t)std::min<int64_t>(cap * (L + 32) + (1 << 20), 0x7fffffff);
+    h->cap_gaps = (uint32_t)std::min<int64_t>(cap * (L / 8 + 8) + (1 << 18), 0x7fffffff);
+    h->cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 2 + 16) + (1 << 20), 0x7fffffff);
+    h->cap_rows = (uint32_t)std::min<int64_t>(cap * 48 + (1 << 20), 0x7fffffff);
     h->gap_threads = 64 * 1024; h->fin_threads = 16 * 1024;
     if (dalloc(&h->d_frames, (size_t)cap * 6 * h->FP) || dalloc(&h->d_tasks, h->cap_tasks) ||
         dalloc(&h->d_gaps, h->cap_gaps) || dalloc(&h->d_hsps, h->cap_hsps) || dalloc(&h->d_sorted, h->cap_hsps) || dalloc(&h->d_v, h->cap_hsps) ||
@@ -473,9 +476,11 @@ extern "C" int mc_search(mc_handle *h, const uint8_t *reads, int64_t nreads, int
     const int64_t B = 1 << 20;
     std::vector<mc_row> all_rows; std::vector<mc_best_hit> all_best; mc_stats tot; memset(&tot, 0, sizeof tot);
     if (mc_upload(h, reads, nreads)) return -1;
-    for (int64_t off = 0; off < nreads || (nreads == 0 && off == 0); off += B) {
-        int64_t nb = std::min<int64_t>(B, nreads - off);
+    int64_t off = 0, step = B;
+    while (off < nreads || (nreads == 0 && off == 0)) {
+        int64_t nb = std::min<int64_t>(step, nreads - off);
         int rc = mc_run_range(h, off, nb, first_read_id + off);
+        if (rc == -2 && nb > 1) { step = std::max<int64_t>(1, nb / 2); continue; }   // a pool overflowed: retry with half the batch
         if (rc) return rc;
         all_rows.insert(all_rows.end(), h->rows.begin(), h->rows.end());
         all_best.insert(all_best.end(), h->best.begin(), h->best.end());
@@ -484,6 +489,8 @@ extern "C" int mc_search(mc_handle *h, const uint8_t *reads, int64_t nreads, int
         tot.ms_translate += h->stats.ms_translate; tot.ms_seed += h->stats.ms_seed; tot.ms_eval += h->stats.ms_eval; tot.ms_gapped += h->stats.ms_gapped;
         tot.ms_sort += h->stats.ms_sort; tot.ms_finish += h->stats.ms_finish; tot.ms_total += h->stats.ms_total;
         if (nreads == 0) break;
+        off += nb;
+        if (step < B) step = std::min<int64_t>(B, step * 2);
     }
     h->rows.swap(all_rows); h->best.swap(all_best); h->stats = tot;
     return 0;

@@ -52,7 +52,7 @@ inline int mc_code_of_char(unsigned char c)
     return 0xA0;
 }
 
-// ---- libstdc++ 4.4 std::sort (pivot by value, threshold 16, heap fallback) -------------------------
+// ---- libstdc++ std::sort as prerapsearch's build instantiates it (threshold 16, heap fallback) ------------
 template <class V, class Less> void mc44_adjust_heap(V *first, long hole, long len, V value, Less lt)
 {
     long top = hole, sc = hole;
@@ -72,9 +72,16 @@ template <class V, class Less> void mc44_introsort_loop(V *first, V *last, long 
             return;
         }
         --depth;
-        V &a = *first, &b = *(first + (last - first) / 2), &c = *(last - 1);
-        V pivot = lt(a, b) ? (lt(b, c) ? b : (lt(a, c) ? c : a)) : (lt(a, c) ? a : (lt(b, c) ? c : b));
-        V *lo = first, *hi = last;
+        // prerapsearch_Linux_2.15 was built with a libstdc++ that moves the median of (first, mid, last-1) to *first
+        // and partitions [first+1, last) around it (__move_median_first, GCC 4.5-4.8); verified bucket by bucket
+        // against the database prerapsearch wrote (tests/test_emul.py::test_index_builder_matches_prerapsearch).
+        V *x = first, *y = first + (last - first) / 2, *z = last - 1;
+        if (lt(*x, *y)) { if (lt(*y, *z)) std::swap(*x, *y); else if (lt(*x, *z)) std::swap(*x, *z); }
+        else if (lt(*x, *z)) {}
+        else if (lt(*y, *z)) std::swap(*x, *z);
+        else std::swap(*x, *y);
+        V pivot = *first;
+        V *lo = first + 1, *hi = last;
         for (;;) {
             while (lt(*lo, pivot)) ++lo;
             --hi;
@@ -102,7 +109,7 @@ template <class V, class Less> void mc44_sort(V *first, V *last, Less lt)
     for (V *i = stop; i < last; ++i) { V val = *i, *l = i, *nx = i - 1; while (lt(val, *nx)) { *l = *nx; l = nx; --nx; } *l = val; }
 }
 
-struct McPostKey { uint32_t post; uint16_t key; };
+struct McPostKey { uint32_t post; uint16_t key; int16_t rem; };   // rem = residues left after the 6-mer (uncapped)
 
 inline bool mc_build_index(McHostIndex &X, const char *const *names, const char *const *seqs, int nseq, std::string &err)
 {
@@ -159,13 +166,20 @@ inline bool mc_build_index(McHostIndex &X, const char *const *names, const char 
         for (int i = 0; i < 4; i++) k |= (uint32_t)(i < rem ? grp_of_dense[X.res[X.off[s] + pos + 6 + i]] : 0xF) << (12 - 4 * i);
         return (uint16_t)k;
     };
-    auto less = [](const McPostKey &a, const McPostKey &b) { return mc_key_lb_less(a.key, b.key); };
+    // CompDbObj (inlined in __introsort_loop@0x42f8d0, e.g. 0x42fa5a-0x42fae1): compare the reduced residues that
+    // follow the 6-mer over n = 4 (both suffixes longer than 3) or min(remA, remB) positions; on a tie the
+    // posting with FEWER residues left in its sequence sorts first.
+    auto less = [](const McPostKey &a, const McPostKey &b) {
+        int n = (a.rem > 3 && b.rem > 3) ? 4 : (a.rem < b.rem ? a.rem : b.rem);
+        if (n > 0) { int sh = (4 - n) * 4; int x = a.key >> sh, y = b.key >> sh; if (x != y) return x < y; }
+        return a.rem < b.rem;
+    };
     for (int b = 0; b < MC_NBUCKET; b++) {
         uint32_t n = X.bstart[b + 1] - X.bstart[b];
         if (!n) continue;
         X.bitmap[b >> 5] |= 1u << (b & 31);
         tmp.resize(n);
-        for (uint32_t i = 0; i < n; i++) { tmp[i].post = X.post[X.bstart[b] + i]; tmp[i].key = key_of(tmp[i].post); }
+        for (uint32_t i = 0; i < n; i++) { uint32_t p = X.post[X.bstart[b] + i]; int sq = (int)(p >> 11); tmp[i].post = p; tmp[i].key = key_of(p); tmp[i].rem = (int16_t)((int)(X.off[sq + 1] - X.off[sq]) - (int)(p & 0x7ff) - 6); }
         mc44_sort(tmp.data(), tmp.data() + n, less);
         for (uint32_t i = 0; i < n; i++) { X.post[X.bstart[b] + i] = tmp[i].post; X.keys[X.bstart[b] + i] = tmp[i].key; }
     }

@@ -1,0 +1,69 @@
+"""Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on MI355X).
+
+The path shards embarrassingly: the accepted-read stream (after the sequential sampling / QC / duplicate
+semantics of process_seqfile, which stay on the host) is cut into contiguous blocks, one per rank, the
+29 MB marker index is replicated in every GPU's HBM, and nothing is exchanged while searching.  The only
+exchange step is the final reduction of the per-family accumulators that aggregate_hits() needs
+(reference microbe_census.py:462-472):
+
+    hits[f]            number of classified reads                       int64
+    aln_sum[f]         sum of alignment lengths                         int64
+    aln_by_len[f, t]   sum of alignment lengths per target length t     int64   (for aln_stat == 'cov')
+
+All integers, so the all_reduce is exact and order independent; cov sums are finished on the host as
+sum_t aln_by_len[f, t] / t, which equals the reference's sum of aln/target_len up to double rounding
+(<= 1e-12 relative, the tolerance BASELINE.md states for 'cov' families).
+"""
+import numpy as np
+
+MAX_TARGET_LEN = 2048
+
+
+def shard_bounds(n_items, rank, world):
+    """Contiguous block [lo, hi) of rank `rank`; blocks differ by at most one item and keep read ids global."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def family_accumulators(best_hits, nfam):
+    """best_hits: structured array with fields family, aln, target_len -> (hits, aln_sum, aln_by_len)."""
+    hits = np.bincount(best_hits["family"], minlength=nfam).astype(np.int64)
+    aln_sum = np.bincount(best_hits["family"], weights=best_hits["aln"], minlength=nfam).astype(np.int64)
+    aln_by_len = np.zeros((nfam, MAX_TARGET_LEN), dtype=np.int64)
+    np.add.at(aln_by_len, (best_hits["family"], best_hits["target_len"]), best_hits["aln"])
+    return hits, aln_sum, aln_by_len
+
+
+def all_reduce_accumulators(hits, aln_sum, aln_by_len, device=None):
+    """Sum the three accumulators over all ranks (RCCL when the process group is nccl, gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return hits, aln_sum, aln_by_len
+    flat = np.concatenate([hits.ravel(), aln_sum.ravel(), aln_by_len.ravel()])
+    t = torch.from_numpy(flat)
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    flat = t.cpu().numpy()
+    n = hits.size
+    return flat[:n].reshape(hits.shape), flat[n:2 * n].reshape(aln_sum.shape), flat[2 * n:].reshape(aln_by_len.shape)
+
+
+def aggregate_from_accumulators(hits, aln_sum, aln_by_len, families, optpars):
+    """agg_hits {family: float} as aggregate_hits() would return it (families without hits are absent)."""
+    agg = {}
+    lens = np.arange(MAX_TARGET_LEN, dtype=np.float64)
+    lens[0] = 1.0
+    for i, fam in enumerate(families):
+        if hits[i] == 0:
+            continue
+        stat = optpars[fam]["aln_stat"]
+        if stat == "hits":
+            agg[fam] = float(hits[i])
+        elif stat == "aln":
+            agg[fam] = float(aln_sum[i])
+        else:
+            agg[fam] = float(np.sum(aln_by_len[i] / lens))
+    return agg

@@ -1,0 +1,525 @@
+"""Host-side mirror of the reference's module API (microbe_census/microbe_census.py of
+snayfach/MicrobeCensus) with the hot path on an MI355X.
+
+Same public names, argument dicts, side effects, messages and return shapes as the reference, so
+`from microbecensus_amd import microbe_census` is a drop-in for `from microbe_census import microbe_census`:
+
+    run_pipeline(args) -> (est_ags, args)            reference :586-631
+    process_seqfile(args, paths)                     reference :328-367   (sampler / QC / trimming)
+    search_seqs(args, paths)                         reference :369-389   -> HIP pipeline instead of rapsearch
+    classify_reads(args, paths) -> best_hits         reference :432-460   -> device classification
+    aggregate_hits(args, paths, best_hits)           reference :462-472
+    estimate_average_genome_size(args, paths, agg)   reference :474-512
+    count_bases(args), report_results(...)           reference :573-584, :514-529
+
+What differs from the reference, on purpose:
+  * search_seqs() does not fork RAPsearch2; it packs the trimmed reads and calls libmcensus_hip.so
+    (include/mcensus.h).  It still leaves `<tempfile>.m8` behind in RAPsearch2's format, so anything that
+    consumed that file keeps working.  args['rapsearch'] (the reference's -r hook) is not honoured.
+  * classify_reads() takes the per-read best hits the device computed; if `<tempfile>.m8` was not produced
+    by this process it falls back to parsing that file exactly as the reference does.
+  * `.bz2` inputs are opened in text mode (the reference returns a bytes stream under Python 3, which makes
+    its own file-type detection exit).
+  * optional args['device'] (default 0) selects the GPU.
+"""
+import bz2
+import gzip
+import io
+import os
+import platform
+import sys
+from tempfile import mkstemp
+
+import numpy as np
+from numpy import mean, median
+
+__version__ = "1.1.0"
+
+VALID_READ_LENGTHS = [50, 60, 70, 80, 90, 100, 110, 120, 130, 140, 150, 175, 200, 225, 250, 300, 350, 400, 450, 500]
+
+_engines = {}       # device -> Engine
+_run_cache = {}     # tempfile -> dict(reads=ndarray | None, best=ndarray | None, families=[...])
+
+
+# ----------------------------------------------------------------------------------------------
+# small helpers with the reference's semantics
+# ----------------------------------------------------------------------------------------------
+def mad(x, const=1.48):
+    """const * median absolute deviation (reference :43-45)."""
+    m = median(x)
+    return const * median([abs(v - m) for v in x])
+
+
+def open_file(inpath):
+    """Text stream over a plain, .gz or .bz2 file (reference :47-59)."""
+    ext = inpath.split(".")[-1]
+    if ext == "gz":
+        return io.TextIOWrapper(gzip.open(inpath))
+    if ext == "bz2":
+        return io.TextIOWrapper(bz2.BZ2File(inpath))
+    return open(inpath)
+
+
+def _model():
+    from . import _native
+    if "model" not in _run_cache:
+        _run_cache["model"] = _native.load_model()
+    return _run_cache["model"]
+
+
+def find_opt_pars(path_optpars, read_length):
+    """{family: {'min_cov','max_aaid','min_score','aln_stat'}} for one read length (reference :61-72)."""
+    pars = _model()["pars"].get(str(read_length), {})
+    return {fam: {"min_cov": p[0], "max_aaid": p[1], "min_score": p[2], "aln_stat": p[3]} for fam, p in pars.items()}
+
+
+def read_list(file, header, dtype):
+    """One value per line (reference :90-99)."""
+    conv = float if dtype == "float" else int if dtype == "int" else (lambda v: v)
+    with open_file(file) as f_in:
+        if header is True:
+            next(f_in)
+        return [conv(line.rstrip()) for line in f_in]
+
+
+def check_os():
+    if platform.system() not in ["Linux", "Darwin"]:
+        sys.exit("Operating system '%s' not supported" % platform.system())
+
+
+def get_relative_paths(args):
+    """Data locations + a fresh temp file (reference :106-123); the maps live in package data."""
+    pkg_dir = os.path.dirname(os.path.abspath(__file__))
+    return {"db": os.path.join(pkg_dir, "data", "markers.faa.gz"), "model": os.path.join(pkg_dir, "data", "model.json"),
+            "tempfile": mkstemp()[1]}
+
+
+def check_paths(paths):
+    for p in paths.values():
+        if not (os.path.isfile(p) or os.path.isdir(p)):
+            sys.exit("Path to file/dir not found: %s" % p)
+
+
+# ----------------------------------------------------------------------------------------------
+# FASTA / FASTQ reading (reference parse_seqs :294-325, a readfq derivative)
+# ----------------------------------------------------------------------------------------------
+class Sequence:
+    _comp = {"A": "T", "T": "A", "G": "C", "C": "G", "N": "N"}
+
+    def __init__(self, name, seq, quality=None):
+        self.id, self.seq, self.quality = name, seq, quality
+
+    def reverse_complement(self):
+        return "".join(self._comp[b] for b in reversed(self.seq))   # KeyError on anything but ACGTN, as the reference
+
+    def phred(self, offset):
+        return [ord(c) - offset for c in self.quality]
+
+
+def parse_seqs(fp):
+    """Yields Sequence records from a FASTA/FASTQ text stream.  Every line loses exactly its last character
+    (the newline) as in the reference; a '+' line after the sequence switches to quality mode, and quality
+    lines are consumed until they cover the sequence length."""
+    pending = None
+    it = iter(fp)
+    while True:
+        if pending is None:
+            for line in it:
+                if line[:1] in (">", "@"):
+                    pending = line[:-1]
+                    break
+            if pending is None:
+                return
+        name = pending[1:].partition(" ")[0]
+        pending, chunks = None, []
+        for line in it:
+            if line[:1] in ("@", "+", ">"):
+                pending = line[:-1]
+                break
+            chunks.append(line[:-1])
+        seq = "".join(chunks)
+        if pending is None or pending[0] != "+":
+            yield Sequence(name, seq)
+            if pending is None:
+                return
+            continue
+        quals, got, done = [], 0, False
+        for line in it:
+            quals.append(line[:-1])
+            got += len(line) - 1
+            if got >= len(seq):
+                done = True
+                break
+        if done:
+            pending = None
+            yield Sequence(name, seq, "".join(quals))
+        else:
+            yield Sequence(name, seq)
+            return
+
+
+read_seqfile_records = parse_seqs
+
+
+def auto_detect_file_type(seqfile):
+    with open_file(seqfile) as f_in:
+        for line in f_in:
+            if line[0] == ">":
+                return "fasta"
+            if line[0] == "@":
+                return "fastq"
+            sys.exit("Filetype [fasta, fastq] of %s could not be recognized" % seqfile)
+
+
+def auto_detect_quality_offset(seqfile):
+    """32 or 64, literally (reference :175-187: the value is later subtracted from ord(char))."""
+    low = set("""!"#$%&'()*+,-./0123456789""")
+    high = set("""KLMNOPQRSTUVWXYZ[\\]^_`abcdefghijklmnopqrstuvwxyz{|}~""")
+    with open_file(seqfile) as f_in:
+        for rec in parse_seqs(f_in):
+            for ch in rec.quality:
+                if ch in low:
+                    return 32
+                if ch in high:
+                    return 64
+    return 32
+
+
+def auto_detect_read_length(seqfile, file_type):
+    lengths = []
+    try:
+        with open_file(seqfile) as f_in:
+            for i, rec in enumerate(parse_seqs(f_in)):
+                if i == 10000:
+                    break
+                lengths.append(len(rec.seq))
+    except Exception:
+        sys.exit("Could not detect read length of: %s\nThis may be due to an invalid format\nTry specifying it with -l" % seqfile)
+    med = int(median(lengths))
+    if med < VALID_READ_LENGTHS[0]:
+        sys.exit("Median read length is %s. Cannot compute AGS using reads shorter than 50 bp." % med)
+    best = VALID_READ_LENGTHS[-1]
+    for i, L in enumerate(VALID_READ_LENGTHS):
+        if L > med:
+            best = VALID_READ_LENGTHS[i - 1]
+            break
+    return best
+
+
+def impute_missing_args(args):
+    for key, val in (("verbose", False), ("outfile", None), ("nreads", 1000000), ("threads", 1), ("filter_dups", False),
+                     ("keep_tmp", False), ("mean_quality", -5), ("min_quality", -5), ("max_unknown", 100)):
+        if key not in args:
+            args[key] = val
+    args["file_type"] = auto_detect_file_type(args["seqfiles"][0])
+    if args["file_type"] == "fastq":
+        args["quality_offset"] = auto_detect_quality_offset(args["seqfiles"][0])
+    if "read_length" not in args or args["read_length"] is None:
+        args["read_length"] = auto_detect_read_length(args["seqfiles"][0], args["file_type"])
+
+
+def check_input(args):
+    for seqfile in args["seqfiles"]:
+        if not os.path.isfile(seqfile):
+            sys.exit("Input file %s not found" % seqfile)
+
+
+def check_arguments(args):
+    if args["file_type"] == "fasta" and any([args["min_quality"] > -5, args["mean_quality"] > -5]):
+        sys.exit("Quality filtering options are only available for FASTQ files")
+    if args["threads"] < 1:
+        sys.exit("Invalid number of threads: %s\nMust be a positive integer." % args["threads"])
+    if args["nreads"] is not None and args["nreads"] < 1:
+        sys.exit("Invalid number of reads: %s\nMust be a positive integer." % args["nreads"])
+
+
+def print_copyright():
+    print("\nMicrobeCensus - estimation of average genome size from shotgun sequence data")
+    print("version %s; github.com/snayfach/MicrobeCensus (MI355X-native search path)" % __version__)
+    print("Freely distributed under the GNU General Public License (GPLv3)\n")
+
+
+def print_parameters(args):
+    fq = args["file_type"] == "fastq"
+    print("=============Parameters==============")
+    print("Input metagenome: %s" % args["seqfiles"])
+    print("Output file: %s" % args["outfile"])
+    print("Reads trimmed to: %s bp" % args["read_length"])
+    print("Maximum reads sampled: %s" % args["nreads"])
+    print("Threads to use for db search: %s" % args["threads"])
+    print("Minimum base-level quality score: %s" % (args["min_quality"] if fq else "NA"))
+    print("Minimum read-level quality score: %s" % (args["mean_quality"] if fq else "NA"))
+    print("Maximum percent unknown bases/read: %s" % args["max_unknown"])
+    print("Filter duplicate reads: %s" % args["filter_dups"])
+    print("Keep temporary files: %s\n" % args["keep_tmp"])
+
+
+def quality_filter(rec, args):
+    """True when the read fails QC; only the first read_length bases/qualities count (reference :265-279)."""
+    L = args["read_length"]
+    head = rec.seq[0:L]
+    if 100 * head.count("N") / float(len(head)) > args["max_unknown"]:
+        return True
+    if args["file_type"] == "fastq":
+        q = rec.phred(args["quality_offset"])[0:L]
+        if mean(q) < args["mean_quality"]:
+            return True
+        if min(q) < args["min_quality"]:
+            return True
+    return False
+
+
+# ----------------------------------------------------------------------------------------------
+# stages
+# ----------------------------------------------------------------------------------------------
+def process_seqfile(args, paths):
+    """Head-take sampler: files in order, records in order; too short -> skip; duplicate (full sequence or its
+    reverse complement, checked before QC) -> skip; QC fail -> skip; else keep seq[:L]; stop at nreads."""
+    if args["verbose"]:
+        print("====Estimating Average Genome Size====")
+        print("Sampling & trimming reads...")
+    L, nreads = args["read_length"], args["nreads"]
+    kept, seen = [], set()
+    dups = too_short = low_qual = 0
+    with open(paths["tempfile"], "w") as out:
+        for seqfile in args["seqfiles"]:
+            for rec in parse_seqs(open_file(seqfile)):
+                if len(rec.seq) < L:
+                    too_short += 1
+                    continue
+                if args["filter_dups"] and (rec.seq in seen or rec.reverse_complement() in seen):
+                    dups += 1
+                    continue
+                if quality_filter(rec, args):
+                    low_qual += 1
+                    continue
+                out.write(">%d\n%s\n" % (len(kept), rec.seq[0:L]))
+                kept.append(rec.seq[0:L])
+                if args["filter_dups"]:
+                    seen.add(rec.seq)
+                if len(kept) == nreads:
+                    break
+            if len(kept) == nreads:
+                break
+    if not kept:
+        clean_up(paths)
+        sys.exit("\nError! No reads remaining after filtering!")
+    args["sampled_reads"] = len(kept)
+    _run_cache[paths["tempfile"]] = {"reads": kept}
+    if args["verbose"]:
+        print("\t%s reads shorter than %s bp and skipped" % (too_short, L))
+        print("\t%s low quality reads found and skipped" % low_qual)
+        print("\t%s duplicate reads found and skipped" % dups)
+        print("\t%s reads sampled from seqfile" % len(kept))
+
+
+def _engine(device):
+    from . import _native
+    if device not in _engines:
+        _engines[device] = _native.Engine(device=device)
+    return _engines[device]
+
+
+def _pack_reads(seqs, L):
+    """(n, L) uint8; characters outside latin-1 cannot be bases, map them to '?'."""
+    blob = "".join(seqs).encode("latin-1", "replace")
+    return np.frombuffer(blob, dtype=np.uint8).reshape(len(seqs), L)
+
+
+def search_seqs(args, paths):
+    """Translated search of the trimmed reads against the marker proteins on the GPU; leaves
+    `<tempfile>.m8` (RAPsearch2 m8 format) behind like the reference does."""
+    if args["verbose"]:
+        print("Searching reads against marker proteins...")
+    L = args["read_length"]
+    cache = _run_cache.get(paths["tempfile"])
+    if cache is None or "reads" not in cache:
+        seqs = [r.seq for r in parse_seqs(open(paths["tempfile"]))]
+        cache = _run_cache[paths["tempfile"]] = {"reads": seqs}
+    model = _model()
+    fams = model["families"]
+    try:
+        eng = _engine(args.get("device", 0) or 0)
+        eng.set_run(L, model["pars"][str(L)], fams)
+        rows, best = eng.search(_pack_reads(cache["reads"], L))
+        with open(paths["tempfile"] + ".m8", "w") as f:
+            f.write("# microbecensus_amd %s: RAPsearch2-compatible m8 written by the MI355X search path\n" % __version__)
+            f.write("# Job submitted: reads=%d trimmed to %d bp\n# Query : %s\n# Subject : %s\n" % (len(cache["reads"]), L, paths["tempfile"], paths["db"]))
+            f.write("# Fields: Query\tSubject\tidentity\taln-len\tmismatch\tgap-openings\tq.start\tq.end\ts.start\ts.end\tlog(e-value)\tbit-score\n")
+        eng.write_m8(paths["tempfile"] + ".m8", append=True)
+    except Exception as error:
+        clean_up(paths)
+        sys.exit("\nDatabase search has exited with the following error:\n%s" % error)
+    cache["best"], cache["families"], cache["rows"] = best, fams, rows
+    if args["verbose"]:
+        print("\t%s reads hit marker proteins" % len(np.unique(rows["query"])))
+
+
+def parse_rapsearch(m8):
+    """Records of an m8 file as dicts of 2 strings and 10 floats (reference :391-398)."""
+    names = ("query", "target", "pid", "aln", "mis", "gaps", "qstart", "qend", "tstart", "tend", "evalue", "score")
+    with open(m8) as f_in:
+        for line in f_in:
+            if line[0] == "#":
+                continue
+            vals = line.rstrip().split()
+            yield dict(zip(names, vals[:2] + [float(v) for v in vals[2:12]]))
+
+
+def alignment_coverage(r):
+    """aln / (largest alignment the read could have had at this position), reference :400-418."""
+    qlen = float(r["query_len"]) / 3
+    qs, qe = sorted([r["qstart"], r["qend"]])
+    frame = qs % 3 if qs % 3 in [1, 2] else 3
+    q_start = (qs + 3 - frame) / 3
+    q_stop = (qe + 1 - frame) / 3
+    t_start, t_stop = sorted([r["tstart"] + 1, r["tend"] + 1])
+    return r["aln"] / (min(q_start - 1, t_start - 1) + r["aln"] + min(qlen - q_stop, r["target_len"] - t_stop))
+
+
+def alignment_filter(r, optpars):
+    p = optpars[r["target_fam"]]
+    return alignment_coverage(r) < p["min_cov"] or r["score"] < p["min_score"] or r["pid"] > p["max_aaid"]
+
+
+def _classify_m8_file(args, paths):
+    """The reference's own classification of an m8 file (used when the file did not come from this process,
+    and by the tests as the checker of the device classification)."""
+    from . import _native
+    optpars = find_opt_pars(None, args["read_length"])
+    model = _model()
+    names, seqs = _native.load_markers(paths.get("db"))
+    fam_of = {n: model["families"][f] for n, f in zip(names, model["marker_family"])}
+    len_of = {n: float(len(s)) for n, s in zip(names, seqs)}
+    best = {}
+    for r in parse_rapsearch(paths["tempfile"] + ".m8"):
+        r["query_len"], r["target_fam"], r["target_len"] = args["read_length"], fam_of[r["target"]], len_of[r["target"]]
+        if alignment_filter(r, optpars):
+            continue
+        if r["query"] not in best or best[r["query"]][-1] < r["score"]:
+            best[r["query"]] = [r["target_fam"], r["aln"], r["aln"] / r["target_len"], r["score"]]
+    return best
+
+
+def classify_reads(args, paths):
+    """{read_id(str): [family, aln, aln/target_len, bit score]} of the best passing hit of every read."""
+    if args["verbose"]:
+        print("Filtering hits...")
+    cache = _run_cache.get(paths["tempfile"], {})
+    if cache.get("best") is not None:
+        fams = cache["families"]
+        best_hits = {}
+        for b in cache["best"]:          # ascending read id = the order the reference meets them in the m8
+            aln = float(b["aln"])
+            best_hits[str(int(b["read"]))] = [fams[b["family"]], aln, aln / float(b["target_len"]), float(b["bits"])]
+    else:
+        best_hits = _classify_m8_file(args, paths)
+    if len(best_hits) == 0:
+        clean_up(paths)
+        sys.exit("\nError: No hits to marker proteins - cannot estimate genome size! Rerun program with more reads.")
+    if args["verbose"]:
+        print("\t%s reads assigned to a marker protein" % len(best_hits))
+    return best_hits
+
+
+def aggregate_hits(args, paths, best_hits):
+    """Per family: number of hits, summed aln/target_len, or summed aln, as pars.map's aln_stat says."""
+    optpars = find_opt_pars(None, args["read_length"])
+    agg = {}
+    for fam, aln, cov, score in best_hits.values():
+        stat = optpars[fam]["aln_stat"]
+        inc = 1.0 if stat == "hits" else cov if stat == "cov" else aln
+        agg[fam] = agg[fam] + inc if fam in agg else inc
+    return agg
+
+
+def estimate_average_genome_size(args, paths, agg_hits):
+    """AGS_j = coefficient_j / (hits_j / sampled bp); drop |AGS_j - median| >= 1.48 MAD; weighted mean."""
+    if args["verbose"]:
+        print("Computing average genome size...")
+    model = _model()
+    L = str(args["read_length"])
+    estimates = {}
+    for fam, hits in agg_hits.items():
+        rate = hits / (args["sampled_reads"] * args["read_length"])
+        if rate == 0:
+            continue
+        estimates[fam] = model["coefficients"]["_".join([L, fam])] / rate
+    spread = mad(list(estimates.values()))
+    centre = median(list(estimates.values()))
+    total = wsum = 0
+    for fam, est in estimates.items():
+        if abs(est - centre) >= spread:
+            continue
+        w = model["weights"]["_".join([L, fam])]
+        total += est * w
+        wsum += w
+    est_ags = total / wsum
+    if args["verbose"]:
+        print("\t%s bp" % str(round(est_ags, 2)))
+    return est_ags
+
+
+def report_results(args, est_ags, count_bases):
+    with open(args["outfile"], "w") as out:
+        out.write("Parameters\n")
+        for key, val in (("metagenome", ",".join(args["seqfiles"])), ("reads_sampled", args["sampled_reads"]), ("trimmed_length", args["read_length"]),
+                         ("min_quality", args["min_quality"]), ("mean_quality", args["mean_quality"]), ("filter_dups", args["filter_dups"]),
+                         ("max_unknown", args["max_unknown"])):
+            out.write("%s:\t%s\n" % (key, val))
+        out.write("\nResults\n")
+        out.write("%s:\t%s\n" % ("average_genome_size", est_ags))
+        if count_bases:
+            out.write("%s:\t%s\n" % ("total_bases", count_bases))
+            out.write("%s:\t%s\n" % ("genome_equivalents", count_bases / est_ags))
+
+
+def clean_up(paths):
+    base = paths["tempfile"]
+    for ext in ("", ".m8", ".aln"):
+        for i in range(20):
+            f = "%s%s.tmp%s" % (base, ext, i)
+            if os.path.isfile(f):
+                os.remove(f)
+        if os.path.isfile(base + ext):
+            os.remove(base + ext)
+    _run_cache.pop(base, None)
+
+
+def read_seqfile(infile):
+    for rec in parse_seqs(infile):
+        yield rec.id, rec.seq, rec.quality
+
+
+def count_bases(args):
+    if args["verbose"]:
+        print("Computing number of genome equivalents...")
+    total = 0
+    for inpath in args["seqfiles"]:
+        with open_file(inpath) as infile:
+            total += sum(len(rec.seq) for rec in parse_seqs(infile))
+    return total
+
+
+def run_pipeline(args):
+    if "verbose" in args and args["verbose"]:
+        print_copyright()
+    check_os()
+    paths = get_relative_paths(args)
+    check_paths(paths)
+    try:
+        check_input(args)
+        impute_missing_args(args)
+        check_arguments(args)
+        if args["verbose"]:
+            print_parameters(args)
+        process_seqfile(args, paths)
+        search_seqs(args, paths)
+        best_hits = classify_reads(args, paths)
+        agg_hits = aggregate_hits(args, paths, best_hits)
+        clean_up(paths)
+        est_ags = estimate_average_genome_size(args, paths, agg_hits)
+        return est_ags, args
+    except Exception as error:     # the reference prints and swallows everything but SystemExit
+        print(error)
+        clean_up(paths)

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Command line of the MI355X-native MicrobeCensus hot path; same flags, defaults and report file as the
+reference's scripts/run_microbe_census.py (flags :14-55, flow :58-67), plus -g/--device."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from microbecensus_amd import microbe_census  # noqa: E402
+
+
+def parse_arguments(argv=None):
+    p = argparse.ArgumentParser(usage="%s [-options] <seqfiles> <outfile>" % os.path.basename(__file__),
+                                description="Estimate average genome size from metagenomic data (GPU search path).")
+    p.add_argument("seqfiles", type=str, help="path to input metagenome(s); comma separated; FASTA/FASTQ, optionally gz/bz2")
+    p.add_argument("outfile", type=str, help="path to the output report")
+    p.add_argument("-v", dest="verbose", action="store_true", default=False, help="print program's progress to stdout")
+    p.add_argument("-r", dest="rapsearch", type=str, default=None, help="accepted for compatibility; the GPU path does not run RAPsearch2")
+    p.add_argument("-n", dest="nreads", type=int, default=2000000, help="number of reads to sample (default = 2000000)")
+    p.add_argument("-t", dest="threads", type=int, default=1, help="host threads (default = 1)")
+    p.add_argument("-e", dest="no_equivs", action="store_true", default=False, help="skip the genome-equivalents pass over the input")
+    p.add_argument("-l", dest="read_length", type=int, choices=microbe_census.VALID_READ_LENGTHS, help="trim all reads to this length")
+    p.add_argument("-q", dest="min_quality", type=int, default=-5, help="minimum base-level PHRED quality (default = -5; no filtering)")
+    p.add_argument("-m", dest="mean_quality", type=int, default=-5, help="minimum read-level PHRED quality (default = -5; no filtering)")
+    p.add_argument("-d", dest="filter_dups", action="store_true", default=False, help="filter duplicate reads")
+    p.add_argument("-u", dest="max_unknown", type=int, default=100, help="max percent of unknown bases per read (default = 100)")
+    p.add_argument("-g", dest="device", type=int, default=0, help="GPU index (default = 0)")
+    args = vars(p.parse_args(argv))
+    args["seqfiles"] = args["seqfiles"].split(",")
+    return args
+
+
+if __name__ == "__main__":
+    args = parse_arguments()
+    est_ags, args = microbe_census.run_pipeline(args)
+    count_bases = microbe_census.count_bases(args) if not args["no_equivs"] else None
+    microbe_census.report_results(args, est_ags, count_bases)

@@ -51,6 +51,14 @@ int main(int argc, char **argv)
     McHostIndex H; std::string err;
     if (!mc_build_index(H, np.data(), sp.data(), (int)mn.size(), err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
     fprintf(stderr, "index: %d seqs %ld residues %zu postings thr %u\n", H.nseq, (long)H.nres, H.post.size(), H.freq_thr);
+    if (getenv("MC_DUMP_INDEX")) {   // raw arrays for tests/test_index.py: bstart, post, keys, codes, thr, letter_p
+        FILE *d = fopen(getenv("MC_DUMP_INDEX"), "wb");
+        uint64_t np_ = H.post.size(), nr_ = H.res_code.size();
+        fwrite(&np_, 8, 1, d); fwrite(&nr_, 8, 1, d);
+        fwrite(H.bstart.data(), 4, H.bstart.size(), d); fwrite(H.post.data(), 4, np_, d); fwrite(H.keys.data(), 2, np_, d); fwrite(H.res_code.data(), 1, nr_, d);
+        fwrite(&H.freq_thr, 4, 1, d); fwrite(H.letter_p, 8, 10, d);
+        fclose(d);
+    }
     int read_len = rs.empty() ? 0 : (int)rs[0].size();
     static McTables T;
     mc_fill_tables(T, H, read_len, getenv("MC_LOGE_THR") ? atof(getenv("MC_LOGE_THR")) : 1.0);

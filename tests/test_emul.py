@@ -1,0 +1,96 @@
+"""CPU checks of the code the GPU runs: the per-thread device functions (microbecensus_amd/csrc/mc_core.h,
+mc_finish.h) and the host index builder (mc_index.h) are compiled with g++ into tests/emul/mc_emul and run
+stage by stage.  The emulation is test infrastructure; the product only ever executes the HIP build."""
+import gzip
+import hashlib
+import json
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+GOLD = os.path.join(HERE, "golden")
+
+
+@pytest.fixture(scope="session")
+def emul_bin(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("emul") / "mc_emul")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(HERE, "emul", "mc_emul.cpp")])
+    return exe
+
+
+@pytest.fixture(scope="session")
+def markers_faa(tmp_path_factory):
+    p = str(tmp_path_factory.mktemp("db") / "markers.faa")
+    with gzip.open(os.path.join(REPO, "microbecensus_amd", "data", "markers.faa.gz"), "rb") as f, open(p, "wb") as o:
+        o.write(f.read())
+    return p
+
+
+def test_device_code_reproduces_reference_m8(emul_bin, markers_faa, tmp_path):
+    """config 1 (example.fq.gz -n 10000 -l 100): same m8 bytes as the reference's RAPsearch2 run."""
+    meta = json.load(open(os.path.join(GOLD, "config1_example_fq.json")))
+    fa = tmp_path / "reads.fa"
+    fa.write_bytes(gzip.open(os.path.join(GOLD, "config1_example_fq.reads.fa.gz"), "rb").read())
+    out = tmp_path / "out.m8"
+    subprocess.check_call([emul_bin, markers_faa, str(fa), str(out)], stderr=subprocess.DEVNULL)
+    assert hashlib.md5(out.read_bytes()).hexdigest() == meta["m8_md5"]
+
+
+def test_index_builder_matches_prerapsearch(emul_bin, markers_faa, ref_dir, tmp_path):
+    """Bucket starts, posting order, suffix keys, residue codes, frequency threshold and letter frequencies of
+    the product's index builder against the database prerapsearch wrote (oracle/_ref/rapdb_2.15[.info])."""
+    fa = tmp_path / "one.fa"
+    fa.write_text(">0\n" + "ACGT" * 25 + "\n")
+    dump = tmp_path / "index.bin"
+    env = dict(os.environ, MC_DUMP_INDEX=str(dump))
+    subprocess.check_call([emul_bin, markers_faa, str(fa), str(tmp_path / "o.m8")], env=env, stderr=subprocess.DEVNULL)
+    b = dump.read_bytes()
+    npost, nres = struct.unpack_from("<QQ", b, 0)
+    p = 16
+    bstart = np.frombuffer(b, "<u4", 1000001, p); p += 4 * 1000001
+    post = np.frombuffer(b, "<u4", npost, p); p += 4 * npost
+    keys = np.frombuffer(b, "<u2", npost, p); p += 2 * npost
+    codes = np.frombuffer(b, "u1", nres, p); p += nres
+    thr = struct.unpack_from("<I", b, p)[0]; p += 4
+    letter_p = np.frombuffer(b, "<f8", 10, p)
+    # parse the boost archive prerapsearch wrote
+    r = open(os.path.join(ref_dir, "rapdb_2.15"), "rb").read()
+    q = 0x28
+    n = struct.unpack_from("<Q", r, q)[0]; q += 8
+    ref_codes = np.frombuffer(r, "u1", n, q); q += n
+    m = struct.unpack_from("<Q", r, q)[0]; q += 8 + 4 * m
+    q += 5 + 8 + 4
+    ref_start = np.zeros(1000001, dtype=np.int64)
+    chunks = []
+    for i in range(1000000):
+        c = struct.unpack_from("<Q", r, q)[0]; q += 8
+        if c:
+            chunks.append(np.frombuffer(r, "<u4", c, q))
+        q += 4 * c
+        ref_start[i + 1] = ref_start[i] + c
+    ref_post = np.concatenate(chunks)
+    q += 5
+    nn = struct.unpack_from("<Q", r, q)[0]; q += 8 + 4
+    for _ in range(nn):
+        l = struct.unpack_from("<Q", r, q)[0]; q += 8 + l
+    q += 5 + 8 + 4
+    kch = []
+    for i in range(1000000):
+        c = struct.unpack_from("<Q", r, q)[0]; q += 8
+        if c:
+            kch.append(np.frombuffer(r, "<u2", c, q))
+        q += 2 * c
+    ref_keys = np.concatenate(kch)
+    assert nres == n and np.array_equal(codes, ref_codes)
+    assert np.array_equal(bstart.astype(np.int64), ref_start)
+    assert np.array_equal(post, ref_post)
+    assert np.array_equal(keys, ref_keys)
+    info = open(os.path.join(ref_dir, "rapdb_2.15.info"), "rb").read()
+    assert thr == struct.unpack_from("<I", info, 68 + 4000000)[0]
+    ref_p = np.frombuffer(info, "<f8", 10, 68 + 4000000 + 4 + 8)
+    assert np.allclose(letter_p, ref_p, rtol=0, atol=1e-6)
