@@ -262,6 +262,113 @@ MC_HDN void mc_seg_mask(const McTables &T, const uint8_t *prot, int n, uint8_t *
 }
 
 // ---------------------------------------------------------------------------------------------
+// SEG, workspace version used by the kernel: identical results to mc_seg_mask, but
+//   * the per-window entropies are reduced to the two facts SEG ever uses (H <= 2.2, H <= 2.5), kept as bit sets;
+//   * the sorted state vector is maintained incrementally (Seg::decrementsv/incrementsv@0x438d30/0x438d70)
+//     instead of being re-sorted for every window;
+//   * all arrays live in a caller-provided workspace (LDS on the device): comp[20], sv[24], stack[16] (int16 pairs).
+// ---------------------------------------------------------------------------------------------
+struct McSegWS { uint8_t *comp; uint8_t *sv; int16_t *stk; };   // 20 B, 24 B, 32 B
+
+MC_HD void mc_sv_dec(uint8_t *sv, int x)
+{ // a class with count x loses one member: the LAST entry equal to x becomes x-1 (keeps the vector sorted)
+    int i = 0;
+    while (sv[i] != 0 && sv[i] != x) i++;
+    while (sv[i + 1] == x) i++;
+    sv[i] = (uint8_t)(x - 1);
+}
+MC_HD void mc_sv_inc(uint8_t *sv, int x)
+{ // a class with count x (possibly 0 = new class) gains one member: the FIRST entry equal to x becomes x+1
+    int i = 0;
+    while (sv[i] != x) i++;
+    sv[i] = (uint8_t)(x + 1);
+    if (x == 0) sv[i + 1] = 0;
+}
+MC_HD void mc_seg_shift(uint8_t *comp, uint8_t *sv, int out, int in)
+{ // Seg::shiftwin1@0x43af30
+    if (out < 20) { mc_sv_dec(sv, comp[out]); comp[out]--; }
+    if (in < 20) { mc_sv_inc(sv, comp[in]); comp[in]++; }
+}
+MC_HD void mc_seg_trim_ws(const McTables &T, const uint8_t *s, int n, int *leftend, int *rightend, const McSegWS &ws)
+{
+    int lend = 0, rend = n - 1, minlen = 1;
+    double minprob = 1.0;
+    if (n - 100 > minlen) minlen = n - 100;
+    for (int len = n; len > minlen; len--) {
+        mc_seg_comp(s, len, ws.comp);
+        mc_seg_state(ws.comp, ws.sv);
+        for (int i = 0;; i++) {
+            double prob = mc_seg_getprob(T, ws.sv, len);
+            if (prob < minprob) { minprob = prob; lend = i; rend = len + i - 1; }
+            if (i + 1 + len > n) break;
+            mc_seg_shift(ws.comp, ws.sv, s[i], s[i + len]);
+        }
+    }
+    *leftend = *leftend + lend;
+    *rightend = *rightend - (n - rend - 1);
+}
+struct McBits192 { uint64_t a, b, c; };   // bit set over <= 192 positions kept in registers (no dynamic indexing)
+MC_HD void mc_bits_clear(McBits192 &x) { x.a = 0; x.b = 0; x.c = 0; }
+MC_HD void mc_bits_set(McBits192 &x, int i) { uint64_t m = 1ull << (i & 63); if (i < 64) x.a |= m; else if (i < 128) x.b |= m; else x.c |= m; }
+MC_HD bool mc_bits_test(const McBits192 &x, int i) { uint64_t w = (i < 64) ? x.a : (i < 128) ? x.b : x.c; return (w >> (i & 63)) & 1; }
+
+MC_HDN void mc_seg_mask_ws(const McTables &T, uint8_t *prot, int n, const McSegWS &ws)
+{ // masks prot in place (masked residues become MC_INV) - only AFTER all ranges were analysed on the original residues
+    int W = (n <= 11) ? 8 : 12;
+    McBits192 lo, hi, mk;
+    mc_bits_clear(mk);
+    if (W > n) return;
+    int sp = 1;
+    ws.stk[0] = 0; ws.stk[1] = (int16_t)n;
+    bool any = false;
+    while (sp > 0) {
+        sp--;
+        int base = ws.stk[2 * sp], m = ws.stk[2 * sp + 1];
+        const uint8_t *s = prot + base;
+        if (W > m) continue;
+        mc_bits_clear(lo); mc_bits_clear(hi);
+        {
+            int start = 0;
+            bool anylo = false;
+            mc_seg_comp(s, W, ws.comp);
+            mc_seg_state(ws.comp, ws.sv);
+            double ent = mc_seg_entropy(T, W, ws.sv);
+            for (int i = 0; i <= m - 1; i++) {
+                if (ent <= 2.2) { mc_bits_set(lo, i); anylo = true; }
+                if (ent <= 2.5) mc_bits_set(hi, i);
+                if (start + 1 + W <= m) {
+                    mc_seg_shift(ws.comp, ws.sv, s[start], s[start + W]);
+                    start++;
+                    ent = mc_seg_entropy(T, W, ws.sv);
+                }
+            }
+            if (!anylo) continue;
+        }
+        int last = m - 1, lowlim = 0;
+        for (int i = 0; i <= last; i++) {
+            if (mc_bits_test(lo, i)) {
+                int j, loi, hii, leftend, rightend;
+                for (j = i; j >= lowlim; j--) { if (!mc_bits_test(hi, j)) break; }
+                loi = j + 1;
+                for (j = i; j <= last; j++) { if (!mc_bits_test(hi, j)) break; }
+                hii = j - 1;
+                leftend = loi; rightend = hii;
+                mc_seg_trim_ws(T, s + leftend, rightend - leftend + 1, &leftend, &rightend, ws);
+                if (i < leftend) {
+                    int lend = loi, rend = leftend - 1;
+                    if (sp < 8) { ws.stk[2 * sp] = (int16_t)(base + lend); ws.stk[2 * sp + 1] = (int16_t)(rend - lend + 1); sp++; }
+                }
+                for (j = leftend; j <= rightend; j++) mc_bits_set(mk, base + j);
+                any = true;
+                i = (hii < rightend) ? hii : rightend;
+                lowlim = i + 1;
+            }
+        }
+    }
+    if (any) for (int i = 0; i < n; i++) if (mc_bits_test(mk, i)) prot[i] = MC_INV;
+}
+
+// ---------------------------------------------------------------------------------------------
 // suffix keys (ExtendSeq2Set 0x413bd2-0x414aa1)
 // ---------------------------------------------------------------------------------------------
 MC_HD int mc_klen(uint32_t k)

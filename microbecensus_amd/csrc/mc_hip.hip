@@ -41,21 +41,42 @@ enum { S_LOOKUPS = 0, S_KEYPROBES, S_N = 4 };   // 64-bit algorithmic-traffic co
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
+// One thread per (read, frame); a block of 256 threads owns 42 consecutive reads (252 frames).  The reads are staged
+// into LDS with coalesced 16-byte loads, every thread translates its frame into its own LDS row, runs SEG there
+// (composition / state vector / work list in LDS, the window flags in registers) and the block writes the frames back
+// with coalesced stores.  LDS per block: 42*L + 256*(FP+76) bytes (~40 KB at 150 bp).
+#define MC_TS_READS 42
 __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restrict__ T, const uint8_t *__restrict__ reads, int L,
                                                        int64_t nreads, uint8_t *__restrict__ frames, int FP)
 {
-    int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= nreads * 6) return;
-    int64_t r = tid / 6;
-    int f = (int)(tid - r * 6);
-    uint8_t prot[MC_MAXAA + 2];
-    uint8_t mask[(MC_MAXAA + 7) / 8];
-    double H[MC_MAXAA + 2];
-    int n = mc_translate_frame(*T, reads + r * L, L, f, prot);
-    mc_seg_mask(*T, prot, n, mask, H);
-    uint8_t *out = frames + (r * 6 + f) * FP;
-    for (int i = 0; i < n; i++) out[i] = (mask[i >> 3] & (1 << (i & 7))) ? (uint8_t)MC_INV : prot[i];
-    for (int i = n; i < FP; i++) out[i] = MC_INV;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * MC_TS_READS;
+    const int nr = (int)((nreads - r0) < MC_TS_READS ? (nreads - r0) : MC_TS_READS);
+    const int rbytes = nr * L;
+    const int stride = (FP + 76 + 3) & ~3;                       // per-thread LDS row: prot[FP] comp[20] sv[24] stk[32]
+    uint8_t *sreads = smem;
+    uint8_t *rows = smem + (((MC_TS_READS * L) + 15) & ~15);
+    {   // coalesced staging of this block's reads (the block's slice starts at r0*L, not necessarily 16-byte aligned)
+        const uint8_t *src = reads + r0 * L;
+        for (int i = tid; i < rbytes; i += 256) sreads[i] = src[i];
+    }
+    __syncthreads();
+    const int lr = tid / 6, f = tid - lr * 6;
+    uint8_t *prot = rows + (size_t)tid * stride;
+    int n = 0;
+    if (lr < nr) {
+        n = mc_translate_frame(*T, sreads + lr * L, L, f, prot);
+        McSegWS ws; ws.comp = prot + FP; ws.sv = prot + FP + 20; ws.stk = (int16_t *)(prot + FP + 44);
+        mc_seg_mask_ws(*T, prot, n, ws);
+        for (int i = n; i < FP; i++) prot[i] = MC_INV;
+    }
+    __syncthreads();
+    {   // frames of the block are contiguous in global memory: nr*6 rows of FP bytes
+        uint8_t *dst = frames + r0 * 6 * FP;
+        const int total = nr * 6 * FP;
+        for (int i = tid; i < total; i += 256) { int row = i / FP, col = i - row * FP; dst[i] = rows[(size_t)row * stride + col]; }
+    }
 }
 
 struct DevEmit {
@@ -389,8 +410,10 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
     HIPCK(hipMemsetAsync(h->d_stats, 0, sizeof(unsigned long long) * S_N, st));
     HIPCK(hipEventRecord(h->ev[0], st));
     {
-        int64_t threads = n * 6;
-        k_translate_seg<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, d_reads, L, n, h->d_frames, FP);
+        const int64_t threads = n * 6;
+        size_t lds = (size_t)(((MC_TS_READS * L) + 15) & ~15) + (size_t)256 * ((FP + 76 + 3) & ~3);
+        if (lds > 48 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_translate_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_translate_seg<<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(256), lds, st>>>(h->d_T, d_reads, L, n, h->d_frames, FP);
         HIPCK(hipEventRecord(h->ev[1], st));
         k_enumerate<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, X, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, h->d_counters, h->d_stats);
         HIPCK(hipEventRecord(h->ev[2], st));

@@ -75,9 +75,15 @@ int main(int argc, char **argv)
             uint8_t *p = &frames[(r * 6 + f) * FP];
             if ((int)rs[r].size() != read_len) { fprintf(stderr, "reads must all have the same length\n"); return 1; }
             int n = mc_translate_frame(T, (const uint8_t *)rs[r].data(), read_len, f, p);
-            uint8_t mask[(MC_MAXAA + 7) / 8]; double Hbuf[MC_MAXAA + 2];
-            mc_seg_mask(T, p, n, mask, Hbuf);
-            for (int i = 0; i < n; i++) if (mask[i >> 3] & (1 << (i & 7))) p[i] = MC_INV;
+            if (getenv("MC_SEG_PLAIN")) {
+                uint8_t mask[(MC_MAXAA + 7) / 8]; double Hbuf[MC_MAXAA + 2];
+                mc_seg_mask(T, p, n, mask, Hbuf);
+                for (int i = 0; i < n; i++) if (mask[i >> 3] & (1 << (i & 7))) p[i] = MC_INV;
+            } else {   // the workspace variant the kernel uses
+                uint8_t comp[20], sv[24]; int16_t stk[16];
+                McSegWS ws{comp, sv, stk};
+                mc_seg_mask_ws(T, p, n, ws);
+            }
             flen[r * 6 + f] = n;
         }
     // stage 2: seed enumeration
