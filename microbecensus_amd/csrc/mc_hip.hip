@@ -109,6 +109,217 @@ __global__ void __launch_bounds__(256) k_enumerate(const McTables *__restrict__ 
     if (stats) { atomicAdd(&stats[S_LOOKUPS], (unsigned long long)sc.lookups); atomicAdd(&stats[S_KEYPROBES], (unsigned long long)sc.keyprobes); }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_enumerate_t0: position-parallel seed probing for databases whose .info frequency threshold is 0 (the marker DB).
+//
+// With threshold 0 the seed-length carry of Searching@0x415050 collapses (mc_enumerate_seeds documents the general
+// rule): a position whose own bucket is non-empty always uses a 9-mer (or is skipped), and only positions with an
+// EMPTY bucket look at `prev` - to decide from where the 10-mer validity check of the neighbourhood starts.  `prev`
+// is 9 if the nearest earlier non-skipped position with a non-empty bucket found a matching 9-mer range, else 6.
+// So the frame is handled in two parallel phases: (1) exact 9-mer probes of all positions, recording which positions
+// define `prev` and which of them hit; (2) the 36 neighbourhood probes of every position.
+//
+// One wave per read.  The 10^6-bit bucket-occupancy bitmap (125 KB) is staged in LDS once per workgroup: three out of
+// four neighbour buckets are empty and never touch memory.  Probes that survive the bitmap are compacted through a
+// per-wave LDS queue so that all 64 lanes take part in the gathers (bucket bounds, binary search over the suffix keys).
+// Seed hits are appended with one atomic per wave.
+// ------------------------------------------------------------------------------------------------
+#define MC_EN_WAVES 8
+#define MC_EN_QCAP 128
+struct McEnWave { uint32_t setter[6][6]; uint32_t hit[6][6]; unsigned long long q[MC_EN_QCAP]; };
+
+__device__ __forceinline__ int mc_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// item: bucket(20) | qk(16)<<20 | pos(8)<<36 | frame(3)<<44 | phase(6)<<47
+__device__ __forceinline__ void mc_en_process(const McIndex &X, unsigned long long item, bool active, uint32_t read, McEnWave *W,
+                                              McSeedTask *tasks, uint32_t cap, uint32_t *counters, McSeedCount &sc, int lane)
+{
+    int cnt = 0, nst = 0;
+    int bucket = (int)(item & 0xFFFFF), pos = (int)((item >> 36) & 0xFF), frame = (int)((item >> 44) & 7), phase = (int)((item >> 47) & 63);
+    uint32_t qk = (uint32_t)((item >> 20) & 0xFFFF);
+    if (active) {
+        cnt = mc_key_range(X, bucket, qk, &nst, &sc);
+        sc.lookups--;                                   // the probe itself was already counted when it was generated
+        if (phase == 0 && cnt > 0) atomicOr(&W->hit[frame][pos >> 5], 1u << (pos & 31));
+    }
+    // wave-aggregated append
+    int incl = cnt;
+    for (int d = 1; d < 64; d <<= 1) { int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+    int total = __shfl(incl, 63);
+    if (total == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&counters[C_TASKS], (uint32_t)total);
+    base = __shfl(base, 0);
+    if (base + (uint32_t)total > cap) { if (lane == 0) counters[C_OVERFLOW] = 1; return; }
+    if (cnt > 0) {
+        uint32_t o = base + (uint32_t)(incl - cnt), b0 = X.bstart[bucket];
+        int seedlen = phase == 0 ? 9 : 10, nkey = phase == 0 ? 3 : 4;
+        for (int i = 0; i < cnt; i++) {
+            McSeedTask t;
+            t.read = read; t.chrono = MC_CHRONO(frame, pos, phase, nst + i); t.posting = X.post[b0 + nst + i];
+            t.seedlen_nkey = (uint32_t)seedlen | ((uint32_t)nkey << 8);
+            tasks[o + i] = t;
+        }
+    }
+}
+
+#define MC_EN_PUSH(pred, item)                                                                                   \
+    do {                                                                                                         \
+        unsigned long long m_ = __ballot(pred);                                                                  \
+        if (m_) {                                                                                                \
+            int off_ = __popcll(m_ & ((1ull << lane) - 1));                                                      \
+            if (pred) W->q[qn + off_] = (item);                                                                  \
+            qn += __popcll(m_);                                                                                  \
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();              \
+            if (qn >= 64) {                                                                                      \
+                unsigned long long it_ = W->q[qn - 64 + lane];                                                   \
+                qn -= 64;                                                                                        \
+                mc_en_process(X, it_, true, (uint32_t)r, W, tasks, cap, counters, sc, lane);                     \
+                __builtin_amdgcn_wave_barrier();                                                                 \
+            }                                                                                                    \
+        }                                                                                                        \
+    } while (0)
+
+#define MC_EN_DRAIN()                                                                                            \
+    do {                                                                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();                  \
+        if (qn > 0) {                                                                                            \
+            unsigned long long it_ = (lane < qn) ? W->q[lane] : 0ull;                                            \
+            mc_en_process(X, it_, lane < qn, (uint32_t)r, W, tasks, cap, counters, sc, lane);                    \
+            qn = 0;                                                                                              \
+        }                                                                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();                  \
+    } while (0)
+
+__global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTables *__restrict__ T, McIndex X, const uint32_t *__restrict__ bitmap,
+                                                                   const uint8_t *__restrict__ frames, int FP, int L, int64_t nreads, McSeedTask *tasks,
+                                                                   uint32_t cap, uint32_t *counters, unsigned long long *stats)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *bm = (uint32_t *)smem;                                        // 31,250 words
+    uint8_t *grp = smem + 125000;                                           // 32-byte group table
+    McEnWave *waves = (McEnWave *)(smem + 125040);
+    uint8_t *fr_all = (uint8_t *)(waves + MC_EN_WAVES);
+    const int lane = mc_lane(), wv = threadIdx.x >> 6;
+    McEnWave *W = waves + wv;
+    const int FPs = (FP + 15) & ~15;
+    uint8_t *fr = fr_all + (size_t)wv * 6 * FPs;
+    for (int i = threadIdx.x; i < (MC_NBUCKET + 31) / 32; i += blockDim.x) bm[i] = bitmap[i];
+    if (threadIdx.x < 32) grp[threadIdx.x] = T->grp[threadIdx.x];
+    __syncthreads();
+    McSeedCount sc; sc.lookups = 0; sc.keyprobes = 0;
+    const int64_t nw = (int64_t)gridDim.x * MC_EN_WAVES;
+    for (int64_t r = (int64_t)blockIdx.x * MC_EN_WAVES + wv; r < nreads; r += nw) {
+        int qn = 0;
+        {   // stage the six frames of this read (rows of FP bytes) into the wave's LDS area, clear the flags
+            const uint8_t *src = frames + r * 6 * FP;
+            for (int f = 0; f < 6; f++) for (int i = lane; i < FP; i += 64) fr[f * FPs + i] = src[f * FP + i];
+            if (lane < 36) { ((uint32_t *)W->setter)[lane] = 0; ((uint32_t *)W->hit)[lane] = 0; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        }
+        // ---- phase 1: exact 9-mers
+        for (int f = 0; f < 6; f++) {
+            const int qlen = (L - f % 3) / 3;
+            const uint8_t *q = fr + f * FPs;
+            for (int p0 = 0; p0 + 6 < qlen; p0 += 64) {
+                int pos = p0 + lane;
+                bool push = false;
+                unsigned long long item = 0;
+                if (pos + 6 < qlen) {
+                    int seed = 0; bool bad = false;
+                    for (int k = 0; k < 6; k++) { int g = grp[q[pos + k]]; bad |= (g == MC_INVGRP); seed = seed * 10 + g; }
+                    if (!bad) {
+                        sc.lookups++;                                   // bucket-size probe of the exact seed
+                        bool nonempty = (bm[seed >> 5] >> (seed & 31)) & 1;
+                        int rest = qlen - pos - 6;
+                        if (nonempty && rest >= 3) {
+                            int g6 = grp[q[pos + 6]], g7 = grp[q[pos + 7]], g8 = grp[q[pos + 8]];
+                            if (g6 != MC_INVGRP && g7 != MC_INVGRP) {
+                                atomicOr(&W->setter[f][pos >> 5], 1u << (pos & 31));
+                                uint32_t qk = ((uint32_t)g6 << 12) | ((uint32_t)g7 << 8) | ((uint32_t)g8 << 4) | 0xFu;
+                                sc.lookups++;                           // the key-range probe (counted as in the sequential kernel)
+                                item = (unsigned long long)seed | ((unsigned long long)qk << 20) | ((unsigned long long)pos << 36) | ((unsigned long long)f << 44);
+                                push = true;
+                            }
+                        }
+                    }
+                }
+                MC_EN_PUSH(push, item);
+            }
+        }
+        MC_EN_DRAIN();
+        // ---- phase 2: one-substitution 10-mers (offsets 3,4,5: neighbour buckets; offset 6: same bucket, other key)
+        for (int f = 0; f < 6; f++) {
+            const int qlen = (L - f % 3) / 3;
+            const uint8_t *q = fr + f * FPs;
+            for (int p0 = 0; p0 + 6 < qlen; p0 += 64) {
+                int pos = p0 + lane;
+                bool live = false;
+                int seed = 0;
+                uint32_t qk = 0;
+                int g6 = 0;
+                if (pos + 6 < qlen && pos + 10 <= qlen) {
+                    bool bad = false;
+                    for (int k = 0; k < 6; k++) { int g = grp[q[pos + k]]; bad |= (g == MC_INVGRP); seed = seed * 10 + g; }
+                    if (!bad) {
+                        bool nonempty = (bm[seed >> 5] >> (seed & 31)) & 1;
+                        g6 = grp[q[pos + 6]];
+                        int g7 = grp[q[pos + 7]], g8 = grp[q[pos + 8]], g9 = grp[q[pos + 9]];
+                        int used;
+                        bool skip = false;
+                        if (nonempty) { used = 9; skip = (g6 == MC_INVGRP || g7 == MC_INVGRP); }   // rest >= 4 here
+                        else {
+                            // prev: nearest earlier position of this frame that probed an exact seed
+                            int prev = 6;
+                            int w = pos >> 5;
+                            uint32_t m = W->setter[f][w] & ((1u << (pos & 31)) - 1);
+                            while (m == 0 && w > 0) { w--; m = W->setter[f][w]; }
+                            if (m) { int b = 31 - __builtin_clz(m); if ((W->hit[f][w] >> b) & 1) prev = 9; }
+                            used = (6 >= prev - 1) ? 6 : prev - 1;
+                        }
+                        if (!skip) {
+                            bool ok = (g9 != MC_INVGRP);
+                            if (used <= 8) ok = ok && (g8 != MC_INVGRP);
+                            if (used <= 7) ok = ok && (g7 != MC_INVGRP);
+                            if (used <= 6) ok = ok && (g6 != MC_INVGRP);
+                            live = ok;
+                            qk = ((uint32_t)g6 << 12) | ((uint32_t)g7 << 8) | ((uint32_t)g8 << 4) | (uint32_t)g9;
+                        }
+                    }
+                }
+                if (__ballot(live) == 0) continue;
+                const int strides[3] = {10, 1, 100};
+                for (int m = 0; m < 3; m++) {
+                    int st = strides[m], start = seed - ((seed / st) % 10) * st;
+                    for (int j = 0; j < 10; j++) {
+                        int v = start + j * st;
+                        bool pr = live && v != seed;
+                        if (pr) { sc.lookups++; pr = (bm[v >> 5] >> (v & 31)) & 1; }
+                        unsigned long long item = (unsigned long long)v | ((unsigned long long)qk << 20) | ((unsigned long long)pos << 36) |
+                                                  ((unsigned long long)f << 44) | ((unsigned long long)(1 + m * 10 + j) << 47);
+                        MC_EN_PUSH(pr, item);
+                    }
+                }
+                bool selfbucket = live && ((bm[seed >> 5] >> (seed & 31)) & 1);
+                for (int k = 0; k < 10; k++) {
+                    bool pr = live && k != g6;
+                    if (pr) { sc.lookups++; pr = selfbucket; }
+                    uint32_t qk2 = (qk & 0x0FFFu) | ((uint32_t)k << 12);
+                    unsigned long long item = (unsigned long long)seed | ((unsigned long long)qk2 << 20) | ((unsigned long long)pos << 36) |
+                                              ((unsigned long long)f << 44) | ((unsigned long long)(31 + k) << 47);
+                    MC_EN_PUSH(pr, item);
+                }
+            }
+        }
+        MC_EN_DRAIN();
+    }
+    if (stats) {
+        unsigned long long a = sc.lookups, b = sc.keyprobes;
+        for (int d = 32; d > 0; d >>= 1) { a += __shfl_down(a, d); b += __shfl_down(b, d); }
+        if (lane == 0) { atomicAdd(&stats[S_LOOKUPS], a); atomicAdd(&stats[S_KEYPROBES], b); }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_eval_seeds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
                                                     const McSeedTask *__restrict__ tasks, uint32_t ntasks, McHsp *hsps, uint32_t cap_hsps,
                                                     McGapTask *gaps, uint32_t cap_gaps, uint32_t *counters)
@@ -237,6 +448,8 @@ struct mc_handle {
     uint8_t *d_reads = nullptr, *d_frames = nullptr;
     const uint8_t *reads_dev = nullptr;   // resident read set (own buffer or attached caller memory)
     unsigned long long *d_stats = nullptr;
+    uint32_t *d_bitmap = nullptr;
+    bool fast_enum = false;
     McSeedTask *d_tasks = nullptr; McGapTask *d_gaps = nullptr; McHsp *d_hsps = nullptr, *d_sorted = nullptr, *d_v = nullptr, *d_tmp = nullptr;
     uint32_t cap_tasks = 0, cap_gaps = 0, cap_hsps = 0, cap_rows = 0;
     uint64_t *d_k64 = nullptr, *d_k64o = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
@@ -274,7 +487,7 @@ extern "C" void mc_close(mc_handle *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_frames, h->d_tasks, h->d_gaps, h->d_hsps,
                     h->d_sorted, h->d_v, h->d_tmp, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, h->d_heads, h->d_sorttmp, h->d_counters, h->d_rows, h->d_rowscratch,
-                    h->d_kscratch, h->d_seginfo, h->d_best, h->d_gH, h->d_gD, h->d_gPH, h->d_gPD, h->d_stats};
+                    h->d_kscratch, h->d_seginfo, h->d_best, h->d_gH, h->d_gD, h->d_gPH, h->d_gPD, h->d_stats, h->d_bitmap};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -304,6 +517,11 @@ static int open_impl(mc_handle *h, const char *const *names, const char *const *
     HIPCK(hipMemcpy(h->d_post, H.post.data(), H.post.size() * 4, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_keys, H.keys.data(), H.keys.size() * 2, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_fam, h->fam.data(), (size_t)nseq * 4, hipMemcpyHostToDevice));
+    if (dalloc(&h->d_bitmap, H.bitmap.size())) return -1;
+    HIPCK(hipMemcpy(h->d_bitmap, H.bitmap.data(), H.bitmap.size() * 4, hipMemcpyHostToDevice));
+    // the position-parallel seed kernel is exact only when the frequency threshold is 0 and no letter frequency is 0
+    h->fast_enum = (H.freq_thr == 0) && !getenv("MC_FORCE_SEQUENTIAL_ENUM");
+    for (int g = 0; g < 10; g++) if (!(H.letter_p[g] > 0.0)) h->fast_enum = false;
     return 0;
 }
 
@@ -415,7 +633,14 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         if (lds > 48 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_translate_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         k_translate_seg<<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(256), lds, st>>>(h->d_T, d_reads, L, n, h->d_frames, FP);
         HIPCK(hipEventRecord(h->ev[1], st));
-        k_enumerate<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, X, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, h->d_counters, h->d_stats);
+        if (h->fast_enum) {
+            const int FPs = (FP + 15) & ~15;
+            size_t lds2 = 125040 + sizeof(McEnWave) * MC_EN_WAVES + (size_t)MC_EN_WAVES * 6 * FPs;
+            HIPCK(hipFuncSetAttribute((const void *)k_enumerate_t0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            int blocks = (int)std::min<int64_t>(256, (n + MC_EN_WAVES - 1) / MC_EN_WAVES);
+            k_enumerate_t0<<<dim3(blocks), dim3(64 * MC_EN_WAVES), lds2, st>>>(h->d_T, X, h->d_bitmap, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, h->d_counters, h->d_stats);
+        } else
+            k_enumerate<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, X, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, h->d_counters, h->d_stats);
         HIPCK(hipEventRecord(h->ev[2], st));
     }
     HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
