@@ -21,6 +21,8 @@
 #else
 #define MC_HD inline
 #define MC_HDN inline
+struct uint4 { uint32_t x, y, z, w; };
+inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { uint4 v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -393,7 +395,7 @@ MC_HD bool mc_key_ub_less(uint32_t qk, uint32_t dbk)
     if (a == b) return false;
     return a < b;
 }
-struct McSeedCount { uint32_t lookups, keyprobes; };   // bucket-bound reads (8 B each) and suffix-key reads (2 B each)
+struct McSeedCount { uint32_t lookups, keyprobes, tasks; };   // bucket-bound reads (8 B each) and suffix-key reads (2 B each)
 
 // range of bucket `seed` whose key matches qk on the common prefix; returns ned-nst (0 = nothing)
 MC_HD int mc_key_range(const McIndex &X, int seed, uint32_t qk, int *nst_out, McSeedCount *sc)
@@ -416,6 +418,49 @@ MC_HD int mc_key_range(const McIndex &X, int seed, uint32_t qk, int *nst_out, Mc
     while (len > 0) { int half = len >> 1; sc->keyprobes++; if (mc_key_ub_less(qk, keys[lo + half])) len = half; else { lo += half + 1; len -= half + 1; } }
     *nst_out = nst;
     return lo - nst;
+}
+// Same range as mc_key_range for short buckets, computed by scanning: most buckets hold a handful of postings (median
+// 3), so instead of two dependent binary searches the first 8 suffix keys are fetched with independent loads and the
+// bounds are obtained by counting.  Counting equals std::lower_bound / std::upper_bound because the bucket is partitioned
+// with respect to both comparators (it is sorted by CompDbObj: reduced residues, then remaining length - the same
+// prefix-then-length order the comparators use); tests/test_emul.py checks this exhaustively on the index.  Buckets
+// longer than 8 use the binary searches.  keyprobes counts the reads of the reference algorithm, not of the scan.
+MC_HD int mc_key_range_scan(const McIndex &X, int seed, uint32_t qk, int *nst_out, McSeedCount *sc)
+{
+    uint32_t b0 = X.bstart[seed], b1 = X.bstart[seed + 1];
+    int n = (int)(b1 - b0);
+    if (n > 8) return mc_key_range(X, seed, qk, nst_out, sc);
+    sc->lookups++;
+    if (n == 0) return 0;
+    const uint16_t *kp = X.keys + b0;
+    uint32_t k[8];
+    for (int i = 0; i < 8; i++) k[i] = kp[i];             // the key array is padded, reading past the bucket is harmless
+    const int lq = mc_klen(qk);
+    int lb = 0, ub = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t dk = k[i];
+        int ld = mc_klen(dk), m = ld < lq ? ld : lq;
+        int sh = (4 - m) * 4;
+        int a = (int)(dk >> sh), b = (int)(qk >> sh);
+        bool in = i < n;
+        bool less_db = (m != 0 && a != b) ? (a < b) : (ld < lq);            // mc_key_lb_less(dk, qk)
+        bool less_q = (m == 0) ? (lq < ld) : (a != b && b < a);               // mc_key_ub_less(qk, dk)
+        lb += (in && less_db);
+        ub += (in && !less_q);
+    }
+    uint32_t at_lb = 0;
+    for (int i = 0; i < 8; i++) if (i == lb) at_lb = k[i];
+    { int lo = 0, len = n; while (len > 0) { int half = len >> 1; sc->keyprobes++; if (lo + half < lb) { lo += half + 1; len -= half + 1; } else len = half; } }
+    if (lb == n) return 0;
+    {
+        int la = mc_klen(at_lb), m = lq < la ? lq : la;
+        if (m == 0) return 0;
+        int sh = (4 - m) * 4;
+        if ((at_lb >> sh) != (qk >> sh)) return 0;
+    }
+    { int lo = 0, len = n; while (len > 0) { int half = len >> 1; sc->keyprobes++; if (lo + half >= ub) len = half; else { lo += half + 1; len -= half + 1; } } }
+    *nst_out = lb;
+    return ub - lb;
 }
 MC_HD uint32_t mc_pack_key(const uint8_t *g, int nkey)
 {

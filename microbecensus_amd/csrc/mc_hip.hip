@@ -36,7 +36,7 @@ extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
     } while (0)
 
 enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_N = 8 };
-enum { S_LOOKUPS = 0, S_KEYPROBES, S_N = 4 };   // 64-bit algorithmic-traffic counters of k_enumerate
+enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_N = 4 };   // 64-bit algorithmic-traffic counters of k_enumerate
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -80,9 +80,10 @@ __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restric
 }
 
 struct DevEmit {
-    McSeedTask *tasks; uint32_t *counters; uint32_t cap; uint32_t read; int frame; const McIndex *X;
+    McSeedTask *tasks; uint32_t *counters; uint32_t cap; uint32_t read; int frame; const McIndex *X; uint32_t emitted;
     __device__ void operator()(int bucket, int nst, int cnt, int seedlen, int nkey, int pos, int phase)
     {
+        emitted += (uint32_t)cnt;
         uint32_t base = atomicAdd(&counters[C_TASKS], (uint32_t)cnt);
         if (base + (uint32_t)cnt > cap) { counters[C_OVERFLOW] = 1; return; }
         uint32_t b0 = X->bstart[bucket];
@@ -103,10 +104,10 @@ __global__ void __launch_bounds__(256) k_enumerate(const McTables *__restrict__ 
     int64_t r = tid / 6;
     int f = (int)(tid - r * 6);
     int qlen = (L - f % 3) / 3;
-    DevEmit e{tasks, counters, cap, (uint32_t)r, f, &X};
-    McSeedCount sc; sc.lookups = 0; sc.keyprobes = 0;
+    DevEmit e{tasks, counters, cap, (uint32_t)r, f, &X, 0u};
+    McSeedCount sc; sc.lookups = 0; sc.keyprobes = 0; sc.tasks = 0;
     mc_enumerate_seeds(*T, X, frames + (r * 6 + f) * FP, qlen, e, &sc);
-    if (stats) { atomicAdd(&stats[S_LOOKUPS], (unsigned long long)sc.lookups); atomicAdd(&stats[S_KEYPROBES], (unsigned long long)sc.keyprobes); }
+    if (stats) { atomicAdd(&stats[S_LOOKUPS], (unsigned long long)sc.lookups); atomicAdd(&stats[S_KEYPROBES], (unsigned long long)sc.keyprobes); atomicAdd(&stats[S_TASKS], (unsigned long long)e.emitted); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -124,33 +125,52 @@ __global__ void __launch_bounds__(256) k_enumerate(const McTables *__restrict__ 
 // per-wave LDS queue so that all 64 lanes take part in the gathers (bucket bounds, binary search over the suffix keys).
 // Seed hits are appended with one atomic per wave.
 // ------------------------------------------------------------------------------------------------
-#define MC_EN_WAVES 8
 #define MC_EN_QCAP 128
-struct McEnWave { uint32_t setter[6][6]; uint32_t hit[6][6]; unsigned long long q[MC_EN_QCAP]; };
+#define MC_EN_BLK 512u                      // task slots a wave reserves at a time (one global atomic per block, not per append)
+#define MC_TASK_NONE 0xFFFFFFFFu            // read id of the padding entries that close a partly used block
+struct McEnWave { uint32_t setter[6][6]; uint32_t hit[6][6]; uint32_t blk_base, blk_used; unsigned long long q[MC_EN_QCAP]; };
 
 __device__ __forceinline__ int mc_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // item: bucket(20) | qk(16)<<20 | pos(8)<<36 | frame(3)<<44 | phase(6)<<47
-__device__ __forceinline__ void mc_en_process(const McIndex &X, unsigned long long item, bool active, uint32_t read, McEnWave *W,
-                                              McSeedTask *tasks, uint32_t cap, uint32_t *counters, McSeedCount &sc, int lane)
+__device__ __noinline__ void mc_en_process(const McIndex &X, unsigned long long item, bool active, uint32_t read, McEnWave *W,
+                                           McSeedTask *tasks, uint32_t cap, uint32_t *counters, McSeedCount &sc, int lane)
 {
     int cnt = 0, nst = 0;
     int bucket = (int)(item & 0xFFFFF), pos = (int)((item >> 36) & 0xFF), frame = (int)((item >> 44) & 7), phase = (int)((item >> 47) & 63);
     uint32_t qk = (uint32_t)((item >> 20) & 0xFFFF);
     if (active) {
-        cnt = mc_key_range(X, bucket, qk, &nst, &sc);
+        cnt = mc_key_range_scan(X, bucket, qk, &nst, &sc);
         sc.lookups--;                                   // the probe itself was already counted when it was generated
         if (phase == 0 && cnt > 0) atomicOr(&W->hit[frame][pos >> 5], 1u << (pos & 31));
     }
-    // wave-aggregated append
+    // wave-aggregated append into the wave's current block of the task pool
     int incl = cnt;
     for (int d = 1; d < 64; d <<= 1) { int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
-    int total = __shfl(incl, 63);
+    const uint32_t total = (uint32_t)__shfl(incl, 63);
     if (total == 0) return;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&counters[C_TASKS], (uint32_t)total);
-    base = __shfl(base, 0);
-    if (base + (uint32_t)total > cap) { if (lane == 0) counters[C_OVERFLOW] = 1; return; }
+    sc.tasks += (uint32_t)cnt;
+    uint32_t base;
+    if (total > MC_EN_BLK) {                     // rare: a long range, reserved directly
+        base = 0;
+        if (lane == 0) base = atomicAdd(&counters[C_TASKS], total);
+        base = __shfl(base, 0);
+        if (base + total > cap) { if (lane == 0) counters[C_OVERFLOW] = 1; return; }
+    } else {
+        uint32_t bb = W->blk_base, bu = W->blk_used;
+        __builtin_amdgcn_wave_barrier();
+        if (bu + total > MC_EN_BLK) {
+            for (uint32_t i = bu + lane; i < MC_EN_BLK; i += 64) tasks[bb + i].read = MC_TASK_NONE;
+            uint32_t nb = 0;
+            if (lane == 0) nb = atomicAdd(&counters[C_TASKS], MC_EN_BLK);
+            nb = __shfl(nb, 0);
+            if (nb + MC_EN_BLK > cap) { if (lane == 0) { counters[C_OVERFLOW] = 1; W->blk_used = MC_EN_BLK; } return; }
+            bb = nb; bu = 0;
+        }
+        base = bb + bu;
+        if (lane == 0) { W->blk_base = bb; W->blk_used = bu + total; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+    }
     if (cnt > 0) {
         uint32_t o = base + (uint32_t)(incl - cnt), b0 = X.bstart[bucket];
         int seedlen = phase == 0 ? 9 : 10, nkey = phase == 0 ? 3 : 4;
@@ -163,34 +183,7 @@ __device__ __forceinline__ void mc_en_process(const McIndex &X, unsigned long lo
     }
 }
 
-#define MC_EN_PUSH(pred, item)                                                                                   \
-    do {                                                                                                         \
-        unsigned long long m_ = __ballot(pred);                                                                  \
-        if (m_) {                                                                                                \
-            int off_ = __popcll(m_ & ((1ull << lane) - 1));                                                      \
-            if (pred) W->q[qn + off_] = (item);                                                                  \
-            qn += __popcll(m_);                                                                                  \
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();              \
-            if (qn >= 64) {                                                                                      \
-                unsigned long long it_ = W->q[qn - 64 + lane];                                                   \
-                qn -= 64;                                                                                        \
-                mc_en_process(X, it_, true, (uint32_t)r, W, tasks, cap, counters, sc, lane);                     \
-                __builtin_amdgcn_wave_barrier();                                                                 \
-            }                                                                                                    \
-        }                                                                                                        \
-    } while (0)
-
-#define MC_EN_DRAIN()                                                                                            \
-    do {                                                                                                         \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();                  \
-        if (qn > 0) {                                                                                            \
-            unsigned long long it_ = (lane < qn) ? W->q[lane] : 0ull;                                            \
-            mc_en_process(X, it_, lane < qn, (uint32_t)r, W, tasks, cap, counters, sc, lane);                    \
-            qn = 0;                                                                                              \
-        }                                                                                                        \
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();                  \
-    } while (0)
-
+template <int MC_EN_WAVES>
 __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTables *__restrict__ T, McIndex X, const uint32_t *__restrict__ bitmap,
                                                                    const uint8_t *__restrict__ frames, int FP, int L, int64_t nreads, McSeedTask *tasks,
                                                                    uint32_t cap, uint32_t *counters, unsigned long long *stats)
@@ -207,7 +200,8 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
     for (int i = threadIdx.x; i < (MC_NBUCKET + 31) / 32; i += blockDim.x) bm[i] = bitmap[i];
     if (threadIdx.x < 32) grp[threadIdx.x] = T->grp[threadIdx.x];
     __syncthreads();
-    McSeedCount sc; sc.lookups = 0; sc.keyprobes = 0;
+    if (lane == 0) { W->blk_base = 0; W->blk_used = MC_EN_BLK; }
+    McSeedCount sc; sc.lookups = 0; sc.keyprobes = 0; sc.tasks = 0;
     const int64_t nw = (int64_t)gridDim.x * MC_EN_WAVES;
     for (int64_t r = (int64_t)blockIdx.x * MC_EN_WAVES + wv; r < nreads; r += nw) {
         int qn = 0;
@@ -217,106 +211,114 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
             if (lane < 36) { ((uint32_t *)W->setter)[lane] = 0; ((uint32_t *)W->hit)[lane] = 0; }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
         }
-        // ---- phase 1: exact 9-mers
-        for (int f = 0; f < 6; f++) {
-            const int qlen = (L - f % 3) / 3;
-            const uint8_t *q = fr + f * FPs;
-            for (int p0 = 0; p0 + 6 < qlen; p0 += 64) {
-                int pos = p0 + lane;
-                bool push = false;
-                unsigned long long item = 0;
-                if (pos + 6 < qlen) {
-                    int seed = 0; bool bad = false;
-                    for (int k = 0; k < 6; k++) { int g = grp[q[pos + k]]; bad |= (g == MC_INVGRP); seed = seed * 10 + g; }
-                    if (!bad) {
-                        sc.lookups++;                                   // bucket-size probe of the exact seed
-                        bool nonempty = (bm[seed >> 5] >> (seed & 31)) & 1;
-                        int rest = qlen - pos - 6;
-                        if (nonempty && rest >= 3) {
-                            int g6 = grp[q[pos + 6]], g7 = grp[q[pos + 7]], g8 = grp[q[pos + 8]];
-                            if (g6 != MC_INVGRP && g7 != MC_INVGRP) {
-                                atomicOr(&W->setter[f][pos >> 5], 1u << (pos & 31));
-                                uint32_t qk = ((uint32_t)g6 << 12) | ((uint32_t)g7 << 8) | ((uint32_t)g8 << 4) | 0xFu;
-                                sc.lookups++;                           // the key-range probe (counted as in the sequential kernel)
-                                item = (unsigned long long)seed | ((unsigned long long)qk << 20) | ((unsigned long long)pos << 36) | ((unsigned long long)f << 44);
-                                push = true;
+        // pass 0: exact 9-mers (one probe per position).  pass 1: the one-substitution 10-mers of every position
+        // (probes 0..29: offsets 4, 5, 3 of the 6-mer = neighbour buckets; 30..39: offset 6 = same bucket, other key).
+        // One probe generator / one queue site for both passes keeps the kernel small enough for 16 waves per CU.
+        for (int pass = 0; pass < 2; pass++) {
+            for (int f = 0; f < 6; f++) {
+                const int qlen = (L - f % 3) / 3;
+                const uint8_t *q = fr + f * FPs;
+                for (int p0 = 0; p0 + 6 < qlen; p0 += 64) {
+                    const int pos = p0 + lane;
+                    bool live = false, selfbucket = false;
+                    int seed = 0, g6 = 0;
+                    uint32_t qk = 0;
+                    if (pos + 6 < qlen) {
+                        bool bad = false;
+                        for (int k = 0; k < 6; k++) { int g = grp[q[pos + k]]; bad |= (g == MC_INVGRP); seed = seed * 10 + g; }
+                        if (!bad) {
+                            selfbucket = (bm[seed >> 5] >> (seed & 31)) & 1;
+                            const int rest = qlen - pos - 6;
+                            g6 = rest >= 1 ? grp[q[pos + 6]] : MC_INVGRP;
+                            const int g7 = rest >= 2 ? grp[q[pos + 7]] : MC_INVGRP, g8 = rest >= 3 ? grp[q[pos + 8]] : MC_INVGRP;
+                            const int g9 = rest >= 4 ? grp[q[pos + 9]] : MC_INVGRP;
+                            if (pass == 0) {
+                                sc.lookups++;                                   // bucket-size probe of the exact seed
+                                if (selfbucket && rest >= 3 && g6 != MC_INVGRP && g7 != MC_INVGRP) {
+                                    atomicOr(&W->setter[f][pos >> 5], 1u << (pos & 31));
+                                    qk = ((uint32_t)g6 << 12) | ((uint32_t)g7 << 8) | ((uint32_t)g8 << 4) | 0xFu;
+                                    sc.lookups++;                               // its key-range probe
+                                    live = true;
+                                }
+                            } else if (rest >= 4) {
+                                int used = 9;
+                                bool skip = false;
+                                if (selfbucket) skip = (g6 == MC_INVGRP || g7 == MC_INVGRP);
+                                else {   // prev: did the nearest earlier position that probed an exact seed find a range?
+                                    int prev = 6, w = pos >> 5;
+                                    uint32_t m = W->setter[f][w] & ((1u << (pos & 31)) - 1);
+                                    while (m == 0 && w > 0) { w--; m = W->setter[f][w]; }
+                                    if (m) { int b = 31 - __builtin_clz(m); if ((W->hit[f][w] >> b) & 1) prev = 9; }
+                                    used = (6 >= prev - 1) ? 6 : prev - 1;
+                                }
+                                if (!skip) {
+                                    bool ok = (g9 != MC_INVGRP);
+                                    if (used <= 8) ok = ok && (g8 != MC_INVGRP);
+                                    if (used <= 7) ok = ok && (g7 != MC_INVGRP);
+                                    if (used <= 6) ok = ok && (g6 != MC_INVGRP);
+                                    live = ok;
+                                    qk = ((uint32_t)g6 << 12) | ((uint32_t)g7 << 8) | ((uint32_t)g8 << 4) | (uint32_t)g9;
+                                }
                             }
                         }
                     }
-                }
-                MC_EN_PUSH(push, item);
-            }
-        }
-        MC_EN_DRAIN();
-        // ---- phase 2: one-substitution 10-mers (offsets 3,4,5: neighbour buckets; offset 6: same bucket, other key)
-        for (int f = 0; f < 6; f++) {
-            const int qlen = (L - f % 3) / 3;
-            const uint8_t *q = fr + f * FPs;
-            for (int p0 = 0; p0 + 6 < qlen; p0 += 64) {
-                int pos = p0 + lane;
-                bool live = false;
-                int seed = 0;
-                uint32_t qk = 0;
-                int g6 = 0;
-                if (pos + 6 < qlen && pos + 10 <= qlen) {
-                    bool bad = false;
-                    for (int k = 0; k < 6; k++) { int g = grp[q[pos + k]]; bad |= (g == MC_INVGRP); seed = seed * 10 + g; }
-                    if (!bad) {
-                        bool nonempty = (bm[seed >> 5] >> (seed & 31)) & 1;
-                        g6 = grp[q[pos + 6]];
-                        int g7 = grp[q[pos + 7]], g8 = grp[q[pos + 8]], g9 = grp[q[pos + 9]];
-                        int used;
-                        bool skip = false;
-                        if (nonempty) { used = 9; skip = (g6 == MC_INVGRP || g7 == MC_INVGRP); }   // rest >= 4 here
-                        else {
-                            // prev: nearest earlier position of this frame that probed an exact seed
-                            int prev = 6;
-                            int w = pos >> 5;
-                            uint32_t m = W->setter[f][w] & ((1u << (pos & 31)) - 1);
-                            while (m == 0 && w > 0) { w--; m = W->setter[f][w]; }
-                            if (m) { int b = 31 - __builtin_clz(m); if ((W->hit[f][w] >> b) & 1) prev = 9; }
-                            used = (6 >= prev - 1) ? 6 : prev - 1;
+                    if (__ballot(live) == 0) continue;
+                    const int d4 = (seed / 10) % 10, d5 = seed % 10, d3 = (seed / 100) % 10;
+                    const int nprobe = pass == 0 ? 1 : 40;
+                    for (int t = 0; t < nprobe; t++) {
+                        bool pr = live;
+                        int v = seed, phase = 0;
+                        uint32_t k2 = qk;
+                        if (pass == 1) {
+                            phase = 1 + t;
+                            if (t < 30) {
+                                const int m = t < 10 ? 0 : t < 20 ? 1 : 2, j = t - m * 10;
+                                const int st = m == 0 ? 10 : m == 1 ? 1 : 100, d = m == 0 ? d4 : m == 1 ? d5 : d3;
+                                v = seed + (j - d) * st;
+                                pr = live && j != d;
+                                if (pr) { sc.lookups++; pr = (bm[v >> 5] >> (v & 31)) & 1; }
+                            } else {
+                                const int k = t - 30;
+                                pr = live && k != g6;
+                                if (pr) { sc.lookups++; pr = selfbucket; }
+                                k2 = (qk & 0x0FFFu) | ((uint32_t)k << 12);
+                            }
                         }
-                        if (!skip) {
-                            bool ok = (g9 != MC_INVGRP);
-                            if (used <= 8) ok = ok && (g8 != MC_INVGRP);
-                            if (used <= 7) ok = ok && (g7 != MC_INVGRP);
-                            if (used <= 6) ok = ok && (g6 != MC_INVGRP);
-                            live = ok;
-                            qk = ((uint32_t)g6 << 12) | ((uint32_t)g7 << 8) | ((uint32_t)g8 << 4) | (uint32_t)g9;
+                        const unsigned long long mask = __ballot(pr);
+                        if (mask == 0) continue;
+                        if (pr) W->q[qn + __popcll(mask & ((1ull << lane) - 1))] =
+                            (unsigned long long)v | ((unsigned long long)k2 << 20) | ((unsigned long long)pos << 36) | ((unsigned long long)f << 44) |
+                            ((unsigned long long)phase << 47);
+                        qn += __popcll(mask);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+                        if (qn >= 64) {
+                            const unsigned long long it = W->q[qn - 64 + lane];
+                            qn -= 64;
+                            mc_en_process(X, it, true, (uint32_t)r, W, tasks, cap, counters, sc, lane);
+                            __builtin_amdgcn_wave_barrier();
                         }
                     }
                 }
-                if (__ballot(live) == 0) continue;
-                const int strides[3] = {10, 1, 100};
-                for (int m = 0; m < 3; m++) {
-                    int st = strides[m], start = seed - ((seed / st) % 10) * st;
-                    for (int j = 0; j < 10; j++) {
-                        int v = start + j * st;
-                        bool pr = live && v != seed;
-                        if (pr) { sc.lookups++; pr = (bm[v >> 5] >> (v & 31)) & 1; }
-                        unsigned long long item = (unsigned long long)v | ((unsigned long long)qk << 20) | ((unsigned long long)pos << 36) |
-                                                  ((unsigned long long)f << 44) | ((unsigned long long)(1 + m * 10 + j) << 47);
-                        MC_EN_PUSH(pr, item);
-                    }
-                }
-                bool selfbucket = live && ((bm[seed >> 5] >> (seed & 31)) & 1);
-                for (int k = 0; k < 10; k++) {
-                    bool pr = live && k != g6;
-                    if (pr) { sc.lookups++; pr = selfbucket; }
-                    uint32_t qk2 = (qk & 0x0FFFu) | ((uint32_t)k << 12);
-                    unsigned long long item = (unsigned long long)seed | ((unsigned long long)qk2 << 20) | ((unsigned long long)pos << 36) |
-                                              ((unsigned long long)f << 44) | ((unsigned long long)(31 + k) << 47);
-                    MC_EN_PUSH(pr, item);
-                }
             }
+            // drain: pass 1 reads the hit flags pass 0 produces; the next read reuses the queue
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+            if (qn > 0) {
+                const unsigned long long it = (lane < qn) ? W->q[lane] : 0ull;
+                mc_en_process(X, it, lane < qn, (uint32_t)r, W, tasks, cap, counters, sc, lane);
+                qn = 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
         }
-        MC_EN_DRAIN();
     }
-    if (stats) {
-        unsigned long long a = sc.lookups, b = sc.keyprobes;
-        for (int d = 32; d > 0; d >>= 1) { a += __shfl_down(a, d); b += __shfl_down(b, d); }
-        if (lane == 0) { atomicAdd(&stats[S_LOOKUPS], a); atomicAdd(&stats[S_KEYPROBES], b); }
+    {   // close the wave's last block
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        const uint32_t bb = W->blk_base, bu = W->blk_used;
+        for (uint32_t i = bu + lane; i < MC_EN_BLK; i += 64) tasks[bb + i].read = MC_TASK_NONE;
+    }
+    {
+        unsigned long long a = sc.lookups, b = sc.keyprobes, c = sc.tasks;
+        for (int d = 32; d > 0; d >>= 1) { a += __shfl_down(a, d); b += __shfl_down(b, d); c += __shfl_down(c, d); }
+        if (lane == 0) { atomicAdd(&stats[S_LOOKUPS], a); atomicAdd(&stats[S_KEYPROBES], b); atomicAdd(&stats[S_TASKS], c); }
     }
 }
 
@@ -327,6 +329,7 @@ __global__ void __launch_bounds__(256) k_eval_seeds(const McTables *__restrict__
     uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= ntasks) return;
     McSeedTask t = tasks[tid];
+    if (t.read == MC_TASK_NONE) return;                 // padding of a partly used block of the task pool
     int frame = (int)(t.chrono >> 25), pos = (int)((t.chrono >> 17) & 0xff);
     int qlen = (L - frame % 3) / 3;
     McGapTask g;
@@ -510,7 +513,7 @@ static int open_impl(mc_handle *h, const char *const *names, const char *const *
     for (auto &e : h->ev) HIPCK(hipEventCreate(&e));
     const McHostIndex &H = h->H;
     if (dalloc(&h->d_res, H.res.size()) || dalloc(&h->d_off, H.off.size()) || dalloc(&h->d_bstart, H.bstart.size()) || dalloc(&h->d_post, H.post.size() + 1) ||
-        dalloc(&h->d_keys, H.keys.size() + 1) || dalloc(&h->d_fam, (size_t)nseq) || dalloc(&h->d_T, 1) || dalloc(&h->d_P, 1) || dalloc(&h->d_counters, C_N) || dalloc(&h->d_stats, S_N)) return -1;
+        dalloc(&h->d_keys, H.keys.size()) || dalloc(&h->d_fam, (size_t)nseq) || dalloc(&h->d_T, 1) || dalloc(&h->d_P, 1) || dalloc(&h->d_counters, C_N) || dalloc(&h->d_stats, S_N)) return -1;
     HIPCK(hipMemcpy(h->d_res, H.res.data(), H.res.size(), hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_off, H.off.data(), H.off.size() * 4, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_bstart, H.bstart.data(), H.bstart.size() * 4, hipMemcpyHostToDevice));
@@ -566,7 +569,7 @@ static int ensure_capacity(mc_handle *h, int64_t nreads)
     // pool sizes: generous multiples of what shotgun reads produce (45-60 seed hits, 10-17 kept HSPs, 1-3 gapped
     // extensions per 100-150 bp read), scaled with the read length; a batch that still overflows is split by mc_search
     const int64_t L = h->read_len;
-    h->cap_tasks = (uint32_t)std::min<int64_t>(cap * (L + 32) + (1 << 20), 0x7fffffff);
+    h->cap_tasks = (uint32_t)std::min<int64_t>(cap * (L + 32) + (1 << 20) + (int64_t)256 * 16 * MC_EN_BLK, 0x7fffffff);
     h->cap_gaps = (uint32_t)std::min<int64_t>(cap * (L / 8 + 8) + (1 << 18), 0x7fffffff);
     h->cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 2 + 16) + (1 << 20), 0x7fffffff);
     h->cap_rows = (uint32_t)std::min<int64_t>(cap * 48 + (1 << 20), 0x7fffffff);
@@ -635,10 +638,18 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         HIPCK(hipEventRecord(h->ev[1], st));
         if (h->fast_enum) {
             const int FPs = (FP + 15) & ~15;
-            size_t lds2 = 125040 + sizeof(McEnWave) * MC_EN_WAVES + (size_t)MC_EN_WAVES * 6 * FPs;
-            HIPCK(hipFuncSetAttribute((const void *)k_enumerate_t0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            int blocks = (int)std::min<int64_t>(256, (n + MC_EN_WAVES - 1) / MC_EN_WAVES);
-            k_enumerate_t0<<<dim3(blocks), dim3(64 * MC_EN_WAVES), lds2, st>>>(h->d_T, X, h->d_bitmap, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, h->d_counters, h->d_stats);
+            const size_t per_wave = sizeof(McEnWave) + (size_t)6 * FPs;
+            const bool w16 = 125040 + 16 * per_wave <= 160 * 1024;          // 16 waves per CU when the frames are short enough
+            const int waves = w16 ? 16 : 8;
+            size_t lds2 = 125040 + waves * per_wave;
+            int blocks = (int)std::min<int64_t>(256, (n + waves - 1) / waves);
+            if (w16) {
+                HIPCK(hipFuncSetAttribute((const void *)k_enumerate_t0<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+                k_enumerate_t0<16><<<dim3(blocks), dim3(64 * 16), lds2, st>>>(h->d_T, X, h->d_bitmap, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, h->d_counters, h->d_stats);
+            } else {
+                HIPCK(hipFuncSetAttribute((const void *)k_enumerate_t0<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+                k_enumerate_t0<8><<<dim3(blocks), dim3(64 * 8), lds2, st>>>(h->d_T, X, h->d_bitmap, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, h->d_counters, h->d_stats);
+            }
         } else
             k_enumerate<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, X, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, h->d_counters, h->d_stats);
         HIPCK(hipEventRecord(h->ev[2], st));
@@ -709,8 +720,8 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         }
         if (bh[oi].family >= 0) { mc_best_hit b; b.read = bh[oi].read; b.family = bh[oi].family; b.aln = bh[oi].aln; b.target_len = bh[oi].target_len; b.bits = bh[oi].bits; h->best.push_back(b); }
     }
-    { unsigned long long ss[S_N]; HIPCK(hipMemcpy(ss, h->d_stats, sizeof ss, hipMemcpyDeviceToHost)); h->stats.bucket_lookups = (int64_t)ss[S_LOOKUPS]; h->stats.key_probes = (int64_t)ss[S_KEYPROBES]; }
-    h->stats.seed_tasks = ntasks; h->stats.gap_tasks = ngaps; h->stats.hsps = nh; h->stats.rows = nrows; h->stats.reads_with_rows = with_rows; h->stats.classified = (int64_t)h->best.size();
+    { unsigned long long ss[S_N]; HIPCK(hipMemcpy(ss, h->d_stats, sizeof ss, hipMemcpyDeviceToHost)); h->stats.bucket_lookups = (int64_t)ss[S_LOOKUPS]; h->stats.key_probes = (int64_t)ss[S_KEYPROBES]; h->stats.seed_tasks = (int64_t)ss[S_TASKS]; }
+    h->stats.gap_tasks = ngaps; h->stats.hsps = nh; h->stats.rows = nrows; h->stats.reads_with_rows = with_rows; h->stats.classified = (int64_t)h->best.size();
     h->stats.ms_translate = ev_ms(h->ev[0], h->ev[1]); h->stats.ms_seed = ev_ms(h->ev[1], h->ev[2]); h->stats.ms_eval = ev_ms(h->ev[2], h->ev[3]);
     h->stats.ms_gapped = ev_ms(h->ev[3], h->ev[4]); h->stats.ms_sort = ev_ms(h->ev[4], h->ev[5]); h->stats.ms_finish = ev_ms(h->ev[5], h->ev[6]); h->stats.ms_total = ev_ms(h->ev[0], h->ev[6]);
     return 0;

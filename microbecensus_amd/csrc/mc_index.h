@@ -156,7 +156,7 @@ inline bool mc_build_index(McHostIndex &X, const char *const *names, const char 
         }
     }
     // suffix keys + bucket order (std::sort with CompDbObj, __introsort_loop@0x42f8d0)
-    X.keys.resize(X.post.size());
+    X.keys.assign(X.post.size() + 64, 0xFFFF);   // +64: mc_key_range_scan reads whole 16-byte groups around a bucket
     X.bitmap.assign((MC_NBUCKET + 31) / 32, 0);
     std::vector<McPostKey> tmp;
     auto key_of = [&](uint32_t p) -> uint16_t {

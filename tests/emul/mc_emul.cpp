@@ -59,6 +59,30 @@ int main(int argc, char **argv)
         fwrite(&H.freq_thr, 4, 1, d); fwrite(H.letter_p, 8, 10, d);
         fclose(d);
     }
+    if (getenv("MC_CHECK_SCAN")) {   // exhaustive: scan-based ranges == binary-search ranges for every key a query could match
+        McIndex Xc; Xc.res = H.res.data(); Xc.off = H.off.data(); Xc.bstart = H.bstart.data(); Xc.post = H.post.data(); Xc.keys = H.keys.data(); Xc.nseq = H.nseq;
+        long checked = 0, bad = 0;
+        for (int b = 0; b < MC_NBUCKET; b++) {
+            uint32_t n = H.bstart[b + 1] - H.bstart[b];
+            for (uint32_t i = 0; i < n; i++) {
+                uint32_t k = H.keys[H.bstart[b] + i];
+                uint32_t cand[6]; int nc = 0;
+                cand[nc++] = k; cand[nc++] = k | 0xF;                       // its 4- and 3-nibble query forms
+                cand[nc++] = (k & 0xFFF0) | ((k + 1) & 0xF); cand[nc++] = ((k + 0x1000) & 0xF000) | (k & 0x0FFF);   // near misses
+                cand[nc++] = (k & 0xFF0F) | 0xA0; cand[nc++] = (k & 0xF0FF) | 0x0A00;                                // keys holding the invalid group
+                for (int c = 0; c < nc; c++) {
+                    uint32_t qk = cand[c] & 0xFFFF;
+                    if (mc_klen(qk) < 3) continue;
+                    McSeedCount s1{0, 0}, s2{0, 0}; int n1 = 0, n2 = 0;
+                    int r1 = mc_key_range(Xc, b, qk, &n1, &s1), r2 = mc_key_range_scan(Xc, b, qk, &n2, &s2);
+                    checked++;
+                    if (r1 != r2 || (r1 > 0 && n1 != n2) || s1.keyprobes != s2.keyprobes || s1.lookups != s2.lookups) bad++;
+                }
+            }
+        }
+        fprintf(stderr, "scan check: %ld probes, %ld mismatches\n", checked, bad);
+        return bad ? 3 : 0;
+    }
     int read_len = rs.empty() ? 0 : (int)rs[0].size();
     static McTables T;
     mc_fill_tables(T, H, read_len, getenv("MC_LOGE_THR") ? atof(getenv("MC_LOGE_THR")) : 1.0);
@@ -89,7 +113,7 @@ int main(int argc, char **argv)
     // stage 2: seed enumeration
     std::vector<McSeedTask> tasks; uint64_t lookups = 0, keyprobes = 0;
     for (size_t r = 0; r < rs.size(); r++)
-        for (int f = 0; f < 6; f++) { Emit e{&tasks, (uint32_t)r, f, &X}; McSeedCount sc{0, 0}; mc_enumerate_seeds(T, X, &frames[(r * 6 + f) * FP], flen[r * 6 + f], e, &sc); lookups += sc.lookups; keyprobes += sc.keyprobes; }
+        for (int f = 0; f < 6; f++) { Emit e{&tasks, (uint32_t)r, f, &X}; McSeedCount sc{0, 0, 0}; mc_enumerate_seeds(T, X, &frames[(r * 6 + f) * FP], flen[r * 6 + f], e, &sc); lookups += sc.lookups; keyprobes += sc.keyprobes; }
     fprintf(stderr, "seed tasks: %zu (%.1f / read) lookups %.1f / read keyprobes %.1f / read\n", tasks.size(), (double)tasks.size() / std::max<size_t>(1, rs.size()), (double)lookups / std::max<size_t>(1, rs.size()), (double)keyprobes / std::max<size_t>(1, rs.size()));
     // stage 3: seed evaluation (+ ungapped) ; stage 4: gapped
     std::vector<McHsp> hsps; std::vector<McGapTask> gaps;

@@ -94,3 +94,14 @@ def test_index_builder_matches_prerapsearch(emul_bin, markers_faa, ref_dir, tmp_
     assert thr == struct.unpack_from("<I", info, 68 + 4000000)[0]
     ref_p = np.frombuffer(info, "<f8", 10, 68 + 4000000 + 4 + 8)
     assert np.allclose(letter_p, ref_p, rtol=0, atol=1e-6)
+
+
+def test_scan_ranges_equal_binary_search(emul_bin, markers_faa, tmp_path):
+    """mc_key_range_scan (what k_enumerate_t0 uses) returns the same posting range, start index and even the same
+    reference key-probe count as the binary searches of ExtendSeq2Set, for every key a query could match (21 M probes)."""
+    fa = tmp_path / "one.fa"
+    fa.write_text(">0\n" + "ACGT" * 25 + "\n")
+    env = dict(os.environ, MC_CHECK_SCAN="1")
+    r = subprocess.run([emul_bin, markers_faa, str(fa), str(tmp_path / "o.m8")], env=env, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    assert b" 0 mismatches" in r.stderr
