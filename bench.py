@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--resident-batches", type=int, default=4)
     ap.add_argument("--cpu-sample", type=int, default=50_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--count-in-timed-steps", action="store_true", help="keep the seed kernel's traffic counters on in the timed steps")
     args = ap.parse_args()
 
     import numpy as np
@@ -156,6 +157,14 @@ def main():
         fam_counts.add_(t)
         return eng.stats()
 
+    # The algorithmic traffic of the seed kernel (index reads of the reference's algorithm) depends on the reads only:
+    # it is counted once per resident batch by untimed launches with the counters on, the timed steps run without them.
+    eng.set_counting(True)
+    traffic = []
+    for b in range(nres):
+        st = step(b)
+        traffic.append((st["bucket_lookups"], st["key_probes"]))
+    eng.set_counting(bool(args.count_in_timed_steps))
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -165,6 +174,7 @@ def main():
     acc = {}
     for i in range(args.steps):
         st = step(args.warmup + i)
+        st["bucket_lookups"], st["key_probes"] = traffic[(args.warmup + i) % nres]
         for k, v in st.items():
             acc[k] = acc.get(k, 0) + v
     torch.cuda.synchronize()

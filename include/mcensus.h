@@ -75,6 +75,13 @@ int mc_run(mc_handle *h, int64_t first_read_id);
 /* runs the pipeline on reads [first, first+count) of the resident set (count <= 2097151). */
 int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id);
 
+/* The seed kernel can count the index reads of the reference's algorithm for the batch (mc_stats.bucket_lookups /
+ * key_probes: what CHashSearch::Searching@0x415050 / ExtendSeq2Set@0x413b90 would read - the algorithmic traffic the
+ * roofline of bench.py is priced on).  Off by default: the two fields stay 0 and the kernel rejects most
+ * one-substitution probes with a Bloom filter over the index's 10-mers instead of searching them.  With on != 0 every
+ * probe is searched and counted.  Results do not depend on it. */
+int mc_set_counting(mc_handle *h, int on);
+
 /* Results of the last mc_search()/mc_run(), owned by the handle until the next call:
  * rows in the reference's m8 order (ascending read id, then RAPsearch2's order within a read); best hits in
  * ascending read id (only reads with a passing hit). */

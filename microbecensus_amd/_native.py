@@ -42,9 +42,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.isfile(LIB_PATH):
-        raise RuntimeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+    path = os.environ.get("MCENSUS_LIB", LIB_PATH)      # development: an alternative build of the same library
+    if not os.path.isfile(path):
+        raise RuntimeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+    lib = C.CDLL(path)
     lib.mc_last_error.restype = C.c_char_p
     lib.mc_device_count.restype = C.c_int
     lib.mc_open.restype = C.c_void_p
@@ -57,6 +58,7 @@ def load_library():
     lib.mc_run.argtypes = [C.c_void_p, C.c_int64]
     lib.mc_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.mc_run_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+    lib.mc_set_counting.argtypes = [C.c_void_p, C.c_int]
     lib.mc_result_rows.restype = C.c_int64
     lib.mc_result_rows.argtypes = [C.c_void_p, C.POINTER(C.POINTER(McRow))]
     lib.mc_result_best_hits.restype = C.c_int64
@@ -68,7 +70,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_index_view", "mc_set_run", "mc_search",
-                    "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8"]
+                    "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8"]
 
 
 def load_markers(path=None):
@@ -159,6 +161,10 @@ class Engine:
     def attach(self, device_ptr, nreads):
         """Adopt caller-owned device memory (nreads x read_len bytes) as the resident read set."""
         self._check(self.lib.mc_attach(self.h, C.c_void_p(device_ptr), nreads), "mc_attach")
+
+    def set_counting(self, on):
+        """Turns the seed kernel's algorithmic-traffic counters (stats bucket_lookups / key_probes) on or off."""
+        self._check(self.lib.mc_set_counting(self.h, 1 if on else 0), "mc_set_counting")
 
     def run_range(self, first, count, first_read_id=0):
         self._check(self.lib.mc_run_range(self.h, first, count, first_read_id), "mc_run_range")

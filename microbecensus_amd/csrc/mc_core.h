@@ -67,6 +67,8 @@ struct McIndex {
     const uint32_t *bstart;    // MC_NBUCKET+1
     const uint32_t *post;      // seqIdx<<11 | pos, in prerapsearch bucket order
     const uint16_t *keys;      // 4 reduced residues after the 6-mer, 0xF past the sequence end
+    const struct McBucketRec *rec;   // per bucket: start + first-residue group boundaries (NULL when the index cannot use them)
+    const uint32_t *filt;      // MC_FILT_WORDS words: Bloom filter over the (bucket, 4-residue key) pairs of the index
     int32_t nseq;
 };
 
@@ -419,49 +421,110 @@ MC_HD int mc_key_range(const McIndex &X, int seed, uint32_t qk, int *nst_out, Mc
     *nst_out = nst;
     return lo - nst;
 }
-// Same range as mc_key_range for short buckets, computed by scanning: most buckets hold a handful of postings (median
-// 3), so instead of two dependent binary searches the first 8 suffix keys are fetched with independent loads and the
-// bounds are obtained by counting.  Counting equals std::lower_bound / std::upper_bound because the bucket is partitioned
-// with respect to both comparators (it is sorted by CompDbObj: reduced residues, then remaining length - the same
-// prefix-then-length order the comparators use); tests/test_emul.py checks this exhaustively on the index.  Buckets
-// longer than 8 use the binary searches.  keyprobes counts the reads of the reference algorithm, not of the scan.
-MC_HD int mc_key_range_scan(const McIndex &X, int seed, uint32_t qk, int *nst_out, McSeedCount *sc)
+// ---- sub-bucket records: the fast form of the same lookup -------------------------------------------------------
+// A bucket is ordered by CompDbObj, so its postings form contiguous groups by the first reduced residue after the 6-mer
+// (postings at the very end of a sequence, key FFFF, first; mc_build_index verifies the grouping).  McBucketRec holds the
+// group boundaries: cum[k] = number of postings in front of group k (k = 0..10, 10 = the invalid residue), cum[11] = bucket
+// size.  A query key can only match inside the group of its own first residue, so the
+// range search runs over that group alone: counting over its first 8 keys when it is that short (89 % of the probes of
+// 150 bp reads; 56 % hit an empty group and need no key at all), binary searches otherwise.  Counting equals
+// std::lower_bound / std::upper_bound because the group is partitioned with respect to both comparators;
+// tests/test_emul.py checks the equality of range, start index and probe count exhaustively on the marker index.
+struct McBucketRec { uint32_t start; uint16_t cum[12]; uint16_t pad[2]; };   // 32 B
+
+MC_HD int mc_klen_fast(uint32_t k) { return 4 - (__builtin_ctz((~k & 0xFFFFu) | 0x10000u) >> 2); }
+
+// number of key reads of the reference's binary search (lower_bound or upper_bound) over n keys that ends at index x
+MC_HD uint32_t mc_bsearch_reads(int n, int x)
 {
-    uint32_t b0 = X.bstart[seed], b1 = X.bstart[seed + 1];
-    int n = (int)(b1 - b0);
-    if (n > 8) return mc_key_range(X, seed, qk, nst_out, sc);
-    sc->lookups++;
-    if (n == 0) return 0;
-    const uint16_t *kp = X.keys + b0;
-    uint32_t k[8];
-    for (int i = 0; i < 8; i++) k[i] = kp[i];             // the key array is padded, reading past the bucket is harmless
-    const int lq = mc_klen(qk);
+    uint32_t c = 0;
+    int lo = 0, len = n;
+    while (len > 0) { int half = len >> 1; c++; if (lo + half < x) { lo += half + 1; len -= half + 1; } else len = half; }
+    return c;
+}
+
+// group of 1..8 keys at kp: returns the number of matching postings, *lb_out = index of the first one inside the group
+MC_HD int mc_group_range8(const uint16_t *kp, int ns, uint32_t qk, int *lb_out)
+{
+    // the 8 keys as five aligned 32-bit words (the key array is padded, reading past the group is harmless)
+    const uintptr_t a = (uintptr_t)kp;
+    const uint32_t *w = (const uint32_t *)(a & ~(uintptr_t)3);
+    uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
+    if (a & 2) { d0 = (d0 >> 16) | (d1 << 16); d1 = (d1 >> 16) | (d2 << 16); d2 = (d2 >> 16) | (d3 << 16); d3 = (d3 >> 16) | (d4 << 16); }
+    const uint32_t k[8] = {d0 & 0xFFFFu, d0 >> 16, d1 & 0xFFFFu, d1 >> 16, d2 & 0xFFFFu, d2 >> 16, d3 & 0xFFFFu, d3 >> 16};
+    const int lq = mc_klen_fast(qk);
     int lb = 0, ub = 0;
     for (int i = 0; i < 8; i++) {
-        uint32_t dk = k[i];
-        int ld = mc_klen(dk), m = ld < lq ? ld : lq;
-        int sh = (4 - m) * 4;
-        int a = (int)(dk >> sh), b = (int)(qk >> sh);
-        bool in = i < n;
-        bool less_db = (m != 0 && a != b) ? (a < b) : (ld < lq);            // mc_key_lb_less(dk, qk)
-        bool less_q = (m == 0) ? (lq < ld) : (a != b && b < a);               // mc_key_ub_less(qk, dk)
+        const uint32_t dk = k[i];
+        const int ld = mc_klen_fast(dk), m = ld < lq ? ld : lq, sh = (4 - m) * 4;
+        const int x = (int)(dk >> sh), y = (int)(qk >> sh);
+        const bool in = i < ns;
+        const bool less_db = (m != 0 && x != y) ? (x < y) : (ld < lq);       // mc_key_lb_less(dk, qk)
+        const bool less_q = (m == 0) ? (lq < ld) : (y < x);                   // mc_key_ub_less(qk, dk)
         lb += (in && less_db);
         ub += (in && !less_q);
     }
-    uint32_t at_lb = 0;
-    for (int i = 0; i < 8; i++) if (i == lb) at_lb = k[i];
-    { int lo = 0, len = n; while (len > 0) { int half = len >> 1; sc->keyprobes++; if (lo + half < lb) { lo += half + 1; len -= half + 1; } else len = half; } }
-    if (lb == n) return 0;
-    {
-        int la = mc_klen(at_lb), m = lq < la ? lq : la;
-        if (m == 0) return 0;
-        int sh = (4 - m) * 4;
-        if ((at_lb >> sh) != (qk >> sh)) return 0;
-    }
-    { int lo = 0, len = n; while (len > 0) { int half = len >> 1; sc->keyprobes++; if (lo + half >= ub) len = half; else { lo += half + 1; len -= half + 1; } } }
-    *nst_out = lb;
+    *lb_out = lb;                                         // where the reference's lower_bound stops, range or not
+    if (lb == ns) return 0;
+    uint32_t at = k[0];
+    for (int i = 1; i < 8; i++) if (i == lb) at = k[i];
+    const int la = mc_klen_fast(at), m = lq < la ? lq : la;
+    if (m == 0) return 0;
+    const int sh = (4 - m) * 4;
+    if ((at >> sh) != (qk >> sh)) return 0;
     return ub - lb;
 }
+
+// the same for a group of any length, by the reference's two binary searches
+MC_HD int mc_group_range_bs(const uint16_t *kp, int ns, uint32_t qk, int *lb_out)
+{
+    int lo = 0, len = ns;
+    while (len > 0) { int half = len >> 1; if (mc_key_lb_less(kp[lo + half], qk)) { lo += half + 1; len -= half + 1; } else len = half; }
+    const int lb = lo;
+    *lb_out = lb;
+    if (lb == ns) return 0;
+    const uint32_t at = kp[lb];
+    const int lq = mc_klen_fast(qk), la = mc_klen_fast(at), m = lq < la ? lq : la;
+    if (m == 0) return 0;
+    const int sh = (4 - m) * 4;
+    if ((at >> sh) != (qk >> sh)) return 0;
+    lo = 0; len = ns;
+    while (len > 0) { int half = len >> 1; if (mc_key_ub_less(qk, kp[lo + half])) len = half; else { lo += half + 1; len -= half + 1; } }
+    return lo - lb;
+}
+
+// record-based equivalent of mc_key_range (same result, same start index, same algorithmic probe counts)
+MC_HD int mc_key_range_rec(const McBucketRec *rec, const uint16_t *keys, int seed, uint32_t qk, int *nst_out, McSeedCount *sc)
+{
+    const McBucketRec *R = rec + seed;
+    const int k6 = (int)(qk >> 12);                       // 0..9, or 10 = the invalid group
+    const int c0 = R->cum[k6], ns = (int)R->cum[k6 + 1] - c0, n = R->cum[11];
+    sc->lookups++;
+    if (n == 0) return 0;
+    int lb = 0, cnt = 0;
+    if (ns > 0) cnt = ns <= 8 ? mc_group_range8(keys + R->start + c0, ns, qk, &lb) : mc_group_range_bs(keys + R->start + c0, ns, qk, &lb);
+    // key reads of the reference: its lower_bound over the whole bucket stops at c0 + lb; upper_bound runs only for a range
+    sc->keyprobes += mc_bsearch_reads(n, c0 + lb) + (cnt > 0 ? mc_bsearch_reads(n, c0 + lb + cnt) : 0u);
+    *nst_out = c0 + lb;
+    return cnt;
+}
+// ---- 10-mer filter ------------------------------------------------------------------------------------------------
+// A 10-mer probe (4-residue key, none of them the end-of-sequence pad) can only find postings whose key is EQUAL to it:
+// a shorter database key sorts in front of the range (mc_key_lb_less: equal prefix, shorter first).  Almost all of
+// the one-substitution probes of a read find nothing (57 hits out of 5,700 for 150 bp reads), so the seed kernel asks
+// a Bloom filter over the (bucket, key) pairs first: 2 bits in one 32-bit word, 2^19 words (2 MB, L2 resident).  No
+// false negatives, ~2 % false positives; a positive goes through the exact range search as before.
+#define MC_FILT_LOG2W 19
+#define MC_FILT_WORDS (1u << MC_FILT_LOG2W)
+MC_HD uint32_t mc_filter_hash(uint32_t bucket, uint32_t key)
+{
+    uint32_t x = bucket * 0x9E3779B1u + key * 0x85EBCA77u;
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
+    return x;
+}
+MC_HD uint32_t mc_filter_word(uint32_t h) { return h >> (32 - MC_FILT_LOG2W); }
+MC_HD uint32_t mc_filter_bits(uint32_t h) { return (1u << (h & 31)) | (1u << ((h >> 5) & 31)); }
+
 MC_HD uint32_t mc_pack_key(const uint8_t *g, int nkey)
 {
     uint32_t qk = 0;

@@ -128,67 +128,128 @@ __global__ void __launch_bounds__(256) k_enumerate(const McTables *__restrict__ 
 #define MC_EN_QCAP 128
 #define MC_EN_BLK 512u                      // task slots a wave reserves at a time (one global atomic per block, not per append)
 #define MC_TASK_NONE 0xFFFFFFFFu            // read id of the padding entries that close a partly used block
-struct McEnWave { uint32_t setter[6][6]; uint32_t hit[6][6]; uint32_t blk_base, blk_used; unsigned long long q[MC_EN_QCAP]; };
+struct McEnWave {
+    uint32_t setter[6][6]; uint32_t hit[6][6]; uint32_t blk_base, blk_used;
+    unsigned long long q[MC_EN_QCAP];       // probes that passed the bucket bitmap
+    unsigned long long hq[MC_EN_QCAP];      // probes whose first-residue group is longer than 8 keys (binary search)
+};
+
+extern __shared__ __attribute__((aligned(16))) uint8_t mc_smem[];   // dynamic LDS of the kernels that use it
 
 __device__ __forceinline__ int mc_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// orders the wave's own LDS traffic for the compiler; the hardware executes one wave's LDS instructions in order
+__device__ __forceinline__ void mc_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 // item: bucket(20) | qk(16)<<20 | pos(8)<<36 | frame(3)<<44 | phase(6)<<47
-__device__ __noinline__ void mc_en_process(const McIndex &X, unsigned long long item, bool active, uint32_t read, McEnWave *W,
-                                           McSeedTask *tasks, uint32_t cap, uint32_t *counters, McSeedCount &sc, int lane)
+// Appends the seed hits of one batch of probes (lane: cnt postings starting at posting index nst of its bucket).
+__device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long long item, int cnt, int nst, uint32_t start, uint32_t read, McEnWave *W,
+                                                 McSeedTask *tasks, uint32_t cap, uint32_t *counters, int lane)
 {
-    int cnt = 0, nst = 0;
-    int bucket = (int)(item & 0xFFFFF), pos = (int)((item >> 36) & 0xFF), frame = (int)((item >> 44) & 7), phase = (int)((item >> 47) & 63);
-    uint32_t qk = (uint32_t)((item >> 20) & 0xFFFF);
-    if (active) {
-        cnt = mc_key_range_scan(X, bucket, qk, &nst, &sc);
-        sc.lookups--;                                   // the probe itself was already counted when it was generated
-        if (phase == 0 && cnt > 0) atomicOr(&W->hit[frame][pos >> 5], 1u << (pos & 31));
+    unsigned long long m = __ballot(cnt > 0);
+    if (m == 0) return 0;
+    const int pos = (int)((item >> 36) & 0xFF), frame = (int)((item >> 44) & 7), phase = (int)((item >> 47) & 63);
+    if (phase == 0 && cnt > 0) atomicOr(&W->hit[frame][pos >> 5], 1u << (pos & 31));
+    // exclusive prefix over the (few) lanes that found something
+    uint32_t total = 0, mine = 0;
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane(cnt, l);
+        if (lane == l) mine = total;
+        total += c;
+        m &= m - 1;
     }
-    // wave-aggregated append into the wave's current block of the task pool
-    int incl = cnt;
-    for (int d = 1; d < 64; d <<= 1) { int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
-    const uint32_t total = (uint32_t)__shfl(incl, 63);
-    if (total == 0) return;
-    sc.tasks += (uint32_t)cnt;
     uint32_t base;
     if (total > MC_EN_BLK) {                     // rare: a long range, reserved directly
         base = 0;
         if (lane == 0) base = atomicAdd(&counters[C_TASKS], total);
-        base = __shfl(base, 0);
-        if (base + total > cap) { if (lane == 0) counters[C_OVERFLOW] = 1; return; }
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base + total > cap) { if (lane == 0) counters[C_OVERFLOW] = 1; return 0; }
     } else {
         uint32_t bb = W->blk_base, bu = W->blk_used;
-        __builtin_amdgcn_wave_barrier();
+        mc_wave_sync();
         if (bu + total > MC_EN_BLK) {
             for (uint32_t i = bu + lane; i < MC_EN_BLK; i += 64) tasks[bb + i].read = MC_TASK_NONE;
             uint32_t nb = 0;
             if (lane == 0) nb = atomicAdd(&counters[C_TASKS], MC_EN_BLK);
-            nb = __shfl(nb, 0);
-            if (nb + MC_EN_BLK > cap) { if (lane == 0) { counters[C_OVERFLOW] = 1; W->blk_used = MC_EN_BLK; } return; }
+            nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+            if (nb + MC_EN_BLK > cap) { if (lane == 0) { counters[C_OVERFLOW] = 1; W->blk_used = MC_EN_BLK; } return 0; }
             bb = nb; bu = 0;
         }
         base = bb + bu;
         if (lane == 0) { W->blk_base = bb; W->blk_used = bu + total; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+        mc_wave_sync();
     }
     if (cnt > 0) {
-        uint32_t o = base + (uint32_t)(incl - cnt), b0 = X.bstart[bucket];
-        int seedlen = phase == 0 ? 9 : 10, nkey = phase == 0 ? 3 : 4;
+        const uint32_t o = base + mine;
+        const uint32_t sn = phase == 0 ? (9u | (3u << 8)) : (10u | (4u << 8));
         for (int i = 0; i < cnt; i++) {
             McSeedTask t;
-            t.read = read; t.chrono = MC_CHRONO(frame, pos, phase, nst + i); t.posting = X.post[b0 + nst + i];
-            t.seedlen_nkey = (uint32_t)seedlen | ((uint32_t)nkey << 8);
+            t.read = read; t.chrono = MC_CHRONO(frame, pos, phase, nst + i); t.posting = X.post[start + nst + i];
+            t.seedlen_nkey = sn;
             tasks[o + i] = t;
         }
     }
+    return (uint32_t)cnt;
 }
 
-template <int MC_EN_WAVES>
+// One batch of (up to 64) probes.  Returns per lane: key reads of the reference (bits 32..), seed hits (bits 8..31);
+// bits 0..7 (uniform): the new fill of the heavy queue.
+template <bool COUNT>
+__device__ __forceinline__ unsigned long long mc_en_process(const McIndex &X, unsigned long long item, bool active, uint32_t read, McEnWave *W, int hn,
+                                                         McSeedTask *tasks, uint32_t cap, uint32_t *counters, int lane)
+{
+    int cnt = 0, lb = 0;
+    uint32_t start = 0, kp = 0;
+    int c0 = 0;
+    bool heavy = false;
+    if (active) {
+        const int bucket = (int)(item & 0xFFFFF);
+        const uint32_t qk = (uint32_t)((item >> 20) & 0xFFFF);
+        const McBucketRec *R = X.rec + bucket;
+        const int k6 = (int)(qk >> 12);
+        start = R->start; c0 = R->cum[k6];
+        const int ns = (int)R->cum[k6 + 1] - c0;
+        heavy = ns > 8;
+        if (ns > 0 && !heavy) cnt = mc_group_range8(X.keys + start + c0, ns, qk, &lb);
+        if (COUNT && !heavy) { const int n = R->cum[11]; kp = mc_bsearch_reads(n, c0 + lb) + (cnt > 0 ? mc_bsearch_reads(n, c0 + lb + cnt) : 0u); }
+    }
+    const unsigned long long hm = __ballot(heavy);
+    if (hm) {
+        if (heavy) W->hq[hn + __popcll(hm & ((1ull << lane) - 1))] = item;
+        hn += __popcll(hm);
+        mc_wave_sync();
+    }
+    const uint32_t nt = mc_en_append(X, item, cnt, c0 + lb, start, read, W, tasks, cap, counters, lane);
+    return ((unsigned long long)kp << 32) | ((unsigned long long)nt << 8) | (unsigned long long)hn;
+}
+
+// One batch of probes whose group needs the binary searches.
+template <bool COUNT>
+__device__ __forceinline__ unsigned long long mc_en_heavy(const McIndex &X, unsigned long long item, bool active, uint32_t read, McEnWave *W,
+                                                       McSeedTask *tasks, uint32_t cap, uint32_t *counters, int lane)
+{
+    int cnt = 0, lb = 0, c0 = 0;
+    uint32_t start = 0, kp = 0;
+    if (active) {
+        const int bucket = (int)(item & 0xFFFFF);
+        const uint32_t qk = (uint32_t)((item >> 20) & 0xFFFF);
+        const McBucketRec *R = X.rec + bucket;
+        const int k6 = (int)(qk >> 12);
+        start = R->start; c0 = R->cum[k6];
+        const int ns = (int)R->cum[k6 + 1] - c0;
+        cnt = mc_group_range_bs(X.keys + start + c0, ns, qk, &lb);
+        if (COUNT) { const int n = R->cum[11]; kp = mc_bsearch_reads(n, c0 + lb) + (cnt > 0 ? mc_bsearch_reads(n, c0 + lb + cnt) : 0u); }
+    }
+    const uint32_t nt = mc_en_append(X, item, cnt, c0 + lb, start, read, W, tasks, cap, counters, lane);
+    return ((unsigned long long)kp << 32) | ((unsigned long long)nt << 8);
+}
+
+template <int MC_EN_WAVES, bool COUNT>
 __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTables *__restrict__ T, McIndex X, const uint32_t *__restrict__ bitmap,
                                                                    const uint8_t *__restrict__ frames, int FP, int L, int64_t nreads, McSeedTask *tasks,
                                                                    uint32_t cap, uint32_t *counters, unsigned long long *stats)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *smem = mc_smem;
     uint32_t *bm = (uint32_t *)smem;                                        // 31,250 words
     uint8_t *grp = smem + 125000;                                           // 32-byte group table
     McEnWave *waves = (McEnWave *)(smem + 125040);
@@ -199,33 +260,84 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
     uint8_t *fr = fr_all + (size_t)wv * 6 * FPs;
     for (int i = threadIdx.x; i < (MC_NBUCKET + 31) / 32; i += blockDim.x) bm[i] = bitmap[i];
     if (threadIdx.x < 32) grp[threadIdx.x] = T->grp[threadIdx.x];
-    __syncthreads();
     if (lane == 0) { W->blk_base = 0; W->blk_used = MC_EN_BLK; }
+    __syncthreads();
     McSeedCount sc; sc.lookups = 0; sc.keyprobes = 0; sc.tasks = 0;
+    const unsigned long long lt = (1ull << lane) - 1;
     const int64_t nw = (int64_t)gridDim.x * MC_EN_WAVES;
     for (int64_t r = (int64_t)blockIdx.x * MC_EN_WAVES + wv; r < nreads; r += nw) {
-        int qn = 0;
+        int qn = 0, hn = 0;
         {   // stage the six frames of this read (rows of FP bytes) into the wave's LDS area, clear the flags
             const uint8_t *src = frames + r * 6 * FP;
             for (int f = 0; f < 6; f++) for (int i = lane; i < FP; i += 64) fr[f * FPs + i] = src[f * FP + i];
             if (lane < 36) { ((uint32_t *)W->setter)[lane] = 0; ((uint32_t *)W->hit)[lane] = 0; }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+            mc_wave_sync();
         }
-        // pass 0: exact 9-mers (one probe per position).  pass 1: the one-substitution 10-mers of every position
-        // (probes 0..29: offsets 4, 5, 3 of the 6-mer = neighbour buckets; 30..39: offset 6 = same bucket, other key).
-        // One probe generator / one queue site for both passes keeps the kernel small enough for 16 waves per CU.
+        // pass 0: the exact 9-mer of every position (group 0, one probe).  pass 1: its one-substitution 10-mers in four
+        // groups of ten probes: groups 0..2 = offsets 4, 5, 3 of the 6-mer (neighbour buckets), group 3 = offset 6 (same
+        // bucket, first key residue substituted).  A group is generated for 64 positions at once: bucket bitmap (LDS), then
+        // - with the counters off - the 10-mer Bloom filter (ten independent L2 gathers); the survivors wait in the
+        // per-lane mask pm and are queued one per lane and iteration.  The generator is a state machine so that each
+        // queue consumer exists once in the kernel.
         for (int pass = 0; pass < 2; pass++) {
-            for (int f = 0; f < 6; f++) {
-                const int qlen = (L - f % 3) / 3;
-                const uint8_t *q = fr + f * FPs;
-                for (int p0 = 0; p0 + 6 < qlen; p0 += 64) {
+            const int ngroups = pass == 0 ? 1 : 4;
+            int f = -1, p0 = 0, qlen = 0, g = ngroups;
+            bool more = true;
+            bool live = false, selfbucket = false;
+            int seed = 0, g6 = 0, d3 = 0, d4 = 0, d5 = 0;
+            uint32_t qk = 0, pm = 0;
+            unsigned long long hi = 0;
+            const uint8_t *q = fr;
+            for (;;) {
+                if (hn >= 64 || (!more && qn == 0 && hn > 0)) {          // probes that need the binary searches
+                    const int take = hn < 64 ? hn : 64;
+                    hn -= take;
+                    const unsigned long long rh = mc_en_heavy<COUNT>(X, (lane < take) ? W->hq[hn + lane] : 0ull, lane < take, (uint32_t)r, W, tasks, cap, counters, lane);
+                    sc.keyprobes += (uint32_t)(rh >> 32); sc.tasks += (uint32_t)(rh >> 8) & 0xFFFFFFu;
+                    mc_wave_sync();
+                    continue;
+                }
+                if (qn >= 64 || (!more && qn > 0)) {                     // probes that passed the filters
+                    const int take = qn < 64 ? qn : 64;
+                    qn -= take;
+                    const unsigned long long ret = mc_en_process<COUNT>(X, (lane < take) ? W->q[qn + lane] : 0ull, lane < take, (uint32_t)r, W, hn, tasks, cap, counters, lane);
+                    hn = __builtin_amdgcn_readfirstlane((int)(ret & 0xFF));
+                    sc.keyprobes += (uint32_t)(ret >> 32); sc.tasks += (uint32_t)(ret >> 8) & 0xFFFFFFu;
+                    mc_wave_sync();
+                    continue;
+                }
+                {   // queue one surviving probe per lane
+                    const unsigned long long pmm = __ballot(pm != 0);
+                    if (pmm) {
+                        const int j = __builtin_ctz(pm | 0x400u), gc = g - 1;
+                        int v = seed, phase = 0;
+                        uint32_t k2 = qk;
+                        if (pass == 1) {
+                            phase = 1 + gc * 10 + j;
+                            if (gc < 3) { const int st = gc == 0 ? 10 : gc == 1 ? 1 : 100, d = gc == 0 ? d4 : gc == 1 ? d5 : d3; v = seed + (j - d) * st; }
+                            else k2 = (qk & 0x0FFFu) | ((uint32_t)j << 12);
+                        }
+                        if (pm) W->q[qn + __popcll(pmm & lt)] = hi | (unsigned long long)v | ((unsigned long long)k2 << 20) | ((unsigned long long)phase << 47);
+                        qn += __popcll(pmm);
+                        pm &= pm - 1;
+                        mc_wave_sync();
+                        continue;
+                    }
+                }
+                if (!more) break;
+                if (g >= ngroups) {                                      // next chunk of positions / next frame
+                    if (f >= 0) p0 += 64;
+                    if (f < 0 || p0 + 6 >= qlen) {
+                        f++; p0 = 0;
+                        if (f == 6) { more = false; continue; }
+                        qlen = (L - f % 3) / 3; q = fr + f * FPs;
+                        if (p0 + 6 >= qlen) continue;
+                    }
                     const int pos = p0 + lane;
-                    bool live = false, selfbucket = false;
-                    int seed = 0, g6 = 0;
-                    uint32_t qk = 0;
+                    live = false; selfbucket = false; seed = 0; g6 = 0; qk = 0;
                     if (pos + 6 < qlen) {
                         bool bad = false;
-                        for (int k = 0; k < 6; k++) { int g = grp[q[pos + k]]; bad |= (g == MC_INVGRP); seed = seed * 10 + g; }
+                        for (int k = 0; k < 6; k++) { int gg = grp[q[pos + k]]; bad |= (gg == MC_INVGRP); seed = seed * 10 + gg; }
                         if (!bad) {
                             selfbucket = (bm[seed >> 5] >> (seed & 31)) & 1;
                             const int rest = qlen - pos - 6;
@@ -233,11 +345,11 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                             const int g7 = rest >= 2 ? grp[q[pos + 7]] : MC_INVGRP, g8 = rest >= 3 ? grp[q[pos + 8]] : MC_INVGRP;
                             const int g9 = rest >= 4 ? grp[q[pos + 9]] : MC_INVGRP;
                             if (pass == 0) {
-                                sc.lookups++;                                   // bucket-size probe of the exact seed
+                                if (COUNT) sc.lookups++;                         // bucket-size probe of the exact seed
                                 if (selfbucket && rest >= 3 && g6 != MC_INVGRP && g7 != MC_INVGRP) {
                                     atomicOr(&W->setter[f][pos >> 5], 1u << (pos & 31));
                                     qk = ((uint32_t)g6 << 12) | ((uint32_t)g7 << 8) | ((uint32_t)g8 << 4) | 0xFu;
-                                    sc.lookups++;                               // its key-range probe
+                                    if (COUNT) sc.lookups++;                     // its key-range probe
                                     live = true;
                                 }
                             } else if (rest >= 4) {
@@ -248,7 +360,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                                     int prev = 6, w = pos >> 5;
                                     uint32_t m = W->setter[f][w] & ((1u << (pos & 31)) - 1);
                                     while (m == 0 && w > 0) { w--; m = W->setter[f][w]; }
-                                    if (m) { int b = 31 - __builtin_clz(m); if ((W->hit[f][w] >> b) & 1) prev = 9; }
+                                    if (m) { int bb = 31 - __builtin_clz(m); if ((W->hit[f][w] >> bb) & 1) prev = 9; }
                                     used = (6 >= prev - 1) ? 6 : prev - 1;
                                 }
                                 if (!skip) {
@@ -262,56 +374,42 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                             }
                         }
                     }
-                    if (__ballot(live) == 0) continue;
-                    const int d4 = (seed / 10) % 10, d5 = seed % 10, d3 = (seed / 100) % 10;
-                    const int nprobe = pass == 0 ? 1 : 40;
-                    for (int t = 0; t < nprobe; t++) {
-                        bool pr = live;
-                        int v = seed, phase = 0;
-                        uint32_t k2 = qk;
-                        if (pass == 1) {
-                            phase = 1 + t;
-                            if (t < 30) {
-                                const int m = t < 10 ? 0 : t < 20 ? 1 : 2, j = t - m * 10;
-                                const int st = m == 0 ? 10 : m == 1 ? 1 : 100, d = m == 0 ? d4 : m == 1 ? d5 : d3;
-                                v = seed + (j - d) * st;
-                                pr = live && j != d;
-                                if (pr) { sc.lookups++; pr = (bm[v >> 5] >> (v & 31)) & 1; }
-                            } else {
-                                const int k = t - 30;
-                                pr = live && k != g6;
-                                if (pr) { sc.lookups++; pr = selfbucket; }
-                                k2 = (qk & 0x0FFFu) | ((uint32_t)k << 12);
-                            }
-                        }
-                        const unsigned long long mask = __ballot(pr);
-                        if (mask == 0) continue;
-                        if (pr) W->q[qn + __popcll(mask & ((1ull << lane) - 1))] =
-                            (unsigned long long)v | ((unsigned long long)k2 << 20) | ((unsigned long long)pos << 36) | ((unsigned long long)f << 44) |
-                            ((unsigned long long)phase << 47);
-                        qn += __popcll(mask);
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
-                        if (qn >= 64) {
-                            const unsigned long long it = W->q[qn - 64 + lane];
-                            qn -= 64;
-                            mc_en_process(X, it, true, (uint32_t)r, W, tasks, cap, counters, sc, lane);
-                            __builtin_amdgcn_wave_barrier();
+                    d4 = (seed / 10) % 10; d5 = seed % 10; d3 = (seed / 100) % 10;
+                    hi = ((unsigned long long)pos << 36) | ((unsigned long long)f << 44);
+                    g = (__ballot(live) == 0) ? ngroups : 0;
+                    continue;
+                }
+                // generate group g of the current chunk
+                if (pass == 0) pm = live ? 1u : 0u;
+                else {
+                    const int st = g == 0 ? 10 : g == 1 ? 1 : 100, d = g == 0 ? d4 : g == 1 ? d5 : d3;
+                    uint32_t ok = 0, fw[10], fb[10];
+#pragma unroll
+                    for (int j = 0; j < 10; j++) {
+                        bool c;
+                        uint32_t vb = (uint32_t)seed, kk = qk;
+                        if (g < 3) { const int v = seed + (j - d) * st; c = live && j != d; if (COUNT && c) sc.lookups++; c = c && ((bm[v >> 5] >> (v & 31)) & 1); vb = (uint32_t)v; }
+                        else { c = live && j != g6; if (COUNT && c) sc.lookups++; c = c && selfbucket; kk = (qk & 0x0FFFu) | ((uint32_t)j << 12); }
+                        ok |= (uint32_t)c << j;
+                        if (!COUNT) {   // Bloom filter word of the 10-mer; lanes without a candidate read word 0
+                            const uint32_t hh = mc_filter_hash(vb, kk);
+                            fb[j] = mc_filter_bits(hh);
+                            fw[j] = X.filt[c ? mc_filter_word(hh) : 0u];
                         }
                     }
+                    if (!COUNT) {
+#pragma unroll
+                        for (int j = 0; j < 10; j++) if ((fw[j] & fb[j]) != fb[j]) ok &= ~(1u << j);
+                    }
+                    pm = ok;
                 }
+                g++;
             }
-            // drain: pass 1 reads the hit flags pass 0 produces; the next read reuses the queue
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
-            if (qn > 0) {
-                const unsigned long long it = (lane < qn) ? W->q[lane] : 0ull;
-                mc_en_process(X, it, lane < qn, (uint32_t)r, W, tasks, cap, counters, sc, lane);
-                qn = 0;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+            mc_wave_sync();
         }
     }
     {   // close the wave's last block
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        mc_wave_sync();
         const uint32_t bb = W->blk_base, bu = W->blk_used;
         for (uint32_t i = bu + lane; i < MC_EN_BLK; i += 64) tasks[bb + i].read = MC_TASK_NONE;
     }
@@ -452,7 +550,10 @@ struct mc_handle {
     const uint8_t *reads_dev = nullptr;   // resident read set (own buffer or attached caller memory)
     unsigned long long *d_stats = nullptr;
     uint32_t *d_bitmap = nullptr;
+    McBucketRec *d_rec = nullptr;
+    uint32_t *d_filt = nullptr;
     bool fast_enum = false;
+    bool count_traffic = false;
     McSeedTask *d_tasks = nullptr; McGapTask *d_gaps = nullptr; McHsp *d_hsps = nullptr, *d_sorted = nullptr, *d_v = nullptr, *d_tmp = nullptr;
     uint32_t cap_tasks = 0, cap_gaps = 0, cap_hsps = 0, cap_rows = 0;
     uint64_t *d_k64 = nullptr, *d_k64o = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
@@ -466,7 +567,7 @@ struct mc_handle {
 
 static McIndex dev_index(const mc_handle *h)
 {
-    McIndex X; X.res = h->d_res; X.off = h->d_off; X.bstart = h->d_bstart; X.post = h->d_post; X.keys = h->d_keys; X.nseq = h->H.nseq;
+    McIndex X; X.res = h->d_res; X.off = h->d_off; X.bstart = h->d_bstart; X.post = h->d_post; X.keys = h->d_keys; X.rec = h->d_rec; X.filt = h->d_filt; X.nseq = h->H.nseq;
     return X;
 }
 
@@ -490,7 +591,7 @@ extern "C" void mc_close(mc_handle *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_frames, h->d_tasks, h->d_gaps, h->d_hsps,
                     h->d_sorted, h->d_v, h->d_tmp, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, h->d_heads, h->d_sorttmp, h->d_counters, h->d_rows, h->d_rowscratch,
-                    h->d_kscratch, h->d_seginfo, h->d_best, h->d_gH, h->d_gD, h->d_gPH, h->d_gPD, h->d_stats, h->d_bitmap};
+                    h->d_kscratch, h->d_seginfo, h->d_best, h->d_gH, h->d_gD, h->d_gPH, h->d_gPD, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -522,8 +623,15 @@ static int open_impl(mc_handle *h, const char *const *names, const char *const *
     HIPCK(hipMemcpy(h->d_fam, h->fam.data(), (size_t)nseq * 4, hipMemcpyHostToDevice));
     if (dalloc(&h->d_bitmap, H.bitmap.size())) return -1;
     HIPCK(hipMemcpy(h->d_bitmap, H.bitmap.data(), H.bitmap.size() * 4, hipMemcpyHostToDevice));
+    if (dalloc(&h->d_filt, H.filt.size())) return -1;
+    HIPCK(hipMemcpy(h->d_filt, H.filt.data(), H.filt.size() * 4, hipMemcpyHostToDevice));
+    if (!H.rec.empty()) {
+        if (dalloc(&h->d_rec, H.rec.size())) return -1;
+        HIPCK(hipMemcpy(h->d_rec, H.rec.data(), H.rec.size() * sizeof(McBucketRec), hipMemcpyHostToDevice));
+    }
+    if (H.max_bucket > 2047) { g_err = "a seed bucket holds more than 2047 postings: the hit-order key cannot index it"; return -1; }
     // the position-parallel seed kernel is exact only when the frequency threshold is 0 and no letter frequency is 0
-    h->fast_enum = (H.freq_thr == 0) && !getenv("MC_FORCE_SEQUENTIAL_ENUM");
+    h->fast_enum = (H.freq_thr == 0) && !H.rec.empty() && !getenv("MC_FORCE_SEQUENTIAL_ENUM");
     for (int g = 0; g < 10; g++) if (!(H.letter_p[g] > 0.0)) h->fast_enum = false;
     return 0;
 }
@@ -639,17 +747,20 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         if (h->fast_enum) {
             const int FPs = (FP + 15) & ~15;
             const size_t per_wave = sizeof(McEnWave) + (size_t)6 * FPs;
-            const bool w16 = 125040 + 16 * per_wave <= 160 * 1024;          // 16 waves per CU when the frames are short enough
-            const int waves = w16 ? 16 : 8;
-            size_t lds2 = 125040 + waves * per_wave;
-            int blocks = (int)std::min<int64_t>(256, (n + waves - 1) / waves);
-            if (w16) {
-                HIPCK(hipFuncSetAttribute((const void *)k_enumerate_t0<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-                k_enumerate_t0<16><<<dim3(blocks), dim3(64 * 16), lds2, st>>>(h->d_T, X, h->d_bitmap, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, h->d_counters, h->d_stats);
-            } else {
-                HIPCK(hipFuncSetAttribute((const void *)k_enumerate_t0<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-                k_enumerate_t0<8><<<dim3(blocks), dim3(64 * 8), lds2, st>>>(h->d_T, X, h->d_bitmap, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, h->d_counters, h->d_stats);
-            }
+            int waves = (int)((160 * 1024 - 125040) / per_wave);            // as many waves per CU as the LDS holds next to the bitmap
+            waves = waves >= 14 ? 14 : waves >= 12 ? 12 : waves >= 8 ? 8 : 4;
+            const size_t lds2 = 125040 + waves * per_wave;
+            if (lds2 > 160 * 1024) { g_err = "reads too long for the seed kernel's LDS layout"; return -1; }
+            const int blocks = (int)std::min<int64_t>(256, (n + waves - 1) / waves);
+#define MC_LAUNCH_EN(WV, CNT)                                                                                                                      \
+    do {                                                                                                                                           \
+        HIPCK(hipFuncSetAttribute((const void *)k_enumerate_t0<WV, CNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                  \
+        k_enumerate_t0<WV, CNT><<<dim3(blocks), dim3(64 * WV), lds2, st>>>(h->d_T, X, h->d_bitmap, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, \
+                                                                            h->d_counters, h->d_stats);                                           \
+    } while (0)
+            if (h->count_traffic) { if (waves == 14) MC_LAUNCH_EN(14, true); else if (waves == 12) MC_LAUNCH_EN(12, true); else if (waves == 8) MC_LAUNCH_EN(8, true); else MC_LAUNCH_EN(4, true); }
+            else { if (waves == 14) MC_LAUNCH_EN(14, false); else if (waves == 12) MC_LAUNCH_EN(12, false); else if (waves == 8) MC_LAUNCH_EN(8, false); else MC_LAUNCH_EN(4, false); }
+#undef MC_LAUNCH_EN
         } else
             k_enumerate<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, X, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, h->d_counters, h->d_stats);
         HIPCK(hipEventRecord(h->ev[2], st));
@@ -724,6 +835,13 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
     h->stats.gap_tasks = ngaps; h->stats.hsps = nh; h->stats.rows = nrows; h->stats.reads_with_rows = with_rows; h->stats.classified = (int64_t)h->best.size();
     h->stats.ms_translate = ev_ms(h->ev[0], h->ev[1]); h->stats.ms_seed = ev_ms(h->ev[1], h->ev[2]); h->stats.ms_eval = ev_ms(h->ev[2], h->ev[3]);
     h->stats.ms_gapped = ev_ms(h->ev[3], h->ev[4]); h->stats.ms_sort = ev_ms(h->ev[4], h->ev[5]); h->stats.ms_finish = ev_ms(h->ev[5], h->ev[6]); h->stats.ms_total = ev_ms(h->ev[0], h->ev[6]);
+    return 0;
+}
+
+extern "C" int mc_set_counting(mc_handle *h, int on)
+{
+    if (!h) { g_err = "null handle"; return -1; }
+    h->count_traffic = on != 0;
     return 0;
 }
 

@@ -24,6 +24,9 @@ struct McHostIndex {
     std::vector<uint32_t> off, bstart, post;
     std::vector<uint16_t> keys;
     std::vector<uint32_t> bitmap;      // 1 bit per bucket: non-empty
+    std::vector<McBucketRec> rec;      // first-residue group boundaries per bucket; empty when the index cannot use them
+    std::vector<uint32_t> filt;        // Bloom filter over (bucket, key) of the postings with a full 4-residue key
+    uint32_t max_bucket;
     uint32_t freq_thr;
     double letter_p[10];
     int64_t nres;
@@ -156,7 +159,7 @@ inline bool mc_build_index(McHostIndex &X, const char *const *names, const char 
         }
     }
     // suffix keys + bucket order (std::sort with CompDbObj, __introsort_loop@0x42f8d0)
-    X.keys.assign(X.post.size() + 64, 0xFFFF);   // +64: mc_key_range_scan reads whole 16-byte groups around a bucket
+    X.keys.assign(X.post.size() + 64, 0xFFFF);   // +64: mc_group_range8 reads whole words around a group
     X.bitmap.assign((MC_NBUCKET + 31) / 32, 0);
     std::vector<McPostKey> tmp;
     auto key_of = [&](uint32_t p) -> uint16_t {
@@ -183,6 +186,42 @@ inline bool mc_build_index(McHostIndex &X, const char *const *names, const char 
         mc44_sort(tmp.data(), tmp.data() + n, less);
         for (uint32_t i = 0; i < n; i++) { X.post[X.bstart[b] + i] = tmp[i].post; X.keys[X.bstart[b] + i] = tmp[i].key; }
     }
+    // first-residue group boundaries (McBucketRec).  Valid only if every bucket really is grouped that way and fits 16 bit.
+    {
+        X.rec.assign(MC_NBUCKET, McBucketRec());
+        X.max_bucket = 0;
+        for (int b = 0; b < MC_NBUCKET; b++) X.max_bucket = std::max(X.max_bucket, X.bstart[b + 1] - X.bstart[b]);
+        bool ok = true;
+        for (int b = 0; b < MC_NBUCKET && ok; b++) {
+            const uint32_t b0 = X.bstart[b], n = X.bstart[b + 1] - b0;
+            McBucketRec &R = X.rec[b];
+            memset(&R, 0, sizeof R);
+            R.start = b0;
+            if (n > 0xFFFF) { ok = false; break; }
+            int prev = -1;                                     // group of the previous posting: -1 = key FFFF, else first residue
+            uint32_t cnt[13]; memset(cnt, 0, sizeof cnt);
+            for (uint32_t i = 0; i < n; i++) {
+                const uint32_t k = X.keys[b0 + i];
+                const int g = (k == 0xFFFF) ? -1 : (int)(k >> 12);
+                if (g < prev || g > 10) { if (getenv("MC_DEBUG_REC")) fprintf(stderr, "rec: bucket %d posting %u key %04x after group %d (n %u)\n", b, i, k, prev, n); ok = false; break; }
+                prev = g;
+                cnt[g + 1]++;                                  // cnt[0] = sequence-end postings, cnt[1 + g] = group g
+            }
+            uint32_t run = cnt[0];
+            for (int g = 0; g < 11; g++) { R.cum[g] = (uint16_t)run; run += cnt[1 + g]; }   // group 10 = the invalid residue
+            R.cum[11] = (uint16_t)n;
+        }
+        if (!ok) X.rec.clear();
+    }
+    // 10-mer filter (mc_filter_hash): every posting whose key has 4 residues
+    X.filt.assign(MC_FILT_WORDS, 0);
+    for (int b = 0; b < MC_NBUCKET; b++)
+        for (uint32_t i = X.bstart[b]; i < X.bstart[b + 1]; i++) {
+            const uint32_t k = X.keys[i];
+            if ((k & 0xF) == 0xF) continue;                    // shorter key: never inside the range of a 10-mer probe
+            const uint32_t h = mc_filter_hash((uint32_t)b, k);
+            X.filt[mc_filter_word(h)] |= mc_filter_bits(h);
+        }
     // .info: median of ALL bucket sizes, reduced-letter frequencies
     { std::vector<uint32_t> c(MC_NBUCKET); for (int b = 0; b < MC_NBUCKET; b++) c[b] = X.bstart[b + 1] - X.bstart[b]; std::nth_element(c.begin(), c.begin() + (MC_NBUCKET >> 1), c.end()); X.freq_thr = c[MC_NBUCKET >> 1]; }
     { int64_t valid = 0; for (int g = 0; g < 10; g++) valid += gcount[g]; for (int g = 0; g < 10; g++) X.letter_p[g] = (double)gcount[g] / (double)valid; }

@@ -60,33 +60,43 @@ int main(int argc, char **argv)
         fclose(d);
     }
     if (getenv("MC_CHECK_SCAN")) {   // exhaustive: scan-based ranges == binary-search ranges for every key a query could match
-        McIndex Xc; Xc.res = H.res.data(); Xc.off = H.off.data(); Xc.bstart = H.bstart.data(); Xc.post = H.post.data(); Xc.keys = H.keys.data(); Xc.nseq = H.nseq;
-        long checked = 0, bad = 0;
+        McIndex Xc; Xc.res = H.res.data(); Xc.off = H.off.data(); Xc.bstart = H.bstart.data(); Xc.post = H.post.data(); Xc.keys = H.keys.data(); Xc.rec = H.rec.data(); Xc.filt = H.filt.data(); Xc.nseq = H.nseq;
+        if (H.rec.empty()) { fprintf(stderr, "scan check: the index has no bucket records\n"); return 3; }
+        fprintf(stderr, "largest bucket: %u postings\n", H.max_bucket);
+        long checked = 0, bad = 0, fneg = 0, fpos = 0, fq = 0;
         for (int b = 0; b < MC_NBUCKET; b++) {
             uint32_t n = H.bstart[b + 1] - H.bstart[b];
             for (uint32_t i = 0; i < n; i++) {
                 uint32_t k = H.keys[H.bstart[b] + i];
-                uint32_t cand[6]; int nc = 0;
+                uint32_t cand[8]; int nc = 0;
                 cand[nc++] = k; cand[nc++] = k | 0xF;                       // its 4- and 3-nibble query forms
                 cand[nc++] = (k & 0xFFF0) | ((k + 1) & 0xF); cand[nc++] = ((k + 0x1000) & 0xF000) | (k & 0x0FFF);   // near misses
-                cand[nc++] = (k & 0xFF0F) | 0xA0; cand[nc++] = (k & 0xF0FF) | 0x0A00;                                // keys holding the invalid group
+                cand[nc++] = (k & 0xFF0F) | 0xA0; cand[nc++] = (k & 0xF0FF) | 0x0A00; cand[nc++] = (k & 0x0FFF) | 0xA000;                                // keys holding the invalid group
                 for (int c = 0; c < nc; c++) {
                     uint32_t qk = cand[c] & 0xFFFF;
                     if (mc_klen(qk) < 3) continue;
-                    McSeedCount s1{0, 0}, s2{0, 0}; int n1 = 0, n2 = 0;
-                    int r1 = mc_key_range(Xc, b, qk, &n1, &s1), r2 = mc_key_range_scan(Xc, b, qk, &n2, &s2);
+                    McSeedCount s1{0, 0, 0}, s2{0, 0, 0}; int n1 = 0, n2 = 0;
+                    int r1 = mc_key_range(Xc, b, qk, &n1, &s1), r2 = mc_key_range_rec(Xc.rec, Xc.keys, b, qk, &n2, &s2);
                     checked++;
                     if (r1 != r2 || (r1 > 0 && n1 != n2) || s1.keyprobes != s2.keyprobes || s1.lookups != s2.lookups) bad++;
+                    if (mc_klen(qk) == 4) {                                   // 10-mer probe: the filter may not lose a range
+                        const uint32_t hh = mc_filter_hash((uint32_t)b, qk), bits = mc_filter_bits(hh);
+                        const bool pass = (H.filt[mc_filter_word(hh)] & bits) == bits;
+                        fq++;
+                        if (r1 > 0 && !pass) fneg++;
+                        if (r1 == 0 && pass) fpos++;
+                    }
                 }
             }
         }
         fprintf(stderr, "scan check: %ld probes, %ld mismatches\n", checked, bad);
-        return bad ? 3 : 0;
+        { long set = 0; for (uint32_t w : H.filt) set += __builtin_popcount(w); fprintf(stderr, "filter check: %ld 10-mer probes, %ld false negatives, %ld false positives among near misses, %.1f %% of the bits set\n", fq, fneg, fpos, 100.0 * (double)set / (32.0 * MC_FILT_WORDS)); }
+        return (bad || fneg) ? 3 : 0;
     }
     int read_len = rs.empty() ? 0 : (int)rs[0].size();
     static McTables T;
     mc_fill_tables(T, H, read_len, getenv("MC_LOGE_THR") ? atof(getenv("MC_LOGE_THR")) : 1.0);
-    McIndex X; X.res = H.res.data(); X.off = H.off.data(); X.bstart = H.bstart.data(); X.post = H.post.data(); X.keys = H.keys.data(); X.nseq = H.nseq;
+    McIndex X; X.res = H.res.data(); X.off = H.off.data(); X.bstart = H.bstart.data(); X.post = H.post.data(); X.keys = H.keys.data(); X.rec = H.rec.empty() ? nullptr : H.rec.data(); X.filt = H.filt.data(); X.nseq = H.nseq;
     McClassPars P; memset(&P, 0, sizeof P); P.nfam = 1; P.read_len = read_len;
     std::vector<int32_t> fam(H.nseq, 0);
 

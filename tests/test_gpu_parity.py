@@ -42,11 +42,18 @@ def engine():
     e.close()
 
 
+@pytest.mark.parametrize("counting", [False, True], ids=["filtered", "counting"])
 @pytest.mark.parametrize("case", ["config1_example_fq", "unittest_metagenome"])
-def test_m8_identical_to_reference(case, engine, tmp_path):
+def test_m8_identical_to_reference(case, counting, engine, tmp_path):
+    """Both forms of the seed kernel: the default one (10-mer Bloom filter in front of the range search) and the one
+    that also counts the reference algorithm's index reads (no filter: every probe is searched)."""
     reads, meta = golden_reads(case)
     engine.set_run(reads.shape[1])
-    rows, _ = engine.search(reads)
+    engine.set_counting(counting)
+    try:
+        rows, _ = engine.search(reads)
+    finally:
+        engine.set_counting(False)
     out = str(tmp_path / "out.m8")
     engine.write_m8(out)
     got = open(out, "rb").read()
@@ -54,3 +61,4 @@ def test_m8_identical_to_reference(case, engine, tmp_path):
     print(case, st)
     assert len(rows) == meta["m8_rows"]
     assert hashlib.md5(got).hexdigest() == meta["m8_md5"]
+    assert (st["bucket_lookups"] > 0 and st["key_probes"] > 0) if counting else (st["bucket_lookups"] == 0 and st["key_probes"] == 0)
