@@ -503,31 +503,34 @@ __global__ void k_gather(const McHsp *__restrict__ hsps, const uint32_t *__restr
 
 struct McSegInfo { uint32_t read, row_off, nrows, pad; };
 
-__global__ void __launch_bounds__(64) k_finish(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
-                                               const McHsp *__restrict__ sorted, uint32_t nhsps, const uint32_t *__restrict__ heads, uint32_t nheads,
-                                               McHsp *v, McHsp *tmp, McRow *rowscratch, double *kscratch, int64_t first_read_id,
-                                               McRow *rows, uint32_t cap_rows, McSegInfo *seginfo, McBestHit *best, uint32_t *counters)
+// One thread per read that has HSPs.  All scratch is addressed by the read's offset into the sorted HSP array (a read
+// never produces more rows than it has HSPs): v = the stacks, tmp = 2 HSP slots per HSP for the sum statistics, reused
+// afterwards for the read's rows and their merge keys (64 + 8 bytes per row <= 96).
+__global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
+                                                const McHsp *__restrict__ sorted, uint32_t nhsps, const uint32_t *__restrict__ heads, uint32_t nheads,
+                                                McHsp *v, McHsp *tmp, int64_t first_read_id,
+                                                McRow *rows, uint32_t cap_rows, McSegInfo *seginfo, McBestHit *best, uint32_t *counters)
 {
-    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
-    McRow *myrows = rowscratch + (size_t)tid * MC_MAX_M8;
-    double *myk = kscratch + (size_t)tid * MC_MAX_M8;
-    for (uint32_t s = tid; s < nheads; s += nthreads) {
-        uint32_t a = heads[s], b = a;
-        uint32_t read = sorted[a].read;
-        while (b < nhsps && sorted[b].read == read) b++;
-        int n = (int)(b - a);
-        McBestHit bh;
-        int nr = mc_finish_read(*T, X, *P, fam, (int)((int64_t)read + first_read_id), sorted + a, n, v + a, tmp + 2 * (size_t)a, myrows, myk, &bh);
-        McSegInfo si; si.read = read; si.nrows = (uint32_t)nr; si.row_off = 0; si.pad = 0;
-        if (nr > 0) {
-            uint32_t off = atomicAdd(&counters[C_ROWS], (uint32_t)nr);
-            si.row_off = off;
-            if (off + (uint32_t)nr <= cap_rows) { for (int i = 0; i < nr; i++) rows[off + i] = myrows[i]; }
-            else counters[C_OVERFLOW] = 4;
-        }
-        seginfo[s] = si;
-        best[s] = bh;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nheads) return;
+    const uint32_t a = heads[s];
+    uint32_t b = a;
+    const uint32_t read = sorted[a].read;
+    while (b < nhsps && sorted[b].read == read) b++;
+    const int n = (int)(b - a);
+    McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
+    double *myk = (double *)(myrows + n);
+    McBestHit bh;
+    const int nr = mc_finish_read(*T, X, *P, fam, (int)((int64_t)read + first_read_id), sorted + a, n, v + a, tmp + 2 * (size_t)a, myrows, myk, &bh);
+    McSegInfo si; si.read = read; si.nrows = (uint32_t)nr; si.row_off = 0; si.pad = 0;
+    if (nr > 0) {
+        const uint32_t off = atomicAdd(&counters[C_ROWS], (uint32_t)nr);
+        si.row_off = off;
+        if (off + (uint32_t)nr <= cap_rows) { for (int i = 0; i < nr; i++) rows[off + i] = myrows[i]; }
+        else counters[C_OVERFLOW] = 4;
     }
+    seginfo[s] = si;
+    best[s] = bh;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -558,9 +561,9 @@ struct mc_handle {
     uint32_t cap_tasks = 0, cap_gaps = 0, cap_hsps = 0, cap_rows = 0;
     uint64_t *d_k64 = nullptr, *d_k64o = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
     uint32_t *d_counters = nullptr;
-    McRow *d_rows = nullptr, *d_rowscratch = nullptr; double *d_kscratch = nullptr; McSegInfo *d_seginfo = nullptr; McBestHit *d_best = nullptr;
+    McRow *d_rows = nullptr; McSegInfo *d_seginfo = nullptr; McBestHit *d_best = nullptr;
     int *d_gH = nullptr, *d_gD = nullptr; McPath *d_gPH = nullptr, *d_gPD = nullptr;
-    int gap_threads = 0, fin_threads = 0;
+    int gap_threads = 0;
     // host results
     std::vector<mc_row> rows; std::vector<mc_best_hit> best; mc_stats stats;
 };
@@ -590,8 +593,8 @@ extern "C" void mc_close(mc_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_frames, h->d_tasks, h->d_gaps, h->d_hsps,
-                    h->d_sorted, h->d_v, h->d_tmp, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, h->d_heads, h->d_sorttmp, h->d_counters, h->d_rows, h->d_rowscratch,
-                    h->d_kscratch, h->d_seginfo, h->d_best, h->d_gH, h->d_gD, h->d_gPH, h->d_gPD, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt};
+                    h->d_sorted, h->d_v, h->d_tmp, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, h->d_heads, h->d_sorttmp, h->d_counters, h->d_rows,
+                    h->d_seginfo, h->d_best, h->d_gH, h->d_gD, h->d_gPH, h->d_gPD, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -681,12 +684,11 @@ static int ensure_capacity(mc_handle *h, int64_t nreads)
     h->cap_gaps = (uint32_t)std::min<int64_t>(cap * (L / 8 + 8) + (1 << 18), 0x7fffffff);
     h->cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 2 + 16) + (1 << 20), 0x7fffffff);
     h->cap_rows = (uint32_t)std::min<int64_t>(cap * 48 + (1 << 20), 0x7fffffff);
-    h->gap_threads = 64 * 1024; h->fin_threads = 16 * 1024;
+    h->gap_threads = 64 * 1024;
     if (dalloc(&h->d_frames, (size_t)cap * 6 * h->FP) || dalloc(&h->d_tasks, h->cap_tasks) ||
         dalloc(&h->d_gaps, h->cap_gaps) || dalloc(&h->d_hsps, h->cap_hsps) || dalloc(&h->d_sorted, h->cap_hsps) || dalloc(&h->d_v, h->cap_hsps) ||
         dalloc(&h->d_tmp, (size_t)h->cap_hsps * 2) || dalloc(&h->d_k64, h->cap_hsps) || dalloc(&h->d_k64o, h->cap_hsps) || dalloc(&h->d_idx, h->cap_hsps) ||
         dalloc(&h->d_idxo, h->cap_hsps) || dalloc(&h->d_heads, (size_t)cap + 1) || dalloc(&h->d_rows, h->cap_rows) ||
-        dalloc(&h->d_rowscratch, (size_t)h->fin_threads * MC_MAX_M8) || dalloc(&h->d_kscratch, (size_t)h->fin_threads * MC_MAX_M8) ||
         dalloc(&h->d_seginfo, (size_t)cap + 1) || dalloc(&h->d_best, (size_t)cap + 1) || dalloc(&h->d_gH, (size_t)h->gap_threads * MC_GAP_W) ||
         dalloc(&h->d_gD, (size_t)h->gap_threads * MC_GAP_W) || dalloc(&h->d_gPH, (size_t)h->gap_threads * MC_GAP_W) || dalloc(&h->d_gPD, (size_t)h->gap_threads * MC_GAP_W))
         return -1;
@@ -797,9 +799,8 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
         nheads = c[C_HEADS];
-        int blocks = std::min<int>(h->fin_threads / 64, (int)((nheads + 63) / 64));
-        k_finish<<<dim3(blocks), dim3(64), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp, h->d_rowscratch, h->d_kscratch,
-                                                      first_read_id, h->d_rows, h->cap_rows, h->d_seginfo, h->d_best, h->d_counters);
+        k_finish<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp,
+                                                                    first_read_id, h->d_rows, h->cap_rows, h->d_seginfo, h->d_best, h->d_counters);
         HIPCK(hipEventRecord(h->ev[6], st));
         HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
