@@ -149,7 +149,7 @@ def main():
     def step(i):
         b = i % nres
         eng.run_range(b * args.batch, args.batch, first_read_id=b * args.batch)
-        _, best = eng.results()
+        best = eng.best_hits(copy=False)    # the rows of the batch are in host memory too (mc_result_rows); the aggregation needs the best hits
         c = np.bincount(best["family"], minlength=len(fams)).astype(np.int64)
         t = torch.from_numpy(c).to(dev)
         if world > 1:

@@ -169,12 +169,26 @@ class Engine:
     def run_range(self, first, count, first_read_id=0):
         self._check(self.lib.mc_run_range(self.h, first, count, first_read_id), "mc_run_range")
 
+    def rows(self, copy=True):
+        """m8 rows of the last run (structured array).  copy=False returns a view of the handle's buffer, valid until the next call."""
+        pr = C.POINTER(McRow)()
+        n = self.lib.mc_result_rows(self.h, C.byref(pr))
+        if not n:
+            return np.zeros(0, ROW_DTYPE)
+        a = np.ctypeslib.as_array(C.cast(pr, C.POINTER(C.c_uint8)), shape=(n * C.sizeof(McRow),)).view(ROW_DTYPE)
+        return a.copy() if copy else a
+
+    def best_hits(self, copy=True):
+        """best hit per classified read of the last run, ascending read id."""
+        pb = C.POINTER(McBestHit)()
+        m = self.lib.mc_result_best_hits(self.h, C.byref(pb))
+        if not m:
+            return np.zeros(0, BEST_DTYPE)
+        a = np.ctypeslib.as_array(C.cast(pb, C.POINTER(C.c_uint8)), shape=(m * C.sizeof(McBestHit),)).view(BEST_DTYPE)
+        return a.copy() if copy else a
+
     def results(self):
-        pr = C.POINTER(McRow)(); pb = C.POINTER(McBestHit)()
-        n = self.lib.mc_result_rows(self.h, C.byref(pr)); m = self.lib.mc_result_best_hits(self.h, C.byref(pb))
-        rows = np.ctypeslib.as_array(C.cast(pr, C.POINTER(C.c_uint8)), shape=(n * C.sizeof(McRow),)).view(ROW_DTYPE).copy() if n else np.zeros(0, ROW_DTYPE)
-        best = np.ctypeslib.as_array(C.cast(pb, C.POINTER(C.c_uint8)), shape=(m * C.sizeof(McBestHit),)).view(BEST_DTYPE).copy() if m else np.zeros(0, BEST_DTYPE)
-        return rows, best
+        return self.rows(), self.best_hits()
 
     def stats(self):
         s = McStats()

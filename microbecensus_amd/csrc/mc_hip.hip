@@ -9,6 +9,7 @@
 //   k_finish          1 thread / read with HSPs  linking, ranking, cap, classification   -> rows, best hits
 // The per-thread algorithms live in mc_core.h / mc_finish.h; see include/mcensus.h for what each entry
 // point replaces in the reference.
+#include <cstddef>
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +24,10 @@
 #include "mc_finish.h"
 #include "mc_index.h"
 
+static_assert(sizeof(McRow) == sizeof(mc_row) && offsetof(McRow, ident) == offsetof(mc_row, ident) && offsetof(McRow, loge) == offsetof(mc_row, loge) &&
+                  offsetof(McRow, score) == offsetof(mc_row, score) && offsetof(McRow, frame) == offsetof(mc_row, nmatch),
+              "the device row is handed out as the ABI row");
+
 static thread_local std::string g_err;
 extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
 
@@ -35,7 +40,7 @@ extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
         }                                                                                                   \
     } while (0)
 
-enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_N = 8 };
+enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_N = 8 };
 enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_N = 4 };   // 64-bit algorithmic-traffic counters of k_enumerate
 
 // ------------------------------------------------------------------------------------------------
@@ -491,25 +496,32 @@ __global__ void k_make_keys(const McHsp *__restrict__ hsps, uint32_t n, uint64_t
     keys[tid] = ((uint64_t)h.read << 43) | ((uint64_t)(uint32_t)h.sidx << 28) | (uint64_t)h.chrono;
     idx[tid] = tid;
 }
-__global__ void k_gather(const McHsp *__restrict__ hsps, const uint32_t *__restrict__ idx, uint32_t n, McHsp *out, uint32_t *heads, uint32_t *counters)
+// sorted order: copies the HSPs and flags the first HSP of every read
+__global__ void k_gather(const McHsp *__restrict__ hsps, const uint32_t *__restrict__ idx, uint32_t n, McHsp *out, uint32_t *flags)
 {
     uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= n) return;
     McHsp h = hsps[idx[tid]];
     out[tid] = h;
-    bool head = (tid == 0) || (hsps[idx[tid - 1]].read != h.read);
-    if (head) heads[atomicAdd(&counters[C_HEADS], 1u)] = tid;
+    flags[tid] = ((tid == 0) || (hsps[idx[tid - 1]].read != h.read)) ? 1u : 0u;
+}
+// heads[k] = index of the first HSP of the k-th read that has HSPs (ascending read id); hpos = exclusive scan of flags
+__global__ void k_heads(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ hpos, uint32_t n, uint32_t *heads, uint32_t *counters)
+{
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n) return;
+    if (flags[tid]) heads[hpos[tid]] = tid;
+    if (tid == n - 1) counters[C_HEADS] = hpos[tid] + flags[tid];
 }
 
-struct McSegInfo { uint32_t read, row_off, nrows, pad; };
 
-// One thread per read that has HSPs.  All scratch is addressed by the read's offset into the sorted HSP array (a read
-// never produces more rows than it has HSPs): v = the stacks, tmp = 2 HSP slots per HSP for the sum statistics, reused
-// afterwards for the read's rows and their merge keys (64 + 8 bytes per row <= 96).
+// One thread per read that has HSPs, in ascending read order.  All scratch is addressed by the read's offset into the
+// sorted HSP array (a read never produces more rows than it has HSPs): v = the stacks, tmp = 2 HSP slots per HSP for the
+// sum statistics, reused afterwards for the read's rows and their merge keys (64 + 8 bytes per row <= 96).  The rows
+// stay in that scratch; k_emit_rows moves them to their final place once the row counts have been scanned.
 __global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
                                                 const McHsp *__restrict__ sorted, uint32_t nhsps, const uint32_t *__restrict__ heads, uint32_t nheads,
-                                                McHsp *v, McHsp *tmp, int64_t first_read_id,
-                                                McRow *rows, uint32_t cap_rows, McSegInfo *seginfo, McBestHit *best, uint32_t *counters)
+                                                McHsp *v, McHsp *tmp, int64_t first_read_id, uint32_t *nrow_of, McBestHit *best, uint32_t *counters)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nheads) return;
@@ -522,15 +534,21 @@ __global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, 
     double *myk = (double *)(myrows + n);
     McBestHit bh;
     const int nr = mc_finish_read(*T, X, *P, fam, (int)((int64_t)read + first_read_id), sorted + a, n, v + a, tmp + 2 * (size_t)a, myrows, myk, &bh);
-    McSegInfo si; si.read = read; si.nrows = (uint32_t)nr; si.row_off = 0; si.pad = 0;
-    if (nr > 0) {
-        const uint32_t off = atomicAdd(&counters[C_ROWS], (uint32_t)nr);
-        si.row_off = off;
-        if (off + (uint32_t)nr <= cap_rows) { for (int i = 0; i < nr; i++) rows[off + i] = myrows[i]; }
-        else counters[C_OVERFLOW] = 4;
-    }
-    seginfo[s] = si;
-    best[s] = bh;
+    nrow_of[s] = (uint32_t)nr;
+    if (nr > 0) atomicAdd(&counters[C_SEGS], 1u);
+    if (bh.family >= 0) best[atomicAdd(&counters[C_BEST], 1u)] = bh;       // few; the host orders them by read
+}
+// rows of read s -> rows[rowoff[s] ...]: the m8 order (ascending read, RAPsearch2's order inside a read)
+__global__ void __launch_bounds__(256) k_emit_rows(const uint32_t *__restrict__ heads, uint32_t nheads, const uint32_t *__restrict__ nrow_of, const uint32_t *__restrict__ rowoff,
+                                                   const McHsp *__restrict__ tmp, McRow *__restrict__ rows, uint32_t cap_rows, uint32_t *counters)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nheads) return;
+    const uint32_t nr = nrow_of[s], off = rowoff[s];
+    if (s == nheads - 1) { counters[C_ROWS] = off + nr; if (off + nr > cap_rows) counters[C_OVERFLOW] = 4; }
+    if (off + nr > cap_rows) return;
+    const McRow *src = (const McRow *)(tmp + 2 * (size_t)heads[s]);
+    for (uint32_t i = 0; i < nr; i++) rows[off + i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -561,11 +579,14 @@ struct mc_handle {
     uint32_t cap_tasks = 0, cap_gaps = 0, cap_hsps = 0, cap_rows = 0;
     uint64_t *d_k64 = nullptr, *d_k64o = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
     uint32_t *d_counters = nullptr;
-    McRow *d_rows = nullptr; McSegInfo *d_seginfo = nullptr; McBestHit *d_best = nullptr;
+    McRow *d_rows = nullptr; uint32_t *d_nrow = nullptr, *d_rowoff = nullptr; McBestHit *d_best = nullptr;
     int *d_gH = nullptr, *d_gD = nullptr; McPath *d_gPH = nullptr, *d_gPD = nullptr;
     int gap_threads = 0;
-    // host results
-    std::vector<mc_row> rows; std::vector<mc_best_hit> best; mc_stats stats;
+    // host results: rows of the last batch land in pinned memory; mc_search() accumulates its batches in all_rows
+    mc_row *pin_rows = nullptr; size_t pin_cap = 0;
+    std::vector<mc_row> all_rows;
+    const mc_row *res_rows = nullptr; int64_t n_res_rows = 0;
+    std::vector<mc_best_hit> best; mc_stats stats;
 };
 
 static McIndex dev_index(const mc_handle *h)
@@ -594,8 +615,9 @@ extern "C" void mc_close(mc_handle *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_frames, h->d_tasks, h->d_gaps, h->d_hsps,
                     h->d_sorted, h->d_v, h->d_tmp, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, h->d_heads, h->d_sorttmp, h->d_counters, h->d_rows,
-                    h->d_seginfo, h->d_best, h->d_gH, h->d_gD, h->d_gPH, h->d_gPD, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt};
+                    h->d_nrow, h->d_rowoff, h->d_best, h->d_gH, h->d_gD, h->d_gPH, h->d_gPD, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (h->pin_rows) (void)hipHostFree(h->pin_rows);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -689,11 +711,13 @@ static int ensure_capacity(mc_handle *h, int64_t nreads)
         dalloc(&h->d_gaps, h->cap_gaps) || dalloc(&h->d_hsps, h->cap_hsps) || dalloc(&h->d_sorted, h->cap_hsps) || dalloc(&h->d_v, h->cap_hsps) ||
         dalloc(&h->d_tmp, (size_t)h->cap_hsps * 2) || dalloc(&h->d_k64, h->cap_hsps) || dalloc(&h->d_k64o, h->cap_hsps) || dalloc(&h->d_idx, h->cap_hsps) ||
         dalloc(&h->d_idxo, h->cap_hsps) || dalloc(&h->d_heads, (size_t)cap + 1) || dalloc(&h->d_rows, h->cap_rows) ||
-        dalloc(&h->d_seginfo, (size_t)cap + 1) || dalloc(&h->d_best, (size_t)cap + 1) || dalloc(&h->d_gH, (size_t)h->gap_threads * MC_GAP_W) ||
+        dalloc(&h->d_nrow, (size_t)cap + 1) || dalloc(&h->d_rowoff, (size_t)cap + 1) || dalloc(&h->d_best, (size_t)cap + 1) || dalloc(&h->d_gH, (size_t)h->gap_threads * MC_GAP_W) ||
         dalloc(&h->d_gD, (size_t)h->gap_threads * MC_GAP_W) || dalloc(&h->d_gPH, (size_t)h->gap_threads * MC_GAP_W) || dalloc(&h->d_gPD, (size_t)h->gap_threads * MC_GAP_W))
         return -1;
-    size_t bytes = 0;
+    size_t bytes = 0, bytes2 = 0;
     HIPCK(rocprim::radix_sort_pairs(nullptr, bytes, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, (size_t)h->cap_hsps, 0, 64, h->stream));
+    HIPCK(rocprim::exclusive_scan(nullptr, bytes2, h->d_idx, h->d_idxo, 0u, (size_t)h->cap_hsps, rocprim::plus<uint32_t>(), h->stream));
+    bytes = std::max(bytes, bytes2);
     if (h->d_sorttmp) { (void)hipFree(h->d_sorttmp); h->d_sorttmp = nullptr; }
     HIPCK(hipMalloc(&h->d_sorttmp, bytes + 16));
     h->sorttmp_bytes = bytes;
@@ -734,7 +758,7 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
     McIndex X = dev_index(h);
     uint32_t c[C_N];
     memset(&h->stats, 0, sizeof h->stats);
-    h->rows.clear(); h->best.clear();
+    h->res_rows = nullptr; h->n_res_rows = 0; h->best.clear();
     h->stats.reads = n;
     if (n == 0) return 0;
     HIPCK(hipMemsetAsync(h->d_counters, 0, sizeof(uint32_t) * C_N, st));
@@ -787,51 +811,52 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
     if (c[C_OVERFLOW]) { g_err = "HSP buffer overflow"; return -2; }
     uint32_t nh = c[C_HSPS];
     uint32_t nheads = 0, nrows = 0;
-    std::vector<McSegInfo> seg;
     std::vector<McBestHit> bh;
-    std::vector<McRow> rows;
+    int64_t with_rows = 0;
     if (nh) {
+        uint32_t *d_flags = h->d_idx, *d_hpos = (uint32_t *)h->d_k64;      // both free once the sort has run
         k_make_keys<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(h->d_hsps, nh, h->d_k64, h->d_idx);
         size_t bytes = h->sorttmp_bytes;
         HIPCK(rocprim::radix_sort_pairs(h->d_sorttmp, bytes, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, (size_t)nh, 0, 64, st));
-        k_gather<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(h->d_hsps, h->d_idxo, nh, h->d_sorted, h->d_heads, h->d_counters);
+        k_gather<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(h->d_hsps, h->d_idxo, nh, h->d_sorted, d_flags);
+        bytes = h->sorttmp_bytes;
+        HIPCK(rocprim::exclusive_scan(h->d_sorttmp, bytes, d_flags, d_hpos, 0u, (size_t)nh, rocprim::plus<uint32_t>(), st));
+        k_heads<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(d_flags, d_hpos, nh, h->d_heads, h->d_counters);
         HIPCK(hipEventRecord(h->ev[5], st));
         HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
         nheads = c[C_HEADS];
         k_finish<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp,
-                                                                    first_read_id, h->d_rows, h->cap_rows, h->d_seginfo, h->d_best, h->d_counters);
+                                                                    first_read_id, h->d_nrow, h->d_best, h->d_counters);
+        bytes = h->sorttmp_bytes;
+        HIPCK(rocprim::exclusive_scan(h->d_sorttmp, bytes, h->d_nrow, h->d_rowoff, 0u, (size_t)nheads, rocprim::plus<uint32_t>(), st));
+        k_emit_rows<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_heads, nheads, h->d_nrow, h->d_rowoff, h->d_tmp, h->d_rows, h->cap_rows, h->d_counters);
         HIPCK(hipEventRecord(h->ev[6], st));
         HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
         if (c[C_OVERFLOW]) { g_err = "row buffer overflow"; return -2; }
-        nrows = c[C_ROWS];
-        seg.resize(nheads); bh.resize(nheads); rows.resize(nrows);
-        HIPCK(hipMemcpy(seg.data(), h->d_seginfo, sizeof(McSegInfo) * nheads, hipMemcpyDeviceToHost));
-        HIPCK(hipMemcpy(bh.data(), h->d_best, sizeof(McBestHit) * nheads, hipMemcpyDeviceToHost));
-        if (nrows) HIPCK(hipMemcpy(rows.data(), h->d_rows, sizeof(McRow) * nrows, hipMemcpyDeviceToHost));
+        nrows = c[C_ROWS]; with_rows = c[C_SEGS];
+        bh.resize(c[C_BEST]);
+        if (nrows > h->pin_cap) {
+            if (h->pin_rows) { (void)hipHostFree(h->pin_rows); h->pin_rows = nullptr; h->pin_cap = 0; }
+            const size_t want = (size_t)nrows + (size_t)nrows / 4 + 1024;
+            HIPCK(hipHostMalloc((void **)&h->pin_rows, want * sizeof(mc_row), hipHostMallocDefault));
+            h->pin_cap = want;
+        }
+        // rows arrive in their final order and layout (McRow == mc_row): one copy into pinned memory
+        if (nrows) HIPCK(hipMemcpyAsync(h->pin_rows, h->d_rows, sizeof(McRow) * nrows, hipMemcpyDeviceToHost, st));
+        if (!bh.empty()) HIPCK(hipMemcpyAsync(bh.data(), h->d_best, sizeof(McBestHit) * bh.size(), hipMemcpyDeviceToHost, st));
+        HIPCK(hipStreamSynchronize(st));
     } else {
         HIPCK(hipEventRecord(h->ev[5], st));
         HIPCK(hipEventRecord(h->ev[6], st));
         HIPCK(hipStreamSynchronize(st));
     }
-    // assemble results in read order
-    std::vector<uint32_t> order(nheads);
-    for (uint32_t i = 0; i < nheads; i++) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return seg[a].read < seg[b].read; });
-    h->rows.reserve(nrows);
-    int64_t with_rows = 0;
-    for (uint32_t oi : order) {
-        const McSegInfo &s = seg[oi];
-        if (s.nrows) with_rows++;
-        for (uint32_t i = 0; i < s.nrows; i++) {
-            const McRow &r = rows[s.row_off + i];
-            mc_row o; o.query = r.query; o.subject = r.subject; o.ident = r.ident; o.alnlen = r.alnlen; o.mismatch = r.mismatch; o.gapopen = r.gapopen;
-            o.qstart = r.qstart; o.qend = r.qend; o.sstart = r.sstart; o.send = r.send; o.loge = r.loge; o.bits = r.bits; o.score = r.score; o.nmatch = r.frame;
-            h->rows.push_back(o);
-        }
-        if (bh[oi].family >= 0) { mc_best_hit b; b.read = bh[oi].read; b.family = bh[oi].family; b.aln = bh[oi].aln; b.target_len = bh[oi].target_len; b.bits = bh[oi].bits; h->best.push_back(b); }
-    }
+    h->res_rows = h->pin_rows; h->n_res_rows = nrows;
+    // classify_reads meets the reads in input order
+    std::sort(bh.begin(), bh.end(), [](const McBestHit &x, const McBestHit &y) { return x.read < y.read; });
+    h->best.reserve(bh.size());
+    for (const McBestHit &x : bh) { mc_best_hit o; o.read = x.read; o.family = x.family; o.aln = x.aln; o.target_len = x.target_len; o.bits = x.bits; h->best.push_back(o); }
     { unsigned long long ss[S_N]; HIPCK(hipMemcpy(ss, h->d_stats, sizeof ss, hipMemcpyDeviceToHost)); h->stats.bucket_lookups = (int64_t)ss[S_LOOKUPS]; h->stats.key_probes = (int64_t)ss[S_KEYPROBES]; h->stats.seed_tasks = (int64_t)ss[S_TASKS]; }
     h->stats.gap_tasks = ngaps; h->stats.hsps = nh; h->stats.rows = nrows; h->stats.reads_with_rows = with_rows; h->stats.classified = (int64_t)h->best.size();
     h->stats.ms_translate = ev_ms(h->ev[0], h->ev[1]); h->stats.ms_seed = ev_ms(h->ev[1], h->ev[2]); h->stats.ms_eval = ev_ms(h->ev[2], h->ev[3]);
@@ -852,7 +877,8 @@ extern "C" int mc_search(mc_handle *h, const uint8_t *reads, int64_t nreads, int
 {
     if (!h || !h->run_set) { g_err = "mc_set_run() must be called first"; return -1; }
     const int64_t B = 1 << 20;
-    std::vector<mc_row> all_rows; std::vector<mc_best_hit> all_best; mc_stats tot; memset(&tot, 0, sizeof tot);
+    std::vector<mc_row> &all_rows = h->all_rows; all_rows.clear();
+    std::vector<mc_best_hit> all_best; mc_stats tot; memset(&tot, 0, sizeof tot);
     if (mc_upload(h, reads, nreads)) return -1;
     int64_t off = 0, step = B;
     while (off < nreads || (nreads == 0 && off == 0)) {
@@ -860,7 +886,7 @@ extern "C" int mc_search(mc_handle *h, const uint8_t *reads, int64_t nreads, int
         int rc = mc_run_range(h, off, nb, first_read_id + off);
         if (rc == -2 && nb > 1) { step = std::max<int64_t>(1, nb / 2); continue; }   // a pool overflowed: retry with half the batch
         if (rc) return rc;
-        all_rows.insert(all_rows.end(), h->rows.begin(), h->rows.end());
+        all_rows.insert(all_rows.end(), h->res_rows, h->res_rows + h->n_res_rows);
         all_best.insert(all_best.end(), h->best.begin(), h->best.end());
         tot.reads += h->stats.reads; tot.seed_tasks += h->stats.seed_tasks; tot.gap_tasks += h->stats.gap_tasks; tot.hsps += h->stats.hsps; tot.rows += h->stats.rows;
         tot.reads_with_rows += h->stats.reads_with_rows; tot.classified += h->stats.classified; tot.bucket_lookups += h->stats.bucket_lookups; tot.key_probes += h->stats.key_probes;
@@ -870,11 +896,11 @@ extern "C" int mc_search(mc_handle *h, const uint8_t *reads, int64_t nreads, int
         off += nb;
         if (step < B) step = std::min<int64_t>(B, step * 2);
     }
-    h->rows.swap(all_rows); h->best.swap(all_best); h->stats = tot;
+    h->res_rows = all_rows.data(); h->n_res_rows = (int64_t)all_rows.size(); h->best.swap(all_best); h->stats = tot;
     return 0;
 }
 
-extern "C" int64_t mc_result_rows(mc_handle *h, const mc_row **rows) { if (!h) return -1; *rows = h->rows.data(); return (int64_t)h->rows.size(); }
+extern "C" int64_t mc_result_rows(mc_handle *h, const mc_row **rows) { if (!h) return -1; *rows = h->res_rows; return h->n_res_rows; }
 extern "C" int64_t mc_result_best_hits(mc_handle *h, const mc_best_hit **hits) { if (!h) return -1; *hits = h->best.data(); return (int64_t)h->best.size(); }
 extern "C" int mc_result_stats(mc_handle *h, mc_stats *out) { if (!h) return -1; *out = h->stats; return 0; }
 
@@ -883,9 +909,11 @@ extern "C" int mc_write_m8(mc_handle *h, const char *path, int append)
     if (!h) { g_err = "null handle"; return -1; }
     FILE *f = fopen(path, append ? "a" : "w");
     if (!f) { g_err = std::string("cannot open ") + path; return -1; }
-    for (const mc_row &r : h->rows)
+    for (int64_t i = 0; i < h->n_res_rows; i++) {
+        const mc_row &r = h->res_rows[i];
         fprintf(f, "%d\t%s\t%g\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%g\t%g\n", r.query, h->H.names[r.subject].c_str(), r.ident, r.alnlen, r.mismatch, r.gapopen, r.qstart, r.qend,
                 r.sstart, r.send, r.loge, r.bits);
+    }
     fclose(f);
     return 0;
 }
