@@ -38,6 +38,7 @@ inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { uint4 
 
 #define MC_GAP_OPEN 11
 #define MC_GAP_EXT 1
+#define MC_SEG_FXBITS 24
 #define MC_SEED_SCORE 11.0
 #define MC_SEED_IDENT 4
 
@@ -51,6 +52,9 @@ struct McTables {
     double entray[2][16];      // Seg::entropy_init@0x439090 for W = 12 / 8
     double lterm[13][16];      // log((1/total)*c)*c, Seg::entropy_cal@0x438f70 general branch
     double lnfac[MC_LNFAC_N];  // lnfac@0x688c40
+    // fixed-point form of the window-entropy tests (mc_seg_mask_fx): seg_f[c] = c*log2(c), seg_tlo/thi[t] = t*(log2(t) - 2.2 / 2.5),
+    // all scaled by 2^MC_SEG_FXBITS; seg_dout[c] = seg_f[c-1] - seg_f[c], seg_din[c] = seg_f[c+1] - seg_f[c]
+    int32_t seg_dout[16], seg_din[16], seg_tlo[16], seg_thi[16];   // contiguous: read as one array of 64
     double xdrop_ungapped, xdrop_gapped, gap_trigger;   // this+0x40388, +0x40398, +0x40378
     // per run (query length m = read_len/3): BlastStat state after blastComputeLengthAdjustmentComp
     double ell, mprime, nprime, logK;
@@ -344,6 +348,77 @@ MC_HDN void mc_seg_mask_ws(const McTables &T, uint8_t *prot, int n, const McSegW
                     mc_seg_shift(ws.comp, ws.sv, s[start], s[start + W]);
                     start++;
                     ent = mc_seg_entropy(T, W, ws.sv);
+                }
+            }
+            if (!anylo) continue;
+        }
+        int last = m - 1, lowlim = 0;
+        for (int i = 0; i <= last; i++) {
+            if (mc_bits_test(lo, i)) {
+                int j, loi, hii, leftend, rightend;
+                for (j = i; j >= lowlim; j--) { if (!mc_bits_test(hi, j)) break; }
+                loi = j + 1;
+                for (j = i; j <= last; j++) { if (!mc_bits_test(hi, j)) break; }
+                hii = j - 1;
+                leftend = loi; rightend = hii;
+                mc_seg_trim_ws(T, s + leftend, rightend - leftend + 1, &leftend, &rightend, ws);
+                if (i < leftend) {
+                    int lend = loi, rend = leftend - 1;
+                    if (sp < 8) { ws.stk[2 * sp] = (int16_t)(base + lend); ws.stk[2 * sp + 1] = (int16_t)(rend - lend + 1); sp++; }
+                }
+                for (j = leftend; j <= rightend; j++) mc_bits_set(mk, base + j);
+                any = true;
+                i = (hii < rightend) ? hii : rightend;
+                lowlim = i + 1;
+            }
+        }
+    }
+    if (any) for (int i = 0; i < n; i++) if (mc_bits_test(mk, i)) prot[i] = MC_INV;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SEG as the kernel runs it.  Same segmentation as mc_seg_mask_ws, but the entropy of the sliding window is never
+// evaluated: with S = sum over residue classes of c*log2(c) and t = number of valid residues in the window,
+//     H = log2(t) - S/t,   so   H <= cut   <=>   S >= t*(log2(t) - cut).
+// S is kept in fixed point and updated when a residue leaves / enters the window (two table reads), the two cuts become
+// two integer compares against per-t constants.  mc_seg_fx_verify (mc_index.h; run by mc_set_run and by the tests) checks
+// over every composition a window can have - every partition of every t <= W - that the integer tests decide exactly
+// like the reference's double arithmetic (Seg::entropy_cal@0x438f70), including the compositions whose entropy equals a
+// cut (e.g. 2,2,1,1,1,1: exactly 2.5).  The rare low-complexity stretches go through the
+// same trimming code as before (mc_seg_trim_ws, double precision).  Workspace: comp[20] and the stack; sv is only
+// touched by the trimming.
+// ---------------------------------------------------------------------------------------------
+MC_HDN void mc_seg_mask_fx(const McTables &T, const int32_t *fx /* seg_dout, seg_din, seg_tlo, seg_thi: 4 x 16 */, uint8_t *prot, int n, const McSegWS &ws)
+{
+    const int W = (n <= 11) ? 8 : 12;
+    McBits192 lo, hi, mk;
+    mc_bits_clear(mk);
+    if (W > n) return;
+    int sp = 1;
+    ws.stk[0] = 0; ws.stk[1] = (int16_t)n;
+    bool any = false;
+    while (sp > 0) {
+        sp--;
+        const int base = ws.stk[2 * sp], m = ws.stk[2 * sp + 1];
+        const uint8_t *s = prot + base;
+        if (W > m) continue;
+        mc_bits_clear(lo); mc_bits_clear(hi);
+        {
+            bool anylo = false;
+            int S = 0, t = 0;
+            for (int i = 0; i < 20; i++) ws.comp[i] = 0;
+            for (int i = 0; i < W; i++) { const int r = s[i]; if (r < 20) { const int c = ws.comp[r]; S += fx[16 + c]; ws.comp[r] = (uint8_t)(c + 1); t++; } }
+            int start = 0;
+            bool l = S >= fx[32 + t], h = S >= fx[48 + t];
+            for (int i = 0; i <= m - 1; i++) {
+                if (l) { mc_bits_set(lo, i); anylo = true; }
+                if (h) mc_bits_set(hi, i);
+                if (start + 1 + W <= m) {
+                    const int o = s[start], e = s[start + W];
+                    if (o < 20) { const int c = ws.comp[o]; S += fx[c]; ws.comp[o] = (uint8_t)(c - 1); t--; }
+                    if (e < 20) { const int c = ws.comp[e]; S += fx[16 + c]; ws.comp[e] = (uint8_t)(c + 1); t++; }
+                    start++;
+                    l = S >= fx[32 + t]; h = S >= fx[48 + t];
                 }
             }
             if (!anylo) continue;

@@ -51,6 +51,9 @@ enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_N = 4 };   // 64-bit algorithmic-t
 // (composition / state vector / work list in LDS, the window flags in registers) and the block writes the frames back
 // with coalesced stores.  LDS per block: 42*L + 256*(FP+76) bytes (~40 KB at 150 bp).
 #define MC_TS_READS 42
+// row pitch: an odd number of 32-bit words, so that the 64 lanes of a wave touching the same offset of their rows
+// fall into different LDS banks (a pitch of 128 bytes put all of them into one)
+#define MC_TS_STRIDE(FP) (((((FP) + 76 + 3) >> 2) | 1) << 2)
 __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restrict__ T, const uint8_t *__restrict__ reads, int L,
                                                        int64_t nreads, uint8_t *__restrict__ frames, int FP)
 {
@@ -59,9 +62,11 @@ __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restric
     const int64_t r0 = (int64_t)blockIdx.x * MC_TS_READS;
     const int nr = (int)((nreads - r0) < MC_TS_READS ? (nreads - r0) : MC_TS_READS);
     const int rbytes = nr * L;
-    const int stride = (FP + 76 + 3) & ~3;                       // per-thread LDS row: prot[FP] comp[20] sv[24] stk[32]
+    const int stride = MC_TS_STRIDE(FP);                         // per-thread LDS row: prot[FP] comp[20] sv[24] stk[32]
+    __shared__ int32_t fxs[64];                                  // fixed-point entropy tables of mc_seg_mask_fx
     uint8_t *sreads = smem;
     uint8_t *rows = smem + (((MC_TS_READS * L) + 15) & ~15);
+    if (tid < 64) fxs[tid] = T->seg_dout[tid];                   // seg_dout, seg_din, seg_tlo, seg_thi are contiguous
     {   // coalesced staging of this block's reads (the block's slice starts at r0*L, not necessarily 16-byte aligned)
         const uint8_t *src = reads + r0 * L;
         for (int i = tid; i < rbytes; i += 256) sreads[i] = src[i];
@@ -73,7 +78,7 @@ __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restric
     if (lr < nr) {
         n = mc_translate_frame(*T, sreads + lr * L, L, f, prot);
         McSegWS ws; ws.comp = prot + FP; ws.sv = prot + FP + 20; ws.stk = (int16_t *)(prot + FP + 44);
-        mc_seg_mask_ws(*T, prot, n, ws);
+        mc_seg_mask_fx(*T, fxs, prot, n, ws);
         for (int i = n; i < FP; i++) prot[i] = MC_INV;
     }
     __syncthreads();
@@ -684,6 +689,7 @@ extern "C" int mc_set_run(mc_handle *h, int32_t read_len, double loge_thr, const
     if (read_len < 18 || read_len > 3 * MC_MAXAA) { g_err = "read_len out of range (18..510)"; return -1; }
     HIPCK(hipSetDevice(h->device));
     mc_fill_tables(h->hT, h->H, read_len, loge_thr);
+    if (mc_seg_fx_verify(h->hT, nullptr) != 0) { g_err = "internal: the fixed-point SEG tests disagree with the reference arithmetic"; return -1; }
     memset(&h->hP, 0, sizeof h->hP);
     h->hP.nfam = h->nfam; h->hP.read_len = read_len;
     for (int f = 0; f < h->nfam; f++) { h->hP.min_cov[f] = min_cov[f]; h->hP.min_score[f] = min_score[f]; h->hP.max_aaid[f] = max_aaid[f]; h->hP.aln_stat[f] = aln_stat[f]; }
@@ -766,7 +772,7 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
     HIPCK(hipEventRecord(h->ev[0], st));
     {
         const int64_t threads = n * 6;
-        size_t lds = (size_t)(((MC_TS_READS * L) + 15) & ~15) + (size_t)256 * ((FP + 76 + 3) & ~3);
+        size_t lds = (size_t)(((MC_TS_READS * L) + 15) & ~15) + (size_t)256 * MC_TS_STRIDE(FP);
         if (lds > 48 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_translate_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         k_translate_seg<<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(256), lds, st>>>(h->d_T, d_reads, L, n, h->d_frames, FP);
         HIPCK(hipEventRecord(h->ev[1], st));

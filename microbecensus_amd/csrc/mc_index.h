@@ -228,6 +228,42 @@ inline bool mc_build_index(McHostIndex &X, const char *const *names, const char 
     return true;
 }
 
+// Proof obligation of mc_seg_mask_fx: for every composition a window of W residues can have (every partition of every
+// t <= W), the integer tests must decide like Seg::entropy_cal's doubles.  Returns the number of disagreements (0).
+inline int mc_seg_fx_verify(const McTables &T, double *min_margin)
+{
+    int bad = 0;
+    double mm = 1e9;
+    for (int w = 0; w < 2; w++) {
+        const int W = w ? 8 : 12;
+        uint8_t sv[24];
+        // enumerate partitions of t into parts in non-increasing order
+        for (int t = 0; t <= W; t++) {
+            int parts[16], np = 0;
+            // iterative partition enumeration
+            std::vector<std::vector<int>> all;
+            std::vector<int> cur;
+            struct Rec { static void go(int rem, int maxp, std::vector<int> &cur, std::vector<std::vector<int>> &all) {
+                if (rem == 0) { all.push_back(cur); return; }
+                for (int p = std::min(rem, maxp); p >= 1; p--) { cur.push_back(p); go(rem - p, p, cur, all); cur.pop_back(); } } };
+            Rec::go(t, t, cur, all);
+            (void)parts; (void)np;
+            for (const auto &pt : all) {
+                if (pt.size() > 20) continue;                  // only 20 residue classes exist
+                int S = 0;
+                for (size_t i = 0; i < pt.size(); i++) { sv[i] = (uint8_t)pt[i]; int c = 0; for (int k = 0; k < pt[i]; k++) { S += T.seg_din[c]; c++; } }
+                sv[pt.size()] = 0;
+                const double H = mc_seg_entropy(T, W, sv);
+                const bool lo = S >= T.seg_tlo[t], hi = S >= T.seg_thi[t];
+                if (lo != (H <= 2.2) || hi != (H <= 2.5)) bad++;
+                mm = std::min(mm, std::min(fabs(H - 2.2), fabs(H - 2.5)));
+            }
+        }
+    }
+    if (min_margin) *min_margin = mm;
+    return bad;
+}
+
 // ---- statistics / constant tables (BlastStat::*@0x437d50-0x438b40, Seg::initialize@0x439650) ----------
 inline int mc_length_adjustment(double n, double nseq, int qlen)
 { // BlastStat::blastComputeLengthAdjustment@0x438410 (NCBI BLAST_ComputeLengthAdjustment, gapped set)
@@ -279,6 +315,21 @@ inline void mc_fill_tables(McTables &T, const McHostIndex &X, int read_len, doub
     for (int w = 0; w < 2; w++) { int W = w ? 8 : 12; T.entray[w][0] = 0.0; for (int i = 1; i <= W; i++) { double p = (double)i / (double)W; T.entray[w][i] = (-p) * log(p) / LN2; } }
     for (int tot = 1; tot <= 12; tot++) { double inv = 1.0 / (double)tot; for (int c = 1; c <= tot; c++) { double x = (double)c; T.lterm[tot][c] = log(inv * x) * x; } }
     { char buf[64]; for (int i = 0; i < MC_LNFAC_N; i++) { snprintf(buf, sizeof buf, "%.6f", lgamma((double)i + 1.0)); T.lnfac[i] = atof(buf); } }
+    {   // fixed-point window-entropy tests of mc_seg_mask_fx
+        const double sc = (double)(1 << MC_SEG_FXBITS);
+        int32_t F[16]; memset(F, 0, sizeof F);
+        for (int c = 2; c <= 12; c++) F[c] = (int32_t)llround((double)c * log2((double)c) * sc);
+        for (int c = 0; c < 16; c++) {
+            T.seg_dout[c] = (c >= 1 && c <= 12) ? F[c - 1] - F[c] : 0;
+            T.seg_din[c] = (c <= 11) ? F[c + 1] - F[c] : 0;
+            T.seg_tlo[c] = T.seg_thi[c] = 0x7fffffff;
+        }
+        T.seg_tlo[0] = T.seg_thi[0] = -0x7fffffff;             // an empty window has entropy 0: below both cuts
+        for (int t = 1; t <= 12; t++) {
+            T.seg_tlo[t] = (int32_t)llround((double)t * (log2((double)t) - 2.2) * sc);
+            T.seg_thi[t] = (int32_t)llround((double)t * (log2((double)t) - 2.5) * sc);
+        }
+    }
     T.gap_trigger = (25.0 * LN2 - 2.0099154790312257) / 0.318;
     T.xdrop_ungapped = (7.0 * LN2 - 2.0099154790312257) / 0.318;
     T.xdrop_gapped = (15.0 * LN2 - 3.1941832122778293) / 0.267;

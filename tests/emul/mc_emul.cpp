@@ -102,6 +102,8 @@ int main(int argc, char **argv)
 
     const int FP = MC_MAXAA + 2;
     std::vector<uint8_t> frames((size_t)rs.size() * 6 * FP);
+    long seg_frames = 0, seg_bad = 0;
+    { double mm = 0; int bad = mc_seg_fx_verify(T, &mm); fprintf(stderr, "seg fixed-point tests: %d disagreements over all window compositions, closest entropy %.3g from a cut\n", bad, mm); if (bad) return 3; }
     std::vector<int> flen(rs.size() * 6);
     // stage 1: translate + SEG
     for (size_t r = 0; r < rs.size(); r++)
@@ -113,13 +115,27 @@ int main(int argc, char **argv)
                 uint8_t mask[(MC_MAXAA + 7) / 8]; double Hbuf[MC_MAXAA + 2];
                 mc_seg_mask(T, p, n, mask, Hbuf);
                 for (int i = 0; i < n; i++) if (mask[i >> 3] & (1 << (i & 7))) p[i] = MC_INV;
-            } else {   // the workspace variant the kernel uses
+            } else if (getenv("MC_SEG_WS")) {   // double-precision workspace variant
                 uint8_t comp[20], sv[24]; int16_t stk[16];
                 McSegWS ws{comp, sv, stk};
                 mc_seg_mask_ws(T, p, n, ws);
+            } else {   // the fixed-point variant the kernel uses
+                uint8_t comp[20], sv[24]; int16_t stk[16];
+                McSegWS ws{comp, sv, stk};
+                mc_seg_mask_fx(T, T.seg_dout, p, n, ws);
+                if (getenv("MC_CHECK_SEG")) {   // frame by frame against the plain restatement
+                    std::vector<uint8_t> q(FP, MC_INV);
+                    int n2 = mc_translate_frame(T, (const uint8_t *)rs[r].data(), read_len, f, q.data());
+                    uint8_t mask[(MC_MAXAA + 7) / 8]; double Hbuf[MC_MAXAA + 2];
+                    mc_seg_mask(T, q.data(), n2, mask, Hbuf);
+                    for (int i = 0; i < n2; i++) if (mask[i >> 3] & (1 << (i & 7))) q[i] = MC_INV;
+                    seg_frames++;
+                    if (n2 != n || memcmp(q.data(), p, (size_t)n)) seg_bad++;
+                }
             }
             flen[r * 6 + f] = n;
         }
+    if (getenv("MC_CHECK_SEG")) { fprintf(stderr, "seg check: %ld frames, %ld differ from the plain restatement\n", seg_frames, seg_bad); if (seg_bad) return 3; }
     // stage 2: seed enumeration
     std::vector<McSeedTask> tasks; uint64_t lookups = 0, keyprobes = 0;
     for (size_t r = 0; r < rs.size(); r++)
