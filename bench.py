@@ -73,6 +73,27 @@ def sample_reads_device(genome_np, nreads, read_len, seed, device):
     return out
 
 
+def profiled_traffic(kernel, n_batch):
+    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/rNN_hbm_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in their own --pmc passes; read bytes = 2 x FETCH_SIZE on gfx950, see
+    profiles/README.md), scaled from the profiled batch to this run's batch.  None if no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic.json")))
+    if not files:
+        return None
+    try:
+        tr = json.load(open(files[-1]))
+        line = json.load(open(files[-1].replace("_hbm_traffic.json", "_bench_line.json")))
+        per = float(line["config"]["batch"])
+        key = [k for k in tr if k.startswith(kernel) and "true" not in k]
+        if not key or tr[key[0]].get("write_kib_per_launch") is None:
+            return None
+        t = tr[key[0]]
+        return (2.0 * t["fetch_kib_per_launch"] + t["write_kib_per_launch"]) * 1024.0 / per * n_batch
+    except Exception:
+        return None
+
+
 def cpu_baseline(sample_reads, read_len, eng_rows):
     """Times the reference's own engine on the host cores on a bounded sample of the bench reads."""
     import numpy as np
@@ -214,7 +235,9 @@ def main():
                        "classified_reads": int(fam_counts.sum().item()),
                        "kernel_ms_per_step": {k: round(v / K, 3) for k, v in kern.items()}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                         "traffic": None, "algorithmic_bytes_per_read": round(per_launch[dom] / n_batch, 1)},
+                         "traffic": (lambda t: None if t is None else round(t, 0))(profiled_traffic("k_enumerate_t0" if dom == "k_enumerate" else dom, n_batch)),
+                         "algorithmic_bytes_per_read": round(per_launch[dom] / n_batch, 1),
+                         "all_kernels_GBps": {k: round(per_launch[k] / (kern[k] / K * 1e-3) / 1e9, 2) for k in kern if kern[k] > 0}},
         }
         if world == 1 and not args.no_cpu_baseline:
             ns = min(args.cpu_sample, args.batch)

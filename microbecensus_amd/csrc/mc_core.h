@@ -174,24 +174,24 @@ MC_HD void mc_seg_comp(const uint8_t *s, int n, uint8_t *comp)
     for (int i = 0; i < 20; i++) comp[i] = 0;
     for (int i = 0; i < n; i++) if (s[i] < 20) comp[s[i]]++;
 }
-MC_HD double mc_seg_getprob(const McTables &T, const uint8_t *sv, int total)
+MC_HD double mc_seg_getprob(const double *lnfac, const uint8_t *sv, int total)
 { // Seg::getprob@0x4393d0 = lnperm + lnass - total*ln 20
-    double ans1 = T.lnfac[20];
+    double ans1 = lnfac[20];
     if (sv[0] != 0) {
         int tot = 20, cls = 1, svim1 = sv[0], svi = 0, i;
         for (i = 0;; svim1 = svi) {
-            if (++i == 20) { ans1 = ans1 - T.lnfac[cls]; break; }
+            if (++i == 20) { ans1 = ans1 - lnfac[cls]; break; }
             else if ((svi = sv[i]) == svim1) cls++;
             else {
                 tot -= cls;
-                ans1 = ans1 - T.lnfac[cls];
-                if (svi == 0) { ans1 = ans1 - T.lnfac[tot]; break; }
+                ans1 = ans1 - lnfac[cls];
+                if (svi == 0) { ans1 = ans1 - lnfac[tot]; break; }
                 cls = 1;
             }
         }
     }
-    double ans2 = T.lnfac[total];
-    for (int i = 0; sv[i] != 0; i++) ans2 = ans2 - T.lnfac[sv[i]];
+    double ans2 = lnfac[total];
+    for (int i = 0; sv[i] != 0; i++) ans2 = ans2 - lnfac[sv[i]];
     double t = (double)total * 2.995732273553991;
     return (ans2 + ans1) - t;
 }
@@ -205,7 +205,7 @@ MC_HD void mc_seg_trim(const McTables &T, const uint8_t *s, int n, int *leftend,
         mc_seg_comp(s, len, comp);
         for (int i = 0;; i++) {
             mc_seg_state(comp, sv);
-            double prob = mc_seg_getprob(T, sv, len);
+            double prob = mc_seg_getprob(T.lnfac, sv, len);
             if (prob < minprob) { minprob = prob; lend = i; rend = len + i - 1; }
             if (i + 1 + len > n) break;
             if (s[i] < 20) comp[s[i]]--;
@@ -297,7 +297,7 @@ MC_HD void mc_seg_shift(uint8_t *comp, uint8_t *sv, int out, int in)
     if (out < 20) { mc_sv_dec(sv, comp[out]); comp[out]--; }
     if (in < 20) { mc_sv_inc(sv, comp[in]); comp[in]++; }
 }
-MC_HD void mc_seg_trim_ws(const McTables &T, const uint8_t *s, int n, int *leftend, int *rightend, const McSegWS &ws)
+MC_HD void mc_seg_trim_ws(const double *lnfac, const uint8_t *s, int n, int *leftend, int *rightend, const McSegWS &ws)
 {
     int lend = 0, rend = n - 1, minlen = 1;
     double minprob = 1.0;
@@ -306,7 +306,7 @@ MC_HD void mc_seg_trim_ws(const McTables &T, const uint8_t *s, int n, int *lefte
         mc_seg_comp(s, len, ws.comp);
         mc_seg_state(ws.comp, ws.sv);
         for (int i = 0;; i++) {
-            double prob = mc_seg_getprob(T, ws.sv, len);
+            double prob = mc_seg_getprob(lnfac, ws.sv, len);
             if (prob < minprob) { minprob = prob; lend = i; rend = len + i - 1; }
             if (i + 1 + len > n) break;
             mc_seg_shift(ws.comp, ws.sv, s[i], s[i + len]);
@@ -361,7 +361,7 @@ MC_HDN void mc_seg_mask_ws(const McTables &T, uint8_t *prot, int n, const McSegW
                 for (j = i; j <= last; j++) { if (!mc_bits_test(hi, j)) break; }
                 hii = j - 1;
                 leftend = loi; rightend = hii;
-                mc_seg_trim_ws(T, s + leftend, rightend - leftend + 1, &leftend, &rightend, ws);
+                mc_seg_trim_ws(T.lnfac, s + leftend, rightend - leftend + 1, &leftend, &rightend, ws);
                 if (i < leftend) {
                     int lend = loi, rend = leftend - 1;
                     if (sp < 8) { ws.stk[2 * sp] = (int16_t)(base + lend); ws.stk[2 * sp + 1] = (int16_t)(rend - lend + 1); sp++; }
@@ -388,7 +388,7 @@ MC_HDN void mc_seg_mask_ws(const McTables &T, uint8_t *prot, int n, const McSegW
 // same trimming code as before (mc_seg_trim_ws, double precision).  Workspace: comp[20] and the stack; sv is only
 // touched by the trimming.
 // ---------------------------------------------------------------------------------------------
-MC_HDN void mc_seg_mask_fx(const McTables &T, const int32_t *fx /* seg_dout, seg_din, seg_tlo, seg_thi: 4 x 16 */, uint8_t *prot, int n, const McSegWS &ws)
+MC_HDN void mc_seg_mask_fx(const double *lnfac /* McTables::lnfac */, const int32_t *fx /* seg_dout, seg_din, seg_tlo, seg_thi: 4 x 16 */, uint8_t *prot, int n, const McSegWS &ws)
 {
     const int W = (n <= 11) ? 8 : 12;
     McBits192 lo, hi, mk;
@@ -422,6 +422,9 @@ MC_HDN void mc_seg_mask_fx(const McTables &T, const int32_t *fx /* seg_dout, seg
                 }
             }
             if (!anylo) continue;
+#ifdef MC_EXP_NOTRIM
+            continue;
+#endif
         }
         int last = m - 1, lowlim = 0;
         for (int i = 0; i <= last; i++) {
@@ -432,7 +435,7 @@ MC_HDN void mc_seg_mask_fx(const McTables &T, const int32_t *fx /* seg_dout, seg
                 for (j = i; j <= last; j++) { if (!mc_bits_test(hi, j)) break; }
                 hii = j - 1;
                 leftend = loi; rightend = hii;
-                mc_seg_trim_ws(T, s + leftend, rightend - leftend + 1, &leftend, &rightend, ws);
+                mc_seg_trim_ws(lnfac, s + leftend, rightend - leftend + 1, &leftend, &rightend, ws);
                 if (i < leftend) {
                     int lend = loi, rend = leftend - 1;
                     if (sp < 8) { ws.stk[2 * sp] = (int16_t)(base + lend); ws.stk[2 * sp + 1] = (int16_t)(rend - lend + 1); sp++; }

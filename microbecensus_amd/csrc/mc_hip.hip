@@ -78,7 +78,9 @@ __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restric
     if (lr < nr) {
         n = mc_translate_frame(*T, sreads + lr * L, L, f, prot);
         McSegWS ws; ws.comp = prot + FP; ws.sv = prot + FP + 20; ws.stk = (int16_t *)(prot + FP + 44);
-        mc_seg_mask_fx(*T, fxs, prot, n, ws);
+#ifndef MC_EXP_NOSEG
+        mc_seg_mask_fx(T->lnfac, fxs, prot, n, ws);   // ln n! from global memory: an LDS copy measured slower (the trimming is LDS bound)
+#endif
         for (int i = n; i < FP; i++) prot[i] = MC_INV;
     }
     __syncthreads();

@@ -122,7 +122,7 @@ int main(int argc, char **argv)
             } else {   // the fixed-point variant the kernel uses
                 uint8_t comp[20], sv[24]; int16_t stk[16];
                 McSegWS ws{comp, sv, stk};
-                mc_seg_mask_fx(T, T.seg_dout, p, n, ws);
+                mc_seg_mask_fx(T.lnfac, T.seg_dout, p, n, ws);
                 if (getenv("MC_CHECK_SEG")) {   // frame by frame against the plain restatement
                     std::vector<uint8_t> q(FP, MC_INV);
                     int n2 = mc_translate_frame(T, (const uint8_t *)rs[r].data(), read_len, f, q.data());

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Profiles the bench command on the GPU box: tools/profile_round.sh r01
+#   pass 1: rocprofv3 --kernel-trace --stats            -> per-kernel durations
+#   pass 2..: rocprofv3 --pmc (counters only, own runs)  -> SQ / TCC / FETCH_SIZE / WRITE_SIZE per kernel
+# Raw output goes to gpurun_out/prof (scratch); tools/profile_summary.py condenses it into gpurun_out/prof/summary/,
+# which is what gets copied into profiles/.
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd /tmp && export TMPDIR=/tmp
+OUT=$R/gpurun_out/prof
+rm -rf $OUT && mkdir -p $OUT
+BENCH="python3 $R/bench.py --steps 3 --warmup 1 --batch 1000000 --resident-batches 2 --no-cpu-baseline"
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG --output-format csv -- $BENCH > $OUT/trace.log 2>&1
+i=0
+for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES" \
+           "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum"; do
+  i=$((i+1))
+  timeout 900 rocprofv3 --pmc $set -d $OUT/pmc$i -o $TAG --output-format csv -- $BENCH > $OUT/pmc$i.log 2>&1
+done
+grep -h '^{' $OUT/trace.log | tail -1 > $OUT/bench_line.json
+python3 $R/tools/profile_summary.py $OUT $TAG
+find $OUT -name "*.db" -delete
+ls -la $OUT/summary
