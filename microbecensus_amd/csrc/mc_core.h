@@ -315,6 +315,81 @@ MC_HD void mc_seg_trim_ws(const double *lnfac, const uint8_t *s, int n, int *lef
     *leftend = *leftend + lend;
     *rightend = *rightend - (n - rend - 1);
 }
+// ---- trimming of a short stretch (<= 15 residues) entirely in registers ---------------------------------------------
+// Same search as mc_seg_trim_ws (every window of every length, the least probable one wins, the first on a tie), but the
+// composition (20 counts) and the sorted state vector are packed 4-bit fields of two registers each, so that sliding the
+// window and evaluating Seg::getprob touch no memory but the ln n! table.  The double arithmetic of getprob is performed
+// in the reference's order, so the probabilities are bit-identical.  Low-complexity stretches are short (7.7 residues on
+// average for 150 bp reads); longer ones use the workspace version.
+struct McRgState { uint64_t clo; uint32_t chi; uint64_t sv; };   // counts of classes 0..15 / 16..19, sorted counts (entry i = nibble i)
+#define MC_RG_ONES 0x1111111111111111ull
+MC_HD uint64_t mc_rg_eqmask(uint64_t sv, int x)
+{ // bit 4i+3 set <=> nibble i of sv equals x (exact, no borrow artefacts)
+    const uint64_t y = sv ^ ((uint64_t)x * MC_RG_ONES);
+    return ~(((y & 0x7777777777777777ull) + 0x7777777777777777ull) | y) & 0x8888888888888888ull;
+}
+MC_HD void mc_rg_add(McRgState &st, int r)
+{ // Seg::incrementsv: the FIRST entry equal to the class' count grows (a new class appends a 1)
+    if (r >= 20) return;
+    const int sh = (r & 15) * 4;
+    const int x = (r < 16) ? (int)((st.clo >> sh) & 15) : (int)((st.chi >> sh) & 15);
+    const uint64_t m = mc_rg_eqmask(st.sv, x);
+    st.sv += 1ull << (__builtin_ctzll(m) - 3);
+    if (r < 16) st.clo += 1ull << sh; else st.chi += 1u << sh;
+}
+MC_HD void mc_rg_remove(McRgState &st, int r)
+{ // Seg::decrementsv: the LAST entry equal to the class' count shrinks
+    if (r >= 20) return;
+    const int sh = (r & 15) * 4;
+    const int x = (r < 16) ? (int)((st.clo >> sh) & 15) : (int)((st.chi >> sh) & 15);
+    const uint64_t m = mc_rg_eqmask(st.sv, x);
+    st.sv -= 1ull << (60 - (__builtin_clzll(m) & ~3));
+    if (r < 16) st.clo -= 1ull << sh; else st.chi -= 1u << sh;
+}
+MC_HD double mc_rg_getprob(const double *lnfac, uint64_t sv, int total)
+{ // Seg::getprob@0x4393d0 on the packed state vector (at most 15 classes, so the 20-class special case cannot occur)
+    double ans1 = lnfac[20];
+    int first = (int)(sv & 15);
+    if (first != 0) {
+        int tot = 20, cls = 1, prev = first;
+        uint64_t w = sv >> 4;
+        for (;;) {
+            const int cur = (int)(w & 15);
+            w >>= 4;
+            if (cur == prev) cls++;
+            else {
+                tot -= cls;
+                ans1 = ans1 - lnfac[cls];
+                if (cur == 0) { ans1 = ans1 - lnfac[tot]; break; }
+                cls = 1;
+            }
+            prev = cur;
+        }
+    }
+    double ans2 = lnfac[total];
+    for (uint64_t w = sv; (w & 15) != 0; w >>= 4) ans2 = ans2 - lnfac[w & 15];
+    const double t = (double)total * 2.995732273553991;
+    return (ans2 + ans1) - t;
+}
+MC_HD void mc_seg_trim_rg(const double *lnfac, const uint8_t *s, int n, int *leftend, int *rightend)
+{ // n <= 15 (so n - maxtrim < 1: every window length down to 2 is tried)
+    int lend = 0, rend = n - 1;
+    double minprob = 1.0;
+    McRgState st0; st0.clo = 0; st0.chi = 0; st0.sv = 0;
+    for (int k = 0; k < n; k++) mc_rg_add(st0, s[k]);
+    for (int len = n; len > 1; len--) {
+        McRgState st = st0;                                   // window [0, len)
+        for (int i = 0;; i++) {
+            const double prob = mc_rg_getprob(lnfac, st.sv, len);
+            if (prob < minprob) { minprob = prob; lend = i; rend = len + i - 1; }
+            if (i + 1 + len > n) break;
+            mc_rg_remove(st, s[i]); mc_rg_add(st, s[i + len]);
+        }
+        mc_rg_remove(st0, s[len - 1]);                        // window [0, len - 1) for the next length
+    }
+    *leftend = *leftend + lend;
+    *rightend = *rightend - (n - rend - 1);
+}
 struct McBits192 { uint64_t a, b, c; };   // bit set over <= 192 positions kept in registers (no dynamic indexing)
 MC_HD void mc_bits_clear(McBits192 &x) { x.a = 0; x.b = 0; x.c = 0; }
 MC_HD void mc_bits_set(McBits192 &x, int i) { uint64_t m = 1ull << (i & 63); if (i < 64) x.a |= m; else if (i < 128) x.b |= m; else x.c |= m; }
@@ -435,7 +510,8 @@ MC_HDN void mc_seg_mask_fx(const double *lnfac /* McTables::lnfac */, const int3
                 for (j = i; j <= last; j++) { if (!mc_bits_test(hi, j)) break; }
                 hii = j - 1;
                 leftend = loi; rightend = hii;
-                mc_seg_trim_ws(lnfac, s + leftend, rightend - leftend + 1, &leftend, &rightend, ws);
+                if (rightend - leftend + 1 <= 15) mc_seg_trim_rg(lnfac, s + leftend, rightend - leftend + 1, &leftend, &rightend);
+                else mc_seg_trim_ws(lnfac, s + leftend, rightend - leftend + 1, &leftend, &rightend, ws);
                 if (i < leftend) {
                     int lend = loi, rend = leftend - 1;
                     if (sp < 8) { ws.stk[2 * sp] = (int16_t)(base + lend); ws.stk[2 * sp + 1] = (int16_t)(rend - lend + 1); sp++; }

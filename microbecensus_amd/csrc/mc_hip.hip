@@ -53,6 +53,7 @@ enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_N = 4 };   // 64-bit algorithmic-t
 #define MC_TS_READS 42
 // row pitch: an odd number of 32-bit words, so that the 64 lanes of a wave touching the same offset of their rows
 // fall into different LDS banks (a pitch of 128 bytes put all of them into one)
+#define MC_TS_NLNF(FP) ((FP) + 2 > 24 ? (FP) + 2 : 24)
 #define MC_TS_STRIDE(FP) (((((FP) + 76 + 3) >> 2) | 1) << 2)
 __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restrict__ T, const uint8_t *__restrict__ reads, int L,
                                                        int64_t nreads, uint8_t *__restrict__ frames, int FP)
@@ -65,8 +66,11 @@ __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restric
     const int stride = MC_TS_STRIDE(FP);                         // per-thread LDS row: prot[FP] comp[20] sv[24] stk[32]
     __shared__ int32_t fxs[64];                                  // fixed-point entropy tables of mc_seg_mask_fx
     uint8_t *sreads = smem;
-    uint8_t *rows = smem + (((MC_TS_READS * L) + 15) & ~15);
+    const int nlnf = MC_TS_NLNF(FP);
+    double *lnf = (double *)(smem + (((MC_TS_READS * L) + 15) & ~15));       // ln n! for n <= max(frame length, 20): all the trimming asks for
+    uint8_t *rows = (uint8_t *)(lnf + nlnf);
     if (tid < 64) fxs[tid] = T->seg_dout[tid];                   // seg_dout, seg_din, seg_tlo, seg_thi are contiguous
+    for (int i = tid; i < nlnf; i += 256) lnf[i] = T->lnfac[i];
     {   // coalesced staging of this block's reads (the block's slice starts at r0*L, not necessarily 16-byte aligned)
         const uint8_t *src = reads + r0 * L;
         for (int i = tid; i < rbytes; i += 256) sreads[i] = src[i];
@@ -79,7 +83,7 @@ __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restric
         n = mc_translate_frame(*T, sreads + lr * L, L, f, prot);
         McSegWS ws; ws.comp = prot + FP; ws.sv = prot + FP + 20; ws.stk = (int16_t *)(prot + FP + 44);
 #ifndef MC_EXP_NOSEG
-        mc_seg_mask_fx(T->lnfac, fxs, prot, n, ws);   // ln n! from global memory: an LDS copy measured slower (the trimming is LDS bound)
+        mc_seg_mask_fx(lnf, fxs, prot, n, ws);
 #endif
         for (int i = n; i < FP; i++) prot[i] = MC_INV;
     }
@@ -774,7 +778,7 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
     HIPCK(hipEventRecord(h->ev[0], st));
     {
         const int64_t threads = n * 6;
-        size_t lds = (size_t)(((MC_TS_READS * L) + 15) & ~15) + (size_t)256 * MC_TS_STRIDE(FP);
+        size_t lds = (size_t)(((MC_TS_READS * L) + 15) & ~15) + (size_t)MC_TS_NLNF(FP) * 8 + (size_t)256 * MC_TS_STRIDE(FP);
         if (lds > 48 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_translate_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         k_translate_seg<<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(256), lds, st>>>(h->d_T, d_reads, L, n, h->d_frames, FP);
         HIPCK(hipEventRecord(h->ev[1], st));
