@@ -28,6 +28,7 @@ sys.path.insert(0, REPO)
 
 METRIC = "reads/sec searched vs marker DB + AGS abs-error, 150 bp @ 1/2/4/8 GPU"
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SURVEY_A = {100: 127403, 150: 207923, 300: 452893}   # modelled algorithmic bytes per read of the seed path
 
 
 def torch_splitmix64(x):
@@ -133,7 +134,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2_000_000)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--resident-batches", type=int, default=4)
-    ap.add_argument("--cpu-sample", type=int, default=50_000)
+    ap.add_argument("--cpu-sample", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--count-in-timed-steps", action="store_true", help="keep the seed kernel's traffic counters on in the timed steps")
     args = ap.parse_args()
@@ -237,6 +238,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                          "traffic": (lambda t: None if t is None else round(t, 0))(profiled_traffic("k_enumerate_t0" if dom == "k_enumerate" else dom, n_batch)),
                          "algorithmic_bytes_per_read": round(per_launch[dom] / n_batch, 1),
+                         # SURVEY.md 8(d) priced the seed path at A(150) = 207,923 B/read assuming whole-bucket visits the engine does not
+                         # perform; for comparison, the same kernel time priced with that figure:
+                         "survey_A_bytes_per_read": SURVEY_A.get(L), "seed_kernel_GBps_with_survey_A": (round(SURVEY_A[L] * n_batch / (kern["k_enumerate"] / K * 1e-3) / 1e9, 2) if L in SURVEY_A and kern["k_enumerate"] > 0 else None),
                          "all_kernels_GBps": {k: round(per_launch[k] / (kern[k] / K * 1e-3) / 1e9, 2) for k in kern if kern[k] > 0}},
         }
         if world == 1 and not args.no_cpu_baseline:

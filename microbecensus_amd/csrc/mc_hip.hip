@@ -718,7 +718,7 @@ static int ensure_capacity(mc_handle *h, int64_t nreads)
     h->cap_gaps = (uint32_t)std::min<int64_t>(cap * (L / 8 + 8) + (1 << 18), 0x7fffffff);
     h->cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 2 + 16) + (1 << 20), 0x7fffffff);
     h->cap_rows = (uint32_t)std::min<int64_t>(cap * 48 + (1 << 20), 0x7fffffff);
-    h->gap_threads = 64 * 1024;
+    h->gap_threads = 256 * 1024;   // 28.8 KB of DP workspace each (7.4 GB): enough resident waves to hide the latency of the serial DP
     if (dalloc(&h->d_frames, (size_t)cap * 6 * h->FP) || dalloc(&h->d_tasks, h->cap_tasks) ||
         dalloc(&h->d_gaps, h->cap_gaps) || dalloc(&h->d_hsps, h->cap_hsps) || dalloc(&h->d_sorted, h->cap_hsps) || dalloc(&h->d_v, h->cap_hsps) ||
         dalloc(&h->d_tmp, (size_t)h->cap_hsps * 2) || dalloc(&h->d_k64, h->cap_hsps) || dalloc(&h->d_k64o, h->cap_hsps) || dalloc(&h->d_idx, h->cap_hsps) ||
