@@ -93,6 +93,31 @@ int mc_result_stats(mc_handle *h, mc_stats *out);
  * no header lines) - what search_seqs() leaves in paths['tempfile']+'.m8'. append != 0 appends. */
 int mc_write_m8(mc_handle *h, const char *path, int append);
 
+/* ---- host stage in front of the search: native read sampler (csrc/mc_reader.cpp; no GPU involved) ----------------
+ * Replaces open_file / parse_seqs / quality_filter / process_seqfile (microbe_census.py:47-59, :294-325, :265-279,
+ * :328-367) and count_bases (:573-584) with identical results, quirks included (see the header of mc_reader.cpp).
+ * Plain and .gz inputs; .bz2 stays with the Python stage.  Errors: NULL / negative + mc_reader_last_error(); -3 = the
+ * reference would have raised inside run_pipeline (its message names the Python exception). */
+typedef struct mc_reader mc_reader;
+typedef struct mc_reader_stats {
+    int64_t sampled, too_short, low_qual, dups;   /* the four counts process_seqfile prints (:362-366) */
+    int64_t records;                              /* records parsed before the sampler stopped */
+} mc_reader_stats;
+
+const char *mc_reader_last_error(void);
+/* fastq: args['file_type'] == 'fastq'; quality_offset: 32 or 64 as auto_detect_quality_offset returns it (:175-187);
+ * fasta_out (may be NULL): the temp FASTA process_seqfile writes, ">{id}\n{seq[:L]}\n" per accepted read. */
+mc_reader *mc_reader_open(const char *const *paths, int32_t npaths, int32_t read_len, int64_t nreads, int32_t fastq, int32_t quality_offset,
+                          double min_quality, double mean_quality, double max_unknown, int32_t filter_dups, const char *fasta_out);
+/* Runs the sampler: returns args['sampled_reads'] (0 = "No reads remaining after filtering"). */
+int64_t mc_reader_run(mc_reader *r);
+/* sampled x read_len bytes, row i = trimmed read i: exactly what mc_search() / mc_upload() take. Owned by the reader. */
+const uint8_t *mc_reader_reads(mc_reader *r);
+int mc_reader_get_stats(mc_reader *r, mc_reader_stats *out);
+void mc_reader_close(mc_reader *r);
+/* count_bases(): total sequence length over every record of every file. */
+int64_t mc_count_bases(const char *const *paths, int32_t npaths);
+
 #ifdef __cplusplus
 }
 #endif

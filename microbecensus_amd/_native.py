@@ -29,6 +29,10 @@ class McStats(C.Structure):
                [(n, C.c_float) for n in ("ms_translate", "ms_seed", "ms_eval", "ms_gapped", "ms_sort", "ms_finish", "ms_total")]
 
 
+class McReaderStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("sampled", "too_short", "low_qual", "dups", "records")]
+
+
 ROW_DTYPE = np.dtype([("query", "<i4"), ("subject", "<i4"), ("ident", "<f8"), ("alnlen", "<i4"), ("mismatch", "<i4"),
                       ("gapopen", "<i4"), ("qstart", "<i4"), ("qend", "<i4"), ("sstart", "<i4"), ("send", "<i4"),
                       ("loge", "<f8"), ("bits", "<f8"), ("score", "<i4"), ("nmatch", "<i4")], align=True)
@@ -65,12 +69,61 @@ def load_library():
     lib.mc_result_best_hits.argtypes = [C.c_void_p, C.POINTER(C.POINTER(McBestHit))]
     lib.mc_result_stats.argtypes = [C.c_void_p, C.POINTER(McStats)]
     lib.mc_write_m8.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    lib.mc_reader_last_error.restype = C.c_char_p
+    lib.mc_reader_open.restype = C.c_void_p
+    lib.mc_reader_open.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_char_p]
+    lib.mc_reader_run.restype = C.c_int64
+    lib.mc_reader_run.argtypes = [C.c_void_p]
+    lib.mc_reader_reads.restype = C.POINTER(C.c_uint8)
+    lib.mc_reader_reads.argtypes = [C.c_void_p]
+    lib.mc_reader_get_stats.argtypes = [C.c_void_p, C.POINTER(McReaderStats)]
+    lib.mc_reader_close.argtypes = [C.c_void_p]
+    lib.mc_count_bases.restype = C.c_int64
+    lib.mc_count_bases.argtypes = [C.POINTER(C.c_char_p), C.c_int32]
     _lib = lib
     return lib
 
 
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_index_view", "mc_set_run", "mc_search",
-                    "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8"]
+                    "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8",
+                    "mc_reader_last_error", "mc_reader_open", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_count_bases"]
+
+
+class ReferenceError_(Exception):
+    """The reference's Python would have raised inside run_pipeline (which prints the error and returns None)."""
+
+
+def sample_reads(paths, read_len, nreads, fastq, quality_offset, min_quality, mean_quality, max_unknown, filter_dups, fasta_out=None):
+    """Native process_seqfile: returns (reads uint8 (n, read_len), stats dict).  Needs no GPU."""
+    lib = load_library()
+    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    r = lib.mc_reader_open(arr, len(paths), read_len, nreads, 1 if fastq else 0, int(quality_offset), float(min_quality), float(mean_quality),
+                           float(max_unknown), 1 if filter_dups else 0, fasta_out.encode() if fasta_out else None)
+    if not r:
+        raise RuntimeError(lib.mc_reader_last_error().decode())
+    try:
+        n = lib.mc_reader_run(r)
+        if n == -3:
+            raise ReferenceError_(lib.mc_reader_last_error().decode())
+        if n < 0:
+            raise RuntimeError(lib.mc_reader_last_error().decode())
+        st = McReaderStats()
+        lib.mc_reader_get_stats(r, C.byref(st))
+        reads = np.ctypeslib.as_array(lib.mc_reader_reads(r), shape=(n * read_len,)).reshape(n, read_len).copy() if n else np.zeros((0, read_len), np.uint8)
+        return reads, {k: getattr(st, k) for k, _ in McReaderStats._fields_}
+    finally:
+        lib.mc_reader_close(r)
+
+
+def count_bases(paths):
+    lib = load_library()
+    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    n = lib.mc_count_bases(arr, len(paths))
+    if n == -3:
+        raise ReferenceError_(lib.mc_reader_last_error().decode())
+    if n < 0:
+        raise RuntimeError(lib.mc_reader_last_error().decode())
+    return n
 
 
 def load_markers(path=None):

@@ -272,12 +272,8 @@ def quality_filter(rec, args):
 # ----------------------------------------------------------------------------------------------
 # stages
 # ----------------------------------------------------------------------------------------------
-def process_seqfile(args, paths):
-    """Head-take sampler: files in order, records in order; too short -> skip; duplicate (full sequence or its
-    reverse complement, checked before QC) -> skip; QC fail -> skip; else keep seq[:L]; stop at nreads."""
-    if args["verbose"]:
-        print("====Estimating Average Genome Size====")
-        print("Sampling & trimming reads...")
+def _process_seqfile_py(args, paths):
+    """The sampler in Python (bz2 inputs; also the readable statement of the rules the native reader follows)."""
     L, nreads = args["read_length"], args["nreads"]
     kept, seen = [], set()
     dups = too_short = low_qual = 0
@@ -301,16 +297,40 @@ def process_seqfile(args, paths):
                     break
             if len(kept) == nreads:
                 break
-    if not kept:
+    return (_pack_reads(kept, L) if kept else np.zeros((0, L), np.uint8)), {"sampled": len(kept), "too_short": too_short, "low_qual": low_qual, "dups": dups}
+
+
+def _native_reader_usable(args):
+    return not any(p.split(".")[-1] == "bz2" for p in args["seqfiles"])
+
+
+def process_seqfile(args, paths):
+    """Head-take sampler: files in order, records in order; too short -> skip; duplicate (full sequence or its
+    reverse complement, checked before QC) -> skip; QC fail -> skip; else keep seq[:L]; stop at nreads.
+    Runs in the native reader of libmcensus_hip.so (mc_reader_*, csrc/mc_reader.cpp); .bz2 inputs in Python."""
+    if args["verbose"]:
+        print("====Estimating Average Genome Size====")
+        print("Sampling & trimming reads...")
+    L = args["read_length"]
+    if _native_reader_usable(args):
+        from . import _native
+        try:
+            reads, st = _native.sample_reads(args["seqfiles"], L, args["nreads"], args["file_type"] == "fastq", args.get("quality_offset") or 0,
+                                             args["min_quality"], args["mean_quality"], args["max_unknown"], args["filter_dups"], paths["tempfile"])
+        except _native.ReferenceError_ as e:      # the reference raises here; run_pipeline prints it and returns None
+            raise Exception(str(e))
+    else:
+        reads, st = _process_seqfile_py(args, paths)
+    if st["sampled"] == 0:
         clean_up(paths)
         sys.exit("\nError! No reads remaining after filtering!")
-    args["sampled_reads"] = len(kept)
-    _run_cache[paths["tempfile"]] = {"reads": kept}
+    args["sampled_reads"] = st["sampled"]
+    _run_cache[paths["tempfile"]] = {"reads": reads}
     if args["verbose"]:
-        print("\t%s reads shorter than %s bp and skipped" % (too_short, L))
-        print("\t%s low quality reads found and skipped" % low_qual)
-        print("\t%s duplicate reads found and skipped" % dups)
-        print("\t%s reads sampled from seqfile" % len(kept))
+        print("\t%s reads shorter than %s bp and skipped" % (st["too_short"], L))
+        print("\t%s low quality reads found and skipped" % st["low_qual"])
+        print("\t%s duplicate reads found and skipped" % st["dups"])
+        print("\t%s reads sampled from seqfile" % st["sampled"])
 
 
 def _engine(device):
@@ -335,13 +355,13 @@ def search_seqs(args, paths):
     cache = _run_cache.get(paths["tempfile"])
     if cache is None or "reads" not in cache:
         seqs = [r.seq for r in parse_seqs(open(paths["tempfile"]))]
-        cache = _run_cache[paths["tempfile"]] = {"reads": seqs}
+        cache = _run_cache[paths["tempfile"]] = {"reads": _pack_reads(seqs, L)}
     model = _model()
     fams = model["families"]
     try:
         eng = _engine(args.get("device", 0) or 0)
         eng.set_run(L, model["pars"][str(L)], fams)
-        rows, best = eng.search(_pack_reads(cache["reads"], L))
+        rows, best = eng.search(cache["reads"])
         with open(paths["tempfile"] + ".m8", "w") as f:
             f.write("# microbecensus_amd %s: RAPsearch2-compatible m8 written by the MI355X search path\n" % __version__)
             f.write("# Job submitted: reads=%d trimmed to %d bp\n# Query : %s\n# Subject : %s\n" % (len(cache["reads"]), L, paths["tempfile"], paths["db"]))
@@ -494,6 +514,12 @@ def read_seqfile(infile):
 def count_bases(args):
     if args["verbose"]:
         print("Computing number of genome equivalents...")
+    if _native_reader_usable(args):
+        from . import _native
+        try:
+            return _native.count_bases(args["seqfiles"])
+        except _native.ReferenceError_ as e:
+            raise Exception(str(e))
     total = 0
     for inpath in args["seqfiles"]:
         with open_file(inpath) as infile:

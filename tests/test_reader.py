@@ -1,0 +1,96 @@
+"""Native read sampler (mc_reader_*, csrc/mc_reader.cpp) and its Python statement against golden vectors produced by the
+reference's own process_seqfile / count_bases on small synthetic files (tests/golden/make_sampler_golden.py).  No GPU."""
+import json
+import os
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+CASES = json.load(open(os.path.join(GOLD, "sampler_cases.json")))["cases"]
+
+
+def _args(case):
+    a = {"seqfiles": [os.path.join(GOLD, "sampler", f) for f in case["files"]], "verbose": False}
+    a.update(case["args"])
+    return a
+
+
+def _prepare(mc, case):
+    args = _args(case)
+    mc.check_input(args)
+    mc.impute_missing_args(args)
+    mc.check_arguments(args)
+    return args
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["case"] for c in CASES])
+def test_native_reader_matches_reference(case, tmp_path):
+    from microbecensus_amd import _native, microbe_census as mc
+    args = _prepare(mc, case)
+    out = str(tmp_path / "tmp.fa")
+    call = lambda: _native.sample_reads(args["seqfiles"], args["read_length"], args["nreads"], args["file_type"] == "fastq",   # noqa: E731
+                                        args.get("quality_offset") or 0, args["min_quality"], args["mean_quality"], args["max_unknown"],
+                                        args["filter_dups"], out)
+    if "raises" in case:
+        with pytest.raises(_native.ReferenceError_) as e:
+            call()
+        assert case["raises"] in str(e.value)
+    else:
+        reads, st = call()
+        if "exit" in case:
+            assert st["sampled"] == 0
+        else:
+            assert st["sampled"] == case["sampled_reads"] and reads.shape == (case["sampled_reads"], args["read_length"])
+            assert (st["too_short"], st["low_qual"], st["dups"]) == (case["too_short"], case["low_qual"], case["dups"])
+            assert open(out).read() == case["temp_fasta"]
+            assert b"".join(b">%d\n%s\n" % (i, bytes(r)) for i, r in enumerate(reads)).decode() == case["temp_fasta"]
+    if "count_bases" in case:
+        assert _native.count_bases(args["seqfiles"]) == case["count_bases"]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["case"] for c in CASES])
+def test_process_seqfile_stage(case, tmp_path, capsys):
+    """The stage function as run_pipeline calls it (native reader inside): same file, same counters, same exits."""
+    from microbecensus_amd import microbe_census as mc
+    args = _prepare(mc, case)
+    args["verbose"] = True
+    paths = {"tempfile": str(tmp_path / "tmp.fa")}
+    if "raises" in case:
+        with pytest.raises(Exception):
+            mc.process_seqfile(args, paths)
+        return
+    if "exit" in case:
+        with pytest.raises(SystemExit) as e:
+            mc.process_seqfile(args, paths)
+        assert str(e.value) == case["exit"]
+        return
+    mc.process_seqfile(args, paths)
+    assert args["sampled_reads"] == case["sampled_reads"]
+    assert open(paths["tempfile"]).read() == case["temp_fasta"]
+    text = capsys.readouterr().out
+    assert "\t%d reads shorter than %d bp and skipped" % (case["too_short"], args["read_length"]) in text
+    assert "\t%d low quality reads found and skipped" % case["low_qual"] in text
+    assert "\t%d duplicate reads found and skipped" % case["dups"] in text
+    assert mc.count_bases(args) == case["count_bases"]
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if "raises" not in c and "exit" not in c], ids=lambda c: c["case"])
+def test_python_statement_of_the_sampler(case, tmp_path):
+    """_process_seqfile_py (used for .bz2 inputs) follows the same rules."""
+    from microbecensus_amd import microbe_census as mc
+    args = _prepare(mc, case)
+    paths = {"tempfile": str(tmp_path / "tmp.fa")}
+    reads, st = mc._process_seqfile_py(args, paths)
+    assert (st["sampled"], st["too_short"], st["low_qual"], st["dups"]) == (case["sampled_reads"], case["too_short"], case["low_qual"], case["dups"])
+    assert open(paths["tempfile"]).read() == case["temp_fasta"]
+
+
+def test_reader_golden_inputs_of_the_reference():
+    """The reference's own example / unit-test files: counters of BASELINE configs[0] and of the unit test."""
+    from microbecensus_amd import _native
+    reads, st = _native.sample_reads([os.path.join(GOLD, "inputs", "example.fq.gz")], 100, 10000, True, 32, -5, -5, 100, False)
+    assert (st["sampled"], st["too_short"]) == (8672, 1328)
+    assert _native.count_bases([os.path.join(GOLD, "inputs", "example.fq.gz")]) == 980306
+    reads, st = _native.sample_reads([os.path.join(GOLD, "inputs", "metagenome.fa.gz")], 100, 1000000, False, 0, -5, -5, 100, False)
+    assert st["sampled"] == 70623
