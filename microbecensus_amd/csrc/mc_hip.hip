@@ -55,6 +55,170 @@ enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_N = 4 };   // 64-bit algorithmic-t
 // fall into different LDS banks (a pitch of 128 bytes put all of them into one)
 #define MC_TS_NLNF(FP) ((FP) + 2 > 24 ? (FP) + 2 : 24)
 #define MC_TS_STRIDE(FP) (((((FP) + 76 + 3) >> 2) | 1) << 2)
+#define MC_TS_STAGE(L) ((((MC_TS_READS * (L)) > 4 * 1416 ? (MC_TS_READS * (L)) : 4 * 1416) + 15) & ~15)   // read staging, later 4 x McSegWaveLds
+
+__device__ __forceinline__ int mc_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// orders the wave's own LDS traffic for the compiler; the hardware executes one wave's LDS instructions in order
+__device__ __forceinline__ void mc_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// ---- SEG for the 64 frames of a wave -----------------------------------------------------------------------------------
+// mc_seg_mask_fx (mc_core.h) is the per-frame statement of the algorithm; this is the same algorithm arranged for a wave.
+// The window scan and the bookkeeping of a frame stay with its lane (cheap, integer only).  What is expensive is the
+// trimming of a low-complexity stretch of n residues - Seg::trim@0x439e20 evaluates Seg::getprob for every window of
+// every length, n(n-1)/2 of them - and only one frame in five needs it, with very unequal n.  So the lanes stop when they
+// reach a stretch, the windows of ALL stretches pending in the wave are numbered consecutively and dealt out to the 64
+// lanes (each builds its window's composition from scratch, in registers for windows <= 15 residues), and the least
+// probable window of every stretch (the first one in the reference's iteration order on a tie) is found with LDS
+// atomics.  The double arithmetic of getprob is the reference's, operation by operation.
+struct McSegWaveLds { unsigned long long best[64]; uint32_t pre[66]; uint32_t bq[64]; uint32_t off[64]; uint16_t n[64]; };   // 1,416 B per wave
+static_assert(sizeof(McSegWaveLds) == 1416, "MC_TS_STAGE reserves 4 x 1416 bytes");
+#define MC_SEG_KEY_ONE 0xBFF0000000000000ull   // order-preserving key of 1.0 (the initial minprob of Seg::trim)
+
+__device__ __forceinline__ unsigned long long mc_seg_key(double x)
+{ // unsigned keys that order like the doubles
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+__device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx, uint8_t *prot, int n, bool act, const McSegWS ws, McSegWaveLds *WL,
+                                         const uint8_t *lds0, int lane)
+{
+    const int W = (n <= 11) ? 8 : 12;
+    enum { POP = 0, SCAN = 1, WAIT = 2, DONE = 3 };
+    int st = (act && W <= n) ? POP : DONE;
+    McBits192 lo, hi, mk;
+    mc_bits_clear(lo); mc_bits_clear(hi); mc_bits_clear(mk);
+    int sp = 1, base = 0, m = 0, i = 0, last = 0, lowlim = 0, loi = 0, hii = 0;
+    bool any = false;
+    if (st != DONE) { ws.stk[0] = 0; ws.stk[1] = (int16_t)n; }
+    const unsigned long long ltmask = (1ull << lane) - 1;
+    for (;;) {
+        // ---- every lane advances its own frame to the next stretch that needs trimming
+        while (st == POP || st == SCAN) {
+            if (st == POP) {
+                if (sp == 0) { st = DONE; break; }
+                sp--;
+                base = ws.stk[2 * sp]; m = ws.stk[2 * sp + 1];
+                if (W > m) continue;
+                const uint8_t *s = prot + base;
+                mc_bits_clear(lo); mc_bits_clear(hi);
+                bool anylo = false;
+                int S = 0, t = 0;
+                for (int k = 0; k < 20; k++) ws.comp[k] = 0;
+                for (int k = 0; k < W; k++) { const int r = s[k]; if (r < 20) { const int c = ws.comp[r]; S += fx[16 + c]; ws.comp[r] = (uint8_t)(c + 1); t++; } }
+                int start = 0;
+                bool l = S >= fx[32 + t], h = S >= fx[48 + t];
+                for (int k = 0; k <= m - 1; k++) {
+                    if (l) { mc_bits_set(lo, k); anylo = true; }
+                    if (h) mc_bits_set(hi, k);
+                    if (start + 1 + W <= m) {
+                        const int o = s[start], e = s[start + W];
+                        if (o < 20) { const int c = ws.comp[o]; S += fx[c]; ws.comp[o] = (uint8_t)(c - 1); t--; }
+                        if (e < 20) { const int c = ws.comp[e]; S += fx[16 + c]; ws.comp[e] = (uint8_t)(c + 1); t++; }
+                        start++;
+                        l = S >= fx[32 + t]; h = S >= fx[48 + t];
+                    }
+                }
+                if (!anylo) continue;
+                i = 0; last = m - 1; lowlim = 0; st = SCAN;
+            }
+            while (i <= last && !mc_bits_test(lo, i)) i++;
+            if (i > last) { st = POP; continue; }
+            int j;
+            for (j = i; j >= lowlim; j--) { if (!mc_bits_test(hi, j)) break; }
+            loi = j + 1;
+            for (j = i; j <= last; j++) { if (!mc_bits_test(hi, j)) break; }
+            hii = j - 1;
+            st = WAIT;
+        }
+        const unsigned long long req = __ballot(st == WAIT);
+        if (req == 0) break;
+        // ---- number the windows of all pending stretches
+        const int nreq = __popcll(req);
+        const int myr = __popcll(req & ltmask);
+        const int myn = hii - loi + 1;
+        if (st == WAIT) {
+            WL->off[myr] = (uint32_t)((prot + base + loi) - lds0);
+            WL->n[myr] = (uint16_t)myn;
+            WL->best[myr] = MC_SEG_KEY_ONE; WL->bq[myr] = 0xFFFFFFFFu;
+        }
+        mc_wave_sync();
+        if (lane == 0) {
+            uint32_t run = 0;
+            WL->pre[0] = 0;
+            for (int r = 0; r < nreq; r++) { const int nn = WL->n[r], minlen = (nn - 100 > 1) ? nn - 100 : 1, K = nn - minlen; run += (uint32_t)(K * (K + 1) / 2); WL->pre[r + 1] = run; }
+        }
+        mc_wave_sync();
+        const uint32_t total = WL->pre[nreq];
+        for (uint32_t p0 = 0; p0 < total; p0 += 64) {
+            const uint32_t p = p0 + (uint32_t)lane;
+            const bool ok = p < total;
+            int r = 0;
+            for (int k = 1; k < nreq; k++) r += (p >= WL->pre[k]);
+            if (!ok) r = 0;
+            const uint32_t q = p - WL->pre[r];
+            const int nn = WL->n[r];
+            const uint8_t *s = lds0 + WL->off[r];
+            // window number q of the stretch, in Seg::trim's order: length nn - j (j = 0, 1, ...) has j + 1 windows
+            int j = (int)((sqrtf((float)(8u * q + 1u)) - 1.0f) * 0.5f);
+            while ((uint32_t)((j + 1) * (j + 2) / 2) <= q) j++;
+            while ((uint32_t)(j * (j + 1) / 2) > q) j--;
+            const int len = nn - j, w0 = (int)q - j * (j + 1) / 2;
+            unsigned long long key = ~0ull;
+            if (ok) {
+                double prob;
+                if (len <= 15) {
+                    McRgState rg; rg.clo = 0; rg.chi = 0; rg.sv = 0;
+                    for (int k = 0; k < len; k++) mc_rg_add(rg, s[w0 + k]);
+                    prob = mc_rg_getprob(lnf, rg.sv, len);
+                } else {
+                    mc_seg_comp(s + w0, len, ws.comp);
+                    mc_seg_state(ws.comp, ws.sv);
+                    prob = mc_seg_getprob(lnf, ws.sv, len);
+                }
+                key = mc_seg_key(prob);
+            }
+            const unsigned long long old = WL->best[r];
+            mc_wave_sync();
+            if (ok && key < MC_SEG_KEY_ONE) atomicMin(&WL->best[r], key);
+            mc_wave_sync();
+            const unsigned long long nb = WL->best[r];
+            if (ok && nb != old) WL->bq[r] = 0xFFFFFFFFu;             // a smaller probability appeared in this round: forget the old window
+            mc_wave_sync();
+            if (ok && key == nb && key < MC_SEG_KEY_ONE) atomicMin(&WL->bq[r], q);
+            mc_wave_sync();
+        }
+        // ---- the owners take their results and go on
+        if (st == WAIT) {
+            const uint32_t q = WL->bq[myr];
+            int lend = 0, rend = myn - 1;
+            if (q != 0xFFFFFFFFu) {
+                int j = (int)((sqrtf((float)(8u * q + 1u)) - 1.0f) * 0.5f);
+                while ((uint32_t)((j + 1) * (j + 2) / 2) <= q) j++;
+                while ((uint32_t)(j * (j + 1) / 2) > q) j--;
+                const int len = myn - j, w0 = (int)q - j * (j + 1) / 2;
+                lend = w0; rend = len + w0 - 1;
+            }
+            const int leftend = loi + lend, rightend = hii - (myn - rend - 1);
+            if (i < leftend) {
+                const int l2 = loi, r2 = leftend - 1;
+                if (sp < 8) { ws.stk[2 * sp] = (int16_t)(base + l2); ws.stk[2 * sp + 1] = (int16_t)(r2 - l2 + 1); sp++; }
+            }
+            for (int k = leftend; k <= rightend; k++) mc_bits_set(mk, base + k);
+            any = true;
+            i = ((hii < rightend) ? hii : rightend) + 1;
+            lowlim = i;
+            st = SCAN;
+        }
+        mc_wave_sync();
+    }
+    if (any) for (int k = 0; k < n; k++) if (mc_bits_test(mk, k)) prot[k] = MC_INV;
+}
+
+// One thread per (read, frame); a block of 256 threads owns 42 consecutive reads (252 frames).  The reads are staged
+// into LDS with coalesced loads, every thread translates its frame into its own LDS row, the four waves run SEG on their
+// 64 frames each (mc_seg_wave) and the block writes the frames back with coalesced stores.  LDS per block:
+// max(42*L, 4 x 1,416) + ln n! + 256*(FP+76) bytes (~40 KB at 150 bp; the staging area is reused by the SEG queues).
 __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restrict__ T, const uint8_t *__restrict__ reads, int L,
                                                        int64_t nreads, uint8_t *__restrict__ frames, int FP)
 {
@@ -64,10 +228,10 @@ __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restric
     const int nr = (int)((nreads - r0) < MC_TS_READS ? (nreads - r0) : MC_TS_READS);
     const int rbytes = nr * L;
     const int stride = MC_TS_STRIDE(FP);                         // per-thread LDS row: prot[FP] comp[20] sv[24] stk[32]
-    __shared__ int32_t fxs[64];                                  // fixed-point entropy tables of mc_seg_mask_fx
+    __shared__ int32_t fxs[64];                                  // fixed-point entropy tables (mc_seg_mask_fx)
     uint8_t *sreads = smem;
     const int nlnf = MC_TS_NLNF(FP);
-    double *lnf = (double *)(smem + (((MC_TS_READS * L) + 15) & ~15));       // ln n! for n <= max(frame length, 20): all the trimming asks for
+    double *lnf = (double *)(smem + MC_TS_STAGE(L));             // ln n! for n <= max(frame length, 20): all the trimming asks for
     uint8_t *rows = (uint8_t *)(lnf + nlnf);
     if (tid < 64) fxs[tid] = T->seg_dout[tid];                   // seg_dout, seg_din, seg_tlo, seg_thi are contiguous
     for (int i = tid; i < nlnf; i += 256) lnf[i] = T->lnfac[i];
@@ -79,13 +243,14 @@ __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restric
     const int lr = tid / 6, f = tid - lr * 6;
     uint8_t *prot = rows + (size_t)tid * stride;
     int n = 0;
-    if (lr < nr) {
-        n = mc_translate_frame(*T, sreads + lr * L, L, f, prot);
+    if (lr < nr) n = mc_translate_frame(*T, sreads + lr * L, L, f, prot);
+    __syncthreads();                                             // the staged reads are dead: their space becomes the SEG queues
+    {
         McSegWS ws; ws.comp = prot + FP; ws.sv = prot + FP + 20; ws.stk = (int16_t *)(prot + FP + 44);
 #ifndef MC_EXP_NOSEG
-        mc_seg_mask_fx(lnf, fxs, prot, n, ws);
+        mc_seg_wave(lnf, fxs, prot, n, lr < nr, ws, (McSegWaveLds *)smem + (tid >> 6), smem, mc_lane());
 #endif
-        for (int i = n; i < FP; i++) prot[i] = MC_INV;
+        if (lr < nr) for (int i = n; i < FP; i++) prot[i] = MC_INV;
     }
     __syncthreads();
     {   // frames of the block are contiguous in global memory: nr*6 rows of FP bytes
@@ -151,10 +316,6 @@ struct McEnWave {
 };
 
 extern __shared__ __attribute__((aligned(16))) uint8_t mc_smem[];   // dynamic LDS of the kernels that use it
-
-__device__ __forceinline__ int mc_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-// orders the wave's own LDS traffic for the compiler; the hardware executes one wave's LDS instructions in order
-__device__ __forceinline__ void mc_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 // item: bucket(20) | qk(16)<<20 | pos(8)<<36 | frame(3)<<44 | phase(6)<<47
 // Appends the seed hits of one batch of probes (lane: cnt postings starting at posting index nst of its bucket).
@@ -778,7 +939,7 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
     HIPCK(hipEventRecord(h->ev[0], st));
     {
         const int64_t threads = n * 6;
-        size_t lds = (size_t)(((MC_TS_READS * L) + 15) & ~15) + (size_t)MC_TS_NLNF(FP) * 8 + (size_t)256 * MC_TS_STRIDE(FP);
+        size_t lds = (size_t)MC_TS_STAGE(L) + (size_t)MC_TS_NLNF(FP) * 8 + (size_t)256 * MC_TS_STRIDE(FP);
         if (lds > 48 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_translate_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         k_translate_seg<<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(256), lds, st>>>(h->d_T, d_reads, L, n, h->d_frames, FP);
         HIPCK(hipEventRecord(h->ev[1], st));
