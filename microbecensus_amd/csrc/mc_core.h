@@ -65,6 +65,13 @@ struct McTables {
     double letter_p[10];       // Db+0x28
 };
 
+// the members of McTables that the extension kernels read per residue, small enough for LDS (1.1 KB)
+struct McHot {
+    int8_t sub[32 * 32];
+    uint8_t grp[32];
+    double xdrop_ungapped, xdrop_gapped, gap_trigger;
+};
+
 struct McIndex {
     const uint8_t *res;        // dense residue codes of all marker sequences
     const uint32_t *off;       // nseq+1
@@ -72,7 +79,7 @@ struct McIndex {
     const uint32_t *post;      // seqIdx<<11 | pos, in prerapsearch bucket order
     const uint16_t *keys;      // 4 reduced residues after the 6-mer, 0xF past the sequence end
     const struct McBucketRec *rec;   // per bucket: start + first-residue group boundaries (NULL when the index cannot use them)
-    const uint32_t *filt;      // MC_FILT_WORDS words: Bloom filter over the (bucket, 4-residue key) pairs of the index
+    const uint32_t *filt;      // MC_FILT_TOTAL_WORDS words: Bloom filters over the (bucket, key) pairs of the index (10-mers, then 9-mers)
     int32_t nseq;
 };
 
@@ -670,6 +677,12 @@ MC_HD int mc_key_range_rec(const McBucketRec *rec, const uint16_t *keys, int see
 // false negatives, ~2 % false positives; a positive goes through the exact range search as before.
 #define MC_FILT_LOG2W 19
 #define MC_FILT_WORDS (1u << MC_FILT_LOG2W)
+// The exact 9-mer probes (3-residue key, written g6 g7 g8 F) get the same treatment with a filter of their own: such a
+// probe matches exactly the postings whose first three key residues equal its own (keys shorter than 3 sort in front of
+// the range), so the filter holds (bucket, k | 0xF) of every posting with at least 3 key residues.  2^18 words (1 MB).
+#define MC_FILT9_LOG2W 18
+#define MC_FILT9_WORDS (1u << MC_FILT9_LOG2W)
+#define MC_FILT_TOTAL_WORDS (MC_FILT_WORDS + MC_FILT9_WORDS)   // one array: the 10-mer filter, then the 9-mer filter
 MC_HD uint32_t mc_filter_hash(uint32_t bucket, uint32_t key)
 {
     uint32_t x = bucket * 0x9E3779B1u + key * 0x85EBCA77u;
@@ -677,6 +690,7 @@ MC_HD uint32_t mc_filter_hash(uint32_t bucket, uint32_t key)
     return x;
 }
 MC_HD uint32_t mc_filter_word(uint32_t h) { return h >> (32 - MC_FILT_LOG2W); }
+MC_HD uint32_t mc_filter9_word(uint32_t h) { return MC_FILT_WORDS + (h >> (32 - MC_FILT9_LOG2W)); }
 MC_HD uint32_t mc_filter_bits(uint32_t h) { return (1u << (h & 31)) | (1u << ((h >> 5) & 31)); }
 
 MC_HD uint32_t mc_pack_key(const uint8_t *g, int nkey)
@@ -774,7 +788,9 @@ MC_HDN void mc_enumerate_seeds(const McTables &T, const McIndex &X, const uint8_
 // ---------------------------------------------------------------------------------------------
 #define MC_SUB(T, a, b) ((int)(T).sub[((a) << 5) | (b)])
 
-MC_HDN int mc_eval_seed(const McTables &T, const McIndex &X, const uint8_t *q, int qlen, int frame, int qpos,
+// TT: McTables, or a compact copy of its hot members (sub, grp, xdrop_*, gap_trigger) - the kernels keep one in LDS
+template <class TT>
+MC_HDN int mc_eval_seed(const TT &T, const McIndex &X, const uint8_t *q, int qlen, int frame, int qpos,
                         uint32_t posting, int seedlen, int nkey, McGapTask *gt)
 {
     int dpos = (int)(posting & 0x7ff), sidx = (int)(posting >> 11);
@@ -857,7 +873,8 @@ struct McGapResult { int gain, c1, c2, ident, steps, runs, gapcols; };
 // workspace: H, D (int) and PH, PD (McPath), each n2+2 entries.
 //   PH[j] = step sequence (origin .. cell) the trace would follow from main[i][j]
 //   PD[j] = the same for the D plane of the cell
-MC_HDN McGapResult mc_align_gapped(const McTables &T, const uint8_t *s1, int st1, const uint8_t *s2, int st2, int n1, int n2,
+template <class TT>
+MC_HDN McGapResult mc_align_gapped(const TT &T, const uint8_t *s1, int st1, const uint8_t *s2, int st2, int n1, int n2,
                                    int *H, int *D, McPath *PH, McPath *PD)
 {
     const int open = MC_GAP_OPEN, ext = MC_GAP_EXT, first = MC_GAP_OPEN + MC_GAP_EXT;

@@ -41,7 +41,7 @@ extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
     } while (0)
 
 enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_N = 8 };
-enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_N = 4 };   // 64-bit algorithmic-traffic counters of k_enumerate
+enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_N = 16 };   // 64-bit algorithmic-traffic counters of k_enumerate; slots 4..: cycle counters of the MC_EXP_TIMING build
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -260,6 +260,14 @@ __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restric
     }
 }
 
+// copies the hot members of the tables into LDS (block-wide; callers __syncthreads() afterwards)
+__device__ __forceinline__ void mc_load_hot(McHot *H, const McTables *T)
+{
+    for (int i = threadIdx.x; i < 32 * 32 / 4; i += blockDim.x) ((uint32_t *)H->sub)[i] = ((const uint32_t *)T->sub)[i];
+    if (threadIdx.x < 32) H->grp[threadIdx.x] = T->grp[threadIdx.x];
+    if (threadIdx.x == 0) { H->xdrop_ungapped = T->xdrop_ungapped; H->xdrop_gapped = T->xdrop_gapped; H->gap_trigger = T->gap_trigger; }
+}
+
 struct DevEmit {
     McSeedTask *tasks; uint32_t *counters; uint32_t cap; uint32_t read; int frame; const McIndex *X; uint32_t emitted;
     __device__ void operator()(int bucket, int nst, int cnt, int seedlen, int nkey, int pos, int phase)
@@ -326,13 +334,13 @@ __device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long
     if (m == 0) return 0;
     const int pos = (int)((item >> 36) & 0xFF), frame = (int)((item >> 44) & 7), phase = (int)((item >> 47) & 63);
     if (phase == 0 && cnt > 0) atomicOr(&W->hit[frame][pos >> 5], 1u << (pos & 31));
-    // exclusive prefix over the (few) lanes that found something
-    uint32_t total = 0, mine = 0;
+#ifdef MC_EXP_NORESERVE
+    return (uint32_t)cnt;
+#endif
+    // total over the (few) lanes that found something
+    uint32_t total = 0;
     while (m) {
-        const int l = __builtin_ctzll(m);
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane(cnt, l);
-        if (lane == l) mine = total;
-        total += c;
+        total += (uint32_t)__builtin_amdgcn_readlane(cnt, __builtin_ctzll(m));
         m &= m - 1;
     }
     uint32_t base;
@@ -356,14 +364,30 @@ __device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long
         if (lane == 0) { W->blk_base = bb; W->blk_used = bu + total; }
         mc_wave_sync();
     }
-    if (cnt > 0) {
-        const uint32_t o = base + mine;
-        const uint32_t sn = phase == 0 ? (9u | (3u << 8)) : (10u | (4u << 8));
-        for (int i = 0; i < cnt; i++) {
-            McSeedTask t;
-            t.read = read; t.chrono = MC_CHRONO(frame, pos, phase, nst + i); t.posting = X.post[start + nst + i];
-            t.seedlen_nkey = sn;
-            tasks[o + i] = t;
+#ifdef MC_EXP_NOAPPEND
+    return (uint32_t)cnt;
+#endif
+    // the ranges are written by the whole wave, one range after the other: a conserved 10-mer occurs in hundreds of
+    // homologous markers, and a lane that wrote its own range alone would keep the other 63 waiting
+    {
+        unsigned long long mm = __ballot(cnt > 0);
+        uint32_t run = 0;
+        while (mm) {
+            const int l = __builtin_ctzll(mm);
+            mm &= mm - 1;
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane(cnt, l);
+            const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)item, l), hi32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(item >> 32), l);
+            const unsigned long long it = ((unsigned long long)hi32 << 32) | lo32;
+            const uint32_t st0 = (uint32_t)__builtin_amdgcn_readlane((int)start, l), ns0 = (uint32_t)__builtin_amdgcn_readlane(nst, l);
+            const int p2 = (int)((it >> 36) & 0xFF), f2 = (int)((it >> 44) & 7), ph2 = (int)((it >> 47) & 63);
+            const uint32_t sn = ph2 == 0 ? (9u | (3u << 8)) : (10u | (4u << 8));
+            for (uint32_t i = (uint32_t)lane; i < c; i += 64) {
+                McSeedTask t;
+                t.read = read; t.chrono = MC_CHRONO(f2, p2, ph2, ns0 + i); t.posting = X.post[st0 + ns0 + i];
+                t.seedlen_nkey = sn;
+                tasks[base + run + i] = t;
+            }
+            run += c;
         }
     }
     return (uint32_t)cnt;
@@ -379,6 +403,9 @@ __device__ __forceinline__ unsigned long long mc_en_process(const McIndex &X, un
     uint32_t start = 0, kp = 0;
     int c0 = 0;
     bool heavy = false;
+#ifdef MC_EXP_NOPROC1
+    if (((item >> 47) & 63) != 0) active = false;
+#endif
     if (active) {
         const int bucket = (int)(item & 0xFFFFF);
         const uint32_t qk = (uint32_t)((item >> 20) & 0xFFFF);
@@ -407,6 +434,9 @@ __device__ __forceinline__ unsigned long long mc_en_heavy(const McIndex &X, unsi
 {
     int cnt = 0, lb = 0, c0 = 0;
     uint32_t start = 0, kp = 0;
+#ifdef MC_EXP_NOHEAVYPROC
+    active = false;
+#endif
     if (active) {
         const int bucket = (int)(item & 0xFFFFF);
         const uint32_t qk = (uint32_t)((item >> 20) & 0xFFFF);
@@ -421,6 +451,11 @@ __device__ __forceinline__ unsigned long long mc_en_heavy(const McIndex &X, unsi
     return ((unsigned long long)kp << 32) | ((unsigned long long)nt << 8);
 }
 
+#ifdef MC_EXP_TIMING
+#define MC_TICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[tcat] += now_ - tlast; tcnt[tcat]++; tlast = now_; tcat = (k); } while (0)
+#else
+#define MC_TICK(k) do { } while (0)
+#endif
 template <int MC_EN_WAVES, bool COUNT>
 __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTables *__restrict__ T, McIndex X, const uint32_t *__restrict__ bitmap,
                                                                    const uint8_t *__restrict__ frames, int FP, int L, int64_t nreads, McSeedTask *tasks,
@@ -442,8 +477,12 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
     McSeedCount sc; sc.lookups = 0; sc.keyprobes = 0; sc.tasks = 0;
     const unsigned long long lt = (1ull << lane) - 1;
     const int64_t nw = (int64_t)gridDim.x * MC_EN_WAVES;
+#ifdef MC_EXP_TIMING
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tcnt[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter(); int tcat = 0;   // 0 staging/other 1 heavy 2 process 3 push 4 setup 5 group
+#endif
     for (int64_t r = (int64_t)blockIdx.x * MC_EN_WAVES + wv; r < nreads; r += nw) {
         int qn = 0, hn = 0;
+        MC_TICK(0);
         {   // stage the six frames of this read (rows of FP bytes) into the wave's LDS area, clear the flags
             const uint8_t *src = frames + r * 6 * FP;
             for (int f = 0; f < 6; f++) for (int i = lane; i < FP; i += 64) fr[f * FPs + i] = src[f * FP + i];
@@ -456,7 +495,11 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
         // - with the counters off - the 10-mer Bloom filter (ten independent L2 gathers); the survivors wait in the
         // per-lane mask pm and are queued one per lane and iteration.  The generator is a state machine so that each
         // queue consumer exists once in the kernel.
+#ifdef MC_EXP_PASS0ONLY
+        for (int pass = 0; pass < 1; pass++) {
+#else
         for (int pass = 0; pass < 2; pass++) {
+#endif
             const int ngroups = pass == 0 ? 1 : 4;
             int f = -1, p0 = 0, qlen = 0, g = ngroups;
             bool more = true;
@@ -467,6 +510,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
             const uint8_t *q = fr;
             for (;;) {
                 if (hn >= 64 || (!more && qn == 0 && hn > 0)) {          // probes that need the binary searches
+                    MC_TICK(1);
                     const int take = hn < 64 ? hn : 64;
                     hn -= take;
                     const unsigned long long rh = mc_en_heavy<COUNT>(X, (lane < take) ? W->hq[hn + lane] : 0ull, lane < take, (uint32_t)r, W, tasks, cap, counters, lane);
@@ -475,6 +519,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                     continue;
                 }
                 if (qn >= 64 || (!more && qn > 0)) {                     // probes that passed the filters
+                    MC_TICK(2);
                     const int take = qn < 64 ? qn : 64;
                     qn -= take;
                     const unsigned long long ret = mc_en_process<COUNT>(X, (lane < take) ? W->q[qn + lane] : 0ull, lane < take, (uint32_t)r, W, hn, tasks, cap, counters, lane);
@@ -486,6 +531,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                 {   // queue one surviving probe per lane
                     const unsigned long long pmm = __ballot(pm != 0);
                     if (pmm) {
+                        MC_TICK(3);
                         const int j = __builtin_ctz(pm | 0x400u), gc = g - 1;
                         int v = seed, phase = 0;
                         uint32_t k2 = qk;
@@ -503,6 +549,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                 }
                 if (!more) break;
                 if (g >= ngroups) {                                      // next chunk of positions / next frame
+                    MC_TICK(4);
                     if (f >= 0) p0 += 64;
                     if (f < 0 || p0 + 6 >= qlen) {
                         f++; p0 = 0;
@@ -557,7 +604,15 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                     continue;
                 }
                 // generate group g of the current chunk
-                if (pass == 0) pm = live ? 1u : 0u;
+                MC_TICK(5);
+                if (pass == 0) {
+                    pm = live ? 1u : 0u;
+                    if (!COUNT) {   // 9-mer Bloom filter: most exact probes find nothing and need no search
+                        const uint32_t hh = mc_filter_hash((uint32_t)seed, qk), fb9 = mc_filter_bits(hh);
+                        const uint32_t fw9 = X.filt[live ? mc_filter9_word(hh) : 0u];
+                        if ((fw9 & fb9) != fb9) pm = 0;
+                    }
+                }
                 else {
                     const int st = g == 0 ? 10 : g == 1 ? 1 : 100, d = g == 0 ? d4 : g == 1 ? d5 : d3;
                     uint32_t ok = 0, fw[10], fb[10];
@@ -579,12 +634,22 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                         for (int j = 0; j < 10; j++) if ((fw[j] & fb[j]) != fb[j]) ok &= ~(1u << j);
                     }
                     pm = ok;
+#ifdef MC_EXP_NOPUSH
+                    pm = 0;
+#endif
+#ifdef MC_EXP_FILTERONLY
+                    pm = (ok == 0x12345678u) ? ok : 0u;
+#endif
                 }
                 g++;
             }
             mc_wave_sync();
         }
     }
+    MC_TICK(0);
+#ifdef MC_EXP_TIMING
+    if (lane == 0) for (int k = 0; k < 6; k++) { atomicAdd(&stats[4 + k], tacc[k]); atomicAdd(&stats[10 + k], tcnt[k]); }
+#endif
     {   // close the wave's last block
         mc_wave_sync();
         const uint32_t bb = W->blk_base, bu = W->blk_used;
@@ -601,6 +666,9 @@ __global__ void __launch_bounds__(256) k_eval_seeds(const McTables *__restrict__
                                                     const McSeedTask *__restrict__ tasks, uint32_t ntasks, McHsp *hsps, uint32_t cap_hsps,
                                                     McGapTask *gaps, uint32_t cap_gaps, uint32_t *counters)
 {
+    __shared__ McHot hot;
+    mc_load_hot(&hot, T);
+    __syncthreads();
     uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= ntasks) return;
     McSeedTask t = tasks[tid];
@@ -609,7 +677,7 @@ __global__ void __launch_bounds__(256) k_eval_seeds(const McTables *__restrict__
     int qlen = (L - frame % 3) / 3;
     McGapTask g;
     g.read = t.read; g.chrono = t.chrono;
-    int rc = mc_eval_seed(*T, X, frames + ((int64_t)t.read * 6 + frame) * FP, qlen, frame, pos, t.posting, (int)(t.seedlen_nkey & 0xff), (int)(t.seedlen_nkey >> 8), &g);
+    int rc = mc_eval_seed(hot, X, frames + ((int64_t)t.read * 6 + frame) * FP, qlen, frame, pos, t.posting, (int)(t.seedlen_nkey & 0xff), (int)(t.seedlen_nkey >> 8), &g);
     if (rc == 1) {
         McHsp h;
         h.read = t.read; h.chrono = t.chrono;
@@ -629,6 +697,9 @@ __global__ void __launch_bounds__(128) k_gapped(const McTables *__restrict__ T, 
                                                 const McGapTask *__restrict__ gaps, uint32_t ngaps, McHsp *hsps, uint32_t cap_hsps, uint32_t *counters,
                                                 int *wsH, int *wsD, McPath *wsPH, McPath *wsPD)
 {
+    __shared__ McHot hot;
+    mc_load_hot(&hot, T);
+    __syncthreads();
     uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
     int *Hh = wsH + (size_t)tid * MC_GAP_W, *Dd = wsD + (size_t)tid * MC_GAP_W;
     McPath *PH = wsPH + (size_t)tid * MC_GAP_W, *PD = wsPD + (size_t)tid * MC_GAP_W;
@@ -643,12 +714,12 @@ __global__ void __launch_bounds__(128) k_gapped(const McTables *__restrict__ T, 
         int alnlen = g.qfwd + g.L + g.qbwd, gapopens = 0, gaptotal = 0;
         int qend = qfwd + g.qp + g.L, dend = dfwd + g.dp + g.L, dright = dlen - dend, qright = qlen - qend;
         if (dright > 2 && qright > 2) {
-            McGapResult R = mc_align_gapped(*T, q + qend, 1, d + dend, 1, qright, dright, Hh, Dd, PH, PD);
+            McGapResult R = mc_align_gapped(hot, q + qend, 1, d + dend, 1, qright, dright, Hh, Dd, PH, PD);
             if (R.gain > 0) { score += R.gain; nmatch += R.ident; qfwd += R.c1; dfwd += R.c2; alnlen += R.steps; gapopens += R.runs; gaptotal += R.gapcols; }
         }
         int dleft = g.dp - dbwd, qleft = g.qp - qbwd;
         if (dleft > 2 && qleft > 2) {
-            McGapResult R = mc_align_gapped(*T, q + qleft - 1, -1, d + dleft - 1, -1, qleft, dleft, Hh, Dd, PH, PD);
+            McGapResult R = mc_align_gapped(hot, q + qleft - 1, -1, d + dleft - 1, -1, qleft, dleft, Hh, Dd, PH, PD);
             if (R.gain > 0) { score += R.gain; nmatch += R.ident; qbwd += R.c1; dbwd += R.c2; alnlen += R.steps; gapopens += R.runs; gaptotal += R.gapcols; }
         }
         McHsp h;
@@ -1030,7 +1101,11 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
     std::sort(bh.begin(), bh.end(), [](const McBestHit &x, const McBestHit &y) { return x.read < y.read; });
     h->best.reserve(bh.size());
     for (const McBestHit &x : bh) { mc_best_hit o; o.read = x.read; o.family = x.family; o.aln = x.aln; o.target_len = x.target_len; o.bits = x.bits; h->best.push_back(o); }
-    { unsigned long long ss[S_N]; HIPCK(hipMemcpy(ss, h->d_stats, sizeof ss, hipMemcpyDeviceToHost)); h->stats.bucket_lookups = (int64_t)ss[S_LOOKUPS]; h->stats.key_probes = (int64_t)ss[S_KEYPROBES]; h->stats.seed_tasks = (int64_t)ss[S_TASKS]; }
+    { unsigned long long ss[S_N]; HIPCK(hipMemcpy(ss, h->d_stats, sizeof ss, hipMemcpyDeviceToHost));
+#ifdef MC_EXP_TIMING
+      { const char *nm[6] = {"staging/other", "heavy", "process", "push", "setup", "group"}; for (int k = 0; k < 6; k++) fprintf(stderr, "timing %-14s %8.3f Mcycles/wave-avg  %10llu entries\n", nm[k], (double)ss[4 + k] / 3584.0 / 1e6, ss[10 + k]); }
+#endif
+      h->stats.bucket_lookups = (int64_t)ss[S_LOOKUPS]; h->stats.key_probes = (int64_t)ss[S_KEYPROBES]; h->stats.seed_tasks = (int64_t)ss[S_TASKS]; }
     h->stats.gap_tasks = ngaps; h->stats.hsps = nh; h->stats.rows = nrows; h->stats.reads_with_rows = with_rows; h->stats.classified = (int64_t)h->best.size();
     h->stats.ms_translate = ev_ms(h->ev[0], h->ev[1]); h->stats.ms_seed = ev_ms(h->ev[1], h->ev[2]); h->stats.ms_eval = ev_ms(h->ev[2], h->ev[3]);
     h->stats.ms_gapped = ev_ms(h->ev[3], h->ev[4]); h->stats.ms_sort = ev_ms(h->ev[4], h->ev[5]); h->stats.ms_finish = ev_ms(h->ev[5], h->ev[6]); h->stats.ms_total = ev_ms(h->ev[0], h->ev[6]);

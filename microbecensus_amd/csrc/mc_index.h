@@ -214,10 +214,14 @@ inline bool mc_build_index(McHostIndex &X, const char *const *names, const char 
         if (!ok) X.rec.clear();
     }
     // 10-mer filter (mc_filter_hash): every posting whose key has 4 residues
-    X.filt.assign(MC_FILT_WORDS, 0);
+    X.filt.assign(MC_FILT_TOTAL_WORDS, 0);
     for (int b = 0; b < MC_NBUCKET; b++)
         for (uint32_t i = X.bstart[b]; i < X.bstart[b + 1]; i++) {
             const uint32_t k = X.keys[i];
+            if ((k & 0xF0) != 0xF0) {                          // at least 3 key residues: inside the range of its 9-mer probe
+                const uint32_t h9 = mc_filter_hash((uint32_t)b, k | 0xFu);
+                X.filt[mc_filter9_word(h9)] |= mc_filter_bits(h9);
+            }
             if ((k & 0xF) == 0xF) continue;                    // shorter key: never inside the range of a 10-mer probe
             const uint32_t h = mc_filter_hash((uint32_t)b, k);
             X.filt[mc_filter_word(h)] |= mc_filter_bits(h);

@@ -63,7 +63,7 @@ int main(int argc, char **argv)
         McIndex Xc; Xc.res = H.res.data(); Xc.off = H.off.data(); Xc.bstart = H.bstart.data(); Xc.post = H.post.data(); Xc.keys = H.keys.data(); Xc.rec = H.rec.data(); Xc.filt = H.filt.data(); Xc.nseq = H.nseq;
         if (H.rec.empty()) { fprintf(stderr, "scan check: the index has no bucket records\n"); return 3; }
         fprintf(stderr, "largest bucket: %u postings\n", H.max_bucket);
-        long checked = 0, bad = 0, fneg = 0, fpos = 0, fq = 0;
+        long checked = 0, bad = 0, fneg = 0, fpos = 0, fq = 0, f9q = 0, f9pos = 0;
         for (int b = 0; b < MC_NBUCKET; b++) {
             uint32_t n = H.bstart[b + 1] - H.bstart[b];
             for (uint32_t i = 0; i < n; i++) {
@@ -79,6 +79,13 @@ int main(int argc, char **argv)
                     int r1 = mc_key_range(Xc, b, qk, &n1, &s1), r2 = mc_key_range_rec(Xc.rec, Xc.keys, b, qk, &n2, &s2);
                     checked++;
                     if (r1 != r2 || (r1 > 0 && n1 != n2) || s1.keyprobes != s2.keyprobes || s1.lookups != s2.lookups) bad++;
+                    if (mc_klen(qk) == 3 && (qk & 0xF) == 0xF) {              // exact 9-mer probe: its filter may not lose a range either
+                        const uint32_t hh = mc_filter_hash((uint32_t)b, qk), bits = mc_filter_bits(hh);
+                        const bool pass = (H.filt[mc_filter9_word(hh)] & bits) == bits;
+                        f9q++;
+                        if (r1 > 0 && !pass) fneg++;
+                        if (r1 == 0 && pass) f9pos++;
+                    }
                     if (mc_klen(qk) == 4) {                                   // 10-mer probe: the filter may not lose a range
                         const uint32_t hh = mc_filter_hash((uint32_t)b, qk), bits = mc_filter_bits(hh);
                         const bool pass = (H.filt[mc_filter_word(hh)] & bits) == bits;
@@ -90,7 +97,8 @@ int main(int argc, char **argv)
             }
         }
         fprintf(stderr, "scan check: %ld probes, %ld mismatches\n", checked, bad);
-        { long set = 0; for (uint32_t w : H.filt) set += __builtin_popcount(w); fprintf(stderr, "filter check: %ld 10-mer probes, %ld false negatives, %ld false positives among near misses, %.1f %% of the bits set\n", fq, fneg, fpos, 100.0 * (double)set / (32.0 * MC_FILT_WORDS)); }
+        { long set = 0, set9 = 0; for (uint32_t i = 0; i < MC_FILT_TOTAL_WORDS; i++) (i < MC_FILT_WORDS ? set : set9) += __builtin_popcount(H.filt[i]);
+          fprintf(stderr, "filter check: %ld 10-mer and %ld 9-mer probes, %ld false negatives, %ld / %ld false positives among near misses, %.1f %% / %.1f %% of the bits set\n", fq, f9q, fneg, fpos, f9pos, 100.0 * (double)set / (32.0 * MC_FILT_WORDS), 100.0 * (double)set9 / (32.0 * MC_FILT9_WORDS)); }
         return (bad || fneg) ? 3 : 0;
     }
     int read_len = rs.empty() ? 0 : (int)rs[0].size();
