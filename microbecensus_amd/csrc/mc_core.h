@@ -79,6 +79,7 @@ struct McIndex {
     const uint32_t *post;      // seqIdx<<11 | pos, in prerapsearch bucket order
     const uint16_t *keys;      // 4 reduced residues after the 6-mer, 0xF past the sequence end
     const struct McBucketRec *rec;   // per bucket: start + first-residue group boundaries (NULL when the index cannot use them)
+    const uint32_t *wild;      // MC_WILD_LINES x 16 words: wildcard filter (mc_wild_*)
     const uint32_t *filt;      // MC_FILT_TOTAL_WORDS words: Bloom filters over the (bucket, key) pairs of the index (10-mers, then 9-mers)
     int32_t nseq;
 };
@@ -692,6 +693,41 @@ MC_HD uint32_t mc_filter_hash(uint32_t bucket, uint32_t key)
 MC_HD uint32_t mc_filter_word(uint32_t h) { return h >> (32 - MC_FILT_LOG2W); }
 MC_HD uint32_t mc_filter9_word(uint32_t h) { return MC_FILT_WORDS + (h >> (32 - MC_FILT9_LOG2W)); }
 MC_HD uint32_t mc_filter_bits(uint32_t h) { return (1u << (h & 31)) | (1u << ((h >> 5) & 31)); }
+
+// ---- wildcard filter: one probe instead of ten ----------------------------------------------------------------------
+// The neighbourhood of a position is its 10-mer with ONE residue substituted, at offset 3, 4 or 5 (a digit of the bucket)
+// or 6 (the first key residue): 4 groups of 9 probes.  Instead of asking the 10-mer filter 36 times, the kernel first
+// asks, per group, "does the index hold ANY 10-mer that equals mine except at this offset?".  The index 10-mers are
+// entered four times, each time with one of the four middle residues left out.  Layout for locality: the six outer
+// residues (offsets 0-2 and 7-9) pick a 64-byte line, the wildcard position picks one of its four 128-bit quarters, the
+// three remaining middle residues pick two bits in it - so the four questions of a position cost ONE cache line.
+// A negative answer is exact (no 10-mer of the group can match); a positive one (2-3 % false) sends the group through the
+// per-probe path (10-mer filter, then the range search).  2^17 lines = 8 MB.
+#define MC_WILD_LOG2L 17
+#define MC_WILD_LINES (1u << MC_WILD_LOG2L)
+MC_HD uint32_t mc_wild_ctx(uint32_t seed, uint32_t key) { return (seed / 1000u) * 4096u + (key & 0xFFFu); }
+MC_HD uint32_t mc_wild_line(uint32_t ctx)
+{
+    uint32_t x = ctx * 0x9E3779B1u;
+    x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
+    return x >> (32 - MC_WILD_LOG2L);
+}
+// group g: 0 = offset 4 (stride 10), 1 = offset 5 (stride 1), 2 = offset 3 (stride 100), 3 = offset 6 (first key residue)
+MC_HD uint32_t mc_wild_bits(uint32_t ctx, uint32_t seed, uint32_t key, int g)
+{ // two bit positions (7 bit each) inside the quarter: low and high halves of the result
+    const uint32_t b3 = (seed / 100u) % 10u, b4 = (seed / 10u) % 10u, b5 = seed % 10u, k0 = key >> 12;
+    const uint32_t a = (g == 2) ? b4 : b3, b = (g == 0 || g == 2) ? b5 : b4, c = (g == 3) ? b5 : k0;
+    uint32_t x = (ctx + 0x51ED27u * (uint32_t)(g + 1)) * 0x2C1B3C6Du + ((a << 8) | (b << 4) | c) * 0x297A2D39u;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15;
+    return (x & 127u) | (((x >> 7) & 127u) << 8);
+}
+MC_HD bool mc_wild_test(const uint32_t q[4], uint32_t bits)
+{
+    const uint32_t p1 = bits & 127u, p2 = bits >> 8;
+    const uint32_t w1 = (p1 < 64) ? ((p1 < 32) ? q[0] : q[1]) : ((p1 < 96) ? q[2] : q[3]);
+    const uint32_t w2 = (p2 < 64) ? ((p2 < 32) ? q[0] : q[1]) : ((p2 < 96) ? q[2] : q[3]);
+    return ((w1 >> (p1 & 31)) & (w2 >> (p2 & 31)) & 1u) != 0;
+}
 
 MC_HD uint32_t mc_pack_key(const uint8_t *g, int nkey)
 {

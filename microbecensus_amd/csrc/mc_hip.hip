@@ -500,12 +500,11 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
 #else
         for (int pass = 0; pass < 2; pass++) {
 #endif
-            const int ngroups = pass == 0 ? 1 : 4;
-            int f = -1, p0 = 0, qlen = 0, g = ngroups;
+            int f = -1, p0 = 0, qlen = 0;
             bool more = true;
             bool live = false, selfbucket = false;
-            int seed = 0, g6 = 0, d3 = 0, d4 = 0, d5 = 0;
-            uint32_t qk = 0, pm = 0;
+            int seed = 0, g6 = 0, d3 = 0, d4 = 0, d5 = 0, pgc = 0;
+            uint32_t qk = 0, pm = 0, wm = 0;             // pm: surviving probes of group pgc; wm: groups of this position still to generate
             unsigned long long hi = 0;
             const uint8_t *q = fr;
             for (;;) {
@@ -532,7 +531,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                     const unsigned long long pmm = __ballot(pm != 0);
                     if (pmm) {
                         MC_TICK(3);
-                        const int j = __builtin_ctz(pm | 0x400u), gc = g - 1;
+                        const int j = __builtin_ctz(pm | 0x400u), gc = pgc;
                         int v = seed, phase = 0;
                         uint32_t k2 = qk;
                         if (pass == 1) {
@@ -548,7 +547,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                     }
                 }
                 if (!more) break;
-                if (g >= ngroups) {                                      // next chunk of positions / next frame
+                if (__ballot(wm != 0) == 0) {                            // next chunk of positions / next frame
                     MC_TICK(4);
                     if (f >= 0) p0 += 64;
                     if (f < 0 || p0 + 6 >= qlen) {
@@ -600,31 +599,52 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                     }
                     d4 = (seed / 10) % 10; d5 = seed % 10; d3 = (seed / 100) % 10;
                     hi = ((unsigned long long)pos << 36) | ((unsigned long long)f << 44);
-                    g = (__ballot(live) == 0) ? ngroups : 0;
+                    // which groups of probes does this position have to generate?
+                    if (pass == 0) wm = live ? 1u : 0u;                  // the exact 9-mer
+                    else if (COUNT) wm = live ? 0xFu : 0u;               // counting form: every probe is searched
+                    else {                                               // wildcard filter: one cache line answers for the four groups
+                        wm = 0;
+                        if (__ballot(live)) {
+                            const uint32_t ctx = mc_wild_ctx((uint32_t)seed, qk);
+                            const uint4 *ln = (const uint4 *)X.wild + (size_t)(live ? mc_wild_line(ctx) : 0u) * 4;
+                            const uint4 q0 = ln[0], q1 = ln[1], q2 = ln[2], q3 = ln[3];
+                            const uint32_t a0[4] = {q0.x, q0.y, q0.z, q0.w}, a1[4] = {q1.x, q1.y, q1.z, q1.w}, a2[4] = {q2.x, q2.y, q2.z, q2.w}, a3[4] = {q3.x, q3.y, q3.z, q3.w};
+                            if (live) {
+                                wm = (mc_wild_test(a0, mc_wild_bits(ctx, (uint32_t)seed, qk, 0)) ? 1u : 0u) | (mc_wild_test(a1, mc_wild_bits(ctx, (uint32_t)seed, qk, 1)) ? 2u : 0u) |
+                                     (mc_wild_test(a2, mc_wild_bits(ctx, (uint32_t)seed, qk, 2)) ? 4u : 0u) | (mc_wild_test(a3, mc_wild_bits(ctx, (uint32_t)seed, qk, 3)) ? 8u : 0u);
+                            }
+                        }
+                    }
                     continue;
                 }
-                // generate group g of the current chunk
+                // every lane generates the next pending group of its position
                 MC_TICK(5);
+                const bool act = wm != 0;
+                const int gl = __builtin_ctz(wm | 16u);
+                wm &= wm - 1;
+                pgc = gl;
                 if (pass == 0) {
-                    pm = live ? 1u : 0u;
+                    pm = act ? 1u : 0u;
                     if (!COUNT) {   // 9-mer Bloom filter: most exact probes find nothing and need no search
                         const uint32_t hh = mc_filter_hash((uint32_t)seed, qk), fb9 = mc_filter_bits(hh);
-                        const uint32_t fw9 = X.filt[live ? mc_filter9_word(hh) : 0u];
+                        const uint32_t fw9 = X.filt[act ? mc_filter9_word(hh) : 0u];
                         if ((fw9 & fb9) != fb9) pm = 0;
                     }
                 }
                 else {
-                    const int st = g == 0 ? 10 : g == 1 ? 1 : 100, d = g == 0 ? d4 : g == 1 ? d5 : d3;
+                    const bool isb = gl < 3;                             // a bucket digit is substituted (else the first key residue)
+                    const int st = gl == 0 ? 10 : gl == 1 ? 1 : gl == 2 ? 100 : 0, d = gl == 0 ? d4 : gl == 1 ? d5 : gl == 2 ? d3 : g6;
                     uint32_t ok = 0, fw[10], fb[10];
 #pragma unroll
                     for (int j = 0; j < 10; j++) {
-                        bool c;
-                        uint32_t vb = (uint32_t)seed, kk = qk;
-                        if (g < 3) { const int v = seed + (j - d) * st; c = live && j != d; if (COUNT && c) sc.lookups++; c = c && ((bm[v >> 5] >> (v & 31)) & 1); vb = (uint32_t)v; }
-                        else { c = live && j != g6; if (COUNT && c) sc.lookups++; c = c && selfbucket; kk = (qk & 0x0FFFu) | ((uint32_t)j << 12); }
+                        const int v = seed + (j - d) * st;               // st = 0 for the key group: the bucket stays
+                        const uint32_t kk = isb ? qk : ((qk & 0x0FFFu) | ((uint32_t)j << 12));
+                        bool c = act && j != d;
+                        if (COUNT && c) sc.lookups++;
+                        c = c && ((bm[v >> 5] >> (v & 31)) & 1);         // bitmap of the probed bucket (the own bucket for the key group)
                         ok |= (uint32_t)c << j;
                         if (!COUNT) {   // Bloom filter word of the 10-mer; lanes without a candidate read word 0
-                            const uint32_t hh = mc_filter_hash(vb, kk);
+                            const uint32_t hh = mc_filter_hash((uint32_t)v, kk);
                             fb[j] = mc_filter_bits(hh);
                             fw[j] = X.filt[c ? mc_filter_word(hh) : 0u];
                         }
@@ -634,14 +654,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                         for (int j = 0; j < 10; j++) if ((fw[j] & fb[j]) != fb[j]) ok &= ~(1u << j);
                     }
                     pm = ok;
-#ifdef MC_EXP_NOPUSH
-                    pm = 0;
-#endif
-#ifdef MC_EXP_FILTERONLY
-                    pm = (ok == 0x12345678u) ? ok : 0u;
-#endif
                 }
-                g++;
             }
             mc_wave_sync();
         }
@@ -815,7 +828,7 @@ struct mc_handle {
     unsigned long long *d_stats = nullptr;
     uint32_t *d_bitmap = nullptr;
     McBucketRec *d_rec = nullptr;
-    uint32_t *d_filt = nullptr;
+    uint32_t *d_filt = nullptr, *d_wild = nullptr;
     bool fast_enum = false;
     bool count_traffic = false;
     McSeedTask *d_tasks = nullptr; McGapTask *d_gaps = nullptr; McHsp *d_hsps = nullptr, *d_sorted = nullptr, *d_v = nullptr, *d_tmp = nullptr;
@@ -834,7 +847,7 @@ struct mc_handle {
 
 static McIndex dev_index(const mc_handle *h)
 {
-    McIndex X; X.res = h->d_res; X.off = h->d_off; X.bstart = h->d_bstart; X.post = h->d_post; X.keys = h->d_keys; X.rec = h->d_rec; X.filt = h->d_filt; X.nseq = h->H.nseq;
+    McIndex X; X.res = h->d_res; X.off = h->d_off; X.bstart = h->d_bstart; X.post = h->d_post; X.keys = h->d_keys; X.rec = h->d_rec; X.filt = h->d_filt; X.wild = h->d_wild; X.nseq = h->H.nseq;
     return X;
 }
 
@@ -858,7 +871,7 @@ extern "C" void mc_close(mc_handle *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_frames, h->d_tasks, h->d_gaps, h->d_hsps,
                     h->d_sorted, h->d_v, h->d_tmp, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, h->d_heads, h->d_sorttmp, h->d_counters, h->d_rows,
-                    h->d_nrow, h->d_rowoff, h->d_best, h->d_gH, h->d_gD, h->d_gPH, h->d_gPD, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt};
+                    h->d_nrow, h->d_rowoff, h->d_best, h->d_gH, h->d_gD, h->d_gPH, h->d_gPD, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->pin_rows) (void)hipHostFree(h->pin_rows);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -891,7 +904,8 @@ static int open_impl(mc_handle *h, const char *const *names, const char *const *
     HIPCK(hipMemcpy(h->d_fam, h->fam.data(), (size_t)nseq * 4, hipMemcpyHostToDevice));
     if (dalloc(&h->d_bitmap, H.bitmap.size())) return -1;
     HIPCK(hipMemcpy(h->d_bitmap, H.bitmap.data(), H.bitmap.size() * 4, hipMemcpyHostToDevice));
-    if (dalloc(&h->d_filt, H.filt.size())) return -1;
+    if (dalloc(&h->d_filt, H.filt.size()) || dalloc(&h->d_wild, H.wild.size())) return -1;
+    HIPCK(hipMemcpy(h->d_wild, H.wild.data(), H.wild.size() * 4, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_filt, H.filt.data(), H.filt.size() * 4, hipMemcpyHostToDevice));
     if (!H.rec.empty()) {
         if (dalloc(&h->d_rec, H.rec.size())) return -1;

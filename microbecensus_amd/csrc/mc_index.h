@@ -25,7 +25,8 @@ struct McHostIndex {
     std::vector<uint16_t> keys;
     std::vector<uint32_t> bitmap;      // 1 bit per bucket: non-empty
     std::vector<McBucketRec> rec;      // first-residue group boundaries per bucket; empty when the index cannot use them
-    std::vector<uint32_t> filt;        // Bloom filter over (bucket, key) of the postings with a full 4-residue key
+    std::vector<uint32_t> filt;        // Bloom filters over (bucket, key): 10-mers, then 9-mers
+    std::vector<uint32_t> wild;        // wildcard filter over the 10-mers (mc_wild_*)
     uint32_t max_bucket;
     uint32_t freq_thr;
     double letter_p[10];
@@ -215,6 +216,7 @@ inline bool mc_build_index(McHostIndex &X, const char *const *names, const char 
     }
     // 10-mer filter (mc_filter_hash): every posting whose key has 4 residues
     X.filt.assign(MC_FILT_TOTAL_WORDS, 0);
+    X.wild.assign((size_t)MC_WILD_LINES * 16, 0);
     for (int b = 0; b < MC_NBUCKET; b++)
         for (uint32_t i = X.bstart[b]; i < X.bstart[b + 1]; i++) {
             const uint32_t k = X.keys[i];
@@ -225,6 +227,12 @@ inline bool mc_build_index(McHostIndex &X, const char *const *names, const char 
             if ((k & 0xF) == 0xF) continue;                    // shorter key: never inside the range of a 10-mer probe
             const uint32_t h = mc_filter_hash((uint32_t)b, k);
             X.filt[mc_filter_word(h)] |= mc_filter_bits(h);
+            const uint32_t ctx = mc_wild_ctx((uint32_t)b, k), line = mc_wild_line(ctx);
+            for (int g = 0; g < 4; g++) {
+                const uint32_t bits = mc_wild_bits(ctx, (uint32_t)b, k, g), p1 = bits & 127u, p2 = bits >> 8;
+                uint32_t *q = &X.wild[(size_t)line * 16 + (size_t)g * 4];
+                q[p1 >> 5] |= 1u << (p1 & 31); q[p2 >> 5] |= 1u << (p2 & 31);
+            }
         }
     // .info: median of ALL bucket sizes, reduced-letter frequencies
     { std::vector<uint32_t> c(MC_NBUCKET); for (int b = 0; b < MC_NBUCKET; b++) c[b] = X.bstart[b + 1] - X.bstart[b]; std::nth_element(c.begin(), c.begin() + (MC_NBUCKET >> 1), c.end()); X.freq_thr = c[MC_NBUCKET >> 1]; }

@@ -60,10 +60,10 @@ int main(int argc, char **argv)
         fclose(d);
     }
     if (getenv("MC_CHECK_SCAN")) {   // exhaustive: scan-based ranges == binary-search ranges for every key a query could match
-        McIndex Xc; Xc.res = H.res.data(); Xc.off = H.off.data(); Xc.bstart = H.bstart.data(); Xc.post = H.post.data(); Xc.keys = H.keys.data(); Xc.rec = H.rec.data(); Xc.filt = H.filt.data(); Xc.nseq = H.nseq;
+        McIndex Xc; Xc.res = H.res.data(); Xc.off = H.off.data(); Xc.bstart = H.bstart.data(); Xc.post = H.post.data(); Xc.keys = H.keys.data(); Xc.rec = H.rec.data(); Xc.filt = H.filt.data(); Xc.wild = H.wild.data(); Xc.nseq = H.nseq;
         if (H.rec.empty()) { fprintf(stderr, "scan check: the index has no bucket records\n"); return 3; }
         fprintf(stderr, "largest bucket: %u postings\n", H.max_bucket);
-        long checked = 0, bad = 0, fneg = 0, fpos = 0, fq = 0, f9q = 0, f9pos = 0;
+        long checked = 0, bad = 0, fneg = 0, fpos = 0, fq = 0, f9q = 0, f9pos = 0, wq = 0, wpos = 0;
         for (int b = 0; b < MC_NBUCKET; b++) {
             uint32_t n = H.bstart[b + 1] - H.bstart[b];
             for (uint32_t i = 0; i < n; i++) {
@@ -92,19 +92,29 @@ int main(int argc, char **argv)
                         fq++;
                         if (r1 > 0 && !pass) fneg++;
                         if (r1 == 0 && pass) fpos++;
+                        // wildcard filter: a 10-mer with a range answers yes for all four wildcard positions
+                        const uint32_t ctx = mc_wild_ctx((uint32_t)b, qk), line = mc_wild_line(ctx);
+                        for (int g = 0; g < 4; g++) {
+                            const bool w = mc_wild_test(&H.wild[(size_t)line * 16 + (size_t)g * 4], mc_wild_bits(ctx, (uint32_t)b, qk, g));
+                            wq++;
+                            if (r1 > 0 && !w) fneg++;
+                            if (r1 == 0 && w) wpos++;
+                        }
                     }
                 }
             }
         }
         fprintf(stderr, "scan check: %ld probes, %ld mismatches\n", checked, bad);
         { long set = 0, set9 = 0; for (uint32_t i = 0; i < MC_FILT_TOTAL_WORDS; i++) (i < MC_FILT_WORDS ? set : set9) += __builtin_popcount(H.filt[i]);
-          fprintf(stderr, "filter check: %ld 10-mer and %ld 9-mer probes, %ld false negatives, %ld / %ld false positives among near misses, %.1f %% / %.1f %% of the bits set\n", fq, f9q, fneg, fpos, f9pos, 100.0 * (double)set / (32.0 * MC_FILT_WORDS), 100.0 * (double)set9 / (32.0 * MC_FILT9_WORDS)); }
+          fprintf(stderr, "filter check: %ld 10-mer and %ld 9-mer probes, %ld false negatives, %ld / %ld false positives among near misses, %.1f %% / %.1f %% of the bits set\n", fq, f9q, fneg, fpos, f9pos, 100.0 * (double)set / (32.0 * MC_FILT_WORDS), 100.0 * (double)set9 / (32.0 * MC_FILT9_WORDS));
+          long setw = 0; for (uint32_t w : H.wild) setw += __builtin_popcount(w);
+          fprintf(stderr, "wildcard filter: %ld questions, %ld positive among near misses, %.1f %% of the bits set\n", wq, wpos, 100.0 * (double)setw / (512.0 * MC_WILD_LINES)); }
         return (bad || fneg) ? 3 : 0;
     }
     int read_len = rs.empty() ? 0 : (int)rs[0].size();
     static McTables T;
     mc_fill_tables(T, H, read_len, getenv("MC_LOGE_THR") ? atof(getenv("MC_LOGE_THR")) : 1.0);
-    McIndex X; X.res = H.res.data(); X.off = H.off.data(); X.bstart = H.bstart.data(); X.post = H.post.data(); X.keys = H.keys.data(); X.rec = H.rec.empty() ? nullptr : H.rec.data(); X.filt = H.filt.data(); X.nseq = H.nseq;
+    McIndex X; X.res = H.res.data(); X.off = H.off.data(); X.bstart = H.bstart.data(); X.post = H.post.data(); X.keys = H.keys.data(); X.rec = H.rec.empty() ? nullptr : H.rec.data(); X.filt = H.filt.data(); X.wild = H.wild.data(); X.nseq = H.nseq;
     McClassPars P; memset(&P, 0, sizeof P); P.nfam = 1; P.read_len = read_len;
     std::vector<int32_t> fam(H.nseq, 0);
 
