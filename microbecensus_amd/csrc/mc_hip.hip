@@ -321,6 +321,7 @@ struct McEnWave {
     uint32_t setter[6][6]; uint32_t hit[6][6]; uint32_t blk_base, blk_used;
     unsigned long long q[MC_EN_QCAP];       // probes that passed the bucket bitmap
     unsigned long long hq[MC_EN_QCAP];      // probes whose first-residue group is longer than 8 keys (binary search)
+    unsigned long long eq[MC_EN_QCAP];      // (position, group) pairs the wildcard filter answered yes for: ten probes each
 };
 
 extern __shared__ __attribute__((aligned(16))) uint8_t mc_smem[];   // dynamic LDS of the kernels that use it
@@ -462,15 +463,13 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                                                                    uint32_t cap, uint32_t *counters, unsigned long long *stats)
 {
     uint8_t *smem = mc_smem;
-    uint32_t *bm = (uint32_t *)smem;                                        // 31,250 words
-    uint8_t *grp = smem + 125000;                                           // 32-byte group table
-    McEnWave *waves = (McEnWave *)(smem + 125040);
+    uint8_t *grp = smem;                                                    // 32-byte group table
+    McEnWave *waves = (McEnWave *)(smem + 64);
     uint8_t *fr_all = (uint8_t *)(waves + MC_EN_WAVES);
     const int lane = mc_lane(), wv = threadIdx.x >> 6;
     McEnWave *W = waves + wv;
     const int FPs = (FP + 15) & ~15;
     uint8_t *fr = fr_all + (size_t)wv * 6 * FPs;
-    for (int i = threadIdx.x; i < (MC_NBUCKET + 31) / 32; i += blockDim.x) bm[i] = bitmap[i];
     if (threadIdx.x < 32) grp[threadIdx.x] = T->grp[threadIdx.x];
     if (lane == 0) { W->blk_base = 0; W->blk_used = MC_EN_BLK; }
     __syncthreads();
@@ -478,10 +477,10 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
     const unsigned long long lt = (1ull << lane) - 1;
     const int64_t nw = (int64_t)gridDim.x * MC_EN_WAVES;
 #ifdef MC_EXP_TIMING
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tcnt[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter(); int tcat = 0;   // 0 staging/other 1 heavy 2 process 3 push 4 setup 5 group
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tcnt[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter(); int tcat = 0;   // 0 staging/other 1 heavy 2 process 3 push 4 setup 5 expand
 #endif
     for (int64_t r = (int64_t)blockIdx.x * MC_EN_WAVES + wv; r < nreads; r += nw) {
-        int qn = 0, hn = 0;
+        int qn = 0, hn = 0, en = 0;
         MC_TICK(0);
         {   // stage the six frames of this read (rows of FP bytes) into the wave's LDS area, clear the flags
             const uint8_t *src = frames + r * 6 * FP;
@@ -489,12 +488,15 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
             if (lane < 36) { ((uint32_t *)W->setter)[lane] = 0; ((uint32_t *)W->hit)[lane] = 0; }
             mc_wave_sync();
         }
-        // pass 0: the exact 9-mer of every position (group 0, one probe).  pass 1: its one-substitution 10-mers in four
-        // groups of ten probes: groups 0..2 = offsets 4, 5, 3 of the 6-mer (neighbour buckets), group 3 = offset 6 (same
-        // bucket, first key residue substituted).  A group is generated for 64 positions at once: bucket bitmap (LDS), then
-        // - with the counters off - the 10-mer Bloom filter (ten independent L2 gathers); the survivors wait in the
-        // per-lane mask pm and are queued one per lane and iteration.  The generator is a state machine so that each
-        // queue consumer exists once in the kernel.
+        // pass 0: the exact 9-mer of every position.  pass 1: its one-substitution 10-mers, four groups of ten probes
+        // (groups 0..2 = offsets 4, 5, 3 of the 6-mer: neighbour buckets; group 3 = offset 6: same bucket, first key
+        // residue substituted).  64 positions are set up at once.  With the counters off, filters decide what is searched:
+        //   exact 9-mer  -> 9-mer Bloom filter -> queue q
+        //   10-mers      -> wildcard filter (one cache line per position answers for its four groups) -> queue eq of
+        //                   (position, group) pairs -> 64 pairs at a time: ten probes each against the bucket bitmap and
+        //                   the 10-mer Bloom filter -> queue q
+        //   q            -> range search on the bucket records (long groups via queue hq to the binary searches) -> seed hits
+        // Every stage runs with full waves; the generator is a state machine so that each stage exists once in the kernel.
 #ifdef MC_EXP_PASS0ONLY
         for (int pass = 0; pass < 1; pass++) {
 #else
@@ -502,13 +504,15 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
 #endif
             int f = -1, p0 = 0, qlen = 0;
             bool more = true;
-            bool live = false, selfbucket = false;
-            int seed = 0, g6 = 0, d3 = 0, d4 = 0, d5 = 0, pgc = 0;
-            uint32_t qk = 0, pm = 0, wm = 0;             // pm: surviving probes of group pgc; wm: groups of this position still to generate
-            unsigned long long hi = 0;
+            uint32_t wm = 0;                             // groups of this lane's position that still have to enter eq
+            unsigned long long wbase = 0;                // seed | key | position | frame of this lane's position
+            uint32_t pm = 0;                             // surviving probes of this lane's expanded pair ...
+            unsigned long long xi = 0;                   // ... and the pair itself
             const uint8_t *q = fr;
             for (;;) {
-                if (hn >= 64 || (!more && qn == 0 && hn > 0)) {          // probes that need the binary searches
+                const bool pmz = __ballot(pm != 0) == 0, wmz = __ballot(wm != 0) == 0;
+                const bool tail = !more && wmz && en == 0 && pmz;            // nothing more will enter q
+                if (hn >= 64 || (tail && qn == 0 && hn > 0)) {           // probes that need the binary searches
                     MC_TICK(1);
                     const int take = hn < 64 ? hn : 64;
                     hn -= take;
@@ -517,7 +521,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                     mc_wave_sync();
                     continue;
                 }
-                if (qn >= 64 || (!more && qn > 0)) {                     // probes that passed the filters
+                if (qn >= 64 || (tail && qn > 0)) {                      // probes that passed the filters
                     MC_TICK(2);
                     const int take = qn < 64 ? qn : 64;
                     qn -= take;
@@ -527,27 +531,68 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                     mc_wave_sync();
                     continue;
                 }
-                {   // queue one surviving probe per lane
+                if (!pmz) {                                              // queue one surviving probe per lane
+                    MC_TICK(3);
                     const unsigned long long pmm = __ballot(pm != 0);
-                    if (pmm) {
-                        MC_TICK(3);
-                        const int j = __builtin_ctz(pm | 0x400u), gc = pgc;
-                        int v = seed, phase = 0;
-                        uint32_t k2 = qk;
-                        if (pass == 1) {
-                            phase = 1 + gc * 10 + j;
-                            if (gc < 3) { const int st = gc == 0 ? 10 : gc == 1 ? 1 : 100, d = gc == 0 ? d4 : gc == 1 ? d5 : d3; v = seed + (j - d) * st; }
-                            else k2 = (qk & 0x0FFFu) | ((uint32_t)j << 12);
+                    const int j = __builtin_ctz(pm | 0x400u), gc = (int)((xi >> 47) & 3);
+                    const int sd = (int)(xi & 0xFFFFF);
+                    const uint32_t xk = (uint32_t)((xi >> 20) & 0xFFFF);
+                    int v = sd;
+                    uint32_t k2 = xk;
+                    if (gc < 3) { const int st = gc == 0 ? 10 : gc == 1 ? 1 : 100, dd = gc == 0 ? (sd / 10) % 10 : gc == 1 ? sd % 10 : (sd / 100) % 10; v = sd + (j - dd) * st; }
+                    else k2 = (xk & 0x0FFFu) | ((uint32_t)j << 12);
+                    if (pm) W->q[qn + __popcll(pmm & lt)] = (xi & 0x00007FF000000000ull) | (unsigned long long)v | ((unsigned long long)k2 << 20) | ((unsigned long long)(1 + gc * 10 + j) << 47);
+                    qn += __popcll(pmm);
+                    pm &= pm - 1;
+                    mc_wave_sync();
+                    continue;
+                }
+                if (en >= 64 || (!more && wmz && en > 0)) {              // expand 64 (position, group) pairs into their ten probes
+                    MC_TICK(5);
+                    const int take = en < 64 ? en : 64;
+                    en -= take;
+                    const bool act = lane < take;
+                    xi = act ? W->eq[en + lane] : 0ull;
+                    const int gl = (int)((xi >> 47) & 3), sd = (int)(xi & 0xFFFFF);
+                    const uint32_t xk = (uint32_t)((xi >> 20) & 0xFFFF);
+                    const bool isb = gl < 3;                             // a bucket digit is substituted (else the first key residue)
+                    const int st = gl == 0 ? 10 : gl == 1 ? 1 : gl == 2 ? 100 : 0;
+                    const int d = gl == 0 ? (sd / 10) % 10 : gl == 1 ? sd % 10 : gl == 2 ? (sd / 100) % 10 : (int)(xk >> 12);
+                    uint32_t ok = 0, fw[10], fb[10];
+#pragma unroll
+                    for (int j = 0; j < 10; j++) {
+                        const int v = sd + (j - d) * st;                 // st = 0 for the key group: the bucket stays
+                        const uint32_t kk = isb ? xk : ((xk & 0x0FFFu) | ((uint32_t)j << 12));
+                        bool c = act && j != d;
+                        if (COUNT && c) sc.lookups++;
+                        if (COUNT) { if (c) c = (bitmap[v >> 5] >> (v & 31)) & 1; }   // counting form: bucket occupancy decides, then the search
+                        ok |= (uint32_t)c << j;
+                        if (!COUNT) {   // Bloom filter word of the 10-mer (an empty bucket has none); lanes without a candidate read word 0
+                            const uint32_t hh = mc_filter_hash((uint32_t)v, kk);
+                            fb[j] = mc_filter_bits(hh);
+                            fw[j] = X.filt[c ? mc_filter_word(hh) : 0u];
                         }
-                        if (pm) W->q[qn + __popcll(pmm & lt)] = hi | (unsigned long long)v | ((unsigned long long)k2 << 20) | ((unsigned long long)phase << 47);
-                        qn += __popcll(pmm);
-                        pm &= pm - 1;
-                        mc_wave_sync();
-                        continue;
                     }
+                    if (!COUNT) {
+#pragma unroll
+                        for (int j = 0; j < 10; j++) if ((fw[j] & fb[j]) != fb[j]) ok &= ~(1u << j);
+                    }
+                    pm = ok;
+                    mc_wave_sync();
+                    continue;
+                }
+                if (!wmz) {                                              // one pending group per lane enters eq
+                    MC_TICK(3);
+                    const unsigned long long wmm = __ballot(wm != 0);
+                    const int gl = __builtin_ctz(wm | 16u);
+                    if (wm) W->eq[en + __popcll(wmm & lt)] = wbase | ((unsigned long long)gl << 47);
+                    en += __popcll(wmm);
+                    wm &= wm - 1;
+                    mc_wave_sync();
+                    continue;
                 }
                 if (!more) break;
-                if (__ballot(wm != 0) == 0) {                            // next chunk of positions / next frame
+                {   // next chunk of positions / next frame
                     MC_TICK(4);
                     if (f >= 0) p0 += 64;
                     if (f < 0 || p0 + 6 >= qlen) {
@@ -557,14 +602,16 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                         if (p0 + 6 >= qlen) continue;
                     }
                     const int pos = p0 + lane;
-                    live = false; selfbucket = false; seed = 0; g6 = 0; qk = 0;
+                    bool live = false, selfbucket = false;
+                    int seed = 0;
+                    uint32_t qk = 0;
                     if (pos + 6 < qlen) {
                         bool bad = false;
                         for (int k = 0; k < 6; k++) { int gg = grp[q[pos + k]]; bad |= (gg == MC_INVGRP); seed = seed * 10 + gg; }
                         if (!bad) {
-                            selfbucket = (bm[seed >> 5] >> (seed & 31)) & 1;
+                            selfbucket = (bitmap[seed >> 5] >> (seed & 31)) & 1;
                             const int rest = qlen - pos - 6;
-                            g6 = rest >= 1 ? grp[q[pos + 6]] : MC_INVGRP;
+                            const int g6 = rest >= 1 ? grp[q[pos + 6]] : MC_INVGRP;
                             const int g7 = rest >= 2 ? grp[q[pos + 7]] : MC_INVGRP, g8 = rest >= 3 ? grp[q[pos + 8]] : MC_INVGRP;
                             const int g9 = rest >= 4 ? grp[q[pos + 9]] : MC_INVGRP;
                             if (pass == 0) {
@@ -597,63 +644,31 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                             }
                         }
                     }
-                    d4 = (seed / 10) % 10; d5 = seed % 10; d3 = (seed / 100) % 10;
-                    hi = ((unsigned long long)pos << 36) | ((unsigned long long)f << 44);
-                    // which groups of probes does this position have to generate?
-                    if (pass == 0) wm = live ? 1u : 0u;                  // the exact 9-mer
-                    else if (COUNT) wm = live ? 0xFu : 0u;               // counting form: every probe is searched
-                    else {                                               // wildcard filter: one cache line answers for the four groups
-                        wm = 0;
-                        if (__ballot(live)) {
-                            const uint32_t ctx = mc_wild_ctx((uint32_t)seed, qk);
-                            const uint4 *ln = (const uint4 *)X.wild + (size_t)(live ? mc_wild_line(ctx) : 0u) * 4;
-                            const uint4 q0 = ln[0], q1 = ln[1], q2 = ln[2], q3 = ln[3];
-                            const uint32_t a0[4] = {q0.x, q0.y, q0.z, q0.w}, a1[4] = {q1.x, q1.y, q1.z, q1.w}, a2[4] = {q2.x, q2.y, q2.z, q2.w}, a3[4] = {q3.x, q3.y, q3.z, q3.w};
-                            if (live) {
-                                wm = (mc_wild_test(a0, mc_wild_bits(ctx, (uint32_t)seed, qk, 0)) ? 1u : 0u) | (mc_wild_test(a1, mc_wild_bits(ctx, (uint32_t)seed, qk, 1)) ? 2u : 0u) |
-                                     (mc_wild_test(a2, mc_wild_bits(ctx, (uint32_t)seed, qk, 2)) ? 4u : 0u) | (mc_wild_test(a3, mc_wild_bits(ctx, (uint32_t)seed, qk, 3)) ? 8u : 0u);
-                            }
+                    wbase = (unsigned long long)seed | ((unsigned long long)qk << 20) | ((unsigned long long)pos << 36) | ((unsigned long long)f << 44);
+                    if (pass == 0) {                                     // the exact 9-mer: its own Bloom filter, then straight into q
+                        bool pr = live;
+                        if (!COUNT && __ballot(live)) {
+                            const uint32_t hh = mc_filter_hash((uint32_t)seed, qk), fb9 = mc_filter_bits(hh);
+                            const uint32_t fw9 = X.filt[live ? mc_filter9_word(hh) : 0u];
+                            pr = live && (fw9 & fb9) == fb9;
+                        }
+                        const unsigned long long prm = __ballot(pr);
+                        if (prm) {
+                            if (pr) W->q[qn + __popcll(prm & lt)] = wbase;  // phase 0
+                            qn += __popcll(prm);
+                            mc_wave_sync();
+                        }
+                    } else if (COUNT) wm = live ? 0xFu : 0u;             // counting form: every probe is generated and searched
+                    else if (__ballot(live)) {                           // wildcard filter: one cache line answers for the four groups
+                        const uint32_t ctx = mc_wild_ctx((uint32_t)seed, qk);
+                        const uint4 *ln = (const uint4 *)X.wild + (size_t)(live ? mc_wild_line(ctx) : 0u) * 4;
+                        const uint4 q0 = ln[0], q1 = ln[1], q2 = ln[2], q3 = ln[3];
+                        const uint32_t a0[4] = {q0.x, q0.y, q0.z, q0.w}, a1[4] = {q1.x, q1.y, q1.z, q1.w}, a2[4] = {q2.x, q2.y, q2.z, q2.w}, a3[4] = {q3.x, q3.y, q3.z, q3.w};
+                        if (live) {
+                            wm = (mc_wild_test(a0, mc_wild_bits(ctx, (uint32_t)seed, qk, 0)) ? 1u : 0u) | (mc_wild_test(a1, mc_wild_bits(ctx, (uint32_t)seed, qk, 1)) ? 2u : 0u) |
+                                 (mc_wild_test(a2, mc_wild_bits(ctx, (uint32_t)seed, qk, 2)) ? 4u : 0u) | (mc_wild_test(a3, mc_wild_bits(ctx, (uint32_t)seed, qk, 3)) ? 8u : 0u);
                         }
                     }
-                    continue;
-                }
-                // every lane generates the next pending group of its position
-                MC_TICK(5);
-                const bool act = wm != 0;
-                const int gl = __builtin_ctz(wm | 16u);
-                wm &= wm - 1;
-                pgc = gl;
-                if (pass == 0) {
-                    pm = act ? 1u : 0u;
-                    if (!COUNT) {   // 9-mer Bloom filter: most exact probes find nothing and need no search
-                        const uint32_t hh = mc_filter_hash((uint32_t)seed, qk), fb9 = mc_filter_bits(hh);
-                        const uint32_t fw9 = X.filt[act ? mc_filter9_word(hh) : 0u];
-                        if ((fw9 & fb9) != fb9) pm = 0;
-                    }
-                }
-                else {
-                    const bool isb = gl < 3;                             // a bucket digit is substituted (else the first key residue)
-                    const int st = gl == 0 ? 10 : gl == 1 ? 1 : gl == 2 ? 100 : 0, d = gl == 0 ? d4 : gl == 1 ? d5 : gl == 2 ? d3 : g6;
-                    uint32_t ok = 0, fw[10], fb[10];
-#pragma unroll
-                    for (int j = 0; j < 10; j++) {
-                        const int v = seed + (j - d) * st;               // st = 0 for the key group: the bucket stays
-                        const uint32_t kk = isb ? qk : ((qk & 0x0FFFu) | ((uint32_t)j << 12));
-                        bool c = act && j != d;
-                        if (COUNT && c) sc.lookups++;
-                        c = c && ((bm[v >> 5] >> (v & 31)) & 1);         // bitmap of the probed bucket (the own bucket for the key group)
-                        ok |= (uint32_t)c << j;
-                        if (!COUNT) {   // Bloom filter word of the 10-mer; lanes without a candidate read word 0
-                            const uint32_t hh = mc_filter_hash((uint32_t)v, kk);
-                            fb[j] = mc_filter_bits(hh);
-                            fw[j] = X.filt[c ? mc_filter_word(hh) : 0u];
-                        }
-                    }
-                    if (!COUNT) {
-#pragma unroll
-                        for (int j = 0; j < 10; j++) if ((fw[j] & fb[j]) != fb[j]) ok &= ~(1u << j);
-                    }
-                    pm = ok;
                 }
             }
             mc_wave_sync();
@@ -1031,9 +1046,9 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         if (h->fast_enum) {
             const int FPs = (FP + 15) & ~15;
             const size_t per_wave = sizeof(McEnWave) + (size_t)6 * FPs;
-            int waves = (int)((160 * 1024 - 125040) / per_wave);            // as many waves per CU as the LDS holds next to the bitmap
-            waves = waves >= 14 ? 14 : waves >= 12 ? 12 : waves >= 8 ? 8 : 4;
-            const size_t lds2 = 125040 + waves * per_wave;
+            int waves = (int)((160 * 1024 - 64) / per_wave);                // waves per workgroup: as many as the LDS holds, at most 16
+            waves = waves >= 16 ? 16 : waves >= 12 ? 12 : waves >= 8 ? 8 : 4;
+            const size_t lds2 = 64 + waves * per_wave;
             if (lds2 > 160 * 1024) { g_err = "reads too long for the seed kernel's LDS layout"; return -1; }
             const int blocks = (int)std::min<int64_t>(256, (n + waves - 1) / waves);
 #define MC_LAUNCH_EN(WV, CNT)                                                                                                                      \
@@ -1042,8 +1057,8 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         k_enumerate_t0<WV, CNT><<<dim3(blocks), dim3(64 * WV), lds2, st>>>(h->d_T, X, h->d_bitmap, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, \
                                                                             h->d_counters, h->d_stats);                                           \
     } while (0)
-            if (h->count_traffic) { if (waves == 14) MC_LAUNCH_EN(14, true); else if (waves == 12) MC_LAUNCH_EN(12, true); else if (waves == 8) MC_LAUNCH_EN(8, true); else MC_LAUNCH_EN(4, true); }
-            else { if (waves == 14) MC_LAUNCH_EN(14, false); else if (waves == 12) MC_LAUNCH_EN(12, false); else if (waves == 8) MC_LAUNCH_EN(8, false); else MC_LAUNCH_EN(4, false); }
+            if (h->count_traffic) { if (waves == 16) MC_LAUNCH_EN(16, true); else if (waves == 12) MC_LAUNCH_EN(12, true); else if (waves == 8) MC_LAUNCH_EN(8, true); else MC_LAUNCH_EN(4, true); }
+            else { if (waves == 16) MC_LAUNCH_EN(16, false); else if (waves == 12) MC_LAUNCH_EN(12, false); else if (waves == 8) MC_LAUNCH_EN(8, false); else MC_LAUNCH_EN(4, false); }
 #undef MC_LAUNCH_EN
         } else
             k_enumerate<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, X, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, h->d_counters, h->d_stats);
