@@ -32,7 +32,14 @@ MC_HD bool mc_hless(const McHsp &a, const McHsp &b, int key)
 {
     return key == 0 ? (a.loge < b.loge) : key == 1 ? (a.frame < b.frame) : (a.qaas < b.qaas);
 }
-MC_HDN void mc_adjust_heap(McHsp *first, long hole, long len, McHsp value, int key)
+// The same sort on 16-byte (key, index) items: the sequence of comparisons and moves of std::sort depends on the keys
+// only, so sorting the items and reading the records through the indices gives the permutation the reference gets by
+// sorting the 48-byte records themselves - at a third of the memory traffic (the final by-log-E sort of a read).
+struct McSortItem { double k; uint32_t i; uint32_t pad; };
+MC_HD bool mc_hless(const McSortItem &a, const McSortItem &b, int) { return a.k < b.k; }
+
+template <class E>
+MC_HDN void mc_adjust_heap(E *first, long hole, long len, E value, int key)
 {
     long top = hole, sc = hole;
     while (sc < (len - 1) / 2) {
@@ -45,27 +52,31 @@ MC_HDN void mc_adjust_heap(McHsp *first, long hole, long len, McHsp value, int k
     while (hole > top && mc_hless(first[parent], value, key)) { first[hole] = first[parent]; hole = parent; parent = (hole - 1) / 2; }
     first[hole] = value;
 }
-MC_HDN void mc_heapsort(McHsp *first, long n, int key)
+template <class E>
+MC_HDN void mc_heapsort(E *first, long n, int key)
 {
     if (n >= 2) for (long parent = (n - 2) / 2;; parent--) { mc_adjust_heap(first, parent, n, first[parent], key); if (parent == 0) break; }
-    for (long m = n; m > 1;) { m--; McHsp v = first[m]; first[m] = first[0]; mc_adjust_heap(first, 0, m, v, key); }
+    for (long m = n; m > 1;) { m--; E v = first[m]; first[m] = first[0]; mc_adjust_heap(first, 0, m, v, key); }
 }
-MC_HDN void mc_unguarded_insert(McHsp *last, McHsp val, int key)
+template <class E>
+MC_HDN void mc_unguarded_insert(E *last, E val, int key)
 {
-    McHsp *next = last - 1;
+    E *next = last - 1;
     while (mc_hless(val, *next, key)) { *last = *next; last = next; --next; }
     *last = val;
 }
-MC_HDN void mc_insertion_sort(McHsp *first, McHsp *last, int key)
+template <class E>
+MC_HDN void mc_insertion_sort(E *first, E *last, int key)
 {
     if (first == last) return;
-    for (McHsp *i = first + 1; i != last; ++i) {
-        McHsp val = *i;
-        if (mc_hless(val, *first, key)) { for (McHsp *p = i; p != first; --p) *p = *(p - 1); *first = val; }
+    for (E *i = first + 1; i != last; ++i) {
+        E val = *i;
+        if (mc_hless(val, *first, key)) { for (E *p = i; p != first; --p) *p = *(p - 1); *first = val; }
         else mc_unguarded_insert(i, val, key);
     }
 }
-MC_HDN void mc_std_sort(McHsp *first, long n, int key)
+template <class E>
+MC_HDN void mc_std_sort(E *first, long n, int key)
 {
     if (n <= 0) return;
     long lg = 0;
@@ -80,8 +91,8 @@ MC_HDN void mc_std_sort(McHsp *first, long n, int key)
         while (l - f > 16) {
             if (depth == 0) { mc_heapsort(first + f, l - f, key); break; }
             --depth;
-            const McHsp &a = first[f], &b = first[f + (l - f) / 2], &c = first[l - 1];
-            McHsp pivot;
+            const E &a = first[f], &b = first[f + (l - f) / 2], &c = first[l - 1];
+            E pivot;
             if (mc_hless(a, b, key)) { if (mc_hless(b, c, key)) pivot = b; else if (mc_hless(a, c, key)) pivot = c; else pivot = a; }
             else if (mc_hless(a, c, key)) pivot = a;
             else if (mc_hless(b, c, key)) pivot = c;
@@ -92,14 +103,14 @@ MC_HDN void mc_std_sort(McHsp *first, long n, int key)
                 --hi;
                 while (mc_hless(pivot, first[hi], key)) --hi;
                 if (!(lo < hi)) break;
-                McHsp t = first[lo]; first[lo] = first[hi]; first[hi] = t;
+                E t = first[lo]; first[lo] = first[hi]; first[hi] = t;
                 ++lo;
             }
             if (sp < 64) { sf[sp] = lo; sl[sp] = l; sd[sp] = depth; sp++; }
             l = lo;
         }
     }
-    if (n > 16) { mc_insertion_sort(first, first + 16, key); for (McHsp *i = first + 16; i != first + n; ++i) mc_unguarded_insert(i, *i, key); }
+    if (n > 16) { mc_insertion_sort(first, first + 16, key); for (E *i = first + 16; i != first + n; ++i) mc_unguarded_insert(i, *i, key); }
     else mc_insertion_sort(first, first + n, key);
 }
 MC_HDN void mc_stable_sort_loge(McHsp *first, long n)
@@ -252,7 +263,7 @@ MC_HD bool mc_row_passes(const McClassPars &P, const McRow &r, int fam, int targ
 // (best->family = -1 when no row passes the filters).
 // ------------------------------------------------------------------------------------------------
 MC_HDN int mc_finish_read(const McTables &T, const McIndex &X, const McClassPars &P, const int32_t *marker_family,
-                          int read_id, const McHsp *in, int n, McHsp *v, McHsp *tmp, McRow *rows, double *krows, McBestHit *best)
+                          int read_id, const McHsp *in, int n, McHsp *v, McHsp *tmp, McRow *rows, double *krows, McSortItem *items, McBestHit *best)
 {
     int vn = 0;
     for (int a = 0; a < n;) {
@@ -274,11 +285,12 @@ MC_HDN int mc_finish_read(const McTables &T, const McIndex &X, const McClassPars
         if (vn - st > 1) vn = mc_sum_evalue(T, v, st, vn, (int)(X.off[sidx + 1] - X.off[sidx]), tmp);
         a = b;
     }
-    mc_std_sort(v, vn, 0);
+    for (int i = 0; i < vn; i++) { items[i].k = v[i].loge; items[i].i = (uint32_t)i; items[i].pad = 0; }
+    mc_std_sort(items, vn, 0);                       // std::sort by log E (PrintRes), on (key, index) items
     int nrows = 0;
     best->read = read_id; best->family = -1; best->aln = 0; best->target_len = 0; best->bits = 0.0;
     for (int i = 0; i < vn && i < MC_MAX_M8; i++) {
-        const McHsp &h = v[i];
+        const McHsp &h = v[items[i].i];
         if (!(h.loge < T.loge_thr)) break;
         McRow &r = rows[nrows];
         r.query = read_id; r.subject = h.sidx; r.ident = (double)h.nmatch * 100.0 / (double)h.alnlen;

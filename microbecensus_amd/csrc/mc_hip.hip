@@ -804,7 +804,8 @@ __global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, 
     McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
     double *myk = (double *)(myrows + n);
     McBestHit bh;
-    const int nr = mc_finish_read(*T, X, *P, fam, (int)((int64_t)read + first_read_id), sorted + a, n, v + a, tmp + 2 * (size_t)a, myrows, myk, &bh);
+    McSortItem *myitems = (McSortItem *)(myk + n);               // 64 n + 8 n + 16 n = 88 n <= 96 n bytes of the read's tmp area
+    const int nr = mc_finish_read(*T, X, *P, fam, (int)((int64_t)read + first_read_id), sorted + a, n, v + a, tmp + 2 * (size_t)a, myrows, myk, myitems, &bh);
     nrow_of[s] = (uint32_t)nr;
     if (nr > 0) atomicAdd(&counters[C_SEGS], 1u);
     if (bh.family >= 0) best[atomicAdd(&counters[C_BEST], 1u)] = bh;       // few; the host orders them by read

@@ -194,12 +194,12 @@ int main(int argc, char **argv)
     fprintf(stderr, "hsps kept: %zu\n", hsps.size());
     // stage 6: per-read finishing
     FILE *o = fopen(argv[3], "w");
-    std::vector<McHsp> v, tmp; std::vector<McRow> rows(MC_MAX_M8); std::vector<double> kr(MC_MAX_M8);
+    std::vector<McHsp> v, tmp; std::vector<McRow> rows(MC_MAX_M8); std::vector<double> kr(MC_MAX_M8); std::vector<McSortItem> items;
     for (size_t a = 0; a < hsps.size();) {
         size_t b = a; while (b < hsps.size() && hsps[b].read == hsps[a].read) b++;
-        int n = (int)(b - a); v.resize(n); tmp.resize(2 * n);
+        int n = (int)(b - a); v.resize(n); tmp.resize(2 * n); items.resize(n);
         McBestHit best;
-        int nr = mc_finish_read(T, X, P, fam.data(), (int)hsps[a].read, &hsps[a], n, v.data(), tmp.data(), rows.data(), kr.data(), &best);
+        int nr = mc_finish_read(T, X, P, fam.data(), (int)hsps[a].read, &hsps[a], n, v.data(), tmp.data(), rows.data(), kr.data(), items.data(), &best);
         for (int i = 0; i < nr; i++) {
             const McRow &r = rows[i];
             fprintf(o, "%s\t%s\t%g\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%g\t%g\n", rn[r.query].c_str(), H.names[r.subject].c_str(), r.ident, r.alnlen, r.mismatch, r.gapopen, r.qstart, r.qend, r.sstart, r.send, r.loge, r.bits);
