@@ -767,14 +767,19 @@ __global__ void k_make_keys(const McHsp *__restrict__ hsps, uint32_t n, uint64_t
     keys[tid] = ((uint64_t)h.read << 43) | ((uint64_t)(uint32_t)h.sidx << 28) | (uint64_t)h.chrono;
     idx[tid] = tid;
 }
-// sorted order: copies the HSPs and flags the first HSP of every read
-__global__ void k_gather(const McHsp *__restrict__ hsps, const uint32_t *__restrict__ idx, uint32_t n, McHsp *out, uint32_t *flags)
+// sorted order: copies the HSPs, flags the first HSP of every read, and marks the HSPs that can make their read print
+// anything: log E below the threshold, or a second HSP on the same subject (sum statistics may lower the group's E).
+// A read without a marked HSP prints no row and has no best hit - k_finish skips it after reading its marks.
+__global__ void k_gather(const McHsp *__restrict__ hsps, const uint32_t *__restrict__ idx, uint32_t n, McHsp *out, uint32_t *flags, uint8_t *mark, double loge_thr)
 {
     uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= n) return;
     McHsp h = hsps[idx[tid]];
     out[tid] = h;
-    flags[tid] = ((tid == 0) || (hsps[idx[tid - 1]].read != h.read)) ? 1u : 0u;
+    bool head = true, same_subject = false;
+    if (tid > 0) { const McHsp &p = hsps[idx[tid - 1]]; head = p.read != h.read; same_subject = !head && p.sidx == h.sidx; }
+    flags[tid] = head ? 1u : 0u;
+    mark[tid] = (h.loge < loge_thr || same_subject) ? 1 : 0;
 }
 // heads[k] = index of the first HSP of the k-th read that has HSPs (ascending read id); hpos = exclusive scan of flags
 __global__ void k_heads(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ hpos, uint32_t n, uint32_t *heads, uint32_t *counters)
@@ -792,15 +797,20 @@ __global__ void k_heads(const uint32_t *__restrict__ flags, const uint32_t *__re
 // stay in that scratch; k_emit_rows moves them to their final place once the row counts have been scanned.
 __global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
                                                 const McHsp *__restrict__ sorted, uint32_t nhsps, const uint32_t *__restrict__ heads, uint32_t nheads,
-                                                McHsp *v, McHsp *tmp, int64_t first_read_id, uint32_t *nrow_of, McBestHit *best, uint32_t *counters)
+                                                const uint8_t *__restrict__ mark, McHsp *v, McHsp *tmp, int64_t first_read_id, uint32_t *nrow_of, McBestHit *best,
+                                                uint32_t *counters)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nheads) return;
     const uint32_t a = heads[s];
-    uint32_t b = a;
-    const uint32_t read = sorted[a].read;
-    while (b < nhsps && sorted[b].read == read) b++;
+    const uint32_t b = (s + 1 < nheads) ? heads[s + 1] : nhsps;
     const int n = (int)(b - a);
+    {   // nine reads in ten have nothing to print: their marks (contiguous, a byte per HSP) say so
+        uint32_t any = 0;
+        for (uint32_t k = a; k < b; k++) any |= mark[k];
+        if (!any) { nrow_of[s] = 0; return; }
+    }
+    const uint32_t read = sorted[a].read;
     McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
     double *myk = (double *)(myrows + n);
     McBestHit bh;
@@ -851,7 +861,7 @@ struct mc_handle {
     uint32_t cap_tasks = 0, cap_gaps = 0, cap_hsps = 0, cap_rows = 0;
     uint64_t *d_k64 = nullptr, *d_k64o = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
     uint32_t *d_counters = nullptr;
-    McRow *d_rows = nullptr; uint32_t *d_nrow = nullptr, *d_rowoff = nullptr; McBestHit *d_best = nullptr;
+    McRow *d_rows = nullptr; uint32_t *d_nrow = nullptr, *d_rowoff = nullptr; McBestHit *d_best = nullptr; uint8_t *d_mark = nullptr;
     int *d_gH = nullptr, *d_gD = nullptr; McPath *d_gPH = nullptr, *d_gPD = nullptr;
     int gap_threads = 0;
     // host results: rows of the last batch land in pinned memory; mc_search() accumulates its batches in all_rows
@@ -887,7 +897,7 @@ extern "C" void mc_close(mc_handle *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_frames, h->d_tasks, h->d_gaps, h->d_hsps,
                     h->d_sorted, h->d_v, h->d_tmp, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, h->d_heads, h->d_sorttmp, h->d_counters, h->d_rows,
-                    h->d_nrow, h->d_rowoff, h->d_best, h->d_gH, h->d_gD, h->d_gPH, h->d_gPD, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild};
+                    h->d_nrow, h->d_rowoff, h->d_best, h->d_mark, h->d_gH, h->d_gD, h->d_gPH, h->d_gPD, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->pin_rows) (void)hipHostFree(h->pin_rows);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -985,7 +995,7 @@ static int ensure_capacity(mc_handle *h, int64_t nreads)
         dalloc(&h->d_gaps, h->cap_gaps) || dalloc(&h->d_hsps, h->cap_hsps) || dalloc(&h->d_sorted, h->cap_hsps) || dalloc(&h->d_v, h->cap_hsps) ||
         dalloc(&h->d_tmp, (size_t)h->cap_hsps * 2) || dalloc(&h->d_k64, h->cap_hsps) || dalloc(&h->d_k64o, h->cap_hsps) || dalloc(&h->d_idx, h->cap_hsps) ||
         dalloc(&h->d_idxo, h->cap_hsps) || dalloc(&h->d_heads, (size_t)cap + 1) || dalloc(&h->d_rows, h->cap_rows) ||
-        dalloc(&h->d_nrow, (size_t)cap + 1) || dalloc(&h->d_rowoff, (size_t)cap + 1) || dalloc(&h->d_best, (size_t)cap + 1) || dalloc(&h->d_gH, (size_t)h->gap_threads * MC_GAP_W) ||
+        dalloc(&h->d_mark, (size_t)h->cap_hsps) || dalloc(&h->d_nrow, (size_t)cap + 1) || dalloc(&h->d_rowoff, (size_t)cap + 1) || dalloc(&h->d_best, (size_t)cap + 1) || dalloc(&h->d_gH, (size_t)h->gap_threads * MC_GAP_W) ||
         dalloc(&h->d_gD, (size_t)h->gap_threads * MC_GAP_W) || dalloc(&h->d_gPH, (size_t)h->gap_threads * MC_GAP_W) || dalloc(&h->d_gPD, (size_t)h->gap_threads * MC_GAP_W))
         return -1;
     size_t bytes = 0, bytes2 = 0;
@@ -1092,7 +1102,7 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         k_make_keys<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(h->d_hsps, nh, h->d_k64, h->d_idx);
         size_t bytes = h->sorttmp_bytes;
         HIPCK(rocprim::radix_sort_pairs(h->d_sorttmp, bytes, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, (size_t)nh, 0, 64, st));
-        k_gather<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(h->d_hsps, h->d_idxo, nh, h->d_sorted, d_flags);
+        k_gather<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(h->d_hsps, h->d_idxo, nh, h->d_sorted, d_flags, h->d_mark, h->hT.loge_thr);
         bytes = h->sorttmp_bytes;
         HIPCK(rocprim::exclusive_scan(h->d_sorttmp, bytes, d_flags, d_hpos, 0u, (size_t)nh, rocprim::plus<uint32_t>(), st));
         k_heads<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(d_flags, d_hpos, nh, h->d_heads, h->d_counters);
@@ -1100,7 +1110,7 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
         nheads = c[C_HEADS];
-        k_finish<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp,
+        k_finish<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_mark, h->d_v, h->d_tmp,
                                                                     first_read_id, h->d_nrow, h->d_best, h->d_counters);
         bytes = h->sorttmp_bytes;
         HIPCK(rocprim::exclusive_scan(h->d_sorttmp, bytes, h->d_nrow, h->d_rowoff, 0u, (size_t)nheads, rocprim::plus<uint32_t>(), st));
