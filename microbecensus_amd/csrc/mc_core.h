@@ -825,14 +825,12 @@ MC_HDN void mc_enumerate_seeds(const McTables &T, const McIndex &X, const uint8_
 #define MC_SUB(T, a, b) ((int)(T).sub[((a) << 5) | (b)])
 
 // TT: McTables, or a compact copy of its hot members (sub, grp, xdrop_*, gap_trigger) - the kernels keep one in LDS
-template <class TT>
-MC_HDN int mc_eval_seed(const TT &T, const McIndex &X, const uint8_t *q, int qlen, int frame, int qpos,
-                        uint32_t posting, int seedlen, int nkey, McGapTask *gt)
+// QP / DP: pointers to the frame and to the subject's residues (d[i] = residue i of the marker) - plain memory, or the
+// kernel's LDS copies: the frame, and the subject window [max(0, dpos - qpos), min(dlen, dpos + qlen - qpos)), which is all this function can touch
+template <class TT, class QP, class DP>
+MC_HDN int mc_eval_seed_core(const TT &T, QP q, int qlen, int frame, int qpos, DP d, int dlen, int dpos, int sidx,
+                             int seedlen, int nkey, McGapTask *gt)
 {
-    int dpos = (int)(posting & 0x7ff), sidx = (int)(posting >> 11);
-    uint32_t o0 = X.off[sidx];
-    int dlen = (int)(X.off[sidx + 1] - o0);
-    const uint8_t *d = X.res + o0;
     if (dpos + seedlen > dlen) return 0;
     if (qpos != 0 && dpos != 0 && T.grp[q[qpos - 1]] == T.grp[d[dpos - 1]] && nkey != 4) return 0;
     int score = 0, ident = 0, L = seedlen;
@@ -846,7 +844,8 @@ MC_HDN int mc_eval_seed(const TT &T, const McIndex &X, const uint8_t *q, int qle
     { // forward
         int n1 = qlen - qp - L, n2 = dlen - dp - L, bl = 0, bi = 0;
         if (n1 != 0 && n2 != 0 && !(s0 < -20)) {
-            const uint8_t *p1 = q + qp + L, *p2 = d + dp + L;
+            QP p1 = q + qp + L;
+            DP p2 = d + dp + L;
             int run = s0, best = s0, id = 0;
             for (int i = 0;;) {
                 int a = p1[i], b = p2[i];
@@ -884,6 +883,14 @@ MC_HDN int mc_eval_seed(const TT &T, const McIndex &X, const uint8_t *q, int qle
     gt->qfwd = (int16_t)qfwd; gt->qbwd = (int16_t)qbwd; gt->score = (int16_t)score; gt->nmatch = (int16_t)ident;
     (void)frame;
     return (!(T.gap_trigger > (double)score)) ? 2 : 1;
+}
+template <class TT>
+MC_HDN int mc_eval_seed(const TT &T, const McIndex &X, const uint8_t *q, int qlen, int frame, int qpos,
+                        uint32_t posting, int seedlen, int nkey, McGapTask *gt)
+{
+    const int dpos = (int)(posting & 0x7ff), sidx = (int)(posting >> 11);
+    const uint32_t o0 = X.off[sidx];
+    return mc_eval_seed_core(T, q, qlen, frame, qpos, X.res + o0, (int)(X.off[sidx + 1] - o0), dpos, sidx, seedlen, nkey, gt);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -71,6 +71,7 @@ __device__ __forceinline__ void mc_wave_sync() { __builtin_amdgcn_fence(__ATOMIC
 // probable window of every stretch (the first one in the reference's iteration order on a tie) is found with LDS
 // atomics.  The double arithmetic of getprob is the reference's, operation by operation.
 struct McSegWaveLds { unsigned long long best[64]; uint32_t pre[66]; uint32_t bq[64]; uint32_t off[64]; uint16_t n[64]; };   // 1,416 B per wave
+static_assert(sizeof(McHsp) == 48 && sizeof(McGapTask) % 4 == 0, "k_eval_seeds copies its staging buffers as 16- and 4-byte words");
 static_assert(sizeof(McSegWaveLds) == 1416, "MC_TS_STAGE reserves 4 x 1416 bytes");
 #define MC_SEG_KEY_ONE 0xBFF0000000000000ull   // order-preserving key of 1.0 (the initial minprob of Seg::trim)
 
@@ -258,6 +259,18 @@ __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restric
         const int total = nr * 6 * FP;
         for (int i = tid; i < total; i += 256) { int row = i / FP, col = i - row * FP; dst[i] = rows[(size_t)row * stride + col]; }
     }
+}
+
+// one atomic per wave: the lanes with want == true receive consecutive slots of a global counter
+__device__ __forceinline__ uint32_t mc_wave_alloc(uint32_t *counter, bool want)
+{
+    const unsigned long long m = __ballot(want);
+    if (m == 0) return 0;
+    const int lane = mc_lane(), leader = __builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
 }
 
 // copies the hot members of the tables into LDS (block-wide; callers __syncthreads() afterwards)
@@ -690,32 +703,70 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
     }
 }
 
+// Seed hits -> HSPs / gap tasks.  Persistent workgroups walk the task pool 256 hits at a time; what survives is staged in
+// LDS and flushed with ONE global atomic per ~800 HSPs: a device-scope atomic on a single counter executes at the memory
+// side (the L2s of the XCDs are not coherent with each other) at ~125 M/s - one per HSP, or even one per wave, cost more
+// than the whole evaluation (measured: 11.6 ms of which 7.9 ms atomics).
+#define MC_EV_STAGE_H 512    // HSPs staged per workgroup (24 KB)
+#define MC_EV_STAGE_G 320    // gap tasks (9 KB)
 __global__ void __launch_bounds__(256) k_eval_seeds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
                                                     const McSeedTask *__restrict__ tasks, uint32_t ntasks, McHsp *hsps, uint32_t cap_hsps,
                                                     McGapTask *gaps, uint32_t cap_gaps, uint32_t *counters)
 {
     __shared__ McHot hot;
+    __shared__ uint32_t fillH, fillG, baseH, baseG;
+    McHsp *stH = (McHsp *)mc_smem;                                // MC_EV_STAGE_H records
+    McGapTask *stG = (McGapTask *)(stH + MC_EV_STAGE_H);          // MC_EV_STAGE_G records
     mc_load_hot(&hot, T);
+    if (threadIdx.x == 0) { fillH = 0; fillG = 0; }
     __syncthreads();
-    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= ntasks) return;
-    McSeedTask t = tasks[tid];
-    if (t.read == MC_TASK_NONE) return;                 // padding of a partly used block of the task pool
-    int frame = (int)(t.chrono >> 25), pos = (int)((t.chrono >> 17) & 0xff);
-    int qlen = (L - frame % 3) / 3;
-    McGapTask g;
-    g.read = t.read; g.chrono = t.chrono;
-    int rc = mc_eval_seed(hot, X, frames + ((int64_t)t.read * 6 + frame) * FP, qlen, frame, pos, t.posting, (int)(t.seedlen_nkey & 0xff), (int)(t.seedlen_nkey >> 8), &g);
-    if (rc == 1) {
-        McHsp h;
-        h.read = t.read; h.chrono = t.chrono;
-        if (mc_make_hsp(*T, L, frame, g, g.qfwd, g.qfwd, g.qbwd, g.qbwd, g.score, g.nmatch, g.qfwd + g.L + g.qbwd, 0, 0, &h)) {
-            uint32_t k = atomicAdd(&counters[C_HSPS], 1u);
-            if (k < cap_hsps) hsps[k] = h; else counters[C_OVERFLOW] = 2;
+    const int lane = mc_lane();
+    const uint32_t nchunks = (ntasks + 255) / 256;
+    for (uint32_t chunk = blockIdx.x;; chunk += gridDim.x) {
+        const bool last = chunk >= nchunks;
+        // flush when the next 256 hits might not fit (or at the end)
+        __syncthreads();                                         // the staging of the previous chunk is complete
+        const uint32_t fh = fillH, fg = fillG;
+        __syncthreads();                                         // everybody has read the fill levels
+        if (last || fh > MC_EV_STAGE_H - 256 || fg > MC_EV_STAGE_G - 256) {
+            if (threadIdx.x == 0) { baseH = fh ? atomicAdd(&counters[C_HSPS], fh) : 0u; baseG = fg ? atomicAdd(&counters[C_GAPS], fg) : 0u; }
+            __syncthreads();
+            const uint32_t bH = baseH, bG = baseG;
+            if (bH + fh > cap_hsps) { if (threadIdx.x == 0) counters[C_OVERFLOW] = 2; }
+            else for (uint32_t i = threadIdx.x; i < fh * 3; i += 256) ((uint4 *)(hsps + bH))[i] = ((const uint4 *)stH)[i];          // 48-byte records as 16-byte words
+            if (bG + fg > cap_gaps) { if (threadIdx.x == 0) counters[C_OVERFLOW] = 3; }
+            else for (uint32_t i = threadIdx.x; i < fg * (uint32_t)(sizeof(McGapTask) / 4); i += 256) ((uint32_t *)(gaps + bG))[i] = ((const uint32_t *)stG)[i];
+            __syncthreads();
+            if (threadIdx.x == 0) { fillH = 0; fillG = 0; }
+            __syncthreads();
         }
-    } else if (rc == 2) {
-        uint32_t k = atomicAdd(&counters[C_GAPS], 1u);
-        if (k < cap_gaps) gaps[k] = g; else counters[C_OVERFLOW] = 3;
+        if (last) break;
+        const uint32_t tid = chunk * 256 + threadIdx.x;
+        int rc = 0;
+        McGapTask g;
+        McHsp h;
+        bool keep = false;
+        if (tid < ntasks) {
+            const McSeedTask t = tasks[tid];
+            if (t.read != MC_TASK_NONE) {                          // (padding of a partly used block of the task pool)
+                const int frame = (int)(t.chrono >> 25), pos = (int)((t.chrono >> 17) & 0xff);
+                const int qlen = (L - frame % 3) / 3;
+                g.read = t.read; g.chrono = t.chrono;
+                rc = mc_eval_seed(hot, X, frames + ((int64_t)t.read * 6 + frame) * FP, qlen, frame, pos, t.posting, (int)(t.seedlen_nkey & 0xff), (int)(t.seedlen_nkey >> 8), &g);
+                if (rc == 1) {
+                    h.read = t.read; h.chrono = t.chrono;
+                    keep = mc_make_hsp(*T, L, frame, g, g.qfwd, g.qfwd, g.qbwd, g.qbwd, g.score, g.nmatch, g.qfwd + g.L + g.qbwd, 0, 0, &h);
+                }
+            }
+        }
+        {   // stage: one LDS atomic per wave and kind
+            const unsigned long long mh = __ballot(keep), mg = __ballot(rc == 2);
+            uint32_t oh = 0, og = 0;
+            if (mh) { const int ld = __builtin_ctzll(mh); if (lane == ld) oh = atomicAdd(&fillH, (uint32_t)__popcll(mh)); oh = (uint32_t)__builtin_amdgcn_readlane((int)oh, ld); }
+            if (mg) { const int ld = __builtin_ctzll(mg); if (lane == ld) og = atomicAdd(&fillG, (uint32_t)__popcll(mg)); og = (uint32_t)__builtin_amdgcn_readlane((int)og, ld); }
+            if (keep) stH[oh + (uint32_t)__popcll(mh & ((1ull << lane) - 1))] = h;
+            if (rc == 2) stG[og + (uint32_t)__popcll(mg & ((1ull << lane) - 1))] = g;
+        }
     }
 }
 
@@ -752,10 +803,9 @@ __global__ void __launch_bounds__(128) k_gapped(const McTables *__restrict__ T, 
         }
         McHsp h;
         h.read = g.read; h.chrono = g.chrono;
-        if (mc_make_hsp(*T, L, frame, g, qfwd, dfwd, qbwd, dbwd, score, nmatch, alnlen, gapopens, gaptotal, &h)) {
-            uint32_t o = atomicAdd(&counters[C_HSPS], 1u);
-            if (o < cap_hsps) hsps[o] = h; else counters[C_OVERFLOW] = 2;
-        }
+        const bool keep = mc_make_hsp(*T, L, frame, g, qfwd, dfwd, qbwd, dbwd, score, nmatch, alnlen, gapopens, gaptotal, &h);
+        const uint32_t o = mc_wave_alloc(&counters[C_HSPS], keep);
+        if (keep) { if (o < cap_hsps) hsps[o] = h; else counters[C_OVERFLOW] = 2; }
     }
 }
 
@@ -810,6 +860,9 @@ __global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, 
         for (uint32_t k = a; k < b; k++) any |= mark[k];
         if (!any) { nrow_of[s] = 0; return; }
     }
+#ifdef MC_EXP_FINISH_MAXN
+    if (n > MC_EXP_FINISH_MAXN) { nrow_of[s] = 0; return; }
+#endif
     const uint32_t read = sorted[a].read;
     McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
     double *myk = (double *)(myrows + n);
@@ -920,7 +973,7 @@ static int open_impl(mc_handle *h, const char *const *names, const char *const *
     HIPCK(hipStreamCreate(&h->stream));
     for (auto &e : h->ev) HIPCK(hipEventCreate(&e));
     const McHostIndex &H = h->H;
-    if (dalloc(&h->d_res, H.res.size()) || dalloc(&h->d_off, H.off.size()) || dalloc(&h->d_bstart, H.bstart.size()) || dalloc(&h->d_post, H.post.size() + 1) ||
+    if (dalloc(&h->d_res, H.res.size() + 64) || dalloc(&h->d_off, H.off.size()) || dalloc(&h->d_bstart, H.bstart.size()) || dalloc(&h->d_post, H.post.size() + 1) ||
         dalloc(&h->d_keys, H.keys.size()) || dalloc(&h->d_fam, (size_t)nseq) || dalloc(&h->d_T, 1) || dalloc(&h->d_P, 1) || dalloc(&h->d_counters, C_N) || dalloc(&h->d_stats, S_N)) return -1;
     HIPCK(hipMemcpy(h->d_res, H.res.data(), H.res.size(), hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_off, H.off.data(), H.off.size() * 4, hipMemcpyHostToDevice));
@@ -991,7 +1044,7 @@ static int ensure_capacity(mc_handle *h, int64_t nreads)
     h->cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 2 + 16) + (1 << 20), 0x7fffffff);
     h->cap_rows = (uint32_t)std::min<int64_t>(cap * 48 + (1 << 20), 0x7fffffff);
     h->gap_threads = 256 * 1024;   // 28.8 KB of DP workspace each (7.4 GB): enough resident waves to hide the latency of the serial DP
-    if (dalloc(&h->d_frames, (size_t)cap * 6 * h->FP) || dalloc(&h->d_tasks, h->cap_tasks) ||
+    if (dalloc(&h->d_frames, (size_t)cap * 6 * h->FP + 64) || dalloc(&h->d_tasks, h->cap_tasks) ||
         dalloc(&h->d_gaps, h->cap_gaps) || dalloc(&h->d_hsps, h->cap_hsps) || dalloc(&h->d_sorted, h->cap_hsps) || dalloc(&h->d_v, h->cap_hsps) ||
         dalloc(&h->d_tmp, (size_t)h->cap_hsps * 2) || dalloc(&h->d_k64, h->cap_hsps) || dalloc(&h->d_k64o, h->cap_hsps) || dalloc(&h->d_idx, h->cap_hsps) ||
         dalloc(&h->d_idxo, h->cap_hsps) || dalloc(&h->d_heads, (size_t)cap + 1) || dalloc(&h->d_rows, h->cap_rows) ||
@@ -1079,7 +1132,9 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
     HIPCK(hipStreamSynchronize(st));
     if (c[C_OVERFLOW]) { g_err = "seed task buffer overflow"; return -2; }
     uint32_t ntasks = c[C_TASKS];
-    if (ntasks) k_eval_seeds<<<dim3((ntasks + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_tasks, ntasks, h->d_hsps, h->cap_hsps, h->d_gaps, h->cap_gaps, h->d_counters);
+    const size_t lds_ev = (size_t)MC_EV_STAGE_H * sizeof(McHsp) + (size_t)MC_EV_STAGE_G * sizeof(McGapTask);   // 33 KB: four workgroups per CU
+    if (ntasks) HIPCK(hipFuncSetAttribute((const void *)k_eval_seeds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ev));
+    if (ntasks) k_eval_seeds<<<dim3((unsigned)std::min<uint32_t>((ntasks + 255) / 256, 256u * 4u)), dim3(256), lds_ev, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_tasks, ntasks, h->d_hsps, h->cap_hsps, h->d_gaps, h->cap_gaps, h->d_counters);
     HIPCK(hipEventRecord(h->ev[3], st));
     HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
     HIPCK(hipStreamSynchronize(st));
