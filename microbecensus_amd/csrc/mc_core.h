@@ -911,28 +911,34 @@ MC_HD McPath mc_path_gap(McPath p, int cls)
     return p;
 }
 
-struct McGapResult { int gain, c1, c2, ident, steps, runs, gapcols; };
+struct McGapResult { int gain, c1, c2, ident, steps, runs, gapcols, overflow; };
 
 // workspace: H, D (int) and PH, PD (McPath), each n2+2 entries.
 //   PH[j] = step sequence (origin .. cell) the trace would follow from main[i][j]
 //   PD[j] = the same for the D plane of the cell
+// DP state of one subject column: main and D plane scores with the path statistics they carry
+struct McGapCell { int H, D; McPath PH, PD; };   // 24 B
+
+// C: workspace of `cap` columns.  The band normally stays within a few columns of the diagonal (max column 53 for 150 bp
+// reads), but nothing bounds it below the subject length: when a column >= cap would be written the function gives up
+// with R.overflow = 1 and the caller repeats the flank with a full-size workspace.
 template <class TT>
-MC_HDN McGapResult mc_align_gapped(const TT &T, const uint8_t *s1, int st1, const uint8_t *s2, int st2, int n1, int n2,
-                                   int *H, int *D, McPath *PH, McPath *PD)
+MC_HDN McGapResult mc_align_gapped(const TT &T, const uint8_t *s1, int st1, const uint8_t *s2, int st2, int n1, int n2, McGapCell *C, int cap)
 {
     const int open = MC_GAP_OPEN, ext = MC_GAP_EXT, first = MC_GAP_OPEN + MC_GAP_EXT;
-    McGapResult R; R.gain = 0; R.c1 = 0; R.c2 = 0; R.ident = 0; R.steps = 0; R.runs = 0; R.gapcols = 0;
+    McGapResult R; R.overflow = 0; R.gain = 0; R.c1 = 0; R.c2 = 0; R.ident = 0; R.steps = 0; R.runs = 0; R.gapcols = 0;
     int jEnd = (int)((T.xdrop_gapped - (double)open) / (double)ext);   // 0x40a693-0x40a6b9
     int best = 0, bestI = 0, bestJ = 0, jStart = 1;
     McPath bestP = mc_path_zero();
-    H[0] = 0; D[0] = -open; PH[0] = mc_path_zero(); PD[0] = mc_path_zero();
+    C[0].H = 0; C[0].D = -open; C[0].PH = mc_path_zero(); C[0].PD = mc_path_zero();
     if (n2 > 0 && jEnd > 0) {                                          // row 0: 'E' then 'e' (0x40a6c1-0x40a770)
         int r = -open;
         McPath pe = mc_path_zero();
         for (int j = 1;;) {
-            r -= ext; H[j] = r; D[j] = r - open;
+            if (j >= cap) { R.overflow = 1; return R; }
+            r -= ext; C[j].H = r; C[j].D = r - open;
             pe = mc_path_gap(pe, 1);
-            PH[j] = pe; PD[j] = pe;
+            C[j].PH = pe; C[j].PD = pe;
             j++;
             if (jEnd < j) break;
             if (n2 < j) break;
@@ -941,34 +947,35 @@ MC_HDN McGapResult mc_align_gapped(const TT &T, const uint8_t *s1, int st1, cons
     if (n1 <= 0 || jEnd <= 1) return R;
     for (int i = 1;;) {
         // left border (i, jStart-1): the planes say 'D' in row 1 (continue from main[0][.]) and 'd' afterwards
-        int diag = H[jStart - 1];
-        McPath pdiag = PH[jStart - 1];
-        int hprev = H[jStart - 1] - first;
-        if (hprev < D[jStart - 1] - ext) hprev = D[jStart - 1] - ext;
-        McPath pborder = mc_path_gap((i == 1) ? PH[jStart - 1] : PD[jStart - 1], 2);
-        D[jStart - 1] = hprev; H[jStart - 1] = hprev;
-        PD[jStart - 1] = pborder; PH[jStart - 1] = pborder;
+        int diag = C[jStart - 1].H;
+        McPath pdiag = C[jStart - 1].PH;
+        int hprev = C[jStart - 1].H - first;
+        if (hprev < C[jStart - 1].D - ext) hprev = C[jStart - 1].D - ext;
+        McPath pborder = mc_path_gap((i == 1) ? C[jStart - 1].PH : C[jStart - 1].PD, 2);
+        C[jStart - 1].D = hprev; C[jStart - 1].H = hprev;
+        C[jStart - 1].PD = pborder; C[jStart - 1].PH = pborder;
         int E = hprev - open, h = 0;
         McPath pE = pborder;       // E plane of the previous cell of this row
         McPath phprev = pborder;   // main path of the previous cell of this row
         bool grow = true, trim = true;
         if (!(jStart > jEnd) && !(n2 < jStart)) {
             for (int j = jStart;;) {                                   // 0x40a8e4-0x40a9f5
+                if (j >= cap) { R.overflow = 1; return R; }
                 int a = hprev - first, b = E - ext, Dn;
                 McPath npE, npD;
                 if (a >= b) { E = a; npE = mc_path_gap(phprev, 1); }   // 'E': from main[i][j-1]
                 else { E = b; npE = mc_path_gap(pE, 1); }              // 'e': from the E plane of (i, j-1)
-                a = H[j] - first; b = D[j] - ext;
-                if (a >= b) { Dn = a; npD = mc_path_gap(PH[j], 2); }   // 'D': from main[i-1][j]
-                else { Dn = b; npD = mc_path_gap(PD[j], 2); }          // 'd': from the D plane of (i-1, j)
+                a = C[j].H - first; b = C[j].D - ext;
+                if (a >= b) { Dn = a; npD = mc_path_gap(C[j].PH, 2); }   // 'D': from main[i-1][j]
+                else { Dn = b; npD = mc_path_gap(C[j].PD, 2); }          // 'd': from the D plane of (i-1, j)
                 int x = s1[(i - 1) * st1], y = s2[(j - 1) * st2];
                 int s = diag + MC_SUB(T, x, y);
                 McPath np = pdiag; np.steps++; np.ident += (x == y); np.cls = 0;
                 h = s;
                 if (E > h) { h = E; np = npE; }
                 if (h < Dn) { h = Dn; np = npD; }
-                diag = H[j]; pdiag = PH[j];
-                H[j] = h; D[j] = Dn; PH[j] = np; PD[j] = npD;
+                diag = C[j].H; pdiag = C[j].PH;
+                C[j].H = h; C[j].D = Dn; C[j].PH = np; C[j].PD = npD;
                 pE = npE; phprev = np; hprev = h;
                 if (h > best) { best = h; bestI = i; bestJ = j; bestP = np; }
                 else if ((double)best - T.xdrop_gapped > (double)h && j > bestJ) {
@@ -983,11 +990,12 @@ MC_HDN McGapResult mc_align_gapped(const TT &T, const uint8_t *s1, int st1, cons
         }
         if (grow) {                                                    // 0x40ac45-0x40ad08
             for (int j = jEnd + 1; !(n2 < j); j++) {
+                if (j >= cap) { R.overflow = 1; return R; }
                 int a = hprev - first, b = E - ext;
                 McPath npE;
                 if (a > b) { E = a; npE = mc_path_gap(phprev, 1); }
                 else { E = b; npE = mc_path_gap(pE, 1); }
-                H[j] = E; D[j] = E - open; PH[j] = npE; PD[j] = npE;
+                C[j].H = E; C[j].D = E - open; C[j].PH = npE; C[j].PD = npE;
                 pE = npE; phprev = npE;
                 if (E > best) { best = E; bestI = i; bestJ = j; bestP = npE; }
                 else if ((double)best - T.xdrop_gapped > (double)E) { jEnd = j; break; }
@@ -996,8 +1004,8 @@ MC_HDN McGapResult mc_align_gapped(const TT &T, const uint8_t *s1, int st1, cons
         }
         if (trim && !(jStart > bestJ)) {                               // 0x40ad0c-0x40ad82
             double lim = (double)best - T.xdrop_gapped;
-            if (lim > (double)H[bestJ]) jStart = bestJ;
-            else { int k = bestJ; for (;;) { k--; if (jStart > k) break; if (lim > (double)H[k]) { jStart = k; break; } } }
+            if (lim > (double)C[bestJ].H) jStart = bestJ;
+            else { int k = bestJ; for (;;) { k--; if (jStart > k) break; if (lim > (double)C[k].H) { jStart = k; break; } } }
         }
         i++;
         if (n1 < i) break;

@@ -40,7 +40,7 @@ extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
         }                                                                                                   \
     } while (0)
 
-enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_N = 8 };
+enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_N = 12 };
 enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_N = 16 };   // 64-bit algorithmic-traffic counters of k_enumerate; slots 4..: cycle counters of the MC_EXP_TIMING build
 
 // ------------------------------------------------------------------------------------------------
@@ -770,19 +770,23 @@ __global__ void __launch_bounds__(256) k_eval_seeds(const McTables *__restrict__
     }
 }
 
-#define MC_GAP_W 1200   // workspace entries per thread (markers are <= 1183 aa, checked in mc_open)
+#define MC_GAP_W 1200   // columns of the full-size DP workspace (markers are <= 1183 aa, checked in mc_open)
 
+// Gapped extension of both flanks, one thread per gap task.  First launch: every thread owns a SMALL workspace (cap
+// columns of 24 bytes, contiguous) - the band stays near the diagonal, and 262 k threads striding through 7 GB of
+// full-size workspaces spent their time in TLB misses (15 ms, of which the arithmetic is ~1).  A flank whose band leaves
+// the small workspace makes its task go to the retry list, which a second launch handles with full-size workspaces.
 __global__ void __launch_bounds__(128) k_gapped(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
-                                                const McGapTask *__restrict__ gaps, uint32_t ngaps, McHsp *hsps, uint32_t cap_hsps, uint32_t *counters,
-                                                int *wsH, int *wsD, McPath *wsPH, McPath *wsPD)
+                                                const McGapTask *__restrict__ gaps, const uint32_t *__restrict__ list, uint32_t ngaps, McHsp *hsps, uint32_t cap_hsps,
+                                                uint32_t *counters, McGapCell *ws, int cap, uint32_t *retry)
 {
     __shared__ McHot hot;
     mc_load_hot(&hot, T);
     __syncthreads();
     uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
-    int *Hh = wsH + (size_t)tid * MC_GAP_W, *Dd = wsD + (size_t)tid * MC_GAP_W;
-    McPath *PH = wsPH + (size_t)tid * MC_GAP_W, *PD = wsPD + (size_t)tid * MC_GAP_W;
-    for (uint32_t k = tid; k < ngaps; k += nthreads) {
+    McGapCell *C = ws + (size_t)tid * cap;
+    for (uint32_t k0 = tid; k0 < ngaps; k0 += nthreads) {
+        const uint32_t k = list ? list[k0] : k0;
         McGapTask g = gaps[k];
         int frame = (int)(g.chrono >> 25);
         int qlen = (L - frame % 3) / 3;
@@ -792,14 +796,29 @@ __global__ void __launch_bounds__(128) k_gapped(const McTables *__restrict__ T, 
         int score = g.score, nmatch = g.nmatch, qfwd = g.qfwd, dfwd = g.qfwd, qbwd = g.qbwd, dbwd = g.qbwd;
         int alnlen = g.qfwd + g.L + g.qbwd, gapopens = 0, gaptotal = 0;
         int qend = qfwd + g.qp + g.L, dend = dfwd + g.dp + g.L, dright = dlen - dend, qright = qlen - qend;
+        bool over = false;
+#ifdef MC_EXP_NODP
+        if (dright > 2000 && qright > 2) {
+#else
         if (dright > 2 && qright > 2) {
-            McGapResult R = mc_align_gapped(hot, q + qend, 1, d + dend, 1, qright, dright, Hh, Dd, PH, PD);
+#endif
+            McGapResult R = mc_align_gapped(hot, q + qend, 1, d + dend, 1, qright, dright, C, cap);
+            over = R.overflow != 0;
             if (R.gain > 0) { score += R.gain; nmatch += R.ident; qfwd += R.c1; dfwd += R.c2; alnlen += R.steps; gapopens += R.runs; gaptotal += R.gapcols; }
         }
         int dleft = g.dp - dbwd, qleft = g.qp - qbwd;
-        if (dleft > 2 && qleft > 2) {
-            McGapResult R = mc_align_gapped(hot, q + qleft - 1, -1, d + dleft - 1, -1, qleft, dleft, Hh, Dd, PH, PD);
+#ifdef MC_EXP_NODP
+        if (dleft > 2000 && qleft > 2) {
+#else
+        if (!over && dleft > 2 && qleft > 2) {
+#endif
+            McGapResult R = mc_align_gapped(hot, q + qleft - 1, -1, d + dleft - 1, -1, qleft, dleft, C, cap);
+            over = R.overflow != 0;
             if (R.gain > 0) { score += R.gain; nmatch += R.ident; qbwd += R.c1; dbwd += R.c2; alnlen += R.steps; gapopens += R.runs; gaptotal += R.gapcols; }
+        }
+        if (over) {                                               // band left the small workspace: the whole task is redone later
+            if (retry) retry[atomicAdd(&counters[C_RETRY], 1u)] = k; else counters[C_OVERFLOW] = 5;
+            continue;
         }
         McHsp h;
         h.read = g.read; h.chrono = g.chrono;
@@ -915,7 +934,7 @@ struct mc_handle {
     uint64_t *d_k64 = nullptr, *d_k64o = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
     uint32_t *d_counters = nullptr;
     McRow *d_rows = nullptr; uint32_t *d_nrow = nullptr, *d_rowoff = nullptr; McBestHit *d_best = nullptr; uint8_t *d_mark = nullptr;
-    int *d_gH = nullptr, *d_gD = nullptr; McPath *d_gPH = nullptr, *d_gPD = nullptr;
+    McGapCell *d_gws = nullptr, *d_gws_full = nullptr; uint32_t *d_retry = nullptr; int gap_cap = 0, gap_threads_full = 0;
     int gap_threads = 0;
     // host results: rows of the last batch land in pinned memory; mc_search() accumulates its batches in all_rows
     mc_row *pin_rows = nullptr; size_t pin_cap = 0;
@@ -950,7 +969,7 @@ extern "C" void mc_close(mc_handle *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_frames, h->d_tasks, h->d_gaps, h->d_hsps,
                     h->d_sorted, h->d_v, h->d_tmp, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, h->d_heads, h->d_sorttmp, h->d_counters, h->d_rows,
-                    h->d_nrow, h->d_rowoff, h->d_best, h->d_mark, h->d_gH, h->d_gD, h->d_gPH, h->d_gPD, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild};
+                    h->d_nrow, h->d_rowoff, h->d_best, h->d_mark, h->d_gws, h->d_gws_full, h->d_retry, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->pin_rows) (void)hipHostFree(h->pin_rows);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -1043,13 +1062,14 @@ static int ensure_capacity(mc_handle *h, int64_t nreads)
     h->cap_gaps = (uint32_t)std::min<int64_t>(cap * (L / 8 + 8) + (1 << 18), 0x7fffffff);
     h->cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 2 + 16) + (1 << 20), 0x7fffffff);
     h->cap_rows = (uint32_t)std::min<int64_t>(cap * 48 + (1 << 20), 0x7fffffff);
-    h->gap_threads = 256 * 1024;   // 28.8 KB of DP workspace each (7.4 GB): enough resident waves to hide the latency of the serial DP
+    h->gap_threads = 256 * 1024; h->gap_cap = (h->FP + 32 + 15) & ~15;   // small DP workspaces: frame length + 32 columns of 24 bytes each
+    h->gap_threads_full = 16 * 1024;                                      // full-size ones for the retry launch (460 MB)
     if (dalloc(&h->d_frames, (size_t)cap * 6 * h->FP + 64) || dalloc(&h->d_tasks, h->cap_tasks) ||
         dalloc(&h->d_gaps, h->cap_gaps) || dalloc(&h->d_hsps, h->cap_hsps) || dalloc(&h->d_sorted, h->cap_hsps) || dalloc(&h->d_v, h->cap_hsps) ||
         dalloc(&h->d_tmp, (size_t)h->cap_hsps * 2) || dalloc(&h->d_k64, h->cap_hsps) || dalloc(&h->d_k64o, h->cap_hsps) || dalloc(&h->d_idx, h->cap_hsps) ||
         dalloc(&h->d_idxo, h->cap_hsps) || dalloc(&h->d_heads, (size_t)cap + 1) || dalloc(&h->d_rows, h->cap_rows) ||
-        dalloc(&h->d_mark, (size_t)h->cap_hsps) || dalloc(&h->d_nrow, (size_t)cap + 1) || dalloc(&h->d_rowoff, (size_t)cap + 1) || dalloc(&h->d_best, (size_t)cap + 1) || dalloc(&h->d_gH, (size_t)h->gap_threads * MC_GAP_W) ||
-        dalloc(&h->d_gD, (size_t)h->gap_threads * MC_GAP_W) || dalloc(&h->d_gPH, (size_t)h->gap_threads * MC_GAP_W) || dalloc(&h->d_gPD, (size_t)h->gap_threads * MC_GAP_W))
+        dalloc(&h->d_mark, (size_t)h->cap_hsps) || dalloc(&h->d_nrow, (size_t)cap + 1) || dalloc(&h->d_rowoff, (size_t)cap + 1) || dalloc(&h->d_best, (size_t)cap + 1) || dalloc(&h->d_gws, (size_t)h->gap_threads * h->gap_cap) ||
+        dalloc(&h->d_gws_full, (size_t)h->gap_threads_full * MC_GAP_W) || dalloc(&h->d_retry, (size_t)h->cap_gaps))
         return -1;
     size_t bytes = 0, bytes2 = 0;
     HIPCK(rocprim::radix_sort_pairs(nullptr, bytes, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, (size_t)h->cap_hsps, 0, 64, h->stream));
@@ -1142,7 +1162,13 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
     uint32_t ngaps = c[C_GAPS];
     if (ngaps) {
         int blocks = std::min<int>(h->gap_threads / 128, (int)((ngaps + 127) / 128));
-        k_gapped<<<dim3(blocks), dim3(128), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, ngaps, h->d_hsps, h->cap_hsps, h->d_counters, h->d_gH, h->d_gD, h->d_gPH, h->d_gPD);
+        k_gapped<<<dim3(blocks), dim3(128), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, nullptr, ngaps, h->d_hsps, h->cap_hsps, h->d_counters, h->d_gws, h->gap_cap, h->d_retry);
+        HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
+        HIPCK(hipStreamSynchronize(st));
+        if (const uint32_t nretry = c[C_RETRY]) {                  // tasks whose band left the small workspace
+            blocks = std::min<int>(h->gap_threads_full / 128, (int)((nretry + 127) / 128));
+            k_gapped<<<dim3(blocks), dim3(128), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, h->d_retry, nretry, h->d_hsps, h->cap_hsps, h->d_counters, h->d_gws_full, MC_GAP_W, nullptr);
+        }
     }
     HIPCK(hipEventRecord(h->ev[4], st));
     HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));

@@ -169,7 +169,7 @@ int main(int argc, char **argv)
         else if (rc == 2) gaps.push_back(g);
     }
     fprintf(stderr, "ungapped hsps: %zu gapped tasks: %zu\n", hsps.size(), gaps.size());
-    std::vector<int> Hh(2100), Dd(2100); std::vector<McPath> PH(2100), PD(2100);
+    std::vector<McGapCell> cells(2100);
     for (const McGapTask &g : gaps) {
         int frame = (int)(g.chrono >> 25);
         const uint8_t *q = &frames[((size_t)g.read * 6 + frame) * FP]; int qlen = flen[(size_t)g.read * 6 + frame];
@@ -178,12 +178,12 @@ int main(int argc, char **argv)
         int alnlen = g.qfwd + g.L + g.qbwd, gapopens = 0, gaptotal = 0;
         int qend = qfwd + g.qp + g.L, dend = dfwd + g.dp + g.L, dright = dlen - dend, qright = qlen - qend;
         if (dright > 2 && qright > 2) {
-            McGapResult R = mc_align_gapped(T, q + qend, 1, d + dend, 1, qright, dright, Hh.data(), Dd.data(), PH.data(), PD.data());
+            McGapResult R = mc_align_gapped(T, q + qend, 1, d + dend, 1, qright, dright, cells.data(), (int)cells.size());
             if (R.gain > 0) { score += R.gain; nmatch += R.ident; qfwd += R.c1; dfwd += R.c2; alnlen += R.steps; gapopens += R.runs; gaptotal += R.gapcols; }
         }
         int dleft = g.dp - dbwd, qleft = g.qp - qbwd;
         if (dleft > 2 && qleft > 2) {
-            McGapResult R = mc_align_gapped(T, q + qleft - 1, -1, d + dleft - 1, -1, qleft, dleft, Hh.data(), Dd.data(), PH.data(), PD.data());
+            McGapResult R = mc_align_gapped(T, q + qleft - 1, -1, d + dleft - 1, -1, qleft, dleft, cells.data(), (int)cells.size());
             if (R.gain > 0) { score += R.gain; nmatch += R.ident; qbwd += R.c1; dbwd += R.c2; alnlen += R.steps; gapopens += R.runs; gaptotal += R.gapcols; }
         }
         McHsp h; h.read = g.read; h.chrono = g.chrono;
