@@ -1062,7 +1062,7 @@ static int ensure_capacity(mc_handle *h, int64_t nreads)
     h->cap_gaps = (uint32_t)std::min<int64_t>(cap * (L / 8 + 8) + (1 << 18), 0x7fffffff);
     h->cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 2 + 16) + (1 << 20), 0x7fffffff);
     h->cap_rows = (uint32_t)std::min<int64_t>(cap * 48 + (1 << 20), 0x7fffffff);
-    h->gap_threads = 256 * 1024; h->gap_cap = (h->FP + 32 + 15) & ~15;   // small DP workspaces: frame length + 32 columns of 24 bytes each
+    h->gap_threads = 1024 * 1024; h->gap_cap = (h->FP + 32 + 15) & ~15;   // small DP workspaces: frame length + 32 columns of 24 bytes each
     h->gap_threads_full = 16 * 1024;                                      // full-size ones for the retry launch (460 MB)
     if (dalloc(&h->d_frames, (size_t)cap * 6 * h->FP + 64) || dalloc(&h->d_tasks, h->cap_tasks) ||
         dalloc(&h->d_gaps, h->cap_gaps) || dalloc(&h->d_hsps, h->cap_hsps) || dalloc(&h->d_sorted, h->cap_hsps) || dalloc(&h->d_v, h->cap_hsps) ||
