@@ -289,17 +289,19 @@ MC_HDN int mc_finish_read(const McTables &T, const McIndex &X, const McClassPars
     mc_std_sort(items, vn, 0);                       // std::sort by log E (PrintRes), on (key, index) items
     int nrows = 0;
     best->read = read_id; best->family = -1; best->aln = 0; best->target_len = 0; best->bits = 0.0;
-    for (int i = 0; i < vn && i < MC_MAX_M8; i++) {
+    while (nrows < vn && nrows < MC_MAX_M8 && v[items[nrows].i].loge < T.loge_thr) nrows++;      // PrintRes: at most 500 rows, log E below the threshold
+    // MergeRes re-sorts the printed rows with std::partial_sort (a heap sort) keyed by the PRINTED log E: same heap on the
+    // (key, index) items, then the rows are written once, in their final order
+    for (int i = 0; i < nrows; i++) items[i].k = mc_round6(v[items[i].i].loge);
+    mc_heapsort(items, nrows, 0);
+    for (int i = 0; i < nrows; i++) {
         const McHsp &h = v[items[i].i];
-        if (!(h.loge < T.loge_thr)) break;
-        McRow &r = rows[nrows];
+        McRow &r = rows[i];
         r.query = read_id; r.subject = h.sidx; r.ident = (double)h.nmatch * 100.0 / (double)h.alnlen;
         r.alnlen = h.alnlen; r.mismatch = h.mism; r.gapopen = h.gaps; r.qstart = h.qnts; r.qend = h.qnte; r.sstart = h.ds; r.send = h.de;
         r.loge = h.loge; r.bits = T.bits_r[h.score]; r.score = h.score; r.frame = h.nmatch;   // frame slot carries nmatch for the classifier
-        krows[nrows] = mc_round6(h.loge);
-        nrows++;
     }
-    mc_merge_res_order(rows, krows, nrows);
+    (void)krows;
     for (int i = 0; i < nrows; i++) {
         McRow &r = rows[i];
         int fam = marker_family[r.subject], tl = (int)(X.off[r.subject + 1] - X.off[r.subject]);
