@@ -38,81 +38,16 @@ MC_HD bool mc_hless(const McHsp &a, const McHsp &b, int key)
 struct McSortItem { double k; uint32_t i; uint32_t pad; };
 MC_HD bool mc_hless(const McSortItem &a, const McSortItem &b, int) { return a.k < b.k; }
 
-template <class E>
-MC_HDN void mc_adjust_heap(E *first, long hole, long len, E value, int key)
-{
-    long top = hole, sc = hole;
-    while (sc < (len - 1) / 2) {
-        sc = 2 * (sc + 1);
-        if (mc_hless(first[sc], first[sc - 1], key)) sc--;
-        first[hole] = first[sc]; hole = sc;
-    }
-    if ((len & 1) == 0 && sc == (len - 2) / 2) { sc = 2 * (sc + 1); first[hole] = first[sc - 1]; hole = sc - 1; }
-    long parent = (hole - 1) / 2;
-    while (hole > top && mc_hless(first[parent], value, key)) { first[hole] = first[parent]; hole = parent; parent = (hole - 1) / 2; }
-    first[hole] = value;
-}
-template <class E>
-MC_HDN void mc_heapsort(E *first, long n, int key)
-{
-    if (n >= 2) for (long parent = (n - 2) / 2;; parent--) { mc_adjust_heap(first, parent, n, first[parent], key); if (parent == 0) break; }
-    for (long m = n; m > 1;) { m--; E v = first[m]; first[m] = first[0]; mc_adjust_heap(first, 0, m, v, key); }
-}
-template <class E>
-MC_HDN void mc_unguarded_insert(E *last, E val, int key)
-{
-    E *next = last - 1;
-    while (mc_hless(val, *next, key)) { *last = *next; last = next; --next; }
-    *last = val;
-}
-template <class E>
-MC_HDN void mc_insertion_sort(E *first, E *last, int key)
-{
-    if (first == last) return;
-    for (E *i = first + 1; i != last; ++i) {
-        E val = *i;
-        if (mc_hless(val, *first, key)) { for (E *p = i; p != first; --p) *p = *(p - 1); *first = val; }
-        else mc_unguarded_insert(i, val, key);
-    }
-}
-template <class E>
-MC_HDN void mc_std_sort(E *first, long n, int key)
-{
-    if (n <= 0) return;
-    long lg = 0;
-    for (long t = n; t > 1; t >>= 1) lg++;
-    // explicit stack of (first, last, depth): the recursion of __introsort_loop goes into the right part
-    long sf[64], sl[64], sd[64];
-    int sp = 0;
-    sf[0] = 0; sl[0] = n; sd[0] = 2 * lg; sp = 1;
-    while (sp > 0) {
-        sp--;
-        long f = sf[sp], l = sl[sp], depth = sd[sp];
-        while (l - f > 16) {
-            if (depth == 0) { mc_heapsort(first + f, l - f, key); break; }
-            --depth;
-            const E &a = first[f], &b = first[f + (l - f) / 2], &c = first[l - 1];
-            E pivot;
-            if (mc_hless(a, b, key)) { if (mc_hless(b, c, key)) pivot = b; else if (mc_hless(a, c, key)) pivot = c; else pivot = a; }
-            else if (mc_hless(a, c, key)) pivot = a;
-            else if (mc_hless(b, c, key)) pivot = c;
-            else pivot = b;
-            long lo = f, hi = l;
-            for (;;) {
-                while (mc_hless(first[lo], pivot, key)) ++lo;
-                --hi;
-                while (mc_hless(pivot, first[hi], key)) --hi;
-                if (!(lo < hi)) break;
-                E t = first[lo]; first[lo] = first[hi]; first[hi] = t;
-                ++lo;
-            }
-            if (sp < 64) { sf[sp] = lo; sl[sp] = l; sd[sp] = depth; sp++; }
-            l = lo;
-        }
-    }
-    if (n > 16) { mc_insertion_sort(first, first + 16, key); for (E *i = first + 16; i != first + n; ++i) mc_unguarded_insert(i, *i, key); }
-    else mc_insertion_sort(first, first + n, key);
-}
+#define MC_SORT_FN(x) x
+#define MC_SORT_ATTR MC_HDN
+#include "mc_sort_impl.h"
+#undef MC_SORT_FN
+#undef MC_SORT_ATTR
+#define MC_SORT_FN(x) x##_inl
+#define MC_SORT_ATTR MC_HD
+#include "mc_sort_impl.h"
+#undef MC_SORT_FN
+#undef MC_SORT_ATTR
 MC_HDN void mc_stable_sort_loge(McHsp *first, long n)
 { // std::stable_sort(CompEvalueObj): any stable sort produces the same permutation
     for (long i = 1; i < n; ++i) {
@@ -262,27 +197,45 @@ MC_HD bool mc_row_passes(const McClassPars &P, const McRow &r, int fam, int targ
 // krows: 500 doubles of scratch.  Returns the number of rows; *best gets the classify_reads result
 // (best->family = -1 when no row passes the filters).
 // ------------------------------------------------------------------------------------------------
+// HSPs in[a, b) of one subject (sorted by chrono) -> out[0, kept): the multimap's view of them, linked by sum statistics.
+// tmp: 2 (b - a) entries of scratch.
+MC_HDN int mc_finish_group(const McTables &T, const McIndex &X, const McHsp *in, int a, int b, McHsp *out, McHsp *tmp)
+{
+    int vn = 0;
+    const int sidx = in[a].sidx;
+    // stack of this subject's HSPs, newest on top; a re-found HSP only replaces the top if it is better
+    for (int k = a; k < b; k++) {
+        const McHsp &h = in[k];
+        if (vn > 0) {
+            McHsp &t = out[vn - 1];
+            if (t.frame == h.frame && t.qaas == h.qaas && t.ds == h.ds && t.qaae == h.qaae && t.de == h.de) {
+                if (t.loge > h.loge) { t.score = h.score; t.loge = h.loge; t.alnlen = h.alnlen; t.mism = h.mism; t.gaps = h.gaps; t.nmatch = h.nmatch; t.qnts = h.qnts; t.qnte = h.qnte; }
+                continue;
+            }
+        }
+        out[vn++] = h;
+    }
+    for (int i = 0, j = vn - 1; i < j; i++, j--) { McHsp t = out[i]; out[i] = out[j]; out[j] = t; }   // multimap order: newest first
+    if (vn > 1) vn = mc_sum_evalue(T, out, 0, vn, (int)(X.off[sidx + 1] - X.off[sidx]), tmp);
+    return vn;
+}
+// one m8 row (PrintRes) from an HSP; the frame slot carries nmatch for the classifier
+MC_HD void mc_fill_row(const McTables &T, int read_id, const McHsp &h, McRow &r)
+{
+    r.query = read_id; r.subject = h.sidx; r.ident = (double)h.nmatch * 100.0 / (double)h.alnlen;
+    r.alnlen = h.alnlen; r.mismatch = h.mism; r.gapopen = h.gaps; r.qstart = h.qnts; r.qend = h.qnte; r.sstart = h.ds; r.send = h.de;
+    r.loge = h.loge; r.bits = T.bits_r[h.score]; r.score = h.score; r.frame = h.nmatch;
+}
+
 MC_HDN int mc_finish_read(const McTables &T, const McIndex &X, const McClassPars &P, const int32_t *marker_family,
                           int read_id, const McHsp *in, int n, McHsp *v, McHsp *tmp, McRow *rows, double *krows, McSortItem *items, McBestHit *best)
 {
     int vn = 0;
     for (int a = 0; a < n;) {
-        int b = a, sidx = in[a].sidx, st = vn;
+        int b = a;
+        const int sidx = in[a].sidx;
         while (b < n && in[b].sidx == sidx) b++;
-        // stack of this subject's HSPs, newest on top; a re-found HSP only replaces the top if it is better
-        for (int k = a; k < b; k++) {
-            const McHsp &h = in[k];
-            if (vn > st) {
-                McHsp &t = v[vn - 1];
-                if (t.frame == h.frame && t.qaas == h.qaas && t.ds == h.ds && t.qaae == h.qaae && t.de == h.de) {
-                    if (t.loge > h.loge) { t.score = h.score; t.loge = h.loge; t.alnlen = h.alnlen; t.mism = h.mism; t.gaps = h.gaps; t.nmatch = h.nmatch; t.qnts = h.qnts; t.qnte = h.qnte; }
-                    continue;
-                }
-            }
-            v[vn++] = h;
-        }
-        for (int i = st, j = vn - 1; i < j; i++, j--) { McHsp t = v[i]; v[i] = v[j]; v[j] = t; }   // multimap order: newest first
-        if (vn - st > 1) vn = mc_sum_evalue(T, v, st, vn, (int)(X.off[sidx + 1] - X.off[sidx]), tmp);
+        vn += mc_finish_group(T, X, in, a, b, v + vn, tmp);
         a = b;
     }
     for (int i = 0; i < vn; i++) { items[i].k = v[i].loge; items[i].i = (uint32_t)i; items[i].pad = 0; }
@@ -295,11 +248,7 @@ MC_HDN int mc_finish_read(const McTables &T, const McIndex &X, const McClassPars
     for (int i = 0; i < nrows; i++) items[i].k = mc_round6(v[items[i].i].loge);
     mc_heapsort(items, nrows, 0);
     for (int i = 0; i < nrows; i++) {
-        const McHsp &h = v[items[i].i];
-        McRow &r = rows[i];
-        r.query = read_id; r.subject = h.sidx; r.ident = (double)h.nmatch * 100.0 / (double)h.alnlen;
-        r.alnlen = h.alnlen; r.mismatch = h.mism; r.gapopen = h.gaps; r.qstart = h.qnts; r.qend = h.qnte; r.sstart = h.ds; r.send = h.de;
-        r.loge = h.loge; r.bits = T.bits_r[h.score]; r.score = h.score; r.frame = h.nmatch;   // frame slot carries nmatch for the classifier
+        mc_fill_row(T, read_id, v[items[i].i], rows[i]);
     }
     (void)krows;
     for (int i = 0; i < nrows; i++) {

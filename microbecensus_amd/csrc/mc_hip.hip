@@ -40,7 +40,7 @@ extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
         }                                                                                                   \
     } while (0)
 
-enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_N = 12 };
+enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_HEAVY, C_HEAVY2, C_N = 12 };
 enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_N = 16 };   // 64-bit algorithmic-traffic counters of k_enumerate; slots 4..: cycle counters of the MC_EXP_TIMING build
 
 // ------------------------------------------------------------------------------------------------
@@ -860,6 +860,10 @@ __global__ void k_heads(const uint32_t *__restrict__ flags, const uint32_t *__re
 }
 
 
+#define MC_FH_MIN 96      // reads with more HSPs than this are finished by a whole wave (k_finish_heavy)
+#define MC_FH_MAXN 2048   // ... up to this many in the standard form (45 KB of LDS per wave, three waves per CU)
+#define MC_FH_BIGN 6144   // ... up to this many in the large form (132 KB, one wave per CU); beyond, back to the single thread
+
 // One thread per read that has HSPs, in ascending read order.  All scratch is addressed by the read's offset into the
 // sorted HSP array (a read never produces more rows than it has HSPs): v = the stacks, tmp = 2 HSP slots per HSP for the
 // sum statistics, reused afterwards for the read's rows and their merge keys (64 + 8 bytes per row <= 96).  The rows
@@ -867,7 +871,7 @@ __global__ void k_heads(const uint32_t *__restrict__ flags, const uint32_t *__re
 __global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
                                                 const McHsp *__restrict__ sorted, uint32_t nhsps, const uint32_t *__restrict__ heads, uint32_t nheads,
                                                 const uint8_t *__restrict__ mark, McHsp *v, McHsp *tmp, int64_t first_read_id, uint32_t *nrow_of, McBestHit *best,
-                                                uint32_t *counters)
+                                                uint32_t *counters, uint32_t *heavy, uint32_t *heavy2, int fh_min)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nheads) return;
@@ -879,9 +883,8 @@ __global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, 
         for (uint32_t k = a; k < b; k++) any |= mark[k];
         if (!any) { nrow_of[s] = 0; return; }
     }
-#ifdef MC_EXP_FINISH_MAXN
-    if (n > MC_EXP_FINISH_MAXN) { nrow_of[s] = 0; return; }
-#endif
+    if (n > fh_min && n <= MC_FH_MAXN) { heavy[atomicAdd(&counters[C_HEAVY], 1u)] = s; return; }
+    if (n > MC_FH_MAXN && n <= MC_FH_BIGN) { heavy2[atomicAdd(&counters[C_HEAVY2], 1u)] = s; return; }   // a read with many HSPs gets a wave of its own
     const uint32_t read = sorted[a].read;
     McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
     double *myk = (double *)(myrows + n);
@@ -892,6 +895,107 @@ __global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, 
     if (nr > 0) atomicAdd(&counters[C_SEGS], 1u);
     if (bh.family >= 0) best[atomicAdd(&counters[C_BEST], 1u)] = bh;       // few; the host orders them by read
 }
+// A read with many HSPs (one that really comes from a marker gene: hundreds of homologous subjects): one wave.
+// Parallel over lanes: the per-subject stacks and sum statistics (mc_finish_group per subject), the (log E, index) items,
+// the rows and their classification.  Sequential, by lane 0 on items held in LDS: the two order-defining sorts (std::sort
+// by log E, MergeRes' heap sort by printed log E), which have to replay libstdc++'s exact sequence of moves.
+// Same scratch layout and same results as k_finish.
+template <int MAXN, int CTR>
+__global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
+                                                     const McHsp *__restrict__ sorted, uint32_t nhsps, const uint32_t *__restrict__ heads, uint32_t nheads,
+                                                     McHsp *v, McHsp *tmp, int64_t first_read_id, uint32_t *nrow_of, McBestHit *best, uint32_t *counters,
+                                                     const uint32_t *__restrict__ heavy)
+{
+    McSortItem *items = (McSortItem *)mc_smem;                      // MAXN sort items, then three index arrays (dynamic LDS)
+    uint16_t *gst = (uint16_t *)(items + MAXN), *gkept = gst + (MAXN + 2), *gofs = gkept + (MAXN + 2);
+    __shared__ int s_vn, s_nrows;
+    const int lane = mc_lane();
+    const unsigned long long lt = (1ull << lane) - 1;
+    const uint32_t nheavy = counters[CTR];
+    for (uint32_t bi = blockIdx.x; bi < nheavy; bi += gridDim.x) {
+        const uint32_t s = heavy[bi], a = heads[s], b = (s + 1 < nheads) ? heads[s + 1] : nhsps;
+        const int n = (int)(b - a);
+        const McHsp *in = sorted + a;
+        const int read_id = (int)((int64_t)in[0].read + first_read_id);
+        // subjects: group starts
+        int ng = 0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const bool st = i < n && (i == 0 || in[i].sidx != in[i - 1].sidx);
+            const unsigned long long m = __ballot(st);
+            if (st) gst[ng + __popcll(m & lt)] = (uint16_t)i;
+            ng += __popcll(m);
+        }
+        if (lane == 0) gst[ng] = (uint16_t)n;
+        __syncthreads();
+        // per subject: stack, reversal, sum statistics - results stay at the group's own offset of v
+        for (int g = lane; g < ng; g += 64) {
+            const int g0 = gst[g], g1 = gst[g + 1];
+            gkept[g] = (uint16_t)mc_finish_group(*T, X, in, g0, g1, v + a + g0, tmp + 2 * ((size_t)a + g0));
+        }
+        __syncthreads();
+        // offsets of the groups in the sequence PrintRes sorts (exclusive scan of the kept counts)
+        {
+            int carry = 0;
+            for (int g0 = 0; g0 < ng; g0 += 64) {
+                const int g = g0 + lane;
+                int x = g < ng ? gkept[g] : 0, incl = x;
+                for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+                if (g < ng) gofs[g] = (uint16_t)(carry + incl - x);
+                carry += __shfl(incl, 63);
+            }
+            if (lane == 0) { gofs[ng] = (uint16_t)carry; s_vn = carry; }
+        }
+        __syncthreads();
+        const int vn = s_vn;
+        for (int g = lane; g < ng; g += 64) {
+            const int g0 = gst[g], o = gofs[g], k = gkept[g];
+            for (int j = 0; j < k; j++) { McSortItem it; it.k = v[a + g0 + j].loge; it.i = (uint32_t)(g0 + j); it.pad = 0; items[o + j] = it; }
+        }
+        __syncthreads();
+        if (lane == 0) mc_std_sort_inl(items, vn, 0);             // std::sort by log E (PrintRes); inlined: the items are addressed as LDS
+        __syncthreads();
+        // rows: at most 500, log E below the threshold (the items are in ascending log E, so the test is monotone)
+        {
+            const int lim = vn < MC_MAX_M8 ? vn : MC_MAX_M8;
+            int cnt = 0;
+            for (int i0 = 0; i0 < lim; i0 += 64) {
+                const int i = i0 + lane;
+                const bool ok = i < lim && v[a + items[i].i].loge < T->loge_thr;
+                cnt += __popcll(__ballot(ok));
+            }
+            if (lane == 0) s_nrows = cnt;
+        }
+        __syncthreads();
+        const int nrows = s_nrows;
+        for (int i = lane; i < nrows; i += 64) items[i].k = mc_round6(v[a + items[i].i].loge);
+        __syncthreads();
+        if (lane == 0) mc_heapsort_inl(items, nrows, 0);              // MergeRes: heap sort by the printed log E
+        __syncthreads();
+        McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);             // the groups' scratch is dead by now
+        double bbits = -1.0; int bidx = 0x7fffffff, bfam = -1, baln = 0, btl = 0;
+        for (int i = lane; i < nrows; i += 64) {
+            McRow r;
+            mc_fill_row(*T, read_id, v[a + items[i].i], r);
+            myrows[i] = r;
+            const int f = fam[r.subject], tl = (int)(X.off[r.subject + 1] - X.off[r.subject]);
+            if (mc_row_passes(*P, r, f, tl, r.frame) && (bfam < 0 || bbits < r.bits)) { bbits = r.bits; bidx = i; bfam = f; baln = r.alnlen; btl = tl; }
+        }
+        // classify_reads keeps the first row with the highest bit score: reduce (bits desc, row index asc) over the lanes
+        for (int d = 32; d > 0; d >>= 1) {
+            const double ob = __shfl_down(bbits, d);
+            const int oi = __shfl_down(bidx, d), of = __shfl_down(bfam, d), oa = __shfl_down(baln, d), ot = __shfl_down(btl, d);
+            if (of >= 0 && (bfam < 0 || ob > bbits || (ob == bbits && oi < bidx))) { bbits = ob; bidx = oi; bfam = of; baln = oa; btl = ot; }
+        }
+        if (lane == 0) {
+            nrow_of[s] = (uint32_t)nrows;
+            if (nrows > 0) atomicAdd(&counters[C_SEGS], 1u);
+            if (bfam >= 0) { McBestHit bh; bh.read = read_id; bh.family = bfam; bh.aln = baln; bh.target_len = btl; bh.bits = bbits; best[atomicAdd(&counters[C_BEST], 1u)] = bh; }
+        }
+        __syncthreads();
+    }
+}
+
 // rows of read s -> rows[rowoff[s] ...]: the m8 order (ascending read, RAPsearch2's order inside a read)
 __global__ void __launch_bounds__(256) k_emit_rows(const uint32_t *__restrict__ heads, uint32_t nheads, const uint32_t *__restrict__ nrow_of, const uint32_t *__restrict__ rowoff,
                                                    const McHsp *__restrict__ tmp, McRow *__restrict__ rows, uint32_t cap_rows, uint32_t *counters)
@@ -1192,7 +1296,17 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         HIPCK(hipStreamSynchronize(st));
         nheads = c[C_HEADS];
         k_finish<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_mark, h->d_v, h->d_tmp,
-                                                                    first_read_id, h->d_nrow, h->d_best, h->d_counters);
+                                                                    first_read_id, h->d_nrow, h->d_best, h->d_counters, h->d_retry, h->d_retry + h->cap_gaps / 2, MC_FH_MIN);
+        // the reads k_finish set aside (d_retry is free again: the gap tasks are done)
+        {
+            const size_t l1 = (size_t)MC_FH_MAXN * 16 + 3 * (size_t)(MC_FH_MAXN + 2) * 2, l2 = (size_t)MC_FH_BIGN * 16 + 3 * (size_t)(MC_FH_BIGN + 2) * 2;
+            HIPCK(hipFuncSetAttribute((const void *)k_finish_heavy<MC_FH_MAXN, C_HEAVY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1));
+            HIPCK(hipFuncSetAttribute((const void *)k_finish_heavy<MC_FH_BIGN, C_HEAVY2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));
+            k_finish_heavy<MC_FH_BIGN, C_HEAVY2><<<dim3(256), dim3(64), l2, st>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp, first_read_id, h->d_nrow,
+                                                                                   h->d_best, h->d_counters, h->d_retry + h->cap_gaps / 2);
+            k_finish_heavy<MC_FH_MAXN, C_HEAVY><<<dim3(2048), dim3(64), l1, st>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp, first_read_id, h->d_nrow,
+                                                                                  h->d_best, h->d_counters, h->d_retry);
+        }
         bytes = h->sorttmp_bytes;
         HIPCK(rocprim::exclusive_scan(h->d_sorttmp, bytes, h->d_nrow, h->d_rowoff, 0u, (size_t)nheads, rocprim::plus<uint32_t>(), st));
         k_emit_rows<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_heads, nheads, h->d_nrow, h->d_rowoff, h->d_tmp, h->d_rows, h->cap_rows, h->d_counters);
