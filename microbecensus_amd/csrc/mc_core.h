@@ -80,6 +80,7 @@ struct McIndex {
     const uint16_t *keys;      // 4 reduced residues after the 6-mer, 0xF past the sequence end
     const struct McBucketRec *rec;   // per bucket: start + first-residue group boundaries (NULL when the index cannot use them)
     const uint32_t *wild;      // MC_WILD_LINES x 16 words: wildcard filter (mc_wild_*)
+    const unsigned long long *rt; uint32_t rt_mask;   // range table of the long groups (mc_rt_*): rt_mask + 1 slots
     const uint32_t *filt;      // MC_FILT_TOTAL_WORDS words: Bloom filters over the (bucket, key) pairs of the index (10-mers, then 9-mers)
     int32_t nseq;
 };
@@ -727,6 +728,34 @@ MC_HD bool mc_wild_test(const uint32_t q[4], uint32_t bits)
     const uint32_t w1 = (p1 < 64) ? ((p1 < 32) ? q[0] : q[1]) : ((p1 < 96) ? q[2] : q[3]);
     const uint32_t w2 = (p2 < 64) ? ((p2 < 32) ? q[0] : q[1]) : ((p2 < 96) ? q[2] : q[3]);
     return ((w1 >> (p1 & 31)) & (w2 >> (p2 & 31)) & 1u) != 0;
+}
+
+// ---- range table: the answer for probes into long groups -----------------------------------------------------------
+// A probe whose first-residue group holds more than 8 keys needs the reference's two binary searches: ~20 dependent
+// loads, and such probes are the rule for true hits (a conserved 10-mer occurs in hundreds of homologous markers).  The
+// kernel does not search for them: every (bucket, key) that has a non-empty range inside a long group is entered, with
+// the range mc_key_range itself returns, into an open-addressing hash table (8-byte slots: bucket 20 | key 16 | start 11
+// | count 11 bits; 0xFFFF... = empty).  A probe that is not in the table has no range.  (The counting form of the kernel
+// still searches: it has to report where the reference's lower_bound stops even when there is no range.)
+MC_HD uint32_t mc_rt_hash(uint32_t bucket, uint32_t key)
+{
+    uint32_t x = bucket * 0x85EBCA77u + key * 0x9E3779B1u;
+    x ^= x >> 16; x *= 0x2C1B3C6Du; x ^= x >> 15;
+    return x;
+}
+MC_HD unsigned long long mc_rt_pack(uint32_t bucket, uint32_t key, uint32_t nst, uint32_t cnt)
+{
+    return ((unsigned long long)bucket << 38) | ((unsigned long long)key << 22) | ((unsigned long long)nst << 11) | (unsigned long long)cnt;
+}
+// returns the number of postings (0 = none), *nst_out = index of the first one inside the bucket
+MC_HD int mc_rt_lookup(const unsigned long long *rt, uint32_t mask, uint32_t bucket, uint32_t key, int *nst_out)
+{
+    const unsigned long long tag = ((unsigned long long)bucket << 16) | key;
+    for (uint32_t i = mc_rt_hash(bucket, key) & mask;; i = (i + 1) & mask) {
+        const unsigned long long e = rt[i];
+        if ((e >> 22) == tag) { *nst_out = (int)((e >> 11) & 0x7FF); return (int)(e & 0x7FF); }
+        if (e == ~0ull) return 0;
+    }
 }
 
 MC_HD uint32_t mc_pack_key(const uint8_t *g, int nkey)

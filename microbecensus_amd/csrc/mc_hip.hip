@@ -335,6 +335,9 @@ struct McEnWave {
     unsigned long long q[MC_EN_QCAP];       // probes that passed the bucket bitmap
     unsigned long long hq[MC_EN_QCAP];      // probes whose first-residue group is longer than 8 keys (binary search)
     unsigned long long eq[MC_EN_QCAP];      // (position, group) pairs the wildcard filter answered yes for: ten probes each
+#ifdef MC_EXP_TIMING
+    unsigned long long tacc[6], tcnt[6];
+#endif
 };
 
 extern __shared__ __attribute__((aligned(16))) uint8_t mc_smem[];   // dynamic LDS of the kernels that use it
@@ -429,6 +432,12 @@ __device__ __forceinline__ unsigned long long mc_en_process(const McIndex &X, un
         const int ns = (int)R->cum[k6 + 1] - c0;
         heavy = ns > 8;
         if (ns > 0 && !heavy) cnt = mc_group_range8(X.keys + start + c0, ns, qk, &lb);
+        if (!COUNT && heavy) {                                    // long group: the range table knows the answer (no binary search, no second queue)
+            int nst_b = 0;
+            cnt = mc_rt_lookup(X.rt, X.rt_mask, (uint32_t)bucket, qk, &nst_b);
+            lb = nst_b - c0;
+            heavy = false;
+        }
         if (COUNT && !heavy) { const int n = R->cum[11]; kp = mc_bsearch_reads(n, c0 + lb) + (cnt > 0 ? mc_bsearch_reads(n, c0 + lb + cnt) : 0u); }
     }
     const unsigned long long hm = __ballot(heavy);
@@ -466,7 +475,7 @@ __device__ __forceinline__ unsigned long long mc_en_heavy(const McIndex &X, unsi
 }
 
 #ifdef MC_EXP_TIMING
-#define MC_TICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[tcat] += now_ - tlast; tcnt[tcat]++; tlast = now_; tcat = (k); } while (0)
+#define MC_TICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane == 0) { W->tacc[tcat] += now_ - tlast; W->tcnt[tcat]++; } tlast = now_; tcat = (k); } while (0)
 #else
 #define MC_TICK(k) do { } while (0)
 #endif
@@ -490,7 +499,8 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
     const unsigned long long lt = (1ull << lane) - 1;
     const int64_t nw = (int64_t)gridDim.x * MC_EN_WAVES;
 #ifdef MC_EXP_TIMING
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tcnt[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter(); int tcat = 0;   // 0 staging/other 1 heavy 2 process 3 push 4 setup 5 expand
+    if (lane < 6) { W->tacc[lane] = 0; W->tcnt[lane] = 0; }
+    unsigned long long tlast = __builtin_readcyclecounter(); int tcat = 0;   // 0 staging/other 1 heavy 2 process 3 push 4 setup 5 expand
 #endif
     for (int64_t r = (int64_t)blockIdx.x * MC_EN_WAVES + wv; r < nreads; r += nw) {
         int qn = 0, hn = 0, en = 0;
@@ -689,7 +699,8 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
     }
     MC_TICK(0);
 #ifdef MC_EXP_TIMING
-    if (lane == 0) for (int k = 0; k < 6; k++) { atomicAdd(&stats[4 + k], tacc[k]); atomicAdd(&stats[10 + k], tcnt[k]); }
+    mc_wave_sync();
+    if (lane == 0) for (int k = 0; k < 6; k++) { atomicAdd(&stats[4 + k], W->tacc[k]); atomicAdd(&stats[10 + k], W->tcnt[k]); }
 #endif
     {   // close the wave's last block
         mc_wave_sync();
@@ -1030,7 +1041,7 @@ struct mc_handle {
     unsigned long long *d_stats = nullptr;
     uint32_t *d_bitmap = nullptr;
     McBucketRec *d_rec = nullptr;
-    uint32_t *d_filt = nullptr, *d_wild = nullptr;
+    uint32_t *d_filt = nullptr, *d_wild = nullptr; unsigned long long *d_rt = nullptr;
     bool fast_enum = false;
     bool count_traffic = false;
     McSeedTask *d_tasks = nullptr; McGapTask *d_gaps = nullptr; McHsp *d_hsps = nullptr, *d_sorted = nullptr, *d_v = nullptr, *d_tmp = nullptr;
@@ -1049,7 +1060,7 @@ struct mc_handle {
 
 static McIndex dev_index(const mc_handle *h)
 {
-    McIndex X; X.res = h->d_res; X.off = h->d_off; X.bstart = h->d_bstart; X.post = h->d_post; X.keys = h->d_keys; X.rec = h->d_rec; X.filt = h->d_filt; X.wild = h->d_wild; X.nseq = h->H.nseq;
+    McIndex X; X.res = h->d_res; X.off = h->d_off; X.bstart = h->d_bstart; X.post = h->d_post; X.keys = h->d_keys; X.rec = h->d_rec; X.filt = h->d_filt; X.wild = h->d_wild; X.rt = h->d_rt; X.rt_mask = h->H.rt_mask; X.nseq = h->H.nseq;
     return X;
 }
 
@@ -1073,7 +1084,7 @@ extern "C" void mc_close(mc_handle *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_frames, h->d_tasks, h->d_gaps, h->d_hsps,
                     h->d_sorted, h->d_v, h->d_tmp, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, h->d_heads, h->d_sorttmp, h->d_counters, h->d_rows,
-                    h->d_nrow, h->d_rowoff, h->d_best, h->d_mark, h->d_gws, h->d_gws_full, h->d_retry, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild};
+                    h->d_nrow, h->d_rowoff, h->d_best, h->d_mark, h->d_gws, h->d_gws_full, h->d_retry, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_rt};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->pin_rows) (void)hipHostFree(h->pin_rows);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -1108,6 +1119,8 @@ static int open_impl(mc_handle *h, const char *const *names, const char *const *
     HIPCK(hipMemcpy(h->d_bitmap, H.bitmap.data(), H.bitmap.size() * 4, hipMemcpyHostToDevice));
     if (dalloc(&h->d_filt, H.filt.size()) || dalloc(&h->d_wild, H.wild.size())) return -1;
     HIPCK(hipMemcpy(h->d_wild, H.wild.data(), H.wild.size() * 4, hipMemcpyHostToDevice));
+    if (dalloc(&h->d_rt, H.rt.size())) return -1;
+    HIPCK(hipMemcpy(h->d_rt, H.rt.data(), H.rt.size() * 8, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_filt, H.filt.data(), H.filt.size() * 4, hipMemcpyHostToDevice));
     if (!H.rec.empty()) {
         if (dalloc(&h->d_rec, H.rec.size())) return -1;
@@ -1338,7 +1351,7 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
     for (const McBestHit &x : bh) { mc_best_hit o; o.read = x.read; o.family = x.family; o.aln = x.aln; o.target_len = x.target_len; o.bits = x.bits; h->best.push_back(o); }
     { unsigned long long ss[S_N]; HIPCK(hipMemcpy(ss, h->d_stats, sizeof ss, hipMemcpyDeviceToHost));
 #ifdef MC_EXP_TIMING
-      { const char *nm[6] = {"staging/other", "heavy", "process", "push", "setup", "group"}; for (int k = 0; k < 6; k++) fprintf(stderr, "timing %-14s %8.3f Mcycles/wave-avg  %10llu entries\n", nm[k], (double)ss[4 + k] / 3584.0 / 1e6, ss[10 + k]); }
+      { const char *nm[6] = {"staging/other", "heavy", "process", "push", "setup", "expand"}; for (int k = 0; k < 6; k++) fprintf(stderr, "timing %-14s %8.3f Mcycles/wave-avg  %10llu entries\n", nm[k], (double)ss[4 + k] / 4096.0 / 1e6, ss[10 + k]); }
 #endif
       h->stats.bucket_lookups = (int64_t)ss[S_LOOKUPS]; h->stats.key_probes = (int64_t)ss[S_KEYPROBES]; h->stats.seed_tasks = (int64_t)ss[S_TASKS]; }
     h->stats.gap_tasks = ngaps; h->stats.hsps = nh; h->stats.rows = nrows; h->stats.reads_with_rows = with_rows; h->stats.classified = (int64_t)h->best.size();

@@ -27,6 +27,8 @@ struct McHostIndex {
     std::vector<McBucketRec> rec;      // first-residue group boundaries per bucket; empty when the index cannot use them
     std::vector<uint32_t> filt;        // Bloom filters over (bucket, key): 10-mers, then 9-mers
     std::vector<uint32_t> wild;        // wildcard filter over the 10-mers (mc_wild_*)
+    std::vector<unsigned long long> rt; // range table of the long first-residue groups (mc_rt_*)
+    uint32_t rt_mask;
     uint32_t max_bucket;
     uint32_t freq_thr;
     double letter_p[10];
@@ -234,6 +236,43 @@ inline bool mc_build_index(McHostIndex &X, const char *const *names, const char 
                 q[p1 >> 5] |= 1u << (p1 & 31); q[p2 >> 5] |= 1u << (p2 & 31);
             }
         }
+    // range table: every query key with a range inside a first-residue group of more than 8 postings, with the range
+    // mc_key_range returns for it
+    {
+        McIndex V; V.res = X.res.data(); V.off = X.off.data(); V.bstart = X.bstart.data(); V.post = X.post.data(); V.keys = X.keys.data(); V.rec = nullptr; V.nseq = X.nseq;
+        std::vector<unsigned long long> ent;
+        std::vector<uint32_t> cand;
+        for (int b = 0; b < MC_NBUCKET && !X.rec.empty(); b++) {
+            const McBucketRec &R = X.rec[b];
+            for (int g = 0; g < 11; g++) {
+                const uint32_t g0 = R.cum[g], g1 = R.cum[g + 1];
+                if (g1 - g0 <= 8) continue;
+                cand.clear();
+                for (uint32_t i = g0; i < g1; i++) {
+                    const uint32_t k = X.keys[R.start + i];
+                    if ((k & 0xF) != 0xF) cand.push_back(k);                  // 10-mer probe form
+                    if ((k & 0xF0) != 0xF0) cand.push_back(k | 0xFu);          // 9-mer probe form
+                }
+                std::sort(cand.begin(), cand.end());
+                cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+                for (uint32_t qk : cand) {
+                    McSeedCount sc{0, 0, 0};
+                    int nst = 0;
+                    const int cnt = mc_key_range(V, b, qk, &nst, &sc);
+                    if (cnt > 0) ent.push_back(mc_rt_pack((uint32_t)b, qk, (uint32_t)nst, (uint32_t)cnt));
+                }
+            }
+        }
+        uint32_t cap = 1024;
+        while (cap < 2 * ent.size() + 16) cap <<= 1;
+        X.rt.assign(cap, ~0ull);
+        X.rt_mask = cap - 1;
+        for (unsigned long long e : ent) {
+            uint32_t i = mc_rt_hash((uint32_t)(e >> 38), (uint32_t)((e >> 22) & 0xFFFF)) & X.rt_mask;
+            while (X.rt[i] != ~0ull) i = (i + 1) & X.rt_mask;
+            X.rt[i] = e;
+        }
+    }
     // .info: median of ALL bucket sizes, reduced-letter frequencies
     { std::vector<uint32_t> c(MC_NBUCKET); for (int b = 0; b < MC_NBUCKET; b++) c[b] = X.bstart[b + 1] - X.bstart[b]; std::nth_element(c.begin(), c.begin() + (MC_NBUCKET >> 1), c.end()); X.freq_thr = c[MC_NBUCKET >> 1]; }
     { int64_t valid = 0; for (int g = 0; g < 10; g++) valid += gcount[g]; for (int g = 0; g < 10; g++) X.letter_p[g] = (double)gcount[g] / (double)valid; }

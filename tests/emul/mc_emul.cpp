@@ -60,10 +60,10 @@ int main(int argc, char **argv)
         fclose(d);
     }
     if (getenv("MC_CHECK_SCAN")) {   // exhaustive: scan-based ranges == binary-search ranges for every key a query could match
-        McIndex Xc; Xc.res = H.res.data(); Xc.off = H.off.data(); Xc.bstart = H.bstart.data(); Xc.post = H.post.data(); Xc.keys = H.keys.data(); Xc.rec = H.rec.data(); Xc.filt = H.filt.data(); Xc.wild = H.wild.data(); Xc.nseq = H.nseq;
+        McIndex Xc; Xc.res = H.res.data(); Xc.off = H.off.data(); Xc.bstart = H.bstart.data(); Xc.post = H.post.data(); Xc.keys = H.keys.data(); Xc.rec = H.rec.data(); Xc.filt = H.filt.data(); Xc.wild = H.wild.data(); Xc.rt = H.rt.data(); Xc.rt_mask = H.rt_mask; Xc.nseq = H.nseq;
         if (H.rec.empty()) { fprintf(stderr, "scan check: the index has no bucket records\n"); return 3; }
         fprintf(stderr, "largest bucket: %u postings\n", H.max_bucket);
-        long checked = 0, bad = 0, fneg = 0, fpos = 0, fq = 0, f9q = 0, f9pos = 0, wq = 0, wpos = 0;
+        long checked = 0, bad = 0, fneg = 0, fpos = 0, fq = 0, f9q = 0, f9pos = 0, wq = 0, wpos = 0, rtq = 0, rtbad = 0;
         for (int b = 0; b < MC_NBUCKET; b++) {
             uint32_t n = H.bstart[b + 1] - H.bstart[b];
             for (uint32_t i = 0; i < n; i++) {
@@ -79,6 +79,16 @@ int main(int argc, char **argv)
                     int r1 = mc_key_range(Xc, b, qk, &n1, &s1), r2 = mc_key_range_rec(Xc.rec, Xc.keys, b, qk, &n2, &s2);
                     checked++;
                     if (r1 != r2 || (r1 > 0 && n1 != n2) || s1.keyprobes != s2.keyprobes || s1.lookups != s2.lookups) bad++;
+                    if (mc_klen(qk) >= 3 && (mc_klen(qk) == 4 || (qk & 0xF) == 0xF)) {   // probe forms: in a long group the range table answers
+                        const McBucketRec &RR = H.rec[b];
+                        const int k6 = (int)(qk >> 12);
+                        if ((int)RR.cum[k6 + 1] - (int)RR.cum[k6] > 8) {
+                            int n3 = 0;
+                            const int r3 = mc_rt_lookup(H.rt.data(), H.rt_mask, (uint32_t)b, qk, &n3);
+                            rtq++;
+                            if (r3 != r1 || (r1 > 0 && n3 != n1)) rtbad++;
+                        }
+                    }
                     if (mc_klen(qk) == 3 && (qk & 0xF) == 0xF) {              // exact 9-mer probe: its filter may not lose a range either
                         const uint32_t hh = mc_filter_hash((uint32_t)b, qk), bits = mc_filter_bits(hh);
                         const bool pass = (H.filt[mc_filter9_word(hh)] & bits) == bits;
@@ -109,12 +119,13 @@ int main(int argc, char **argv)
           fprintf(stderr, "filter check: %ld 10-mer and %ld 9-mer probes, %ld false negatives, %ld / %ld false positives among near misses, %.1f %% / %.1f %% of the bits set\n", fq, f9q, fneg, fpos, f9pos, 100.0 * (double)set / (32.0 * MC_FILT_WORDS), 100.0 * (double)set9 / (32.0 * MC_FILT9_WORDS));
           long setw = 0; for (uint32_t w : H.wild) setw += __builtin_popcount(w);
           fprintf(stderr, "wildcard filter: %ld questions, %ld positive among near misses, %.1f %% of the bits set\n", wq, wpos, 100.0 * (double)setw / (512.0 * MC_WILD_LINES)); }
-        return (bad || fneg) ? 3 : 0;
+        { size_t used = 0; for (unsigned long long e : H.rt) used += (e != ~0ull); fprintf(stderr, "range table: %zu entries in %zu slots; %ld probes into long groups checked, %ld differ from the binary searches\n", used, H.rt.size(), rtq, rtbad); }
+        return (bad || fneg || rtbad) ? 3 : 0;
     }
     int read_len = rs.empty() ? 0 : (int)rs[0].size();
     static McTables T;
     mc_fill_tables(T, H, read_len, getenv("MC_LOGE_THR") ? atof(getenv("MC_LOGE_THR")) : 1.0);
-    McIndex X; X.res = H.res.data(); X.off = H.off.data(); X.bstart = H.bstart.data(); X.post = H.post.data(); X.keys = H.keys.data(); X.rec = H.rec.empty() ? nullptr : H.rec.data(); X.filt = H.filt.data(); X.wild = H.wild.data(); X.nseq = H.nseq;
+    McIndex X; X.res = H.res.data(); X.off = H.off.data(); X.bstart = H.bstart.data(); X.post = H.post.data(); X.keys = H.keys.data(); X.rec = H.rec.empty() ? nullptr : H.rec.data(); X.filt = H.filt.data(); X.wild = H.wild.data(); X.rt = H.rt.data(); X.rt_mask = H.rt_mask; X.nseq = H.nseq;
     McClassPars P; memset(&P, 0, sizeof P); P.nfam = 1; P.read_len = read_len;
     std::vector<int32_t> fam(H.nseq, 0);
 
