@@ -328,6 +328,7 @@ __global__ void __launch_bounds__(256) k_enumerate(const McTables *__restrict__ 
 // Seed hits are appended with one atomic per wave.
 // ------------------------------------------------------------------------------------------------
 #define MC_EN_QCAP 128
+#define MC_EN_NCHUNK(L) ((((L) / 3 - 6) + 63) / 64 > 0 ? (((L) / 3 - 6) + 63) / 64 : 1)
 #define MC_EN_BLK 512u                      // task slots a wave reserves at a time (one global atomic per block, not per append)
 #define MC_TASK_NONE 0xFFFFFFFFu            // read id of the padding entries that close a partly used block
 struct McEnWave {
@@ -491,7 +492,9 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
     const int lane = mc_lane(), wv = threadIdx.x >> 6;
     McEnWave *W = waves + wv;
     const int FPs = (FP + 15) & ~15;
-    uint8_t *fr = fr_all + (size_t)wv * 6 * FPs;
+    const int nchunk = MC_EN_NCHUNK(L);                                    // chunks of 64 positions per frame
+    uint8_t *fr = fr_all + (size_t)wv * (6 * FPs + 6 * nchunk * 512);
+    unsigned long long *pre = (unsigned long long *)(fr + 6 * FPs);        // per (frame, chunk, lane): seed 20 | g6..g9 16 | valid 1 | bucket occupied 1
     if (threadIdx.x < 32) grp[threadIdx.x] = T->grp[threadIdx.x];
     if (lane == 0) { W->blk_base = 0; W->blk_used = MC_EN_BLK; }
     __syncthreads();
@@ -511,6 +514,36 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
             if (lane < 36) { ((uint32_t *)W->setter)[lane] = 0; ((uint32_t *)W->hit)[lane] = 0; }
             mc_wave_sync();
         }
+        // what both passes need of every position - the 6-mer's bucket, the four key residues, whether the bucket holds
+        // anything - is worked out once; the six bucket-bitmap gathers of a chunk are in flight together
+        for (int c = 0; c < nchunk; c++) {
+            uint32_t sdv[6], gkv[6], bw[6];
+            bool vd[6];
+#pragma unroll
+            for (int f = 0; f < 6; f++) {
+                const int qlen = (L - f % 3) / 3, pos = c * 64 + lane;
+                const uint8_t *q = fr + f * FPs;
+                uint32_t seed = 0, gk = 0;
+                bool ok = pos + 6 < qlen;
+                if (ok) {
+                    bool bad = false;
+                    for (int k = 0; k < 6; k++) { const uint32_t gg = grp[q[pos + k]]; bad |= (gg == MC_INVGRP); seed = seed * 10 + gg; }
+                    const int rest = qlen - pos - 6;
+                    const uint32_t g6 = rest >= 1 ? grp[q[pos + 6]] : MC_INVGRP, g7 = rest >= 2 ? grp[q[pos + 7]] : MC_INVGRP;
+                    const uint32_t g8 = rest >= 3 ? grp[q[pos + 8]] : MC_INVGRP, g9 = rest >= 4 ? grp[q[pos + 9]] : MC_INVGRP;
+                    gk = (g6 << 12) | (g7 << 8) | (g8 << 4) | g9;
+                    ok = !bad;
+                }
+                sdv[f] = ok ? seed : 0u; gkv[f] = gk; vd[f] = ok;
+            }
+#pragma unroll
+            for (int f = 0; f < 6; f++) bw[f] = bitmap[sdv[f] >> 5];
+#pragma unroll
+            for (int f = 0; f < 6; f++)
+                pre[(f * nchunk + c) * 64 + lane] = (unsigned long long)sdv[f] | ((unsigned long long)gkv[f] << 20) | ((unsigned long long)(vd[f] ? 1u : 0u) << 36) |
+                                                     ((unsigned long long)((bw[f] >> (sdv[f] & 31)) & 1u) << 37);
+        }
+        mc_wave_sync();
         // pass 0: the exact 9-mer of every position.  pass 1: its one-substitution 10-mers, four groups of ten probes
         // (groups 0..2 = offsets 4, 5, 3 of the 6-mer: neighbour buckets; group 3 = offset 6: same bucket, first key
         // residue substituted).  64 positions are set up at once.  With the counters off, filters decide what is searched:
@@ -625,18 +658,15 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                         if (p0 + 6 >= qlen) continue;
                     }
                     const int pos = p0 + lane;
-                    bool live = false, selfbucket = false;
-                    int seed = 0;
+                    bool live = false;
                     uint32_t qk = 0;
-                    if (pos + 6 < qlen) {
-                        bool bad = false;
-                        for (int k = 0; k < 6; k++) { int gg = grp[q[pos + k]]; bad |= (gg == MC_INVGRP); seed = seed * 10 + gg; }
-                        if (!bad) {
-                            selfbucket = (bitmap[seed >> 5] >> (seed & 31)) & 1;
+                    const unsigned long long pw = pre[(f * nchunk + (p0 >> 6)) * 64 + lane];
+                    const int seed = (int)(pw & 0xFFFFF);
+                    {
+                        if ((pw >> 36) & 1) {
+                            const bool selfbucket = (pw >> 37) & 1;
                             const int rest = qlen - pos - 6;
-                            const int g6 = rest >= 1 ? grp[q[pos + 6]] : MC_INVGRP;
-                            const int g7 = rest >= 2 ? grp[q[pos + 7]] : MC_INVGRP, g8 = rest >= 3 ? grp[q[pos + 8]] : MC_INVGRP;
-                            const int g9 = rest >= 4 ? grp[q[pos + 9]] : MC_INVGRP;
+                            const int g6 = (int)((pw >> 32) & 15), g7 = (int)((pw >> 28) & 15), g8 = (int)((pw >> 24) & 15), g9 = (int)((pw >> 20) & 15);
                             if (pass == 0) {
                                 if (COUNT) sc.lookups++;                         // bucket-size probe of the exact seed
                                 if (selfbucket && rest >= 3 && g6 != MC_INVGRP && g7 != MC_INVGRP) {
@@ -1246,7 +1276,7 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         HIPCK(hipEventRecord(h->ev[1], st));
         if (h->fast_enum) {
             const int FPs = (FP + 15) & ~15;
-            const size_t per_wave = sizeof(McEnWave) + (size_t)6 * FPs;
+            const size_t per_wave = sizeof(McEnWave) + (size_t)6 * FPs + (size_t)6 * MC_EN_NCHUNK(L) * 512;
             int waves = (int)((160 * 1024 - 64) / per_wave);                // waves per workgroup: as many as the LDS holds, at most 16
             waves = waves >= 16 ? 16 : waves >= 12 ? 12 : waves >= 8 ? 8 : 4;
             const size_t lds2 = 64 + waves * per_wave;
