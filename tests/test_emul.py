@@ -96,12 +96,32 @@ def test_index_builder_matches_prerapsearch(emul_bin, markers_faa, ref_dir, tmp_
     assert np.allclose(letter_p, ref_p, rtol=0, atol=1e-6)
 
 
-def test_scan_ranges_equal_binary_search(emul_bin, markers_faa, tmp_path):
-    """mc_key_range_scan (what k_enumerate_t0 uses) returns the same posting range, start index and even the same
-    reference key-probe count as the binary searches of ExtendSeq2Set, for every key a query could match (21 M probes)."""
+def test_gpu_index_structures_agree_with_the_binary_searches(emul_bin, markers_faa, tmp_path):
+    """Exhaustive check, over every key of the marker index and its near misses (25 M probes), of the structures the
+    seed kernel uses instead of the reference's per-bucket binary searches (ExtendSeq2Set):
+      * bucket records + group scan (mc_key_range_rec): same posting range, same start index, same reference key-probe count;
+      * 10-mer / 9-mer Bloom filters and the wildcard filter: no false negative (a probe with a range always passes);
+      * range table of the long groups: same range and start index as the binary searches."""
     fa = tmp_path / "one.fa"
     fa.write_text(">0\n" + "ACGT" * 25 + "\n")
     env = dict(os.environ, MC_CHECK_SCAN="1")
     r = subprocess.run([emul_bin, markers_faa, str(fa), str(tmp_path / "o.m8")], env=env, stderr=subprocess.PIPE)
-    assert r.returncode == 0, r.stderr.decode()
-    assert b" 0 mismatches" in r.stderr
+    err = r.stderr.decode()
+    assert r.returncode == 0, err
+    assert " 0 mismatches" in err
+    assert " 0 false negatives" in err
+    assert " 0 differ from the binary searches" in err
+
+
+def test_seg_variants_agree_frame_by_frame(emul_bin, markers_faa, tmp_path):
+    """The fixed-point / register SEG the kernel runs against the plain restatement, on every frame of the config-1 reads;
+    the emulation also proves the integer entropy tests over every possible window composition (mc_seg_fx_verify)."""
+    import gzip
+    fa = tmp_path / "c1.fa"
+    fa.write_bytes(gzip.open(os.path.join(GOLD, "config1_example_fq.reads.fa.gz")).read())
+    env = dict(os.environ, MC_CHECK_SEG="1")
+    r = subprocess.run([emul_bin, markers_faa, str(fa), str(tmp_path / "o.m8")], env=env, stderr=subprocess.PIPE)
+    err = r.stderr.decode()
+    assert r.returncode == 0, err
+    assert "0 disagreements over all window compositions" in err
+    assert ", 0 differ from the plain restatement" in err
