@@ -722,13 +722,14 @@ MC_HD uint32_t mc_wild_bits(uint32_t ctx, uint32_t seed, uint32_t key, int g)
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15;
     return (x & 127u) | (((x >> 7) & 127u) << 8);
 }
-MC_HD bool mc_wild_test(const uint32_t q[4], uint32_t bits)
-{
+MC_HD bool mc_wild_test4(uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t bits)
+{ // two bits of the 128-bit quarter x|y|z|w; written with 64-bit shifts so that no indexed (scratch) array appears
     const uint32_t p1 = bits & 127u, p2 = bits >> 8;
-    const uint32_t w1 = (p1 < 64) ? ((p1 < 32) ? q[0] : q[1]) : ((p1 < 96) ? q[2] : q[3]);
-    const uint32_t w2 = (p2 < 64) ? ((p2 < 32) ? q[0] : q[1]) : ((p2 < 96) ? q[2] : q[3]);
-    return ((w1 >> (p1 & 31)) & (w2 >> (p2 & 31)) & 1u) != 0;
+    const unsigned long long lo = (unsigned long long)x | ((unsigned long long)y << 32), hi = (unsigned long long)z | ((unsigned long long)w << 32);
+    const unsigned long long s1 = (p1 < 64) ? lo : hi, s2 = (p2 < 64) ? lo : hi;
+    return (((s1 >> (p1 & 63)) & (s2 >> (p2 & 63))) & 1ull) != 0;
 }
+MC_HD bool mc_wild_test(const uint32_t q[4], uint32_t bits) { return mc_wild_test4(q[0], q[1], q[2], q[3], bits); }
 
 // ---- range table: the answer for probes into long groups -----------------------------------------------------------
 // A probe whose first-residue group holds more than 8 keys needs the reference's two binary searches: ~20 dependent

@@ -716,10 +716,9 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                         const uint32_t ctx = mc_wild_ctx((uint32_t)seed, qk);
                         const uint4 *ln = (const uint4 *)X.wild + (size_t)(live ? mc_wild_line(ctx) : 0u) * 4;
                         const uint4 q0 = ln[0], q1 = ln[1], q2 = ln[2], q3 = ln[3];
-                        const uint32_t a0[4] = {q0.x, q0.y, q0.z, q0.w}, a1[4] = {q1.x, q1.y, q1.z, q1.w}, a2[4] = {q2.x, q2.y, q2.z, q2.w}, a3[4] = {q3.x, q3.y, q3.z, q3.w};
                         if (live) {
-                            wm = (mc_wild_test(a0, mc_wild_bits(ctx, (uint32_t)seed, qk, 0)) ? 1u : 0u) | (mc_wild_test(a1, mc_wild_bits(ctx, (uint32_t)seed, qk, 1)) ? 2u : 0u) |
-                                 (mc_wild_test(a2, mc_wild_bits(ctx, (uint32_t)seed, qk, 2)) ? 4u : 0u) | (mc_wild_test(a3, mc_wild_bits(ctx, (uint32_t)seed, qk, 3)) ? 8u : 0u);
+                            wm = (mc_wild_test4(q0.x, q0.y, q0.z, q0.w, mc_wild_bits(ctx, (uint32_t)seed, qk, 0)) ? 1u : 0u) | (mc_wild_test4(q1.x, q1.y, q1.z, q1.w, mc_wild_bits(ctx, (uint32_t)seed, qk, 1)) ? 2u : 0u) |
+                                 (mc_wild_test4(q2.x, q2.y, q2.z, q2.w, mc_wild_bits(ctx, (uint32_t)seed, qk, 2)) ? 4u : 0u) | (mc_wild_test4(q3.x, q3.y, q3.z, q3.w, mc_wild_bits(ctx, (uint32_t)seed, qk, 3)) ? 8u : 0u);
                         }
                     }
                 }
