@@ -95,6 +95,28 @@ def profiled_traffic(kernel, n_batch):
         return None
 
 
+def ags_abs_error(device):
+    """The metric's second half: |AGS(GPU pipeline) - AGS(reference)| on the reference's own inputs, through run_pipeline
+    (native sampler -> HIP search -> classification -> estimate).  The reference values are the committed goldens produced by
+    running the reference here (tests/golden/*.json); nothing of /root/reference is read."""
+    import contextlib
+    import io
+    from microbecensus_amd import microbe_census as mc
+    out = {}
+    for case, seqfile, extra in (("config1_example_fq", "example.fq.gz", {"nreads": 10000, "read_length": 100}), ("unittest_metagenome", "metagenome.fa.gz", {})):
+        gold = os.path.join(REPO, "tests", "golden", case + ".json")
+        inp = os.path.join(REPO, "tests", "golden", "inputs", seqfile)
+        if not (os.path.exists(gold) and os.path.exists(inp)):
+            continue
+        want = json.load(open(gold))["est_ags"]
+        args = {"seqfiles": [inp], "device": device}
+        args.update(extra)
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = mc.run_pipeline(args)
+        out[case] = None if res is None else abs(res[0] - want)
+    return out
+
+
 def cpu_baseline(sample_reads, read_len, eng_rows):
     """Times the reference's own engine on the host cores on a bounded sample of the bench reads."""
     import numpy as np
@@ -136,6 +158,7 @@ def main():
     ap.add_argument("--resident-batches", type=int, default=4)
     ap.add_argument("--cpu-sample", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ags-check", action="store_true", help="skip the run_pipeline AGS comparison on the reference's own inputs")
     ap.add_argument("--count-in-timed-steps", action="store_true", help="keep the seed kernel's traffic counters on in the timed steps")
     args = ap.parse_args()
 
@@ -249,6 +272,8 @@ def main():
             eng.upload(sample); eng.run(0)
             rows, _ = eng.results()
             out["cpu_baseline"] = cpu_baseline(sample, L, rows)
+        if world == 1 and not args.no_ags_check:
+            out["config"]["ags_abs_error_vs_reference"] = ags_abs_error(local)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rm -rf /tmp/kt && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --batch 1000000 --resident-batches 2 --no-cpu-baseline > /tmp/kt.log 2>&1
+rm -rf /tmp/kt && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --batch 1000000 --resident-batches 2 --no-cpu-baseline --no-ags-check > /tmp/kt.log 2>&1
 python3 - <<'PY'
 import csv,glob
 for f in glob.glob('/tmp/kt/**/*kernel_stats.csv', recursive=True):
