@@ -506,9 +506,6 @@ MC_HDN void mc_seg_mask_fx(const double *lnfac /* McTables::lnfac */, const int3
                 }
             }
             if (!anylo) continue;
-#ifdef MC_EXP_NOTRIM
-            continue;
-#endif
         }
         int last = m - 1, lowlim = 0;
         for (int i = 0; i <= last; i++) {

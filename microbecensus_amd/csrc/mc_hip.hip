@@ -248,9 +248,7 @@ __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restric
     __syncthreads();                                             // the staged reads are dead: their space becomes the SEG queues
     {
         McSegWS ws; ws.comp = prot + FP; ws.sv = prot + FP + 20; ws.stk = (int16_t *)(prot + FP + 44);
-#ifndef MC_EXP_NOSEG
         mc_seg_wave(lnf, fxs, prot, n, lr < nr, ws, (McSegWaveLds *)smem + (tid >> 6), smem, mc_lane());
-#endif
         if (lr < nr) for (int i = n; i < FP; i++) prot[i] = MC_INV;
     }
     __syncthreads();
@@ -352,9 +350,6 @@ __device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long
     if (m == 0) return 0;
     const int pos = (int)((item >> 36) & 0xFF), frame = (int)((item >> 44) & 7), phase = (int)((item >> 47) & 63);
     if (phase == 0 && cnt > 0) atomicOr(&W->hit[frame][pos >> 5], 1u << (pos & 31));
-#ifdef MC_EXP_NORESERVE
-    return (uint32_t)cnt;
-#endif
     // total over the (few) lanes that found something
     uint32_t total = 0;
     while (m) {
@@ -382,9 +377,6 @@ __device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long
         if (lane == 0) { W->blk_base = bb; W->blk_used = bu + total; }
         mc_wave_sync();
     }
-#ifdef MC_EXP_NOAPPEND
-    return (uint32_t)cnt;
-#endif
     // the ranges are written by the whole wave, one range after the other: a conserved 10-mer occurs in hundreds of
     // homologous markers, and a lane that wrote its own range alone would keep the other 63 waiting
     {
@@ -421,9 +413,6 @@ __device__ __forceinline__ unsigned long long mc_en_process(const McIndex &X, un
     uint32_t start = 0, kp = 0;
     int c0 = 0;
     bool heavy = false;
-#ifdef MC_EXP_NOPROC1
-    if (((item >> 47) & 63) != 0) active = false;
-#endif
     if (active) {
         const int bucket = (int)(item & 0xFFFFF);
         const uint32_t qk = (uint32_t)((item >> 20) & 0xFFFF);
@@ -458,9 +447,6 @@ __device__ __forceinline__ unsigned long long mc_en_heavy(const McIndex &X, unsi
 {
     int cnt = 0, lb = 0, c0 = 0;
     uint32_t start = 0, kp = 0;
-#ifdef MC_EXP_NOHEAVYPROC
-    active = false;
-#endif
     if (active) {
         const int bucket = (int)(item & 0xFFFFF);
         const uint32_t qk = (uint32_t)((item >> 20) & 0xFFFF);
@@ -553,11 +539,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
         //                   the 10-mer Bloom filter -> queue q
         //   q            -> range search on the bucket records (long groups via queue hq to the binary searches) -> seed hits
         // Every stage runs with full waves; the generator is a state machine so that each stage exists once in the kernel.
-#ifdef MC_EXP_PASS0ONLY
-        for (int pass = 0; pass < 1; pass++) {
-#else
         for (int pass = 0; pass < 2; pass++) {
-#endif
             int f = -1, p0 = 0, qlen = 0;
             bool more = true;
             uint32_t wm = 0;                             // groups of this lane's position that still have to enter eq
@@ -837,21 +819,13 @@ __global__ void __launch_bounds__(128) k_gapped(const McTables *__restrict__ T, 
         int alnlen = g.qfwd + g.L + g.qbwd, gapopens = 0, gaptotal = 0;
         int qend = qfwd + g.qp + g.L, dend = dfwd + g.dp + g.L, dright = dlen - dend, qright = qlen - qend;
         bool over = false;
-#ifdef MC_EXP_NODP
-        if (dright > 2000 && qright > 2) {
-#else
         if (dright > 2 && qright > 2) {
-#endif
             McGapResult R = mc_align_gapped(hot, q + qend, 1, d + dend, 1, qright, dright, C, cap);
             over = R.overflow != 0;
             if (R.gain > 0) { score += R.gain; nmatch += R.ident; qfwd += R.c1; dfwd += R.c2; alnlen += R.steps; gapopens += R.runs; gaptotal += R.gapcols; }
         }
         int dleft = g.dp - dbwd, qleft = g.qp - qbwd;
-#ifdef MC_EXP_NODP
-        if (dleft > 2000 && qleft > 2) {
-#else
         if (!over && dleft > 2 && qleft > 2) {
-#endif
             McGapResult R = mc_align_gapped(hot, q + qleft - 1, -1, d + dleft - 1, -1, qleft, dleft, C, cap);
             over = R.overflow != 0;
             if (R.gain > 0) { score += R.gain; nmatch += R.ident; qbwd += R.c1; dbwd += R.c2; alnlen += R.steps; gapopens += R.runs; gaptotal += R.gapcols; }
