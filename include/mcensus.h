@@ -102,6 +102,8 @@ typedef struct mc_reader mc_reader;
 typedef struct mc_reader_stats {
     int64_t sampled, too_short, low_qual, dups;   /* the four counts process_seqfile prints (:362-366) */
     int64_t records;                              /* records parsed before the sampler stopped */
+    int64_t bases;                                /* their total sequence length ... */
+    int64_t exhausted;                            /* ... which is count_bases() (:573-584) when every file was read to its end (1) */
 } mc_reader_stats;
 
 const char *mc_reader_last_error(void);

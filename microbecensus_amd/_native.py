@@ -30,7 +30,7 @@ class McStats(C.Structure):
 
 
 class McReaderStats(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in ("sampled", "too_short", "low_qual", "dups", "records")]
+    _fields_ = [(n, C.c_int64) for n in ("sampled", "too_short", "low_qual", "dups", "records", "bases", "exhausted")]
 
 
 ROW_DTYPE = np.dtype([("query", "<i4"), ("subject", "<i4"), ("ident", "<f8"), ("alnlen", "<i4"), ("mismatch", "<i4"),

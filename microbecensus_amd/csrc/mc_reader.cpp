@@ -211,6 +211,7 @@ extern "C" int64_t mc_reader_run(mc_reader *r)
         if (!ps.src.open(path.c_str())) { r_err = "cannot open " + path; rcode = -1; break; }
         while (ps.next(rec)) {
             r->st.records++;
+            r->st.bases += (int64_t)rec.seq.size();
             if (rec.seq.size() < L) { r->st.too_short++; continue; }
             if (r->filter_dups) {
                 if (seen.count(rec.seq)) { r->st.dups++; continue; }
@@ -246,6 +247,7 @@ extern "C" int64_t mc_reader_run(mc_reader *r)
     }
     if (out) fclose(out);
     if (rcode < 0) return rcode;
+    r->st.exhausted = (kept < r->nreads) ? 1 : 0;             // every file was read to its end: bases is count_bases()
     r->st.sampled = kept;
     return kept;
 }

@@ -38,7 +38,8 @@ __version__ = "1.1.0"
 VALID_READ_LENGTHS = [50, 60, 70, 80, 90, 100, 110, 120, 130, 140, 150, 175, 200, 225, 250, 300, 350, 400, 450, 500]
 
 _engines = {}       # device -> Engine
-_run_cache = {}     # tempfile -> dict(reads=ndarray | None, best=ndarray | None, families=[...])
+_run_cache = {}          # tempfile -> dict(reads=ndarray | None, best=ndarray | None, families=[...])
+_bases_cache = {}        # seqfiles -> total bases, when the sampler happened to read every record
 
 
 # ----------------------------------------------------------------------------------------------
@@ -321,6 +322,8 @@ def process_seqfile(args, paths):
             raise Exception(str(e))
     else:
         reads, st = _process_seqfile_py(args, paths)
+    if st.get("exhausted"):                        # the sampler saw every record: count_bases() need not read the files again
+        _bases_cache[tuple(args["seqfiles"])] = st["bases"]
     if st["sampled"] == 0:
         clean_up(paths)
         sys.exit("\nError! No reads remaining after filtering!")
@@ -514,6 +517,9 @@ def read_seqfile(infile):
 def count_bases(args):
     if args["verbose"]:
         print("Computing number of genome equivalents...")
+    cached = _bases_cache.pop(tuple(args["seqfiles"]), None)
+    if cached is not None:
+        return cached
     if _native_reader_usable(args):
         from . import _native
         try:

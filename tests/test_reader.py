@@ -94,3 +94,20 @@ def test_reader_golden_inputs_of_the_reference():
     assert _native.count_bases([os.path.join(GOLD, "inputs", "example.fq.gz")]) == 980306
     reads, st = _native.sample_reads([os.path.join(GOLD, "inputs", "metagenome.fa.gz")], 100, 1000000, False, 0, -5, -5, 100, False)
     assert st["sampled"] == 70623
+
+
+def test_count_bases_comes_from_the_sampler_pass_when_it_saw_everything(tmp_path, monkeypatch):
+    """process_seqfile that reads every record leaves count_bases() its answer (no second pass over the files); a sampler
+    stopped by nreads does not."""
+    from microbecensus_amd import _native, microbe_census as mc
+    case = [c for c in CASES if c["case"] == "fa_default"][0]
+    args = _prepare(mc, case)
+    mc.process_seqfile(args, {"tempfile": str(tmp_path / "a.fa")})
+    monkeypatch.setattr(_native, "count_bases", lambda paths: (_ for _ in ()).throw(AssertionError("second pass")))
+    assert mc.count_bases(args) == case["count_bases"]
+    monkeypatch.undo()
+    case = [c for c in CASES if c["case"] == "fa_n10"][0]
+    args = _prepare(mc, case)
+    mc.process_seqfile(args, {"tempfile": str(tmp_path / "b.fa")})
+    assert tuple(args["seqfiles"]) not in mc._bases_cache
+    assert mc.count_bases(args) == case["count_bases"]
