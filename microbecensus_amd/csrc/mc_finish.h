@@ -222,6 +222,7 @@ MC_HDN int mc_finish_group(const McTables &T, const McIndex &X, const McHsp *in,
 // one m8 row (PrintRes) from an HSP; the frame slot carries nmatch for the classifier
 MC_HD void mc_fill_row(const McTables &T, int read_id, const McHsp &h, McRow &r)
 {
+    { uint32_t *z = (uint32_t *)&r; for (unsigned i = 0; i < sizeof(McRow) / 4; i++) z[i] = 0; }   // padding bytes too: the rows are handed out as raw memory
     r.query = read_id; r.subject = h.sidx; r.ident = (double)h.nmatch * 100.0 / (double)h.alnlen;
     r.alnlen = h.alnlen; r.mismatch = h.mism; r.gapopen = h.gaps; r.qstart = h.qnts; r.qend = h.qnte; r.sstart = h.ds; r.send = h.de;
     r.loge = h.loge; r.bits = T.bits_r[h.score]; r.score = h.score; r.frame = h.nmatch;
