@@ -546,7 +546,6 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
             unsigned long long wbase = 0;                // seed | key | position | frame of this lane's position
             uint32_t pm = 0;                             // surviving probes of this lane's expanded pair ...
             unsigned long long xi = 0;                   // ... and the pair itself
-            const uint8_t *q = fr;
             for (;;) {
                 const bool pmz = __ballot(pm != 0) == 0, wmz = __ballot(wm != 0) == 0;
                 const bool tail = !more && wmz && en == 0 && pmz;            // nothing more will enter q
@@ -636,7 +635,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                     if (f < 0 || p0 + 6 >= qlen) {
                         f++; p0 = 0;
                         if (f == 6) { more = false; continue; }
-                        qlen = (L - f % 3) / 3; q = fr + f * FPs;
+                        qlen = (L - f % 3) / 3;
                         if (p0 + 6 >= qlen) continue;
                     }
                     const int pos = p0 + lane;
@@ -878,6 +877,21 @@ __global__ void k_heads(const uint32_t *__restrict__ flags, const uint32_t *__re
 #define MC_FH_MAXN 2048   // ... up to this many in the standard form (45 KB of LDS per wave, three waves per CU)
 #define MC_FH_BIGN 6144   // ... up to this many in the large form (132 KB, one wave per CU); beyond, back to the single thread
 
+// The reads that get a wave of their own (k_finish_heavy), collected before the finishing kernels start so that the three of
+// them can run side by side on separate streams.  A read without a marked HSP prints nothing whatever its size.
+__global__ void k_heavy_lists(const uint32_t *__restrict__ heads, uint32_t nheads, uint32_t nhsps, const uint8_t *__restrict__ mark, uint32_t *nrow_of,
+                              uint32_t *counters, uint32_t *heavy, uint32_t *heavy2)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nheads) return;
+    const uint32_t a = heads[s], b = (s + 1 < nheads) ? heads[s + 1] : nhsps, n = b - a;
+    if (n <= MC_FH_MIN || n > MC_FH_BIGN) return;
+    uint32_t any = 0;
+    for (uint32_t k = a; k < b; k++) any |= mark[k];
+    if (!any) { nrow_of[s] = 0; return; }
+    if (n <= MC_FH_MAXN) heavy[atomicAdd(&counters[C_HEAVY], 1u)] = s; else heavy2[atomicAdd(&counters[C_HEAVY2], 1u)] = s;
+}
+
 // One thread per read that has HSPs, in ascending read order.  All scratch is addressed by the read's offset into the
 // sorted HSP array (a read never produces more rows than it has HSPs): v = the stacks, tmp = 2 HSP slots per HSP for the
 // sum statistics, reused afterwards for the read's rows and their merge keys (64 + 8 bytes per row <= 96).  The rows
@@ -885,7 +899,7 @@ __global__ void k_heads(const uint32_t *__restrict__ flags, const uint32_t *__re
 __global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
                                                 const McHsp *__restrict__ sorted, uint32_t nhsps, const uint32_t *__restrict__ heads, uint32_t nheads,
                                                 const uint8_t *__restrict__ mark, McHsp *v, McHsp *tmp, int64_t first_read_id, uint32_t *nrow_of, McBestHit *best,
-                                                uint32_t *counters, uint32_t *heavy, uint32_t *heavy2, int fh_min)
+                                                uint32_t *counters)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nheads) return;
@@ -897,8 +911,7 @@ __global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, 
         for (uint32_t k = a; k < b; k++) any |= mark[k];
         if (!any) { nrow_of[s] = 0; return; }
     }
-    if (n > fh_min && n <= MC_FH_MAXN) { heavy[atomicAdd(&counters[C_HEAVY], 1u)] = s; return; }
-    if (n > MC_FH_MAXN && n <= MC_FH_BIGN) { heavy2[atomicAdd(&counters[C_HEAVY2], 1u)] = s; return; }   // a read with many HSPs gets a wave of its own
+    if (n > MC_FH_MIN && n <= MC_FH_BIGN) return;                 // k_heavy_lists handed this read to a wave (k_finish_heavy)
     const uint32_t read = sorted[a].read;
     McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
     double *myk = (double *)(myrows + n);
@@ -1030,8 +1043,8 @@ struct mc_handle {
     McHostIndex H;
     std::vector<int32_t> fam;
     int nfam = 0, device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
+    hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;
+    hipEvent_t ev[8] = {}, ev_fork = nullptr, ev_join2 = nullptr, ev_join3 = nullptr;
     // device index + tables
     uint8_t *d_res = nullptr; uint32_t *d_off = nullptr, *d_bstart = nullptr, *d_post = nullptr; uint16_t *d_keys = nullptr; int32_t *d_fam = nullptr;
     McTables *d_T = nullptr; McClassPars *d_P = nullptr;
@@ -1091,7 +1104,8 @@ extern "C" void mc_close(mc_handle *h)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->pin_rows) (void)hipHostFree(h->pin_rows);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    for (hipEvent_t e : {h->ev_fork, h->ev_join2, h->ev_join3}) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t q : {h->stream, h->stream2, h->stream3}) if (q) (void)hipStreamDestroy(q);
     delete h;
 }
 
@@ -1107,8 +1121,9 @@ static int open_impl(mc_handle *h, const char *const *names, const char *const *
     h->fam.assign(marker_family, marker_family + nseq);
     h->nfam = nfam; h->device = device;
     HIPCK(hipSetDevice(device));
-    HIPCK(hipStreamCreate(&h->stream));
+    HIPCK(hipStreamCreate(&h->stream)); HIPCK(hipStreamCreate(&h->stream2)); HIPCK(hipStreamCreate(&h->stream3));
     for (auto &e : h->ev) HIPCK(hipEventCreate(&e));
+    HIPCK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); HIPCK(hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming)); HIPCK(hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming));
     const McHostIndex &H = h->H;
     if (dalloc(&h->d_res, H.res.size() + 64) || dalloc(&h->d_off, H.off.size()) || dalloc(&h->d_bstart, H.bstart.size()) || dalloc(&h->d_post, H.post.size() + 1) ||
         dalloc(&h->d_keys, H.keys.size()) || dalloc(&h->d_fam, (size_t)nseq) || dalloc(&h->d_T, 1) || dalloc(&h->d_P, 1) || dalloc(&h->d_counters, C_N) || dalloc(&h->d_stats, S_N)) return -1;
@@ -1311,18 +1326,27 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
         nheads = c[C_HEADS];
-        k_finish<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_mark, h->d_v, h->d_tmp,
-                                                                    first_read_id, h->d_nrow, h->d_best, h->d_counters, h->d_retry, h->d_retry + h->cap_gaps / 2, MC_FH_MIN);
-        // the reads k_finish set aside (d_retry is free again: the gap tasks are done)
+        // finishing: the single-thread kernel and the two wave-per-read kernels are independent - three streams
+        uint32_t *d_heavy = h->d_retry, *d_heavy2 = h->d_retry + h->cap_gaps / 2;      // (d_retry is free again: the gap tasks are done)
+        k_heavy_lists<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_heads, nheads, nh, h->d_mark, h->d_nrow, h->d_counters, d_heavy, d_heavy2);
+        HIPCK(hipEventRecord(h->ev_fork, st));
         {
             const size_t l1 = (size_t)MC_FH_MAXN * 16 + 3 * (size_t)(MC_FH_MAXN + 2) * 2, l2 = (size_t)MC_FH_BIGN * 16 + 3 * (size_t)(MC_FH_BIGN + 2) * 2;
             HIPCK(hipFuncSetAttribute((const void *)k_finish_heavy<MC_FH_MAXN, C_HEAVY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1));
             HIPCK(hipFuncSetAttribute((const void *)k_finish_heavy<MC_FH_BIGN, C_HEAVY2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));
-            k_finish_heavy<MC_FH_BIGN, C_HEAVY2><<<dim3(256), dim3(64), l2, st>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp, first_read_id, h->d_nrow,
-                                                                                   h->d_best, h->d_counters, h->d_retry + h->cap_gaps / 2);
-            k_finish_heavy<MC_FH_MAXN, C_HEAVY><<<dim3(2048), dim3(64), l1, st>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp, first_read_id, h->d_nrow,
-                                                                                  h->d_best, h->d_counters, h->d_retry);
+            HIPCK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+            k_finish_heavy<MC_FH_BIGN, C_HEAVY2><<<dim3(256), dim3(64), l2, h->stream2>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp, first_read_id,
+                                                                                           h->d_nrow, h->d_best, h->d_counters, d_heavy2);
+            HIPCK(hipEventRecord(h->ev_join2, h->stream2));
+            HIPCK(hipStreamWaitEvent(h->stream3, h->ev_fork, 0));
+            k_finish_heavy<MC_FH_MAXN, C_HEAVY><<<dim3(2048), dim3(64), l1, h->stream3>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp, first_read_id,
+                                                                                           h->d_nrow, h->d_best, h->d_counters, d_heavy);
+            HIPCK(hipEventRecord(h->ev_join3, h->stream3));
         }
+        k_finish<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_mark, h->d_v, h->d_tmp,
+                                                                    first_read_id, h->d_nrow, h->d_best, h->d_counters);
+        HIPCK(hipStreamWaitEvent(st, h->ev_join2, 0));
+        HIPCK(hipStreamWaitEvent(st, h->ev_join3, 0));
         bytes = h->sorttmp_bytes;
         HIPCK(rocprim::exclusive_scan(h->d_sorttmp, bytes, h->d_nrow, h->d_rowoff, 0u, (size_t)nheads, rocprim::plus<uint32_t>(), st));
         k_emit_rows<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_heads, nheads, h->d_nrow, h->d_rowoff, h->d_tmp, h->d_rows, h->cap_rows, h->d_counters);
