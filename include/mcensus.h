@@ -51,6 +51,16 @@ mc_handle *mc_open(const char *const *names, const char *const *seqs, int32_t ns
                    const int32_t *marker_family, int32_t nfam, int32_t device);
 void mc_close(mc_handle *h);
 
+/* The same from a database `prerapsearch` already wrote (the reference ships one as data/rapdb_2.15): residues, buckets,
+ * posting order and suffix keys are taken from the file, the GPU-side structures derived from them.  All markers start in
+ * family 0 of 1; name them with mc_marker_name() and assign the families with mc_set_families() (gene_fam.map), then
+ * mc_set_run().  mc_rapdb_verify() needs no GPU: 0 if the file holds exactly the index mc_open() builds from the sequences. */
+mc_handle *mc_open_rapdb(const char *rapdb_path, int32_t device);
+int32_t mc_marker_count(const mc_handle *h);
+const char *mc_marker_name(const mc_handle *h, int32_t i);
+int mc_set_families(mc_handle *h, const int32_t *marker_family, int32_t nfam);
+int mc_rapdb_verify(const char *rapdb_path, const char *const *names, const char *const *seqs, int32_t nseq);
+
 /* Host views of the index, for cross-checking against a prerapsearch-built database (tests only). */
 int mc_index_view(const mc_handle *h, const uint8_t **res_codes, const uint32_t **offsets, const uint32_t **bucket_starts,
                   const uint32_t **postings, const uint16_t **keys, int64_t *nres, int64_t *npostings,

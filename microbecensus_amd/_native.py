@@ -55,6 +55,14 @@ def load_library():
     lib.mc_open.restype = C.c_void_p
     lib.mc_open.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32]
     lib.mc_close.argtypes = [C.c_void_p]
+    lib.mc_open_rapdb.restype = C.c_void_p
+    lib.mc_open_rapdb.argtypes = [C.c_char_p, C.c_int32]
+    lib.mc_marker_count.restype = C.c_int32
+    lib.mc_marker_count.argtypes = [C.c_void_p]
+    lib.mc_marker_name.restype = C.c_char_p
+    lib.mc_marker_name.argtypes = [C.c_void_p, C.c_int32]
+    lib.mc_set_families.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]
+    lib.mc_rapdb_verify.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int32]
     lib.mc_index_view.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 5 + [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     lib.mc_set_run.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.mc_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
@@ -84,7 +92,7 @@ def load_library():
     return lib
 
 
-EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_index_view", "mc_set_run", "mc_search",
+EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_index_view", "mc_set_run", "mc_search",
                     "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8",
                     "mc_reader_last_error", "mc_reader_open", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_count_bases"]
 
@@ -124,6 +132,13 @@ def count_bases(paths):
     if n < 0:
         raise RuntimeError(lib.mc_reader_last_error().decode())
     return n
+
+
+def rapdb_verify(rapdb_path, names, seqs):
+    """0 when the prerapsearch database holds exactly the index mc_open() builds from (names, seqs).  No GPU involved."""
+    lib = load_library()
+    n = len(names)
+    return lib.mc_rapdb_verify(rapdb_path.encode(), (C.c_char_p * n)(*[s.encode() for s in names]), (C.c_char_p * n)(*[s.encode() for s in seqs]), n)
 
 
 def load_markers(path=None):
@@ -167,6 +182,31 @@ class Engine:
         if not self.h:
             raise RuntimeError("mc_open failed: %s" % lib.mc_last_error().decode())
         self.read_len = None
+
+    @classmethod
+    def from_rapdb(cls, rapdb_path, device=0, family_of=None, families=None):
+        """Engine on a database written by prerapsearch (e.g. the reference's data/rapdb_2.15).  family_of: marker name ->
+        family name (gene_fam.map); default: the packaged model's."""
+        lib = load_library()
+        self = cls.__new__(cls)
+        self.lib = lib
+        self.h = lib.mc_open_rapdb(rapdb_path.encode(), device)
+        if not self.h:
+            raise RuntimeError("mc_open_rapdb failed: %s" % lib.mc_last_error().decode())
+        n = lib.mc_marker_count(self.h)
+        self.names = [lib.mc_marker_name(self.h, i).decode() for i in range(n)]
+        if family_of is None:
+            model = load_model()
+            pk_names, _ = load_markers()
+            families = model["families"]
+            fam_idx = dict(zip(pk_names, model["marker_family"]))
+            fam = [fam_idx[nm] for nm in self.names]
+        else:
+            fam = [families.index(family_of[nm]) for nm in self.names]
+        self.nfam = len(families)
+        self._check(lib.mc_set_families(self.h, (C.c_int32 * n)(*fam), self.nfam), "mc_set_families")
+        self.read_len = None
+        return self
 
     def _check(self, rc, what):
         if rc != 0:

@@ -1109,16 +1109,16 @@ extern "C" void mc_close(mc_handle *h)
     delete h;
 }
 
-static int open_impl(mc_handle *h, const char *const *names, const char *const *seqs, int32_t nseq, const int32_t *marker_family, int32_t nfam, int32_t device)
+// h->H holds the host index (built from FASTA or loaded from a rapdb): everything device side
+static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, int32_t device)
 {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device available: libmcensus_hip has no CPU fallback"; return -1; }
     if (device < 0 || device >= ndev) { g_err = "device index out of range"; return -1; }
     if (nfam > 32) { g_err = "at most 32 gene families are supported"; return -1; }
-    std::string err;
-    if (!mc_build_index(h->H, names, seqs, nseq, err)) { g_err = err; return -1; }
+    const int nseq = h->H.nseq;
     for (int s = 0; s < nseq; s++) if ((int)(h->H.off[s + 1] - h->H.off[s]) > MC_GAP_W - 8) { g_err = "marker longer than the gapped-extension workspace"; return -1; }
-    h->fam.assign(marker_family, marker_family + nseq);
+    if (marker_family) h->fam.assign(marker_family, marker_family + nseq); else h->fam.assign((size_t)nseq, 0);
     h->nfam = nfam; h->device = device;
     HIPCK(hipSetDevice(device));
     HIPCK(hipStreamCreate(&h->stream)); HIPCK(hipStreamCreate(&h->stream2)); HIPCK(hipStreamCreate(&h->stream3));
@@ -1154,8 +1154,51 @@ static int open_impl(mc_handle *h, const char *const *names, const char *const *
 extern "C" mc_handle *mc_open(const char *const *names, const char *const *seqs, int32_t nseq, const int32_t *marker_family, int32_t nfam, int32_t device)
 {
     mc_handle *h = new mc_handle();
-    if (open_impl(h, names, seqs, nseq, marker_family, nfam, device) != 0) { std::string e = g_err; mc_close(h); g_err = e; return nullptr; }
+    std::string err;
+    if (!mc_build_index(h->H, names, seqs, nseq, err)) { delete h; g_err = err; return nullptr; }
+    if (open_impl(h, marker_family, nfam, device) != 0) { std::string e = g_err; mc_close(h); g_err = e; return nullptr; }
     return h;
+}
+
+extern "C" mc_handle *mc_open_rapdb(const char *rapdb_path, int32_t device)
+{
+    mc_handle *h = new mc_handle();
+    std::string err;
+    if (!mc_load_rapdb(h->H, rapdb_path, err)) { delete h; g_err = err; return nullptr; }
+    if (open_impl(h, nullptr, 1, device) != 0) { std::string e = g_err; mc_close(h); g_err = e; return nullptr; }
+    return h;
+}
+
+extern "C" int32_t mc_marker_count(const mc_handle *h) { return h ? h->H.nseq : -1; }
+extern "C" const char *mc_marker_name(const mc_handle *h, int32_t i) { return (h && i >= 0 && i < h->H.nseq) ? h->H.names[(size_t)i].c_str() : nullptr; }
+
+extern "C" int mc_set_families(mc_handle *h, const int32_t *marker_family, int32_t nfam)
+{
+    if (!h || !marker_family) { g_err = "null argument"; return -1; }
+    if (nfam < 1 || nfam > 32) { g_err = "1..32 gene families are supported"; return -1; }
+    for (int i = 0; i < h->H.nseq; i++) if (marker_family[i] < 0 || marker_family[i] >= nfam) { g_err = "family index out of range"; return -1; }
+    HIPCK(hipSetDevice(h->device));
+    h->fam.assign(marker_family, marker_family + h->H.nseq);
+    h->nfam = nfam;
+    HIPCK(hipMemcpy(h->d_fam, h->fam.data(), (size_t)h->H.nseq * 4, hipMemcpyHostToDevice));
+    h->run_set = false;                                            // per-family parameters have to be set again
+    return 0;
+}
+
+// Host only (no GPU): is the database prerapsearch wrote the same index mc_open() builds from these sequences?
+// 0 = identical (residues, offsets, buckets, postings in order, suffix keys); > 0 = number of the first differing part.
+extern "C" int mc_rapdb_verify(const char *rapdb_path, const char *const *names, const char *const *seqs, int32_t nseq)
+{
+    McHostIndex A, B;
+    std::string err;
+    if (!mc_load_rapdb(A, rapdb_path, err) || !mc_build_index(B, names, seqs, nseq, err)) { g_err = err; return -1; }
+    if (A.nseq != B.nseq || A.off != B.off) { g_err = "sequence count / offsets differ"; return 1; }
+    if (A.res != B.res) { g_err = "residues differ"; return 2; }
+    if (A.bstart != B.bstart) { g_err = "bucket sizes differ"; return 3; }
+    if (A.post != B.post) { g_err = "posting order differs"; return 4; }
+    if (A.keys != B.keys) { g_err = "suffix keys differ"; return 5; }
+    if (A.names != B.names) { g_err = "names differ"; return 6; }
+    return 0;
 }
 
 extern "C" int mc_index_view(const mc_handle *h, const uint8_t **res_codes, const uint32_t **offsets, const uint32_t **bucket_starts, const uint32_t **postings,

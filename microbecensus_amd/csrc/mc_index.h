@@ -117,6 +117,8 @@ template <class V, class Less> void mc44_sort(V *first, V *last, Less lt)
 
 struct McPostKey { uint32_t post; uint16_t key; int16_t rem; };   // rem = residues left after the 6-mer (uncapped)
 
+inline void mc_index_derive(McHostIndex &X);
+
 inline bool mc_build_index(McHostIndex &X, const char *const *names, const char *const *seqs, int nseq, std::string &err)
 {
     X.nseq = nseq;
@@ -132,13 +134,11 @@ inline bool mc_build_index(McHostIndex &X, const char *const *names, const char 
     X.res.resize((size_t)total); X.res_code.resize((size_t)total);
     uint8_t grp_of_dense[32];
     for (int d = 0; d < 32; d++) grp_of_dense[d] = (uint8_t)mc_group_of_dense(d);
-    int64_t gcount[11] = {0};
     for (int s = 0; s < nseq; s++)
         for (uint32_t i = X.off[s], k = 0; i < X.off[s + 1]; i++, k++) {
             unsigned char c = (unsigned char)seqs[s][k];
             X.res[i] = (uint8_t)mc_dense_of_char(c);
             X.res_code[i] = (uint8_t)mc_code_of_char(c);
-            gcount[grp_of_dense[X.res[i]]]++;
         }
     // buckets: every window but the last of each sequence, 6 valid reduced residues
     std::vector<uint32_t> count(MC_NBUCKET + 1, 0);
@@ -189,6 +189,16 @@ inline bool mc_build_index(McHostIndex &X, const char *const *names, const char 
         mc44_sort(tmp.data(), tmp.data() + n, less);
         for (uint32_t i = 0; i < n; i++) { X.post[X.bstart[b] + i] = tmp[i].post; X.keys[X.bstart[b] + i] = tmp[i].key; }
     }
+    mc_index_derive(X);
+    return true;
+}
+
+// Everything that follows from (res, off, bstart, post, keys): bucket bitmap, bucket records, filters, range table and the
+// two figures of the .info file.  Shared by the FASTA builder above and the rapdb loader below.
+inline void mc_index_derive(McHostIndex &X)
+{
+    X.bitmap.assign((MC_NBUCKET + 31) / 32, 0);
+    for (int b = 0; b < MC_NBUCKET; b++) if (X.bstart[b + 1] > X.bstart[b]) X.bitmap[b >> 5] |= 1u << (b & 31);
     // first-residue group boundaries (McBucketRec).  Valid only if every bucket really is grouped that way and fits 16 bit.
     {
         X.rec.assign(MC_NBUCKET, McBucketRec());
@@ -275,7 +285,74 @@ inline bool mc_build_index(McHostIndex &X, const char *const *names, const char 
     }
     // .info: median of ALL bucket sizes, reduced-letter frequencies
     { std::vector<uint32_t> c(MC_NBUCKET); for (int b = 0; b < MC_NBUCKET; b++) c[b] = X.bstart[b + 1] - X.bstart[b]; std::nth_element(c.begin(), c.begin() + (MC_NBUCKET >> 1), c.end()); X.freq_thr = c[MC_NBUCKET >> 1]; }
-    { int64_t valid = 0; for (int g = 0; g < 10; g++) valid += gcount[g]; for (int g = 0; g < 10; g++) X.letter_p[g] = (double)gcount[g] / (double)valid; }
+    {
+        int64_t gcount[11] = {0}, valid = 0;
+        for (uint8_t d : X.res) gcount[mc_group_of_dense(d)]++;
+        for (int g = 0; g < 10; g++) valid += gcount[g];
+        for (int g = 0; g < 10; g++) X.letter_p[g] = (double)gcount[g] / (double)valid;
+    }
+}
+
+
+// ---- loading a database written by `prerapsearch -d markers.faa -n rapdb` -------------------------------
+// boost::archive::binary_oarchive, as RAPSearch2 2.15 writes it (little endian, 64-bit counts):
+//   0x28 bytes of archive header | u64 n + n residue codes (group << 4 | 1 + index inside the group, 0xA0 = none) |
+//   u64 nseq+1 + offsets (u32) | 5 + 12 bytes | 10^6 x (u64 count + postings u32: seq << 11 | pos) |
+//   5 + 12 bytes | nseq x (u64 length + name) | 5 + 12 bytes | 10^6 x (u64 count + suffix keys u16)
+// The postings and keys are taken in the file's order - which is the order mc_build_index reproduces from the FASTA.
+inline bool mc_load_rapdb(McHostIndex &X, const char *path, std::string &err)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) { err = std::string("cannot open ") + path; return false; }
+    std::vector<uint8_t> b;
+    { fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); b.resize(n > 0 ? (size_t)n : 0); if (n > 0 && fread(b.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f); err = "short read"; return false; } fclose(f); }
+    size_t p = 0x28;
+    bool bad = false;
+    auto u64 = [&](void) -> uint64_t { uint64_t v = 0; if (p + 8 > b.size()) { bad = true; return 0; } memcpy(&v, &b[p], 8); p += 8; return v; };
+    auto need = [&](uint64_t n) { if (p + n > b.size()) bad = true; return !bad; };
+    if (b.size() < 0x40 || memcmp(&b[8], "serialization::archive", 22) != 0) { err = "not a boost binary archive"; return false; }
+    const uint64_t nres = u64();
+    if (bad || !need(nres)) { err = "truncated rapdb (residues)"; return false; }
+    X.res_code.assign(b.begin() + (long)p, b.begin() + (long)(p + nres)); p += nres;
+    const uint64_t noff = u64();
+    if (bad || noff < 1 || !need(4 * noff)) { err = "truncated rapdb (offsets)"; return false; }
+    X.nseq = (int)noff - 1; X.nres = (int64_t)nres;
+    X.off.resize(noff); memcpy(X.off.data(), &b[p], 4 * noff); p += 4 * noff;
+    p += 5;
+    if (u64() != MC_NBUCKET || bad) { err = "rapdb: unexpected bucket count"; return false; }
+    p += 4;
+    X.bstart.assign(MC_NBUCKET + 1, 0);
+    X.post.clear();
+    for (int i = 0; i < MC_NBUCKET; i++) {
+        const uint64_t c = u64();
+        if (bad || !need(4 * c)) { err = "truncated rapdb (postings)"; return false; }
+        const size_t o = X.post.size();
+        X.post.resize(o + c);
+        if (c) memcpy(&X.post[o], &b[p], 4 * c);
+        p += 4 * c;
+        X.bstart[i + 1] = (uint32_t)X.post.size();
+    }
+    p += 5;
+    if (u64() != (uint64_t)X.nseq || bad) { err = "rapdb: name count mismatch"; return false; }
+    p += 4;
+    X.names.clear();
+    for (int i = 0; i < X.nseq; i++) { const uint64_t l = u64(); if (bad || !need(l)) { err = "truncated rapdb (names)"; return false; } X.names.emplace_back((const char *)&b[p], (size_t)l); p += l; }
+    p += 5 + 8 + 4;
+    X.keys.assign(X.post.size() + 64, 0xFFFF);
+    for (int i = 0; i < MC_NBUCKET; i++) {
+        const uint64_t c = u64();
+        if (bad || c != X.bstart[i + 1] - X.bstart[i] || !need(2 * c)) { err = "truncated rapdb (keys)"; return false; }
+        if (c) memcpy(&X.keys[X.bstart[i]], &b[p], 2 * c);
+        p += 2 * c;
+    }
+    // residue codes -> dense codes
+    X.res.resize(X.res_code.size());
+    for (size_t i = 0; i < X.res.size(); i++) {
+        const int c = X.res_code[i], g = c >> 4, k = (c & 15) - 1;
+        X.res[i] = (g < 10 && k >= 0 && k < (int)strlen(MC_GROUPS[g])) ? (uint8_t)mc_dense_of_char((unsigned char)MC_GROUPS[g][k]) : (uint8_t)MC_INV;
+    }
+    for (int s2 = 0; s2 < X.nseq; s2++) if (X.off[s2 + 1] - X.off[s2] >= 2048) { err = "marker sequence longer than 2047 residues: " + X.names[s2]; return false; }
+    mc_index_derive(X);
     return true;
 }
 
