@@ -791,6 +791,19 @@ __global__ void __launch_bounds__(256) k_eval_seeds(const McTables *__restrict__
     }
 }
 
+// sort key of a gap task: the number of query residues its two flanks can still consume (= DP rows); tasks of similar
+// size then share a wave
+__global__ void k_gap_keys(const McGapTask *__restrict__ gaps, uint32_t ngaps, int L, uint32_t *key, uint32_t *idx)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ngaps) return;
+    const McGapTask g = gaps[k];
+    const int frame = (int)(g.chrono >> 25), qlen = (L - frame % 3) / 3;
+    const int qright = qlen - (g.qfwd + g.qp + g.L), qleft = g.qp - g.qbwd;
+    key[k] = (uint32_t)((qright > 0 ? qright : 0) + (qleft > 0 ? qleft : 0));
+    idx[k] = k;
+}
+
 #define MC_GAP_W 1200   // columns of the full-size DP workspace (markers are <= 1183 aa, checked in mc_open)
 
 // Gapped extension of both flanks, one thread per gap task.  First launch: every thread owns a SMALL workspace (cap
@@ -1223,8 +1236,9 @@ extern "C" int mc_set_run(mc_handle *h, int32_t read_len, double loge_thr, const
     for (int f = 0; f < h->nfam; f++) { h->hP.min_cov[f] = min_cov[f]; h->hP.min_score[f] = min_score[f]; h->hP.max_aaid[f] = max_aaid[f]; h->hP.aln_stat[f] = aln_stat[f]; }
     HIPCK(hipMemcpy(h->d_T, &h->hT, sizeof(McTables), hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_P, &h->hP, sizeof(McClassPars), hipMemcpyHostToDevice));
-    h->read_len = read_len; h->FP = ((read_len / 3 + 2) + 3) & ~3; h->run_set = true;
-    h->cap_reads = 0;   // frame pitch may have changed
+    const int newFP = ((read_len / 3 + 2) + 3) & ~3;
+    if (newFP != h->FP || read_len != h->read_len) h->cap_reads = 0;   // pools are sized by read length and frame pitch
+    h->read_len = read_len; h->FP = newFP; h->run_set = true;
     return 0;
 }
 
@@ -1252,6 +1266,8 @@ static int ensure_capacity(mc_handle *h, int64_t nreads)
     size_t bytes = 0, bytes2 = 0;
     HIPCK(rocprim::radix_sort_pairs(nullptr, bytes, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, (size_t)h->cap_hsps, 0, 64, h->stream));
     HIPCK(rocprim::exclusive_scan(nullptr, bytes2, h->d_idx, h->d_idxo, 0u, (size_t)h->cap_hsps, rocprim::plus<uint32_t>(), h->stream));
+    bytes = std::max(bytes, bytes2);
+    HIPCK(rocprim::radix_sort_pairs_desc(nullptr, bytes2, h->d_idx, h->d_idxo, h->d_idx, h->d_idxo, (size_t)h->cap_gaps, 0, 10, h->stream));
     bytes = std::max(bytes, bytes2);
     if (h->d_sorttmp) { (void)hipFree(h->d_sorttmp); h->d_sorttmp = nullptr; }
     HIPCK(hipMalloc(&h->d_sorttmp, bytes + 16));
@@ -1340,7 +1356,12 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
     uint32_t ngaps = c[C_GAPS];
     if (ngaps) {
         int blocks = std::min<int>(h->gap_threads / 128, (int)((ngaps + 127) / 128));
-        k_gapped<<<dim3(blocks), dim3(128), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, nullptr, ngaps, h->d_hsps, h->cap_hsps, h->d_counters, h->d_gws, h->gap_cap, h->d_retry);
+        // order of work: by DP size (the sort buffers of the HSP sort are idle at this point)
+        uint32_t *gk = (uint32_t *)h->d_k64, *gko = gk + ngaps, *gi = h->d_idx, *gio = h->d_idxo;
+        k_gap_keys<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_gaps, ngaps, L, gk, gi);
+        size_t gbytes = h->sorttmp_bytes;
+        HIPCK(rocprim::radix_sort_pairs_desc(h->d_sorttmp, gbytes, gk, gko, gi, gio, (size_t)ngaps, 0, 10, st));
+        k_gapped<<<dim3(blocks), dim3(128), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, gio, ngaps, h->d_hsps, h->cap_hsps, h->d_counters, h->d_gws, h->gap_cap, h->d_retry);
         HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
         if (const uint32_t nretry = c[C_RETRY]) {                  // tasks whose band left the small workspace
