@@ -1280,7 +1280,8 @@ extern "C" int mc_upload(mc_handle *h, const uint8_t *reads, int64_t nreads)
 {
     if (!h || !h->run_set) { g_err = "mc_set_run() must be called first"; return -1; }
     HIPCK(hipSetDevice(h->device));
-    if (nreads > h->cap_own) { if (dalloc(&h->d_reads, (size_t)nreads * h->read_len + 16)) return -1; h->cap_own = nreads; }
+    const int64_t need = nreads * (int64_t)h->read_len + 16;       // capacity in bytes: the read length may change between runs
+    if (need > h->cap_own) { if (dalloc(&h->d_reads, (size_t)need)) return -1; h->cap_own = need; }
     if (nreads) HIPCK(hipMemcpyAsync(h->d_reads, reads, (size_t)nreads * h->read_len, hipMemcpyHostToDevice, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
     h->reads_dev = h->d_reads; h->nreads = nreads;
