@@ -125,3 +125,51 @@ def test_seg_variants_agree_frame_by_frame(emul_bin, markers_faa, tmp_path):
     assert r.returncode == 0, err
     assert "0 disagreements over all window compositions" in err
     assert ", 0 differ from the plain restatement" in err
+
+
+def test_shared_algorithms_and_reader_under_sanitizers(markers_faa, tmp_path):
+    """AddressSanitizer + UBSan (CPU build; GPU sanitizers are not available on the pool): the per-thread algorithms the
+    kernels share with this emulation, on 1,500 config-1 reads with the SEG cross-check, and the native reader on truncated
+    copies of the sampler inputs."""
+    exe = str(tmp_path / "mc_emul_asan")
+    flags = ["-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
+    subprocess.check_call(["g++"] + flags + ["-o", exe, os.path.join(HERE, "emul", "mc_emul.cpp")])
+    fa = tmp_path / "c1.fa"
+    lines = gzip.open(os.path.join(GOLD, "config1_example_fq.reads.fa.gz"), "rt").readlines()[:3000]
+    fa.write_text("".join(lines))
+    env = dict(os.environ, MC_CHECK_SEG="1")
+    r = subprocess.run([exe, markers_faa, str(fa), str(tmp_path / "o.m8")], env=env, stderr=subprocess.PIPE)
+    err = r.stderr.decode()
+    assert r.returncode == 0 and "AddressSanitizer" not in err and "runtime error" not in err, err[-2000:]
+    # reader: every sampler input truncated at ~100 places, four parameter sets each
+    drv = tmp_path / "rd.cpp"
+    drv.write_text(r'''
+#include <cstdio>
+#include <vector>
+#include "%s"
+int main(int argc, char **argv) {
+    for (int a = 2; a < argc; a++) {
+        FILE *f = fopen(argv[a], "rb"); if (!f) return 2;
+        std::vector<char> b; fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); b.resize(n); if (n && fread(b.data(), 1, n, f) != (size_t)n) return 2; fclose(f);
+        for (size_t cut = 0; cut <= b.size(); cut += b.size() / 97 + 1) {
+            FILE *o = fopen(argv[1], "wb"); fwrite(b.data(), 1, cut, o); fclose(o);
+            for (int mode = 0; mode < 4; mode++) {
+                const char *paths[1] = {argv[1]};
+                mc_reader *r = mc_reader_open(paths, 1, mode & 1 ? 50 : 100, 1000000, mode >> 1, 32, mode >> 1 ? 20 : -5, -5, mode & 1 ? 5 : 100, mode & 1, nullptr);
+                if (!r) return 3;
+                long long k = mc_reader_run(r);
+                if (k > 0) { const uint8_t *p = mc_reader_reads(r); volatile unsigned s = 0; for (long long i = 0; i < k * (mode & 1 ? 50 : 100); i++) s += p[i]; }
+                mc_reader_close(r);
+                (void)mc_count_bases(paths, 1);
+            }
+        }
+    }
+    return 0;
+}
+''' % os.path.join(REPO, "include", "mcensus.h"))
+    rexe = str(tmp_path / "rd_asan")
+    subprocess.check_call(["g++"] + flags + ["-o", rexe, str(drv), os.path.join(REPO, "microbecensus_amd", "csrc", "mc_reader.cpp"), "-lz"])
+    inputs = sorted(os.path.join(GOLD, "sampler", f) for f in os.listdir(os.path.join(GOLD, "sampler")))
+    r = subprocess.run([rexe, str(tmp_path / "cut.bin")] + inputs, stderr=subprocess.PIPE)
+    err = r.stderr.decode()
+    assert r.returncode == 0 and "AddressSanitizer" not in err and "runtime error" not in err, err[-2000:]
