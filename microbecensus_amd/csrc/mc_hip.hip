@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256) k_enumerate(const McTables *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 #define MC_EN_QCAP 128
 #define MC_EN_NCHUNK(L) ((((L) / 3 - 6) + 63) / 64 > 0 ? (((L) / 3 - 6) + 63) / 64 : 1)
-#define MC_EN_BLK 512u                      // task slots a wave reserves at a time (one global atomic per block, not per append)
+#define MC_EN_BLK 2048u                     // task slots a wave reserves at a time (one global atomic per block, not per append)
 #define MC_TASK_NONE 0xFFFFFFFFu            // read id of the padding entries that close a partly used block
 struct McEnWave {
     uint32_t setter[6][6]; uint32_t hit[6][6]; uint32_t blk_base, blk_used;
@@ -932,8 +932,9 @@ __global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, 
     McSortItem *myitems = (McSortItem *)(myk + n);               // 64 n + 8 n + 16 n = 88 n <= 96 n bytes of the read's tmp area
     const int nr = mc_finish_read(*T, X, *P, fam, (int)((int64_t)read + first_read_id), sorted + a, n, v + a, tmp + 2 * (size_t)a, myrows, myk, myitems, &bh);
     nrow_of[s] = (uint32_t)nr;
-    if (nr > 0) atomicAdd(&counters[C_SEGS], 1u);
-    if (bh.family >= 0) best[atomicAdd(&counters[C_BEST], 1u)] = bh;       // few; the host orders them by read
+    (void)mc_wave_alloc(&counters[C_SEGS], nr > 0);               // (one atomic per wave, not per read)
+    const uint32_t bslot = mc_wave_alloc(&counters[C_BEST], bh.family >= 0);
+    if (bh.family >= 0) best[bslot] = bh;                         // few; the host orders them by read
 }
 // A read with many HSPs (one that really comes from a marker gene: hundreds of homologous subjects): one wave.
 // Parallel over lanes: the per-subject stacks and sum statistics (mc_finish_group per subject), the (log E, index) items,
