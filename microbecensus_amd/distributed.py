@@ -67,3 +67,47 @@ def aggregate_from_accumulators(hits, aln_sum, aln_by_len, families, optpars):
         else:
             agg[fam] = float(np.sum(aln_by_len[i] / lens))
     return agg
+
+
+def run_pipeline_distributed(args, device=None):
+    """run_pipeline() over all ranks of the initialised torch.distributed group (one process per GPU; backend "nccl" = RCCL
+    on MI355X, or gloo).  Every rank runs the (sequential, deterministic) sampler on the same input, searches its own
+    contiguous block of the accepted reads on its GPU with global read ids, the per-family integer accumulators are summed
+    with ONE all_reduce, and every rank finishes the estimate from the same sums.  Returns (est_ags, args) like run_pipeline;
+    hits are integers and the 'cov' sums are finished from exact integer sums, so the result does not depend on the number
+    of ranks (<= 1e-12 relative against the single-process sum order)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from . import microbe_census as mc
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    paths = mc.get_relative_paths(args)                                        # (mkstemp: every rank has its own temp file)
+    mc.check_paths(paths)
+    mc.check_input(args)
+    mc.impute_missing_args(args)
+    mc.check_arguments(args)
+    args["verbose"] = bool(args.get("verbose")) and rank == 0
+    try:
+        mc.process_seqfile(args, paths)
+        reads = mc._run_cache[paths["tempfile"]]["reads"]
+        L = args["read_length"]
+        lo, hi = shard_bounds(len(reads), rank, world)
+        model = mc._model()
+        fams = model["families"]
+        eng = mc._engine(device)
+        eng.set_run(L, model["pars"][str(L)], fams)
+        eng.search(reads[lo:hi], first_read_id=lo)
+        best = eng.best_hits()
+        acc = family_accumulators(best, len(fams))
+        dev = torch.device("cuda", device) if (dist.is_initialized() and dist.get_backend() == "nccl") else None
+        acc = all_reduce_accumulators(*acc, device=dev)
+        agg = aggregate_from_accumulators(*acc, fams, mc.find_opt_pars(None, L))
+        if not agg:
+            raise SystemExit("\nError: No hits to marker proteins - cannot estimate genome size! Rerun program with more reads.")
+        est = mc.estimate_average_genome_size(args, paths, agg)
+        return est, args
+    finally:
+        mc.clean_up(paths)

@@ -30,8 +30,29 @@ def parse_arguments(argv=None):
     return args
 
 
+def main_distributed(args):
+    """Launched by torchrun (one process per GPU): reads sharded over the ranks, one RCCL all_reduce of the per-family sums,
+    rank 0 writes the report."""
+    import torch
+    import torch.distributed as dist
+    from microbecensus_amd import distributed
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    try:
+        est_ags, args = distributed.run_pipeline_distributed(args, device=local)
+        if dist.get_rank() == 0:
+            count_bases = microbe_census.count_bases(args) if not args["no_equivs"] else None
+            microbe_census.report_results(args, est_ags, count_bases)
+    finally:
+        dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     args = parse_arguments()
-    est_ags, args = microbe_census.run_pipeline(args)
-    count_bases = microbe_census.count_bases(args) if not args["no_equivs"] else None
-    microbe_census.report_results(args, est_ags, count_bases)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:            # python -m torch.distributed.run --nproc-per-node N scripts/run_microbe_census.py ...
+        main_distributed(args)
+    else:
+        est_ags, args = microbe_census.run_pipeline(args)
+        count_bases = microbe_census.count_bases(args) if not args["no_equivs"] else None
+        microbe_census.report_results(args, est_ags, count_bases)

@@ -211,3 +211,30 @@ def test_generic_sequential_seed_kernel_agrees(engine, monkeypatch):
     assert _rows(fast) == _rows(slow) == _rows(counted)          # (field by field: the structs carry 4 padding bytes)
     # both count the reference algorithm's index reads: identical numbers
     assert (st["bucket_lookups"], st["key_probes"], st["seed_tasks"]) == (st2["bucket_lookups"], st2["key_probes"], st2["seed_tasks"])
+
+
+def test_distributed_pipeline_two_ranks(tmp_path):
+    """run_pipeline_distributed with two processes (both on this box's one GPU, gloo for the reduction): the per-family
+    sums, and with them the AGS, equal the single-process result and the reference's golden value."""
+    import subprocess
+    import sys
+    worker = tmp_path / "w.py"
+    worker.write_text(r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from microbecensus_amd import distributed as D
+dist.init_process_group(backend="gloo")
+est, args = D.run_pipeline_distributed({"seqfiles": [os.path.join(sys.argv[1], "tests", "golden", "inputs", "metagenome.fa.gz")]}, device=0)
+if dist.get_rank() == 0:
+    json.dump({"est": est, "sampled": args["sampled_reads"], "L": args["read_length"]}, open(sys.argv[2], "w"))
+dist.destroy_process_group()
+''')
+    out = tmp_path / "o.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29531", str(worker), REPO, str(out)], env=env, timeout=900)
+    res = json.load(open(out))
+    gold = json.load(open(os.path.join(GOLD, "unittest_metagenome.json")))
+    assert res["sampled"] == gold["sampled_reads"] and res["L"] == gold["args"]["read_length"]
+    assert abs(res["est"] - gold["est_ags"]) <= 1e-9 * gold["est_ags"]
