@@ -60,6 +60,8 @@ int32_t mc_marker_count(const mc_handle *h);
 const char *mc_marker_name(const mc_handle *h, int32_t i);
 int mc_set_families(mc_handle *h, const int32_t *marker_family, int32_t nfam);
 int mc_rapdb_verify(const char *rapdb_path, const char *const *names, const char *const *seqs, int32_t nseq);
+/* ... and the writer (no GPU): what `prerapsearch -d <fasta> -n <path>` produces, <path> and <path>.info. */
+int mc_rapdb_write(const char *const *names, const char *const *seqs, int32_t nseq, const char *path);
 
 /* Host views of the index, for cross-checking against a prerapsearch-built database (tests only). */
 int mc_index_view(const mc_handle *h, const uint8_t **res_codes, const uint32_t **offsets, const uint32_t **bucket_starts,

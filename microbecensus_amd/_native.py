@@ -63,6 +63,7 @@ def load_library():
     lib.mc_marker_name.argtypes = [C.c_void_p, C.c_int32]
     lib.mc_set_families.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]
     lib.mc_rapdb_verify.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int32]
+    lib.mc_rapdb_write.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int32, C.c_char_p]
     lib.mc_index_view.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 5 + [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     lib.mc_set_run.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.mc_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
@@ -92,7 +93,7 @@ def load_library():
     return lib
 
 
-EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_index_view", "mc_set_run", "mc_search",
+EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
                     "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8",
                     "mc_reader_last_error", "mc_reader_open", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_count_bases"]
 
@@ -139,6 +140,14 @@ def rapdb_verify(rapdb_path, names, seqs):
     lib = load_library()
     n = len(names)
     return lib.mc_rapdb_verify(rapdb_path.encode(), (C.c_char_p * n)(*[s.encode() for s in names]), (C.c_char_p * n)(*[s.encode() for s in seqs]), n)
+
+
+def rapdb_write(names, seqs, path):
+    """Writes <path> and <path>.info as `prerapsearch -d markers.faa -n <path>` would.  No GPU involved."""
+    lib = load_library()
+    n = len(names)
+    if lib.mc_rapdb_write((C.c_char_p * n)(*[s.encode() for s in names]), (C.c_char_p * n)(*[s.encode() for s in seqs]), n, path.encode()) != 0:
+        raise RuntimeError(lib.mc_last_error().decode())
 
 
 def load_markers(path=None):

@@ -1199,6 +1199,16 @@ extern "C" int mc_set_families(mc_handle *h, const int32_t *marker_family, int32
     return 0;
 }
 
+// Host only (no GPU): `prerapsearch -d <fasta> -n <path>` - builds the index from the sequences and writes <path> and
+// <path>.info in RAPSearch2 2.15's on-disk format.
+extern "C" int mc_rapdb_write(const char *const *names, const char *const *seqs, int32_t nseq, const char *path)
+{
+    McHostIndex A;
+    std::string err;
+    if (!mc_build_index(A, names, seqs, nseq, err) || !mc_write_rapdb(A, path, err)) { g_err = err; return -1; }
+    return 0;
+}
+
 // Host only (no GPU): is the database prerapsearch wrote the same index mc_open() builds from these sequences?
 // 0 = identical (residues, offsets, buckets, postings in order, suffix keys); > 0 = number of the first differing part.
 extern "C" int mc_rapdb_verify(const char *rapdb_path, const char *const *names, const char *const *seqs, int32_t nseq)

@@ -288,7 +288,7 @@ inline void mc_index_derive(McHostIndex &X)
     {
         int64_t gcount[11] = {0}, valid = 0;
         for (uint8_t d : X.res) gcount[mc_group_of_dense(d)]++;
-        for (int g = 0; g < 10; g++) valid += gcount[g];
+        valid = (int64_t)X.res.size();                     // prerapsearch divides by ALL residues, the few invalid ones included
         for (int g = 0; g < 10; g++) X.letter_p[g] = (double)gcount[g] / (double)valid;
     }
 }
@@ -353,6 +353,41 @@ inline bool mc_load_rapdb(McHostIndex &X, const char *path, std::string &err)
     }
     for (int s2 = 0; s2 < X.nseq; s2++) if (X.off[s2 + 1] - X.off[s2] >= 2048) { err = "marker sequence longer than 2047 residues: " + X.names[s2]; return false; }
     mc_index_derive(X);
+    return true;
+}
+
+// ---- and writing one: the two files `prerapsearch -d markers.faa -n <path>` leaves (<path> and <path>.info) ------------
+inline bool mc_write_rapdb(const McHostIndex &X, const char *path, std::string &err)
+{
+    static const unsigned char hdr[0x28] = {0x16, 0, 0, 0, 0, 0, 0, 0, 's', 'e', 'r', 'i', 'a', 'l', 'i', 'z', 'a', 't', 'i', 'o', 'n', ':', ':', 'a', 'r', 'c', 'h', 'i', 'v', 'e',
+                                            0x09, 0x00, 0x04, 0x08, 0x04, 0x08, 0x01, 0x00, 0x00, 0x00};
+    std::vector<uint8_t> b;
+    auto put = [&](const void *p, size_t n) { const uint8_t *q = (const uint8_t *)p; b.insert(b.end(), q, q + n); };
+    auto u64 = [&](uint64_t v) { put(&v, 8); };
+    auto u32 = [&](uint32_t v) { put(&v, 4); };
+    auto cls = [&](uint64_t count) { const uint8_t z[5] = {0, 0, 0, 0, 0}; put(z, 5); u64(count); u32(0); };   // class info + count + item version
+    put(hdr, sizeof hdr);
+    u64((uint64_t)X.res_code.size()); put(X.res_code.data(), X.res_code.size());
+    u64((uint64_t)X.off.size()); put(X.off.data(), X.off.size() * 4);
+    cls(MC_NBUCKET);
+    for (int i = 0; i < MC_NBUCKET; i++) { const uint32_t c = X.bstart[i + 1] - X.bstart[i]; u64(c); if (c) put(&X.post[X.bstart[i]], (size_t)c * 4); }
+    cls((uint64_t)X.nseq);
+    for (int i = 0; i < X.nseq; i++) { u64((uint64_t)X.names[(size_t)i].size()); put(X.names[(size_t)i].data(), X.names[(size_t)i].size()); }
+    cls(MC_NBUCKET);
+    for (int i = 0; i < MC_NBUCKET; i++) { const uint32_t c = X.bstart[i + 1] - X.bstart[i]; u64(c); if (c) put(&X.keys[X.bstart[i]], (size_t)c * 2); }
+    FILE *f = fopen(path, "wb");
+    if (!f || fwrite(b.data(), 1, b.size(), f) != b.size()) { if (f) fclose(f); err = std::string("cannot write ") + path; return false; }
+    fclose(f);
+    // .info: header, 1, nseq, nres, bucket sizes, their median (the seed-lengthening threshold), the 10 group frequencies
+    b.clear();
+    put(hdr, sizeof hdr);
+    u32(1); u64((uint64_t)X.nseq); u64((uint64_t)X.res_code.size()); u64(MC_NBUCKET);
+    for (int i = 0; i < MC_NBUCKET; i++) u32(X.bstart[i + 1] - X.bstart[i]);
+    u32(X.freq_thr); u64(10); put(X.letter_p, 80);
+    const std::string ip = std::string(path) + ".info";
+    f = fopen(ip.c_str(), "wb");
+    if (!f || fwrite(b.data(), 1, b.size(), f) != b.size()) { if (f) fclose(f); err = "cannot write " + ip; return false; }
+    fclose(f);
     return true;
 }
 

@@ -56,3 +56,16 @@ def test_engine_on_the_prerapsearch_database():
         assert len(best) == len(meta["best_hits"])
     finally:
         eng.close()
+
+
+@needs_db
+def test_writer_reproduces_prerapsearch_byte_for_byte(tmp_path):
+    """mc_rapdb_write (index built from the FASTA, written in RAPSearch2 2.15's on-disk format) == the two files
+    `prerapsearch_Linux_2.15 -d markers.faa -n rapdb_2.15` wrote, byte for byte: bucket order, suffix keys, .info median and
+    letter frequencies included."""
+    from microbecensus_amd import _native
+    names, seqs = _native.load_markers()
+    out = str(tmp_path / "db")
+    _native.rapdb_write(names, seqs, out)
+    for suffix in ("", ".info"):
+        assert hashlib.md5(open(out + suffix, "rb").read()).hexdigest() == hashlib.md5(open(RAPDB + suffix, "rb").read()).hexdigest(), suffix
