@@ -238,3 +238,48 @@ dist.destroy_process_group()
     gold = json.load(open(os.path.join(GOLD, "unittest_metagenome.json")))
     assert res["sampled"] == gold["sampled_reads"] and res["L"] == gold["args"]["read_length"]
     assert abs(res["est"] - gold["est_ags"]) <= 1e-9 * gold["est_ags"]
+
+
+def test_config5_shape_300bp_fastq_quality_and_duplicate_filters(engine, tmp_path):
+    """BASELINE configs[4] in small: 300 bp FASTQ (phred+33 qualities), 5 % of the reads with one base below 20 (dropped
+    by -q 20), exact and reverse-complement duplicates (dropped by -d).  Stage by stage: the sampler keeps what the
+    Python statement of the reference's rules keeps, the m8 equals the oracle's on the kept reads, the device
+    classification equals the reference's algorithm applied to that m8."""
+    import numpy as np
+    from microbecensus_amd import _native, synth
+    names, seqs = _native.load_markers()
+    genome = synth.build_genomes(seqs, total_bp=500_000, seed=55, marker_gene_fraction=0.25)
+    n, L = 4000, 300
+    reads = synth.sample_reads(genome, n, L, seed=56)
+    rng = np.random.RandomState(5)
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    recs = []
+    for i in range(n):
+        s = bytes(reads[i])
+        q = bytearray((rng.randint(25, 41, size=L) + 33).astype(np.uint8))
+        if i % 20 == 7:
+            q[rng.randint(0, L)] = 33 + 10                       # one base below 20
+        recs.append((b"r%d" % i, s, bytes(q)))
+        if i % 50 == 3:
+            recs.append((b"dup%d" % i, s, bytes(q)))             # exact duplicate
+        if i % 100 == 11:
+            recs.append((b"rc%d" % i, s[::-1].translate(comp), bytes(q)))   # reverse-complement duplicate
+    fq = tmp_path / "c5.fq"
+    fq.write_bytes(b"".join(b"@%s\n%s\n+\n%s\n" % r for r in recs))
+    args = {"seqfiles": [str(fq)], "read_length": L, "min_quality": 20, "filter_dups": True, "nreads": 100000, "verbose": False}
+    paths = mc.get_relative_paths(args)
+    mc.check_paths(paths); mc.check_input(args); mc.impute_missing_args(args); mc.check_arguments(args)
+    assert args["file_type"] == "fastq"
+    mc.process_seqfile(args, paths)
+    kept = mc._run_cache[paths["tempfile"]]["reads"].copy()
+    ref_reads, ref_st = mc._process_seqfile_py(dict(args), {"tempfile": str(tmp_path / "py.fa")})
+    assert args["sampled_reads"] == ref_st["sampled"] and (kept == ref_reads).all()
+    assert ref_st["low_qual"] >= n // 20 - 2 and ref_st["dups"] >= n // 50
+    mc.search_seqs(args, paths)
+    rows = mc._run_cache[paths["tempfile"]]["rows"]
+    assert_rows_equal(_rows(rows), _oracle_rows(kept))
+    best = mc.classify_reads(args, paths)
+    assert best == mc._classify_m8_file(args, paths) and len(best) > 5
+    agg = mc.aggregate_hits(args, paths, best)
+    mc.clean_up(paths)
+    assert mc.estimate_average_genome_size(args, paths, agg) > 0
