@@ -1,0 +1,14 @@
+"""Development aid: PCIe-inclusive rate of mc_search() (host buffer in, rows + best hits back in host memory)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from microbecensus_amd import _native, synth
+names, seqs = _native.load_markers(); model = _native.load_model(); fams = model["families"]
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+genome = synth.build_genomes(seqs, total_bp=8_000_000, seed=20261001)
+reads = synth.sample_reads(genome, n, 150, seed=1000)
+eng = _native.Engine(device=0); eng.set_run(150, model["pars"]["150"], fams)
+for it in range(3):
+    t = time.time(); eng.lib.mc_search(eng.h, reads.ctypes.data, n, 0); dt = time.time() - t
+    st = eng.stats()
+    print("mc_search %d reads (pageable host buffer): %.1f ms -> %.2f M reads/s; device %.1f ms; rows %d" % (n, dt * 1e3, n / dt / 1e6, st["ms_total"], st["rows"]))
