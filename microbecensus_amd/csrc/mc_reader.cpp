@@ -24,7 +24,6 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
-#include <unordered_set>
 #include <vector>
 
 #include <zlib.h>
@@ -147,6 +146,55 @@ struct Parser {
     }
 };
 
+// Exact set of the accepted (untrimmed) sequences for -d: the strings live back to back in one arena, an open-addressing
+// table holds (hash, offset) - no allocation per sequence, one cache miss per lookup; equality is decided on the bytes.
+struct SeqSet {
+    std::vector<char> arena;
+    std::vector<uint64_t> hash, off;             // off: arena offset + 1 (0 = empty slot); the length sits in front of the bytes
+    size_t used = 0;
+    static uint64_t h64(const char *p, size_t n)
+    {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xff51afd7ed558ccdull);
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = (h ^ w) * 0x9FB21C651E98DF25ull; h ^= h >> 29; }
+        uint64_t w = 0;
+        if (i < n) { memcpy(&w, p + i, n - i); h = (h ^ w) * 0x9FB21C651E98DF25ull; h ^= h >> 29; }
+        h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 32;
+        return h;
+    }
+    void grow()
+    {
+        const size_t cap = hash.empty() ? (1u << 16) : hash.size() * 2;
+        std::vector<uint64_t> nh(cap, 0), no(cap, 0);
+        for (size_t i = 0; i < hash.size(); i++) if (off[i]) { size_t j = hash[i] & (cap - 1); while (no[j]) j = (j + 1) & (cap - 1); nh[j] = hash[i]; no[j] = off[i]; }
+        hash.swap(nh); off.swap(no);
+    }
+    bool contains(const std::string &s) const
+    {
+        if (hash.empty()) return false;
+        const uint64_t h = h64(s.data(), s.size());
+        for (size_t j = h & (hash.size() - 1);; j = (j + 1) & (hash.size() - 1)) {
+            if (!off[j]) return false;
+            if (hash[j] == h) {
+                const char *q = arena.data() + (off[j] - 1);
+                uint64_t len; memcpy(&len, q, 8);
+                if (len == s.size() && memcmp(q + 8, s.data(), s.size()) == 0) return true;
+            }
+        }
+    }
+    void insert(const std::string &s)              // (the caller has checked that it is not there)
+    {
+        if ((used + 1) * 2 > hash.size()) grow();
+        const uint64_t h = h64(s.data(), s.size()), len = s.size();
+        const size_t o = arena.size();
+        arena.resize(o + 8 + s.size());
+        memcpy(arena.data() + o, &len, 8); memcpy(arena.data() + o + 8, s.data(), s.size());
+        size_t j = h & (hash.size() - 1);
+        while (off[j]) j = (j + 1) & (hash.size() - 1);
+        hash[j] = h; off[j] = o + 1; used++;
+    }
+};
+
 bool is_bz2(const char *path) { size_t n = strlen(path); return n >= 4 && strcmp(path + n - 4, ".bz2") == 0; }
 
 }   // namespace
@@ -179,14 +227,15 @@ extern "C" mc_reader *mc_reader_open(const char *const *paths, int32_t npaths, i
 extern "C" void mc_reader_close(mc_reader *r) { delete r; }
 
 static bool revcomp(const std::string &s, std::string &out)
-{
-    out.resize(s.size());
-    for (size_t i = 0, n = s.size(); i < n; i++) {
-        char c = s[n - 1 - i], d;
-        switch (c) { case 'A': d = 'T'; break; case 'T': d = 'A'; break; case 'G': d = 'C'; break; case 'C': d = 'G'; break; case 'N': d = 'N'; break; default: return false; }
-        out[i] = d;
-    }
-    return true;
+{ // Sequence.reverse_complement (reference :288-292): ACGTN only, anything else is a KeyError there
+    static const struct Tab { unsigned char t[256]; Tab() { memset(t, 0, sizeof t); t['A'] = 'T'; t['T'] = 'A'; t['G'] = 'C'; t['C'] = 'G'; t['N'] = 'N'; } } tab;
+    const size_t n = s.size();
+    out.resize(n);
+    const unsigned char *p = (const unsigned char *)s.data() + n;
+    char *o = &out[0];
+    unsigned char all = 0xFF;
+    for (size_t i = 0; i < n; i++) { const unsigned char d = tab.t[*--p]; o[i] = (char)d; all &= (unsigned char)(d ? 0xFF : 0); }
+    return all != 0 || n == 0;
 }
 
 extern "C" int64_t mc_reader_run(mc_reader *r)
@@ -199,7 +248,7 @@ extern "C" int64_t mc_reader_run(mc_reader *r)
         if (!out) { r_err = "cannot write " + r->fasta_out; return -1; }
         setvbuf(out, nullptr, _IOFBF, 1 << 22);
     }
-    std::unordered_set<std::string> seen;
+    SeqSet seen;
     std::string rc;
     const size_t L = (size_t)r->L;
     int64_t kept = 0;
@@ -214,9 +263,9 @@ extern "C" int64_t mc_reader_run(mc_reader *r)
             r->st.bases += (int64_t)rec.seq.size();
             if (rec.seq.size() < L) { r->st.too_short++; continue; }
             if (r->filter_dups) {
-                if (seen.count(rec.seq)) { r->st.dups++; continue; }
+                if (seen.contains(rec.seq)) { r->st.dups++; continue; }
                 if (!revcomp(rec.seq, rc)) { r_err = "KeyError: base outside ACGTN in reverse_complement"; rcode = -3; break; }
-                if (seen.count(rc)) { r->st.dups++; continue; }
+                if (seen.contains(rc)) { r->st.dups++; continue; }
             }
             // quality_filter
             size_t ncount = 0;
