@@ -23,7 +23,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <zlib.h>
@@ -35,29 +38,72 @@ namespace {
 thread_local std::string r_err;
 
 struct LineSource {   // bytes of a plain or gzip file, split into lines with universal-newline semantics
+    // A producer thread inflates / reads the file 4 MB at a time into a ring of three blocks while the caller parses: for
+    // .gz input the inflate (the slower half) runs beside the parser instead of in front of it.
+    enum { NBLK = 3, BLK = 1 << 22 };
     gzFile gz = nullptr;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<unsigned char> ring[NBLK];
+    size_t ring_n[NBLK] = {0, 0, 0};
+    int head = 0, tail = 0, count = 0;
+    bool prod_done = false, stop = false;
     std::vector<unsigned char> buf;
     size_t pos = 0, end = 0;
     bool eof = false, pending_cr = false;
+    ~LineSource() { close(); }
     bool open(const char *path)
     {
         gz = gzopen(path, "rb");                 // zlib reads plain files transparently as well
         if (!gz) return false;
         gzbuffer(gz, 1 << 20);
-        buf.resize(1 << 22);
+        buf.resize(BLK);
+        for (auto &r : ring) r.resize(BLK);
+        th = std::thread([this] { produce(); });
         return true;
     }
-    void close() { if (gz) { gzclose(gz); gz = nullptr; } }
+    void produce()
+    {
+        for (;;) {
+            int slot;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [this] { return count < NBLK || stop; });
+                if (stop) return;
+                slot = tail;
+            }
+            const int n = gzread(gz, ring[slot].data(), (unsigned)BLK);
+            std::unique_lock<std::mutex> lk(mu);
+            if (n <= 0) { prod_done = true; cv.notify_all(); return; }
+            ring_n[slot] = (size_t)n; tail = (tail + 1) % NBLK; count++;
+            cv.notify_all();
+        }
+    }
+    void close()
+    {
+        if (th.joinable()) {
+            { std::unique_lock<std::mutex> lk(mu); stop = true; cv.notify_all(); }
+            th.join();
+        }
+        if (gz) { gzclose(gz); gz = nullptr; }
+    }
     bool fill()
     {
         if (eof) return false;
         if (pos < end) { memmove(buf.data(), buf.data() + pos, end - pos); }
         end -= pos; pos = 0;
-        if (end == buf.size()) buf.resize(buf.size() * 2);
-        int n = gzread(gz, buf.data() + end, (unsigned)(buf.size() - end));
-        if (n < 0) { eof = true; return false; }
-        if (n == 0) { eof = true; return false; }
-        end += (size_t)n;
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return count > 0 || prod_done; });
+        if (count == 0) { eof = true; return false; }
+        const size_t n = ring_n[head];
+        if (end + n > buf.size()) buf.resize(end + n > buf.size() * 2 ? end + n : buf.size() * 2);
+        lk.unlock();
+        memcpy(buf.data() + end, ring[head].data(), n);          // (the producer never touches a block that is still counted)
+        end += n;
+        lk.lock();
+        head = (head + 1) % NBLK; count--;
+        cv.notify_all();
         return true;
     }
     // Next line: [*p, *p + *n) = the characters in front of the terminator (valid until the next call); *nl = the line

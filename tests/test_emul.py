@@ -168,7 +168,7 @@ int main(int argc, char **argv) {
 }
 ''' % os.path.join(REPO, "include", "mcensus.h"))
     rexe = str(tmp_path / "rd_asan")
-    subprocess.check_call(["g++"] + flags + ["-o", rexe, str(drv), os.path.join(REPO, "microbecensus_amd", "csrc", "mc_reader.cpp"), "-lz"])
+    subprocess.check_call(["g++"] + flags + ["-pthread", "-o", rexe, str(drv), os.path.join(REPO, "microbecensus_amd", "csrc", "mc_reader.cpp"), "-lz"])
     inputs = sorted(os.path.join(GOLD, "sampler", f) for f in os.listdir(os.path.join(GOLD, "sampler")))
     r = subprocess.run([rexe, str(tmp_path / "cut.bin")] + inputs, stderr=subprocess.PIPE)
     err = r.stderr.decode()
