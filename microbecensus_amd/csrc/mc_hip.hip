@@ -887,7 +887,7 @@ __global__ void k_heads(const uint32_t *__restrict__ flags, const uint32_t *__re
 
 
 #define MC_FH_MIN 96      // reads with more HSPs than this are finished by a whole wave (k_finish_heavy)
-#define MC_FH_MAXN 2048   // ... up to this many in the standard form (45 KB of LDS per wave, three waves per CU)
+#define MC_FH_MAXN 1536   // ... up to this many in the standard form (34 KB of LDS per wave, four waves per CU; balances the three kernels)
 #define MC_FH_BIGN 6144   // ... up to this many in the large form (132 KB, one wave per CU); beyond, back to the single thread
 
 // The reads that get a wave of their own (k_finish_heavy), collected before the finishing kernels start so that the three of
