@@ -479,8 +479,9 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
     McEnWave *W = waves + wv;
     const int FPs = (FP + 15) & ~15;
     const int nchunk = MC_EN_NCHUNK(L);                                    // chunks of 64 positions per frame
-    uint8_t *fr = fr_all + (size_t)wv * (6 * FPs + 6 * nchunk * 512);
+    uint8_t *fr = fr_all + (size_t)wv * (6 * FPs + 6 * nchunk * (512 + 128));
     unsigned long long *pre = (unsigned long long *)(fr + 6 * FPs);        // per (frame, chunk, lane): seed 20 | g6..g9 16 | valid 1 | bucket occupied 1
+    uint16_t *dq = (uint16_t *)(pre + 6 * nchunk * 64);                    // positions whose neighbourhood waits for the exact probes' results
     if (threadIdx.x < 32) grp[threadIdx.x] = T->grp[threadIdx.x];
     if (lane == 0) { W->blk_base = 0; W->blk_used = MC_EN_BLK; }
     __syncthreads();
@@ -539,8 +540,9 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
         //                   the 10-mer Bloom filter -> queue q
         //   q            -> range search on the bucket records (long groups via queue hq to the binary searches) -> seed hits
         // Every stage runs with full waves; the generator is a state machine so that each stage exists once in the kernel.
+        int dn = 0;                                      // deferred positions (dq)
         for (int pass = 0; pass < 2; pass++) {
-            int f = -1, p0 = 0, qlen = 0;
+            int f = -1, p0 = 0, qlen = 0, dpos = 0;
             bool more = true;
             uint32_t wm = 0;                             // groups of this lane's position that still have to enter eq
             unsigned long long wbase = 0;                // seed | key | position | frame of this lane's position
@@ -629,70 +631,80 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                     continue;
                 }
                 if (!more) break;
-                {   // next chunk of positions / next frame
+                {   // next 64 positions: of the sweep over the frames (pass 0) or of the deferred list (pass 1)
                     MC_TICK(4);
-                    if (f >= 0) p0 += 64;
-                    if (f < 0 || p0 + 6 >= qlen) {
-                        f++; p0 = 0;
-                        if (f == 6) { more = false; continue; }
-                        qlen = (L - f % 3) / 3;
-                        if (p0 + 6 >= qlen) continue;
+                    int pos, fl, idx;
+                    bool here;
+                    if (pass == 0) {
+                        if (f >= 0) p0 += 64;
+                        if (f < 0 || p0 + 6 >= qlen) {
+                            f++; p0 = 0;
+                            if (f == 6) { more = false; continue; }
+                            qlen = (L - f % 3) / 3;
+                            if (p0 + 6 >= qlen) continue;
+                        }
+                        pos = p0 + lane; fl = f; idx = (f * nchunk + (p0 >> 6)) * 64 + lane; here = true;
+                    } else {
+                        if (dpos >= dn) { more = false; continue; }
+                        here = dpos + lane < dn;
+                        idx = here ? dq[dpos + lane] : 0;
+                        dpos += 64;
+                        fl = idx / (nchunk * 64);
+                        pos = (idx - fl * nchunk * 64);                  // chunk * 64 + lane = the position
                     }
-                    const int pos = p0 + lane;
-                    bool live = false;
-                    uint32_t qk = 0;
-                    const unsigned long long pw = pre[(f * nchunk + (p0 >> 6)) * 64 + lane];
+                    bool live0 = false, live = false, defer = false;     // exact probe; neighbourhood; neighbourhood decided later
+                    uint32_t qk = 0, qk0 = 0;
+                    const unsigned long long pw = pre[idx];
                     const int seed = (int)(pw & 0xFFFFF);
-                    {
-                        if ((pw >> 36) & 1) {
-                            const bool selfbucket = (pw >> 37) & 1;
+                    if (here && ((pw >> 36) & 1)) {
+                        const bool selfbucket = (pw >> 37) & 1;
+                        const int g6 = (int)((pw >> 32) & 15), g7 = (int)((pw >> 28) & 15), g8 = (int)((pw >> 24) & 15), g9 = (int)((pw >> 20) & 15);
+                        const bool v6 = g6 != MC_INVGRP, v7 = g7 != MC_INVGRP, v8 = g8 != MC_INVGRP, v9 = g9 != MC_INVGRP;
+                        qk = ((uint32_t)g6 << 12) | ((uint32_t)g7 << 8) | ((uint32_t)g8 << 4) | (uint32_t)g9;
+                        if (pass == 0) {
                             const int rest = qlen - pos - 6;
-                            const int g6 = (int)((pw >> 32) & 15), g7 = (int)((pw >> 28) & 15), g8 = (int)((pw >> 24) & 15), g9 = (int)((pw >> 20) & 15);
-                            if (pass == 0) {
-                                if (COUNT) sc.lookups++;                         // bucket-size probe of the exact seed
-                                if (selfbucket && rest >= 3 && g6 != MC_INVGRP && g7 != MC_INVGRP) {
-                                    atomicOr(&W->setter[f][pos >> 5], 1u << (pos & 31));
-                                    qk = ((uint32_t)g6 << 12) | ((uint32_t)g7 << 8) | ((uint32_t)g8 << 4) | 0xFu;
-                                    if (COUNT) sc.lookups++;                     // its key-range probe
-                                    live = true;
-                                }
-                            } else if (rest >= 4) {
-                                int used = 9;
-                                bool skip = false;
-                                if (selfbucket) skip = (g6 == MC_INVGRP || g7 == MC_INVGRP);
-                                else {   // prev: did the nearest earlier position that probed an exact seed find a range?
-                                    int prev = 6, w = pos >> 5;
-                                    uint32_t m = W->setter[f][w] & ((1u << (pos & 31)) - 1);
-                                    while (m == 0 && w > 0) { w--; m = W->setter[f][w]; }
-                                    if (m) { int bb = 31 - __builtin_clz(m); if ((W->hit[f][w] >> bb) & 1) prev = 9; }
-                                    used = (6 >= prev - 1) ? 6 : prev - 1;
-                                }
-                                if (!skip) {
-                                    bool ok = (g9 != MC_INVGRP);
-                                    if (used <= 8) ok = ok && (g8 != MC_INVGRP);
-                                    if (used <= 7) ok = ok && (g7 != MC_INVGRP);
-                                    if (used <= 6) ok = ok && (g6 != MC_INVGRP);
-                                    live = ok;
-                                    qk = ((uint32_t)g6 << 12) | ((uint32_t)g7 << 8) | ((uint32_t)g8 << 4) | (uint32_t)g9;
-                                }
+                            if (COUNT) sc.lookups++;                             // bucket-size probe of the exact seed
+                            if (selfbucket && rest >= 3 && v6 && v7) {
+                                atomicOr(&W->setter[fl][pos >> 5], 1u << (pos & 31));
+                                qk0 = (qk & 0xFFF0u) | 0xFu;
+                                if (COUNT) sc.lookups++;                         // its key-range probe
+                                live0 = true;
                             }
+                            // The neighbourhood's validity check starts at residue `used`: 9 when the own bucket is occupied, else 8
+                            // or 6 depending on whether the nearest earlier exact probe of the frame found a range (prev).  That
+                            // only matters when g8, g9 are valid and g6 or g7 is not: those few positions wait for pass 1.
+                            if (rest >= 4) {
+                                if (selfbucket) live = v6 && v7 && v9;
+                                else if (v8 && v9) { if (v6 && v7) live = true; else defer = true; }
+                            }
+                        } else {   // a deferred position: own bucket empty, g8 and g9 valid, g6 or g7 invalid -> live iff prev == 9
+                            int w = pos >> 5;
+                            uint32_t m = W->setter[fl][w] & ((1u << (pos & 31)) - 1);
+                            while (m == 0 && w > 0) { w--; m = W->setter[fl][w]; }
+                            if (m) { const int bb = 31 - __builtin_clz(m); live = (W->hit[fl][w] >> bb) & 1; }
                         }
                     }
-                    wbase = (unsigned long long)seed | ((unsigned long long)qk << 20) | ((unsigned long long)pos << 36) | ((unsigned long long)f << 44);
+                    if (pass == 0) {
+                        const unsigned long long dm = __ballot(defer);
+                        if (dm) { if (defer) dq[dn + __popcll(dm & lt)] = (uint16_t)idx; dn += __popcll(dm); }
+                    }
+                    const unsigned long long posf = ((unsigned long long)pos << 36) | ((unsigned long long)fl << 44);
+                    wbase = (unsigned long long)seed | ((unsigned long long)qk << 20) | posf;
                     if (pass == 0) {                                     // the exact 9-mer: its own Bloom filter, then straight into q
-                        bool pr = live;
-                        if (!COUNT && __ballot(live)) {
-                            const uint32_t hh = mc_filter_hash((uint32_t)seed, qk), fb9 = mc_filter_bits(hh);
-                            const uint32_t fw9 = X.filt[live ? mc_filter9_word(hh) : 0u];
-                            pr = live && (fw9 & fb9) == fb9;
+                        bool pr = live0;
+                        if (!COUNT && __ballot(live0)) {
+                            const uint32_t hh = mc_filter_hash((uint32_t)seed, qk0), fb9 = mc_filter_bits(hh);
+                            const uint32_t fw9 = X.filt[live0 ? mc_filter9_word(hh) : 0u];
+                            pr = live0 && (fw9 & fb9) == fb9;
                         }
                         const unsigned long long prm = __ballot(pr);
                         if (prm) {
-                            if (pr) W->q[qn + __popcll(prm & lt)] = wbase;  // phase 0
+                            if (pr) W->q[qn + __popcll(prm & lt)] = (unsigned long long)seed | ((unsigned long long)qk0 << 20) | posf;   // phase 0
                             qn += __popcll(prm);
                             mc_wave_sync();
                         }
-                    } else if (COUNT) wm = live ? 0xFu : 0u;             // counting form: every probe is generated and searched
+                    }
+                    if (COUNT) wm = live ? 0xFu : 0u;                    // counting form: every probe is generated and searched
                     else if (__ballot(live)) {                           // wildcard filter: one cache line answers for the four groups
                         const uint32_t ctx = mc_wild_ctx((uint32_t)seed, qk);
                         const uint4 *ln = (const uint4 *)X.wild + (size_t)(live ? mc_wild_line(ctx) : 0u) * 4;
@@ -1335,7 +1347,7 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         HIPCK(hipEventRecord(h->ev[1], st));
         if (h->fast_enum) {
             const int FPs = (FP + 15) & ~15;
-            const size_t per_wave = sizeof(McEnWave) + (size_t)6 * FPs + (size_t)6 * MC_EN_NCHUNK(L) * 512;
+            const size_t per_wave = sizeof(McEnWave) + (size_t)6 * FPs + (size_t)6 * MC_EN_NCHUNK(L) * (512 + 128);
             int waves = (int)((160 * 1024 - 64) / per_wave);                // waves per workgroup: as many as the LDS holds, at most 16
             waves = waves >= 16 ? 16 : waves >= 12 ? 12 : waves >= 8 ? 8 : 4;
             const size_t lds2 = 64 + waves * per_wave;
