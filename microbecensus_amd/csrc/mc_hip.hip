@@ -531,14 +531,18 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                                                      ((unsigned long long)((bw[f] >> (sdv[f] & 31)) & 1u) << 37);
         }
         mc_wave_sync();
-        // pass 0: the exact 9-mer of every position.  pass 1: its one-substitution 10-mers, four groups of ten probes
-        // (groups 0..2 = offsets 4, 5, 3 of the 6-mer: neighbour buckets; group 3 = offset 6: same bucket, first key
-        // residue substituted).  64 positions are set up at once.  With the counters off, filters decide what is searched:
+        // Per position: its exact 9-mer, and its one-substitution 10-mers in four groups of ten probes (groups 0..2 =
+        // offsets 4, 5, 3 of the 6-mer: neighbour buckets; group 3 = offset 6: same bucket, first key residue substituted).
+        // Pass 0 sweeps the frames 64 positions at a time and generates both.  Whether a position has a neighbourhood
+        // depends, for a few of them (own bucket empty, g8 and g9 valid, g6 or g7 not: ~3 % of the positions), on whether
+        // the nearest earlier exact probe of the frame found a range; those wait in the list dq until pass 0 has drained
+        // its queues and are generated in pass 1.  With the counters off, filters decide what is searched:
         //   exact 9-mer  -> 9-mer Bloom filter -> queue q
         //   10-mers      -> wildcard filter (one cache line per position answers for its four groups) -> queue eq of
-        //                   (position, group) pairs -> 64 pairs at a time: ten probes each against the bucket bitmap and
-        //                   the 10-mer Bloom filter -> queue q
-        //   q            -> range search on the bucket records (long groups via queue hq to the binary searches) -> seed hits
+        //                   (position, group) pairs -> 64 pairs at a time: ten probes each against the 10-mer Bloom
+        //                   filter -> queue q
+        //   q            -> bucket records: group scan, or the range table for long groups -> seed hits
+        // (the counting form searches every probe; its long groups go through queue hq to the binary searches).
         // Every stage runs with full waves; the generator is a state machine so that each stage exists once in the kernel.
         int dn = 0;                                      // deferred positions (dq)
         for (int pass = 0; pass < 2; pass++) {
