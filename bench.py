@@ -1,21 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py - reads/s of the MI355X translated-search hot path on synthetic 150 bp reads.
+"""bench.py - reads/s of the MI355X translated-search hot path on synthetic shotgun reads.
 
     python bench.py --gpus N --steps K --warmup W
-(for N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[2], the 150 bp single-GPU configuration the metric is quoted on):
-synthetic error-free 150 bp shotgun reads, resident in HBM before the timed region starts.  One "step" is
-one pass of the whole device pipeline (translate+SEG, seeds, extension, ranking, classification) over one
-batch of --batch reads; step i works on batch i mod (resident batches).  With the defaults, K*batch = 20 M
-reads per GPU.  Reads shard across ranks with no data-path collective; per-family hit counts are summed
-with one RCCL all_reduce per step (weak scaling: every rank processes its own K batches).
+With N > 1 and no torchrun environment, bench.py starts the N ranks itself (a child `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N ... bench.py ...`, started before anything touches the GPU), relays rank 0's JSON line and
+exits with the child's code.  Launched under torchrun (RANK / LOCAL_RANK / WORLD_SIZE set) it is one rank.
 
-Rank 0 prints ONE JSON line: metric/value (whole-job reads/s), roofline of the dominant kernel
-(algorithmic bytes counted by the kernel itself / HIP-event duration), and - at N=1 - the reference's own
-RAPsearch2 binary timed on this host's cores on a bounded sample of the same reads (cpu_baseline).
+Workload: error-free reads sampled from the reference's 30 real genomes (tests/golden/genomes, 84.8 Mbp,
+251 contigs), uniform start, strand by fair coin, resident in HBM before the timed region starts.
+  N = 1: BASELINE configs[2] - K x batch distinct single reads of --read-len bp (defaults: 10 x 2 M = 20 M reads of 150 bp).
+  N > 1: BASELINE configs[3] in weak-scaling form - a paired library (mate 2 = reverse complement of the fragment end, insert
+         --insert), the stream "all of file 1, then all of file 2" cut into contiguous blocks, one per rank, K x batch reads each.
+One "step" is one pass of the whole device pipeline (translate + SEG, seeds, extension, ranking, classification) over one batch;
+the per-family accumulators of every step are summed over the ranks with an RCCL all_reduce.
+
+Rank 0 prints ONE JSON line: metric / value (whole-job reads/s), `roofline` for the dominant kernel and, at N = 1, `cpu_baseline`
+(the reference's own RAPsearch2 binary on this host's cores on bounded samples of the same reads, m8 compared by md5) and `e2e`
+(file -> AGS through run_pipeline).
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -28,50 +33,31 @@ sys.path.insert(0, REPO)
 
 METRIC = "reads/sec searched vs marker DB + AGS abs-error, 150 bp @ 1/2/4/8 GPU"
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-SURVEY_A = {100: 127403, 150: 207923, 300: 452893}   # modelled algorithmic bytes per read of the seed path
+SURVEY_A = {100: 127403, 150: 207923, 300: 452893}   # modelled algorithmic bytes per read of the whole path
 
 
-def torch_splitmix64(x):
-    import torch
-    M = lambda v: torch.tensor(v, dtype=torch.int64, device=x.device)  # noqa: E731
-    lsr = lambda v, k: (v >> k) & ((1 << (64 - k)) - 1)                # noqa: E731  logical shift on int64
-    x = x + M(-7046029254386353131)         # 0x9E3779B97F4A7C15
-    z = x
-    z = (z ^ lsr(z, 30)) * M(-4658895280553007687)   # 0xBF58476D1CE4E5B9
-    z = (z ^ lsr(z, 27)) * M(-7723592293110705685)   # 0x94D049BB133111EB
-    return z ^ lsr(z, 31)
-
-
-def sample_reads_device(genome_np, nreads, read_len, seed, device):
-    """Same reads as microbecensus_amd.synth.sample_reads, generated directly in HBM with torch."""
-    import numpy as np
-    import torch
-    from microbecensus_amd.synth import splitmix64
-    g = torch.from_numpy(genome_np).to(device)
-    rc = torch.zeros(256, dtype=torch.uint8, device=device)
-    for a, b in zip(b"ACGTN", b"TGCAN"):
-        rc[a] = b
-    base = int(splitmix64(np.array([seed], dtype=np.uint64))[0])
-    base = base - (1 << 64) if base >= (1 << 63) else base
-    mul = -3372029247567499371 & 0xFFFFFFFFFFFFFFFF   # 0xD1342543DE82EF95
-    mul = mul - (1 << 64) if mul >= (1 << 63) else mul
-    out = torch.empty((nreads, read_len), dtype=torch.uint8, device=device)
-    span = len(genome_np) - read_len
-    ar = torch.arange(read_len, device=device, dtype=torch.int64)
-    chunk, k = 1 << 20, 0
-    for s in range(0, nreads, chunk):
-        m = min(chunk, nreads - s)
-        idx = torch.arange(k, k + m, device=device, dtype=torch.int64)
-        v1 = torch_splitmix64(idx * mul + base); k += m
-        idx = torch.arange(k, k + m, device=device, dtype=torch.int64)
-        v2 = torch_splitmix64(idx * mul + base); k += m
-        # unsigned v1 % span
-        start = (((v1 >> 1) & 0x7FFFFFFFFFFFFFFF) % span * 2 + (v1 & 1)) % span
-        rev = (v2 & 1).bool()
-        block = g[start[:, None] + ar[None, :]]
-        rblock = rc[torch.flip(block, dims=[1]).long()]
-        out[s:s + m] = torch.where(rev[:, None], rblock, block)
-    return out
+def spawn_ranks(n, argv):
+    """Start n ranks (one per GPU) as a child torchrun; nothing in this process has touched the GPU yet."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + argv
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if line:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return rc if rc else (0 if line else 1)
 
 
 def profiled_traffic(kernel, n_batch):
@@ -117,35 +103,95 @@ def ags_abs_error(device):
     return out
 
 
-def cpu_baseline(sample_reads, read_len, eng_rows):
-    """Times the reference's own engine on the host cores on a bounded sample of the bench reads."""
-    import numpy as np
+def m8_md5(lines):
+    h = hashlib.md5()
+    for ln in lines:
+        h.update(ln.encode() if isinstance(ln, str) else ln)
+    return h.hexdigest()
+
+
+def cpu_baseline(eng, sample_reads, read_len, plan):
+    """Times the reference's own engine (oracle/_ref: the bundled rapsearch binary + the canonical database) on the host cores on
+    bounded prefixes of the bench reads, at several thread counts, and compares the md5 of its m8 body with the md5 of the m8 the
+    GPU produced for the same reads.  plan: [(threads, nreads), ...]; the first entry is the headline value."""
     ref = os.path.join(REPO, "oracle", "_ref")
-    cores = os.cpu_count() or 1
-    n = sample_reads.shape[0]
+    rap, db = os.path.join(ref, "rapsearch_Linux_2.15"), os.path.join(ref, "rapdb_2.15")
+    port = os.path.join(REPO, "oracle", "rs_port")
+    kind = "reference" if (os.path.exists(rap) and os.path.exists(db)) else "port"
+    if kind == "port" and not (os.path.exists(port) and os.path.exists(db)):
+        return None
+    nmax = max(n for _, n in plan)
+    sample_reads = sample_reads[:nmax]
+    runs = []
     with tempfile.TemporaryDirectory() as td:
-        fa = os.path.join(td, "sample.fa")
-        with open(fa, "w") as f:
-            f.write("".join(">%d\n%s\n" % (i, bytes(r).decode()) for i, r in enumerate(sample_reads)))
-        rap, db = os.path.join(ref, "rapsearch_Linux_2.15"), os.path.join(ref, "rapdb_2.15")
-        if os.path.exists(rap) and os.path.exists(db):
-            kind = "reference"
-            cmd = [rap, "-q", fa, "-d", db, "-o", os.path.join(td, "out"), "-z", str(cores), "-e", "1", "-t", "n", "-p", "f", "-b", "0"]
-            t = time.time(); subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); dt = time.time() - t
-            got = [l for l in open(os.path.join(td, "out.m8")) if not l.startswith("#")]
+        eng.upload(sample_reads); eng.run(0)
+        gm8 = os.path.join(td, "gpu.m8")
+        eng.write_m8(gm8)
+        gpu_lines = open(gm8).readlines()
+        gq = [int(l.split("\t", 1)[0]) for l in gpu_lines]
+        for threads, n in plan:
+            n = min(n, sample_reads.shape[0])
+            fa = os.path.join(td, "sample_%d.fa" % n)
+            if not os.path.exists(fa):
+                with open(fa, "w") as f:
+                    f.write("".join(">%d\n%s\n" % (i, bytes(r).decode()) for i, r in enumerate(sample_reads[:n])))
+            out = os.path.join(td, "out_%d_%d" % (threads, n))
+            if kind == "reference":
+                cmd = [rap, "-q", fa, "-d", db, "-o", out, "-z", str(threads), "-e", "1", "-t", "n", "-p", "f", "-b", "0"]
+                t = time.time(); subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); dt = time.time() - t
+                got = [l for l in open(out + ".m8") if not l.startswith("#")]
+            else:
+                t = time.time(); subprocess.check_call([port, db, fa, out + ".m8"]); dt = time.time() - t
+                got = open(out + ".m8").readlines()
+                threads = 1
+            want = [l for l, q in zip(gpu_lines, gq) if q < n]
+            runs.append({"threads": threads, "reads": n, "wall_s": round(dt, 2), "reads_per_s": round(n / dt, 1), "m8_rows": len(got),
+                         "m8_md5_equals_gpu": m8_md5(got) == m8_md5(want)})
+    head = runs[0]
+    return {"value": head["reads_per_s"], "unit": "reads/s", "cores": head["threads"], "kind": kind,
+            "sample": "prefixes of the bench workload (%d bp): %s -e 1 -t n -p f -b 0, wall time of the process incl. DB load; headline = first run" %
+                      (read_len, "rapsearch_Linux_2.15 -z T" if kind == "reference" else "oracle/rs_port (C restatement, 1 thread)"),
+            "host_cores": os.cpu_count(), "runs": runs, "m8_md5_equals_gpu": all(r["m8_md5_equals_gpu"] for r in runs)}
+
+
+def e2e_rate(device, gen, n, L, gz):
+    """File -> AGS through run_pipeline (native reader, HIP search, classification, estimate) on a FASTQ file of n reads of the
+    bench workload written to the box's temp directory.  Returns reads/s of the whole call (file open to estimate)."""
+    import contextlib
+    import gzip
+    import io
+    import numpy as np
+    from microbecensus_amd import microbe_census as mc
+    reads = gen.single(n, L, first=1 << 40).cpu().numpy()      # (indices far away from the resident set)
+    w = len(str(n - 1))
+    rec = np.empty((n, 1 + w + 1 + L + 3 + L + 1), dtype=np.uint8)
+    rec[:, 0] = ord("@")
+    ids = np.arange(n)
+    for k in range(w):
+        rec[:, w - k] = ord("0") + (ids // 10 ** k) % 10
+    rec[:, 1 + w] = 10
+    rec[:, 2 + w:2 + w + L] = reads
+    rec[:, 2 + w + L:5 + w + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rec[:, 5 + w + L:5 + w + 2 * L] = ord("I")
+    rec[:, 5 + w + L + 7:5 + w + 2 * L:10] = ord("5")          # (a character only phred+33 files hold: the offset detection stops at the first record)
+    rec[:, -1] = 10
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "reads.fq" + (".gz" if gz else ""))
+        if gz:
+            with gzip.open(path, "wb", compresslevel=1) as f:
+                f.write(rec.tobytes())
         else:
-            kind = "port"
-            port = os.path.join(REPO, "oracle", "rs_port")
-            if not (os.path.exists(port) and os.path.exists(db)):
-                return None
-            t = time.time(); subprocess.check_call([port, db, fa, os.path.join(td, "out.m8")]); dt = time.time() - t
-            got = open(os.path.join(td, "out.m8")).readlines()
-    same = None
-    if eng_rows is not None:
-        same = (len(got) == len(eng_rows))
-    return {"value": round(n / dt, 1), "unit": "reads/s", "cores": cores, "kind": kind,
-            "sample": "first %d reads of the bench workload (%d bp), rapsearch -z %d -e 1 -t n -p f -b 0, wall %.1f s incl. DB load" % (n, read_len, cores, dt),
-            "rows_match_gpu": same}
+            rec.tofile(path)
+        size = os.path.getsize(path)
+        args = {"seqfiles": [path], "device": device, "nreads": n, "read_length": L, "file_type": "fastq", "quality_offset": 33}
+        t = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = mc.run_pipeline(args)
+        dt = time.time() - t
+    if res is None:
+        return None
+    return {"reads": n, "file": "FASTQ" + (".gz" if gz else ""), "file_bytes": size, "wall_s": round(dt, 3), "reads_per_s": round(n / dt, 1),
+            "sampled_reads": int(res[1]["sampled_reads"]), "est_ags": res[0]}
 
 
 def main():
@@ -155,17 +201,28 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=2_000_000)
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--resident-batches", type=int, default=4)
-    ap.add_argument("--cpu-sample", type=int, default=200_000)
+    ap.add_argument("--insert", type=int, default=300, help="fragment length of the paired library (N > 1)")
+    ap.add_argument("--workload", choices=["genomes", "orfs"], default="genomes", help="genomes: reads of the 30 real genomes (SURVEY 8d); orfs: round 1's artificial ORF community")
+    ap.add_argument("--resident-batches", type=int, default=0, help="distinct batches resident in HBM (0 = one per step: no read is searched twice in the timed region)")
+    ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads of the largest cpu_baseline run (-z all cores)")
+    ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline on >= 1 M reads at -z 1 / 8 / all cores (takes ~20 min)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ags-check", action="store_true", help="skip the run_pipeline AGS comparison on the reference's own inputs")
+    ap.add_argument("--e2e-reads", type=int, default=4_000_000, help="reads of the end-to-end (file -> AGS) measurement; 0 = skip")
     ap.add_argument("--count-in-timed-steps", action="store_true", help="keep the seed kernel's traffic counters on in the timed steps")
     args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s" % (args.gpus, env_world))
 
     import numpy as np
     import torch
     import torch.distributed as dist
-    from microbecensus_amd import _native, synth
+    from microbecensus_amd import _native, distributed as mcd, synth
+    from microbecensus_amd import microbe_census as mc
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -174,7 +231,7 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
     names, seqs = _native.load_markers()
     model = _native.load_model()
@@ -183,23 +240,49 @@ def main():
     eng = _native.Engine(device=local)
     eng.set_run(L, model["pars"][str(L)], fams)
 
-    genome = synth.build_genomes(seqs, total_bp=8_000_000, seed=20261001)
-    nres = min(args.resident_batches, max(1, args.steps))
-    total_resident = args.batch * nres
-    reads = sample_reads_device(genome, total_resident, L, seed=1000 + rank, device=dev)
+    K = args.steps
+    nres = args.resident_batches if args.resident_batches > 0 else max(1, K)
+    per_rank = args.batch * nres
+    gen = None
+    if args.workload == "genomes":
+        gen = synth.GenomeReads(device=dev, seed=20261001)
+        if world == 1:
+            reads = gen.single(per_rank, L)
+            wl = "BASELINE configs[2]: error-free %d bp reads sampled from the reference's 30 genomes" % L
+        else:
+            # the paired library as the reference would consume it: file 1 (mate 1 of every fragment), then file 2
+            total = per_rank * world
+            F = total // 2
+            lo, hi = rank * per_rank, (rank + 1) * per_rank
+            parts = []
+            if lo < F:
+                parts.append(gen.paired(min(hi, F) - lo, L, frag=args.insert, first=lo)[0])
+            if hi > F:
+                a = max(lo, F) - F
+                parts.append(gen.paired(hi - F - a, L, frag=args.insert, first=a)[1])
+            reads = torch.cat(parts) if len(parts) > 1 else parts[0]
+            wl = "BASELINE configs[3] (weak-scaling form): error-free paired %d bp reads (insert %d) of the 30 genomes, stream = file 1 then file 2, contiguous block per rank" % (L, args.insert)
+    else:
+        genome = synth.build_genomes(seqs, total_bp=8_000_000, seed=20261001)
+        reads = torch.from_numpy(synth.sample_reads(genome, per_rank, L, seed=1000 + rank)).to(dev)
+        wl = "artificial ORF community (round 1 workload), %d bp" % L
     torch.cuda.synchronize()
-    eng.attach(reads.data_ptr(), total_resident)
-    fam_counts = torch.zeros(len(fams), dtype=torch.int64, device=dev)
+    eng.attach(reads.data_ptr(), per_rank)
+    nf = len(fams)
+    tot_hits = np.zeros(nf, np.int64); tot_aln = np.zeros(nf, np.int64); tot_bylen = np.zeros((nf, mcd.MAX_TARGET_LEN), np.int64)
 
-    def step(i):
+    def step(i, collect=True):
         b = i % nres
         eng.run_range(b * args.batch, args.batch, first_read_id=b * args.batch)
         best = eng.best_hits(copy=False)    # the rows of the batch are in host memory too (mc_result_rows); the aggregation needs the best hits
-        c = np.bincount(best["family"], minlength=len(fams)).astype(np.int64)
-        t = torch.from_numpy(c).to(dev)
-        if world > 1:
-            dist.all_reduce(t)          # RCCL: per-family hit counts of this step over all GPUs
-        fam_counts.add_(t)
+        hits, aln, bylen = mcd.family_accumulators(best, nf)
+        if world > 1:                       # RCCL: per-family hit counts / alignment sums of this step over all GPUs
+            t = torch.from_numpy(np.concatenate([hits, aln])).to(dev)
+            dist.all_reduce(t)
+            t = t.cpu().numpy()
+            hits, aln = t[:nf], t[nf:]
+        if collect:
+            tot_hits.__iadd__(hits); tot_aln.__iadd__(aln); tot_bylen.__iadd__(bylen)
         return eng.stats()
 
     # The algorithmic traffic of the seed kernel (index reads of the reference's algorithm) depends on the reads only:
@@ -207,19 +290,19 @@ def main():
     eng.set_counting(True)
     traffic = []
     for b in range(nres):
-        st = step(b)
+        st = step(b, collect=False)
         traffic.append((st["bucket_lookups"], st["key_probes"]))
     eng.set_counting(bool(args.count_in_timed_steps))
     for i in range(args.warmup):
-        step(i)
+        step(i, collect=False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.time()
     acc = {}
-    for i in range(args.steps):
-        st = step(args.warmup + i)
-        st["bucket_lookups"], st["key_probes"] = traffic[(args.warmup + i) % nres]
+    for i in range(K):
+        st = step(i)
+        st["bucket_lookups"], st["key_probes"] = traffic[i % nres]
         for k, v in st.items():
             acc[k] = acc.get(k, 0) + v
     torch.cuda.synchronize()
@@ -229,18 +312,25 @@ def main():
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tb = torch.from_numpy(tot_bylen).to(dev)
+        dist.all_reduce(tb)                 # the 'cov' numerators (alignment length per target length): once, at the end
+        tot_bylen = tb.cpu().numpy()
+        cnt = torch.tensor([acc["rows"], acc["reads_with_rows"], acc["hsps"], acc["gap_tasks"], acc["seed_tasks"]], dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt)
+        job = dict(zip(("rows", "reads_with_rows", "hsps", "gap_tasks", "seed_tasks"), [int(x) for x in cnt.tolist()]))
+    else:
+        job = {k: int(acc[k]) for k in ("rows", "reads_with_rows", "hsps", "gap_tasks", "seed_tasks")}
     dt = float(tmax.item())
 
     if rank == 0:
-        K = args.steps
         reads_total = args.batch * K * world
-        # dominant kernel = the one with the largest accumulated HIP-event time
+        # dominant kernel = the one with the largest accumulated HIP-event time (rank 0's events, on the library's own stream)
         kern = {"k_translate_seg": acc["ms_translate"], "k_enumerate": acc["ms_seed"], "k_eval_seeds": acc["ms_eval"], "k_gapped": acc["ms_gapped"],
                 "sort": acc["ms_sort"], "k_finish": acc["ms_finish"]}
         dom = max(kern, key=kern.get)
         n_batch = args.batch
         per_launch = {
-            # algorithmic bytes per launch, counted by the kernels themselves (DESIGN.md "Measurement")
+            # algorithmic bytes per launch: what the reference's algorithm reads / writes for the same reads
             "k_translate_seg": n_batch * (L + 6 * (L // 3)),
             "k_enumerate": (n_batch * 6 * (L // 3) * K + 8 * acc["bucket_lookups"] + 2 * acc["key_probes"] + 20 * acc["seed_tasks"]) / K,
             "k_eval_seeds": (acc["seed_tasks"] * (16 + 4 + 8 + 2 * 20)) / K,
@@ -249,33 +339,61 @@ def main():
             "k_finish": acc["hsps"] * 48 * 3 / K,
         }
         ach = per_launch[dom] / (kern[dom] / K * 1e-3) / 1e9
+        traffic_dom = profiled_traffic("k_enumerate_t0" if dom == "k_enumerate" else dom, n_batch)
+        # the whole device pipeline of one batch as one "launch": SURVEY 8(d)'s own definition, achieved = reads/s x A(L)
+        pipe_gbs = (SURVEY_A[L] * (reads_total / world) / dt / 1e9) if L in SURVEY_A else None
+        agg = mcd.aggregate_from_accumulators(tot_hits, tot_aln, tot_bylen, fams, mc.find_opt_pars(None, L))
+        try:
+            est = mc.estimate_average_genome_size({"read_length": L, "sampled_reads": reads_total, "verbose": False}, None, agg)
+        except BaseException:
+            est = None
         out = {
             "metric": METRIC, "value": round(reads_total / dt, 1), "unit": "reads/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: synthetic error-free %d bp reads, %d reads/step/GPU, %d steps (=%d reads/GPU), resident in HBM" % (L, n_batch, K, n_batch * K),
-                       "read_len": L, "batch": n_batch, "parallelism": "reads sharded over %d GPU(s), RCCL all_reduce of per-family hit counts" % world,
+            "config": {"workload": "%s; %d reads/step/GPU, %d steps, %d distinct reads resident in HBM per GPU" % (wl, n_batch, K, per_rank),
+                       "read_len": L, "batch": n_batch, "parallelism": "reads sharded over %d GPU(s), RCCL all_reduce of per-family accumulators per step" % world,
                        "marker_db": "%d proteins / %d families" % (len(names), len(fams)),
-                       "classified_reads": int(fam_counts.sum().item()),
-                       "kernel_ms_per_step": {k: round(v / K, 3) for k, v in kern.items()}},
+                       "classified_reads": int(tot_hits.sum()), "classified_per_read": round(float(tot_hits.sum()) / reads_total, 6),
+                       "rows_per_read": round(job["rows"] / reads_total, 4), "reads_with_rows": round(job["reads_with_rows"] / reads_total, 5),
+                       "hsps_per_read": round(job["hsps"] / reads_total, 3), "gapped_extensions_per_read": round(job["gap_tasks"] / reads_total, 3),
+                       "seed_hits_per_read": round(job["seed_tasks"] / reads_total, 2), "ags_estimate_of_workload": est,
+                       "kernel_ms_per_step": {k: round(v / K, 3) for k, v in kern.items()},
+                       "sum_kernel_ms_per_step": round(sum(kern.values()) / K, 3)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                         "traffic": (lambda t: None if t is None else round(t, 0))(profiled_traffic("k_enumerate_t0" if dom == "k_enumerate" else dom, n_batch)),
+                         "traffic": (None if traffic_dom is None else round(traffic_dom, 0)),
+                         "basis": "achieved = algorithmic bytes of the reference's algorithm for the launch (index reads it would issue, counted by the "
+                                  "kernel's own counting form; DESIGN.md 4) / HIP-event time of the kernel. A disposal rate: filters answer most probes, the "
+                                  "kernel does not move these bytes. physical_* = HBM-side bytes of the committed rocprofv3 PMC profile / the same time",
+                         "physical_GBps": (None if traffic_dom is None else round(traffic_dom / (kern[dom] / K * 1e-3) / 1e9, 2)),
+                         "physical_frac": (None if traffic_dom is None else round(traffic_dom / (kern[dom] / K * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)),
                          "algorithmic_bytes_per_read": round(per_launch[dom] / n_batch, 1),
-                         # SURVEY.md 8(d) priced the seed path at A(150) = 207,923 B/read assuming whole-bucket visits the engine does not
-                         # perform; for comparison, the same kernel time priced with that figure:
-                         "survey_A_bytes_per_read": SURVEY_A.get(L), "seed_kernel_GBps_with_survey_A": (round(SURVEY_A[L] * n_batch / (kern["k_enumerate"] / K * 1e-3) / 1e9, 2) if L in SURVEY_A and kern["k_enumerate"] > 0 else None),
-                         "all_kernels_GBps": {k: round(per_launch[k] / (kern[k] / K * 1e-3) / 1e9, 2) for k in kern if kern[k] > 0}},
+                         # SURVEY.md 8(d) priced the whole path at A(150) = 207,923 B/read assuming whole-bucket visits the engine does not
+                         # perform; its definition achieved = reads/s x A(L), per GPU:
+                         "survey_A_bytes_per_read": SURVEY_A.get(L),
+                         "pipeline_GBps_with_survey_A": (None if pipe_gbs is None else round(pipe_gbs, 2)),
+                         "pipeline_frac_with_survey_A": (None if pipe_gbs is None else round(pipe_gbs / HBM_PEAK_GBS, 5)),
+                         "all_kernels_algorithmic_GBps": {k: round(per_launch[k] / (kern[k] / K * 1e-3) / 1e9, 2) for k in kern if kern[k] > 0},
+                         "all_kernels_physical_GBps": {k: (lambda t: None if t is None else round(t / (kern[k] / K * 1e-3) / 1e9, 2))(
+                             profiled_traffic("k_enumerate_t0" if k == "k_enumerate" else k, n_batch)) for k in kern if kern[k] > 0 and k != "sort"}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            ns = min(args.cpu_sample, args.batch)
-            sample = reads[:ns].cpu().numpy()
-            eng.upload(sample); eng.run(0)
-            rows, _ = eng.results()
-            out["cpu_baseline"] = cpu_baseline(sample, L, rows)
+            cores = os.cpu_count() or 1
+            if args.cpu_full:
+                plan = [(cores, 1_000_000), (8, 1_000_000), (1, 1_000_000)]
+            else:   # bounded: about 10-15 s of wall time per run
+                plan = [(cores, args.cpu_sample), (8, max(1000, args.cpu_sample // 5)), (1, max(1000, args.cpu_sample // 15))]
+            ns = min(max(n for _, n in plan), per_rank)
+            out["cpu_baseline"] = cpu_baseline(eng, reads[:ns].cpu().numpy(), L, [(t, min(n, ns)) for t, n in plan])
         if world == 1 and not args.no_ags_check:
             out["config"]["ags_abs_error_vs_reference"] = ags_abs_error(local)
+        if world == 1 and args.e2e_reads > 0 and gen is not None:
+            out["e2e"] = {"what": "run_pipeline(file -> AGS): native reader + HIP search + classification + estimate, wall time of the call",
+                          "plain": e2e_rate(local, gen, args.e2e_reads, L, gz=False), "gz": e2e_rate(local, gen, max(1, args.e2e_reads // 4), L, gz=True)}
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

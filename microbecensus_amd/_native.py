@@ -105,6 +105,8 @@ class ReferenceError_(Exception):
 def sample_reads(paths, read_len, nreads, fastq, quality_offset, min_quality, mean_quality, max_unknown, filter_dups, fasta_out=None):
     """Native process_seqfile: returns (reads uint8 (n, read_len), stats dict).  Needs no GPU."""
     lib = load_library()
+    if nreads is None:                   # the reference's "no cap" (its `read_id == args['nreads']` is never true for None)
+        nreads = (1 << 63) - 1
     arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
     r = lib.mc_reader_open(arr, len(paths), read_len, nreads, 1 if fastq else 0, int(quality_offset), float(min_quality), float(mean_quality),
                            float(max_unknown), 1 if filter_dups else 0, fasta_out.encode() if fasta_out else None)

@@ -1147,6 +1147,7 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
     if (device < 0 || device >= ndev) { g_err = "device index out of range"; return -1; }
     if (nfam > 32) { g_err = "at most 32 gene families are supported"; return -1; }
     const int nseq = h->H.nseq;
+    if (nseq > 32767) { g_err = "more than 32767 markers: the HSP sort key (read<<43 | subject<<28 | hit order) holds 15 bits of subject index"; return -1; }
     for (int s = 0; s < nseq; s++) if ((int)(h->H.off[s + 1] - h->H.off[s]) > MC_GAP_W - 8) { g_err = "marker longer than the gapped-extension workspace"; return -1; }
     if (marker_family) h->fam.assign(marker_family, marker_family + nseq); else h->fam.assign((size_t)nseq, 0);
     h->nfam = nfam; h->device = device;
@@ -1277,6 +1278,7 @@ static int ensure_capacity(mc_handle *h, int64_t nreads)
     // pool sizes: generous multiples of what shotgun reads produce (45-60 seed hits, 10-17 kept HSPs, 1-3 gapped
     // extensions per 100-150 bp read), scaled with the read length; a batch that still overflows is split by mc_search
     const int64_t L = h->read_len;
+    h->cap_reads = 0;                                               // pools are being replaced: nothing is usable until all of them exist
     h->cap_tasks = (uint32_t)std::min<int64_t>(cap * (L + 32) + (1 << 20) + (int64_t)256 * 16 * MC_EN_BLK, 0x7fffffff);
     h->cap_gaps = (uint32_t)std::min<int64_t>(cap * (L / 8 + 8) + (1 << 18), 0x7fffffff);
     h->cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 2 + 16) + (1 << 20), 0x7fffffff);

@@ -48,7 +48,8 @@ struct LineSource {   // bytes of a plain or gzip file, split into lines with un
     std::vector<unsigned char> ring[NBLK];
     size_t ring_n[NBLK] = {0, 0, 0};
     int head = 0, tail = 0, count = 0;
-    bool prod_done = false, stop = false;
+    bool prod_done = false, stop = false, prod_err = false;   // prod_err: the stream is truncated or corrupt (gzip.open raises there)
+    std::string prod_msg;
     std::vector<unsigned char> buf;
     size_t pos = 0, end = 0;
     bool eof = false, pending_cr = false;
@@ -75,7 +76,14 @@ struct LineSource {   // bytes of a plain or gzip file, split into lines with un
             }
             const int n = gzread(gz, ring[slot].data(), (unsigned)BLK);
             std::unique_lock<std::mutex> lk(mu);
-            if (n <= 0) { prod_done = true; cv.notify_all(); return; }
+            if (n <= 0) {
+                // gzip.open raises EOFError / BadGzipFile on a truncated or corrupt stream (reference :47-59); zlib reports a
+                // truncated stream as Z_BUF_ERROR, a damaged one as Z_DATA_ERROR - a clean end leaves Z_OK / Z_STREAM_END and gzeof
+                int errnum = 0;
+                const char *msg = gzerror(gz, &errnum);
+                if (n < 0 || (errnum != Z_OK && errnum != Z_STREAM_END) || !gzeof(gz)) { prod_err = true; prod_msg = msg ? msg : "read error"; }
+                prod_done = true; cv.notify_all(); return;
+            }
             ring_n[slot] = (size_t)n; tail = (tail + 1) % NBLK; count++;
             cv.notify_all();
         }
@@ -148,7 +156,6 @@ struct Parser {
     LineSource src;
     bool have_pending = false, done = false;
     std::string pending;                         // header line without its last character
-    bool bad = false;                            // the reference would raise (IndexError on an empty pending header)
     static void chomp(const unsigned char *p, size_t n, bool nl, std::string &out)
     { // line[:-1]
         if (!nl && n > 0) n--;
@@ -163,6 +170,7 @@ struct Parser {
                 if (!src.next(&p, &n, &nl)) { done = true; return false; }
                 if (n > 0 && (p[0] == '>' || p[0] == '@')) { chomp(p, n, nl, pending); have_pending = true; break; }
             }
+            if (pending.empty()) { done = true; return false; }        // a lone '>' / '@' without newline at the end of the file: `if not last: break`
         }
         have_pending = false;
         rec.seq.clear(); rec.qual.clear(); rec.has_qual = false;
@@ -174,7 +182,7 @@ struct Parser {
             rec.seq.append((const char *)p, m);
         }
         if (!got_next) { done = true; return true; }                 // last record of the file, no qualities
-        if (pending.empty()) { bad = true; done = true; return false; }   // pending[0] raises IndexError in the reference
+        if (pending.empty()) { done = true; return true; }           // `not last or last[0] != '+'` short-circuits on the empty header: the record goes out without qualities, the parser stops
         if (pending[0] != '+') { have_pending = true; return true; }
         size_t got = 0;
         bool complete = false;
@@ -336,7 +344,7 @@ extern "C" int64_t mc_reader_run(mc_reader *r)
             if (r->filter_dups) seen.insert(rec.seq);
             if (kept == r->nreads) break;
         }
-        if (ps.bad && rcode == 0) { r_err = "IndexError: empty header line at the end of " + path; rcode = -3; }
+        if (ps.src.prod_err && rcode == 0 && kept < r->nreads) { r_err = "EOFError: compressed file ended before the end-of-stream marker was reached (" + path + ": " + ps.src.prod_msg + ")"; rcode = -3; }
         ps.src.close();
         if (rcode < 0 || kept == r->nreads) break;
     }
@@ -359,9 +367,10 @@ extern "C" int64_t mc_count_bases(const char *const *paths, int32_t npaths)
         Parser ps;
         if (!ps.src.open(paths[i])) { r_err = std::string("cannot open ") + paths[i]; return -1; }
         while (ps.next(rec)) total += (int64_t)rec.seq.size();
-        bool bad = ps.bad;
+        const bool bad = ps.src.prod_err;
+        const std::string msg = ps.src.prod_msg;
         ps.src.close();
-        if (bad) { r_err = "IndexError: empty header line"; return -3; }
+        if (bad) { r_err = std::string("EOFError: compressed file ended before the end-of-stream marker was reached (") + paths[i] + ": " + msg + ")"; return -3; }
     }
     return total;
 }

@@ -129,7 +129,7 @@ def parse_seqs(fp):
                 if line[:1] in (">", "@"):
                     pending = line[:-1]
                     break
-            if pending is None:
+            if not pending:                      # end of file, or a lone '>' / '@' without newline as the last line
                 return
         name = pending[1:].partition(" ")[0]
         pending, chunks = None, []
@@ -139,9 +139,9 @@ def parse_seqs(fp):
                 break
             chunks.append(line[:-1])
         seq = "".join(chunks)
-        if pending is None or pending[0] != "+":
+        if not pending or pending[0] != "+":     # (a lone '+', '>' or '@' without newline as the last line leaves '')
             yield Sequence(name, seq)
-            if pending is None:
+            if not pending:
                 return
             continue
         quals, got, done = [], 0, False
@@ -316,7 +316,8 @@ def process_seqfile(args, paths):
     if _native_reader_usable(args):
         from . import _native
         try:
-            reads, st = _native.sample_reads(args["seqfiles"], L, args["nreads"], args["file_type"] == "fastq", args.get("quality_offset") or 0,
+            nreads = args["nreads"] if args["nreads"] is not None else (1 << 63) - 1      # None = no cap, as in the reference (read_id == None is never true)
+            reads, st = _native.sample_reads(args["seqfiles"], L, nreads, args["file_type"] == "fastq", args.get("quality_offset") or 0,
                                              args["min_quality"], args["mean_quality"], args["max_unknown"], args["filter_dups"], paths["tempfile"])
         except _native.ReferenceError_ as e:      # the reference raises here; run_pipeline prints it and returns None
             raise Exception(str(e))

@@ -10,6 +10,8 @@ uniformly over the genomes, strand by fair coin, error free.
 The generator is counter based (splitmix64 of seed and index), so every value is a pure function of
 (seed, index): identical on every platform and cheap to vectorise with numpy.
 """
+import os
+
 import numpy as np
 
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
@@ -105,3 +107,95 @@ def sample_reads(genome, nreads, read_len, seed=1, chunk=1 << 20):
         block[rev] = rc_map[block[rev][:, ::-1]]
         out[s:s + m] = block
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Reads from the reference's 30 real genomes; data fixture written by tests/golden/make_genomes_fixture.py
+# ---------------------------------------------------------------------------------------------------------------------
+GENOMES_NPZ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "genomes", "genomes30.npz")
+
+
+def load_genomes(path=None):
+    """(bases uint8 [total], contig_off int64 [ncontig + 1]) of the 30 genomes (251 contigs, 84.8 Mbp)."""
+    z = np.load(path or GENOMES_NPZ)
+    p = z["packed"]
+    b = np.empty((len(p), 4), dtype=np.uint8)
+    for k in range(4):
+        b[:, k] = (p >> (2 * k)) & 3
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[b.reshape(-1)[: int(z["contig_off"][-1])]]
+    bases[z["exc_pos"]] = z["exc_chr"]
+    return bases, z["contig_off"].astype(np.int64)
+
+
+def _t_splitmix64(x):
+    import torch
+    M = lambda v: torch.tensor(v, dtype=torch.int64, device=x.device)  # noqa: E731
+    lsr = lambda v, k: (v >> k) & ((1 << (64 - k)) - 1)                # noqa: E731  logical shift on int64
+    x = x + M(-7046029254386353131)                  # 0x9E3779B97F4A7C15
+    z = (x ^ lsr(x, 30)) * M(-4658895280553007687)   # 0xBF58476D1CE4E5B9
+    z = (z ^ lsr(z, 27)) * M(-7723592293110705685)   # 0x94D049BB133111EB
+    return z ^ lsr(z, 31)
+
+
+class GenomeReads:
+    """Error-free shotgun reads of the 30 genomes, generated with torch on any device (a pure function of (seed, read
+    index), so every rank / device / chunking produces the same read for the same index).  Start positions are uniform
+    over the positions of every contig that can hold the whole read (or fragment); strand by fair coin.
+
+    single(n, L): n reads.   paired(n, L, frag): n fragments of `frag` bases -> (mate1, mate2), mate 1 = the first L bases
+    of the fragment, mate 2 = the reverse complement of its last L bases (BASELINE configs[3]; the reference consumes the two
+    files one after the other, /root/reference/microbe_census/microbe_census.py:337-356)."""
+
+    def __init__(self, device="cpu", seed=20261001, path=None):
+        import torch
+        bases, off = load_genomes(path)
+        self.torch, self.device, self.seed = torch, torch.device(device), int(seed)
+        self.g = torch.from_numpy(bases).to(self.device)
+        self.off = torch.from_numpy(off).to(self.device)
+        self.clen = self.off[1:] - self.off[:-1]
+        rc = torch.zeros(256, dtype=torch.uint8)
+        for a, b in zip(b"ACGTN", b"TGCAN"):
+            rc[a] = b
+        for c in range(256):
+            if rc[c] == 0:
+                rc[c] = ord("N")
+        self.rc = rc.to(self.device)
+
+    def _starts(self, first, n, span):
+        torch = self.torch
+        valid = torch.clamp(self.clen - span + 1, min=0)
+        cum = torch.cumsum(valid, 0)
+        total = int(cum[-1].item())
+        idx = torch.arange(first, first + n, device=self.device, dtype=torch.int64)
+        v = _t_splitmix64(_t_splitmix64(idx + self.seed * 1000003))
+        u = ((v >> 1) & 0x7FFFFFFFFFFFFFFF) % total
+        c = torch.searchsorted(cum, u, right=True)
+        start = self.off[c] + (u - (cum[c] - valid[c]))
+        return start, (v & 1).bool()
+
+    def _take(self, start, rev, span, L):
+        """first L bases of the (strand-oriented) fragment [start, start+span)"""
+        torch = self.torch
+        ar = torch.arange(L, device=self.device, dtype=torch.int64)
+        fwd = self.g[start[:, None] + ar[None, :]]
+        back = self.rc[self.g[(start + span - 1)[:, None] - ar[None, :]].long()]
+        return torch.where(rev[:, None], back, fwd)
+
+    def single(self, n, L, first=0, chunk=1 << 20):
+        out = self.torch.empty((n, L), dtype=self.torch.uint8, device=self.device)
+        for s in range(0, n, chunk):
+            m = min(chunk, n - s)
+            start, rev = self._starts(first + s, m, L)
+            out[s:s + m] = self._take(start, rev, L, L)
+        return out
+
+    def paired(self, n, L, frag=400, first=0, chunk=1 << 20):
+        torch = self.torch
+        m1 = torch.empty((n, L), dtype=torch.uint8, device=self.device)
+        m2 = torch.empty((n, L), dtype=torch.uint8, device=self.device)
+        for s in range(0, n, chunk):
+            m = min(chunk, n - s)
+            start, rev = self._starts(first + s, m, frag)
+            m1[s:s + m] = self._take(start, rev, frag, L)
+            m2[s:s + m] = self._take(start, ~rev, frag, L)          # the other end, on the other strand
+        return m1, m2

@@ -71,7 +71,29 @@ def write_inputs():
     files["b.fq"] = fq.encode()
     files["b.fq.gz"] = gzip.compress(fq.encode())
     files["b_trunc.fq"] = (fq + "@last\n" + dna(80) + "\n+\n" + q_ok(40)).encode()
+    # a lone '+', '>' or '@' WITHOUT newline as the last line: `last = l[:-1]` leaves '' and the parser stops after the current record
+    files["b_loneplus.fq"] = (fq + "@last\n" + dna(80) + "\n+").encode()
+    files["a_lonegt.fa"] = (txt + ">").encode()
+    files["a_loneat.fa"] = (txt + "@").encode()
+    files["a_onlygt.fa"] = (">r0\n" + dna(60) + "\n\n@").encode()
     files["b_iupac.fa"] = (">x1\n" + dna(60) + "\n>x2\n" + dna(30) + "RYK" + dna(40) + "\n>x3\n" + dna(70) + "\n").encode()
+    # 4. BASELINE configs[4] in small: 300+ bp FASTQ, phred+33 qualities ~ clipped N(34, 6), 5 % of the reads with one base < 20 inside
+    #    the first 300, 2 % exact duplicates, 1 % reverse-complement duplicates, a few short reads
+    d, pool = "", []
+    for i in range(600):
+        u = rnd.random()
+        if pool and u < 0.02:
+            s = rnd.choice(pool)
+        elif pool and u < 0.03:
+            s = rc(rnd.choice(pool))
+        else:
+            s = dna(rnd.choice([250, 300, 301, 320, 350]))
+            pool.append(s)
+        q = [min(41, max(20, int(round(rnd.gauss(34, 6))))) for _ in s]
+        if rnd.random() < 0.05:
+            q[rnd.randrange(min(len(s), 300))] = rnd.choice([2, 10, 19])
+        d += "@d%d\n%s\n+\n%s\n" % (i, s, "".join(chr(33 + v) for v in q))
+    files["d.fq.gz"] = gzip.compress(d.encode())
     # 3. second FASTA for multi-file sampling
     files["c.fa.gz"] = gzip.compress("".join(">c%d\n%s\n" % (i, dna(100)) for i in range(40)).encode())
     os.makedirs(OUT, exist_ok=True)
@@ -104,6 +126,13 @@ CASES = [
     ("multi_dups", ["c.fa.gz", "c.fa.gz"], {"read_length": 100, "filter_dups": True}),
     ("iupac_dups", ["b_iupac.fa"], {"read_length": 50, "filter_dups": True}),
     ("none_left", ["a.fa"], {"read_length": 500}),
+    ("fq_lone_plus", ["b_loneplus.fq"], {"read_length": 50}),                      # last record has no qualities: TypeError in quality_filter
+    ("fq_lone_plus_n20", ["b_loneplus.fq"], {"read_length": 50, "nreads": 20}),
+    ("fa_lone_gt", ["a_lonegt.fa"], {"read_length": 50}),
+    ("fa_lone_at", ["a_loneat.fa", "c.fa.gz"], {"read_length": 50}),
+    ("fa_only_gt", ["a_onlygt.fa"], {"read_length": 50}),
+    ("fa_nreads_none", ["a.fa", "c.fa.gz"], {"read_length": 50, "nreads": None}),  # None = no cap (read_id == None is never true)
+    ("fq_q20_dups_300", ["d.fq.gz"], {"read_length": 300, "min_quality": 20, "filter_dups": True}),   # BASELINE configs[4] in small
 ]
 
 

@@ -111,3 +111,29 @@ def test_count_bases_comes_from_the_sampler_pass_when_it_saw_everything(tmp_path
     mc.process_seqfile(args, {"tempfile": str(tmp_path / "b.fa")})
     assert tuple(args["seqfiles"]) not in mc._bases_cache
     assert mc.count_bases(args) == case["count_bases"]
+
+
+def test_truncated_gz_is_an_error_not_a_short_file(tmp_path):
+    """gzip.open raises EOFError on a stream cut in half (reference open_file :47-59), run_pipeline prints it and returns None;
+    the native reader must not hand out a partial sample or a partial count_bases()."""
+    from microbecensus_amd import _native, microbe_census as mc
+    src = os.path.join(GOLD, "inputs", "example.fq.gz")
+    data = open(src, "rb").read()
+    cut = str(tmp_path / "cut.fq.gz")
+    with open(cut, "wb") as f:
+        f.write(data[: len(data) // 2])
+    with pytest.raises(_native.ReferenceError_) as e:
+        _native.sample_reads([cut], 100, 1000000, True, 32, -5, -5, 100, False)
+    assert "EOFError" in str(e.value)
+    with pytest.raises(_native.ReferenceError_):
+        _native.count_bases([cut])
+    # a sampler that stops (nreads reached) before the damage never sees it - like the reference's generator
+    reads, st = _native.sample_reads([cut], 100, 100, True, 32, -5, -5, 100, False)
+    assert st["sampled"] == 100
+    assert tuple([cut]) not in mc._bases_cache
+
+
+def test_nreads_none_means_no_cap():
+    from microbecensus_amd import _native
+    reads, st = _native.sample_reads([os.path.join(GOLD, "sampler", "a.fa")], 50, None, False, 0, -5, -5, 100, False)
+    assert st["sampled"] == 60 and st["exhausted"] == 1
