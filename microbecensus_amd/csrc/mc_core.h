@@ -1043,6 +1043,133 @@ MC_HDN McGapResult mc_align_gapped(const TT &T, const uint8_t *s1, int st1, cons
     return R;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same extension on a SLIDING WINDOW of W columns with 12-byte cells - the form k_gapped runs with the window in LDS.
+//
+// * Only the columns jStart-1 .. jEnd of the previous row are ever read again (jStart never decreases, a row writes every
+//   column it leaves behind up to its new jEnd), so the DP rows live in a circular buffer indexed by column mod W; a write to a
+//   column >= (jStart-1) + W means the band is wider than the window: overflow, the caller repeats the flank with
+//   mc_align_gapped on a full-size workspace.
+// * Path statistics in 32 bits: ident | diag << 8 | runs << 16 | cls << 24 (diag = number of substitution steps).  A path
+//   from the origin to cell (i, j) has i = diag + D-gap columns and j = diag + E-gap columns, so the gap columns and the number
+//   of steps need not be carried: gapcols = i + j - 2 diag, steps = i + j - diag.  No field can overflow: ident <= diag <=
+//   MC_MAXAA = 170 < 256; every gap run costs >= open + ext = 12 and every substitution step gains <= 11, and a path that is
+//   still alive scores >= -xdrop, so runs <= (11 * 170 + 27) / 12 = 158 < 256.
+// * Scores in 16 bits: |score| <= 11 * 170 + 64.
+// * The subject residue of a column travels with the column's cell (read from memory once, when the column enters the band).
+// WS: load(slot, H, D, PH, PD, y) / store(slot, H, D, PH, PD, y) / loadH(slot), slot = 0 .. W-1 (the accessor owns the layout).
+// ---------------------------------------------------------------------------------------------
+#define MC_PP_ZERO 0x03000000u
+MC_HD uint32_t mc_pp_gap(uint32_t p, uint32_t cls) { return ((p & 0x00FFFFFFu) + (((p >> 24) != cls) ? 0x10000u : 0u)) | (cls << 24); }
+MC_HD uint32_t mc_pp_diag(uint32_t p, bool same) { return (p & 0x00FFFFFFu) + 0x100u + (same ? 1u : 0u); }
+
+template <class TT, class WS>
+MC_HDN McGapResult mc_align_gapped_win(const TT &T, const uint8_t *s1, int st1, const uint8_t *s2, int st2, int n1, int n2, WS &ws, int W)
+{
+    const int open = MC_GAP_OPEN, ext = MC_GAP_EXT, first = MC_GAP_OPEN + MC_GAP_EXT;
+    McGapResult R; R.overflow = 0; R.gain = 0; R.c1 = 0; R.c2 = 0; R.ident = 0; R.steps = 0; R.runs = 0; R.gapcols = 0;
+    int jEnd = (int)((T.xdrop_gapped - (double)open) / (double)ext);
+    int best = 0, bestI = 0, bestJ = 0, jStart = 1;
+    uint32_t bestP = MC_PP_ZERO;
+    ws.store(0, 0, -open, MC_PP_ZERO, MC_PP_ZERO, 0);
+    if (n2 > 0 && jEnd > 0) {
+        int r = -open;
+        uint32_t pe = MC_PP_ZERO;
+        for (int j = 1;;) {
+            if (j >= W) { R.overflow = 1; return R; }
+            r -= ext;
+            pe = mc_pp_gap(pe, 1);
+            ws.store(j, r, r - open, pe, pe, s2[(j - 1) * st2]);
+            j++;
+            if (jEnd < j) break;
+            if (n2 < j) break;
+        }
+    }
+    if (n1 <= 0 || jEnd <= 1) return R;
+    const int xd = (int)T.xdrop_gapped;        // (double)best - xdrop > (double)h  <=>  best - h > (int)xdrop  (integers against a positive threshold)
+    int base = 0, cbase = 0;                   // lowest live column and its slot; slot of column j >= base: cbase + (j - base), minus W when >= W
+#define MC_WSLOT(j) ((cbase + ((j) - base)) >= W ? (cbase + ((j) - base)) - W : (cbase + ((j) - base)))
+    int x = s1[0];
+    for (int i = 1;;) {
+        { const int nb = jStart - 1; cbase = MC_WSLOT(nb); base = nb; }
+        const int xn = (i < n1) ? s1[i * st1] : 0;                     // next row's query residue: its load overlaps this row
+        int bH, bD, by; uint32_t bPH, bPD;
+        ws.load(cbase, bH, bD, bPH, bPD, by);
+        int diag = bH;
+        uint32_t pdiag = bPH;
+        int hprev = bH - first;
+        if (hprev < bD - ext) hprev = bD - ext;
+        const uint32_t pborder = mc_pp_gap((i == 1) ? bPH : bPD, 2);
+        ws.store(cbase, hprev, hprev, pborder, pborder, by);
+        int E = hprev - open, h = 0;
+        uint32_t pE = pborder, phprev = pborder;
+        bool grow = true, trim = true;
+        if (!(jStart > jEnd) && !(n2 < jStart)) {
+            int cj = cbase;
+            for (int j = jStart;;) {
+                if (j - base >= W) { R.overflow = 1; return R; }
+                cj = (cj + 1 == W) ? 0 : cj + 1;
+                int cH, cD, y; uint32_t cPH, cPD;
+                ws.load(cj, cH, cD, cPH, cPD, y);
+                int a = hprev - first, b = E - ext, Dn;
+                uint32_t npE, npD;
+                if (a >= b) { E = a; npE = mc_pp_gap(phprev, 1); }
+                else { E = b; npE = mc_pp_gap(pE, 1); }
+                a = cH - first; b = cD - ext;
+                if (a >= b) { Dn = a; npD = mc_pp_gap(cPH, 2); }
+                else { Dn = b; npD = mc_pp_gap(cPD, 2); }
+                const int s = diag + MC_SUB(T, x, y);
+                uint32_t np = mc_pp_diag(pdiag, x == y);
+                h = s;
+                if (E > h) { h = E; np = npE; }
+                if (h < Dn) { h = Dn; np = npD; }
+                diag = cH; pdiag = cPH;
+                ws.store(cj, h, Dn, np, npD, y);
+                pE = npE; phprev = np; hprev = h;
+                if (h > best) { best = h; bestI = i; bestJ = j; bestP = np; }
+                else if (best - h > xd && j > bestJ) {
+                    if (j >= jEnd) { jEnd = j; }
+                    else { jEnd = j; grow = false; trim = false; }
+                    break;
+                }
+                j++;
+                if (n2 < j) break;
+                if (j > jEnd) break;
+            }
+        }
+        if (grow) {
+            for (int j = jEnd + 1; !(n2 < j); j++) {
+                if (j - base >= W) { R.overflow = 1; return R; }
+                const int a = hprev - first, b = E - ext;
+                uint32_t npE;
+                if (a > b) { E = a; npE = mc_pp_gap(phprev, 1); }
+                else { E = b; npE = mc_pp_gap(pE, 1); }
+                ws.store(MC_WSLOT(j), E, E - open, npE, npE, s2[(j - 1) * st2]);
+                pE = npE; phprev = npE;
+                if (E > best) { best = E; bestI = i; bestJ = j; bestP = npE; }
+                else if (best - E > xd) { jEnd = j; break; }
+                hprev = E;
+            }
+        }
+        if (trim && !(jStart > bestJ)) {
+            if (best - ws.loadH(MC_WSLOT(bestJ)) > xd) jStart = bestJ;
+            else { int k = bestJ; for (;;) { k--; if (jStart > k) break; if (best - ws.loadH(MC_WSLOT(k)) > xd) { jStart = k; break; } } }
+        }
+        i++;
+        x = xn;
+        if (n1 < i) break;
+        if (!(jStart < jEnd)) break;
+    }
+#undef MC_WSLOT
+    R.gain = best; R.c1 = bestI; R.c2 = bestJ;
+    if (best > 0) {
+        const int diagn = (int)((bestP >> 8) & 0xFF);
+        R.ident = (int)(bestP & 0xFF); R.runs = (int)((bestP >> 16) & 0xFF);
+        R.gapcols = bestI + bestJ - 2 * diagn; R.steps = bestI + bestJ - diagn;
+    }
+    return R;
+}
+
 // finalise one HSP (CalRes@0x4077a0 up to the keep test).  Returns false when the HSP is not kept.
 MC_HD bool mc_make_hsp(const McTables &T, int ntlen, int frame, const McGapTask &g, int qfwd, int dfwd, int qbwd, int dbwd,
                        int score, int nmatch, int alnlen, int gapopens, int gaptotal, McHsp *h)

@@ -40,7 +40,7 @@ extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
         }                                                                                                   \
     } while (0)
 
-enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_HEAVY, C_HEAVY2, C_N = 12 };
+enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_HEAVY, C_HEAVY2, C_UNIQ, C_RETRY2, C_N = 16 };
 enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_N = 16 };   // 64-bit algorithmic-traffic counters of k_enumerate; slots 4..: cycle counters of the MC_EXP_TIMING build
 
 // ------------------------------------------------------------------------------------------------
@@ -269,6 +269,26 @@ __device__ __forceinline__ uint32_t mc_wave_alloc(uint32_t *counter, bool want)
     if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
     base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
     return base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+}
+
+// one atomic per 256-thread workgroup (every thread of the block must call it): a device-scope atomic on ONE counter runs at
+// the memory side at ~125 M/s, so even one per wave is too many for kernels of millions of threads
+__device__ __forceinline__ uint32_t mc_block_alloc(uint32_t *counter, bool want)
+{
+    __shared__ uint32_t wcnt[4], wbase[4];
+    const unsigned long long m = __ballot(want);
+    const int lane = mc_lane(), wv = threadIdx.x >> 6;
+    if (lane == 0) wcnt[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3], tot = c0 + c1 + c2 + c3;
+        const uint32_t b = tot ? atomicAdd(counter, tot) : 0u;
+        wbase[0] = b; wbase[1] = b + c0; wbase[2] = b + c0 + c1; wbase[3] = b + c0 + c1 + c2;
+    }
+    __syncthreads();
+    const uint32_t r = wbase[wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+    __syncthreads();                                             // (the arrays are reused by the next call)
+    return r;
 }
 
 // copies the hot members of the tables into LDS (block-wide; callers __syncthreads() afterwards)
@@ -807,66 +827,178 @@ __global__ void __launch_bounds__(256) k_eval_seeds(const McTables *__restrict__
     }
 }
 
-// sort key of a gap task: the number of query residues its two flanks can still consume (= DP rows); tasks of similar
-// size then share a wave
-__global__ void k_gap_keys(const McGapTask *__restrict__ gaps, uint32_t ngaps, int L, uint32_t *key, uint32_t *idx)
+// Gap tasks are massively redundant: a read that really comes from a marker gene hits every seed of its diagonal, and the
+// ungapped X-drop extension of all of them ends in the same segment - same read, frame, subject, start and end.  The gapped
+// extension of both flanks depends on nothing else, so it is computed once per distinct segment (2.7 x fewer DPs on reads of
+// real genomes) and every task of the group gets its own HSP from the leader's result (the reference keeps them all until
+// CalRes compares coordinates; so do we).  Grouping: one open-addressing table of 64-bit entries (tag | task index + 1),
+// claimed with a CAS; equal tags are verified on the task records themselves.  Which member of a group becomes its leader
+// depends on timing; the results do not.
+struct McGapOut { int16_t c1r, c2r, c1l, c2l, dscore, dnmatch, dsteps, runs, gapcols, over; };   // what the two flanks added (20 B)
+
+__device__ __forceinline__ bool mc_gap_same_segment(const McGapTask &a, const McGapTask &b)
+{
+    return a.read == b.read && a.sidx == b.sidx && (a.chrono >> 25) == (b.chrono >> 25) && a.qp - a.qbwd == b.qp - b.qbwd && a.dp - a.qbwd == b.dp - b.qbwd &&
+           a.qp + a.L + a.qfwd == b.qp + b.L + b.qfwd;
+}
+__global__ void __launch_bounds__(256) k_gap_dedupe(const McGapTask *__restrict__ gaps, uint32_t ngaps, unsigned long long *tab, uint32_t mask, uint32_t *leader,
+                                                    uint32_t *uniq, uint32_t *counters)
+{
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    bool lead = false;
+    if (p < ngaps) {
+        const McGapTask g = gaps[p];
+        unsigned long long h = ((unsigned long long)g.read << 32) ^ ((unsigned long long)g.sidx << 12) ^ (unsigned long long)(g.chrono >> 25);
+        h ^= ((unsigned long long)(uint16_t)(g.qp - g.qbwd) << 48) ^ ((unsigned long long)(uint16_t)(g.dp - g.qbwd) << 20) ^ ((unsigned long long)(uint16_t)(g.qp + g.L + g.qfwd) << 3);
+        h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+        const unsigned long long mine = (h & ~0x7FFFFFFull) | (unsigned long long)(p + 1);          // tag: the upper 37 bits of the hash
+        uint32_t slot = (uint32_t)h & mask, who = p;
+        for (;;) {
+            unsigned long long e = tab[slot];
+            if (e == 0) e = atomicCAS(&tab[slot], 0ull, mine);
+            if (e == 0) { lead = true; break; }
+            if ((e & ~0x7FFFFFFull) == (mine & ~0x7FFFFFFull)) {
+                const uint32_t q = (uint32_t)(e & 0x7FFFFFFull) - 1;
+                if (mc_gap_same_segment(g, gaps[q])) { who = q; break; }
+            }
+            slot = (slot + 1) & mask;
+        }
+        leader[p] = who;
+    }
+    const uint32_t o = mc_block_alloc(&counters[C_UNIQ], lead);
+    if (lead) uniq[o] = p;
+}
+
+// sort key of a (distinct) gap task: the number of query residues its two flanks can still consume (= DP rows); tasks of
+// similar size then share a wave
+// (launched over all ngaps slots: the slots behind the distinct tasks get key 0 and sort to the end)
+__global__ void k_gap_keys(const McGapTask *__restrict__ gaps, const uint32_t *__restrict__ uniq, const uint32_t *__restrict__ nuniq_p, uint32_t ngaps, int L, uint32_t *key, uint32_t *idx)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ngaps) return;
-    const McGapTask g = gaps[k];
+    if (k >= *nuniq_p) { key[k] = 0; idx[k] = 0xFFFFFFFFu; return; }
+    const uint32_t p = uniq[k];
+    const McGapTask g = gaps[p];
     const int frame = (int)(g.chrono >> 25), qlen = (L - frame % 3) / 3;
     const int qright = qlen - (g.qfwd + g.qp + g.L), qleft = g.qp - g.qbwd;
-    key[k] = (uint32_t)((qright > 0 ? qright : 0) + (qleft > 0 ? qleft : 0));
-    idx[k] = k;
+    key[k] = 1u + (uint32_t)((qright > 0 ? qright : 0) + (qleft > 0 ? qleft : 0));
+    idx[k] = p;
+}
+
+// every gap task -> its HSP, from the result of its group's leader
+__global__ void __launch_bounds__(256) k_gap_emit(const McTables *__restrict__ T, int L, const McGapTask *__restrict__ gaps, uint32_t ngaps, const uint32_t *__restrict__ leader,
+                                                  const McGapOut *__restrict__ gout, McHsp *hsps, uint32_t cap_hsps, uint32_t *counters)
+{
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    McHsp h;
+    if (p < ngaps) {
+        const McGapTask g = gaps[p];
+        const McGapOut o = gout[leader[p]];
+        const int frame = (int)(g.chrono >> 25);
+        h.read = g.read; h.chrono = g.chrono;
+        keep = mc_make_hsp(*T, L, frame, g, g.qfwd + o.c1r, g.qfwd + o.c2r, g.qbwd + o.c1l, g.qbwd + o.c2l, g.score + o.dscore, g.nmatch + o.dnmatch,
+                           g.qfwd + g.L + g.qbwd + o.dsteps, o.runs, o.gapcols, &h);
+    }
+    const uint32_t o = mc_block_alloc(&counters[C_HSPS], keep);
+    if (keep) { if (o < cap_hsps) hsps[o] = h; else counters[C_OVERFLOW] = 2; }
 }
 
 #define MC_GAP_W 1200   // columns of the full-size DP workspace (markers are <= 1183 aa, checked in mc_open)
+#define MC_GAP_WIN 40   // columns of the LDS window of the first launch (30 KB per wave: five waves per CU)
+#define MC_GAP_WIN2 64  // ... of the second one, for the tasks whose band left the first (48 KB per wave)
 
-// Gapped extension of both flanks, one thread per gap task.  First launch: every thread owns a SMALL workspace (cap
-// columns of 24 bytes, contiguous) - the band stays near the diagonal, and 262 k threads striding through 7 GB of
-// full-size workspaces spent their time in TLB misses (15 ms, of which the arithmetic is ~1).  A flank whose band leaves
-// the small workspace makes its task go to the retry list, which a second launch handles with full-size workspaces.
+// both flanks of one gap task; align(s1, stride1, s2, stride2, n1, n2) is the DP form the kernel uses
+template <class Align>
+__device__ __forceinline__ McGapOut mc_gap_both_flanks(const McGapTask &g, const uint8_t *q, int qlen, const uint8_t *d, int dlen, Align &&align)
+{
+    McGapOut o; o.c1r = 0; o.c2r = 0; o.c1l = 0; o.c2l = 0; o.dscore = 0; o.dnmatch = 0; o.dsteps = 0; o.runs = 0; o.gapcols = 0; o.over = 0;
+    const int qend = g.qfwd + g.qp + g.L, dend = g.qfwd + g.dp + g.L, dright = dlen - dend, qright = qlen - qend;
+    if (dright > 2 && qright > 2) {
+        const McGapResult R = align(q + qend, 1, d + dend, 1, qright, dright);
+        if (R.overflow) { o.over = 1; return o; }
+        if (R.gain > 0) { o.dscore += (int16_t)R.gain; o.dnmatch += (int16_t)R.ident; o.c1r = (int16_t)R.c1; o.c2r = (int16_t)R.c2; o.dsteps += (int16_t)R.steps; o.runs += (int16_t)R.runs; o.gapcols += (int16_t)R.gapcols; }
+    }
+    const int dleft = g.dp - g.qbwd, qleft = g.qp - g.qbwd;
+    if (dleft > 2 && qleft > 2) {
+        const McGapResult R = align(q + qleft - 1, -1, d + dleft - 1, -1, qleft, dleft);
+        if (R.overflow) { o.over = 1; return o; }
+        if (R.gain > 0) { o.dscore += (int16_t)R.gain; o.dnmatch += (int16_t)R.ident; o.c1l = (int16_t)R.c1; o.c2l = (int16_t)R.c2; o.dsteps += (int16_t)R.steps; o.runs += (int16_t)R.runs; o.gapcols += (int16_t)R.gapcols; }
+    }
+    return o;
+}
+
+// Gapped extension with full-size DP rows in global memory (24 bytes per column, one row set per thread): the retry launch for
+// the few tasks whose band leaves the LDS window of k_gapped_lds.
 __global__ void __launch_bounds__(128) k_gapped(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
-                                                const McGapTask *__restrict__ gaps, const uint32_t *__restrict__ list, uint32_t ngaps, McHsp *hsps, uint32_t cap_hsps,
-                                                uint32_t *counters, McGapCell *ws, int cap, uint32_t *retry)
+                                                const McGapTask *__restrict__ gaps, const uint32_t *__restrict__ list, const uint32_t *__restrict__ ngaps_p, McGapOut *gout, uint32_t *counters,
+                                                McGapCell *ws, int cap)
 {
     __shared__ McHot hot;
+    const uint32_t ngaps = *ngaps_p;                             // (a device-side count: usually 0 - nothing left the window)
+    if (ngaps == 0) return;
     mc_load_hot(&hot, T);
     __syncthreads();
-    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
     McGapCell *C = ws + (size_t)tid * cap;
     for (uint32_t k0 = tid; k0 < ngaps; k0 += nthreads) {
-        const uint32_t k = list ? list[k0] : k0;
-        McGapTask g = gaps[k];
-        int frame = (int)(g.chrono >> 25);
-        int qlen = (L - frame % 3) / 3;
-        const uint8_t *q = frames + ((int64_t)g.read * 6 + frame) * FP;
+        const uint32_t k = list[k0];
+        const McGapTask g = gaps[k];
+        const int frame = (int)(g.chrono >> 25), qlen = (L - frame % 3) / 3;
         const uint8_t *d = X.res + X.off[g.sidx];
-        int dlen = (int)(X.off[g.sidx + 1] - X.off[g.sidx]);
-        int score = g.score, nmatch = g.nmatch, qfwd = g.qfwd, dfwd = g.qfwd, qbwd = g.qbwd, dbwd = g.qbwd;
-        int alnlen = g.qfwd + g.L + g.qbwd, gapopens = 0, gaptotal = 0;
-        int qend = qfwd + g.qp + g.L, dend = dfwd + g.dp + g.L, dright = dlen - dend, qright = qlen - qend;
-        bool over = false;
-        if (dright > 2 && qright > 2) {
-            McGapResult R = mc_align_gapped(hot, q + qend, 1, d + dend, 1, qright, dright, C, cap);
-            over = R.overflow != 0;
-            if (R.gain > 0) { score += R.gain; nmatch += R.ident; qfwd += R.c1; dfwd += R.c2; alnlen += R.steps; gapopens += R.runs; gaptotal += R.gapcols; }
-        }
-        int dleft = g.dp - dbwd, qleft = g.qp - qbwd;
-        if (!over && dleft > 2 && qleft > 2) {
-            McGapResult R = mc_align_gapped(hot, q + qleft - 1, -1, d + dleft - 1, -1, qleft, dleft, C, cap);
-            over = R.overflow != 0;
-            if (R.gain > 0) { score += R.gain; nmatch += R.ident; qbwd += R.c1; dbwd += R.c2; alnlen += R.steps; gapopens += R.runs; gaptotal += R.gapcols; }
-        }
-        if (over) {                                               // band left the small workspace: the whole task is redone later
-            if (retry) retry[atomicAdd(&counters[C_RETRY], 1u)] = k; else counters[C_OVERFLOW] = 5;
-            continue;
-        }
-        McHsp h;
-        h.read = g.read; h.chrono = g.chrono;
-        const bool keep = mc_make_hsp(*T, L, frame, g, qfwd, dfwd, qbwd, dbwd, score, nmatch, alnlen, gapopens, gaptotal, &h);
-        const uint32_t o = mc_wave_alloc(&counters[C_HSPS], keep);
-        if (keep) { if (o < cap_hsps) hsps[o] = h; else counters[C_OVERFLOW] = 2; }
+        const McGapOut o = mc_gap_both_flanks(g, frames + ((int64_t)g.read * 6 + frame) * FP, qlen, d, (int)(X.off[g.sidx + 1] - X.off[g.sidx]),
+                                              [&](const uint8_t *s1, int st1, const uint8_t *s2, int st2, int n1, int n2) { return mc_align_gapped(hot, s1, st1, s2, st2, n1, n2, C, cap); });
+        if (o.over) counters[C_OVERFLOW] = 5;
+        gout[k] = o;
+    }
+}
+
+// Gapped extension, first launch: one thread per (distinct) gap task with its DP rows in LDS.  mc_align_gapped_win keeps only
+// the live band (a circular window of W columns, 12 bytes per column: scores 12 + 12 bits and the subject residue in one word,
+// the two path-statistics words) - nothing of the DP touches global memory.  Layout: word (slot, lane) of a wave's window sits at
+// slot * 64 + lane, so whatever slots the 64 lanes are working on they fall into 64 different banks.  A flank whose band is
+// wider than the window (0.02 % of the flanks of 150 bp reads at W = 40) sends its task to the retry list: k_gapped with
+// full-size rows in global memory.  Tasks arrive ordered by DP size, so the lanes of a wave run loops of similar length.
+template <int W>
+struct McGapLds {
+    uint32_t *hd, *ph, *pd;                                        // this lane's column 0 of the three word arrays
+    __device__ __forceinline__ void load(int c, int &H, int &D, uint32_t &PH, uint32_t &PD, int &y) const
+    {
+        const uint32_t w = hd[c * 64];
+        H = (int)(w << 20) >> 20; D = (int)(w << 8) >> 20; y = (int)(w >> 24);
+        PH = ph[c * 64]; PD = pd[c * 64];
+    }
+    __device__ __forceinline__ void store(int c, int H, int D, uint32_t PH, uint32_t PD, int y)
+    {
+        hd[c * 64] = ((uint32_t)H & 0xFFFu) | (((uint32_t)D & 0xFFFu) << 12) | ((uint32_t)y << 24);
+        ph[c * 64] = PH; pd[c * 64] = PD;
+    }
+    __device__ __forceinline__ int loadH(int c) const { return (int)(hd[c * 64] << 20) >> 20; }
+};
+
+template <int W>
+__global__ void __launch_bounds__(64) k_gapped_lds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
+                                                   const McGapTask *__restrict__ gaps, const uint32_t *__restrict__ list, const uint32_t *__restrict__ ngaps_p, McGapOut *gout,
+                                                   uint32_t *counters, uint32_t *retry)
+{
+    __shared__ McHot hot;
+    __shared__ uint32_t win[3 * W * 64];
+    const uint32_t ngaps = *ngaps_p;                             // distinct tasks (device-side count)
+    mc_load_hot(&hot, T);
+    __syncthreads();
+    const int lane = threadIdx.x;
+    McGapLds<W> ws; ws.hd = win + lane; ws.ph = win + W * 64 + lane; ws.pd = win + 2 * W * 64 + lane;
+    const uint32_t tid = blockIdx.x * 64 + threadIdx.x, nthreads = gridDim.x * 64;
+    for (uint32_t k0 = tid; k0 < ngaps; k0 += nthreads) {
+        const uint32_t k = list[k0];
+        const McGapTask g = gaps[k];
+        const int frame = (int)(g.chrono >> 25), qlen = (L - frame % 3) / 3;
+        const uint8_t *d = X.res + X.off[g.sidx];
+        const McGapOut o = mc_gap_both_flanks(g, frames + ((int64_t)g.read * 6 + frame) * FP, qlen, d, (int)(X.off[g.sidx + 1] - X.off[g.sidx]),
+                                              [&](const uint8_t *s1, int st1, const uint8_t *s2, int st2, int n1, int n2) { return mc_align_gapped_win(hot, s1, st1, s2, st2, n1, n2, ws, W); });
+        gout[k] = o;
+        const uint32_t ro = mc_wave_alloc(&counters[C_RETRY], o.over != 0);                 // band left the window: the task is redone with full-size rows
+        if (o.over) retry[ro] = k;
     }
 }
 
@@ -1095,8 +1227,8 @@ struct mc_handle {
     uint64_t *d_k64 = nullptr, *d_k64o = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
     uint32_t *d_counters = nullptr;
     McRow *d_rows = nullptr; uint32_t *d_nrow = nullptr, *d_rowoff = nullptr; McBestHit *d_best = nullptr; uint8_t *d_mark = nullptr;
-    McGapCell *d_gws = nullptr, *d_gws_full = nullptr; uint32_t *d_retry = nullptr; int gap_cap = 0, gap_threads_full = 0;
-    int gap_threads = 0;
+    McGapCell *d_gws_full = nullptr; uint32_t *d_retry = nullptr, *d_retry2 = nullptr; int gap_threads_full = 0;
+    unsigned long long *d_gtab = nullptr; uint32_t gtab_slots = 0; uint32_t *d_gleader = nullptr, *d_guniq = nullptr; McGapOut *d_gout = nullptr;
     // host results: rows of the last batch land in pinned memory; mc_search() accumulates its batches in all_rows
     mc_row *pin_rows = nullptr; size_t pin_cap = 0;
     std::vector<mc_row> all_rows;
@@ -1130,7 +1262,7 @@ extern "C" void mc_close(mc_handle *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_frames, h->d_tasks, h->d_gaps, h->d_hsps,
                     h->d_sorted, h->d_v, h->d_tmp, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, h->d_heads, h->d_sorttmp, h->d_counters, h->d_rows,
-                    h->d_nrow, h->d_rowoff, h->d_best, h->d_mark, h->d_gws, h->d_gws_full, h->d_retry, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_rt};
+                    h->d_nrow, h->d_rowoff, h->d_best, h->d_mark, h->d_gws_full, h->d_retry, h->d_retry2, h->d_gtab, h->d_gleader, h->d_guniq, h->d_gout, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_rt};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->pin_rows) (void)hipHostFree(h->pin_rows);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -1283,14 +1415,15 @@ static int ensure_capacity(mc_handle *h, int64_t nreads)
     h->cap_gaps = (uint32_t)std::min<int64_t>(cap * (L / 8 + 8) + (1 << 18), 0x7fffffff);
     h->cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 2 + 16) + (1 << 20), 0x7fffffff);
     h->cap_rows = (uint32_t)std::min<int64_t>(cap * 48 + (1 << 20), 0x7fffffff);
-    h->gap_threads = 1024 * 1024; h->gap_cap = (h->FP + 32 + 15) & ~15;   // small DP workspaces: frame length + 32 columns of 24 bytes each
+
     h->gap_threads_full = 16 * 1024;                                      // full-size ones for the retry launch (460 MB)
     if (dalloc(&h->d_frames, (size_t)cap * 6 * h->FP + 64) || dalloc(&h->d_tasks, h->cap_tasks) ||
         dalloc(&h->d_gaps, h->cap_gaps) || dalloc(&h->d_hsps, h->cap_hsps) || dalloc(&h->d_sorted, h->cap_hsps) || dalloc(&h->d_v, h->cap_hsps) ||
         dalloc(&h->d_tmp, (size_t)h->cap_hsps * 2) || dalloc(&h->d_k64, h->cap_hsps) || dalloc(&h->d_k64o, h->cap_hsps) || dalloc(&h->d_idx, h->cap_hsps) ||
         dalloc(&h->d_idxo, h->cap_hsps) || dalloc(&h->d_heads, (size_t)cap + 1) || dalloc(&h->d_rows, h->cap_rows) ||
-        dalloc(&h->d_mark, (size_t)h->cap_hsps) || dalloc(&h->d_nrow, (size_t)cap + 1) || dalloc(&h->d_rowoff, (size_t)cap + 1) || dalloc(&h->d_best, (size_t)cap + 1) || dalloc(&h->d_gws, (size_t)h->gap_threads * h->gap_cap) ||
-        dalloc(&h->d_gws_full, (size_t)h->gap_threads_full * MC_GAP_W) || dalloc(&h->d_retry, (size_t)h->cap_gaps))
+        dalloc(&h->d_mark, (size_t)h->cap_hsps) || dalloc(&h->d_nrow, (size_t)cap + 1) || dalloc(&h->d_rowoff, (size_t)cap + 1) || dalloc(&h->d_best, (size_t)cap + 1) ||
+        dalloc(&h->d_gws_full, (size_t)h->gap_threads_full * MC_GAP_W) || dalloc(&h->d_retry, (size_t)h->cap_gaps) || dalloc(&h->d_retry2, (size_t)h->cap_gaps) || dalloc(&h->d_gleader, (size_t)h->cap_gaps) ||
+        dalloc(&h->d_guniq, (size_t)h->cap_gaps) || dalloc(&h->d_gout, (size_t)h->cap_gaps))
         return -1;
     size_t bytes = 0, bytes2 = 0;
     HIPCK(rocprim::radix_sort_pairs(nullptr, bytes, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, (size_t)h->cap_hsps, 0, 64, h->stream));
@@ -1385,19 +1518,23 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
     if (c[C_OVERFLOW]) { g_err = "HSP / gap task buffer overflow"; return -2; }
     uint32_t ngaps = c[C_GAPS];
     if (ngaps) {
-        int blocks = std::min<int>(h->gap_threads / 128, (int)((ngaps + 127) / 128));
-        // order of work: by DP size (the sort buffers of the HSP sort are idle at this point)
+        // 1. group the tasks that extend the same ungapped segment (k_gap_dedupe); 2. order the distinct ones by DP size (the sort
+        // buffers of the HSP sort are idle at this point); 3. extend them with the DP rows in LDS, the few whose band leaves the
+        // window again with full-size rows; 4. every task takes its HSP from its group's result.  Counts stay on the device.
+        uint32_t slots = 1u << 16;
+        while (slots < 2 * ngaps) slots <<= 1;
+        if (slots > h->gtab_slots) { if (dalloc(&h->d_gtab, (size_t)slots)) return -1; h->gtab_slots = slots; }
+        HIPCK(hipMemsetAsync(h->d_gtab, 0, (size_t)slots * 8, st));
+        k_gap_dedupe<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_gaps, ngaps, h->d_gtab, slots - 1, h->d_gleader, h->d_guniq, h->d_counters);
         uint32_t *gk = (uint32_t *)h->d_k64, *gko = gk + ngaps, *gi = h->d_idx, *gio = h->d_idxo;
-        k_gap_keys<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_gaps, ngaps, L, gk, gi);
+        k_gap_keys<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_gaps, h->d_guniq, h->d_counters + C_UNIQ, ngaps, L, gk, gi);
         size_t gbytes = h->sorttmp_bytes;
         HIPCK(rocprim::radix_sort_pairs_desc(h->d_sorttmp, gbytes, gk, gko, gi, gio, (size_t)ngaps, 0, 10, st));
-        k_gapped<<<dim3(blocks), dim3(128), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, gio, ngaps, h->d_hsps, h->cap_hsps, h->d_counters, h->d_gws, h->gap_cap, h->d_retry);
-        HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
-        HIPCK(hipStreamSynchronize(st));
-        if (const uint32_t nretry = c[C_RETRY]) {                  // tasks whose band left the small workspace
-            blocks = std::min<int>(h->gap_threads_full / 128, (int)((nretry + 127) / 128));
-            k_gapped<<<dim3(blocks), dim3(128), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, h->d_retry, nretry, h->d_hsps, h->cap_hsps, h->d_counters, h->d_gws_full, MC_GAP_W, nullptr);
-        }
+        k_gapped_lds<MC_GAP_WIN><<<dim3(std::min<uint32_t>((ngaps + 63) / 64, 256u * 5u * 4u)), dim3(64), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, gio, h->d_counters + C_UNIQ, h->d_gout,
+                                                                                                             h->d_counters, h->d_retry);
+        k_gapped_lds<MC_GAP_WIN2><<<dim3(256u * 3u), dim3(64), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, h->d_retry, h->d_counters + C_RETRY, h->d_gout, h->d_counters + (C_RETRY2 - C_RETRY), h->d_retry2);
+        k_gapped<<<dim3(h->gap_threads_full / 128), dim3(128), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, h->d_retry2, h->d_counters + C_RETRY2, h->d_gout, h->d_counters, h->d_gws_full, MC_GAP_W);
+        k_gap_emit<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_T, L, h->d_gaps, ngaps, h->d_gleader, h->d_gout, h->d_hsps, h->cap_hsps, h->d_counters);
     }
     HIPCK(hipEventRecord(h->ev[4], st));
     HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));

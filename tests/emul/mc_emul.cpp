@@ -181,6 +181,26 @@ int main(int argc, char **argv)
     }
     fprintf(stderr, "ungapped hsps: %zu gapped tasks: %zu\n", hsps.size(), gaps.size());
     std::vector<McGapCell> cells(2100);
+    // the windowed 12-byte-cell form the kernel runs (mc_align_gapped_win) must return what the full-size form returns
+    struct HostWin {
+        std::vector<int> H, D, Y; std::vector<uint32_t> PH, PD;
+        explicit HostWin(int w) : H(w), D(w), Y(w), PH(w), PD(w) {}
+        void load(int c, int &h, int &d, uint32_t &ph, uint32_t &pd, int &y) const { h = H[c]; d = D[c]; ph = PH[c]; pd = PD[c]; y = Y[c]; }
+        void store(int c, int h, int d, uint32_t ph, uint32_t pd, int y)
+        {   // the kernel's cell packs H and D into 12 bits each and the residue into 5: what it would read back
+            H[c] = (int)((uint32_t)h << 20) >> 20; D[c] = (int)((uint32_t)d << 20) >> 20; PH[c] = ph; PD[c] = pd; Y[c] = y & 31;
+        }
+        int loadH(int c) const { return H[c]; }
+    };
+    const int WIN = getenv("MC_GAP_WIN") ? atoi(getenv("MC_GAP_WIN")) : 32;
+    long win_flanks = 0, win_over = 0, win_bad = 0;
+    auto check_win = [&](const McGapResult &R, const uint8_t *s1, int st1, const uint8_t *s2, int st2, int n1, int n2) {
+        HostWin ws(WIN);
+        const McGapResult Q = mc_align_gapped_win(T, s1, st1, s2, st2, n1, n2, ws, WIN);
+        win_flanks++;
+        if (Q.overflow) { win_over++; return; }
+        if (Q.gain != R.gain || Q.c1 != R.c1 || Q.c2 != R.c2 || Q.ident != R.ident || Q.steps != R.steps || Q.runs != R.runs || Q.gapcols != R.gapcols) win_bad++;
+    };
     for (const McGapTask &g : gaps) {
         int frame = (int)(g.chrono >> 25);
         const uint8_t *q = &frames[((size_t)g.read * 6 + frame) * FP]; int qlen = flen[(size_t)g.read * 6 + frame];
@@ -190,16 +210,20 @@ int main(int argc, char **argv)
         int qend = qfwd + g.qp + g.L, dend = dfwd + g.dp + g.L, dright = dlen - dend, qright = qlen - qend;
         if (dright > 2 && qright > 2) {
             McGapResult R = mc_align_gapped(T, q + qend, 1, d + dend, 1, qright, dright, cells.data(), (int)cells.size());
+            check_win(R, q + qend, 1, d + dend, 1, qright, dright);
             if (R.gain > 0) { score += R.gain; nmatch += R.ident; qfwd += R.c1; dfwd += R.c2; alnlen += R.steps; gapopens += R.runs; gaptotal += R.gapcols; }
         }
         int dleft = g.dp - dbwd, qleft = g.qp - qbwd;
         if (dleft > 2 && qleft > 2) {
             McGapResult R = mc_align_gapped(T, q + qleft - 1, -1, d + dleft - 1, -1, qleft, dleft, cells.data(), (int)cells.size());
+            check_win(R, q + qleft - 1, -1, d + dleft - 1, -1, qleft, dleft);
             if (R.gain > 0) { score += R.gain; nmatch += R.ident; qbwd += R.c1; dbwd += R.c2; alnlen += R.steps; gapopens += R.runs; gaptotal += R.gapcols; }
         }
         McHsp h; h.read = g.read; h.chrono = g.chrono;
         if (mc_make_hsp(T, read_len, frame, g, qfwd, dfwd, qbwd, dbwd, score, nmatch, alnlen, gapopens, gaptotal, &h)) hsps.push_back(h);
     }
+    fprintf(stderr, "gapped window check (W = %d): %ld flanks, %ld leave the window, %ld differ from the full-size form\n", WIN, win_flanks, win_over, win_bad);
+    if (win_bad) return 3;
     // stage 5: sort by (read, subject, chrono)
     std::sort(hsps.begin(), hsps.end(), [](const McHsp &a, const McHsp &b) { if (a.read != b.read) return a.read < b.read; if (a.sidx != b.sidx) return a.sidx < b.sidx; return a.chrono < b.chrono; });
     fprintf(stderr, "hsps kept: %zu\n", hsps.size());
