@@ -40,7 +40,7 @@ extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
         }                                                                                                   \
     } while (0)
 
-enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_HEAVY, C_HEAVY2, C_UNIQ, C_RETRY2, C_N = 16 };
+enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_HEAVY, C_HEAVY2, C_ITEMS, C_RETRY2, C_N = 16 };
 enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_N = 16 };   // 64-bit algorithmic-traffic counters of k_enumerate; slots 4..: cycle counters of the MC_EXP_TIMING build
 
 // ------------------------------------------------------------------------------------------------
@@ -834,18 +834,61 @@ __global__ void __launch_bounds__(256) k_eval_seeds(const McTables *__restrict__
 // CalRes compares coordinates; so do we).  Grouping: one open-addressing table of 64-bit entries (tag | task index + 1),
 // claimed with a CAS; equal tags are verified on the task records themselves.  Which member of a group becomes its leader
 // depends on timing; the results do not.
-struct McGapOut { int16_t c1r, c2r, c1l, c2l, dscore, dnmatch, dsteps, runs, gapcols, over; };   // what the two flanks added (20 B)
+// The unit of DP work is ONE FLANK of a distinct segment (item = 2 x leader task + side): the two flanks of a task have
+// unrelated sizes (a seed near the read's left end has a long right flank), and a wave whose lanes run flank loops of
+// different lengths one after the other idles most of the time.  Items are ordered by their number of DP rows.
+struct McFlankOut { int16_t gain, c1, c2, ident, steps, runs, gapcols, over; };   // what one flank added (16 B)
+
+// side 0: right flank, walked forwards; side 1: left flank, walked backwards in place.  Returns false when the reference does
+// not extend that flank (AlignSeqs 0x413599, 0x4135a9: more than 2 residues must remain on both sequences).
+struct McFlank { int qoff, doff, st, n1, n2; };
+__device__ __forceinline__ bool mc_flank_of(const McGapTask &g, int qlen, int dlen, int side, McFlank &f)
+{
+    if (side == 0) {
+        const int qend = g.qfwd + g.qp + g.L, dend = g.qfwd + g.dp + g.L;
+        f.qoff = qend; f.doff = dend; f.st = 1; f.n1 = qlen - qend; f.n2 = dlen - dend;
+    } else {
+        const int qleft = g.qp - g.qbwd, dleft = g.dp - g.qbwd;
+        f.qoff = qleft - 1; f.doff = dleft - 1; f.st = -1; f.n1 = qleft; f.n2 = dleft;
+    }
+    return f.n1 > 2 && f.n2 > 2;
+}
 
 __device__ __forceinline__ bool mc_gap_same_segment(const McGapTask &a, const McGapTask &b)
 {
     return a.read == b.read && a.sidx == b.sidx && (a.chrono >> 25) == (b.chrono >> 25) && a.qp - a.qbwd == b.qp - b.qbwd && a.dp - a.qbwd == b.dp - b.qbwd &&
            a.qp + a.L + a.qfwd == b.qp + b.L + b.qfwd;
 }
-__global__ void __launch_bounds__(256) k_gap_dedupe(const McGapTask *__restrict__ gaps, uint32_t ngaps, unsigned long long *tab, uint32_t mask, uint32_t *leader,
-                                                    uint32_t *uniq, uint32_t *counters)
+
+// consecutive slots of a global counter for n (0..2) entries per thread, one atomic per 256-thread workgroup
+__device__ __forceinline__ uint32_t mc_block_alloc_n(uint32_t *counter, uint32_t n)
+{
+    __shared__ uint32_t wcnt[4], wbase[4];
+    const int lane = mc_lane(), wv = threadIdx.x >> 6;
+    uint32_t incl = n;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+    if (lane == 63) wcnt[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3], tot = c0 + c1 + c2 + c3;
+        const uint32_t b = tot ? atomicAdd(counter, tot) : 0u;
+        wbase[0] = b; wbase[1] = b + c0; wbase[2] = b + c0 + c1; wbase[3] = b + c0 + c1 + c2;
+    }
+    __syncthreads();
+    const uint32_t r = wbase[wv] + incl - n;
+    __syncthreads();
+    return r;
+}
+
+// groups the tasks (leader[p] = first task of p's segment to claim the table slot) and lists the flanks of the leaders with
+// their sort keys (1 + DP rows; the slots behind the list keep key 0 from the memset and sort to the end)
+__global__ void __launch_bounds__(256) k_gap_dedupe(McIndex X, int L, const McGapTask *__restrict__ gaps, uint32_t ngaps, unsigned long long *tab, uint32_t mask, uint32_t *leader,
+                                                    uint32_t *key, uint32_t *item, uint32_t *counters)
 {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-    bool lead = false;
+    uint32_t n = 0;
+    McFlank fr, fl;
+    bool hr = false, hl = false;
     if (p < ngaps) {
         const McGapTask g = gaps[p];
         unsigned long long h = ((unsigned long long)g.read << 32) ^ ((unsigned long long)g.sidx << 12) ^ (unsigned long long)(g.chrono >> 25);
@@ -853,6 +896,7 @@ __global__ void __launch_bounds__(256) k_gap_dedupe(const McGapTask *__restrict_
         h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
         const unsigned long long mine = (h & ~0x7FFFFFFull) | (unsigned long long)(p + 1);          // tag: the upper 37 bits of the hash
         uint32_t slot = (uint32_t)h & mask, who = p;
+        bool lead = false;
         for (;;) {
             unsigned long long e = tab[slot];
             if (e == 0) e = atomicCAS(&tab[slot], 0ull, mine);
@@ -864,41 +908,40 @@ __global__ void __launch_bounds__(256) k_gap_dedupe(const McGapTask *__restrict_
             slot = (slot + 1) & mask;
         }
         leader[p] = who;
+        if (lead) {
+            const int frame = (int)(g.chrono >> 25), qlen = (L - frame % 3) / 3, dlen = (int)(X.off[g.sidx + 1] - X.off[g.sidx]);
+            hr = mc_flank_of(g, qlen, dlen, 0, fr); hl = mc_flank_of(g, qlen, dlen, 1, fl);
+            n = (hr ? 1u : 0u) + (hl ? 1u : 0u);
+        }
     }
-    const uint32_t o = mc_block_alloc(&counters[C_UNIQ], lead);
-    if (lead) uniq[o] = p;
+    uint32_t o = mc_block_alloc_n(&counters[C_ITEMS], n);
+    if (hr) { key[o] = 1u + (uint32_t)fr.n1; item[o] = 2 * p; o++; }
+    if (hl) { key[o] = 1u + (uint32_t)fl.n1; item[o] = 2 * p + 1; }
 }
 
-// sort key of a (distinct) gap task: the number of query residues its two flanks can still consume (= DP rows); tasks of
-// similar size then share a wave
-// (launched over all ngaps slots: the slots behind the distinct tasks get key 0 and sort to the end)
-__global__ void k_gap_keys(const McGapTask *__restrict__ gaps, const uint32_t *__restrict__ uniq, const uint32_t *__restrict__ nuniq_p, uint32_t ngaps, int L, uint32_t *key, uint32_t *idx)
-{
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= ngaps) return;
-    if (k >= *nuniq_p) { key[k] = 0; idx[k] = 0xFFFFFFFFu; return; }
-    const uint32_t p = uniq[k];
-    const McGapTask g = gaps[p];
-    const int frame = (int)(g.chrono >> 25), qlen = (L - frame % 3) / 3;
-    const int qright = qlen - (g.qfwd + g.qp + g.L), qleft = g.qp - g.qbwd;
-    key[k] = 1u + (uint32_t)((qright > 0 ? qright : 0) + (qleft > 0 ? qleft : 0));
-    idx[k] = p;
-}
-
-// every gap task -> its HSP, from the result of its group's leader
-__global__ void __launch_bounds__(256) k_gap_emit(const McTables *__restrict__ T, int L, const McGapTask *__restrict__ gaps, uint32_t ngaps, const uint32_t *__restrict__ leader,
-                                                  const McGapOut *__restrict__ gout, McHsp *hsps, uint32_t cap_hsps, uint32_t *counters)
+// every gap task -> its HSP, from the flank results of its group's leader
+__global__ void __launch_bounds__(256) k_gap_emit(const McTables *__restrict__ T, McIndex X, int L, const McGapTask *__restrict__ gaps, uint32_t ngaps, const uint32_t *__restrict__ leader,
+                                                  const McFlankOut *__restrict__ fout, McHsp *hsps, uint32_t cap_hsps, uint32_t *counters)
 {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     bool keep = false;
     McHsp h;
     if (p < ngaps) {
         const McGapTask g = gaps[p];
-        const McGapOut o = gout[leader[p]];
-        const int frame = (int)(g.chrono >> 25);
+        const uint32_t ld = leader[p];
+        const int frame = (int)(g.chrono >> 25), qlen = (L - frame % 3) / 3, dlen = (int)(X.off[g.sidx + 1] - X.off[g.sidx]);
+        int score = g.score, nmatch = g.nmatch, qfwd = g.qfwd, dfwd = g.qfwd, qbwd = g.qbwd, dbwd = g.qbwd, alnlen = g.qfwd + g.L + g.qbwd, gapopens = 0, gaptotal = 0;
+        McFlank f;
+        if (mc_flank_of(g, qlen, dlen, 0, f)) {
+            const McFlankOut R = fout[2 * (size_t)ld];
+            if (R.gain > 0) { score += R.gain; nmatch += R.ident; qfwd += R.c1; dfwd += R.c2; alnlen += R.steps; gapopens += R.runs; gaptotal += R.gapcols; }
+        }
+        if (mc_flank_of(g, qlen, dlen, 1, f)) {
+            const McFlankOut R = fout[2 * (size_t)ld + 1];
+            if (R.gain > 0) { score += R.gain; nmatch += R.ident; qbwd += R.c1; dbwd += R.c2; alnlen += R.steps; gapopens += R.runs; gaptotal += R.gapcols; }
+        }
         h.read = g.read; h.chrono = g.chrono;
-        keep = mc_make_hsp(*T, L, frame, g, g.qfwd + o.c1r, g.qfwd + o.c2r, g.qbwd + o.c1l, g.qbwd + o.c2l, g.score + o.dscore, g.nmatch + o.dnmatch,
-                           g.qfwd + g.L + g.qbwd + o.dsteps, o.runs, o.gapcols, &h);
+        keep = mc_make_hsp(*T, L, frame, g, qfwd, dfwd, qbwd, dbwd, score, nmatch, alnlen, gapopens, gaptotal, &h);
     }
     const uint32_t o = mc_block_alloc(&counters[C_HSPS], keep);
     if (keep) { if (o < cap_hsps) hsps[o] = h; else counters[C_OVERFLOW] = 2; }
@@ -906,59 +949,48 @@ __global__ void __launch_bounds__(256) k_gap_emit(const McTables *__restrict__ T
 
 #define MC_GAP_W 1200   // columns of the full-size DP workspace (markers are <= 1183 aa, checked in mc_open)
 #define MC_GAP_WIN 40   // columns of the LDS window of the first launch (30 KB per wave: five waves per CU)
-#define MC_GAP_WIN2 64  // ... of the second one, for the tasks whose band left the first (48 KB per wave)
+#define MC_GAP_WIN2 64  // ... of the second one, for the flanks whose band left the first (48 KB per wave)
 
-// both flanks of one gap task; align(s1, stride1, s2, stride2, n1, n2) is the DP form the kernel uses
-template <class Align>
-__device__ __forceinline__ McGapOut mc_gap_both_flanks(const McGapTask &g, const uint8_t *q, int qlen, const uint8_t *d, int dlen, Align &&align)
+__device__ __forceinline__ McFlankOut mc_flank_out(const McGapResult &R)
 {
-    McGapOut o; o.c1r = 0; o.c2r = 0; o.c1l = 0; o.c2l = 0; o.dscore = 0; o.dnmatch = 0; o.dsteps = 0; o.runs = 0; o.gapcols = 0; o.over = 0;
-    const int qend = g.qfwd + g.qp + g.L, dend = g.qfwd + g.dp + g.L, dright = dlen - dend, qright = qlen - qend;
-    if (dright > 2 && qright > 2) {
-        const McGapResult R = align(q + qend, 1, d + dend, 1, qright, dright);
-        if (R.overflow) { o.over = 1; return o; }
-        if (R.gain > 0) { o.dscore += (int16_t)R.gain; o.dnmatch += (int16_t)R.ident; o.c1r = (int16_t)R.c1; o.c2r = (int16_t)R.c2; o.dsteps += (int16_t)R.steps; o.runs += (int16_t)R.runs; o.gapcols += (int16_t)R.gapcols; }
-    }
-    const int dleft = g.dp - g.qbwd, qleft = g.qp - g.qbwd;
-    if (dleft > 2 && qleft > 2) {
-        const McGapResult R = align(q + qleft - 1, -1, d + dleft - 1, -1, qleft, dleft);
-        if (R.overflow) { o.over = 1; return o; }
-        if (R.gain > 0) { o.dscore += (int16_t)R.gain; o.dnmatch += (int16_t)R.ident; o.c1l = (int16_t)R.c1; o.c2l = (int16_t)R.c2; o.dsteps += (int16_t)R.steps; o.runs += (int16_t)R.runs; o.gapcols += (int16_t)R.gapcols; }
-    }
+    McFlankOut o;
+    o.gain = (int16_t)R.gain; o.c1 = (int16_t)R.c1; o.c2 = (int16_t)R.c2; o.ident = (int16_t)R.ident; o.steps = (int16_t)R.steps; o.runs = (int16_t)R.runs;
+    o.gapcols = (int16_t)R.gapcols; o.over = (int16_t)R.overflow;
     return o;
 }
 
-// Gapped extension with full-size DP rows in global memory (24 bytes per column, one row set per thread): the retry launch for
-// the few tasks whose band leaves the LDS window of k_gapped_lds.
+// Gapped extension with full-size DP rows in global memory (24 bytes per column, one row set per thread): the last resort for
+// the flanks whose band leaves both LDS windows of k_gapped_lds.
 __global__ void __launch_bounds__(128) k_gapped(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
-                                                const McGapTask *__restrict__ gaps, const uint32_t *__restrict__ list, const uint32_t *__restrict__ ngaps_p, McGapOut *gout, uint32_t *counters,
-                                                McGapCell *ws, int cap)
+                                                const McGapTask *__restrict__ gaps, const uint32_t *__restrict__ list, const uint32_t *__restrict__ nitems_p, McFlankOut *fout,
+                                                uint32_t *counters, McGapCell *ws, int cap)
 {
     __shared__ McHot hot;
-    const uint32_t ngaps = *ngaps_p;                             // (a device-side count: usually 0 - nothing left the window)
-    if (ngaps == 0) return;
+    const uint32_t nitems = *nitems_p;                            // (a device-side count: usually 0 - nothing left the windows)
+    if (nitems == 0) return;
     mc_load_hot(&hot, T);
     __syncthreads();
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
     McGapCell *C = ws + (size_t)tid * cap;
-    for (uint32_t k0 = tid; k0 < ngaps; k0 += nthreads) {
-        const uint32_t k = list[k0];
-        const McGapTask g = gaps[k];
+    for (uint32_t k0 = tid; k0 < nitems; k0 += nthreads) {
+        const uint32_t it = list[k0];
+        const McGapTask g = gaps[it >> 1];
         const int frame = (int)(g.chrono >> 25), qlen = (L - frame % 3) / 3;
-        const uint8_t *d = X.res + X.off[g.sidx];
-        const McGapOut o = mc_gap_both_flanks(g, frames + ((int64_t)g.read * 6 + frame) * FP, qlen, d, (int)(X.off[g.sidx + 1] - X.off[g.sidx]),
-                                              [&](const uint8_t *s1, int st1, const uint8_t *s2, int st2, int n1, int n2) { return mc_align_gapped(hot, s1, st1, s2, st2, n1, n2, C, cap); });
-        if (o.over) counters[C_OVERFLOW] = 5;
-        gout[k] = o;
+        const uint32_t o0 = X.off[g.sidx];
+        McFlank f;
+        (void)mc_flank_of(g, qlen, (int)(X.off[g.sidx + 1] - o0), (int)(it & 1), f);
+        const McGapResult R = mc_align_gapped(hot, frames + ((int64_t)g.read * 6 + frame) * FP + f.qoff, f.st, X.res + o0 + f.doff, f.st, f.n1, f.n2, C, cap);
+        if (R.overflow) counters[C_OVERFLOW] = 5;
+        fout[it] = mc_flank_out(R);
     }
 }
 
-// Gapped extension, first launch: one thread per (distinct) gap task with its DP rows in LDS.  mc_align_gapped_win keeps only
-// the live band (a circular window of W columns, 12 bytes per column: scores 12 + 12 bits and the subject residue in one word,
-// the two path-statistics words) - nothing of the DP touches global memory.  Layout: word (slot, lane) of a wave's window sits at
+// Gapped extension: one thread per flank item with its DP rows in LDS.  mc_align_gapped_win keeps only the live band (a
+// circular window of W columns, 12 bytes per column: scores 12 + 12 bits and the subject residue in one word, the two
+// path-statistics words) - nothing of the DP touches global memory.  Layout: word (slot, lane) of a wave's window sits at
 // slot * 64 + lane, so whatever slots the 64 lanes are working on they fall into 64 different banks.  A flank whose band is
-// wider than the window (0.02 % of the flanks of 150 bp reads at W = 40) sends its task to the retry list: k_gapped with
-// full-size rows in global memory.  Tasks arrive ordered by DP size, so the lanes of a wave run loops of similar length.
+// wider than the window (0.02 % of the flanks of 150 bp reads at W = 40) goes to the retry list: the same kernel with a
+// 64-column window, and behind that k_gapped with full-size rows in global memory.
 template <int W>
 struct McGapLds {
     uint32_t *hd, *ph, *pd;                                        // this lane's column 0 of the three word arrays
@@ -976,29 +1008,34 @@ struct McGapLds {
     __device__ __forceinline__ int loadH(int c) const { return (int)(hd[c * 64] << 20) >> 20; }
 };
 
-template <int W>
+template <int W, int LANES>
 __global__ void __launch_bounds__(64) k_gapped_lds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
-                                                   const McGapTask *__restrict__ gaps, const uint32_t *__restrict__ list, const uint32_t *__restrict__ ngaps_p, McGapOut *gout,
-                                                   uint32_t *counters, uint32_t *retry)
+                                                   const McGapTask *__restrict__ gaps, const uint32_t *__restrict__ list, const uint32_t *__restrict__ nitems_p, McFlankOut *fout,
+                                                   uint32_t *retry_count, uint32_t *retry)
 {
     __shared__ McHot hot;
     __shared__ uint32_t win[3 * W * 64];
-    const uint32_t ngaps = *ngaps_p;                             // distinct tasks (device-side count)
+    const uint32_t nitems = *nitems_p;                            // device-side count
+    if (nitems == 0) return;
     mc_load_hot(&hot, T);
     __syncthreads();
     const int lane = threadIdx.x;
     McGapLds<W> ws; ws.hd = win + lane; ws.ph = win + W * 64 + lane; ws.pd = win + 2 * W * 64 + lane;
-    const uint32_t tid = blockIdx.x * 64 + threadIdx.x, nthreads = gridDim.x * 64;
-    for (uint32_t k0 = tid; k0 < ngaps; k0 += nthreads) {
-        const uint32_t k = list[k0];
-        const McGapTask g = gaps[k];
+    // LANES < 64 (the retry launch: few, large, unequal flanks): only the first LANES lanes of a wave take items, so that the
+    // wave's run time is that of a few flanks, not of 64 different ones one after the other
+    if (lane >= LANES) return;
+    const uint32_t tid = blockIdx.x * LANES + threadIdx.x, nthreads = gridDim.x * LANES;
+    for (uint32_t k0 = tid; k0 < nitems; k0 += nthreads) {
+        const uint32_t it = list[k0];
+        const McGapTask g = gaps[it >> 1];
         const int frame = (int)(g.chrono >> 25), qlen = (L - frame % 3) / 3;
-        const uint8_t *d = X.res + X.off[g.sidx];
-        const McGapOut o = mc_gap_both_flanks(g, frames + ((int64_t)g.read * 6 + frame) * FP, qlen, d, (int)(X.off[g.sidx + 1] - X.off[g.sidx]),
-                                              [&](const uint8_t *s1, int st1, const uint8_t *s2, int st2, int n1, int n2) { return mc_align_gapped_win(hot, s1, st1, s2, st2, n1, n2, ws, W); });
-        gout[k] = o;
-        const uint32_t ro = mc_wave_alloc(&counters[C_RETRY], o.over != 0);                 // band left the window: the task is redone with full-size rows
-        if (o.over) retry[ro] = k;
+        const uint32_t o0 = X.off[g.sidx];
+        McFlank f;
+        (void)mc_flank_of(g, qlen, (int)(X.off[g.sidx + 1] - o0), (int)(it & 1), f);
+        const McGapResult R = mc_align_gapped_win(hot, frames + ((int64_t)g.read * 6 + frame) * FP + f.qoff, f.st, X.res + o0 + f.doff, f.st, f.n1, f.n2, ws, W);
+        fout[it] = mc_flank_out(R);
+        const uint32_t ro = mc_wave_alloc(retry_count, R.overflow != 0);                    // band left the window: the flank is redone with a wider one
+        if (R.overflow) retry[ro] = it;
     }
 }
 
@@ -1228,7 +1265,7 @@ struct mc_handle {
     uint32_t *d_counters = nullptr;
     McRow *d_rows = nullptr; uint32_t *d_nrow = nullptr, *d_rowoff = nullptr; McBestHit *d_best = nullptr; uint8_t *d_mark = nullptr;
     McGapCell *d_gws_full = nullptr; uint32_t *d_retry = nullptr, *d_retry2 = nullptr; int gap_threads_full = 0;
-    unsigned long long *d_gtab = nullptr; uint32_t gtab_slots = 0; uint32_t *d_gleader = nullptr, *d_guniq = nullptr; McGapOut *d_gout = nullptr;
+    unsigned long long *d_gtab = nullptr; uint32_t gtab_slots = 0; uint32_t *d_gleader = nullptr; McFlankOut *d_fout = nullptr;
     // host results: rows of the last batch land in pinned memory; mc_search() accumulates its batches in all_rows
     mc_row *pin_rows = nullptr; size_t pin_cap = 0;
     std::vector<mc_row> all_rows;
@@ -1262,7 +1299,7 @@ extern "C" void mc_close(mc_handle *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_frames, h->d_tasks, h->d_gaps, h->d_hsps,
                     h->d_sorted, h->d_v, h->d_tmp, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, h->d_heads, h->d_sorttmp, h->d_counters, h->d_rows,
-                    h->d_nrow, h->d_rowoff, h->d_best, h->d_mark, h->d_gws_full, h->d_retry, h->d_retry2, h->d_gtab, h->d_gleader, h->d_guniq, h->d_gout, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_rt};
+                    h->d_nrow, h->d_rowoff, h->d_best, h->d_mark, h->d_gws_full, h->d_retry, h->d_retry2, h->d_gtab, h->d_gleader, h->d_fout, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_rt};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->pin_rows) (void)hipHostFree(h->pin_rows);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -1422,14 +1459,14 @@ static int ensure_capacity(mc_handle *h, int64_t nreads)
         dalloc(&h->d_tmp, (size_t)h->cap_hsps * 2) || dalloc(&h->d_k64, h->cap_hsps) || dalloc(&h->d_k64o, h->cap_hsps) || dalloc(&h->d_idx, h->cap_hsps) ||
         dalloc(&h->d_idxo, h->cap_hsps) || dalloc(&h->d_heads, (size_t)cap + 1) || dalloc(&h->d_rows, h->cap_rows) ||
         dalloc(&h->d_mark, (size_t)h->cap_hsps) || dalloc(&h->d_nrow, (size_t)cap + 1) || dalloc(&h->d_rowoff, (size_t)cap + 1) || dalloc(&h->d_best, (size_t)cap + 1) ||
-        dalloc(&h->d_gws_full, (size_t)h->gap_threads_full * MC_GAP_W) || dalloc(&h->d_retry, (size_t)h->cap_gaps) || dalloc(&h->d_retry2, (size_t)h->cap_gaps) || dalloc(&h->d_gleader, (size_t)h->cap_gaps) ||
-        dalloc(&h->d_guniq, (size_t)h->cap_gaps) || dalloc(&h->d_gout, (size_t)h->cap_gaps))
+        dalloc(&h->d_gws_full, (size_t)h->gap_threads_full * MC_GAP_W) || dalloc(&h->d_retry, (size_t)h->cap_gaps * 2) || dalloc(&h->d_retry2, (size_t)h->cap_gaps * 2) || dalloc(&h->d_gleader, (size_t)h->cap_gaps) ||
+        dalloc(&h->d_fout, (size_t)h->cap_gaps * 2))
         return -1;
     size_t bytes = 0, bytes2 = 0;
     HIPCK(rocprim::radix_sort_pairs(nullptr, bytes, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, (size_t)h->cap_hsps, 0, 64, h->stream));
     HIPCK(rocprim::exclusive_scan(nullptr, bytes2, h->d_idx, h->d_idxo, 0u, (size_t)h->cap_hsps, rocprim::plus<uint32_t>(), h->stream));
     bytes = std::max(bytes, bytes2);
-    HIPCK(rocprim::radix_sort_pairs_desc(nullptr, bytes2, h->d_idx, h->d_idxo, h->d_idx, h->d_idxo, (size_t)h->cap_gaps, 0, 10, h->stream));
+    HIPCK(rocprim::radix_sort_pairs_desc(nullptr, bytes2, h->d_idx, h->d_idxo, h->d_idx, h->d_idxo, (size_t)h->cap_gaps * 2, 0, 10, h->stream));
     bytes = std::max(bytes, bytes2);
     if (h->d_sorttmp) { (void)hipFree(h->d_sorttmp); h->d_sorttmp = nullptr; }
     HIPCK(hipMalloc(&h->d_sorttmp, bytes + 16));
@@ -1524,17 +1561,17 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         uint32_t slots = 1u << 16;
         while (slots < 2 * ngaps) slots <<= 1;
         if (slots > h->gtab_slots) { if (dalloc(&h->d_gtab, (size_t)slots)) return -1; h->gtab_slots = slots; }
+        uint32_t *gk = (uint32_t *)h->d_k64, *gko = gk + 2 * (size_t)ngaps, *gi = h->d_idx, *gio = h->d_idxo;     // (2 ngaps <= cap_hsps: see ensure_capacity)
         HIPCK(hipMemsetAsync(h->d_gtab, 0, (size_t)slots * 8, st));
-        k_gap_dedupe<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_gaps, ngaps, h->d_gtab, slots - 1, h->d_gleader, h->d_guniq, h->d_counters);
-        uint32_t *gk = (uint32_t *)h->d_k64, *gko = gk + ngaps, *gi = h->d_idx, *gio = h->d_idxo;
-        k_gap_keys<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_gaps, h->d_guniq, h->d_counters + C_UNIQ, ngaps, L, gk, gi);
+        HIPCK(hipMemsetAsync(gk, 0, (size_t)ngaps * 8, st));
+        k_gap_dedupe<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(X, L, h->d_gaps, ngaps, h->d_gtab, slots - 1, h->d_gleader, gk, gi, h->d_counters);
         size_t gbytes = h->sorttmp_bytes;
-        HIPCK(rocprim::radix_sort_pairs_desc(h->d_sorttmp, gbytes, gk, gko, gi, gio, (size_t)ngaps, 0, 10, st));
-        k_gapped_lds<MC_GAP_WIN><<<dim3(std::min<uint32_t>((ngaps + 63) / 64, 256u * 5u * 4u)), dim3(64), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, gio, h->d_counters + C_UNIQ, h->d_gout,
-                                                                                                             h->d_counters, h->d_retry);
-        k_gapped_lds<MC_GAP_WIN2><<<dim3(256u * 3u), dim3(64), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, h->d_retry, h->d_counters + C_RETRY, h->d_gout, h->d_counters + (C_RETRY2 - C_RETRY), h->d_retry2);
-        k_gapped<<<dim3(h->gap_threads_full / 128), dim3(128), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, h->d_retry2, h->d_counters + C_RETRY2, h->d_gout, h->d_counters, h->d_gws_full, MC_GAP_W);
-        k_gap_emit<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_T, L, h->d_gaps, ngaps, h->d_gleader, h->d_gout, h->d_hsps, h->cap_hsps, h->d_counters);
+        HIPCK(rocprim::radix_sort_pairs_desc(h->d_sorttmp, gbytes, gk, gko, gi, gio, (size_t)ngaps * 2, 0, 10, st));
+        k_gapped_lds<MC_GAP_WIN, 64><<<dim3(std::min<uint32_t>((2 * ngaps + 63) / 64, 256u * 5u * 4u)), dim3(64), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, gio, h->d_counters + C_ITEMS, h->d_fout,
+                                                                                                                 h->d_counters + C_RETRY, h->d_retry);
+        k_gapped_lds<MC_GAP_WIN2, 4><<<dim3(256u * 3u * 4u), dim3(64), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, h->d_retry, h->d_counters + C_RETRY, h->d_fout, h->d_counters + C_RETRY2, h->d_retry2);
+        k_gapped<<<dim3(h->gap_threads_full / 128), dim3(128), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, h->d_retry2, h->d_counters + C_RETRY2, h->d_fout, h->d_counters, h->d_gws_full, MC_GAP_W);
+        k_gap_emit<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, L, h->d_gaps, ngaps, h->d_gleader, h->d_fout, h->d_hsps, h->cap_hsps, h->d_counters);
     }
     HIPCK(hipEventRecord(h->ev[4], st));
     HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
