@@ -40,7 +40,7 @@ extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
         }                                                                                                   \
     } while (0)
 
-enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_HEAVY, C_HEAVY2, C_ITEMS, C_RETRY2, C_N = 16 };
+enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_HEAVY, C_HEAVY2, C_ITEMS, C_RETRY2, C_HEAVY3, C_N = 16 };
 enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_N = 16 };   // 64-bit algorithmic-traffic counters of k_enumerate; slots 4..: cycle counters of the MC_EXP_TIMING build
 
 // ------------------------------------------------------------------------------------------------
@@ -1072,22 +1072,27 @@ __global__ void k_heads(const uint32_t *__restrict__ flags, const uint32_t *__re
 
 
 #define MC_FH_MIN 96      // reads with more HSPs than this are finished by a whole wave (k_finish_heavy)
-#define MC_FH_MAXN 1536   // ... up to this many in the standard form (34 KB of LDS per wave, four waves per CU; balances the three kernels)
-#define MC_FH_BIGN 6144   // ... up to this many in the large form (132 KB, one wave per CU); beyond, back to the single thread
+#define MC_FH_N1 512      // subjects / ranked HSPs a read may have in the first wave kernel (11 KB of LDS per wave) ...
+#define MC_FH_N2 2048     // ... in the second (45 KB) ...
+#define MC_FH_N3 6144     // ... and in the third (135 KB, one wave per CU), where anything larger is finished by lane 0 alone
 
-// The reads that get a wave of their own (k_finish_heavy), collected before the finishing kernels start so that the three of
-// them can run side by side on separate streams.  A read without a marked HSP prints nothing whatever its size.
-__global__ void k_heavy_lists(const uint32_t *__restrict__ heads, uint32_t nheads, uint32_t nhsps, const uint8_t *__restrict__ mark, uint32_t *nrow_of,
-                              uint32_t *counters, uint32_t *heavy, uint32_t *heavy2)
+// The reads that get a wave of their own (k_finish_heavy), collected before the finishing kernels start so that they can run
+// beside the thread-per-read kernel on a second stream.  A read without a marked HSP prints nothing whatever its size.
+__global__ void __launch_bounds__(256) k_heavy_lists(const uint32_t *__restrict__ heads, uint32_t nheads, uint32_t nhsps, const uint8_t *__restrict__ mark, uint32_t *nrow_of,
+                                                     McBestHit *best_of, uint32_t *counters, uint32_t *heavy)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nheads) return;
-    const uint32_t a = heads[s], b = (s + 1 < nheads) ? heads[s + 1] : nhsps, n = b - a;
-    if (n <= MC_FH_MIN || n > MC_FH_BIGN) return;
-    uint32_t any = 0;
-    for (uint32_t k = a; k < b; k++) any |= mark[k];
-    if (!any) { nrow_of[s] = 0; return; }
-    if (n <= MC_FH_MAXN) heavy[atomicAdd(&counters[C_HEAVY], 1u)] = s; else heavy2[atomicAdd(&counters[C_HEAVY2], 1u)] = s;
+    bool want = false;
+    if (s < nheads) {
+        const uint32_t a = heads[s], b = (s + 1 < nheads) ? heads[s + 1] : nhsps, n = b - a;
+        if (n > MC_FH_MIN) {
+            uint32_t any = 0;
+            for (uint32_t k = a; k < b; k++) any |= mark[k];
+            if (!any) { nrow_of[s] = 0; best_of[s].family = -1; } else want = true;
+        }
+    }
+    const uint32_t o = mc_block_alloc(&counters[C_HEAVY], want);
+    if (want) heavy[o] = s;
 }
 
 // One thread per read that has HSPs, in ascending read order.  All scratch is addressed by the read's offset into the
@@ -1107,9 +1112,9 @@ __global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, 
     {   // nine reads in ten have nothing to print: their marks (contiguous, a byte per HSP) say so
         uint32_t any = 0;
         for (uint32_t k = a; k < b; k++) any |= mark[k];
-        if (!any) { nrow_of[s] = 0; return; }
+        if (!any) { nrow_of[s] = 0; best[s].family = -1; return; }
     }
-    if (n > MC_FH_MIN && n <= MC_FH_BIGN) return;                 // k_heavy_lists handed this read to a wave (k_finish_heavy)
+    if (n > MC_FH_MIN) return;                                    // k_heavy_lists handed this read to a wave (k_finish_heavy)
     const uint32_t read = sorted[a].read;
     McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
     double *myk = (double *)(myrows + n);
@@ -1117,24 +1122,146 @@ __global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, 
     McSortItem *myitems = (McSortItem *)(myk + n);               // 64 n + 8 n + 16 n = 88 n <= 96 n bytes of the read's tmp area
     const int nr = mc_finish_read(*T, X, *P, fam, (int)((int64_t)read + first_read_id), sorted + a, n, v + a, tmp + 2 * (size_t)a, myrows, myk, myitems, &bh);
     nrow_of[s] = (uint32_t)nr;
-    (void)mc_wave_alloc(&counters[C_SEGS], nr > 0);               // (one atomic per wave, not per read)
-    const uint32_t bslot = mc_wave_alloc(&counters[C_BEST], bh.family >= 0);
-    if (bh.family >= 0) best[bslot] = bh;                         // few; the host orders them by read
+    best[s] = bh;                                                 // per read that has HSPs (family -1: none); k_emit_rows collects them
 }
+// ---- std::sort (libstdc++ 4.4 introsort) replayed by a whole wave -----------------------------------------------------------
+// mc_std_sort (mc_sort_impl.h) is the move-for-move statement; this computes the same permutation with the 64 lanes:
+//  * __unguarded_partition: the left scan stops at the elements that are not < pivot, in order of position (A_0 < A_1 < ...),
+//    the right scan at the elements that are not > pivot, from the right (B_0 > B_1 > ...); both scans only ever see elements
+//    nobody has moved yet, so the k-th swap exchanges A_k and B_k as long as A_k < B_k, and the cut is min(A_K, B_(K-1)) for the
+//    first K that fails (the swapped-in element at B_(K-1) stops the left scan at the latest).  Ranks by ballot + popcount,
+//    all swaps at once.
+//  * the recursion (depth limit, ranges of <= 16 left alone, heap-sort fallback by lane 0) is the reference's own;
+//  * __final_insertion_sort is a stable sort of an array in which no element is further than 15 positions from its place
+//    (ranges of <= 16 between ordered neighbours): place = position - (larger keys among the 15 before) + (smaller keys among
+//    the 15 behind).
+// Checked against mc_std_sort on 200,000 random arrays (ties, sorted, reversed; tests/test_emul.py runs the same formulation).
+__device__ __forceinline__ void mc_wave_std_sort(McSortItem *items, int n, uint16_t *posA, uint16_t *posB, uint16_t *npos, int *stk, int lane)
+{
+    if (n <= 1) return;
+    const unsigned long long lt = (1ull << lane) - 1;
+    int lg = 0;
+    for (int t = n; t > 1; t >>= 1) lg++;
+    int sp = 1;
+    if (lane == 0) { stk[0] = 0; stk[1] = n; stk[2] = 2 * lg; }
+    mc_wave_sync();
+    while (sp > 0) {
+        sp--;
+        int f = stk[3 * sp], l = stk[3 * sp + 1], depth = stk[3 * sp + 2];
+        mc_wave_sync();
+        while (l - f > 16) {
+            if (depth == 0) { if (lane == 0) mc_heapsort_inl(items + f, (long)(l - f), 0); mc_wave_sync(); break; }
+            --depth;
+            const double x = items[f].k, y = items[f + (l - f) / 2].k, z = items[l - 1].k;
+            double p;
+            if (x < y) { if (y < z) p = y; else if (x < z) p = z; else p = x; }
+            else if (x < z) p = x;
+            else if (y < z) p = z;
+            else p = y;
+            int nA = 0, nB = 0;
+            for (int c0 = f; c0 < l; c0 += 64) {
+                const int i = c0 + lane;
+                const bool fa = i < l && !(items[i < l ? i : f].k < p);
+                const unsigned long long m = __ballot(fa);
+                if (fa) posA[nA + __popcll(m & lt)] = (uint16_t)i;
+                nA += __popcll(m);
+            }
+            for (int c0 = l - 1; c0 >= f; c0 -= 64) {
+                const int i = c0 - lane;
+                const bool fb = i >= f && !(p < items[i >= f ? i : f].k);
+                const unsigned long long m = __ballot(fb);
+                if (fb) posB[nB + __popcll(m & lt)] = (uint16_t)i;
+                nB += __popcll(m);
+            }
+            mc_wave_sync();
+            const int mn = nA < nB ? nA : nB;
+            int K = 0;
+            for (int k0 = 0; k0 < mn; k0 += 64) {
+                const int k = k0 + lane;
+                const unsigned long long m = __ballot(k < mn && posA[k < mn ? k : 0] < posB[k < mn ? k : 0]);
+                K += __popcll(m);
+                if (m != ~0ull) break;
+            }
+            for (int k0 = 0; k0 < K; k0 += 64) {
+                const int k = k0 + lane;
+                if (k < K) { const int a = posA[k], b = posB[k]; const McSortItem t1 = items[a], t2 = items[b]; items[a] = t2; items[b] = t1; }
+            }
+            int split;
+            if (K == 0) split = posA[0];
+            else if (K < nA) { const int a = posA[K], b = posB[K - 1]; split = a < b ? a : b; }
+            else split = posB[K - 1];
+            mc_wave_sync();
+            if (lane == 0) { stk[3 * sp] = split; stk[3 * sp + 1] = l; stk[3 * sp + 2] = depth; }
+            sp++;
+            l = split;
+        }
+        mc_wave_sync();
+    }
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int x = c0 + lane;
+        if (x < n) {
+            const double kx = items[x].k;
+            int np = x;
+            const int y0 = x - 15 > 0 ? x - 15 : 0, y1 = x + 15 < n - 1 ? x + 15 : n - 1;
+            for (int yy = y0; yy < x; yy++) np -= (items[yy].k > kx) ? 1 : 0;
+            for (int yy = x + 1; yy <= y1; yy++) np += (items[yy].k < kx) ? 1 : 0;
+            npos[x] = (uint16_t)np;
+        }
+    }
+    mc_wave_sync();
+    McSortItem cur = items[lane < n ? lane : 0];
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int nx = c0 + 64 + lane;
+        const McSortItem nxt = items[nx < n ? nx : 0];            // the next 64 are in registers before anything of this round is written
+        mc_wave_sync();
+        if (c0 + lane < n) items[npos[c0 + lane]] = cur;
+        cur = nxt;
+        mc_wave_sync();
+    }
+}
+
+// ---- MergeRes' heap sort (std::partial_sort over the whole range) on packed words ---------------------------------------------
+// The rows arrive in ascending log E, so their printed keys are non-decreasing: a row's key is replaced by its dense rank
+// (the number of distinct printed keys in front of it) and the heap runs on 32-bit words rank << 16 | position, element e in word
+// e + 1 - the two children of a node then share one aligned 64-bit LDS read.  mc_heapsort (mc_sort_impl.h) move for move.
+__device__ __forceinline__ void mc_heapw_adjust(uint32_t *hw, int hole, int len, uint32_t value)
+{
+    const int top = hole;
+    int sc = hole;
+    while (sc < (len - 1) / 2) {
+        sc = 2 * (sc + 1);
+        const uint2 ch = *(const uint2 *)(hw + sc);                // elements sc - 1 and sc
+        uint32_t pick = ch.y;
+        if ((ch.y >> 16) < (ch.x >> 16)) { sc--; pick = ch.x; }
+        hw[hole + 1] = pick; hole = sc;
+    }
+    if ((len & 1) == 0 && sc == (len - 2) / 2) { sc = 2 * (sc + 1); hw[hole + 1] = hw[sc]; hole = sc - 1; }
+    int parent = (hole - 1) / 2;
+    while (hole > top && (hw[parent + 1] >> 16) < (value >> 16)) { hw[hole + 1] = hw[parent + 1]; hole = parent; parent = (hole - 1) / 2; }
+    hw[hole + 1] = value;
+}
+__device__ __forceinline__ void mc_heapw_sort(uint32_t *hw, int n)
+{
+    if (n >= 2) for (int parent = (n - 2) / 2;; parent--) { mc_heapw_adjust(hw, parent, n, hw[parent + 1]); if (parent == 0) break; }
+    for (int m = n; m > 1;) { m--; const uint32_t v = hw[m + 1]; hw[m + 1] = hw[1]; mc_heapw_adjust(hw, 0, m, v); }
+}
+
 // A read with many HSPs (one that really comes from a marker gene: hundreds of homologous subjects): one wave.
 // Parallel over lanes: the per-subject stacks and sum statistics (mc_finish_group per subject), the (log E, index) items,
-// the rows and their classification.  Sequential, by lane 0 on items held in LDS: the two order-defining sorts (std::sort
-// by log E, MergeRes' heap sort by printed log E), which have to replay libstdc++'s exact sequence of moves.
+// std::sort by log E (mc_wave_std_sort), the rows and their classification.  Sequential, by lane 0 on packed words in LDS:
+// MergeRes' heap sort by printed log E, which has to replay libstdc++'s exact sequence of moves.
 // Same scratch layout and same results as k_finish.
-template <int MAXN, int CTR>
+template <int MAXN, int CTR, int CTR_NEXT>
 __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
                                                      const McHsp *__restrict__ sorted, uint32_t nhsps, const uint32_t *__restrict__ heads, uint32_t nheads,
-                                                     McHsp *v, McHsp *tmp, int64_t first_read_id, uint32_t *nrow_of, McBestHit *best, uint32_t *counters,
-                                                     const uint32_t *__restrict__ heavy)
+                                                     McHsp *v, McHsp *tmp, int64_t first_read_id, uint32_t *nrow_of, McBestHit *best_of, uint32_t *counters,
+                                                     const uint32_t *__restrict__ heavy, uint32_t *heavy_next)
 {
     McSortItem *items = (McSortItem *)mc_smem;                      // MAXN sort items, then three index arrays (dynamic LDS)
     uint16_t *gst = (uint16_t *)(items + MAXN), *gkept = gst + (MAXN + 2), *gofs = gkept + (MAXN + 2);
     __shared__ int s_vn, s_nrows;
+    __shared__ int s_stk[3 * 64];
+    uint32_t *hw = (uint32_t *)gst;                                 // the heap words reuse the index arrays (8-byte aligned, >= 502 words)
     const int lane = mc_lane();
     const unsigned long long lt = (1ull << lane) - 1;
     const uint32_t nheavy = counters[CTR];
@@ -1143,43 +1270,66 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
         const int n = (int)(b - a);
         const McHsp *in = sorted + a;
         const int read_id = (int)((int64_t)in[0].read + first_read_id);
-        // subjects: group starts
+        // subjects: group starts (counted first: a read with more subjects than this kernel's arrays hold moves on)
         int ng = 0;
         for (int i0 = 0; i0 < n; i0 += 64) {
             const int i = i0 + lane;
-            const bool st = i < n && (i == 0 || in[i].sidx != in[i - 1].sidx);
-            const unsigned long long m = __ballot(st);
-            if (st) gst[ng + __popcll(m & lt)] = (uint16_t)i;
-            ng += __popcll(m);
+            ng += __popcll(__ballot(i < n && (i == 0 || in[i].sidx != in[i - 1].sidx)));
         }
-        if (lane == 0) gst[ng] = (uint16_t)n;
-        __syncthreads();
-        // per subject: stack, reversal, sum statistics - results stay at the group's own offset of v
-        for (int g = lane; g < ng; g += 64) {
-            const int g0 = gst[g], g1 = gst[g + 1];
-            gkept[g] = (uint16_t)mc_finish_group(*T, X, in, g0, g1, v + a + g0, tmp + 2 * ((size_t)a + g0));
-        }
-        __syncthreads();
-        // offsets of the groups in the sequence PrintRes sorts (exclusive scan of the kept counts)
-        {
-            int carry = 0;
-            for (int g0 = 0; g0 < ng; g0 += 64) {
-                const int g = g0 + lane;
-                int x = g < ng ? gkept[g] : 0, incl = x;
-                for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
-                if (g < ng) gofs[g] = (uint16_t)(carry + incl - x);
-                carry += __shfl(incl, 63);
+        bool punt = ng > MAXN || n > 65535;
+        int vn = 0;
+        if (!punt) {
+            ng = 0;
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                const int i = i0 + lane;
+                const bool st = i < n && (i == 0 || in[i].sidx != in[i - 1].sidx);
+                const unsigned long long m = __ballot(st);
+                if (st) gst[ng + __popcll(m & lt)] = (uint16_t)i;
+                ng += __popcll(m);
             }
-            if (lane == 0) { gofs[ng] = (uint16_t)carry; s_vn = carry; }
+            if (lane == 0) gst[ng] = (uint16_t)n;
+            __syncthreads();
+            // per subject: stack, reversal, sum statistics - results stay at the group's own offset of v
+            for (int g = lane; g < ng; g += 64) {
+                const int g0 = gst[g], g1 = gst[g + 1];
+                gkept[g] = (uint16_t)mc_finish_group(*T, X, in, g0, g1, v + a + g0, tmp + 2 * ((size_t)a + g0));
+            }
+            __syncthreads();
+            // offsets of the groups in the sequence PrintRes sorts (exclusive scan of the kept counts)
+            {
+                int carry = 0;
+                for (int g0 = 0; g0 < ng; g0 += 64) {
+                    const int g = g0 + lane;
+                    int x = g < ng ? gkept[g] : 0, incl = x;
+                    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+                    if (g < ng) gofs[g] = (uint16_t)(carry + incl - x);
+                    carry += __shfl(incl, 63);
+                }
+                if (lane == 0) { gofs[ng] = (uint16_t)carry; s_vn = carry; }
+            }
+            __syncthreads();
+            vn = s_vn;
+            punt = vn > MAXN;                                       // (the groups are recomputed by the next kernel: mc_finish_group only reads `in`)
         }
-        __syncthreads();
-        const int vn = s_vn;
+        if (punt) {
+            if (CTR_NEXT >= 0) { if (lane == 0) heavy_next[atomicAdd(&counters[CTR_NEXT < 0 ? 0 : CTR_NEXT], 1u)] = s; }
+            else if (lane == 0) {                                   // larger than the largest arrays: lane 0 alone, everything in the read's global scratch
+                McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
+                double *myk = (double *)(myrows + n);
+                McSortItem *myitems = (McSortItem *)(myk + n);
+                McBestHit bh;
+                nrow_of[s] = (uint32_t)mc_finish_read(*T, X, *P, fam, read_id, in, n, v + a, tmp + 2 * (size_t)a, myrows, myk, myitems, &bh);
+                best_of[s] = bh;
+            }
+            __syncthreads();
+            continue;
+        }
         for (int g = lane; g < ng; g += 64) {
             const int g0 = gst[g], o = gofs[g], k = gkept[g];
             for (int j = 0; j < k; j++) { McSortItem it; it.k = v[a + g0 + j].loge; it.i = (uint32_t)(g0 + j); it.pad = 0; items[o + j] = it; }
         }
         __syncthreads();
-        if (lane == 0) mc_std_sort_inl(items, vn, 0);             // std::sort by log E (PrintRes); inlined: the items are addressed as LDS
+        mc_wave_std_sort(items, vn, gst, gkept, gofs, s_stk, lane);   // std::sort by log E (PrintRes)
         __syncthreads();
         // rows: at most 500, log E below the threshold (the items are in ascending log E, so the test is monotone)
         {
@@ -1187,7 +1337,7 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
             int cnt = 0;
             for (int i0 = 0; i0 < lim; i0 += 64) {
                 const int i = i0 + lane;
-                const bool ok = i < lim && v[a + items[i].i].loge < T->loge_thr;
+                const bool ok = i < lim && v[a + items[i < lim ? i : 0].i].loge < T->loge_thr;
                 cnt += __popcll(__ballot(ok));
             }
             if (lane == 0) s_nrows = cnt;
@@ -1196,13 +1346,24 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
         const int nrows = s_nrows;
         for (int i = lane; i < nrows; i += 64) items[i].k = mc_round6(v[a + items[i].i].loge);
         __syncthreads();
-        if (lane == 0) mc_heapsort_inl(items, nrows, 0);              // MergeRes: heap sort by the printed log E
+        {   // dense ranks of the printed keys -> heap words
+            int carry = 0;
+            for (int i0 = 0; i0 < nrows; i0 += 64) {
+                const int i = i0 + lane;
+                const bool nw = i < nrows && i > 0 && items[i].k != items[i - 1].k;
+                const unsigned long long m = __ballot(nw);
+                if (i < nrows) hw[i + 1] = ((uint32_t)(carry + __popcll(m & (lt | (1ull << lane)))) << 16) | (uint32_t)i;
+                carry += __popcll(m);
+            }
+        }
+        __syncthreads();
+        if (lane == 0) mc_heapw_sort(hw, nrows);                      // MergeRes: heap sort by the printed log E
         __syncthreads();
         McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);             // the groups' scratch is dead by now
         double bbits = -1.0; int bidx = 0x7fffffff, bfam = -1, baln = 0, btl = 0;
         for (int i = lane; i < nrows; i += 64) {
             McRow r;
-            mc_fill_row(*T, read_id, v[a + items[i].i], r);
+            mc_fill_row(*T, read_id, v[a + items[hw[i + 1] & 0xFFFFu].i], r);
             myrows[i] = r;
             const int f = fam[r.subject], tl = (int)(X.off[r.subject + 1] - X.off[r.subject]);
             if (mc_row_passes(*P, r, f, tl, r.frame) && (bfam < 0 || bbits < r.bits)) { bbits = r.bits; bidx = i; bfam = f; baln = r.alnlen; btl = tl; }
@@ -1215,24 +1376,35 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
         }
         if (lane == 0) {
             nrow_of[s] = (uint32_t)nrows;
-            if (nrows > 0) atomicAdd(&counters[C_SEGS], 1u);
-            if (bfam >= 0) { McBestHit bh; bh.read = read_id; bh.family = bfam; bh.aln = baln; bh.target_len = btl; bh.bits = bbits; best[atomicAdd(&counters[C_BEST], 1u)] = bh; }
+            McBestHit bh; bh.read = read_id; bh.family = bfam; bh.aln = bfam >= 0 ? baln : 0; bh.target_len = bfam >= 0 ? btl : 0; bh.bits = bfam >= 0 ? bbits : 0.0;
+            best_of[s] = bh;
         }
         __syncthreads();
     }
 }
 
-// rows of read s -> rows[rowoff[s] ...]: the m8 order (ascending read, RAPsearch2's order inside a read)
+// rows of read s -> rows[rowoff[s] ...]: the m8 order (ascending read, RAPsearch2's order inside a read); the best hits of the
+// reads that have one are collected (any order: the host sorts them by read), the reads with rows counted
 __global__ void __launch_bounds__(256) k_emit_rows(const uint32_t *__restrict__ heads, uint32_t nheads, const uint32_t *__restrict__ nrow_of, const uint32_t *__restrict__ rowoff,
-                                                   const McHsp *__restrict__ tmp, McRow *__restrict__ rows, uint32_t cap_rows, uint32_t *counters)
+                                                   const McHsp *__restrict__ tmp, McRow *__restrict__ rows, uint32_t cap_rows, const McBestHit *__restrict__ best_of, McBestHit *best,
+                                                   uint32_t *counters)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nheads) return;
-    const uint32_t nr = nrow_of[s], off = rowoff[s];
-    if (s == nheads - 1) { counters[C_ROWS] = off + nr; if (off + nr > cap_rows) counters[C_OVERFLOW] = 4; }
-    if (off + nr > cap_rows) return;
-    const McRow *src = (const McRow *)(tmp + 2 * (size_t)heads[s]);
-    for (uint32_t i = 0; i < nr; i++) rows[off + i] = src[i];
+    uint32_t nr = 0;
+    McBestHit bh; bh.family = -1;
+    if (s < nheads) {
+        nr = nrow_of[s];
+        bh = best_of[s];
+        const uint32_t off = rowoff[s];
+        if (s == nheads - 1) { counters[C_ROWS] = off + nr; if (off + nr > cap_rows) counters[C_OVERFLOW] = 4; }
+        if (off + nr <= cap_rows) {
+            const McRow *src = (const McRow *)(tmp + 2 * (size_t)heads[s]);
+            for (uint32_t i = 0; i < nr; i++) rows[off + i] = src[i];
+        }
+    }
+    (void)mc_block_alloc(&counters[C_SEGS], nr > 0);
+    const uint32_t o = mc_block_alloc(&counters[C_BEST], bh.family >= 0);
+    if (bh.family >= 0) best[o] = bh;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1263,7 +1435,7 @@ struct mc_handle {
     uint32_t cap_tasks = 0, cap_gaps = 0, cap_hsps = 0, cap_rows = 0;
     uint64_t *d_k64 = nullptr, *d_k64o = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
     uint32_t *d_counters = nullptr;
-    McRow *d_rows = nullptr; uint32_t *d_nrow = nullptr, *d_rowoff = nullptr; McBestHit *d_best = nullptr; uint8_t *d_mark = nullptr;
+    McRow *d_rows = nullptr; uint32_t *d_nrow = nullptr, *d_rowoff = nullptr; McBestHit *d_best = nullptr, *d_bestof = nullptr; uint8_t *d_mark = nullptr;
     McGapCell *d_gws_full = nullptr; uint32_t *d_retry = nullptr, *d_retry2 = nullptr; int gap_threads_full = 0;
     unsigned long long *d_gtab = nullptr; uint32_t gtab_slots = 0; uint32_t *d_gleader = nullptr; McFlankOut *d_fout = nullptr;
     // host results: rows of the last batch land in pinned memory; mc_search() accumulates its batches in all_rows
@@ -1299,7 +1471,7 @@ extern "C" void mc_close(mc_handle *h)
     (void)hipSetDevice(h->device);
     void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_frames, h->d_tasks, h->d_gaps, h->d_hsps,
                     h->d_sorted, h->d_v, h->d_tmp, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, h->d_heads, h->d_sorttmp, h->d_counters, h->d_rows,
-                    h->d_nrow, h->d_rowoff, h->d_best, h->d_mark, h->d_gws_full, h->d_retry, h->d_retry2, h->d_gtab, h->d_gleader, h->d_fout, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_rt};
+                    h->d_nrow, h->d_rowoff, h->d_best, h->d_bestof, h->d_mark, h->d_gws_full, h->d_retry, h->d_retry2, h->d_gtab, h->d_gleader, h->d_fout, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_rt};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->pin_rows) (void)hipHostFree(h->pin_rows);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -1458,8 +1630,8 @@ static int ensure_capacity(mc_handle *h, int64_t nreads)
         dalloc(&h->d_gaps, h->cap_gaps) || dalloc(&h->d_hsps, h->cap_hsps) || dalloc(&h->d_sorted, h->cap_hsps) || dalloc(&h->d_v, h->cap_hsps) ||
         dalloc(&h->d_tmp, (size_t)h->cap_hsps * 2) || dalloc(&h->d_k64, h->cap_hsps) || dalloc(&h->d_k64o, h->cap_hsps) || dalloc(&h->d_idx, h->cap_hsps) ||
         dalloc(&h->d_idxo, h->cap_hsps) || dalloc(&h->d_heads, (size_t)cap + 1) || dalloc(&h->d_rows, h->cap_rows) ||
-        dalloc(&h->d_mark, (size_t)h->cap_hsps) || dalloc(&h->d_nrow, (size_t)cap + 1) || dalloc(&h->d_rowoff, (size_t)cap + 1) || dalloc(&h->d_best, (size_t)cap + 1) ||
-        dalloc(&h->d_gws_full, (size_t)h->gap_threads_full * MC_GAP_W) || dalloc(&h->d_retry, (size_t)h->cap_gaps * 2) || dalloc(&h->d_retry2, (size_t)h->cap_gaps * 2) || dalloc(&h->d_gleader, (size_t)h->cap_gaps) ||
+        dalloc(&h->d_mark, (size_t)h->cap_hsps) || dalloc(&h->d_nrow, (size_t)cap + 1) || dalloc(&h->d_rowoff, (size_t)cap + 1) || dalloc(&h->d_best, (size_t)cap + 1) || dalloc(&h->d_bestof, (size_t)cap + 1) ||
+        dalloc(&h->d_gws_full, (size_t)h->gap_threads_full * MC_GAP_W) || dalloc(&h->d_retry, (size_t)h->cap_gaps * 2 + (size_t)cap + 1) || dalloc(&h->d_retry2, (size_t)h->cap_gaps * 2) || dalloc(&h->d_gleader, (size_t)h->cap_gaps) ||
         dalloc(&h->d_fout, (size_t)h->cap_gaps * 2))
         return -1;
     size_t bytes = 0, bytes2 = 0;
@@ -1594,30 +1766,29 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
         nheads = c[C_HEADS];
-        // finishing: the single-thread kernel and the two wave-per-read kernels are independent - three streams
-        uint32_t *d_heavy = h->d_retry, *d_heavy2 = h->d_retry + h->cap_gaps / 2;      // (d_retry is free again: the gap tasks are done)
-        k_heavy_lists<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_heads, nheads, nh, h->d_mark, h->d_nrow, h->d_counters, d_heavy, d_heavy2);
+        // finishing: the thread-per-read kernel (reads with few HSPs) on this stream, the wave-per-read kernels one after the
+        // other on a second one (each hands the reads its LDS arrays cannot hold to the next)
+        uint32_t *d_heavy = h->d_retry, *d_heavy2 = h->d_retry + h->cap_gaps / 2, *d_heavy3 = h->d_retry + h->cap_gaps;      // (d_retry is free again: the gap tasks are done)
+        k_heavy_lists<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_heads, nheads, nh, h->d_mark, h->d_nrow, h->d_bestof, h->d_counters, d_heavy);
         HIPCK(hipEventRecord(h->ev_fork, st));
         {
-            const size_t l1 = (size_t)MC_FH_MAXN * 16 + 3 * (size_t)(MC_FH_MAXN + 2) * 2, l2 = (size_t)MC_FH_BIGN * 16 + 3 * (size_t)(MC_FH_BIGN + 2) * 2;
-            HIPCK(hipFuncSetAttribute((const void *)k_finish_heavy<MC_FH_MAXN, C_HEAVY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1));
-            HIPCK(hipFuncSetAttribute((const void *)k_finish_heavy<MC_FH_BIGN, C_HEAVY2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));
-            HIPCK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-            k_finish_heavy<MC_FH_BIGN, C_HEAVY2><<<dim3(256), dim3(64), l2, h->stream2>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp, first_read_id,
-                                                                                           h->d_nrow, h->d_best, h->d_counters, d_heavy2);
-            HIPCK(hipEventRecord(h->ev_join2, h->stream2));
+            const size_t l1 = (size_t)MC_FH_N1 * 16 + 3 * (size_t)(MC_FH_N1 + 2) * 2, l2 = (size_t)MC_FH_N2 * 16 + 3 * (size_t)(MC_FH_N2 + 2) * 2, l3 = (size_t)MC_FH_N3 * 16 + 3 * (size_t)(MC_FH_N3 + 2) * 2;
+            HIPCK(hipFuncSetAttribute((const void *)k_finish_heavy<MC_FH_N3, C_HEAVY3, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
             HIPCK(hipStreamWaitEvent(h->stream3, h->ev_fork, 0));
-            k_finish_heavy<MC_FH_MAXN, C_HEAVY><<<dim3(2048), dim3(64), l1, h->stream3>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp, first_read_id,
-                                                                                           h->d_nrow, h->d_best, h->d_counters, d_heavy);
+            k_finish_heavy<MC_FH_N1, C_HEAVY, C_HEAVY2><<<dim3(256 * 12), dim3(64), l1, h->stream3>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp, first_read_id,
+                                                                                                       h->d_nrow, h->d_bestof, h->d_counters, d_heavy, d_heavy2);
+            k_finish_heavy<MC_FH_N2, C_HEAVY2, C_HEAVY3><<<dim3(256 * 3), dim3(64), l2, h->stream3>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp, first_read_id,
+                                                                                                       h->d_nrow, h->d_bestof, h->d_counters, d_heavy2, d_heavy3);
+            k_finish_heavy<MC_FH_N3, C_HEAVY3, -1><<<dim3(256), dim3(64), l3, h->stream3>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp, first_read_id,
+                                                                                             h->d_nrow, h->d_bestof, h->d_counters, d_heavy3, nullptr);
             HIPCK(hipEventRecord(h->ev_join3, h->stream3));
         }
         k_finish<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_mark, h->d_v, h->d_tmp,
-                                                                    first_read_id, h->d_nrow, h->d_best, h->d_counters);
-        HIPCK(hipStreamWaitEvent(st, h->ev_join2, 0));
+                                                                    first_read_id, h->d_nrow, h->d_bestof, h->d_counters);
         HIPCK(hipStreamWaitEvent(st, h->ev_join3, 0));
         bytes = h->sorttmp_bytes;
         HIPCK(rocprim::exclusive_scan(h->d_sorttmp, bytes, h->d_nrow, h->d_rowoff, 0u, (size_t)nheads, rocprim::plus<uint32_t>(), st));
-        k_emit_rows<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_heads, nheads, h->d_nrow, h->d_rowoff, h->d_tmp, h->d_rows, h->cap_rows, h->d_counters);
+        k_emit_rows<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_heads, nheads, h->d_nrow, h->d_rowoff, h->d_tmp, h->d_rows, h->cap_rows, h->d_bestof, h->d_best, h->d_counters);
         HIPCK(hipEventRecord(h->ev[6], st));
         HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
