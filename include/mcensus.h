@@ -87,6 +87,11 @@ int mc_run(mc_handle *h, int64_t first_read_id);
 /* runs the pipeline on reads [first, first+count) of the resident set (count <= 2097151). */
 int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id);
 
+/* mc_run_range() cuts its range into `parts` parts (default and maximum 2) whose pipeline stages are issued alternately on
+ * separate HIP streams, so that the host's waits for one part's counters and the tails of its latency-bound kernels are covered
+ * by the other part's work.  parts = 1 runs one kernel at a time (what a per-kernel profile wants).  Results do not depend on it. */
+int mc_set_parts(mc_handle *h, int parts);
+
 /* The seed kernel can count the index reads of the reference's algorithm for the batch (mc_stats.bucket_lookups /
  * key_probes: what CHashSearch::Searching@0x415050 / ExtendSeq2Set@0x413b90 would read - the algorithmic traffic the
  * roofline of bench.py is priced on).  Off by default: the two fields stay 0 and the kernel rejects most

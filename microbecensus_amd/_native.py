@@ -72,6 +72,7 @@ def load_library():
     lib.mc_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.mc_run_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
     lib.mc_set_counting.argtypes = [C.c_void_p, C.c_int]
+    lib.mc_set_parts.argtypes = [C.c_void_p, C.c_int]
     lib.mc_result_rows.restype = C.c_int64
     lib.mc_result_rows.argtypes = [C.c_void_p, C.POINTER(C.POINTER(McRow))]
     lib.mc_result_best_hits.restype = C.c_int64
@@ -94,7 +95,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
-                    "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8",
+                    "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_set_parts", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8",
                     "mc_reader_last_error", "mc_reader_open", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_count_bases"]
 
 
@@ -269,6 +270,10 @@ class Engine:
     def set_counting(self, on):
         """Turns the seed kernel's algorithmic-traffic counters (stats bucket_lookups / key_probes) on or off."""
         self._check(self.lib.mc_set_counting(self.h, 1 if on else 0), "mc_set_counting")
+
+    def set_parts(self, parts):
+        """2 (default): a range runs as two overlapping halves on two streams; 1: one kernel at a time (profiling)."""
+        self._check(self.lib.mc_set_parts(self.h, parts), "mc_set_parts")
 
     def run_range(self, first, count, first_read_id=0):
         self._check(self.lib.mc_run_range(self.h, first, count, first_read_id), "mc_run_range")

@@ -767,9 +767,10 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
 #define MC_EV_STAGE_H 512    // HSPs staged per workgroup (24 KB)
 #define MC_EV_STAGE_G 320    // gap tasks (9 KB)
 __global__ void __launch_bounds__(256) k_eval_seeds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
-                                                    const McSeedTask *__restrict__ tasks, uint32_t ntasks, McHsp *hsps, uint32_t cap_hsps,
+                                                    const McSeedTask *__restrict__ tasks, const uint32_t *__restrict__ ntasks_p, uint32_t cap_tasks, McHsp *hsps, uint32_t cap_hsps,
                                                     McGapTask *gaps, uint32_t cap_gaps, uint32_t *counters)
 {
+    const uint32_t ntasks = *ntasks_p <= cap_tasks ? *ntasks_p : 0u;   // (device-side count of the seed kernel; after an overflow the host discards the batch)
     __shared__ McHot hot;
     __shared__ uint32_t fillH, fillG, baseH, baseG;
     McHsp *stH = (McHsp *)mc_smem;                                // MC_EV_STAGE_H records
@@ -1410,35 +1411,51 @@ __global__ void __launch_bounds__(256) k_emit_rows(const uint32_t *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------------------
-struct mc_handle {
-    McHostIndex H;
-    std::vector<int32_t> fam;
-    int nfam = 0, device = 0;
-    hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr;
-    hipEvent_t ev[8] = {}, ev_fork = nullptr, ev_join2 = nullptr, ev_join3 = nullptr;
-    // device index + tables
-    uint8_t *d_res = nullptr; uint32_t *d_off = nullptr, *d_bstart = nullptr, *d_post = nullptr; uint16_t *d_keys = nullptr; int32_t *d_fam = nullptr;
-    McTables *d_T = nullptr; McClassPars *d_P = nullptr;
-    McTables hT; McClassPars hP;
-    int read_len = 0, FP = 0; bool run_set = false;
-    // batch buffers
-    int64_t cap_reads = 0, nreads = 0, cap_own = 0;
-    uint8_t *d_reads = nullptr, *d_frames = nullptr;
-    const uint8_t *reads_dev = nullptr;   // resident read set (own buffer or attached caller memory)
-    unsigned long long *d_stats = nullptr;
-    uint32_t *d_bitmap = nullptr;
-    McBucketRec *d_rec = nullptr;
-    uint32_t *d_filt = nullptr, *d_wild = nullptr; unsigned long long *d_rt = nullptr;
-    bool fast_enum = false;
-    bool count_traffic = false;
-    McSeedTask *d_tasks = nullptr; McGapTask *d_gaps = nullptr; McHsp *d_hsps = nullptr, *d_sorted = nullptr, *d_v = nullptr, *d_tmp = nullptr;
+// Everything one batch in flight needs.  A handle owns MC_NCTX of them: mc_run_range() cuts its range into as many parts and
+// issues their stages alternately, so that while the host waits for the counters of one part the GPU works on the other
+// (and the tails of the latency-bound kernels of one part overlap the kernels of the other).
+#define MC_NCTX 2
+struct McCtx {
+    hipStream_t stream = nullptr, side = nullptr;
+    hipEvent_t ev[8] = {}, ev_fork = nullptr, ev_join = nullptr;
+    int64_t cap_reads = 0;
     uint32_t cap_tasks = 0, cap_gaps = 0, cap_hsps = 0, cap_rows = 0;
+    uint8_t *d_frames = nullptr;
+    unsigned long long *d_stats = nullptr;
+    McSeedTask *d_tasks = nullptr; McGapTask *d_gaps = nullptr; McHsp *d_hsps = nullptr, *d_sorted = nullptr, *d_v = nullptr, *d_tmp = nullptr;
     uint64_t *d_k64 = nullptr, *d_k64o = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
     uint32_t *d_counters = nullptr;
     McRow *d_rows = nullptr; uint32_t *d_nrow = nullptr, *d_rowoff = nullptr; McBestHit *d_best = nullptr, *d_bestof = nullptr; uint8_t *d_mark = nullptr;
     McGapCell *d_gws_full = nullptr; uint32_t *d_retry = nullptr, *d_retry2 = nullptr; int gap_threads_full = 0;
     unsigned long long *d_gtab = nullptr; uint32_t gtab_slots = 0; uint32_t *d_gleader = nullptr; McFlankOut *d_fout = nullptr;
-    // host results: rows of the last batch land in pinned memory; mc_search() accumulates its batches in all_rows
+    // pinned host mirrors
+    uint32_t *h_c = nullptr; unsigned long long *h_stats = nullptr; McBestHit *h_best = nullptr; size_t h_best_cap = 0;
+    // the part being processed
+    const uint8_t *reads = nullptr; int64_t n = 0, first_read_id = 0;
+    uint32_t ntasks = 0, ngaps = 0, nh = 0, nheads = 0, nrows = 0, nbest = 0, nsegs = 0;
+};
+
+struct mc_handle {
+    McHostIndex H;
+    std::vector<int32_t> fam;
+    int nfam = 0, device = 0;
+    // device index + tables
+    uint8_t *d_res = nullptr; uint32_t *d_off = nullptr, *d_bstart = nullptr, *d_post = nullptr; uint16_t *d_keys = nullptr; int32_t *d_fam = nullptr;
+    McTables *d_T = nullptr; McClassPars *d_P = nullptr;
+    McTables hT; McClassPars hP;
+    int read_len = 0, FP = 0; bool run_set = false;
+    uint32_t *d_bitmap = nullptr;
+    McBucketRec *d_rec = nullptr;
+    uint32_t *d_filt = nullptr, *d_wild = nullptr; unsigned long long *d_rt = nullptr;
+    bool fast_enum = false;
+    bool count_traffic = false;
+    int parts = MC_NCTX;                  // parts a range is cut into (mc_set_parts; 1 = one kernel at a time, for profiling)
+    // resident reads
+    int64_t nreads = 0, cap_own = 0;
+    uint8_t *d_reads = nullptr;
+    const uint8_t *reads_dev = nullptr;   // resident read set (own buffer or attached caller memory)
+    McCtx ctx[MC_NCTX];
+    // host results: rows of the last run land in pinned memory; mc_search() accumulates its batches in all_rows
     mc_row *pin_rows = nullptr; size_t pin_cap = 0;
     std::vector<mc_row> all_rows;
     const mc_row *res_rows = nullptr; int64_t n_res_rows = 0;
@@ -1465,18 +1482,26 @@ extern "C" int mc_device_count(void)
     return n;
 }
 
+static void ctx_free(McCtx &c)
+{
+    void *ptrs[] = {c.d_frames, c.d_tasks, c.d_gaps, c.d_hsps, c.d_sorted, c.d_v, c.d_tmp, c.d_k64, c.d_k64o, c.d_idx, c.d_idxo, c.d_heads, c.d_sorttmp, c.d_counters, c.d_rows,
+                    c.d_nrow, c.d_rowoff, c.d_best, c.d_bestof, c.d_mark, c.d_gws_full, c.d_retry, c.d_retry2, c.d_gtab, c.d_gleader, c.d_fout, c.d_stats};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : {(void *)c.h_c, (void *)c.h_stats, (void *)c.h_best}) if (p) (void)hipHostFree(p);
+    for (auto &e : c.ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {c.ev_fork, c.ev_join}) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t q : {c.stream, c.side}) if (q) (void)hipStreamDestroy(q);
+    c = McCtx();
+}
+
 extern "C" void mc_close(mc_handle *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_frames, h->d_tasks, h->d_gaps, h->d_hsps,
-                    h->d_sorted, h->d_v, h->d_tmp, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, h->d_heads, h->d_sorttmp, h->d_counters, h->d_rows,
-                    h->d_nrow, h->d_rowoff, h->d_best, h->d_bestof, h->d_mark, h->d_gws_full, h->d_retry, h->d_retry2, h->d_gtab, h->d_gleader, h->d_fout, h->d_stats, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_rt};
+    void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_rt};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (McCtx &c : h->ctx) ctx_free(c);
     if (h->pin_rows) (void)hipHostFree(h->pin_rows);
-    for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {h->ev_fork, h->ev_join2, h->ev_join3}) if (e) (void)hipEventDestroy(e);
-    for (hipStream_t q : {h->stream, h->stream2, h->stream3}) if (q) (void)hipStreamDestroy(q);
     delete h;
 }
 
@@ -1493,12 +1518,17 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
     if (marker_family) h->fam.assign(marker_family, marker_family + nseq); else h->fam.assign((size_t)nseq, 0);
     h->nfam = nfam; h->device = device;
     HIPCK(hipSetDevice(device));
-    HIPCK(hipStreamCreate(&h->stream)); HIPCK(hipStreamCreate(&h->stream2)); HIPCK(hipStreamCreate(&h->stream3));
-    for (auto &e : h->ev) HIPCK(hipEventCreate(&e));
-    HIPCK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); HIPCK(hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming)); HIPCK(hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming));
+    for (McCtx &c : h->ctx) {
+        HIPCK(hipStreamCreate(&c.stream)); HIPCK(hipStreamCreate(&c.side));
+        for (auto &e : c.ev) HIPCK(hipEventCreate(&e));
+        HIPCK(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming)); HIPCK(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
+        if (dalloc(&c.d_counters, C_N) || dalloc(&c.d_stats, S_N)) return -1;
+        HIPCK(hipHostMalloc((void **)&c.h_c, sizeof(uint32_t) * C_N, hipHostMallocDefault));
+        HIPCK(hipHostMalloc((void **)&c.h_stats, sizeof(unsigned long long) * S_N, hipHostMallocDefault));
+    }
     const McHostIndex &H = h->H;
     if (dalloc(&h->d_res, H.res.size() + 64) || dalloc(&h->d_off, H.off.size()) || dalloc(&h->d_bstart, H.bstart.size()) || dalloc(&h->d_post, H.post.size() + 1) ||
-        dalloc(&h->d_keys, H.keys.size()) || dalloc(&h->d_fam, (size_t)nseq) || dalloc(&h->d_T, 1) || dalloc(&h->d_P, 1) || dalloc(&h->d_counters, C_N) || dalloc(&h->d_stats, S_N)) return -1;
+        dalloc(&h->d_keys, H.keys.size()) || dalloc(&h->d_fam, (size_t)nseq) || dalloc(&h->d_T, 1) || dalloc(&h->d_P, 1)) return -1;
     HIPCK(hipMemcpy(h->d_res, H.res.data(), H.res.size(), hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_off, H.off.data(), H.off.size() * 4, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_bstart, H.bstart.data(), H.bstart.size() * 4, hipMemcpyHostToDevice));
@@ -1606,44 +1636,46 @@ extern "C" int mc_set_run(mc_handle *h, int32_t read_len, double loge_thr, const
     HIPCK(hipMemcpy(h->d_T, &h->hT, sizeof(McTables), hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_P, &h->hP, sizeof(McClassPars), hipMemcpyHostToDevice));
     const int newFP = ((read_len / 3 + 2) + 3) & ~3;
-    if (newFP != h->FP || read_len != h->read_len) h->cap_reads = 0;   // pools are sized by read length and frame pitch
+    if (newFP != h->FP || read_len != h->read_len) for (McCtx &c : h->ctx) c.cap_reads = 0;   // pools are sized by read length and frame pitch
     h->read_len = read_len; h->FP = newFP; h->run_set = true;
     return 0;
 }
 
-static int ensure_capacity(mc_handle *h, int64_t nreads)
+static int ensure_capacity(mc_handle *h, McCtx &c, int64_t nreads)
 {
-    if (nreads <= h->cap_reads) return 0;
+    if (nreads <= c.cap_reads) return 0;
     int64_t cap = nreads;
     if (cap > (1 << 21) - 1) { g_err = "batch larger than 2097151 reads"; return -1; }
-    // pool sizes: generous multiples of what shotgun reads produce (45-60 seed hits, 10-17 kept HSPs, 1-3 gapped
-    // extensions per 100-150 bp read), scaled with the read length; a batch that still overflows is split by mc_search
+    // pool sizes: generous multiples of what shotgun reads produce (75 seed hits, 23 kept HSPs, 5 gapped extensions per 150 bp
+    // read of a real genome), scaled with the read length; a batch that still overflows is split by mc_search
     const int64_t L = h->read_len;
-    h->cap_reads = 0;                                               // pools are being replaced: nothing is usable until all of them exist
-    h->cap_tasks = (uint32_t)std::min<int64_t>(cap * (L + 32) + (1 << 20) + (int64_t)256 * 16 * MC_EN_BLK, 0x7fffffff);
-    h->cap_gaps = (uint32_t)std::min<int64_t>(cap * (L / 8 + 8) + (1 << 18), 0x7fffffff);
-    h->cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 2 + 16) + (1 << 20), 0x7fffffff);
-    h->cap_rows = (uint32_t)std::min<int64_t>(cap * 48 + (1 << 20), 0x7fffffff);
-
-    h->gap_threads_full = 16 * 1024;                                      // full-size ones for the retry launch (460 MB)
-    if (dalloc(&h->d_frames, (size_t)cap * 6 * h->FP + 64) || dalloc(&h->d_tasks, h->cap_tasks) ||
-        dalloc(&h->d_gaps, h->cap_gaps) || dalloc(&h->d_hsps, h->cap_hsps) || dalloc(&h->d_sorted, h->cap_hsps) || dalloc(&h->d_v, h->cap_hsps) ||
-        dalloc(&h->d_tmp, (size_t)h->cap_hsps * 2) || dalloc(&h->d_k64, h->cap_hsps) || dalloc(&h->d_k64o, h->cap_hsps) || dalloc(&h->d_idx, h->cap_hsps) ||
-        dalloc(&h->d_idxo, h->cap_hsps) || dalloc(&h->d_heads, (size_t)cap + 1) || dalloc(&h->d_rows, h->cap_rows) ||
-        dalloc(&h->d_mark, (size_t)h->cap_hsps) || dalloc(&h->d_nrow, (size_t)cap + 1) || dalloc(&h->d_rowoff, (size_t)cap + 1) || dalloc(&h->d_best, (size_t)cap + 1) || dalloc(&h->d_bestof, (size_t)cap + 1) ||
-        dalloc(&h->d_gws_full, (size_t)h->gap_threads_full * MC_GAP_W) || dalloc(&h->d_retry, (size_t)h->cap_gaps * 2 + (size_t)cap + 1) || dalloc(&h->d_retry2, (size_t)h->cap_gaps * 2) || dalloc(&h->d_gleader, (size_t)h->cap_gaps) ||
-        dalloc(&h->d_fout, (size_t)h->cap_gaps * 2))
+    c.cap_reads = 0;                                                // pools are being replaced: nothing is usable until all of them exist
+    c.cap_tasks = (uint32_t)std::min<int64_t>(cap * (L + 32) + (1 << 20) + (int64_t)256 * 16 * MC_EN_BLK, 0x7fffffff);
+    c.cap_gaps = (uint32_t)std::min<int64_t>(cap * (L / 8 + 8) + (1 << 18), 0x7fffffff);
+    c.cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 2 + 16) + (1 << 20), 0x7fffffff);
+    c.cap_rows = (uint32_t)std::min<int64_t>(cap * 48 + (1 << 20), 0x7fffffff);
+    c.gap_threads_full = 16 * 1024;                                 // full-size DP rows for the last-resort launch (460 MB)
+    if (dalloc(&c.d_frames, (size_t)cap * 6 * h->FP + 64) || dalloc(&c.d_tasks, c.cap_tasks) ||
+        dalloc(&c.d_gaps, c.cap_gaps) || dalloc(&c.d_hsps, c.cap_hsps) || dalloc(&c.d_sorted, c.cap_hsps) || dalloc(&c.d_v, c.cap_hsps) ||
+        dalloc(&c.d_tmp, (size_t)c.cap_hsps * 2) || dalloc(&c.d_k64, c.cap_hsps) || dalloc(&c.d_k64o, c.cap_hsps) || dalloc(&c.d_idx, c.cap_hsps) ||
+        dalloc(&c.d_idxo, c.cap_hsps) || dalloc(&c.d_heads, (size_t)cap + 1) || dalloc(&c.d_rows, c.cap_rows) ||
+        dalloc(&c.d_mark, (size_t)c.cap_hsps) || dalloc(&c.d_nrow, (size_t)cap + 1) || dalloc(&c.d_rowoff, (size_t)cap + 1) || dalloc(&c.d_best, (size_t)cap + 1) || dalloc(&c.d_bestof, (size_t)cap + 1) ||
+        dalloc(&c.d_gws_full, (size_t)c.gap_threads_full * MC_GAP_W) || dalloc(&c.d_retry, (size_t)c.cap_gaps * 2 + (size_t)cap + 1) || dalloc(&c.d_retry2, (size_t)c.cap_gaps * 2) || dalloc(&c.d_gleader, (size_t)c.cap_gaps) ||
+        dalloc(&c.d_fout, (size_t)c.cap_gaps * 2))
         return -1;
+    if (c.h_best) { (void)hipHostFree(c.h_best); c.h_best = nullptr; }
+    HIPCK(hipHostMalloc((void **)&c.h_best, sizeof(McBestHit) * ((size_t)cap + 1), hipHostMallocDefault));
+    c.h_best_cap = (size_t)cap + 1;
     size_t bytes = 0, bytes2 = 0;
-    HIPCK(rocprim::radix_sort_pairs(nullptr, bytes, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, (size_t)h->cap_hsps, 0, 64, h->stream));
-    HIPCK(rocprim::exclusive_scan(nullptr, bytes2, h->d_idx, h->d_idxo, 0u, (size_t)h->cap_hsps, rocprim::plus<uint32_t>(), h->stream));
+    HIPCK(rocprim::radix_sort_pairs(nullptr, bytes, c.d_k64, c.d_k64o, c.d_idx, c.d_idxo, (size_t)c.cap_hsps, 0, 64, c.stream));
+    HIPCK(rocprim::exclusive_scan(nullptr, bytes2, c.d_idx, c.d_idxo, 0u, (size_t)c.cap_hsps, rocprim::plus<uint32_t>(), c.stream));
     bytes = std::max(bytes, bytes2);
-    HIPCK(rocprim::radix_sort_pairs_desc(nullptr, bytes2, h->d_idx, h->d_idxo, h->d_idx, h->d_idxo, (size_t)h->cap_gaps * 2, 0, 10, h->stream));
+    HIPCK(rocprim::radix_sort_pairs_desc(nullptr, bytes2, c.d_idx, c.d_idxo, c.d_idx, c.d_idxo, (size_t)c.cap_gaps * 2, 0, 10, c.stream));
     bytes = std::max(bytes, bytes2);
-    if (h->d_sorttmp) { (void)hipFree(h->d_sorttmp); h->d_sorttmp = nullptr; }
-    HIPCK(hipMalloc(&h->d_sorttmp, bytes + 16));
-    h->sorttmp_bytes = bytes;
-    h->cap_reads = cap;
+    if (c.d_sorttmp) { (void)hipFree(c.d_sorttmp); c.d_sorttmp = nullptr; }
+    HIPCK(hipMalloc(&c.d_sorttmp, bytes + 16));
+    c.sorttmp_bytes = bytes;
+    c.cap_reads = cap;
     return 0;
 }
 
@@ -1653,8 +1685,8 @@ extern "C" int mc_upload(mc_handle *h, const uint8_t *reads, int64_t nreads)
     HIPCK(hipSetDevice(h->device));
     const int64_t need = nreads * (int64_t)h->read_len + 16;       // capacity in bytes: the read length may change between runs
     if (need > h->cap_own) { if (dalloc(&h->d_reads, (size_t)need)) return -1; h->cap_own = need; }
-    if (nreads) HIPCK(hipMemcpyAsync(h->d_reads, reads, (size_t)nreads * h->read_len, hipMemcpyHostToDevice, h->stream));
-    HIPCK(hipStreamSynchronize(h->stream));
+    if (nreads) HIPCK(hipMemcpyAsync(h->d_reads, reads, (size_t)nreads * h->read_len, hipMemcpyHostToDevice, h->ctx[0].stream));
+    HIPCK(hipStreamSynchronize(h->ctx[0].stream));
     h->reads_dev = h->d_reads; h->nreads = nreads;
     return 0;
 }
@@ -1668,161 +1700,218 @@ extern "C" int mc_attach(mc_handle *h, const void *device_reads, int64_t nreads)
 
 static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 
+// The pipeline of one part, in five stages.  Each stage only ISSUES work on the part's stream and ends with an asynchronous copy
+// of the device counters into pinned host memory; the next stage starts by waiting for that copy (stage_wait) and sizes its
+// launches from it.  mc_run_range() interleaves the stages of its parts.
+static int stage_wait(McCtx &c) { HIPCK(hipStreamSynchronize(c.stream)); return 0; }
+static int counters_to_host(McCtx &c) { HIPCK(hipMemcpyAsync(c.h_c, c.d_counters, sizeof(uint32_t) * C_N, hipMemcpyDeviceToHost, c.stream)); return 0; }
+
+// A: translation + SEG, seed enumeration, seed evaluation (gate, growth, ungapped X-drop)
+static int stage_a(mc_handle *h, McCtx &c)
+{
+    const int64_t n = c.n;
+    const int L = h->read_len, FP = h->FP;
+    hipStream_t st = c.stream;
+    McIndex X = dev_index(h);
+    c.ntasks = c.ngaps = c.nh = c.nheads = c.nrows = c.nbest = c.nsegs = 0;
+    HIPCK(hipMemsetAsync(c.d_counters, 0, sizeof(uint32_t) * C_N, st));
+    HIPCK(hipMemsetAsync(c.d_stats, 0, sizeof(unsigned long long) * S_N, st));
+    HIPCK(hipEventRecord(c.ev[0], st));
+    const int64_t threads = n * 6;
+    size_t lds = (size_t)MC_TS_STAGE(L) + (size_t)MC_TS_NLNF(FP) * 8 + (size_t)256 * MC_TS_STRIDE(FP);
+    if (lds > 48 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_translate_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_translate_seg<<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(256), lds, st>>>(h->d_T, c.reads, L, n, c.d_frames, FP);
+    HIPCK(hipEventRecord(c.ev[1], st));
+    if (h->fast_enum) {
+        const int FPs = (FP + 15) & ~15;
+        const size_t per_wave = sizeof(McEnWave) + (size_t)6 * FPs + (size_t)6 * MC_EN_NCHUNK(L) * (512 + 128);
+        int waves = (int)((160 * 1024 - 64) / per_wave);                // waves per workgroup: as many as the LDS holds, at most 16
+        waves = waves >= 16 ? 16 : waves >= 12 ? 12 : waves >= 8 ? 8 : 4;
+        const size_t lds2 = 64 + waves * per_wave;
+        if (lds2 > 160 * 1024) { g_err = "reads too long for the seed kernel's LDS layout"; return -1; }
+        const int blocks = (int)std::min<int64_t>(256, (n + waves - 1) / waves);
+#define MC_LAUNCH_EN(WV, CNT)                                                                                                                      \
+    do {                                                                                                                                           \
+        HIPCK(hipFuncSetAttribute((const void *)k_enumerate_t0<WV, CNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                  \
+        k_enumerate_t0<WV, CNT><<<dim3(blocks), dim3(64 * WV), lds2, st>>>(h->d_T, X, h->d_bitmap, c.d_frames, FP, L, n, c.d_tasks, c.cap_tasks, \
+                                                                            c.d_counters, c.d_stats);                                             \
+    } while (0)
+        if (h->count_traffic) { if (waves == 16) MC_LAUNCH_EN(16, true); else if (waves == 12) MC_LAUNCH_EN(12, true); else if (waves == 8) MC_LAUNCH_EN(8, true); else MC_LAUNCH_EN(4, true); }
+        else { if (waves == 16) MC_LAUNCH_EN(16, false); else if (waves == 12) MC_LAUNCH_EN(12, false); else if (waves == 8) MC_LAUNCH_EN(8, false); else MC_LAUNCH_EN(4, false); }
+#undef MC_LAUNCH_EN
+    } else
+        k_enumerate<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, X, c.d_frames, FP, L, n, c.d_tasks, c.cap_tasks, c.d_counters, c.d_stats);
+    HIPCK(hipEventRecord(c.ev[2], st));
+    // the number of seed hits stays on the device: persistent workgroups walk the pool
+    const size_t lds_ev = (size_t)MC_EV_STAGE_H * sizeof(McHsp) + (size_t)MC_EV_STAGE_G * sizeof(McGapTask);   // 33 KB: four workgroups per CU
+    HIPCK(hipFuncSetAttribute((const void *)k_eval_seeds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ev));
+    k_eval_seeds<<<dim3(256u * 4u), dim3(256), lds_ev, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_tasks, c.d_counters + C_TASKS, c.cap_tasks, c.d_hsps, c.cap_hsps, c.d_gaps, c.cap_gaps, c.d_counters);
+    HIPCK(hipEventRecord(c.ev[3], st));
+    return counters_to_host(c);
+}
+
+// B: gapped extension
+static int stage_b(mc_handle *h, McCtx &c)
+{
+    const int L = h->read_len, FP = h->FP;
+    hipStream_t st = c.stream;
+    McIndex X = dev_index(h);
+    if (c.h_c[C_OVERFLOW]) { g_err = "seed task / HSP / gap task buffer overflow"; return -2; }
+    c.ntasks = c.h_c[C_TASKS];
+    const uint32_t ngaps = c.ngaps = c.h_c[C_GAPS];
+    if (ngaps) {
+        // 1. group the tasks that extend the same ungapped segment and list the flanks of the distinct ones (k_gap_dedupe);
+        // 2. order the flanks by DP size (the sort buffers of the HSP sort are idle at this point); 3. extend them with the DP rows
+        // in LDS, those whose band leaves the window again with a wider one, the rest with full-size rows; 4. every task takes its
+        // HSP from its group's flank results.  The counts of 2. - 4. stay on the device.
+        uint32_t slots = 1u << 16;
+        while (slots < 2 * ngaps) slots <<= 1;
+        if (slots > c.gtab_slots) { if (dalloc(&c.d_gtab, (size_t)slots)) return -1; c.gtab_slots = slots; }
+        uint32_t *gk = (uint32_t *)c.d_k64, *gko = gk + 2 * (size_t)ngaps, *gi = c.d_idx, *gio = c.d_idxo;     // (2 ngaps <= cap_hsps: see ensure_capacity)
+        HIPCK(hipMemsetAsync(c.d_gtab, 0, (size_t)slots * 8, st));
+        HIPCK(hipMemsetAsync(gk, 0, (size_t)ngaps * 8, st));
+        k_gap_dedupe<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(X, L, c.d_gaps, ngaps, c.d_gtab, slots - 1, c.d_gleader, gk, gi, c.d_counters);
+        size_t gbytes = c.sorttmp_bytes;
+        HIPCK(rocprim::radix_sort_pairs_desc(c.d_sorttmp, gbytes, gk, gko, gi, gio, (size_t)ngaps * 2, 0, 10, st));
+        k_gapped_lds<MC_GAP_WIN, 64><<<dim3(std::min<uint32_t>((2 * ngaps + 63) / 64, 256u * 5u * 4u)), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, gio, c.d_counters + C_ITEMS, c.d_fout,
+                                                                                                                 c.d_counters + C_RETRY, c.d_retry);
+        k_gapped_lds<MC_GAP_WIN2, 4><<<dim3(256u * 3u * 4u), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry, c.d_counters + C_RETRY, c.d_fout, c.d_counters + C_RETRY2, c.d_retry2);
+        k_gapped<<<dim3(c.gap_threads_full / 128), dim3(128), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry2, c.d_counters + C_RETRY2, c.d_fout, c.d_counters, c.d_gws_full, MC_GAP_W);
+        k_gap_emit<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, L, c.d_gaps, ngaps, c.d_gleader, c.d_fout, c.d_hsps, c.cap_hsps, c.d_counters);
+    }
+    HIPCK(hipEventRecord(c.ev[4], st));
+    return counters_to_host(c);
+}
+
+// C: HSPs into (read, subject, hit order); heads of the reads
+static int stage_c(mc_handle *h, McCtx &c)
+{
+    hipStream_t st = c.stream;
+    if (c.h_c[C_OVERFLOW]) { g_err = "HSP buffer overflow"; return -2; }
+    const uint32_t nh = c.nh = c.h_c[C_HSPS];
+    if (nh) {
+        uint32_t *d_flags = c.d_idx, *d_hpos = (uint32_t *)c.d_k64;      // both free once the sort has run
+        k_make_keys<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(c.d_hsps, nh, c.d_k64, c.d_idx);
+        size_t bytes = c.sorttmp_bytes;
+        int rbits = 1;
+        while ((1ll << rbits) < c.n) rbits++;
+        HIPCK(rocprim::radix_sort_pairs(c.d_sorttmp, bytes, c.d_k64, c.d_k64o, c.d_idx, c.d_idxo, (size_t)nh, 0, 43 + rbits, st));
+        k_gather<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(c.d_hsps, c.d_idxo, nh, c.d_sorted, d_flags, c.d_mark, h->hT.loge_thr);
+        bytes = c.sorttmp_bytes;
+        HIPCK(rocprim::exclusive_scan(c.d_sorttmp, bytes, d_flags, d_hpos, 0u, (size_t)nh, rocprim::plus<uint32_t>(), st));
+        k_heads<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(d_flags, d_hpos, nh, c.d_heads, c.d_counters);
+    }
+    HIPCK(hipEventRecord(c.ev[5], st));
+    return counters_to_host(c);
+}
+
+// D: per-read finishing (linking, ranking, cap, classification), rows into m8 order
+static int stage_d(mc_handle *h, McCtx &c)
+{
+    hipStream_t st = c.stream;
+    McIndex X = dev_index(h);
+    const uint32_t nh = c.nh, nheads = c.nheads = nh ? c.h_c[C_HEADS] : 0u;
+    if (nh) {
+        // the thread-per-read kernel (reads with few HSPs) on this stream, the wave-per-read kernels one after the other on a
+        // second one (each hands the reads its LDS arrays cannot hold to the next)
+        uint32_t *d_heavy = c.d_retry, *d_heavy2 = c.d_retry + c.cap_gaps / 2, *d_heavy3 = c.d_retry + c.cap_gaps;      // (d_retry is free again: the gap tasks are done)
+        k_heavy_lists<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(c.d_heads, nheads, nh, c.d_mark, c.d_nrow, c.d_bestof, c.d_counters, d_heavy);
+        HIPCK(hipEventRecord(c.ev_fork, st));
+        {
+            const size_t l1 = (size_t)MC_FH_N1 * 16 + 3 * (size_t)(MC_FH_N1 + 2) * 2, l2 = (size_t)MC_FH_N2 * 16 + 3 * (size_t)(MC_FH_N2 + 2) * 2, l3 = (size_t)MC_FH_N3 * 16 + 3 * (size_t)(MC_FH_N3 + 2) * 2;
+            HIPCK(hipFuncSetAttribute((const void *)k_finish_heavy<MC_FH_N3, C_HEAVY3, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
+            HIPCK(hipStreamWaitEvent(c.side, c.ev_fork, 0));
+            k_finish_heavy<MC_FH_N1, C_HEAVY, C_HEAVY2><<<dim3(256 * 12), dim3(64), l1, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_sorted, nh, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
+                                                                                                   c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy2);
+            k_finish_heavy<MC_FH_N2, C_HEAVY2, C_HEAVY3><<<dim3(256 * 3), dim3(64), l2, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_sorted, nh, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
+                                                                                                   c.d_nrow, c.d_bestof, c.d_counters, d_heavy2, d_heavy3);
+            k_finish_heavy<MC_FH_N3, C_HEAVY3, -1><<<dim3(256), dim3(64), l3, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_sorted, nh, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
+                                                                                         c.d_nrow, c.d_bestof, c.d_counters, d_heavy3, nullptr);
+            HIPCK(hipEventRecord(c.ev_join, c.side));
+        }
+        k_finish<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, c.d_sorted, nh, c.d_heads, nheads, c.d_mark, c.d_v, c.d_tmp,
+                                                                    c.first_read_id, c.d_nrow, c.d_bestof, c.d_counters);
+        HIPCK(hipStreamWaitEvent(st, c.ev_join, 0));
+        size_t bytes = c.sorttmp_bytes;
+        HIPCK(rocprim::exclusive_scan(c.d_sorttmp, bytes, c.d_nrow, c.d_rowoff, 0u, (size_t)nheads, rocprim::plus<uint32_t>(), st));
+        k_emit_rows<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(c.d_heads, nheads, c.d_nrow, c.d_rowoff, c.d_tmp, c.d_rows, c.cap_rows, c.d_bestof, c.d_best, c.d_counters);
+    }
+    HIPCK(hipEventRecord(c.ev[6], st));
+    HIPCK(hipMemcpyAsync(c.h_stats, c.d_stats, sizeof(unsigned long long) * S_N, hipMemcpyDeviceToHost, st));
+    return counters_to_host(c);
+}
+
+// E: rows (final order and ABI layout: McRow == mc_row) and best hits into pinned host memory; rows_at = where this part's rows
+// go in the handle's row buffer
+static int stage_e(mc_handle *h, McCtx &c, size_t rows_at)
+{
+    hipStream_t st = c.stream;
+    if (c.nrows) HIPCK(hipMemcpyAsync(h->pin_rows + rows_at, c.d_rows, sizeof(McRow) * c.nrows, hipMemcpyDeviceToHost, st));
+    if (c.nbest) HIPCK(hipMemcpyAsync(c.h_best, c.d_best, sizeof(McBestHit) * c.nbest, hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
 extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id)
 {
     if (!h || !h->run_set) { g_err = "mc_set_run() must be called first"; return -1; }
     if (first < 0 || count < 0 || first + count > h->nreads) { g_err = "range outside the resident read set"; return -1; }
+    if (count > (1 << 21) - 1) { g_err = "batch larger than 2097151 reads"; return -1; }
     HIPCK(hipSetDevice(h->device));
-    if (ensure_capacity(h, count)) return -1;
-    const int64_t n = count;
-    const uint8_t *d_reads = h->reads_dev + first * h->read_len;
-    const int L = h->read_len, FP = h->FP;
-    hipStream_t st = h->stream;
-    McIndex X = dev_index(h);
-    uint32_t c[C_N];
     memset(&h->stats, 0, sizeof h->stats);
     h->res_rows = nullptr; h->n_res_rows = 0; h->best.clear();
-    h->stats.reads = n;
-    if (n == 0) return 0;
-    HIPCK(hipMemsetAsync(h->d_counters, 0, sizeof(uint32_t) * C_N, st));
-    HIPCK(hipMemsetAsync(h->d_stats, 0, sizeof(unsigned long long) * S_N, st));
-    HIPCK(hipEventRecord(h->ev[0], st));
-    {
-        const int64_t threads = n * 6;
-        size_t lds = (size_t)MC_TS_STAGE(L) + (size_t)MC_TS_NLNF(FP) * 8 + (size_t)256 * MC_TS_STRIDE(FP);
-        if (lds > 48 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_translate_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_translate_seg<<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(256), lds, st>>>(h->d_T, d_reads, L, n, h->d_frames, FP);
-        HIPCK(hipEventRecord(h->ev[1], st));
-        if (h->fast_enum) {
-            const int FPs = (FP + 15) & ~15;
-            const size_t per_wave = sizeof(McEnWave) + (size_t)6 * FPs + (size_t)6 * MC_EN_NCHUNK(L) * (512 + 128);
-            int waves = (int)((160 * 1024 - 64) / per_wave);                // waves per workgroup: as many as the LDS holds, at most 16
-            waves = waves >= 16 ? 16 : waves >= 12 ? 12 : waves >= 8 ? 8 : 4;
-            const size_t lds2 = 64 + waves * per_wave;
-            if (lds2 > 160 * 1024) { g_err = "reads too long for the seed kernel's LDS layout"; return -1; }
-            const int blocks = (int)std::min<int64_t>(256, (n + waves - 1) / waves);
-#define MC_LAUNCH_EN(WV, CNT)                                                                                                                      \
-    do {                                                                                                                                           \
-        HIPCK(hipFuncSetAttribute((const void *)k_enumerate_t0<WV, CNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                  \
-        k_enumerate_t0<WV, CNT><<<dim3(blocks), dim3(64 * WV), lds2, st>>>(h->d_T, X, h->d_bitmap, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, \
-                                                                            h->d_counters, h->d_stats);                                           \
-    } while (0)
-            if (h->count_traffic) { if (waves == 16) MC_LAUNCH_EN(16, true); else if (waves == 12) MC_LAUNCH_EN(12, true); else if (waves == 8) MC_LAUNCH_EN(8, true); else MC_LAUNCH_EN(4, true); }
-            else { if (waves == 16) MC_LAUNCH_EN(16, false); else if (waves == 12) MC_LAUNCH_EN(12, false); else if (waves == 8) MC_LAUNCH_EN(8, false); else MC_LAUNCH_EN(4, false); }
-#undef MC_LAUNCH_EN
-        } else
-            k_enumerate<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, X, h->d_frames, FP, L, n, h->d_tasks, h->cap_tasks, h->d_counters, h->d_stats);
-        HIPCK(hipEventRecord(h->ev[2], st));
+    h->stats.reads = count;
+    if (count == 0) return 0;
+    // parts: two halves (small ranges: one part)
+    const int np = (count >= 65536 && h->parts > 1) ? MC_NCTX : 1;
+    int64_t at = 0;
+    for (int p = 0; p < np; p++) {
+        McCtx &c = h->ctx[p];
+        const int64_t n = (count - at) / (np - p);
+        if (ensure_capacity(h, c, n)) return -1;
+        c.reads = h->reads_dev + (first + at) * h->read_len; c.n = n; c.first_read_id = first_read_id + at;
+        at += n;
     }
-    HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
-    HIPCK(hipStreamSynchronize(st));
-    if (c[C_OVERFLOW]) { g_err = "seed task buffer overflow"; return -2; }
-    uint32_t ntasks = c[C_TASKS];
-    const size_t lds_ev = (size_t)MC_EV_STAGE_H * sizeof(McHsp) + (size_t)MC_EV_STAGE_G * sizeof(McGapTask);   // 33 KB: four workgroups per CU
-    if (ntasks) HIPCK(hipFuncSetAttribute((const void *)k_eval_seeds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ev));
-    if (ntasks) k_eval_seeds<<<dim3((unsigned)std::min<uint32_t>((ntasks + 255) / 256, 256u * 4u)), dim3(256), lds_ev, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_tasks, ntasks, h->d_hsps, h->cap_hsps, h->d_gaps, h->cap_gaps, h->d_counters);
-    HIPCK(hipEventRecord(h->ev[3], st));
-    HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
-    HIPCK(hipStreamSynchronize(st));
-    if (c[C_OVERFLOW]) { g_err = "HSP / gap task buffer overflow"; return -2; }
-    uint32_t ngaps = c[C_GAPS];
-    if (ngaps) {
-        // 1. group the tasks that extend the same ungapped segment (k_gap_dedupe); 2. order the distinct ones by DP size (the sort
-        // buffers of the HSP sort are idle at this point); 3. extend them with the DP rows in LDS, the few whose band leaves the
-        // window again with full-size rows; 4. every task takes its HSP from its group's result.  Counts stay on the device.
-        uint32_t slots = 1u << 16;
-        while (slots < 2 * ngaps) slots <<= 1;
-        if (slots > h->gtab_slots) { if (dalloc(&h->d_gtab, (size_t)slots)) return -1; h->gtab_slots = slots; }
-        uint32_t *gk = (uint32_t *)h->d_k64, *gko = gk + 2 * (size_t)ngaps, *gi = h->d_idx, *gio = h->d_idxo;     // (2 ngaps <= cap_hsps: see ensure_capacity)
-        HIPCK(hipMemsetAsync(h->d_gtab, 0, (size_t)slots * 8, st));
-        HIPCK(hipMemsetAsync(gk, 0, (size_t)ngaps * 8, st));
-        k_gap_dedupe<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(X, L, h->d_gaps, ngaps, h->d_gtab, slots - 1, h->d_gleader, gk, gi, h->d_counters);
-        size_t gbytes = h->sorttmp_bytes;
-        HIPCK(rocprim::radix_sort_pairs_desc(h->d_sorttmp, gbytes, gk, gko, gi, gio, (size_t)ngaps * 2, 0, 10, st));
-        k_gapped_lds<MC_GAP_WIN, 64><<<dim3(std::min<uint32_t>((2 * ngaps + 63) / 64, 256u * 5u * 4u)), dim3(64), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, gio, h->d_counters + C_ITEMS, h->d_fout,
-                                                                                                                 h->d_counters + C_RETRY, h->d_retry);
-        k_gapped_lds<MC_GAP_WIN2, 4><<<dim3(256u * 3u * 4u), dim3(64), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, h->d_retry, h->d_counters + C_RETRY, h->d_fout, h->d_counters + C_RETRY2, h->d_retry2);
-        k_gapped<<<dim3(h->gap_threads_full / 128), dim3(128), 0, st>>>(h->d_T, X, h->d_frames, FP, L, h->d_gaps, h->d_retry2, h->d_counters + C_RETRY2, h->d_fout, h->d_counters, h->d_gws_full, MC_GAP_W);
-        k_gap_emit<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, L, h->d_gaps, ngaps, h->d_gleader, h->d_fout, h->d_hsps, h->cap_hsps, h->d_counters);
+    int rc = 0;
+#define MC_ALL(stmt) for (int p = 0; p < np && rc == 0; p++) { McCtx &c = h->ctx[p]; stmt; }
+    MC_ALL(rc = stage_a(h, c))
+    MC_ALL(if ((rc = stage_wait(c)) == 0) rc = stage_b(h, c))
+    MC_ALL(if ((rc = stage_wait(c)) == 0) rc = stage_c(h, c))
+    MC_ALL(if ((rc = stage_wait(c)) == 0) rc = stage_d(h, c))
+    size_t nrows = 0;
+    for (int p = 0; p < np && rc == 0; p++) {
+        McCtx &c = h->ctx[p];
+        if ((rc = stage_wait(c)) != 0) break;
+        if (c.h_c[C_OVERFLOW]) { g_err = "row buffer overflow"; rc = -2; break; }
+        c.nrows = c.nh ? c.h_c[C_ROWS] : 0u; c.nsegs = c.h_c[C_SEGS]; c.nbest = c.h_c[C_BEST];
+        nrows += c.nrows;
     }
-    HIPCK(hipEventRecord(h->ev[4], st));
-    HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
-    HIPCK(hipStreamSynchronize(st));
-    if (c[C_OVERFLOW]) { g_err = "HSP buffer overflow"; return -2; }
-    uint32_t nh = c[C_HSPS];
-    uint32_t nheads = 0, nrows = 0;
-    std::vector<McBestHit> bh;
-    int64_t with_rows = 0;
-    if (nh) {
-        uint32_t *d_flags = h->d_idx, *d_hpos = (uint32_t *)h->d_k64;      // both free once the sort has run
-        k_make_keys<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(h->d_hsps, nh, h->d_k64, h->d_idx);
-        size_t bytes = h->sorttmp_bytes;
-        HIPCK(rocprim::radix_sort_pairs(h->d_sorttmp, bytes, h->d_k64, h->d_k64o, h->d_idx, h->d_idxo, (size_t)nh, 0, 64, st));
-        k_gather<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(h->d_hsps, h->d_idxo, nh, h->d_sorted, d_flags, h->d_mark, h->hT.loge_thr);
-        bytes = h->sorttmp_bytes;
-        HIPCK(rocprim::exclusive_scan(h->d_sorttmp, bytes, d_flags, d_hpos, 0u, (size_t)nh, rocprim::plus<uint32_t>(), st));
-        k_heads<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(d_flags, d_hpos, nh, h->d_heads, h->d_counters);
-        HIPCK(hipEventRecord(h->ev[5], st));
-        HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
-        HIPCK(hipStreamSynchronize(st));
-        nheads = c[C_HEADS];
-        // finishing: the thread-per-read kernel (reads with few HSPs) on this stream, the wave-per-read kernels one after the
-        // other on a second one (each hands the reads its LDS arrays cannot hold to the next)
-        uint32_t *d_heavy = h->d_retry, *d_heavy2 = h->d_retry + h->cap_gaps / 2, *d_heavy3 = h->d_retry + h->cap_gaps;      // (d_retry is free again: the gap tasks are done)
-        k_heavy_lists<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_heads, nheads, nh, h->d_mark, h->d_nrow, h->d_bestof, h->d_counters, d_heavy);
-        HIPCK(hipEventRecord(h->ev_fork, st));
-        {
-            const size_t l1 = (size_t)MC_FH_N1 * 16 + 3 * (size_t)(MC_FH_N1 + 2) * 2, l2 = (size_t)MC_FH_N2 * 16 + 3 * (size_t)(MC_FH_N2 + 2) * 2, l3 = (size_t)MC_FH_N3 * 16 + 3 * (size_t)(MC_FH_N3 + 2) * 2;
-            HIPCK(hipFuncSetAttribute((const void *)k_finish_heavy<MC_FH_N3, C_HEAVY3, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
-            HIPCK(hipStreamWaitEvent(h->stream3, h->ev_fork, 0));
-            k_finish_heavy<MC_FH_N1, C_HEAVY, C_HEAVY2><<<dim3(256 * 12), dim3(64), l1, h->stream3>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp, first_read_id,
-                                                                                                       h->d_nrow, h->d_bestof, h->d_counters, d_heavy, d_heavy2);
-            k_finish_heavy<MC_FH_N2, C_HEAVY2, C_HEAVY3><<<dim3(256 * 3), dim3(64), l2, h->stream3>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp, first_read_id,
-                                                                                                       h->d_nrow, h->d_bestof, h->d_counters, d_heavy2, d_heavy3);
-            k_finish_heavy<MC_FH_N3, C_HEAVY3, -1><<<dim3(256), dim3(64), l3, h->stream3>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_v, h->d_tmp, first_read_id,
-                                                                                             h->d_nrow, h->d_bestof, h->d_counters, d_heavy3, nullptr);
-            HIPCK(hipEventRecord(h->ev_join3, h->stream3));
-        }
-        k_finish<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, h->d_sorted, nh, h->d_heads, nheads, h->d_mark, h->d_v, h->d_tmp,
-                                                                    first_read_id, h->d_nrow, h->d_bestof, h->d_counters);
-        HIPCK(hipStreamWaitEvent(st, h->ev_join3, 0));
-        bytes = h->sorttmp_bytes;
-        HIPCK(rocprim::exclusive_scan(h->d_sorttmp, bytes, h->d_nrow, h->d_rowoff, 0u, (size_t)nheads, rocprim::plus<uint32_t>(), st));
-        k_emit_rows<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_heads, nheads, h->d_nrow, h->d_rowoff, h->d_tmp, h->d_rows, h->cap_rows, h->d_bestof, h->d_best, h->d_counters);
-        HIPCK(hipEventRecord(h->ev[6], st));
-        HIPCK(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, st));
-        HIPCK(hipStreamSynchronize(st));
-        if (c[C_OVERFLOW]) { g_err = "row buffer overflow"; return -2; }
-        nrows = c[C_ROWS]; with_rows = c[C_SEGS];
-        bh.resize(c[C_BEST]);
-        if (nrows > h->pin_cap) {
-            if (h->pin_rows) { (void)hipHostFree(h->pin_rows); h->pin_rows = nullptr; h->pin_cap = 0; }
-            const size_t want = (size_t)nrows + (size_t)nrows / 4 + 1024;
-            HIPCK(hipHostMalloc((void **)&h->pin_rows, want * sizeof(mc_row), hipHostMallocDefault));
-            h->pin_cap = want;
-        }
-        // rows arrive in their final order and layout (McRow == mc_row): one copy into pinned memory
-        if (nrows) HIPCK(hipMemcpyAsync(h->pin_rows, h->d_rows, sizeof(McRow) * nrows, hipMemcpyDeviceToHost, st));
-        if (!bh.empty()) HIPCK(hipMemcpyAsync(bh.data(), h->d_best, sizeof(McBestHit) * bh.size(), hipMemcpyDeviceToHost, st));
-        HIPCK(hipStreamSynchronize(st));
-    } else {
-        HIPCK(hipEventRecord(h->ev[5], st));
-        HIPCK(hipEventRecord(h->ev[6], st));
-        HIPCK(hipStreamSynchronize(st));
+    if (rc) { for (int p = 0; p < np; p++) (void)hipStreamSynchronize(h->ctx[p].stream); return rc; }
+    if (nrows > h->pin_cap) {
+        if (h->pin_rows) { (void)hipHostFree(h->pin_rows); h->pin_rows = nullptr; h->pin_cap = 0; }
+        const size_t want = nrows + nrows / 4 + 1024;
+        HIPCK(hipHostMalloc((void **)&h->pin_rows, want * sizeof(mc_row), hipHostMallocDefault));
+        h->pin_cap = want;
     }
-    h->res_rows = h->pin_rows; h->n_res_rows = nrows;
+    { size_t o = 0; MC_ALL(rc = stage_e(h, c, o); o += c.nrows) }
+    MC_ALL(rc = stage_wait(c))
+#undef MC_ALL
+    if (rc) return rc;
+    h->res_rows = h->pin_rows; h->n_res_rows = (int64_t)nrows;
     // classify_reads meets the reads in input order
-    std::sort(bh.begin(), bh.end(), [](const McBestHit &x, const McBestHit &y) { return x.read < y.read; });
-    h->best.reserve(bh.size());
-    for (const McBestHit &x : bh) { mc_best_hit o; o.read = x.read; o.family = x.family; o.aln = x.aln; o.target_len = x.target_len; o.bits = x.bits; h->best.push_back(o); }
-    { unsigned long long ss[S_N]; HIPCK(hipMemcpy(ss, h->d_stats, sizeof ss, hipMemcpyDeviceToHost));
+    for (int p = 0; p < np; p++) {
+        McCtx &c = h->ctx[p];
+        std::sort(c.h_best, c.h_best + c.nbest, [](const McBestHit &x, const McBestHit &y) { return x.read < y.read; });
+        for (uint32_t i = 0; i < c.nbest; i++) { const McBestHit &x = c.h_best[i]; mc_best_hit o; o.read = x.read; o.family = x.family; o.aln = x.aln; o.target_len = x.target_len; o.bits = x.bits; h->best.push_back(o); }
 #ifdef MC_EXP_TIMING
-      { const char *nm[6] = {"staging/other", "heavy", "process", "push", "setup", "expand"}; for (int k = 0; k < 6; k++) fprintf(stderr, "timing %-14s %8.3f Mcycles/wave-avg  %10llu entries\n", nm[k], (double)ss[4 + k] / 4096.0 / 1e6, ss[10 + k]); }
+        { const char *nm[6] = {"staging/other", "heavy", "process", "push", "setup", "expand"}; for (int k = 0; k < 6; k++) fprintf(stderr, "timing %-14s %8.3f Mcycles/wave-avg  %10llu entries\n", nm[k], (double)c.h_stats[4 + k] / 4096.0 / 1e6, c.h_stats[10 + k]); }
 #endif
-      h->stats.bucket_lookups = (int64_t)ss[S_LOOKUPS]; h->stats.key_probes = (int64_t)ss[S_KEYPROBES]; h->stats.seed_tasks = (int64_t)ss[S_TASKS]; }
-    h->stats.gap_tasks = ngaps; h->stats.hsps = nh; h->stats.rows = nrows; h->stats.reads_with_rows = with_rows; h->stats.classified = (int64_t)h->best.size();
-    h->stats.ms_translate = ev_ms(h->ev[0], h->ev[1]); h->stats.ms_seed = ev_ms(h->ev[1], h->ev[2]); h->stats.ms_eval = ev_ms(h->ev[2], h->ev[3]);
-    h->stats.ms_gapped = ev_ms(h->ev[3], h->ev[4]); h->stats.ms_sort = ev_ms(h->ev[4], h->ev[5]); h->stats.ms_finish = ev_ms(h->ev[5], h->ev[6]); h->stats.ms_total = ev_ms(h->ev[0], h->ev[6]);
+        h->stats.bucket_lookups += (int64_t)c.h_stats[S_LOOKUPS]; h->stats.key_probes += (int64_t)c.h_stats[S_KEYPROBES]; h->stats.seed_tasks += (int64_t)c.h_stats[S_TASKS];
+        h->stats.gap_tasks += c.ngaps; h->stats.hsps += c.nh; h->stats.rows += c.nrows; h->stats.reads_with_rows += c.nsegs;
+        // kernel times: HIP events on the part's own stream (the parts overlap, so the sums exceed the wall time of the call)
+        h->stats.ms_translate += ev_ms(c.ev[0], c.ev[1]); h->stats.ms_seed += ev_ms(c.ev[1], c.ev[2]); h->stats.ms_eval += ev_ms(c.ev[2], c.ev[3]);
+        h->stats.ms_gapped += ev_ms(c.ev[3], c.ev[4]); h->stats.ms_sort += ev_ms(c.ev[4], c.ev[5]); h->stats.ms_finish += ev_ms(c.ev[5], c.ev[6]); h->stats.ms_total += ev_ms(c.ev[0], c.ev[6]);
+    }
+    h->stats.classified = (int64_t)h->best.size();
     return 0;
 }
 
@@ -1830,6 +1919,13 @@ extern "C" int mc_set_counting(mc_handle *h, int on)
 {
     if (!h) { g_err = "null handle"; return -1; }
     h->count_traffic = on != 0;
+    return 0;
+}
+
+extern "C" int mc_set_parts(mc_handle *h, int parts)
+{
+    if (!h || parts < 1) { g_err = "bad argument"; return -1; }
+    h->parts = parts > MC_NCTX ? MC_NCTX : parts;
     return 0;
 }
 
