@@ -113,7 +113,7 @@ int mc_write_m8(mc_handle *h, const char *path, int append);
 /* ---- host stage in front of the search: native read sampler (csrc/mc_reader.cpp; no GPU involved) ----------------
  * Replaces open_file / parse_seqs / quality_filter / process_seqfile (microbe_census.py:47-59, :294-325, :265-279,
  * :328-367) and count_bases (:573-584) with identical results, quirks included (see the header of mc_reader.cpp).
- * Plain and .gz inputs; .bz2 stays with the Python stage.  Errors: NULL / negative + mc_reader_last_error(); -3 = the
+ * Plain, .gz and .bz2 inputs (libbz2 is bound at run time).  Errors: NULL / negative + mc_reader_last_error(); -3 = the
  * reference would have raised inside run_pipeline (its message names the Python exception). */
 typedef struct mc_reader mc_reader;
 typedef struct mc_reader_stats {
@@ -136,6 +136,23 @@ int mc_reader_get_stats(mc_reader *r, mc_reader_stats *out);
 void mc_reader_close(mc_reader *r);
 /* count_bases(): total sequence length over every record of every file. */
 int64_t mc_count_bases(const char *const *paths, int32_t npaths);
+
+/* Streaming form of the sampler: mc_reader_start() runs it on a thread of its own; mc_reader_fetch() blocks until reads
+ * [first, first + max_reads) are sampled (or the sampler has ended), copies them to dst and returns how many there were
+ * (0: no more; negative: the sampler's error); mc_reader_join() waits for the end and returns what mc_reader_run() would have. */
+int mc_reader_start(mc_reader *r);
+int64_t mc_reader_fetch(mc_reader *r, int64_t first, int64_t max_reads, uint8_t *dst);
+int64_t mc_reader_join(mc_reader *r);
+int32_t mc_reader_read_len(const mc_reader *r);
+
+/* process_seqfile() + search_seqs() + classify_reads() in one call (microbe_census.py:328-460): the sampler runs beside the
+ * search, batches of accepted reads go through pinned staging memory to the GPU while the batch before is searched.  Results as
+ * after mc_search(); the reader's statistics (mc_reader_get_stats) are complete when it returns.  -3: the reference would have
+ * raised while sampling (mc_last_error names the Python exception). */
+int mc_search_files(mc_handle *h, mc_reader *r, int64_t first_read_id);
+/* keep != 0 (default): mc_search() / mc_search_files() collect the m8 rows of all their batches for mc_result_rows(); 0: only the
+ * best hits and the statistics (the rows are still computed - classification reads them on the device). */
+int mc_set_keep_rows(mc_handle *h, int keep);
 
 #ifdef __cplusplus
 }

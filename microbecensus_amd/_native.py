@@ -90,41 +90,84 @@ def load_library():
     lib.mc_reader_close.argtypes = [C.c_void_p]
     lib.mc_count_bases.restype = C.c_int64
     lib.mc_count_bases.argtypes = [C.POINTER(C.c_char_p), C.c_int32]
+    lib.mc_reader_start.argtypes = [C.c_void_p]
+    lib.mc_reader_fetch.restype = C.c_int64
+    lib.mc_reader_fetch.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    lib.mc_reader_join.restype = C.c_int64
+    lib.mc_reader_join.argtypes = [C.c_void_p]
+    lib.mc_reader_read_len.restype = C.c_int32
+    lib.mc_reader_read_len.argtypes = [C.c_void_p]
+    lib.mc_search_files.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.mc_set_keep_rows.argtypes = [C.c_void_p, C.c_int]
     _lib = lib
     return lib
 
 
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
                     "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_set_parts", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8",
-                    "mc_reader_last_error", "mc_reader_open", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_count_bases"]
+                    "mc_reader_last_error", "mc_reader_open", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_count_bases",
+                    "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_search_files", "mc_set_keep_rows"]
 
 
 class ReferenceError_(Exception):
     """The reference's Python would have raised inside run_pipeline (which prints the error and returns None)."""
 
 
+class Reader:
+    """The native sampler (mc_reader_*): process_seqfile's rules on plain / .gz / .bz2 FASTA / FASTQ files.  Needs no GPU."""
+
+    def __init__(self, paths, read_len, nreads, fastq, quality_offset, min_quality, mean_quality, max_unknown, filter_dups, fasta_out=None):
+        lib = load_library()
+        if nreads is None:                   # the reference's "no cap" (its `read_id == args['nreads']` is never true for None)
+            nreads = (1 << 63) - 1
+        arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        self.lib, self.read_len = lib, read_len
+        self.r = lib.mc_reader_open(arr, len(paths), read_len, nreads, 1 if fastq else 0, int(quality_offset), float(min_quality), float(mean_quality),
+                                    float(max_unknown), 1 if filter_dups else 0, fasta_out.encode() if fasta_out else None)
+        if not self.r:
+            raise RuntimeError(lib.mc_reader_last_error().decode())
+
+    def close(self):
+        if getattr(self, "r", None):
+            self.lib.mc_reader_close(self.r)
+            self.r = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, n):
+        if n == -3:
+            raise ReferenceError_(self.lib.mc_reader_last_error().decode())
+        if n < 0:
+            raise RuntimeError(self.lib.mc_reader_last_error().decode())
+        return n
+
+    def run(self):
+        return self.check(self.lib.mc_reader_run(self.r))
+
+    def stats(self):
+        st = McReaderStats()
+        self.lib.mc_reader_get_stats(self.r, C.byref(st))
+        return {k: getattr(st, k) for k, _ in McReaderStats._fields_}
+
+    def reads(self, n):
+        """(n, read_len) uint8 view of the sampled reads; it keeps the reader alive."""
+        if not n:
+            return np.zeros((0, self.read_len), np.uint8)
+        buf = (C.c_uint8 * (n * self.read_len)).from_address(C.addressof(self.lib.mc_reader_reads(self.r).contents))
+        buf._owner = self
+        a = np.frombuffer(buf, dtype=np.uint8).reshape(n, self.read_len)
+        return a
+
+
 def sample_reads(paths, read_len, nreads, fastq, quality_offset, min_quality, mean_quality, max_unknown, filter_dups, fasta_out=None):
     """Native process_seqfile: returns (reads uint8 (n, read_len), stats dict).  Needs no GPU."""
-    lib = load_library()
-    if nreads is None:                   # the reference's "no cap" (its `read_id == args['nreads']` is never true for None)
-        nreads = (1 << 63) - 1
-    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
-    r = lib.mc_reader_open(arr, len(paths), read_len, nreads, 1 if fastq else 0, int(quality_offset), float(min_quality), float(mean_quality),
-                           float(max_unknown), 1 if filter_dups else 0, fasta_out.encode() if fasta_out else None)
-    if not r:
-        raise RuntimeError(lib.mc_reader_last_error().decode())
-    try:
-        n = lib.mc_reader_run(r)
-        if n == -3:
-            raise ReferenceError_(lib.mc_reader_last_error().decode())
-        if n < 0:
-            raise RuntimeError(lib.mc_reader_last_error().decode())
-        st = McReaderStats()
-        lib.mc_reader_get_stats(r, C.byref(st))
-        reads = np.ctypeslib.as_array(lib.mc_reader_reads(r), shape=(n * read_len,)).reshape(n, read_len).copy() if n else np.zeros((0, read_len), np.uint8)
-        return reads, {k: getattr(st, k) for k, _ in McReaderStats._fields_}
-    finally:
-        lib.mc_reader_close(r)
+    rd = Reader(paths, read_len, nreads, fastq, quality_offset, min_quality, mean_quality, max_unknown, filter_dups, fasta_out)
+    n = rd.run()
+    return rd.reads(n), rd.stats()
 
 
 def count_bases(paths):
@@ -253,6 +296,18 @@ class Engine:
         reads = np.ascontiguousarray(reads, dtype=np.uint8)
         assert reads.ndim == 2 and reads.shape[1] == self.read_len
         self._check(self.lib.mc_search(self.h, reads.ctypes.data_as(C.c_void_p), reads.shape[0], first_read_id), "mc_search")
+        return self.results()
+
+    def search_files(self, reader, first_read_id=0, keep_rows=True):
+        """process_seqfile + search_seqs + classify_reads in one call (mc_search_files): the reader samples beside the search."""
+        self._check(self.lib.mc_set_keep_rows(self.h, 1 if keep_rows else 0), "mc_set_keep_rows")
+        try:
+            rc = self.lib.mc_search_files(self.h, reader.r, first_read_id)
+            if rc == -3:
+                raise ReferenceError_(self.lib.mc_last_error().decode())
+            self._check(rc, "mc_search_files")
+        finally:
+            self.lib.mc_set_keep_rows(self.h, 1)
         return self.results()
 
     def upload(self, reads):

@@ -17,7 +17,11 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mcensus.h"
@@ -1450,6 +1454,8 @@ struct mc_handle {
     bool fast_enum = false;
     bool count_traffic = false;
     int parts = MC_NCTX;                  // parts a range is cut into (mc_set_parts; 1 = one kernel at a time, for profiling)
+    bool keep_rows = true;                // mc_search / mc_search_files hand out the m8 rows (mc_set_keep_rows)
+    uint8_t *stage_pin[2] = {nullptr, nullptr}, *stage_dev[2] = {nullptr, nullptr}; int stage_len = 0; hipStream_t copy_stream = nullptr;   // run_stream
     // resident reads
     int64_t nreads = 0, cap_own = 0;
     uint8_t *d_reads = nullptr;
@@ -1501,6 +1507,8 @@ extern "C" void mc_close(mc_handle *h)
     void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_rt};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (McCtx &c : h->ctx) ctx_free(c);
+    for (int k = 0; k < 2; k++) { if (h->stage_pin[k]) (void)hipHostFree(h->stage_pin[k]); if (h->stage_dev[k]) (void)hipFree(h->stage_dev[k]); }
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->pin_rows) (void)hipHostFree(h->pin_rows);
     delete h;
 }
@@ -1931,30 +1939,119 @@ extern "C" int mc_set_parts(mc_handle *h, int parts)
 
 extern "C" int mc_run(mc_handle *h, int64_t first_read_id) { return h ? mc_run_range(h, 0, h->nreads, first_read_id) : -1; }
 
+// The streaming form of the pipeline: batches of reads are fetched from a host-side source into pinned staging memory and
+// uploaded by a thread of their own (two staging / device buffers in turn) while the calling thread runs mc_run_range() on the
+// batch before - upload and search overlap.  fetch(first, max, dst) copies reads [first, first + max) into dst and returns
+// how many there were (0: the source has ended; < 0: its error).
+struct McBatchSlot { uint8_t *pin = nullptr, *dev = nullptr; int64_t n = 0, first = 0; int state = 0; /* 0 free, 1 ready, 2 end / error */ int64_t rc = 0; };
+
+static int run_stream(mc_handle *h, const std::function<int64_t(int64_t, int64_t, uint8_t *)> &fetch, int64_t first_read_id)
+{
+    HIPCK(hipSetDevice(h->device));
+    const int64_t B = 2000000, L = h->read_len;
+    if (!h->stage_pin[0] || h->stage_len != L) {
+        for (int k = 0; k < 2; k++) {
+            if (h->stage_pin[k]) { (void)hipHostFree(h->stage_pin[k]); h->stage_pin[k] = nullptr; }
+            if (h->stage_dev[k]) { (void)hipFree(h->stage_dev[k]); h->stage_dev[k] = nullptr; }
+            HIPCK(hipHostMalloc((void **)&h->stage_pin[k], (size_t)(B * L + 64), hipHostMallocDefault));
+            HIPCK(hipMalloc((void **)&h->stage_dev[k], (size_t)(B * L + 64)));
+        }
+        if (!h->copy_stream) HIPCK(hipStreamCreate(&h->copy_stream));
+        h->stage_len = (int)L;
+    }
+    McBatchSlot slot[2];
+    for (int k = 0; k < 2; k++) { slot[k].pin = h->stage_pin[k]; slot[k].dev = h->stage_dev[k]; }
+    std::mutex mu; std::condition_variable cv;
+    bool abort_up = false;
+    std::string up_err;
+    std::thread uploader([&] {
+        (void)hipSetDevice(h->device);
+        int64_t at = 0;
+        for (int k = 0;; k ^= 1) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return slot[k].state == 0 || abort_up; }); if (abort_up) return; }
+            const int64_t n = fetch(at, B, slot[k].pin);
+            int64_t rc = n;
+            if (n > 0) {
+                hipError_t e = hipMemcpyAsync(slot[k].dev, slot[k].pin, (size_t)(n * L), hipMemcpyHostToDevice, h->copy_stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(h->copy_stream);
+                if (e != hipSuccess) { up_err = std::string("upload: ") + hipGetErrorString(e); rc = -1; }
+            }
+            std::unique_lock<std::mutex> lk(mu);
+            slot[k].n = n > 0 ? n : 0; slot[k].first = at; slot[k].rc = rc; slot[k].state = rc > 0 ? 1 : 2;
+            cv.notify_all();
+            if (rc <= 0) return;
+            at += n;
+        }
+    });
+    std::vector<mc_row> &all_rows = h->all_rows; all_rows.clear();
+    std::vector<mc_best_hit> all_best; mc_stats tot; memset(&tot, 0, sizeof tot);
+    int rc = 0;
+    const uint8_t *saved_reads = h->reads_dev; const int64_t saved_n = h->nreads;
+    for (int k = 0;; k ^= 1) {
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return slot[k].state != 0; }); }
+        if (slot[k].state == 2) { if (slot[k].rc < 0) { rc = (int)slot[k].rc; if (!up_err.empty()) g_err = up_err; } break; }
+        h->reads_dev = slot[k].dev; h->nreads = slot[k].n;
+        // a pool overflow (-2) is answered by running the batch in smaller ranges
+        int64_t off = 0, step = slot[k].n;
+        while (off < slot[k].n) {
+            const int64_t nb = std::min<int64_t>(step, slot[k].n - off);
+            rc = mc_run_range(h, off, nb, first_read_id + slot[k].first + off);
+            if (rc == -2 && nb > 1) { step = std::max<int64_t>(1, nb / 2); rc = 0; continue; }
+            if (rc) break;
+            if (h->keep_rows) all_rows.insert(all_rows.end(), h->res_rows, h->res_rows + h->n_res_rows);
+            all_best.insert(all_best.end(), h->best.begin(), h->best.end());
+            tot.reads += h->stats.reads; tot.seed_tasks += h->stats.seed_tasks; tot.gap_tasks += h->stats.gap_tasks; tot.hsps += h->stats.hsps; tot.rows += h->stats.rows;
+            tot.reads_with_rows += h->stats.reads_with_rows; tot.classified += h->stats.classified; tot.bucket_lookups += h->stats.bucket_lookups; tot.key_probes += h->stats.key_probes;
+            tot.ms_translate += h->stats.ms_translate; tot.ms_seed += h->stats.ms_seed; tot.ms_eval += h->stats.ms_eval; tot.ms_gapped += h->stats.ms_gapped;
+            tot.ms_sort += h->stats.ms_sort; tot.ms_finish += h->stats.ms_finish; tot.ms_total += h->stats.ms_total;
+            off += nb;
+        }
+        if (rc) break;
+        { std::unique_lock<std::mutex> lk(mu); slot[k].state = 0; cv.notify_all(); }
+    }
+    { std::unique_lock<std::mutex> lk(mu); abort_up = true; cv.notify_all(); }
+    uploader.join();
+    h->reads_dev = saved_reads; h->nreads = saved_n;
+    if (rc) return rc;
+    h->res_rows = all_rows.data(); h->n_res_rows = (int64_t)all_rows.size(); h->best.swap(all_best); h->stats = tot;
+    return 0;
+}
+
 extern "C" int mc_search(mc_handle *h, const uint8_t *reads, int64_t nreads, int64_t first_read_id)
 {
     if (!h || !h->run_set) { g_err = "mc_set_run() must be called first"; return -1; }
-    const int64_t B = 1 << 20;
-    std::vector<mc_row> &all_rows = h->all_rows; all_rows.clear();
-    std::vector<mc_best_hit> all_best; mc_stats tot; memset(&tot, 0, sizeof tot);
-    if (mc_upload(h, reads, nreads)) return -1;
-    int64_t off = 0, step = B;
-    while (off < nreads || (nreads == 0 && off == 0)) {
-        int64_t nb = std::min<int64_t>(step, nreads - off);
-        int rc = mc_run_range(h, off, nb, first_read_id + off);
-        if (rc == -2 && nb > 1) { step = std::max<int64_t>(1, nb / 2); continue; }   // a pool overflowed: retry with half the batch
-        if (rc) return rc;
-        all_rows.insert(all_rows.end(), h->res_rows, h->res_rows + h->n_res_rows);
-        all_best.insert(all_best.end(), h->best.begin(), h->best.end());
-        tot.reads += h->stats.reads; tot.seed_tasks += h->stats.seed_tasks; tot.gap_tasks += h->stats.gap_tasks; tot.hsps += h->stats.hsps; tot.rows += h->stats.rows;
-        tot.reads_with_rows += h->stats.reads_with_rows; tot.classified += h->stats.classified; tot.bucket_lookups += h->stats.bucket_lookups; tot.key_probes += h->stats.key_probes;
-        tot.ms_translate += h->stats.ms_translate; tot.ms_seed += h->stats.ms_seed; tot.ms_eval += h->stats.ms_eval; tot.ms_gapped += h->stats.ms_gapped;
-        tot.ms_sort += h->stats.ms_sort; tot.ms_finish += h->stats.ms_finish; tot.ms_total += h->stats.ms_total;
-        if (nreads == 0) break;
-        off += nb;
-        if (step < B) step = std::min<int64_t>(B, step * 2);
-    }
-    h->res_rows = all_rows.data(); h->n_res_rows = (int64_t)all_rows.size(); h->best.swap(all_best); h->stats = tot;
+    if (nreads < 0 || (nreads > 0 && !reads)) { g_err = "bad argument"; return -1; }
+    const int64_t L = h->read_len;
+    return run_stream(h, [&](int64_t first, int64_t max_reads, uint8_t *dst) -> int64_t {
+        const int64_t n = std::max<int64_t>(0, std::min(max_reads, nreads - first));
+        if (n > 0) memcpy(dst, reads + first * L, (size_t)(n * L));
+        return n;
+    }, first_read_id);
+}
+
+extern "C" int mc_search_files(mc_handle *h, mc_reader *r, int64_t first_read_id)
+{
+    if (!h || !h->run_set) { g_err = "mc_set_run() must be called first"; return -1; }
+    if (!r) { g_err = "null reader"; return -1; }
+    if (mc_reader_read_len(r) != h->read_len) { g_err = "the reader trims to another length than mc_set_run() was given"; return -1; }
+    if (mc_reader_start(r) != 0) { g_err = mc_reader_last_error(); return -1; }
+    std::string ferr;
+    const int rc = run_stream(h, [&](int64_t first, int64_t max_reads, uint8_t *dst) -> int64_t {
+        const int64_t n = mc_reader_fetch(r, first, max_reads, dst);
+        if (n < 0) ferr = mc_reader_last_error();
+        return n;
+    }, first_read_id);
+    const int64_t sampled = mc_reader_join(r);
+    if (rc == -3 || sampled == -3) { g_err = ferr.empty() ? std::string(mc_reader_last_error()) : ferr; return -3; }
+    if (rc == 0 && sampled < 0) { g_err = mc_reader_last_error(); return (int)sampled; }
+    if (rc < 0 && !ferr.empty()) g_err = ferr;
+    return rc;
+}
+
+extern "C" int mc_set_keep_rows(mc_handle *h, int keep)
+{
+    if (!h) { g_err = "null handle"; return -1; }
+    h->keep_rows = keep != 0;
     return 0;
 }
 

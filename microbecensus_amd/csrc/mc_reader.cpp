@@ -1,34 +1,57 @@
 // mc_reader.cpp - native read sampler: the host stage in front of the search (include/mcensus.h, mc_reader_*).
 //
 // Replaces, with identical results, the Python stages of the reference that feed the hot path
-//   open_file            /root/reference/microbe_census/microbe_census.py:47-59   (plain and .gz; .bz2 stays in Python)
+//   open_file            /root/reference/microbe_census/microbe_census.py:47-59   (plain, .gz and .bz2)
 //   parse_seqs           :294-325   readfq-style FASTA/FASTQ records, with its quirks (below)
 //   quality_filter       :265-279
 //   process_seqfile      :328-367   head-take sampler: files in order, records in order
 //   count_bases          :573-584   second pass over every file
-// and hands the accepted reads over as one packed n x read_len byte matrix, which is what mc_search() takes.
+// and hands the accepted reads over as packed read_len-byte rows, which is what mc_search() / mc_upload() take.
 //
 // Quirks of the reference reproduced here:
 //   * text mode with universal newlines: "\r\n" and a lone "\r" end a line like "\n";
 //   * every line loses exactly its last character - the newline - so the last line of a file that does not end in a
-//     newline loses its last real character;
-//   * the record name is the header without its first character up to the first SPACE (tabs stay);
+//     newline loses its last real character; a lone '+', '>' or '@' as such a last line becomes '' and ends the parse;
 //   * sequence lines run until a line that starts with '@', '+' or '>'; after '+', quality lines are consumed until they
 //     cover the sequence length; a file that ends inside the qualities yields the record without qualities and stops;
 //   * a read is too short when len(seq) < L; duplicates (the untrimmed sequence or its reverse complement already
 //     accepted) are tested BEFORE the quality filter and only when requested; only accepted reads enter the set;
 //     reverse_complement knows ACGTN only - any other character is an error (KeyError in the reference);
 //   * QC looks at the first L bases / qualities: 100*count('N')/L > max_unknown, mean(q) < mean_quality, min(q) < min_quality
-//     with q = ord(c) - quality_offset, in IEEE double like numpy.
+//     with q = ord(c) - quality_offset, in IEEE double like numpy;
+//   * a truncated or corrupt compressed stream is an error (gzip.open raises EOFError) - but only if the sampler gets there.
+//
+// How it is made fast (the sampler is sequential by definition: head-take, first occurrence wins):
+//   * the byte stream is taken in regions of whole lines (plain files: slices of one mmap, nothing is copied; compressed
+//     files: a producer thread inflates ahead while the region in hand is parsed);
+//   * a region is cut into pieces at GUESSED record starts ('@' line whose second next line starts with '+', or a '>' line);
+//     the worker threads run the exact state machine of parse_seqs on the pieces, each from its guess up to the next one, and
+//     evaluate their records (length, N count, quality sum / minimum, 64-bit hashes of the sequence and of its reverse
+//     complement).  Then the pieces are stitched in order: a piece counts only if its predecessor ended exactly where it
+//     started - otherwise the predecessor's parser is continued sequentially until it meets a later piece's start (never
+//     happens on well-formed files, keeps odd files exact);
+//   * the merge walks the record descriptors in file order (too short / duplicate / low quality / accept, duplicates against
+//     an exact set keyed by the precomputed hashes) and assigns output slots; the workers copy the accepted reads.
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
-#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include "../../include/mcensus.h"
@@ -37,32 +60,157 @@ namespace {
 
 thread_local std::string r_err;
 
-struct LineSource {   // bytes of a plain or gzip file, split into lines with universal-newline semantics
-    // A producer thread inflates / reads the file 4 MB at a time into a ring of three blocks while the caller parses: for
-    // .gz input the inflate (the slower half) runs beside the parser instead of in front of it.
-    enum { NBLK = 3, BLK = 1 << 22 };
-    gzFile gz = nullptr;
-    std::thread th;
+// ------------------------------------------------------------------------------------------------------------------
+// worker pool: run(n, f) calls f(i) for i in [0, n) on the pool's threads and the caller
+// ------------------------------------------------------------------------------------------------------------------
+struct Pool {
+    std::vector<std::thread> th;
     std::mutex mu;
-    std::condition_variable cv;
-    std::vector<unsigned char> ring[NBLK];
-    size_t ring_n[NBLK] = {0, 0, 0};
+    std::condition_variable cv, cv_done;
+    const std::function<void(int)> *job = nullptr;
+    int njobs = 0, busy = 0;
+    std::atomic<int> next{0};
+    uint64_t gen = 0;
+    bool stop = false;
+    explicit Pool(int nthreads) { for (int i = 1; i < nthreads; i++) th.emplace_back([this] { loop(); }); }
+    ~Pool()
+    {
+        { std::unique_lock<std::mutex> lk(mu); stop = true; cv.notify_all(); }
+        for (auto &t : th) t.join();
+    }
+    int size() const { return (int)th.size() + 1; }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)> *f;
+            int n;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen; f = job; n = njobs;
+                if (!f) continue;
+                busy++;
+            }
+            for (int i; (i = next.fetch_add(1)) < n;) (*f)(i);
+            { std::unique_lock<std::mutex> lk(mu); if (--busy == 0) cv_done.notify_all(); }
+        }
+    }
+    void run(int n, const std::function<void(int)> &f)
+    {
+        if (n <= 0) return;
+        if (th.empty() || n == 1) { for (int i = 0; i < n; i++) f(i); return; }
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            job = &f; njobs = n; next.store(0); busy = 1; gen++;
+            cv.notify_all();
+        }
+        for (int i; (i = next.fetch_add(1)) < n;) f(i);
+        std::unique_lock<std::mutex> lk(mu);
+        busy--;
+        cv_done.wait(lk, [&] { return busy == 0; });
+        job = nullptr;                                   // (a worker that wakes up late finds no job and goes back to sleep)
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// byte stream of one file: a window of contiguous bytes that can be extended at its end and consumed at its front
+// ------------------------------------------------------------------------------------------------------------------
+bool has_ext(const char *path, const char *ext) { size_t n = strlen(path), m = strlen(ext); return n >= m && strcmp(path + n - m, ext) == 0; }
+
+// libbz2 is on every machine that runs Python's bz2 module, but its header is not in this image: the four entry points of
+// its stdio-like interface are bound at run time
+struct Bz2Api {
+    void *lib = nullptr;
+    void *(*open)(const char *, const char *) = nullptr;
+    int (*read)(void *, void *, int) = nullptr;
+    void (*close)(void *) = nullptr;
+    const char *(*error)(void *, int *) = nullptr;
+    bool load()
+    {
+        if (lib) return open != nullptr;
+        for (const char *n : {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so"}) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        if (!lib) return false;
+        open = (void *(*)(const char *, const char *))dlsym(lib, "BZ2_bzopen");
+        read = (int (*)(void *, void *, int))dlsym(lib, "BZ2_bzread");
+        close = (void (*)(void *))dlsym(lib, "BZ2_bzclose");
+        error = (const char *(*)(void *, int *))dlsym(lib, "BZ2_bzerror");
+        if (!(open && read && close && error)) { open = nullptr; return false; }
+        return true;
+    }
+};
+Bz2Api g_bz2;
+std::mutex g_bz2_mu;
+
+struct Stream {
+    enum { NBLK = 16, BLK = 1 << 22 };
+    // plain file: one mapping; the window is a slice of it
+    const uint8_t *map = nullptr; size_t map_n = 0;
+    // compressed stream: a producer thread inflates BLK-sized blocks into a ring; the window lives in `buf`
+    gzFile gz = nullptr; void *bz = nullptr;
+    std::thread th;
+    std::mutex mu; std::condition_variable cv;
+    std::vector<uint8_t> ring[NBLK]; size_t ring_n[NBLK] = {};
     int head = 0, tail = 0, count = 0;
-    bool prod_done = false, stop = false, prod_err = false;   // prod_err: the stream is truncated or corrupt (gzip.open raises there)
+    bool prod_done = false, prod_err = false, stop = false;
     std::string prod_msg;
-    std::vector<unsigned char> buf;
-    size_t pos = 0, end = 0;
-    bool eof = false, pending_cr = false;
-    ~LineSource() { close(); }
+    std::vector<uint8_t> buf; size_t buf_at = 0;
+    // the window
+    const uint8_t *win = nullptr; size_t len = 0;
+    bool at_end = false;                        // nothing can be added to the window any more
+    bool failed = false;                        // ... because the stream is truncated / corrupt
+    bool compressed = false;
+
+    ~Stream() { close(); }
     bool open(const char *path)
     {
-        gz = gzopen(path, "rb");                 // zlib reads plain files transparently as well
-        if (!gz) return false;
-        gzbuffer(gz, 1 << 20);
-        buf.resize(BLK);
-        for (auto &r : ring) r.resize(BLK);
-        th = std::thread([this] { produce(); });
+        if (has_ext(path, ".bz2")) {
+            std::unique_lock<std::mutex> lk(g_bz2_mu);
+            if (!g_bz2.load()) { r_err = "cannot load libbz2 for " + std::string(path); return false; }
+            bz = g_bz2.open(path, "rb");
+            if (!bz) { r_err = std::string("cannot open ") + path; return false; }
+            compressed = true;
+        } else {
+            int fd = ::open(path, O_RDONLY);
+            if (fd < 0) { r_err = std::string("cannot open ") + path; return false; }
+            unsigned char magic[2] = {0, 0};
+            const ssize_t got = pread(fd, magic, 2, 0);
+            struct stat sb;
+            const bool reg = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+            if ((got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) || !reg) {   // gzip by its magic (zlib reads anything else transparently: pipes)
+                gz = gzdopen(fd, "rb");
+                if (!gz) { ::close(fd); r_err = std::string("cannot open ") + path; return false; }
+                gzbuffer(gz, 1 << 20);
+                compressed = true;
+            } else {
+                map_n = (size_t)sb.st_size;
+                if (map_n) {
+                    void *m = mmap(nullptr, map_n, PROT_READ, MAP_PRIVATE, fd, 0);
+                    if (m == MAP_FAILED) { ::close(fd); r_err = std::string("cannot map ") + path; return false; }
+                    madvise(m, map_n, MADV_SEQUENTIAL);
+                    map = (const uint8_t *)m;
+                }
+                ::close(fd);
+                win = map; len = 0;
+                if (map_n == 0) at_end = true;
+            }
+        }
+        if (compressed) {
+            for (auto &r : ring) r.resize(BLK);
+            th = std::thread([this] { produce(); });
+        }
         return true;
+    }
+    void close()
+    {
+        if (th.joinable()) {
+            { std::unique_lock<std::mutex> lk(mu); stop = true; cv.notify_all(); }
+            th.join();
+        }
+        if (gz) { gzclose(gz); gz = nullptr; }
+        if (bz) { g_bz2.close(bz); bz = nullptr; }
+        if (map) { munmap((void *)map, map_n); map = nullptr; }
     }
     void produce()
     {
@@ -74,148 +222,287 @@ struct LineSource {   // bytes of a plain or gzip file, split into lines with un
                 if (stop) return;
                 slot = tail;
             }
-            const int n = gzread(gz, ring[slot].data(), (unsigned)BLK);
-            std::unique_lock<std::mutex> lk(mu);
-            if (n <= 0) {
-                // gzip.open raises EOFError / BadGzipFile on a truncated or corrupt stream (reference :47-59); zlib reports a
-                // truncated stream as Z_BUF_ERROR, a damaged one as Z_DATA_ERROR - a clean end leaves Z_OK / Z_STREAM_END and gzeof
-                int errnum = 0;
-                const char *msg = gzerror(gz, &errnum);
-                if (n < 0 || (errnum != Z_OK && errnum != Z_STREAM_END) || !gzeof(gz)) { prod_err = true; prod_msg = msg ? msg : "read error"; }
-                prod_done = true; cv.notify_all(); return;
+            int n;
+            bool bad = false;
+            std::string msg;
+            if (gz) {
+                n = gzread(gz, ring[slot].data(), (unsigned)BLK);
+                if (n < (int)BLK) {
+                    // gzip.open raises EOFError / BadGzipFile on a truncated or corrupt stream (reference :47-59); zlib reports a
+                    // truncated stream as Z_BUF_ERROR, a damaged one as Z_DATA_ERROR - a clean end leaves Z_OK / Z_STREAM_END and gzeof
+                    int errnum = 0;
+                    const char *m = gzerror(gz, &errnum);
+                    if (n < 0 || (errnum != Z_OK && errnum != Z_STREAM_END) || !gzeof(gz)) { bad = true; msg = m ? m : "read error"; }
+                }
+            } else {
+                n = g_bz2.read(bz, ring[slot].data(), (int)BLK);
+                if (n < (int)BLK) {
+                    int errnum = 0;
+                    const char *m = g_bz2.error(bz, &errnum);
+                    if (n < 0 || (errnum != 0 /* BZ_OK */ && errnum != 4 /* BZ_STREAM_END */)) { bad = true; msg = m ? m : "read error"; }
+                }
             }
-            ring_n[slot] = (size_t)n; tail = (tail + 1) % NBLK; count++;
+            std::unique_lock<std::mutex> lk(mu);
+            if (n > 0) { ring_n[slot] = (size_t)n; tail = (tail + 1) % NBLK; count++; }
+            if (n < (int)BLK) { prod_done = true; prod_err = bad; prod_msg = msg; cv.notify_all(); return; }
             cv.notify_all();
         }
     }
-    void close()
+    // make the window at least `want` bytes long if the stream has them
+    void extend(size_t want)
     {
-        if (th.joinable()) {
-            { std::unique_lock<std::mutex> lk(mu); stop = true; cv.notify_all(); }
-            th.join();
+        if (!compressed) {
+            const size_t have = (size_t)(map + map_n - win);
+            len = std::min(want, have);
+            if (len == have) at_end = true;
+            return;
         }
-        if (gz) { gzclose(gz); gz = nullptr; }
-    }
-    bool fill()
-    {
-        if (eof) return false;
-        if (pos < end) { memmove(buf.data(), buf.data() + pos, end - pos); }
-        end -= pos; pos = 0;
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [this] { return count > 0 || prod_done; });
-        if (count == 0) { eof = true; return false; }
-        const size_t n = ring_n[head];
-        if (end + n > buf.size()) buf.resize(end + n > buf.size() * 2 ? end + n : buf.size() * 2);
-        lk.unlock();
-        memcpy(buf.data() + end, ring[head].data(), n);          // (the producer never touches a block that is still counted)
-        end += n;
-        lk.lock();
-        head = (head + 1) % NBLK; count--;
-        cv.notify_all();
-        return true;
-    }
-    // Next line: [*p, *p + *n) = the characters in front of the terminator (valid until the next call); *nl = the line
-    // had a terminator.  Returns false at end of file (no line).
-    bool next(const unsigned char **p, size_t *n, bool *nl)
-    {
-        if (pending_cr) {                        // "\r" ended the previous line: a directly following "\n" belongs to it
-            if (pos == end) fill();
-            if (pos < end && buf[pos] == '\n') pos++;
-            pending_cr = false;
-        }
-        size_t scan = 0;                         // characters after pos already known to hold no terminator
-        for (;;) {
-            const unsigned char *b = buf.data() + pos;
-            const size_t avail = end - pos;
-            const unsigned char *q = (const unsigned char *)memchr(b + scan, '\n', avail - scan);
-            const size_t lim = q ? (size_t)(q - b) : avail;
-            const unsigned char *c = (const unsigned char *)memchr(b + scan, '\r', lim - scan);
-            if (c) q = c;
-            if (q) {
-                const size_t at = (size_t)(q - b);
-                *p = b; *n = at; *nl = true;
-                pending_cr = (*q == '\r');
-                pos += at + 1;
-                return true;
+        while (len < want && !at_end) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [this] { return count > 0 || prod_done; });
+            if (count == 0) { at_end = true; failed = prod_err; break; }
+            const size_t n = ring_n[head];
+            lk.unlock();
+            if (buf_at + len + n > buf.size()) {                         // make room: move the window to the front, grow if needed
+                if (buf_at) { memmove(buf.data(), buf.data() + buf_at, len); buf_at = 0; }
+                if (len + n > buf.size()) buf.resize(std::max(len + n, buf.size() * 2));
             }
-            scan = avail;
-            if (!fill()) {
-                if (end == pos) return false;
-                *p = buf.data() + pos; *n = end - pos; *nl = false;
-                pos = end;
-                return true;
-            }
+            memcpy(buf.data() + buf_at + len, ring[head].data(), n);
+            len += n;
+            lk.lock();
+            head = (head + 1) % NBLK; count--;
+            cv.notify_all();
         }
+        win = buf.data() + buf_at;
+    }
+    void consume(size_t k)
+    {
+        if (!compressed) { win += k; len -= k; return; }
+        buf_at += k; len -= k; win = buf.data() + buf_at;
     }
 };
 
-struct Record { std::string seq, qual; bool has_qual = false; };
-
-// parse_seqs (reference :294-325) as a pull parser
-struct Parser {
-    LineSource src;
-    bool have_pending = false, done = false;
-    std::string pending;                         // header line without its last character
-    static void chomp(const unsigned char *p, size_t n, bool nl, std::string &out)
-    { // line[:-1]
-        if (!nl && n > 0) n--;
-        out.assign((const char *)p, n);
+// [p, p + n) cut back to whole lines (0: no line end found)
+size_t whole_lines(const uint8_t *p, size_t n)
+{
+    for (size_t i = n; i > 0; i--) {
+        if (p[i - 1] == '\n') return i;
+        if (n - i > ((size_t)16 << 20)) break;
     }
-    bool next(Record &rec)
+    for (size_t i = n; i > 1; i--) if (p[i - 2] == '\r' && p[i - 1] != '\n') return i - 1;   // lone-CR files: a '\r' whose successor is known
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// parse_seqs as a restartable state machine over a region of whole lines, and the per-record evaluation
+// ------------------------------------------------------------------------------------------------------------------
+enum : uint8_t { R_SHORT = 1, R_QUAL = 2, R_RCBAD = 4 };
+struct Rec {
+    const uint8_t *seq; const uint8_t *qual;
+    uint32_t len, qlen;
+    uint32_t ncount, nq; int32_t qmin; int64_t qsum;   // first L bases / first min(L, qlen) qualities
+    uint64_t h1, h2;                                   // hashes of the sequence and of its reverse complement (only with -d)
+    uint32_t out;                                      // slot in the output of this region (or ~0)
+    uint8_t flags;
+};
+
+struct Arena {   // stable storage for records whose sequence spans several lines
+    std::vector<std::unique_ptr<uint8_t[]>> blocks; size_t at = 0, cap = 0;
+    uint8_t *alloc(size_t n)
     {
-        if (done) return false;
-        const unsigned char *p; size_t n; bool nl;
-        if (!have_pending) {
-            for (;;) {
-                if (!src.next(&p, &n, &nl)) { done = true; return false; }
-                if (n > 0 && (p[0] == '>' || p[0] == '@')) { chomp(p, n, nl, pending); have_pending = true; break; }
+        if (at + n > cap) { cap = std::max<size_t>(n, 1 << 20); blocks.emplace_back(new uint8_t[cap]); at = 0; }
+        uint8_t *p = blocks.back().get() + at; at += n; return p;
+    }
+    void clear() { blocks.clear(); at = cap = 0; }
+};
+
+struct Piece {
+    size_t start = 0, stop = 0, end = 0;               // offsets into the region: first byte, guessed start of the next piece, first unconsumed byte
+    bool done = false;                                  // the parser reached its terminal state (the generator returned)
+    std::vector<Rec> recs;
+    Arena arena;
+    int64_t bases = 0;
+};
+
+struct Line { const uint8_t *p; size_t n; bool nl; size_t off; };
+// next line of [pos, e): content without terminator; returns false at e
+inline bool next_line(const uint8_t *base, size_t &pos, size_t e, Line &ln)
+{
+    if (pos >= e) return false;
+    const uint8_t *b = base + pos;
+    const size_t avail = e - pos;
+    const uint8_t *q = (const uint8_t *)memchr(b, '\n', avail);
+    const size_t lim = q ? (size_t)(q - b) : avail;
+    const uint8_t *c = lim ? (const uint8_t *)memchr(b, '\r', lim) : nullptr;
+    if (c) q = c;
+    ln.p = b; ln.off = pos;
+    if (!q) { ln.n = avail; ln.nl = false; pos = e; return true; }
+    ln.n = (size_t)(q - b); ln.nl = true;
+    pos += ln.n + 1;
+    if (*q == '\r' && pos < e && base[pos] == '\n') pos++;
+    return true;
+}
+
+uint64_t h64(const uint8_t *p, size_t n)
+{
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xff51afd7ed558ccdull);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = (h ^ w) * 0x9FB21C651E98DF25ull; h ^= h >> 29; }
+    uint64_t w = 0;
+    if (i < n) { memcpy(&w, p + i, n - i); h = (h ^ w) * 0x9FB21C651E98DF25ull; h ^= h >> 29; }
+    h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 32;
+    return h;
+}
+struct RcTab { uint8_t t[256]; RcTab() { memset(t, 0, sizeof t); t['A'] = 'T'; t['T'] = 'A'; t['G'] = 'C'; t['C'] = 'G'; t['N'] = 'N'; } };
+const RcTab g_rc;
+// the same hash over the reverse complement, read off the sequence backwards; false: a base outside ACGTN
+bool h64_rc(const uint8_t *p, size_t n, uint64_t *out)
+{
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xff51afd7ed558ccdull);
+    uint8_t all = 0xFF;
+    size_t i = 0;
+    const uint8_t *q = p + n;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w = 0;
+        for (int k = 0; k < 8; k++) { const uint8_t d = g_rc.t[*--q]; all &= (uint8_t)(d ? 0xFF : 0); w |= (uint64_t)d << (8 * k); }
+        h = (h ^ w) * 0x9FB21C651E98DF25ull; h ^= h >> 29;
+    }
+    if (i < n) {
+        uint64_t w = 0;
+        for (int k = 0; i < n; i++, k++) { const uint8_t d = g_rc.t[*--q]; all &= (uint8_t)(d ? 0xFF : 0); w |= (uint64_t)d << (8 * k); }
+        h = (h ^ w) * 0x9FB21C651E98DF25ull; h ^= h >> 29;
+    }
+    h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 32;
+    *out = h;
+    return all != 0 || n == 0;
+}
+
+struct Params { size_t L = 0; int fastq = 0, qoff = 0, dups = 0; bool count_only = false; };
+
+void evaluate(Rec &r, const Params &P)
+{
+    r.flags = (r.qual ? R_QUAL : 0); r.out = ~0u;
+    r.ncount = 0; r.nq = 0; r.qmin = 1 << 30; r.qsum = 0; r.h1 = r.h2 = 0;
+    if (P.count_only) return;
+    if (r.len < P.L) { r.flags |= R_SHORT; return; }
+    uint32_t nc = 0;
+    for (size_t i = 0; i < P.L; i++) nc += (r.seq[i] == 'N');
+    r.ncount = nc;
+    if (P.fastq && r.qual) {
+        const size_t nq = r.qlen < P.L ? r.qlen : P.L;
+        int64_t sum = 0; int mn = 1 << 30;
+        for (size_t i = 0; i < nq; i++) { const int q = (int)r.qual[i] - P.qoff; sum += q; mn = q < mn ? q : mn; }
+        r.nq = (uint32_t)nq; r.qsum = sum; r.qmin = mn;
+    }
+    if (P.dups) { r.h1 = h64(r.seq, r.len); if (!h64_rc(r.seq, r.len, &r.h2)) r.flags |= R_RCBAD; }
+}
+
+// Runs parse_seqs (reference :294-325) over region[start, e) until a header line at an offset >= stop would be consumed (or
+// the region ends).  eof: the region ends the file (else an unfinished record at its end is left for the next region:
+// pc.end = offset of its header line).
+void parse_piece(const uint8_t *base, size_t e, bool eof, Piece &pc, const Params &P)
+{
+    size_t pos = pc.start;
+    const size_t stop = pc.stop;
+    Line ln;
+    bool have_hdr = false;
+    size_t hdr_off = 0;
+    auto chomped = [](const Line &l) { return (!l.nl && l.n > 0) ? l.n - 1 : l.n; };   // len(line[:-1])
+    auto emit = [&](const uint8_t *s, size_t sn, const uint8_t *q, size_t qn, bool hasq) {
+        Rec r; r.seq = s; r.len = (uint32_t)sn; r.qual = hasq ? q : nullptr; r.qlen = hasq ? (uint32_t)qn : 0;
+        evaluate(r, P);
+        pc.bases += (int64_t)sn;
+        pc.recs.push_back(r);
+    };
+    for (;;) {
+        if (!have_hdr) {                                             // search for the start of the next record
+            bool found = false;
+            while (next_line(base, pos, e, ln)) {
+                if (ln.n > 0 && (ln.p[0] == '>' || ln.p[0] == '@')) {
+                    if (ln.off >= stop) { pc.end = ln.off; return; }
+                    found = true; hdr_off = ln.off;
+                    break;
+                }
             }
-            if (pending.empty()) { done = true; return false; }        // a lone '>' / '@' without newline at the end of the file: `if not last: break`
+            if (!found) { pc.end = e; if (eof) pc.done = true; return; }
+            if (chomped(ln) == 0) { pc.end = e; pc.done = true; return; }   // a lone '>' / '@' without newline ends the file: `if not last: break`
         }
-        have_pending = false;
-        rec.seq.clear(); rec.qual.clear(); rec.has_qual = false;
+        have_hdr = false;
+        // the sequence: lines up to one that starts with '@', '+' or '>'
+        const uint8_t *s0 = nullptr; size_t sn = 0; int nparts = 0; uint8_t *joined = nullptr; size_t jcap = 0;
         bool got_next = false;
+        Line nx{};
         for (;;) {
-            if (!src.next(&p, &n, &nl)) break;
-            if (n > 0 && (p[0] == '@' || p[0] == '+' || p[0] == '>')) { chomp(p, n, nl, pending); got_next = true; break; }
-            size_t m = (!nl && n > 0) ? n - 1 : n;
-            rec.seq.append((const char *)p, m);
+            if (!next_line(base, pos, e, ln)) break;
+            if (ln.n > 0 && (ln.p[0] == '@' || ln.p[0] == '+' || ln.p[0] == '>')) { nx = ln; got_next = true; break; }
+            const size_t m = chomped(ln);
+            if (nparts == 0) { s0 = ln.p; sn = m; }
+            else {                                                   // a sequence over several lines is joined in the piece's arena
+                if (nparts == 1) { jcap = std::max<size_t>((sn + m) * 2, 256); joined = pc.arena.alloc(jcap); if (sn) memcpy(joined, s0, sn); }
+                else if (sn + m > jcap) { const size_t nc = (sn + m) * 2; uint8_t *nj = pc.arena.alloc(nc); memcpy(nj, joined, sn); joined = nj; jcap = nc; }
+                memcpy(joined + sn, ln.p, m); sn += m;
+            }
+            nparts++;
         }
-        if (!got_next) { done = true; return true; }                 // last record of the file, no qualities
-        if (pending.empty()) { done = true; return true; }           // `not last or last[0] != '+'` short-circuits on the empty header: the record goes out without qualities, the parser stops
-        if (pending[0] != '+') { have_pending = true; return true; }
-        size_t got = 0;
+        const uint8_t *seq = nparts <= 1 ? s0 : joined;
+        if (!got_next) {                                              // ran out of lines
+            if (!eof) { pc.end = hdr_off; return; }                  // unfinished: the next region starts again at its header
+            emit(seq, sn, nullptr, 0, false); pc.end = e; pc.done = true; return;
+        }
+        const size_t nxn = chomped(nx);
+        if (nxn == 0) { emit(seq, sn, nullptr, 0, false); pc.end = e; pc.done = true; return; }   // '' : record goes out, the generator returns
+        if (nx.p[0] != '+') {                                          // a FASTA record; nx is the next header
+            emit(seq, sn, nullptr, 0, false);
+            if (nx.off >= stop) { pc.end = nx.off; return; }
+            have_hdr = true; hdr_off = nx.off;
+            continue;
+        }
+        // qualities: lines until they cover the sequence
+        const uint8_t *q0 = nullptr; size_t qn = 0; int qparts = 0; uint8_t *qj = nullptr; size_t qcap = 0;
         bool complete = false;
         for (;;) {
-            if (!src.next(&p, &n, &nl)) break;
-            size_t m = (!nl && n > 0) ? n - 1 : n;
-            rec.qual.append((const char *)p, m);
-            // the reference counts len(line) - 1: a last line without newline that is empty cannot occur
-            got += m;
-            if (got >= rec.seq.size()) { complete = true; break; }
+            if (!next_line(base, pos, e, ln)) break;
+            const size_t m = chomped(ln);
+            if (qparts == 0) { q0 = ln.p; qn = m; }
+            else {
+                if (qparts == 1) { qcap = std::max<size_t>((qn + m) * 2, 256); qj = pc.arena.alloc(qcap); if (qn) memcpy(qj, q0, qn); }
+                else if (qn + m > qcap) { const size_t nc = (qn + m) * 2; uint8_t *nj = pc.arena.alloc(nc); memcpy(nj, qj, qn); qj = nj; qcap = nc; }
+                memcpy(qj + qn, ln.p, m); qn += m;
+            }
+            qparts++;
+            if (qn >= sn) { complete = true; break; }
         }
-        if (complete) { rec.has_qual = true; return true; }
-        rec.qual.clear(); done = true;                                 // truncated qualities: record without them, then stop
-        return true;
+        if (complete) { emit(seq, sn, qparts <= 1 ? q0 : qj, qn, true); continue; }
+        if (!eof) { pc.end = hdr_off; return; }
+        emit(seq, sn, nullptr, 0, false); pc.end = e; pc.done = true; return;   // the file ends inside the qualities
     }
-};
+}
+
+// guessed record start at or behind `from`: offset of a '@' line whose second next line starts with '+', or of a '>' line
+size_t guess_start(const uint8_t *base, size_t from, size_t e)
+{
+    size_t pos = from;
+    Line ln;
+    if (pos > 0) { if (!next_line(base, pos, e, ln)) return e; }     // (skip the line `from` points into)
+    for (int tries = 0; tries < 64; tries++) {
+        const size_t at = pos;
+        if (!next_line(base, pos, e, ln)) return e;
+        if (ln.n == 0) continue;
+        if (ln.p[0] == '>') return at;
+        if (ln.p[0] == '@') {
+            size_t p2 = pos; Line a, b;
+            if (next_line(base, p2, e, a) && next_line(base, p2, e, b) && b.n > 0 && b.p[0] == '+' && !(a.n > 0 && (a.p[0] == '@' || a.p[0] == '>' || a.p[0] == '+'))) return at;
+        }
+    }
+    return e;
+}
 
 // Exact set of the accepted (untrimmed) sequences for -d: the strings live back to back in one arena, an open-addressing
 // table holds (hash, offset) - no allocation per sequence, one cache miss per lookup; equality is decided on the bytes.
 struct SeqSet {
-    std::vector<char> arena;
+    std::vector<uint8_t> arena;
     std::vector<uint64_t> hash, off;             // off: arena offset + 1 (0 = empty slot); the length sits in front of the bytes
     size_t used = 0;
-    static uint64_t h64(const char *p, size_t n)
-    {
-        uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xff51afd7ed558ccdull);
-        size_t i = 0;
-        for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = (h ^ w) * 0x9FB21C651E98DF25ull; h ^= h >> 29; }
-        uint64_t w = 0;
-        if (i < n) { memcpy(&w, p + i, n - i); h = (h ^ w) * 0x9FB21C651E98DF25ull; h ^= h >> 29; }
-        h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 32;
-        return h;
-    }
     void grow()
     {
         const size_t cap = hash.empty() ? (1u << 16) : hash.size() * 2;
@@ -223,33 +510,120 @@ struct SeqSet {
         for (size_t i = 0; i < hash.size(); i++) if (off[i]) { size_t j = hash[i] & (cap - 1); while (no[j]) j = (j + 1) & (cap - 1); nh[j] = hash[i]; no[j] = off[i]; }
         hash.swap(nh); off.swap(no);
     }
-    bool contains(const std::string &s) const
+    // is s (rc = false) or the reverse complement of s (rc = true) in the set?  h = the matching hash
+    bool contains(uint64_t h, const uint8_t *s, size_t n, bool rc) const
     {
         if (hash.empty()) return false;
-        const uint64_t h = h64(s.data(), s.size());
         for (size_t j = h & (hash.size() - 1);; j = (j + 1) & (hash.size() - 1)) {
             if (!off[j]) return false;
             if (hash[j] == h) {
-                const char *q = arena.data() + (off[j] - 1);
+                const uint8_t *q = arena.data() + (off[j] - 1);
                 uint64_t len; memcpy(&len, q, 8);
-                if (len == s.size() && memcmp(q + 8, s.data(), s.size()) == 0) return true;
+                if (len == n) {
+                    q += 8;
+                    if (!rc) { if (memcmp(q, s, n) == 0) return true; }
+                    else { size_t i = 0; for (; i < n; i++) if (q[i] != g_rc.t[s[n - 1 - i]]) break; if (i == n) return true; }
+                }
             }
         }
     }
-    void insert(const std::string &s)              // (the caller has checked that it is not there)
+    void insert(uint64_t h, const uint8_t *s, size_t n)              // (the caller has checked that it is not there)
     {
         if ((used + 1) * 2 > hash.size()) grow();
-        const uint64_t h = h64(s.data(), s.size()), len = s.size();
+        const uint64_t len = n;
         const size_t o = arena.size();
-        arena.resize(o + 8 + s.size());
-        memcpy(arena.data() + o, &len, 8); memcpy(arena.data() + o + 8, s.data(), s.size());
+        arena.resize(o + 8 + n);
+        memcpy(arena.data() + o, &len, 8); memcpy(arena.data() + o + 8, s, n);
         size_t j = h & (hash.size() - 1);
         while (off[j]) j = (j + 1) & (hash.size() - 1);
         hash[j] = h; off[j] = o + 1; used++;
     }
 };
 
-bool is_bz2(const char *path) { size_t n = strlen(path); return n >= 4 && strcmp(path + n - 4, ".bz2") == 0; }
+int reader_threads()
+{
+    if (const char *e = getenv("MC_READER_THREADS")) { const int v = atoi(e); if (v >= 1) return v > 256 ? 256 : v; }
+    const unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::min<unsigned>(hc ? hc : 1, 32);
+}
+
+// One file, region by region.  on_region(pieces) sees the stitched pieces of a region in file order and returns false to stop
+// the file early (sampler full).  Returns 0, or -1 (I/O) / -3 (the reference would have raised).
+int walk_file(const std::string &path, const Params &P, Pool &pool, const std::function<bool(std::vector<Piece *> &)> &on_region)
+{
+    Stream st;
+    if (!st.open(path.c_str())) return -1;
+    const int T = pool.size();
+    size_t region_bytes = (size_t)std::max(1, std::min(T, 16)) * ((size_t)4 << 20), piece_bytes = (size_t)256 << 10;
+    if (const char *v = getenv("MC_READER_REGION_BYTES")) region_bytes = std::max<size_t>(16, (size_t)atoll(v));   // (tests: many regions and pieces on small files)
+    if (const char *v = getenv("MC_READER_PIECE_BYTES")) piece_bytes = std::max<size_t>(1, (size_t)atoll(v));
+    std::vector<Piece> pieces;
+    bool parser_done = false;
+    while (!parser_done) {
+        st.extend(region_bytes);
+        if (st.len == 0) {
+            if (st.failed) { r_err = "EOFError: compressed file ended before the end-of-stream marker was reached (" + path + ": " + st.prod_msg + ")"; return -3; }
+            break;
+        }
+        // the region: whole lines, unless the stream ends here; a damaged stream never "ends" - what lies in front of the damage is
+        // parsed like any region in the middle of a file, and the error surfaces when the parser wants more
+        const bool eof = st.at_end && !st.failed;
+        size_t e = eof ? st.len : whole_lines(st.win, st.len);
+        if (e == 0) {
+            if (st.at_end) { r_err = "EOFError: compressed file ended before the end-of-stream marker was reached (" + path + ": " + st.prod_msg + ")"; return -3; }
+            region_bytes *= 2; continue;
+        }
+        const uint8_t *base = st.win;
+        // pieces at guessed record starts
+        const int np = (int)std::max<size_t>(1, std::min<size_t>(piece_bytes < 4096 ? 4096 : (size_t)T * 4, e / piece_bytes));
+        std::vector<size_t> starts{0};
+        for (int k = 1; k < np; k++) {
+            const size_t g = guess_start(base, e / np * k, e);
+            if (g < e && g > starts.back()) starts.push_back(g);
+        }
+        pieces.clear(); pieces.resize(starts.size());
+        for (size_t k = 0; k < starts.size(); k++) { pieces[k].start = starts[k]; pieces[k].stop = k + 1 < starts.size() ? starts[k + 1] : e; }
+        pool.run((int)pieces.size(), [&](int k) { parse_piece(base, e, eof, pieces[k], P); });
+        // stitch in file order: a piece counts only if the parse so far ended exactly at its (guessed) start; where no piece starts,
+        // the parser is continued sequentially up to the next guess
+        std::vector<Piece *> order;
+        std::vector<std::unique_ptr<Piece>> extra;
+        size_t at = 0, k = 0;
+        bool done = false;
+        while (at < e && !done) {
+            while (k < pieces.size() && pieces[k].start < at) k++;      // guesses inside a record that ran over them
+            Piece *pc;
+            if (k < pieces.size() && pieces[k].start == at) pc = &pieces[k++];
+            else {
+                extra.emplace_back(new Piece());
+                pc = extra.back().get();
+                pc->start = at; pc->stop = k < pieces.size() ? pieces[k].start : e;
+                parse_piece(base, e, eof, *pc, P);
+            }
+            done = pc->done;
+            if (pc->end == at && pc->recs.empty() && !done) break;      // an unfinished record at the end of the region: the next region starts with it
+            order.push_back(pc);
+            at = pc->end;
+        }
+        parser_done = done;
+        const bool go_on = on_region(order);
+        if (!go_on) return 0;
+        if (parser_done) break;
+        if (at == 0) {                                               // one record larger than the region: take more
+            if (st.at_end) {
+                if (st.failed) { r_err = "EOFError: compressed file ended before the end-of-stream marker was reached (" + path + ": " + st.prod_msg + ")"; return -3; }
+                break;
+            }
+            region_bytes *= 2; continue;
+        }
+        st.consume(at);
+        if (st.len == 0 && st.at_end) {
+            if (st.failed) { r_err = "EOFError: compressed file ended before the end-of-stream marker was reached (" + path + ": " + st.prod_msg + ")"; return -3; }
+            break;
+        }
+    }
+    return 0;
+}
 
 }   // namespace
 
@@ -259,8 +633,26 @@ struct mc_reader {
     int64_t nreads = 0;
     double min_q = 0, mean_q = 0, max_unknown = 0;
     std::string fasta_out;
-    std::vector<uint8_t> reads;
+    uint8_t *reads = nullptr; size_t reads_cap = 0, reads_n = 0;   // anonymous mapping grown with mremap (no copies, no zero fill up front)
     mc_reader_stats st{};
+    // streaming (mc_reader_start / fetch / join): the sampler runs on a thread of its own and publishes how far it has got
+    std::thread run_th;
+    std::mutex pmu; std::condition_variable pcv;
+    int64_t published = 0; bool finished = false; int64_t result = 0; std::string result_err;
+    std::shared_mutex buf_mu;                                      // mremap may move the rows while a consumer copies
+    ~mc_reader() { if (run_th.joinable()) run_th.join(); if (reads) munmap(reads, reads_cap); }
+    bool reserve(size_t bytes)
+    {
+        if (bytes <= reads_cap) return true;
+        size_t want = std::max<size_t>(bytes, reads_cap * 2);
+        want = (want + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        std::unique_lock<std::shared_mutex> lk(buf_mu);
+        void *p = reads ? mremap(reads, reads_cap, want, MREMAP_MAYMOVE) : mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (p == MAP_FAILED) return false;
+        reads = (uint8_t *)p; reads_cap = want;
+        return true;
+    }
+    void publish(int64_t kept) { std::unique_lock<std::mutex> lk(pmu); published = kept; pcv.notify_all(); }
 };
 
 extern "C" const char *mc_reader_last_error(void) { return r_err.c_str(); }
@@ -269,7 +661,6 @@ extern "C" mc_reader *mc_reader_open(const char *const *paths, int32_t npaths, i
                                      double min_quality, double mean_quality, double max_unknown, int32_t filter_dups, const char *fasta_out)
 {
     if (npaths <= 0 || read_len <= 0 || nreads <= 0) { r_err = "mc_reader_open: bad arguments"; return nullptr; }
-    for (int i = 0; i < npaths; i++) if (is_bz2(paths[i])) { r_err = "bz2 input is read by the Python stage"; return nullptr; }
     mc_reader *r = new mc_reader();
     for (int i = 0; i < npaths; i++) r->paths.push_back(paths[i]);
     r->L = read_len; r->nreads = nreads; r->fastq = fastq; r->qoff = quality_offset; r->filter_dups = filter_dups;
@@ -280,97 +671,131 @@ extern "C" mc_reader *mc_reader_open(const char *const *paths, int32_t npaths, i
 
 extern "C" void mc_reader_close(mc_reader *r) { delete r; }
 
-static bool revcomp(const std::string &s, std::string &out)
-{ // Sequence.reverse_complement (reference :288-292): ACGTN only, anything else is a KeyError there
-    static const struct Tab { unsigned char t[256]; Tab() { memset(t, 0, sizeof t); t['A'] = 'T'; t['T'] = 'A'; t['G'] = 'C'; t['C'] = 'G'; t['N'] = 'N'; } } tab;
-    const size_t n = s.size();
-    out.resize(n);
-    const unsigned char *p = (const unsigned char *)s.data() + n;
-    char *o = &out[0];
-    unsigned char all = 0xFF;
-    for (size_t i = 0; i < n; i++) { const unsigned char d = tab.t[*--p]; o[i] = (char)d; all &= (unsigned char)(d ? 0xFF : 0); }
-    return all != 0 || n == 0;
-}
-
 extern "C" int64_t mc_reader_run(mc_reader *r)
 {
     if (!r) { r_err = "null reader"; return -1; }
-    r->reads.clear(); memset(&r->st, 0, sizeof r->st);
+    r->reads_n = 0; memset(&r->st, 0, sizeof r->st);
     FILE *out = nullptr;
     if (!r->fasta_out.empty()) {
         out = fopen(r->fasta_out.c_str(), "w");
         if (!out) { r_err = "cannot write " + r->fasta_out; return -1; }
         setvbuf(out, nullptr, _IOFBF, 1 << 22);
     }
+    Pool pool(reader_threads());
+    Params P; P.L = (size_t)r->L; P.fastq = r->fastq; P.qoff = r->qoff; P.dups = r->filter_dups;
     SeqSet seen;
-    std::string rc;
     const size_t L = (size_t)r->L;
-    int64_t kept = 0;
-    Record rec;
+    int64_t kept = 0, rcode = 0;
     char idbuf[32];
-    int64_t rcode = 0;
     for (const std::string &path : r->paths) {
-        Parser ps;
-        if (!ps.src.open(path.c_str())) { r_err = "cannot open " + path; rcode = -1; break; }
-        while (ps.next(rec)) {
-            r->st.records++;
-            r->st.bases += (int64_t)rec.seq.size();
-            if (rec.seq.size() < L) { r->st.too_short++; continue; }
-            if (r->filter_dups) {
-                if (seen.contains(rec.seq)) { r->st.dups++; continue; }
-                if (!revcomp(rec.seq, rc)) { r_err = "KeyError: base outside ACGTN in reverse_complement"; rcode = -3; break; }
-                if (seen.contains(rc)) { r->st.dups++; continue; }
+        const int rc = walk_file(path, P, pool, [&](std::vector<Piece *> &order) -> bool {
+            // the sampler's decisions, record by record in file order
+            const int64_t kept0 = kept;
+            bool full = false;
+            for (Piece *pc : order) {
+                for (Rec &rec : pc->recs) {
+                    r->st.records++;
+                    r->st.bases += (int64_t)rec.len;
+                    if (rec.flags & R_SHORT) { r->st.too_short++; continue; }
+                    if (r->filter_dups) {
+                        if (seen.contains(rec.h1, rec.seq, rec.len, false)) { r->st.dups++; continue; }
+                        if (rec.flags & R_RCBAD) { r_err = "KeyError: base outside ACGTN in reverse_complement"; rcode = -3; return false; }
+                        if (seen.contains(rec.h2, rec.seq, rec.len, true)) { r->st.dups++; continue; }
+                    }
+                    bool fail = (double)(100 * (long long)rec.ncount) / (double)L > r->max_unknown;
+                    if (!fail && r->fastq) {
+                        if (!(rec.flags & R_QUAL)) { r_err = "TypeError: record without qualities in a FASTQ run"; rcode = -3; return false; }
+                        if (rec.nq == 0) { r_err = "ValueError: empty quality string"; rcode = -3; return false; }
+                        if ((double)rec.qsum / (double)rec.nq < r->mean_q) fail = true;
+                        else if ((double)rec.qmin < r->min_q) fail = true;
+                    }
+                    if (fail) { r->st.low_qual++; continue; }
+                    rec.out = (uint32_t)(kept - kept0);
+                    if (out) {
+                        const int k = snprintf(idbuf, sizeof idbuf, ">%lld\n", (long long)kept);
+                        fwrite(idbuf, 1, (size_t)k, out); fwrite(rec.seq, 1, L, out); fputc('\n', out);
+                    }
+                    kept++;
+                    if (r->filter_dups) seen.insert(rec.h1, rec.seq, rec.len);
+                    if (kept == r->nreads) { full = true; break; }
+                }
+                if (full) break;
             }
-            // quality_filter
-            size_t ncount = 0;
-            for (size_t i = 0; i < L; i++) ncount += (rec.seq[i] == 'N');
-            bool fail = (double)(100 * (long long)ncount) / (double)L > r->max_unknown;
-            if (!fail && r->fastq) {
-                if (!rec.has_qual) { r_err = "TypeError: record without qualities in a FASTQ run"; rcode = -3; break; }
-                size_t nq = rec.qual.size() < L ? rec.qual.size() : L;
-                long long sum = 0; int mn = 1 << 30;
-                for (size_t i = 0; i < nq; i++) { int q = (int)(unsigned char)rec.qual[i] - r->qoff; sum += q; if (q < mn) mn = q; }
-                if (nq == 0) { r_err = "ValueError: empty quality string"; rcode = -3; break; }
-                if ((double)sum / (double)nq < r->mean_q) fail = true;
-                else if ((double)mn < r->min_q) fail = true;
+            // the accepted reads of the region -> output rows (copied by the workers, piece by piece)
+            if (kept > kept0) {
+                if (!r->reserve((size_t)kept * L)) { r_err = "out of memory for the sampled reads"; rcode = -1; return false; }
+                uint8_t *dst = r->reads + (size_t)kept0 * L;
+                pool.run((int)order.size(), [&](int k) { for (const Rec &rec : order[k]->recs) if (rec.out != ~0u) memcpy(dst + (size_t)rec.out * L, rec.seq, L); });
+                r->publish(kept);
             }
-            if (fail) { r->st.low_qual++; continue; }
-            if (out) {
-                int k = snprintf(idbuf, sizeof idbuf, ">%lld\n", (long long)kept);
-                fwrite(idbuf, 1, (size_t)k, out); fwrite(rec.seq.data(), 1, L, out); fputc('\n', out);
-            }
-            r->reads.insert(r->reads.end(), rec.seq.begin(), rec.seq.begin() + (long)L);
-            kept++;
-            if (r->filter_dups) seen.insert(rec.seq);
-            if (kept == r->nreads) break;
-        }
-        if (ps.src.prod_err && rcode == 0 && kept < r->nreads) { r_err = "EOFError: compressed file ended before the end-of-stream marker was reached (" + path + ": " + ps.src.prod_msg + ")"; rcode = -3; }
-        ps.src.close();
+            return !full;
+        });
+        if (rc < 0 && rcode == 0) rcode = rc;
         if (rcode < 0 || kept == r->nreads) break;
     }
     if (out) fclose(out);
     if (rcode < 0) return rcode;
+    r->reads_n = (size_t)kept;
     r->st.exhausted = (kept < r->nreads) ? 1 : 0;             // every file was read to its end: bases is count_bases()
     r->st.sampled = kept;
     return kept;
 }
 
-extern "C" const uint8_t *mc_reader_reads(mc_reader *r) { return r ? r->reads.data() : nullptr; }
+extern "C" const uint8_t *mc_reader_reads(mc_reader *r) { return r ? r->reads : nullptr; }
 extern "C" int mc_reader_get_stats(mc_reader *r, mc_reader_stats *out) { if (!r || !out) return -1; *out = r->st; return 0; }
 
 extern "C" int64_t mc_count_bases(const char *const *paths, int32_t npaths)
 {
     int64_t total = 0;
-    Record rec;
+    Pool pool(reader_threads());
+    Params P; P.count_only = true;
     for (int i = 0; i < npaths; i++) {
-        if (is_bz2(paths[i])) { r_err = "bz2 input is read by the Python stage"; return -1; }
-        Parser ps;
-        if (!ps.src.open(paths[i])) { r_err = std::string("cannot open ") + paths[i]; return -1; }
-        while (ps.next(rec)) total += (int64_t)rec.seq.size();
-        const bool bad = ps.src.prod_err;
-        const std::string msg = ps.src.prod_msg;
-        ps.src.close();
-        if (bad) { r_err = std::string("EOFError: compressed file ended before the end-of-stream marker was reached (") + paths[i] + ": " + msg + ")"; return -3; }
+        const int rc = walk_file(paths[i], P, pool, [&](std::vector<Piece *> &order) -> bool { for (Piece *pc : order) total += pc->bases; return true; });
+        if (rc < 0) return rc;
     }
     return total;
 }
+
+// ---- streaming form ---------------------------------------------------------------------------------------------------
+extern "C" int mc_reader_start(mc_reader *r)
+{
+    if (!r) { r_err = "null reader"; return -1; }
+    if (r->run_th.joinable()) { r_err = "the sampler is already running"; return -1; }
+    { std::unique_lock<std::mutex> lk(r->pmu); r->published = 0; r->finished = false; r->result = 0; }
+    r->run_th = std::thread([r] {
+        const int64_t rc = mc_reader_run(r);
+        std::unique_lock<std::mutex> lk(r->pmu);
+        r->result = rc; r->result_err = r_err; r->finished = true;
+        if (rc > r->published) r->published = rc;
+        r->pcv.notify_all();
+    });
+    return 0;
+}
+
+extern "C" int64_t mc_reader_fetch(mc_reader *r, int64_t first, int64_t max_reads, uint8_t *dst)
+{
+    if (!r || first < 0 || max_reads < 0) { r_err = "bad argument"; return -1; }
+    int64_t have;
+    {
+        std::unique_lock<std::mutex> lk(r->pmu);
+        r->pcv.wait(lk, [&] { return r->finished || r->published >= first + max_reads; });
+        if (r->finished && r->result < 0) { r_err = r->result_err; return r->result; }
+        have = r->published;
+    }
+    const int64_t n = std::max<int64_t>(0, std::min(max_reads, have - first));
+    if (n > 0 && dst) {
+        std::shared_lock<std::shared_mutex> lk(r->buf_mu);
+        memcpy(dst, r->reads + (size_t)first * (size_t)r->L, (size_t)n * (size_t)r->L);
+    }
+    return n;
+}
+
+extern "C" int64_t mc_reader_join(mc_reader *r)
+{
+    if (!r) { r_err = "null reader"; return -1; }
+    if (r->run_th.joinable()) r->run_th.join();
+    if (r->result < 0) r_err = r->result_err;
+    return r->result;
+}
+
+extern "C" int32_t mc_reader_read_len(const mc_reader *r) { return r ? r->L : 0; }

@@ -18,8 +18,11 @@ What differs from the reference, on purpose:
     consumed that file keeps working.  args['rapsearch'] (the reference's -r hook) is not honoured.
   * classify_reads() takes the per-read best hits the device computed; if `<tempfile>.m8` was not produced
     by this process it falls back to parsing that file exactly as the reference does.
-  * `.bz2` inputs are opened in text mode (the reference returns a bytes stream under Python 3, which makes
-    its own file-type detection exit).
+  * `.bz2` inputs are read (the reference returns a bytes stream under Python 3, which makes its own
+    file-type detection exit).
+  * run_pipeline() samples, searches and classifies in one native call (mc_search_files) and writes neither the
+    temp FASTA nor the m8 text - the reference deletes both before it returns; args['keep_tmp'] = True runs stage by
+    stage and leaves them (until clean_up) like the reference.
   * optional args['device'] (default 0) selects the GPU.
 """
 import bz2
@@ -302,7 +305,7 @@ def _process_seqfile_py(args, paths):
 
 
 def _native_reader_usable(args):
-    return not any(p.split(".")[-1] == "bz2" for p in args["seqfiles"])
+    return not args.get("python_reader")          # (args['python_reader']: the sampler in Python, the readable statement of the rules)
 
 
 def process_seqfile(args, paths):
@@ -335,6 +338,48 @@ def process_seqfile(args, paths):
         print("\t%s low quality reads found and skipped" % st["low_qual"])
         print("\t%s duplicate reads found and skipped" % st["dups"])
         print("\t%s reads sampled from seqfile" % st["sampled"])
+
+
+def _sample_search_classify(args, paths):
+    """process_seqfile + search_seqs + the device half of classify_reads in one native call (mc_search_files): the sampler
+    reads beside the search, batch by batch; no temp FASTA and no m8 text are written (run_pipeline deletes both unseen)."""
+    from . import _native
+    L = args["read_length"]
+    if args["verbose"]:
+        print("====Estimating Average Genome Size====")
+        print("Sampling & trimming reads...")
+    model = _model()
+    fams = model["families"]
+    rd = _native.Reader(args["seqfiles"], L, args["nreads"], args["file_type"] == "fastq", args.get("quality_offset") or 0,
+                        args["min_quality"], args["mean_quality"], args["max_unknown"], args["filter_dups"])
+    try:
+        try:
+            eng = _engine(args.get("device", 0) or 0)
+            eng.set_run(L, model["pars"][str(L)], fams)
+            rows, best = eng.search_files(rd, keep_rows=False)
+        except _native.ReferenceError_ as e:       # the reference raises here; run_pipeline prints it and returns None
+            raise Exception(str(e))
+        except RuntimeError as error:
+            clean_up(paths)
+            sys.exit("\nDatabase search has exited with the following error:\n%s" % error)
+        st = rd.stats()
+        hit_reads = eng.stats()["reads_with_rows"]
+    finally:
+        rd.close()
+    if st.get("exhausted"):
+        _bases_cache[tuple(args["seqfiles"])] = st["bases"]
+    if st["sampled"] == 0:
+        clean_up(paths)
+        sys.exit("\nError! No reads remaining after filtering!")
+    args["sampled_reads"] = st["sampled"]
+    _run_cache[paths["tempfile"]] = {"reads": None, "best": best, "families": fams}
+    if args["verbose"]:
+        print("\t%s reads shorter than %s bp and skipped" % (st["too_short"], L))
+        print("\t%s low quality reads found and skipped" % st["low_qual"])
+        print("\t%s duplicate reads found and skipped" % st["dups"])
+        print("\t%s reads sampled from seqfile" % st["sampled"])
+        print("Searching reads against marker proteins...")
+        print("\t%s reads hit marker proteins" % hit_reads)
 
 
 def _engine(device):
@@ -546,8 +591,11 @@ def run_pipeline(args):
         check_arguments(args)
         if args["verbose"]:
             print_parameters(args)
-        process_seqfile(args, paths)
-        search_seqs(args, paths)
+        if _native_reader_usable(args) and not args.get("keep_tmp"):
+            _sample_search_classify(args, paths)
+        else:                                      # stage by stage, with the temp FASTA and the m8 file the reference leaves behind
+            process_seqfile(args, paths)
+            search_seqs(args, paths)
         best_hits = classify_reads(args, paths)
         agg_hits = aggregate_hits(args, paths, best_hits)
         clean_up(paths)

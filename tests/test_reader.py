@@ -24,9 +24,19 @@ def _prepare(mc, case):
     return args
 
 
+# the reader cuts its input into regions (carry of the unfinished record) and pieces (speculative parallel parse, stitched in
+# order): the default sizes put these small files into one piece, the tiny ones make every record boundary a seam
+GEOMETRIES = [None, (4096, 300), (700, 97), (64, 1)]
+
+
+@pytest.mark.parametrize("geometry", GEOMETRIES, ids=["default", "r4096-p300", "r700-p97", "r64-p1"])
 @pytest.mark.parametrize("case", CASES, ids=[c["case"] for c in CASES])
-def test_native_reader_matches_reference(case, tmp_path):
+def test_native_reader_matches_reference(case, geometry, tmp_path, monkeypatch):
     from microbecensus_amd import _native, microbe_census as mc
+    if geometry:
+        monkeypatch.setenv("MC_READER_REGION_BYTES", str(geometry[0]))
+        monkeypatch.setenv("MC_READER_PIECE_BYTES", str(geometry[1]))
+        monkeypatch.setenv("MC_READER_THREADS", "4")
     args = _prepare(mc, case)
     out = str(tmp_path / "tmp.fa")
     call = lambda: _native.sample_reads(args["seqfiles"], args["read_length"], args["nreads"], args["file_type"] == "fastq",   # noqa: E731
@@ -137,3 +147,41 @@ def test_nreads_none_means_no_cap():
     from microbecensus_amd import _native
     reads, st = _native.sample_reads([os.path.join(GOLD, "sampler", "a.fa")], 50, None, False, 0, -5, -5, 100, False)
     assert st["sampled"] == 60 and st["exhausted"] == 1
+
+
+def test_bz2_input_is_read_natively(tmp_path):
+    """.bz2 goes through the same native sampler (libbz2 bound at run time): same reads as the .gz of the same text."""
+    import bz2
+    import gzip
+    from microbecensus_amd import _native
+    text = gzip.open(os.path.join(GOLD, "inputs", "example.fq.gz"), "rb").read()
+    p = str(tmp_path / "example.fq.bz2")
+    with open(p, "wb") as f:
+        f.write(bz2.compress(text))
+    a, sa = _native.sample_reads([os.path.join(GOLD, "inputs", "example.fq.gz")], 100, 10000, True, 32, -5, -5, 100, False)
+    b, sb = _native.sample_reads([p], 100, 10000, True, 32, -5, -5, 100, False)
+    assert sa == sb and (a == b).all() and sb["sampled"] == 8672
+    assert _native.count_bases([p]) == 980306
+
+
+def test_streaming_fetch_equals_run(tmp_path):
+    """mc_reader_start / fetch / join hand out the same reads mc_reader_run collects."""
+    import ctypes as C
+    import numpy as np
+    from microbecensus_amd import _native
+    path = os.path.join(GOLD, "inputs", "metagenome.fa.gz")
+    want, st = _native.sample_reads([path], 100, 1000000, False, 0, -5, -5, 100, False)
+    rd = _native.Reader([path], 100, 1000000, False, 0, -5, -5, 100, False)
+    lib = rd.lib
+    assert lib.mc_reader_start(rd.r) == 0
+    got, at = [], 0
+    buf = np.empty((7000, 100), np.uint8)
+    while True:
+        n = lib.mc_reader_fetch(rd.r, at, 7000, buf.ctypes.data_as(C.c_void_p))
+        assert n >= 0
+        if n == 0:
+            break
+        got.append(buf[:n].copy()); at += n
+    assert lib.mc_reader_join(rd.r) == st["sampled"] == at
+    assert (np.concatenate(got) == want).all()
+    rd.close()
