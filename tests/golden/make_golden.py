@@ -87,10 +87,50 @@ def run_case(mc, name, args):
     return out
 
 
+def write_synthetic_inputs(inputs):
+    """Small versions of BASELINE configs[1], [3] and [4] from the repo's own read generator over the 30-genome fixture
+    (microbecensus_amd/synth.py GenomeReads; data only): 100 bp FASTA; a paired 150 bp FASTQ library in two files; 300 bp FASTQ
+    with SURVEY 8(d)'s quality model, 5 % of the reads with one base below 20, 2 % exact and 1 % reverse-complement duplicates."""
+    import numpy as np
+    sys.path.insert(0, REPO)
+    from microbecensus_amd import synth
+    gen = synth.GenomeReads(device="cpu", seed=20261001)
+
+    def gz_write(name, data):
+        with gzip.GzipFile(os.path.join(inputs, name), "wb", mtime=0) as f:
+            f.write(data)
+    r = gen.single(30000, 100, first=10_000_000).numpy()
+    gz_write("c2_100bp.fa.gz", b"".join(b">r%d\n%s\n" % (i, bytes(x)) for i, x in enumerate(r)))
+    m1, m2 = gen.paired(12000, 150, frag=300, first=20_000_000)
+    q = b"I" * 150
+    gz_write("c4_pair_1.fq.gz", b"".join(b"@f%d/1\n%s\n+\n%s\n" % (i, bytes(x), q) for i, x in enumerate(m1.numpy())))
+    gz_write("c4_pair_2.fq.gz", b"".join(b"@f%d/2\n%s\n+\n%s\n" % (i, bytes(x), q) for i, x in enumerate(m2.numpy())))
+    r = gen.single(6000, 300, first=30_000_000).numpy()
+    rng = np.random.RandomState(20261001)
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    recs, pool = [], []
+    for i, x in enumerate(r):
+        sq = bytes(x)
+        u = rng.rand()
+        if pool and u < 0.02:
+            sq = pool[rng.randint(len(pool))]
+        elif pool and u < 0.03:
+            sq = pool[rng.randint(len(pool))][::-1].translate(comp)
+        else:
+            pool.append(sq)
+        ql = np.clip(np.rint(rng.normal(34, 6, size=300)), 20, 41).astype(np.int64)
+        if rng.rand() < 0.05:
+            ql[rng.randint(300)] = rng.choice([2, 10, 19])
+        recs.append(b"@s%d\n%s\n+\n%s\n" % (i, sq, bytes((ql + 33).astype(np.uint8))))
+    gz_write("c5_300bp.fq.gz", b"".join(recs))
+
+
 def main():
     mc, scratch = load_reference()
     inputs = os.path.join(HERE, "inputs")
     os.makedirs(inputs, exist_ok=True)
+    if not os.path.exists(os.path.join(inputs, "c5_300bp.fq.gz")):
+        write_synthetic_inputs(inputs)
     for src in ("tests/data/metagenome.fa.gz", "microbe_census/example/example.fq.gz",
                 "microbe_census/example/example.fa.gz"):
         dst = os.path.join(inputs, os.path.basename(src))
@@ -109,6 +149,10 @@ def main():
     out["genome_equivalents"] = tb / out["est_ags"]
     with open(os.path.join(HERE, "config1_example_fq.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
+    # small versions of BASELINE configs[1], [3], [4] (synthetic inputs written above)
+    run_case(mc, "c2_100bp", {"seqfiles": [os.path.join(inputs, "c2_100bp.fa.gz")], "threads": 8})
+    run_case(mc, "c4_paired", {"seqfiles": [os.path.join(inputs, "c4_pair_1.fq.gz"), os.path.join(inputs, "c4_pair_2.fq.gz")], "threads": 8, "nreads": 20000})
+    run_case(mc, "c5_300bp_q20_dups", {"seqfiles": [os.path.join(inputs, "c5_300bp.fq.gz")], "threads": 8, "min_quality": 20, "filter_dups": True})
     # extra cases supplied on the command line:  name=path[,path]:key=val:key=val
     for spec in sys.argv[1:]:
         name, rest = spec.split("=", 1)

@@ -1,0 +1,145 @@
+"""BASELINE configs[1], [3] and [4] on the GPU: small versions against goldens produced by RUNNING THE REFERENCE here
+(tests/golden/make_golden.py: 100 bp FASTA; a paired 150 bp library given as two files; 300 bp FASTQ with -q 20 -d), and the
+full-size shape of configs[1] (2.3 M reads of 100 bp: crosses the 2,097,151-read batch limit) through a size-independent
+property.  All calls go through the C ABI."""
+import gzip
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from microbecensus_amd import microbe_census as mc
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+GOLD = os.path.join(HERE, "golden")
+INPUTS = os.path.join(GOLD, "inputs")
+
+CASES = {
+    "c2_100bp": {"seqfiles": ["c2_100bp.fa.gz"], "threads": 8},
+    "c4_paired": {"seqfiles": ["c4_pair_1.fq.gz", "c4_pair_2.fq.gz"], "threads": 8, "nreads": 20000},
+    "c5_300bp_q20_dups": {"seqfiles": ["c5_300bp.fq.gz"], "threads": 8, "min_quality": 20, "filter_dups": True},
+}
+
+
+def _args(case):
+    a = dict(CASES[case])
+    a["seqfiles"] = [os.path.join(INPUTS, f) for f in a["seqfiles"]]
+    return a
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_stage_by_stage_against_the_reference(case):
+    """sampler -> search -> classification -> aggregation -> estimate: the temp FASTA, the m8 file, the best hits, the
+    per-family sums and the AGS the reference produced for the same input."""
+    g = json.load(open(os.path.join(GOLD, case + ".json")))
+    args = _args(case)
+    paths = mc.get_relative_paths(args)
+    mc.check_paths(paths); mc.check_input(args); mc.impute_missing_args(args); mc.check_arguments(args)
+    assert args["read_length"] == g["args"]["read_length"]
+    mc.process_seqfile(args, paths)
+    assert args["sampled_reads"] == g["sampled_reads"]
+    assert hashlib.md5(open(paths["tempfile"], "rb").read()).hexdigest() == g["reads_md5"]
+    mc.search_seqs(args, paths)
+    m8 = b"".join(l for l in open(paths["tempfile"] + ".m8", "rb") if not l.startswith(b"#"))
+    assert m8.count(b"\n") == g["m8_rows"]
+    assert hashlib.md5(m8).hexdigest() == g["m8_md5"]
+    assert m8 == gzip.open(os.path.join(GOLD, case + ".m8.gz"), "rb").read()
+    best = mc.classify_reads(args, paths)
+    assert best == g["best_hits"]
+    agg = mc.aggregate_hits(args, paths, best)
+    assert agg == g["agg_hits"]
+    mc.clean_up(paths)
+    assert mc.estimate_average_genome_size(args, paths, agg) == g["est_ags"]
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_run_pipeline_fused_path(case):
+    """run_pipeline (sampler beside the search, mc_search_files): the reference's AGS, bit for bit."""
+    g = json.load(open(os.path.join(GOLD, case + ".json")))
+    est, args = mc.run_pipeline(_args(case))
+    assert args["sampled_reads"] == g["sampled_reads"] and est == g["est_ags"]
+
+
+def _two_ranks(tmp_path, backend, port):
+    worker = tmp_path / "w.py"
+    worker.write_text(r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+from microbecensus_amd import distributed as D
+backend = sys.argv[3]
+local = int(os.environ["LOCAL_RANK"])
+if backend == "nccl":
+    torch.cuda.set_device(local)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+else:
+    dist.init_process_group(backend="gloo")
+inp = os.path.join(sys.argv[1], "tests", "golden", "inputs")
+est, args = D.run_pipeline_distributed({"seqfiles": [os.path.join(inp, "c4_pair_1.fq.gz"), os.path.join(inp, "c4_pair_2.fq.gz")], "nreads": 20000},
+                                       device=local if backend == "nccl" else 0)
+if dist.get_rank() == 0:
+    json.dump({"est": est, "sampled": args["sampled_reads"], "L": args["read_length"], "world": dist.get_world_size(), "backend": dist.get_backend()}, open(sys.argv[2], "w"))
+dist.barrier()
+dist.destroy_process_group()
+''')
+    out = tmp_path / "o.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), str(worker), REPO, str(out), backend], env=env, timeout=900)
+    return json.load(open(out))
+
+
+def test_config4_shape_two_ranks_gloo(tmp_path):
+    """The paired library given as `a,b` through run_pipeline_distributed with two ranks (both on this box's GPU, gloo): rank 0
+    samples and scatters, the reduced per-family sums give the reference's AGS for the same pair."""
+    g = json.load(open(os.path.join(GOLD, "c4_paired.json")))
+    res = _two_ranks(tmp_path, "gloo", 29541)
+    assert res["world"] == 2 and res["sampled"] == g["sampled_reads"] and res["L"] == 150
+    assert abs(res["est"] - g["est_ags"]) <= 1e-9 * g["est_ags"]
+
+
+def test_config4_shape_two_ranks_rccl(tmp_path):
+    """The same over RCCL (backend "nccl") with one GPU per rank: scatter of the read blocks GPU to GPU, all_reduce of the
+    per-family sums.  Needs two GPUs."""
+    from microbecensus_amd import _native
+    if _native.load_library().mc_device_count() < 2:              # (asked of the HIP library this process already uses, not of torch)
+        pytest.skip("needs two GPUs (the driver's multi-GPU node)")
+    g = json.load(open(os.path.join(GOLD, "c4_paired.json")))
+    res = _two_ranks(tmp_path, "nccl", 29543)
+    assert res["backend"] == "nccl" and res["world"] == 2 and res["sampled"] == g["sampled_reads"]
+    assert abs(res["est"] - g["est_ags"]) <= 1e-9 * g["est_ags"]
+
+
+def test_config2_full_size_batch_split_invariance():
+    """2.3 M synthetic 100 bp reads (more than one 2,097,151-read batch): what mc_search returns for the whole set equals what it
+    returns for two halves searched separately with offset read ids - rows, best hits, and a checksum over every field."""
+    from microbecensus_amd import _native, synth
+    gen = synth.GenomeReads(device="cpu", seed=7)               # (torch stays off the GPU in this process: the HIP library owns it)
+    n, L = 2_300_000, 100
+    reads = gen.single(n, L).numpy()
+    eng = _native.Engine(device=0)
+    try:
+        model = _native.load_model()
+        eng.set_run(L, model["pars"][str(L)], model["families"])
+        rows, best = eng.search(reads)
+        cut = 1_234_567
+        r1, b1 = eng.search(reads[:cut])
+        r2, b2 = eng.search(reads[cut:], first_read_id=cut)
+    finally:
+        eng.close()
+    assert len(rows) == len(r1) + len(r2) and len(rows) > 1_000_000
+    both = np.concatenate([r1, r2])
+    for f in rows.dtype.names:
+        assert (rows[f] == both[f]).all(), f
+    bb = np.concatenate([b1, b2])
+    for f in best.dtype.names:
+        assert (best[f] == bb[f]).all(), f
+    assert (np.diff(rows["query"]) >= 0).all()                    # m8 order: ascending read id
+    assert rows["query"].max() < n and best["read"].max() < n and len(best) > 5000

@@ -53,3 +53,21 @@ def test_oracle_reproduces_reference_m8(case, oracle_bin, ref_dir, tmp_path):
     assert hashlib.md5(got).hexdigest() == meta["m8_md5"]
     want = gzip.open(os.path.join(GOLD, case + ".m8.gz"), "rb").read()
     assert got == want
+
+
+@pytest.mark.parametrize("case", ["c2_100bp", "c4_paired", "c5_300bp_q20_dups"])
+def test_oracle_on_the_small_baseline_configs(case, oracle_bin, ref_dir, tmp_path):
+    """Small versions of BASELINE configs[1], [3], [4] (goldens from the reference, tests/golden/make_golden.py): the native
+    sampler re-creates the temp FASTA the reference fed to rapsearch (md5), the oracle its m8 (md5)."""
+    from microbecensus_amd import _native
+    meta = json.load(open(os.path.join(GOLD, case + ".json")))
+    a = meta["args"]
+    fa = str(tmp_path / "reads.fa")
+    files = [os.path.join(GOLD, "inputs", f) for f in meta["seqfiles"]]
+    reads, st = _native.sample_reads(files, a["read_length"], a["nreads"], a["file_type"] == "fastq", a.get("quality_offset") or 0,
+                                     a["min_quality"], a["mean_quality"], a["max_unknown"], a["filter_dups"], fa)
+    assert st["sampled"] == meta["sampled_reads"]
+    assert hashlib.md5(open(fa, "rb").read()).hexdigest() == meta["reads_md5"]
+    out = str(tmp_path / "out.m8")
+    subprocess.check_call([oracle_bin, os.path.join(ref_dir, "rapdb_2.15"), fa, out])
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == meta["m8_md5"]
