@@ -532,6 +532,116 @@ MC_HDN void mc_seg_mask_fx(const double *lnfac /* McTables::lnfac */, const int3
     if (any) for (int i = 0; i < n; i++) if (mc_bits_test(mk, i)) prot[i] = MC_INV;
 }
 
+// ---- the same masking with the window flags computed ONCE per frame -------------------------------------------------------
+// A sub-segment [base, base + m) that Seg::segseq pushes (the part of a stretch left of the trimmed window) is scanned again
+// by the reference, but its window k is the frame's window base + k as long as it fits into the sub-segment, and every later
+// position reuses the last window that fits: flag_sub(i) = F(base + min(i, m - W)), F(x) = flags of the frame's window that
+// starts at x.  So F is computed once (one pass of the incremental fixed-point entropy test) and every segment reads its
+// flags off it with shifts; stretches are found with count-trailing-zeros instead of loops.  mc_seg_mask_fx is the plain
+// statement; tests/emul checks the two frame by frame.
+MC_HD McBits192 mc_bits_shr(const McBits192 &x, int k)
+{ // x >> k, 0 <= k < 192
+    McBits192 r;
+    uint64_t w0 = x.a, w1 = x.b, w2 = x.c;
+    if (k >= 128) { w0 = w2; w1 = 0; w2 = 0; k -= 128; }
+    else if (k >= 64) { w0 = w1; w1 = w2; w2 = 0; k -= 64; }
+    if (k) { r.a = (w0 >> k) | (w1 << (64 - k)); r.b = (w1 >> k) | (w2 << (64 - k)); r.c = w2 >> k; }
+    else { r.a = w0; r.b = w1; r.c = w2; }
+    return r;
+}
+MC_HD McBits192 mc_bits_low(int n)
+{ // bits [0, n) set, 0 <= n <= 192
+    McBits192 r;
+    r.a = n >= 64 ? ~0ull : (n > 0 ? (1ull << n) - 1 : 0);
+    r.b = n >= 128 ? ~0ull : (n > 64 ? (1ull << (n - 64)) - 1 : 0);
+    r.c = n >= 192 ? ~0ull : (n > 128 ? (1ull << (n - 128)) - 1 : 0);
+    return r;
+}
+MC_HD McBits192 mc_bits_and(const McBits192 &x, const McBits192 &y) { McBits192 r; r.a = x.a & y.a; r.b = x.b & y.b; r.c = x.c & y.c; return r; }
+MC_HD McBits192 mc_bits_or(const McBits192 &x, const McBits192 &y) { McBits192 r; r.a = x.a | y.a; r.b = x.b | y.b; r.c = x.c | y.c; return r; }
+MC_HD McBits192 mc_bits_andnot(const McBits192 &x, const McBits192 &y) { McBits192 r; r.a = x.a & ~y.a; r.b = x.b & ~y.b; r.c = x.c & ~y.c; return r; }
+MC_HD McBits192 mc_bits_range(int lo, int hi) { return mc_bits_andnot(mc_bits_low(hi + 1), mc_bits_low(lo)); }   // bits [lo, hi]
+// lowest set bit at or above `from` (192 if none)
+MC_HD int mc_bits_next(const McBits192 &x, int from)
+{
+    if (from >= 192) return 192;
+    McBits192 y = mc_bits_andnot(x, mc_bits_low(from));
+    if (y.a) return __builtin_ctzll(y.a);
+    if (y.b) return 64 + __builtin_ctzll(y.b);
+    if (y.c) return 128 + __builtin_ctzll(y.c);
+    return 192;
+}
+// highest set bit at or below `from` (-1 if none)
+MC_HD int mc_bits_prev(const McBits192 &x, int from)
+{
+    if (from < 0) return -1;
+    McBits192 y = mc_bits_and(x, mc_bits_low(from + 1));
+    if (y.c) return 191 - __builtin_clzll(y.c);
+    if (y.b) return 127 - __builtin_clzll(y.b);
+    if (y.a) return 63 - __builtin_clzll(y.a);
+    return -1;
+}
+// the flags of segment [base, base + m) read off the frame's window flags F (windows 0 .. nF-1 ... nF = n - W + 1)
+MC_HD McBits192 mc_seg_flags_of(const McBits192 &F, int base, int m, int W)
+{
+    McBits192 r = mc_bits_and(mc_bits_shr(F, base), mc_bits_low(m - W + 1));
+    if (mc_bits_test(r, m - W)) r = mc_bits_or(r, mc_bits_range(m - W + 1, m - 1));
+    return r;
+}
+// F: the window flags of a frame (one incremental pass; comp: 20 bytes of workspace)
+MC_HD void mc_seg_window_flags(const int32_t *fx, const uint8_t *s, int n, int W, uint8_t *comp, McBits192 &Flo, McBits192 &Fhi)
+{
+    mc_bits_clear(Flo); mc_bits_clear(Fhi);
+    int S = 0, t = 0;
+    for (int i = 0; i < 20; i++) comp[i] = 0;
+    for (int i = 0; i < W; i++) { const int r = s[i]; if (r < 20) { const int c = comp[r]; S += fx[16 + c]; comp[r] = (uint8_t)(c + 1); t++; } }
+    for (int x = 0;; x++) {
+        if (S >= fx[32 + t]) mc_bits_set(Flo, x);
+        if (S >= fx[48 + t]) mc_bits_set(Fhi, x);
+        if (x + 1 + W > n) break;
+        const int o = s[x], e = s[x + W];
+        if (o < 20) { const int c = comp[o]; S += fx[c]; comp[o] = (uint8_t)(c - 1); t--; }
+        if (e < 20) { const int c = comp[e]; S += fx[16 + c]; comp[e] = (uint8_t)(c + 1); t++; }
+    }
+}
+MC_HDN void mc_seg_mask_fx2(const double *lnfac, const int32_t *fx, uint8_t *prot, int n, const McSegWS &ws)
+{
+    const int W = (n <= 11) ? 8 : 12;
+    if (W > n) return;
+    McBits192 Flo, Fhi, mk;
+    mc_bits_clear(mk);
+    mc_seg_window_flags(fx, prot, n, W, ws.comp, Flo, Fhi);
+    if (!(Flo.a | Flo.b | Flo.c)) return;
+    int sp = 1;
+    ws.stk[0] = 0; ws.stk[1] = (int16_t)n;
+    bool any = false;
+    while (sp > 0) {
+        sp--;
+        const int base = ws.stk[2 * sp], m = ws.stk[2 * sp + 1];
+        const uint8_t *s = prot + base;
+        if (W > m) continue;
+        const McBits192 lo = mc_seg_flags_of(Flo, base, m, W), hi = mc_seg_flags_of(Fhi, base, m, W);
+        const McBits192 nhi = mc_bits_andnot(mc_bits_low(m), hi);                 // positions of the segment that are NOT high
+        int lowlim = 0;
+        for (int i = mc_bits_next(lo, 0); i < m; i = mc_bits_next(lo, i + 1)) {
+            int loi = mc_bits_prev(nhi, i) + 1; if (loi < lowlim) loi = lowlim;
+            int hii = mc_bits_next(nhi, i) - 1; if (hii > m - 1) hii = m - 1;
+            int leftend = loi, rightend = hii;
+            if (rightend - leftend + 1 <= 15) mc_seg_trim_rg(lnfac, s + leftend, rightend - leftend + 1, &leftend, &rightend);
+            else mc_seg_trim_ws(lnfac, s + leftend, rightend - leftend + 1, &leftend, &rightend, ws);
+            if (i < leftend) {
+                const int lend = loi, rend = leftend - 1;
+                if (sp < 8) { ws.stk[2 * sp] = (int16_t)(base + lend); ws.stk[2 * sp + 1] = (int16_t)(rend - lend + 1); sp++; }
+            }
+            mk = mc_bits_or(mk, mc_bits_range(base + leftend, base + rightend));
+            any = true;
+            i = (hii < rightend) ? hii : rightend;
+            lowlim = i + 1;
+        }
+    }
+    if (any) for (int i = 0; i < n; i++) if (mc_bits_test(mk, i)) prot[i] = MC_INV;
+}
+
 // ---------------------------------------------------------------------------------------------
 // suffix keys (ExtendSeq2Set 0x413bd2-0x414aa1)
 // ---------------------------------------------------------------------------------------------

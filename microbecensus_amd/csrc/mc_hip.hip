@@ -91,9 +91,15 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
     const int W = (n <= 11) ? 8 : 12;
     enum { POP = 0, SCAN = 1, WAIT = 2, DONE = 3 };
     int st = (act && W <= n) ? POP : DONE;
-    McBits192 lo, hi, mk;
-    mc_bits_clear(lo); mc_bits_clear(hi); mc_bits_clear(mk);
-    int sp = 1, base = 0, m = 0, i = 0, last = 0, lowlim = 0, loi = 0, hii = 0;
+    // the window flags of the frame, once (mc_seg_mask_fx2 in mc_core.h is this function for one frame): every segment the
+    // reference scans again reads its flags off them
+    McBits192 Flo, Fhi, lo, nhi, mk;
+    mc_bits_clear(Flo); mc_bits_clear(Fhi); mc_bits_clear(lo); mc_bits_clear(nhi); mc_bits_clear(mk);
+    if (st != DONE) {
+        mc_seg_window_flags(fx, prot, n, W, ws.comp, Flo, Fhi);
+        if (!(Flo.a | Flo.b | Flo.c)) st = DONE;
+    }
+    int sp = 1, base = 0, m = 0, i = 0, lowlim = 0, loi = 0, hii = 0;
     bool any = false;
     if (st != DONE) { ws.stk[0] = 0; ws.stk[1] = (int16_t)n; }
     const unsigned long long ltmask = (1ull << lane) - 1;
@@ -105,35 +111,14 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
                 sp--;
                 base = ws.stk[2 * sp]; m = ws.stk[2 * sp + 1];
                 if (W > m) continue;
-                const uint8_t *s = prot + base;
-                mc_bits_clear(lo); mc_bits_clear(hi);
-                bool anylo = false;
-                int S = 0, t = 0;
-                for (int k = 0; k < 20; k++) ws.comp[k] = 0;
-                for (int k = 0; k < W; k++) { const int r = s[k]; if (r < 20) { const int c = ws.comp[r]; S += fx[16 + c]; ws.comp[r] = (uint8_t)(c + 1); t++; } }
-                int start = 0;
-                bool l = S >= fx[32 + t], h = S >= fx[48 + t];
-                for (int k = 0; k <= m - 1; k++) {
-                    if (l) { mc_bits_set(lo, k); anylo = true; }
-                    if (h) mc_bits_set(hi, k);
-                    if (start + 1 + W <= m) {
-                        const int o = s[start], e = s[start + W];
-                        if (o < 20) { const int c = ws.comp[o]; S += fx[c]; ws.comp[o] = (uint8_t)(c - 1); t--; }
-                        if (e < 20) { const int c = ws.comp[e]; S += fx[16 + c]; ws.comp[e] = (uint8_t)(c + 1); t++; }
-                        start++;
-                        l = S >= fx[32 + t]; h = S >= fx[48 + t];
-                    }
-                }
-                if (!anylo) continue;
-                i = 0; last = m - 1; lowlim = 0; st = SCAN;
+                lo = mc_seg_flags_of(Flo, base, m, W);
+                i = mc_bits_next(lo, 0);
+                if (i >= m) continue;
+                nhi = mc_bits_andnot(mc_bits_low(m), mc_seg_flags_of(Fhi, base, m, W));
+                lowlim = 0; st = SCAN;
             }
-            while (i <= last && !mc_bits_test(lo, i)) i++;
-            if (i > last) { st = POP; continue; }
-            int j;
-            for (j = i; j >= lowlim; j--) { if (!mc_bits_test(hi, j)) break; }
-            loi = j + 1;
-            for (j = i; j <= last; j++) { if (!mc_bits_test(hi, j)) break; }
-            hii = j - 1;
+            loi = mc_bits_prev(nhi, i) + 1; if (loi < lowlim) loi = lowlim;
+            hii = mc_bits_next(nhi, i) - 1; if (hii > m - 1) hii = m - 1;
             st = WAIT;
         }
         const unsigned long long req = __ballot(st == WAIT);
@@ -151,46 +136,68 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
         if (lane == 0) {
             uint32_t run = 0;
             WL->pre[0] = 0;
-            for (int r = 0; r < nreq; r++) { const int nn = WL->n[r], minlen = (nn - 100 > 1) ? nn - 100 : 1, K = nn - minlen; run += (uint32_t)(K * (K + 1) / 2); WL->pre[r + 1] = run; }
+            for (int r = 0; r < nreq; r++) {
+                const int nn = WL->n[r], minlen = (nn - 100 > 1) ? nn - 100 : 1, K = nn - minlen, A = K >> 3, B = K & 7;
+                run += (uint32_t)(4 * A * (A + 1) + B * (A + 1));          // sum over j < K of ceil((j + 1) / 8)
+                WL->pre[r + 1] = run;
+            }
         }
         mc_wave_sync();
+        // One work item = up to MC_SEG_RUN = 8 consecutive windows of one LENGTH of one stretch (Seg::trim: len = nn - j has j + 1
+        // windows, j = 0 .. nn - minlen - 1): the lane builds the composition of its first window and slides it (one residue out,
+        // one in), keeping the first least probable window; bounded items keep the 64 lanes of a round in step, and the best of a
+        // stretch is then found with two LDS atomics per item.  Items of a stretch are numbered by (j, run): j = 8 A + B has A + 1
+        // runs, 4 A (A + 1) + B (A + 1) items lie in front of it.
         const uint32_t total = WL->pre[nreq];
         for (uint32_t p0 = 0; p0 < total; p0 += 64) {
             const uint32_t p = p0 + (uint32_t)lane;
             const bool ok = p < total;
             int r = 0;
-            for (int k = 1; k < nreq; k++) r += (p >= WL->pre[k]);
+            for (int stp = 32; stp > 0; stp >>= 1) { const int k = r + stp; if (k < nreq && p >= WL->pre[k]) r = k; }   // the stretch item p belongs to: last r with pre[r] <= p
             if (!ok) r = 0;
-            const uint32_t q = p - WL->pre[r];
+            const int x = (int)(p - WL->pre[r]);
+            int A = (int)((sqrtf((float)(x + 1)) - 1.0f) * 0.5f);
+            while (4 * (A + 1) * (A + 2) <= x) A++;
+            while (4 * A * (A + 1) > x) A--;
+            const int rem = x - 4 * A * (A + 1), B = rem / (A + 1), run = rem - B * (A + 1);
+            const int j = 8 * A + B, wfirst = 8 * run, wlast = (wfirst + 7 < j) ? wfirst + 7 : j;
             const int nn = WL->n[r];
             const uint8_t *s = lds0 + WL->off[r];
-            // window number q of the stretch, in Seg::trim's order: length nn - j (j = 0, 1, ...) has j + 1 windows
-            int j = (int)((sqrtf((float)(8u * q + 1u)) - 1.0f) * 0.5f);
-            while ((uint32_t)((j + 1) * (j + 2) / 2) <= q) j++;
-            while ((uint32_t)(j * (j + 1) / 2) > q) j--;
-            const int len = nn - j, w0 = (int)q - j * (j + 1) / 2;
-            unsigned long long key = ~0ull;
+            const int len = nn - j;
+            const uint32_t qbase = (uint32_t)(j * (j + 1) / 2);          // number of window 0 of this length in Seg::trim's order
+            unsigned long long key = MC_SEG_KEY_ONE;                     // (minprob starts at 1.0: only a smaller probability counts)
+            uint32_t kq = 0xFFFFFFFFu;
             if (ok) {
-                double prob;
                 if (len <= 15) {
                     McRgState rg; rg.clo = 0; rg.chi = 0; rg.sv = 0;
-                    for (int k = 0; k < len; k++) mc_rg_add(rg, s[w0 + k]);
-                    prob = mc_rg_getprob(lnf, rg.sv, len);
+                    for (int k = 0; k < len; k++) mc_rg_add(rg, s[wfirst + k]);
+                    uint64_t lastsv = ~0ull; unsigned long long lastkey = 0;
+                    for (int w0 = wfirst;; w0++) {
+                        if (rg.sv != lastsv) { lastsv = rg.sv; lastkey = mc_seg_key(mc_rg_getprob(lnf, rg.sv, len)); }   // (the probability depends on the state vector only)
+                        if (lastkey < key) { key = lastkey; kq = qbase + (uint32_t)w0; }
+                        if (w0 == wlast) break;
+                        mc_rg_remove(rg, s[w0]); mc_rg_add(rg, s[w0 + len]);
+                    }
                 } else {
-                    mc_seg_comp(s + w0, len, ws.comp);
+                    mc_seg_comp(s + wfirst, len, ws.comp);
                     mc_seg_state(ws.comp, ws.sv);
-                    prob = mc_seg_getprob(lnf, ws.sv, len);
+                    for (int w0 = wfirst;; w0++) {
+                        const unsigned long long k2 = mc_seg_key(mc_seg_getprob(lnf, ws.sv, len));
+                        if (k2 < key) { key = k2; kq = qbase + (uint32_t)w0; }
+                        if (w0 == wlast) break;
+                        mc_seg_shift(ws.comp, ws.sv, s[w0], s[w0 + len]);
+                    }
                 }
-                key = mc_seg_key(prob);
             }
+            const bool cand = ok && key < MC_SEG_KEY_ONE;
             const unsigned long long old = WL->best[r];
             mc_wave_sync();
-            if (ok && key < MC_SEG_KEY_ONE) atomicMin(&WL->best[r], key);
+            if (cand) atomicMin(&WL->best[r], key);
             mc_wave_sync();
             const unsigned long long nb = WL->best[r];
             if (ok && nb != old) WL->bq[r] = 0xFFFFFFFFu;             // a smaller probability appeared in this round: forget the old window
             mc_wave_sync();
-            if (ok && key == nb && key < MC_SEG_KEY_ONE) atomicMin(&WL->bq[r], q);
+            if (cand && key == nb) atomicMin(&WL->bq[r], kq);
             mc_wave_sync();
         }
         // ---- the owners take their results and go on
@@ -209,11 +216,11 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
                 const int l2 = loi, r2 = leftend - 1;
                 if (sp < 8) { ws.stk[2 * sp] = (int16_t)(base + l2); ws.stk[2 * sp + 1] = (int16_t)(r2 - l2 + 1); sp++; }
             }
-            for (int k = leftend; k <= rightend; k++) mc_bits_set(mk, base + k);
+            mk = mc_bits_or(mk, mc_bits_range(base + leftend, base + rightend));
             any = true;
-            i = ((hii < rightend) ? hii : rightend) + 1;
-            lowlim = i;
-            st = SCAN;
+            lowlim = ((hii < rightend) ? hii : rightend) + 1;
+            i = mc_bits_next(lo, lowlim);
+            st = i < m ? SCAN : POP;
         }
         mc_wave_sync();
     }
@@ -356,12 +363,13 @@ __global__ void __launch_bounds__(256) k_enumerate(const McTables *__restrict__ 
 struct McEnWave {
     uint32_t setter[6][6]; uint32_t hit[6][6]; uint32_t blk_base, blk_used;
     unsigned long long q[MC_EN_QCAP];       // probes that passed the bucket bitmap
-    unsigned long long hq[MC_EN_QCAP];      // probes whose first-residue group is longer than 8 keys (binary search)
     unsigned long long eq[MC_EN_QCAP];      // (position, group) pairs the wildcard filter answered yes for: ten probes each
 #ifdef MC_EXP_TIMING
     unsigned long long tacc[6], tcnt[6];
 #endif
+    unsigned long long hq[MC_EN_QCAP];      // probes whose first-residue group is longer than 8 keys (binary search): counting form only - last member, not allocated otherwise
 };
+#define MC_EN_WAVE_BYTES(COUNT) ((COUNT) ? sizeof(McEnWave) : offsetof(McEnWave, hq))
 
 extern __shared__ __attribute__((aligned(16))) uint8_t mc_smem[];   // dynamic LDS of the kernels that use it
 
@@ -497,10 +505,9 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
 {
     uint8_t *smem = mc_smem;
     uint8_t *grp = smem;                                                    // 32-byte group table
-    McEnWave *waves = (McEnWave *)(smem + 64);
-    uint8_t *fr_all = (uint8_t *)(waves + MC_EN_WAVES);
     const int lane = mc_lane(), wv = threadIdx.x >> 6;
-    McEnWave *W = waves + wv;
+    McEnWave *W = (McEnWave *)(smem + 64 + (size_t)wv * MC_EN_WAVE_BYTES(COUNT));
+    uint8_t *fr_all = smem + 64 + (size_t)MC_EN_WAVES * MC_EN_WAVE_BYTES(COUNT);
     const int FPs = (FP + 15) & ~15;
     const int nchunk = MC_EN_NCHUNK(L);                                    // chunks of 64 positions per frame
     uint8_t *fr = fr_all + (size_t)wv * (6 * FPs + 6 * nchunk * (512 + 128));
@@ -1554,6 +1561,7 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
         if (dalloc(&h->d_rec, H.rec.size())) return -1;
         HIPCK(hipMemcpy(h->d_rec, H.rec.data(), H.rec.size() * sizeof(McBucketRec), hipMemcpyHostToDevice));
     }
+    if (const char *e = getenv("MC_PARTS")) { const int v = atoi(e); if (v >= 1) h->parts = v > MC_NCTX ? MC_NCTX : v; }   // (profiling: MC_PARTS=1 = one kernel at a time)
     if (H.max_bucket > 2047) { g_err = "a seed bucket holds more than 2047 postings: the hit-order key cannot index it"; return -1; }
     // the position-parallel seed kernel is exact only when the frequency threshold is 0 and no letter frequency is 0
     h->fast_enum = (H.freq_thr == 0) && !H.rec.empty() && !getenv("MC_FORCE_SEQUENTIAL_ENUM");
@@ -1658,7 +1666,7 @@ static int ensure_capacity(mc_handle *h, McCtx &c, int64_t nreads)
     // read of a real genome), scaled with the read length; a batch that still overflows is split by mc_search
     const int64_t L = h->read_len;
     c.cap_reads = 0;                                                // pools are being replaced: nothing is usable until all of them exist
-    c.cap_tasks = (uint32_t)std::min<int64_t>(cap * (L + 32) + (1 << 20) + (int64_t)256 * 16 * MC_EN_BLK, 0x7fffffff);
+    c.cap_tasks = (uint32_t)std::min<int64_t>(cap * (L + 32) + (1 << 20) + (int64_t)256 * 32 * MC_EN_BLK, 0x7fffffff);
     c.cap_gaps = (uint32_t)std::min<int64_t>(cap * (L / 8 + 8) + (1 << 18), 0x7fffffff);
     c.cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 2 + 16) + (1 << 20), 0x7fffffff);
     c.cap_rows = (uint32_t)std::min<int64_t>(cap * 48 + (1 << 20), 0x7fffffff);
@@ -1732,12 +1740,17 @@ static int stage_a(mc_handle *h, McCtx &c)
     HIPCK(hipEventRecord(c.ev[1], st));
     if (h->fast_enum) {
         const int FPs = (FP + 15) & ~15;
-        const size_t per_wave = sizeof(McEnWave) + (size_t)6 * FPs + (size_t)6 * MC_EN_NCHUNK(L) * (512 + 128);
-        int waves = (int)((160 * 1024 - 64) / per_wave);                // waves per workgroup: as many as the LDS holds, at most 16
-        waves = waves >= 16 ? 16 : waves >= 12 ? 12 : waves >= 8 ? 8 : 4;
+        const size_t per_wave = MC_EN_WAVE_BYTES(h->count_traffic) + (size_t)6 * FPs + (size_t)6 * MC_EN_NCHUNK(L) * (512 + 128);
+        // Waves per workgroup: the kernel needs ~138 VGPRs; under __launch_bounds__(1024) the compiler fits it into 128 (one spill),
+        // i.e. 4 waves per SIMD - the best measured shape (2 per SIMD: 21.9 ms per 1 M reads of 150 bp, 3: 16.2, 4: 13.7; 5 and 6 forced
+        // with amdgpu_waves_per_eu spill 28 / 50 registers and bring 13.2 / 13.8).  So: 16 waves in one workgroup per CU when the LDS
+        // holds them, else as many as fit.
+        int waves = 0, bpc = 1;
+        for (int wv : {16, 12, 8, 4}) if (!waves && 64 + wv * per_wave <= 160 * 1024) waves = wv;
+        if (!waves) { g_err = "reads too long for the seed kernel's LDS layout"; return -1; }
+        if (const char *e = getenv("MC_EN_SHAPE")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 16 || a == 12 || a == 8 || a == 4) && b >= 1 && (size_t)b * (64 + a * per_wave) <= 160 * 1024) { waves = a; bpc = b; } }   // (experiments)
         const size_t lds2 = 64 + waves * per_wave;
-        if (lds2 > 160 * 1024) { g_err = "reads too long for the seed kernel's LDS layout"; return -1; }
-        const int blocks = (int)std::min<int64_t>(256, (n + waves - 1) / waves);
+        const int blocks = (int)std::min<int64_t>((int64_t)256 * bpc, (n + waves - 1) / waves);
 #define MC_LAUNCH_EN(WV, CNT)                                                                                                                      \
     do {                                                                                                                                           \
         HIPCK(hipFuncSetAttribute((const void *)k_enumerate_t0<WV, CNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                  \

@@ -152,7 +152,15 @@ int main(int argc, char **argv)
                 uint8_t comp[20], sv[24]; int16_t stk[16];
                 McSegWS ws{comp, sv, stk};
                 mc_seg_mask_fx(T.lnfac, T.seg_dout, p, n, ws);
-                if (getenv("MC_CHECK_SEG")) {   // frame by frame against the plain restatement
+                if (getenv("MC_CHECK_SEG")) {   // the form that computes the window flags once per frame (what the kernel runs) ...
+                    std::vector<uint8_t> q2(FP, MC_INV);
+                    int n3 = mc_translate_frame(T, (const uint8_t *)rs[r].data(), read_len, f, q2.data());
+                    uint8_t comp2[20], sv2[24]; int16_t stk2[16];
+                    McSegWS ws2{comp2, sv2, stk2};
+                    mc_seg_mask_fx2(T.lnfac, T.seg_dout, q2.data(), n3, ws2);
+                    if (n3 != n || memcmp(q2.data(), p, (size_t)n)) seg_bad++;
+                }
+                if (getenv("MC_CHECK_SEG")) {   // ... and frame by frame against the plain restatement
                     std::vector<uint8_t> q(FP, MC_INV);
                     int n2 = mc_translate_frame(T, (const uint8_t *)rs[r].data(), read_len, f, q.data());
                     uint8_t mask[(MC_MAXAA + 7) / 8]; double Hbuf[MC_MAXAA + 2];
