@@ -150,6 +150,11 @@ int32_t mc_reader_read_len(const mc_reader *r);
  * after mc_search(); the reader's statistics (mc_reader_get_stats) are complete when it returns.  -3: the reference would have
  * raised while sampling (mc_last_error names the Python exception). */
 int mc_search_files(mc_handle *h, mc_reader *r, int64_t first_read_id);
+/* The same over n_dev GPUs of this process (the multi-device entry; the one-process-per-GPU form with an RCCL
+ * reduce is microbecensus_amd/distributed.py): handles[d] was opened on device d and given the same mc_set_run(); the sampler
+ * runs once, batches of accepted reads are dealt to the devices as they ask for them (global read ids), one host thread per
+ * device.  Results stay with the handles (mc_result_* per handle): the caller adds the per-family sums - integers. */
+int mc_search_files_multi(mc_handle *const *handles, int32_t n_dev, mc_reader *r, int64_t first_read_id);
 /* keep != 0 (default): mc_search() / mc_search_files() collect the m8 rows of all their batches for mc_result_rows(); 0: only the
  * best hits and the statistics (the rows are still computed - classification reads them on the device). */
 int mc_set_keep_rows(mc_handle *h, int keep);

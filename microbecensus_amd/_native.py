@@ -98,6 +98,7 @@ def load_library():
     lib.mc_reader_read_len.restype = C.c_int32
     lib.mc_reader_read_len.argtypes = [C.c_void_p]
     lib.mc_search_files.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.mc_search_files_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int64]
     lib.mc_set_keep_rows.argtypes = [C.c_void_p, C.c_int]
     _lib = lib
     return lib
@@ -106,7 +107,7 @@ def load_library():
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
                     "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_set_parts", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8",
                     "mc_reader_last_error", "mc_reader_open", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_count_bases",
-                    "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_search_files", "mc_set_keep_rows"]
+                    "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows"]
 
 
 class ReferenceError_(Exception):
@@ -373,3 +374,23 @@ class Engine:
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dtype).itemsize,)).view(dtype).copy()
         return {"res": arr(p[0], "u1", nres.value), "off": arr(p[1], "<u4", nseq + 1), "bstart": arr(p[2], "<u4", 1000001),
                 "post": arr(p[3], "<u4", npost.value), "keys": arr(p[4], "<u2", npost.value), "thr": thr.value, "letter_p": list(lp)}
+
+
+def search_files_multi(engines, reader, first_read_id=0, keep_rows=False):
+    """mc_search_files_multi: one sampler, its batches dealt to several engines (GPUs) of this process.  Returns the best hits of
+    all engines in ascending read order."""
+    lib = load_library()
+    arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
+    for e in engines:
+        lib.mc_set_keep_rows(e.h, 1 if keep_rows else 0)
+    try:
+        rc = lib.mc_search_files_multi(arr, len(engines), reader.r, first_read_id)
+        if rc == -3:
+            raise ReferenceError_(lib.mc_last_error().decode())
+        if rc != 0:
+            raise RuntimeError("mc_search_files_multi failed (%d): %s" % (rc, lib.mc_last_error().decode()))
+    finally:
+        for e in engines:
+            lib.mc_set_keep_rows(e.h, 1)
+    best = np.concatenate([e.best_hits() for e in engines])
+    return best[np.argsort(best["read"], kind="stable")]

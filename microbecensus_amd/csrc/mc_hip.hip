@@ -1954,20 +1954,27 @@ extern "C" int mc_run(mc_handle *h, int64_t first_read_id) { return h ? mc_run_r
 
 // The streaming form of the pipeline: batches of reads are fetched from a host-side source into pinned staging memory and
 // uploaded by a thread of their own (two staging / device buffers in turn) while the calling thread runs mc_run_range() on the
-// batch before - upload and search overlap.  fetch(first, max, dst) copies reads [first, first + max) into dst and returns
-// how many there were (0: the source has ended; < 0: its error).
+// batch before - upload and search overlap.
+#define MC_STREAM_BATCH 2000000
+static int64_t stream_batch()
+{   // reads per batch of the streaming pipeline (MC_STREAM_BATCH in the environment: tests deal small batches)
+    if (const char *e = getenv("MC_STREAM_BATCH")) { const long long v = atoll(e); if (v >= 1000 && v <= MC_STREAM_BATCH) return (int64_t)v; }
+    return MC_STREAM_BATCH;
+}
 struct McBatchSlot { uint8_t *pin = nullptr, *dev = nullptr; int64_t n = 0, first = 0; int state = 0; /* 0 free, 1 ready, 2 end / error */ int64_t rc = 0; };
 
-static int run_stream(mc_handle *h, const std::function<int64_t(int64_t, int64_t, uint8_t *)> &fetch, int64_t first_read_id)
+// fetch(dst, max, &first) copies the next batch of at most `max` reads into dst, stores the index of its first read and returns
+// how many there were (0: the source has ended; < 0: its error).
+static int run_stream(mc_handle *h, const std::function<int64_t(uint8_t *, int64_t, int64_t *)> &fetch, int64_t first_read_id)
 {
     HIPCK(hipSetDevice(h->device));
-    const int64_t B = 2000000, L = h->read_len;
+    const int64_t BMAX = MC_STREAM_BATCH, B = stream_batch(), L = h->read_len;
     if (!h->stage_pin[0] || h->stage_len != L) {
         for (int k = 0; k < 2; k++) {
             if (h->stage_pin[k]) { (void)hipHostFree(h->stage_pin[k]); h->stage_pin[k] = nullptr; }
             if (h->stage_dev[k]) { (void)hipFree(h->stage_dev[k]); h->stage_dev[k] = nullptr; }
-            HIPCK(hipHostMalloc((void **)&h->stage_pin[k], (size_t)(B * L + 64), hipHostMallocDefault));
-            HIPCK(hipMalloc((void **)&h->stage_dev[k], (size_t)(B * L + 64)));
+            HIPCK(hipHostMalloc((void **)&h->stage_pin[k], (size_t)(BMAX * L + 64), hipHostMallocDefault));
+            HIPCK(hipMalloc((void **)&h->stage_dev[k], (size_t)(BMAX * L + 64)));
         }
         if (!h->copy_stream) HIPCK(hipStreamCreate(&h->copy_stream));
         h->stage_len = (int)L;
@@ -1979,10 +1986,10 @@ static int run_stream(mc_handle *h, const std::function<int64_t(int64_t, int64_t
     std::string up_err;
     std::thread uploader([&] {
         (void)hipSetDevice(h->device);
-        int64_t at = 0;
         for (int k = 0;; k ^= 1) {
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return slot[k].state == 0 || abort_up; }); if (abort_up) return; }
-            const int64_t n = fetch(at, B, slot[k].pin);
+            int64_t at = 0;
+            const int64_t n = fetch(slot[k].pin, B, &at);
             int64_t rc = n;
             if (n > 0) {
                 hipError_t e = hipMemcpyAsync(slot[k].dev, slot[k].pin, (size_t)(n * L), hipMemcpyHostToDevice, h->copy_stream);
@@ -1993,7 +2000,6 @@ static int run_stream(mc_handle *h, const std::function<int64_t(int64_t, int64_t
             slot[k].n = n > 0 ? n : 0; slot[k].first = at; slot[k].rc = rc; slot[k].state = rc > 0 ? 1 : 2;
             cv.notify_all();
             if (rc <= 0) return;
-            at += n;
         }
     });
     std::vector<mc_row> &all_rows = h->all_rows; all_rows.clear();
@@ -2035,31 +2041,59 @@ extern "C" int mc_search(mc_handle *h, const uint8_t *reads, int64_t nreads, int
     if (!h || !h->run_set) { g_err = "mc_set_run() must be called first"; return -1; }
     if (nreads < 0 || (nreads > 0 && !reads)) { g_err = "bad argument"; return -1; }
     const int64_t L = h->read_len;
-    return run_stream(h, [&](int64_t first, int64_t max_reads, uint8_t *dst) -> int64_t {
-        const int64_t n = std::max<int64_t>(0, std::min(max_reads, nreads - first));
-        if (n > 0) memcpy(dst, reads + first * L, (size_t)(n * L));
+    int64_t at = 0;
+    return run_stream(h, [&](uint8_t *dst, int64_t max_reads, int64_t *first) -> int64_t {
+        const int64_t n = std::max<int64_t>(0, std::min(max_reads, nreads - at));
+        if (n > 0) memcpy(dst, reads + at * L, (size_t)(n * L));
+        *first = at; at += n;
         return n;
     }, first_read_id);
 }
 
-extern "C" int mc_search_files(mc_handle *h, mc_reader *r, int64_t first_read_id)
+// process_seqfile + search_seqs + classify_reads over n_dev GPUs of this process (the library-owned form of the
+// multi-GPU path; one process per GPU + RCCL is microbecensus_amd/distributed.py).  The sampler runs once; batches of
+// MC_STREAM_BATCH accepted reads are dealt to the devices in the order they ask for them (reads are independent and keep their
+// global ids), every device runs the streaming pipeline on a host thread of its own.  Results stay with the handles
+// (mc_result_* per handle); the caller sums what it needs - the per-family accumulators are integers.
+extern "C" int mc_search_files_multi(mc_handle *const *handles, int32_t n_dev, mc_reader *r, int64_t first_read_id)
 {
-    if (!h || !h->run_set) { g_err = "mc_set_run() must be called first"; return -1; }
-    if (!r) { g_err = "null reader"; return -1; }
-    if (mc_reader_read_len(r) != h->read_len) { g_err = "the reader trims to another length than mc_set_run() was given"; return -1; }
+    if (!handles || n_dev < 1 || !r) { g_err = "bad argument"; return -1; }
+    for (int d = 0; d < n_dev; d++) {
+        if (!handles[d] || !handles[d]->run_set) { g_err = "mc_set_run() must be called first on every handle"; return -1; }
+        if (mc_reader_read_len(r) != handles[d]->read_len) { g_err = "the reader trims to another length than mc_set_run() was given"; return -1; }
+    }
     if (mc_reader_start(r) != 0) { g_err = mc_reader_last_error(); return -1; }
-    std::string ferr;
-    const int rc = run_stream(h, [&](int64_t first, int64_t max_reads, uint8_t *dst) -> int64_t {
-        const int64_t n = mc_reader_fetch(r, first, max_reads, dst);
-        if (n < 0) ferr = mc_reader_last_error();
-        return n;
-    }, first_read_id);
+    std::mutex deal_mu;
+    int64_t next = 0;
+    bool ended = false;
+    std::vector<int> rcs((size_t)n_dev, 0);
+    std::vector<std::string> errs((size_t)n_dev);
+    auto work = [&](int d) {
+        std::string ferr;
+        rcs[(size_t)d] = run_stream(handles[d], [&](uint8_t *dst, int64_t max_reads, int64_t *first) -> int64_t {
+            int64_t at;
+            { std::unique_lock<std::mutex> lk(deal_mu); if (ended) return 0; at = next; next += max_reads; }
+            const int64_t n = mc_reader_fetch(r, at, max_reads, dst);
+            if (n < 0) ferr = mc_reader_last_error();
+            if (n < max_reads) { std::unique_lock<std::mutex> lk(deal_mu); ended = true; }
+            *first = at;
+            return n;
+        }, first_read_id);
+        errs[(size_t)d] = !ferr.empty() ? ferr : std::string(rcs[(size_t)d] ? mc_last_error() : "");
+    };
+    std::vector<std::thread> th;
+    for (int d = 1; d < n_dev; d++) th.emplace_back(work, d);
+    work(0);
+    for (auto &t : th) t.join();
     const int64_t sampled = mc_reader_join(r);
-    if (rc == -3 || sampled == -3) { g_err = ferr.empty() ? std::string(mc_reader_last_error()) : ferr; return -3; }
-    if (rc == 0 && sampled < 0) { g_err = mc_reader_last_error(); return (int)sampled; }
-    if (rc < 0 && !ferr.empty()) g_err = ferr;
-    return rc;
+    for (int d = 0; d < n_dev; d++) if (rcs[(size_t)d] == -3) { g_err = errs[(size_t)d]; return -3; }
+    if (sampled == -3) { g_err = mc_reader_last_error(); return -3; }
+    for (int d = 0; d < n_dev; d++) if (rcs[(size_t)d]) { g_err = errs[(size_t)d]; return rcs[(size_t)d]; }
+    if (sampled < 0) { g_err = mc_reader_last_error(); return (int)sampled; }
+    return 0;
 }
+
+extern "C" int mc_search_files(mc_handle *h, mc_reader *r, int64_t first_read_id) { return mc_search_files_multi(&h, 1, r, first_read_id); }
 
 extern "C" int mc_set_keep_rows(mc_handle *h, int keep)
 {

@@ -143,3 +143,30 @@ def test_config2_full_size_batch_split_invariance():
         assert (best[f] == bb[f]).all(), f
     assert (np.diff(rows["query"]) >= 0).all()                    # m8 order: ascending read id
     assert rows["query"].max() < n and best["read"].max() < n and len(best) > 5000
+
+
+def test_multi_device_entry_deals_batches(monkeypatch):
+    """mc_search_files_multi with two handles (both on this box's GPU), batches of 9,000 reads dealt between them: the union of
+    their best hits is what one handle finds."""
+    from microbecensus_amd import _native
+    monkeypatch.setenv("MC_STREAM_BATCH", "9000")
+    path = os.path.join(INPUTS, "metagenome.fa.gz")
+    model = _native.load_model()
+    engs = [_native.Engine(device=0) for _ in range(2)]
+    try:
+        for e in engs:
+            e.set_run(100, model["pars"]["100"], model["families"])
+        rd = _native.Reader([path], 100, 1000000, False, 0, -5, -5, 100, False)
+        both = _native.search_files_multi(engs, rd)
+        assert min(e.stats()["reads"] for e in engs) > 9000          # both handles really worked
+        rd.close()
+        rd = _native.Reader([path], 100, 1000000, False, 0, -5, -5, 100, False)
+        rows, one = engs[0].search_files(rd, keep_rows=False)
+        rd.close()
+    finally:
+        for e in engs:
+            e.close()
+    g = json.load(open(os.path.join(GOLD, "unittest_metagenome.json")))
+    assert len(both) == len(one) == len(g["best_hits"])
+    for f in one.dtype.names:
+        assert (both[f] == one[f]).all(), f
