@@ -109,6 +109,9 @@ int mc_result_stats(mc_handle *h, mc_stats *out);
 /* Writes the rows of the last run as RAPsearch2 m8 text (PrintRes formatting: %g columns, tab separated,
  * no header lines) - what search_seqs() leaves in paths['tempfile']+'.m8'. append != 0 appends. */
 int mc_write_m8(mc_handle *h, const char *path, int append);
+/* The same with the Query column taken from query_names[query id - first_read_id] (rapsearch prints the FASTA header's first
+ * token; process_seqfile names its reads 0, 1, ... so the two agree there) - for the rapsearch-compatible executable. */
+int mc_write_m8_named(mc_handle *h, const char *path, int append, const char *const *query_names, int64_t n_names, int64_t first_read_id);
 
 /* ---- host stage in front of the search: native read sampler (csrc/mc_reader.cpp; no GPU involved) ----------------
  * Replaces open_file / parse_seqs / quality_filter / process_seqfile (microbe_census.py:47-59, :294-325, :265-279,

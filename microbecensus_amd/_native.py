@@ -79,6 +79,7 @@ def load_library():
     lib.mc_result_best_hits.argtypes = [C.c_void_p, C.POINTER(C.POINTER(McBestHit))]
     lib.mc_result_stats.argtypes = [C.c_void_p, C.POINTER(McStats)]
     lib.mc_write_m8.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    lib.mc_write_m8_named.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_int64, C.c_int64]
     lib.mc_reader_last_error.restype = C.c_char_p
     lib.mc_reader_open.restype = C.c_void_p
     lib.mc_reader_open.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_char_p]
@@ -105,7 +106,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
-                    "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_set_parts", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8",
+                    "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_set_parts", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8", "mc_write_m8_named",
                     "mc_reader_last_error", "mc_reader_open", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_count_bases",
                     "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows"]
 
@@ -256,7 +257,7 @@ class Engine:
             pk_names, _ = load_markers()
             families = model["families"]
             fam_idx = dict(zip(pk_names, model["marker_family"]))
-            fam = [fam_idx[nm] for nm in self.names]
+            fam = [fam_idx.get(nm, 0) for nm in self.names]       # (a database of other sequences: one family; searching needs none)
         else:
             fam = [families.index(family_of[nm]) for nm in self.names]
         self.nfam = len(families)
@@ -362,6 +363,10 @@ class Engine:
 
     def write_m8(self, path, append=False):
         self._check(self.lib.mc_write_m8(self.h, path.encode(), 1 if append else 0), "mc_write_m8")
+
+    def write_m8_named(self, path, names, append=False, first_read_id=0):
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        self._check(self.lib.mc_write_m8_named(self.h, path.encode(), 1 if append else 0, arr, len(names), first_read_id), "mc_write_m8_named")
 
     def index_view(self):
         p = [C.c_void_p() for _ in range(5)]

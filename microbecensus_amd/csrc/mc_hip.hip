@@ -2106,16 +2106,28 @@ extern "C" int64_t mc_result_rows(mc_handle *h, const mc_row **rows) { if (!h) r
 extern "C" int64_t mc_result_best_hits(mc_handle *h, const mc_best_hit **hits) { if (!h) return -1; *hits = h->best.data(); return (int64_t)h->best.size(); }
 extern "C" int mc_result_stats(mc_handle *h, mc_stats *out) { if (!h) return -1; *out = h->stats; return 0; }
 
-extern "C" int mc_write_m8(mc_handle *h, const char *path, int append)
+static int write_m8(mc_handle *h, const char *path, int append, const char *const *query_names, int64_t n_names, int64_t first_read_id)
 {
     if (!h) { g_err = "null handle"; return -1; }
     FILE *f = fopen(path, append ? "a" : "w");
     if (!f) { g_err = std::string("cannot open ") + path; return -1; }
+    setvbuf(f, nullptr, _IOFBF, 1 << 22);
     for (int64_t i = 0; i < h->n_res_rows; i++) {
         const mc_row &r = h->res_rows[i];
-        fprintf(f, "%d\t%s\t%g\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%g\t%g\n", r.query, h->H.names[r.subject].c_str(), r.ident, r.alnlen, r.mismatch, r.gapopen, r.qstart, r.qend,
+        if (query_names) {
+            const int64_t k = (int64_t)r.query - first_read_id;
+            if (k < 0 || k >= n_names) { fclose(f); g_err = "a row's query id lies outside the names given"; return -1; }
+            fprintf(f, "%s", query_names[k]);
+        } else fprintf(f, "%d", r.query);
+        fprintf(f, "\t%s\t%g\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%g\t%g\n", h->H.names[r.subject].c_str(), r.ident, r.alnlen, r.mismatch, r.gapopen, r.qstart, r.qend,
                 r.sstart, r.send, r.loge, r.bits);
     }
     fclose(f);
     return 0;
+}
+extern "C" int mc_write_m8(mc_handle *h, const char *path, int append) { return write_m8(h, path, append, nullptr, 0, 0); }
+extern "C" int mc_write_m8_named(mc_handle *h, const char *path, int append, const char *const *query_names, int64_t n_names, int64_t first_read_id)
+{
+    if (!query_names) { g_err = "null names"; return -1; }
+    return write_m8(h, path, append, query_names, n_names, first_read_id);
 }

@@ -15,7 +15,9 @@ Same public names, argument dicts, side effects, messages and return shapes as t
 What differs from the reference, on purpose:
   * search_seqs() does not fork RAPsearch2; it packs the trimmed reads and calls libmcensus_hip.so
     (include/mcensus.h).  It still leaves `<tempfile>.m8` behind in RAPsearch2's format, so anything that
-    consumed that file keeps working.  args['rapsearch'] (the reference's -r hook) is not honoured.
+    consumed that file keeps working.  args['rapsearch'] (the reference's -r hook) runs that executable instead,
+    exactly as the reference does, on a database the library writes in RAPsearch2's format: the bundled CPU binary
+    for an A/B run, or scripts/rapsearch_mi355x (the GPU engine behind RAPsearch2's command line).
   * classify_reads() takes the per-read best hits the device computed; if `<tempfile>.m8` was not produced
     by this process it falls back to parsing that file exactly as the reference does.
   * `.bz2` inputs are read (the reference returns a bytes stream under Python 3, which makes its own
@@ -94,8 +96,54 @@ def check_os():
 def get_relative_paths(args):
     """Data locations + a fresh temp file (reference :106-123); the maps live in package data."""
     pkg_dir = os.path.dirname(os.path.abspath(__file__))
-    return {"db": os.path.join(pkg_dir, "data", "markers.faa.gz"), "model": os.path.join(pkg_dir, "data", "model.json"),
-            "tempfile": mkstemp()[1]}
+    paths = {"db": os.path.join(pkg_dir, "data", "markers.faa.gz"), "model": os.path.join(pkg_dir, "data", "model.json"),
+             "tempfile": mkstemp()[1]}
+    if args.get("rapsearch"):                     # the reference's -r hook (:110-111): an external RAPsearch2-compatible executable
+        paths["rapsearch"] = args["rapsearch"]
+    return paths
+
+
+def check_rapsearch(rapsearch):
+    """The executable must answer `-h` like RAPsearch2 v2.15 (reference :135-145)."""
+    import subprocess
+    process = subprocess.Popen(rapsearch + " -h", shell=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    output, error = process.communicate()
+    if os.path.isdir(rapsearch) or len(error.decode().split("\n")) < 2:
+        sys.exit("Problem executing rapsearch2: '%s'" % rapsearch)
+    if error.decode().split("\n")[1] != "rapsearch v2.15: Fast protein similarity search tool for short reads":
+        sys.exit("Incorrect version of rapsearch2 detected:'%s\nMicrobeCensus requires rapsearch v2.15" % rapsearch)
+
+
+def _rapdb_for_external_search():
+    """The marker database in RAPsearch2's on-disk format (what `prerapsearch -d markers.faa -n rapdb_2.15` writes), produced once
+    per machine by the library's own writer (mc_rapdb_write) from the packaged markers."""
+    import hashlib
+    import tempfile
+    from . import _native
+    names, seqs = _native.load_markers()
+    tag = hashlib.md5(("".join(names) + "".join(seqs)).encode()).hexdigest()[:16]
+    path = os.path.join(tempfile.gettempdir(), "microbecensus_amd_rapdb_2.15_" + tag)
+    if not (os.path.isfile(path) and os.path.isfile(path + ".info")):
+        tmp = path + ".%d" % os.getpid()
+        _native.rapdb_write(names, seqs, tmp)
+        os.replace(tmp + ".info", path + ".info")
+        os.replace(tmp, path)
+    return path
+
+
+def _search_seqs_external(args, paths):
+    """search_seqs exactly as the reference runs it (:369-389), with the executable given by -r / args['rapsearch']."""
+    import subprocess
+    command = "%s -q %s -d %s -o %s -z %s -e 1 -t n -p f -b 0" % (paths["rapsearch"], paths["tempfile"], _rapdb_for_external_search(), paths["tempfile"], args["threads"])
+    process = subprocess.Popen(command, shell=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    output, error = process.communicate()
+    if process.returncode != 0:
+        clean_up(paths)
+        sys.exit("\nDatabase search has exited with the following error:\n%s" % error)
+    _run_cache.setdefault(paths["tempfile"], {}).pop("best", None)       # classify_reads parses the m8 file, like the reference
+    if args["verbose"]:
+        with open(paths["tempfile"] + ".m8") as f_in:
+            print("\t%s reads hit marker proteins" % len(set(line.split()[0] for line in f_in if line[0] != "#")))
 
 
 def check_paths(paths):
@@ -400,6 +448,8 @@ def search_seqs(args, paths):
     `<tempfile>.m8` (RAPsearch2 m8 format) behind like the reference does."""
     if args["verbose"]:
         print("Searching reads against marker proteins...")
+    if paths.get("rapsearch"):
+        return _search_seqs_external(args, paths)
     L = args["read_length"]
     cache = _run_cache.get(paths["tempfile"])
     if cache is None or "reads" not in cache:
@@ -591,7 +641,9 @@ def run_pipeline(args):
         check_arguments(args)
         if args["verbose"]:
             print_parameters(args)
-        if _native_reader_usable(args) and not args.get("keep_tmp"):
+        if paths.get("rapsearch"):
+            check_rapsearch(paths["rapsearch"])
+        if _native_reader_usable(args) and not args.get("keep_tmp") and not paths.get("rapsearch"):
             _sample_search_classify(args, paths)
         else:                                      # stage by stage, with the temp FASTA and the m8 file the reference leaves behind
             process_seqfile(args, paths)

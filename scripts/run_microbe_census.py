@@ -15,7 +15,7 @@ def parse_arguments(argv=None):
     p.add_argument("seqfiles", type=str, help="path to input metagenome(s); comma separated; FASTA/FASTQ, optionally gz/bz2")
     p.add_argument("outfile", type=str, help="path to the output report")
     p.add_argument("-v", dest="verbose", action="store_true", default=False, help="print program's progress to stdout")
-    p.add_argument("-r", dest="rapsearch", type=str, default=None, help="accepted for compatibility; the GPU path does not run RAPsearch2")
+    p.add_argument("-r", dest="rapsearch", type=str, default=None, help="path to an external RAPsearch2 v2.15 compatible executable to run instead of the in-process GPU search (the reference's hook)")
     p.add_argument("-n", dest="nreads", type=int, default=2000000, help="number of reads to sample (default = 2000000)")
     p.add_argument("-t", dest="threads", type=int, default=1, help="host threads (default = 1)")
     p.add_argument("-e", dest="no_equivs", action="store_true", default=False, help="skip the genome-equivalents pass over the input")

@@ -170,3 +170,27 @@ def test_multi_device_entry_deals_batches(monkeypatch):
     assert len(both) == len(one) == len(g["best_hits"])
     for f in one.dtype.names:
         assert (both[f] == one[f]).all(), f
+
+
+def test_rapsearch_compatible_executable(tmp_path):
+    """scripts/rapsearch_mi355x behind RAPsearch2's command line (the reference's -r hook and training/search_reads.py:57 call it
+    like this): -h passes check_rapsearch, the m8 has RAPsearch2's five header lines and the reference's rows, the .aln exists
+    (empty for -b 0); run_pipeline with args['rapsearch'] = the executable gives the reference's AGS."""
+    import contextlib
+    import io
+    exe = os.path.join(REPO, "scripts", "rapsearch_mi355x")
+    mc.check_rapsearch(exe)
+    g = json.load(open(os.path.join(GOLD, "config1_example_fq.json")))
+    fa = tmp_path / "reads.fa"
+    fa.write_bytes(gzip.open(os.path.join(GOLD, "config1_example_fq.reads.fa.gz"), "rb").read())
+    db = mc._rapdb_for_external_search()
+    out = str(tmp_path / "out")
+    subprocess.check_call([exe, "-q", str(fa), "-d", db, "-o", out, "-z", "1", "-e", "1", "-t", "n", "-p", "f", "-b", "0"], stdout=subprocess.DEVNULL)
+    lines = open(out + ".m8", "rb").readlines()
+    assert [l[:1] for l in lines[:6]] == [b"#"] * 5 + [b"1"] and lines[0] == b"# RAPSearch\n" and lines[4].startswith(b"# Fields: Query\tSubject\tidentity")
+    assert hashlib.md5(b"".join(lines[5:])).hexdigest() == g["m8_md5"]
+    assert os.path.getsize(out + ".aln") == 0
+    args = {"seqfiles": [os.path.join(INPUTS, "example.fq.gz")], "nreads": 10000, "read_length": 100, "threads": 1, "rapsearch": exe}
+    with contextlib.redirect_stdout(io.StringIO()):
+        est, args = mc.run_pipeline(args)
+    assert est == g["est_ags"]

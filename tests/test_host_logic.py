@@ -115,3 +115,36 @@ def test_report_format(tmp_path):
 def test_count_bases_config1():
     g = golden("config1_example_fq")
     assert mc.count_bases({"seqfiles": [os.path.join(INPUTS, "example.fq.gz")], "verbose": False}) == g["total_bases"]
+
+
+def test_rapsearch_hook_runs_the_external_executable(ref_dir):
+    """args['rapsearch'] (the reference's -r, microbe_census.py:110-111): the bundled RAPsearch2 binary runs as a subprocess on the
+    database the library's own writer produces, the m8 it leaves is classified by the Python statement of classify_reads - the
+    whole host side without a GPU: same AGS as the reference, bit for bit (BASELINE configs[0])."""
+    import contextlib
+    import io
+    import json
+    import os
+    from microbecensus_amd import microbe_census as mc
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = json.load(open(os.path.join(here, "golden", "config1_example_fq.json")))
+    args = {"seqfiles": [os.path.join(here, "golden", "inputs", "example.fq.gz")], "nreads": 10000, "read_length": 100, "threads": 8,
+            "rapsearch": os.path.join(ref_dir, "rapsearch_Linux_2.15"), "verbose": True}
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        res = mc.run_pipeline(args)
+    assert res is not None, buf.getvalue()
+    est, args = res
+    assert args["sampled_reads"] == g["sampled_reads"] and est == g["est_ags"]
+    assert "reads hit marker proteins" in buf.getvalue()
+
+
+def test_rapsearch_hook_rejects_other_programs(tmp_path):
+    import pytest
+    from microbecensus_amd import microbe_census as mc
+    fake = tmp_path / "fake"
+    fake.write_text("#!/bin/sh\necho line1 >&2\necho 'not rapsearch' >&2\n")
+    fake.chmod(0o755)
+    with pytest.raises(SystemExit) as e:
+        mc.check_rapsearch(str(fake))
+    assert "Incorrect version of rapsearch2" in str(e.value)
