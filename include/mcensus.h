@@ -113,6 +113,15 @@ int mc_write_m8(mc_handle *h, const char *path, int append);
  * token; process_seqfile names its reads 0, 1, ... so the two agree there) - for the rapsearch-compatible executable. */
 int mc_write_m8_named(mc_handle *h, const char *path, int append, const char *const *query_names, int64_t n_names, int64_t first_read_id);
 
+/* The training workflow's grid search (training/training.py:311-334 classify_reads, called by training/class_reads.py:51-66 with
+ * 4 aln_covs x 6 max_pids x 27 min_scores) over the m8 rows of the last mc_search() / mc_run(): for every combination, the rows
+ * that pass alignment coverage >= aln_cov, identity <= max_pid (integers, as in class_reads.py), bit score >= min_score; per
+ * read the best-scoring survivor (the first on a tie); per family the number of such reads, the sum of their alignment lengths,
+ * the sum of alignment length / target length.  Outputs are [n_cov][n_pid][n_score][nfam] arrays; hits and aln are exact, the
+ * coverage sums are accumulated in no fixed order (1e-12 relative against the reference's sequential sum).  One device pass. */
+int mc_grid_classify(mc_handle *h, const double *aln_covs, int32_t n_cov, const int32_t *max_pids, int32_t n_pid, const double *min_scores, int32_t n_score,
+                     int64_t *count_hits, int64_t *count_aln, double *count_cov);
+
 /* ---- host stage in front of the search: native read sampler (csrc/mc_reader.cpp; no GPU involved) ----------------
  * Replaces open_file / parse_seqs / quality_filter / process_seqfile (microbe_census.py:47-59, :294-325, :265-279,
  * :328-367) and count_bases (:573-584) with identical results, quirks included (see the header of mc_reader.cpp).

@@ -101,6 +101,8 @@ def load_library():
     lib.mc_search_files.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.mc_search_files_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int64]
     lib.mc_set_keep_rows.argtypes = [C.c_void_p, C.c_int]
+    lib.mc_grid_classify.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_double), C.c_int32,
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     _lib = lib
     return lib
 
@@ -108,7 +110,7 @@ def load_library():
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
                     "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_set_parts", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8", "mc_write_m8_named",
                     "mc_reader_last_error", "mc_reader_open", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_count_bases",
-                    "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows"]
+                    "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows", "mc_grid_classify"]
 
 
 class ReferenceError_(Exception):
@@ -367,6 +369,17 @@ class Engine:
     def write_m8_named(self, path, names, append=False, first_read_id=0):
         arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
         self._check(self.lib.mc_write_m8_named(self.h, path.encode(), 1 if append else 0, arr, len(names), first_read_id), "mc_write_m8_named")
+
+    def grid_classify(self, aln_covs, max_pids, min_scores):
+        """The training grid (training/training.py:311-334) over the rows of the last search: (hits, aln, cov) arrays of shape
+        (len(aln_covs), len(max_pids), len(min_scores), nfam)."""
+        nc, npid, ns = len(aln_covs), len(max_pids), len(min_scores)
+        shape = (nc, npid, ns, self.nfam)
+        hits = np.zeros(shape, np.int64); aln = np.zeros(shape, np.int64); cov = np.zeros(shape, np.float64)
+        self._check(self.lib.mc_grid_classify(self.h, (C.c_double * nc)(*aln_covs), nc, (C.c_int32 * npid)(*[int(p) for p in max_pids]), npid, (C.c_double * ns)(*min_scores), ns,
+                                              hits.ctypes.data_as(C.POINTER(C.c_int64)), aln.ctypes.data_as(C.POINTER(C.c_int64)), cov.ctypes.data_as(C.POINTER(C.c_double))),
+                    "mc_grid_classify")
+        return hits, aln, cov
 
     def index_view(self):
         p = [C.c_void_p() for _ in range(5)]

@@ -168,6 +168,26 @@ MC_HDN void mc_merge_res_order(McRow *a, double *k, int n)
 // ------------------------------------------------------------------------------------------------
 // alignment_coverage + alignment_filter (microbe_census.py:400-430) on one row, all in IEEE double
 // ------------------------------------------------------------------------------------------------
+// alignment_coverage (microbe_census.py:400-418; training/training.py:248-265 computes the same): aln / the longest alignment
+// the read could have had at this position of the target
+MC_HD double mc_row_coverage(int read_len, const McRow &r, int target_len)
+{
+    double query_len = (double)read_len / 3.0;
+    double qs = (double)(r.qstart < r.qend ? r.qstart : r.qend), qe = (double)(r.qstart < r.qend ? r.qend : r.qstart);
+    double md = fmod(qs, 3.0);
+    double frame = (md == 1.0 || md == 2.0) ? md : 3.0;
+    double query_start = (qs + 3.0 - frame) / 3.0;
+    double query_stop = (qe + 1.0 - frame) / 3.0;
+    double t1 = (double)r.sstart + 1.0, t2 = (double)r.send + 1.0;
+    double t_start = t1 < t2 ? t1 : t2, t_stop = t1 < t2 ? t2 : t1;
+    double x1 = query_start - 1.0, x2 = t_start - 1.0;
+    double x = x1 < x2 ? x1 : x2;       // python min(a, b): b if b < a else a
+    double y = (double)r.alnlen;
+    double z1 = query_len - query_stop, z2 = (double)target_len - t_stop;
+    double z = z2 < z1 ? z2 : z1;
+    double maxaln = x + y + z;
+    return (double)r.alnlen / maxaln;
+}
 MC_HD bool mc_row_passes(const McClassPars &P, const McRow &r, int fam, int target_len, int nmatch)
 {
     double query_len = (double)P.read_len / 3.0;

@@ -1419,6 +1419,55 @@ __global__ void __launch_bounds__(256) k_emit_rows(const uint32_t *__restrict__ 
     if (bh.family >= 0) best[o] = bh;
 }
 
+// ---- the training workflow's grid search over the classification parameters (training/training.py:311-334) -------------------
+// classify_reads there filters the m8 rows by (aln_cov, max_pid, min_score), keeps the best-scoring row per read (the first on
+// a tie) and counts hits / aligned residues / coverage per family - for every combination of 4 x 6 x 27 parameter values, one
+// pass over the file each.  Here one thread per read does all of it in one pass over the read's rows: for a given (aln_cov,
+// max_pid) the best row does not depend on min_score (a higher cut-off only removes lower rows), so the read contributes its
+// best row to every cut-off <= that row's bit score - one atomic into bin k = number of (ascending) cut-offs it reaches; the
+// host turns the bins into the per-cut-off counts with a suffix sum.
+#define MC_GRID_MAXC 8
+#define MC_GRID_MAXP 8
+#define MC_GRID_MAXS 64
+struct McGridPars { int read_len, n_cov, n_pid, n_score, nfam; double cov[MC_GRID_MAXC]; int pid[MC_GRID_MAXP]; double score[MC_GRID_MAXS]; };
+
+__global__ void __launch_bounds__(128) k_grid_classify(McGridPars G, McIndex X, const int32_t *__restrict__ fam, const McRow *__restrict__ rows, int64_t nrows,
+                                                       unsigned long long *bin_hits, unsigned long long *bin_aln, double *bin_cov)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows) return;
+    const int q = rows[i].query;
+    if (i > 0 && rows[i - 1].query == q) return;                 // one thread per read: the one at its first row
+    double bbits[MC_GRID_MAXC * MC_GRID_MAXP];
+    int bidx[MC_GRID_MAXC * MC_GRID_MAXP];
+    for (int c = 0; c < G.n_cov * G.n_pid; c++) { bbits[c] = 0.0; bidx[c] = -1; }
+    for (int64_t k = i; k < nrows && rows[k].query == q; k++) {
+        const McRow r = rows[k];
+        const int tl = (int)(X.off[r.subject + 1] - X.off[r.subject]);
+        const double cov = mc_row_coverage(G.read_len, r, tl);
+        for (int ic = 0; ic < G.n_cov; ic++) {
+            if (cov < G.cov[ic]) continue;
+            for (int ip = 0; ip < G.n_pid; ip++) {
+                if (100 * r.frame > G.pid[ip] * r.alnlen) continue;          // pid > max_pid (McRow::frame carries the identities)
+                const int c = ic * G.n_pid + ip;
+                if (bidx[c] < 0 || bbits[c] < r.bits) { bbits[c] = r.bits; bidx[c] = (int)(k - i); }
+            }
+        }
+    }
+    for (int c = 0; c < G.n_cov * G.n_pid; c++) {
+        if (bidx[c] < 0) continue;
+        int nk = 0;
+        for (int j = 0; j < G.n_score; j++) nk += !(bbits[c] < G.score[j]) ? 1 : 0;   // cut-offs ascending: the row passes the first nk of them
+        if (nk == 0) continue;
+        const McRow r = rows[i + bidx[c]];
+        const int f = fam[r.subject], tl = (int)(X.off[r.subject + 1] - X.off[r.subject]);
+        const size_t o = ((size_t)c * (MC_GRID_MAXS + 1) + (size_t)nk) * (size_t)G.nfam + (size_t)f;
+        atomicAdd(&bin_hits[o], 1ull);
+        atomicAdd(&bin_aln[o], (unsigned long long)r.alnlen);
+        atomicAdd(&bin_cov[o], (double)r.alnlen / (double)tl);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------------------
@@ -2094,6 +2143,53 @@ extern "C" int mc_search_files_multi(mc_handle *const *handles, int32_t n_dev, m
 }
 
 extern "C" int mc_search_files(mc_handle *h, mc_reader *r, int64_t first_read_id) { return mc_search_files_multi(&h, 1, r, first_read_id); }
+
+extern "C" int mc_grid_classify(mc_handle *h, const double *aln_covs, int32_t n_cov, const int32_t *max_pids, int32_t n_pid, const double *min_scores, int32_t n_score,
+                                int64_t *count_hits, int64_t *count_aln, double *count_cov)
+{
+    if (!h || !h->run_set) { g_err = "mc_set_run() must be called first"; return -1; }
+    if (n_cov < 1 || n_cov > MC_GRID_MAXC || n_pid < 1 || n_pid > MC_GRID_MAXP || n_score < 1 || n_score > MC_GRID_MAXS) { g_err = "grid larger than 8 x 8 x 64"; return -1; }
+    if (!aln_covs || !max_pids || !min_scores || !count_hits || !count_aln || !count_cov) { g_err = "null argument"; return -1; }
+    HIPCK(hipSetDevice(h->device));
+    const int nfam = h->nfam;
+    McGridPars G; memset(&G, 0, sizeof G);
+    G.read_len = h->read_len; G.n_cov = n_cov; G.n_pid = n_pid; G.n_score = n_score; G.nfam = nfam;
+    for (int i = 0; i < n_cov; i++) G.cov[i] = aln_covs[i];
+    for (int i = 0; i < n_pid; i++) G.pid[i] = max_pids[i];
+    std::vector<int> order((size_t)n_score);
+    for (int i = 0; i < n_score; i++) order[(size_t)i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return min_scores[a] < min_scores[b]; });
+    for (int i = 0; i < n_score; i++) G.score[i] = min_scores[order[(size_t)i]];
+    const size_t nbins = (size_t)n_cov * n_pid * (MC_GRID_MAXS + 1) * nfam;
+    const size_t nout = (size_t)n_cov * n_pid * n_score * nfam;
+    memset(count_hits, 0, nout * 8); memset(count_aln, 0, nout * 8); memset(count_cov, 0, nout * 8);
+    const int64_t nrows = h->n_res_rows;
+    if (nrows == 0) return 0;
+    McRow *d_rows = nullptr; unsigned long long *d_bins = nullptr;
+    HIPCK(hipMalloc((void **)&d_rows, (size_t)nrows * sizeof(McRow)));
+    if (hipMalloc((void **)&d_bins, nbins * 24) != hipSuccess) { (void)hipFree(d_rows); g_err = "out of device memory"; return -1; }
+    hipStream_t st = h->ctx[0].stream;
+    HIPCK(hipMemcpyAsync(d_rows, h->res_rows, (size_t)nrows * sizeof(McRow), hipMemcpyHostToDevice, st));
+    HIPCK(hipMemsetAsync(d_bins, 0, nbins * 24, st));
+    k_grid_classify<<<dim3((unsigned)((nrows + 127) / 128)), dim3(128), 0, st>>>(G, dev_index(h), h->d_fam, d_rows, nrows, d_bins, d_bins + nbins, (double *)(d_bins + 2 * nbins));
+    std::vector<unsigned long long> bins(nbins * 3);
+    HIPCK(hipMemcpyAsync(bins.data(), d_bins, nbins * 24, hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    (void)hipFree(d_rows); (void)hipFree(d_bins);
+    const double *bcov = (const double *)(bins.data() + 2 * nbins);
+    // bin nk = reads whose best row passes exactly the first nk (ascending) cut-offs: cut-off j (ascending) counts the bins nk > j
+    for (int c = 0; c < n_cov * n_pid; c++)
+        for (int f = 0; f < nfam; f++) {
+            unsigned long long sh = 0, sa = 0; double sc = 0.0;
+            for (int j = n_score - 1; j >= 0; j--) {
+                const size_t o = ((size_t)c * (MC_GRID_MAXS + 1) + (size_t)(j + 1)) * (size_t)nfam + (size_t)f;
+                sh += bins[o]; sa += bins[nbins + o]; sc += bcov[o];
+                const size_t out = ((size_t)c * n_score + (size_t)order[(size_t)j]) * (size_t)nfam + (size_t)f;
+                count_hits[out] = (int64_t)sh; count_aln[out] = (int64_t)sa; count_cov[out] = sc;
+            }
+        }
+    return 0;
+}
 
 extern "C" int mc_set_keep_rows(mc_handle *h, int keep)
 {

@@ -194,3 +194,60 @@ def test_rapsearch_compatible_executable(tmp_path):
     with contextlib.redirect_stdout(io.StringIO()):
         est, args = mc.run_pipeline(args)
     assert est == g["est_ags"]
+
+
+def test_training_grid_on_device_rows():
+    """The training workflow's grid search (training/training.py:311-334; 4 aln_covs x 6 max_pids x 27 min_scores as
+    training/class_reads.py:51-53 sets them) on the device rows of the unit-test metagenome against a Python statement of that
+    function applied to the reference's own m8 text: hits and aligned residues identical, coverage sums to 1e-12."""
+    from microbecensus_amd import _native
+    g = json.load(open(os.path.join(GOLD, "unittest_metagenome.json")))
+    L = 100
+    model = _native.load_model()
+    fams = model["families"]
+    names, seqs = _native.load_markers()
+    gene2fam = {n: fams[f] for n, f in zip(names, model["marker_family"])}
+    gene2len = {n: len(s) for n, s in zip(names, seqs)}
+    aln_covs, max_pids = [0.00, 0.25, 0.50, 0.75], [50, 60, 70, 80, 90, 100]
+    min_scores, r = [], 23
+    while r < 50:
+        min_scores.append(r); r += 1
+    # --- the reference's algorithm on the reference's m8 (text fields parsed as training.parse_rapsearch does)
+    hits = []
+    for line in gzip.open(os.path.join(GOLD, "unittest_metagenome.m8.gz"), "rt"):
+        x = line.split()
+        q, t, pid, aln, qs, qe, ts, te, score = x[0], x[1], float(x[2]), int(x[3]), float(x[6]), float(x[7]), float(x[8]), float(x[9]), float(x[11])
+        a, b = sorted([qs, qe])
+        frame = a % 3 if a % 3 in [1, 2] else 3
+        hits.append([q, t, gene2fam[t], pid, aln, (a + 3 - frame) / 3, (b + 1 - frame) / 3] + sorted([ts + 1, te + 1]) + [score])
+    want = {}
+    for ic, aln_cov in enumerate(aln_covs):
+        h1 = [h for h in hits if not (h[4] / (min(h[5] - 1, h[7] - 1) + h[4] + min(float(L) / 3 - h[6], gene2len[h[1]] - h[8])) < aln_cov)]
+        for ip, max_pid in enumerate(max_pids):
+            h2 = [h for h in h1 if not h[3] > max_pid]
+            for isc, min_score in enumerate(min_scores):
+                best = {}
+                for h in h2:
+                    if h[-1] < min_score:
+                        continue
+                    if h[0] not in best or best[h[0]][-1] < h[-1]:
+                        best[h[0]] = h
+                for h in best.values():
+                    k = (ic, ip, isc, fams.index(h[2]))
+                    w = want.setdefault(k, [0, 0, 0.0])
+                    w[0] += 1; w[1] += h[4]; w[2] += float(h[4]) / gene2len[h[1]]
+    # --- the device grid on the device rows
+    reads, st = _native.sample_reads([os.path.join(INPUTS, "metagenome.fa.gz")], L, 1000000, False, 0, -5, -5, 100, False)
+    eng = _native.Engine(device=0)
+    try:
+        eng.set_run(L, model["pars"][str(L)], fams)
+        rows, _ = eng.search(reads)
+        assert len(rows) == g["m8_rows"]
+        gh, ga, gc = eng.grid_classify(aln_covs, max_pids, min_scores)
+    finally:
+        eng.close()
+    assert gh.sum() == sum(w[0] for w in want.values()) and gh.sum() > 5000
+    for k, w in want.items():
+        assert gh[k] == w[0] and ga[k] == w[1], k
+        assert abs(gc[k] - w[2]) <= 1e-12 * w[2], k
+    assert int((gh > 0).sum()) == len(want)
