@@ -60,10 +60,17 @@ def spawn_ranks(n, argv):
     return rc if rc else (0 if line else 1)
 
 
-def profiled_traffic(kernel, n_batch):
-    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/rNN_hbm_traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in their own --pmc passes; read bytes = 2 x FETCH_SIZE on gfx950, see
-    profiles/README.md), scaled from the profiled batch to this run's batch.  None if no profile is committed."""
+STAGE_KERNELS = {   # kernels whose HIP-event time a stage of mc_stats spans (prefixes of the names in the rocprofv3 summaries)
+    "k_translate_seg": ["k_translate_seg"], "k_enumerate_t0": ["k_enumerate_t0<"], "k_enumerate": ["k_enumerate_t0<", "k_enumerate"], "k_eval_seeds": ["k_eval_seeds"],
+    "k_gapped": ["k_gap_dedupe", "k_gapped_lds", "k_gapped", "k_gap_emit"], "k_finish": ["k_finish", "k_finish_heavy", "k_heavy_lists", "k_emit_rows"],
+    "sort": ["k_make_keys", "k_gather", "k_heads"],
+}
+
+
+def profiled_traffic(stage, n_batch):
+    """HBM-side bytes per launch of the kernels of `stage` from the newest committed rocprofv3 PMC summary
+    (profiles/rNN_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in their own --pmc passes; read bytes = 2 x FETCH_SIZE on
+    gfx950, see profiles/README.md), scaled from the profiled batch to this run's batch.  None if no profile is committed."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic.json")))
     if not files:
@@ -72,11 +79,14 @@ def profiled_traffic(kernel, n_batch):
         tr = json.load(open(files[-1]))
         line = json.load(open(files[-1].replace("_hbm_traffic.json", "_bench_line.json")))
         per = float(line["config"]["batch"])
-        key = [k for k in tr if k.startswith(kernel) and "true" not in k]
-        if not key or tr[key[0]].get("write_kib_per_launch") is None:
-            return None
-        t = tr[key[0]]
-        return (2.0 * t["fetch_kib_per_launch"] + t["write_kib_per_launch"]) * 1024.0 / per * n_batch
+        total, found = 0.0, False
+        for k, t in tr.items():
+            if "true" in k or t.get("write_kib_per_launch") is None:      # (the counting form of the seed kernel is not the timed one)
+                continue
+            if any(k == p or k.startswith(p + "<") or (p.endswith("<") and k.startswith(p)) for p in STAGE_KERNELS.get(stage, [stage])):
+                total += (2.0 * t["fetch_kib_per_launch"] + t["write_kib_per_launch"]) * 1024.0
+                found = True
+        return total / per * n_batch if found else None
     except Exception:
         return None
 
@@ -348,7 +358,9 @@ def main():
         # dominant kernel = the one with the largest accumulated HIP-event time (rank 0's events, on the library's own stream)
         kern = {"k_translate_seg": acc["ms_translate"], "k_enumerate": acc["ms_seed"], "k_eval_seeds": acc["ms_eval"], "k_gapped": acc["ms_gapped"],
                 "sort": acc["ms_sort"], "k_finish": acc["ms_finish"]}
-        dom = max(kern, key=kern.get)
+        SEQ = {"k_translate_seg": "ms_translate", "k_enumerate": "ms_seed", "k_eval_seeds": "ms_eval", "k_gapped": "ms_gapped", "sort": "ms_sort", "k_finish": "ms_finish"}
+        kseq = {k: seq[m] / nseq for k, m in SEQ.items()}           # ms per step, every kernel alone on the GPU
+        dom = max(kseq, key=kseq.get)
         n_batch = args.batch
         per_launch = {
             # algorithmic bytes per launch: what the reference's algorithm reads / writes for the same reads
@@ -359,7 +371,12 @@ def main():
             "sort": acc["hsps"] * (12 * 4 + 48 * 2) / K,
             "k_finish": acc["hsps"] * 48 * 3 / K,
         }
-        ach = per_launch[dom] / (kern[dom] / K * 1e-3) / 1e9
+        # The two parts of a step overlap in the timed region, so a kernel's HIP events there also span the other part's kernels;
+        # its own duration is measured by the same events right after the timed region with one kernel at a time (mc_set_parts(1)),
+        # which is also how the committed rocprofv3 profile (profiles/, MC_PARTS=1) is taken.  achieved / frac use that duration;
+        # achieved_in_timed_region uses the overlapped one.
+        ach = per_launch[dom] / (kseq[dom] * 1e-3) / 1e9
+        ach_timed = per_launch[dom] / (kern[dom] / K * 1e-3) / 1e9
         traffic_dom = profiled_traffic("k_enumerate_t0" if dom == "k_enumerate" else dom, n_batch)
         # the whole device pipeline of one batch as one "launch": SURVEY 8(d)'s own definition, achieved = reads/s x A(L)
         pipe_gbs = (SURVEY_A[L] * (reads_total / world) / dt / 1e9) if L in SURVEY_A else None
@@ -388,22 +405,24 @@ def main():
                                                          ("k_eval_seeds", "ms_eval"), ("k_gapped", "ms_gapped"), ("sort", "ms_sort"), ("k_finish", "ms_finish"))}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                          "traffic": (None if traffic_dom is None else round(traffic_dom, 0)),
-                         "basis": "achieved = algorithmic bytes of the reference's algorithm for the launch (index reads it would issue, counted by the "
-                                  "kernel's own counting form; DESIGN.md 4) / HIP-event time of the kernel. A disposal rate: filters answer most probes, the "
-                                  "kernel does not move these bytes. physical_* = HBM-side bytes of the committed rocprofv3 PMC profile / the same time",
-                         "physical_GBps": (None if traffic_dom is None else round(traffic_dom / (kern[dom] / K * 1e-3) / 1e9, 2)),
-                         "physical_frac": (None if traffic_dom is None else round(traffic_dom / (kern[dom] / K * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)),
-                         "achieved_sequential": round(per_launch[dom] / (seq[{"k_translate_seg": "ms_translate", "k_enumerate": "ms_seed", "k_eval_seeds": "ms_eval", "k_gapped": "ms_gapped",
-                                                                                   "sort": "ms_sort", "k_finish": "ms_finish"}[dom]] / nseq * 1e-3) / 1e9, 2),
+                         "basis": "achieved = algorithmic bytes of the reference's algorithm for one step's launches of the kernel (for the seed kernel: the index "
+                                  "reads the reference would issue, counted by the kernel's own counting form; DESIGN.md 5) / HIP-event time of those launches, one "
+                                  "kernel at a time (measured right after the timed region; in it the two parts of a step overlap). For the seed kernel a disposal "
+                                  "rate: filters answer most probes, the kernel does not move these bytes. physical_* = HBM-side bytes of the committed rocprofv3 "
+                                  "PMC profile / the same time",
+                         "physical_GBps": (None if traffic_dom is None else round(traffic_dom / (kseq[dom] * 1e-3) / 1e9, 2)),
+                         "physical_frac": (None if traffic_dom is None else round(traffic_dom / (kseq[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)),
+                         "kernel_ms_per_step": round(kseq[dom], 3),
+                         "achieved_in_timed_region": round(ach_timed, 2),
                          "algorithmic_bytes_per_read": round(per_launch[dom] / n_batch, 1),
                          # SURVEY.md 8(d) priced the whole path at A(150) = 207,923 B/read assuming whole-bucket visits the engine does not
                          # perform; its definition achieved = reads/s x A(L), per GPU:
                          "survey_A_bytes_per_read": SURVEY_A.get(L),
                          "pipeline_GBps_with_survey_A": (None if pipe_gbs is None else round(pipe_gbs, 2)),
                          "pipeline_frac_with_survey_A": (None if pipe_gbs is None else round(pipe_gbs / HBM_PEAK_GBS, 5)),
-                         "all_kernels_algorithmic_GBps": {k: round(per_launch[k] / (kern[k] / K * 1e-3) / 1e9, 2) for k in kern if kern[k] > 0},
-                         "all_kernels_physical_GBps": {k: (lambda t: None if t is None else round(t / (kern[k] / K * 1e-3) / 1e9, 2))(
-                             profiled_traffic("k_enumerate_t0" if k == "k_enumerate" else k, n_batch)) for k in kern if kern[k] > 0 and k != "sort"}},
+                         "all_kernels_algorithmic_GBps": {k: round(per_launch[k] / (kseq[k] * 1e-3) / 1e9, 2) for k in kseq if kseq[k] > 0},
+                         "all_kernels_physical_GBps": {k: (lambda t: None if t is None else round(t / (kseq[k] * 1e-3) / 1e9, 2))(
+                             profiled_traffic("k_enumerate_t0" if k == "k_enumerate" else k, n_batch)) for k in kseq if kseq[k] > 0 and k != "sort"}},
         }
         if world == 1 and not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
