@@ -44,7 +44,7 @@ extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
         }                                                                                                   \
     } while (0)
 
-enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_HEAVY, C_HEAVY2, C_ITEMS, C_RETRY2, C_HEAVY3, C_N = 16 };
+enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_HEAVY, C_HEAVY2, C_ITEMS, C_RETRY2, C_HEAVY3, C_LIGHT0, C_LIGHT1, C_LIGHT2, C_LIGHT3, C_N = 24 };
 enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_N = 16 };   // 64-bit algorithmic-traffic counters of k_enumerate; slots 4..: cycle counters of the MC_EXP_TIMING build
 
 // ------------------------------------------------------------------------------------------------
@@ -1090,21 +1090,28 @@ __global__ void k_heads(const uint32_t *__restrict__ flags, const uint32_t *__re
 
 // The reads that get a wave of their own (k_finish_heavy), collected before the finishing kernels start so that they can run
 // beside the thread-per-read kernel on a second stream.  A read without a marked HSP prints nothing whatever its size.
+// The reads with a marked HSP that a single thread finishes (k_finish) are listed by size class as well: a wave of k_finish
+// then holds reads of similar size instead of one read of 90 HSPs among 63 idle lanes.
+#define MC_LIGHT_CLASS(n) ((n) <= 4 ? 0 : (n) <= 16 ? 1 : (n) <= 48 ? 2 : 3)
 __global__ void __launch_bounds__(256) k_heavy_lists(const uint32_t *__restrict__ heads, uint32_t nheads, uint32_t nhsps, const uint8_t *__restrict__ mark, uint32_t *nrow_of,
-                                                     McBestHit *best_of, uint32_t *counters, uint32_t *heavy)
+                                                     McBestHit *best_of, uint32_t *counters, uint32_t *heavy, uint32_t *light, uint32_t light_pitch)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    bool want = false;
+    int cls = -1;                                                // -1 nothing to do, 0..3 light class, 4 heavy
     if (s < nheads) {
         const uint32_t a = heads[s], b = (s + 1 < nheads) ? heads[s + 1] : nhsps, n = b - a;
-        if (n > MC_FH_MIN) {
-            uint32_t any = 0;
-            for (uint32_t k = a; k < b; k++) any |= mark[k];
-            if (!any) { nrow_of[s] = 0; best_of[s].family = -1; } else want = true;
-        }
+        uint32_t any = 0;
+        for (uint32_t k = a; k < b; k++) any |= mark[k];
+        if (!any) { nrow_of[s] = 0; best_of[s].family = -1; }
+        else cls = n > MC_FH_MIN ? 4 : MC_LIGHT_CLASS(n);
     }
-    const uint32_t o = mc_block_alloc(&counters[C_HEAVY], want);
-    if (want) heavy[o] = s;
+    const uint32_t o = mc_block_alloc(&counters[C_HEAVY], cls == 4);
+    if (cls == 4) heavy[o] = s;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t oc = mc_block_alloc(&counters[C_LIGHT0 + c], cls == c);
+        if (cls == c) light[(size_t)c * light_pitch + oc] = s;
+    }
 }
 
 // One thread per read that has HSPs, in ascending read order.  All scratch is addressed by the read's offset into the
@@ -1113,20 +1120,15 @@ __global__ void __launch_bounds__(256) k_heavy_lists(const uint32_t *__restrict_
 // stay in that scratch; k_emit_rows moves them to their final place once the row counts have been scanned.
 __global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
                                                 const McHsp *__restrict__ sorted, uint32_t nhsps, const uint32_t *__restrict__ heads, uint32_t nheads,
-                                                const uint8_t *__restrict__ mark, McHsp *v, McHsp *tmp, int64_t first_read_id, uint32_t *nrow_of, McBestHit *best,
-                                                uint32_t *counters)
+                                                McHsp *v, McHsp *tmp, int64_t first_read_id, uint32_t *nrow_of, McBestHit *best,
+                                                const uint32_t *__restrict__ list, const uint32_t *__restrict__ nlist_p)
 {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nheads) return;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= *nlist_p) return;                                  // (the reads of one size class that have something to print: k_heavy_lists)
+    const uint32_t s = list[idx];
     const uint32_t a = heads[s];
     const uint32_t b = (s + 1 < nheads) ? heads[s + 1] : nhsps;
     const int n = (int)(b - a);
-    {   // nine reads in ten have nothing to print: their marks (contiguous, a byte per HSP) say so
-        uint32_t any = 0;
-        for (uint32_t k = a; k < b; k++) any |= mark[k];
-        if (!any) { nrow_of[s] = 0; best[s].family = -1; return; }
-    }
-    if (n > MC_FH_MIN) return;                                    // k_heavy_lists handed this read to a wave (k_finish_heavy)
     const uint32_t read = sorted[a].read;
     McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
     double *myk = (double *)(myrows + n);
@@ -1885,7 +1887,9 @@ static int stage_d(mc_handle *h, McCtx &c)
         // the thread-per-read kernel (reads with few HSPs) on this stream, the wave-per-read kernels one after the other on a
         // second one (each hands the reads its LDS arrays cannot hold to the next)
         uint32_t *d_heavy = c.d_retry, *d_heavy2 = c.d_retry + c.cap_gaps / 2, *d_heavy3 = c.d_retry + c.cap_gaps;      // (d_retry is free again: the gap tasks are done)
-        k_heavy_lists<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(c.d_heads, nheads, nh, c.d_mark, c.d_nrow, c.d_bestof, c.d_counters, d_heavy);
+        uint32_t *d_light = c.d_retry + c.cap_gaps + c.cap_gaps / 2;
+        const uint32_t light_pitch = (uint32_t)c.cap_reads + 1;
+        k_heavy_lists<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(c.d_heads, nheads, nh, c.d_mark, c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_light, light_pitch);
         HIPCK(hipEventRecord(c.ev_fork, st));
         {
             const size_t l1 = (size_t)MC_FH_N1 * 16 + 3 * (size_t)(MC_FH_N1 + 2) * 2, l2 = (size_t)MC_FH_N2 * 16 + 3 * (size_t)(MC_FH_N2 + 2) * 2, l3 = (size_t)MC_FH_N3 * 16 + 3 * (size_t)(MC_FH_N3 + 2) * 2;
@@ -1899,8 +1903,9 @@ static int stage_d(mc_handle *h, McCtx &c)
                                                                                          c.d_nrow, c.d_bestof, c.d_counters, d_heavy3, nullptr);
             HIPCK(hipEventRecord(c.ev_join, c.side));
         }
-        k_finish<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, c.d_sorted, nh, c.d_heads, nheads, c.d_mark, c.d_v, c.d_tmp,
-                                                                    c.first_read_id, c.d_nrow, c.d_bestof, c.d_counters);
+        for (int cl = 3; cl >= 0; cl--)                           // the light reads, class by class (largest first; the counts stay on the device)
+            k_finish<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, c.d_sorted, nh, c.d_heads, nheads, c.d_v, c.d_tmp,
+                                                                        c.first_read_id, c.d_nrow, c.d_bestof, d_light + (size_t)cl * light_pitch, c.d_counters + C_LIGHT0 + cl);
         HIPCK(hipStreamWaitEvent(st, c.ev_join, 0));
         size_t bytes = c.sorttmp_bytes;
         HIPCK(rocprim::exclusive_scan(c.d_sorttmp, bytes, c.d_nrow, c.d_rowoff, 0u, (size_t)nheads, rocprim::plus<uint32_t>(), st));
