@@ -247,9 +247,14 @@ __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restric
     uint8_t *rows = (uint8_t *)(lnf + nlnf);
     if (tid < 64) fxs[tid] = T->seg_dout[tid];                   // seg_dout, seg_din, seg_tlo, seg_thi are contiguous
     for (int i = tid; i < nlnf; i += 256) lnf[i] = T->lnfac[i];
-    {   // coalesced staging of this block's reads (the block's slice starts at r0*L, not necessarily 16-byte aligned)
+    {   // coalesced staging of this block's reads: 4 bytes per lane where the slice allows it (it starts at r0*L: any alignment)
         const uint8_t *src = reads + r0 * L;
-        for (int i = tid; i < rbytes; i += 256) sreads[i] = src[i];
+        const int head = (int)((4 - ((uintptr_t)src & 3)) & 3), nhead = head < rbytes ? head : rbytes;
+        if (tid < nhead) sreads[tid] = src[tid];
+        const int nw = (rbytes - nhead) >> 2;
+        if (nhead == 0) for (int i = tid; i < nw; i += 256) ((uint32_t *)sreads)[i] = ((const uint32_t *)src)[i];
+        else for (int i = tid; i < nw; i += 256) { const uint32_t w = ((const uint32_t *)(src + nhead))[i]; uint8_t *d = sreads + nhead + 4 * i; d[0] = (uint8_t)w; d[1] = (uint8_t)(w >> 8); d[2] = (uint8_t)(w >> 16); d[3] = (uint8_t)(w >> 24); }
+        for (int i = nhead + 4 * nw + tid; i < rbytes; i += 256) sreads[i] = src[i];
     }
     __syncthreads();
     const int lr = tid / 6, f = tid - lr * 6;
@@ -264,9 +269,9 @@ __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restric
     }
     __syncthreads();
     {   // frames of the block are contiguous in global memory: nr*6 rows of FP bytes
-        uint8_t *dst = frames + r0 * 6 * FP;
-        const int total = nr * 6 * FP;
-        for (int i = tid; i < total; i += 256) { int row = i / FP, col = i - row * FP; dst[i] = rows[(size_t)row * stride + col]; }
+        uint32_t *dst = (uint32_t *)(frames + r0 * 6 * FP);          // (FP and the LDS row pitch are multiples of 4: a word never straddles two rows)
+        const int total = nr * 6 * FP / 4, fpw = FP / 4;
+        for (int i = tid; i < total; i += 256) { const int row = i / fpw, col = i - row * fpw; dst[i] = *(const uint32_t *)(rows + (size_t)row * stride + 4 * col); }
     }
 }
 
@@ -2019,7 +2024,7 @@ struct McBatchSlot { uint8_t *pin = nullptr, *dev = nullptr; int64_t n = 0, firs
 
 // fetch(dst, max, &first) copies the next batch of at most `max` reads into dst, stores the index of its first read and returns
 // how many there were (0: the source has ended; < 0: its error).
-static int run_stream(mc_handle *h, const std::function<int64_t(uint8_t *, int64_t, int64_t *)> &fetch, int64_t first_read_id)
+static int run_stream(mc_handle *h, const std::function<int64_t(uint8_t *, int64_t, int64_t *)> &fetch, int64_t first_read_id, int64_t expect_reads = 0)
 {
     HIPCK(hipSetDevice(h->device));
     const int64_t BMAX = MC_STREAM_BATCH, B = stream_batch(), L = h->read_len;
@@ -2057,6 +2062,7 @@ static int run_stream(mc_handle *h, const std::function<int64_t(uint8_t *, int64
         }
     });
     std::vector<mc_row> &all_rows = h->all_rows; all_rows.clear();
+    if (h->keep_rows && expect_reads > 0) all_rows.reserve((size_t)expect_reads * 2 + 1024);   // (shotgun reads of real genomes: 1.9 rows per read; untouched pages cost nothing)
     std::vector<mc_best_hit> all_best; mc_stats tot; memset(&tot, 0, sizeof tot);
     int rc = 0;
     const uint8_t *saved_reads = h->reads_dev; const int64_t saved_n = h->nreads;
@@ -2101,7 +2107,7 @@ extern "C" int mc_search(mc_handle *h, const uint8_t *reads, int64_t nreads, int
         if (n > 0) memcpy(dst, reads + at * L, (size_t)(n * L));
         *first = at; at += n;
         return n;
-    }, first_read_id);
+    }, first_read_id, nreads);
 }
 
 // process_seqfile + search_seqs + classify_reads over n_dev GPUs of this process (the library-owned form of the

@@ -251,3 +251,40 @@ def test_training_grid_on_device_rows():
         assert gh[k] == w[0] and ga[k] == w[1], k
         assert abs(gc[k] - w[2]) <= 1e-12 * w[2], k
     assert int((gh > 0).sum()) == len(want)
+
+
+def test_config5_shape_at_size_native_sampler_equals_python_statement(tmp_path):
+    """BASELINE configs[4] shape at a size where the parallel reader cuts many regions and pieces: 150,000 FASTQ records of 300 bp
+    (phred+33 qualities ~ N(34, 6), 5 % with one base below 20, 2 % exact and 1 % reverse-complement duplicates) with -q 20 -d.
+    run_pipeline's fused path (native sampler beside the search) against the Python statement of process_seqfile feeding the same
+    search stage by stage: same sample size, same AGS."""
+    from microbecensus_amd import synth
+    gen = synth.GenomeReads(device="cpu", seed=11)
+    n, L = 150_000, 300
+    r = gen.single(n, L).numpy()
+    rng = np.random.RandomState(3)
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    qual = (np.clip(np.rint(rng.normal(34, 6, size=(n, L))), 20, 41).astype(np.uint8) + 33)
+    low = rng.rand(n) < 0.05
+    qual[low, rng.randint(0, L, size=int(low.sum()))] = 33 + 10
+    u = rng.rand(n)
+    recs, pool = [], []
+    for i in range(n):
+        sq = bytes(r[i])
+        if b"Y" in sq or b"S" in sq:                              # (the genomes hold two IUPAC letters; reverse_complement knows ACGTN only)
+            sq = sq.replace(b"Y", b"N").replace(b"S", b"N")
+        if pool and u[i] < 0.02:
+            sq = pool[rng.randint(len(pool))]
+        elif pool and u[i] < 0.03:
+            sq = pool[rng.randint(len(pool))][::-1].translate(comp)
+        elif len(pool) < 5000:
+            pool.append(sq)
+        recs.append(b"@s%d\n%s\n+\n%s\n" % (i, sq, bytes(qual[i])))
+    fq = tmp_path / "c5.fq"
+    fq.write_bytes(b"".join(recs))
+    base = {"seqfiles": [str(fq)], "min_quality": 20, "filter_dups": True, "nreads": 10_000_000}
+    est, args = mc.run_pipeline(dict(base))
+    est_py, args_py = mc.run_pipeline(dict(base, python_reader=True, keep_tmp=True))
+    assert args["read_length"] == 300 and args["sampled_reads"] == args_py["sampled_reads"]
+    assert 0.90 * n < args["sampled_reads"] < 0.94 * n           # ~5 % low quality, ~3 % duplicates
+    assert est == est_py
