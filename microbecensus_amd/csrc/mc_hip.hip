@@ -364,6 +364,7 @@ __global__ void __launch_bounds__(256) k_enumerate(const McTables *__restrict__ 
 #define MC_EN_QCAP 128
 #define MC_EN_NCHUNK(L) ((((L) / 3 - 6) + 63) / 64 > 0 ? (((L) / 3 - 6) + 63) / 64 : 1)
 #define MC_EN_BLK 2048u                     // task slots a wave reserves at a time (one global atomic per block, not per append)
+#define MC_EN_SHORT 4                      // seed-hit ranges up to this long are written by the lane that found them
 #define MC_TASK_NONE 0xFFFFFFFFu            // read id of the padding entries that close a partly used block
 struct McEnWave {
     uint32_t setter[6][6]; uint32_t hit[6][6]; uint32_t blk_base, blk_used;
@@ -387,12 +388,11 @@ __device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long
     if (m == 0) return 0;
     const int pos = (int)((item >> 36) & 0xFF), frame = (int)((item >> 44) & 7), phase = (int)((item >> 47) & 63);
     if (phase == 0 && cnt > 0) atomicOr(&W->hit[frame][pos >> 5], 1u << (pos & 31));
-    // total over the (few) lanes that found something
-    uint32_t total = 0;
-    while (m) {
-        total += (uint32_t)__builtin_amdgcn_readlane(cnt, __builtin_ctzll(m));
-        m &= m - 1;
-    }
+    // slot of every lane's range: prefix sum of the counts over the lanes
+    uint32_t incl = (uint32_t)cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += y; }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), excl = incl - (uint32_t)cnt;
     uint32_t base;
     if (total > MC_EN_BLK) {                     // rare: a long range, reserved directly
         base = 0;
@@ -414,14 +414,26 @@ __device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long
         if (lane == 0) { W->blk_base = bb; W->blk_used = bu + total; }
         mc_wave_sync();
     }
-    // the ranges are written by the whole wave, one range after the other: a conserved 10-mer occurs in hundreds of
-    // homologous markers, and a lane that wrote its own range alone would keep the other 63 waiting
+    // Short ranges (most: a 10-mer of an unrelated read matches one or two markers) are written by their own lanes, all at once.
+    // Long ones are written by the whole wave, one range after the other: a conserved 10-mer occurs in hundreds of homologous
+    // markers, and a lane that wrote such a range alone would keep the other 63 waiting.
+    if (cnt > 0 && cnt <= MC_EN_SHORT) {
+        const uint32_t sn = phase == 0 ? (9u | (3u << 8)) : (10u | (4u << 8));
+#pragma unroll
+        for (int i = 0; i < MC_EN_SHORT; i++)
+            if (i < cnt) {
+                McSeedTask t;
+                t.read = read; t.chrono = MC_CHRONO(frame, pos, phase, (uint32_t)nst + (uint32_t)i); t.posting = X.post[start + (uint32_t)nst + (uint32_t)i];
+                t.seedlen_nkey = sn;
+                tasks[base + excl + (uint32_t)i] = t;
+            }
+    }
     {
-        unsigned long long mm = __ballot(cnt > 0);
-        uint32_t run = 0;
+        unsigned long long mm = __ballot(cnt > MC_EN_SHORT);
         while (mm) {
             const int l = __builtin_ctzll(mm);
             mm &= mm - 1;
+            const uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)excl, l);
             const uint32_t c = (uint32_t)__builtin_amdgcn_readlane(cnt, l);
             const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)item, l), hi32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(item >> 32), l);
             const unsigned long long it = ((unsigned long long)hi32 << 32) | lo32;
@@ -434,7 +446,6 @@ __device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long
                 t.seedlen_nkey = sn;
                 tasks[base + run + i] = t;
             }
-            run += c;
         }
     }
     return (uint32_t)cnt;
