@@ -91,6 +91,26 @@ def profiled_traffic(stage, n_batch):
         return None
 
 
+def profiled_l2_hit_rate(stage):
+    """TCC_HIT / (TCC_HIT + TCC_MISS) of the stage's kernels in the newest committed PMC summary (profiles/rNN_pmc_per_launch.csv)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_per_launch.csv")))
+    if not files:
+        return None
+    try:
+        hit = miss = 0.0
+        for r in csv.DictReader(open(files[-1])):
+            k = r["Kernel"]
+            if "true" in k or not r.get("TCC_HIT_sum"):
+                continue
+            if any(k == p or k.startswith(p + "<") or (p.endswith("<") and k.startswith(p)) for p in STAGE_KERNELS.get(stage, [stage])):
+                hit += float(r["TCC_HIT_sum"]); miss += float(r["TCC_MISS_sum"])
+        return round(hit / (hit + miss), 4) if hit + miss > 0 else None
+    except Exception:
+        return None
+
+
 def ags_abs_error(device):
     """The metric's second half: |AGS(GPU pipeline) - AGS(reference)| on the reference's own inputs, through run_pipeline
     (native sampler -> HIP search -> classification -> estimate).  The reference values are the committed goldens produced by
@@ -413,6 +433,7 @@ def main():
                          "physical_GBps": (None if traffic_dom is None else round(traffic_dom / (kseq[dom] * 1e-3) / 1e9, 2)),
                          "physical_frac": (None if traffic_dom is None else round(traffic_dom / (kseq[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)),
                          "kernel_ms_per_step": round(kseq[dom], 3),
+                         "l2_hit_rate": profiled_l2_hit_rate("k_enumerate_t0" if dom == "k_enumerate" else dom),
                          "achieved_in_timed_region": round(ach_timed, 2),
                          "algorithmic_bytes_per_read": round(per_launch[dom] / n_batch, 1),
                          # SURVEY.md 8(d) priced the whole path at A(150) = 207,923 B/read assuming whole-bucket visits the engine does not
