@@ -1076,8 +1076,11 @@ __global__ void k_make_keys(const McHsp *__restrict__ hsps, uint32_t n, uint64_t
     idx[tid] = tid;
 }
 // sorted order: copies the HSPs, flags the first HSP of every read, and marks the HSPs that can make their read print
-// anything: log E below the threshold, or a second HSP on the same subject (sum statistics may lower the group's E).
-// A read without a marked HSP prints no row and has no best hit - k_finish skips it after reading its marks.
+// anything: log E below the threshold, or a second, DIFFERENT HSP on the same subject (sum statistics may lower the group's E).
+// HSPs of a subject that all carry the same frame and coordinates are one HSP found from several seeds: CalRes keeps the best
+// of them (mc_finish_group's stack), a group of one, printed only if its own log E is below the threshold - so equal neighbours
+// mark nothing, and a subject whose neighbours are all equal is all equal.  A read without a marked HSP prints no row and has no
+// best hit; the finishing kernels never see it.
 __global__ void k_gather(const McHsp *__restrict__ hsps, const uint32_t *__restrict__ idx, uint32_t n, McHsp *out, uint32_t *flags, uint8_t *mark, double loge_thr)
 {
     uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1085,7 +1088,11 @@ __global__ void k_gather(const McHsp *__restrict__ hsps, const uint32_t *__restr
     McHsp h = hsps[idx[tid]];
     out[tid] = h;
     bool head = true, same_subject = false;
-    if (tid > 0) { const McHsp &p = hsps[idx[tid - 1]]; head = p.read != h.read; same_subject = !head && p.sidx == h.sidx; }
+    if (tid > 0) {
+        const McHsp &p = hsps[idx[tid - 1]];
+        head = p.read != h.read;
+        same_subject = !head && p.sidx == h.sidx && !(p.frame == h.frame && p.qaas == h.qaas && p.ds == h.ds && p.qaae == h.qaae && p.de == h.de);
+    }
     flags[tid] = head ? 1u : 0u;
     mark[tid] = (h.loge < loge_thr || same_subject) ? 1 : 0;
 }
