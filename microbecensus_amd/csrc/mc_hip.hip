@@ -1975,22 +1975,27 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
     MC_ALL(if ((rc = stage_wait(c)) == 0) rc = stage_b(h, c))
     MC_ALL(if ((rc = stage_wait(c)) == 0) rc = stage_c(h, c))
     MC_ALL(if ((rc = stage_wait(c)) == 0) rc = stage_d(h, c))
+    // E, part by part: as soon as a part's finishing is done its rows start travelling, while the next part is still finishing
     size_t nrows = 0;
     for (int p = 0; p < np && rc == 0; p++) {
         McCtx &c = h->ctx[p];
         if ((rc = stage_wait(c)) != 0) break;
         if (c.h_c[C_OVERFLOW]) { g_err = "row buffer overflow"; rc = -2; break; }
         c.nrows = c.nh ? c.h_c[C_ROWS] : 0u; c.nsegs = c.h_c[C_SEGS]; c.nbest = c.h_c[C_BEST];
+        const size_t need = nrows + c.nrows;
+        if (need > h->pin_cap) {                                     // grow the pinned row buffer (with room for the parts still to come)
+            for (int q = 0; q < p; q++) (void)hipStreamSynchronize(h->ctx[q].stream);      // (their copies write into the old buffer)
+            const size_t want = need + (size_t)(np - 1 - p) * ((size_t)c.nrows + c.nrows / 4) + need / 4 + 1024;
+            mc_row *nb = nullptr;
+            if (hipHostMalloc((void **)&nb, want * sizeof(mc_row), hipHostMallocDefault) != hipSuccess) { g_err = "out of pinned host memory for the rows"; rc = -1; break; }
+            if (nrows) memcpy(nb, h->pin_rows, nrows * sizeof(mc_row));
+            if (h->pin_rows) (void)hipHostFree(h->pin_rows);
+            h->pin_rows = nb; h->pin_cap = want;
+        }
+        rc = stage_e(h, c, nrows);
         nrows += c.nrows;
     }
     if (rc) { for (int p = 0; p < np; p++) (void)hipStreamSynchronize(h->ctx[p].stream); return rc; }
-    if (nrows > h->pin_cap) {
-        if (h->pin_rows) { (void)hipHostFree(h->pin_rows); h->pin_rows = nullptr; h->pin_cap = 0; }
-        const size_t want = nrows + nrows / 4 + 1024;
-        HIPCK(hipHostMalloc((void **)&h->pin_rows, want * sizeof(mc_row), hipHostMallocDefault));
-        h->pin_cap = want;
-    }
-    { size_t o = 0; MC_ALL(rc = stage_e(h, c, o); o += c.nrows) }
     MC_ALL(rc = stage_wait(c))
 #undef MC_ALL
     if (rc) return rc;
