@@ -59,7 +59,7 @@ enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_N = 16 };   // 64-bit algorithmic-
 // fall into different LDS banks (a pitch of 128 bytes put all of them into one)
 #define MC_TS_NLNF(FP) ((FP) + 2 > 24 ? (FP) + 2 : 24)
 #define MC_TS_STRIDE(FP) (((((FP) + 76 + 3) >> 2) | 1) << 2)
-#define MC_TS_STAGE(L) ((((MC_TS_READS * (L)) > 4 * 1416 ? (MC_TS_READS * (L)) : 4 * 1416) + 15) & ~15)   // read staging, later 4 x McSegWaveLds
+#define MC_TS_STAGE(L) ((((MC_TS_READS * (L)) > 4 * 1680 ? (MC_TS_READS * (L)) : 4 * 1680) + 15) & ~15)   // read staging, later 4 x McSegWaveLds
 
 __device__ __forceinline__ int mc_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 // orders the wave's own LDS traffic for the compiler; the hardware executes one wave's LDS instructions in order
@@ -74,9 +74,9 @@ __device__ __forceinline__ void mc_wave_sync() { __builtin_amdgcn_fence(__ATOMIC
 // lanes (each builds its window's composition from scratch, in registers for windows <= 15 residues), and the least
 // probable window of every stretch (the first one in the reference's iteration order on a tie) is found with LDS
 // atomics.  The double arithmetic of getprob is the reference's, operation by operation.
-struct McSegWaveLds { unsigned long long best[64]; uint32_t pre[66]; uint32_t bq[64]; uint32_t off[64]; uint16_t n[64]; };   // 1,416 B per wave
+struct McSegWaveLds { unsigned long long best[64]; uint32_t pre[66]; uint32_t pre2[66]; uint32_t bq[64]; uint32_t off[64]; uint16_t n[64]; };   // 1,680 B per wave
 static_assert(sizeof(McHsp) == 48 && sizeof(McGapTask) % 4 == 0, "k_eval_seeds copies its staging buffers as 16- and 4-byte words");
-static_assert(sizeof(McSegWaveLds) == 1416, "MC_TS_STAGE reserves 4 x 1416 bytes");
+static_assert(sizeof(McSegWaveLds) == 1680, "MC_TS_STAGE reserves 4 x 1680 bytes");
 #define MC_SEG_KEY_ONE 0xBFF0000000000000ull   // order-preserving key of 1.0 (the initial minprob of Seg::trim)
 
 __device__ __forceinline__ unsigned long long mc_seg_key(double x)
@@ -133,42 +133,49 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
             WL->best[myr] = MC_SEG_KEY_ONE; WL->bq[myr] = 0xFFFFFFFFu;
         }
         mc_wave_sync();
+        // One work item = up to 8 consecutive windows of one LENGTH of one stretch (Seg::trim: len = nn - j has j + 1 windows,
+        // j = 0 .. nn - minlen - 1): the lane builds the composition of its first window and slides it (one residue out, one in),
+        // keeping the first least probable window; bounded items keep the 64 lanes of a round in step, and the best of a stretch is
+        // then found with two LDS atomics per item.  Items of a stretch are numbered by (j, run): j = 8 A + B has A + 1 runs,
+        // C(j) = 4 A (A + 1) + B (A + 1) items lie in front of it.  Windows of up to 15 residues are evaluated in registers, longer
+        // ones on the lane's LDS row (several times slower): the two kinds go in SEPARATE rounds - class 0: lengths <= 15
+        // (j >= nn - 15), class 1: the others - so that a round of register items does not wait for one LDS item.
+#define MC_SEG_CJ(j) (4 * ((j) >> 3) * (((j) >> 3) + 1) + ((j) & 7) * (((j) >> 3) + 1))
         if (lane == 0) {
-            uint32_t run = 0;
-            WL->pre[0] = 0;
+            uint32_t run0 = 0, run1 = 0;
+            WL->pre[0] = 0; WL->pre2[0] = 0;
             for (int r = 0; r < nreq; r++) {
-                const int nn = WL->n[r], minlen = (nn - 100 > 1) ? nn - 100 : 1, K = nn - minlen, A = K >> 3, B = K & 7;
-                run += (uint32_t)(4 * A * (A + 1) + B * (A + 1));          // sum over j < K of ceil((j + 1) / 8)
-                WL->pre[r + 1] = run;
+                const int nn = WL->n[r], minlen = (nn - 100 > 1) ? nn - 100 : 1, K = nn - minlen, j0 = nn - 15 > 0 ? (nn - 15 < K ? nn - 15 : K) : 0;
+                run1 += (uint32_t)MC_SEG_CJ(j0);                          // lengths > 15: j < j0
+                run0 += (uint32_t)(MC_SEG_CJ(K) - MC_SEG_CJ(j0));          // lengths <= 15
+                WL->pre[r + 1] = run0; WL->pre2[r + 1] = run1;
             }
         }
         mc_wave_sync();
-        // One work item = up to MC_SEG_RUN = 8 consecutive windows of one LENGTH of one stretch (Seg::trim: len = nn - j has j + 1
-        // windows, j = 0 .. nn - minlen - 1): the lane builds the composition of its first window and slides it (one residue out,
-        // one in), keeping the first least probable window; bounded items keep the 64 lanes of a round in step, and the best of a
-        // stretch is then found with two LDS atomics per item.  Items of a stretch are numbered by (j, run): j = 8 A + B has A + 1
-        // runs, 4 A (A + 1) + B (A + 1) items lie in front of it.
-        const uint32_t total = WL->pre[nreq];
+        for (int cls = 0; cls < 2; cls++) {
+        const uint32_t *pre = cls ? WL->pre2 : WL->pre;
+        const uint32_t total = pre[nreq];
         for (uint32_t p0 = 0; p0 < total; p0 += 64) {
             const uint32_t p = p0 + (uint32_t)lane;
             const bool ok = p < total;
             int r = 0;
-            for (int stp = 32; stp > 0; stp >>= 1) { const int k = r + stp; if (k < nreq && p >= WL->pre[k]) r = k; }   // the stretch item p belongs to: last r with pre[r] <= p
+            for (int stp = 32; stp > 0; stp >>= 1) { const int k = r + stp; if (k < nreq && p >= pre[k]) r = k; }   // the stretch item p belongs to: last r with pre[r] <= p
             if (!ok) r = 0;
-            const int x = (int)(p - WL->pre[r]);
+            const int nn = WL->n[r];
+            int x = (int)(p - pre[r]);
+            if (cls == 0) { const int minlen = (nn - 100 > 1) ? nn - 100 : 1, K = nn - minlen, j0 = nn - 15 > 0 ? (nn - 15 < K ? nn - 15 : K) : 0; x += MC_SEG_CJ(j0); }
             int A = (int)((sqrtf((float)(x + 1)) - 1.0f) * 0.5f);
             while (4 * (A + 1) * (A + 2) <= x) A++;
             while (4 * A * (A + 1) > x) A--;
             const int rem = x - 4 * A * (A + 1), B = rem / (A + 1), run = rem - B * (A + 1);
             const int j = 8 * A + B, wfirst = 8 * run, wlast = (wfirst + 7 < j) ? wfirst + 7 : j;
-            const int nn = WL->n[r];
             const uint8_t *s = lds0 + WL->off[r];
             const int len = nn - j;
             const uint32_t qbase = (uint32_t)(j * (j + 1) / 2);          // number of window 0 of this length in Seg::trim's order
             unsigned long long key = MC_SEG_KEY_ONE;                     // (minprob starts at 1.0: only a smaller probability counts)
             uint32_t kq = 0xFFFFFFFFu;
             if (ok) {
-                if (len <= 15) {
+                if (cls == 0) {
                     McRgState rg; rg.clo = 0; rg.chi = 0; rg.sv = 0;
                     for (int k = 0; k < len; k++) mc_rg_add(rg, s[wfirst + k]);
                     uint64_t lastsv = ~0ull; unsigned long long lastkey = 0;
@@ -200,6 +207,8 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
             if (cand && key == nb) atomicMin(&WL->bq[r], kq);
             mc_wave_sync();
         }
+        }
+#undef MC_SEG_CJ
         // ---- the owners take their results and go on
         if (st == WAIT) {
             const uint32_t q = WL->bq[myr];
