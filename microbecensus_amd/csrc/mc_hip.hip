@@ -59,7 +59,7 @@ enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_N = 16 };   // 64-bit algorithmic-
 // fall into different LDS banks (a pitch of 128 bytes put all of them into one)
 #define MC_TS_NLNF(FP) ((FP) + 2 > 24 ? (FP) + 2 : 24)
 #define MC_TS_STRIDE(FP) (((((FP) + 76 + 3) >> 2) | 1) << 2)
-#define MC_TS_STAGE(L) ((((MC_TS_READS * (L)) > 4 * 1680 ? (MC_TS_READS * (L)) : 4 * 1680) + 15) & ~15)   // read staging, later 4 x McSegWaveLds
+#define MC_TS_STAGE(L) ((((MC_TS_READS * (L)) > 4 * 1488 ? (MC_TS_READS * (L)) : 4 * 1488) + 15) & ~15)   // read staging, later 4 x McSegWaveLds
 
 __device__ __forceinline__ int mc_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 // orders the wave's own LDS traffic for the compiler; the hardware executes one wave's LDS instructions in order
@@ -74,9 +74,9 @@ __device__ __forceinline__ void mc_wave_sync() { __builtin_amdgcn_fence(__ATOMIC
 // lanes (each builds its window's composition from scratch, in registers for windows <= 15 residues), and the least
 // probable window of every stretch (the first one in the reference's iteration order on a tie) is found with LDS
 // atomics.  The double arithmetic of getprob is the reference's, operation by operation.
-struct McSegWaveLds { unsigned long long best[64]; uint32_t pre[66]; uint32_t pre2[66]; uint32_t bq[64]; uint32_t off[64]; uint16_t n[64]; };   // 1,680 B per wave
+struct McSegWaveLds { unsigned long long best[64]; uint32_t pre[66]; uint32_t pre2[66]; uint32_t bq[64]; uint16_t off[64]; uint8_t n[64]; };   // 1,488 B per wave (four of them must fit under the 42 staged reads: 4 workgroups per CU at 150 bp)
 static_assert(sizeof(McHsp) == 48 && sizeof(McGapTask) % 4 == 0, "k_eval_seeds copies its staging buffers as 16- and 4-byte words");
-static_assert(sizeof(McSegWaveLds) == 1680, "MC_TS_STAGE reserves 4 x 1680 bytes");
+static_assert(sizeof(McSegWaveLds) == 1488, "MC_TS_STAGE reserves 4 x 1488 bytes");
 #define MC_SEG_KEY_ONE 0xBFF0000000000000ull   // order-preserving key of 1.0 (the initial minprob of Seg::trim)
 
 __device__ __forceinline__ unsigned long long mc_seg_key(double x)
@@ -128,8 +128,8 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
         const int myr = __popcll(req & ltmask);
         const int myn = hii - loi + 1;
         if (st == WAIT) {
-            WL->off[myr] = (uint32_t)((prot + base + loi) - lds0);
-            WL->n[myr] = (uint16_t)myn;
+            WL->off[myr] = (uint16_t)((prot + base + loi) - lds0);
+            WL->n[myr] = (uint8_t)myn;
             WL->best[myr] = MC_SEG_KEY_ONE; WL->bq[myr] = 0xFFFFFFFFu;
         }
         mc_wave_sync();
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restric
     __syncthreads();                                             // the staged reads are dead: their space becomes the SEG queues
     {
         McSegWS ws; ws.comp = prot + FP; ws.sv = prot + FP + 20; ws.stk = (int16_t *)(prot + FP + 44);
-        mc_seg_wave(lnf, fxs, prot, n, lr < nr, ws, (McSegWaveLds *)smem + (tid >> 6), smem, mc_lane());
+        mc_seg_wave(lnf, fxs, prot, n, lr < nr, ws, (McSegWaveLds *)smem + (tid >> 6), rows, mc_lane());   // (stretch offsets are kept relative to the rows: 256 x 252 bytes at most, 16 bits)
         if (lr < nr) for (int i = n; i < FP; i++) prot[i] = MC_INV;
     }
     __syncthreads();
