@@ -240,7 +240,8 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
 // into LDS with coalesced loads, every thread translates its frame into its own LDS row, the four waves run SEG on their
 // 64 frames each (mc_seg_wave) and the block writes the frames back with coalesced stores.  LDS per block:
 // max(42*L, 4 x 1,416) + ln n! + 256*(FP+76) bytes (~40 KB at 150 bp; the staging area is reused by the SEG queues).
-__global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restrict__ T, const uint8_t *__restrict__ reads, int L,
+template <bool STAGED>                                           // STAGED: the block's reads go through LDS (coalesced); otherwise each thread
+__global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restrict__ T, const uint8_t *__restrict__ reads, int L,   // walks its read in global memory and the LDS it saves buys a workgroup per CU (long reads)
                                                        int64_t nreads, uint8_t *__restrict__ frames, int FP)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -252,11 +253,11 @@ __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restric
     __shared__ int32_t fxs[64];                                  // fixed-point entropy tables (mc_seg_mask_fx)
     uint8_t *sreads = smem;
     const int nlnf = MC_TS_NLNF(FP);
-    double *lnf = (double *)(smem + MC_TS_STAGE(L));             // ln n! for n <= max(frame length, 20): all the trimming asks for
+    double *lnf = (double *)(smem + (STAGED ? MC_TS_STAGE(L) : MC_TS_STAGE(0)));   // ln n! for n <= max(frame length, 20): all the trimming asks for
     uint8_t *rows = (uint8_t *)(lnf + nlnf);
     if (tid < 64) fxs[tid] = T->seg_dout[tid];                   // seg_dout, seg_din, seg_tlo, seg_thi are contiguous
     for (int i = tid; i < nlnf; i += 256) lnf[i] = T->lnfac[i];
-    {   // coalesced staging of this block's reads: 4 bytes per lane where the slice allows it (it starts at r0*L: any alignment)
+    if (STAGED) {   // coalesced staging of this block's reads: 4 bytes per lane where the slice allows it (it starts at r0*L: any alignment)
         const uint8_t *src = reads + r0 * L;
         const int head = (int)((4 - ((uintptr_t)src & 3)) & 3), nhead = head < rbytes ? head : rbytes;
         if (tid < nhead) sreads[tid] = src[tid];
@@ -269,7 +270,7 @@ __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restric
     const int lr = tid / 6, f = tid - lr * 6;
     uint8_t *prot = rows + (size_t)tid * stride;
     int n = 0;
-    if (lr < nr) n = mc_translate_frame(*T, sreads + lr * L, L, f, prot);
+    if (lr < nr) n = STAGED ? mc_translate_frame(*T, sreads + lr * L, L, f, prot) : mc_translate_frame(*T, reads + (r0 + lr) * L, L, f, prot);
     __syncthreads();                                             // the staged reads are dead: their space becomes the SEG queues
     {
         McSegWS ws; ws.comp = prot + FP; ws.sv = prot + FP + 20; ws.stk = (int16_t *)(prot + FP + 44);
@@ -1817,9 +1818,19 @@ static int stage_a(mc_handle *h, McCtx &c)
     HIPCK(hipMemsetAsync(c.d_stats, 0, sizeof(unsigned long long) * S_N, st));
     HIPCK(hipEventRecord(c.ev[0], st));
     const int64_t threads = n * 6;
-    size_t lds = (size_t)MC_TS_STAGE(L) + (size_t)MC_TS_NLNF(FP) * 8 + (size_t)256 * MC_TS_STRIDE(FP);
-    if (lds > 48 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_translate_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_translate_seg<<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(256), lds, st>>>(h->d_T, c.reads, L, n, c.d_frames, FP);
+    const size_t lds_rest = (size_t)MC_TS_NLNF(FP) * 8 + (size_t)256 * MC_TS_STRIDE(FP);
+    const size_t lds_staged = (size_t)MC_TS_STAGE(L) + lds_rest, lds_direct = (size_t)MC_TS_STAGE(0) + lds_rest;
+    static const int ts_force = getenv("MC_TS_STAGED") ? atoi(getenv("MC_TS_STAGED")) : -1;
+    const size_t cu_lds = 160 * 1024 - 1024;                      // (static LDS of the kernel and allocation granules)
+    const bool staged = ts_force >= 0 ? ts_force != 0 : cu_lds / lds_staged >= cu_lds / lds_direct;   // staging stays while it does not cost a resident workgroup
+    const size_t lds = staged ? lds_staged : lds_direct;
+    if (staged) {
+        if (lds > 48 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_translate_seg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_translate_seg<true><<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(256), lds, st>>>(h->d_T, c.reads, L, n, c.d_frames, FP);
+    } else {
+        if (lds > 48 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_translate_seg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_translate_seg<false><<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(256), lds, st>>>(h->d_T, c.reads, L, n, c.d_frames, FP);
+    }
     HIPCK(hipEventRecord(c.ev[1], st));
     if (h->fast_enum) {
         const int FPs = (FP + 15) & ~15;
