@@ -80,6 +80,7 @@ struct McIndex {
     const uint16_t *keys;      // 4 reduced residues after the 6-mer, 0xF past the sequence end
     const struct McBucketRec *rec;   // per bucket: start + first-residue group boundaries (NULL when the index cannot use them)
     const uint32_t *wild;      // MC_WILD_LINES x 16 words: wildcard filter (mc_wild_*)
+    const uint32_t *pair;      // MC_PAIR_BLOCKS x 4 words: which residues at a wildcard offset complete an index 10-mer (mc_pair_*)
     const unsigned long long *rt; uint32_t rt_mask;   // range table of the long groups (mc_rt_*): rt_mask + 1 slots
     const uint32_t *filt;      // MC_FILT_TOTAL_WORDS words: Bloom filters over the (bucket, key) pairs of the index (10-mers, then 9-mers)
     int32_t nseq;
@@ -837,6 +838,44 @@ MC_HD bool mc_wild_test4(uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_
     return (((s1 >> (p1 & 63)) & (s2 >> (p2 & 63))) & 1ull) != 0;
 }
 MC_HD bool mc_wild_test(const uint32_t q[4], uint32_t bits) { return mc_wild_test4(q[0], q[1], q[2], q[3], bits); }
+
+// ---- pair filter: the ten probes of a (position, wildcard offset) pair in ONE 16-byte read ------------------------------
+// A pair that passed the wildcard filter used to ask the 10-mer Bloom filter once per substituted residue: nine scattered
+// words, nine L2 requests - and the seed kernel is bound by the requests its CU can keep in flight.  Here the nine known
+// residues and the offset pick a 128-bit block; the block holds ten 12-bit cells, one per residue value at the wildcard
+// offset, and the context picks two of the twelve bits (the same two in every cell).  An index 10-mer sets its two bits
+// in the cell of its own residue, once per offset; a query reads the block and gets the mask of residues that may complete
+// an index 10-mer with a handful of 64-bit operations.  No false negatives; false positives go through the exact search.
+#define MC_PAIR_LOG2B 19
+#define MC_PAIR_BLOCKS (1u << MC_PAIR_LOG2B)
+// group g: 0 = offset 4 (bucket digit of stride 10), 1 = offset 5 (stride 1), 2 = offset 3 (stride 100), 3 = offset 6 (first key residue)
+MC_HD uint32_t mc_pair_digit(uint32_t seed, uint32_t key, int g) { return g == 0 ? (seed / 10u) % 10u : g == 1 ? seed % 10u : g == 2 ? (seed / 100u) % 10u : key >> 12; }
+MC_HD uint32_t mc_pair_hash(uint32_t seed, uint32_t key, int g)
+{ // hash of the 10-mer with the residue at the wildcard offset taken out
+    const uint32_t d = mc_pair_digit(seed, key, g), st = g == 0 ? 10u : g == 1 ? 1u : g == 2 ? 100u : 0u;
+    const uint32_t s0 = seed - d * st, k0 = g == 3 ? (key & 0x0FFFu) : key;
+    uint32_t x = s0 * 0x9E3779B1u + k0 * 0x85EBCA77u + (uint32_t)(g + 1) * 0x51ED270Bu;
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13; x *= 0x297A2D39u; x ^= x >> 16;
+    return x;
+}
+MC_HD uint32_t mc_pair_block(uint32_t h) { return h >> (32 - MC_PAIR_LOG2B); }
+MC_HD uint32_t mc_pair_bit_a(uint32_t h) { return ((h & 0xFFu) * 12u) >> 8; }
+MC_HD uint32_t mc_pair_bit_b(uint32_t h) { return (((h >> 8) & 0xFFu) * 12u) >> 8; }
+MC_HD void mc_pair_set(uint32_t q[4], uint32_t h, uint32_t j)
+{ // cells 0..4 in words 0,1 (bit 12 j), cells 5..9 in words 2,3
+    if (j > 9) return;
+    const uint32_t base = (j < 5 ? 0u : 64u) + 12u * (j < 5 ? j : j - 5u), pa = base + mc_pair_bit_a(h), pb = base + mc_pair_bit_b(h);
+    q[pa >> 5] |= 1u << (pa & 31); q[pb >> 5] |= 1u << (pb & 31);
+}
+MC_HD uint32_t mc_pair_test4(uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t h)
+{ // bit j of the result: residue j at the wildcard offset may complete an index 10-mer
+    const uint32_t a = mc_pair_bit_a(h), b = mc_pair_bit_b(h);
+    const unsigned long long lo = (unsigned long long)x | ((unsigned long long)y << 32), hi = (unsigned long long)z | ((unsigned long long)w << 32);
+    const unsigned long long ml = (lo >> a) & (lo >> b), mh = (hi >> a) & (hi >> b);
+    uint32_t r = 0;
+    for (int j = 0; j < 5; j++) r |= ((uint32_t)(ml >> (12 * j)) & 1u) << j | ((uint32_t)(mh >> (12 * j)) & 1u) << (j + 5);
+    return r;
+}
 
 // ---- range table: the answer for probes into long groups -----------------------------------------------------------
 // A probe whose first-residue group holds more than 8 keys needs the reference's two binary searches: ~20 dependent

@@ -465,7 +465,11 @@ __device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long
 // bits 0..7 (uniform): the new fill of the heavy queue.
 template <bool COUNT>
 __device__ __forceinline__ unsigned long long mc_en_process(const McIndex &X, unsigned long long item, bool active, uint32_t read, McEnWave *W, int hn,
-                                                         McSeedTask *tasks, uint32_t cap, uint32_t *counters, int lane)
+                                                         McSeedTask *tasks, uint32_t cap, uint32_t *counters, int lane
+#ifdef MC_EXP_TIMING
+                                                         , unsigned long long *tl_, int *tc_
+#endif
+                                                         )
 {
     int cnt = 0, lb = 0;
     uint32_t start = 0, kp = 0;
@@ -494,6 +498,9 @@ __device__ __forceinline__ unsigned long long mc_en_process(const McIndex &X, un
         hn += __popcll(hm);
         mc_wave_sync();
     }
+#ifdef MC_EXP_TIMING
+    { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane == 0) { W->tacc[2] += now_ - *tl_; W->tcnt[2]++; } *tl_ = now_; *tc_ = 1; }
+#endif
     const uint32_t nt = mc_en_append(X, item, cnt, c0 + lb, start, read, W, tasks, cap, counters, lane);
     return ((unsigned long long)kp << 32) | ((unsigned long long)nt << 8) | (unsigned long long)hn;
 }
@@ -625,25 +632,34 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                     MC_TICK(2);
                     const int take = qn < 64 ? qn : 64;
                     qn -= take;
-                    const unsigned long long ret = mc_en_process<COUNT>(X, (lane < take) ? W->q[qn + lane] : 0ull, lane < take, (uint32_t)r, W, hn, tasks, cap, counters, lane);
+                    const unsigned long long ret = mc_en_process<COUNT>(X, (lane < take) ? W->q[qn + lane] : 0ull, lane < take, (uint32_t)r, W, hn, tasks, cap, counters, lane
+#ifdef MC_EXP_TIMING
+                                                                             , &tlast, &tcat
+#endif
+                                                                             );
                     hn = __builtin_amdgcn_readfirstlane((int)(ret & 0xFF));
                     sc.keyprobes += (uint32_t)(ret >> 32); sc.tasks += (uint32_t)(ret >> 8) & 0xFFFFFFu;
                     mc_wave_sync();
                     continue;
                 }
-                if (!pmz) {                                              // queue one surviving probe per lane
+                if (!pmz) {                                              // queue the surviving probes: one per lane and turn, until q holds a full batch
                     MC_TICK(3);
-                    const unsigned long long pmm = __ballot(pm != 0);
-                    const int j = __builtin_ctz(pm | 0x400u), gc = (int)((xi >> 47) & 3);
-                    const int sd = (int)(xi & 0xFFFFF);
+                    const int gc = (int)((xi >> 47) & 3), sd = (int)(xi & 0xFFFFF);
                     const uint32_t xk = (uint32_t)((xi >> 20) & 0xFFFF);
-                    int v = sd;
-                    uint32_t k2 = xk;
-                    if (gc < 3) { const int st = gc == 0 ? 10 : gc == 1 ? 1 : 100, dd = gc == 0 ? (sd / 10) % 10 : gc == 1 ? sd % 10 : (sd / 100) % 10; v = sd + (j - dd) * st; }
-                    else k2 = (xk & 0x0FFFu) | ((uint32_t)j << 12);
-                    if (pm) W->q[qn + __popcll(pmm & lt)] = (xi & 0x00007FF000000000ull) | (unsigned long long)v | ((unsigned long long)k2 << 20) | ((unsigned long long)(1 + gc * 10 + j) << 47);
-                    qn += __popcll(pmm);
-                    pm &= pm - 1;
+                    const int st = gc == 0 ? 10 : gc == 1 ? 1 : gc == 2 ? 100 : 0;
+                    const int dd = gc == 0 ? (sd / 10) % 10 : gc == 1 ? sd % 10 : (sd / 100) % 10;
+                    const int s0 = sd - dd * st;                         // the bucket with the substituted digit taken out (gc 3: the bucket itself)
+                    const unsigned long long keep = xi & 0x00007FF000000000ull;
+                    for (;;) {
+                        const unsigned long long pmm = __ballot(pm != 0);
+                        if (pmm == 0 || qn >= 64) break;
+                        const int j = __builtin_ctz(pm | 0x400u);
+                        const int v = s0 + j * st;
+                        const uint32_t k2 = gc < 3 ? xk : ((xk & 0x0FFFu) | ((uint32_t)j << 12));
+                        if (pm) W->q[qn + __popcll(pmm & lt)] = keep | (unsigned long long)v | ((unsigned long long)k2 << 20) | ((unsigned long long)(1 + gc * 10 + j) << 47);
+                        qn += __popcll(pmm);
+                        pm &= pm - 1;
+                    }
                     mc_wave_sync();
                     continue;
                 }
@@ -655,39 +671,36 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                     xi = act ? W->eq[en + lane] : 0ull;
                     const int gl = (int)((xi >> 47) & 3), sd = (int)(xi & 0xFFFFF);
                     const uint32_t xk = (uint32_t)((xi >> 20) & 0xFFFF);
-                    const bool isb = gl < 3;                             // a bucket digit is substituted (else the first key residue)
                     const int st = gl == 0 ? 10 : gl == 1 ? 1 : gl == 2 ? 100 : 0;
                     const int d = gl == 0 ? (sd / 10) % 10 : gl == 1 ? sd % 10 : gl == 2 ? (sd / 100) % 10 : (int)(xk >> 12);
-                    uint32_t ok = 0, fw[10], fb[10];
+                    uint32_t ok = 0;
+                    if (COUNT) {
 #pragma unroll
-                    for (int j = 0; j < 10; j++) {
-                        const int v = sd + (j - d) * st;                 // st = 0 for the key group: the bucket stays
-                        const uint32_t kk = isb ? xk : ((xk & 0x0FFFu) | ((uint32_t)j << 12));
-                        bool c = act && j != d;
-                        if (COUNT && c) sc.lookups++;
-                        if (COUNT) { if (c) c = (bitmap[v >> 5] >> (v & 31)) & 1; }   // counting form: bucket occupancy decides, then the search
-                        ok |= (uint32_t)c << j;
-                        if (!COUNT) {   // Bloom filter word of the 10-mer (an empty bucket has none); lanes without a candidate read word 0
-                            const uint32_t hh = mc_filter_hash((uint32_t)v, kk);
-                            fb[j] = mc_filter_bits(hh);
-                            fw[j] = X.filt[c ? mc_filter_word(hh) : 0u];
+                        for (int j = 0; j < 10; j++) {
+                            const int v = sd + (j - d) * st;             // st = 0 for the key group: the bucket stays
+                            bool c = act && j != d;
+                            if (c) { sc.lookups++; c = (bitmap[v >> 5] >> (v & 31)) & 1; }   // counting form: bucket occupancy decides, then the search
+                            ok |= (uint32_t)c << j;
                         }
-                    }
-                    if (!COUNT) {
-#pragma unroll
-                        for (int j = 0; j < 10; j++) if ((fw[j] & fb[j]) != fb[j]) ok &= ~(1u << j);
+                    } else {   // pair filter: one 16-byte block answers for the ten residues (lanes without a pair read block 0)
+                        const uint32_t hp = mc_pair_hash((uint32_t)sd, xk, gl);
+                        const uint4 blk = ((const uint4 *)X.pair)[act ? mc_pair_block(hp) : 0u];
+                        ok = act ? (mc_pair_test4(blk.x, blk.y, blk.z, blk.w, hp) & ~(1u << d) & 0x3FFu) : 0u;
                     }
                     pm = ok;
                     mc_wave_sync();
                     continue;
                 }
-                if (!wmz) {                                              // one pending group per lane enters eq
+                if (!wmz) {                                              // pending groups enter eq: one per lane and turn, until eq holds a full batch
                     MC_TICK(3);
-                    const unsigned long long wmm = __ballot(wm != 0);
-                    const int gl = __builtin_ctz(wm | 16u);
-                    if (wm) W->eq[en + __popcll(wmm & lt)] = wbase | ((unsigned long long)gl << 47);
-                    en += __popcll(wmm);
-                    wm &= wm - 1;
+                    for (;;) {
+                        const unsigned long long wmm = __ballot(wm != 0);
+                        if (wmm == 0 || en >= 64) break;
+                        const int gl = __builtin_ctz(wm | 16u);
+                        if (wm) W->eq[en + __popcll(wmm & lt)] = wbase | ((unsigned long long)gl << 47);
+                        en += __popcll(wmm);
+                        wm &= wm - 1;
+                    }
                     mc_wave_sync();
                     continue;
                 }
@@ -1541,7 +1554,7 @@ struct mc_handle {
     int read_len = 0, FP = 0; bool run_set = false;
     uint32_t *d_bitmap = nullptr;
     McBucketRec *d_rec = nullptr;
-    uint32_t *d_filt = nullptr, *d_wild = nullptr; unsigned long long *d_rt = nullptr;
+    uint32_t *d_filt = nullptr, *d_wild = nullptr, *d_pair = nullptr; unsigned long long *d_rt = nullptr;
     bool fast_enum = false;
     bool count_traffic = false;
     int parts = MC_NCTX;                  // parts a range is cut into (mc_set_parts; 1 = one kernel at a time, for profiling)
@@ -1561,7 +1574,7 @@ struct mc_handle {
 
 static McIndex dev_index(const mc_handle *h)
 {
-    McIndex X; X.res = h->d_res; X.off = h->d_off; X.bstart = h->d_bstart; X.post = h->d_post; X.keys = h->d_keys; X.rec = h->d_rec; X.filt = h->d_filt; X.wild = h->d_wild; X.rt = h->d_rt; X.rt_mask = h->H.rt_mask; X.nseq = h->H.nseq;
+    McIndex X; X.res = h->d_res; X.off = h->d_off; X.bstart = h->d_bstart; X.post = h->d_post; X.keys = h->d_keys; X.rec = h->d_rec; X.filt = h->d_filt; X.wild = h->d_wild; X.pair = h->d_pair; X.rt = h->d_rt; X.rt_mask = h->H.rt_mask; X.nseq = h->H.nseq;
     return X;
 }
 
@@ -1595,7 +1608,7 @@ extern "C" void mc_close(mc_handle *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_rt};
+    void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_pair, h->d_rt};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (McCtx &c : h->ctx) ctx_free(c);
     for (int k = 0; k < 2; k++) { if (h->stage_pin[k]) (void)hipHostFree(h->stage_pin[k]); if (h->stage_dev[k]) (void)hipFree(h->stage_dev[k]); }
@@ -1636,7 +1649,8 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
     HIPCK(hipMemcpy(h->d_fam, h->fam.data(), (size_t)nseq * 4, hipMemcpyHostToDevice));
     if (dalloc(&h->d_bitmap, H.bitmap.size())) return -1;
     HIPCK(hipMemcpy(h->d_bitmap, H.bitmap.data(), H.bitmap.size() * 4, hipMemcpyHostToDevice));
-    if (dalloc(&h->d_filt, H.filt.size()) || dalloc(&h->d_wild, H.wild.size())) return -1;
+    if (dalloc(&h->d_filt, H.filt.size()) || dalloc(&h->d_wild, H.wild.size()) || dalloc(&h->d_pair, H.pair.size())) return -1;
+    HIPCK(hipMemcpy(h->d_pair, H.pair.data(), H.pair.size() * 4, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_wild, H.wild.data(), H.wild.size() * 4, hipMemcpyHostToDevice));
     if (dalloc(&h->d_rt, H.rt.size())) return -1;
     HIPCK(hipMemcpy(h->d_rt, H.rt.data(), H.rt.size() * 8, hipMemcpyHostToDevice));
@@ -2026,7 +2040,7 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         std::sort(c.h_best, c.h_best + c.nbest, [](const McBestHit &x, const McBestHit &y) { return x.read < y.read; });
         for (uint32_t i = 0; i < c.nbest; i++) { const McBestHit &x = c.h_best[i]; mc_best_hit o; o.read = x.read; o.family = x.family; o.aln = x.aln; o.target_len = x.target_len; o.bits = x.bits; h->best.push_back(o); }
 #ifdef MC_EXP_TIMING
-        { const char *nm[6] = {"staging/other", "heavy", "process", "push", "setup", "expand"}; for (int k = 0; k < 6; k++) fprintf(stderr, "timing %-14s %8.3f Mcycles/wave-avg  %10llu entries\n", nm[k], (double)c.h_stats[4 + k] / 4096.0 / 1e6, c.h_stats[10 + k]); }
+        { const char *nm[6] = {"staging/other", "append", "lookup", "push", "setup", "expand"}; for (int k = 0; k < 6; k++) fprintf(stderr, "timing %-14s %8.3f Mcycles/wave-avg  %10llu entries\n", nm[k], (double)c.h_stats[4 + k] / 4096.0 / 1e6, c.h_stats[10 + k]); }
 #endif
         h->stats.bucket_lookups += (int64_t)c.h_stats[S_LOOKUPS]; h->stats.key_probes += (int64_t)c.h_stats[S_KEYPROBES]; h->stats.seed_tasks += (int64_t)c.h_stats[S_TASKS];
         h->stats.gap_tasks += c.ngaps; h->stats.hsps += c.nh; h->stats.rows += c.nrows; h->stats.reads_with_rows += c.nsegs;

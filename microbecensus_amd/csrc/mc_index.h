@@ -27,6 +27,7 @@ struct McHostIndex {
     std::vector<McBucketRec> rec;      // first-residue group boundaries per bucket; empty when the index cannot use them
     std::vector<uint32_t> filt;        // Bloom filters over (bucket, key): 10-mers, then 9-mers
     std::vector<uint32_t> wild;        // wildcard filter over the 10-mers (mc_wild_*)
+    std::vector<uint32_t> pair;        // pair filter over the 10-mers (mc_pair_*)
     std::vector<unsigned long long> rt; // range table of the long first-residue groups (mc_rt_*)
     uint32_t rt_mask;
     uint32_t max_bucket;
@@ -229,6 +230,7 @@ inline void mc_index_derive(McHostIndex &X)
     // 10-mer filter (mc_filter_hash): every posting whose key has 4 residues
     X.filt.assign(MC_FILT_TOTAL_WORDS, 0);
     X.wild.assign((size_t)MC_WILD_LINES * 16, 0);
+    X.pair.assign((size_t)MC_PAIR_BLOCKS * 4, 0);
     for (int b = 0; b < MC_NBUCKET; b++)
         for (uint32_t i = X.bstart[b]; i < X.bstart[b + 1]; i++) {
             const uint32_t k = X.keys[i];
@@ -244,6 +246,8 @@ inline void mc_index_derive(McHostIndex &X)
                 const uint32_t bits = mc_wild_bits(ctx, (uint32_t)b, k, g), p1 = bits & 127u, p2 = bits >> 8;
                 uint32_t *q = &X.wild[(size_t)line * 16 + (size_t)g * 4];
                 q[p1 >> 5] |= 1u << (p1 & 31); q[p2 >> 5] |= 1u << (p2 & 31);
+                const uint32_t hp = mc_pair_hash((uint32_t)b, k, g);
+                mc_pair_set(&X.pair[(size_t)mc_pair_block(hp) * 4], hp, mc_pair_digit((uint32_t)b, k, g));
             }
         }
     // range table: every query key with a range inside a first-residue group of more than 8 postings, with the range

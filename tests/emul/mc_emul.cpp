@@ -60,10 +60,10 @@ int main(int argc, char **argv)
         fclose(d);
     }
     if (getenv("MC_CHECK_SCAN")) {   // exhaustive: scan-based ranges == binary-search ranges for every key a query could match
-        McIndex Xc; Xc.res = H.res.data(); Xc.off = H.off.data(); Xc.bstart = H.bstart.data(); Xc.post = H.post.data(); Xc.keys = H.keys.data(); Xc.rec = H.rec.data(); Xc.filt = H.filt.data(); Xc.wild = H.wild.data(); Xc.rt = H.rt.data(); Xc.rt_mask = H.rt_mask; Xc.nseq = H.nseq;
+        McIndex Xc; Xc.res = H.res.data(); Xc.off = H.off.data(); Xc.bstart = H.bstart.data(); Xc.post = H.post.data(); Xc.keys = H.keys.data(); Xc.rec = H.rec.data(); Xc.filt = H.filt.data(); Xc.wild = H.wild.data(); Xc.pair = H.pair.data(); Xc.rt = H.rt.data(); Xc.rt_mask = H.rt_mask; Xc.nseq = H.nseq;
         if (H.rec.empty()) { fprintf(stderr, "scan check: the index has no bucket records\n"); return 3; }
         fprintf(stderr, "largest bucket: %u postings\n", H.max_bucket);
-        long checked = 0, bad = 0, fneg = 0, fpos = 0, fq = 0, f9q = 0, f9pos = 0, wq = 0, wpos = 0, rtq = 0, rtbad = 0;
+        long checked = 0, bad = 0, fneg = 0, fpos = 0, fq = 0, f9q = 0, f9pos = 0, wq = 0, wpos = 0, rtq = 0, rtbad = 0, pq = 0, ppos = 0;
         for (int b = 0; b < MC_NBUCKET; b++) {
             uint32_t n = H.bstart[b + 1] - H.bstart[b];
             for (uint32_t i = 0; i < n; i++) {
@@ -109,6 +109,15 @@ int main(int argc, char **argv)
                             wq++;
                             if (r1 > 0 && !w) fneg++;
                             if (r1 == 0 && w) wpos++;
+                            // pair filter: the residue at the wildcard offset is among the answers of its (context, offset) block
+                            const uint32_t hp = mc_pair_hash((uint32_t)b, qk, g), dj = mc_pair_digit((uint32_t)b, qk, g);
+                            if (dj <= 9) {
+                                const uint32_t *pb = &H.pair[(size_t)mc_pair_block(hp) * 4];
+                                const bool pp = (mc_pair_test4(pb[0], pb[1], pb[2], pb[3], hp) >> dj) & 1u;
+                                pq++;
+                                if (r1 > 0 && !pp) fneg++;
+                                if (r1 == 0 && pp) ppos++;
+                            }
                         }
                     }
                 }
@@ -118,14 +127,16 @@ int main(int argc, char **argv)
         { long set = 0, set9 = 0; for (uint32_t i = 0; i < MC_FILT_TOTAL_WORDS; i++) (i < MC_FILT_WORDS ? set : set9) += __builtin_popcount(H.filt[i]);
           fprintf(stderr, "filter check: %ld 10-mer and %ld 9-mer probes, %ld false negatives, %ld / %ld false positives among near misses, %.1f %% / %.1f %% of the bits set\n", fq, f9q, fneg, fpos, f9pos, 100.0 * (double)set / (32.0 * MC_FILT_WORDS), 100.0 * (double)set9 / (32.0 * MC_FILT9_WORDS));
           long setw = 0; for (uint32_t w : H.wild) setw += __builtin_popcount(w);
-          fprintf(stderr, "wildcard filter: %ld questions, %ld positive among near misses, %.1f %% of the bits set\n", wq, wpos, 100.0 * (double)setw / (512.0 * MC_WILD_LINES)); }
+          fprintf(stderr, "wildcard filter: %ld questions, %ld positive among near misses, %.1f %% of the bits set\n", wq, wpos, 100.0 * (double)setw / (512.0 * MC_WILD_LINES));
+          long setp = 0; for (uint32_t w : H.pair) setp += __builtin_popcount(w);
+          fprintf(stderr, "pair filter: %ld questions, %ld positive among near misses, %.1f %% of the cell bits set\n", pq, ppos, 100.0 * (double)setp / (120.0 * MC_PAIR_BLOCKS)); }
         { size_t used = 0; for (unsigned long long e : H.rt) used += (e != ~0ull); fprintf(stderr, "range table: %zu entries in %zu slots; %ld probes into long groups checked, %ld differ from the binary searches\n", used, H.rt.size(), rtq, rtbad); }
         return (bad || fneg || rtbad) ? 3 : 0;
     }
     int read_len = rs.empty() ? 0 : (int)rs[0].size();
     static McTables T;
     mc_fill_tables(T, H, read_len, getenv("MC_LOGE_THR") ? atof(getenv("MC_LOGE_THR")) : 1.0);
-    McIndex X; X.res = H.res.data(); X.off = H.off.data(); X.bstart = H.bstart.data(); X.post = H.post.data(); X.keys = H.keys.data(); X.rec = H.rec.empty() ? nullptr : H.rec.data(); X.filt = H.filt.data(); X.wild = H.wild.data(); X.rt = H.rt.data(); X.rt_mask = H.rt_mask; X.nseq = H.nseq;
+    McIndex X; X.res = H.res.data(); X.off = H.off.data(); X.bstart = H.bstart.data(); X.post = H.post.data(); X.keys = H.keys.data(); X.rec = H.rec.empty() ? nullptr : H.rec.data(); X.filt = H.filt.data(); X.wild = H.wild.data(); X.pair = H.pair.data(); X.rt = H.rt.data(); X.rt_mask = H.rt_mask; X.nseq = H.nseq;
     McClassPars P; memset(&P, 0, sizeof P); P.nfam = 1; P.read_len = read_len;
     std::vector<int32_t> fam(H.nseq, 0);
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Counters of ONE kernel (development aid, run on the GPU box): tools/pmc_focus.sh <kernel-regex> [read-len]
-# Each counter set is its own rocprofv3 --pmc pass (no tracing options beside it); prints per-launch averages.
+# PMC_SETS="A B;C D" replaces the default counter sets.  Each counter set is its own rocprofv3 --pmc pass (no tracing options beside it); prints per-launch averages.
 K=${1:-k_gapped}
 L=${2:-150}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -9,10 +9,11 @@ OUT=$R/gpurun_out/focus
 rm -rf $OUT && mkdir -p $OUT
 BENCH="python3 $R/bench.py --steps 2 --warmup 1 --batch 1000000 --resident-batches 1 --read-len $L --no-cpu-baseline --no-ags-check --e2e-reads 0"
 i=0
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+if [ -n "$PMC_SETS" ]; then IFS=';' read -ra SETS <<< "$PMC_SETS"; else SETS=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_RD SQ_INSTS_BRANCH SQ_INSTS_SMEM" \
-           "FETCH_SIZE" "WRITE_SIZE"; do
+           "FETCH_SIZE" "WRITE_SIZE"); fi
+for set in "${SETS[@]}"; do
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $set --kernel-include-regex "$K" -d $OUT/pmc$i -o f --output-format csv -- $BENCH > $OUT/pmc$i.log 2>&1
 done
