@@ -79,7 +79,7 @@ struct McIndex {
     const uint32_t *post;      // seqIdx<<11 | pos, in prerapsearch bucket order
     const uint16_t *keys;      // 4 reduced residues after the 6-mer, 0xF past the sequence end
     const struct McBucketRec *rec;   // per bucket: start + first-residue group boundaries (NULL when the index cannot use them)
-    const uint32_t *wild;      // MC_WILD_LINES x 16 words: wildcard filter (mc_wild_*)
+    const uint32_t *wild;      // MC_WILD_LINES x 8 words: wildcard filter (mc_wild_*)
     const uint32_t *pair;      // MC_PAIR_BLOCKS x 4 words: which residues at a wildcard offset complete an index 10-mer (mc_pair_*)
     const unsigned long long *rt; uint32_t rt_mask;   // range table of the long groups (mc_rt_*): rt_mask + 1 slots
     const uint32_t *filt;      // MC_FILT_TOTAL_WORDS words: Bloom filters over the (bucket, key) pairs of the index (10-mers, then 9-mers)
@@ -805,15 +805,16 @@ MC_HD uint32_t mc_filter_bits(uint32_t h) { return (1u << (h & 31)) | (1u << ((h
 
 // ---- wildcard filter: one probe instead of ten ----------------------------------------------------------------------
 // The neighbourhood of a position is its 10-mer with ONE residue substituted, at offset 3, 4 or 5 (a digit of the bucket)
-// or 6 (the first key residue): 4 groups of 9 probes.  Instead of asking the 10-mer filter 36 times, the kernel first
-// asks, per group, "does the index hold ANY 10-mer that equals mine except at this offset?".  The index 10-mers are
-// entered four times, each time with one of the four middle residues left out.  Layout for locality: the six outer
-// residues (offsets 0-2 and 7-9) pick a 64-byte line, the wildcard position picks one of its four 128-bit quarters, the
-// three remaining middle residues pick two bits in it - so the four questions of a position cost ONE cache line.
-// A negative answer is exact (no 10-mer of the group can match); a positive one (2-3 % false) sends the group through the
-// per-probe path (10-mer filter, then the range search).  2^17 lines = 8 MB.
-#define MC_WILD_LOG2L 17
+// or 6 (the first key residue): 4 groups of 9 probes.  Instead of asking about every probe, the kernel first asks, per
+// group, "does the index hold ANY 10-mer that equals mine except at this offset?".  The index 10-mers are entered four
+// times, each time with one of the four middle residues left out.  Layout for locality: the six outer residues (offsets
+// 0-2 and 7-9) pick a 32-byte line, the wildcard position picks one of its four 64-bit parts, the three remaining middle
+// residues pick one bit in each of the part's two words - so the four questions of a position cost ONE 32-byte read and
+// three operations each.  A negative answer is exact (no 10-mer of the group can match); a positive one sends the group
+// to the pair filter.  2^18 lines = 8 MB.
+#define MC_WILD_LOG2L 18
 #define MC_WILD_LINES (1u << MC_WILD_LOG2L)
+#define MC_WILD_LINE_WORDS 8
 MC_HD uint32_t mc_wild_ctx(uint32_t seed, uint32_t key) { return (seed / 1000u) * 4096u + (key & 0xFFFu); }
 MC_HD uint32_t mc_wild_line(uint32_t ctx)
 {
@@ -823,30 +824,25 @@ MC_HD uint32_t mc_wild_line(uint32_t ctx)
 }
 // group g: 0 = offset 4 (stride 10), 1 = offset 5 (stride 1), 2 = offset 3 (stride 100), 3 = offset 6 (first key residue)
 MC_HD uint32_t mc_wild_bits(uint32_t ctx, uint32_t seed, uint32_t key, int g)
-{ // two bit positions (7 bit each) inside the quarter: low and high halves of the result
+{ // a bit position in each of the part's two words: low and high byte of the result
     const uint32_t b3 = (seed / 100u) % 10u, b4 = (seed / 10u) % 10u, b5 = seed % 10u, k0 = key >> 12;
     const uint32_t a = (g == 2) ? b4 : b3, b = (g == 0 || g == 2) ? b5 : b4, c = (g == 3) ? b5 : k0;
     uint32_t x = (ctx + 0x51ED27u * (uint32_t)(g + 1)) * 0x2C1B3C6Du + ((a << 8) | (b << 4) | c) * 0x297A2D39u;
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15;
-    return (x & 127u) | (((x >> 7) & 127u) << 8);
+    return (x & 31u) | (((x >> 5) & 31u) << 8);
 }
-MC_HD bool mc_wild_test4(uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t bits)
-{ // two bits of the 128-bit quarter x|y|z|w; written with 64-bit shifts so that no indexed (scratch) array appears
-    const uint32_t p1 = bits & 127u, p2 = bits >> 8;
-    const unsigned long long lo = (unsigned long long)x | ((unsigned long long)y << 32), hi = (unsigned long long)z | ((unsigned long long)w << 32);
-    const unsigned long long s1 = (p1 < 64) ? lo : hi, s2 = (p2 < 64) ? lo : hi;
-    return (((s1 >> (p1 & 63)) & (s2 >> (p2 & 63))) & 1ull) != 0;
-}
-MC_HD bool mc_wild_test(const uint32_t q[4], uint32_t bits) { return mc_wild_test4(q[0], q[1], q[2], q[3], bits); }
+MC_HD bool mc_wild_test2(uint32_t w0, uint32_t w1, uint32_t bits) { return (((w0 >> (bits & 31u)) & (w1 >> (bits >> 8))) & 1u) != 0; }
+MC_HD bool mc_wild_test(const uint32_t q[2], uint32_t bits) { return mc_wild_test2(q[0], q[1], bits); }
+MC_HD void mc_wild_set(uint32_t q[2], uint32_t bits) { q[0] |= 1u << (bits & 31u); q[1] |= 1u << (bits >> 8); }
 
 // ---- pair filter: the ten probes of a (position, wildcard offset) pair in ONE 16-byte read ------------------------------
 // A pair that passed the wildcard filter used to ask the 10-mer Bloom filter once per substituted residue: nine scattered
 // words, nine L2 requests - and the seed kernel is bound by the requests its CU can keep in flight.  Here the nine known
 // residues and the offset pick a 128-bit block; the block holds ten 12-bit cells, one per residue value at the wildcard
-// offset, and the context picks two of the twelve bits (the same two in every cell).  An index 10-mer sets its two bits
+// offset, and the context picks three of the twelve bits (the same three in every cell).  An index 10-mer sets its three bits
 // in the cell of its own residue, once per offset; a query reads the block and gets the mask of residues that may complete
 // an index 10-mer with a handful of 64-bit operations.  No false negatives; false positives go through the exact search.
-#define MC_PAIR_LOG2B 19
+#define MC_PAIR_LOG2B 20
 #define MC_PAIR_BLOCKS (1u << MC_PAIR_LOG2B)
 // group g: 0 = offset 4 (bucket digit of stride 10), 1 = offset 5 (stride 1), 2 = offset 3 (stride 100), 3 = offset 6 (first key residue)
 MC_HD uint32_t mc_pair_digit(uint32_t seed, uint32_t key, int g) { return g == 0 ? (seed / 10u) % 10u : g == 1 ? seed % 10u : g == 2 ? (seed / 100u) % 10u : key >> 12; }
@@ -859,19 +855,22 @@ MC_HD uint32_t mc_pair_hash(uint32_t seed, uint32_t key, int g)
     return x;
 }
 MC_HD uint32_t mc_pair_block(uint32_t h) { return h >> (32 - MC_PAIR_LOG2B); }
-MC_HD uint32_t mc_pair_bit_a(uint32_t h) { return ((h & 0xFFu) * 12u) >> 8; }
-MC_HD uint32_t mc_pair_bit_b(uint32_t h) { return (((h >> 8) & 0xFFu) * 12u) >> 8; }
+MC_HD uint32_t mc_pair_mix(uint32_t h) { uint32_t y = h * 0x9E3779B1u; return y ^ (y >> 15); }   // the block index uses the top bits of h: the pattern gets bits of its own
+MC_HD uint32_t mc_pair_bit_a(uint32_t y) { return ((y & 0xFFu) * 12u) >> 8; }
+MC_HD uint32_t mc_pair_bit_b(uint32_t y) { return (((y >> 8) & 0xFFu) * 12u) >> 8; }
+MC_HD uint32_t mc_pair_bit_c(uint32_t y) { return (((y >> 16) & 0xFFu) * 12u) >> 8; }
 MC_HD void mc_pair_set(uint32_t q[4], uint32_t h, uint32_t j)
 { // cells 0..4 in words 0,1 (bit 12 j), cells 5..9 in words 2,3
     if (j > 9) return;
-    const uint32_t base = (j < 5 ? 0u : 64u) + 12u * (j < 5 ? j : j - 5u), pa = base + mc_pair_bit_a(h), pb = base + mc_pair_bit_b(h);
-    q[pa >> 5] |= 1u << (pa & 31); q[pb >> 5] |= 1u << (pb & 31);
+    const uint32_t y = mc_pair_mix(h);
+    const uint32_t base = (j < 5 ? 0u : 64u) + 12u * (j < 5 ? j : j - 5u), pa = base + mc_pair_bit_a(y), pb = base + mc_pair_bit_b(y), pc = base + mc_pair_bit_c(y);
+    q[pa >> 5] |= 1u << (pa & 31); q[pb >> 5] |= 1u << (pb & 31); q[pc >> 5] |= 1u << (pc & 31);
 }
 MC_HD uint32_t mc_pair_test4(uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t h)
 { // bit j of the result: residue j at the wildcard offset may complete an index 10-mer
-    const uint32_t a = mc_pair_bit_a(h), b = mc_pair_bit_b(h);
+    const uint32_t m = mc_pair_mix(h), a = mc_pair_bit_a(m), b = mc_pair_bit_b(m), c = mc_pair_bit_c(m);
     const unsigned long long lo = (unsigned long long)x | ((unsigned long long)y << 32), hi = (unsigned long long)z | ((unsigned long long)w << 32);
-    const unsigned long long ml = (lo >> a) & (lo >> b), mh = (hi >> a) & (hi >> b);
+    const unsigned long long ml = (lo >> a) & (lo >> b) & (lo >> c), mh = (hi >> a) & (hi >> b) & (hi >> c);
     uint32_t r = 0;
     for (int j = 0; j < 5; j++) r |= ((uint32_t)(ml >> (12 * j)) & 1u) << j | ((uint32_t)(mh >> (12 * j)) & 1u) << (j + 5);
     return r;

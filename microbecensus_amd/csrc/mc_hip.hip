@@ -373,6 +373,7 @@ __global__ void __launch_bounds__(256) k_enumerate(const McTables *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 #define MC_EN_QCAP 128
 #define MC_EN_NCHUNK(L) ((((L) / 3 - 6) + 63) / 64 > 0 ? (((L) / 3 - 6) + 63) / 64 : 1)
+static_assert(6 * MC_EN_NCHUNK(3 * MC_MAXAA) * 64 <= 2048, "a deferred position is kept in 11 bits beside the wildcard filter's 4-bit answer");
 #define MC_EN_BLK 2048u                     // task slots a wave reserves at a time (one global atomic per block, not per append)
 #define MC_EN_SHORT 4                      // seed-hit ranges up to this long are written by the lane that found them
 #define MC_TASK_NONE 0xFFFFFFFFu            // read id of the padding entries that close a partly used block
@@ -543,6 +544,9 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
     uint8_t *fr_all = smem + 64 + (size_t)MC_EN_WAVES * MC_EN_WAVE_BYTES(COUNT);
     const int FPs = (FP + 15) & ~15;
     const int nchunk = MC_EN_NCHUNK(L);                                    // chunks of 64 positions per frame
+    const int ql0 = L / 3, ql1 = (L - 1) / 3, ql2 = (L - 2) / 3;           // frame lengths (frames f and f + 3 alike) and the running
+    const int cn0 = ql0 > 6 ? ql0 - 6 : 0, cn1 = ql1 > 6 ? ql1 - 6 : 0, cn2 = ql2 > 6 ? ql2 - 6 : 0;   // number of seed positions of the frames
+    const int cum1 = cn0, cum2 = cum1 + cn1, cum3 = cum2 + cn2, cum4 = cum3 + cn0, cum5 = cum4 + cn1, cum6 = cum5 + cn2;
     uint8_t *fr = fr_all + (size_t)wv * (6 * FPs + 6 * nchunk * (512 + 128));
     unsigned long long *pre = (unsigned long long *)(fr + 6 * FPs);        // per (frame, chunk, lane): seed 20 | g6..g9 16 | valid 1 | bucket occupied 1
     uint16_t *dq = (uint16_t *)(pre + 6 * nchunk * 64);                    // positions whose neighbourhood waits for the exact probes' results
@@ -610,7 +614,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
         // Every stage runs with full waves; the generator is a state machine so that each stage exists once in the kernel.
         int dn = 0;                                      // deferred positions (dq)
         for (int pass = 0; pass < 2; pass++) {
-            int f = -1, p0 = 0, qlen = 0, dpos = 0;
+            int flat0 = 0, dpos = 0;
             bool more = true;
             uint32_t wm = 0;                             // groups of this lane's position that still have to enter eq
             unsigned long long wbase = 0;                // seed | key | position | frame of this lane's position
@@ -705,26 +709,31 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                     continue;
                 }
                 if (!more) break;
-                {   // next 64 positions: of the sweep over the frames (pass 0) or of the deferred list (pass 1)
+                {   // next 64 positions: of the sweep over the frames (pass 0: the positions of the six frames are numbered through,
+                    // so every step but the last has 64 of them) or of the deferred list (pass 1)
                     MC_TICK(4);
-                    int pos, fl, idx;
+                    int pos, fl, idx, qlen;
                     bool here;
+                    uint32_t wmd = 0;
                     if (pass == 0) {
-                        if (f >= 0) p0 += 64;
-                        if (f < 0 || p0 + 6 >= qlen) {
-                            f++; p0 = 0;
-                            if (f == 6) { more = false; continue; }
-                            qlen = (L - f % 3) / 3;
-                            if (p0 + 6 >= qlen) continue;
-                        }
-                        pos = p0 + lane; fl = f; idx = (f * nchunk + (p0 >> 6)) * 64 + lane; here = true;
+                        if (flat0 >= cum6) { more = false; continue; }
+                        const int flat = flat0 + lane;
+                        flat0 += 64;
+                        here = flat < cum6;
+                        fl = (flat >= cum1) + (flat >= cum2) + (flat >= cum3) + (flat >= cum4) + (flat >= cum5);
+                        pos = flat - (fl == 0 ? 0 : fl == 1 ? cum1 : fl == 2 ? cum2 : fl == 3 ? cum3 : fl == 4 ? cum4 : cum5);
+                        const int fm = fl >= 3 ? fl - 3 : fl;
+                        qlen = fm == 0 ? ql0 : fm == 1 ? ql1 : ql2;
+                        idx = here ? fl * nchunk * 64 + pos : 0;
                     } else {
                         if (dpos >= dn) { more = false; continue; }
                         here = dpos + lane < dn;
-                        idx = here ? dq[dpos + lane] : 0;
+                        const uint32_t e = here ? dq[dpos + lane] : 0u;      // position | the wildcard filter's answer, asked in pass 0
                         dpos += 64;
+                        idx = (int)(e & 0x7FFu); wmd = e >> 11;
                         fl = idx / (nchunk * 64);
                         pos = (idx - fl * nchunk * 64);                  // chunk * 64 + lane = the position
+                        qlen = 0;
                     }
                     bool live0 = false, live = false, defer = false;     // exact probe; neighbourhood; neighbourhood decided later
                     uint32_t qk = 0, qk0 = 0;
@@ -746,7 +755,8 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                             }
                             // The neighbourhood's validity check starts at residue `used`: 9 when the own bucket is occupied, else 8
                             // or 6 depending on whether the nearest earlier exact probe of the frame found a range (prev).  That
-                            // only matters when g8, g9 are valid and g6 or g7 is not: those few positions wait for pass 1.
+                            // only matters when g8, g9 are valid and g6 or g7 is not: those few positions wait for pass 1 - with
+                            // the wildcard filter's answer, which is asked now (no answer, no wait).
                             if (rest >= 4) {
                                 if (selfbucket) live = v6 && v7 && v9;
                                 else if (v8 && v9) { if (v6 && v7) live = true; else defer = true; }
@@ -758,36 +768,42 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                             if (m) { const int bb = 31 - __builtin_clz(m); live = (W->hit[fl][w] >> bb) & 1; }
                         }
                     }
-                    if (pass == 0) {
-                        const unsigned long long dm = __ballot(defer);
-                        if (dm) { if (defer) dq[dn + __popcll(dm & lt)] = (uint16_t)idx; dn += __popcll(dm); }
-                    }
                     const unsigned long long posf = ((unsigned long long)pos << 36) | ((unsigned long long)fl << 44);
                     wbase = (unsigned long long)seed | ((unsigned long long)qk << 20) | posf;
-                    if (pass == 0) {                                     // the exact 9-mer: its own Bloom filter, then straight into q
-                        bool pr = live0;
-                        if (!COUNT && __ballot(live0)) {
-                            const uint32_t hh = mc_filter_hash((uint32_t)seed, qk0), fb9 = mc_filter_bits(hh);
-                            const uint32_t fw9 = X.filt[live0 ? mc_filter9_word(hh) : 0u];
-                            pr = live0 && (fw9 & fb9) == fb9;
+                    if (pass == 0) {
+                        // both filters are asked before either answer is looked at: their reads are in flight together
+                        const bool ask = live || defer;
+                        const bool any9 = !COUNT && __ballot(live0), anyw = !COUNT && __ballot(ask);
+                        uint32_t fw9 = 0, fb9 = 0, ctx = 0;
+                        uint4 q0 = {0, 0, 0, 0}, q1 = {0, 0, 0, 0};
+                        if (any9) {                                      // the exact 9-mer: its own Bloom filter, then straight into q
+                            const uint32_t hh = mc_filter_hash((uint32_t)seed, qk0);
+                            fb9 = mc_filter_bits(hh);
+                            fw9 = X.filt[live0 ? mc_filter9_word(hh) : 0u];
                         }
+                        if (anyw) {                                      // wildcard filter: one 32-byte line answers for the four groups
+                            ctx = mc_wild_ctx((uint32_t)seed, qk);
+                            const uint4 *ln = (const uint4 *)X.wild + (size_t)(ask ? mc_wild_line(ctx) : 0u) * 2;
+                            q0 = ln[0]; q1 = ln[1];
+                        }
+                        const bool pr = live0 && (COUNT || (fw9 & fb9) == fb9);
                         const unsigned long long prm = __ballot(pr);
                         if (prm) {
                             if (pr) W->q[qn + __popcll(prm & lt)] = (unsigned long long)seed | ((unsigned long long)qk0 << 20) | posf;   // phase 0
                             qn += __popcll(prm);
-                            mc_wave_sync();
                         }
-                    }
-                    if (COUNT) wm = live ? 0xFu : 0u;                    // counting form: every probe is generated and searched
-                    else if (__ballot(live)) {                           // wildcard filter: one cache line answers for the four groups
-                        const uint32_t ctx = mc_wild_ctx((uint32_t)seed, qk);
-                        const uint4 *ln = (const uint4 *)X.wild + (size_t)(live ? mc_wild_line(ctx) : 0u) * 4;
-                        const uint4 q0 = ln[0], q1 = ln[1], q2 = ln[2], q3 = ln[3];
-                        if (live) {
-                            wm = (mc_wild_test4(q0.x, q0.y, q0.z, q0.w, mc_wild_bits(ctx, (uint32_t)seed, qk, 0)) ? 1u : 0u) | (mc_wild_test4(q1.x, q1.y, q1.z, q1.w, mc_wild_bits(ctx, (uint32_t)seed, qk, 1)) ? 2u : 0u) |
-                                 (mc_wild_test4(q2.x, q2.y, q2.z, q2.w, mc_wild_bits(ctx, (uint32_t)seed, qk, 2)) ? 4u : 0u) | (mc_wild_test4(q3.x, q3.y, q3.z, q3.w, mc_wild_bits(ctx, (uint32_t)seed, qk, 3)) ? 8u : 0u);
+                        uint32_t wmt = 0xFu;                             // counting form: every probe is generated and searched
+                        if (!COUNT) {
+                            wmt = 0;
+                            if (ask) wmt = (mc_wild_test2(q0.x, q0.y, mc_wild_bits(ctx, (uint32_t)seed, qk, 0)) ? 1u : 0u) | (mc_wild_test2(q0.z, q0.w, mc_wild_bits(ctx, (uint32_t)seed, qk, 1)) ? 2u : 0u) |
+                                            (mc_wild_test2(q1.x, q1.y, mc_wild_bits(ctx, (uint32_t)seed, qk, 2)) ? 4u : 0u) | (mc_wild_test2(q1.z, q1.w, mc_wild_bits(ctx, (uint32_t)seed, qk, 3)) ? 8u : 0u);
                         }
-                    }
+                        wm = live ? wmt : 0u;
+                        defer = defer && wmt != 0;
+                        const unsigned long long dm = __ballot(defer);
+                        if (dm) { if (defer) dq[dn + __popcll(dm & lt)] = (uint16_t)((uint32_t)idx | (wmt << 11)); dn += __popcll(dm); }
+                        if (prm | dm) mc_wave_sync();
+                    } else wm = live ? wmd : 0u;
                 }
             }
             mc_wave_sync();

@@ -229,7 +229,7 @@ inline void mc_index_derive(McHostIndex &X)
     }
     // 10-mer filter (mc_filter_hash): every posting whose key has 4 residues
     X.filt.assign(MC_FILT_TOTAL_WORDS, 0);
-    X.wild.assign((size_t)MC_WILD_LINES * 16, 0);
+    X.wild.assign((size_t)MC_WILD_LINES * MC_WILD_LINE_WORDS, 0);
     X.pair.assign((size_t)MC_PAIR_BLOCKS * 4, 0);
     for (int b = 0; b < MC_NBUCKET; b++)
         for (uint32_t i = X.bstart[b]; i < X.bstart[b + 1]; i++) {
@@ -243,9 +243,7 @@ inline void mc_index_derive(McHostIndex &X)
             X.filt[mc_filter_word(h)] |= mc_filter_bits(h);
             const uint32_t ctx = mc_wild_ctx((uint32_t)b, k), line = mc_wild_line(ctx);
             for (int g = 0; g < 4; g++) {
-                const uint32_t bits = mc_wild_bits(ctx, (uint32_t)b, k, g), p1 = bits & 127u, p2 = bits >> 8;
-                uint32_t *q = &X.wild[(size_t)line * 16 + (size_t)g * 4];
-                q[p1 >> 5] |= 1u << (p1 & 31); q[p2 >> 5] |= 1u << (p2 & 31);
+                mc_wild_set(&X.wild[(size_t)line * MC_WILD_LINE_WORDS + (size_t)g * 2], mc_wild_bits(ctx, (uint32_t)b, k, g));
                 const uint32_t hp = mc_pair_hash((uint32_t)b, k, g);
                 mc_pair_set(&X.pair[(size_t)mc_pair_block(hp) * 4], hp, mc_pair_digit((uint32_t)b, k, g));
             }

@@ -105,7 +105,7 @@ int main(int argc, char **argv)
                         // wildcard filter: a 10-mer with a range answers yes for all four wildcard positions
                         const uint32_t ctx = mc_wild_ctx((uint32_t)b, qk), line = mc_wild_line(ctx);
                         for (int g = 0; g < 4; g++) {
-                            const bool w = mc_wild_test(&H.wild[(size_t)line * 16 + (size_t)g * 4], mc_wild_bits(ctx, (uint32_t)b, qk, g));
+                            const bool w = mc_wild_test(&H.wild[(size_t)line * MC_WILD_LINE_WORDS + (size_t)g * 2], mc_wild_bits(ctx, (uint32_t)b, qk, g));
                             wq++;
                             if (r1 > 0 && !w) fneg++;
                             if (r1 == 0 && w) wpos++;
@@ -127,7 +127,7 @@ int main(int argc, char **argv)
         { long set = 0, set9 = 0; for (uint32_t i = 0; i < MC_FILT_TOTAL_WORDS; i++) (i < MC_FILT_WORDS ? set : set9) += __builtin_popcount(H.filt[i]);
           fprintf(stderr, "filter check: %ld 10-mer and %ld 9-mer probes, %ld false negatives, %ld / %ld false positives among near misses, %.1f %% / %.1f %% of the bits set\n", fq, f9q, fneg, fpos, f9pos, 100.0 * (double)set / (32.0 * MC_FILT_WORDS), 100.0 * (double)set9 / (32.0 * MC_FILT9_WORDS));
           long setw = 0; for (uint32_t w : H.wild) setw += __builtin_popcount(w);
-          fprintf(stderr, "wildcard filter: %ld questions, %ld positive among near misses, %.1f %% of the bits set\n", wq, wpos, 100.0 * (double)setw / (512.0 * MC_WILD_LINES));
+          fprintf(stderr, "wildcard filter: %ld questions, %ld positive among near misses, %.1f %% of the bits set\n", wq, wpos, 100.0 * (double)setw / (32.0 * MC_WILD_LINE_WORDS * MC_WILD_LINES));
           long setp = 0; for (uint32_t w : H.pair) setp += __builtin_popcount(w);
           fprintf(stderr, "pair filter: %ld questions, %ld positive among near misses, %.1f %% of the cell bits set\n", pq, ppos, 100.0 * (double)setp / (120.0 * MC_PAIR_BLOCKS)); }
         { size_t used = 0; for (unsigned long long e : H.rt) used += (e != ~0ull); fprintf(stderr, "range table: %zu entries in %zu slots; %ld probes into long groups checked, %ld differ from the binary searches\n", used, H.rt.size(), rtq, rtbad); }
