@@ -746,6 +746,26 @@ MC_HD int mc_group_range8(const uint16_t *kp, int ns, uint32_t qk, int *lb_out)
     return ub - lb;
 }
 
+// The same for a PROBE of the seed kernel (three or four key residues, then only the 0xF pad): a database key is inside the range
+// exactly when its first three / four residues equal the probe's - a shorter key differs at its own pad and sorts in front of
+// the range, a longer one compares on the probe's length (mc_key_lb_less / mc_key_ub_less).  *lb_out is set for a range only.
+// Checked against mc_group_range8 over every key of the index and its near misses (tests/emul, MC_CHECK_SCAN).
+MC_HD int mc_group_match8(const uint16_t *kp, int ns, uint32_t qk, int *lb_out)
+{
+    const uintptr_t a = (uintptr_t)kp;
+    const uint32_t *w = (const uint32_t *)(a & ~(uintptr_t)3);
+    uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
+    if (a & 2) { d0 = (d0 >> 16) | (d1 << 16); d1 = (d1 >> 16) | (d2 << 16); d2 = (d2 >> 16) | (d3 << 16); d3 = (d3 >> 16) | (d4 << 16); }
+    const int sh = (4 - mc_klen_fast(qk)) * 4;
+    const uint32_t q2 = (qk >> sh) * 0x10001u, lm = (0xFFFFu >> sh) * 0x10001u;
+    const uint32_t x0 = ((d0 >> sh) & lm) ^ q2, x1 = ((d1 >> sh) & lm) ^ q2, x2 = ((d2 >> sh) & lm) ^ q2, x3 = ((d3 >> sh) & lm) ^ q2;
+    uint32_t m = ((x0 & 0xFFFFu) == 0 ? 1u : 0u) | ((x0 >> 16) == 0 ? 2u : 0u) | ((x1 & 0xFFFFu) == 0 ? 4u : 0u) | ((x1 >> 16) == 0 ? 8u : 0u) |
+                 ((x2 & 0xFFFFu) == 0 ? 16u : 0u) | ((x2 >> 16) == 0 ? 32u : 0u) | ((x3 & 0xFFFFu) == 0 ? 64u : 0u) | ((x3 >> 16) == 0 ? 128u : 0u);
+    m &= (1u << ns) - 1u;
+    *lb_out = __builtin_ctz(m | 256u);
+    return __builtin_popcount(m);
+}
+
 // the same for a group of any length, by the reference's two binary searches
 MC_HD int mc_group_range_bs(const uint16_t *kp, int ns, uint32_t qk, int *lb_out)
 {
@@ -823,13 +843,23 @@ MC_HD uint32_t mc_wild_line(uint32_t ctx)
     return x >> (32 - MC_WILD_LOG2L);
 }
 // group g: 0 = offset 4 (stride 10), 1 = offset 5 (stride 1), 2 = offset 3 (stride 100), 3 = offset 6 (first key residue)
-MC_HD uint32_t mc_wild_bits(uint32_t ctx, uint32_t seed, uint32_t key, int g)
-{ // a bit position in each of the part's two words: low and high byte of the result
-    const uint32_t b3 = (seed / 100u) % 10u, b4 = (seed / 10u) % 10u, b5 = seed % 10u, k0 = key >> 12;
-    const uint32_t a = (g == 2) ? b4 : b3, b = (g == 0 || g == 2) ? b5 : b4, c = (g == 3) ? b5 : k0;
-    uint32_t x = (ctx + 0x51ED27u * (uint32_t)(g + 1)) * 0x2C1B3C6Du + ((a << 8) | (b << 4) | c) * 0x297A2D39u;
+// The two bit positions of a group hash the line context and the three middle residues that are NOT the wildcard: one sum
+// over all four (mc_wild_sum), minus the wildcard residue's own term, then one mixing round per group.
+#define MC_WILD_K3 0x297A2D39u
+#define MC_WILD_K4 0x68E31DA5u
+#define MC_WILD_K5 0x1B56C4E9u
+#define MC_WILD_K6 0x4CF5AD43u
+MC_HD uint32_t mc_wild_sum(uint32_t ctx, uint32_t r3, uint32_t r4, uint32_t r5, uint32_t r6) { return ctx * 0x2C1B3C6Du + r3 * MC_WILD_K3 + r4 * MC_WILD_K4 + r5 * MC_WILD_K5 + r6 * MC_WILD_K6; }
+MC_HD uint32_t mc_wild_bits_s(uint32_t sum, uint32_t rg, int g)
+{ // rg: the residue at the group's wildcard offset; result: a bit position in each of the part's two words (low and high byte)
+    uint32_t x = sum - rg * (g == 0 ? MC_WILD_K4 : g == 1 ? MC_WILD_K5 : g == 2 ? MC_WILD_K3 : MC_WILD_K6) + 0x51ED27u * (uint32_t)(g + 1);
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15;
     return (x & 31u) | (((x >> 5) & 31u) << 8);
+}
+MC_HD uint32_t mc_wild_bits(uint32_t ctx, uint32_t seed, uint32_t key, int g)
+{
+    const uint32_t r3 = (seed / 100u) % 10u, r4 = (seed / 10u) % 10u, r5 = seed % 10u, r6 = key >> 12;
+    return mc_wild_bits_s(mc_wild_sum(ctx, r3, r4, r5, r6), g == 0 ? r4 : g == 1 ? r5 : g == 2 ? r3 : r6, g);
 }
 MC_HD bool mc_wild_test2(uint32_t w0, uint32_t w1, uint32_t bits) { return (((w0 >> (bits & 31u)) & (w1 >> (bits >> 8))) & 1u) != 0; }
 MC_HD bool mc_wild_test(const uint32_t q[2], uint32_t bits) { return mc_wild_test2(q[0], q[1], bits); }
@@ -846,14 +876,15 @@ MC_HD void mc_wild_set(uint32_t q[2], uint32_t bits) { q[0] |= 1u << (bits & 31u
 #define MC_PAIR_BLOCKS (1u << MC_PAIR_LOG2B)
 // group g: 0 = offset 4 (bucket digit of stride 10), 1 = offset 5 (stride 1), 2 = offset 3 (stride 100), 3 = offset 6 (first key residue)
 MC_HD uint32_t mc_pair_digit(uint32_t seed, uint32_t key, int g) { return g == 0 ? (seed / 10u) % 10u : g == 1 ? seed % 10u : g == 2 ? (seed / 100u) % 10u : key >> 12; }
-MC_HD uint32_t mc_pair_hash(uint32_t seed, uint32_t key, int g)
-{ // hash of the 10-mer with the residue at the wildcard offset taken out
-    const uint32_t d = mc_pair_digit(seed, key, g), st = g == 0 ? 10u : g == 1 ? 1u : g == 2 ? 100u : 0u;
+MC_HD uint32_t mc_pair_hash_d(uint32_t seed, uint32_t key, int g, uint32_t d)
+{ // hash of the 10-mer with the residue at the wildcard offset (d) taken out
+    const uint32_t st = g == 0 ? 10u : g == 1 ? 1u : g == 2 ? 100u : 0u;
     const uint32_t s0 = seed - d * st, k0 = g == 3 ? (key & 0x0FFFu) : key;
     uint32_t x = s0 * 0x9E3779B1u + k0 * 0x85EBCA77u + (uint32_t)(g + 1) * 0x51ED270Bu;
     x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13; x *= 0x297A2D39u; x ^= x >> 16;
     return x;
 }
+MC_HD uint32_t mc_pair_hash(uint32_t seed, uint32_t key, int g) { return mc_pair_hash_d(seed, key, g, mc_pair_digit(seed, key, g)); }
 MC_HD uint32_t mc_pair_block(uint32_t h) { return h >> (32 - MC_PAIR_LOG2B); }
 MC_HD uint32_t mc_pair_mix(uint32_t h) { uint32_t y = h * 0x9E3779B1u; return y ^ (y >> 15); }   // the block index uses the top bits of h: the pattern gets bits of its own
 MC_HD uint32_t mc_pair_bit_a(uint32_t y) { return ((y & 0xFFu) * 12u) >> 8; }

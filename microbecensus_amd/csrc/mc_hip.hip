@@ -63,6 +63,17 @@ enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_N = 16 };   // 64-bit algorithmic-
 
 __device__ __forceinline__ int mc_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 // orders the wave's own LDS traffic for the compiler; the hardware executes one wave's LDS instructions in order
+// inclusive prefix sum over the 64 lanes in six DPP additions: shifts inside the rows of 16, then the row totals carried across
+__device__ __forceinline__ uint32_t mc_wave_scan_add(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);    // row_shr:1 (lanes shifted in from outside a row read 0)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
 __device__ __forceinline__ void mc_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 // ---- SEG for the 64 frames of a wave -----------------------------------------------------------------------------------
@@ -374,6 +385,7 @@ __global__ void __launch_bounds__(256) k_enumerate(const McTables *__restrict__ 
 #define MC_EN_QCAP 128
 #define MC_EN_NCHUNK(L) ((((L) / 3 - 6) + 63) / 64 > 0 ? (((L) / 3 - 6) + 63) / 64 : 1)
 static_assert(6 * MC_EN_NCHUNK(3 * MC_MAXAA) * 64 <= 2048, "a deferred position is kept in 11 bits beside the wildcard filter's 4-bit answer");
+#define MC_EN_ROW(FP) ((((FP) + 10 + 7) / 8) * 4)   // bytes of a frame's row of reduced-alphabet codes, two per byte, padded past the last seed's key
 #define MC_EN_BLK 2048u                     // task slots a wave reserves at a time (one global atomic per block, not per append)
 #define MC_EN_SHORT 4                      // seed-hit ranges up to this long are written by the lane that found them
 #define MC_TASK_NONE 0xFFFFFFFFu            // read id of the padding entries that close a partly used block
@@ -400,9 +412,7 @@ __device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long
     const int pos = (int)((item >> 36) & 0xFF), frame = (int)((item >> 44) & 7), phase = (int)((item >> 47) & 63);
     if (phase == 0 && cnt > 0) atomicOr(&W->hit[frame][pos >> 5], 1u << (pos & 31));
     // slot of every lane's range: prefix sum of the counts over the lanes
-    uint32_t incl = (uint32_t)cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += y; }
+    const uint32_t incl = mc_wave_scan_add((uint32_t)cnt);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), excl = incl - (uint32_t)cnt;
     uint32_t base;
     if (total > MC_EN_BLK) {                     // rare: a long range, reserved directly
@@ -484,7 +494,7 @@ __device__ __forceinline__ unsigned long long mc_en_process(const McIndex &X, un
         start = R->start; c0 = R->cum[k6];
         const int ns = (int)R->cum[k6 + 1] - c0;
         heavy = ns > 8;
-        if (ns > 0 && !heavy) cnt = mc_group_range8(X.keys + start + c0, ns, qk, &lb);
+        if (ns > 0 && !heavy) cnt = COUNT ? mc_group_range8(X.keys + start + c0, ns, qk, &lb) : mc_group_match8(X.keys + start + c0, ns, qk, &lb);   // (the counting form wants the lower bound of an empty range too)
         if (!COUNT && heavy) {                                    // long group: the range table knows the answer (no binary search, no second queue)
             int nst_b = 0;
             cnt = mc_rt_lookup(X.rt, X.rt_mask, (uint32_t)bucket, qk, &nst_b);
@@ -532,8 +542,13 @@ __device__ __forceinline__ unsigned long long mc_en_heavy(const McIndex &X, unsi
 #else
 #define MC_TICK(k) do { } while (0)
 #endif
+#ifdef MC_EN_WPE                          // (experiments: force an occupancy)
+#define MC_EN_ATTR __attribute__((amdgpu_waves_per_eu(MC_EN_WPE, MC_EN_WPE)))
+#else
+#define MC_EN_ATTR
+#endif
 template <int MC_EN_WAVES, bool COUNT>
-__global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTables *__restrict__ T, McIndex X, const uint32_t *__restrict__ bitmap,
+__global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTables *__restrict__ T, McIndex X, const uint32_t *__restrict__ bitmap,
                                                                    const uint8_t *__restrict__ frames, int FP, int L, int64_t nreads, McSeedTask *tasks,
                                                                    uint32_t cap, uint32_t *counters, unsigned long long *stats)
 {
@@ -542,13 +557,13 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
     const int lane = mc_lane(), wv = threadIdx.x >> 6;
     McEnWave *W = (McEnWave *)(smem + 64 + (size_t)wv * MC_EN_WAVE_BYTES(COUNT));
     uint8_t *fr_all = smem + 64 + (size_t)MC_EN_WAVES * MC_EN_WAVE_BYTES(COUNT);
-    const int FPs = (FP + 15) & ~15;
+    const int FPn = MC_EN_ROW(FP);
     const int nchunk = MC_EN_NCHUNK(L);                                    // chunks of 64 positions per frame
     const int ql0 = L / 3, ql1 = (L - 1) / 3, ql2 = (L - 2) / 3;           // frame lengths (frames f and f + 3 alike) and the running
     const int cn0 = ql0 > 6 ? ql0 - 6 : 0, cn1 = ql1 > 6 ? ql1 - 6 : 0, cn2 = ql2 > 6 ? ql2 - 6 : 0;   // number of seed positions of the frames
     const int cum1 = cn0, cum2 = cum1 + cn1, cum3 = cum2 + cn2, cum4 = cum3 + cn0, cum5 = cum4 + cn1, cum6 = cum5 + cn2;
-    uint8_t *fr = fr_all + (size_t)wv * (6 * FPs + 6 * nchunk * (512 + 128));
-    unsigned long long *pre = (unsigned long long *)(fr + 6 * FPs);        // per (frame, chunk, lane): seed 20 | g6..g9 16 | valid 1 | bucket occupied 1
+    uint8_t *fr = fr_all + (size_t)wv * (6 * FPn + 6 * nchunk * (512 + 128));
+    unsigned long long *pre = (unsigned long long *)(fr + 6 * FPn);        // per (frame, chunk, lane): seed 20 | g6..g9 16 | valid 1 | bucket occupied 1 | g3 g4 g5 12
     uint16_t *dq = (uint16_t *)(pre + 6 * nchunk * 64);                    // positions whose neighbourhood waits for the exact probes' results
     if (threadIdx.x < 32) grp[threadIdx.x] = T->grp[threadIdx.x];
     if (lane == 0) { W->blk_base = 0; W->blk_used = MC_EN_BLK; }
@@ -563,40 +578,46 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
     for (int64_t r = (int64_t)blockIdx.x * MC_EN_WAVES + wv; r < nreads; r += nw) {
         int qn = 0, hn = 0, en = 0;
         MC_TICK(0);
-        {   // stage the six frames of this read (rows of FP bytes) into the wave's LDS area, clear the flags
+        {   // stage the six frames of this read as reduced-alphabet codes, two per byte (rows of FPn bytes, padded with the
+            // invalid code: a seed's key residues past the frame end then read as invalid by themselves); clear the flags
             const uint8_t *src = frames + r * 6 * FP;
-            for (int f = 0; f < 6; f++) for (int i = lane; i < FP; i += 64) fr[f * FPs + i] = src[f * FP + i];
+            for (int f = 0; f < 6; f++)
+                for (int i = lane; i < FPn; i += 64) {
+                    uint32_t g0 = MC_INVGRP, g1 = MC_INVGRP;
+                    if (2 * i < FP) { const uint32_t two = *(const uint16_t *)(src + f * FP + 2 * i); g0 = grp[two & 0xFF]; g1 = grp[two >> 8]; }   // (FP is a multiple of 4)
+                    fr[f * FPn + i] = (uint8_t)(g0 | (g1 << 4));
+                }
             if (lane < 36) { ((uint32_t *)W->setter)[lane] = 0; ((uint32_t *)W->hit)[lane] = 0; }
             mc_wave_sync();
         }
         // what both passes need of every position - the 6-mer's bucket, the four key residues, whether the bucket holds
-        // anything - is worked out once; the six bucket-bitmap gathers of a chunk are in flight together
+        // anything - is worked out once (ten codes = 40 bits out of three aligned words of the row); the six bucket-bitmap
+        // gathers of a chunk are in flight together
         for (int c = 0; c < nchunk; c++) {
-            uint32_t sdv[6], gkv[6], bw[6];
+            uint32_t sdv[6], gkv[6], bw[6], d3v[6];
             bool vd[6];
 #pragma unroll
             for (int f = 0; f < 6; f++) {
-                const int qlen = (L - f % 3) / 3, pos = c * 64 + lane;
-                const uint8_t *q = fr + f * FPs;
-                uint32_t seed = 0, gk = 0;
-                bool ok = pos + 6 < qlen;
-                if (ok) {
-                    bool bad = false;
-                    for (int k = 0; k < 6; k++) { const uint32_t gg = grp[q[pos + k]]; bad |= (gg == MC_INVGRP); seed = seed * 10 + gg; }
-                    const int rest = qlen - pos - 6;
-                    const uint32_t g6 = rest >= 1 ? grp[q[pos + 6]] : MC_INVGRP, g7 = rest >= 2 ? grp[q[pos + 7]] : MC_INVGRP;
-                    const uint32_t g8 = rest >= 3 ? grp[q[pos + 8]] : MC_INVGRP, g9 = rest >= 4 ? grp[q[pos + 9]] : MC_INVGRP;
-                    gk = (g6 << 12) | (g7 << 8) | (g8 << 4) | g9;
-                    ok = !bad;
-                }
-                sdv[f] = ok ? seed : 0u; gkv[f] = gk; vd[f] = ok;
+                const int qlen = f % 3 == 0 ? ql0 : f % 3 == 1 ? ql1 : ql2, pos = c * 64 + lane;
+                const uint32_t *rw = (const uint32_t *)(fr + f * FPn) + (pos >> 3);
+                const int o4 = (pos & 7) * 4;
+                const uint32_t w0 = rw[0], w1 = rw[1], w2 = rw[2];
+                unsigned long long v = (((unsigned long long)w1 << 32) | w0) >> o4;
+                if (o4 == 28) v |= (unsigned long long)w2 << 36;
+                const uint32_t six = (uint32_t)v & 0xFFFFFFu, y = six ^ 0xAAAAAAu;
+                const bool bad = ((y - 0x111111u) & ~y & 0x888888u) != 0;      // one of the six codes is the invalid one
+                const uint32_t seed = (six & 15u) * 100000u + ((six >> 4) & 15u) * 10000u + ((six >> 8) & 15u) * 1000u + ((six >> 12) & 15u) * 100u + ((six >> 16) & 15u) * 10u + (six >> 20);
+                const uint32_t hi4 = (uint32_t)(v >> 24) & 0xFFFFu;            // g6 lowest
+                const uint32_t gk = ((hi4 & 15u) << 12) | (((hi4 >> 4) & 15u) << 8) | (((hi4 >> 8) & 15u) << 4) | (hi4 >> 12);
+                const bool ok = pos + 6 < qlen && !bad;
+                sdv[f] = ok ? seed : 0u; gkv[f] = gk; vd[f] = ok; d3v[f] = (six >> 12) & 0xFFFu;
             }
 #pragma unroll
             for (int f = 0; f < 6; f++) bw[f] = bitmap[sdv[f] >> 5];
 #pragma unroll
             for (int f = 0; f < 6; f++)
                 pre[(f * nchunk + c) * 64 + lane] = (unsigned long long)sdv[f] | ((unsigned long long)gkv[f] << 20) | ((unsigned long long)(vd[f] ? 1u : 0u) << 36) |
-                                                     ((unsigned long long)((bw[f] >> (sdv[f] & 31)) & 1u) << 37);
+                                                     ((unsigned long long)((bw[f] >> (sdv[f] & 31)) & 1u) << 37) | ((unsigned long long)d3v[f] << 38);
         }
         mc_wave_sync();
         // Per position: its exact 9-mer, and its one-substitution 10-mers in four groups of ten probes (groups 0..2 =
@@ -616,7 +637,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
         for (int pass = 0; pass < 2; pass++) {
             int flat0 = 0, dpos = 0;
             bool more = true;
-            uint32_t wm = 0;                             // groups of this lane's position that still have to enter eq
+            uint32_t wm = 0, wdig = 0;                   // groups of this lane's position that still have to enter eq; their own residues at the wildcard offsets
             unsigned long long wbase = 0;                // seed | key | position | frame of this lane's position
             uint32_t pm = 0;                             // surviving probes of this lane's expanded pair ...
             unsigned long long xi = 0;                   // ... and the pair itself
@@ -651,7 +672,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                     const int gc = (int)((xi >> 47) & 3), sd = (int)(xi & 0xFFFFF);
                     const uint32_t xk = (uint32_t)((xi >> 20) & 0xFFFF);
                     const int st = gc == 0 ? 10 : gc == 1 ? 1 : gc == 2 ? 100 : 0;
-                    const int dd = gc == 0 ? (sd / 10) % 10 : gc == 1 ? sd % 10 : (sd / 100) % 10;
+                    const int dd = (int)((xi >> 53) & 15);
                     const int s0 = sd - dd * st;                         // the bucket with the substituted digit taken out (gc 3: the bucket itself)
                     const unsigned long long keep = xi & 0x00007FF000000000ull;
                     for (;;) {
@@ -676,7 +697,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                     const int gl = (int)((xi >> 47) & 3), sd = (int)(xi & 0xFFFFF);
                     const uint32_t xk = (uint32_t)((xi >> 20) & 0xFFFF);
                     const int st = gl == 0 ? 10 : gl == 1 ? 1 : gl == 2 ? 100 : 0;
-                    const int d = gl == 0 ? (sd / 10) % 10 : gl == 1 ? sd % 10 : gl == 2 ? (sd / 100) % 10 : (int)(xk >> 12);
+                    const int d = (int)((xi >> 53) & 15);                // the position's own residue at the wildcard offset
                     uint32_t ok = 0;
                     if (COUNT) {
 #pragma unroll
@@ -687,7 +708,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                             ok |= (uint32_t)c << j;
                         }
                     } else {   // pair filter: one 16-byte block answers for the ten residues (lanes without a pair read block 0)
-                        const uint32_t hp = mc_pair_hash((uint32_t)sd, xk, gl);
+                        const uint32_t hp = mc_pair_hash_d((uint32_t)sd, xk, gl, (uint32_t)d);
                         const uint4 blk = ((const uint4 *)X.pair)[act ? mc_pair_block(hp) : 0u];
                         ok = act ? (mc_pair_test4(blk.x, blk.y, blk.z, blk.w, hp) & ~(1u << d) & 0x3FFu) : 0u;
                     }
@@ -701,7 +722,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                         const unsigned long long wmm = __ballot(wm != 0);
                         if (wmm == 0 || en >= 64) break;
                         const int gl = __builtin_ctz(wm | 16u);
-                        if (wm) W->eq[en + __popcll(wmm & lt)] = wbase | ((unsigned long long)gl << 47);
+                        if (wm) W->eq[en + __popcll(wmm & lt)] = wbase | ((unsigned long long)gl << 47) | ((unsigned long long)((wdig >> (4 * gl)) & 15u) << 53);
                         en += __popcll(wmm);
                         wm &= wm - 1;
                     }
@@ -739,6 +760,8 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                     uint32_t qk = 0, qk0 = 0;
                     const unsigned long long pw = pre[idx];
                     const int seed = (int)(pw & 0xFFFFF);
+                    const uint32_t d3 = (uint32_t)(pw >> 38) & 15u, d4 = (uint32_t)(pw >> 42) & 15u, d5 = (uint32_t)(pw >> 46) & 15u;   // bucket digits at offsets 3, 4, 5
+                    wdig = d4 | (d5 << 4) | (d3 << 8) | ((uint32_t)((pw >> 32) & 15) << 12);   // the residue at the wildcard offset of groups 0..3
                     if (here && ((pw >> 36) & 1)) {
                         const bool selfbucket = (pw >> 37) & 1;
                         const int g6 = (int)((pw >> 32) & 15), g7 = (int)((pw >> 28) & 15), g8 = (int)((pw >> 24) & 15), g9 = (int)((pw >> 20) & 15);
@@ -774,7 +797,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                         // both filters are asked before either answer is looked at: their reads are in flight together
                         const bool ask = live || defer;
                         const bool any9 = !COUNT && __ballot(live0), anyw = !COUNT && __ballot(ask);
-                        uint32_t fw9 = 0, fb9 = 0, ctx = 0;
+                        uint32_t fw9 = 0, fb9 = 0, ctx = 0, wsum = 0;
                         uint4 q0 = {0, 0, 0, 0}, q1 = {0, 0, 0, 0};
                         if (any9) {                                      // the exact 9-mer: its own Bloom filter, then straight into q
                             const uint32_t hh = mc_filter_hash((uint32_t)seed, qk0);
@@ -785,6 +808,7 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                             ctx = mc_wild_ctx((uint32_t)seed, qk);
                             const uint4 *ln = (const uint4 *)X.wild + (size_t)(ask ? mc_wild_line(ctx) : 0u) * 2;
                             q0 = ln[0]; q1 = ln[1];
+                            wsum = mc_wild_sum(ctx, d3, d4, d5, qk >> 12);
                         }
                         const bool pr = live0 && (COUNT || (fw9 & fb9) == fb9);
                         const unsigned long long prm = __ballot(pr);
@@ -795,8 +819,8 @@ __global__ void __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTable
                         uint32_t wmt = 0xFu;                             // counting form: every probe is generated and searched
                         if (!COUNT) {
                             wmt = 0;
-                            if (ask) wmt = (mc_wild_test2(q0.x, q0.y, mc_wild_bits(ctx, (uint32_t)seed, qk, 0)) ? 1u : 0u) | (mc_wild_test2(q0.z, q0.w, mc_wild_bits(ctx, (uint32_t)seed, qk, 1)) ? 2u : 0u) |
-                                            (mc_wild_test2(q1.x, q1.y, mc_wild_bits(ctx, (uint32_t)seed, qk, 2)) ? 4u : 0u) | (mc_wild_test2(q1.z, q1.w, mc_wild_bits(ctx, (uint32_t)seed, qk, 3)) ? 8u : 0u);
+                            if (ask) wmt = (mc_wild_test2(q0.x, q0.y, mc_wild_bits_s(wsum, d4, 0)) ? 1u : 0u) | (mc_wild_test2(q0.z, q0.w, mc_wild_bits_s(wsum, d5, 1)) ? 2u : 0u) |
+                                            (mc_wild_test2(q1.x, q1.y, mc_wild_bits_s(wsum, d3, 2)) ? 4u : 0u) | (mc_wild_test2(q1.z, q1.w, mc_wild_bits_s(wsum, qk >> 12, 3)) ? 8u : 0u);
                         }
                         wm = live ? wmt : 0u;
                         defer = defer && wmt != 0;
@@ -1863,8 +1887,7 @@ static int stage_a(mc_handle *h, McCtx &c)
     }
     HIPCK(hipEventRecord(c.ev[1], st));
     if (h->fast_enum) {
-        const int FPs = (FP + 15) & ~15;
-        const size_t per_wave = MC_EN_WAVE_BYTES(h->count_traffic) + (size_t)6 * FPs + (size_t)6 * MC_EN_NCHUNK(L) * (512 + 128);
+        const size_t per_wave = MC_EN_WAVE_BYTES(h->count_traffic) + (size_t)6 * MC_EN_ROW(FP) + (size_t)6 * MC_EN_NCHUNK(L) * (512 + 128);
         // Waves per workgroup: the kernel needs ~138 VGPRs; under __launch_bounds__(1024) the compiler fits it into 128 (one spill),
         // i.e. 4 waves per SIMD - the best measured shape (2 per SIMD: 21.9 ms per 1 M reads of 150 bp, 3: 16.2, 4: 13.7; 5 and 6 forced
         // with amdgpu_waves_per_eu spill 28 / 50 registers and bring 13.2 / 13.8).  So: 16 waves in one workgroup per CU when the LDS

@@ -63,7 +63,7 @@ int main(int argc, char **argv)
         McIndex Xc; Xc.res = H.res.data(); Xc.off = H.off.data(); Xc.bstart = H.bstart.data(); Xc.post = H.post.data(); Xc.keys = H.keys.data(); Xc.rec = H.rec.data(); Xc.filt = H.filt.data(); Xc.wild = H.wild.data(); Xc.pair = H.pair.data(); Xc.rt = H.rt.data(); Xc.rt_mask = H.rt_mask; Xc.nseq = H.nseq;
         if (H.rec.empty()) { fprintf(stderr, "scan check: the index has no bucket records\n"); return 3; }
         fprintf(stderr, "largest bucket: %u postings\n", H.max_bucket);
-        long checked = 0, bad = 0, fneg = 0, fpos = 0, fq = 0, f9q = 0, f9pos = 0, wq = 0, wpos = 0, rtq = 0, rtbad = 0, pq = 0, ppos = 0;
+        long checked = 0, bad = 0, fneg = 0, fpos = 0, fq = 0, f9q = 0, f9pos = 0, wq = 0, wpos = 0, rtq = 0, rtbad = 0, pq = 0, ppos = 0, gmq = 0, gmbad = 0;
         for (int b = 0; b < MC_NBUCKET; b++) {
             uint32_t n = H.bstart[b + 1] - H.bstart[b];
             for (uint32_t i = 0; i < n; i++) {
@@ -82,6 +82,13 @@ int main(int argc, char **argv)
                     if (mc_klen(qk) >= 3 && (mc_klen(qk) == 4 || (qk & 0xF) == 0xF)) {   // probe forms: in a long group the range table answers
                         const McBucketRec &RR = H.rec[b];
                         const int k6 = (int)(qk >> 12);
+                        if (k6 <= 10 && (int)RR.cum[k6 + 1] - (int)RR.cum[k6] <= 8 && (int)RR.cum[k6 + 1] > (int)RR.cum[k6]) {   // short group: the probe form of the scan
+                            int la = 0, lb2 = 0;
+                            const int ns = (int)RR.cum[k6 + 1] - (int)RR.cum[k6];
+                            const int ca = mc_group_range8(H.keys.data() + RR.start + RR.cum[k6], ns, qk, &la), cb = mc_group_match8(H.keys.data() + RR.start + RR.cum[k6], ns, qk, &lb2);
+                            gmq++;
+                            if (ca != cb || (ca > 0 && la != lb2)) gmbad++;
+                        }
                         if ((int)RR.cum[k6 + 1] - (int)RR.cum[k6] > 8) {
                             int n3 = 0;
                             const int r3 = mc_rt_lookup(H.rt.data(), H.rt_mask, (uint32_t)b, qk, &n3);
@@ -131,7 +138,8 @@ int main(int argc, char **argv)
           long setp = 0; for (uint32_t w : H.pair) setp += __builtin_popcount(w);
           fprintf(stderr, "pair filter: %ld questions, %ld positive among near misses, %.1f %% of the cell bits set\n", pq, ppos, 100.0 * (double)setp / (120.0 * MC_PAIR_BLOCKS)); }
         { size_t used = 0; for (unsigned long long e : H.rt) used += (e != ~0ull); fprintf(stderr, "range table: %zu entries in %zu slots; %ld probes into long groups checked, %ld differ from the binary searches\n", used, H.rt.size(), rtq, rtbad); }
-        return (bad || fneg || rtbad) ? 3 : 0;
+        fprintf(stderr, "probe form of the group scan: %ld probes, %ld differ from the general form\n", gmq, gmbad);
+        return (bad || fneg || rtbad || gmbad) ? 3 : 0;
     }
     int read_len = rs.empty() ? 0 : (int)rs[0].size();
     static McTables T;

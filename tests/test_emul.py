@@ -101,7 +101,8 @@ def test_gpu_index_structures_agree_with_the_binary_searches(emul_bin, markers_f
     seed kernel uses instead of the reference's per-bucket binary searches (ExtendSeq2Set):
       * bucket records + group scan (mc_key_range_rec): same posting range, same start index, same reference key-probe count;
       * 10-mer / 9-mer Bloom filters and the wildcard filter: no false negative (a probe with a range always passes);
-      * range table of the long groups: same range and start index as the binary searches."""
+      * range table of the long groups: same range and start index as the binary searches;
+      * pair filter: no false negative; probe form of the short-group scan (mc_group_match8): same range as the general form."""
     fa = tmp_path / "one.fa"
     fa.write_text(">0\n" + "ACGT" * 25 + "\n")
     env = dict(os.environ, MC_CHECK_SCAN="1")
@@ -111,6 +112,7 @@ def test_gpu_index_structures_agree_with_the_binary_searches(emul_bin, markers_f
     assert " 0 mismatches" in err
     assert " 0 false negatives" in err
     assert " 0 differ from the binary searches" in err
+    assert " 0 differ from the general form" in err
 
 
 def test_seg_variants_agree_frame_by_frame(emul_bin, markers_faa, tmp_path):
