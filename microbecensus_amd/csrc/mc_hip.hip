@@ -559,11 +559,9 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
     uint8_t *fr_all = smem + 64 + (size_t)MC_EN_WAVES * MC_EN_WAVE_BYTES(COUNT);
     const int FPn = MC_EN_ROW(FP);
     const int nchunk = MC_EN_NCHUNK(L);                                    // chunks of 64 positions per frame
-    const int ql0 = L / 3, ql1 = (L - 1) / 3, ql2 = (L - 2) / 3;           // frame lengths (frames f and f + 3 alike) and the running
-    const int cn0 = ql0 > 6 ? ql0 - 6 : 0, cn1 = ql1 > 6 ? ql1 - 6 : 0, cn2 = ql2 > 6 ? ql2 - 6 : 0;   // number of seed positions of the frames
-    const int cum1 = cn0, cum2 = cum1 + cn1, cum3 = cum2 + cn2, cum4 = cum3 + cn0, cum5 = cum4 + cn1, cum6 = cum5 + cn2;
+    const int ql0 = L / 3, ql1 = (L - 1) / 3, ql2 = (L - 2) / 3;           // frame lengths (frames f and f + 3 alike)
     uint8_t *fr = fr_all + (size_t)wv * (6 * FPn + 6 * nchunk * (512 + 128));
-    unsigned long long *pre = (unsigned long long *)(fr + 6 * FPn);        // per (frame, chunk, lane): seed 20 | g6..g9 16 | valid 1 | bucket occupied 1 | g3 g4 g5 12
+    unsigned long long *pre = (unsigned long long *)(fr + 6 * FPn);        // the positions of the read that probe anything (at most 6 * nchunk * 64)
     uint16_t *dq = (uint16_t *)(pre + 6 * nchunk * 64);                    // positions whose neighbourhood waits for the exact probes' results
     if (threadIdx.x < 32) grp[threadIdx.x] = T->grp[threadIdx.x];
     if (lane == 0) { W->blk_base = 0; W->blk_used = MC_EN_BLK; }
@@ -593,6 +591,7 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
         // what both passes need of every position - the 6-mer's bucket, the four key residues, whether the bucket holds
         // anything - is worked out once (ten codes = 40 bits out of three aligned words of the row); the six bucket-bitmap
         // gathers of a chunk are in flight together
+        int npre = 0;                                    // positions kept
         for (int c = 0; c < nchunk; c++) {
             uint32_t sdv[6], gkv[6], bw[6], d3v[6];
             bool vd[6];
@@ -614,10 +613,29 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
             }
 #pragma unroll
             for (int f = 0; f < 6; f++) bw[f] = bitmap[sdv[f] >> 5];
+            // what the position will do is decided here, and only the positions that do something are kept (a third have an
+            // invalid residue in the 6-mer or nothing to ask): entry = seed 20 | g6..g9 16 | position 8 | frame 3 (the four
+            // fields of a queue item, in place) | exact probe 1 | neighbourhood 1 | neighbourhood decided in pass 1 1 | g3 g4 g5 12
 #pragma unroll
-            for (int f = 0; f < 6; f++)
-                pre[(f * nchunk + c) * 64 + lane] = (unsigned long long)sdv[f] | ((unsigned long long)gkv[f] << 20) | ((unsigned long long)(vd[f] ? 1u : 0u) << 36) |
-                                                     ((unsigned long long)((bw[f] >> (sdv[f] & 31)) & 1u) << 37) | ((unsigned long long)d3v[f] << 38);
+            for (int f = 0; f < 6; f++) {
+                const int qlen = f % 3 == 0 ? ql0 : f % 3 == 1 ? ql1 : ql2, pos = c * 64 + lane, rest = qlen - pos - 6;
+                const bool occ = (bw[f] >> (sdv[f] & 31)) & 1u;
+                const uint32_t gk = gkv[f];
+                const bool v6 = (gk >> 12) != MC_INVGRP, v7 = ((gk >> 8) & 15u) != MC_INVGRP, v8 = ((gk >> 4) & 15u) != MC_INVGRP, v9 = (gk & 15u) != MC_INVGRP;
+                const bool live0 = vd[f] && occ && rest >= 3 && v6 && v7;        // exact 9-mer probe: it also defines `prev` for the positions behind it
+                // The neighbourhood's validity check starts at residue `used`: 9 when the own bucket is occupied, else 8 or 6
+                // depending on whether the nearest earlier exact probe of the frame found a range (prev).  That only matters
+                // when g8, g9 are valid and g6 or g7 is not: those few positions are decided in pass 1.
+                bool live = false, defer = false;
+                if (vd[f] && rest >= 4) { if (occ) live = v6 && v7 && v9; else if (v8 && v9) { if (v6 && v7) live = true; else defer = true; } }
+                if (COUNT && vd[f]) sc.lookups += live0 ? 2 : 1;               // bucket-size probe of the exact seed, and its key-range probe
+                if (live0) atomicOr(&W->setter[f][pos >> 5], 1u << (pos & 31));
+                const bool keep = live0 || live || defer;
+                const unsigned long long km = __ballot(keep);
+                if (keep) pre[npre + __popcll(km & lt)] = (unsigned long long)sdv[f] | ((unsigned long long)gk << 20) | ((unsigned long long)pos << 36) | ((unsigned long long)f << 44) |
+                                                          ((unsigned long long)(live0 ? 1u : 0u) << 47) | ((unsigned long long)(live ? 1u : 0u) << 48) | ((unsigned long long)(defer ? 1u : 0u) << 49) | ((unsigned long long)d3v[f] << 50);
+                npre += __popcll(km);
+            }
         }
         mc_wave_sync();
         // Per position: its exact 9-mer, and its one-substitution 10-mers in four groups of ten probes (groups 0..2 =
@@ -730,82 +748,44 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
                     continue;
                 }
                 if (!more) break;
-                {   // next 64 positions: of the sweep over the frames (pass 0: the positions of the six frames are numbered through,
-                    // so every step but the last has 64 of them) or of the deferred list (pass 1)
+                {   // next 64 positions: of the kept ones (pass 0) or of the deferred list (pass 1)
                     MC_TICK(4);
-                    int pos, fl, idx, qlen;
+                    int idx;
                     bool here;
                     uint32_t wmd = 0;
                     if (pass == 0) {
-                        if (flat0 >= cum6) { more = false; continue; }
-                        const int flat = flat0 + lane;
+                        if (flat0 >= npre) { more = false; continue; }
+                        idx = flat0 + lane;
                         flat0 += 64;
-                        here = flat < cum6;
-                        fl = (flat >= cum1) + (flat >= cum2) + (flat >= cum3) + (flat >= cum4) + (flat >= cum5);
-                        pos = flat - (fl == 0 ? 0 : fl == 1 ? cum1 : fl == 2 ? cum2 : fl == 3 ? cum3 : fl == 4 ? cum4 : cum5);
-                        const int fm = fl >= 3 ? fl - 3 : fl;
-                        qlen = fm == 0 ? ql0 : fm == 1 ? ql1 : ql2;
-                        idx = here ? fl * nchunk * 64 + pos : 0;
+                        here = idx < npre;
                     } else {
                         if (dpos >= dn) { more = false; continue; }
                         here = dpos + lane < dn;
                         const uint32_t e = here ? dq[dpos + lane] : 0u;      // position | the wildcard filter's answer, asked in pass 0
                         dpos += 64;
                         idx = (int)(e & 0x7FFu); wmd = e >> 11;
-                        fl = idx / (nchunk * 64);
-                        pos = (idx - fl * nchunk * 64);                  // chunk * 64 + lane = the position
-                        qlen = 0;
                     }
-                    bool live0 = false, live = false, defer = false;     // exact probe; neighbourhood; neighbourhood decided later
-                    uint32_t qk = 0, qk0 = 0;
-                    const unsigned long long pw = pre[idx];
-                    const int seed = (int)(pw & 0xFFFFF);
-                    const uint32_t d3 = (uint32_t)(pw >> 38) & 15u, d4 = (uint32_t)(pw >> 42) & 15u, d5 = (uint32_t)(pw >> 46) & 15u;   // bucket digits at offsets 3, 4, 5
-                    wdig = d4 | (d5 << 4) | (d3 << 8) | ((uint32_t)((pw >> 32) & 15) << 12);   // the residue at the wildcard offset of groups 0..3
-                    if (here && ((pw >> 36) & 1)) {
-                        const bool selfbucket = (pw >> 37) & 1;
-                        const int g6 = (int)((pw >> 32) & 15), g7 = (int)((pw >> 28) & 15), g8 = (int)((pw >> 24) & 15), g9 = (int)((pw >> 20) & 15);
-                        const bool v6 = g6 != MC_INVGRP, v7 = g7 != MC_INVGRP, v8 = g8 != MC_INVGRP, v9 = g9 != MC_INVGRP;
-                        qk = ((uint32_t)g6 << 12) | ((uint32_t)g7 << 8) | ((uint32_t)g8 << 4) | (uint32_t)g9;
-                        if (pass == 0) {
-                            const int rest = qlen - pos - 6;
-                            if (COUNT) sc.lookups++;                             // bucket-size probe of the exact seed
-                            if (selfbucket && rest >= 3 && v6 && v7) {
-                                atomicOr(&W->setter[fl][pos >> 5], 1u << (pos & 31));
-                                qk0 = (qk & 0xFFF0u) | 0xFu;
-                                if (COUNT) sc.lookups++;                         // its key-range probe
-                                live0 = true;
-                            }
-                            // The neighbourhood's validity check starts at residue `used`: 9 when the own bucket is occupied, else 8
-                            // or 6 depending on whether the nearest earlier exact probe of the frame found a range (prev).  That
-                            // only matters when g8, g9 are valid and g6 or g7 is not: those few positions wait for pass 1 - with
-                            // the wildcard filter's answer, which is asked now (no answer, no wait).
-                            if (rest >= 4) {
-                                if (selfbucket) live = v6 && v7 && v9;
-                                else if (v8 && v9) { if (v6 && v7) live = true; else defer = true; }
-                            }
-                        } else {   // a deferred position: own bucket empty, g8 and g9 valid, g6 or g7 invalid -> live iff prev == 9
-                            int w = pos >> 5;
-                            uint32_t m = W->setter[fl][w] & ((1u << (pos & 31)) - 1);
-                            while (m == 0 && w > 0) { w--; m = W->setter[fl][w]; }
-                            if (m) { const int bb = 31 - __builtin_clz(m); live = (W->hit[fl][w] >> bb) & 1; }
-                        }
-                    }
-                    const unsigned long long posf = ((unsigned long long)pos << 36) | ((unsigned long long)fl << 44);
-                    wbase = (unsigned long long)seed | ((unsigned long long)qk << 20) | posf;
+                    const unsigned long long pw = pre[here ? idx : 0];
+                    const uint32_t seed = (uint32_t)(pw & 0xFFFFF), qk = (uint32_t)(pw >> 20) & 0xFFFFu;
+                    const uint32_t d3 = (uint32_t)(pw >> 50) & 15u, d4 = (uint32_t)(pw >> 54) & 15u, d5 = (uint32_t)(pw >> 58) & 15u;   // bucket digits at offsets 3, 4, 5
+                    wdig = d4 | (d5 << 4) | (d3 << 8) | ((qk >> 12) << 12);  // the residue at the wildcard offset of groups 0..3
+                    wbase = pw & 0x00007FFFFFFFFFFFull;                      // seed | key | position | frame: a queue item without its phase
                     if (pass == 0) {
+                        const bool live0 = here && ((pw >> 47) & 1), live = here && ((pw >> 48) & 1);
+                        bool defer = here && ((pw >> 49) & 1);
                         // both filters are asked before either answer is looked at: their reads are in flight together
                         const bool ask = live || defer;
                         const bool any9 = !COUNT && __ballot(live0), anyw = !COUNT && __ballot(ask);
-                        uint32_t fw9 = 0, fb9 = 0, ctx = 0, wsum = 0;
+                        const uint32_t qk0 = (qk & 0xFFF0u) | 0xFu;
+                        uint32_t fw9 = 0, fb9 = 0, wsum = 0;
                         uint4 q0 = {0, 0, 0, 0}, q1 = {0, 0, 0, 0};
                         if (any9) {                                      // the exact 9-mer: its own Bloom filter, then straight into q
-                            const uint32_t hh = mc_filter_hash((uint32_t)seed, qk0);
+                            const uint32_t hh = mc_filter_hash(seed, qk0);
                             fb9 = mc_filter_bits(hh);
                             fw9 = X.filt[live0 ? mc_filter9_word(hh) : 0u];
                         }
                         if (anyw) {                                      // wildcard filter: one 32-byte line answers for the four groups
-                            ctx = mc_wild_ctx((uint32_t)seed, qk);
+                            const uint32_t ctx = mc_wild_ctx(seed, qk);
                             const uint4 *ln = (const uint4 *)X.wild + (size_t)(ask ? mc_wild_line(ctx) : 0u) * 2;
                             q0 = ln[0]; q1 = ln[1];
                             wsum = mc_wild_sum(ctx, d3, d4, d5, qk >> 12);
@@ -813,7 +793,7 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
                         const bool pr = live0 && (COUNT || (fw9 & fb9) == fb9);
                         const unsigned long long prm = __ballot(pr);
                         if (prm) {
-                            if (pr) W->q[qn + __popcll(prm & lt)] = (unsigned long long)seed | ((unsigned long long)qk0 << 20) | posf;   // phase 0
+                            if (pr) W->q[qn + __popcll(prm & lt)] = wbase | (0xFull << 20);   // phase 0; key g6 g7 g8 F
                             qn += __popcll(prm);
                         }
                         uint32_t wmt = 0xFu;                             // counting form: every probe is generated and searched
@@ -823,11 +803,29 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
                                             (mc_wild_test2(q1.x, q1.y, mc_wild_bits_s(wsum, d3, 2)) ? 4u : 0u) | (mc_wild_test2(q1.z, q1.w, mc_wild_bits_s(wsum, qk >> 12, 3)) ? 8u : 0u);
                         }
                         wm = live ? wmt : 0u;
-                        defer = defer && wmt != 0;
+                        defer = defer && wmt != 0;                       // (no group can match: nothing to decide later)
                         const unsigned long long dm = __ballot(defer);
                         if (dm) { if (defer) dq[dn + __popcll(dm & lt)] = (uint16_t)((uint32_t)idx | (wmt << 11)); dn += __popcll(dm); }
-                        if (prm | dm) mc_wave_sync();
-                    } else wm = live ? wmd : 0u;
+                    } else {   // a deferred position: own bucket empty, g8 and g9 valid, g6 or g7 invalid -> live iff prev == 9
+                        bool live = false;
+                        if (here) {
+                            const int pos = (int)((pw >> 36) & 0xFF), fl = (int)((pw >> 44) & 7);
+                            int w = pos >> 5;
+                            uint32_t m = W->setter[fl][w] & ((1u << (pos & 31)) - 1);
+                            while (m == 0 && w > 0) { w--; m = W->setter[fl][w]; }
+                            if (m) { const int bb = 31 - __builtin_clz(m); live = (W->hit[fl][w] >> bb) & 1; }
+                        }
+                        wm = live ? wmd : 0u;
+                    }
+                    for (;;) {   // the groups enter eq at once while it has room (else from the state above)
+                        const unsigned long long wmm = __ballot(wm != 0);
+                        if (wmm == 0 || en >= 64) break;
+                        const int gl = __builtin_ctz(wm | 16u);
+                        if (wm) W->eq[en + __popcll(wmm & lt)] = wbase | ((unsigned long long)gl << 47) | ((unsigned long long)((wdig >> (4 * gl)) & 15u) << 53);
+                        en += __popcll(wmm);
+                        wm &= wm - 1;
+                    }
+                    mc_wave_sync();
                 }
             }
             mc_wave_sync();
