@@ -560,6 +560,9 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
     const int FPn = MC_EN_ROW(FP);
     const int nchunk = MC_EN_NCHUNK(L);                                    // chunks of 64 positions per frame
     const int ql0 = L / 3, ql1 = (L - 1) / 3, ql2 = (L - 2) / 3;           // frame lengths (frames f and f + 3 alike)
+    const int cn0 = ql0 > 6 ? ql0 - 6 : 0, cn1 = ql1 > 6 ? ql1 - 6 : 0, cn2 = ql2 > 6 ? ql2 - 6 : 0;   // seed positions of the frames, and their running sums
+    const int cum1 = cn0, cum2 = cum1 + cn1, cum3 = cum2 + cn2, cum4 = cum3 + cn0, cum5 = cum4 + cn1, cum6 = cum5 + cn2;
+    const uint32_t rcp_fpn = (65536u + (uint32_t)FPn - 1u) / (uint32_t)FPn;   // i / FPn = (i * rcp_fpn) >> 16 for the i < 6 * FPn in use
     uint8_t *fr = fr_all + (size_t)wv * (6 * FPn + 6 * nchunk * (512 + 128));
     unsigned long long *pre = (unsigned long long *)(fr + 6 * FPn);        // the positions of the read that probe anything (at most 6 * nchunk * 64)
     uint16_t *dq = (uint16_t *)(pre + 6 * nchunk * 64);                    // positions whose neighbourhood waits for the exact probes' results
@@ -579,26 +582,33 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
         {   // stage the six frames of this read as reduced-alphabet codes, two per byte (rows of FPn bytes, padded with the
             // invalid code: a seed's key residues past the frame end then read as invalid by themselves); clear the flags
             const uint8_t *src = frames + r * 6 * FP;
-            for (int f = 0; f < 6; f++)
-                for (int i = lane; i < FPn; i += 64) {
-                    uint32_t g0 = MC_INVGRP, g1 = MC_INVGRP;
-                    if (2 * i < FP) { const uint32_t two = *(const uint16_t *)(src + f * FP + 2 * i); g0 = grp[two & 0xFF]; g1 = grp[two >> 8]; }   // (FP is a multiple of 4)
-                    fr[f * FPn + i] = (uint8_t)(g0 | (g1 << 4));
-                }
+            for (int i = lane; i < 6 * FPn; i += 64) {                         // byte i of the six rows
+                const int f = (int)(((uint32_t)i * rcp_fpn) >> 16), b2 = 2 * (i - f * FPn);
+                uint32_t g0 = MC_INVGRP, g1 = MC_INVGRP;
+                if (b2 < FP) { const uint32_t two = *(const uint16_t *)(src + f * FP + b2); g0 = grp[two & 0xFF]; g1 = grp[two >> 8]; }   // (FP is a multiple of 4)
+                fr[i] = (uint8_t)(g0 | (g1 << 4));
+            }
             if (lane < 36) { ((uint32_t *)W->setter)[lane] = 0; ((uint32_t *)W->hit)[lane] = 0; }
             mc_wave_sync();
         }
-        // what both passes need of every position - the 6-mer's bucket, the four key residues, whether the bucket holds
-        // anything - is worked out once (ten codes = 40 bits out of three aligned words of the row); the six bucket-bitmap
-        // gathers of a chunk are in flight together
+        // What a seed position will do is decided here, once: the 6-mer's bucket and the four key residues (ten codes = 40
+        // bits out of three aligned words of the row), whether the bucket holds anything (bitmap gather; those of three sweeps
+        // are in flight together), and from that which probes it makes.  The positions of the six frames are numbered through
+        // (every sweep but the last has 64 of them), and only the positions that probe anything are kept - a third have an
+        // invalid residue in the 6-mer or nothing to ask: entry = seed 20 | g6..g9 16 | position 8 | frame 3 (the four fields
+        // of a queue item, in place) | exact probe 1 | neighbourhood 1 | neighbourhood decided in pass 1 1 | g3 g4 g5 12
         int npre = 0;                                    // positions kept
-        for (int c = 0; c < nchunk; c++) {
-            uint32_t sdv[6], gkv[6], bw[6], d3v[6];
-            bool vd[6];
+        for (int k0 = 0; k0 < cum6; k0 += 192) {
+            uint32_t sdv[3], gkv[3], bw[3], d3v[3], pfv[3];
+            bool vd[3];
 #pragma unroll
-            for (int f = 0; f < 6; f++) {
-                const int qlen = f % 3 == 0 ? ql0 : f % 3 == 1 ? ql1 : ql2, pos = c * 64 + lane;
-                const uint32_t *rw = (const uint32_t *)(fr + f * FPn) + (pos >> 3);
+            for (int u = 0; u < 3; u++) {
+                sdv[u] = 0; gkv[u] = 0; vd[u] = false; d3v[u] = 0; pfv[u] = 0;
+                if (k0 + u * 64 >= cum6) continue;                             // (uniform)
+                const int flat = k0 + u * 64 + lane;
+                const int f = (flat >= cum1) + (flat >= cum2) + (flat >= cum3) + (flat >= cum4) + (flat >= cum5);
+                const int pos = flat - (f == 0 ? 0 : f == 1 ? cum1 : f == 2 ? cum2 : f == 3 ? cum3 : f == 4 ? cum4 : cum5);
+                const uint32_t *rw = (const uint32_t *)(fr + f * FPn) + (pos >> 3);   // (past the last position: some words of the wave's LDS, not used)
                 const int o4 = (pos & 7) * 4;
                 const uint32_t w0 = rw[0], w1 = rw[1], w2 = rw[2];
                 unsigned long long v = (((unsigned long long)w1 << 32) | w0) >> o4;
@@ -608,32 +618,31 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
                 const uint32_t seed = (six & 15u) * 100000u + ((six >> 4) & 15u) * 10000u + ((six >> 8) & 15u) * 1000u + ((six >> 12) & 15u) * 100u + ((six >> 16) & 15u) * 10u + (six >> 20);
                 const uint32_t hi4 = (uint32_t)(v >> 24) & 0xFFFFu;            // g6 lowest
                 const uint32_t gk = ((hi4 & 15u) << 12) | (((hi4 >> 4) & 15u) << 8) | (((hi4 >> 8) & 15u) << 4) | (hi4 >> 12);
-                const bool ok = pos + 6 < qlen && !bad;
-                sdv[f] = ok ? seed : 0u; gkv[f] = gk; vd[f] = ok; d3v[f] = (six >> 12) & 0xFFFu;
+                const bool ok = flat < cum6 && !bad;
+                sdv[u] = ok ? seed : 0u; gkv[u] = gk; vd[u] = ok; d3v[u] = (six >> 12) & 0xFFFu; pfv[u] = (uint32_t)pos | ((uint32_t)f << 8);
             }
 #pragma unroll
-            for (int f = 0; f < 6; f++) bw[f] = bitmap[sdv[f] >> 5];
-            // what the position will do is decided here, and only the positions that do something are kept (a third have an
-            // invalid residue in the 6-mer or nothing to ask): entry = seed 20 | g6..g9 16 | position 8 | frame 3 (the four
-            // fields of a queue item, in place) | exact probe 1 | neighbourhood 1 | neighbourhood decided in pass 1 1 | g3 g4 g5 12
+            for (int u = 0; u < 3; u++) bw[u] = bitmap[sdv[u] >> 5];
 #pragma unroll
-            for (int f = 0; f < 6; f++) {
-                const int qlen = f % 3 == 0 ? ql0 : f % 3 == 1 ? ql1 : ql2, pos = c * 64 + lane, rest = qlen - pos - 6;
-                const bool occ = (bw[f] >> (sdv[f] & 31)) & 1u;
-                const uint32_t gk = gkv[f];
+            for (int u = 0; u < 3; u++) {
+                if (k0 + u * 64 >= cum6) break;
+                const int pos = (int)(pfv[u] & 0xFF), f = (int)(pfv[u] >> 8), fm = f >= 3 ? f - 3 : f;
+                const int rest = (fm == 0 ? cn0 : fm == 1 ? cn1 : cn2) - pos;   // residues behind the 6-mer
+                const bool occ = (bw[u] >> (sdv[u] & 31)) & 1u;
+                const uint32_t gk = gkv[u];
                 const bool v6 = (gk >> 12) != MC_INVGRP, v7 = ((gk >> 8) & 15u) != MC_INVGRP, v8 = ((gk >> 4) & 15u) != MC_INVGRP, v9 = (gk & 15u) != MC_INVGRP;
-                const bool live0 = vd[f] && occ && rest >= 3 && v6 && v7;        // exact 9-mer probe: it also defines `prev` for the positions behind it
+                const bool live0 = vd[u] && occ && rest >= 3 && v6 && v7;        // exact 9-mer probe: it also defines `prev` for the positions behind it
                 // The neighbourhood's validity check starts at residue `used`: 9 when the own bucket is occupied, else 8 or 6
                 // depending on whether the nearest earlier exact probe of the frame found a range (prev).  That only matters
                 // when g8, g9 are valid and g6 or g7 is not: those few positions are decided in pass 1.
                 bool live = false, defer = false;
-                if (vd[f] && rest >= 4) { if (occ) live = v6 && v7 && v9; else if (v8 && v9) { if (v6 && v7) live = true; else defer = true; } }
-                if (COUNT && vd[f]) sc.lookups += live0 ? 2 : 1;               // bucket-size probe of the exact seed, and its key-range probe
+                if (vd[u] && rest >= 4) { if (occ) live = v6 && v7 && v9; else if (v8 && v9) { if (v6 && v7) live = true; else defer = true; } }
+                if (COUNT && vd[u]) sc.lookups += live0 ? 2 : 1;               // bucket-size probe of the exact seed, and its key-range probe
                 if (live0) atomicOr(&W->setter[f][pos >> 5], 1u << (pos & 31));
                 const bool keep = live0 || live || defer;
                 const unsigned long long km = __ballot(keep);
-                if (keep) pre[npre + __popcll(km & lt)] = (unsigned long long)sdv[f] | ((unsigned long long)gk << 20) | ((unsigned long long)pos << 36) | ((unsigned long long)f << 44) |
-                                                          ((unsigned long long)(live0 ? 1u : 0u) << 47) | ((unsigned long long)(live ? 1u : 0u) << 48) | ((unsigned long long)(defer ? 1u : 0u) << 49) | ((unsigned long long)d3v[f] << 50);
+                if (keep) pre[npre + __popcll(km & lt)] = (unsigned long long)sdv[u] | ((unsigned long long)gk << 20) | ((unsigned long long)pfv[u] << 36) |
+                                                          ((unsigned long long)(live0 ? 1u : 0u) << 47) | ((unsigned long long)(live ? 1u : 0u) << 48) | ((unsigned long long)(defer ? 1u : 0u) << 49) | ((unsigned long long)d3v[u] << 50);
                 npre += __popcll(km);
             }
         }
@@ -1886,12 +1895,14 @@ static int stage_a(mc_handle *h, McCtx &c)
     HIPCK(hipEventRecord(c.ev[1], st));
     if (h->fast_enum) {
         const size_t per_wave = MC_EN_WAVE_BYTES(h->count_traffic) + (size_t)6 * MC_EN_ROW(FP) + (size_t)6 * MC_EN_NCHUNK(L) * (512 + 128);
-        // Waves per workgroup: the kernel needs ~138 VGPRs; under __launch_bounds__(1024) the compiler fits it into 128 (one spill),
-        // i.e. 4 waves per SIMD - the best measured shape (2 per SIMD: 21.9 ms per 1 M reads of 150 bp, 3: 16.2, 4: 13.7; 5 and 6 forced
-        // with amdgpu_waves_per_eu spill 28 / 50 registers and bring 13.2 / 13.8).  So: 16 waves in one workgroup per CU when the LDS
-        // holds them, else as many as fit.
+        // Launch shape: the kernel needs 79 VGPRs (6 waves per SIMD) and is bound by instruction issue with some latency left to
+        // hide - measured per 1 M reads of 150 bp: 16 waves per CU 6.77 ms, 20: 6.45, 24 (2 x 12, 3 x 8, 6 x 4 alike): 6.39.
+        // So: as many waves per CU as the LDS holds, up to 24, in workgroups of 12 / 8 / 4 / 16 waves.
         int waves = 0, bpc = 1;
-        for (int wv : {16, 12, 8, 4}) if (!waves && 64 + wv * per_wave <= 160 * 1024) waves = wv;
+        {
+            static const int shapes[][2] = {{12, 2}, {8, 3}, {4, 6}, {4, 5}, {16, 1}, {8, 2}, {4, 4}, {12, 1}, {4, 3}, {8, 1}, {4, 2}, {4, 1}};
+            for (const auto &sh : shapes) if (!waves && (size_t)sh[1] * (64 + sh[0] * per_wave) <= 160 * 1024) { waves = sh[0]; bpc = sh[1]; }
+        }
         if (!waves) { g_err = "reads too long for the seed kernel's LDS layout"; return -1; }
         if (const char *e = getenv("MC_EN_SHAPE")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 16 || a == 12 || a == 8 || a == 4) && b >= 1 && (size_t)b * (64 + a * per_wave) <= 160 * 1024) { waves = a; bpc = b; } }   // (experiments)
         const size_t lds2 = 64 + waves * per_wave;
