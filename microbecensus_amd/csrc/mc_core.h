@@ -82,7 +82,7 @@ struct McIndex {
     const uint32_t *wild;      // MC_WILD_LINES x 8 words: wildcard filter (mc_wild_*)
     const uint32_t *pair;      // MC_PAIR_BLOCKS x 4 words: which residues at a wildcard offset complete an index 10-mer (mc_pair_*)
     const unsigned long long *rt; uint32_t rt_mask;   // range table of the long groups (mc_rt_*): rt_mask + 1 slots
-    const uint32_t *filt;      // MC_FILT_TOTAL_WORDS words: Bloom filters over the (bucket, key) pairs of the index (10-mers, then 9-mers)
+    const uint32_t *filt;      // MC_FILT9_WORDS words: Bloom filter over the (bucket, 3-residue key) pairs of the index (exact 9-mer probes)
     int32_t nseq;
 };
 
@@ -799,28 +799,21 @@ MC_HD int mc_key_range_rec(const McBucketRec *rec, const uint16_t *keys, int see
     *nst_out = c0 + lb;
     return cnt;
 }
-// ---- 10-mer filter ------------------------------------------------------------------------------------------------
-// A 10-mer probe (4-residue key, none of them the end-of-sequence pad) can only find postings whose key is EQUAL to it:
-// a shorter database key sorts in front of the range (mc_key_lb_less: equal prefix, shorter first).  Almost all of
-// the one-substitution probes of a read find nothing (57 hits out of 5,700 for 150 bp reads), so the seed kernel asks
-// a Bloom filter over the (bucket, key) pairs first: 2 bits in one 32-bit word, 2^19 words (2 MB, L2 resident).  No
-// false negatives, ~2 % false positives; a positive goes through the exact range search as before.
-#define MC_FILT_LOG2W 19
-#define MC_FILT_WORDS (1u << MC_FILT_LOG2W)
-// The exact 9-mer probes (3-residue key, written g6 g7 g8 F) get the same treatment with a filter of their own: such a
-// probe matches exactly the postings whose first three key residues equal its own (keys shorter than 3 sort in front of
-// the range), so the filter holds (bucket, k | 0xF) of every posting with at least 3 key residues.  2^18 words (1 MB).
+// ---- 9-mer filter -------------------------------------------------------------------------------------------------
+// An exact 9-mer probe (3-residue key, written g6 g7 g8 F) matches exactly the postings whose first three key residues
+// equal its own (keys shorter than 3 sort in front of the range: mc_key_lb_less, equal prefix, shorter first).  Most exact
+// probes of a read find nothing, so the seed kernel asks a Bloom filter first: it holds (bucket, k | 0xF) of every posting
+// with at least 3 key residues, 2 bits in one 32-bit word, 2^18 words (1 MB, L2 resident).  No false negatives; a positive
+// goes through the exact range search.  (The one-substitution 10-mer probes have the wildcard and pair filters below.)
 #define MC_FILT9_LOG2W 18
 #define MC_FILT9_WORDS (1u << MC_FILT9_LOG2W)
-#define MC_FILT_TOTAL_WORDS (MC_FILT_WORDS + MC_FILT9_WORDS)   // one array: the 10-mer filter, then the 9-mer filter
 MC_HD uint32_t mc_filter_hash(uint32_t bucket, uint32_t key)
 {
     uint32_t x = bucket * 0x9E3779B1u + key * 0x85EBCA77u;
     x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
     return x;
 }
-MC_HD uint32_t mc_filter_word(uint32_t h) { return h >> (32 - MC_FILT_LOG2W); }
-MC_HD uint32_t mc_filter9_word(uint32_t h) { return MC_FILT_WORDS + (h >> (32 - MC_FILT9_LOG2W)); }
+MC_HD uint32_t mc_filter9_word(uint32_t h) { return h >> (32 - MC_FILT9_LOG2W); }
 MC_HD uint32_t mc_filter_bits(uint32_t h) { return (1u << (h & 31)) | (1u << ((h >> 5) & 31)); }
 
 // ---- wildcard filter: one probe instead of ten ----------------------------------------------------------------------

@@ -374,13 +374,13 @@ __global__ void __launch_bounds__(256) k_enumerate(const McTables *__restrict__ 
 // rule): a position whose own bucket is non-empty always uses a 9-mer (or is skipped), and only positions with an
 // EMPTY bucket look at `prev` - to decide from where the 10-mer validity check of the neighbourhood starts.  `prev`
 // is 9 if the nearest earlier non-skipped position with a non-empty bucket found a matching 9-mer range, else 6.
-// So the frame is handled in two parallel phases: (1) exact 9-mer probes of all positions, recording which positions
-// define `prev` and which of them hit; (2) the 36 neighbourhood probes of every position.
+// So a read is handled in two parallel passes: (0) the exact 9-mer probes and the 36 neighbourhood probes of every
+// position whose neighbourhood does not depend on `prev`; (1) the few positions that do.
 //
-// One wave per read.  The 10^6-bit bucket-occupancy bitmap (125 KB) is staged in LDS once per workgroup: three out of
-// four neighbour buckets are empty and never touch memory.  Probes that survive the bitmap are compacted through a
-// per-wave LDS queue so that all 64 lanes take part in the gathers (bucket bounds, binary search over the suffix keys).
-// Seed hits are appended with one atomic per wave.
+// One wave per read, 24 waves per CU.  The kernel is bound by instruction issue (VALU + SALU), not by memory: every stage
+// is arranged so that all 64 lanes work - positions, (position, wildcard offset) pairs and probes are compacted through
+// per-wave LDS queues - and so that a stage costs few instructions per item (filters that answer in one read, packed
+// codes, prefix sums by DPP).  Seed hits are appended to slots from a prefix sum; one global atomic per 2048 slots.
 // ------------------------------------------------------------------------------------------------
 #define MC_EN_QCAP 128
 #define MC_EN_NCHUNK(L) ((((L) / 3 - 6) + 63) / 64 > 0 ? (((L) / 3 - 6) + 63) / 64 : 1)
@@ -649,14 +649,15 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
         mc_wave_sync();
         // Per position: its exact 9-mer, and its one-substitution 10-mers in four groups of ten probes (groups 0..2 =
         // offsets 4, 5, 3 of the 6-mer: neighbour buckets; group 3 = offset 6: same bucket, first key residue substituted).
-        // Pass 0 sweeps the frames 64 positions at a time and generates both.  Whether a position has a neighbourhood
+        // Pass 0 sweeps the kept positions 64 at a time and generates both.  Whether a position has a neighbourhood
         // depends, for a few of them (own bucket empty, g8 and g9 valid, g6 or g7 not: ~3 % of the positions), on whether
-        // the nearest earlier exact probe of the frame found a range; those wait in the list dq until pass 0 has drained
-        // its queues and are generated in pass 1.  With the counters off, filters decide what is searched:
+        // the nearest earlier exact probe of the frame found a range; those wait in the list dq - with the wildcard
+        // filter's answer, asked in pass 0 - until pass 0 has drained its queues, and are generated in pass 1.
+        // With the counters off, filters decide what is searched:
         //   exact 9-mer  -> 9-mer Bloom filter -> queue q
-        //   10-mers      -> wildcard filter (one cache line per position answers for its four groups) -> queue eq of
-        //                   (position, group) pairs -> 64 pairs at a time: ten probes each against the 10-mer Bloom
-        //                   filter -> queue q
+        //   10-mers      -> wildcard filter (one 32-byte line per position answers for its four groups) -> queue eq of
+        //                   (position, group) pairs -> 64 pairs at a time: pair filter (one 16-byte block answers for the
+        //                   ten residues of the pair) -> queue q
         //   q            -> bucket records: group scan, or the range table for long groups -> seed hits
         // (the counting form searches every probe; its long groups go through queue hq to the binary searches).
         // Every stage runs with full waves; the generator is a state machine so that each stage exists once in the kernel.

@@ -25,7 +25,7 @@ struct McHostIndex {
     std::vector<uint16_t> keys;
     std::vector<uint32_t> bitmap;      // 1 bit per bucket: non-empty
     std::vector<McBucketRec> rec;      // first-residue group boundaries per bucket; empty when the index cannot use them
-    std::vector<uint32_t> filt;        // Bloom filters over (bucket, key): 10-mers, then 9-mers
+    std::vector<uint32_t> filt;        // Bloom filter over (bucket, 3-residue key): the exact 9-mer probes
     std::vector<uint32_t> wild;        // wildcard filter over the 10-mers (mc_wild_*)
     std::vector<uint32_t> pair;        // pair filter over the 10-mers (mc_pair_*)
     std::vector<unsigned long long> rt; // range table of the long first-residue groups (mc_rt_*)
@@ -227,8 +227,8 @@ inline void mc_index_derive(McHostIndex &X)
         }
         if (!ok) X.rec.clear();
     }
-    // 10-mer filter (mc_filter_hash): every posting whose key has 4 residues
-    X.filt.assign(MC_FILT_TOTAL_WORDS, 0);
+    // 9-mer filter, and the wildcard and pair filters over the postings whose key has 4 residues
+    X.filt.assign(MC_FILT9_WORDS, 0);
     X.wild.assign((size_t)MC_WILD_LINES * MC_WILD_LINE_WORDS, 0);
     X.pair.assign((size_t)MC_PAIR_BLOCKS * 4, 0);
     for (int b = 0; b < MC_NBUCKET; b++)
@@ -239,8 +239,6 @@ inline void mc_index_derive(McHostIndex &X)
                 X.filt[mc_filter9_word(h9)] |= mc_filter_bits(h9);
             }
             if ((k & 0xF) == 0xF) continue;                    // shorter key: never inside the range of a 10-mer probe
-            const uint32_t h = mc_filter_hash((uint32_t)b, k);
-            X.filt[mc_filter_word(h)] |= mc_filter_bits(h);
             const uint32_t ctx = mc_wild_ctx((uint32_t)b, k), line = mc_wild_line(ctx);
             for (int g = 0; g < 4; g++) {
                 mc_wild_set(&X.wild[(size_t)line * MC_WILD_LINE_WORDS + (size_t)g * 2], mc_wild_bits(ctx, (uint32_t)b, k, g));
