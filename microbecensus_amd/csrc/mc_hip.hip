@@ -858,13 +858,19 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
     }
 }
 
-// Seed hits -> HSPs / gap tasks.  Persistent workgroups walk the task pool 256 hits at a time; what survives is staged in
-// LDS and flushed with ONE global atomic per ~800 HSPs: a device-scope atomic on a single counter executes at the memory
-// side (the L2s of the XCDs are not coherent with each other) at ~125 M/s - one per HSP, or even one per wave, cost more
-// than the whole evaluation (measured: 11.6 ms of which 7.9 ms atomics).
-#define MC_EV_STAGE_H 512    // HSPs staged per workgroup (24 KB)
-#define MC_EV_STAGE_G 320    // gap tasks (9 KB)
-__global__ void __launch_bounds__(256) k_eval_seeds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
+// Seed hits -> HSPs / gap tasks.  Persistent workgroups walk the task pool 512 hits at a time; what survives is staged in
+// LDS and flushed with ONE global atomic per ~400 HSPs / ~300 gap tasks: a device-scope atomic on a single counter executes
+// at the memory side (the L2s of the XCDs are not coherent with each other) at ~125 M/s - one per HSP, or even one per wave,
+// cost more than the whole evaluation (measured: 11.6 ms of which 7.9 ms atomics).
+// The kernel waits on scattered byte reads of the residues (SQ_WAIT_ANY 77 % of the wave cycles), so it runs at the occupancy
+// its registers allow, 24 waves per CU (80 VGPRs), as 3 workgroups of 8 waves whose staging pools just fit the LDS -
+// measured per 1 M reads of 150 bp: 4 x 4 waves 5.3 ms, 4 x 5 waves 4.85, 3 x 8 waves 4.6, 2 x 12 waves 4.6; pools that flush
+// more often (4 x 6 waves, 5 x 4 waves) 6.6 - 7.1.
+#define MC_EV_BS 512         // threads per workgroup
+#define MC_EV_BPC 3          // workgroups per CU
+#define MC_EV_STAGE_H 704    // HSPs staged per workgroup (33 KB)
+#define MC_EV_STAGE_G 640    // gap tasks (17.5 KB)
+__global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(MC_EV_BS) k_eval_seeds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
                                                     const McSeedTask *__restrict__ tasks, const uint32_t *__restrict__ ntasks_p, uint32_t cap_tasks, McHsp *hsps, uint32_t cap_hsps,
                                                     McGapTask *gaps, uint32_t cap_gaps, uint32_t *counters)
 {
@@ -877,27 +883,32 @@ __global__ void __launch_bounds__(256) k_eval_seeds(const McTables *__restrict__
     if (threadIdx.x == 0) { fillH = 0; fillG = 0; }
     __syncthreads();
     const int lane = mc_lane();
-    const uint32_t nchunks = (ntasks + 255) / 256;
+    const uint32_t nchunks = (ntasks + MC_EV_BS - 1) / MC_EV_BS;
     for (uint32_t chunk = blockIdx.x;; chunk += gridDim.x) {
         const bool last = chunk >= nchunks;
         // flush when the next 256 hits might not fit (or at the end)
         __syncthreads();                                         // the staging of the previous chunk is complete
         const uint32_t fh = fillH, fg = fillG;
         __syncthreads();                                         // everybody has read the fill levels
-        if (last || fh > MC_EV_STAGE_H - 256 || fg > MC_EV_STAGE_G - 256) {
-            if (threadIdx.x == 0) { baseH = fh ? atomicAdd(&counters[C_HSPS], fh) : 0u; baseG = fg ? atomicAdd(&counters[C_GAPS], fg) : 0u; }
+        const bool flH = fh != 0 && (last || fh > MC_EV_STAGE_H - MC_EV_BS), flG = fg != 0 && (last || fg > MC_EV_STAGE_G - MC_EV_BS);   // each pool by itself
+        if (flH || flG) {
+            if (threadIdx.x == 0) { if (flH) baseH = atomicAdd(&counters[C_HSPS], fh); if (flG) baseG = atomicAdd(&counters[C_GAPS], fg); }
             __syncthreads();
             const uint32_t bH = baseH, bG = baseG;
-            if (bH + fh > cap_hsps) { if (threadIdx.x == 0) counters[C_OVERFLOW] = 2; }
-            else for (uint32_t i = threadIdx.x; i < fh * 3; i += 256) ((uint4 *)(hsps + bH))[i] = ((const uint4 *)stH)[i];          // 48-byte records as 16-byte words
-            if (bG + fg > cap_gaps) { if (threadIdx.x == 0) counters[C_OVERFLOW] = 3; }
-            else for (uint32_t i = threadIdx.x; i < fg * (uint32_t)(sizeof(McGapTask) / 4); i += 256) ((uint32_t *)(gaps + bG))[i] = ((const uint32_t *)stG)[i];
+            if (flH) {
+                if (bH + fh > cap_hsps) { if (threadIdx.x == 0) counters[C_OVERFLOW] = 2; }
+                else for (uint32_t i = threadIdx.x; i < fh * 3; i += MC_EV_BS) ((uint4 *)(hsps + bH))[i] = ((const uint4 *)stH)[i];          // 48-byte records as 16-byte words
+            }
+            if (flG) {
+                if (bG + fg > cap_gaps) { if (threadIdx.x == 0) counters[C_OVERFLOW] = 3; }
+                else for (uint32_t i = threadIdx.x; i < fg * (uint32_t)(sizeof(McGapTask) / 4); i += MC_EV_BS) ((uint32_t *)(gaps + bG))[i] = ((const uint32_t *)stG)[i];
+            }
             __syncthreads();
-            if (threadIdx.x == 0) { fillH = 0; fillG = 0; }
+            if (threadIdx.x == 0) { if (flH) fillH = 0; if (flG) fillG = 0; }
             __syncthreads();
         }
         if (last) break;
-        const uint32_t tid = chunk * 256 + threadIdx.x;
+        const uint32_t tid = chunk * MC_EV_BS + threadIdx.x;
         int rc = 0;
         McGapTask g;
         McHsp h;
@@ -1921,9 +1932,9 @@ static int stage_a(mc_handle *h, McCtx &c)
         k_enumerate<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, X, c.d_frames, FP, L, n, c.d_tasks, c.cap_tasks, c.d_counters, c.d_stats);
     HIPCK(hipEventRecord(c.ev[2], st));
     // the number of seed hits stays on the device: persistent workgroups walk the pool
-    const size_t lds_ev = (size_t)MC_EV_STAGE_H * sizeof(McHsp) + (size_t)MC_EV_STAGE_G * sizeof(McGapTask);   // 33 KB: four workgroups per CU
+    const size_t lds_ev = (size_t)MC_EV_STAGE_H * sizeof(McHsp) + (size_t)MC_EV_STAGE_G * sizeof(McGapTask);   // 51.7 KB: three workgroups per CU
     HIPCK(hipFuncSetAttribute((const void *)k_eval_seeds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ev));
-    k_eval_seeds<<<dim3(256u * 4u), dim3(256), lds_ev, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_tasks, c.d_counters + C_TASKS, c.cap_tasks, c.d_hsps, c.cap_hsps, c.d_gaps, c.cap_gaps, c.d_counters);
+    k_eval_seeds<<<dim3(256u * MC_EV_BPC), dim3(MC_EV_BS), lds_ev, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_tasks, c.d_counters + C_TASKS, c.cap_tasks, c.d_hsps, c.cap_hsps, c.d_gaps, c.cap_gaps, c.d_counters);
     HIPCK(hipEventRecord(c.ev[3], st));
     return counters_to_host(c);
 }
