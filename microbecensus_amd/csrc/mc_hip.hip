@@ -1934,7 +1934,8 @@ static int stage_a(mc_handle *h, McCtx &c)
     // the number of seed hits stays on the device: persistent workgroups walk the pool
     const size_t lds_ev = (size_t)MC_EV_STAGE_H * sizeof(McHsp) + (size_t)MC_EV_STAGE_G * sizeof(McGapTask);   // 51.7 KB: three workgroups per CU
     HIPCK(hipFuncSetAttribute((const void *)k_eval_seeds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ev));
-    k_eval_seeds<<<dim3(256u * MC_EV_BPC), dim3(MC_EV_BS), lds_ev, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_tasks, c.d_counters + C_TASKS, c.cap_tasks, c.d_hsps, c.cap_hsps, c.d_gaps, c.cap_gaps, c.d_counters);
+    static const unsigned ev_bpc = getenv("MC_EV_BPC") ? (unsigned)atoi(getenv("MC_EV_BPC")) : (unsigned)MC_EV_BPC;   // (experiments)
+    k_eval_seeds<<<dim3(256u * ev_bpc), dim3(MC_EV_BS), lds_ev, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_tasks, c.d_counters + C_TASKS, c.cap_tasks, c.d_hsps, c.cap_hsps, c.d_gaps, c.cap_gaps, c.d_counters);
     HIPCK(hipEventRecord(c.ev[3], st));
     return counters_to_host(c);
 }
