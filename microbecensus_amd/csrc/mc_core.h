@@ -381,6 +381,38 @@ MC_HD double mc_rg_getprob(const double *lnfac, uint64_t sv, int total)
     const double t = (double)total * 2.995732273553991;
     return (ans2 + ans1) - t;
 }
+// ---- Seg::getprob of the register path as a table -------------------------------------------------------------------
+// A window of up to 15 residues has one of a few thousand (length, state vector) pairs - the partitions of every t <= len into
+// counts - and its probability depends on nothing else.  The host evaluates mc_rg_getprob once per pair (same IEEE double
+// operations as the device would perform, same order: bit-identical) and the kernel reads the order-preserving key of the
+// result out of an open-addressing table: key word = state vector (<= 15 nibbles) | length << 60.  8192 slots of 16 bytes.
+#define MC_SEGTAB_LOG2 13
+#define MC_SEGTAB_SLOTS (1u << MC_SEGTAB_LOG2)
+MC_HD uint64_t mc_seg_prob_key(double x)
+{ // unsigned keys that order like the doubles
+    uint64_t u;
+    __builtin_memcpy(&u, &x, 8);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+MC_HD uint32_t mc_segtab_hash(uint64_t k)
+{
+    uint32_t x = (uint32_t)k * 0x9E3779B1u + (uint32_t)(k >> 32) * 0x85EBCA77u;
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
+    return x >> (32 - MC_SEGTAB_LOG2);
+}
+// tab: MC_SEGTAB_SLOTS x {key word, probability key}; an empty slot has key word 0 (no pair has an empty state vector AND length 0)
+MC_HD uint64_t mc_segtab_lookup(const uint64_t *tab, uint64_t sv, int len)
+{
+    const uint64_t k = sv | ((uint64_t)len << 60);
+    uint32_t h = mc_segtab_hash(k);
+    for (;;) {
+        const uint64_t kk = tab[2 * h];
+        if (kk == k) return tab[2 * h + 1];
+        if (kk == 0) return 0;                                // (not reached: every pair a window can have is in the table)
+        h = (h + 1) & (MC_SEGTAB_SLOTS - 1);
+    }
+}
+
 MC_HD void mc_seg_trim_rg(const double *lnfac, const uint8_t *s, int n, int *leftend, int *rightend)
 { // n <= 15 (so n - maxtrim < 1: every window length down to 2 is tried)
     int lend = 0, rend = n - 1;

@@ -88,6 +88,12 @@ __device__ __forceinline__ void mc_wave_sync() { __builtin_amdgcn_fence(__ATOMIC
 struct McSegWaveLds { unsigned long long best[64]; uint32_t pre[66]; uint32_t pre2[66]; uint32_t bq[64]; uint16_t off[64]; uint8_t n[64]; };   // 1,488 B per wave (four of them must fit under the 42 staged reads: 4 workgroups per CU at 150 bp)
 static_assert(sizeof(McHsp) == 48 && sizeof(McGapTask) % 4 == 0, "k_eval_seeds copies its staging buffers as 16- and 4-byte words");
 static_assert(sizeof(McSegWaveLds) == 1488, "MC_TS_STAGE reserves 4 x 1488 bytes");
+#ifdef MC_EXP_TIMING
+__device__ unsigned long long g_ts_acc[8], g_ts_cnt[8];
+#define MC_TS_TICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane == 0) { atomicAdd(&g_ts_acc[tcat_], now_ - tlast_); atomicAdd(&g_ts_cnt[tcat_], 1ull); } tlast_ = now_; tcat_ = (k); } while (0)
+#else
+#define MC_TS_TICK(k) do { } while (0)
+#endif
 #define MC_SEG_KEY_ONE 0xBFF0000000000000ull   // order-preserving key of 1.0 (the initial minprob of Seg::trim)
 
 __device__ __forceinline__ unsigned long long mc_seg_key(double x)
@@ -96,10 +102,13 @@ __device__ __forceinline__ unsigned long long mc_seg_key(double x)
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
-__device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx, uint8_t *prot, int n, bool act, const McSegWS ws, McSegWaveLds *WL,
+__device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx, const uint64_t *__restrict__ segtab, uint8_t *prot, int n, bool act, const McSegWS ws, McSegWaveLds *WL,
                                          const uint8_t *lds0, int lane)
 {
     const int W = (n <= 11) ? 8 : 12;
+#ifdef MC_EXP_TIMING
+    unsigned long long tlast_ = __builtin_readcyclecounter(); int tcat_ = 0;   // 0 flags 1 advance 2 numbering 3 class-0 rounds 4 class-1 rounds 5 reduction 6 owners
+#endif
     enum { POP = 0, SCAN = 1, WAIT = 2, DONE = 3 };
     int st = (act && W <= n) ? POP : DONE;
     // the window flags of the frame, once (mc_seg_mask_fx2 in mc_core.h is this function for one frame): every segment the
@@ -115,6 +124,7 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
     if (st != DONE) { ws.stk[0] = 0; ws.stk[1] = (int16_t)n; }
     const unsigned long long ltmask = (1ull << lane) - 1;
     for (;;) {
+        MC_TS_TICK(1);
         // ---- every lane advances its own frame to the next stretch that needs trimming
         while (st == POP || st == SCAN) {
             if (st == POP) {
@@ -133,6 +143,7 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
             st = WAIT;
         }
         const unsigned long long req = __ballot(st == WAIT);
+        MC_TS_TICK(2);
         if (req == 0) break;
         // ---- number the windows of all pending stretches
         const int nreq = __popcll(req);
@@ -144,29 +155,45 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
             WL->best[myr] = MC_SEG_KEY_ONE; WL->bq[myr] = 0xFFFFFFFFu;
         }
         mc_wave_sync();
-        // One work item = up to 8 consecutive windows of one LENGTH of one stretch (Seg::trim: len = nn - j has j + 1 windows,
+        // One work item = up to R consecutive windows of one LENGTH of one stretch (Seg::trim: len = nn - j has j + 1 windows,
         // j = 0 .. nn - minlen - 1): the lane builds the composition of its first window and slides it (one residue out, one in),
-        // keeping the first least probable window; bounded items keep the 64 lanes of a round in step, and the best of a stretch is
-        // then found with two LDS atomics per item.  Items of a stretch are numbered by (j, run): j = 8 A + B has A + 1 runs,
-        // C(j) = 4 A (A + 1) + B (A + 1) items lie in front of it.  Windows of up to 15 residues are evaluated in registers, longer
-        // ones on the lane's LDS row (several times slower): the two kinds go in SEPARATE rounds - class 0: lengths <= 15
-        // (j >= nn - 15), class 1: the others - so that a round of register items does not wait for one LDS item.
-#define MC_SEG_CJ(j) (4 * ((j) >> 3) * (((j) >> 3) + 1) + ((j) & 7) * (((j) >> 3) + 1))
-        if (lane == 0) {
-            uint32_t run0 = 0, run1 = 0;
-            WL->pre[0] = 0; WL->pre2[0] = 0;
-            for (int r = 0; r < nreq; r++) {
-                const int nn = WL->n[r], minlen = (nn - 100 > 1) ? nn - 100 : 1, K = nn - minlen, j0 = nn - 15 > 0 ? (nn - 15 < K ? nn - 15 : K) : 0;
-                run1 += (uint32_t)MC_SEG_CJ(j0);                          // lengths > 15: j < j0
-                run0 += (uint32_t)(MC_SEG_CJ(K) - MC_SEG_CJ(j0));          // lengths <= 15
-                WL->pre[r + 1] = run0; WL->pre2[r + 1] = run1;
+        // keeping the first least probable window; the best of a stretch is then found with two LDS atomics per item.
+        // A round takes as long as its longest item, and most rounds are far from full (a frame's stretches come one after the
+        // other, so a wave goes through ~15 batches of a few stretches each): R = 1, 2, 4 or 8 is chosen per batch and class as
+        // the smallest run for which the items still fit ONE round - the same windows, spread over more lanes.  Items of a
+        // stretch are numbered by (j, run): j = R A + B has A + 1 runs, C(j) = R A (A + 1) / 2 + B (A + 1) items lie in front
+        // of it.  Windows of up to 15 residues are evaluated in registers, longer ones on the lane's LDS row (several times
+        // slower): the two kinds go in SEPARATE rounds - class 0: lengths <= 15 (j >= nn - 15), class 1: the others - so that
+        // a round of register items does not wait for one LDS item.
+#define MC_SEG_CJ(j, sh) (((((j) >> (sh)) * (((j) >> (sh)) + 1)) << (sh)) / 2 + ((j) & ((1 << (sh)) - 1)) * (((j) >> (sh)) + 1))
+        int sh0 = 3, sh1 = 3;
+        {   // lane r counts the items of stretch r for the four run lengths; prefix sums over the lanes give the numbering
+            int K = 0, j0 = 0;
+            if (lane < nreq) { const int nn = WL->n[lane], minlen = (nn - 100 > 1) ? nn - 100 : 1; K = nn - minlen; j0 = nn - 15 > 0 ? (nn - 15 < K ? nn - 15 : K) : 0; }
+            uint32_t s0 = 0, s1 = 0;
+#pragma unroll
+            for (int sh = 2; sh >= 0; sh--) {                           // smallest run whose items fit one round (else 8)
+                const uint32_t c1 = (uint32_t)MC_SEG_CJ(j0, sh), c0 = (uint32_t)MC_SEG_CJ(K, sh) - c1;
+                const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)mc_wave_scan_add(c0), 63), t1 = (uint32_t)__builtin_amdgcn_readlane((int)mc_wave_scan_add(c1), 63);
+                if (t0 <= 64) sh0 = sh;
+                if (t1 <= 64) sh1 = sh;
             }
+            {
+                const uint32_t c1 = sh1 == 0 ? (uint32_t)MC_SEG_CJ(j0, 0) : sh1 == 1 ? (uint32_t)MC_SEG_CJ(j0, 1) : sh1 == 2 ? (uint32_t)MC_SEG_CJ(j0, 2) : (uint32_t)MC_SEG_CJ(j0, 3);
+                const uint32_t cj0 = sh0 == 0 ? (uint32_t)MC_SEG_CJ(j0, 0) : sh0 == 1 ? (uint32_t)MC_SEG_CJ(j0, 1) : sh0 == 2 ? (uint32_t)MC_SEG_CJ(j0, 2) : (uint32_t)MC_SEG_CJ(j0, 3);
+                const uint32_t ck = sh0 == 0 ? (uint32_t)MC_SEG_CJ(K, 0) : sh0 == 1 ? (uint32_t)MC_SEG_CJ(K, 1) : sh0 == 2 ? (uint32_t)MC_SEG_CJ(K, 2) : (uint32_t)MC_SEG_CJ(K, 3);
+                s0 = mc_wave_scan_add(ck - cj0); s1 = mc_wave_scan_add(c1);    // lengths <= 15; lengths > 15 (j < j0)
+            }
+            if (lane == 0) { WL->pre[0] = 0; WL->pre2[0] = 0; }
+            WL->pre[lane + 1] = s0; WL->pre2[lane + 1] = s1;            // (entries past nreq repeat the total)
         }
         mc_wave_sync();
         for (int cls = 0; cls < 2; cls++) {
         const uint32_t *pre = cls ? WL->pre2 : WL->pre;
         const uint32_t total = pre[nreq];
+        const int sh = cls ? sh1 : sh0, R = 1 << sh;
         for (uint32_t p0 = 0; p0 < total; p0 += 64) {
+            MC_TS_TICK(3 + cls);
             const uint32_t p = p0 + (uint32_t)lane;
             const bool ok = p < total;
             int r = 0;
@@ -174,12 +201,13 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
             if (!ok) r = 0;
             const int nn = WL->n[r];
             int x = (int)(p - pre[r]);
-            if (cls == 0) { const int minlen = (nn - 100 > 1) ? nn - 100 : 1, K = nn - minlen, j0 = nn - 15 > 0 ? (nn - 15 < K ? nn - 15 : K) : 0; x += MC_SEG_CJ(j0); }
-            int A = (int)((sqrtf((float)(x + 1)) - 1.0f) * 0.5f);
-            while (4 * (A + 1) * (A + 2) <= x) A++;
-            while (4 * A * (A + 1) > x) A--;
-            const int rem = x - 4 * A * (A + 1), B = rem / (A + 1), run = rem - B * (A + 1);
-            const int j = 8 * A + B, wfirst = 8 * run, wlast = (wfirst + 7 < j) ? wfirst + 7 : j;
+            if (cls == 0) { const int minlen = (nn - 100 > 1) ? nn - 100 : 1, K = nn - minlen, j0 = nn - 15 > 0 ? (nn - 15 < K ? nn - 15 : K) : 0; x += MC_SEG_CJ(j0, sh); }
+            // x = R A (A + 1) / 2 + B (A + 1) + run: the largest A with R A (A + 1) / 2 <= x
+            int A = (int)((sqrtf(1.0f + 8.0f * (float)x / (float)R) - 1.0f) * 0.5f);
+            while ((((A + 1) * (A + 2)) << sh) / 2 <= x) A++;
+            while (((A * (A + 1)) << sh) / 2 > x) A--;
+            const int rem = x - ((A * (A + 1)) << sh) / 2, B = rem / (A + 1), run = rem - B * (A + 1);
+            const int j = (A << sh) + B, wfirst = run << sh, wlast = (wfirst + R - 1 < j) ? wfirst + R - 1 : j;
             const uint8_t *s = lds0 + WL->off[r];
             const int len = nn - j;
             const uint32_t qbase = (uint32_t)(j * (j + 1) / 2);          // number of window 0 of this length in Seg::trim's order
@@ -191,7 +219,7 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
                     for (int k = 0; k < len; k++) mc_rg_add(rg, s[wfirst + k]);
                     uint64_t lastsv = ~0ull; unsigned long long lastkey = 0;
                     for (int w0 = wfirst;; w0++) {
-                        if (rg.sv != lastsv) { lastsv = rg.sv; lastkey = mc_seg_key(mc_rg_getprob(lnf, rg.sv, len)); }   // (the probability depends on the state vector only)
+                        if (rg.sv != lastsv) { lastsv = rg.sv; lastkey = mc_segtab_lookup(segtab, rg.sv, len); }   // (the probability depends on length and state vector only: mc_rg_getprob, tabulated)
                         if (lastkey < key) { key = lastkey; kq = qbase + (uint32_t)w0; }
                         if (w0 == wlast) break;
                         mc_rg_remove(rg, s[w0]); mc_rg_add(rg, s[w0 + len]);
@@ -207,6 +235,7 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
                     }
                 }
             }
+            MC_TS_TICK(5);
             const bool cand = ok && key < MC_SEG_KEY_ONE;
             const unsigned long long old = WL->best[r];
             mc_wave_sync();
@@ -221,6 +250,7 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
         }
 #undef MC_SEG_CJ
         // ---- the owners take their results and go on
+        MC_TS_TICK(6);
         if (st == WAIT) {
             const uint32_t q = WL->bq[myr];
             int lend = 0, rend = myn - 1;
@@ -244,7 +274,9 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
         }
         mc_wave_sync();
     }
+    MC_TS_TICK(7);
     if (any) for (int k = 0; k < n; k++) if (mc_bits_test(mk, k)) prot[k] = MC_INV;
+    MC_TS_TICK(0);
 }
 
 // One thread per (read, frame); a block of 256 threads owns 42 consecutive reads (252 frames).  The reads are staged
@@ -253,7 +285,7 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
 // max(42*L, 4 x 1,416) + ln n! + 256*(FP+76) bytes (~40 KB at 150 bp; the staging area is reused by the SEG queues).
 template <bool STAGED>                                           // STAGED: the block's reads go through LDS (coalesced); otherwise each thread
 __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restrict__ T, const uint8_t *__restrict__ reads, int L,   // walks its read in global memory and the LDS it saves buys a workgroup per CU (long reads)
-                                                       int64_t nreads, uint8_t *__restrict__ frames, int FP)
+                                                       int64_t nreads, uint8_t *__restrict__ frames, int FP, const uint64_t *__restrict__ segtab)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
@@ -285,7 +317,7 @@ __global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restric
     __syncthreads();                                             // the staged reads are dead: their space becomes the SEG queues
     {
         McSegWS ws; ws.comp = prot + FP; ws.sv = prot + FP + 20; ws.stk = (int16_t *)(prot + FP + 44);
-        mc_seg_wave(lnf, fxs, prot, n, lr < nr, ws, (McSegWaveLds *)smem + (tid >> 6), rows, mc_lane());   // (stretch offsets are kept relative to the rows: 256 x 252 bytes at most, 16 bits)
+        mc_seg_wave(lnf, fxs, segtab, prot, n, lr < nr, ws, (McSegWaveLds *)smem + (tid >> 6), rows, mc_lane());   // (stretch offsets are kept relative to the rows: 256 x 252 bytes at most, 16 bits)
         if (lr < nr) for (int i = n; i < FP; i++) prot[i] = MC_INV;
     }
     __syncthreads();
@@ -1613,7 +1645,7 @@ struct mc_handle {
     int read_len = 0, FP = 0; bool run_set = false;
     uint32_t *d_bitmap = nullptr;
     McBucketRec *d_rec = nullptr;
-    uint32_t *d_filt = nullptr, *d_wild = nullptr, *d_pair = nullptr; unsigned long long *d_rt = nullptr;
+    uint32_t *d_filt = nullptr, *d_wild = nullptr, *d_pair = nullptr; uint64_t *d_segtab = nullptr; unsigned long long *d_rt = nullptr;
     bool fast_enum = false;
     bool count_traffic = false;
     int parts = MC_NCTX;                  // parts a range is cut into (mc_set_parts; 1 = one kernel at a time, for profiling)
@@ -1667,7 +1699,7 @@ extern "C" void mc_close(mc_handle *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_pair, h->d_rt};
+    void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_pair, h->d_rt, h->d_segtab};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (McCtx &c : h->ctx) ctx_free(c);
     for (int k = 0; k < 2; k++) { if (h->stage_pin[k]) (void)hipHostFree(h->stage_pin[k]); if (h->stage_dev[k]) (void)hipFree(h->stage_dev[k]); }
@@ -1807,6 +1839,12 @@ extern "C" int mc_set_run(mc_handle *h, int32_t read_len, double loge_thr, const
     h->hP.nfam = h->nfam; h->hP.read_len = read_len;
     for (int f = 0; f < h->nfam; f++) { h->hP.min_cov[f] = min_cov[f]; h->hP.min_score[f] = min_score[f]; h->hP.max_aaid[f] = max_aaid[f]; h->hP.aln_stat[f] = aln_stat[f]; }
     HIPCK(hipMemcpy(h->d_T, &h->hT, sizeof(McTables), hipMemcpyHostToDevice));
+    if (!h->d_segtab) {   // Seg::getprob of every short window, tabulated once (ln n! does not depend on the run)
+        std::vector<uint64_t> tab;
+        mc_build_segtab(h->hT.lnfac, tab);
+        if (dalloc(&h->d_segtab, tab.size())) return -1;
+        HIPCK(hipMemcpy(h->d_segtab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    }
     HIPCK(hipMemcpy(h->d_P, &h->hP, sizeof(McClassPars), hipMemcpyHostToDevice));
     const int newFP = ((read_len / 3 + 2) + 3) & ~3;
     if (newFP != h->FP || read_len != h->read_len) for (McCtx &c : h->ctx) c.cap_reads = 0;   // pools are sized by read length and frame pitch
@@ -1899,12 +1937,24 @@ static int stage_a(mc_handle *h, McCtx &c)
     const size_t lds = staged ? lds_staged : lds_direct;
     if (staged) {
         if (lds > 48 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_translate_seg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_translate_seg<true><<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(256), lds, st>>>(h->d_T, c.reads, L, n, c.d_frames, FP);
+        k_translate_seg<true><<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(256), lds, st>>>(h->d_T, c.reads, L, n, c.d_frames, FP, h->d_segtab);
     } else {
         if (lds > 48 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_translate_seg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_translate_seg<false><<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(256), lds, st>>>(h->d_T, c.reads, L, n, c.d_frames, FP);
+        k_translate_seg<false><<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(256), lds, st>>>(h->d_T, c.reads, L, n, c.d_frames, FP, h->d_segtab);
     }
     HIPCK(hipEventRecord(c.ev[1], st));
+#ifdef MC_EXP_TIMING
+    {
+        HIPCK(hipStreamSynchronize(st));
+        unsigned long long acc[8], cnt[8];
+        HIPCK(hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_ts_acc), sizeof acc)); HIPCK(hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_ts_cnt), sizeof cnt));
+        const char *nm[8] = {"flags", "advance", "numbering", "class-0 rounds", "class-1 rounds", "reduction", "owners", "mask"};
+        const double waves = (double)((n + MC_TS_READS - 1) / MC_TS_READS) * 4.0;
+        for (int k = 0; k < 8; k++) fprintf(stderr, "ts-timing %-15s %9.1f cycles/wave  %8.2f entries/wave\n", nm[k], (double)acc[k] / waves, (double)cnt[k] / waves);
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_ts_acc), z, sizeof z)); HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_ts_cnt), z, sizeof z));
+    }
+#endif
     if (h->fast_enum) {
         const size_t per_wave = MC_EN_WAVE_BYTES(h->count_traffic) + (size_t)6 * MC_EN_ROW(FP) + (size_t)6 * MC_EN_NCHUNK(L) * (512 + 128);
         // Launch shape: the kernel needs 79 VGPRs (6 waves per SIMD) and is bound by instruction issue with some latency left to

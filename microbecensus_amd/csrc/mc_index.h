@@ -456,6 +456,37 @@ inline int mc_length_adjustment(double n, double nseq, int qlen)
     return adj;
 }
 
+// mc_segtab_*: every (length <= 15, state vector) pair -> order-preserving key of mc_rg_getprob.  State vectors are the
+// non-increasing sequences of counts with sum t <= length (residues of the window that are not amino acids count for the
+// length only).
+inline void mc_build_segtab(const double *lnfac, std::vector<uint64_t> &tab)
+{
+    tab.assign((size_t)MC_SEGTAB_SLOTS * 2, 0);
+    size_t npairs = 0;
+    // enumerate the partitions recursively: parts[0] >= parts[1] >= ... > 0
+    struct Rec {
+        const double *lnfac; std::vector<uint64_t> &tab; size_t &npairs;
+        void emit(uint64_t sv, int t)
+        {
+            for (int len = (t > 2 ? t : 2); len <= 15; len++) {
+                const uint64_t k = sv | ((uint64_t)len << 60);
+                uint32_t h = mc_segtab_hash(k);
+                while (tab[2 * h] != 0) h = (h + 1) & (MC_SEGTAB_SLOTS - 1);
+                tab[2 * h] = k; tab[2 * h + 1] = mc_seg_prob_key(mc_rg_getprob(lnfac, sv, len));
+                npairs++;
+            }
+        }
+        void go(uint64_t sv, int nparts, int t, int maxpart)
+        {
+            emit(sv, t);
+            if (nparts == 15) return;
+            for (int p = 1; p <= maxpart && t + p <= 15; p++) go(sv | ((uint64_t)p << (4 * nparts)), nparts + 1, t + p, p);
+        }
+    } rec{lnfac, tab, npairs};
+    rec.go(0, 0, 0, 15);
+    (void)npairs;
+}
+
 inline void mc_fill_tables(McTables &T, const McHostIndex &X, int read_len, double loge_thr)
 {
     static const int8_t B62[20][20] = {
