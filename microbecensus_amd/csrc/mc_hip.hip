@@ -217,13 +217,27 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
                 if (cls == 0) {
                     McRgState rg; rg.clo = 0; rg.chi = 0; rg.sv = 0;
                     for (int k = 0; k < len; k++) mc_rg_add(rg, s[wfirst + k]);
-                    uint64_t lastsv = ~0ull; unsigned long long lastkey = 0;
-                    for (int w0 = wfirst;; w0++) {
-                        if (rg.sv != lastsv) { lastsv = rg.sv; lastkey = mc_segtab_lookup(segtab, rg.sv, len); }   // (the probability depends on length and state vector only: mc_rg_getprob, tabulated)
-                        if (lastkey < key) { key = lastkey; kq = qbase + (uint32_t)w0; }
-                        if (w0 == wlast) break;
-                        mc_rg_remove(rg, s[w0]); mc_rg_add(rg, s[w0 + len]);
+                    // the state vectors of the run first, then their table reads (in flight together), then the comparison in window order
+                    const int cnt = wlast - wfirst + 1;
+                    uint64_t svs[8], kk[8], vv[8];
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        svs[t] = rg.sv;
+                        if (t + 1 < cnt) { mc_rg_remove(rg, s[wfirst + t]); mc_rg_add(rg, s[wfirst + t + len]); }
                     }
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        const uint64_t k = svs[t] | ((uint64_t)len << 60);
+                        const ulonglong2 e = ((const ulonglong2 *)segtab)[t < cnt ? mc_segtab_hash(k) : 0u];
+                        kk[t] = e.x; vv[t] = e.y;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; t++)
+                        if (t < cnt) {
+                            const uint64_t k = svs[t] | ((uint64_t)len << 60);
+                            const unsigned long long pk = kk[t] == k ? vv[t] : mc_segtab_lookup(segtab, svs[t], len);   // (first slot taken by another pair: walk on)
+                            if (pk < key) { key = pk; kq = qbase + (uint32_t)(wfirst + t); }
+                        }
                 } else {
                     mc_seg_comp(s + wfirst, len, ws.comp);
                     mc_seg_state(ws.comp, ws.sv);
@@ -284,7 +298,7 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
 // 64 frames each (mc_seg_wave) and the block writes the frames back with coalesced stores.  LDS per block:
 // max(42*L, 4 x 1,416) + ln n! + 256*(FP+76) bytes (~40 KB at 150 bp; the staging area is reused by the SEG queues).
 template <bool STAGED>                                           // STAGED: the block's reads go through LDS (coalesced); otherwise each thread
-__global__ void __launch_bounds__(256) k_translate_seg(const McTables *__restrict__ T, const uint8_t *__restrict__ reads, int L,   // walks its read in global memory and the LDS it saves buys a workgroup per CU (long reads)
+__global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(256) k_translate_seg(const McTables *__restrict__ T, const uint8_t *__restrict__ reads, int L,   // walks its read in global memory and the LDS it saves buys a workgroup per CU (long reads)
                                                        int64_t nreads, uint8_t *__restrict__ frames, int FP, const uint64_t *__restrict__ segtab)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
