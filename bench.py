@@ -33,6 +33,11 @@ sys.path.insert(0, REPO)
 
 METRIC = "reads/sec searched vs marker DB + AGS abs-error, 150 bp @ 1/2/4/8 GPU"
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+def seed_positions(L):
+    """seed positions of a read's six frames (a frame of n residues has n - 6)"""
+    return 2 * sum(max((L - r) // 3 - 6, 0) for r in range(3))
+
+
 SURVEY_A = {100: 127403, 150: 207923, 300: 452893}   # SURVEY.md 8(d): modelled algorithmic bytes per read of the whole path
 
 
@@ -81,7 +86,7 @@ def profiled_traffic(stage, n_batch):
         per = float(line["config"]["batch"])
         total, found = 0.0, False
         for k, t in tr.items():
-            if "true" in k or t.get("write_kib_per_launch") is None:      # (the counting form of the seed kernel is not the timed one)
+            if (k.startswith("k_enumerate") and k.rstrip().endswith("true>")) or t.get("write_kib_per_launch") is None:      # (the counting form of the seed kernel is not the timed one)
                 continue
             if any(k == p or k.startswith(p + "<") or (p.endswith("<") and k.startswith(p)) for p in STAGE_KERNELS.get(stage, [stage])):
                 total += (2.0 * t["fetch_kib_per_launch"] + t["write_kib_per_launch"]) * 1024.0
@@ -102,7 +107,7 @@ def profiled_l2_hit_rate(stage):
         hit = miss = 0.0
         for r in csv.DictReader(open(files[-1])):
             k = r["Kernel"]
-            if "true" in k or not r.get("TCC_HIT_sum"):
+            if (k.startswith("k_enumerate") and k.rstrip().rstrip('"').endswith("true>")) or not r.get("TCC_HIT_sum"):
                 continue
             if any(k == p or k.startswith(p + "<") or (p.endswith("<") and k.startswith(p)) for p in STAGE_KERNELS.get(stage, [stage])):
                 hit += float(r["TCC_HIT_sum"]); miss += float(r["TCC_MISS_sum"])
@@ -385,12 +390,18 @@ def main():
         per_launch = {
             # algorithmic bytes per launch: what the reference's algorithm reads / writes for the same reads
             "k_translate_seg": n_batch * (L + 6 * (L // 3)),
-            "k_enumerate": (n_batch * 6 * (L // 3) * K + 8 * acc["bucket_lookups"] + 2 * acc["key_probes"] + 20 * acc["seed_tasks"]) / K,
+            # the seed kernel's OWN algorithm: frames in, one bucket-bitmap word per seed position, what it asks its filters (9-mer
+            # filter word 4 B, wildcard line 32 B, pair block 16 B), bucket record + key group per surviving probe (32 + 16 B), posting
+            # in (4 B) and seed hit out (16 B) per hit - counted by the timed kernel itself (mc_stats.seed_*)
+            "k_enumerate": (n_batch * (6 * (L // 3) + 4 * seed_positions(L)) * K + 4 * acc["seed_exact_asks"] + 32 * acc["seed_wild_asks"] + 16 * acc["seed_pair_asks"]
+                            + 48 * acc["seed_probes"] + 20 * acc["seed_tasks"]) / K,
             "k_eval_seeds": (acc["seed_tasks"] * (16 + 4 + 8 + 2 * 20)) / K,
             "k_gapped": (acc["gap_tasks"] * 24 + acc["hsps"] * 48) / K,
             "sort": acc["hsps"] * (12 * 4 + 48 * 2) / K,
             "k_finish": acc["hsps"] * 48 * 3 / K,
         }
+        # the index reads the REFERENCE's algorithm would issue for the same reads (counting form of the seed kernel): what the filters dispose of
+        ref_seed_bytes = (n_batch * 6 * (L // 3) * K + 8 * acc["bucket_lookups"] + 2 * acc["key_probes"] + 20 * acc["seed_tasks"]) / K
         # The two parts of a step overlap in the timed region, so a kernel's HIP events there also span the other part's kernels;
         # its own duration is measured by the same events right after the timed region with one kernel at a time (mc_set_parts(1)),
         # which is also how the committed rocprofv3 profile (profiles/, MC_PARTS=1) is taken.  achieved / frac use that duration;
@@ -425,11 +436,15 @@ def main():
                                                          ("k_eval_seeds", "ms_eval"), ("k_gapped", "ms_gapped"), ("sort", "ms_sort"), ("k_finish", "ms_finish"))}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                          "traffic": (None if traffic_dom is None else round(traffic_dom, 0)),
-                         "basis": "achieved = algorithmic bytes of the reference's algorithm for one step's launches of the kernel (for the seed kernel: the index "
-                                  "reads the reference would issue, counted by the kernel's own counting form; DESIGN.md 5) / HIP-event time of those launches, one "
-                                  "kernel at a time (measured right after the timed region; in it the two parts of a step overlap). For the seed kernel a disposal "
-                                  "rate: filters answer most probes, the kernel does not move these bytes. physical_* = HBM-side bytes of the committed rocprofv3 "
-                                  "PMC profile / the same time",
+                         "basis": "achieved = algorithmic bytes of one step's launches of the kernel (DESIGN.md 5; for the seed kernel: what its own algorithm "
+                                  "asks for - frames, bitmap words, filter words / lines / blocks, bucket records, key groups, postings, seed hits - counted by the "
+                                  "timed kernel) / HIP-event time of those launches, one kernel at a time (measured right after the timed region; in it the two "
+                                  "parts of a step overlap). traffic / physical_* = fabric-side bytes (2 x FETCH_SIZE + WRITE_SIZE) of the committed rocprofv3 "
+                                  "PMC profile: above the algorithmic bytes because a 16- or 32-byte item arrives as a 128-byte line; mostly Infinity-Cache "
+                                  "hits (the index is 110 MB). seed_kernel_reference_algorithm_*: the index reads the reference's algorithm would issue for the "
+                                  "same reads / the same time - a disposal rate, the filters answer those probes",
+                         "seed_kernel_reference_algorithm_bytes_per_read": round(ref_seed_bytes / n_batch, 1),
+                         "seed_kernel_reference_algorithm_GBps": round(ref_seed_bytes / (kseq["k_enumerate"] * 1e-3) / 1e9, 2),
                          "physical_GBps": (None if traffic_dom is None else round(traffic_dom / (kseq[dom] * 1e-3) / 1e9, 2)),
                          "physical_frac": (None if traffic_dom is None else round(traffic_dom / (kseq[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)),
                          "kernel_ms_per_step": round(kseq[dom], 3),

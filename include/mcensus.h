@@ -39,6 +39,9 @@ typedef struct mc_stats {
     int64_t reads, seed_tasks, gap_tasks, hsps, rows, reads_with_rows, classified;
     int64_t bucket_lookups, key_probes;   /* algorithmic traffic of the seed kernel: 8 B and 2 B reads */
     float ms_translate, ms_seed, ms_eval, ms_gapped, ms_sort, ms_finish, ms_total;
+    /* what the seed kernel itself asked its structures (timed form): 9-mer filter words (4 B), wildcard filter lines (32 B),
+     * pair filter blocks (16 B), bucket records + key groups searched (32 B + 16 B); seed_tasks postings (4 B) came out */
+    int64_t seed_exact_asks, seed_wild_asks, seed_pair_asks, seed_probes;
 } mc_stats;
 
 const char *mc_last_error(void);
@@ -148,6 +151,9 @@ int mc_reader_get_stats(mc_reader *r, mc_reader_stats *out);
 void mc_reader_close(mc_reader *r);
 /* count_bases(): total sequence length over every record of every file. */
 int64_t mc_count_bases(const char *const *paths, int32_t npaths);
+/* auto_detect_quality_offset() (microbe_census.py:175-187): 32 or 64 by the first quality character of the file that decides
+ * (32 when none does); -2 = a record without a quality line (take the Python path: it fails the way the reference does). */
+int32_t mc_quality_offset(const char *path);
 
 /* Streaming form of the sampler: mc_reader_start() runs it on a thread of its own; mc_reader_fetch() blocks until reads
  * [first, first + max_reads) are sampled (or the sampler has ended), copies them to dst and returns how many there were

@@ -26,7 +26,8 @@ class McBestHit(C.Structure):
 
 class McStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("reads", "seed_tasks", "gap_tasks", "hsps", "rows", "reads_with_rows", "classified", "bucket_lookups", "key_probes")] + \
-               [(n, C.c_float) for n in ("ms_translate", "ms_seed", "ms_eval", "ms_gapped", "ms_sort", "ms_finish", "ms_total")]
+               [(n, C.c_float) for n in ("ms_translate", "ms_seed", "ms_eval", "ms_gapped", "ms_sort", "ms_finish", "ms_total")] + \
+               [("_pad", C.c_float)] + [(n, C.c_int64) for n in ("seed_exact_asks", "seed_wild_asks", "seed_pair_asks", "seed_probes")]
 
 
 class McReaderStats(C.Structure):
@@ -91,6 +92,8 @@ def load_library():
     lib.mc_reader_close.argtypes = [C.c_void_p]
     lib.mc_count_bases.restype = C.c_int64
     lib.mc_count_bases.argtypes = [C.POINTER(C.c_char_p), C.c_int32]
+    lib.mc_quality_offset.restype = C.c_int32
+    lib.mc_quality_offset.argtypes = [C.c_char_p]
     lib.mc_reader_start.argtypes = [C.c_void_p]
     lib.mc_reader_fetch.restype = C.c_int64
     lib.mc_reader_fetch.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
@@ -109,7 +112,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
                     "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_set_parts", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8", "mc_write_m8_named",
-                    "mc_reader_last_error", "mc_reader_open", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_count_bases",
+                    "mc_reader_last_error", "mc_reader_open", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_count_bases", "mc_quality_offset",
                     "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows", "mc_grid_classify"]
 
 
@@ -183,6 +186,13 @@ def count_bases(paths):
     if n < 0:
         raise RuntimeError(lib.mc_reader_last_error().decode())
     return n
+
+
+def quality_offset(path):
+    """auto_detect_quality_offset by the native parser: 32 or 64; None when the Python path has to decide (a record without
+    qualities, an unreadable file: it then fails the way the reference does)."""
+    v = load_library().mc_quality_offset(path.encode())
+    return v if v in (32, 64) else None
 
 
 def rapdb_verify(rapdb_path, names, seqs):
@@ -361,7 +371,7 @@ class Engine:
     def stats(self):
         s = McStats()
         self._check(self.lib.mc_result_stats(self.h, C.byref(s)), "mc_result_stats")
-        return {k: getattr(s, k) for k, _ in McStats._fields_}
+        return {k: getattr(s, k) for k, _ in McStats._fields_ if not k.startswith("_")}
 
     def write_m8(self, path, append=False):
         self._check(self.lib.mc_write_m8(self.h, path.encode(), 1 if append else 0), "mc_write_m8")

@@ -45,7 +45,7 @@ extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
     } while (0)
 
 enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_HEAVY, C_HEAVY2, C_ITEMS, C_RETRY2, C_HEAVY3, C_LIGHT0, C_LIGHT1, C_LIGHT2, C_LIGHT3, C_N = 24 };
-enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_N = 16 };   // 64-bit algorithmic-traffic counters of k_enumerate; slots 4..: cycle counters of the MC_EXP_TIMING build
+enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_EXACT = 16, S_WILD, S_PAIRS, S_PROBES, S_N = 20 };   // 64-bit algorithmic-traffic counters of k_enumerate; slots 4..: cycle counters of the MC_EXP_TIMING build
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -616,6 +616,7 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
     if (lane == 0) { W->blk_base = 0; W->blk_used = MC_EN_BLK; }
     __syncthreads();
     McSeedCount sc; sc.lookups = 0; sc.keyprobes = 0; sc.tasks = 0;
+    uint32_t n_exact = 0, n_wild = 0, n_pairs = 0, n_probes = 0;         // what this wave asked its structures (wave-uniform)
     const unsigned long long lt = (1ull << lane) - 1;
     const int64_t nw = (int64_t)gridDim.x * MC_EN_WAVES;
 #ifdef MC_EXP_TIMING
@@ -731,6 +732,7 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
                     MC_TICK(2);
                     const int take = qn < 64 ? qn : 64;
                     qn -= take;
+                    n_probes += (uint32_t)take;
                     const unsigned long long ret = mc_en_process<COUNT>(X, (lane < take) ? W->q[qn + lane] : 0ull, lane < take, (uint32_t)r, W, hn, tasks, cap, counters, lane
 #ifdef MC_EXP_TIMING
                                                                              , &tlast, &tcat
@@ -766,6 +768,7 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
                     MC_TICK(5);
                     const int take = en < 64 ? en : 64;
                     en -= take;
+                    n_pairs += (uint32_t)take;
                     const bool act = lane < take;
                     xi = act ? W->eq[en + lane] : 0ull;
                     const int gl = (int)((xi >> 47) & 3), sd = (int)(xi & 0xFFFFF);
@@ -831,7 +834,9 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
                         bool defer = here && ((pw >> 49) & 1);
                         // both filters are asked before either answer is looked at: their reads are in flight together
                         const bool ask = live || defer;
-                        const bool any9 = !COUNT && __ballot(live0), anyw = !COUNT && __ballot(ask);
+                        const unsigned long long m9 = __ballot(live0), mw = __ballot(ask);
+                        const bool any9 = !COUNT && m9, anyw = !COUNT && mw;
+                        n_exact += (uint32_t)__popcll(m9); n_wild += (uint32_t)__popcll(mw);
                         const uint32_t qk0 = (qk & 0xFFF0u) | 0xFu;
                         uint32_t fw9 = 0, fb9 = 0, wsum = 0;
                         uint4 q0 = {0, 0, 0, 0}, q1 = {0, 0, 0, 0};
@@ -900,7 +905,7 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
     {
         unsigned long long a = sc.lookups, b = sc.keyprobes, c = sc.tasks;
         for (int d = 32; d > 0; d >>= 1) { a += __shfl_down(a, d); b += __shfl_down(b, d); c += __shfl_down(c, d); }
-        if (lane == 0) { atomicAdd(&stats[S_LOOKUPS], a); atomicAdd(&stats[S_KEYPROBES], b); atomicAdd(&stats[S_TASKS], c); }
+        if (lane == 0) { atomicAdd(&stats[S_LOOKUPS], a); atomicAdd(&stats[S_KEYPROBES], b); atomicAdd(&stats[S_TASKS], c); atomicAdd(&stats[S_EXACT], (unsigned long long)n_exact); atomicAdd(&stats[S_WILD], (unsigned long long)n_wild); atomicAdd(&stats[S_PAIRS], (unsigned long long)n_pairs); atomicAdd(&stats[S_PROBES], (unsigned long long)n_probes); }
     }
 }
 
@@ -2168,6 +2173,7 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         { const char *nm[6] = {"staging/other", "append", "lookup", "push", "setup", "expand"}; for (int k = 0; k < 6; k++) fprintf(stderr, "timing %-14s %8.3f Mcycles/wave-avg  %10llu entries\n", nm[k], (double)c.h_stats[4 + k] / 4096.0 / 1e6, c.h_stats[10 + k]); }
 #endif
         h->stats.bucket_lookups += (int64_t)c.h_stats[S_LOOKUPS]; h->stats.key_probes += (int64_t)c.h_stats[S_KEYPROBES]; h->stats.seed_tasks += (int64_t)c.h_stats[S_TASKS];
+        h->stats.seed_exact_asks += (int64_t)c.h_stats[S_EXACT]; h->stats.seed_wild_asks += (int64_t)c.h_stats[S_WILD]; h->stats.seed_pair_asks += (int64_t)c.h_stats[S_PAIRS]; h->stats.seed_probes += (int64_t)c.h_stats[S_PROBES];
         h->stats.gap_tasks += c.ngaps; h->stats.hsps += c.nh; h->stats.rows += c.nrows; h->stats.reads_with_rows += c.nsegs;
         // kernel times: HIP events on the part's own stream (the parts overlap, so the sums exceed the wall time of the call)
         h->stats.ms_translate += ev_ms(c.ev[0], c.ev[1]); h->stats.ms_seed += ev_ms(c.ev[1], c.ev[2]); h->stats.ms_eval += ev_ms(c.ev[2], c.ev[3]);

@@ -756,6 +756,33 @@ extern "C" int64_t mc_count_bases(const char *const *paths, int32_t npaths)
     return total;
 }
 
+// auto_detect_quality_offset (microbe_census.py:175-187): the first quality character of the file that decides - one of
+// !"#$%&'()*+,-./0123456789 says 32, one of K..~ says 64, a file without either says 32.  The reference walks the records with
+// its Python parser until it finds one (the whole file if every quality lies in ':'..'J'); this walks them with the native
+// parser.  Returns 32 or 64; -2 when a record has no quality line (the caller then takes the Python path and fails the way the
+// reference does); < 0 otherwise as the reader's other entry points.
+extern "C" int32_t mc_quality_offset(const char *path)
+{
+    if (!path) { r_err = "null path"; return -1; }
+    int32_t answer = 0;
+    Pool pool(reader_threads());
+    Params P; P.count_only = true;
+    const int rc = walk_file(path, P, pool, [&](std::vector<Piece *> &order) -> bool {
+        for (Piece *pc : order)
+            for (const Rec &r : pc->recs) {
+                if (!r.qual) { answer = -2; return false; }
+                for (uint32_t i = 0; i < r.qlen; i++) {
+                    const uint8_t ch = r.qual[i];
+                    if (ch >= '!' && ch <= '9') { answer = 32; return false; }
+                    if (ch >= 'K' && ch <= '~') { answer = 64; return false; }
+                }
+            }
+        return true;
+    });
+    if (rc < 0) return rc;
+    return answer ? answer : 32;
+}
+
 // ---- streaming form ---------------------------------------------------------------------------------------------------
 extern "C" int mc_reader_start(mc_reader *r)
 {

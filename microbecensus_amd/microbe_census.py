@@ -225,6 +225,14 @@ def auto_detect_file_type(seqfile):
 
 def auto_detect_quality_offset(seqfile):
     """32 or 64, literally (reference :175-187: the value is later subtracted from ord(char))."""
+    if not os.environ.get("MCENSUS_PYTHON_READER"):   # the same walk by the native parser (a file whose qualities all lie in ':'..'J' is walked to its end)
+        try:
+            from . import _native
+            v = _native.quality_offset(seqfile)
+            if v is not None:
+                return v
+        except Exception:
+            pass
     low = set("""!"#$%&'()*+,-./0123456789""")
     high = set("""KLMNOPQRSTUVWXYZ[\\]^_`abcdefghijklmnopqrstuvwxyz{|}~""")
     with open_file(seqfile) as f_in:

@@ -185,3 +185,46 @@ def test_streaming_fetch_equals_run(tmp_path):
     assert lib.mc_reader_join(rd.r) == st["sampled"] == at
     assert (np.concatenate(got) == want).all()
     rd.close()
+
+
+@pytest.mark.parametrize("quals,expect", [
+    (["IIIIIIII", "IIII5III"], 32),          # a low character decides
+    (["IIIIIIII", "IIIIhIII"], 64),          # a high character decides
+    (["IIIIIIII", "JJJJ::::"], 32),          # nothing decides: the whole file is walked, 32
+    (["hIII5III"], 64),                      # the first one that decides wins
+    (["IIII", "II5I"], 32),                  # (with the multi-line record below)
+])
+def test_quality_offset_native_equals_python(quals, expect, tmp_path, monkeypatch):
+    """auto_detect_quality_offset (reference :175-187) by the native parser, against the Python statement of the same walk;
+    plain, gz, multi-line records, many regions and pieces."""
+    import gzip
+    from microbecensus_amd import _native, microbe_census as mc
+    recs = []
+    for i, q in enumerate(quals * 40):
+        seq = "ACGTNACG"[:len(q)]
+        if i % 7 == 3 and len(q) == 8:       # a record whose sequence and quality span two lines
+            recs.append("@r%d\n%s\n%s\n+\n%s\n%s\n" % (i, seq[:4], seq[4:], q[:4], q[4:]))
+        else:
+            recs.append("@r%d\n%s\n+\n%s\n" % (i, seq, q))
+    text = "".join(recs)
+    plain = tmp_path / "q.fq"; plain.write_text(text)
+    gz = tmp_path / "q.fq.gz"
+    with gzip.open(gz, "wt") as f:
+        f.write(text)
+    for path in (str(plain), str(gz)):
+        for geom in ({}, {"MC_READER_REGION_BYTES": "97", "MC_READER_PIECE_BYTES": "13"}):
+            for k, v in geom.items():
+                monkeypatch.setenv(k, v)
+            assert _native.quality_offset(path) == expect
+            for k in geom:
+                monkeypatch.delenv(k)
+        monkeypatch.setenv("MCENSUS_PYTHON_READER", "1")
+        assert mc.auto_detect_quality_offset(path) == expect
+        monkeypatch.delenv("MCENSUS_PYTHON_READER")
+        assert mc.auto_detect_quality_offset(path) == expect
+
+
+def test_quality_offset_of_a_fasta_record_is_left_to_python(tmp_path):
+    from microbecensus_amd import _native
+    p = tmp_path / "x.fa"; p.write_text(">a\nACGT\n>b\nACGT\n")
+    assert _native.quality_offset(str(p)) is None
