@@ -2269,6 +2269,7 @@ static int run_stream(mc_handle *h, const std::function<int64_t(uint8_t *, int64
             all_best.insert(all_best.end(), h->best.begin(), h->best.end());
             tot.reads += h->stats.reads; tot.seed_tasks += h->stats.seed_tasks; tot.gap_tasks += h->stats.gap_tasks; tot.hsps += h->stats.hsps; tot.rows += h->stats.rows;
             tot.reads_with_rows += h->stats.reads_with_rows; tot.classified += h->stats.classified; tot.bucket_lookups += h->stats.bucket_lookups; tot.key_probes += h->stats.key_probes;
+            tot.seed_exact_asks += h->stats.seed_exact_asks; tot.seed_wild_asks += h->stats.seed_wild_asks; tot.seed_pair_asks += h->stats.seed_pair_asks; tot.seed_probes += h->stats.seed_probes;
             tot.ms_translate += h->stats.ms_translate; tot.ms_seed += h->stats.ms_seed; tot.ms_eval += h->stats.ms_eval; tot.ms_gapped += h->stats.ms_gapped;
             tot.ms_sort += h->stats.ms_sort; tot.ms_finish += h->stats.ms_finish; tot.ms_total += h->stats.ms_total;
             off += nb;
