@@ -96,10 +96,10 @@ int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t first_read_
 int mc_set_parts(mc_handle *h, int parts);
 
 /* The seed kernel can count the index reads of the reference's algorithm for the batch (mc_stats.bucket_lookups /
- * key_probes: what CHashSearch::Searching@0x415050 / ExtendSeq2Set@0x413b90 would read - the algorithmic traffic the
- * roofline of bench.py is priced on).  Off by default: the two fields stay 0 and the kernel rejects most
- * one-substitution probes with a Bloom filter over the index's 10-mers instead of searching them.  With on != 0 every
- * probe is searched and counted.  Results do not depend on it. */
+ * key_probes: what CHashSearch::Searching@0x415050 / ExtendSeq2Set@0x413b90 would read - bench.py reports the rate at which
+ * the timed kernel disposes of them).  Off by default: the two fields stay 0 and the kernel answers most one-substitution
+ * probes from its wildcard and pair filters instead of searching them (mc_stats.seed_* count what it asks).  With on != 0
+ * every probe is searched and counted.  Results do not depend on it. */
 int mc_set_counting(mc_handle *h, int on);
 
 /* Results of the last mc_search()/mc_run(), owned by the handle until the next call:
