@@ -385,7 +385,35 @@ MC_HD double mc_rg_getprob(const double *lnfac, uint64_t sv, int total)
 // A window of up to 15 residues has one of a few thousand (length, state vector) pairs - the partitions of every t <= len into
 // counts - and its probability depends on nothing else.  The host evaluates mc_rg_getprob once per pair (same IEEE double
 // operations as the device would perform, same order: bit-identical) and the kernel reads the order-preserving key of the
-// result out of an open-addressing table: key word = state vector (<= 15 nibbles) | length << 60.  8192 slots of 16 bytes.
+// result out of an open-addressing table: key word = histogram of the state vector's counts | length << 60.  8192 slots of 16 bytes.
+// The key of a pair is not the sorted state vector but the HISTOGRAM of its counts (nibble c - 1 = number of classes that occur
+// c times; at most 15 classes, counts up to 15: 60 bits): the same information, and sliding a window changes two nibbles of it
+// - no search for "the first entry equal to the class' count" as in Seg::incrementsv / decrementsv.
+struct McRhState { uint64_t clo; uint32_t chi; uint64_t hist; };   // counts of classes 0..15 / 16..19 (4 bit each), histogram of the counts
+MC_HD void mc_rh_add(McRhState &st, int r)
+{
+    if (r >= 20) return;
+    const int sh = (r & 15) * 4;
+    const int x = (r < 16) ? (int)((st.clo >> sh) & 15) : (int)((st.chi >> sh) & 15);       // the class' count so far
+    st.hist += 1ull << (4 * x);                                                             // one more class with x + 1
+    if (x) st.hist -= 1ull << (4 * (x - 1));                                                // one less with x
+    if (r < 16) st.clo += 1ull << sh; else st.chi += 1u << sh;
+}
+MC_HD void mc_rh_remove(McRhState &st, int r)
+{
+    if (r >= 20) return;
+    const int sh = (r & 15) * 4;
+    const int x = (r < 16) ? (int)((st.clo >> sh) & 15) : (int)((st.chi >> sh) & 15);       // >= 1
+    st.hist -= 1ull << (4 * (x - 1));
+    if (x > 1) st.hist += 1ull << (4 * (x - 2));
+    if (r < 16) st.clo -= 1ull << sh; else st.chi -= 1u << sh;
+}
+MC_HD uint64_t mc_rh_of_sv(uint64_t sv)
+{ // histogram of a sorted state vector (host: table build, checks)
+    uint64_t h = 0;
+    for (uint64_t w = sv; (w & 15) != 0; w >>= 4) h += 1ull << (4 * ((w & 15) - 1));
+    return h;
+}
 #define MC_SEGTAB_LOG2 13
 #define MC_SEGTAB_SLOTS (1u << MC_SEGTAB_LOG2)
 MC_HD uint64_t mc_seg_prob_key(double x)
@@ -401,9 +429,9 @@ MC_HD uint32_t mc_segtab_hash(uint64_t k)
     return x >> (32 - MC_SEGTAB_LOG2);
 }
 // tab: MC_SEGTAB_SLOTS x {key word, probability key}; an empty slot has key word 0 (no pair has an empty state vector AND length 0)
-MC_HD uint64_t mc_segtab_lookup(const uint64_t *tab, uint64_t sv, int len)
+MC_HD uint64_t mc_segtab_lookup(const uint64_t *tab, uint64_t hist, int len)
 {
-    const uint64_t k = sv | ((uint64_t)len << 60);
+    const uint64_t k = hist | ((uint64_t)len << 60);
     uint32_t h = mc_segtab_hash(k);
     for (;;) {
         const uint64_t kk = tab[2 * h];

@@ -215,15 +215,15 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
             uint32_t kq = 0xFFFFFFFFu;
             if (ok) {
                 if (cls == 0) {
-                    McRgState rg; rg.clo = 0; rg.chi = 0; rg.sv = 0;
-                    for (int k = 0; k < len; k++) mc_rg_add(rg, s[wfirst + k]);
+                    McRhState rg; rg.clo = 0; rg.chi = 0; rg.hist = 0;
+                    for (int k = 0; k < len; k++) mc_rh_add(rg, s[wfirst + k]);
                     // the state vectors of the run first, then their table reads (in flight together), then the comparison in window order
                     const int cnt = wlast - wfirst + 1;
                     uint64_t svs[8], kk[8], vv[8];
 #pragma unroll
                     for (int t = 0; t < 8; t++) {
-                        svs[t] = rg.sv;
-                        if (t + 1 < cnt) { mc_rg_remove(rg, s[wfirst + t]); mc_rg_add(rg, s[wfirst + t + len]); }
+                        svs[t] = rg.hist;
+                        if (t + 1 < cnt) { mc_rh_remove(rg, s[wfirst + t]); mc_rh_add(rg, s[wfirst + t + len]); }
                     }
 #pragma unroll
                     for (int t = 0; t < 8; t++) {

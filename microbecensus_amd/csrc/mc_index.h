@@ -469,7 +469,7 @@ inline void mc_build_segtab(const double *lnfac, std::vector<uint64_t> &tab)
         void emit(uint64_t sv, int t)
         {
             for (int len = (t > 2 ? t : 2); len <= 15; len++) {
-                const uint64_t k = sv | ((uint64_t)len << 60);
+                const uint64_t k = mc_rh_of_sv(sv) | ((uint64_t)len << 60);
                 uint32_t h = mc_segtab_hash(k);
                 while (tab[2 * h] != 0) h = (h + 1) & (MC_SEGTAB_SLOTS - 1);
                 tab[2 * h] = k; tab[2 * h + 1] = mc_seg_prob_key(mc_rg_getprob(lnfac, sv, len));

@@ -148,12 +148,12 @@ int main(int argc, char **argv)
     std::vector<uint8_t> frames((size_t)rs.size() * 6 * FP);
     long seg_frames = 0, seg_bad = 0;
     { double mm = 0; int bad = mc_seg_fx_verify(T, &mm); fprintf(stderr, "seg fixed-point tests: %d disagreements over all window compositions, closest entropy %.3g from a cut\n", bad, mm); if (bad) return 3; }
-    {   // the tabulated Seg::getprob of short windows (what k_translate_seg reads) against the function itself: every window of 300,000 random stretches
+    {   // the tabulated Seg::getprob of short windows (what k_translate_seg reads) against the function itself: every window of 100,000 random stretches
         std::vector<uint64_t> tab;
         mc_build_segtab(T.lnfac, tab);
         size_t used = 0; for (size_t i = 0; i < tab.size(); i += 2) used += tab[i] != 0;
         uint64_t rng = 0x9E3779B97F4A7C15ull; long checked = 0, badp = 0;
-        for (int it = 0; it < 300000; it++) {
+        for (int it = 0; it < 100000; it++) {
             uint8_t w[15];
             rng = rng * 6364136223846793005ull + 1442695040888963407ull;
             const int n = 2 + (int)((rng >> 33) % 14), alpha = 1 + (int)((rng >> 40) % 6);          // low-complexity: few distinct residues
@@ -162,8 +162,12 @@ int main(int argc, char **argv)
                 for (int i = 0; i + len <= n; i++) {
                     McRgState st; st.clo = 0; st.chi = 0; st.sv = 0;
                     for (int k = 0; k < len; k++) mc_rg_add(st, w[i + k]);
+                    // the kernel's form of the state: histogram of the counts, kept while the window slides in from the left end of the stretch
+                    McRhState rh; rh.clo = 0; rh.chi = 0; rh.hist = 0;
+                    for (int k = 0; k < len; k++) mc_rh_add(rh, w[k]);
+                    for (int k = 0; k < i; k++) { mc_rh_remove(rh, w[k]); mc_rh_add(rh, w[k + len]); }
                     checked++;
-                    if (mc_segtab_lookup(tab.data(), st.sv, len) != mc_seg_prob_key(mc_rg_getprob(T.lnfac, st.sv, len))) badp++;
+                    if (rh.hist != mc_rh_of_sv(st.sv) || mc_segtab_lookup(tab.data(), rh.hist, len) != mc_seg_prob_key(mc_rg_getprob(T.lnfac, st.sv, len))) badp++;
                 }
         }
         fprintf(stderr, "seg probability table: %zu pairs in %u slots; %ld windows checked, %ld differ from mc_rg_getprob\n", used, MC_SEGTAB_SLOTS, checked, badp);
