@@ -50,16 +50,16 @@ enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_EXACT = 16, S_WILD, S_PAIRS, S_PRO
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-// One thread per (read, frame); a block of 256 threads owns 42 consecutive reads (252 frames).  The reads are staged
-// into LDS with coalesced 16-byte loads, every thread translates its frame into its own LDS row, runs SEG there
-// (composition / state vector / work list in LDS, the window flags in registers) and the block writes the frames back
-// with coalesced stores.  LDS per block: 42*L + 256*(FP+76) bytes (~40 KB at 150 bp).
-#define MC_TS_READS 42
+// k_translate_seg: one thread per (read, frame); a workgroup is ONE wave and owns 10 consecutive reads (60 frames) - a workgroup
+// of four waves (42 reads) waited for its slowest SEG: 5.75 against 5.27 ms per 1 M reads of 150 bp.
+#define MC_TS_THREADS 64
+#define MC_TS_WAVES (MC_TS_THREADS / 64)
+#define MC_TS_READS (MC_TS_THREADS / 6)
 // row pitch: an odd number of 32-bit words, so that the 64 lanes of a wave touching the same offset of their rows
 // fall into different LDS banks (a pitch of 128 bytes put all of them into one)
 #define MC_TS_NLNF(FP) ((FP) + 2 > 24 ? (FP) + 2 : 24)
 #define MC_TS_STRIDE(FP) (((((FP) + 76 + 3) >> 2) | 1) << 2)
-#define MC_TS_STAGE(L) ((((MC_TS_READS * (L)) > 4 * 1488 ? (MC_TS_READS * (L)) : 4 * 1488) + 15) & ~15)   // read staging, later 4 x McSegWaveLds
+#define MC_TS_STAGE(L) ((((MC_TS_READS * (L)) > MC_TS_WAVES * 1488 ? (MC_TS_READS * (L)) : MC_TS_WAVES * 1488) + 15) & ~15)   // read staging, later one McSegWaveLds per wave
 
 __device__ __forceinline__ int mc_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 // orders the wave's own LDS traffic for the compiler; the hardware executes one wave's LDS instructions in order
@@ -85,9 +85,9 @@ __device__ __forceinline__ void mc_wave_sync() { __builtin_amdgcn_fence(__ATOMIC
 // lanes (each builds its window's composition from scratch, in registers for windows <= 15 residues), and the least
 // probable window of every stretch (the first one in the reference's iteration order on a tie) is found with LDS
 // atomics.  The double arithmetic of getprob is the reference's, operation by operation.
-struct McSegWaveLds { unsigned long long best[64]; uint32_t pre[66]; uint32_t pre2[66]; uint32_t bq[64]; uint16_t off[64]; uint8_t n[64]; };   // 1,488 B per wave (four of them must fit under the 42 staged reads: 4 workgroups per CU at 150 bp)
+struct McSegWaveLds { unsigned long long best[64]; uint32_t pre[66]; uint32_t pre2[66]; uint32_t bq[64]; uint16_t off[64]; uint8_t n[64]; };   // 1,488 B per wave (it lies under the staged reads)
 static_assert(sizeof(McHsp) == 48 && sizeof(McGapTask) % 4 == 0, "k_eval_seeds copies its staging buffers as 16- and 4-byte words");
-static_assert(sizeof(McSegWaveLds) == 1488, "MC_TS_STAGE reserves 4 x 1488 bytes");
+static_assert(sizeof(McSegWaveLds) == 1488, "MC_TS_STAGE reserves 1488 bytes per wave");
 #ifdef MC_EXP_TIMING
 __device__ unsigned long long g_ts_acc[8], g_ts_cnt[8];
 #define MC_TS_TICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane == 0) { atomicAdd(&g_ts_acc[tcat_], now_ - tlast_); atomicAdd(&g_ts_cnt[tcat_], 1ull); } tlast_ = now_; tcat_ = (k); } while (0)
@@ -293,12 +293,12 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
     MC_TS_TICK(0);
 }
 
-// One thread per (read, frame); a block of 256 threads owns 42 consecutive reads (252 frames).  The reads are staged
-// into LDS with coalesced loads, every thread translates its frame into its own LDS row, the four waves run SEG on their
-// 64 frames each (mc_seg_wave) and the block writes the frames back with coalesced stores.  LDS per block:
-// max(42*L, 4 x 1,416) + ln n! + 256*(FP+76) bytes (~40 KB at 150 bp; the staging area is reused by the SEG queues).
+// One thread per (read, frame).  The workgroup's reads are staged into LDS with coalesced loads, every thread translates its
+// frame into its own LDS row, the wave runs SEG on its frames (mc_seg_wave) and writes them back with coalesced stores.
+// LDS per workgroup: max(10 L, 1,488) + ln n! + 64 (FP + 76) bytes (~10 KB at 150 bp; the staging area is reused by the SEG
+// queues) - the registers (127) allow 16 waves per CU, the LDS holds 15.
 template <bool STAGED>                                           // STAGED: the block's reads go through LDS (coalesced); otherwise each thread
-__global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(256) k_translate_seg(const McTables *__restrict__ T, const uint8_t *__restrict__ reads, int L,   // walks its read in global memory and the LDS it saves buys a workgroup per CU (long reads)
+__global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(MC_TS_THREADS) k_translate_seg(const McTables *__restrict__ T, const uint8_t *__restrict__ reads, int L,   // walks its read in global memory and the LDS it saves buys a workgroup per CU (long reads)
                                                        int64_t nreads, uint8_t *__restrict__ frames, int FP, const uint64_t *__restrict__ segtab)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -313,15 +313,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(256
     double *lnf = (double *)(smem + (STAGED ? MC_TS_STAGE(L) : MC_TS_STAGE(0)));   // ln n! for n <= max(frame length, 20): all the trimming asks for
     uint8_t *rows = (uint8_t *)(lnf + nlnf);
     if (tid < 64) fxs[tid] = T->seg_dout[tid];                   // seg_dout, seg_din, seg_tlo, seg_thi are contiguous
-    for (int i = tid; i < nlnf; i += 256) lnf[i] = T->lnfac[i];
+    for (int i = tid; i < nlnf; i += MC_TS_THREADS) lnf[i] = T->lnfac[i];
     if (STAGED) {   // coalesced staging of this block's reads: 4 bytes per lane where the slice allows it (it starts at r0*L: any alignment)
         const uint8_t *src = reads + r0 * L;
         const int head = (int)((4 - ((uintptr_t)src & 3)) & 3), nhead = head < rbytes ? head : rbytes;
         if (tid < nhead) sreads[tid] = src[tid];
         const int nw = (rbytes - nhead) >> 2;
-        if (nhead == 0) for (int i = tid; i < nw; i += 256) ((uint32_t *)sreads)[i] = ((const uint32_t *)src)[i];
-        else for (int i = tid; i < nw; i += 256) { const uint32_t w = ((const uint32_t *)(src + nhead))[i]; uint8_t *d = sreads + nhead + 4 * i; d[0] = (uint8_t)w; d[1] = (uint8_t)(w >> 8); d[2] = (uint8_t)(w >> 16); d[3] = (uint8_t)(w >> 24); }
-        for (int i = nhead + 4 * nw + tid; i < rbytes; i += 256) sreads[i] = src[i];
+        if (nhead == 0) for (int i = tid; i < nw; i += MC_TS_THREADS) ((uint32_t *)sreads)[i] = ((const uint32_t *)src)[i];
+        else for (int i = tid; i < nw; i += MC_TS_THREADS) { const uint32_t w = ((const uint32_t *)(src + nhead))[i]; uint8_t *d = sreads + nhead + 4 * i; d[0] = (uint8_t)w; d[1] = (uint8_t)(w >> 8); d[2] = (uint8_t)(w >> 16); d[3] = (uint8_t)(w >> 24); }
+        for (int i = nhead + 4 * nw + tid; i < rbytes; i += MC_TS_THREADS) sreads[i] = src[i];
     }
     __syncthreads();
     const int lr = tid / 6, f = tid - lr * 6;
@@ -338,7 +338,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(256
     {   // frames of the block are contiguous in global memory: nr*6 rows of FP bytes
         uint32_t *dst = (uint32_t *)(frames + r0 * 6 * FP);          // (FP and the LDS row pitch are multiples of 4: a word never straddles two rows)
         const int total = nr * 6 * FP / 4, fpw = FP / 4;
-        for (int i = tid; i < total; i += 256) { const int row = i / fpw, col = i - row * fpw; dst[i] = *(const uint32_t *)(rows + (size_t)row * stride + 4 * col); }
+        for (int i = tid; i < total; i += MC_TS_THREADS) { const int row = i / fpw, col = i - row * fpw; dst[i] = *(const uint32_t *)(rows + (size_t)row * stride + 4 * col); }
     }
 }
 
@@ -1948,7 +1948,7 @@ static int stage_a(mc_handle *h, McCtx &c)
     HIPCK(hipMemsetAsync(c.d_stats, 0, sizeof(unsigned long long) * S_N, st));
     HIPCK(hipEventRecord(c.ev[0], st));
     const int64_t threads = n * 6;
-    const size_t lds_rest = (size_t)MC_TS_NLNF(FP) * 8 + (size_t)256 * MC_TS_STRIDE(FP);
+    const size_t lds_rest = (size_t)MC_TS_NLNF(FP) * 8 + (size_t)MC_TS_THREADS * MC_TS_STRIDE(FP);
     const size_t lds_staged = (size_t)MC_TS_STAGE(L) + lds_rest, lds_direct = (size_t)MC_TS_STAGE(0) + lds_rest;
     static const int ts_force = getenv("MC_TS_STAGED") ? atoi(getenv("MC_TS_STAGED")) : -1;
     const size_t cu_lds = 160 * 1024 - 1024;                      // (static LDS of the kernel and allocation granules)
@@ -1956,10 +1956,10 @@ static int stage_a(mc_handle *h, McCtx &c)
     const size_t lds = staged ? lds_staged : lds_direct;
     if (staged) {
         if (lds > 48 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_translate_seg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_translate_seg<true><<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(256), lds, st>>>(h->d_T, c.reads, L, n, c.d_frames, FP, h->d_segtab);
+        k_translate_seg<true><<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(MC_TS_THREADS), lds, st>>>(h->d_T, c.reads, L, n, c.d_frames, FP, h->d_segtab);
     } else {
         if (lds > 48 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_translate_seg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_translate_seg<false><<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(256), lds, st>>>(h->d_T, c.reads, L, n, c.d_frames, FP, h->d_segtab);
+        k_translate_seg<false><<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(MC_TS_THREADS), lds, st>>>(h->d_T, c.reads, L, n, c.d_frames, FP, h->d_segtab);
     }
     HIPCK(hipEventRecord(c.ev[1], st));
 #ifdef MC_EXP_TIMING
@@ -1968,7 +1968,7 @@ static int stage_a(mc_handle *h, McCtx &c)
         unsigned long long acc[8], cnt[8];
         HIPCK(hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_ts_acc), sizeof acc)); HIPCK(hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_ts_cnt), sizeof cnt));
         const char *nm[8] = {"flags", "advance", "numbering", "class-0 rounds", "class-1 rounds", "reduction", "owners", "mask"};
-        const double waves = (double)((n + MC_TS_READS - 1) / MC_TS_READS) * 4.0;
+        const double waves = (double)((n + MC_TS_READS - 1) / MC_TS_READS) * MC_TS_WAVES;
         for (int k = 0; k < 8; k++) fprintf(stderr, "ts-timing %-15s %9.1f cycles/wave  %8.2f entries/wave\n", nm[k], (double)acc[k] / waves, (double)cnt[k] / waves);
         unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_ts_acc), z, sizeof z)); HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_ts_cnt), z, sizeof z));
