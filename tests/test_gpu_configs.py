@@ -288,3 +288,28 @@ def test_config5_shape_at_size_native_sampler_equals_python_statement(tmp_path):
     assert args["read_length"] == 300 and args["sampled_reads"] == args_py["sampled_reads"]
     assert 0.90 * n < args["sampled_reads"] < 0.94 * n           # ~5 % low quality, ~3 % duplicates
     assert est == est_py
+
+
+@pytest.mark.gpu
+def test_read_lengths_off_the_reference_grid_against_the_oracle(tmp_path):
+    """The C ABI takes any read length from 18 to 510 bp (the reference's CLI only the 20 lengths of its parameter table):
+    the shortest, some odd ones and the longest, genome reads, m8 md5 against the oracle's (every launch shape of the seed
+    kernel and both staging forms of k_translate_seg are among them)."""
+    from microbecensus_amd import _native, synth
+    port, db = os.path.join(REPO, "oracle", "rs_port"), os.path.join(REPO, "oracle", "_ref", "rapdb_2.15")
+    if not (os.path.exists(port) and os.path.exists(db)):
+        pytest.skip("oracle not built")
+    gen = synth.GenomeReads(device="cpu", seed=77)
+    eng = _native.Engine(device=0)
+    try:
+        for L, n in ((18, 4000), (33, 6000), (47, 6000), (64, 6000), (199, 5000), (255, 4000), (510, 2500)):
+            reads = gen.single(n, L, first=L * 7919).numpy()
+            fa = tmp_path / "r.fa"
+            fa.write_text("".join(">%d\n%s\n" % (i, bytes(r).decode()) for i, r in enumerate(reads)))
+            eng.set_run(L)
+            eng.search(reads)
+            eng.write_m8(str(tmp_path / "gpu.m8"))
+            subprocess.check_call([port, db, str(fa), str(tmp_path / "cpu.m8")])
+            assert hashlib.md5((tmp_path / "gpu.m8").read_bytes()).hexdigest() == hashlib.md5((tmp_path / "cpu.m8").read_bytes()).hexdigest(), "read length %d" % L
+    finally:
+        eng.close()
