@@ -535,10 +535,10 @@ def classify_reads(args, paths):
     cache = _run_cache.get(paths["tempfile"], {})
     if cache.get("best") is not None:
         fams = cache["families"]
-        best_hits = {}
-        for b in cache["best"]:          # ascending read id = the order the reference meets them in the m8
-            aln = float(b["aln"])
-            best_hits[str(int(b["read"]))] = [fams[b["family"]], aln, aln / float(b["target_len"]), float(b["bits"])]
+        b = cache["best"]                # ascending read id = the order the reference meets them in the m8
+        aln = b["aln"].astype(np.float64)
+        cov = aln / b["target_len"].astype(np.float64)
+        best_hits = {str(r): [fams[f], a, c, s] for r, f, a, c, s in zip(b["read"].tolist(), b["family"].tolist(), aln.tolist(), cov.tolist(), b["bits"].astype(np.float64).tolist())}
     else:
         best_hits = _classify_m8_file(args, paths)
     if len(best_hits) == 0:

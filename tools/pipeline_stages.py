@@ -44,3 +44,9 @@ for rep in range(3):
         res = mc.run_pipeline(args)
     dt = time.time() - t
     print("run %d: %.3f s = %.2f M reads/s" % (rep, dt, n / dt / 1e6), {k: round(v, 3) for k, v in timers.items()})
+import cProfile, pstats
+args = {"seqfiles": [path], "device": 0, "nreads": n, "read_length": L}
+pr = cProfile.Profile()
+with contextlib.redirect_stdout(io.StringIO()):
+    pr.enable(); res = mc.run_pipeline(args); pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
