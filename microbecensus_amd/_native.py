@@ -82,6 +82,8 @@ def load_library():
     lib.mc_write_m8.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.mc_write_m8_named.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_int64, C.c_int64]
     lib.mc_reader_last_error.restype = C.c_char_p
+    lib.mc_set_host_threads.restype = None
+    lib.mc_set_host_threads.argtypes = [C.c_int32]
     lib.mc_reader_open.restype = C.c_void_p
     lib.mc_reader_open.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_char_p]
     lib.mc_reader_run.restype = C.c_int64
@@ -112,7 +114,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
                     "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_set_parts", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8", "mc_write_m8_named",
-                    "mc_reader_last_error", "mc_reader_open", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_count_bases", "mc_quality_offset",
+                    "mc_reader_last_error", "mc_set_host_threads", "mc_reader_open", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_count_bases", "mc_quality_offset",
                     "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows", "mc_grid_classify"]
 
 

@@ -1276,130 +1276,189 @@ MC_HDN McGapResult mc_align_gapped(const TT &T, const uint8_t *s1, int st1, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same extension on a SLIDING WINDOW of W columns with 12-byte cells - the form k_gapped runs with the window in LDS.
+// The same extension on a SLIDING WINDOW of W columns with 12-byte cells - the form the gapped kernels run with the window in LDS.
 //
 // * Only the columns jStart-1 .. jEnd of the previous row are ever read again (jStart never decreases, a row writes every
 //   column it leaves behind up to its new jEnd), so the DP rows live in a circular buffer indexed by column mod W; a write to a
-//   column >= (jStart-1) + W means the band is wider than the window: overflow, the caller repeats the flank with
-//   mc_align_gapped on a full-size workspace.
-// * Path statistics in 32 bits: ident | diag << 8 | runs << 16 | cls << 24 (diag = number of substitution steps).  A path
-//   from the origin to cell (i, j) has i = diag + D-gap columns and j = diag + E-gap columns, so the gap columns and the number
-//   of steps need not be carried: gapcols = i + j - 2 diag, steps = i + j - diag.  No field can overflow: ident <= diag <=
-//   MC_MAXAA = 170 < 256; every gap run costs >= open + ext = 12 and every substitution step gains <= 11, and a path that is
-//   still alive scores >= -xdrop, so runs <= (11 * 170 + 27) / 12 = 158 < 256.
+//   column >= (jStart-1) + W means the band is wider than the window: overflow, the caller repeats the flank with a wider window
+//   or with mc_align_gapped on a full-size workspace.
+// * Path statistics in 24 bits: ident | diag << 8 | runs << 16 (diag = number of substitution steps).  A path from the origin
+//   to cell (i, j) has i = diag + D-gap columns and j = diag + E-gap columns, so the gap columns and the number of steps need
+//   not be carried: gapcols = i + j - 2 diag, steps = i + j - diag.  No field can overflow: ident <= diag <= MC_MAXAA = 170 <
+//   256; every gap run costs >= open + ext = 12 and every substitution step gains <= 11, and a path that is still alive scores
+//   >= -xdrop, so runs <= (11 * 170 + 27) / 12 = 158 < 256.
+// * The class of a path's last step (mc_align_gapped's McPath::cls, which decides whether a gap step opens a new run) is not
+//   carried: it follows from the step itself.  OPENING a gap from a main cell (a >= b) means main - first >= plane - ext, i.e.
+//   main >= plane + 11 > plane: the main cell did not take its value from that plane, so its path does not end in a gap of that
+//   class - always a new run (the left border of a row and the cells of row 0 / of the right growth have main - D = open or
+//   main = D: they tie or lose, see below).  EXTENDING continues the plane's own path: never a new run - except through the D
+//   plane of a cell written by row 0 or by the right growth, whose "D path" is the cell's E path (PD = PH there): only the left
+//   border of a later row can continue such a cell (an in-band cell over it has main - first = D - ext: a tie, which opens), so
+//   those cells carry a flag (MC_PD_GROW) that the border looks at.
 // * Scores in 16 bits: |score| <= 11 * 170 + 64.
-// * The subject residue of a column travels with the column's cell (read from memory once, when the column enters the band).
-// WS: load(slot, H, D, PH, PD, y) / store(slot, H, D, PH, PD, y) / loadH(slot), slot = 0 .. W-1 (the accessor owns the layout).
+// * The subject residue of a column travels with the column's cell (read from memory once, when the column enters the band):
+//   bits 24..28 of the PD word.
+// WS: load(slot, H, D, PH, PD) / store(slot, H, D, PH, PD) / loadH(slot), slot = 0 .. W-1 (the accessor owns the layout).
+//
+// The extension is a state machine - mc_gap_begin (row 0), mc_gap_row (one DP row), mc_gap_result - so that a GPU lane can take
+// the next flank the moment its own ends (k_gapped_lds); mc_align_gapped_win runs it to the end for one flank.
 // ---------------------------------------------------------------------------------------------
-#define MC_PP_ZERO 0x03000000u
-MC_HD uint32_t mc_pp_gap(uint32_t p, uint32_t cls) { return ((p & 0x00FFFFFFu) + (((p >> 24) != cls) ? 0x10000u : 0u)) | (cls << 24); }
-MC_HD uint32_t mc_pp_diag(uint32_t p, bool same) { return (p & 0x00FFFFFFu) + 0x100u + (same ? 1u : 0u); }
+#define MC_PP_RUN 0x10000u
+#define MC_PD_GROW 0x80000000u
+#define MC_PD_YMASK 0x1F000000u
+#define MC_PD_PATH 0x00FFFFFFu
+
+struct McGapState {
+    const uint8_t *s1, *s2;
+    int st, n1, n2;
+    int i, jStart, jEnd, best, bestI, bestJ, base, cbase, x, over;
+    uint32_t bestP;
+};
+
+// row 0 ('E' then 'e', 0x40a6c1-0x40a770); false: no DP row follows (nothing to extend, or the window is too narrow: S.over).
+// have: the subject residues of columns 1 .. 16 were fetched ahead (lo: columns 1 .. 8, hi: 9 .. 16, one byte each) - a GPU lane
+// loads them while it is still busy with its previous flank; without them row 0 reads the subject itself.  x0: the first query residue.
+template <class TT, class WS>
+MC_HD bool mc_gap_begin(const TT &T, McGapState &S, const uint8_t *s1, const uint8_t *s2, int st, int n1, int n2, WS &ws, int W, bool have = false, uint64_t lo = 0, uint64_t hi = 0, int x0 = 0)
+{
+    const int open = MC_GAP_OPEN, ext = MC_GAP_EXT;
+    S.s1 = s1; S.s2 = s2; S.st = st; S.n1 = n1; S.n2 = n2; S.over = 0;
+    S.jEnd = (int)((T.xdrop_gapped - (double)open) / (double)ext);
+    S.best = 0; S.bestI = 0; S.bestJ = 0; S.jStart = 1; S.bestP = 0; S.base = 0; S.cbase = 0; S.i = 1; S.x = 0;
+    ws.store(0, 0, -open, 0u, 0u);
+    if (n2 > 0 && S.jEnd > 0) {
+        int r = -open;
+        const int last = S.jEnd < n2 ? S.jEnd : n2;
+        if (last >= W) { S.over = 1; return false; }
+        for (int j = 1; j <= last; j++) {
+            r -= ext;
+            const uint32_t y = (have && j <= 16) ? (uint32_t)((j <= 8 ? lo : hi) >> (8 * ((j - 1) & 7))) & 31u : (uint32_t)s2[(j - 1) * st];
+            ws.store(j, r, r - open, MC_PP_RUN, MC_PP_RUN | (y << 24) | MC_PD_GROW);   // one E run from the origin
+        }
+    }
+    if (n1 <= 0 || S.jEnd <= 1) return false;
+    S.x = have ? x0 : (int)s1[0];
+    return true;
+}
+
+// one DP row (0x40a7e0-0x40ad82); true: the extension has ended (S.over: the band left the window)
+template <class TT, class WS>
+MC_HD bool mc_gap_row(const TT &T, McGapState &S, WS &ws, int W)
+{
+    const int open = MC_GAP_OPEN, ext = MC_GAP_EXT, first = MC_GAP_OPEN + MC_GAP_EXT;
+    const int xd = (int)T.xdrop_gapped;        // (double)best - xdrop > (double)h  <=>  best - h > (int)xdrop  (integers against a positive threshold)
+    const int i = S.i, n2 = S.n2, st = S.st;
+    int base = S.base, cbase = S.cbase;        // lowest live column and its slot; slot of column j >= base: cbase + (j - base), minus W when >= W
+#define MC_WSLOT(j) ((cbase + ((j) - base)) >= W ? (cbase + ((j) - base)) - W : (cbase + ((j) - base)))
+    int jStart = S.jStart, jEnd = S.jEnd, best = S.best, bestI = S.bestI, bestJ = S.bestJ;
+    uint32_t bestP = S.bestP;
+    { const int nb = jStart - 1; cbase = MC_WSLOT(nb); base = nb; }
+    const int x = S.x;
+    const int xn = (i < S.n1) ? S.s1[i * st] : 0;                     // next row's query residue: its load overlaps this row
+    // the subject residues of the first two columns the right growth would add (it starts behind the jEnd of the row's entry, or not
+    // at all): in flight during the band
+    const uint32_t gy0 = (jEnd + 1 <= n2) ? (uint32_t)S.s2[jEnd * st] : 0u, gy1 = (jEnd + 2 <= n2) ? (uint32_t)S.s2[(jEnd + 1) * st] : 0u;
+    const int gfirst = jEnd + 1;
+    const int8_t *subrow = T.sub + (x << 5);
+    int bH, bD; uint32_t bPH, bPD;
+    ws.load(cbase, bH, bD, bPH, bPD);
+    int cj = (cbase + 1 == W) ? 0 : cbase + 1;
+    int cH, cD; uint32_t cPH, cPD;
+    ws.load(cj, cH, cD, cPH, cPD);                                     // the first cell of the band (column jStart): in flight with the border's
+    // left border (i, jStart-1): the planes say 'D' in row 1 (continue from main[0][.]) and 'd' afterwards
+    int diag = bH;
+    uint32_t pdiag = bPH;
+    int hprev = bH - first;
+    if (hprev < bD - ext) hprev = bD - ext;
+    const uint32_t pborder = (i == 1) ? bPH + MC_PP_RUN : (bPD & MC_PD_PATH) + ((bPD & MC_PD_GROW) ? MC_PP_RUN : 0u);
+    ws.store(cbase, hprev, hprev, pborder, pborder | (bPD & MC_PD_YMASK));
+    int E = hprev - open;
+    uint32_t pE = pborder, phprev = pborder;
+    bool grow = true, trim = true;
+    {   // the band (0x40a8e4-0x40a9f5): columns jStart .. min(jEnd, n2) unless the X-drop test ends the row earlier (on entry jStart < jEnd and
+        // jStart <= n2: at least one cell).  One exit test per cell; what the exit means is sorted out behind the loop.  The cell of the
+        // NEXT column and its substitution score are fetched while the current one is computed (one slot past the band is read and not used).
+        int jLast = jEnd < n2 ? jEnd : n2;
+        const bool wide = jLast > base + W - 1;                        // the row would leave the window
+        if (wide) jLast = base + W - 1;
+        int j = jStart;
+        int y = (int)((cPD >> 24) & 31u), sub = (int)subrow[y];
+        bool brk;
+        for (;;) {
+            const int cjn = (cj + 1 == W) ? 0 : cj + 1;
+            int nH, nD; uint32_t nPH, nPD;
+            ws.load(cjn, nH, nD, nPH, nPD);
+            int a = hprev - first, b = E - ext;
+            const uint32_t npE = (a >= b) ? phprev + MC_PP_RUN : pE;   // 'E': from main[i][j-1]; 'e': from the E plane of (i, j-1)
+            E = a >= b ? a : b;
+            a = cH - first; b = cD - ext;
+            const uint32_t npD = (a >= b) ? cPH + MC_PP_RUN : (cPD & MC_PD_PATH);   // 'D': from main[i-1][j]; 'd': from the D plane of (i-1, j)
+            const int Dn = a >= b ? a : b;
+            const int s = diag + sub;
+            uint32_t np = pdiag + 0x100u + (x == y ? 1u : 0u);
+            int h = s;
+            if (E > h) { h = E; np = npE; }                            // ties: s over E, (s | E) over D
+            if (h < Dn) { h = Dn; np = npD; }
+            diag = cH; pdiag = cPH;
+            ws.store(cj, h, Dn, np, npD | (cPD & MC_PD_YMASK));
+            pE = npE; phprev = np; hprev = h;
+            const bool up = h > best;
+            brk = !up && best - h > xd && j > bestJ;
+            if (up) { best = h; bestI = i; bestJ = j; bestP = np; }
+            const int yn = (int)((nPD >> 24) & 31u);
+            const int subn = (int)subrow[yn];
+            if (brk || j >= jLast) break;
+            j++; cj = cjn; cH = nH; cD = nD; cPH = nPH; cPD = nPD; y = yn; sub = subn;
+        }
+        if (brk) {
+            if (j < jEnd) { grow = false; trim = false; }              // 0x40a9f5: next row; else 0x40b48f: fall into the right growth
+            jEnd = j;
+        } else if (wide) { S.over = 1; return true; }
+    }
+    if (grow) {                                                        // 0x40ac45-0x40ad08
+        for (int j = jEnd + 1; !(n2 < j); j++) {
+            if (j - base >= W) { S.over = 1; return true; }
+            const int a = hprev - first, b = E - ext;
+            const uint32_t npE = (a > b) ? phprev + MC_PP_RUN : pE;
+            E = a > b ? a : b;
+            const uint32_t yy = j == gfirst ? gy0 : j == gfirst + 1 ? gy1 : (uint32_t)S.s2[(j - 1) * st];
+            ws.store(MC_WSLOT(j), E, E - open, npE, npE | (yy << 24) | MC_PD_GROW);
+            pE = npE; phprev = npE;
+            if (E > best) { best = E; bestI = i; bestJ = j; bestP = npE; }
+            else if (best - E > xd) { jEnd = j; break; }
+            hprev = E;
+        }
+    }
+    if (trim && !(jStart > bestJ)) {                                   // 0x40ad0c-0x40ad82
+        if (best - ws.loadH(MC_WSLOT(bestJ)) > xd) jStart = bestJ;
+        else { int k = bestJ; for (;;) { k--; if (jStart > k) break; if (best - ws.loadH(MC_WSLOT(k)) > xd) { jStart = k; break; } } }
+    }
+#undef MC_WSLOT
+    S.base = base; S.cbase = cbase; S.jStart = jStart; S.jEnd = jEnd; S.best = best; S.bestI = bestI; S.bestJ = bestJ; S.bestP = bestP;
+    S.i = i + 1; S.x = xn;
+    return S.n1 < S.i || !(jStart < jEnd);
+}
+
+MC_HD McGapResult mc_gap_result(const McGapState &S)
+{
+    McGapResult R; R.overflow = S.over; R.gain = 0; R.c1 = 0; R.c2 = 0; R.ident = 0; R.steps = 0; R.runs = 0; R.gapcols = 0;
+    if (S.over) return R;
+    R.gain = S.best; R.c1 = S.bestI; R.c2 = S.bestJ;
+    if (S.best > 0) {
+        const int diagn = (int)((S.bestP >> 8) & 0xFF);
+        R.ident = (int)(S.bestP & 0xFF); R.runs = (int)((S.bestP >> 16) & 0xFF);
+        R.gapcols = S.bestI + S.bestJ - 2 * diagn; R.steps = S.bestI + S.bestJ - diagn;
+    }
+    return R;
+}
 
 template <class TT, class WS>
 MC_HDN McGapResult mc_align_gapped_win(const TT &T, const uint8_t *s1, int st1, const uint8_t *s2, int st2, int n1, int n2, WS &ws, int W)
 {
-    const int open = MC_GAP_OPEN, ext = MC_GAP_EXT, first = MC_GAP_OPEN + MC_GAP_EXT;
-    McGapResult R; R.overflow = 0; R.gain = 0; R.c1 = 0; R.c2 = 0; R.ident = 0; R.steps = 0; R.runs = 0; R.gapcols = 0;
-    int jEnd = (int)((T.xdrop_gapped - (double)open) / (double)ext);
-    int best = 0, bestI = 0, bestJ = 0, jStart = 1;
-    uint32_t bestP = MC_PP_ZERO;
-    ws.store(0, 0, -open, MC_PP_ZERO, MC_PP_ZERO, 0);
-    if (n2 > 0 && jEnd > 0) {
-        int r = -open;
-        uint32_t pe = MC_PP_ZERO;
-        for (int j = 1;;) {
-            if (j >= W) { R.overflow = 1; return R; }
-            r -= ext;
-            pe = mc_pp_gap(pe, 1);
-            ws.store(j, r, r - open, pe, pe, s2[(j - 1) * st2]);
-            j++;
-            if (jEnd < j) break;
-            if (n2 < j) break;
-        }
-    }
-    if (n1 <= 0 || jEnd <= 1) return R;
-    const int xd = (int)T.xdrop_gapped;        // (double)best - xdrop > (double)h  <=>  best - h > (int)xdrop  (integers against a positive threshold)
-    int base = 0, cbase = 0;                   // lowest live column and its slot; slot of column j >= base: cbase + (j - base), minus W when >= W
-#define MC_WSLOT(j) ((cbase + ((j) - base)) >= W ? (cbase + ((j) - base)) - W : (cbase + ((j) - base)))
-    int x = s1[0];
-    for (int i = 1;;) {
-        { const int nb = jStart - 1; cbase = MC_WSLOT(nb); base = nb; }
-        const int xn = (i < n1) ? s1[i * st1] : 0;                     // next row's query residue: its load overlaps this row
-        int bH, bD, by; uint32_t bPH, bPD;
-        ws.load(cbase, bH, bD, bPH, bPD, by);
-        int diag = bH;
-        uint32_t pdiag = bPH;
-        int hprev = bH - first;
-        if (hprev < bD - ext) hprev = bD - ext;
-        const uint32_t pborder = mc_pp_gap((i == 1) ? bPH : bPD, 2);
-        ws.store(cbase, hprev, hprev, pborder, pborder, by);
-        int E = hprev - open, h = 0;
-        uint32_t pE = pborder, phprev = pborder;
-        bool grow = true, trim = true;
-        if (!(jStart > jEnd) && !(n2 < jStart)) {
-            int cj = cbase;
-            for (int j = jStart;;) {
-                if (j - base >= W) { R.overflow = 1; return R; }
-                cj = (cj + 1 == W) ? 0 : cj + 1;
-                int cH, cD, y; uint32_t cPH, cPD;
-                ws.load(cj, cH, cD, cPH, cPD, y);
-                int a = hprev - first, b = E - ext, Dn;
-                uint32_t npE, npD;
-                if (a >= b) { E = a; npE = mc_pp_gap(phprev, 1); }
-                else { E = b; npE = mc_pp_gap(pE, 1); }
-                a = cH - first; b = cD - ext;
-                if (a >= b) { Dn = a; npD = mc_pp_gap(cPH, 2); }
-                else { Dn = b; npD = mc_pp_gap(cPD, 2); }
-                const int s = diag + MC_SUB(T, x, y);
-                uint32_t np = mc_pp_diag(pdiag, x == y);
-                h = s;
-                if (E > h) { h = E; np = npE; }
-                if (h < Dn) { h = Dn; np = npD; }
-                diag = cH; pdiag = cPH;
-                ws.store(cj, h, Dn, np, npD, y);
-                pE = npE; phprev = np; hprev = h;
-                if (h > best) { best = h; bestI = i; bestJ = j; bestP = np; }
-                else if (best - h > xd && j > bestJ) {
-                    if (j >= jEnd) { jEnd = j; }
-                    else { jEnd = j; grow = false; trim = false; }
-                    break;
-                }
-                j++;
-                if (n2 < j) break;
-                if (j > jEnd) break;
-            }
-        }
-        if (grow) {
-            for (int j = jEnd + 1; !(n2 < j); j++) {
-                if (j - base >= W) { R.overflow = 1; return R; }
-                const int a = hprev - first, b = E - ext;
-                uint32_t npE;
-                if (a > b) { E = a; npE = mc_pp_gap(phprev, 1); }
-                else { E = b; npE = mc_pp_gap(pE, 1); }
-                ws.store(MC_WSLOT(j), E, E - open, npE, npE, s2[(j - 1) * st2]);
-                pE = npE; phprev = npE;
-                if (E > best) { best = E; bestI = i; bestJ = j; bestP = npE; }
-                else if (best - E > xd) { jEnd = j; break; }
-                hprev = E;
-            }
-        }
-        if (trim && !(jStart > bestJ)) {
-            if (best - ws.loadH(MC_WSLOT(bestJ)) > xd) jStart = bestJ;
-            else { int k = bestJ; for (;;) { k--; if (jStart > k) break; if (best - ws.loadH(MC_WSLOT(k)) > xd) { jStart = k; break; } } }
-        }
-        i++;
-        x = xn;
-        if (n1 < i) break;
-        if (!(jStart < jEnd)) break;
-    }
-#undef MC_WSLOT
-    R.gain = best; R.c1 = bestI; R.c2 = bestJ;
-    if (best > 0) {
-        const int diagn = (int)((bestP >> 8) & 0xFF);
-        R.ident = (int)(bestP & 0xFF); R.runs = (int)((bestP >> 16) & 0xFF);
-        R.gapcols = bestI + bestJ - 2 * diagn; R.steps = bestI + bestJ - diagn;
-    }
-    return R;
+    (void)st2;                                                          // (both sequences are walked in the same direction)
+    McGapState S;
+    if (mc_gap_begin(T, S, s1, s2, st1, n1, n2, ws, W)) while (!mc_gap_row(T, S, ws, W)) { }
+    return mc_gap_result(S);
 }
 
 // finalise one HSP (CalRes@0x4077a0 up to the keep test).  Returns false when the HSP is not kept.

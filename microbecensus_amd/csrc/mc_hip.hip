@@ -1146,33 +1146,46 @@ __global__ void __launch_bounds__(128) k_gapped(const McTables *__restrict__ T, 
     }
 }
 
-// Gapped extension: one thread per flank item with its DP rows in LDS.  mc_align_gapped_win keeps only the live band (a
-// circular window of W columns, 12 bytes per column: scores 12 + 12 bits and the subject residue in one word, the two
-// path-statistics words) - nothing of the DP touches global memory.  Layout: word (slot, lane) of a wave's window sits at
-// slot * 64 + lane, so whatever slots the 64 lanes are working on they fall into 64 different banks.  A flank whose band is
-// wider than the window (0.02 % of the flanks of 150 bp reads at W = 40) goes to the retry list: the same kernel with a
-// 64-column window, and behind that k_gapped with full-size rows in global memory.
+// Gapped extension: one lane per flank item with its DP rows in LDS.  The extension (mc_gap_begin / mc_gap_row, mc_core.h) keeps
+// only the live band - a circular window of W columns, 12 bytes per column: the two scores (16 + 16 bits) in one word, the two
+// path-statistics words, the subject residue in the spare byte of the second - nothing of the DP touches global memory.
+// Layout: word (slot, lane) of a wave's window sits at slot * 64 + lane, so whatever slots the 64 lanes are working on they fall
+// into 64 different banks.  A flank whose band is wider than the window (0.02 % of the flanks of 150 bp reads at W = 40) goes to
+// the retry list: the same kernel with a 64-column window, and behind that k_gapped with full-size rows in global memory.
+//
+// PERSISTENT LANES.  How long a flank takes is not known before it ends: its DP rows (the sort key) are only an upper bound -
+// the X-drop rule ends most extensions early - so 64 flanks of equal key dealt to the 64 lanes of a wave keep 58 % (150 bp) /
+// 39 % (300 bp) of the lanes busy even with perfectly balanced rows (measured on the host: cells per flank, tests/emul).  So a
+// lane does not wait for its wave: the wave loops over DP ROWS, and whenever MC_GAP_REFILL lanes have ended their flanks they
+// start their next ones together (row 0 is set up by all of them at once).  Wave w of G owns items w, w + G, w + 2 G ... of the
+// list, which is in descending order of DP rows: every wave sees the same mix, longest first.
+// FETCHED AHEAD.  A flank starts with a chain of dependent global reads - item id, task record, subject offsets, the subject
+// residues of row 0 - each a memory round trip that the whole wave would wait for.  So a lane claims its next item the moment it
+// starts one, and walks that chain one link per loop iteration (a DP row of the others) while it works: when its flank ends the
+// next one is ready in registers.  The same inside a row: the query residue of the next row and the subject residues the right
+// growth will need are requested at the row's start (mc_gap_row).
+#define MC_GAP_REFILL 16
 template <int W>
 struct McGapLds {
     uint32_t *hd, *ph, *pd;                                        // this lane's column 0 of the three word arrays
-    __device__ __forceinline__ void load(int c, int &H, int &D, uint32_t &PH, uint32_t &PD, int &y) const
+    __device__ __forceinline__ void load(int c, int &H, int &D, uint32_t &PH, uint32_t &PD) const
     {
         const uint32_t w = hd[c * 64];
-        H = (int)(w << 20) >> 20; D = (int)(w << 8) >> 20; y = (int)(w >> 24);
+        H = (int)(int16_t)(w & 0xFFFFu); D = (int)w >> 16;
         PH = ph[c * 64]; PD = pd[c * 64];
     }
-    __device__ __forceinline__ void store(int c, int H, int D, uint32_t PH, uint32_t PD, int y)
+    __device__ __forceinline__ void store(int c, int H, int D, uint32_t PH, uint32_t PD)
     {
-        hd[c * 64] = ((uint32_t)H & 0xFFFu) | (((uint32_t)D & 0xFFFu) << 12) | ((uint32_t)y << 24);
+        hd[c * 64] = ((uint32_t)H & 0xFFFFu) | ((uint32_t)D << 16);
         ph[c * 64] = PH; pd[c * 64] = PD;
     }
-    __device__ __forceinline__ int loadH(int c) const { return (int)(hd[c * 64] << 20) >> 20; }
+    __device__ __forceinline__ int loadH(int c) const { return (int)(int16_t)(hd[c * 64] & 0xFFFFu); }
 };
 
 template <int W, int LANES>
 __global__ void __launch_bounds__(64) k_gapped_lds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
                                                    const McGapTask *__restrict__ gaps, const uint32_t *__restrict__ list, const uint32_t *__restrict__ nitems_p, McFlankOut *fout,
-                                                   uint32_t *retry_count, uint32_t *retry)
+                                                   uint32_t *retry_count, uint32_t *retry, int refill)
 {
     __shared__ McHot hot;
     __shared__ uint32_t win[3 * W * 64];
@@ -1184,19 +1197,79 @@ __global__ void __launch_bounds__(64) k_gapped_lds(const McTables *__restrict__ 
     McGapLds<W> ws; ws.hd = win + lane; ws.ph = win + W * 64 + lane; ws.pd = win + 2 * W * 64 + lane;
     // LANES < 64 (the retry launch: few, large, unequal flanks): only the first LANES lanes of a wave take items, so that the
     // wave's run time is that of a few flanks, not of 64 different ones one after the other
-    if (lane >= LANES) return;
-    const uint32_t tid = blockIdx.x * LANES + threadIdx.x, nthreads = gridDim.x * LANES;
-    for (uint32_t k0 = tid; k0 < nitems; k0 += nthreads) {
-        const uint32_t it = list[k0];
-        const McGapTask g = gaps[it >> 1];
-        const int frame = (int)(g.chrono >> 25), qlen = (L - frame % 3) / 3;
-        const uint32_t o0 = X.off[g.sidx];
-        McFlank f;
-        (void)mc_flank_of(g, qlen, (int)(X.off[g.sidx + 1] - o0), (int)(it & 1), f);
-        const McGapResult R = mc_align_gapped_win(hot, frames + ((int64_t)g.read * 6 + frame) * FP + f.qoff, f.st, X.res + o0 + f.doff, f.st, f.n1, f.n2, ws, W);
-        fout[it] = mc_flank_out(R);
-        const uint32_t ro = mc_wave_alloc(retry_count, R.overflow != 0);                    // band left the window: the flank is redone with a wider one
-        if (R.overflow) retry[ro] = it;
+    const bool mine = lane < LANES;
+    const uint32_t G = gridDim.x, w0 = blockIdx.x;
+    const uint32_t share = nitems > w0 ? (nitems - w0 + G - 1) / G : 0u;   // items of this wave: list[w0 + G k], k < share
+    const unsigned long long lt = (1ull << lane) - 1;
+    const int REFILL = LANES < refill ? 1 : refill;
+    uint32_t taken = 0;
+    // the flank being extended
+    bool active = false;
+    uint32_t it = 0;
+    McGapState S;
+    // the flank fetched ahead.  nstage: 0 nothing claimed, 1 item id on its way, 2 task record, 3 subject offsets, 4 row-0 residues, 5 ready
+    int nstage = 0;
+    uint32_t nit = 0, no0 = 0, no1 = 0, nraw[sizeof(McGapTask) / 4];
+    McFlank nf;
+    const uint8_t *ns1 = nullptr, *ns2 = nullptr;
+    uint64_t nlo = 0, nhi = 0;
+    uint32_t nx0 = 0;
+    nf.qoff = nf.doff = nf.st = nf.n1 = nf.n2 = 0;
+    for (;;) {
+        // Everything this wave requested from global memory during the last iteration - a DP row ago - has arrived by now: said once,
+        // here, so that no later use waits for it together with the requests of THIS iteration (the counter is in order).
+        __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0)
+        bool fin = false;
+        {   // ---- the idle lanes whose next flank is ready start it - MC_GAP_REFILL of them together, or when nothing else is left to do
+            const bool ready = mine && !active && nstage == 5;
+            const unsigned long long rm = __ballot(ready);
+            if (rm && (__popcll(rm) >= REFILL || taken >= share || __ballot(active) == 0)) {
+                if (ready) {
+                    it = nit; active = true; nstage = 0;
+                    fin = !mc_gap_begin(hot, S, ns1, ns2, nf.st, nf.n1, nf.n2, ws, W, true, nlo, nhi, (int)nx0);
+                }
+            }
+        }
+        // ---- the flank behind it: one link of the chain per iteration (what the link needs was requested an iteration ago)
+        if (nstage == 4) {                                          // the 16 residues in walking order, one byte each
+            if (nf.st < 0) { const uint64_t a = nlo; nlo = __builtin_bswap64(nhi); nhi = __builtin_bswap64(a); }
+            nstage = 5;
+        } else if (nstage == 3) {
+            McGapTask ng;
+            __builtin_memcpy(&ng, nraw, sizeof ng);
+            const int frame = (int)(ng.chrono >> 25), qlen = (L - frame % 3) / 3;
+            (void)mc_flank_of(ng, qlen, (int)(no1 - no0), (int)(nit & 1), nf);
+            ns1 = frames + ((int64_t)ng.read * 6 + frame) * FP + nf.qoff; ns2 = X.res + no0 + nf.doff;
+            const uint8_t *lowest = nf.st > 0 ? ns2 : ns2 - 15;    // 16 bytes in memory order (the residue array is padded by 64 bytes at both ends)
+            __builtin_memcpy(&nlo, lowest, 8); __builtin_memcpy(&nhi, lowest + 8, 8);
+            nx0 = ns1[0];
+            nstage = 4;
+        } else if (nstage == 2) {
+            const uint32_t sidx = nraw[offsetof(McGapTask, sidx) / 4];
+            no0 = X.off[sidx]; no1 = X.off[sidx + 1];
+            nstage = 3;
+        } else if (nstage == 1) {
+            const uint32_t *gp = (const uint32_t *)(gaps + (nit >> 1));
+#pragma unroll
+            for (int k = 0; k < (int)(sizeof(McGapTask) / 4); k++) nraw[k] = gp[k];
+            nstage = 2;
+        }
+        {   // claim: the lanes without a next item take the next ones of the wave's share
+            const bool want = mine && nstage == 0;
+            const unsigned long long cm = __ballot(want);
+            if (cm && taken < share) {
+                const uint32_t k = taken + (uint32_t)__popcll(cm & lt);
+                if (want && k < share) { nit = list[w0 + G * k]; nstage = 1; }
+                taken += (uint32_t)__popcll(cm);
+            }
+        }
+        // ---- one DP row of every flank in progress
+        if (active && !fin) fin = mc_gap_row(hot, S, ws, W);
+        if (fin) { fout[it] = mc_flank_out(mc_gap_result(S)); active = false; }
+        const bool over = fin && S.over != 0;
+        const uint32_t ro = mc_wave_alloc(retry_count, over);      // band left the window: the flank is redone with a wider one
+        if (over) retry[ro] = it;
+        if (taken >= share && __ballot(active || nstage != 0) == 0) break;
     }
 }
 
@@ -1658,7 +1731,7 @@ struct mc_handle {
     std::vector<int32_t> fam;
     int nfam = 0, device = 0;
     // device index + tables
-    uint8_t *d_res = nullptr; uint32_t *d_off = nullptr, *d_bstart = nullptr, *d_post = nullptr; uint16_t *d_keys = nullptr; int32_t *d_fam = nullptr;
+    uint8_t *d_res = nullptr, *d_res_base = nullptr; uint32_t *d_off = nullptr, *d_bstart = nullptr, *d_post = nullptr; uint16_t *d_keys = nullptr; int32_t *d_fam = nullptr;
     McTables *d_T = nullptr; McClassPars *d_P = nullptr;
     McTables hT; McClassPars hP;
     int read_len = 0, FP = 0; bool run_set = false;
@@ -1677,7 +1750,7 @@ struct mc_handle {
     McCtx ctx[MC_NCTX];
     // host results: rows of the last run land in pinned memory; mc_search() accumulates its batches in all_rows
     mc_row *pin_rows = nullptr; size_t pin_cap = 0;
-    std::vector<mc_row> all_rows;
+    std::vector<mc_row> all_rows, split_rows;                       // accumulated over the batches of a stream / over the halves of a range that overflowed
     const mc_row *res_rows = nullptr; int64_t n_res_rows = 0;
     std::vector<mc_best_hit> best; mc_stats stats;
 };
@@ -1718,7 +1791,7 @@ extern "C" void mc_close(mc_handle *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void *ptrs[] = {h->d_res, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_pair, h->d_rt, h->d_segtab};
+    void *ptrs[] = {h->d_res_base, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_pair, h->d_rt, h->d_segtab};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (McCtx &c : h->ctx) ctx_free(c);
     for (int k = 0; k < 2; k++) { if (h->stage_pin[k]) (void)hipHostFree(h->stage_pin[k]); if (h->stage_dev[k]) (void)hipFree(h->stage_dev[k]); }
@@ -1749,8 +1822,10 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
         HIPCK(hipHostMalloc((void **)&c.h_stats, sizeof(unsigned long long) * S_N, hipHostMallocDefault));
     }
     const McHostIndex &H = h->H;
-    if (dalloc(&h->d_res, H.res.size() + 64) || dalloc(&h->d_off, H.off.size()) || dalloc(&h->d_bstart, H.bstart.size()) || dalloc(&h->d_post, H.post.size() + 1) ||
+    if (dalloc(&h->d_res_base, H.res.size() + 128) || dalloc(&h->d_off, H.off.size()) || dalloc(&h->d_bstart, H.bstart.size()) || dalloc(&h->d_post, H.post.size() + 1) ||
         dalloc(&h->d_keys, H.keys.size()) || dalloc(&h->d_fam, (size_t)nseq) || dalloc(&h->d_T, 1) || dalloc(&h->d_P, 1)) return -1;
+    HIPCK(hipMemset(h->d_res_base, MC_INV, H.res.size() + 128));
+    h->d_res = h->d_res_base + 64;                                 // (k_gapped_lds reads 16 bytes at a time around a flank's first residues)
     HIPCK(hipMemcpy(h->d_res, H.res.data(), H.res.size(), hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_off, H.off.data(), H.off.size() * 4, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_bstart, H.bstart.data(), H.bstart.size() * 4, hipMemcpyHostToDevice));
@@ -2023,6 +2098,8 @@ static int stage_b(mc_handle *h, McCtx &c)
         // 2. order the flanks by DP size (the sort buffers of the HSP sort are idle at this point); 3. extend them with the DP rows
         // in LDS, those whose band leaves the window again with a wider one, the rest with full-size rows; 4. every task takes its
         // HSP from its group's flank results.  The counts of 2. - 4. stay on the device.
+        static const int gap_refill = getenv("MC_GAP_REFILL") ? std::max(1, std::min(64, atoi(getenv("MC_GAP_REFILL")))) : MC_GAP_REFILL;   // (experiments)
+        static const unsigned gap_wpc = getenv("MC_GAP_WPC") ? (unsigned)std::max(1, atoi(getenv("MC_GAP_WPC"))) : 5u;                      // waves per CU of the launch
         uint32_t slots = 1u << 16;
         while (slots < 2 * ngaps) slots <<= 1;
         if (slots > c.gtab_slots) { if (dalloc(&c.d_gtab, (size_t)slots)) return -1; c.gtab_slots = slots; }
@@ -2032,9 +2109,9 @@ static int stage_b(mc_handle *h, McCtx &c)
         k_gap_dedupe<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(X, L, c.d_gaps, ngaps, c.d_gtab, slots - 1, c.d_gleader, gk, gi, c.d_counters);
         size_t gbytes = c.sorttmp_bytes;
         HIPCK(rocprim::radix_sort_pairs_desc(c.d_sorttmp, gbytes, gk, gko, gi, gio, (size_t)ngaps * 2, 0, 10, st));
-        k_gapped_lds<MC_GAP_WIN, 64><<<dim3(std::min<uint32_t>((2 * ngaps + 63) / 64, 256u * 5u * 4u)), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, gio, c.d_counters + C_ITEMS, c.d_fout,
-                                                                                                                 c.d_counters + C_RETRY, c.d_retry);
-        k_gapped_lds<MC_GAP_WIN2, 4><<<dim3(256u * 3u * 4u), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry, c.d_counters + C_RETRY, c.d_fout, c.d_counters + C_RETRY2, c.d_retry2);
+        k_gapped_lds<MC_GAP_WIN, 64><<<dim3(std::min<uint32_t>((2 * ngaps + 63) / 64, 256u * gap_wpc)), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, gio, c.d_counters + C_ITEMS, c.d_fout,
+                                                                                                                 c.d_counters + C_RETRY, c.d_retry, gap_refill);
+        k_gapped_lds<MC_GAP_WIN2, 4><<<dim3(256u * 3u * 4u), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry, c.d_counters + C_RETRY, c.d_fout, c.d_counters + C_RETRY2, c.d_retry2, 1);
         k_gapped<<<dim3(c.gap_threads_full / 128), dim3(128), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry2, c.d_counters + C_RETRY2, c.d_fout, c.d_counters, c.d_gws_full, MC_GAP_W);
         k_gap_emit<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, L, c.d_gaps, ngaps, c.d_gleader, c.d_fout, c.d_hsps, c.cap_hsps, c.d_counters);
     }
@@ -2113,7 +2190,41 @@ static int stage_e(mc_handle *h, McCtx &c, size_t rows_at)
     return 0;
 }
 
+static void stats_add(mc_stats &tot, const mc_stats &s)
+{
+    tot.reads += s.reads; tot.seed_tasks += s.seed_tasks; tot.gap_tasks += s.gap_tasks; tot.hsps += s.hsps; tot.rows += s.rows;
+    tot.reads_with_rows += s.reads_with_rows; tot.classified += s.classified; tot.bucket_lookups += s.bucket_lookups; tot.key_probes += s.key_probes;
+    tot.seed_exact_asks += s.seed_exact_asks; tot.seed_wild_asks += s.seed_wild_asks; tot.seed_pair_asks += s.seed_pair_asks; tot.seed_probes += s.seed_probes;
+    tot.ms_translate += s.ms_translate; tot.ms_seed += s.ms_seed; tot.ms_eval += s.ms_eval; tot.ms_gapped += s.ms_gapped;
+    tot.ms_sort += s.ms_sort; tot.ms_finish += s.ms_finish; tot.ms_total += s.ms_total;
+}
+
+static int run_range_once(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id);
+
+// A range whose seed hits / HSPs / rows overflow the pools sized for ordinary shotgun reads (-2 from the pipeline) is run again in
+// halves, and their results joined: the caller sees one range either way.
 extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id)
+{
+    int rc = run_range_once(h, first, count, first_read_id);
+    if (rc != -2 || count <= 1) return rc;
+    std::vector<mc_row> &rows = h->split_rows; rows.clear();
+    std::vector<mc_best_hit> best; mc_stats tot; memset(&tot, 0, sizeof tot);
+    int64_t off = 0, step = std::max<int64_t>(1, count / 2);
+    while (off < count) {
+        const int64_t nb = std::min<int64_t>(step, count - off);
+        rc = run_range_once(h, first + off, nb, first_read_id + off);
+        if (rc == -2 && nb > 1) { step = std::max<int64_t>(1, nb / 2); continue; }
+        if (rc) return rc;
+        rows.insert(rows.end(), h->res_rows, h->res_rows + h->n_res_rows);
+        best.insert(best.end(), h->best.begin(), h->best.end());
+        stats_add(tot, h->stats);
+        off += nb;
+    }
+    h->res_rows = rows.data(); h->n_res_rows = (int64_t)rows.size(); h->best.swap(best); h->stats = tot;
+    return 0;
+}
+
+static int run_range_once(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id)
 {
     if (!h || !h->run_set) { g_err = "mc_set_run() must be called first"; return -1; }
     if (first < 0 || count < 0 || first + count > h->nreads) { g_err = "range outside the resident read set"; return -1; }
@@ -2258,21 +2369,11 @@ static int run_stream(mc_handle *h, const std::function<int64_t(uint8_t *, int64
         { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return slot[k].state != 0; }); }
         if (slot[k].state == 2) { if (slot[k].rc < 0) { rc = (int)slot[k].rc; if (!up_err.empty()) g_err = up_err; } break; }
         h->reads_dev = slot[k].dev; h->nreads = slot[k].n;
-        // a pool overflow (-2) is answered by running the batch in smaller ranges
-        int64_t off = 0, step = slot[k].n;
-        while (off < slot[k].n) {
-            const int64_t nb = std::min<int64_t>(step, slot[k].n - off);
-            rc = mc_run_range(h, off, nb, first_read_id + slot[k].first + off);
-            if (rc == -2 && nb > 1) { step = std::max<int64_t>(1, nb / 2); rc = 0; continue; }
-            if (rc) break;
+        rc = mc_run_range(h, 0, slot[k].n, first_read_id + slot[k].first);      // (a pool overflow is answered inside: smaller ranges)
+        if (rc == 0) {
             if (h->keep_rows) all_rows.insert(all_rows.end(), h->res_rows, h->res_rows + h->n_res_rows);
             all_best.insert(all_best.end(), h->best.begin(), h->best.end());
-            tot.reads += h->stats.reads; tot.seed_tasks += h->stats.seed_tasks; tot.gap_tasks += h->stats.gap_tasks; tot.hsps += h->stats.hsps; tot.rows += h->stats.rows;
-            tot.reads_with_rows += h->stats.reads_with_rows; tot.classified += h->stats.classified; tot.bucket_lookups += h->stats.bucket_lookups; tot.key_probes += h->stats.key_probes;
-            tot.seed_exact_asks += h->stats.seed_exact_asks; tot.seed_wild_asks += h->stats.seed_wild_asks; tot.seed_pair_asks += h->stats.seed_pair_asks; tot.seed_probes += h->stats.seed_probes;
-            tot.ms_translate += h->stats.ms_translate; tot.ms_seed += h->stats.ms_seed; tot.ms_eval += h->stats.ms_eval; tot.ms_gapped += h->stats.ms_gapped;
-            tot.ms_sort += h->stats.ms_sort; tot.ms_finish += h->stats.ms_finish; tot.ms_total += h->stats.ms_total;
-            off += nb;
+            stats_add(tot, h->stats);
         }
         if (rc) break;
         { std::unique_lock<std::mutex> lk(mu); slot[k].state = 0; cv.notify_all(); }

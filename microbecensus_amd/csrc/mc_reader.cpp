@@ -119,36 +119,93 @@ struct Pool {
 // ------------------------------------------------------------------------------------------------------------------
 bool has_ext(const char *path, const char *ext) { size_t n = strlen(path), m = strlen(ext); return n >= m && strcmp(path + n - m, ext) == 0; }
 
-// libbz2 is on every machine that runs Python's bz2 module, but its header is not in this image: the four entry points of
-// its stdio-like interface are bound at run time
+// libbz2 is on every machine that runs Python's bz2 module, but its header is not in this image: the three entry points of
+// its low-level interface are bound at run time (bz_stream as bzlib.h 1.0 declares it).  The low-level interface, not
+// BZ2_bzread: a .bz2 file may hold several streams back to back (pbzip2 and lbzip2 write such files, `cat a.bz2 b.bz2` makes
+// one) and Python's bz2 module reads all of them, while BZ2_bzread stops at the end of the first.
+struct BzStream {
+    char *next_in; unsigned int avail_in, total_in_lo32, total_in_hi32;
+    char *next_out; unsigned int avail_out, total_out_lo32, total_out_hi32;
+    void *state;
+    void *(*bzalloc)(void *, int, int); void (*bzfree)(void *, void *); void *opaque;
+};
 struct Bz2Api {
     void *lib = nullptr;
-    void *(*open)(const char *, const char *) = nullptr;
-    int (*read)(void *, void *, int) = nullptr;
-    void (*close)(void *) = nullptr;
-    const char *(*error)(void *, int *) = nullptr;
+    int (*init)(BzStream *, int, int) = nullptr;
+    int (*decompress)(BzStream *) = nullptr;
+    int (*end)(BzStream *) = nullptr;
     bool load()
     {
-        if (lib) return open != nullptr;
+        if (lib) return init != nullptr;
         for (const char *n : {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so"}) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
         if (!lib) return false;
-        open = (void *(*)(const char *, const char *))dlsym(lib, "BZ2_bzopen");
-        read = (int (*)(void *, void *, int))dlsym(lib, "BZ2_bzread");
-        close = (void (*)(void *))dlsym(lib, "BZ2_bzclose");
-        error = (const char *(*)(void *, int *))dlsym(lib, "BZ2_bzerror");
-        if (!(open && read && close && error)) { open = nullptr; return false; }
+        init = (int (*)(BzStream *, int, int))dlsym(lib, "BZ2_bzDecompressInit");
+        decompress = (int (*)(BzStream *))dlsym(lib, "BZ2_bzDecompress");
+        end = (int (*)(BzStream *))dlsym(lib, "BZ2_bzDecompressEnd");
+        if (!(init && decompress && end)) { init = nullptr; return false; }
         return true;
     }
 };
 Bz2Api g_bz2;
 std::mutex g_bz2_mu;
 
+// A .bz2 file as a sequence of bzip2 streams.  read() fills the buffer like a file read: < n only at the end of the data;
+// bad = the file ends inside a stream or holds damaged data (Python: EOFError / OSError).  Bytes behind the last complete stream
+// that do not start another one are ignored, as Python's bz2 module ignores them.
+struct Bz2File {
+    int fd = -1;
+    BzStream z{};
+    bool live = false, eof_in = false, fresh = true;               // fresh: nothing of the current stream has been decoded yet
+    std::vector<char> in;
+    bool open(const char *path) { fd = ::open(path, O_RDONLY); in.resize(1 << 20); return fd >= 0; }
+    void close() { if (live) { g_bz2.end(&z); live = false; } if (fd >= 0) { ::close(fd); fd = -1; } }
+    int read(uint8_t *dst, int n, bool *bad, std::string *msg)
+    {
+        int got = 0;
+        *bad = false;
+        while (got < n) {
+            if (!live) {
+                if (z.avail_in == 0 && eof_in) break;                  // clean end: between two streams
+                memset(&z.state, 0, sizeof z.state); z.bzalloc = nullptr; z.bzfree = nullptr; z.opaque = nullptr;
+                const unsigned keep_n = z.avail_in; char *keep_p = z.next_in;
+                if (g_bz2.init(&z, 0, 0) != 0) { *bad = true; *msg = "BZ2_bzDecompressInit failed"; return got; }
+                z.avail_in = keep_n; z.next_in = keep_p;
+                live = true; fresh = true;
+            }
+            if (z.avail_in == 0 && !eof_in) {
+                const ssize_t k = ::read(fd, in.data(), in.size());
+                if (k < 0) { *bad = true; *msg = "read error"; return got; }
+                if (k == 0) eof_in = true;
+                z.next_in = in.data(); z.avail_in = (unsigned)k;
+            }
+            if (z.avail_in == 0 && eof_in) {                          // the input ends inside a stream
+                if (fresh && got_any_stream) break;                    // (nothing but the end of the file behind the last stream)
+                *bad = true; *msg = "compressed file ended before the end-of-stream marker was reached"; return got;
+            }
+            z.next_out = (char *)dst + got; z.avail_out = (unsigned)(n - got);
+            const unsigned in0 = z.avail_in;
+            const int rc = g_bz2.decompress(&z);
+            got = n - (int)z.avail_out;
+            if (in0 != z.avail_in) fresh = false;
+            if (rc == 4 /* BZ_STREAM_END */) { g_bz2.end(&z); live = false; got_any_stream = true; continue; }
+            if (rc != 0 /* BZ_OK */) {
+                if (got_any_stream && first_block_of_stream()) { g_bz2.end(&z); live = false; z.avail_in = 0; eof_in = true; break; }   // trailing bytes that are no stream
+                *bad = true; *msg = "invalid data stream"; return got;
+            }
+        }
+        return got;
+    }
+    bool got_any_stream = false;
+    // a decode error before the stream produced anything: the bytes behind the last stream were not a stream at all
+    bool first_block_of_stream() const { return z.total_out_lo32 == 0 && z.total_out_hi32 == 0; }
+};
+
 struct Stream {
     enum { NBLK = 16, BLK = 1 << 22 };
     // plain file: one mapping; the window is a slice of it
     const uint8_t *map = nullptr; size_t map_n = 0;
     // compressed stream: a producer thread inflates BLK-sized blocks into a ring; the window lives in `buf`
-    gzFile gz = nullptr; void *bz = nullptr;
+    gzFile gz = nullptr; Bz2File *bz = nullptr;
     std::thread th;
     std::mutex mu; std::condition_variable cv;
     std::vector<uint8_t> ring[NBLK]; size_t ring_n[NBLK] = {};
@@ -168,8 +225,8 @@ struct Stream {
         if (has_ext(path, ".bz2")) {
             std::unique_lock<std::mutex> lk(g_bz2_mu);
             if (!g_bz2.load()) { r_err = "cannot load libbz2 for " + std::string(path); return false; }
-            bz = g_bz2.open(path, "rb");
-            if (!bz) { r_err = std::string("cannot open ") + path; return false; }
+            bz = new Bz2File();
+            if (!bz->open(path)) { delete bz; bz = nullptr; r_err = std::string("cannot open ") + path; return false; }
             compressed = true;
         } else {
             int fd = ::open(path, O_RDONLY);
@@ -209,7 +266,7 @@ struct Stream {
             th.join();
         }
         if (gz) { gzclose(gz); gz = nullptr; }
-        if (bz) { g_bz2.close(bz); bz = nullptr; }
+        if (bz) { bz->close(); delete bz; bz = nullptr; }
         if (map) { munmap((void *)map, map_n); map = nullptr; }
     }
     void produce()
@@ -235,12 +292,7 @@ struct Stream {
                     if (n < 0 || (errnum != Z_OK && errnum != Z_STREAM_END) || !gzeof(gz)) { bad = true; msg = m ? m : "read error"; }
                 }
             } else {
-                n = g_bz2.read(bz, ring[slot].data(), (int)BLK);
-                if (n < (int)BLK) {
-                    int errnum = 0;
-                    const char *m = g_bz2.error(bz, &errnum);
-                    if (n < 0 || (errnum != 0 /* BZ_OK */ && errnum != 4 /* BZ_STREAM_END */)) { bad = true; msg = m ? m : "read error"; }
-                }
+                n = bz->read(ring[slot].data(), (int)BLK, &bad, &msg);
             }
             std::unique_lock<std::mutex> lk(mu);
             if (n > 0) { ring_n[slot] = (size_t)n; tail = (tail + 1) % NBLK; count++; }
@@ -540,9 +592,14 @@ struct SeqSet {
     }
 };
 
+// Worker threads of the reader: MC_READER_THREADS in the environment, else the caller's cap (mc_set_host_threads: run_pipeline
+// passes args['threads'], the reference's -t), else the machine's cores up to 32.
+std::atomic<int> g_host_threads{0};
 int reader_threads()
 {
     if (const char *e = getenv("MC_READER_THREADS")) { const int v = atoi(e); if (v >= 1) return v > 256 ? 256 : v; }
+    const int cap = g_host_threads.load();
+    if (cap >= 1) return cap > 256 ? 256 : cap;
     const unsigned hc = std::thread::hardware_concurrency();
     return (int)std::min<unsigned>(hc ? hc : 1, 32);
 }
@@ -663,6 +720,7 @@ struct mc_reader {
 };
 
 extern "C" const char *mc_reader_last_error(void) { return r_err.c_str(); }
+extern "C" void mc_set_host_threads(int32_t n) { g_host_threads.store(n > 0 ? n : 0); }
 
 extern "C" mc_reader *mc_reader_open(const char *const *paths, int32_t npaths, int32_t read_len, int64_t nreads, int32_t fastq, int32_t quality_offset,
                                      double min_quality, double mean_quality, double max_unknown, int32_t filter_dups, const char *fasta_out)

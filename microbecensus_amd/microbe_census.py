@@ -26,6 +26,7 @@ What differs from the reference, on purpose:
     temp FASTA nor the m8 text - the reference deletes both before it returns; args['keep_tmp'] = True runs stage by
     stage and leaves them (until clean_up) like the reference.
   * optional args['device'] (default 0) selects the GPU.
+  * args['threads'] (-t), when given, caps the worker threads of the native sampler (the reference forwards it to rapsearch -z).
 """
 import bz2
 import gzip
@@ -438,6 +439,16 @@ def _sample_search_classify(args, paths):
         print("\t%s reads hit marker proteins" % hit_reads)
 
 
+def _cap_host_threads(threads):
+    """args['threads'] is the reference's rapsearch -z (:375); here the search runs on the GPU and the host threads are the
+    native sampler's workers: an explicit value caps them, without one the machine's cores (up to 32) are used."""
+    try:
+        from . import _native
+        _native.load_library().mc_set_host_threads(int(threads) if threads and int(threads) > 0 else 0)
+    except Exception:
+        pass
+
+
 def _engine(device):
     from . import _native
     if device not in _engines:
@@ -645,6 +656,7 @@ def run_pipeline(args):
     check_paths(paths)
     try:
         check_input(args)
+        _cap_host_threads(args.get("threads"))     # an explicit args['threads'] (-t) caps the sampler's worker threads
         impute_missing_args(args)
         check_arguments(args)
         if args["verbose"]:

@@ -17,7 +17,7 @@ def parse_arguments(argv=None):
     p.add_argument("-v", dest="verbose", action="store_true", default=False, help="print program's progress to stdout")
     p.add_argument("-r", dest="rapsearch", type=str, default=None, help="path to an external RAPsearch2 v2.15 compatible executable to run instead of the in-process GPU search (the reference's hook)")
     p.add_argument("-n", dest="nreads", type=int, default=2000000, help="number of reads to sample (default = 2000000)")
-    p.add_argument("-t", dest="threads", type=int, default=1, help="host threads (default = 1)")
+    p.add_argument("-t", dest="threads", type=int, default=None, help="cap on the host threads of the read sampler (default: the machine's cores, up to 32; the reference's -t is the rapsearch thread count)")
     p.add_argument("-e", dest="no_equivs", action="store_true", default=False, help="skip the genome-equivalents pass over the input")
     p.add_argument("-l", dest="read_length", type=int, choices=microbe_census.VALID_READ_LENGTHS, help="trim all reads to this length")
     p.add_argument("-q", dest="min_quality", type=int, default=-5, help="minimum base-level PHRED quality (default = -5; no filtering)")
@@ -27,6 +27,8 @@ def parse_arguments(argv=None):
     p.add_argument("-g", dest="device", type=int, default=0, help="GPU index (default = 0)")
     args = vars(p.parse_args(argv))
     args["seqfiles"] = args["seqfiles"].split(",")
+    if args["threads"] is None:
+        del args["threads"]                      # impute_missing_args() fills in the reference's default (1) for the report; the sampler is not capped
     return args
 
 

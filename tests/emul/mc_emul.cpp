@@ -231,12 +231,12 @@ int main(int argc, char **argv)
     std::vector<McGapCell> cells(2100);
     // the windowed 12-byte-cell form the kernel runs (mc_align_gapped_win) must return what the full-size form returns
     struct HostWin {
-        std::vector<int> H, D, Y; std::vector<uint32_t> PH, PD;
-        explicit HostWin(int w) : H(w), D(w), Y(w), PH(w), PD(w) {}
-        void load(int c, int &h, int &d, uint32_t &ph, uint32_t &pd, int &y) const { h = H[c]; d = D[c]; ph = PH[c]; pd = PD[c]; y = Y[c]; }
-        void store(int c, int h, int d, uint32_t ph, uint32_t pd, int y)
-        {   // the kernel's cell packs H and D into 12 bits each and the residue into 5: what it would read back
-            H[c] = (int)((uint32_t)h << 20) >> 20; D[c] = (int)((uint32_t)d << 20) >> 20; PH[c] = ph; PD[c] = pd; Y[c] = y & 31;
+        std::vector<int> H, D; std::vector<uint32_t> PH, PD;
+        explicit HostWin(int w) : H(w), D(w), PH(w), PD(w) {}
+        void load(int c, int &h, int &d, uint32_t &ph, uint32_t &pd) const { h = H[c]; d = D[c]; ph = PH[c]; pd = PD[c]; }
+        void store(int c, int h, int d, uint32_t ph, uint32_t pd)
+        {   // the kernel's cell packs H and D into 16 bits each: what it would read back
+            H[c] = (int)(int16_t)h; D[c] = (int)(int16_t)d; PH[c] = ph; PD[c] = pd;
         }
         int loadH(int c) const { return H[c]; }
     };

@@ -164,6 +164,35 @@ def test_bz2_input_is_read_natively(tmp_path):
     assert _native.count_bases([p]) == 980306
 
 
+def test_bz2_with_several_streams_is_read_to_its_end(tmp_path):
+    """pbzip2 / lbzip2 / `cat a.bz2 b.bz2` write several bzip2 streams into one file; Python's bz2 module (what the
+    reference's open_file :55-58 uses) reads all of them, and so does the native reader.  Bytes behind the last stream that are
+    no stream are ignored like Python ignores them; a file cut inside a stream is an EOFError."""
+    import bz2
+    import gzip
+    from microbecensus_amd import _native
+    text = gzip.open(os.path.join(GOLD, "inputs", "example.fq.gz"), "rb").read()
+    lines = text.split(b"\n")
+    cut = (len(lines) // 8) * 4                                   # a record boundary near the middle
+    a, b = b"\n".join(lines[:cut]) + b"\n", b"\n".join(lines[cut:])
+    want, sw = _native.sample_reads([os.path.join(GOLD, "inputs", "example.fq.gz")], 100, 10000, True, 32, -5, -5, 100, False)
+    for name, blob in (("two", bz2.compress(a) + bz2.compress(b)), ("three", bz2.compress(a[:1000]) + bz2.compress(a[1000:]) + bz2.compress(b)),
+                       ("trailing", bz2.compress(a) + bz2.compress(b) + b"not a stream")):
+        p = str(tmp_path / (name + ".fq.bz2"))
+        with open(p, "wb") as f:
+            f.write(blob)
+        assert bz2.open(p).read() == text
+        got, sg = _native.sample_reads([p], 100, 10000, True, 32, -5, -5, 100, False)
+        assert sg == sw and (got == want).all(), name
+        assert _native.count_bases([p]) == 980306, name
+    p = str(tmp_path / "cut.fq.bz2")
+    with open(p, "wb") as f:
+        f.write((bz2.compress(a) + bz2.compress(b))[:-40])
+    with pytest.raises(_native.ReferenceError_) as e:
+        _native.count_bases([p])
+    assert "EOFError" in str(e.value)
+
+
 def test_streaming_fetch_equals_run(tmp_path):
     """mc_reader_start / fetch / join hand out the same reads mc_reader_run collects."""
     import ctypes as C
