@@ -364,7 +364,7 @@ def main():
         eng.run_range(b * args.batch, args.batch, first_read_id=b * args.batch)
         for k, v in eng.stats().items():
             seq[k] = seq.get(k, 0) + v
-    eng.set_parts(2)
+    eng.set_parts(1)
     tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -90,9 +90,10 @@ int mc_run(mc_handle *h, int64_t first_read_id);
 /* runs the pipeline on reads [first, first+count) of the resident set (count <= 2097151). */
 int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id);
 
-/* mc_run_range() cuts its range into `parts` parts (default and maximum 2) whose pipeline stages are issued alternately on
- * separate HIP streams, so that the host's waits for one part's counters and the tails of its latency-bound kernels are covered
- * by the other part's work.  parts = 1 runs one kernel at a time (what a per-kernel profile wants).  Results do not depend on it. */
+/* mc_run_range() can cut its range into `parts` parts (1, the default, or 2) whose pipeline stages are issued alternately on
+ * separate HIP streams.  Every kernel of the pipeline fills the GPU by itself and the host's waits between the stages are short
+ * (0.3 ms of 46 per 2 M reads), so one part is as fast as two (round 3: 45.6 against 49.5 ms) and is the default; 2 is kept for
+ * experiments.  Results do not depend on it. */
 int mc_set_parts(mc_handle *h, int parts);
 
 /* The seed kernel can count the index reads of the reference's algorithm for the batch (mc_stats.bucket_lookups /
@@ -179,6 +180,13 @@ int mc_search_files_multi(mc_handle *const *handles, int32_t n_dev, mc_reader *r
 /* keep != 0 (default): mc_search() / mc_search_files() collect the m8 rows of all their batches for mc_result_rows(); 0: only the
  * best hits and the statistics (the rows are still computed - classification reads them on the device). */
 int mc_set_keep_rows(mc_handle *h, int keep);
+/* on != 0: the runs that follow produce the best hits only (what classify_reads :432-460 keeps) - no m8 rows.  A read none of
+ * whose HSPs would pass its family's thresholds (min_cov, max_aaid, min_score) as an m8 row cannot be classified, whatever its
+ * ranking: only the reads that have such an HSP are sorted and finished (with ALL their HSPs: ranking, sum statistics and the
+ * 500-row cap are the reference's).  mc_result_best_hits() is identical to the full path's; mc_result_rows() is empty and
+ * mc_stats.rows / reads_with_rows count the finished reads only.  run_pipeline() uses it when it is not asked for the
+ * "reads hit marker proteins" line (verbose). */
+int mc_set_best_hits_only(mc_handle *h, int on);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,7 @@ def load_library():
     lib.mc_search_files.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.mc_search_files_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int64]
     lib.mc_set_keep_rows.argtypes = [C.c_void_p, C.c_int]
+    lib.mc_set_best_hits_only.argtypes = [C.c_void_p, C.c_int]
     lib.mc_grid_classify.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_double), C.c_int32,
                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     _lib = lib
@@ -115,7 +116,7 @@ def load_library():
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
                     "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_set_parts", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8", "mc_write_m8_named",
                     "mc_reader_last_error", "mc_set_host_threads", "mc_reader_open", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_count_bases", "mc_quality_offset",
-                    "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows", "mc_grid_classify"]
+                    "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows", "mc_set_best_hits_only", "mc_grid_classify"]
 
 
 class ReferenceError_(Exception):
@@ -314,9 +315,14 @@ class Engine:
         self._check(self.lib.mc_search(self.h, reads.ctypes.data_as(C.c_void_p), reads.shape[0], first_read_id), "mc_search")
         return self.results()
 
-    def search_files(self, reader, first_read_id=0, keep_rows=True):
+    def set_best_hits_only(self, on):
+        """Only the reads that can be classified are ranked (mc_set_best_hits_only): same best hits, no rows."""
+        self._check(self.lib.mc_set_best_hits_only(self.h, 1 if on else 0), "mc_set_best_hits_only")
+
+    def search_files(self, reader, first_read_id=0, keep_rows=True, best_only=False):
         """process_seqfile + search_seqs + classify_reads in one call (mc_search_files): the reader samples beside the search."""
         self._check(self.lib.mc_set_keep_rows(self.h, 1 if keep_rows else 0), "mc_set_keep_rows")
+        self.set_best_hits_only(best_only)
         try:
             rc = self.lib.mc_search_files(self.h, reader.r, first_read_id)
             if rc == -3:
@@ -324,6 +330,7 @@ class Engine:
             self._check(rc, "mc_search_files")
         finally:
             self.lib.mc_set_keep_rows(self.h, 1)
+            self.lib.mc_set_best_hits_only(self.h, 0)
         return self.results()
 
     def upload(self, reads):

@@ -44,7 +44,7 @@ extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
         }                                                                                                   \
     } while (0)
 
-enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_HEAVY, C_HEAVY2, C_ITEMS, C_RETRY2, C_HEAVY3, C_LIGHT0, C_LIGHT1, C_LIGHT2, C_LIGHT3, C_N = 24 };
+enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_HEAVY, C_HEAVY2, C_ITEMS, C_RETRY2, C_HEAVY3, C_LIGHT0, C_LIGHT1, C_LIGHT2, C_LIGHT3, C_HSPS2, C_N = 24 };
 enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_EXACT = 16, S_WILD, S_PAIRS, S_PROBES, S_N = 20 };   // 64-bit algorithmic-traffic counters of k_enumerate; slots 4..: cycle counters of the MC_EXP_TIMING build
 
 // ------------------------------------------------------------------------------------------------
@@ -909,6 +909,20 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
     }
 }
 
+// ---- best hits only (mc_set_best_hits_only) -------------------------------------------------------------------------------------
+// classify_reads keeps, per read, the best-scoring m8 row that passes the family's three thresholds (microbe_census.py:432-460).
+// A row is an HSP's own alignment (sum statistics only change its log E): a read none of whose HSPs would pass the thresholds as a
+// row cannot be classified, whatever the ranking does - 99 % of the reads of a shotgun library.  The kernels that make HSPs mark
+// the reads that have such an HSP (cand), and only THEIR HSPs - all of them: the others still decide the sums, the order and the
+// 500-row cap - are sorted and finished.
+__device__ __forceinline__ bool mc_hsp_can_classify(const McTables &T, const McClassPars &P, const McIndex &X, const int32_t *fam, const McHsp &h)
+{
+    const int f = fam[h.sidx];
+    if (T.bits_r[h.score] < P.min_score[f]) return false;        // (most HSPs end here)
+    McRow r;
+    mc_fill_row(T, 0, h, r);
+    return mc_row_passes(P, r, f, (int)(X.off[h.sidx + 1] - X.off[h.sidx]), r.frame);
+}
 // Seed hits -> HSPs / gap tasks.  Persistent workgroups walk the task pool 512 hits at a time; what survives is staged in
 // LDS and flushed with ONE global atomic per ~400 HSPs / ~300 gap tasks: a device-scope atomic on a single counter executes
 // at the memory side (the L2s of the XCDs are not coherent with each other) at ~125 M/s - one per HSP, or even one per wave,
@@ -923,7 +937,7 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
 #define MC_EV_STAGE_G 640    // gap tasks (17.5 KB)
 __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(MC_EV_BS) k_eval_seeds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
                                                     const McSeedTask *__restrict__ tasks, const uint32_t *__restrict__ ntasks_p, uint32_t cap_tasks, McHsp *hsps, uint32_t cap_hsps,
-                                                    McGapTask *gaps, uint32_t cap_gaps, uint32_t *counters)
+                                                    McGapTask *gaps, uint32_t cap_gaps, uint32_t *counters, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam, uint8_t *cand)
 {
     const uint32_t ntasks = *ntasks_p <= cap_tasks ? *ntasks_p : 0u;   // (device-side count of the seed kernel; after an overflow the host discards the batch)
     __shared__ McHot hot;
@@ -974,6 +988,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(MC_
                 if (rc == 1) {
                     h.read = t.read; h.chrono = t.chrono;
                     keep = mc_make_hsp(*T, L, frame, g, g.qfwd, g.qfwd, g.qbwd, g.qbwd, g.score, g.nmatch, g.qfwd + g.L + g.qbwd, 0, 0, &h);
+                    if (keep && cand && mc_hsp_can_classify(*T, *P, X, fam, h)) cand[h.read] = 1;
                 }
             }
         }
@@ -1082,7 +1097,8 @@ __global__ void __launch_bounds__(256) k_gap_dedupe(McIndex X, int L, const McGa
 
 // every gap task -> its HSP, from the flank results of its group's leader
 __global__ void __launch_bounds__(256) k_gap_emit(const McTables *__restrict__ T, McIndex X, int L, const McGapTask *__restrict__ gaps, uint32_t ngaps, const uint32_t *__restrict__ leader,
-                                                  const McFlankOut *__restrict__ fout, McHsp *hsps, uint32_t cap_hsps, uint32_t *counters)
+                                                  const McFlankOut *__restrict__ fout, McHsp *hsps, uint32_t cap_hsps, uint32_t *counters, const McClassPars *__restrict__ P,
+                                                  const int32_t *__restrict__ fam, uint8_t *cand)
 {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     bool keep = false;
@@ -1103,6 +1119,7 @@ __global__ void __launch_bounds__(256) k_gap_emit(const McTables *__restrict__ T
         }
         h.read = g.read; h.chrono = g.chrono;
         keep = mc_make_hsp(*T, L, frame, g, qfwd, dfwd, qbwd, dbwd, score, nmatch, alnlen, gapopens, gaptotal, &h);
+        if (keep && cand && mc_hsp_can_classify(*T, *P, X, fam, h)) cand[h.read] = 1;
     }
     const uint32_t o = mc_block_alloc(&counters[C_HSPS], keep);
     if (keep) { if (o < cap_hsps) hsps[o] = h; else counters[C_OVERFLOW] = 2; }
@@ -1111,6 +1128,7 @@ __global__ void __launch_bounds__(256) k_gap_emit(const McTables *__restrict__ T
 #define MC_GAP_W 1200   // columns of the full-size DP workspace (markers are <= 1183 aa, checked in mc_open)
 #define MC_GAP_WIN 40   // columns of the LDS window of the first launch (30 KB per wave: five waves per CU)
 #define MC_GAP_WIN2 64  // ... of the second one, for the flanks whose band left the first (48 KB per wave)
+#define MC_GAP_LANES2 16 // lanes of a wave that take flanks in the second launch (300 bp, per 1 M reads: 4 lanes 2.2 ms, 8: 1.55, 16 or 64: 0.98)
 
 __device__ __forceinline__ McFlankOut mc_flank_out(const McGapResult &R)
 {
@@ -1164,7 +1182,7 @@ __global__ void __launch_bounds__(128) k_gapped(const McTables *__restrict__ T, 
 // starts one, and walks that chain one link per loop iteration (a DP row of the others) while it works: when its flank ends the
 // next one is ready in registers.  The same inside a row: the query residue of the next row and the subject residues the right
 // growth will need are requested at the row's start (mc_gap_row).
-#define MC_GAP_REFILL 16
+#define MC_GAP_REFILL 8
 template <int W>
 struct McGapLds {
     uint32_t *hd, *ph, *pd;                                        // this lane's column 0 of the three word arrays
@@ -1195,8 +1213,8 @@ __global__ void __launch_bounds__(64) k_gapped_lds(const McTables *__restrict__ 
     __syncthreads();
     const int lane = threadIdx.x;
     McGapLds<W> ws; ws.hd = win + lane; ws.ph = win + W * 64 + lane; ws.pd = win + 2 * W * 64 + lane;
-    // LANES < 64 (the retry launch: few, large, unequal flanks): only the first LANES lanes of a wave take items, so that the
-    // wave's run time is that of a few flanks, not of 64 different ones one after the other
+    // LANES < 64 (the retry launch: few, large flanks - its run time is that of the longest chain of them in one lane): only the
+    // first LANES lanes of a wave take items, so that the items spread over all the waves the GPU holds
     const bool mine = lane < LANES;
     const uint32_t G = gridDim.x, w0 = blockIdx.x;
     const uint32_t share = nitems > w0 ? (nitems - w0 + G - 1) / G : 0u;   // items of this wave: list[w0 + G k], k < share
@@ -1270,6 +1288,25 @@ __global__ void __launch_bounds__(64) k_gapped_lds(const McTables *__restrict__ 
         const uint32_t ro = mc_wave_alloc(retry_count, over);      // band left the window: the flank is redone with a wider one
         if (over) retry[ro] = it;
         if (taken >= share && __ballot(active || nstage != 0) == 0) break;
+    }
+}
+
+// sort keys of the HSPs of the marked reads, packed (their count in counters[C_HSPS2]); the HSP count is read on the device
+__global__ void __launch_bounds__(256) k_select_keys(const McHsp *__restrict__ hsps, const uint32_t *__restrict__ counters_in, uint32_t cap_hsps, const uint8_t *__restrict__ cand,
+                                                     uint64_t *keys, uint32_t *idx, uint32_t *counters)
+{
+    const uint32_t n = counters_in[C_HSPS] <= cap_hsps ? counters_in[C_HSPS] : 0u;
+    for (uint32_t b0 = blockIdx.x * 256u; b0 < n; b0 += gridDim.x * 256u) {
+        const uint32_t tid = b0 + threadIdx.x;
+        bool want = false;
+        uint64_t key = 0;
+        if (tid < n) {
+            const McHsp &h = hsps[tid];
+            want = cand[h.read] != 0;
+            key = ((uint64_t)h.read << 43) | ((uint64_t)(uint32_t)h.sidx << 28) | (uint64_t)h.chrono;
+        }
+        const uint32_t o = mc_block_alloc(&counters[C_HSPS2], want);
+        if (want) { keys[o] = key; idx[o] = tid; }
     }
 }
 
@@ -1630,7 +1667,7 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
 // reads that have one are collected (any order: the host sorts them by read), the reads with rows counted
 __global__ void __launch_bounds__(256) k_emit_rows(const uint32_t *__restrict__ heads, uint32_t nheads, const uint32_t *__restrict__ nrow_of, const uint32_t *__restrict__ rowoff,
                                                    const McHsp *__restrict__ tmp, McRow *__restrict__ rows, uint32_t cap_rows, const McBestHit *__restrict__ best_of, McBestHit *best,
-                                                   uint32_t *counters)
+                                                   uint32_t *counters, int copy_rows)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t nr = 0;
@@ -1639,8 +1676,8 @@ __global__ void __launch_bounds__(256) k_emit_rows(const uint32_t *__restrict__ 
         nr = nrow_of[s];
         bh = best_of[s];
         const uint32_t off = rowoff[s];
-        if (s == nheads - 1) { counters[C_ROWS] = off + nr; if (off + nr > cap_rows) counters[C_OVERFLOW] = 4; }
-        if (off + nr <= cap_rows) {
+        if (s == nheads - 1) { counters[C_ROWS] = off + nr; if (copy_rows && off + nr > cap_rows) counters[C_OVERFLOW] = 4; }
+        if (copy_rows && off + nr <= cap_rows) {
             const McRow *src = (const McRow *)(tmp + 2 * (size_t)heads[s]);
             for (uint32_t i = 0; i < nr; i++) rows[off + i] = src[i];
         }
@@ -1716,14 +1753,14 @@ struct McCtx {
     McSeedTask *d_tasks = nullptr; McGapTask *d_gaps = nullptr; McHsp *d_hsps = nullptr, *d_sorted = nullptr, *d_v = nullptr, *d_tmp = nullptr;
     uint64_t *d_k64 = nullptr, *d_k64o = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
     uint32_t *d_counters = nullptr;
-    McRow *d_rows = nullptr; uint32_t *d_nrow = nullptr, *d_rowoff = nullptr; McBestHit *d_best = nullptr, *d_bestof = nullptr; uint8_t *d_mark = nullptr;
+    McRow *d_rows = nullptr; uint32_t *d_nrow = nullptr, *d_rowoff = nullptr; McBestHit *d_best = nullptr, *d_bestof = nullptr; uint8_t *d_mark = nullptr, *d_cand = nullptr;
     McGapCell *d_gws_full = nullptr; uint32_t *d_retry = nullptr, *d_retry2 = nullptr; int gap_threads_full = 0;
     unsigned long long *d_gtab = nullptr; uint32_t gtab_slots = 0; uint32_t *d_gleader = nullptr; McFlankOut *d_fout = nullptr;
     // pinned host mirrors
     uint32_t *h_c = nullptr; unsigned long long *h_stats = nullptr; McBestHit *h_best = nullptr; size_t h_best_cap = 0;
     // the part being processed
     const uint8_t *reads = nullptr; int64_t n = 0, first_read_id = 0;
-    uint32_t ntasks = 0, ngaps = 0, nh = 0, nheads = 0, nrows = 0, nbest = 0, nsegs = 0;
+    uint32_t ntasks = 0, ngaps = 0, nh = 0, nh_all = 0, nheads = 0, nrows = 0, nbest = 0, nsegs = 0;
 };
 
 struct mc_handle {
@@ -1740,8 +1777,9 @@ struct mc_handle {
     uint32_t *d_filt = nullptr, *d_wild = nullptr, *d_pair = nullptr; uint64_t *d_segtab = nullptr; unsigned long long *d_rt = nullptr;
     bool fast_enum = false;
     bool count_traffic = false;
-    int parts = MC_NCTX;                  // parts a range is cut into (mc_set_parts; 1 = one kernel at a time, for profiling)
+    int parts = 1;                        // parts a range is cut into (mc_set_parts): 1 = one kernel at a time; 2 = two halves whose stages alternate
     bool keep_rows = true;                // mc_search / mc_search_files hand out the m8 rows (mc_set_keep_rows)
+    bool best_only = false;               // only the reads that can be classified are ranked; no rows (mc_set_best_hits_only)
     uint8_t *stage_pin[2] = {nullptr, nullptr}, *stage_dev[2] = {nullptr, nullptr}; int stage_len = 0; hipStream_t copy_stream = nullptr;   // run_stream
     // resident reads
     int64_t nreads = 0, cap_own = 0;
@@ -1778,7 +1816,7 @@ extern "C" int mc_device_count(void)
 static void ctx_free(McCtx &c)
 {
     void *ptrs[] = {c.d_frames, c.d_tasks, c.d_gaps, c.d_hsps, c.d_sorted, c.d_v, c.d_tmp, c.d_k64, c.d_k64o, c.d_idx, c.d_idxo, c.d_heads, c.d_sorttmp, c.d_counters, c.d_rows,
-                    c.d_nrow, c.d_rowoff, c.d_best, c.d_bestof, c.d_mark, c.d_gws_full, c.d_retry, c.d_retry2, c.d_gtab, c.d_gleader, c.d_fout, c.d_stats};
+                    c.d_nrow, c.d_rowoff, c.d_best, c.d_bestof, c.d_mark, c.d_cand, c.d_gws_full, c.d_retry, c.d_retry2, c.d_gtab, c.d_gleader, c.d_fout, c.d_stats};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : {(void *)c.h_c, (void *)c.h_stats, (void *)c.h_best}) if (p) (void)hipHostFree(p);
     for (auto &e : c.ev) if (e) (void)hipEventDestroy(e);
@@ -1844,7 +1882,7 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
         if (dalloc(&h->d_rec, H.rec.size())) return -1;
         HIPCK(hipMemcpy(h->d_rec, H.rec.data(), H.rec.size() * sizeof(McBucketRec), hipMemcpyHostToDevice));
     }
-    if (const char *e = getenv("MC_PARTS")) { const int v = atoi(e); if (v >= 1) h->parts = v > MC_NCTX ? MC_NCTX : v; }   // (profiling: MC_PARTS=1 = one kernel at a time)
+    if (const char *e = getenv("MC_PARTS")) { const int v = atoi(e); if (v >= 1) h->parts = v > MC_NCTX ? MC_NCTX : v; }   // (experiments)
     if (H.max_bucket > 2047) { g_err = "a seed bucket holds more than 2047 postings: the hit-order key cannot index it"; return -1; }
     // the position-parallel seed kernel is exact only when the frequency threshold is 0 and no letter frequency is 0
     h->fast_enum = (H.freq_thr == 0) && !H.rec.empty() && !getenv("MC_FORCE_SEQUENTIAL_ENUM");
@@ -1964,7 +2002,7 @@ static int ensure_capacity(mc_handle *h, McCtx &c, int64_t nreads)
         dalloc(&c.d_gaps, c.cap_gaps) || dalloc(&c.d_hsps, c.cap_hsps) || dalloc(&c.d_sorted, c.cap_hsps) || dalloc(&c.d_v, c.cap_hsps) ||
         dalloc(&c.d_tmp, (size_t)c.cap_hsps * 2) || dalloc(&c.d_k64, c.cap_hsps) || dalloc(&c.d_k64o, c.cap_hsps) || dalloc(&c.d_idx, c.cap_hsps) ||
         dalloc(&c.d_idxo, c.cap_hsps) || dalloc(&c.d_heads, (size_t)cap + 1) || dalloc(&c.d_rows, c.cap_rows) ||
-        dalloc(&c.d_mark, (size_t)c.cap_hsps) || dalloc(&c.d_nrow, (size_t)cap + 1) || dalloc(&c.d_rowoff, (size_t)cap + 1) || dalloc(&c.d_best, (size_t)cap + 1) || dalloc(&c.d_bestof, (size_t)cap + 1) ||
+        dalloc(&c.d_mark, (size_t)c.cap_hsps) || dalloc(&c.d_cand, (size_t)cap + 64) || dalloc(&c.d_nrow, (size_t)cap + 1) || dalloc(&c.d_rowoff, (size_t)cap + 1) || dalloc(&c.d_best, (size_t)cap + 1) || dalloc(&c.d_bestof, (size_t)cap + 1) ||
         dalloc(&c.d_gws_full, (size_t)c.gap_threads_full * MC_GAP_W) || dalloc(&c.d_retry, (size_t)c.cap_gaps * 2 + (size_t)cap + 1) || dalloc(&c.d_retry2, (size_t)c.cap_gaps * 2) || dalloc(&c.d_gleader, (size_t)c.cap_gaps) ||
         dalloc(&c.d_fout, (size_t)c.cap_gaps * 2))
         return -1;
@@ -2021,6 +2059,7 @@ static int stage_a(mc_handle *h, McCtx &c)
     c.ntasks = c.ngaps = c.nh = c.nheads = c.nrows = c.nbest = c.nsegs = 0;
     HIPCK(hipMemsetAsync(c.d_counters, 0, sizeof(uint32_t) * C_N, st));
     HIPCK(hipMemsetAsync(c.d_stats, 0, sizeof(unsigned long long) * S_N, st));
+    if (h->best_only) HIPCK(hipMemsetAsync(c.d_cand, 0, (size_t)n, st));
     HIPCK(hipEventRecord(c.ev[0], st));
     const int64_t threads = n * 6;
     const size_t lds_rest = (size_t)MC_TS_NLNF(FP) * 8 + (size_t)MC_TS_THREADS * MC_TS_STRIDE(FP);
@@ -2079,7 +2118,7 @@ static int stage_a(mc_handle *h, McCtx &c)
     const size_t lds_ev = (size_t)MC_EV_STAGE_H * sizeof(McHsp) + (size_t)MC_EV_STAGE_G * sizeof(McGapTask);   // 51.7 KB: three workgroups per CU
     HIPCK(hipFuncSetAttribute((const void *)k_eval_seeds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ev));
     static const unsigned ev_bpc = getenv("MC_EV_BPC") ? (unsigned)atoi(getenv("MC_EV_BPC")) : (unsigned)MC_EV_BPC;   // (experiments)
-    k_eval_seeds<<<dim3(256u * ev_bpc), dim3(MC_EV_BS), lds_ev, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_tasks, c.d_counters + C_TASKS, c.cap_tasks, c.d_hsps, c.cap_hsps, c.d_gaps, c.cap_gaps, c.d_counters);
+    k_eval_seeds<<<dim3(256u * ev_bpc), dim3(MC_EV_BS), lds_ev, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_tasks, c.d_counters + C_TASKS, c.cap_tasks, c.d_hsps, c.cap_hsps, c.d_gaps, c.cap_gaps, c.d_counters, h->d_P, h->d_fam, h->best_only ? c.d_cand : nullptr);
     HIPCK(hipEventRecord(c.ev[3], st));
     return counters_to_host(c);
 }
@@ -2111,11 +2150,13 @@ static int stage_b(mc_handle *h, McCtx &c)
         HIPCK(rocprim::radix_sort_pairs_desc(c.d_sorttmp, gbytes, gk, gko, gi, gio, (size_t)ngaps * 2, 0, 10, st));
         k_gapped_lds<MC_GAP_WIN, 64><<<dim3(std::min<uint32_t>((2 * ngaps + 63) / 64, 256u * gap_wpc)), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, gio, c.d_counters + C_ITEMS, c.d_fout,
                                                                                                                  c.d_counters + C_RETRY, c.d_retry, gap_refill);
-        k_gapped_lds<MC_GAP_WIN2, 4><<<dim3(256u * 3u * 4u), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry, c.d_counters + C_RETRY, c.d_fout, c.d_counters + C_RETRY2, c.d_retry2, 1);
+        k_gapped_lds<MC_GAP_WIN2, MC_GAP_LANES2><<<dim3(256u * 3u), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry, c.d_counters + C_RETRY, c.d_fout, c.d_counters + C_RETRY2, c.d_retry2, 1);
         k_gapped<<<dim3(c.gap_threads_full / 128), dim3(128), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry2, c.d_counters + C_RETRY2, c.d_fout, c.d_counters, c.d_gws_full, MC_GAP_W);
-        k_gap_emit<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, L, c.d_gaps, ngaps, c.d_gleader, c.d_fout, c.d_hsps, c.cap_hsps, c.d_counters);
+        k_gap_emit<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, L, c.d_gaps, ngaps, c.d_gleader, c.d_fout, c.d_hsps, c.cap_hsps, c.d_counters, h->d_P, h->d_fam, h->best_only ? c.d_cand : nullptr);
     }
     HIPCK(hipEventRecord(c.ev[4], st));
+    if (h->best_only)                                             // every HSP exists now: the sort keys of the marked reads' HSPs (their count goes to the host with the other counters)
+        k_select_keys<<<dim3(256u * 8u), dim3(256), 0, st>>>(c.d_hsps, c.d_counters, c.cap_hsps, c.d_cand, c.d_k64, c.d_idx, c.d_counters);
     return counters_to_host(c);
 }
 
@@ -2124,10 +2165,11 @@ static int stage_c(mc_handle *h, McCtx &c)
 {
     hipStream_t st = c.stream;
     if (c.h_c[C_OVERFLOW]) { g_err = "HSP buffer overflow"; return -2; }
-    const uint32_t nh = c.nh = c.h_c[C_HSPS];
+    c.nh_all = c.h_c[C_HSPS];
+    const uint32_t nh = c.nh = h->best_only ? c.h_c[C_HSPS2] : c.h_c[C_HSPS];      // HSPs that are ranked
     if (nh) {
         uint32_t *d_flags = c.d_idx, *d_hpos = (uint32_t *)c.d_k64;      // both free once the sort has run
-        k_make_keys<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(c.d_hsps, nh, c.d_k64, c.d_idx);
+        if (!h->best_only) k_make_keys<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(c.d_hsps, nh, c.d_k64, c.d_idx);
         size_t bytes = c.sorttmp_bytes;
         int rbits = 1;
         while ((1ll << rbits) < c.n) rbits++;
@@ -2173,7 +2215,7 @@ static int stage_d(mc_handle *h, McCtx &c)
         HIPCK(hipStreamWaitEvent(st, c.ev_join, 0));
         size_t bytes = c.sorttmp_bytes;
         HIPCK(rocprim::exclusive_scan(c.d_sorttmp, bytes, c.d_nrow, c.d_rowoff, 0u, (size_t)nheads, rocprim::plus<uint32_t>(), st));
-        k_emit_rows<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(c.d_heads, nheads, c.d_nrow, c.d_rowoff, c.d_tmp, c.d_rows, c.cap_rows, c.d_bestof, c.d_best, c.d_counters);
+        k_emit_rows<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(c.d_heads, nheads, c.d_nrow, c.d_rowoff, c.d_tmp, c.d_rows, c.cap_rows, c.d_bestof, c.d_best, c.d_counters, h->best_only ? 0 : 1);
     }
     HIPCK(hipEventRecord(c.ev[6], st));
     HIPCK(hipMemcpyAsync(c.h_stats, c.d_stats, sizeof(unsigned long long) * S_N, hipMemcpyDeviceToHost, st));
@@ -2256,7 +2298,7 @@ static int run_range_once(mc_handle *h, int64_t first, int64_t count, int64_t fi
         McCtx &c = h->ctx[p];
         if ((rc = stage_wait(c)) != 0) break;
         if (c.h_c[C_OVERFLOW]) { g_err = "row buffer overflow"; rc = -2; break; }
-        c.nrows = c.nh ? c.h_c[C_ROWS] : 0u; c.nsegs = c.h_c[C_SEGS]; c.nbest = c.h_c[C_BEST];
+        c.nrows = (c.nh && !h->best_only) ? c.h_c[C_ROWS] : 0u; c.nsegs = c.h_c[C_SEGS]; c.nbest = c.h_c[C_BEST];
         const size_t need = nrows + c.nrows;
         if (need > h->pin_cap) {                                     // grow the pinned row buffer (with room for the parts still to come)
             for (int q = 0; q < p; q++) (void)hipStreamSynchronize(h->ctx[q].stream);      // (their copies write into the old buffer)
@@ -2285,7 +2327,7 @@ static int run_range_once(mc_handle *h, int64_t first, int64_t count, int64_t fi
 #endif
         h->stats.bucket_lookups += (int64_t)c.h_stats[S_LOOKUPS]; h->stats.key_probes += (int64_t)c.h_stats[S_KEYPROBES]; h->stats.seed_tasks += (int64_t)c.h_stats[S_TASKS];
         h->stats.seed_exact_asks += (int64_t)c.h_stats[S_EXACT]; h->stats.seed_wild_asks += (int64_t)c.h_stats[S_WILD]; h->stats.seed_pair_asks += (int64_t)c.h_stats[S_PAIRS]; h->stats.seed_probes += (int64_t)c.h_stats[S_PROBES];
-        h->stats.gap_tasks += c.ngaps; h->stats.hsps += c.nh; h->stats.rows += c.nrows; h->stats.reads_with_rows += c.nsegs;
+        h->stats.gap_tasks += c.ngaps; h->stats.hsps += c.nh_all; h->stats.rows += c.nrows; h->stats.reads_with_rows += c.nsegs;
         // kernel times: HIP events on the part's own stream (the parts overlap, so the sums exceed the wall time of the call)
         h->stats.ms_translate += ev_ms(c.ev[0], c.ev[1]); h->stats.ms_seed += ev_ms(c.ev[1], c.ev[2]); h->stats.ms_eval += ev_ms(c.ev[2], c.ev[3]);
         h->stats.ms_gapped += ev_ms(c.ev[3], c.ev[4]); h->stats.ms_sort += ev_ms(c.ev[4], c.ev[5]); h->stats.ms_finish += ev_ms(c.ev[5], c.ev[6]); h->stats.ms_total += ev_ms(c.ev[0], c.ev[6]);
@@ -2496,6 +2538,13 @@ extern "C" int mc_set_keep_rows(mc_handle *h, int keep)
 {
     if (!h) { g_err = "null handle"; return -1; }
     h->keep_rows = keep != 0;
+    return 0;
+}
+
+extern "C" int mc_set_best_hits_only(mc_handle *h, int on)
+{
+    if (!h) { g_err = "null handle"; return -1; }
+    h->best_only = on != 0;
     return 0;
 }
 

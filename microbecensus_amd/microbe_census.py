@@ -413,7 +413,8 @@ def _sample_search_classify(args, paths):
         try:
             eng = _engine(args.get("device", 0) or 0)
             eng.set_run(L, model["pars"][str(L)], fams)
-            rows, best = eng.search_files(rd, keep_rows=False)
+            # (the count of reads with m8 rows is only printed when verbose: without it only the reads that can be classified are ranked)
+            rows, best = eng.search_files(rd, keep_rows=False, best_only=not args["verbose"])
         except _native.ReferenceError_ as e:       # the reference raises here; run_pipeline prints it and returns None
             raise Exception(str(e))
         except RuntimeError as error:

@@ -283,3 +283,58 @@ def test_config5_shape_300bp_fastq_quality_and_duplicate_filters(engine, tmp_pat
     agg = mc.aggregate_hits(args, paths, best)
     mc.clean_up(paths)
     assert mc.estimate_average_genome_size(args, paths, agg) > 0
+
+
+GOLDEN_SETS = {   # golden case -> (input files, read length, sampler arguments after the length)
+    "unittest_metagenome": (["metagenome.fa.gz"], 100, (1000000, False, 0, -5, -5, 100, False)),
+    "config1_example_fq": (["example.fq.gz"], 100, (10000, True, 32, -5, -5, 100, False)),
+    "c2_100bp": (["c2_100bp.fa.gz"], 100, (1000000, False, 0, -5, -5, 100, False)),
+    "c4_paired": (["c4_pair_1.fq.gz", "c4_pair_2.fq.gz"], 150, (20000, True, 32, -5, -5, 100, False)),
+    "c5_300bp_q20_dups": (["c5_300bp.fq.gz"], 300, (1000000, True, 32, 20, -5, 100, True)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(GOLDEN_SETS))
+def test_best_hits_only_equals_the_reference_classification(case, engine):
+    """mc_set_best_hits_only (what run_pipeline runs when it is not verbose): only the reads that have an HSP passing their
+    family's thresholds are ranked - the best hits must still be the reference's classify_reads (:432-460) on every golden set,
+    and the rows path must give the same."""
+    from microbecensus_amd import _native
+    files, L, rest = GOLDEN_SETS[case]
+    g = golden(case)
+    model = _native.load_model()
+    fams = model["families"]
+    reads, st = _native.sample_reads([os.path.join(INPUTS, f) for f in files], L, *rest)
+    assert st["sampled"] == g["sampled_reads"]
+    engine.set_run(L, model["pars"][str(L)], fams)
+    engine.set_best_hits_only(True)
+    try:
+        rows, best = engine.search(reads)
+    finally:
+        engine.set_best_hits_only(False)
+    assert len(rows) == 0
+    got = {str(r): [fams[f], float(a), float(a) / float(t), float(s)] for r, f, a, t, s in zip(best["read"].tolist(), best["family"].tolist(), best["aln"].tolist(), best["target_len"].tolist(), best["bits"].tolist())}
+    assert got == g["best_hits"]
+    rows2, best2 = engine.search(reads)
+    assert len(rows2) == g["m8_rows"] and (best2 == best).all()
+
+
+def test_best_hits_only_differential_on_genome_reads(engine):
+    """1,000,000 error-free 150 bp reads of the 30 genomes (the bench workload): best hits of the best-hits-only path == those of
+    the rows path, bit for bit, through both parts of the range and several batches of the stream."""
+    from microbecensus_amd import _native, synth
+    model = _native.load_model()
+    fams = model["families"]
+    gen = synth.GenomeReads(device="cpu", seed=20261001)           # (torch's own HIP runtime cannot be initialised beside the engine's in one process)
+    reads = gen.single(1_000_000, 150, first=7_000_000).numpy()
+    engine.set_run(150, model["pars"]["150"], fams)
+    _, full = engine.search(reads)
+    engine.set_best_hits_only(True)
+    try:
+        rows, only = engine.search(reads)
+        st = engine.stats()
+    finally:
+        engine.set_best_hits_only(False)
+    assert len(full) > 4000 and len(rows) == 0
+    assert only.dtype == full.dtype and len(only) == len(full) and (only == full).all()
+    assert st["classified"] == len(full) and st["hsps"] > 10 * len(reads)        # (every HSP is still made and counted; few are ranked)
