@@ -1994,7 +1994,7 @@ static int ensure_capacity(mc_handle *h, McCtx &c, int64_t nreads)
     const int64_t L = h->read_len;
     c.cap_reads = 0;                                                // pools are being replaced: nothing is usable until all of them exist
     c.cap_tasks = (uint32_t)std::min<int64_t>(cap * (L + 32) + (1 << 20) + (int64_t)256 * 32 * MC_EN_BLK, 0x7fffffff);
-    c.cap_gaps = (uint32_t)std::min<int64_t>(cap * (L / 8 + 8) + (1 << 18), 0x7fffffff);
+    c.cap_gaps = (uint32_t)std::min<int64_t>(cap * (L / 8 + 8) + (1 << 18), (1 << 27) - 2);   // (k_gap_dedupe keeps task index + 1 in 27 bits of a table entry: more tasks than that overflow the pool and the range is split)
     c.cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 2 + 16) + (1 << 20), 0x7fffffff);
     c.cap_rows = (uint32_t)std::min<int64_t>(cap * 48 + (1 << 20), 0x7fffffff);
     c.gap_threads_full = 16 * 1024;                                 // full-size DP rows for the last-resort launch (460 MB)

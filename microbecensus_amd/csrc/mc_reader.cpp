@@ -19,7 +19,9 @@
 //     reverse_complement knows ACGTN only - any other character is an error (KeyError in the reference);
 //   * QC looks at the first L bases / qualities: 100*count('N')/L > max_unknown, mean(q) < mean_quality, min(q) < min_quality
 //     with q = ord(c) - quality_offset, in IEEE double like numpy;
-//   * a truncated or corrupt compressed stream is an error (gzip.open raises EOFError) - but only if the sampler gets there.
+//   * a truncated or corrupt compressed stream is an error (gzip.open raises EOFError) - but only if the sampler gets there;
+//   * the codec follows the file NAME (.gz, .bz2, anything else is plain text), as open_file does: a *.gz file that does not hold
+//     gzip data is an error (BadGzipFile), gzip data under another name is read as the bytes it is.
 //
 // How it is made fast (the sampler is sequential by definition: head-take, first occurrence wins):
 //   * the byte stream is taken in regions of whole lines (plain files: slices of one mmap, nothing is copied; compressed
@@ -218,6 +220,7 @@ struct Stream {
     bool at_end = false;                        // nothing can be added to the window any more
     bool failed = false;                        // ... because the stream is truncated / corrupt
     bool compressed = false;
+    bool bad_gzip = false;                      // open() failed because a *.gz file does not hold gzip data
 
     ~Stream() { close(); }
     bool open(const char *path)
@@ -235,7 +238,10 @@ struct Stream {
             const ssize_t got = pread(fd, magic, 2, 0);
             struct stat sb;
             const bool reg = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
-            if ((got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) || !reg) {   // gzip by its magic (zlib reads anything else transparently: pipes)
+            const bool is_gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+            // the codec follows the file NAME, as open_file does (reference :47-59): a *.gz that is not gzip is gzip.open's BadGzipFile
+            if (has_ext(path, ".gz") && reg && got > 0 && !is_gz) { ::close(fd); r_err = std::string("BadGzipFile: Not a gzipped file (") + path + ")"; bad_gzip = true; return false; }
+            if (has_ext(path, ".gz") || !reg) {                          // (anything that is not a regular file - a pipe - is read through zlib, which passes plain bytes on)
                 gz = gzdopen(fd, "rb");
                 if (!gz) { ::close(fd); r_err = std::string("cannot open ") + path; return false; }
                 gzbuffer(gz, 1 << 20);
@@ -609,7 +615,7 @@ int reader_threads()
 int walk_file(const std::string &path, const Params &P, Pool &pool, const std::function<bool(std::vector<Piece *> &)> &on_region)
 {
     Stream st;
-    if (!st.open(path.c_str())) return -1;
+    if (!st.open(path.c_str())) return st.bad_gzip ? -3 : -1;
     const int T = pool.size();
     size_t region_bytes = (size_t)std::max(1, std::min(T, 16)) * ((size_t)4 << 20), piece_bytes = (size_t)256 << 10;
     if (const char *v = getenv("MC_READER_REGION_BYTES")) region_bytes = std::max<size_t>(16, (size_t)atoll(v));   // (tests: many regions and pieces on small files)

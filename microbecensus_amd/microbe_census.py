@@ -117,18 +117,34 @@ def check_rapsearch(rapsearch):
 
 def _rapdb_for_external_search():
     """The marker database in RAPsearch2's on-disk format (what `prerapsearch -d markers.faa -n rapdb_2.15` writes), produced once
-    per machine by the library's own writer (mc_rapdb_write) from the packaged markers."""
+    per user by the library's own writer (mc_rapdb_write) from the packaged markers.  It lives in a directory only this user can
+    write (~/.cache/microbecensus_amd, mode 0700); the pair of files is written into a fresh directory and renamed into place as a
+    whole, and a database found there is checked against the packaged markers (mc_rapdb_verify) before it is used."""
     import hashlib
+    import shutil
     import tempfile
     from . import _native
     names, seqs = _native.load_markers()
     tag = hashlib.md5(("".join(names) + "".join(seqs)).encode()).hexdigest()[:16]
-    path = os.path.join(tempfile.gettempdir(), "microbecensus_amd_rapdb_2.15_" + tag)
-    if not (os.path.isfile(path) and os.path.isfile(path + ".info")):
-        tmp = path + ".%d" % os.getpid()
-        _native.rapdb_write(names, seqs, tmp)
-        os.replace(tmp + ".info", path + ".info")
-        os.replace(tmp, path)
+    root = os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "microbecensus_amd")
+    os.makedirs(root, mode=0o700, exist_ok=True)
+    st = os.stat(root)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        root = tempfile.mkdtemp(prefix="microbecensus_amd_")          # somebody else's directory: a private one for this run
+    d = os.path.join(root, "rapdb_2.15_" + tag)
+    path = os.path.join(d, "rapdb_2.15")
+    if os.path.isfile(path) and os.path.isfile(path + ".info") and _native.rapdb_verify(path, names, seqs) == 0:
+        return path
+    tmp = tempfile.mkdtemp(prefix="rapdb_", dir=root)
+    _native.rapdb_write(names, seqs, os.path.join(tmp, "rapdb_2.15"))
+    if os.path.isdir(d):
+        shutil.rmtree(d, ignore_errors=True)
+    try:
+        os.rename(tmp, d)
+    except OSError:                                                   # another process of this user was faster
+        if not (os.path.isfile(path) and os.path.isfile(path + ".info")):
+            return os.path.join(tmp, "rapdb_2.15")
+        shutil.rmtree(tmp, ignore_errors=True)
     return path
 
 

@@ -198,44 +198,22 @@ def test_rapsearch_compatible_executable(tmp_path):
 
 def test_training_grid_on_device_rows():
     """The training workflow's grid search (training/training.py:311-334; 4 aln_covs x 6 max_pids x 27 min_scores as
-    training/class_reads.py:51-53 sets them) on the device rows of the unit-test metagenome against a Python statement of that
-    function applied to the reference's own m8 text: hits and aligned residues identical, coverage sums to 1e-12."""
+    training/class_reads.py:51-53 sets them) on the device rows of the unit-test metagenome against the .hits table the
+    REFERENCE's own functions produced from its own m8 (tests/golden/training_grid_unittest.json.gz, written by
+    tests/golden/make_training_golden.py, which executes training.py:229-334 unchanged): hits and aligned residues identical,
+    coverage sums to 1e-12."""
     from microbecensus_amd import _native
     g = json.load(open(os.path.join(GOLD, "unittest_metagenome.json")))
+    gold = json.load(gzip.open(os.path.join(GOLD, "training_grid_unittest.json.gz"), "rt"))
     L = 100
     model = _native.load_model()
     fams = model["families"]
-    names, seqs = _native.load_markers()
-    gene2fam = {n: fams[f] for n, f in zip(names, model["marker_family"])}
-    gene2len = {n: len(s) for n, s in zip(names, seqs)}
-    aln_covs, max_pids = [0.00, 0.25, 0.50, 0.75], [50, 60, 70, 80, 90, 100]
-    min_scores, r = [], 23
-    while r < 50:
-        min_scores.append(r); r += 1
-    # --- the reference's algorithm on the reference's m8 (text fields parsed as training.parse_rapsearch does)
-    hits = []
-    for line in gzip.open(os.path.join(GOLD, "unittest_metagenome.m8.gz"), "rt"):
-        x = line.split()
-        q, t, pid, aln, qs, qe, ts, te, score = x[0], x[1], float(x[2]), int(x[3]), float(x[6]), float(x[7]), float(x[8]), float(x[9]), float(x[11])
-        a, b = sorted([qs, qe])
-        frame = a % 3 if a % 3 in [1, 2] else 3
-        hits.append([q, t, gene2fam[t], pid, aln, (a + 3 - frame) / 3, (b + 1 - frame) / 3] + sorted([ts + 1, te + 1]) + [score])
+    aln_covs, max_pids, min_scores = gold["aln_covs"], gold["max_pids"], gold["min_scores"]
+    assert (len(aln_covs), len(max_pids), len(min_scores)) == (4, 6, 27)
     want = {}
-    for ic, aln_cov in enumerate(aln_covs):
-        h1 = [h for h in hits if not (h[4] / (min(h[5] - 1, h[7] - 1) + h[4] + min(float(L) / 3 - h[6], gene2len[h[1]] - h[8])) < aln_cov)]
-        for ip, max_pid in enumerate(max_pids):
-            h2 = [h for h in h1 if not h[3] > max_pid]
-            for isc, min_score in enumerate(min_scores):
-                best = {}
-                for h in h2:
-                    if h[-1] < min_score:
-                        continue
-                    if h[0] not in best or best[h[0]][-1] < h[-1]:
-                        best[h[0]] = h
-                for h in best.values():
-                    k = (ic, ip, isc, fams.index(h[2]))
-                    w = want.setdefault(k, [0, 0, 0.0])
-                    w[0] += 1; w[1] += h[4]; w[2] += float(h[4]) / gene2len[h[1]]
+    for fam, aln_cov, max_pid, min_score, hits, aln, cov in gold["rows"]:
+        want[(aln_covs.index(aln_cov), max_pids.index(max_pid), min_scores.index(min_score), fams.index(fam))] = (hits, aln, cov)
+    assert len(want) == gold["n_rows_with_hits"]
     # --- the device grid on the device rows
     reads, st = _native.sample_reads([os.path.join(INPUTS, "metagenome.fa.gz")], L, 1000000, False, 0, -5, -5, 100, False)
     eng = _native.Engine(device=0)
@@ -253,41 +231,31 @@ def test_training_grid_on_device_rows():
     assert int((gh > 0).sum()) == len(want)
 
 
-def test_config5_shape_at_size_native_sampler_equals_python_statement(tmp_path):
+def test_config5_shape_at_size_native_sampler_equals_the_reference(tmp_path):
     """BASELINE configs[4] shape at a size where the parallel reader cuts many regions and pieces: 150,000 FASTQ records of 300 bp
-    (phred+33 qualities ~ N(34, 6), 5 % with one base below 20, 2 % exact and 1 % reverse-complement duplicates) with -q 20 -d.
-    run_pipeline's fused path (native sampler beside the search) against the Python statement of process_seqfile feeding the same
-    search stage by stage: same sample size, same AGS."""
-    from microbecensus_amd import synth
-    gen = synth.GenomeReads(device="cpu", seed=11)
-    n, L = 150_000, 300
-    r = gen.single(n, L).numpy()
-    rng = np.random.RandomState(3)
-    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
-    qual = (np.clip(np.rint(rng.normal(34, 6, size=(n, L))), 20, 41).astype(np.uint8) + 33)
-    low = rng.rand(n) < 0.05
-    qual[low, rng.randint(0, L, size=int(low.sum()))] = 33 + 10
-    u = rng.rand(n)
-    recs, pool = [], []
-    for i in range(n):
-        sq = bytes(r[i])
-        if b"Y" in sq or b"S" in sq:                              # (the genomes hold two IUPAC letters; reverse_complement knows ACGTN only)
-            sq = sq.replace(b"Y", b"N").replace(b"S", b"N")
-        if pool and u[i] < 0.02:
-            sq = pool[rng.randint(len(pool))]
-        elif pool and u[i] < 0.03:
-            sq = pool[rng.randint(len(pool))][::-1].translate(comp)
-        elif len(pool) < 5000:
-            pool.append(sq)
-        recs.append(b"@s%d\n%s\n+\n%s\n" % (i, sq, bytes(qual[i])))
+    (tests/golden/c5_at_size.py) with -q 20 -d.  The expected sample comes from the REFERENCE's own process_seqfile run on the same
+    file (tests/golden/c5_at_size.json, make_sampler_at_size_golden.py): counters, sample size and the md5 of the temp FASTA; the
+    fused path (native sampler beside the search) and the stage-by-stage path then give the same AGS."""
+    sys.path.insert(0, GOLD)
+    import c5_at_size
+    g = json.load(open(os.path.join(GOLD, "c5_at_size.json")))
     fq = tmp_path / "c5.fq"
-    fq.write_bytes(b"".join(recs))
+    c5_at_size.write_fastq(str(fq))
+    assert hashlib.md5(fq.read_bytes()).hexdigest() == g["file_md5"]
     base = {"seqfiles": [str(fq)], "min_quality": 20, "filter_dups": True, "nreads": 10_000_000}
     est, args = mc.run_pipeline(dict(base))
-    est_py, args_py = mc.run_pipeline(dict(base, python_reader=True, keep_tmp=True))
-    assert args["read_length"] == 300 and args["sampled_reads"] == args_py["sampled_reads"]
-    assert 0.90 * n < args["sampled_reads"] < 0.94 * n           # ~5 % low quality, ~3 % duplicates
-    assert est == est_py
+    assert args["read_length"] == g["read_length"] and args["quality_offset"] == g["quality_offset"] and args["sampled_reads"] == g["sampled_reads"]
+    # stage by stage: the temp FASTA is the reference's, byte for byte
+    args2 = dict(base)
+    paths = mc.get_relative_paths(args2)
+    mc.check_input(args2); mc.impute_missing_args(args2); mc.check_arguments(args2)
+    mc.process_seqfile(args2, paths)
+    assert hashlib.md5(open(paths["tempfile"], "rb").read()).hexdigest() == g["reads_md5"]
+    mc.search_seqs(args2, paths)
+    est2 = mc.estimate_average_genome_size(args2, paths, mc.aggregate_hits(args2, paths, mc.classify_reads(args2, paths)))
+    mc.clean_up(paths)
+    assert est == est2
+    assert mc.count_bases(args2) == g["count_bases"]
 
 
 @pytest.mark.gpu

@@ -62,3 +62,14 @@ def test_m8_identical_to_reference(case, counting, engine, tmp_path):
     assert len(rows) == meta["m8_rows"]
     assert hashlib.md5(got).hexdigest() == meta["m8_md5"]
     assert (st["bucket_lookups"] > 0 and st["key_probes"] > 0) if counting else (st["bucket_lookups"] == 0 and st["key_probes"] == 0)
+
+
+def test_the_product_library_is_the_one_loaded():
+    """The GPU tests must exercise microbecensus_amd/libmcensus_hip.so itself: no MCENSUS_LIB override in the environment, and
+    the library mapped into this process is the in-tree one."""
+    from microbecensus_amd import _native
+    assert "MCENSUS_LIB" not in os.environ
+    _native.load_library()
+    want = os.path.realpath(os.path.join(os.path.dirname(os.path.abspath(_native.__file__)), "libmcensus_hip.so"))
+    mapped = {os.path.realpath(line.split()[-1]) for line in open("/proc/self/maps") if "libmcensus_hip" in line}
+    assert mapped == {want}

@@ -193,6 +193,55 @@ def test_bz2_with_several_streams_is_read_to_its_end(tmp_path):
     assert "EOFError" in str(e.value)
 
 
+def test_sampler_at_size_equals_the_reference(tmp_path, monkeypatch):
+    """150,000 FASTQ records of 300 bp with -q 20 -d (BASELINE configs[4] shape; tests/golden/c5_at_size.py): counters, sample and
+    count_bases against what the REFERENCE's own process_seqfile produced for the same file (tests/golden/c5_at_size.json) - with
+    the default geometry (many pieces per region) and with small regions."""
+    import hashlib
+    import json
+    import sys
+    from microbecensus_amd import _native
+    sys.path.insert(0, GOLD)
+    import c5_at_size
+    g = json.load(open(os.path.join(GOLD, "c5_at_size.json")))
+    fq = str(tmp_path / "c5.fq")
+    c5_at_size.write_fastq(fq)
+    assert hashlib.md5(open(fq, "rb").read()).hexdigest() == g["file_md5"]
+    for geom in ({}, {"MC_READER_REGION_BYTES": str(3 << 20), "MC_READER_PIECE_BYTES": str(64 << 10)}):
+        for k, v in geom.items():
+            monkeypatch.setenv(k, v)
+        fa = str(tmp_path / "out.fa")
+        reads, st = _native.sample_reads([fq], 300, 10_000_000, True, g["quality_offset"], 20, -5, 100, True, fa)
+        assert {k: st[k] for k in ("too_short", "low_qual", "dups", "sampled")} == g["counters"]
+        assert hashlib.md5(open(fa, "rb").read()).hexdigest() == g["reads_md5"]
+        assert st["exhausted"] == 1 and st["bases"] == g["count_bases"]
+        for k in geom:
+            monkeypatch.delenv(k)
+    assert _native.count_bases([fq]) == g["count_bases"]
+
+
+def test_codec_follows_the_file_name(tmp_path):
+    """open_file (reference :47-59) picks gzip / bz2 / plain by the extension: a plain-text file called *.gz makes gzip.open raise
+    BadGzipFile (run_pipeline prints it and returns None) - the native reader reports the same instead of reading it."""
+    import gzip
+    from microbecensus_amd import _native
+    text = b"".join(b">r%d\n%s\n" % (i, b"ACGT" * 30) for i in range(50))
+    p = str(tmp_path / "plain.fa.gz")
+    open(p, "wb").write(text)
+    with pytest.raises(_native.ReferenceError_) as e:
+        _native.count_bases([p])
+    assert "BadGzipFile" in str(e.value)
+    with pytest.raises(Exception):
+        gzip.open(p).read()
+    q = str(tmp_path / "real.fa.gz")
+    with gzip.open(q, "wb") as f:
+        f.write(text)
+    assert _native.count_bases([q]) == 50 * 120
+    e0 = str(tmp_path / "empty.fa.gz")
+    open(e0, "wb").close()
+    assert gzip.open(e0).read() == b"" and _native.count_bases([e0]) == 0
+
+
 def test_streaming_fetch_equals_run(tmp_path):
     """mc_reader_start / fetch / join hand out the same reads mc_reader_run collects."""
     import ctypes as C
