@@ -1,0 +1,746 @@
+// mc_pgzip.h - parallel inflate of a .gz file (host side of the read sampler, mc_reader.cpp).
+//
+// open_file (reference microbe_census.py:47-59) hands gzip.open() to the parser: one inflate stream, ~0.5 GB/s of text, far below
+// what the parser (and the GPU behind it) take.  A gzip member cannot be cut into independent pieces - every deflate block may
+// refer back to the 32 KB in front of it - so the file is decoded SPECULATIVELY, the way pugz / rapidgzip do it:
+//
+//   * the compressed bytes are cut into chunks; a worker looks for a deflate block header behind its chunk's nominal start (a
+//     dynamic-Huffman header that passes every consistency test of RFC 1951, or a gzip member header) and decodes from there with
+//     an UNKNOWN window: a back-reference that reaches in front of the chunk becomes a marker symbol (16-bit output: 0..255 a byte,
+//     256 + k = "byte k of the 32 KB in front of this chunk"), and copies of markers stay markers;
+//   * the chunks are stitched in file order: chunk k counts only if chunk k - 1 ended exactly at the bit where k started (a false
+//     block header is found out here at the latest: the chunk is then decoded again from the true position, sequentially, with
+//     zlib and the known window); its markers are replaced from the last 32 KB of what lies in front of it, which is known by
+//     then - that replacement and the CRC are again parallel over the chunks;
+//   * chunk 0, and every repair, is plain zlib (raw inflate primed to the bit position, window set as dictionary, stopping at
+//     block boundaries with Z_BLOCK).
+// What comes out is byte for byte what zlib's gzread produces, for any gzip file: several members (bgzip, pigz -i, cat a.gz b.gz),
+// stored and fixed-Huffman blocks, non-text data (decoded by the sequential repair path when the speculative one declines it);
+// CRC-32 and ISIZE of every member are verified; a truncated or damaged file delivers what lies in front of the damage and then
+// fails (gzip.open's EOFError / BadGzipFile), like the single-stream reader it replaces.
+#pragma once
+#include <zlib.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace mcgz {
+
+// ------------------------------------------------------------------------------------------------------------------
+// bit reader over the mapped file (LSB first, as deflate packs its bits)
+// ------------------------------------------------------------------------------------------------------------------
+struct Bits {
+    const uint8_t *base = nullptr, *p = nullptr, *end = nullptr;
+    uint64_t buf = 0;
+    int cnt = 0;                                                    // valid bits in buf
+    void init(const uint8_t *b, const uint8_t *e, uint64_t bitpos)
+    {
+        base = b; end = e; p = b + (bitpos >> 3); buf = 0; cnt = 0;
+        refill();
+        const int skip = (int)(bitpos & 7);
+        if (cnt >= skip) { buf >>= skip; cnt -= skip; } else cnt = -1;
+    }
+    inline void refill()
+    {
+        if (p + 8 <= end) {                                          // whole bytes that fit: one unaligned load
+            uint64_t w;
+            memcpy(&w, p, 8);
+            buf |= w << cnt;
+            const int take = (63 - cnt) >> 3;
+            p += take; cnt += take * 8;
+        } else {
+            while (cnt <= 56 && p < end) { buf |= (uint64_t)*p++ << cnt; cnt += 8; }
+        }
+    }
+    inline uint32_t peek(int n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
+    inline void drop(int n) { buf >>= n; cnt -= n; }
+    inline bool need(int n) { if (cnt < n) refill(); return cnt >= n; }
+    uint64_t bitpos() const { return (uint64_t)(p - base) * 8 - (uint64_t)cnt; }
+    void align_byte() { const int r = cnt & 7; buf >>= r; cnt -= r; }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// canonical Huffman decoding tables (primary table of PB bits; longer codes are walked bit by bit - they are rare)
+// ------------------------------------------------------------------------------------------------------------------
+template <int PB, int MAXSYM>
+struct Huff {
+    uint16_t tab[1 << PB];                                          // symbol << 4 | length (0: longer than PB bits, or no such code)
+    uint16_t count[16], sorted[MAXSYM];                             // canonical form for the slow path
+    int nsym = 0;
+    // 0 ok, -1 over-subscribed, -2 incomplete (a single code of length 1 and the empty code are reported as ok: RFC 1951 allows them for distances)
+    int build(const uint8_t *lens, int n)
+    {
+        nsym = n;
+        memset(count, 0, sizeof count);
+        for (int i = 0; i < n; i++) count[lens[i]]++;
+        const int used = n - count[0];
+        int left = 1;
+        for (int len = 1; len <= 15; len++) { left <<= 1; left -= count[len]; if (left < 0) return -1; }
+        uint16_t offs[16];
+        offs[1] = 0;
+        for (int len = 1; len < 15; len++) offs[len + 1] = (uint16_t)(offs[len] + count[len]);
+        for (int i = 0; i < n; i++) if (lens[i]) sorted[offs[lens[i]]++] = (uint16_t)i;
+        memset(tab, 0, sizeof tab);
+        // codes in canonical order; the table is indexed by the bit-reversed code (the stream is read LSB first)
+        uint32_t code = 0;
+        int idx = 0;
+        for (int len = 1; len <= 15; len++) {
+            for (int k = 0; k < count[len]; k++, idx++, code++) {
+                if (len > PB) continue;
+                uint32_t rev = 0;
+                for (int b = 0; b < len; b++) rev |= ((code >> b) & 1u) << (len - 1 - b);
+                const uint16_t e = (uint16_t)((sorted[idx] << 4) | len);
+                for (uint32_t j = rev; j < (1u << PB); j += 1u << len) tab[j] = e;
+            }
+            code <<= 1;
+        }
+        if (left > 0 && !(used <= 1)) return -2;
+        return 0;
+    }
+    // returns the symbol, or -1 (no such code / not enough input)
+    inline int decode(Bits &br) const
+    {
+        if (br.cnt < 15) br.refill();
+        const uint16_t e = tab[br.peek(PB)];
+        const int len = e & 15;
+        if (len) { if (br.cnt < len) return -1; br.drop(len); return e >> 4; }
+        // slow path (puff): walk the code bit by bit
+        int code = 0, first = 0, index = 0;
+        uint64_t b = br.buf;
+        for (int l = 1; l <= 15; l++) {
+            if (br.cnt < l) return -1;
+            code |= (int)(b & 1); b >>= 1;
+            const int c = count[l];
+            if (code - c < first) { br.drop(l); return sorted[index + (code - first)]; }
+            index += c; first += c; first <<= 1; code <<= 1;
+        }
+        return -1;
+    }
+};
+
+typedef Huff<11, 288> LitHuff;
+typedef Huff<9, 32> DistHuff;
+typedef Huff<7, 19> ClHuff;
+
+static const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+static const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+static const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+static const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+static const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// Reads the header of a dynamic-Huffman block (the 3 header bits are already consumed) and builds its tables.  strict: refuse
+// what zlib refuses AND what a real compressor never writes (used while guessing block starts).
+inline bool read_dynamic(Bits &br, LitHuff &lit, DistHuff &dist, bool strict)
+{
+    if (!br.need(14)) return false;
+    const int hlit = (int)br.peek(5) + 257; br.drop(5);
+    const int hdist = (int)br.peek(5) + 1; br.drop(5);
+    const int hclen = (int)br.peek(4) + 4; br.drop(4);
+    if (hlit > 286 || hdist > 30) return false;
+    uint8_t cl[19] = {0};
+    for (int i = 0; i < hclen; i++) { if (!br.need(3)) return false; cl[kClOrder[i]] = (uint8_t)br.peek(3); br.drop(3); }
+    ClHuff ch;
+    if (ch.build(cl, 19) != 0) return false;                        // zlib: the code-length code must be complete
+    { int used = 0; for (int i = 0; i < 19; i++) used += cl[i] != 0; if (used < 2) return false; }
+    uint8_t lens[286 + 30 + 138];
+    int n = 0;
+    const int total = hlit + hdist;
+    while (n < total) {
+        const int sym = ch.decode(br);
+        if (sym < 0) return false;
+        if (sym < 16) lens[n++] = (uint8_t)sym;
+        else {
+            int rep, val = 0;
+            if (sym == 16) { if (n == 0 || !br.need(2)) return false; val = lens[n - 1]; rep = 3 + (int)br.peek(2); br.drop(2); }
+            else if (sym == 17) { if (!br.need(3)) return false; rep = 3 + (int)br.peek(3); br.drop(3); }
+            else { if (!br.need(7)) return false; rep = 11 + (int)br.peek(7); br.drop(7); }
+            if (n + rep > total) return false;
+            while (rep--) lens[n++] = (uint8_t)val;
+        }
+    }
+    if (lens[256] == 0) return false;                               // no end-of-block code
+    if (lit.build(lens, hlit) != 0) return false;                    // (a lone literal/length code cannot be: 256 is one, data another)
+    const int dr = dist.build(lens + hlit, hdist);
+    if (dr != 0) return false;
+    if (strict) { int used = 0; for (int i = 0; i < hlit; i++) used += lens[i] != 0; if (used < 3) return false; }
+    return true;
+}
+
+inline void fixed_tables(LitHuff &lit, DistHuff &dist)
+{
+    uint8_t l[288], d[30];
+    for (int i = 0; i < 144; i++) l[i] = 8;
+    for (int i = 144; i < 256; i++) l[i] = 9;
+    for (int i = 256; i < 280; i++) l[i] = 7;
+    for (int i = 280; i < 288; i++) l[i] = 8;
+    for (int i = 0; i < 30; i++) d[i] = 5;
+    lit.build(l, 288); dist.build(d, 30);
+}
+
+// gzip member header at p (RFC 1952); returns its length, 0 if p does not hold one, -1 if the file ends inside it
+inline long member_header(const uint8_t *p, const uint8_t *end)
+{
+    if (end - p < 10) return (end - p >= 2 && p[0] == 0x1f && p[1] == 0x8b) || end - p < 2 ? -1 : 0;
+    if (p[0] != 0x1f || p[1] != 0x8b) return 0;
+    if (p[2] != 8 || (p[3] & 0xE0)) return 0;
+    const int flg = p[3];
+    const uint8_t *q = p + 10;
+    if (flg & 4) { if (end - q < 2) return -1; const size_t xl = q[0] | (q[1] << 8); q += 2; if ((size_t)(end - q) < xl) return -1; q += xl; }
+    if (flg & 8) { while (q < end && *q) q++; if (q >= end) return -1; q++; }
+    if (flg & 16) { while (q < end && *q) q++; if (q >= end) return -1; q++; }
+    if (flg & 2) { if (end - q < 2) return -1; q += 2; }
+    return (long)(q - p);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// what a decoded chunk consists of
+// ------------------------------------------------------------------------------------------------------------------
+struct MemberEnd { uint64_t out_pos; uint32_t crc, isize; };      // a member ended after out_pos bytes of this chunk's output
+
+struct SymBuf {                                                    // 16-bit symbols; grows without touching what it has not written
+    uint16_t *p = nullptr; size_t n = 0, cap = 0;
+    ~SymBuf() { free(p); }
+    SymBuf() {}
+    SymBuf(const SymBuf &) = delete;
+    SymBuf &operator=(const SymBuf &) = delete;
+    void reserve(size_t c, size_t keep = 0) { if (c <= cap) return; uint16_t *q = (uint16_t *)malloc(c * 2); if (keep) memcpy(q, p, keep * 2); free(p); p = q; cap = c; }
+    uint16_t *data() { return p; }
+    size_t size() const { return n; }
+    void drop() { free(p); p = nullptr; n = cap = 0; }
+    void swap(SymBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
+};
+
+struct Chunk {
+    uint64_t nominal_bit = 0;                                       // where the search for its first block started
+    uint64_t start_bit = 0, end_bit = 0;                            // first block decoded / first bit behind the last one
+    bool found = false;                                             // a start was found and decoded to the chunk's end
+    bool starts_member = false;                                     // start_bit is the first deflate bit of a gzip member (window empty: no markers)
+    bool at_eof = false;                                            // the data ended with this chunk (last member complete)
+    bool bad = false; std::string msg;                              // damage met while decoding from a KNOWN position
+    SymBuf sym;                                                     // speculative output (markers)
+    std::vector<uint8_t> bytes;                                     // final output
+    std::vector<MemberEnd> ends;
+    std::vector<uint32_t> seg_crc;                                  // crc of bytes between member ends (ends.size() + 1 segments)
+    bool have_bytes = false, skipped = false;                      // skipped: the chunk in front of it covered it entirely
+    // scheduling
+    int state = 0;                                                  // 0 queued, 1 decoded, 2 resolved
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// speculative decoding of one chunk
+// ------------------------------------------------------------------------------------------------------------------
+struct Spec {
+    const uint8_t *base, *end;                                      // the whole file
+    uint64_t data_end_bit;
+    LitHuff lit; DistHuff dist;
+
+    // Decodes blocks from `bit` until a block starts at or behind stop_bit (or the data ends).  out: 16-bit symbols.  mstart: index in
+    // out where the current member began (-1: it began in front of the chunk: the window is unknown).  Returns false on anything
+    // that cannot be deflate data (or that a text file would not hold, while the window is unknown).
+    bool run(uint64_t bit, uint64_t stop_bit, bool member_start, Chunk &c)
+    {
+        SymBuf &out = c.sym;
+        c.ends.clear();
+        size_t cap = out.cap < (1u << 20) ? (1u << 20) : out.cap;
+        out.reserve(cap);
+        uint16_t *o = out.data();
+        size_t pos = 0;
+        long mstart = member_start ? 0 : -1;
+        Bits br;
+        br.init(base, end, bit);
+        if (br.cnt < 0) return false;
+        uint32_t crc_dummy = 0; (void)crc_dummy;
+        for (;;) {
+            const uint64_t here = br.bitpos();
+            if (here >= stop_bit && pos > 0) { c.end_bit = here; break; }
+            if (!br.need(3)) return false;
+            const int bfinal = (int)br.peek(1), btype = (int)(br.peek(3) >> 1);
+            br.drop(3);
+            if (btype == 3) return false;
+            if (btype == 0) {
+                br.align_byte();
+                if (!br.need(32)) return false;
+                const uint32_t len = br.peek(16); br.drop(16);
+                const uint32_t nlen = br.peek(16); br.drop(16);
+                if ((len ^ 0xFFFFu) != nlen) return false;
+                // the bytes follow byte-aligned: take them from memory
+                const uint8_t *src = base + (br.bitpos() >> 3);
+                if ((uint64_t)(end - src) < len) return false;
+                if (pos + len + 300 > cap) { cap = std::max(cap * 2, pos + len + 65536); out.reserve(cap, pos); o = out.data(); }
+                for (uint32_t i = 0; i < len; i++) o[pos + i] = src[i];
+                pos += len;
+                br.init(base, end, (uint64_t)(src + len - base) * 8);
+            } else {
+                if (btype == 1) fixed_tables(lit, dist);
+                else if (!read_dynamic(br, lit, dist, false)) return false;
+                for (;;) {
+                    if (pos + 300 > cap) { cap *= 2; out.reserve(cap, pos); o = out.data(); }
+                    int sym = lit.decode(br);
+                    if (sym < 0) return false;
+                    if (sym < 256) {
+                        if (mstart < 0 && (sym >= 0x80 || (sym < 0x20 && sym != '\n' && sym != '\r' && sym != '\t'))) return false;   // not text: left to the sequential path
+                        o[pos++] = (uint16_t)sym;
+                        continue;
+                    }
+                    if (sym == 256) break;
+                    sym -= 257;
+                    if (sym >= 29) return false;
+                    int len = kLenBase[sym];
+                    const int le = kLenExtra[sym];
+                    if (le) { if (!br.need(le)) return false; len += (int)br.peek(le); br.drop(le); }
+                    const int ds = dist.decode(br);
+                    if (ds < 0 || ds >= 30) return false;
+                    long d = kDistBase[ds];
+                    const int de = kDistExtra[ds];
+                    if (de) { if (!br.need(de)) return false; d += (long)br.peek(de); br.drop(de); }
+                    long src = (long)pos - d;
+                    if (mstart >= 0) { if (src < mstart) return false; }
+                    else if (src < -32768) return false;
+                    if (src >= 0) {
+                        if (d >= len) memcpy(o + pos, o + src, (size_t)len * 2);
+                        else for (int i = 0; i < len; i++) o[pos + i] = o[src + i];
+                        pos += (size_t)len;
+                    } else {
+                        for (int i = 0; i < len; i++, src++) o[pos++] = src < 0 ? (uint16_t)(256 + 32768 + src) : o[src];
+                    }
+                }
+            }
+            if (bfinal) {
+                // end of a member: trailer, then either the end of the data or the next member
+                br.align_byte();
+                const uint8_t *t = base + (br.bitpos() >> 3);
+                if (end - t < 8) return false;
+                MemberEnd me; me.out_pos = pos;
+                me.crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+                me.isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+                c.ends.push_back(me);
+                t += 8;
+                while (t < end && *t == 0) t++;                          // (zero padding between / behind members)
+                const long h = t < end ? member_header(t, end) : 0;
+                if (t >= end || h == 0) { c.end_bit = (uint64_t)(end - base) * 8; c.at_eof = true; break; }      // end of the data (bytes that are no member are ignored, as zlib does)
+                if (h < 0) return false;
+                br.init(base, end, (uint64_t)(t + h - base) * 8);
+                mstart = (long)pos;
+            }
+        }
+        out.n = pos;
+        return true;
+    }
+
+    // A bit position at or behind `from` (and in front of `limit`) where a block may start, verified by decoding the chunk from it.
+    bool find_and_decode(uint64_t from, uint64_t limit, uint64_t stop_bit, Chunk &c)
+    {
+        const uint64_t last = std::min<uint64_t>(limit, data_end_bit > 192 ? data_end_bit - 192 : 0);
+        for (uint64_t bit = from; bit < last; bit++) {
+            const uint8_t *p = base + (bit >> 3);
+            if ((bit & 7) == 0 && p[0] == 0x1f && p[1] == 0x8b && p[2] == 8 && !(p[3] & 0xE0)) {     // a gzip member header (bgzip, pigz -i, concatenated files)
+                const long h = member_header(p, end);
+                if (h > 0 && run((uint64_t)(p + h - base) * 8, stop_bit, true, c)) { c.start_bit = (uint64_t)(p + h - base) * 8; c.starts_member = true; return true; }
+            }
+            uint64_t lo, hi;
+            memcpy(&lo, p, 8); memcpy(&hi, p + 8, 8);
+            const int sh = (int)(bit & 7);
+            const uint64_t w = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;      // 64 bits of the stream from `bit`
+            if ((w & 6u) != 4u) continue;                                    // BTYPE = 2 (a member's last block - BFINAL = 1 - starts many chunks of a bgzip file)
+            {   // the cheap tests of read_dynamic first: counts in range, code-length code complete (most positions end here)
+                if (((w >> 3) & 31u) > 29u || ((w >> 8) & 31u) > 29u) continue;
+                const int hclen = (int)((w >> 13) & 15u) + 4;
+                const uint64_t w2 = sh ? (hi >> sh) : hi;                    // bits 64 .. of the stream (at least 56 of them)
+                int kraft = 0, used = 0;
+                for (int i = 0; i < hclen; i++) {
+                    const int at = 17 + 3 * i;
+                    const uint32_t l = at + 3 <= 64 ? (uint32_t)(w >> at) & 7u : at >= 64 ? (uint32_t)(w2 >> (at - 64)) & 7u : (uint32_t)((w >> at) | (w2 << (64 - at))) & 7u;
+                    if (l) { kraft += 128 >> l; used++; }
+                }
+                if (kraft != 128 || used < 2) continue;
+            }
+            Bits br;
+            br.init(base, end, bit + 3);
+            if (!read_dynamic(br, lit, dist, true)) continue;
+            if (run(bit, stop_bit, false, c)) { c.start_bit = bit; c.starts_member = false; return true; }
+        }
+        return false;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// sequential decoding from a known position with a known window (zlib): chunk 0 and repairs
+// ------------------------------------------------------------------------------------------------------------------
+// Decodes from `bit` (inside a member whose last 32 KB are `window`, window_n bytes; or at the first deflate bit of a member when
+// member_start) until a block boundary at or behind stop_bit, the end of the data, or damage.  Fills c.bytes / c.ends / c.end_bit.
+inline void decode_known(const uint8_t *base, const uint8_t *end, uint64_t bit, uint64_t stop_bit, const uint8_t *window, size_t window_n, Chunk &c)
+{
+    c.bytes.clear(); c.ends.clear(); c.bad = false; c.at_eof = false;
+    std::vector<uint8_t> &out = c.bytes;
+    size_t cap = std::max<size_t>(out.capacity(), 1u << 20);
+    out.resize(cap);
+    size_t pos = 0;
+    for (;;) {                                                       // one member (or the rest of one) per turn
+        z_stream z;
+        memset(&z, 0, sizeof z);
+        if (inflateInit2(&z, -15) != Z_OK) { c.bad = true; c.msg = "inflateInit2 failed"; break; }
+        const uint8_t *p = base + (bit >> 3);
+        const int skip = (int)(bit & 7);
+        if (skip) { inflatePrime(&z, 8 - skip, *p >> skip); p++; }
+        if (window_n) inflateSetDictionary(&z, window, (uInt)window_n);
+        z.next_in = (Bytef *)p;
+        const uint8_t *in0 = p;
+        bool member_done = false, stop = false;
+        for (;;) {
+            if (cap - pos < (1u << 16)) { cap *= 2; out.resize(cap); }
+            z.avail_in = (uInt)std::min<size_t>((size_t)(end - z.next_in), 1u << 30);
+            z.next_out = out.data() + pos;
+            z.avail_out = (uInt)std::min<size_t>(cap - pos, 1u << 30);
+            const int rc = inflate(&z, Z_BLOCK);
+            pos = (size_t)(z.next_out - out.data());
+            if (rc == Z_STREAM_END) { member_done = true; break; }
+            if (rc != Z_OK && rc != Z_BUF_ERROR) { c.bad = true; c.msg = z.msg ? z.msg : "invalid deflate data"; break; }
+            if (rc == Z_BUF_ERROR && z.avail_in == 0 && z.next_in >= end && z.avail_out) { c.bad = true; c.msg = "compressed file ended before the end-of-stream marker was reached"; break; }
+            if ((z.data_type & 128) && !(z.data_type & 64)) {        // at a block boundary (not the end of the last block)
+                const uint64_t here = ((uint64_t)(z.next_in - base) * 8) - (uint64_t)(z.data_type & 63);
+                if (here >= stop_bit && pos > 0) { c.end_bit = here; stop = true; break; }
+            }
+        }
+        const uint8_t *t = z.next_in;                                // (after Z_STREAM_END: the byte behind the last deflate byte)
+        (void)in0;
+        inflateEnd(&z);
+        if (c.bad || stop) break;
+        if (member_done) {
+            if (end - t < 8) { c.bad = true; c.msg = "compressed file ended before the end-of-stream marker was reached"; break; }
+            MemberEnd me; me.out_pos = pos;
+            me.crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+            me.isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+            c.ends.push_back(me);
+            t += 8;
+            while (t < end && *t == 0) t++;
+            const long h = t < end ? member_header(t, end) : 0;
+            if (t >= end || h == 0) { c.end_bit = (uint64_t)(end - base) * 8; c.at_eof = true; break; }
+            if (h < 0) { c.bad = true; c.msg = "compressed file ended before the end-of-stream marker was reached"; break; }
+            bit = (uint64_t)(t + h - base) * 8;
+            window_n = 0;
+            if (bit >= stop_bit) { c.end_bit = bit; c.starts_member = false; break; }   // the next chunk starts with this member (its worker found the same header)
+        }
+    }
+    out.resize(pos);
+    c.have_bytes = true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the reader: read() delivers the decompressed bytes in order
+// ------------------------------------------------------------------------------------------------------------------
+class ParallelGz {
+public:
+    // data: the mapped file [data, data + n); threads >= 2
+    ParallelGz(const uint8_t *data, size_t n, int threads, size_t chunk_bytes = (size_t)1 << 20)
+        : base_(data), end_(data + n), nthreads_(threads), chunk_bytes_(chunk_bytes) {}
+    ~ParallelGz() { stop(); if (getenv("MC_PGZ_DEBUG")) fprintf(stderr, "pgzip: %zu chunks: %zu speculative, %zu sequential (%zu of them had found no start), %zu skipped\n", chunks_.size(), n_spec_, n_seq_, n_notfound_, n_skip_); }
+
+    // false: not a gzip file this reader handles (the caller falls back to gzread)
+    bool start()
+    {
+        const long h = member_header(base_, end_);
+        if (h <= 0) return false;
+        first_bit_ = (uint64_t)h * 8;
+        const uint64_t data_bits = (uint64_t)(end_ - base_) * 8;
+        // chunk k looks for its start from bit first_bit_ + k * chunk_bytes_ * 8
+        for (uint64_t b = first_bit_; b < data_bits; b += (uint64_t)chunk_bytes_ * 8) {
+            std::unique_ptr<Chunk> c(new Chunk());
+            c->nominal_bit = b;
+            chunks_.push_back(std::move(c));
+        }
+        for (int i = 0; i < nthreads_; i++) workers_.emplace_back([this] { work(); });
+        return true;
+    }
+
+    // like a file read: < n only at the end of the data; bad: the file is truncated / damaged behind what was delivered
+    int read(uint8_t *dst, int n, bool *bad, std::string *msg)
+    {
+        int got = 0;
+        *bad = false;
+        while (got < n) {
+            if (cur_ && cur_off_ < cur_->bytes.size()) {
+                const size_t k = std::min<size_t>((size_t)(n - got), cur_->bytes.size() - cur_off_);
+                memcpy(dst + got, cur_->bytes.data() + cur_off_, k);
+                cur_off_ += k; got += (int)k;
+                continue;
+            }
+            if (cur_) { if (cur_failed_) { *bad = true; *msg = err_; return got; } release(cur_index_); cur_ = nullptr; }
+            if (finished_) { if (failed_) { *bad = true; *msg = err_; } return got; }
+            if (!next_chunk()) { if (failed_ && !cur_) { *bad = true; *msg = err_; return got; } }
+        }
+        return got;
+    }
+
+private:
+    const uint8_t *base_, *end_;
+    int nthreads_;
+    size_t chunk_bytes_;
+    uint64_t first_bit_ = 0;
+    std::vector<std::unique_ptr<Chunk>> chunks_;
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_work_, cv_done_;
+    bool quit_ = false;
+    size_t next_decode_ = 1;                                        // next chunk a worker decodes speculatively (chunk 0 is decoded from its known start)
+    size_t limit_decode_ = 0;                                       // ... but none at or behind this one (bounds the memory in flight)
+    std::deque<std::function<void()>> jobs_;                        // resolve jobs (they go first)
+    // consumer state
+    size_t cur_index_ = 0; Chunk *cur_ = nullptr; size_t cur_off_ = 0; bool cur_failed_ = false;
+    size_t stitch_next_ = 0, consume_next_ = 0;                     // next chunk to stitch / to hand to the consumer
+    size_t n_spec_ = 0, n_seq_ = 0, n_notfound_ = 0, n_skip_ = 0;
+    // Buffers of finished chunks are kept and handed to the next ones: a fresh 10 MB buffer is 2,500 page faults, and a dozen threads
+    // faulting at once queue up in the kernel (the first 65 MB of a file took 0.85 s instead of 0.13 s).
+    std::vector<std::unique_ptr<SymBuf>> pool_sym_;
+    std::vector<std::vector<uint8_t>> pool_bytes_;
+    bool stitch_stop_ = false;                                      // the data ends (or is damaged) in the last stitched chunk
+    uint64_t stitched_end_bit_ = 0;
+    bool at_member_start_ = true;                                   // the stitched position is the first deflate bit of a member
+    std::vector<uint8_t> window_;                                   // last <= 32 KB of the current member in front of the stitched position
+    uint32_t run_crc_ = 0; uint64_t run_len_ = 0;                   // CRC / length of the current member so far
+    bool finished_ = false, failed_ = false; std::string err_;
+
+    void stop()
+    {
+        { std::unique_lock<std::mutex> lk(mu_); quit_ = true; cv_work_.notify_all(); }
+        for (auto &t : workers_) t.join();
+        workers_.clear();
+    }
+
+    void work()
+    {
+        Spec sp; sp.base = base_; sp.end = end_; sp.data_end_bit = (uint64_t)(end_ - base_) * 8;
+        for (;;) {
+            std::function<void()> job;
+            size_t k = 0;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_work_.wait(lk, [&] { return quit_ || !jobs_.empty() || (next_decode_ < chunks_.size() && next_decode_ < limit_decode_); });
+                if (quit_) return;
+                if (!jobs_.empty()) { job = std::move(jobs_.front()); jobs_.pop_front(); }
+                else k = next_decode_++;
+            }
+            if (job) { job(); continue; }
+            Chunk &c = *chunks_[k];
+            take_buffers(c, true);
+            const uint64_t stop_bit = k + 1 < chunks_.size() ? chunks_[k + 1]->nominal_bit : sp.data_end_bit;
+            c.found = sp.find_and_decode(c.nominal_bit, stop_bit, stop_bit, c);
+            if (!c.found) recycle_sym(c);
+            { std::unique_lock<std::mutex> lk(mu_); c.state = 1; cv_done_.notify_all(); }
+        }
+    }
+
+    void release(size_t k)
+    {
+        Chunk &c = *chunks_[k];
+        recycle_sym(c);
+        if (c.bytes.capacity()) {
+            c.bytes.clear();
+            std::unique_lock<std::mutex> lk(mu_);
+            if (pool_bytes_.size() < 4 * (size_t)nthreads_) { pool_bytes_.emplace_back(); pool_bytes_.back().swap(c.bytes); }
+        }
+        std::vector<uint8_t>().swap(c.bytes);
+    }
+    void recycle_sym(Chunk &c)
+    {
+        if (!c.sym.cap) return;
+        std::unique_lock<std::mutex> lk(mu_);
+        if (pool_sym_.size() < 4 * (size_t)nthreads_) { pool_sym_.emplace_back(new SymBuf()); pool_sym_.back()->swap(c.sym); c.sym.n = 0; return; }
+        lk.unlock();
+        c.sym.drop();
+    }
+    void take_buffers(Chunk &c, bool sym)
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        if (sym && !c.sym.cap && !pool_sym_.empty()) { c.sym.swap(*pool_sym_.back()); pool_sym_.pop_back(); c.sym.n = 0; }
+        if (!c.bytes.capacity() && !pool_bytes_.empty()) { c.bytes.swap(pool_bytes_.back()); pool_bytes_.pop_back(); c.bytes.clear(); }
+    }
+
+    void fail(const std::string &m) { failed_ = true; finished_ = true; err_ = m; }
+
+    // accounts the bytes of a finished chunk to the running member CRC; false on a CRC / length mismatch
+    bool account(Chunk &c)
+    {
+        size_t at = 0;
+        for (size_t s = 0; s <= c.ends.size(); s++) {
+            const size_t to = s < c.ends.size() ? (size_t)c.ends[s].out_pos : c.bytes.size();
+            const size_t n = to - at;
+            if (n) {
+                const uint32_t sc = s < c.seg_crc.size() ? c.seg_crc[s] : (uint32_t)crc32(0, c.bytes.data() + at, (uInt)n);
+                run_crc_ = run_len_ ? (uint32_t)crc32_combine(run_crc_, sc, (z_off_t)n) : sc;
+                run_len_ += n;
+            }
+            if (s < c.ends.size()) {
+                if (run_crc_ != c.ends[s].crc || (uint32_t)run_len_ != c.ends[s].isize) return false;
+                run_crc_ = 0; run_len_ = 0;
+            }
+            at = to;
+        }
+        return true;
+    }
+
+    static void seg_crcs(Chunk &c)
+    {
+        c.seg_crc.clear();
+        size_t at = 0;
+        for (size_t s = 0; s <= c.ends.size(); s++) {
+            const size_t to = s < c.ends.size() ? (size_t)c.ends[s].out_pos : c.bytes.size();
+            uint32_t v = 0;
+            for (size_t o = at; o < to; o += (size_t)1 << 30) v = (uint32_t)crc32(v, c.bytes.data() + o, (uInt)std::min<size_t>(to - o, (size_t)1 << 30));
+            c.seg_crc.push_back(v);
+            at = to;
+        }
+    }
+
+    void update_window(const Chunk &c)
+    {   // the last 32 KB of the current member behind this chunk
+        size_t from = 0;
+        bool fresh = false;
+        if (!c.ends.empty()) { from = (size_t)c.ends.back().out_pos; fresh = true; }
+        const size_t n = c.bytes.size() - from;
+        if (fresh) window_.clear();
+        if (n >= 32768) window_.assign(c.bytes.end() - 32768, c.bytes.end());
+        else {
+            window_.insert(window_.end(), c.bytes.begin() + (long)from, c.bytes.end());
+            if (window_.size() > 32768) window_.erase(window_.begin(), window_.end() - 32768);
+        }
+    }
+
+    // markers -> bytes for symbols [from, to) of a chunk whose window is w (wn bytes); false: a marker reaches in front of the member
+    static bool resolve(const uint16_t *s, uint8_t *o, size_t from, size_t to, const uint8_t *w, size_t wn)
+    {
+        size_t i = from;
+#if defined(__SSE2__)
+        const __m128i hi = _mm_set1_epi16((short)0xFF00);
+        while (i + 16 <= to) {                                       // 16 symbols at a time while none of them is a marker
+            const __m128i a = _mm_loadu_si128((const __m128i *)(s + i)), b = _mm_loadu_si128((const __m128i *)(s + i + 8));
+            if (_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_and_si128(_mm_or_si128(a, b), hi), _mm_setzero_si128())) != 0xFFFF) {
+                for (size_t e = i + 16; i < e; i++) {
+                    const uint16_t v = s[i];
+                    if (v < 256) o[i] = (uint8_t)v;
+                    else { const size_t j = (size_t)v - 256; if (j + wn < 32768) return false; o[i] = w[j + wn - 32768]; }
+                }
+                continue;
+            }
+            _mm_storeu_si128((__m128i *)(o + i), _mm_packus_epi16(a, b));
+            i += 16;
+        }
+#endif
+        for (; i < to; i++) {
+            const uint16_t v = s[i];
+            if (v < 256) o[i] = (uint8_t)v;
+            else { const size_t j = (size_t)v - 256; if (j + wn < 32768) return false; o[i] = w[j + wn - 32768]; }
+        }
+        return true;
+    }
+
+    // Stitches the decoded chunks in file order as far as they are ready (at most `ahead` chunks in front of the consumer): checks
+    // that a chunk starts where the one before it ended, hands its marker replacement + CRC to the workers, and keeps the 32 KB
+    // window going; a chunk that does not fit is decoded here, sequentially.  wait_for: the chunk the consumer needs now.
+    void stitch(size_t wait_for)
+    {
+        const uint64_t data_bits = (uint64_t)(end_ - base_) * 8;
+        while (stitch_next_ < chunks_.size() && stitch_next_ <= wait_for + (size_t)nthreads_ && !stitch_stop_) {
+            const size_t k = stitch_next_;
+            Chunk &c = *chunks_[k];
+            const uint64_t from = k == 0 ? first_bit_ : stitched_end_bit_;
+            const uint64_t stop_bit = k + 1 < chunks_.size() ? chunks_[k + 1]->nominal_bit : data_bits;
+            if (k > 0) {
+                std::unique_lock<std::mutex> lk(mu_);
+                if (c.state < 1) { if (k > wait_for) return; cv_done_.wait(lk, [&] { return c.state >= 1; }); }
+            }
+            if (from >= stop_bit && k + 1 < chunks_.size()) {           // the chunk in front ran over this one entirely
+                release(k); n_skip_++;
+                c.bytes.clear(); c.ends.clear(); c.bad = false; c.at_eof = false; c.skipped = true;
+                { std::unique_lock<std::mutex> lk(mu_); c.state = 2; }
+                stitch_next_++;
+                continue;
+            }
+            bool usable = k > 0 && c.found && c.start_bit == from && !(c.starts_member && !at_member_start_);
+            if (getenv("MC_PGZ_DEBUG2")) fprintf(stderr, "chunk %zu nominal %llu from %llu found %d start %llu member %d at_member_start %d\n", k, (unsigned long long)c.nominal_bit, (unsigned long long)from, (int)c.found, (unsigned long long)c.start_bit, (int)c.starts_member, (int)at_member_start_);
+            if (usable) {
+                // the window behind this chunk needs its last 32 KB only: replaced here; the rest (and the CRC) is a job
+                const size_t n = c.sym.size();
+                std::shared_ptr<std::vector<uint8_t>> w(new std::vector<uint8_t>(c.starts_member ? std::vector<uint8_t>() : window_));
+                c.bytes.resize(n);
+                const size_t tail = n > 32768 ? n - 32768 : 0;
+                size_t mfrom = c.ends.empty() ? 0 : (size_t)c.ends.back().out_pos;      // the current member's part of the chunk
+                if (!resolve(c.sym.data(), c.bytes.data(), std::max(tail, mfrom), n, w->data(), w->size())) usable = false;
+                else {
+                    std::vector<uint8_t> nw;
+                    if (!c.ends.empty()) window_.clear();
+                    if (n - mfrom >= 32768) nw.assign(c.bytes.begin() + (long)(n - 32768), c.bytes.end());
+                    else { nw = window_; nw.insert(nw.end(), c.bytes.begin() + (long)mfrom, c.bytes.end()); if (nw.size() > 32768) nw.erase(nw.begin(), nw.end() - 32768); }
+                    window_.swap(nw);
+                    Chunk *cp = &c;
+                    std::unique_lock<std::mutex> lk(mu_);
+                    jobs_.push_back([this, cp, w] {
+                        const bool ok = resolve(cp->sym.data(), cp->bytes.data(), 0, cp->sym.size(), w->data(), w->size());
+                        recycle_sym(*cp);
+                        if (!ok) { cp->bad = true; cp->msg = "invalid distance too far back"; cp->bytes.clear(); cp->ends.clear(); }
+                        seg_crcs(*cp);
+                        std::unique_lock<std::mutex> lk2(mu_);
+                        cp->state = 2;
+                        cv_done_.notify_all();
+                    });
+                    cv_work_.notify_all();
+                }
+            }
+            if (usable) n_spec_++; else { n_seq_++; if (k > 0 && !c.found) n_notfound_++; }
+            if (!usable) {                                               // the sequential path: from the known position with the known window
+                recycle_sym(c);
+                if (k == 0) take_buffers(c, false);
+                c.ends.clear(); c.at_eof = false;
+                decode_known(base_, end_, from, stop_bit, at_member_start_ ? nullptr : window_.data(), at_member_start_ ? 0 : window_.size(), c);
+                seg_crcs(c);
+                update_window(c);
+                std::unique_lock<std::mutex> lk(mu_);
+                c.state = 2;
+            }
+            stitched_end_bit_ = c.end_bit;
+            at_member_start_ = !c.ends.empty() && (size_t)c.ends.back().out_pos == (usable ? c.bytes.size() : c.bytes.size());
+            stitch_next_ = k + 1;
+            if (c.bad || c.at_eof || c.end_bit >= data_bits) stitch_stop_ = true;   // nothing behind this chunk
+        }
+    }
+
+    // makes the next chunk's bytes available as cur_; false when the stream has ended
+    bool next_chunk()
+    {
+        const size_t k = consume_next_;
+        if (k >= chunks_.size() || (stitch_stop_ && k >= stitch_next_)) { finished_ = true; return false; }
+        {   // let the workers run ahead of the consumer (bounded)
+            std::unique_lock<std::mutex> lk(mu_);
+            limit_decode_ = std::max(limit_decode_, k + 1 + (size_t)nthreads_ * 2);
+            cv_work_.notify_all();
+        }
+        stitch(k);
+        Chunk &c = *chunks_[k];
+        { std::unique_lock<std::mutex> lk(mu_); cv_done_.wait(lk, [&] { return c.state >= 2; }); }
+        consume_next_ = k + 1;
+        if (c.skipped) return true;
+        const uint64_t data_bits = (uint64_t)(end_ - base_) * 8;
+        if (!account(c)) { c.bytes.clear(); fail("CRC check failed"); return false; }
+        cur_ = &c; cur_index_ = k; cur_off_ = 0; cur_failed_ = false;
+        if (c.bad) { cur_failed_ = true; failed_ = true; finished_ = true; err_ = c.msg; }
+        else if (c.at_eof) finished_ = true;
+        else if (c.end_bit >= data_bits) { cur_failed_ = true; failed_ = true; finished_ = true; err_ = "compressed file ended before the end-of-stream marker was reached"; }
+        return true;
+    }
+};
+
+}   // namespace mcgz

@@ -57,6 +57,7 @@
 #include <zlib.h>
 
 #include "../../include/mcensus.h"
+#include "mc_pgzip.h"
 
 namespace {
 
@@ -202,12 +203,15 @@ struct Bz2File {
     bool first_block_of_stream() const { return z.total_out_lo32 == 0 && z.total_out_hi32 == 0; }
 };
 
+int reader_threads();
+
 struct Stream {
     enum { NBLK = 16, BLK = 1 << 22 };
     // plain file: one mapping; the window is a slice of it
     const uint8_t *map = nullptr; size_t map_n = 0;
     // compressed stream: a producer thread inflates BLK-sized blocks into a ring; the window lives in `buf`
     gzFile gz = nullptr; Bz2File *bz = nullptr;
+    mcgz::ParallelGz *pgz = nullptr; const uint8_t *gzmap = nullptr; size_t gzmap_n = 0;   // a regular .gz file: mapped and inflated in parallel (mc_pgzip.h)
     std::thread th;
     std::mutex mu; std::condition_variable cv;
     std::vector<uint8_t> ring[NBLK]; size_t ring_n[NBLK] = {};
@@ -241,7 +245,26 @@ struct Stream {
             const bool is_gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
             // the codec follows the file NAME, as open_file does (reference :47-59): a *.gz that is not gzip is gzip.open's BadGzipFile
             if (has_ext(path, ".gz") && reg && got > 0 && !is_gz) { ::close(fd); r_err = std::string("BadGzipFile: Not a gzipped file (") + path + ")"; bad_gzip = true; return false; }
-            if (has_ext(path, ".gz") || !reg) {                          // (anything that is not a regular file - a pipe - is read through zlib, which passes plain bytes on)
+            const int gzt = reader_threads();
+            if (has_ext(path, ".gz") && reg && is_gz && gzt >= 2 && !getenv("MC_READER_SERIAL_GZ")) {
+                // several inflate workers beside the parser (one inflate stream tops out at ~0.5 GB/s of text); with one thread allowed, zlib's own reader below
+                gzmap_n = (size_t)sb.st_size;
+                void *m = mmap(nullptr, gzmap_n, PROT_READ, MAP_PRIVATE, fd, 0);
+                ::close(fd);
+                if (m == MAP_FAILED) { r_err = std::string("cannot map ") + path; return false; }
+                madvise(m, gzmap_n, MADV_SEQUENTIAL);
+                gzmap = (const uint8_t *)m;
+                size_t chunk = (size_t)1 << 20;                          // compressed bytes per speculative chunk
+                if (const char *v = getenv("MC_READER_GZ_CHUNK")) chunk = std::max<size_t>(4096, (size_t)atoll(v));   // (tests: many chunks on small files)
+                pgz = new mcgz::ParallelGz(gzmap, gzmap_n, std::min(gzt, 32), chunk);
+                if (!pgz->start()) {                                     // (a header it does not take - cut short, odd fields: zlib's reader decides)
+                    delete pgz; pgz = nullptr; munmap(m, gzmap_n); gzmap = nullptr;
+                    gz = gzopen(path, "rb");
+                    if (!gz) { r_err = std::string("cannot open ") + path; return false; }
+                    gzbuffer(gz, 1 << 20);
+                }
+                compressed = true;
+            } else if (has_ext(path, ".gz") || !reg) {                   // (anything that is not a regular file - a pipe - is read through zlib, which passes plain bytes on)
                 gz = gzdopen(fd, "rb");
                 if (!gz) { ::close(fd); r_err = std::string("cannot open ") + path; return false; }
                 gzbuffer(gz, 1 << 20);
@@ -271,6 +294,8 @@ struct Stream {
             { std::unique_lock<std::mutex> lk(mu); stop = true; cv.notify_all(); }
             th.join();
         }
+        if (pgz) { delete pgz; pgz = nullptr; }
+        if (gzmap) { munmap((void *)gzmap, gzmap_n); gzmap = nullptr; }
         if (gz) { gzclose(gz); gz = nullptr; }
         if (bz) { bz->close(); delete bz; bz = nullptr; }
         if (map) { munmap((void *)map, map_n); map = nullptr; }
@@ -288,7 +313,9 @@ struct Stream {
             int n;
             bool bad = false;
             std::string msg;
-            if (gz) {
+            if (pgz) {
+                n = pgz->read(ring[slot].data(), (int)BLK, &bad, &msg);
+            } else if (gz) {
                 n = gzread(gz, ring[slot].data(), (unsigned)BLK);
                 if (n < (int)BLK) {
                     // gzip.open raises EOFError / BadGzipFile on a truncated or corrupt stream (reference :47-59); zlib reports a
