@@ -72,48 +72,116 @@ STAGE_KERNELS = {   # kernels whose HIP-event time a stage of mc_stats spans (pr
 }
 
 
-def profiled_traffic(stage, n_batch):
-    """HBM-side bytes per launch of the kernels of `stage` from the newest committed rocprofv3 PMC summary
-    (profiles/rNN_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in their own --pmc passes; read bytes = 2 x FETCH_SIZE on
-    gfx950, see profiles/README.md), scaled from the profiled batch to this run's batch.  None if no profile is committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic.json")))
-    if not files:
-        return None
-    try:
-        tr = json.load(open(files[-1]))
-        line = json.load(open(files[-1].replace("_hbm_traffic.json", "_bench_line.json")))
-        per = float(line["config"]["batch"])
-        total, found = 0.0, False
-        for k, t in tr.items():
-            if (k.startswith("k_enumerate") and k.rstrip().endswith("true>")) or t.get("write_kib_per_launch") is None:      # (the counting form of the seed kernel is not the timed one)
-                continue
-            if any(k == p or k.startswith(p + "<") or (p.endswith("<") and k.startswith(p)) for p in STAGE_KERNELS.get(stage, [stage])):
-                total += (2.0 * t["fetch_kib_per_launch"] + t["write_kib_per_launch"]) * 1024.0
-                found = True
-        return total / per * n_batch if found else None
-    except Exception:
-        return None
+FETCH_FACTOR_STREAM = 2.0   # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads
+GATHER_KERNELS = ("k_enumerate_t0<", "k_eval_seeds")   # kernels whose global reads are scattered 4..32-byte items
 
 
-def profiled_l2_hit_rate(stage):
-    """TCC_HIT / (TCC_HIT + TCC_MISS) of the stage's kernels in the newest committed PMC summary (profiles/rNN_pmc_per_launch.csv)."""
+def load_profile(L):
+    """The newest committed rocprofv3 summary taken AT THIS READ LENGTH (profiles/rNN_L<L>_*; tools/profile_round.sh): per-kernel
+    durations (kernel-trace pass) and PMC counters per launch (their own --pmc passes).  None when no profile of this length is
+    committed - a profile of another length is never scaled."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_per_launch.csv")))
-    if not files:
+    stats = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_L%d_kernel_stats.csv" % L)))
+    if not stats:
         return None
+    base = stats[-1][: -len("_kernel_stats.csv")]
+    prof = {"files": os.path.basename(base) + "_{kernel_stats.csv,pmc_per_launch.csv,hbm_traffic.json,bench_line.json}", "kernels": {}, "reads_per_launch": None}
     try:
-        hit = miss = 0.0
-        for r in csv.DictReader(open(files[-1])):
-            k = r["Kernel"]
-            if (k.startswith("k_enumerate") and k.rstrip().rstrip('"').endswith("true>")) or not r.get("TCC_HIT_sum"):
-                continue
-            if any(k == p or k.startswith(p + "<") or (p.endswith("<") and k.startswith(p)) for p in STAGE_KERNELS.get(stage, [stage])):
-                hit += float(r["TCC_HIT_sum"]); miss += float(r["TCC_MISS_sum"])
-        return round(hit / (hit + miss), 4) if hit + miss > 0 else None
-    except Exception:
+        prof["reads_per_launch"] = int(json.load(open(base + "_bench_line.json"))["config"]["batch"])
+        for r in csv.DictReader(open(base + "_kernel_stats.csv")):
+            prof["kernels"].setdefault(r["Name"], {})["avg_ns"] = float(r["AverageNs"])
+            prof["kernels"][r["Name"]]["calls"] = int(r["Calls"])
+        for r in csv.DictReader(open(base + "_pmc_per_launch.csv")):
+            d = prof["kernels"].setdefault(r["Kernel"], {})
+            for k, v in r.items():
+                if k not in ("Kernel", "Launches") and v not in ("", None):
+                    d[k] = float(v)
+        cal = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_fetch_calibration.json")))
+        prof["gather_factor"], prof["calibration"] = None, None
+        if cal:
+            c = json.load(open(cal[-1]))
+            g = c.get("k_gather<32>", {})
+            if g.get("FETCH_SIZE_over_requested"):
+                # bytes the fabric moved per byte FETCH_SIZE reports, for scattered 32-byte items: one 128-byte line per item
+                prof["gather_factor"] = c.get("gather_fetch_factor")
+                prof["calibration"] = os.path.basename(cal[-1])
+    except Exception as e:                                    # a damaged profile is no profile
+        sys.stderr.write("bench.py: profile %s unreadable: %s\n" % (base, e))
         return None
+    return prof
+
+
+def stage_counters(prof, stage):
+    """Sums the per-launch counters of the kernels of a stage (one launch of each per pass of the pipeline over the profiled batch;
+    kernels launched several times per pass - the four k_finish size classes - count with their number of calls per pass)."""
+    if prof is None:
+        return None
+    pref = STAGE_KERNELS.get(stage, [stage])
+    tot, names, per_pass = {}, [], None
+    for k, d in prof["kernels"].items():
+        if k.rstrip().endswith("true>") and k.startswith("k_enumerate"):       # (the counting form of the seed kernel is not the timed one)
+            continue
+        if not any(k == q or k.startswith(q + "<") or (q.endswith("<") and k.startswith(q)) for q in pref):
+            continue
+        names.append(k)
+        calls = d.get("calls", 0)
+        if per_pass is None and stage != "k_finish":
+            per_pass = calls
+        mult = 1.0
+        if k == "k_finish":
+            mult = 4.0                                          # one launch per size class
+        for c, v in d.items():
+            if c in ("calls",):
+                continue
+            tot[c] = tot.get(c, 0.0) + v * mult
+    if not names:
+        return None
+    tot["_kernels"] = sorted(names)
+    return tot
+
+
+def derived(prof, stage):
+    """Counter-derived figures of a stage at the profiled batch size (every one recomputes from the committed files):
+    issue_frac = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles) - a wave64 VALU instruction holds its SIMD for 4 cycles;
+    salu_frac = SQ_INSTS_SALU / (256 scalar units x kernel cycles) - one scalar issue per CU and cycle (the two run side by side, so
+    they are NOT added); kernel cycles = duration x 2.4 GHz (the peak clock: the fractions are lower bounds); wait_frac = SQ_WAIT_ANY /
+    SQ_WAVE_CYCLES; lanes = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64); hbm_bytes = factor x FETCH_SIZE + WRITE_SIZE (KiB as
+    rocprofv3 reports them; factor 2 for streaming reads, the gather calibration's upper bound for the two gather kernels), hbm_frac =
+    hbm_bytes / duration / 8 TB/s; l2_hit = TCC_HIT / (HIT + MISS)."""
+    c = stage_counters(prof, stage)
+    if not c or not c.get("avg_ns"):
+        return None
+    ns = c["avg_ns"]
+    cycles = ns * 2.4
+    out = {"kernels": c["_kernels"], "profiled_ms": round(ns / 1e6, 4), "reads_per_launch": prof["reads_per_launch"]}
+    if c.get("SQ_INSTS_VALU"):
+        out["issue_frac"] = round(c["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cycles), 4)
+        out["salu_frac"] = round(c.get("SQ_INSTS_SALU", 0.0) / (256.0 * cycles), 4)
+    if c.get("SQ_WAVE_CYCLES"):
+        out["wait_frac"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)
+    if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_THREAD_CYCLES_VALU"):
+        out["valu_lanes_of_64"] = round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"], 2)
+    if c.get("SQ_LDS_IDX_ACTIVE"):
+        out["lds_bank_conflict_frac"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
+    if c.get("FETCH_SIZE") is not None and c.get("WRITE_SIZE") is not None:
+        gather = any(k.startswith(GATHER_KERNELS) for k in c["_kernels"])
+        f = (prof.get("gather_factor") or FETCH_FACTOR_STREAM) if gather else FETCH_FACTOR_STREAM
+        hb = (f * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        out["fetch_factor"] = f
+        out["hbm_bytes_per_launch"] = round(hb, 0)
+        out["hbm_frac"] = round(hb / (ns * 1e-9) / (HBM_PEAK_GBS * 1e9), 5)
+        if gather:                                              # (a scattered request moves 64 or 128 bytes: lower bound with factor 1)
+            out["hbm_frac_lower"] = round((1.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / (ns * 1e-9) / (HBM_PEAK_GBS * 1e9), 5)
+    if c.get("TCC_HIT_sum") is not None and (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)) > 0:
+        out["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
+    # what binds the kernel, by the counters
+    cand = {"valu_issue": out.get("issue_frac", 0.0), "salu_issue": out.get("salu_frac", 0.0), "hbm": out.get("hbm_frac", 0.0)}
+    bound = max(cand, key=cand.get)
+    if out.get("wait_frac", 0.0) >= 0.6 and cand[bound] < 0.5:
+        bound = "latency"
+    out["bound"] = bound
+    return out
 
 
 def ags_abs_error(device):
@@ -184,19 +252,18 @@ def cpu_baseline(eng, sample_reads, read_len, plan):
                          "m8_md5_equals_gpu": m8_md5(got) == m8_md5(want)})
     head = runs[0]
     return {"value": head["reads_per_s"], "unit": "reads/s", "cores": head["threads"], "kind": kind,
-            "sample": "prefixes of the bench workload (%d bp): %s -e 1 -t n -p f -b 0, wall time of the process incl. DB load; headline = first run" %
-                      (read_len, "rapsearch_Linux_2.15 -z T" if kind == "reference" else "oracle/rs_port (C restatement, 1 thread)"),
+            "sample": "BOUNDED sample (about 15 s of wall time per run, so that the default bench finishes in minutes): prefixes of the bench workload (%d bp) of %s "
+                      "reads; %s -e 1 -t n -p f -b 0, wall time of the process incl. DB load; headline = first run. On 1,000,000 reads of the same workload "
+                      "(bench.py --cpu-full, profiles/r02_bench_full.json) the same binary ran 14.3 k / 12.7 k / 3.0 k reads/s at -z 256 / 8 / 1" %
+                      (read_len, " / ".join(str(r["reads"]) for r in runs), "rapsearch_Linux_2.15 -z T" if kind == "reference" else "oracle/rs_port (C restatement, 1 thread)"),
+            "note": "'cores' is the -z of the headline run; RAPsearch2 2.15 stops scaling at about 8 threads (see runs), whatever the host has",
             "host_cores": os.cpu_count(), "runs": runs, "m8_md5_equals_gpu": all(r["m8_md5_equals_gpu"] for r in runs)}
 
 
-def e2e_rate(device, gen, n, L, gz):
-    """File -> AGS through run_pipeline (native reader, HIP search, classification, estimate) on a FASTQ file of n reads of the
-    bench workload written to the box's temp directory.  Returns reads/s of the whole call (file open to estimate)."""
-    import contextlib
+def write_fastq(gen, n, L, path, gz):
+    """n reads of the bench workload as a FASTQ file (ids 0 .. n-1, qualities 'I' with a '5' every tenth base: phred+33)."""
     import gzip
-    import io
     import numpy as np
-    from microbecensus_amd import microbe_census as mc
     reads = gen.single(n, L, first=1 << 40).cpu().numpy()      # (indices far away from the resident set)
     w = len(str(n - 1))
     rec = np.empty((n, 1 + w + 1 + L + 3 + L + 1), dtype=np.uint8)
@@ -210,14 +277,23 @@ def e2e_rate(device, gen, n, L, gz):
     rec[:, 5 + w + L:5 + w + 2 * L] = ord("I")
     rec[:, 5 + w + L + 7:5 + w + 2 * L:10] = ord("5")          # (a character only phred+33 files hold: the offset detection stops at the first record)
     rec[:, -1] = 10
+    if gz:
+        with gzip.open(path, "wb", compresslevel=1) as f:
+            f.write(rec.tobytes())
+    else:
+        rec.tofile(path)
+    return os.path.getsize(path)
+
+
+def e2e_rate(device, gen, n, L, gz):
+    """File -> AGS through run_pipeline (native reader, HIP search, classification, estimate) on a FASTQ file of n reads of the
+    bench workload written to the box's temp directory.  Returns reads/s of the whole call (file open to estimate)."""
+    import contextlib
+    import io
+    from microbecensus_amd import microbe_census as mc
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "reads.fq" + (".gz" if gz else ""))
-        if gz:
-            with gzip.open(path, "wb", compresslevel=1) as f:
-                f.write(rec.tobytes())
-        else:
-            rec.tofile(path)
-        size = os.path.getsize(path)
+        size = write_fastq(gen, n, L, path, gz)
         walls = []
         for rep in range(2):                                       # the first call also allocates the engine's pools for this batch size
             args = {"seqfiles": [path], "device": device, "nreads": n, "read_length": L}
@@ -230,6 +306,39 @@ def e2e_rate(device, gen, n, L, gz):
     dt = walls[-1]
     return {"reads": n, "file": "FASTQ" + (".gz" if gz else ""), "file_bytes": size, "wall_s": round(dt, 3), "reads_per_s": round(n / dt, 1),
             "first_call_wall_s": round(walls[0], 3), "sampled_reads": int(res[1]["sampled_reads"]), "est_ags": res[0]}
+
+
+def e2e_distributed(gen, n, L, rank, world, local, rdev):
+    """File -> AGS over all ranks (microbecensus_amd.distributed.run_pipeline_distributed): rank 0 samples the file and deals batches
+    of 2 M accepted reads to the ranks while it samples; every rank searches what it is dealt; one all_reduce of the per-family sums.
+    Wall time from before the call to after it on every rank, the maximum over the ranks."""
+    import contextlib
+    import io
+    import shutil
+    import torch
+    import torch.distributed as dist
+    from microbecensus_amd import distributed as mcd
+    box = [None]
+    if rank == 0:
+        td = tempfile.mkdtemp(prefix="mc_e2e_")
+        box[0] = os.path.join(td, "reads.fq")
+        write_fastq(gen, n, L, box[0], False)
+    dist.broadcast_object_list(box, src=0)
+    walls, est = [], None
+    for rep in range(2):
+        dist.barrier()
+        t = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            est, a = mcd.run_pipeline_distributed({"seqfiles": [box[0]], "nreads": n, "read_length": L}, device=local)
+        dist.barrier()
+        w = torch.tensor([time.time() - t], dtype=torch.float64, device=rdev)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        walls.append(float(w.item()))
+    if rank == 0:
+        shutil.rmtree(os.path.dirname(box[0]), ignore_errors=True)
+    return {"what": "run_pipeline_distributed(file -> AGS) over %d ranks: rank 0 samples and deals batches while the ranks search; wall time of the second of two calls, "
+                    "maximum over the ranks" % world, "reads": n, "file": "FASTQ", "wall_s": round(walls[-1], 3), "reads_per_s": round(n / walls[-1], 1),
+            "first_call_wall_s": round(walls[0], 3), "sampled_reads": int(a["sampled_reads"]), "est_ags": est}
 
 
 def main():
@@ -247,7 +356,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ags-check", action="store_true", help="skip the run_pipeline AGS comparison on the reference's own inputs")
     ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the end-to-end (file -> AGS) measurement (plain FASTQ; a tenth of it for .gz); 0 = skip")
-    ap.add_argument("--count-in-timed-steps", action="store_true", help="keep the seed kernel's traffic counters on in the timed steps")
+    ap.add_argument("--no-best-only-leg", action="store_true", help="skip the extra timed leg with mc_set_best_hits_only (what run_pipeline runs)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL, one GPU per rank (the measurement); gloo: all ranks on GPU 0, reductions on the host - "
                                                                                "only to exercise the N > 1 code path on a one-GPU box")
     args = ap.parse_args()
@@ -331,14 +440,6 @@ def main():
             tot_hits.__iadd__(hits); tot_aln.__iadd__(aln); tot_bylen.__iadd__(bylen)
         return eng.stats()
 
-    # The algorithmic traffic of the seed kernel (index reads of the reference's algorithm) depends on the reads only:
-    # it is counted once per resident batch by untimed launches with the counters on, the timed steps run without them.
-    eng.set_counting(True)
-    traffic = []
-    for b in range(nres):
-        st = step(b, collect=False)
-        traffic.append((st["bucket_lookups"], st["key_probes"]))
-    eng.set_counting(bool(args.count_in_timed_steps))
     for i in range(args.warmup):
         step(i, collect=False)
     torch.cuda.synchronize()
@@ -348,23 +449,34 @@ def main():
     acc = {}
     for i in range(K):
         st = step(i)
-        st["bucket_lookups"], st["key_probes"] = traffic[i % nres]
         for k, v in st.items():
             acc[k] = acc.get(k, 0) + v
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.time() - t0
-    # the same kernels one at a time (no overlap of the two parts): their own durations, outside the timed region
-    eng.set_parts(1)
-    seq = {}
-    nseq = min(2, K)
-    for i in range(nseq):
-        b = i % nres
-        eng.run_range(b * args.batch, args.batch, first_read_id=b * args.batch)
-        for k, v in eng.stats().items():
-            seq[k] = seq.get(k, 0) + v
-    eng.set_parts(1)
+    # the same steps with mc_set_best_hits_only (run_pipeline's path: only the reads that can be classified are ranked, no rows)
+    dt_only, st_only = None, None
+    if not args.no_best_only_leg:
+        eng.set_best_hits_only(True)
+        step(0, collect=False)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.time()
+        st_only = {}
+        for i in range(K):
+            for k, v in step(i, collect=False).items():
+                st_only[k] = st_only.get(k, 0) + v
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt_only = time.time() - t1
+        eng.set_best_hits_only(False)
+        if world > 1:
+            t2 = torch.tensor([dt_only], dtype=torch.float64, device=rdev)
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            dt_only = float(t2.item())
     tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -377,6 +489,10 @@ def main():
     else:
         job = {k: int(acc[k]) for k in ("rows", "reads_with_rows", "hsps", "gap_tasks", "seed_tasks")}
     dt = float(tmax.item())
+    e2e_multi = None
+    if world > 1 and args.e2e_reads > 0 and gen is not None:
+        eng.attach(0, 0)
+        e2e_multi = e2e_distributed(gen, min(args.e2e_reads, 4_000_000 * world), L, rank, world, local, rdev)
 
     if rank == 0:
         reads_total = args.batch * K * world
@@ -384,38 +500,37 @@ def main():
         kern = {"k_translate_seg": acc["ms_translate"], "k_enumerate": acc["ms_seed"], "k_eval_seeds": acc["ms_eval"], "k_gapped": acc["ms_gapped"],
                 "sort": acc["ms_sort"], "k_finish": acc["ms_finish"]}
         SEQ = {"k_translate_seg": "ms_translate", "k_enumerate": "ms_seed", "k_eval_seeds": "ms_eval", "k_gapped": "ms_gapped", "sort": "ms_sort", "k_finish": "ms_finish"}
-        kseq = {k: seq[m] / nseq for k, m in SEQ.items()}           # ms per step, every kernel alone on the GPU
+        kseq = {k: acc[m] / K for k, m in SEQ.items()}              # ms per step: HIP events around each stage on the library's stream (one kernel at a time)
         dom = max(kseq, key=kseq.get)
         n_batch = args.batch
+        hits, hsps, gtasks, rows = acc["seed_tasks"] / K, acc["hsps"] / K, acc["gap_tasks"] / K, acc["rows"] / K
         per_launch = {
-            # algorithmic bytes per launch: what the reference's algorithm reads / writes for the same reads
-            "k_translate_seg": n_batch * (L + 6 * (L // 3)),
-            # the seed kernel's OWN algorithm: frames in, one bucket-bitmap word per seed position, what it asks its filters (9-mer
-            # filter word 4 B, wildcard line 32 B, pair block 16 B), bucket record + key group per surviving probe (32 + 16 B), posting
-            # in (4 B) and seed hit out (16 B) per hit - counted by the timed kernel itself (mc_stats.seed_*)
-            "k_enumerate": (n_batch * (6 * (L // 3) + 4 * seed_positions(L)) * K + 4 * acc["seed_exact_asks"] + 32 * acc["seed_wild_asks"] + 16 * acc["seed_pair_asks"]
-                            + 48 * acc["seed_probes"] + 20 * acc["seed_tasks"]) / K,
-            "k_eval_seeds": (acc["seed_tasks"] * (16 + 4 + 8 + 2 * 20)) / K,
-            "k_gapped": (acc["gap_tasks"] * 24 + acc["hsps"] * 48) / K,
-            "sort": acc["hsps"] * (12 * 4 + 48 * 2) / K,
-            "k_finish": acc["hsps"] * 48 * 3 / K,
+            # ALGORITHMIC bytes per launch = the arrays a kernel must read and write, each once (the index is not counted: it
+            # is resident in L2 / Infinity Cache).  Nothing here is counted by the kernels themselves.
+            "k_translate_seg": n_batch * (L + 6 * (L // 3)),                 # bases in, six frames out
+            "k_enumerate": n_batch * 6 * (L // 3) + 16 * hits,               # frames in, seed hits out (16 B)
+            "k_eval_seeds": 16 * hits + 48 * hsps + 28 * gtasks,             # seed hits in, HSPs (48 B) and gap tasks (28 B) out
+            "k_gapped": (28 + 32 + 48) * gtasks,                             # gap tasks in, two flank results (16 B) and an HSP out per task
+            "sort": hsps * (48 + 48 + 2 * 12),                               # HSPs in and out in (read, subject, hit order); keys
+            "k_finish": hsps * 48 + rows * 64,                               # HSPs in, m8 rows out
         }
-        # the index reads the REFERENCE's algorithm would issue for the same reads (counting form of the seed kernel): what the filters dispose of
-        ref_seed_bytes = (n_batch * 6 * (L // 3) * K + 8 * acc["bucket_lookups"] + 2 * acc["key_probes"] + 20 * acc["seed_tasks"]) / K
-        # The two parts of a step overlap in the timed region, so a kernel's HIP events there also span the other part's kernels;
-        # its own duration is measured by the same events right after the timed region with one kernel at a time (mc_set_parts(1)),
-        # which is also how the committed rocprofv3 profile (profiles/, MC_PARTS=1) is taken.  achieved / frac use that duration;
-        # achieved_in_timed_region uses the overlapped one.
+        prof = load_profile(L)
+        der = {k: derived(prof, "k_enumerate_t0" if k == "k_enumerate" else k) for k in kseq}
+        d_dom = der.get(dom)
         ach = per_launch[dom] / (kseq[dom] * 1e-3) / 1e9
-        ach_timed = per_launch[dom] / (kern[dom] / K * 1e-3) / 1e9
-        traffic_dom = profiled_traffic("k_enumerate_t0" if dom == "k_enumerate" else dom, n_batch)
-        # the whole device pipeline of one batch as one "launch": SURVEY 8(d)'s own definition, achieved = reads/s x A(L)
+        # the whole device pipeline of one batch as one "launch": SURVEY 8(d)'s own definition, achieved = reads/s x A(L) - a LEGACY
+        # figure: its A(L) assumes whole-bucket visits the engine does not perform
         pipe_gbs = (SURVEY_A[L] * (reads_total / world) / dt / 1e9) if L in SURVEY_A else None
         agg = mcd.aggregate_from_accumulators(tot_hits, tot_aln, tot_bylen, fams, mc.find_opt_pars(None, L))
         try:
             est = mc.estimate_average_genome_size({"read_length": L, "sampled_reads": reads_total, "verbose": False}, None, agg)
         except BaseException:
             est = None
+        # HBM bytes of the dominant kernel per launch of THIS run's batch: the profile's counters are per launch of its own batch size;
+        # the pipeline is linear in the number of reads, so only the reads-per-launch ratio is applied - never another read length
+        traffic_dom = None
+        if d_dom and d_dom.get("hbm_bytes_per_launch") is not None and d_dom.get("reads_per_launch"):
+            traffic_dom = d_dom["hbm_bytes_per_launch"] * n_batch / d_dom["reads_per_launch"]
         out = {
             "metric": METRIC, "value": round(reads_total / dt, 1), "unit": "reads/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32",
@@ -427,39 +542,40 @@ def main():
                        "rows_per_read": round(job["rows"] / reads_total, 4), "reads_with_rows": round(job["reads_with_rows"] / reads_total, 5),
                        "hsps_per_read": round(job["hsps"] / reads_total, 3), "gapped_extensions_per_read": round(job["gap_tasks"] / reads_total, 3),
                        "seed_hits_per_read": round(job["seed_tasks"] / reads_total, 2), "ags_estimate_of_workload": est,
-                       # HIP events on each part's own stream inside the timed region: the two parts of a step overlap, so these
-                       # durations include waiting for the other part's kernels (their sum exceeds ms_per_step)
+                       # HIP events on the library's own stream around each stage, timed region (one kernel at a time: mc_run_range's default)
                        "kernel_ms_per_step": {k: round(v / K, 3) for k, v in kern.items()},
-                       "sum_kernel_ms_per_step": round(sum(kern.values()) / K, 3),
-                       # the same kernels run one at a time after the timed region (mc_set_parts(1))
-                       "kernel_ms_per_step_sequential": {k: round(seq[m] / nseq, 3) for k, m in (("k_translate_seg", "ms_translate"), ("k_enumerate", "ms_seed"),
-                                                         ("k_eval_seeds", "ms_eval"), ("k_gapped", "ms_gapped"), ("sort", "ms_sort"), ("k_finish", "ms_finish"))}},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                       "sum_kernel_ms_per_step": round(sum(kern.values()) / K, 3)},
+            "roofline": {"kernel": dom, "bound": (d_dom or {}).get("bound", "valu_issue"), "nominal_bound": "hbm",
+                         "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                          "traffic": (None if traffic_dom is None else round(traffic_dom, 0)),
-                         "basis": "achieved = algorithmic bytes of one step's launches of the kernel (DESIGN.md 5; for the seed kernel: what its own algorithm "
-                                  "asks for - frames, bitmap words, filter words / lines / blocks, bucket records, key groups, postings, seed hits - counted by the "
-                                  "timed kernel) / HIP-event time of those launches, one kernel at a time (measured right after the timed region; in it the two "
-                                  "parts of a step overlap). traffic / physical_* = fabric-side bytes (2 x FETCH_SIZE + WRITE_SIZE) of the committed rocprofv3 "
-                                  "PMC profile: above the algorithmic bytes because a 16- or 32-byte item arrives as a 128-byte line; mostly Infinity-Cache "
-                                  "hits (the index is 110 MB). seed_kernel_reference_algorithm_*: the index reads the reference's algorithm would issue for the "
-                                  "same reads / the same time - a disposal rate, the filters answer those probes",
-                         "seed_kernel_reference_algorithm_bytes_per_read": round(ref_seed_bytes / n_batch, 1),
-                         "seed_kernel_reference_algorithm_GBps": round(ref_seed_bytes / (kseq["k_enumerate"] * 1e-3) / 1e9, 2),
-                         "physical_GBps": (None if traffic_dom is None else round(traffic_dom / (kseq[dom] * 1e-3) / 1e9, 2)),
-                         "physical_frac": (None if traffic_dom is None else round(traffic_dom / (kseq[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)),
-                         "kernel_ms_per_step": round(kseq[dom], 3),
-                         "l2_hit_rate": profiled_l2_hit_rate("k_enumerate_t0" if dom == "k_enumerate" else dom),
-                         "achieved_in_timed_region": round(ach_timed, 2),
-                         "algorithmic_bytes_per_read": round(per_launch[dom] / n_batch, 1),
-                         # SURVEY.md 8(d) priced the whole path at A(150) = 207,923 B/read assuming whole-bucket visits the engine does not
-                         # perform; its definition achieved = reads/s x A(L), per GPU:
-                         "survey_A_bytes_per_read": SURVEY_A.get(L),
-                         "pipeline_GBps_with_survey_A": (None if pipe_gbs is None else round(pipe_gbs, 2)),
-                         "pipeline_frac_with_survey_A": (None if pipe_gbs is None else round(pipe_gbs / HBM_PEAK_GBS, 5)),
-                         "all_kernels_algorithmic_GBps": {k: round(per_launch[k] / (kseq[k] * 1e-3) / 1e9, 2) for k in kseq if kseq[k] > 0},
-                         "all_kernels_physical_GBps": {k: (lambda t: None if t is None else round(t / (kseq[k] * 1e-3) / 1e9, 2))(
-                             profiled_traffic("k_enumerate_t0" if k == "k_enumerate" else k, n_batch)) for k in kseq if kseq[k] > 0 and k != "sort"}},
+                         "hbm_frac": (d_dom or {}).get("hbm_frac"), "hbm_frac_lower": (d_dom or {}).get("hbm_frac_lower"), "issue_frac": (d_dom or {}).get("issue_frac"),
+                         "salu_frac": (d_dom or {}).get("salu_frac"), "wait_frac": (d_dom or {}).get("wait_frac"),
+                         "valu_lanes_of_64": (d_dom or {}).get("valu_lanes_of_64"), "l2_hit_rate": (d_dom or {}).get("l2_hit_rate"),
+                         "kernel_ms_per_step": round(kseq[dom], 3), "algorithmic_bytes_per_read": round(per_launch[dom] / n_batch, 1),
+                         "profile": (None if prof is None else prof["files"]), "fetch_calibration": (None if prof is None else prof.get("calibration")),
+                         "basis": "kernel = the stage with the largest HIP-event time per step. achieved = ALGORITHMIC bytes of one launch (the arrays the kernel "
+                                  "must read and write, each once: DESIGN.md 5 - nothing counted by the kernel itself) / the live HIP-event duration of that "
+                                  "launch; frac = achieved / 8 TB/s. Everything else comes from the committed rocprofv3 profile of THIS read length (profile; null "
+                                  "when none is committed - a profile of another length is never scaled): traffic = (fetch_factor x FETCH_SIZE + WRITE_SIZE) KiB x 1024 "
+                                  "per profiled launch x (this batch / profiled batch), fetch_factor 2 for streaming reads (MI355X_MICROARCH.md) and the gather "
+                                  "calibration's (fetch_calibration) for the seed kernels; hbm_frac = that / profiled duration / 8 TB/s (mostly Infinity-Cache hits: "
+                                  "the index is 110 MB; hbm_frac_lower: the same with one 64-byte half line per scattered request); issue_frac = SQ_INSTS_VALU x 4 / "
+                                  "(1024 SIMDs x kernel cycles), salu_frac = SQ_INSTS_SALU / (256 scalar units x kernel cycles) - the two issue side by side and are "
+                                  "not added -, kernel cycles = profiled duration x 2.4 GHz; wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES; valu_lanes_of_64 = "
+                                  "SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU; bound = the largest of issue_frac, salu_frac and hbm_frac ('latency' when all are "
+                                  "below 0.5 and wait_frac >= 0.6). No kernel of this path is HBM bound: the nominal roofline (nominal_bound) is kept because "
+                                  "the metric asks for it.",
+                         "all_kernels": {k: dict({"ms_per_step": round(kseq[k], 3), "algorithmic_GBps": round(per_launch[k] / (kseq[k] * 1e-3) / 1e9, 2)},
+                                                 **({} if not der.get(k) else {m: der[k][m] for m in ("bound", "issue_frac", "salu_frac", "wait_frac", "hbm_frac", "hbm_frac_lower", "valu_lanes_of_64", "lds_bank_conflict_frac", "l2_hit_rate", "profiled_ms") if m in der[k]}))
+                                         for k in kseq if kseq[k] > 0},
+                         "legacy_survey_A": {"bytes_per_read": SURVEY_A.get(L), "pipeline_GBps": (None if pipe_gbs is None else round(pipe_gbs, 2)),
+                                             "note": "SURVEY.md 8(d) priced the whole path at A(L) assuming whole-bucket visits the engine does not perform (DESIGN.md 2): kept as a labelled legacy figure, not a fraction of anything"}},
         }
+        if dt_only is not None:
+            out["classification_only"] = {"what": "the same steps with mc_set_best_hits_only (what run_pipeline runs when not verbose): every HSP is made, only the reads "
+                                                  "that have an HSP passing their family's thresholds are sorted and finished, no m8 rows; identical best hits",
+                                          "value": round(reads_total / dt_only, 1), "unit": "reads/s", "ms_per_step": round(dt_only / K * 1e3, 3),
+                                          "kernel_ms_per_step": {k: round(st_only[m] / K, 3) for k, m in SEQ.items()}}
         if world == 1 and not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
             if args.cpu_full:
@@ -474,6 +590,8 @@ def main():
             out["e2e"] = {"what": "run_pipeline(file -> AGS): native reader beside the HIP search (mc_search_files), classification, estimate; wall time of the second "
                                   "of two calls on the same file (first_call_wall_s includes the one-time pool allocation); .gz is bounded by single-stream inflate",
                           "plain": e2e_rate(local, gen, args.e2e_reads, L, gz=False), "gz": e2e_rate(local, gen, max(1, args.e2e_reads // 10), L, gz=True)}
+        if e2e_multi is not None:
+            out["e2e"] = e2e_multi
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:

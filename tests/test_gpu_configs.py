@@ -85,12 +85,14 @@ inp = os.path.join(sys.argv[1], "tests", "golden", "inputs")
 est, args = D.run_pipeline_distributed({"seqfiles": [os.path.join(inp, "c4_pair_1.fq.gz"), os.path.join(inp, "c4_pair_2.fq.gz")], "nreads": 20000},
                                        device=local if backend == "nccl" else 0)
 if dist.get_rank() == 0:
-    json.dump({"est": est, "sampled": args["sampled_reads"], "L": args["read_length"], "world": dist.get_world_size(), "backend": dist.get_backend()}, open(sys.argv[2], "w"))
+    tr = D.run_pipeline_distributed.last_trace
+    json.dump({"est": est, "sampled": args["sampled_reads"], "L": args["read_length"], "world": dist.get_world_size(), "backend": dist.get_backend(),
+               "deals": sum(1 for t in tr if t[0] == "deal")}, open(sys.argv[2], "w"))
 dist.barrier()
 dist.destroy_process_group()
 ''')
     out = tmp_path / "o.json"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MC_DIST_BATCH="3000")   # 20,000 reads dealt in 7 batches
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                            "--master-port", str(port), str(worker), REPO, str(out), backend], env=env, timeout=900)
     return json.load(open(out))
@@ -98,15 +100,16 @@ dist.destroy_process_group()
 
 def test_config4_shape_two_ranks_gloo(tmp_path):
     """The paired library given as `a,b` through run_pipeline_distributed with two ranks (both on this box's GPU, gloo): rank 0
-    samples and scatters, the reduced per-family sums give the reference's AGS for the same pair."""
+    samples and deals batches to the two ranks while it samples, the reduced per-family sums give the reference's AGS for the same pair."""
     g = json.load(open(os.path.join(GOLD, "c4_paired.json")))
     res = _two_ranks(tmp_path, "gloo", 29541)
     assert res["world"] == 2 and res["sampled"] == g["sampled_reads"] and res["L"] == 150
+    assert res["deals"] == 7                                      # streamed: 3,000-read batches dealt round robin while the sampler runs
     assert abs(res["est"] - g["est_ags"]) <= 1e-9 * g["est_ags"]
 
 
 def test_config4_shape_two_ranks_rccl(tmp_path):
-    """The same over RCCL (backend "nccl") with one GPU per rank: scatter of the read blocks GPU to GPU, all_reduce of the
+    """The same over RCCL (backend "nccl") with one GPU per rank: batches dealt GPU to GPU (isend / recv), all_reduce of the
     per-family sums.  Needs two GPUs."""
     from microbecensus_amd import _native
     if _native.load_library().mc_device_count() < 2:              # (asked of the HIP library this process already uses, not of torch)
