@@ -413,13 +413,14 @@ class Engine:
                 "post": arr(p[3], "<u4", npost.value), "keys": arr(p[4], "<u2", npost.value), "thr": thr.value, "letter_p": list(lp)}
 
 
-def search_files_multi(engines, reader, first_read_id=0, keep_rows=False):
+def search_files_multi(engines, reader, first_read_id=0, keep_rows=False, best_only=False):
     """mc_search_files_multi: one sampler, its batches dealt to several engines (GPUs) of this process.  Returns the best hits of
     all engines in ascending read order."""
     lib = load_library()
     arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
     for e in engines:
         lib.mc_set_keep_rows(e.h, 1 if keep_rows else 0)
+        lib.mc_set_best_hits_only(e.h, 1 if best_only else 0)
     try:
         rc = lib.mc_search_files_multi(arr, len(engines), reader.r, first_read_id)
         if rc == -3:
@@ -429,5 +430,6 @@ def search_files_multi(engines, reader, first_read_id=0, keep_rows=False):
     finally:
         for e in engines:
             lib.mc_set_keep_rows(e.h, 1)
+            lib.mc_set_best_hits_only(e.h, 0)
     best = np.concatenate([e.best_hits() for e in engines])
     return best[np.argsort(best["read"], kind="stable")]

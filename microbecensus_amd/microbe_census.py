@@ -25,7 +25,9 @@ What differs from the reference, on purpose:
   * run_pipeline() samples, searches and classifies in one native call (mc_search_files) and writes neither the
     temp FASTA nor the m8 text - the reference deletes both before it returns; args['keep_tmp'] = True runs stage by
     stage and leaves them (until clean_up) like the reference.
-  * optional args['device'] (default 0) selects the GPU.
+  * optional args['device'] selects ONE GPU; args['devices'] (a list of indices, or 'all') several: the sampler's batches of 2 M reads
+    are dealt to them inside one process (mc_search_files_multi).  With neither, every visible GPU is used - as far as the run has
+    batches for them (-n up to 2 M reads: one GPU).  Results do not depend on the number of GPUs.
   * args['threads'] (-t), when given, caps the worker threads of the native sampler (the reference forwards it to rapsearch -z).
 """
 import bz2
@@ -427,17 +429,22 @@ def _sample_search_classify(args, paths):
                         args["min_quality"], args["mean_quality"], args["max_unknown"], args["filter_dups"])
     try:
         try:
-            eng = _engine(args.get("device", 0) or 0)
-            eng.set_run(L, model["pars"][str(L)], fams)
+            devs = _devices_for(args)
+            engs = _engines_on(devs)
+            for eng in engs:
+                eng.set_run(L, model["pars"][str(L)], fams)
             # (the count of reads with m8 rows is only printed when verbose: without it only the reads that can be classified are ranked)
-            rows, best = eng.search_files(rd, keep_rows=False, best_only=not args["verbose"])
+            if len(engs) == 1:
+                rows, best = engs[0].search_files(rd, keep_rows=False, best_only=not args["verbose"])
+            else:       # one sampler, batches of 2 M accepted reads dealt to the GPUs as they ask for them (mc_search_files_multi): same best hits
+                best = _native.search_files_multi(engs, rd, keep_rows=False, best_only=not args["verbose"])
         except _native.ReferenceError_ as e:       # the reference raises here; run_pipeline prints it and returns None
             raise Exception(str(e))
         except RuntimeError as error:
             clean_up(paths)
             sys.exit("\nDatabase search has exited with the following error:\n%s" % error)
         st = rd.stats()
-        hit_reads = eng.stats()["reads_with_rows"]
+        hit_reads = sum(e.stats()["reads_with_rows"] for e in engs)
     finally:
         rd.close()
     if st.get("exhausted"):
@@ -471,6 +478,56 @@ def _engine(device):
     if device not in _engines:
         _engines[device] = _native.Engine(device=device)
     return _engines[device]
+
+
+STREAM_BATCH = 2000000      # accepted reads per batch of mc_search_files(_multi)
+
+
+def _devices_for(args):
+    """The GPUs a run uses.  args['devices']: a list of device indices, or 'all'; else args['device'] (default 0) when given; else
+    every visible device - but never more than the library can keep busy: batches of 2 M accepted reads are dealt to the devices,
+    so a run of n reads uses at most ceil(n / 2 M) of them (the reference's default -n of 1 - 2 M reads: one GPU).  The results do
+    not depend on it (reads are independent; per-family sums are integers)."""
+    from . import _native
+    devs = args.get("devices")
+    if devs is None and args.get("device") is not None:
+        return [int(args["device"])]
+    visible = max(1, _native.load_library().mc_device_count())
+    if devs is None or devs == "all":
+        devs = list(range(visible))
+    devs = [int(d) for d in devs]
+    n = args.get("nreads")
+    if n is not None:
+        devs = devs[: max(1, -(-int(n) // STREAM_BATCH))]
+    return devs or [0]
+
+
+def _engines_on(devs):
+    """One engine per entry of devs (an index may repeat: several handles on one GPU), opened in parallel: mc_open builds the
+    marker index on the host, a second of work per handle."""
+    import threading
+    from . import _native
+    keys, seen = [], {}
+    for d in devs:                                   # the second handle on device d is engine (d, 1) ...
+        k = seen.get(d, 0)
+        seen[d] = k + 1
+        keys.append(d if k == 0 else (d, k))
+    missing = [k for k in keys if k not in _engines]
+    errs = []
+
+    def make(k):
+        try:
+            _engines[k] = _native.Engine(device=k if isinstance(k, int) else k[0])
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=make, args=(k,)) for k in missing]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if errs:
+        raise RuntimeError(str(errs[0]))
+    return [_engines[k] for k in keys]
 
 
 def _pack_reads(seqs, L):

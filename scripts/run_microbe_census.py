@@ -24,9 +24,11 @@ def parse_arguments(argv=None):
     p.add_argument("-m", dest="mean_quality", type=int, default=-5, help="minimum read-level PHRED quality (default = -5; no filtering)")
     p.add_argument("-d", dest="filter_dups", action="store_true", default=False, help="filter duplicate reads")
     p.add_argument("-u", dest="max_unknown", type=int, default=100, help="max percent of unknown bases per read (default = 100)")
-    p.add_argument("-g", dest="device", type=int, default=0, help="GPU index (default = 0)")
+    p.add_argument("-g", dest="device", type=int, default=None, help="GPU index (default: every visible GPU the run has batches of 2 M reads for)")
     args = vars(p.parse_args(argv))
     args["seqfiles"] = args["seqfiles"].split(",")
+    if args["device"] is None:
+        del args["device"]
     if args["threads"] is None:
         del args["threads"]                      # impute_missing_args() fills in the reference's default (1) for the report; the sampler is not capped
     return args

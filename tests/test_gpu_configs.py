@@ -66,6 +66,21 @@ def test_run_pipeline_fused_path(case):
     assert args["sampled_reads"] == g["sampled_reads"] and est == g["est_ags"]
 
 
+def test_run_pipeline_over_several_handles_in_one_process(monkeypatch):
+    """args['devices'] (the optional GPU-count key): the sampler's batches dealt to several engines of this process
+    (mc_search_files_multi) - here three handles on this box's one GPU and batches of 4,000 reads - must give the reference's AGS,
+    bit for bit, like one engine does."""
+    g = json.load(open(os.path.join(GOLD, "c2_100bp.json")))
+    monkeypatch.setenv("MC_STREAM_BATCH", "4000")
+    args = _args("c2_100bp")
+    args.pop("device", None)
+    args["devices"] = [0, 0, 0]
+    args["nreads"] = 10_000_000                                  # (else a run of this size would be given one device)
+    est, out = mc.run_pipeline(args)
+    assert out["sampled_reads"] == g["sampled_reads"] and est == g["est_ags"]
+    assert [k for k in mc._engines if isinstance(k, tuple)] == [(0, 1), (0, 2)]
+
+
 def _two_ranks(tmp_path, backend, port):
     worker = tmp_path / "w.py"
     worker.write_text(r'''
