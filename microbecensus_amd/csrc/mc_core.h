@@ -1308,6 +1308,28 @@ MC_HDN McGapResult mc_align_gapped(const TT &T, const uint8_t *s1, int st1, cons
 #define MC_PD_YMASK 0x1F000000u
 #define MC_PD_PATH 0x00FFFFFFu
 
+// A cell in 64 bits (what the LDS windows of k_gapped_lds hold):
+//   word 0: H 12 bits (signed) | min(H - D, 11) 4 bits | ident, diag of PH 16 bits
+//   word 1: ident, diag of PD 16 bits | runs of PH 5 bits | runs of PD 5 bits | subject residue 5 bits | MC_PD_GROW 1 bit
+// D itself is not needed: a cell is only ever asked whether H - first >= D - ext (H - D >= 11: the gap opens, and D drops out of the
+// result) and otherwise for D - ext with H - D <= 10 - so H - D is kept, capped at 11, and unpacking returns H - 11 for a capped D
+// (same decision, same value).  Returns nonzero when a run count does not fit its 5 bits (a live path with 32 gap runs).
+MC_HD uint32_t mc_gap_pack(int H, int D, uint32_t PH, uint32_t PD, uint32_t &w0, uint32_t &w1)
+{
+    int delta = H - D;
+    if (delta > 11) delta = 11;
+    w0 = ((uint32_t)H & 0xFFFu) | ((uint32_t)delta << 12) | (PH << 16);
+    w1 = (PD & 0xFFFFu) | ((PH >> 16) & 0x1Fu) << 16 | ((PD >> 16) & 0x1Fu) << 21 | ((PD >> 24) & 0x1Fu) << 26 | (PD & MC_PD_GROW);
+    return ((PH | PD) >> 21) & 7u;                                  // bits 21..23 of either path word: runs >= 32
+}
+MC_HD void mc_gap_unpack(uint32_t w0, uint32_t w1, int &H, int &D, uint32_t &PH, uint32_t &PD)
+{
+    H = (int)(w0 << 20) >> 20;
+    D = H - (int)((w0 >> 12) & 15u);
+    PH = (w0 >> 16) | ((w1 >> 16) & 0x1Fu) << 16;
+    PD = (w1 & 0xFFFFu) | ((w1 >> 21) & 0x1Fu) << 16 | ((w1 >> 26) & 0x1Fu) << 24 | (w1 & MC_PD_GROW);
+}
+
 struct McGapState {
     const uint8_t *s1, *s2;
     int st, n1, n2;

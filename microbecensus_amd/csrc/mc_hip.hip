@@ -1126,8 +1126,9 @@ __global__ void __launch_bounds__(256) k_gap_emit(const McTables *__restrict__ T
 }
 
 #define MC_GAP_W 1200   // columns of the full-size DP workspace (markers are <= 1183 aa, checked in mc_open)
-#define MC_GAP_WIN 40   // columns of the LDS window of the first launch (30 KB per wave: five waves per CU)
-#define MC_GAP_WIN2 64  // ... of the second one, for the flanks whose band left the first (48 KB per wave)
+#define MC_GAP_WIN 36   // columns of the LDS window of the first launch (18 KB per wave: eight waves per CU; per 1 M reads of 150 / 300 bp, first + second launch:
+                        // 40 columns x 7 waves 2.00 + 0.41 / 9.49 + 1.05 ms, 36 x 8: 1.73 + 0.44 / 8.19 + 1.64, 32 x 9: 1.85 + 0.81 / 8.43 + 5.89)
+#define MC_GAP_WIN2 64  // ... of the second one, for the flanks whose band left the first (32 KB per wave)
 #define MC_GAP_LANES2 16 // lanes of a wave that take flanks in the second launch (300 bp, per 1 M reads: 4 lanes 2.2 ms, 8: 1.55, 16 or 64: 0.98)
 
 __device__ __forceinline__ McFlankOut mc_flank_out(const McGapResult &R)
@@ -1168,7 +1169,7 @@ __global__ void __launch_bounds__(128) k_gapped(const McTables *__restrict__ T, 
 // only the live band - a circular window of W columns, 12 bytes per column: the two scores (16 + 16 bits) in one word, the two
 // path-statistics words, the subject residue in the spare byte of the second - nothing of the DP touches global memory.
 // Layout: word (slot, lane) of a wave's window sits at slot * 64 + lane, so whatever slots the 64 lanes are working on they fall
-// into 64 different banks.  A flank whose band is wider than the window (0.02 % of the flanks of 150 bp reads at W = 40) goes to
+// into 64 different banks.  A flank whose band is wider than the window (0.3 % of the flanks of 150 bp reads at W = 36) goes to
 // the retry list: the same kernel with a 64-column window, and behind that k_gapped with full-size rows in global memory.
 //
 // PERSISTENT LANES.  How long a flank takes is not known before it ends: its DP rows (the sort key) are only an upper bound -
@@ -1183,21 +1184,25 @@ __global__ void __launch_bounds__(128) k_gapped(const McTables *__restrict__ T, 
 // next one is ready in registers.  The same inside a row: the query residue of the next row and the subject residues the right
 // growth will need are requested at the row's start (mc_gap_row).
 #define MC_GAP_REFILL 8
+// A DP column in 8 bytes (mc_gap_pack / mc_gap_unpack, mc_core.h): 20 KB per wave at 40 columns - seven waves per CU instead of the five
+// that 12-byte columns allowed, and the kernel's speed is proportional to the waves a CU holds (it waits on its own chains of
+// dependent instructions: 2 / 3 / 4 / 5 waves per CU ran 5.6 / 3.8 / 3.1 / 2.45 ms).  One 64-bit LDS access per cell and direction.
 template <int W>
 struct McGapLds {
-    uint32_t *hd, *ph, *pd;                                        // this lane's column 0 of the three word arrays
+    uint2 *cell;                                                   // this lane's column 0; column c at cell[c * 64]
+    uint32_t ovf;                                                  // a path statistic left its packed field (nothing the kernel cannot redo wider)
     __device__ __forceinline__ void load(int c, int &H, int &D, uint32_t &PH, uint32_t &PD) const
     {
-        const uint32_t w = hd[c * 64];
-        H = (int)(int16_t)(w & 0xFFFFu); D = (int)w >> 16;
-        PH = ph[c * 64]; PD = pd[c * 64];
+        const uint2 w = cell[c * 64];
+        mc_gap_unpack(w.x, w.y, H, D, PH, PD);
     }
     __device__ __forceinline__ void store(int c, int H, int D, uint32_t PH, uint32_t PD)
     {
-        hd[c * 64] = ((uint32_t)H & 0xFFFFu) | ((uint32_t)D << 16);
-        ph[c * 64] = PH; pd[c * 64] = PD;
+        uint2 w;
+        ovf |= mc_gap_pack(H, D, PH, PD, w.x, w.y);
+        cell[c * 64] = w;
     }
-    __device__ __forceinline__ int loadH(int c) const { return (int)(int16_t)(hd[c * 64] & 0xFFFFu); }
+    __device__ __forceinline__ int loadH(int c) const { return (int)(cell[c * 64].x << 20) >> 20; }
 };
 
 template <int W, int LANES>
@@ -1206,13 +1211,13 @@ __global__ void __launch_bounds__(64) k_gapped_lds(const McTables *__restrict__ 
                                                    uint32_t *retry_count, uint32_t *retry, int refill)
 {
     __shared__ McHot hot;
-    __shared__ uint32_t win[3 * W * 64];
+    __shared__ uint2 win[W * 64];
     const uint32_t nitems = *nitems_p;                            // device-side count
     if (nitems == 0) return;
     mc_load_hot(&hot, T);
     __syncthreads();
     const int lane = threadIdx.x;
-    McGapLds<W> ws; ws.hd = win + lane; ws.ph = win + W * 64 + lane; ws.pd = win + 2 * W * 64 + lane;
+    McGapLds<W> ws; ws.cell = win + lane; ws.ovf = 0;
     // LANES < 64 (the retry launch: few, large flanks - its run time is that of the longest chain of them in one lane): only the
     // first LANES lanes of a wave take items, so that the items spread over all the waves the GPU holds
     const bool mine = lane < LANES;
@@ -1243,7 +1248,7 @@ __global__ void __launch_bounds__(64) k_gapped_lds(const McTables *__restrict__ 
             const unsigned long long rm = __ballot(ready);
             if (rm && (__popcll(rm) >= REFILL || taken >= share || __ballot(active) == 0)) {
                 if (ready) {
-                    it = nit; active = true; nstage = 0;
+                    it = nit; active = true; nstage = 0; ws.ovf = 0;
                     fin = !mc_gap_begin(hot, S, ns1, ns2, nf.st, nf.n1, nf.n2, ws, W, true, nlo, nhi, (int)nx0);
                 }
             }
@@ -1283,6 +1288,7 @@ __global__ void __launch_bounds__(64) k_gapped_lds(const McTables *__restrict__ 
         }
         // ---- one DP row of every flank in progress
         if (active && !fin) fin = mc_gap_row(hot, S, ws, W);
+        if (fin && ws.ovf) S.over = 1;                              // (more than 31 gap runs on a live path: redone with the wider launch, in the end with full-size cells)
         if (fin) { fout[it] = mc_flank_out(mc_gap_result(S)); active = false; }
         const bool over = fin && S.over != 0;
         const uint32_t ro = mc_wave_alloc(retry_count, over);      // band left the window: the flank is redone with a wider one
@@ -2138,7 +2144,7 @@ static int stage_b(mc_handle *h, McCtx &c)
         // in LDS, those whose band leaves the window again with a wider one, the rest with full-size rows; 4. every task takes its
         // HSP from its group's flank results.  The counts of 2. - 4. stay on the device.
         static const int gap_refill = getenv("MC_GAP_REFILL") ? std::max(1, std::min(64, atoi(getenv("MC_GAP_REFILL")))) : MC_GAP_REFILL;   // (experiments)
-        static const unsigned gap_wpc = getenv("MC_GAP_WPC") ? (unsigned)std::max(1, atoi(getenv("MC_GAP_WPC"))) : 5u;                      // waves per CU of the launch
+        static const unsigned gap_wpc = getenv("MC_GAP_WPC") ? (unsigned)std::max(1, atoi(getenv("MC_GAP_WPC"))) : 8u;                      // waves per CU of the launch
         uint32_t slots = 1u << 16;
         while (slots < 2 * ngaps) slots <<= 1;
         if (slots > c.gtab_slots) { if (dalloc(&c.d_gtab, (size_t)slots)) return -1; c.gtab_slots = slots; }
@@ -2150,7 +2156,7 @@ static int stage_b(mc_handle *h, McCtx &c)
         HIPCK(rocprim::radix_sort_pairs_desc(c.d_sorttmp, gbytes, gk, gko, gi, gio, (size_t)ngaps * 2, 0, 10, st));
         k_gapped_lds<MC_GAP_WIN, 64><<<dim3(std::min<uint32_t>((2 * ngaps + 63) / 64, 256u * gap_wpc)), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, gio, c.d_counters + C_ITEMS, c.d_fout,
                                                                                                                  c.d_counters + C_RETRY, c.d_retry, gap_refill);
-        k_gapped_lds<MC_GAP_WIN2, MC_GAP_LANES2><<<dim3(256u * 3u), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry, c.d_counters + C_RETRY, c.d_fout, c.d_counters + C_RETRY2, c.d_retry2, 1);
+        k_gapped_lds<MC_GAP_WIN2, MC_GAP_LANES2><<<dim3(256u * 4u), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry, c.d_counters + C_RETRY, c.d_fout, c.d_counters + C_RETRY2, c.d_retry2, 1);
         k_gapped<<<dim3(c.gap_threads_full / 128), dim3(128), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry2, c.d_counters + C_RETRY2, c.d_fout, c.d_counters, c.d_gws_full, MC_GAP_W);
         k_gap_emit<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, L, c.d_gaps, ngaps, c.d_gleader, c.d_fout, c.d_hsps, c.cap_hsps, c.d_counters, h->d_P, h->d_fam, h->best_only ? c.d_cand : nullptr);
     }

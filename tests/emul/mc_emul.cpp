@@ -230,15 +230,12 @@ int main(int argc, char **argv)
     fprintf(stderr, "ungapped hsps: %zu gapped tasks: %zu\n", hsps.size(), gaps.size());
     std::vector<McGapCell> cells(2100);
     // the windowed 12-byte-cell form the kernel runs (mc_align_gapped_win) must return what the full-size form returns
-    struct HostWin {
-        std::vector<int> H, D; std::vector<uint32_t> PH, PD;
-        explicit HostWin(int w) : H(w), D(w), PH(w), PD(w) {}
-        void load(int c, int &h, int &d, uint32_t &ph, uint32_t &pd) const { h = H[c]; d = D[c]; ph = PH[c]; pd = PD[c]; }
-        void store(int c, int h, int d, uint32_t ph, uint32_t pd)
-        {   // the kernel's cell packs H and D into 16 bits each: what it would read back
-            H[c] = (int)(int16_t)h; D[c] = (int)(int16_t)d; PH[c] = ph; PD[c] = pd;
-        }
-        int loadH(int c) const { return H[c]; }
+    struct HostWin {   // the kernel's 8-byte cell (mc_gap_pack): what it would read back
+        std::vector<uint32_t> W0, W1; uint32_t ovf = 0;
+        explicit HostWin(int w) : W0(w), W1(w) {}
+        void load(int c, int &h, int &d, uint32_t &ph, uint32_t &pd) const { mc_gap_unpack(W0[c], W1[c], h, d, ph, pd); }
+        void store(int c, int h, int d, uint32_t ph, uint32_t pd) { ovf |= mc_gap_pack(h, d, ph, pd, W0[c], W1[c]); }
+        int loadH(int c) const { return (int)(W0[c] << 20) >> 20; }
     };
     const int WIN = getenv("MC_GAP_WIN") ? atoi(getenv("MC_GAP_WIN")) : 32;
     long win_flanks = 0, win_over = 0, win_bad = 0;
@@ -246,7 +243,7 @@ int main(int argc, char **argv)
         HostWin ws(WIN);
         const McGapResult Q = mc_align_gapped_win(T, s1, st1, s2, st2, n1, n2, ws, WIN);
         win_flanks++;
-        if (Q.overflow) { win_over++; return; }
+        if (Q.overflow || ws.ovf) { win_over++; return; }
         if (Q.gain != R.gain || Q.c1 != R.c1 || Q.c2 != R.c2 || Q.ident != R.ident || Q.steps != R.steps || Q.runs != R.runs || Q.gapcols != R.gapcols) win_bad++;
     };
     for (const McGapTask &g : gaps) {
