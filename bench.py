@@ -588,7 +588,7 @@ def main():
             out["config"]["ags_abs_error_vs_reference"] = ags_abs_error(local)
         if world == 1 and args.e2e_reads > 0 and gen is not None:
             out["e2e"] = {"what": "run_pipeline(file -> AGS): native reader beside the HIP search (mc_search_files), classification, estimate; wall time of the second "
-                                  "of two calls on the same file (first_call_wall_s includes the one-time pool allocation); .gz is bounded by single-stream inflate",
+                                  "of two calls on the same file (first_call_wall_s includes the one-time pool allocation); .gz is inflated by several workers (csrc/mc_pgzip.h) as far as the CPUs the process may use allow (cgroup quota)",
                           "plain": e2e_rate(local, gen, args.e2e_reads, L, gz=False), "gz": e2e_rate(local, gen, max(1, args.e2e_reads // 10), L, gz=True)}
         if e2e_multi is not None:
             out["e2e"] = e2e_multi

@@ -36,6 +36,7 @@
 //     an exact set keyed by the precomputed hashes) and assigns output slots; the workers copy the accepted reads.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -62,6 +63,7 @@
 namespace {
 
 thread_local std::string r_err;
+thread_local bool t_peek = false;   // the caller will most likely stop after a few records (mc_quality_offset): no parallel inflate, small first regions
 
 // ------------------------------------------------------------------------------------------------------------------
 // worker pool: run(n, f) calls f(i) for i in [0, n) on the pool's threads and the caller
@@ -204,9 +206,10 @@ struct Bz2File {
 };
 
 int reader_threads();
+int inflate_threads();
 
 struct Stream {
-    enum { NBLK = 16, BLK = 1 << 22 };
+    enum { NBLK = 16, BLK = 1 << 22, BLK_PEEK = 1 << 16 };
     // plain file: one mapping; the window is a slice of it
     const uint8_t *map = nullptr; size_t map_n = 0;
     // compressed stream: a producer thread inflates BLK-sized blocks into a ring; the window lives in `buf`
@@ -225,6 +228,9 @@ struct Stream {
     bool failed = false;                        // ... because the stream is truncated / corrupt
     bool compressed = false;
     bool bad_gzip = false;                      // open() failed because a *.gz file does not hold gzip data
+    int peek_blocks = 0;                        // the first blocks of the producer are small ones
+    double t_prod_read = 0, t_prod_wait = 0, t_ext_wait = 0, t_ext_copy = 0;   // (MC_READER_TIMING)
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
     ~Stream() { close(); }
     bool open(const char *path)
@@ -246,7 +252,7 @@ struct Stream {
             // the codec follows the file NAME, as open_file does (reference :47-59): a *.gz that is not gzip is gzip.open's BadGzipFile
             if (has_ext(path, ".gz") && reg && got > 0 && !is_gz) { ::close(fd); r_err = std::string("BadGzipFile: Not a gzipped file (") + path + ")"; bad_gzip = true; return false; }
             const int gzt = reader_threads();
-            if (has_ext(path, ".gz") && reg && is_gz && gzt >= 2 && !getenv("MC_READER_SERIAL_GZ")) {
+            if (has_ext(path, ".gz") && reg && is_gz && gzt >= 2 && !t_peek && !getenv("MC_READER_SERIAL_GZ")) {
                 // several inflate workers beside the parser (one inflate stream tops out at ~0.5 GB/s of text); with one thread allowed, zlib's own reader below
                 gzmap_n = (size_t)sb.st_size;
                 void *m = mmap(nullptr, gzmap_n, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -256,7 +262,7 @@ struct Stream {
                 gzmap = (const uint8_t *)m;
                 size_t chunk = (size_t)1 << 20;                          // compressed bytes per speculative chunk
                 if (const char *v = getenv("MC_READER_GZ_CHUNK")) chunk = std::max<size_t>(4096, (size_t)atoll(v));   // (tests: many chunks on small files)
-                pgz = new mcgz::ParallelGz(gzmap, gzmap_n, std::min(gzt, 32), chunk);
+                pgz = new mcgz::ParallelGz(gzmap, gzmap_n, std::min(inflate_threads(), 32), chunk);
                 if (!pgz->start()) {                                     // (a header it does not take - cut short, odd fields: zlib's reader decides)
                     delete pgz; pgz = nullptr; munmap(m, gzmap_n); gzmap = nullptr;
                     gz = gzopen(path, "rb");
@@ -283,6 +289,7 @@ struct Stream {
             }
         }
         if (compressed) {
+            if (t_peek) peek_blocks = 8;
             for (auto &r : ring) r.resize(BLK);
             th = std::thread([this] { produce(); });
         }
@@ -290,6 +297,7 @@ struct Stream {
     }
     void close()
     {
+        if (compressed && getenv("MC_READER_TIMING") && (t_prod_read + t_ext_copy) > 0) fprintf(stderr, "reader timing: producer inflate+copy %.3f s, producer waits for ring space %.3f s | consumer waits for data %.3f s, consumer copies %.3f s\n", t_prod_read, t_prod_wait, t_ext_wait, t_ext_copy);
         if (th.joinable()) {
             { std::unique_lock<std::mutex> lk(mu); stop = true; cv.notify_all(); }
             th.join();
@@ -305,19 +313,24 @@ struct Stream {
         for (;;) {
             int slot;
             {
+                const double w0 = now();
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [this] { return count < NBLK || stop; });
+                t_prod_wait += now() - w0;
                 if (stop) return;
                 slot = tail;
             }
+            const double r0 = now();
             int n;
             bool bad = false;
             std::string msg;
+            const int want = peek_blocks > 0 ? (int)BLK_PEEK : (int)BLK;     // (a reader that may stop after a few records gets its first bytes early)
+            if (peek_blocks > 0) peek_blocks--;
             if (pgz) {
-                n = pgz->read(ring[slot].data(), (int)BLK, &bad, &msg);
+                n = pgz->read(ring[slot].data(), want, &bad, &msg);
             } else if (gz) {
-                n = gzread(gz, ring[slot].data(), (unsigned)BLK);
-                if (n < (int)BLK) {
+                n = gzread(gz, ring[slot].data(), (unsigned)want);
+                if (n < want) {
                     // gzip.open raises EOFError / BadGzipFile on a truncated or corrupt stream (reference :47-59); zlib reports a
                     // truncated stream as Z_BUF_ERROR, a damaged one as Z_DATA_ERROR - a clean end leaves Z_OK / Z_STREAM_END and gzeof
                     int errnum = 0;
@@ -325,11 +338,12 @@ struct Stream {
                     if (n < 0 || (errnum != Z_OK && errnum != Z_STREAM_END) || !gzeof(gz)) { bad = true; msg = m ? m : "read error"; }
                 }
             } else {
-                n = bz->read(ring[slot].data(), (int)BLK, &bad, &msg);
+                n = bz->read(ring[slot].data(), want, &bad, &msg);
             }
+            t_prod_read += now() - r0;
             std::unique_lock<std::mutex> lk(mu);
             if (n > 0) { ring_n[slot] = (size_t)n; tail = (tail + 1) % NBLK; count++; }
-            if (n < (int)BLK) { prod_done = true; prod_err = bad; prod_msg = msg; cv.notify_all(); return; }
+            if (n < want) { prod_done = true; prod_err = bad; prod_msg = msg; cv.notify_all(); return; }
             cv.notify_all();
         }
     }
@@ -343,17 +357,21 @@ struct Stream {
             return;
         }
         while (len < want && !at_end) {
+            const double w0 = now();
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [this] { return count > 0 || prod_done; });
+            t_ext_wait += now() - w0;
             if (count == 0) { at_end = true; failed = prod_err; break; }
             const size_t n = ring_n[head];
             lk.unlock();
+            const double c0 = now();
             if (buf_at + len + n > buf.size()) {                         // make room: move the window to the front, grow if needed
                 if (buf_at) { memmove(buf.data(), buf.data() + buf_at, len); buf_at = 0; }
                 if (len + n > buf.size()) buf.resize(std::max(len + n, buf.size() * 2));
             }
             memcpy(buf.data() + buf_at + len, ring[head].data(), n);
             len += n;
+            t_ext_copy += now() - c0;
             lk.lock();
             head = (head + 1) % NBLK; count--;
             cv.notify_all();
@@ -628,6 +646,27 @@ struct SeqSet {
 // Worker threads of the reader: MC_READER_THREADS in the environment, else the caller's cap (mc_set_host_threads: run_pipeline
 // passes args['threads'], the reference's -t), else the machine's cores up to 32.
 std::atomic<int> g_host_threads{0};
+// CPUs this process may actually use: the machine's, or the container's CPU quota when that is smaller (cgroup cpu.max / cfs quota:
+// a box that shows 256 CPUs may be allowed 16 of them - threads beyond the quota only get throttled)
+int effective_cores()
+{
+    static const int cached = [] {
+        const unsigned hc = std::thread::hardware_concurrency();
+        int n = hc ? (int)hc : 1;
+        long long quota = -1, period = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = {0};
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else {
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = 0; fclose(g); }
+        }
+        if (quota > 0 && period > 0) { const int c = (int)((quota + period - 1) / period); if (c >= 1 && c < n) n = c; }
+        return n;
+    }();
+    return cached;
+}
 int reader_threads()
 {
     if (const char *e = getenv("MC_READER_THREADS")) { const int v = atoi(e); if (v >= 1) return v > 256 ? 256 : v; }
@@ -635,6 +674,14 @@ int reader_threads()
     if (cap >= 1) return cap > 256 ? 256 : cap;
     const unsigned hc = std::thread::hardware_concurrency();
     return (int)std::min<unsigned>(hc ? hc : 1, 32);
+}
+// inflate workers of a .gz input: they keep their cores busy all the time (the parser's threads mostly wait), so no more of them
+// than three quarters of the CPUs the process may use
+int inflate_threads()
+{
+    if (const char *v = getenv("MC_READER_GZ_THREADS")) { const int k = atoi(v); if (k >= 1) return k > 64 ? 64 : k; }
+    const int t = reader_threads();
+    return std::max(1, std::min(t, std::max(2, effective_cores() * 3 / 4)));
 }
 
 // One file, region by region.  on_region(pieces) sees the stitched pieces of a region in file order and returns false to stop
@@ -645,6 +692,8 @@ int walk_file(const std::string &path, const Params &P, Pool &pool, const std::f
     if (!st.open(path.c_str())) return st.bad_gzip ? -3 : -1;
     const int T = pool.size();
     size_t region_bytes = (size_t)std::max(1, std::min(T, 16)) * ((size_t)4 << 20), piece_bytes = (size_t)256 << 10;
+    const size_t full_region = region_bytes;
+    if (t_peek) region_bytes = (size_t)1 << 16;                    // grows to the full size region by region
     if (const char *v = getenv("MC_READER_REGION_BYTES")) region_bytes = std::max<size_t>(16, (size_t)atoll(v));   // (tests: many regions and pieces on small files)
     if (const char *v = getenv("MC_READER_PIECE_BYTES")) piece_bytes = std::max<size_t>(1, (size_t)atoll(v));
     std::vector<Piece> pieces;
@@ -707,6 +756,7 @@ int walk_file(const std::string &path, const Params &P, Pool &pool, const std::f
             region_bytes *= 2; continue;
         }
         st.consume(at);
+        if (t_peek && region_bytes < full_region) region_bytes = std::min(full_region, region_bytes * 4);
         if (st.len == 0 && st.at_end) {
             if (st.failed) { r_err = "EOFError: compressed file ended before the end-of-stream marker was reached (" + path + ": " + st.prod_msg + ")"; return -3; }
             break;
@@ -733,13 +783,28 @@ struct mc_reader {
     ~mc_reader()
     {
         if (run_th.joinable()) run_th.join();
-        if (reads) {   // returning gigabytes of pages takes a while (0.17 s for the 3 GB of 20 M reads): not on the caller's time
+        if (reads) {
+            // The buffer of a closed reader is kept for the next one (one buffer, up to 8 GB): returning gigabytes of pages takes a while
+            // (0.17 s for the 3 GB of 20 M reads) and so does faulting them in again - a second run_pipeline() of the same process
+            // pays neither.  Anything larger is unmapped, off the caller's time.
             uint8_t *p = reads; const size_t n = reads_cap;
-            if (n >= ((size_t)64 << 20)) std::thread([p, n] { munmap(p, n); }).detach(); else munmap(p, n);
+            {
+                std::unique_lock<std::mutex> lk(cache_mu());
+                if (!cache_ptr() && n <= ((size_t)8 << 30) && !getenv("MC_READER_NO_CACHE")) { cache_ptr() = p; cache_cap() = n; p = nullptr; }
+            }
+            if (p) { if (n >= ((size_t)64 << 20)) std::thread([p, n] { munmap(p, n); }).detach(); else munmap(p, n); }
         }
     }
+    static std::mutex &cache_mu() { static std::mutex m; return m; }
+    static uint8_t *&cache_ptr() { static uint8_t *p = nullptr; return p; }
+    static size_t &cache_cap() { static size_t n = 0; return n; }
     bool reserve(size_t bytes)
     {
+        if (bytes <= reads_cap) return true;
+        if (!reads) {                                                  // the buffer a closed reader left behind
+            std::unique_lock<std::mutex> lk(cache_mu());
+            if (cache_ptr()) { std::unique_lock<std::shared_mutex> lk2(buf_mu); reads = cache_ptr(); reads_cap = cache_cap(); cache_ptr() = nullptr; cache_cap() = 0; }
+        }
         if (bytes <= reads_cap) return true;
         size_t want = std::max<size_t>(bytes, reads_cap * 2);
         want = (want + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
@@ -865,6 +930,7 @@ extern "C" int32_t mc_quality_offset(const char *path)
     int32_t answer = 0;
     Pool pool(reader_threads());
     Params P; P.count_only = true;
+    struct Peek { Peek() { t_peek = true; } ~Peek() { t_peek = false; } } peek;   // most files decide in their first record
     const int rc = walk_file(path, P, pool, [&](std::vector<Piece *> &order) -> bool {
         for (Piece *pc : order)
             for (const Rec &r : pc->recs) {

@@ -613,17 +613,51 @@ def _classify_m8_file(args, paths):
     return best
 
 
+class _BestHits(dict):
+    """classify_reads' result {read_id(str): [family, aln, aln/target_len, bit score]} backed by the device's best-hit array.  The dict
+    itself (a Python object per classified read: 0.35 s for the 126,000 of a 20 M-read library) is only built when somebody looks
+    into it; run_pipeline does not - aggregate_hits() sums straight from the array, in the dict's order."""
+
+    def __init__(self, best, fams):
+        dict.__init__(self)
+        self._best, self._fams, self._built = best, fams, False
+
+    def _build(self):
+        if not self._built:
+            self._built = True
+            b, fams = self._best, self._fams
+            aln = b["aln"].astype(np.float64)
+            cov = aln / b["target_len"].astype(np.float64)
+            dict.update(self, {str(r): [fams[f], a, c, s] for r, f, a, c, s in zip(b["read"].tolist(), b["family"].tolist(), aln.tolist(), cov.tolist(), b["bits"].astype(np.float64).tolist())})
+        return self
+
+    def __len__(self):
+        return len(self._best) if not self._built else dict.__len__(self)
+
+    def __bool__(self):
+        return len(self) > 0
+
+
+def _lazy(name):
+    def f(self, *a, **k):
+        return getattr(dict, name)(self._build(), *a, **k)
+    f.__name__ = name
+    return f
+
+
+for _n in ("__getitem__", "__iter__", "__contains__", "__eq__", "__ne__", "__repr__", "__setitem__", "__delitem__", "__reduce__", "__reduce_ex__", "__or__", "__ror__", "__ior__",
+           "keys", "values", "items", "get", "pop", "popitem", "setdefault", "update", "copy", "clear"):
+    setattr(_BestHits, _n, _lazy(_n))
+_BestHits.__hash__ = None
+
+
 def classify_reads(args, paths):
     """{read_id(str): [family, aln, aln/target_len, bit score]} of the best passing hit of every read."""
     if args["verbose"]:
         print("Filtering hits...")
     cache = _run_cache.get(paths["tempfile"], {})
     if cache.get("best") is not None:
-        fams = cache["families"]
-        b = cache["best"]                # ascending read id = the order the reference meets them in the m8
-        aln = b["aln"].astype(np.float64)
-        cov = aln / b["target_len"].astype(np.float64)
-        best_hits = {str(r): [fams[f], a, c, s] for r, f, a, c, s in zip(b["read"].tolist(), b["family"].tolist(), aln.tolist(), cov.tolist(), b["bits"].astype(np.float64).tolist())}
+        best_hits = _BestHits(cache["best"], cache["families"])      # ascending read id = the order the reference meets them in the m8
     else:
         best_hits = _classify_m8_file(args, paths)
     if len(best_hits) == 0:
@@ -637,6 +671,22 @@ def classify_reads(args, paths):
 def aggregate_hits(args, paths, best_hits):
     """Per family: number of hits, summed aln/target_len, or summed aln, as pars.map's aln_stat says."""
     optpars = find_opt_pars(None, args["read_length"])
+    if isinstance(best_hits, _BestHits) and not best_hits._built:
+        # the same sums from the array: families in the order of their first hit (the dict's insertion order - estimate's weighted
+        # sum runs over it), every family's increments added one after the other in read order (np.add.accumulate is that running sum)
+        b, fams = best_hits._best, best_hits._fams
+        fam = b["family"]
+        aln = b["aln"].astype(np.float64)
+        cov = aln / b["target_len"].astype(np.float64)
+        present, first = np.unique(fam, return_index=True)
+        agg = {}
+        for f in present[np.argsort(first)].tolist():
+            name = fams[f]
+            stat = optpars[name]["aln_stat"]
+            sel = fam == f
+            inc = np.ones(int(sel.sum())) if stat == "hits" else cov[sel] if stat == "cov" else aln[sel]
+            agg[name] = float(np.add.accumulate(inc)[-1])
+        return agg
     agg = {}
     for fam, aln, cov, score in best_hits.values():
         stat = optpars[fam]["aln_stat"]
