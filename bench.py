@@ -176,7 +176,8 @@ def derived(prof, stage):
     if c.get("TCC_HIT_sum") is not None and (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)) > 0:
         out["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
     # what binds the kernel, by the counters
-    cand = {"valu_issue": out.get("issue_frac", 0.0), "salu_issue": out.get("salu_frac", 0.0), "hbm": out.get("hbm_frac", 0.0)}
+    # (for the gather kernels the bytes that certainly moved - the lower bound - decide: the upper bound assumes a whole 128-byte line per item)
+    cand = {"valu_issue": out.get("issue_frac", 0.0), "salu_issue": out.get("salu_frac", 0.0), "hbm": out.get("hbm_frac_lower", out.get("hbm_frac", 0.0))}
     bound = max(cand, key=cand.get)
     if out.get("wait_frac", 0.0) >= 0.6 and cand[bound] < 0.5:
         bound = "latency"
@@ -562,7 +563,7 @@ def main():
                                   "the index is 110 MB; hbm_frac_lower: the same with one 64-byte half line per scattered request); issue_frac = SQ_INSTS_VALU x 4 / "
                                   "(1024 SIMDs x kernel cycles), salu_frac = SQ_INSTS_SALU / (256 scalar units x kernel cycles) - the two issue side by side and are "
                                   "not added -, kernel cycles = profiled duration x 2.4 GHz; wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES; valu_lanes_of_64 = "
-                                  "SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU; bound = the largest of issue_frac, salu_frac and hbm_frac ('latency' when all are "
+                                  "SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU; bound = the largest of issue_frac, salu_frac and hbm_frac (hbm_frac_lower where there is one; 'latency' when all are "
                                   "below 0.5 and wait_frac >= 0.6). No kernel of this path is HBM bound: the nominal roofline (nominal_bound) is kept because "
                                   "the metric asks for it.",
                          "all_kernels": {k: dict({"ms_per_step": round(kseq[k], 3), "algorithmic_GBps": round(per_launch[k] / (kseq[k] * 1e-3) / 1e9, 2)},

@@ -1793,7 +1793,11 @@ struct mc_handle {
     const uint8_t *reads_dev = nullptr;   // resident read set (own buffer or attached caller memory)
     McCtx ctx[MC_NCTX];
     // host results: rows of the last run land in pinned memory; mc_search() accumulates its batches in all_rows
-    mc_row *pin_rows = nullptr; size_t pin_cap = 0;
+    // The rows travel to the host while the caller goes on (two pinned buffers in turn, a stream and an event of their own):
+    // mc_run_range() returns when the best hits are there; whoever looks at the rows waits for their copy (rows_wait).
+    mc_row *pin_slot[2] = {nullptr, nullptr}; size_t pin_slot_cap[2] = {0, 0}; int pin_cur = 0;
+    mc_row *pin_rows = nullptr; size_t pin_cap = 0;                // the slot of the current run
+    hipStream_t rows_stream = nullptr; hipEvent_t ev_rows = nullptr; bool rows_pending = false, rows_ever = false;
     std::vector<mc_row> all_rows, split_rows;                       // accumulated over the batches of a stream / over the halves of a range that overflowed
     const mc_row *res_rows = nullptr; int64_t n_res_rows = 0;
     std::vector<mc_best_hit> best; mc_stats stats;
@@ -1840,7 +1844,9 @@ extern "C" void mc_close(mc_handle *h)
     for (McCtx &c : h->ctx) ctx_free(c);
     for (int k = 0; k < 2; k++) { if (h->stage_pin[k]) (void)hipHostFree(h->stage_pin[k]); if (h->stage_dev[k]) (void)hipFree(h->stage_dev[k]); }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
-    if (h->pin_rows) (void)hipHostFree(h->pin_rows);
+    if (h->rows_stream) { (void)hipStreamSynchronize(h->rows_stream); (void)hipStreamDestroy(h->rows_stream); }
+    if (h->ev_rows) (void)hipEventDestroy(h->ev_rows);
+    for (mc_row *p : h->pin_slot) if (p) (void)hipHostFree(p);
     delete h;
 }
 
@@ -1865,6 +1871,7 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
         HIPCK(hipHostMalloc((void **)&c.h_c, sizeof(uint32_t) * C_N, hipHostMallocDefault));
         HIPCK(hipHostMalloc((void **)&c.h_stats, sizeof(unsigned long long) * S_N, hipHostMallocDefault));
     }
+    HIPCK(hipStreamCreate(&h->rows_stream)); HIPCK(hipEventCreateWithFlags(&h->ev_rows, hipEventDisableTiming));
     const McHostIndex &H = h->H;
     if (dalloc(&h->d_res_base, H.res.size() + 128) || dalloc(&h->d_off, H.off.size()) || dalloc(&h->d_bstart, H.bstart.size()) || dalloc(&h->d_post, H.post.size() + 1) ||
         dalloc(&h->d_keys, H.keys.size()) || dalloc(&h->d_fam, (size_t)nseq) || dalloc(&h->d_T, 1) || dalloc(&h->d_P, 1)) return -1;
@@ -2221,6 +2228,7 @@ static int stage_d(mc_handle *h, McCtx &c)
         HIPCK(hipStreamWaitEvent(st, c.ev_join, 0));
         size_t bytes = c.sorttmp_bytes;
         HIPCK(rocprim::exclusive_scan(c.d_sorttmp, bytes, c.d_nrow, c.d_rowoff, 0u, (size_t)nheads, rocprim::plus<uint32_t>(), st));
+        if (h->rows_ever) HIPCK(hipStreamWaitEvent(st, h->ev_rows, 0));   // (the rows of the run before may still be leaving d_rows)
         k_emit_rows<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(c.d_heads, nheads, c.d_nrow, c.d_rowoff, c.d_tmp, c.d_rows, c.cap_rows, c.d_bestof, c.d_best, c.d_counters, h->best_only ? 0 : 1);
     }
     HIPCK(hipEventRecord(c.ev[6], st));
@@ -2233,9 +2241,14 @@ static int stage_d(mc_handle *h, McCtx &c)
 static int stage_e(mc_handle *h, McCtx &c, size_t rows_at)
 {
     hipStream_t st = c.stream;
-    if (c.nrows) HIPCK(hipMemcpyAsync(h->pin_rows + rows_at, c.d_rows, sizeof(McRow) * c.nrows, hipMemcpyDeviceToHost, st));
+    if (c.nrows) HIPCK(hipMemcpyAsync(h->pin_rows + rows_at, c.d_rows, sizeof(McRow) * c.nrows, hipMemcpyDeviceToHost, h->rows_stream));   // (the part's stream has been waited for: d_rows is final)
     if (c.nbest) HIPCK(hipMemcpyAsync(c.h_best, c.d_best, sizeof(McBestHit) * c.nbest, hipMemcpyDeviceToHost, st));
     return 0;
+}
+
+static void rows_wait(mc_handle *h)
+{   // the rows of the last run are on their way to the host: wait for them
+    if (h->rows_pending) { (void)hipEventSynchronize(h->ev_rows); h->rows_pending = false; }
 }
 
 static void stats_add(mc_stats &tot, const mc_stats &s)
@@ -2263,6 +2276,7 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         rc = run_range_once(h, first + off, nb, first_read_id + off);
         if (rc == -2 && nb > 1) { step = std::max<int64_t>(1, nb / 2); continue; }
         if (rc) return rc;
+        rows_wait(h);
         rows.insert(rows.end(), h->res_rows, h->res_rows + h->n_res_rows);
         best.insert(best.end(), h->best.begin(), h->best.end());
         stats_add(tot, h->stats);
@@ -2280,6 +2294,7 @@ static int run_range_once(mc_handle *h, int64_t first, int64_t count, int64_t fi
     HIPCK(hipSetDevice(h->device));
     memset(&h->stats, 0, sizeof h->stats);
     h->res_rows = nullptr; h->n_res_rows = 0; h->best.clear();
+    h->pin_cur ^= 1; h->pin_rows = h->pin_slot[h->pin_cur]; h->pin_cap = h->pin_slot_cap[h->pin_cur];   // (the other slot may still be receiving the rows of the run before)
     h->stats.reads = count;
     if (count == 0) return 0;
     // parts: two halves (small ranges: one part)
@@ -2307,18 +2322,19 @@ static int run_range_once(mc_handle *h, int64_t first, int64_t count, int64_t fi
         c.nrows = (c.nh && !h->best_only) ? c.h_c[C_ROWS] : 0u; c.nsegs = c.h_c[C_SEGS]; c.nbest = c.h_c[C_BEST];
         const size_t need = nrows + c.nrows;
         if (need > h->pin_cap) {                                     // grow the pinned row buffer (with room for the parts still to come)
-            for (int q = 0; q < p; q++) (void)hipStreamSynchronize(h->ctx[q].stream);      // (their copies write into the old buffer)
+            (void)hipStreamSynchronize(h->rows_stream);                  // (copies of earlier parts / of the run before write into the old buffers)
             const size_t want = need + (size_t)(np - 1 - p) * ((size_t)c.nrows + c.nrows / 4) + need / 4 + 1024;
             mc_row *nb = nullptr;
             if (hipHostMalloc((void **)&nb, want * sizeof(mc_row), hipHostMallocDefault) != hipSuccess) { g_err = "out of pinned host memory for the rows"; rc = -1; break; }
             if (nrows) memcpy(nb, h->pin_rows, nrows * sizeof(mc_row));
             if (h->pin_rows) (void)hipHostFree(h->pin_rows);
-            h->pin_rows = nb; h->pin_cap = want;
+            h->pin_rows = nb; h->pin_cap = want; h->pin_slot[h->pin_cur] = nb; h->pin_slot_cap[h->pin_cur] = want;
         }
         rc = stage_e(h, c, nrows);
         nrows += c.nrows;
     }
-    if (rc) { for (int p = 0; p < np; p++) (void)hipStreamSynchronize(h->ctx[p].stream); return rc; }
+    if (rc) { for (int p = 0; p < np; p++) (void)hipStreamSynchronize(h->ctx[p].stream); (void)hipStreamSynchronize(h->rows_stream); return rc; }
+    if (nrows) { HIPCK(hipEventRecord(h->ev_rows, h->rows_stream)); h->rows_pending = true; h->rows_ever = true; }
     MC_ALL(rc = stage_wait(c))
 #undef MC_ALL
     if (rc) return rc;
@@ -2419,7 +2435,7 @@ static int run_stream(mc_handle *h, const std::function<int64_t(uint8_t *, int64
         h->reads_dev = slot[k].dev; h->nreads = slot[k].n;
         rc = mc_run_range(h, 0, slot[k].n, first_read_id + slot[k].first);      // (a pool overflow is answered inside: smaller ranges)
         if (rc == 0) {
-            if (h->keep_rows) all_rows.insert(all_rows.end(), h->res_rows, h->res_rows + h->n_res_rows);
+            if (h->keep_rows) { rows_wait(h); all_rows.insert(all_rows.end(), h->res_rows, h->res_rows + h->n_res_rows); }
             all_best.insert(all_best.end(), h->best.begin(), h->best.end());
             stats_add(tot, h->stats);
         }
@@ -2514,6 +2530,7 @@ extern "C" int mc_grid_classify(mc_handle *h, const double *aln_covs, int32_t n_
     memset(count_hits, 0, nout * 8); memset(count_aln, 0, nout * 8); memset(count_cov, 0, nout * 8);
     const int64_t nrows = h->n_res_rows;
     if (nrows == 0) return 0;
+    rows_wait(h);
     McRow *d_rows = nullptr; unsigned long long *d_bins = nullptr;
     HIPCK(hipMalloc((void **)&d_rows, (size_t)nrows * sizeof(McRow)));
     if (hipMalloc((void **)&d_bins, nbins * 24) != hipSuccess) { (void)hipFree(d_rows); g_err = "out of device memory"; return -1; }
@@ -2554,13 +2571,14 @@ extern "C" int mc_set_best_hits_only(mc_handle *h, int on)
     return 0;
 }
 
-extern "C" int64_t mc_result_rows(mc_handle *h, const mc_row **rows) { if (!h) return -1; *rows = h->res_rows; return h->n_res_rows; }
+extern "C" int64_t mc_result_rows(mc_handle *h, const mc_row **rows) { if (!h) return -1; rows_wait(h); *rows = h->res_rows; return h->n_res_rows; }
 extern "C" int64_t mc_result_best_hits(mc_handle *h, const mc_best_hit **hits) { if (!h) return -1; *hits = h->best.data(); return (int64_t)h->best.size(); }
 extern "C" int mc_result_stats(mc_handle *h, mc_stats *out) { if (!h) return -1; *out = h->stats; return 0; }
 
 static int write_m8(mc_handle *h, const char *path, int append, const char *const *query_names, int64_t n_names, int64_t first_read_id)
 {
     if (!h) { g_err = "null handle"; return -1; }
+    rows_wait(h);
     FILE *f = fopen(path, append ? "a" : "w");
     if (!f) { g_err = std::string("cannot open ") + path; return -1; }
     setvbuf(f, nullptr, _IOFBF, 1 << 22);
