@@ -1129,7 +1129,7 @@ __global__ void __launch_bounds__(256) k_gap_emit(const McTables *__restrict__ T
 #define MC_GAP_WIN 36   // columns of the LDS window of the first launch (18 KB per wave: eight waves per CU; per 1 M reads of 150 / 300 bp, first + second launch:
                         // 40 columns x 7 waves 2.00 + 0.41 / 9.49 + 1.05 ms, 36 x 8: 1.73 + 0.44 / 8.19 + 1.64, 32 x 9: 1.85 + 0.81 / 8.43 + 5.89)
 #define MC_GAP_WIN2 64  // ... of the second one, for the flanks whose band left the first (32 KB per wave)
-#define MC_GAP_LANES2 16 // lanes of a wave that take flanks in the second launch (300 bp, per 1 M reads: 4 lanes 2.2 ms, 8: 1.55, 16 or 64: 0.98)
+#define MC_GAP_LANES2 64 // lanes of a wave that take flanks in the second launch (per 1 M reads of 300 bp behind a 36-column first launch: 16 lanes 1.65 ms, 32: 1.43, 64: 0.93)
 
 __device__ __forceinline__ McFlankOut mc_flank_out(const McGapResult &R)
 {
