@@ -356,7 +356,7 @@ def main():
     ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline on >= 1 M reads at -z 1 / 8 / all cores (takes ~20 min)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ags-check", action="store_true", help="skip the run_pipeline AGS comparison on the reference's own inputs")
-    ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the end-to-end (file -> AGS) measurement (plain FASTQ; a tenth of it for .gz); 0 = skip")
+    ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the end-to-end (file -> AGS) measurement (plain FASTQ; a fifth of it, at least 4 M, for .gz); 0 = skip")
     ap.add_argument("--no-best-only-leg", action="store_true", help="skip the extra timed leg with mc_set_best_hits_only (what run_pipeline runs)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL, one GPU per rank (the measurement); gloo: all ranks on GPU 0, reductions on the host - "
                                                                                "only to exercise the N > 1 code path on a one-GPU box")
@@ -590,7 +590,7 @@ def main():
         if world == 1 and args.e2e_reads > 0 and gen is not None:
             out["e2e"] = {"what": "run_pipeline(file -> AGS): native reader beside the HIP search (mc_search_files), classification, estimate; wall time of the second "
                                   "of two calls on the same file (first_call_wall_s includes the one-time pool allocation); .gz is inflated by several workers (csrc/mc_pgzip.h) as far as the CPUs the process may use allow (cgroup quota)",
-                          "plain": e2e_rate(local, gen, args.e2e_reads, L, gz=False), "gz": e2e_rate(local, gen, max(1, args.e2e_reads // 10), L, gz=True)}
+                          "plain": e2e_rate(local, gen, args.e2e_reads, L, gz=False), "gz": e2e_rate(local, gen, max(1, min(args.e2e_reads, max(args.e2e_reads // 5, 4_000_000))), L, gz=True)}
         if e2e_multi is not None:
             out["e2e"] = e2e_multi
         print(json.dumps(out))
