@@ -2329,6 +2329,14 @@ static int run_range_once(mc_handle *h, int64_t first, int64_t count, int64_t fi
             if (nrows) memcpy(nb, h->pin_rows, nrows * sizeof(mc_row));
             if (h->pin_rows) (void)hipHostFree(h->pin_rows);
             h->pin_rows = nb; h->pin_cap = want; h->pin_slot[h->pin_cur] = nb; h->pin_slot_cap[h->pin_cur] = want;
+            const int other = h->pin_cur ^ 1;                            // the other slot grows with it (pinning 300 MB takes 40 ms: not in the middle of a later run)
+            if (h->pin_slot_cap[other] < want) {
+                mc_row *ob = nullptr;
+                if (hipHostMalloc((void **)&ob, want * sizeof(mc_row), hipHostMallocDefault) == hipSuccess) {
+                    if (h->pin_slot[other]) (void)hipHostFree(h->pin_slot[other]);
+                    h->pin_slot[other] = ob; h->pin_slot_cap[other] = want;
+                }
+            }
         }
         rc = stage_e(h, c, nrows);
         nrows += c.nrows;
