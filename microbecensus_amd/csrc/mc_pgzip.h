@@ -145,7 +145,9 @@ static const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12
 
 // Reads the header of a dynamic-Huffman block (the 3 header bits are already consumed) and builds its tables.  strict: refuse
 // what zlib refuses AND what a real compressor never writes (used while guessing block starts).
-inline bool read_dynamic(Bits &br, LitHuff &lit, DistHuff &dist, bool strict)
+inline bool is_text(int c) { return c < 0x80 && (c >= 0x20 || c == '\n' || c == '\r' || c == '\t'); }
+
+inline bool read_dynamic(Bits &br, LitHuff &lit, DistHuff &dist, bool strict, bool *all_text = nullptr)
 {
     if (!br.need(14)) return false;
     const int hlit = (int)br.peek(5) + 257; br.drop(5);
@@ -178,6 +180,7 @@ inline bool read_dynamic(Bits &br, LitHuff &lit, DistHuff &dist, bool strict)
     const int dr = dist.build(lens + hlit, hdist);
     if (dr != 0) return false;
     if (strict) { int used = 0; for (int i = 0; i < hlit; i++) used += lens[i] != 0; if (used < 3) return false; }
+    if (all_text) { bool t = true; for (int i = 0; i < 256; i++) if (lens[i] && !is_text(i)) { t = false; break; } *all_text = t; }   // (a compressor gives codes to the bytes that occur)
     return true;
 }
 
@@ -286,14 +289,17 @@ struct Spec {
                 pos += len;
                 br.init(base, end, (uint64_t)(src + len - base) * 8);
             } else {
+                bool all_text = false;
                 if (btype == 1) fixed_tables(lit, dist);
-                else if (!read_dynamic(br, lit, dist, false)) return false;
+                else if (!read_dynamic(br, lit, dist, false, &all_text)) return false;
+                if (mstart < 0 && btype == 2 && !all_text) return false;       // not text: left to the sequential path
+                const bool check_lit = mstart < 0 && btype == 1;           // (a fixed-Huffman block has a code for every byte: look at each literal)
                 for (;;) {
                     if (pos + 300 > cap) { cap *= 2; out.reserve(cap, pos); o = out.data(); }
                     int sym = lit.decode(br);
                     if (sym < 0) return false;
                     if (sym < 256) {
-                        if (mstart < 0 && (sym >= 0x80 || (sym < 0x20 && sym != '\n' && sym != '\r' && sym != '\t'))) return false;   // not text: left to the sequential path
+                        if (check_lit && !is_text(sym)) return false;
                         o[pos++] = (uint16_t)sym;
                         continue;
                     }
