@@ -130,6 +130,18 @@ MC_HD int mc_nt_idx_rc(uint8_t c)
     return c == 'A' ? 0 : c == 'G' ? 1 : (c == 'T' || c == 'U') ? 2 : c == 'C' ? 3 : -1;
 }
 
+// The same two maps without compare chains: (c >> 1) & 3 separates the upper-case bases (A 0, C 1, T and U 2, G 3); a 32-bit set
+// says which of 'A'..'`' are bases at all, a packed permutation turns the separated code into the index.
+#define MC_NT_FWD_SET 0x00080045u    // A C G T
+#define MC_NT_FWD_PERM 0xC6u         // A -> 2, C -> 1, T -> 0, G -> 3
+#define MC_NT_RC_SET 0x00180045u     // A C G T U
+#define MC_NT_RC_PERM 0x6Cu          // A -> 0, C -> 3, T/U -> 2, G -> 1
+MC_HD int mc_nt_code(uint32_t c, uint32_t set, uint32_t perm)
+{
+    const uint32_t k = c - 0x41u;
+    return (k < 32u && ((set >> k) & 1u)) ? (int)((perm >> (((c >> 1) & 3u) * 2)) & 3u) : -1;
+}
+
 MC_HD int mc_translate_frame(const McTables &T, const uint8_t *read, int len, int frame, uint8_t *prot)
 {
     int o = frame % 3, n = (len - o) / 3, i;

@@ -89,10 +89,20 @@ struct McSegWaveLds { unsigned long long best[64]; uint32_t pre[66]; uint32_t pr
 static_assert(sizeof(McHsp) == 48 && sizeof(McGapTask) % 4 == 0, "k_eval_seeds copies its staging buffers as 16- and 4-byte words");
 static_assert(sizeof(McSegWaveLds) == 1488, "MC_TS_STAGE reserves 1488 bytes per wave");
 #ifdef MC_EXP_TIMING
-__device__ unsigned long long g_ts_acc[8], g_ts_cnt[8];
-#define MC_TS_TICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane == 0) { atomicAdd(&g_ts_acc[tcat_], now_ - tlast_); atomicAdd(&g_ts_cnt[tcat_], 1ull); } tlast_ = now_; tcat_ = (k); } while (0)
+__device__ unsigned long long g_ts_acc[12], g_ts_cnt[12];
+// (accumulated per wave in LDS and added to the global counters once at the end: an atomic per tick queues in front of the kernel's own loads and
+// turns up as time of whichever phase touches global memory next)
+#define MC_TS_TICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane == 0) { ts_acc_[tcat_] += now_ - tlast_; ts_acc_[12 + tcat_] += 1; } tlast_ = now_; tcat_ = (k); } while (0)
+#define MC_TS_BEGIN(k) __shared__ unsigned long long ts_acc_[24]; if (lane < 24) ts_acc_[lane] = 0; mc_wave_sync(); unsigned long long tlast_ = __builtin_readcyclecounter(); int tcat_ = (k)
+#define MC_TS_PARAMS , unsigned long long &tlast_, int &tcat_, unsigned long long *ts_acc_
+#define MC_TS_ARGS , tlast_, tcat_, ts_acc_
+#define MC_TS_END do { mc_wave_sync(); if (lane < 12) { atomicAdd(&g_ts_acc[lane], ts_acc_[lane]); atomicAdd(&g_ts_cnt[lane], ts_acc_[12 + lane]); } } while (0)
 #else
 #define MC_TS_TICK(k) do { } while (0)
+#define MC_TS_BEGIN(k) do { } while (0)
+#define MC_TS_PARAMS
+#define MC_TS_ARGS
+#define MC_TS_END do { } while (0)
 #endif
 #define MC_SEG_KEY_ONE 0xBFF0000000000000ull   // order-preserving key of 1.0 (the initial minprob of Seg::trim)
 
@@ -103,12 +113,10 @@ __device__ __forceinline__ unsigned long long mc_seg_key(double x)
 }
 
 __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx, const uint64_t *__restrict__ segtab, uint8_t *prot, int n, bool act, const McSegWS ws, McSegWaveLds *WL,
-                                         const uint8_t *lds0, int lane)
+                                         const uint8_t *lds0, int lane MC_TS_PARAMS)
 {
     const int W = (n <= 11) ? 8 : 12;
-#ifdef MC_EXP_TIMING
-    unsigned long long tlast_ = __builtin_readcyclecounter(); int tcat_ = 0;   // 0 flags 1 advance 2 numbering 3 class-0 rounds 4 class-1 rounds 5 reduction 6 owners
-#endif
+    MC_TS_TICK(0);   // 0 flags 1 advance 2 numbering 3 class-0 rounds 4 class-1 rounds 5 reduction 6 owners 7 mask | the kernel: 8 staging 9 translation 10 write-out
     enum { POP = 0, SCAN = 1, WAIT = 2, DONE = 3 };
     int st = (act && W <= n) ? POP : DONE;
     // the window flags of the frame, once (mc_seg_mask_fx2 in mc_core.h is this function for one frame): every segment the
@@ -290,7 +298,43 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
     }
     MC_TS_TICK(7);
     if (any) for (int k = 0; k < n; k++) if (mc_bits_test(mk, k)) prot[k] = MC_INV;
-    MC_TS_TICK(0);
+    MC_TS_TICK(10);
+}
+
+// mc_translate_frame for a lane of k_translate_seg.  The plain form reads three bases, walks two compare chains per base, looks the
+// codon up in the tables in global memory and stores one byte - and as the bases and the frame are both bytes in LDS, every store
+// orders the loads behind it: one codon at a time at the latency of a global load, half of the kernel's time (cycle counters).
+// Here: the codon table lies in LDS (cod, 64 bytes), the bases of 8 codons are read together, indices come from mc_nt_code
+// (shifts and masks), the 8 residues leave as two words.  prot is 4-byte aligned.
+__device__ __forceinline__ int mc_translate_frame_lds(const uint8_t *cod, const uint8_t *read, int len, int frame, uint8_t *prot)
+{
+    const int o = frame % 3;
+    int n = (len - o) / 3;
+    if (n < 0) n = 0;
+    const bool rc = frame >= 3;
+    const uint32_t set = rc ? MC_NT_RC_SET : MC_NT_FWD_SET, perm = rc ? MC_NT_RC_PERM : MC_NT_FWD_PERM;
+    const uint8_t *p = read + (rc ? len - 1 - o : o);                // base k of the frame: p[k] forward, p[-k] on the reverse strand
+    const int s = rc ? -1 : 1;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint32_t b[24], w[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 24; k++) b[k] = p[s * (3 * i + k)];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int a0 = mc_nt_code(b[3 * k], set, perm), a1 = mc_nt_code(b[3 * k + 1], set, perm), a2 = mc_nt_code(b[3 * k + 2], set, perm);
+            const uint32_t aa = cod[(16 * a0 + 4 * a1 + a2) & 63];
+            w[k >> 2] |= ((a0 | a1 | a2) < 0 ? (uint32_t)MC_INV : aa) << (8 * (k & 3));
+        }
+        *(uint32_t *)(prot + i) = w[0];
+        *(uint32_t *)(prot + i + 4) = w[1];
+    }
+    for (; i < n; i++) {
+        const int a0 = mc_nt_code(p[s * (3 * i)], set, perm), a1 = mc_nt_code(p[s * (3 * i + 1)], set, perm), a2 = mc_nt_code(p[s * (3 * i + 2)], set, perm);
+        const uint8_t aa = cod[(16 * a0 + 4 * a1 + a2) & 63];
+        prot[i] = (a0 | a1 | a2) < 0 ? (uint8_t)MC_INV : aa;
+    }
+    return n;
 }
 
 // One thread per (read, frame).  The workgroup's reads are staged into LDS with coalesced loads, every thread translates its
@@ -308,11 +352,17 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(MC_
     const int rbytes = nr * L;
     const int stride = MC_TS_STRIDE(FP);                         // per-thread LDS row: prot[FP] comp[20] sv[24] stk[32]
     __shared__ int32_t fxs[64];                                  // fixed-point entropy tables (mc_seg_mask_fx)
+#ifdef MC_EXP_TIMING
+    const int lane = mc_lane();
+#endif
+    MC_TS_BEGIN(8);
     uint8_t *sreads = smem;
     const int nlnf = MC_TS_NLNF(FP);
     double *lnf = (double *)(smem + (STAGED ? MC_TS_STAGE(L) : MC_TS_STAGE(0)));   // ln n! for n <= max(frame length, 20): all the trimming asks for
     uint8_t *rows = (uint8_t *)(lnf + nlnf);
+    __shared__ __attribute__((aligned(4))) uint8_t cod[64];      // the codon table
     if (tid < 64) fxs[tid] = T->seg_dout[tid];                   // seg_dout, seg_din, seg_tlo, seg_thi are contiguous
+    if (tid < 16) ((uint32_t *)cod)[tid] = ((const uint32_t *)T->codon)[tid];
     for (int i = tid; i < nlnf; i += MC_TS_THREADS) lnf[i] = T->lnfac[i];
     if (STAGED) {   // coalesced staging of this block's reads: 4 bytes per lane where the slice allows it (it starts at r0*L: any alignment)
         const uint8_t *src = reads + r0 * L;
@@ -324,14 +374,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(MC_
         for (int i = nhead + 4 * nw + tid; i < rbytes; i += MC_TS_THREADS) sreads[i] = src[i];
     }
     __syncthreads();
+    MC_TS_TICK(9);
     const int lr = tid / 6, f = tid - lr * 6;
     uint8_t *prot = rows + (size_t)tid * stride;
     int n = 0;
-    if (lr < nr) n = STAGED ? mc_translate_frame(*T, sreads + lr * L, L, f, prot) : mc_translate_frame(*T, reads + (r0 + lr) * L, L, f, prot);
+    if (lr < nr) n = mc_translate_frame_lds(cod, STAGED ? sreads + lr * L : reads + (r0 + lr) * L, L, f, prot);
     __syncthreads();                                             // the staged reads are dead: their space becomes the SEG queues
     {
         McSegWS ws; ws.comp = prot + FP; ws.sv = prot + FP + 20; ws.stk = (int16_t *)(prot + FP + 44);
-        mc_seg_wave(lnf, fxs, segtab, prot, n, lr < nr, ws, (McSegWaveLds *)smem + (tid >> 6), rows, mc_lane());   // (stretch offsets are kept relative to the rows: 256 x 252 bytes at most, 16 bits)
+        mc_seg_wave(lnf, fxs, segtab, prot, n, lr < nr, ws, (McSegWaveLds *)smem + (tid >> 6), rows, mc_lane() MC_TS_ARGS);   // (stretch offsets are kept relative to the rows: 256 x 252 bytes at most, 16 bits)
         if (lr < nr) for (int i = n; i < FP; i++) prot[i] = MC_INV;
     }
     __syncthreads();
@@ -340,6 +391,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(MC_
         const int total = nr * 6 * FP / 4, fpw = FP / 4;
         for (int i = tid; i < total; i += MC_TS_THREADS) { const int row = i / fpw, col = i - row * fpw; dst[i] = *(const uint32_t *)(rows + (size_t)row * stride + 4 * col); }
     }
+    MC_TS_TICK(0);
+    MC_TS_END;
 }
 
 // one atomic per wave: the lanes with want == true receive consecutive slots of a global counter
@@ -2092,12 +2145,12 @@ static int stage_a(mc_handle *h, McCtx &c)
 #ifdef MC_EXP_TIMING
     {
         HIPCK(hipStreamSynchronize(st));
-        unsigned long long acc[8], cnt[8];
+        unsigned long long acc[12], cnt[12];
         HIPCK(hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_ts_acc), sizeof acc)); HIPCK(hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_ts_cnt), sizeof cnt));
-        const char *nm[8] = {"flags", "advance", "numbering", "class-0 rounds", "class-1 rounds", "reduction", "owners", "mask"};
+        const char *nm[12] = {"flags", "advance", "numbering", "class-0 rounds", "class-1 rounds", "reduction", "owners", "mask", "staging", "translation", "write-out", ""};
         const double waves = (double)((n + MC_TS_READS - 1) / MC_TS_READS) * MC_TS_WAVES;
-        for (int k = 0; k < 8; k++) fprintf(stderr, "ts-timing %-15s %9.1f cycles/wave  %8.2f entries/wave\n", nm[k], (double)acc[k] / waves, (double)cnt[k] / waves);
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < 11; k++) fprintf(stderr, "ts-timing %-15s %9.1f cycles/wave  %8.2f entries/wave  total %8.1f Mcycles\n", nm[k], (double)acc[k] / waves, (double)cnt[k] / waves, acc[k] / 1e6);
+        unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_ts_acc), z, sizeof z)); HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_ts_cnt), z, sizeof z));
     }
 #endif

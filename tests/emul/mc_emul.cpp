@@ -212,6 +212,12 @@ int main(int argc, char **argv)
             }
             flen[r * 6 + f] = n;
         }
+    if (getenv("MC_CHECK_SEG")) {   // the kernel's shift-and-mask base codes (mc_nt_code) against the compare chains, over every byte
+        int nt_bad = 0;
+        for (int c = 0; c < 256; c++) nt_bad += (mc_nt_code((uint32_t)c, MC_NT_FWD_SET, MC_NT_FWD_PERM) != mc_nt_idx((uint8_t)c)) + (mc_nt_code((uint32_t)c, MC_NT_RC_SET, MC_NT_RC_PERM) != mc_nt_idx_rc((uint8_t)c));
+        fprintf(stderr, "base codes: %d of 512 differ from the compare chains\n", nt_bad);
+        if (nt_bad) return 3;
+    }
     if (getenv("MC_CHECK_SEG")) { fprintf(stderr, "seg check: %ld frames, %ld differ from the plain restatement\n", seg_frames, seg_bad); if (seg_bad) return 3; }
     // stage 2: seed enumeration
     std::vector<McSeedTask> tasks; uint64_t lookups = 0, keyprobes = 0;

@@ -127,6 +127,7 @@ def test_seg_variants_agree_frame_by_frame(emul_bin, markers_faa, tmp_path):
     assert r.returncode == 0, err
     assert "0 disagreements over all window compositions" in err
     assert ", 0 differ from the plain restatement" in err
+    assert "base codes: 0 of 512 differ" in err
 
 
 def test_shared_algorithms_and_reader_under_sanitizers(markers_faa, tmp_path):

@@ -5,10 +5,11 @@ import numpy as np, torch
 import bench
 from microbecensus_amd import _native, synth
 names, seqs = _native.load_markers(); model = _native.load_model(); fams = model["families"]
-eng = _native.Engine(device=0); eng.set_run(150, model["pars"]["150"], fams)
-genome = synth.build_genomes(seqs, total_bp=8_000_000, seed=20261001)
+eng = _native.Engine(device=0); L_ = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+eng.set_run(L_, model["pars"][str(L_)], fams)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-reads = bench.sample_reads_device(genome, n, 150, seed=1000, device=torch.device("cuda", 0)); torch.cuda.synchronize()
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+reads = synth.GenomeReads(device=torch.device("cuda", 0), seed=20261001).single(n, L); torch.cuda.synchronize()
 eng.attach(reads.data_ptr(), n)
 for it in range(3):
     t0 = time.time(); eng.run_range(0, n); t1 = time.time(); rows, best = eng.rows(copy=False), eng.best_hits(copy=False); t2 = time.time(); st = eng.stats(); t3 = time.time()
