@@ -434,23 +434,29 @@ MC_HD uint64_t mc_seg_prob_key(double x)
     __builtin_memcpy(&u, &x, 8);
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
-MC_HD uint32_t mc_segtab_hash(uint64_t k)
+// Every pair lies in one of TWO slots (cuckoo placement, mc_build_segtab): a reader fetches both at once and never walks - with
+// linear probing one pair in seven sat behind another one, and a round of 64 lanes x 8 windows then waited for a chain of
+// dependent loads in nearly every round.
+// The key word is sparse (few low bits set in a few nibbles: multiplicative hashes of its halves collide in all 32 bits for dozens
+// of pairs), so it is first packed into 32 bits without loss - the histogram's nibbles for counts 1..8 need 19 bits of the low
+// word, the seven one-bit nibbles for counts 9..15 and the length go into the gaps - and then mixed by one multiplication.  The
+// multiplier was searched for so that the placement exists (the set of pairs is a constant; mc_build_segtab checks).
+MC_HD void mc_segtab_slots(uint64_t k, uint32_t &h1, uint32_t &h2)
 {
-    uint32_t x = (uint32_t)k * 0x9E3779B1u + (uint32_t)(k >> 32) * 0x85EBCA77u;
-    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
-    return x >> (32 - MC_SEGTAB_LOG2);
+    const uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
+    uint32_t x = (lo ^ (hi << 7) ^ (((hi >> 28) * 0x924000u) & 0x04444000u)) * 0xBA1BF32Fu;
+    x ^= x >> 15;
+    h1 = x >> (32 - MC_SEGTAB_LOG2);
+    h2 = (x >> 6) & (MC_SEGTAB_SLOTS - 1);
 }
 // tab: MC_SEGTAB_SLOTS x {key word, probability key}; an empty slot has key word 0 (no pair has an empty state vector AND length 0)
 MC_HD uint64_t mc_segtab_lookup(const uint64_t *tab, uint64_t hist, int len)
 {
     const uint64_t k = hist | ((uint64_t)len << 60);
-    uint32_t h = mc_segtab_hash(k);
-    for (;;) {
-        const uint64_t kk = tab[2 * h];
-        if (kk == k) return tab[2 * h + 1];
-        if (kk == 0) return 0;                                // (not reached: every pair a window can have is in the table)
-        h = (h + 1) & (MC_SEGTAB_SLOTS - 1);
-    }
+    uint32_t h1, h2;
+    mc_segtab_slots(k, h1, h2);
+    if (tab[2 * h1] == k) return tab[2 * h1 + 1];
+    return tab[2 * h2] == k ? tab[2 * h2 + 1] : 0;            // (0 is not reached: every pair a window can have is in the table)
 }
 
 MC_HD void mc_seg_trim_rg(const double *lnfac, const uint8_t *s, int n, int *leftend, int *rightend)

@@ -227,25 +227,31 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
                     for (int k = 0; k < len; k++) mc_rh_add(rg, s[wfirst + k]);
                     // the state vectors of the run first, then their table reads (in flight together), then the comparison in window order
                     const int cnt = wlast - wfirst + 1;
-                    uint64_t svs[8], kk[8], vv[8];
+                    uint64_t svs[8];
 #pragma unroll
                     for (int t = 0; t < 8; t++) {
-                        svs[t] = rg.hist;
+                        svs[t] = rg.hist | ((uint64_t)len << 60);
                         if (t + 1 < cnt) { mc_rh_remove(rg, s[wfirst + t]); mc_rh_add(rg, s[wfirst + t + len]); }
                     }
+                    // a pair lies in one of two slots (mc_segtab_slots): both are fetched, four windows' worth in flight at a time
 #pragma unroll
-                    for (int t = 0; t < 8; t++) {
-                        const uint64_t k = svs[t] | ((uint64_t)len << 60);
-                        const ulonglong2 e = ((const ulonglong2 *)segtab)[t < cnt ? mc_segtab_hash(k) : 0u];
-                        kk[t] = e.x; vv[t] = e.y;
-                    }
+                    for (int t0 = 0; t0 < 8; t0 += 4) {
+                        if (t0 && R <= 4) break;                             // (R is the same for the whole wave)
+                        ulonglong2 ea[4], eb[4];
 #pragma unroll
-                    for (int t = 0; t < 8; t++)
-                        if (t < cnt) {
-                            const uint64_t k = svs[t] | ((uint64_t)len << 60);
-                            const unsigned long long pk = kk[t] == k ? vv[t] : mc_segtab_lookup(segtab, svs[t], len);   // (first slot taken by another pair: walk on)
-                            if (pk < key) { key = pk; kq = qbase + (uint32_t)(wfirst + t); }
+                        for (int t = 0; t < 4; t++) {
+                            uint32_t h1, h2;
+                            mc_segtab_slots(svs[t0 + t], h1, h2);
+                            const bool in = t0 + t < cnt;
+                            ea[t] = ((const ulonglong2 *)segtab)[in ? h1 : 0u]; eb[t] = ((const ulonglong2 *)segtab)[in ? h2 : 0u];
                         }
+#pragma unroll
+                        for (int t = 0; t < 4; t++)
+                            if (t0 + t < cnt) {
+                                const unsigned long long pk = ea[t].x == svs[t0 + t] ? ea[t].y : eb[t].y;
+                                if (pk < key) { key = pk; kq = qbase + (uint32_t)(wfirst + t0 + t); }
+                            }
+                    }
                 } else {
                     mc_seg_comp(s + wfirst, len, ws.comp);
                     mc_seg_state(ws.comp, ws.sv);

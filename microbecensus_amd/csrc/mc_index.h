@@ -470,9 +470,18 @@ inline void mc_build_segtab(const double *lnfac, std::vector<uint64_t> &tab)
         {
             for (int len = (t > 2 ? t : 2); len <= 15; len++) {
                 const uint64_t k = mc_rh_of_sv(sv) | ((uint64_t)len << 60);
-                uint32_t h = mc_segtab_hash(k);
-                while (tab[2 * h] != 0) h = (h + 1) & (MC_SEGTAB_SLOTS - 1);
-                tab[2 * h] = k; tab[2 * h + 1] = mc_seg_prob_key(mc_rg_getprob(lnfac, sv, len));
+                uint64_t ck = k, cv = mc_seg_prob_key(mc_rg_getprob(lnfac, sv, len));
+                // cuckoo placement: the pair goes to its first slot and whoever sat there moves to its other one (2,452 pairs, 8,192 slots)
+                uint32_t at = 0xFFFFFFFFu;
+                for (int kick = 0;; kick++) {
+                    if (kick >= 512) { fprintf(stderr, "mc_build_segtab: no placement\n"); abort(); }   // (not reached at this load; deterministic)
+                    uint32_t h1, h2;
+                    mc_segtab_slots(ck, h1, h2);
+                    const uint32_t h = (at == h1) ? h2 : h1;                 // a displaced pair takes the slot it did not come from
+                    std::swap(ck, tab[2 * h]); std::swap(cv, tab[2 * h + 1]);
+                    at = h;
+                    if (ck == 0) break;
+                }
                 npairs++;
             }
         }
