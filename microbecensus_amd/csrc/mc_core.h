@@ -683,6 +683,55 @@ MC_HD void mc_seg_window_flags(const int32_t *fx, const uint8_t *s, int n, int W
         if (e < 20) { const int c = comp[e]; S += fx[16 + c]; comp[e] = (uint8_t)(c + 1); t++; }
     }
 }
+// The same pass with the composition in registers (20 counts of 4 bits: a window holds at most 12 residues).  With the counts in
+// memory every step is a chain of dependent byte accesses - read a count, look its term up, write it back, and the next read
+// must wait for that write; here the loop stores nothing, so the loads of the residues and of the terms run ahead.
+MC_HD void mc_seg_window_flags_rg(const int32_t *fx, const uint8_t *s, int n, int W, McBits192 &Flo, McBits192 &Fhi)
+{
+    uint64_t clo = 0; uint32_t chi = 0;
+    int S = 0, t = 0;
+    for (int i = 0; i < W; i++) {
+        const int r = s[i];
+        if (r < 20) {
+            const int sh = (r & 15) * 4;
+            const int c = (r < 16) ? (int)((clo >> sh) & 15) : (int)((chi >> sh) & 15);
+            S += fx[16 + c]; t++;
+            if (r < 16) clo += 1ull << sh; else chi += 1u << sh;
+        }
+    }
+    const int nwin = n - W + 1;
+    uint64_t wl[3] = {0, 0, 0}, wh[3] = {0, 0, 0};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int q = 0; q < 3; q++) {
+        uint64_t a = 0, b = 0;
+        const int x1 = nwin - 64 * q < 64 ? nwin - 64 * q : 64;
+        for (int xx = 0; xx < x1; xx++) {
+            const int x = 64 * q + xx;
+            a |= (uint64_t)(S >= fx[32 + t]) << xx;
+            b |= (uint64_t)(S >= fx[48 + t]) << xx;
+            if (x + 1 < nwin) {
+                const int o = s[x], e = s[x + W];
+                if (o < 20) {
+                    const int sh = (o & 15) * 4;
+                    const int c = (o < 16) ? (int)((clo >> sh) & 15) : (int)((chi >> sh) & 15);
+                    S += fx[c]; t--;
+                    if (o < 16) clo -= 1ull << sh; else chi -= 1u << sh;
+                }
+                if (e < 20) {
+                    const int sh = (e & 15) * 4;
+                    const int c = (e < 16) ? (int)((clo >> sh) & 15) : (int)((chi >> sh) & 15);
+                    S += fx[16 + c]; t++;
+                    if (e < 16) clo += 1ull << sh; else chi += 1u << sh;
+                }
+            }
+        }
+        wl[q] = a; wh[q] = b;
+    }
+    Flo.a = wl[0]; Flo.b = wl[1]; Flo.c = wl[2];
+    Fhi.a = wh[0]; Fhi.b = wh[1]; Fhi.c = wh[2];
+}
 MC_HDN void mc_seg_mask_fx2(const double *lnfac, const int32_t *fx, uint8_t *prot, int n, const McSegWS &ws)
 {
     const int W = (n <= 11) ? 8 : 12;

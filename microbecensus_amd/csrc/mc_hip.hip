@@ -124,7 +124,7 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
     McBits192 Flo, Fhi, lo, nhi, mk;
     mc_bits_clear(Flo); mc_bits_clear(Fhi); mc_bits_clear(lo); mc_bits_clear(nhi); mc_bits_clear(mk);
     if (st != DONE) {
-        mc_seg_window_flags(fx, prot, n, W, ws.comp, Flo, Fhi);
+        mc_seg_window_flags_rg(fx, prot, n, W, Flo, Fhi);
         if (!(Flo.a | Flo.b | Flo.c)) st = DONE;
     }
     int sp = 1, base = 0, m = 0, i = 0, lowlim = 0, loi = 0, hii = 0;

@@ -199,6 +199,14 @@ int main(int argc, char **argv)
                     McSegWS ws2{comp2, sv2, stk2};
                     mc_seg_mask_fx2(T.lnfac, T.seg_dout, q2.data(), n3, ws2);
                     if (n3 != n || memcmp(q2.data(), p, (size_t)n)) seg_bad++;
+                    const int W3 = (n3 <= 11) ? 8 : 12;
+                    if (W3 <= n3) {   // ... with the window flags from the register form of the pass
+                        McBits192 a0, b0, a1, b1;
+                        mc_translate_frame(T, (const uint8_t *)rs[r].data(), read_len, f, q2.data());
+                        mc_seg_window_flags(T.seg_dout, q2.data(), n3, W3, comp2, a0, b0);
+                        mc_seg_window_flags_rg(T.seg_dout, q2.data(), n3, W3, a1, b1);
+                        if (a0.a != a1.a || a0.b != a1.b || a0.c != a1.c || b0.a != b1.a || b0.b != b1.b || b0.c != b1.c) seg_bad++;
+                    }
                 }
                 if (getenv("MC_CHECK_SEG")) {   // ... and frame by frame against the plain restatement
                     std::vector<uint8_t> q(FP, MC_INV);
