@@ -545,32 +545,52 @@ __device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long
     // markers, and a lane that wrote such a range alone would keep the other 63 waiting.
     if (cnt > 0 && cnt <= MC_EN_SHORT) {
         const uint32_t sn = phase == 0 ? (9u | (3u << 8)) : (10u | (4u << 8));
+        uint32_t pst[MC_EN_SHORT];                   // the postings first, then the stores: a store between two loads orders them (the pointers may alias)
+#pragma unroll
+        for (int i = 0; i < MC_EN_SHORT; i++) pst[i] = X.post[start + (uint32_t)nst + (uint32_t)(i < cnt ? i : 0)];
 #pragma unroll
         for (int i = 0; i < MC_EN_SHORT; i++)
             if (i < cnt) {
                 McSeedTask t;
-                t.read = read; t.chrono = MC_CHRONO(frame, pos, phase, (uint32_t)nst + (uint32_t)i); t.posting = X.post[start + (uint32_t)nst + (uint32_t)i];
+                t.read = read; t.chrono = MC_CHRONO(frame, pos, phase, (uint32_t)nst + (uint32_t)i); t.posting = pst[i];
                 t.seedlen_nkey = sn;
                 tasks[base + excl + (uint32_t)i] = t;
             }
     }
-    {
-        unsigned long long mm = __ballot(cnt > MC_EN_SHORT);
-        while (mm) {
-            const int l = __builtin_ctzll(mm);
-            mm &= mm - 1;
-            const uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)excl, l);
-            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane(cnt, l);
-            const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)item, l), hi32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(item >> 32), l);
-            const unsigned long long it = ((unsigned long long)hi32 << 32) | lo32;
-            const uint32_t st0 = (uint32_t)__builtin_amdgcn_readlane((int)start, l), ns0 = (uint32_t)__builtin_amdgcn_readlane(nst, l);
-            const int p2 = (int)((it >> 36) & 0xFF), f2 = (int)((it >> 44) & 7), ph2 = (int)((it >> 47) & 63);
-            const uint32_t sn = ph2 == 0 ? (9u | (3u << 8)) : (10u | (4u << 8));
-            for (uint32_t i = (uint32_t)lane; i < c; i += 64) {
-                McSeedTask t;
-                t.read = read; t.chrono = MC_CHRONO(f2, p2, ph2, ns0 + i); t.posting = X.post[st0 + ns0 + i];
-                t.seedlen_nkey = sn;
-                tasks[base + run + i] = t;
+    {   // the long ranges as ONE list of hits, 128 of them per turn whatever range they belong to: lane x finds the range it is in
+        // (binary search over the running sums of the lanes, by permute), fetches that lane's fields and writes one hit.  Range
+        // after range - a turn of the wave each, most of them shorter than the wave, the load of the posting and the store of the
+        // hit of one range finished before the next began - took a quarter of the kernel (cycle counters).
+        const bool lng = cnt > MC_EN_SHORT;
+        if (__ballot(lng)) {
+            const uint32_t lc = lng ? (uint32_t)cnt : 0u;
+            const uint32_t lincl = mc_wave_scan_add(lc);
+            const uint32_t ltot = (uint32_t)__builtin_amdgcn_readlane((int)lincl, 63);
+            const uint32_t lexcl = lincl - lc, hi32 = (uint32_t)(item >> 32), from = start + (uint32_t)nst;
+            for (uint32_t x0 = 0; x0 < ltot; x0 += 128) {
+                uint32_t pst[2], slot[2], chr[2], snk[2];
+                bool in[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t x = x0 + 64u * (uint32_t)u + (uint32_t)lane;
+                    int ol = 0;                                            // lanes whose running sum is <= x: the owner of hit x
+#pragma unroll
+                    for (int stp = 32; stp > 0; stp >>= 1) { const uint32_t v = (uint32_t)__shfl((int)lincl, ol + stp - 1); if (v <= x) ol += stp; }
+                    ol &= 63;
+                    const uint32_t i = x - (uint32_t)__shfl((int)lexcl, ol), oh = (uint32_t)__shfl((int)hi32, ol);
+                    const uint32_t ofrom = (uint32_t)__shfl((int)from, ol), oex = (uint32_t)__shfl((int)excl, ol), onst = (uint32_t)__shfl(nst, ol);
+                    in[u] = x < ltot;
+                    const int p2 = (int)((oh >> 4) & 0xFF), f2 = (int)((oh >> 12) & 7), ph2 = (int)((oh >> 15) & 63);
+                    pst[u] = X.post[in[u] ? ofrom + i : 0u];
+                    slot[u] = base + oex + i; chr[u] = MC_CHRONO(f2, p2, ph2, onst + i); snk[u] = ph2 == 0 ? (9u | (3u << 8)) : (10u | (4u << 8));
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+                    if (in[u]) {
+                        McSeedTask t;
+                        t.read = read; t.chrono = chr[u]; t.posting = pst[u]; t.seedlen_nkey = snk[u];
+                        tasks[slot[u]] = t;
+                    }
             }
         }
     }
@@ -650,7 +670,7 @@ __device__ __forceinline__ unsigned long long mc_en_heavy(const McIndex &X, unsi
 #ifdef MC_EN_WPE                          // (experiments: force an occupancy)
 #define MC_EN_ATTR __attribute__((amdgpu_waves_per_eu(MC_EN_WPE, MC_EN_WPE)))
 #else
-#define MC_EN_ATTR
+#define MC_EN_ATTR __attribute__((amdgpu_waves_per_eu(6, 6)))   // 80 VGPRs: the 24 waves per CU of the launch (the allocator stops at 83 by itself)
 #endif
 template <int MC_EN_WAVES, bool COUNT>
 __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTables *__restrict__ T, McIndex X, const uint32_t *__restrict__ bitmap,
