@@ -1472,11 +1472,15 @@ __global__ void __launch_bounds__(256) k_heavy_lists(const uint32_t *__restrict_
 __global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
                                                 const McHsp *__restrict__ sorted, uint32_t nhsps, const uint32_t *__restrict__ heads, uint32_t nheads,
                                                 McHsp *v, McHsp *tmp, int64_t first_read_id, uint32_t *nrow_of, McBestHit *best,
-                                                const uint32_t *__restrict__ list, const uint32_t *__restrict__ nlist_p)
+                                                const uint32_t *__restrict__ light, uint32_t light_pitch, const uint32_t *__restrict__ nlight)
 {
+    // blockIdx.y = size class, the largest first: the four classes in ONE launch - a thread walks its read alone at the latency of
+    // global memory and the reads that print anything fill a fraction of the GPU, so four launches one after the other took four
+    // times the slowest thread of a class
+    const int cl = 3 - (int)blockIdx.y;
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= *nlist_p) return;                                  // (the reads of one size class that have something to print: k_heavy_lists)
-    const uint32_t s = list[idx];
+    if (idx >= nlight[cl]) return;                                // (the reads of one size class that have something to print: k_heavy_lists)
+    const uint32_t s = light[(size_t)cl * light_pitch + idx];
     const uint32_t a = heads[s];
     const uint32_t b = (s + 1 < nheads) ? heads[s + 1] : nhsps;
     const int n = (int)(b - a);
@@ -1616,6 +1620,12 @@ __device__ __forceinline__ void mc_heapw_sort(uint32_t *hw, int n)
 // std::sort by log E (mc_wave_std_sort), the rows and their classification.  Sequential, by lane 0 on packed words in LDS:
 // MergeRes' heap sort by printed log E, which has to replay libstdc++'s exact sequence of moves.
 // Same scratch layout and same results as k_finish.
+#ifdef MC_EXP_TIMING
+__device__ unsigned long long g_fh_acc[8], g_fh_cnt[8];
+#define MC_FH_TICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane == 0) { fh_acc_[fcat_] += now_ - flast_; fh_acc_[8 + fcat_] += 1; } flast_ = now_; fcat_ = (k); } while (0)
+#else
+#define MC_FH_TICK(k) do { } while (0)
+#endif
 template <int MAXN, int CTR, int CTR_NEXT>
 __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
                                                      const McHsp *__restrict__ sorted, uint32_t nhsps, const uint32_t *__restrict__ heads, uint32_t nheads,
@@ -1630,7 +1640,14 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
     const int lane = mc_lane();
     const unsigned long long lt = (1ull << lane) - 1;
     const uint32_t nheavy = counters[CTR];
+#ifdef MC_EXP_TIMING
+    __shared__ unsigned long long fh_acc_[16];
+    if (lane < 16) fh_acc_[lane] = 0;
+    __syncthreads();
+    unsigned long long flast_ = __builtin_readcyclecounter(); int fcat_ = 7;   // 0 group starts 1 groups 2 scan, items 3 sort 4 threshold, ranks 5 heap sort 6 rows 7 other
+#endif
     for (uint32_t bi = blockIdx.x; bi < nheavy; bi += gridDim.x) {
+        MC_FH_TICK(0);
         const uint32_t s = heavy[bi], a = heads[s], b = (s + 1 < nheads) ? heads[s + 1] : nhsps;
         const int n = (int)(b - a);
         const McHsp *in = sorted + a;
@@ -1655,11 +1672,13 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
             if (lane == 0) gst[ng] = (uint16_t)n;
             __syncthreads();
             // per subject: stack, reversal, sum statistics - results stay at the group's own offset of v
+            MC_FH_TICK(1);
             for (int g = lane; g < ng; g += 64) {
                 const int g0 = gst[g], g1 = gst[g + 1];
                 gkept[g] = (uint16_t)mc_finish_group(*T, X, in, g0, g1, v + a + g0, tmp + 2 * ((size_t)a + g0));
             }
             __syncthreads();
+            MC_FH_TICK(2);
             // offsets of the groups in the sequence PrintRes sorts (exclusive scan of the kept counts)
             {
                 int carry = 0;
@@ -1694,8 +1713,10 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
             for (int j = 0; j < k; j++) { McSortItem it; it.k = v[a + g0 + j].loge; it.i = (uint32_t)(g0 + j); it.pad = 0; items[o + j] = it; }
         }
         __syncthreads();
+        MC_FH_TICK(3);
         mc_wave_std_sort(items, vn, gst, gkept, gofs, s_stk, lane);   // std::sort by log E (PrintRes)
         __syncthreads();
+        MC_FH_TICK(4);
         // rows: at most 500, log E below the threshold (the items are in ascending log E, so the test is monotone)
         {
             const int lim = vn < MC_MAX_M8 ? vn : MC_MAX_M8;
@@ -1722,8 +1743,10 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
             }
         }
         __syncthreads();
+        MC_FH_TICK(5);
         if (lane == 0) mc_heapw_sort(hw, nrows);                      // MergeRes: heap sort by the printed log E
         __syncthreads();
+        MC_FH_TICK(6);
         McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);             // the groups' scratch is dead by now
         double bbits = -1.0; int bidx = 0x7fffffff, bfam = -1, baln = 0, btl = 0;
         for (int i = lane; i < nrows; i += 64) {
@@ -1745,7 +1768,13 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
             best_of[s] = bh;
         }
         __syncthreads();
+        MC_FH_TICK(7);
     }
+#ifdef MC_EXP_TIMING
+    MC_FH_TICK(7);
+    __syncthreads();
+    if (lane < 8) { atomicAdd(&g_fh_acc[lane], fh_acc_[lane]); atomicAdd(&g_fh_cnt[lane], fh_acc_[8 + lane]); }
+#endif
 }
 
 // rows of read s -> rows[rowoff[s] ...]: the m8 order (ascending read, RAPsearch2's order inside a read); the best hits of the
@@ -2301,9 +2330,9 @@ static int stage_d(mc_handle *h, McCtx &c)
                                                                                          c.d_nrow, c.d_bestof, c.d_counters, d_heavy3, nullptr);
             HIPCK(hipEventRecord(c.ev_join, c.side));
         }
-        for (int cl = 3; cl >= 0; cl--)                           // the light reads, class by class (largest first; the counts stay on the device)
-            k_finish<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, c.d_sorted, nh, c.d_heads, nheads, c.d_v, c.d_tmp,
-                                                                        c.first_read_id, c.d_nrow, c.d_bestof, d_light + (size_t)cl * light_pitch, c.d_counters + C_LIGHT0 + cl);
+        // the light reads: the four size classes side by side (the counts stay on the device; blocks past a class' count leave at once)
+        k_finish<<<dim3((nheads + 255) / 256, 4), dim3(256), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, c.d_sorted, nh, c.d_heads, nheads, c.d_v, c.d_tmp,
+                                                                       c.first_read_id, c.d_nrow, c.d_bestof, d_light, light_pitch, c.d_counters + C_LIGHT0);
         HIPCK(hipStreamWaitEvent(st, c.ev_join, 0));
         size_t bytes = c.sorttmp_bytes;
         HIPCK(rocprim::exclusive_scan(c.d_sorttmp, bytes, c.d_nrow, c.d_rowoff, 0u, (size_t)nheads, rocprim::plus<uint32_t>(), st));
@@ -2311,6 +2340,17 @@ static int stage_d(mc_handle *h, McCtx &c)
         k_emit_rows<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(c.d_heads, nheads, c.d_nrow, c.d_rowoff, c.d_tmp, c.d_rows, c.cap_rows, c.d_bestof, c.d_best, c.d_counters, h->best_only ? 0 : 1);
     }
     HIPCK(hipEventRecord(c.ev[6], st));
+#ifdef MC_EXP_TIMING
+    {
+        HIPCK(hipStreamSynchronize(st)); HIPCK(hipStreamSynchronize(c.side));
+        unsigned long long acc[8], cnt[8];
+        HIPCK(hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_fh_acc), sizeof acc)); HIPCK(hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_fh_cnt), sizeof cnt));
+        const char *nm[8] = {"group starts", "groups", "scan, items", "sort", "threshold, ranks", "heap sort", "rows", "other"};
+        for (int k = 0; k < 8; k++) fprintf(stderr, "fh-timing %-17s total %9.1f Mcycles %9llu entries\n", nm[k], acc[k] / 1e6, cnt[k]);
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_fh_acc), z, sizeof z)); HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_fh_cnt), z, sizeof z));
+    }
+#endif
     HIPCK(hipMemcpyAsync(c.h_stats, c.d_stats, sizeof(unsigned long long) * S_N, hipMemcpyDeviceToHost, st));
     return counters_to_host(c);
 }
