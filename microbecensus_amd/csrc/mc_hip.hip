@@ -1626,17 +1626,125 @@ __device__ unsigned long long g_fh_acc[8], g_fh_cnt[8];
 #else
 #define MC_FH_TICK(k) do { } while (0)
 #endif
+// the heap words of a heavy read: in its own scratch, behind the place of its rows (64 n bytes; the area holds 96 n)
+__device__ __forceinline__ uint32_t *mc_heavy_words(McHsp *tmp, uint32_t a, int n) { return (uint32_t *)((uint8_t *)(tmp + 2 * (size_t)a) + (size_t)64 * n); }
+
+// MergeRes' heap sort for the heavy reads, ONE LANE PER READ: the sort replays libstdc++'s exact sequence of moves and is a chain
+// of dependent LDS accesses - as lane 0 of the read's own wave it was half of the heavy kernels' time (cycle counters), with 63
+// lanes waiting; here 64 reads are replayed side by side.  Words transposed in LDS (word e of lane l at e * 64 + l: lanes on the
+// same word never share a bank), 502 words per lane = 128.5 KB: one wave per CU.
+#define MC_HL_H(e) lds[((e) << 6) + lane]
+__global__ void __launch_bounds__(64) k_heap_lanes(const uint32_t *__restrict__ heads, uint32_t nheads, uint32_t nhsps, McHsp *tmp, const uint32_t *__restrict__ nrow_of,
+                                                   const uint32_t *__restrict__ counters, const uint32_t *__restrict__ heavy_first)
+{
+    uint32_t *lds = (uint32_t *)mc_smem;
+    __shared__ uint32_t s_nr[64];
+    __shared__ uint32_t *s_hw[64];
+    const int lane = mc_lane();
+    const uint32_t nheavy = counters[C_HEAVY];
+    for (uint32_t slot0 = blockIdx.x * 64u; slot0 < nheavy; slot0 += gridDim.x * 64u) {
+        int n = 0;
+        {
+            const uint32_t slot = slot0 + (uint32_t)lane;
+            uint32_t *hw = nullptr;
+            if (slot < nheavy) {
+                const uint32_t e = heavy_first[slot];
+                if (e & 0x80000000u) {
+                    const uint32_t s = e & 0x7FFFFFFFu, a = heads[s], b = (s + 1 < nheads) ? heads[s + 1] : nhsps;
+                    n = (int)nrow_of[s];
+                    hw = mc_heavy_words(tmp, a, (int)(b - a));
+                }
+            }
+            if (n < 2) n = 0;                                       // (nothing to sort)
+            s_nr[lane] = (uint32_t)n; s_hw[lane] = hw;
+        }
+        __syncthreads();
+        for (int r = 0; r < 64; r++) {                               // the words of the 64 reads in, read by read (coalesced)
+            const int nr = (int)s_nr[r];
+            const uint32_t *hw = s_hw[r];
+            for (int e = 1 + lane; e <= nr; e += 64) lds[(e << 6) + r] = hw[e];
+        }
+        __syncthreads();
+        if (n >= 2) {   // mc_heapsort (mc_sort_impl.h) move for move, element e in word e + 1; the keys are the upper halves
+#define MC_HL_ADJUST(HOLE, LEN, VALUE)                                                                                             \
+    do {                                                                                                                           \
+        int hole_ = (HOLE), sc_ = hole_;                                                                                           \
+        const int top_ = hole_, len_ = (LEN);                                                                                      \
+        const uint32_t value_ = (VALUE);                                                                                           \
+        while (sc_ < (len_ - 1) / 2) {                                                                                             \
+            sc_ = 2 * (sc_ + 1);                                                                                                   \
+            const uint32_t cx_ = MC_HL_H(sc_), cy_ = MC_HL_H(sc_ + 1);            /* elements sc - 1 and sc */                      \
+            uint32_t pick_ = cy_;                                                                                                  \
+            if ((cy_ >> 16) < (cx_ >> 16)) { sc_--; pick_ = cx_; }                                                                 \
+            MC_HL_H(hole_ + 1) = pick_; hole_ = sc_;                                                                               \
+        }                                                                                                                          \
+        if ((len_ & 1) == 0 && sc_ == (len_ - 2) / 2) { sc_ = 2 * (sc_ + 1); MC_HL_H(hole_ + 1) = MC_HL_H(sc_); hole_ = sc_ - 1; } \
+        int parent_ = (hole_ - 1) / 2;                                                                                             \
+        while (hole_ > top_ && (MC_HL_H(parent_ + 1) >> 16) < (value_ >> 16)) { MC_HL_H(hole_ + 1) = MC_HL_H(parent_ + 1); hole_ = parent_; parent_ = (hole_ - 1) / 2; } \
+        MC_HL_H(hole_ + 1) = value_;                                                                                               \
+    } while (0)
+            for (int parent = (n - 2) / 2;; parent--) { MC_HL_ADJUST(parent, n, MC_HL_H(parent + 1)); if (parent == 0) break; }
+            for (int m = n; m > 1;) { m--; const uint32_t vv = MC_HL_H(m + 1); MC_HL_H(m + 1) = MC_HL_H(1); MC_HL_ADJUST(0, m, vv); }
+#undef MC_HL_ADJUST
+        }
+        __syncthreads();
+        for (int r = 0; r < 64; r++) {
+            const int nr = (int)s_nr[r];
+            uint32_t *hw = s_hw[r];
+            for (int e = 1 + lane; e <= nr; e += 64) hw[e] = lds[(e << 6) + r];
+        }
+        __syncthreads();
+    }
+}
+#undef MC_HL_H
+
+// The rows of the heavy reads in their final order, and their classification: one wave per read.
+__global__ void __launch_bounds__(64) k_heavy_rows(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
+                                                   const McHsp *__restrict__ sorted, uint32_t nhsps, const uint32_t *__restrict__ heads, uint32_t nheads,
+                                                   const McHsp *__restrict__ v, McHsp *tmp, int64_t first_read_id, const uint32_t *__restrict__ nrow_of, McBestHit *best_of,
+                                                   const uint32_t *__restrict__ counters, const uint32_t *__restrict__ heavy_first)
+{
+    const int lane = mc_lane();
+    const uint32_t nheavy = counters[C_HEAVY];
+    for (uint32_t slot = blockIdx.x; slot < nheavy; slot += gridDim.x) {
+        const uint32_t e = heavy_first[slot];
+        if (!(e & 0x80000000u)) continue;                            // (finished by lane 0 of the last wave kernel)
+        const uint32_t s = e & 0x7FFFFFFFu, a = heads[s], b = (s + 1 < nheads) ? heads[s + 1] : nhsps;
+        const int n = (int)(b - a), nrows = (int)nrow_of[s];
+        const int read_id = (int)((int64_t)sorted[a].read + first_read_id);
+        const uint32_t *hw = mc_heavy_words(tmp, a, n);
+        McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
+        double bbits = -1.0; int bidx = 0x7fffffff, bfam = -1, baln = 0, btl = 0;
+        for (int i = lane; i < nrows; i += 64) {
+            McRow r;
+            mc_fill_row(*T, read_id, v[a + (hw[i + 1] & 0xFFFFu)], r);
+            myrows[i] = r;
+            const int f = fam[r.subject], tl = (int)(X.off[r.subject + 1] - X.off[r.subject]);
+            if (mc_row_passes(*P, r, f, tl, r.frame) && (bfam < 0 || bbits < r.bits)) { bbits = r.bits; bidx = i; bfam = f; baln = r.alnlen; btl = tl; }
+        }
+        // classify_reads keeps the first row with the highest bit score: reduce (bits desc, row index asc) over the lanes
+        for (int d = 32; d > 0; d >>= 1) {
+            const double ob = __shfl_down(bbits, d);
+            const int oi = __shfl_down(bidx, d), of = __shfl_down(bfam, d), oa = __shfl_down(baln, d), ot = __shfl_down(btl, d);
+            if (of >= 0 && (bfam < 0 || ob > bbits || (ob == bbits && oi < bidx))) { bbits = ob; bidx = oi; bfam = of; baln = oa; btl = ot; }
+        }
+        if (lane == 0) {
+            McBestHit bh; bh.read = read_id; bh.family = bfam; bh.aln = bfam >= 0 ? baln : 0; bh.target_len = bfam >= 0 ? btl : 0; bh.bits = bfam >= 0 ? bbits : 0.0;
+            best_of[s] = bh;
+        }
+    }
+}
+
 template <int MAXN, int CTR, int CTR_NEXT>
 __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
                                                      const McHsp *__restrict__ sorted, uint32_t nhsps, const uint32_t *__restrict__ heads, uint32_t nheads,
                                                      McHsp *v, McHsp *tmp, int64_t first_read_id, uint32_t *nrow_of, McBestHit *best_of, uint32_t *counters,
-                                                     const uint32_t *__restrict__ heavy, uint32_t *heavy_next)
+                                                     uint32_t *heavy_first, const uint32_t *__restrict__ list, uint32_t *list_next)
 {
     McSortItem *items = (McSortItem *)mc_smem;                      // MAXN sort items, then three index arrays (dynamic LDS)
     uint16_t *gst = (uint16_t *)(items + MAXN), *gkept = gst + (MAXN + 2), *gofs = gkept + (MAXN + 2);
     __shared__ int s_vn, s_nrows;
     __shared__ int s_stk[3 * 64];
-    uint32_t *hw = (uint32_t *)gst;                                 // the heap words reuse the index arrays (8-byte aligned, >= 502 words)
     const int lane = mc_lane();
     const unsigned long long lt = (1ull << lane) - 1;
     const uint32_t nheavy = counters[CTR];
@@ -1648,7 +1756,8 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
 #endif
     for (uint32_t bi = blockIdx.x; bi < nheavy; bi += gridDim.x) {
         MC_FH_TICK(0);
-        const uint32_t s = heavy[bi], a = heads[s], b = (s + 1 < nheads) ? heads[s + 1] : nhsps;
+        const uint32_t slot = CTR == C_HEAVY ? bi : list[bi];        // position in the first list (heavy_first): the later lists hold slots
+        const uint32_t s = heavy_first[slot] & 0x7FFFFFFFu, a = heads[s], b = (s + 1 < nheads) ? heads[s + 1] : nhsps;
         const int n = (int)(b - a);
         const McHsp *in = sorted + a;
         const int read_id = (int)((int64_t)in[0].read + first_read_id);
@@ -1696,7 +1805,7 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
             punt = vn > MAXN;                                       // (the groups are recomputed by the next kernel: mc_finish_group only reads `in`)
         }
         if (punt) {
-            if (CTR_NEXT >= 0) { if (lane == 0) heavy_next[atomicAdd(&counters[CTR_NEXT < 0 ? 0 : CTR_NEXT], 1u)] = s; }
+            if (CTR_NEXT >= 0) { if (lane == 0) list_next[atomicAdd(&counters[CTR_NEXT < 0 ? 0 : CTR_NEXT], 1u)] = slot; }
             else if (lane == 0) {                                   // larger than the largest arrays: lane 0 alone, everything in the read's global scratch
                 McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
                 double *myk = (double *)(myrows + n);
@@ -1732,41 +1841,20 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
         const int nrows = s_nrows;
         for (int i = lane; i < nrows; i += 64) items[i].k = mc_round6(v[a + items[i].i].loge);
         __syncthreads();
-        {   // dense ranks of the printed keys -> heap words
+        {   // dense ranks of the printed keys -> heap words rank << 16 | index of the HSP in v, into the read's scratch behind the
+            // place of its rows (the groups' scratch is dead by now): MergeRes' heap sort and the rows follow in k_heap_lanes and
+            // k_heavy_rows
+            uint32_t *ghw = mc_heavy_words(tmp, a, n);
             int carry = 0;
             for (int i0 = 0; i0 < nrows; i0 += 64) {
                 const int i = i0 + lane;
                 const bool nw = i < nrows && i > 0 && items[i].k != items[i - 1].k;
                 const unsigned long long m = __ballot(nw);
-                if (i < nrows) hw[i + 1] = ((uint32_t)(carry + __popcll(m & (lt | (1ull << lane)))) << 16) | (uint32_t)i;
+                if (i < nrows) ghw[i + 1] = ((uint32_t)(carry + __popcll(m & (lt | (1ull << lane)))) << 16) | items[i].i;
                 carry += __popcll(m);
             }
         }
-        __syncthreads();
-        MC_FH_TICK(5);
-        if (lane == 0) mc_heapw_sort(hw, nrows);                      // MergeRes: heap sort by the printed log E
-        __syncthreads();
-        MC_FH_TICK(6);
-        McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);             // the groups' scratch is dead by now
-        double bbits = -1.0; int bidx = 0x7fffffff, bfam = -1, baln = 0, btl = 0;
-        for (int i = lane; i < nrows; i += 64) {
-            McRow r;
-            mc_fill_row(*T, read_id, v[a + items[hw[i + 1] & 0xFFFFu].i], r);
-            myrows[i] = r;
-            const int f = fam[r.subject], tl = (int)(X.off[r.subject + 1] - X.off[r.subject]);
-            if (mc_row_passes(*P, r, f, tl, r.frame) && (bfam < 0 || bbits < r.bits)) { bbits = r.bits; bidx = i; bfam = f; baln = r.alnlen; btl = tl; }
-        }
-        // classify_reads keeps the first row with the highest bit score: reduce (bits desc, row index asc) over the lanes
-        for (int d = 32; d > 0; d >>= 1) {
-            const double ob = __shfl_down(bbits, d);
-            const int oi = __shfl_down(bidx, d), of = __shfl_down(bfam, d), oa = __shfl_down(baln, d), ot = __shfl_down(btl, d);
-            if (of >= 0 && (bfam < 0 || ob > bbits || (ob == bbits && oi < bidx))) { bbits = ob; bidx = oi; bfam = of; baln = oa; btl = ot; }
-        }
-        if (lane == 0) {
-            nrow_of[s] = (uint32_t)nrows;
-            McBestHit bh; bh.read = read_id; bh.family = bfam; bh.aln = bfam >= 0 ? baln : 0; bh.target_len = bfam >= 0 ? btl : 0; bh.bits = bfam >= 0 ? bbits : 0.0;
-            best_of[s] = bh;
-        }
+        if (lane == 0) { nrow_of[s] = (uint32_t)nrows; heavy_first[slot] = s | 0x80000000u; }   // (the flag: heap sort and rows still to come)
         __syncthreads();
         MC_FH_TICK(7);
     }
@@ -2323,11 +2411,16 @@ static int stage_d(mc_handle *h, McCtx &c)
             HIPCK(hipFuncSetAttribute((const void *)k_finish_heavy<MC_FH_N3, C_HEAVY3, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
             HIPCK(hipStreamWaitEvent(c.side, c.ev_fork, 0));
             k_finish_heavy<MC_FH_N1, C_HEAVY, C_HEAVY2><<<dim3(256 * 12), dim3(64), l1, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_sorted, nh, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
-                                                                                                   c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy2);
+                                                                                                   c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy, d_heavy2);
             k_finish_heavy<MC_FH_N2, C_HEAVY2, C_HEAVY3><<<dim3(256 * 3), dim3(64), l2, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_sorted, nh, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
-                                                                                                   c.d_nrow, c.d_bestof, c.d_counters, d_heavy2, d_heavy3);
+                                                                                                   c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy2, d_heavy3);
             k_finish_heavy<MC_FH_N3, C_HEAVY3, -1><<<dim3(256), dim3(64), l3, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_sorted, nh, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
-                                                                                         c.d_nrow, c.d_bestof, c.d_counters, d_heavy3, nullptr);
+                                                                                         c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy3, nullptr);
+            // MergeRes' heap sort of all of them (a lane per read), then their rows (a wave per read)
+            const size_t lh = (size_t)(MC_MAX_M8 + 2) * 64 * 4;
+            HIPCK(hipFuncSetAttribute((const void *)k_heap_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lh));
+            k_heap_lanes<<<dim3(256), dim3(64), lh, c.side>>>(c.d_heads, nheads, nh, c.d_tmp, c.d_nrow, c.d_counters, d_heavy);
+            k_heavy_rows<<<dim3(256 * 12), dim3(64), 0, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_sorted, nh, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id, c.d_nrow, c.d_bestof, c.d_counters, d_heavy);
             HIPCK(hipEventRecord(c.ev_join, c.side));
         }
         // the light reads: the four size classes side by side (the counts stay on the device; blocks past a class' count leave at once)
