@@ -248,9 +248,22 @@ MC_HD void mc_fill_row(const McTables &T, int read_id, const McHsp &h, McRow &r)
     r.loge = h.loge; r.bits = T.bits_r[h.score]; r.score = h.score; r.frame = h.nmatch;
 }
 
+#if defined(MC_EXP_TIMING) && defined(__HIPCC__)
+__device__ unsigned long long g_fr_acc[8];           // cycle counters of the timing build: wall time of a thread per phase, summed over the threads
+#endif
+#if defined(MC_EXP_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#define MC_FR_BEGIN unsigned long long fr_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fr_last_ = __builtin_readcyclecounter()
+#define MC_FR_TICK(prev) do { const unsigned long long now_ = __builtin_readcyclecounter(); fr_acc_[prev] += now_ - fr_last_; fr_last_ = now_; } while (0)
+#define MC_FR_END do { for (int k_ = 0; k_ < 8; k_++) if (fr_acc_[k_]) atomicAdd(&g_fr_acc[k_], fr_acc_[k_]); } while (0)
+#else
+#define MC_FR_BEGIN do { } while (0)
+#define MC_FR_TICK(prev) do { } while (0)
+#define MC_FR_END do { } while (0)
+#endif
 MC_HDN int mc_finish_read(const McTables &T, const McIndex &X, const McClassPars &P, const int32_t *marker_family,
                           int read_id, const McHsp *in, int n, McHsp *v, McHsp *tmp, McRow *rows, double *krows, McSortItem *items, McBestHit *best)
 {
+    MC_FR_BEGIN;
     int vn = 0;
     for (int a = 0; a < n;) {
         int b = a;
@@ -259,18 +272,24 @@ MC_HDN int mc_finish_read(const McTables &T, const McIndex &X, const McClassPars
         vn += mc_finish_group(T, X, in, a, b, v + vn, tmp);
         a = b;
     }
+    MC_FR_TICK(0);
     for (int i = 0; i < vn; i++) { items[i].k = v[i].loge; items[i].i = (uint32_t)i; items[i].pad = 0; }
+    MC_FR_TICK(1);
     mc_std_sort(items, vn, 0);                       // std::sort by log E (PrintRes), on (key, index) items
+    MC_FR_TICK(2);
     int nrows = 0;
     best->read = read_id; best->family = -1; best->aln = 0; best->target_len = 0; best->bits = 0.0;
     while (nrows < vn && nrows < MC_MAX_M8 && v[items[nrows].i].loge < T.loge_thr) nrows++;      // PrintRes: at most 500 rows, log E below the threshold
     // MergeRes re-sorts the printed rows with std::partial_sort (a heap sort) keyed by the PRINTED log E: same heap on the
     // (key, index) items, then the rows are written once, in their final order
     for (int i = 0; i < nrows; i++) items[i].k = mc_round6(v[items[i].i].loge);
+    MC_FR_TICK(3);
     mc_heapsort(items, nrows, 0);
+    MC_FR_TICK(4);
     for (int i = 0; i < nrows; i++) {
         mc_fill_row(T, read_id, v[items[i].i], rows[i]);
     }
+    MC_FR_TICK(5);
     (void)krows;
     for (int i = 0; i < nrows; i++) {
         McRow &r = rows[i];
@@ -280,5 +299,7 @@ MC_HDN int mc_finish_read(const McTables &T, const McIndex &X, const McClassPars
             if (best->family < 0 || best->bits < r.bits) { best->family = fam; best->aln = r.alnlen; best->target_len = tl; best->bits = r.bits; }
         }
     }
+    MC_FR_TICK(6);
+    MC_FR_END;
     return nrows;
 }

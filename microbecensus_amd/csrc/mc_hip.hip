@@ -1434,7 +1434,10 @@ __global__ void k_heads(const uint32_t *__restrict__ flags, const uint32_t *__re
 }
 
 
-#define MC_FH_MIN 96      // reads with more HSPs than this are finished by a whole wave (k_finish_heavy)
+#ifndef MC_FH_MIN
+#define MC_FH_MIN 96
+#endif
+// MC_FH_MIN: reads with more HSPs than this are finished by a whole wave (k_finish_heavy)
 #define MC_FH_N1 512      // subjects / ranked HSPs a read may have in the first wave kernel (11 KB of LDS per wave) ...
 #define MC_FH_N2 2048     // ... in the second (45 KB) ...
 #define MC_FH_N3 6144     // ... and in the third (135 KB, one wave per CU), where anything larger is finished by lane 0 alone
@@ -2438,6 +2441,14 @@ static int stage_d(mc_handle *h, McCtx &c)
         HIPCK(hipStreamSynchronize(st)); HIPCK(hipStreamSynchronize(c.side));
         unsigned long long acc[8], cnt[8];
         HIPCK(hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_fh_acc), sizeof acc)); HIPCK(hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_fh_cnt), sizeof cnt));
+        {
+            unsigned long long fr[8];
+            HIPCK(hipMemcpyFromSymbol(fr, HIP_SYMBOL(g_fr_acc), sizeof fr));
+            const char *fn[7] = {"groups", "items", "std::sort", "threshold, keys", "heap sort", "rows", "classification"};
+            for (int k = 0; k < 7; k++) fprintf(stderr, "fr-timing %-17s total %9.1f Mcycles (thread wall time, summed)\n", fn[k], fr[k] / 1e6);
+            unsigned long long z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_fr_acc), z8, sizeof z8));
+        }
         const char *nm[8] = {"group starts", "groups", "scan, items", "sort", "threshold, ranks", "heap sort", "rows", "other"};
         for (int k = 0; k < 8; k++) fprintf(stderr, "fh-timing %-17s total %9.1f Mcycles %9llu entries\n", nm[k], acc[k] / 1e6, cnt[k]);
         unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
