@@ -91,8 +91,13 @@ struct McSeedTask {
     uint32_t read;             // read index inside the batch
     uint32_t chrono;           // MC_CHRONO
     uint32_t posting;
-    uint32_t seedlen_nkey;     // seedlen | nkey<<8
+    uint32_t seedlen_nkey;     // seedlen | nkey<<8 (emulation) / MC_TASK_W3 (kernels)
 };
+// What the kernels keep in the fourth word: the hit's position in the residue array (off[sidx] + dpos, 24 bits: the marker
+// database has 5.5 M residues; mc_set_db refuses one past 16 M), so that the evaluation reads the subject's residues without
+// first fetching the subject's offset; seed length and number of key residues above it.
+#define MC_TASK_W3(abs, seedlen, nkey) ((uint32_t)(abs) | ((uint32_t)(seedlen) << 24) | ((uint32_t)(nkey) << 28))
+#define MC_TASK_ABS_LIMIT (1u << 24)
 
 // seed hit whose ungapped score reached the gapped trigger (AlignSeqs 0x4134c8)
 struct McGapTask {
@@ -1154,13 +1159,24 @@ MC_HDN void mc_enumerate_seeds(const McTables &T, const McIndex &X, const uint8_
 // QP / DP: pointers to the frame and to the subject's residues (d[i] = residue i of the marker) - plain memory, or the
 // kernel's LDS copies: the frame, and the subject window [max(0, dpos - qpos), min(dlen, dpos + qlen - qpos)), which is all this function can touch
 template <class TT, class QP, class DP>
+MC_HDN int mc_eval_seed_tail(const TT &T, QP q, int qlen, int frame, int qpos, DP d, int dlen, int dpos, int sidx,
+                             int seedlen, int score, int ident, McGapTask *gt);
+template <class TT, class QP, class DP>
 MC_HDN int mc_eval_seed_core(const TT &T, QP q, int qlen, int frame, int qpos, DP d, int dlen, int dpos, int sidx,
                              int seedlen, int nkey, McGapTask *gt)
 {
     if (dpos + seedlen > dlen) return 0;
     if (qpos != 0 && dpos != 0 && T.grp[q[qpos - 1]] == T.grp[d[dpos - 1]] && nkey != 4) return 0;
-    int score = 0, ident = 0, L = seedlen;
+    int score = 0, ident = 0;
     for (int k = 0; k < seedlen; k++) { int a = q[qpos + k], b = d[dpos + k]; score += MC_SUB(T, a, b); ident += (a == b); }
+    return mc_eval_seed_tail(T, q, qlen, frame, qpos, d, dlen, dpos, sidx, seedlen, score, ident, gt);
+}
+// ... from the seed's own score on: growth in both directions, the gate, the ungapped X-drop extension
+template <class TT, class QP, class DP>
+MC_HDN int mc_eval_seed_tail(const TT &T, QP q, int qlen, int frame, int qpos, DP d, int dlen, int dpos, int sidx,
+                             int seedlen, int score, int ident, McGapTask *gt)
+{
+    int L = seedlen;
     int lim = dlen - dpos; if (lim > qlen - qpos) lim = qlen - qpos;
     while (lim > L && T.grp[q[qpos + L]] == T.grp[d[dpos + L]]) { int a = q[qpos + L], b = d[dpos + L]; score += MC_SUB(T, a, b); ident += (a == b); L++; }
     int back = qpos < dpos ? qpos : dpos, qp = qpos, dp = dpos;

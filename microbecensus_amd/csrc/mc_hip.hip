@@ -452,7 +452,7 @@ struct DevEmit {
         for (int i = 0; i < cnt; i++) {
             McSeedTask t;
             t.read = read; t.chrono = MC_CHRONO(frame, pos, phase, nst + i); t.posting = X->post[b0 + nst + i];
-            t.seedlen_nkey = (uint32_t)seedlen | ((uint32_t)nkey << 8);
+            t.seedlen_nkey = MC_TASK_W3(X->off[t.posting >> 11] + (t.posting & 0x7ff), seedlen, nkey);
             tasks[base + i] = t;
         }
     }
@@ -544,16 +544,18 @@ __device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long
     // Long ones are written by the whole wave, one range after the other: a conserved 10-mer occurs in hundreds of homologous
     // markers, and a lane that wrote such a range alone would keep the other 63 waiting.
     if (cnt > 0 && cnt <= MC_EN_SHORT) {
-        const uint32_t sn = phase == 0 ? (9u | (3u << 8)) : (10u | (4u << 8));
-        uint32_t pst[MC_EN_SHORT];                   // the postings first, then the stores: a store between two loads orders them (the pointers may alias)
+        const uint32_t sn = phase == 0 ? MC_TASK_W3(0, 9, 3) : MC_TASK_W3(0, 10, 4);
+        uint32_t pst[MC_EN_SHORT], ofs[MC_EN_SHORT];   // the postings and the subjects' offsets first, then the stores: a store between two loads orders them (the pointers may alias)
 #pragma unroll
         for (int i = 0; i < MC_EN_SHORT; i++) pst[i] = X.post[start + (uint32_t)nst + (uint32_t)(i < cnt ? i : 0)];
+#pragma unroll
+        for (int i = 0; i < MC_EN_SHORT; i++) ofs[i] = X.off[pst[i] >> 11];
 #pragma unroll
         for (int i = 0; i < MC_EN_SHORT; i++)
             if (i < cnt) {
                 McSeedTask t;
                 t.read = read; t.chrono = MC_CHRONO(frame, pos, phase, (uint32_t)nst + (uint32_t)i); t.posting = pst[i];
-                t.seedlen_nkey = sn;
+                t.seedlen_nkey = sn | (ofs[i] + (pst[i] & 0x7ffu));
                 tasks[base + excl + (uint32_t)i] = t;
             }
     }
@@ -582,8 +584,10 @@ __device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long
                     in[u] = x < ltot;
                     const int p2 = (int)((oh >> 4) & 0xFF), f2 = (int)((oh >> 12) & 7), ph2 = (int)((oh >> 15) & 63);
                     pst[u] = X.post[in[u] ? ofrom + i : 0u];
-                    slot[u] = base + oex + i; chr[u] = MC_CHRONO(f2, p2, ph2, onst + i); snk[u] = ph2 == 0 ? (9u | (3u << 8)) : (10u | (4u << 8));
+                    slot[u] = base + oex + i; chr[u] = MC_CHRONO(f2, p2, ph2, onst + i); snk[u] = ph2 == 0 ? MC_TASK_W3(0, 9, 3) : MC_TASK_W3(0, 10, 4);
                 }
+#pragma unroll
+                for (int u = 0; u < 2; u++) snk[u] |= X.off[pst[u] >> 11] + (pst[u] & 0x7ffu);
 #pragma unroll
                 for (int u = 0; u < 2; u++)
                     if (in[u]) {
@@ -1010,6 +1014,91 @@ __device__ __forceinline__ bool mc_hsp_can_classify(const McTables &T, const McC
 // its registers allow, 24 waves per CU (80 VGPRs), as 3 workgroups of 8 waves whose staging pools just fit the LDS -
 // measured per 1 M reads of 150 bp: 4 x 4 waves 5.3 ms, 4 x 5 waves 4.85, 3 x 8 waves 4.6, 2 x 12 waves 4.6; pools that flush
 // more often (4 x 6 waves, 5 x 4 waves) 6.6 - 7.1.
+// mc_eval_seed_tail (mc_core.h) for k_eval_seeds: the same growth, gate and ungapped X-drop extension, with the two extension
+// loops reading EIGHT residues of both sequences per turn (one 8-byte load each, any alignment) and looking their eight scores
+// up together - the plain loops make one trip to the L1 / L2 and one to LDS per residue, each waiting for the one before, and
+// were half of the kernel's wave time (cycle counters).  The steps themselves are taken one residue at a time with the
+// reference's exit tests, in the same order.  Rows and residue array have room on both sides (what a load reads past a
+// sequence's end is never used: the step that would use it is behind an exit test).
+__device__ __forceinline__ uint64_t mc_ld8(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ int mc_eval_seed_tail_dev(const McHot &T, const uint8_t *q, int qlen, int qpos, const uint8_t *d, int dlen, int dpos, int sidx,
+                                                     int seedlen, int score, int ident, McGapTask *gt)
+{
+    int L = seedlen;
+    int lim = dlen - dpos; if (lim > qlen - qpos) lim = qlen - qpos;
+    while (lim > L && T.grp[q[qpos + L]] == T.grp[d[dpos + L]]) { int a = q[qpos + L], b = d[dpos + L]; score += MC_SUB(T, a, b); ident += (a == b); L++; }
+    int back = qpos < dpos ? qpos : dpos, qp = qpos, dp = dpos;
+    while (back > 0 && T.grp[q[qp - 1]] == T.grp[d[dp - 1]]) { qp--; dp--; back--; L++; int a = q[qp], b = d[dp]; score += MC_SUB(T, a, b); ident += (a == b); }
+    if (!((double)score >= MC_SEED_SCORE && ident >= MC_SEED_IDENT)) return 0;
+    const double xd = T.xdrop_ungapped;
+    int s0 = score, qfwd = 0, qbwd = 0, fgain = 0, bgain = 0;
+    { // forward
+        const int n1 = qlen - qp - L, n2 = dlen - dp - L;
+        int bl = 0, bi = 0;
+        if (n1 != 0 && n2 != 0 && !(s0 < -20)) {
+            const uint8_t *p1 = q + qp + L, *p2 = d + dp + L;
+            int run = s0, best = s0, id = 0, i = 0;
+            bool stop = false;
+            do {
+                const uint64_t wa = mc_ld8(p1 + i), wb = mc_ld8(p2 + i);
+                int sc[8];
+                uint32_t eq = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t a = (uint32_t)(wa >> (8 * k)) & 0xFFu, b = (uint32_t)(wb >> (8 * k)) & 0xFFu;
+                    sc[k] = (int)T.sub[((a << 5) | b) & 1023u]; eq |= (uint32_t)(a == b) << k;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (!stop) {
+                        run += sc[k]; id += (int)((eq >> k) & 1u); i++;
+                        if (run > best) { best = run; bl = i; bi = id; }
+                        stop = !(n2 > i) || n1 <= i || run < -20 || (double)run < (double)best - xd;
+                    }
+            } while (!stop);
+            fgain = best - s0;
+        }
+        ident += bi; qfwd = bl;
+    }
+    { // backward, restarting from the seed score
+        int a = qp - 1, b = dp - 1, bl = 0, bi = 0;
+        if (a >= 0 && b >= 0 && !(s0 < -20)) {
+            int run = s0, best = s0, id = 0, cnt = 0;
+            bool stop = false;
+            do {
+                const uint64_t wa = mc_ld8(q + a - 7), wb = mc_ld8(d + b - 7);       // residues a - 7 .. a: step k uses byte 7 - k
+                int sc[8];
+                uint32_t eq = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t x = (uint32_t)(wa >> (8 * (7 - k))) & 0xFFu, y = (uint32_t)(wb >> (8 * (7 - k))) & 0xFFu;
+                    sc[k] = (int)T.sub[((x << 5) | y) & 1023u]; eq |= (uint32_t)(x == y) << k;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (!stop) {
+                        run += sc[k]; id += (int)((eq >> k) & 1u); cnt++;
+                        if (best < run) { best = run; bl = cnt; bi = id; }
+                        a--; b--;
+                        stop = b < 0 || a < 0 || run < -20 || (double)run < (double)best - xd;
+                    }
+            } while (!stop);
+            bgain = best - s0;
+        }
+        ident += bi; qbwd = bl;
+    }
+    score = s0 + bgain + fgain;
+    gt->sidx = (uint32_t)sidx; gt->qp = (int16_t)qp; gt->dp = (int16_t)dp; gt->L = (int16_t)L;
+    gt->qfwd = (int16_t)qfwd; gt->qbwd = (int16_t)qbwd; gt->score = (int16_t)score; gt->nmatch = (int16_t)ident;
+    return (!(T.gap_trigger > (double)score)) ? 2 : 1;
+}
+
+#ifdef MC_EXP_TIMING
+__device__ unsigned long long g_ev_acc[8];           // wave time per phase, summed over the waves: 0 barriers / flush 1 record, first reads, seed score 2 growth, gate, X-drop 3 HSP 4 staging
+#define MC_EV_TICK(prev) do { const unsigned long long now_ = __builtin_readcyclecounter(); ev_acc_[prev] += now_ - ev_last_; ev_last_ = now_; } while (0)
+#else
+#define MC_EV_TICK(prev) do { } while (0)
+#endif
 #define MC_EV_BS 512         // threads per workgroup
 #define MC_EV_BPC 3          // workgroups per CU
 #define MC_EV_STAGE_H 704    // HSPs staged per workgroup (33 KB)
@@ -1028,6 +1117,16 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(MC_
     __syncthreads();
     const int lane = mc_lane();
     const uint32_t nchunks = (ntasks + MC_EV_BS - 1) / MC_EV_BS;
+    // The chain of dependent reads of a hit was: its record -> the subject's offsets -> the residue in front of the seed -> the
+    // seed's residues, four trips to the L2 before the gate that ends seven hits in ten.  Now: the record of the NEXT chunk is
+    // fetched while this one is evaluated, the record carries the hit's position in the residue array (MC_TASK_W3), and the
+    // subject's end, the residues in front of the seed and the seed's own ten are read together: one trip.
+#ifdef MC_EXP_TIMING
+    unsigned long long ev_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ev_last_ = __builtin_readcyclecounter();
+#endif
+    McSeedTask tn;
+    tn.read = MC_TASK_NONE; tn.chrono = 0; tn.posting = 0; tn.seedlen_nkey = 0;
+    if (blockIdx.x * MC_EV_BS + threadIdx.x < ntasks) tn = tasks[blockIdx.x * MC_EV_BS + threadIdx.x];
     for (uint32_t chunk = blockIdx.x;; chunk += gridDim.x) {
         const bool last = chunk >= nchunks;
         // flush when the next 256 hits might not fit (or at the end)
@@ -1052,25 +1151,52 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(MC_
             __syncthreads();
         }
         if (last) break;
+        MC_EV_TICK(0);
         const uint32_t tid = chunk * MC_EV_BS + threadIdx.x;
         int rc = 0;
         McGapTask g;
         McHsp h;
         bool keep = false;
+        const McSeedTask t = tn;
+        {
+            const uint64_t nx = (uint64_t)(chunk + gridDim.x) * MC_EV_BS + threadIdx.x;
+            tn.read = MC_TASK_NONE;
+            if (nx < ntasks) tn = tasks[nx];
+        }
         if (tid < ntasks) {
-            const McSeedTask t = tasks[tid];
             if (t.read != MC_TASK_NONE) {                          // (padding of a partly used block of the task pool)
                 const int frame = (int)(t.chrono >> 25), pos = (int)((t.chrono >> 17) & 0xff);
                 const int qlen = (L - frame % 3) / 3;
                 g.read = t.read; g.chrono = t.chrono;
-                rc = mc_eval_seed(hot, X, frames + ((int64_t)t.read * 6 + frame) * FP, qlen, frame, pos, t.posting, (int)(t.seedlen_nkey & 0xff), (int)(t.seedlen_nkey >> 8), &g);
+                const uint32_t w3 = t.seedlen_nkey;
+                const int seedlen = (int)((w3 >> 24) & 15u), nkey = (int)(w3 >> 28), dpos = (int)(t.posting & 0x7ffu), sidx = (int)(t.posting >> 11);
+                const uint32_t o0 = (w3 & 0xFFFFFFu) - (uint32_t)dpos;
+                const uint8_t *q = frames + ((int64_t)t.read * 6 + frame) * FP, *d = X.res + o0;
+                const uint32_t o1 = X.off[sidx + 1];
+                const int qm1 = q[pos > 0 ? pos - 1 : 0], dm1 = d[dpos - 1];        // (the residue array has room in front)
+                int qa[10], da[10];
+#pragma unroll
+                for (int k = 0; k < 10; k++) { qa[k] = q[pos + k]; da[k] = d[dpos + k]; }   // (rows and residue array are padded: a 9-mer's tenth is read and not used)
+                const int dlen = (int)(o1 - o0);
+                int score = 0, ident = 0;
+#pragma unroll
+                for (int k = 0; k < 10; k++) if (k < seedlen) { score += MC_SUB(hot, qa[k], da[k]); ident += (qa[k] == da[k]); }
+                const bool go = !(dpos + seedlen > dlen) && !(pos != 0 && dpos != 0 && hot.grp[qm1] == hot.grp[dm1] && nkey != 4);
+#ifdef MC_EXP_TIMING
+                if (score == 12345678) rc = 3;                      // (keeps the loads in front of the tick)
+                MC_EV_TICK(1);
+#endif
+                if (go) rc = mc_eval_seed_tail_dev(hot, q, qlen, pos, d, dlen, dpos, sidx, seedlen, score, ident, &g);
+                MC_EV_TICK(2);
                 if (rc == 1) {
                     h.read = t.read; h.chrono = t.chrono;
                     keep = mc_make_hsp(*T, L, frame, g, g.qfwd, g.qfwd, g.qbwd, g.qbwd, g.score, g.nmatch, g.qfwd + g.L + g.qbwd, 0, 0, &h);
                     if (keep && cand && mc_hsp_can_classify(*T, *P, X, fam, h)) cand[h.read] = 1;
                 }
+                MC_EV_TICK(3);
             }
         }
+        MC_EV_TICK(3);
         {   // stage: one LDS atomic per wave and kind
             const unsigned long long mh = __ballot(keep), mg = __ballot(rc == 2);
             uint32_t oh = 0, og = 0;
@@ -1079,7 +1205,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(MC_
             if (keep) stH[oh + (uint32_t)__popcll(mh & ((1ull << lane) - 1))] = h;
             if (rc == 2) stG[og + (uint32_t)__popcll(mg & ((1ull << lane) - 1))] = g;
         }
+        MC_EV_TICK(4);
     }
+#ifdef MC_EXP_TIMING
+    if (lane == 0) for (int k = 0; k < 5; k++) atomicAdd(&g_ev_acc[k], ev_acc_[k]);
+#endif
 }
 
 // Gap tasks are massively redundant: a read that really comes from a marker gene hits every seed of its diagonal, and the
@@ -1953,7 +2083,7 @@ struct McCtx {
     hipEvent_t ev[8] = {}, ev_fork = nullptr, ev_join = nullptr;
     int64_t cap_reads = 0;
     uint32_t cap_tasks = 0, cap_gaps = 0, cap_hsps = 0, cap_rows = 0;
-    uint8_t *d_frames = nullptr;
+    uint8_t *d_frames = nullptr, *d_frames_base = nullptr;   // (64 bytes of room in front: k_eval_seeds reads 8 bytes at a time backwards from a seed)
     unsigned long long *d_stats = nullptr;
     McSeedTask *d_tasks = nullptr; McGapTask *d_gaps = nullptr; McHsp *d_hsps = nullptr, *d_sorted = nullptr, *d_v = nullptr, *d_tmp = nullptr;
     uint64_t *d_k64 = nullptr, *d_k64o = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
@@ -2024,7 +2154,7 @@ extern "C" int mc_device_count(void)
 
 static void ctx_free(McCtx &c)
 {
-    void *ptrs[] = {c.d_frames, c.d_tasks, c.d_gaps, c.d_hsps, c.d_sorted, c.d_v, c.d_tmp, c.d_k64, c.d_k64o, c.d_idx, c.d_idxo, c.d_heads, c.d_sorttmp, c.d_counters, c.d_rows,
+    void *ptrs[] = {c.d_frames_base, c.d_tasks, c.d_gaps, c.d_hsps, c.d_sorted, c.d_v, c.d_tmp, c.d_k64, c.d_k64o, c.d_idx, c.d_idxo, c.d_heads, c.d_sorttmp, c.d_counters, c.d_rows,
                     c.d_nrow, c.d_rowoff, c.d_best, c.d_bestof, c.d_mark, c.d_cand, c.d_gws_full, c.d_retry, c.d_retry2, c.d_gtab, c.d_gleader, c.d_fout, c.d_stats};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : {(void *)c.h_c, (void *)c.h_stats, (void *)c.h_best}) if (p) (void)hipHostFree(p);
@@ -2072,6 +2202,7 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
     }
     HIPCK(hipStreamCreate(&h->rows_stream)); HIPCK(hipEventCreateWithFlags(&h->ev_rows, hipEventDisableTiming));
     const McHostIndex &H = h->H;
+    if (H.res.size() >= MC_TASK_ABS_LIMIT) { g_err = "marker database too large: more than 16 M residues (MC_TASK_W3)"; return -1; }
     if (dalloc(&h->d_res_base, H.res.size() + 128) || dalloc(&h->d_off, H.off.size()) || dalloc(&h->d_bstart, H.bstart.size()) || dalloc(&h->d_post, H.post.size() + 1) ||
         dalloc(&h->d_keys, H.keys.size()) || dalloc(&h->d_fam, (size_t)nseq) || dalloc(&h->d_T, 1) || dalloc(&h->d_P, 1)) return -1;
     HIPCK(hipMemset(h->d_res_base, MC_INV, H.res.size() + 128));
@@ -2210,7 +2341,7 @@ static int ensure_capacity(mc_handle *h, McCtx &c, int64_t nreads)
     c.cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 2 + 16) + (1 << 20), 0x7fffffff);
     c.cap_rows = (uint32_t)std::min<int64_t>(cap * 48 + (1 << 20), 0x7fffffff);
     c.gap_threads_full = 16 * 1024;                                 // full-size DP rows for the last-resort launch (460 MB)
-    if (dalloc(&c.d_frames, (size_t)cap * 6 * h->FP + 64) || dalloc(&c.d_tasks, c.cap_tasks) ||
+    if (dalloc(&c.d_frames_base, (size_t)cap * 6 * h->FP + 128) || dalloc(&c.d_tasks, c.cap_tasks) ||
         dalloc(&c.d_gaps, c.cap_gaps) || dalloc(&c.d_hsps, c.cap_hsps) || dalloc(&c.d_sorted, c.cap_hsps) || dalloc(&c.d_v, c.cap_hsps) ||
         dalloc(&c.d_tmp, (size_t)c.cap_hsps * 2) || dalloc(&c.d_k64, c.cap_hsps) || dalloc(&c.d_k64o, c.cap_hsps) || dalloc(&c.d_idx, c.cap_hsps) ||
         dalloc(&c.d_idxo, c.cap_hsps) || dalloc(&c.d_heads, (size_t)cap + 1) || dalloc(&c.d_rows, c.cap_rows) ||
@@ -2218,6 +2349,8 @@ static int ensure_capacity(mc_handle *h, McCtx &c, int64_t nreads)
         dalloc(&c.d_gws_full, (size_t)c.gap_threads_full * MC_GAP_W) || dalloc(&c.d_retry, (size_t)c.cap_gaps * 2 + (size_t)cap + 1) || dalloc(&c.d_retry2, (size_t)c.cap_gaps * 2) || dalloc(&c.d_gleader, (size_t)c.cap_gaps) ||
         dalloc(&c.d_fout, (size_t)c.cap_gaps * 2))
         return -1;
+    c.d_frames = c.d_frames_base + 64;
+    HIPCK(hipMemsetAsync(c.d_frames_base, MC_INV, 64, c.stream));
     if (c.h_best) { (void)hipHostFree(c.h_best); c.h_best = nullptr; }
     HIPCK(hipHostMalloc((void **)&c.h_best, sizeof(McBestHit) * ((size_t)cap + 1), hipHostMallocDefault));
     c.h_best_cap = (size_t)cap + 1;
@@ -2448,6 +2581,14 @@ static int stage_d(mc_handle *h, McCtx &c)
             for (int k = 0; k < 7; k++) fprintf(stderr, "fr-timing %-17s total %9.1f Mcycles (thread wall time, summed)\n", fn[k], fr[k] / 1e6);
             unsigned long long z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_fr_acc), z8, sizeof z8));
+        }
+        {
+            unsigned long long ev[8];
+            HIPCK(hipMemcpyFromSymbol(ev, HIP_SYMBOL(g_ev_acc), sizeof ev));
+            const char *en[5] = {"barriers, flush", "record, first reads", "growth, gate, X-drop", "HSP", "staging"};
+            for (int k = 0; k < 5; k++) fprintf(stderr, "ev-timing %-21s total %9.1f Mcycles (lane 0 of every wave)\n", en[k], ev[k] / 1e6);
+            unsigned long long z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_ev_acc), z8, sizeof z8));
         }
         const char *nm[8] = {"group starts", "groups", "scan, items", "sort", "threshold, ranks", "heap sort", "rows", "other"};
         for (int k = 0; k < 8; k++) fprintf(stderr, "fh-timing %-17s total %9.1f Mcycles %9llu entries\n", nm[k], acc[k] / 1e6, cnt[k]);
