@@ -1022,13 +1022,25 @@ __device__ __forceinline__ bool mc_hsp_can_classify(const McTables &T, const McC
 // sequence's end is never used: the step that would use it is behind an exit test).
 __device__ __forceinline__ uint64_t mc_ld8(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ __forceinline__ int mc_eval_seed_tail_dev(const McHot &T, const uint8_t *q, int qlen, int qpos, const uint8_t *d, int dlen, int dpos, int sidx,
-                                                     int seedlen, int score, int ident, McGapTask *gt)
+                                                     int seedlen, int score, int ident, McGapTask *gt, uint64_t q0, uint64_t q2, uint64_t d0, uint64_t d2)
 {
+    // growth: residues 9 .. 15 behind the seed's first one and the 8 in front of it are in registers (q2, d2 / q0, d0: the caller's
+    // loads); most hits stop growing at once on both sides and reach the gate without another read
     int L = seedlen;
     int lim = dlen - dpos; if (lim > qlen - qpos) lim = qlen - qpos;
-    while (lim > L && T.grp[q[qpos + L]] == T.grp[d[dpos + L]]) { int a = q[qpos + L], b = d[dpos + L]; score += MC_SUB(T, a, b); ident += (a == b); L++; }
+#pragma unroll
+    for (int j = 9; j < 16; j++) {
+        const int a = (int)((q2 >> (8 * (j - 8))) & 0xFFu), b = (int)((d2 >> (8 * (j - 8))) & 0xFFu);
+        if (L == j && lim > L && T.grp[a & 31] == T.grp[b & 31]) { score += MC_SUB(T, a, b); ident += (a == b); L++; }
+    }
+    if (L == 16) while (lim > L && T.grp[q[qpos + L]] == T.grp[d[dpos + L]]) { int a = q[qpos + L], b = d[dpos + L]; score += MC_SUB(T, a, b); ident += (a == b); L++; }
     int back = qpos < dpos ? qpos : dpos, qp = qpos, dp = dpos;
-    while (back > 0 && T.grp[q[qp - 1]] == T.grp[d[dp - 1]]) { qp--; dp--; back--; L++; int a = q[qp], b = d[dp]; score += MC_SUB(T, a, b); ident += (a == b); }
+#pragma unroll
+    for (int j = 1; j <= 8; j++) {
+        const int a = (int)((q0 >> (8 * (8 - j))) & 0xFFu), b = (int)((d0 >> (8 * (8 - j))) & 0xFFu);
+        if (qpos - qp == j - 1 && back > 0 && T.grp[a & 31] == T.grp[b & 31]) { qp--; dp--; back--; L++; score += MC_SUB(T, a, b); ident += (a == b); }
+    }
+    if (qpos - qp == 8) while (back > 0 && T.grp[q[qp - 1]] == T.grp[d[dp - 1]]) { qp--; dp--; back--; L++; int a = q[qp], b = d[dp]; score += MC_SUB(T, a, b); ident += (a == b); }
     if (!((double)score >= MC_SEED_SCORE && ident >= MC_SEED_IDENT)) return 0;
     const double xd = T.xdrop_ungapped;
     int s0 = score, qfwd = 0, qbwd = 0, fgain = 0, bgain = 0;
@@ -1173,20 +1185,23 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(MC_
                 const uint32_t o0 = (w3 & 0xFFFFFFu) - (uint32_t)dpos;
                 const uint8_t *q = frames + ((int64_t)t.read * 6 + frame) * FP, *d = X.res + o0;
                 const uint32_t o1 = X.off[sidx + 1];
-                const int qm1 = q[pos > 0 ? pos - 1 : 0], dm1 = d[dpos - 1];        // (the residue array has room in front)
-                int qa[10], da[10];
-#pragma unroll
-                for (int k = 0; k < 10; k++) { qa[k] = q[pos + k]; da[k] = d[dpos + k]; }   // (rows and residue array are padded: a 9-mer's tenth is read and not used)
+                // residues pos - 8 .. pos + 15 of the frame and dpos - 8 .. dpos + 15 of the subject: six loads, one trip (rows and residue array have room on both sides)
+                const uint64_t q0 = mc_ld8(q + pos - 8), q1 = mc_ld8(q + pos), q2 = mc_ld8(q + pos + 8), d0 = mc_ld8(d + dpos - 8), d1 = mc_ld8(d + dpos), d2 = mc_ld8(d + dpos + 8);
+                const int qm1 = (int)(q0 >> 56), dm1 = (int)(d0 >> 56);
                 const int dlen = (int)(o1 - o0);
                 int score = 0, ident = 0;
 #pragma unroll
-                for (int k = 0; k < 10; k++) if (k < seedlen) { score += MC_SUB(hot, qa[k], da[k]); ident += (qa[k] == da[k]); }
+                for (int k = 0; k < 10; k++)
+                    if (k < seedlen) {
+                        const int a = (int)((k < 8 ? q1 >> (8 * k) : q2 >> (8 * (k - 8))) & 0xFFu), b = (int)((k < 8 ? d1 >> (8 * k) : d2 >> (8 * (k - 8))) & 0xFFu);
+                        score += MC_SUB(hot, a, b); ident += (a == b);
+                    }
                 const bool go = !(dpos + seedlen > dlen) && !(pos != 0 && dpos != 0 && hot.grp[qm1] == hot.grp[dm1] && nkey != 4);
 #ifdef MC_EXP_TIMING
                 if (score == 12345678) rc = 3;                      // (keeps the loads in front of the tick)
                 MC_EV_TICK(1);
 #endif
-                if (go) rc = mc_eval_seed_tail_dev(hot, q, qlen, pos, d, dlen, dpos, sidx, seedlen, score, ident, &g);
+                if (go) rc = mc_eval_seed_tail_dev(hot, q, qlen, pos, d, dlen, dpos, sidx, seedlen, score, ident, &g, q0, q2, d0, d2);
                 MC_EV_TICK(2);
                 if (rc == 1) {
                     h.read = t.read; h.chrono = t.chrono;
