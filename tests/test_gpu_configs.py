@@ -78,7 +78,7 @@ def test_run_pipeline_over_several_handles_in_one_process(monkeypatch):
     args["nreads"] = 10_000_000                                  # (else a run of this size would be given one device)
     est, out = mc.run_pipeline(args)
     assert out["sampled_reads"] == g["sampled_reads"] and est == g["est_ags"]
-    assert [k for k in mc._engines if isinstance(k, tuple)] == [(0, 1), (0, 2)]
+    assert sorted(k for k in mc._engines if isinstance(k, tuple)) == [(0, 1), (0, 2)]     # (the extra handles are opened side by side: any order)
 
 
 def _two_ranks(tmp_path, backend, port):
