@@ -223,18 +223,23 @@ MC_HDN int mc_finish_group(const McTables &T, const McIndex &X, const McHsp *in,
 {
     int vn = 0;
     const int sidx = in[a].sidx;
-    // stack of this subject's HSPs, newest on top; a re-found HSP only replaces the top if it is better
-    for (int k = a; k < b; k++) {
-        const McHsp &h = in[k];
-        if (vn > 0) {
-            McHsp &t = out[vn - 1];
-            if (t.frame == h.frame && t.qaas == h.qaas && t.ds == h.ds && t.qaae == h.qaae && t.de == h.de) {
-                if (t.loge > h.loge) { t.score = h.score; t.loge = h.loge; t.alnlen = h.alnlen; t.mism = h.mism; t.gaps = h.gaps; t.nmatch = h.nmatch; t.qnts = h.qnts; t.qnte = h.qnte; }
-                continue;
-            }
+    // stack of this subject's HSPs, newest on top; a re-found HSP only replaces the top if it is better.  The top of the stack is
+    // kept in registers and written when the next HSP goes on top of it (the thread walks global memory alone: reading back what
+    // it has just written was a trip per HSP); the record behind the current one is read ahead.
+    McHsp t = in[a];
+    McHsp nx = t;
+    if (a + 1 < b) nx = in[a + 1];
+    for (int k = a + 1; k < b; k++) {
+        const McHsp h = nx;
+        if (k + 1 < b) nx = in[k + 1];
+        if (t.frame == h.frame && t.qaas == h.qaas && t.ds == h.ds && t.qaae == h.qaae && t.de == h.de) {
+            if (t.loge > h.loge) { t.score = h.score; t.loge = h.loge; t.alnlen = h.alnlen; t.mism = h.mism; t.gaps = h.gaps; t.nmatch = h.nmatch; t.qnts = h.qnts; t.qnte = h.qnte; }
+            continue;
         }
-        out[vn++] = h;
+        out[vn++] = t;
+        t = h;
     }
+    out[vn++] = t;
     for (int i = 0, j = vn - 1; i < j; i++, j--) { McHsp t = out[i]; out[i] = out[j]; out[j] = t; }   // multimap order: newest first
     if (vn > 1) vn = mc_sum_evalue(T, out, 0, vn, (int)(X.off[sidx + 1] - X.off[sidx]), tmp);
     return vn;
@@ -265,12 +270,20 @@ MC_HDN int mc_finish_read(const McTables &T, const McIndex &X, const McClassPars
 {
     MC_FR_BEGIN;
     int vn = 0;
-    for (int a = 0; a < n;) {
-        int b = a;
-        const int sidx = in[a].sidx;
-        while (b < n && in[b].sidx == sidx) b++;
-        vn += mc_finish_group(T, X, in, a, b, v + vn, tmp);
-        a = b;
+    {   // a subject with ONE HSP (most subjects of most reads) goes straight to v; the record of the next HSP is read while this one
+        // is dealt with - the read's thread walks global memory alone, every dependent access a trip of its own
+        McHsp cur = in[0];
+        for (int a = 0; a < n;) {
+            if (a + 1 >= n) { v[vn++] = cur; break; }
+            const McHsp nxt = in[a + 1];
+            if (nxt.sidx != cur.sidx) { v[vn++] = cur; cur = nxt; a++; continue; }
+            int b = a + 2;
+            const int sidx = cur.sidx;
+            while (b < n && in[b].sidx == sidx) b++;
+            vn += mc_finish_group(T, X, in, a, b, v + vn, tmp);
+            a = b;
+            if (a < n) cur = in[a];
+        }
     }
     MC_FR_TICK(0);
     for (int i = 0; i < vn; i++) { items[i].k = v[i].loge; items[i].i = (uint32_t)i; items[i].pad = 0; }

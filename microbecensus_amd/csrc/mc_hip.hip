@@ -28,7 +28,7 @@
 #include "mc_finish.h"
 #include "mc_index.h"
 
-static_assert(sizeof(McRow) == sizeof(mc_row) && offsetof(McRow, ident) == offsetof(mc_row, ident) && offsetof(McRow, loge) == offsetof(mc_row, loge) &&
+static_assert(sizeof(McRow) % 8 == 0 && sizeof(McRow) == sizeof(mc_row) && offsetof(McRow, ident) == offsetof(mc_row, ident) && offsetof(McRow, loge) == offsetof(mc_row, loge) &&
                   offsetof(McRow, score) == offsetof(mc_row, score) && offsetof(McRow, frame) == offsetof(mc_row, nmatch),
               "the device row is handed out as the ABI row");
 
@@ -2020,16 +2020,32 @@ __global__ void __launch_bounds__(256) k_emit_rows(const uint32_t *__restrict__ 
                                                    uint32_t *counters, int copy_rows)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t nr = 0;
+    uint32_t nr = 0, cp_n = 0;
+    const uint2 *cp_src = nullptr;
+    uint2 *cp_dst = nullptr;
     McBestHit bh; bh.family = -1;
     if (s < nheads) {
         nr = nrow_of[s];
         bh = best_of[s];
         const uint32_t off = rowoff[s];
         if (s == nheads - 1) { counters[C_ROWS] = off + nr; if (copy_rows && off + nr > cap_rows) counters[C_OVERFLOW] = 4; }
-        if (copy_rows && off + nr <= cap_rows) {
-            const McRow *src = (const McRow *)(tmp + 2 * (size_t)heads[s]);
-            for (uint32_t i = 0; i < nr; i++) rows[off + i] = src[i];
+        if (copy_rows && off + nr <= cap_rows && nr > 0) { cp_src = (const uint2 *)(tmp + 2 * (size_t)heads[s]); cp_dst = (uint2 *)(rows + off); cp_n = nr * (uint32_t)(sizeof(McRow) / 8); }
+    }
+    {   // the rows of the block's reads, read by read with all 256 threads (8 bytes each, coalesced: a row is 72 bytes) - one read in twelve prints
+        // anything, 23 rows on average, and a thread copying its read's rows alone moved 64 bytes per turn
+        __shared__ const uint2 *l_src[256];
+        __shared__ uint2 *l_dst[256];
+        __shared__ uint32_t l_n[256], l_cnt;
+        if (threadIdx.x == 0) l_cnt = 0;
+        __syncthreads();
+        if (cp_n) { const uint32_t k = atomicAdd(&l_cnt, 1u); l_src[k] = cp_src; l_dst[k] = cp_dst; l_n[k] = cp_n; }   // (any order: the destinations are disjoint)
+        __syncthreads();
+        const uint32_t cnt = l_cnt;
+        for (uint32_t k = 0; k < cnt; k++) {
+            const uint2 *src = l_src[k];
+            uint2 *dst = l_dst[k];
+            const uint32_t n16 = l_n[k];
+            for (uint32_t i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
         }
     }
     (void)mc_block_alloc(&counters[C_SEGS], nr > 0);
