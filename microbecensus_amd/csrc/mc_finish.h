@@ -57,6 +57,16 @@ MC_HDN void mc_stable_sort_loge(McHsp *first, long n)
     }
 }
 
+#if defined(MC_EXP_TIMING) && defined(__HIPCC__)
+__device__ unsigned long long g_fr_acc2[8];          // timing build: inside the groups - 0 stack 1 sort by frame 2 sort by start + stable sort 3 choice 4 sum statistics 5 copy back
+#endif
+#if defined(MC_EXP_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#define MC_FG_BEGIN unsigned long long fg_last_ = __builtin_readcyclecounter()
+#define MC_FG_TICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&g_fr_acc2[k], now_ - fg_last_); fg_last_ = now_; } while (0)
+#else
+#define MC_FG_BEGIN do { } while (0)
+#define MC_FG_TICK(k) do { } while (0)
+#endif
 // ------------------------------------------------------------------------------------------------
 // sum statistics (BlastStat::sumScore2Expect@0x438300 -> @0x437f90)
 // ------------------------------------------------------------------------------------------------
@@ -87,7 +97,9 @@ MC_HDN int mc_sum_evalue(const McTables &T, McHsp *v, int st, int ed, int subj_l
 {
     McHsp *a = v + st;
     int n = ed - st, part, nres = 0;
+    MC_FG_BEGIN;
     mc_std_sort(a, n, 1);
+    MC_FG_TICK(1);
     for (part = 0; part < n && !(a[part].frame > 2); part++) {}
     if ((n - part) <= 1 && part <= 1) return ed;
     McHsp *res = tmp, *chosen = tmp + n;
@@ -96,8 +108,10 @@ MC_HDN int mc_sum_evalue(const McTables &T, McHsp *v, int st, int ed, int subj_l
         int gn = pass ? n - part : part, nc = 0;
         if (gn == 0) continue;
         if (gn == 1) { if (T.loge_thr > g[0].loge) res[nres++] = g[0]; continue; }
+        MC_FG_TICK(5);
         mc_std_sort(g, gn, 2);
         mc_stable_sort_loge(g, gn);
+        MC_FG_TICK(2);
         chosen[nc++] = g[0];
         for (int i = 1; i < gn; i++) {
             const McHsp &e = g[i];
@@ -113,6 +127,7 @@ MC_HDN int mc_sum_evalue(const McTables &T, McHsp *v, int st, int ed, int subj_l
             }
             if (ok) chosen[nc++] = e;
         }
+        MC_FG_TICK(3);
         if (nc == 1) { if (T.loge_thr > chosen[0].loge) res[nres++] = chosen[0]; }
         else {
             double sc[5];
@@ -122,8 +137,10 @@ MC_HDN int mc_sum_evalue(const McTables &T, McHsp *v, int st, int ed, int subj_l
             double le = (E == 0.0) ? -10000.0 : log(E) / 2.302585092994046;
             if (T.loge_thr > le) for (int i = 0; i < nc; i++) { chosen[i].loge = le; res[nres++] = chosen[i]; }
         }
+        MC_FG_TICK(4);
     }
-    if (nres > 0) { for (int i = 0; i < nres; i++) v[st + i] = res[i]; return st + nres; }
+    if (nres > 0) { for (int i = 0; i < nres; i++) v[st + i] = res[i]; MC_FG_TICK(5); return st + nres; }
+    MC_FG_TICK(5);
     return ed;
 }
 
@@ -219,10 +236,9 @@ MC_HD bool mc_row_passes(const McClassPars &P, const McRow &r, int fam, int targ
 // ------------------------------------------------------------------------------------------------
 // HSPs in[a, b) of one subject (sorted by chrono) -> out[0, kept): the multimap's view of them, linked by sum statistics.
 // tmp: 2 (b - a) entries of scratch.
-MC_HDN int mc_finish_group(const McTables &T, const McIndex &X, const McHsp *in, int a, int b, McHsp *out, McHsp *tmp)
+MC_HDN int mc_group_stack(const McHsp *in, int a, int b, McHsp *out)
 {
     int vn = 0;
-    const int sidx = in[a].sidx;
     // stack of this subject's HSPs, newest on top; a re-found HSP only replaces the top if it is better.  The top of the stack is
     // kept in registers and written when the next HSP goes on top of it (the thread walks global memory alone: reading back what
     // it has just written was a trip per HSP); the record behind the current one is read ahead.
@@ -240,7 +256,16 @@ MC_HDN int mc_finish_group(const McTables &T, const McIndex &X, const McHsp *in,
         t = h;
     }
     out[vn++] = t;
+#if defined(MC_EXP_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    atomicAdd(&g_fr_acc2[6], 1ull); if (vn > 1) atomicAdd(&g_fr_acc2[7], 1ull);
+#endif
     for (int i = 0, j = vn - 1; i < j; i++, j--) { McHsp t = out[i]; out[i] = out[j]; out[j] = t; }   // multimap order: newest first
+    return vn;
+}
+MC_HDN int mc_finish_group(const McTables &T, const McIndex &X, const McHsp *in, int a, int b, McHsp *out, McHsp *tmp)
+{
+    const int sidx = in[a].sidx;
+    int vn = mc_group_stack(in, a, b, out);
     if (vn > 1) vn = mc_sum_evalue(T, out, 0, vn, (int)(X.off[sidx + 1] - X.off[sidx]), tmp);
     return vn;
 }
@@ -269,20 +294,51 @@ MC_HDN int mc_finish_read(const McTables &T, const McIndex &X, const McClassPars
                           int read_id, const McHsp *in, int n, McHsp *v, McHsp *tmp, McRow *rows, double *krows, McSortItem *items, McBestHit *best)
 {
     MC_FR_BEGIN;
-    int vn = 0;
-    {   // a subject with ONE HSP (most subjects of most reads) goes straight to v; the record of the next HSP is read while this one
-        // is dealt with - the read's thread walks global memory alone, every dependent access a trip of its own
+    // Three passes over the read's subjects.  (1) the stacks, packed into v; a subject with ONE HSP (most subjects of most reads)
+    // goes straight there, the record of the next HSP is read while this one is dealt with.  The first record of a subject's
+    // stack carries the stack's size in .read and what is kept of it in .chrono (neither field is used again).  (2) sum
+    // statistics for the subjects with more than one HSP, in a loop of their own: the threads of a wave that have such a
+    // subject link it AT THE SAME TIME - inside the first loop each thread met its subjects at a different turn and the wave
+    // went through the sorts and logarithms of every one of them separately, which was the light kernel's time (cycle counters).
+    // (3) the kept HSPs moved together, if anything shrank.
+    int vn = 0, nlink = 0;
+    {
         McHsp cur = in[0];
         for (int a = 0; a < n;) {
-            if (a + 1 >= n) { v[vn++] = cur; break; }
-            const McHsp nxt = in[a + 1];
-            if (nxt.sidx != cur.sidx) { v[vn++] = cur; cur = nxt; a++; continue; }
+            const bool lastone = a + 1 >= n;
+            McHsp nxt = cur;
+            if (!lastone) nxt = in[a + 1];
+            if (lastone || nxt.sidx != cur.sidx) { cur.read = 1u; cur.chrono = 1u; v[vn++] = cur; cur = nxt; a++; continue; }
             int b = a + 2;
             const int sidx = cur.sidx;
             while (b < n && in[b].sidx == sidx) b++;
-            vn += mc_finish_group(T, X, in, a, b, v + vn, tmp);
+            const int k = mc_group_stack(in, a, b, v + vn);
+            v[vn].read = (uint32_t)k; v[vn].chrono = (uint32_t)k;
+            nlink += k > 1;
+            vn += k;
             a = b;
             if (a < n) cur = in[a];
+        }
+    }
+    if (nlink) {
+        bool shrank = false;
+        for (int p = 0;;) {
+            while (p < vn && v[p].read < 2u) p++;                   // (a stack of one is one record: the walk steps by the sizes)
+            if (p >= vn) break;
+            const int k = (int)v[p].read, sidx = v[p].sidx;
+            const int kept = mc_sum_evalue(T, v, p, p + k, (int)(X.off[sidx + 1] - X.off[sidx]), tmp) - p;
+            v[p].read = (uint32_t)k; v[p].chrono = (uint32_t)kept;
+            shrank |= kept != k;
+            p += k;
+        }
+        if (shrank) {
+            int w = 0;
+            for (int p = 0; p < vn;) {
+                const int k = (int)v[p].read, kept = (int)v[p].chrono;
+                if (w != p) for (int j = 0; j < kept; j++) v[w + j] = v[p + j];
+                w += kept; p += k;
+            }
+            vn = w;
         }
     }
     MC_FR_TICK(0);

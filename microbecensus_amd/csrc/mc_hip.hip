@@ -2612,6 +2612,10 @@ static int stage_d(mc_handle *h, McCtx &c)
             for (int k = 0; k < 7; k++) fprintf(stderr, "fr-timing %-17s total %9.1f Mcycles (thread wall time, summed)\n", fn[k], fr[k] / 1e6);
             unsigned long long z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_fr_acc), z8, sizeof z8));
+            HIPCK(hipMemcpyFromSymbol(fr, HIP_SYMBOL(g_fr_acc2), sizeof fr));
+            const char *gn[8] = {"-", "sort by frame", "sort by start, stable", "choice", "sum statistics", "copies", "groups (count)", "groups linked (count)"};
+            for (int k = 1; k < 8; k++) fprintf(stderr, "fg-timing %-22s %12.1f M\n", gn[k], fr[k] / 1e6);
+            HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_fr_acc2), z8, sizeof z8));
         }
         {
             unsigned long long ev[8];
