@@ -67,7 +67,7 @@ def spawn_ranks(n, argv):
 
 STAGE_KERNELS = {   # kernels whose HIP-event time a stage of mc_stats spans (prefixes of the names in the rocprofv3 summaries)
     "k_translate_seg": ["k_translate_seg"], "k_enumerate_t0": ["k_enumerate_t0<"], "k_enumerate": ["k_enumerate_t0<", "k_enumerate"], "k_eval_seeds": ["k_eval_seeds"],
-    "k_gapped": ["k_gap_dedupe", "k_gapped_lds", "k_gapped", "k_gap_emit"], "k_finish": ["k_finish", "k_finish_heavy", "k_heavy_lists", "k_emit_rows"],
+    "k_gapped": ["k_gap_dedupe", "k_gapped_lds", "k_gapped", "k_gap_emit"], "k_finish": ["k_finish", "k_finish_heavy", "k_heap_lanes", "k_heavy_rows", "k_heavy_lists", "k_emit_rows"],
     "sort": ["k_make_keys", "k_gather", "k_heads"],
 }
 
@@ -114,7 +114,7 @@ def load_profile(L):
 
 def stage_counters(prof, stage):
     """Sums the per-launch counters of the kernels of a stage (one launch of each per pass of the pipeline over the profiled batch;
-    kernels launched several times per pass - the four k_finish size classes - count with their number of calls per pass)."""
+    a kernel launched several times per pass counts with its number of calls per pass)."""
     if prof is None:
         return None
     pref = STAGE_KERNELS.get(stage, [stage])
@@ -129,8 +129,9 @@ def stage_counters(prof, stage):
         if per_pass is None and stage != "k_finish":
             per_pass = calls
         mult = 1.0
-        if k == "k_finish":
-            mult = 4.0                                          # one launch per size class
+        if k == "k_finish":                                     # (profiles taken before the size classes shared one launch: four launches per pass)
+            passes = prof["kernels"].get("k_heavy_lists", {}).get("calls", 0)
+            mult = float(calls) / passes if passes else 1.0
         for c, v in d.items():
             if c in ("calls",):
                 continue
