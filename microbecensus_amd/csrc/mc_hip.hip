@@ -1570,12 +1570,16 @@ __global__ void k_gather(const McHsp *__restrict__ hsps, const uint32_t *__restr
     mark[tid] = (h.loge < loge_thr || same_subject) ? 1 : 0;
 }
 // heads[k] = index of the first HSP of the k-th read that has HSPs (ascending read id); hpos = exclusive scan of flags
-__global__ void k_heads(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ hpos, uint32_t n, uint32_t *heads, uint32_t *counters)
+// ... and the reads that have a marked HSP: nrow_of (zeroed by the caller) is set to 1 for them - k_heavy_lists then knows
+// without walking the read's marks, and the finishing kernels overwrite it with the number of rows
+__global__ void k_heads(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ hpos, const uint8_t *__restrict__ mark, uint32_t n, uint32_t *heads, uint32_t *nrow_of, uint32_t *counters)
 {
     uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= n) return;
-    if (flags[tid]) heads[hpos[tid]] = tid;
-    if (tid == n - 1) counters[C_HEADS] = hpos[tid] + flags[tid];
+    const uint32_t f = flags[tid], hp = hpos[tid];
+    if (f) heads[hp] = tid;
+    if (mark[tid]) nrow_of[hp + f - 1] = 1u;                       // (hpos is the exclusive scan of the flags: the read of HSP tid is hp + f - 1)
+    if (tid == n - 1) counters[C_HEADS] = hp + f;
 }
 
 
@@ -1599,9 +1603,8 @@ __global__ void __launch_bounds__(256) k_heavy_lists(const uint32_t *__restrict_
     int cls = -1;                                                // -1 nothing to do, 0..3 light class, 4 heavy
     if (s < nheads) {
         const uint32_t a = heads[s], b = (s + 1 < nheads) ? heads[s + 1] : nhsps, n = b - a;
-        uint32_t any = 0;
-        for (uint32_t k = a; k < b; k++) any |= mark[k];
-        if (!any) { nrow_of[s] = 0; best_of[s].family = -1; }
+        const uint32_t any = nrow_of[s];                           // (k_heads: the read has a marked HSP)
+        if (!any) best_of[s].family = -1;
         else cls = n > MC_FH_MIN ? 4 : MC_LIGHT_CLASS(n);
     }
     const uint32_t o = mc_block_alloc(&counters[C_HEAVY], cls == 4);
@@ -2553,7 +2556,8 @@ static int stage_c(mc_handle *h, McCtx &c)
         k_gather<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(c.d_hsps, c.d_idxo, nh, c.d_sorted, d_flags, c.d_mark, h->hT.loge_thr);
         bytes = c.sorttmp_bytes;
         HIPCK(rocprim::exclusive_scan(c.d_sorttmp, bytes, d_flags, d_hpos, 0u, (size_t)nh, rocprim::plus<uint32_t>(), st));
-        k_heads<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(d_flags, d_hpos, nh, c.d_heads, c.d_counters);
+        HIPCK(hipMemsetAsync(c.d_nrow, 0, ((size_t)c.n + 1) * sizeof(uint32_t), st));
+        k_heads<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(d_flags, d_hpos, c.d_mark, nh, c.d_heads, c.d_nrow, c.d_counters);
     }
     HIPCK(hipEventRecord(c.ev[5], st));
     return counters_to_host(c);

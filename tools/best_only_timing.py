@@ -17,9 +17,10 @@ eng = _native.Engine(device=0)
 eng.set_run(L, model["pars"][str(L)], model["families"])
 eng.attach(reads.data_ptr(), 2 * N)
 import time
-for parts in (1, 2):
+only_modes = (True,) if os.environ.get("MC_BOT_ONLY") else (False, True)      # (tools/best_only_trace.sh: the best-hits-only path alone)
+for parts in ((1,) if os.environ.get("MC_BOT_ONLY") else (1, 2)):
     eng.set_parts(parts)
-    for only in (False, True):
+    for only in only_modes:
         eng.set_best_hits_only(only)
         for rep in range(3):
             t = time.time()
