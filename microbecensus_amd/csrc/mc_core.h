@@ -201,6 +201,24 @@ MC_HD void mc_seg_comp(const uint8_t *s, int n, uint8_t *comp)
     for (int i = 0; i < 20; i++) comp[i] = 0;
     for (int i = 0; i < n; i++) if (s[i] < 20) comp[s[i]]++;
 }
+// The same counts gathered in registers (20 classes x 8 bits in three words) and written once: with the counts in memory every
+// residue is a read of the residue, a read of its count and a write of it, each waiting for the one before - a window of 60
+// residues costs more than the eight probabilities of a trimming item behind it.  comp must be 4-byte aligned.
+MC_HD void mc_seg_comp_rg(const uint8_t *s, int n, uint8_t *comp)
+{
+    uint64_t c0 = 0, c1 = 0;
+    uint32_t c2 = 0;
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const int r0 = s[i], r1 = s[i + 1], r2 = s[i + 2], r3 = s[i + 3];
+#define MC_COMP_ADD(r) do { const uint64_t inc = 1ull << (((r) & 7) * 8); if ((r) < 8) c0 += inc; else if ((r) < 16) c1 += inc; else if ((r) < 20) c2 += (uint32_t)inc; } while (0)
+        MC_COMP_ADD(r0); MC_COMP_ADD(r1); MC_COMP_ADD(r2); MC_COMP_ADD(r3);
+    }
+    for (; i < n; i++) { const int r = s[i]; MC_COMP_ADD(r); }
+#undef MC_COMP_ADD
+    uint32_t *w = (uint32_t *)comp;
+    w[0] = (uint32_t)c0; w[1] = (uint32_t)(c0 >> 32); w[2] = (uint32_t)c1; w[3] = (uint32_t)(c1 >> 32); w[4] = c2;
+}
 MC_HD double mc_seg_getprob(const double *lnfac, const uint8_t *sv, int total)
 { // Seg::getprob@0x4393d0 = lnperm + lnass - total*ln 20
     double ans1 = lnfac[20];

@@ -253,7 +253,7 @@ __device__ __forceinline__ void mc_seg_wave(const double *lnf, const int32_t *fx
                             }
                     }
                 } else {
-                    mc_seg_comp(s + wfirst, len, ws.comp);
+                    mc_seg_comp_rg(s + wfirst, len, ws.comp);
                     mc_seg_state(ws.comp, ws.sv);
                     for (int w0 = wfirst;; w0++) {
                         const unsigned long long k2 = mc_seg_key(mc_seg_getprob(lnf, ws.sv, len));

@@ -199,6 +199,14 @@ int main(int argc, char **argv)
                     McSegWS ws2{comp2, sv2, stk2};
                     mc_seg_mask_fx2(T.lnfac, T.seg_dout, q2.data(), n3, ws2);
                     if (n3 != n || memcmp(q2.data(), p, (size_t)n)) seg_bad++;
+                    if (n3 >= 16) {   // ... and the register form of the composition count on a long window of the frame
+                        alignas(4) uint8_t ca[20], cb[20];
+                        mc_translate_frame(T, (const uint8_t *)rs[r].data(), read_len, f, q2.data());
+                        const int wl = 16 + (int)((r * 7 + (size_t)f) % (size_t)(n3 - 15)), ws0 = (int)((r + (size_t)f) % (size_t)(n3 - wl + 1));
+                        mc_seg_comp(q2.data() + ws0, wl, ca);
+                        mc_seg_comp_rg(q2.data() + ws0, wl, cb);
+                        if (memcmp(ca, cb, 20)) seg_bad++;
+                    }
                     const int W3 = (n3 <= 11) ? 8 : 12;
                     if (W3 <= n3) {   // ... with the window flags from the register form of the pass
                         McBits192 a0, b0, a1, b1;
