@@ -1777,8 +1777,10 @@ __device__ unsigned long long g_fh_acc[8], g_fh_cnt[8];
 #else
 #define MC_FH_TICK(k) do { } while (0)
 #endif
-// the heap words of a heavy read: in its own scratch, behind the place of its rows (64 n bytes; the area holds 96 n)
-__device__ __forceinline__ uint32_t *mc_heavy_words(McHsp *tmp, uint32_t a, int n) { return (uint32_t *)((uint8_t *)(tmp + 2 * (size_t)a) + (size_t)64 * n); }
+// the heap words of a heavy read: in its own scratch, behind the place of its rows (at most n rows of 72 bytes; the area holds 96 n
+// bytes and the words need 4 n + 8)
+static_assert(sizeof(McRow) == 72 && sizeof(McHsp) == 48, "mc_heavy_words: rows of 72 bytes in an area of 2 x 48 bytes per HSP");
+__device__ __forceinline__ uint32_t *mc_heavy_words(McHsp *tmp, uint32_t a, int n) { return (uint32_t *)((uint8_t *)(tmp + 2 * (size_t)a) + (size_t)sizeof(McRow) * n); }
 
 // MergeRes' heap sort for the heavy reads, ONE LANE PER READ: the sort replays libstdc++'s exact sequence of moves and is a chain
 // of dependent LDS accesses - as lane 0 of the read's own wave it was half of the heavy kernels' time (cycle counters), with 63

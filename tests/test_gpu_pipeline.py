@@ -122,6 +122,20 @@ def test_synthetic_lengths_against_oracle(engine, L, n):
     assert len(rows) > 100
 
 
+def test_heavy_read_whose_hsps_nearly_all_print(engine):
+    """A 50 bp read of the genome set with 198 rows out of about as many HSPs: it is finished by the wave-per-read kernels, and
+    the words of MergeRes' heap sort lie in the read's scratch behind the place of its rows - which nearly fill it here (the
+    words once sat where the last rows are written).  Alone and among copies that fill a wave's worth of such reads."""
+    import numpy as np
+    read = np.frombuffer(b"CCTGGCAATGATGACTCCATCAGAGCAATTGGTTATTACGCAAGAGAAAT", dtype=np.uint8)
+    for reps in (1, 70):
+        reads = np.tile(read, (reps, 1))
+        engine.set_run(50)
+        rows, _ = engine.search(reads)
+        assert len(rows) == 198 * reps
+        assert_rows_equal(_rows(rows), _oracle_rows(reads))
+
+
 def test_edge_cases_against_oracle(engine):
     """Lower-case reads give no hits; a codon holding N becomes an unknown residue (-5) that does not break the
     alignment; poly-A / low-complexity reads are SEG-masked; a read identical to a marker gene hits it at 100 %."""
