@@ -491,6 +491,10 @@ __global__ void __launch_bounds__(256) k_enumerate(const McTables *__restrict__ 
 #define MC_EN_NCHUNK(L) ((((L) / 3 - 6) + 63) / 64 > 0 ? (((L) / 3 - 6) + 63) / 64 : 1)
 static_assert(6 * MC_EN_NCHUNK(3 * MC_MAXAA) * 64 <= 2048, "a deferred position is kept in 11 bits beside the wildcard filter's 4-bit answer");
 #define MC_EN_ROW(FP) ((((FP) + 10 + 7) / 8) * 4)   // bytes of a frame's row of reduced-alphabet codes, two per byte, padded past the last seed's key
+#define MC_EN_RAWB(FP) ((6 * (FP) + 255) / 256 * 256)   // the NEXT read's six frames as they lie in global memory, fetched straight into LDS while this read is searched
+#define MC_EN_CN(x) ((x) > 6 ? (x) - 6 : 0)
+#define MC_EN_NPOS(L) ((2 * (MC_EN_CN((L) / 3) + MC_EN_CN(((L) - 1) / 3) + MC_EN_CN(((L) - 2) / 3)) + 7) / 8 * 8)   // seed positions of a read's six frames (padded): what pre and dq can hold
+#define MC_EN_WAVE_LDS(FP, L) ((size_t)6 * MC_EN_ROW(FP) + MC_EN_RAWB(FP) + (size_t)MC_EN_NPOS(L) * (8 + 2))
 #define MC_EN_BLK 2048u                     // task slots a wave reserves at a time (one global atomic per block, not per append)
 #define MC_EN_SHORT 4                      // seed-hit ranges up to this long are written by the lane that found them
 #define MC_TASK_NONE 0xFFFFFFFFu            // read id of the padding entries that close a partly used block
@@ -687,14 +691,14 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
     McEnWave *W = (McEnWave *)(smem + 64 + (size_t)wv * MC_EN_WAVE_BYTES(COUNT));
     uint8_t *fr_all = smem + 64 + (size_t)MC_EN_WAVES * MC_EN_WAVE_BYTES(COUNT);
     const int FPn = MC_EN_ROW(FP);
-    const int nchunk = MC_EN_NCHUNK(L);                                    // chunks of 64 positions per frame
     const int ql0 = L / 3, ql1 = (L - 1) / 3, ql2 = (L - 2) / 3;           // frame lengths (frames f and f + 3 alike)
     const int cn0 = ql0 > 6 ? ql0 - 6 : 0, cn1 = ql1 > 6 ? ql1 - 6 : 0, cn2 = ql2 > 6 ? ql2 - 6 : 0;   // seed positions of the frames, and their running sums
     const int cum1 = cn0, cum2 = cum1 + cn1, cum3 = cum2 + cn2, cum4 = cum3 + cn0, cum5 = cum4 + cn1, cum6 = cum5 + cn2;
     const uint32_t rcp_fpn = (65536u + (uint32_t)FPn - 1u) / (uint32_t)FPn;   // i / FPn = (i * rcp_fpn) >> 16 for the i < 6 * FPn in use
-    uint8_t *fr = fr_all + (size_t)wv * (6 * FPn + 6 * nchunk * (512 + 128));
-    unsigned long long *pre = (unsigned long long *)(fr + 6 * FPn);        // the positions of the read that probe anything (at most 6 * nchunk * 64)
-    uint16_t *dq = (uint16_t *)(pre + 6 * nchunk * 64);                    // positions whose neighbourhood waits for the exact probes' results
+    uint8_t *fr = fr_all + (size_t)wv * MC_EN_WAVE_LDS(FP, L);
+    uint8_t *raw = fr + 6 * FPn;                                            // the next read's frames, on their way (global_load_lds)
+    unsigned long long *pre = (unsigned long long *)(raw + MC_EN_RAWB(FP));   // the positions of the read that probe anything (at most MC_EN_NPOS)
+    uint16_t *dq = (uint16_t *)(pre + MC_EN_NPOS(L));                       // positions whose neighbourhood waits for the exact probes' results
     if (threadIdx.x < 32) grp[threadIdx.x] = T->grp[threadIdx.x];
     if (lane == 0) { W->blk_base = 0; W->blk_used = MC_EN_BLK; }
     __syncthreads();
@@ -706,12 +710,24 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
     if (lane < 6) { W->tacc[lane] = 0; W->tcnt[lane] = 0; }
     unsigned long long tlast = __builtin_readcyclecounter(); int tcat = 0;   // 0 staging/other 1 heavy 2 process 3 push 4 setup 5 expand
 #endif
+    // The frames of a read come from HBM; with one wave per read that trip stood at the head of every read.  They are fetched
+    // straight into LDS (no registers) one read ahead: issued when this read's codes have been staged, needed when it is done.
+    const int nraw = 6 * FP / 4;                                            // dwords of a read's frames (FP is a multiple of 4)
+#define MC_EN_FETCH(rr)                                                                                                          \
+    do {                                                                                                                         \
+        const uint32_t *gs_ = (const uint32_t *)(frames + (rr) * 6 * FP);                                                        \
+        for (int i0_ = 0; i0_ < nraw; i0_ += 64)                                                                                 \
+            if (i0_ + lane < nraw) __builtin_amdgcn_global_load_lds(gs_ + i0_ + lane, (uint32_t *)raw + i0_, 4, 0, 0);            \
+    } while (0)
+    if ((int64_t)blockIdx.x * MC_EN_WAVES + wv < nreads) MC_EN_FETCH((int64_t)blockIdx.x * MC_EN_WAVES + wv);
     for (int64_t r = (int64_t)blockIdx.x * MC_EN_WAVES + wv; r < nreads; r += nw) {
         int qn = 0, hn = 0, en = 0;
         MC_TICK(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0): this read's frames have arrived
+        mc_wave_sync();
         {   // stage the six frames of this read as reduced-alphabet codes, two per byte (rows of FPn bytes, padded with the
             // invalid code: a seed's key residues past the frame end then read as invalid by themselves); clear the flags
-            const uint8_t *src = frames + r * 6 * FP;
+            const uint8_t *src = raw;
             for (int i = lane; i < 6 * FPn; i += 64) {                         // byte i of the six rows
                 const int f = (int)(((uint32_t)i * rcp_fpn) >> 16), b2 = 2 * (i - f * FPn);
                 uint32_t g0 = MC_INVGRP, g1 = MC_INVGRP;
@@ -721,6 +737,7 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
             if (lane < 36) { ((uint32_t *)W->setter)[lane] = 0; ((uint32_t *)W->hit)[lane] = 0; }
             mc_wave_sync();
         }
+        if (r + nw < nreads) MC_EN_FETCH(r + nw);
         // What a seed position will do is decided here, once: the 6-mer's bucket and the four key residues (ten codes = 40
         // bits out of three aligned words of the row), whether the bucket holds anything (bitmap gather; those of three sweeps
         // are in flight together), and from that which probes it makes.  The positions of the six frames are numbered through
@@ -2470,7 +2487,7 @@ static int stage_a(mc_handle *h, McCtx &c)
     }
 #endif
     if (h->fast_enum) {
-        const size_t per_wave = MC_EN_WAVE_BYTES(h->count_traffic) + (size_t)6 * MC_EN_ROW(FP) + (size_t)6 * MC_EN_NCHUNK(L) * (512 + 128);
+        const size_t per_wave = MC_EN_WAVE_BYTES(h->count_traffic) + MC_EN_WAVE_LDS(FP, L);
         // Launch shape: the kernel needs 79 VGPRs (6 waves per SIMD) and is bound by instruction issue with some latency left to
         // hide - measured per 1 M reads of 150 bp: 16 waves per CU 6.77 ms, 20: 6.45, 24 (2 x 12, 3 x 8, 6 x 4 alike): 6.39.
         // So: as many waves per CU as the LDS holds, up to 24, in workgroups of 12 / 8 / 4 / 16 waves.
