@@ -1015,6 +1015,7 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
 // row cannot be classified, whatever the ranking does - 99 % of the reads of a shotgun library.  The kernels that make HSPs mark
 // the reads that have such an HSP (cand), and only THEIR HSPs - all of them: the others still decide the sums, the order and the
 // 500-row cap - are sorted and finished.
+#define MC_HSP_KEY(h) (((uint64_t)(h).read << 43) | ((uint64_t)(uint32_t)(h).sidx << 28) | (uint64_t)(h).chrono)   // (read, subject, hit order)
 __device__ __forceinline__ bool mc_hsp_can_classify(const McTables &T, const McClassPars &P, const McIndex &X, const int32_t *fam, const McHsp &h)
 {
     const int f = fam[h.sidx];
@@ -1134,7 +1135,7 @@ __device__ unsigned long long g_ev_acc[8];           // wave time per phase, sum
 #define MC_EV_STAGE_G 640    // gap tasks (17.5 KB)
 __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(MC_EV_BS) k_eval_seeds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
                                                     const McSeedTask *__restrict__ tasks, const uint32_t *__restrict__ ntasks_p, uint32_t cap_tasks, McHsp *hsps, uint32_t cap_hsps,
-                                                    McGapTask *gaps, uint32_t cap_gaps, uint32_t *counters, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam, uint8_t *cand)
+                                                    McGapTask *gaps, uint32_t cap_gaps, uint32_t *counters, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam, uint8_t *cand, uint64_t *hkeys)
 {
     const uint32_t ntasks = *ntasks_p <= cap_tasks ? *ntasks_p : 0u;   // (device-side count of the seed kernel; after an overflow the host discards the batch)
     __shared__ McHot hot;
@@ -1169,7 +1170,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(MC_
             const uint32_t bH = baseH, bG = baseG;
             if (flH) {
                 if (bH + fh > cap_hsps) { if (threadIdx.x == 0) counters[C_OVERFLOW] = 2; }
-                else for (uint32_t i = threadIdx.x; i < fh * 3; i += MC_EV_BS) ((uint4 *)(hsps + bH))[i] = ((const uint4 *)stH)[i];          // 48-byte records as 16-byte words
+                else {
+                    for (uint32_t i = threadIdx.x; i < fh * 3; i += MC_EV_BS) ((uint4 *)(hsps + bH))[i] = ((const uint4 *)stH)[i];          // 48-byte records as 16-byte words
+                    for (uint32_t i = threadIdx.x; i < fh; i += MC_EV_BS) hkeys[bH + i] = MC_HSP_KEY(stH[i]);
+                }
             }
             if (flG) {
                 if (bG + fg > cap_gaps) { if (threadIdx.x == 0) counters[C_OVERFLOW] = 3; }
@@ -1339,7 +1343,7 @@ __global__ void __launch_bounds__(256) k_gap_dedupe(McIndex X, int L, const McGa
 // every gap task -> its HSP, from the flank results of its group's leader
 __global__ void __launch_bounds__(256) k_gap_emit(const McTables *__restrict__ T, McIndex X, int L, const McGapTask *__restrict__ gaps, uint32_t ngaps, const uint32_t *__restrict__ leader,
                                                   const McFlankOut *__restrict__ fout, McHsp *hsps, uint32_t cap_hsps, uint32_t *counters, const McClassPars *__restrict__ P,
-                                                  const int32_t *__restrict__ fam, uint8_t *cand)
+                                                  const int32_t *__restrict__ fam, uint8_t *cand, uint64_t *hkeys)
 {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     bool keep = false;
@@ -1363,7 +1367,7 @@ __global__ void __launch_bounds__(256) k_gap_emit(const McTables *__restrict__ T
         if (keep && cand && mc_hsp_can_classify(*T, *P, X, fam, h)) cand[h.read] = 1;
     }
     const uint32_t o = mc_block_alloc(&counters[C_HSPS], keep);
-    if (keep) { if (o < cap_hsps) hsps[o] = h; else counters[C_OVERFLOW] = 2; }
+    if (keep) { if (o < cap_hsps) { hsps[o] = h; hkeys[o] = MC_HSP_KEY(h); } else counters[C_OVERFLOW] = 2; }
 }
 
 #define MC_GAP_W 1200   // columns of the full-size DP workspace (markers are <= 1183 aa, checked in mc_open)
@@ -1539,7 +1543,9 @@ __global__ void __launch_bounds__(64) k_gapped_lds(const McTables *__restrict__ 
 }
 
 // sort keys of the HSPs of the marked reads, packed (their count in counters[C_HSPS2]); the HSP count is read on the device
-__global__ void __launch_bounds__(256) k_select_keys(const McHsp *__restrict__ hsps, const uint32_t *__restrict__ counters_in, uint32_t cap_hsps, const uint8_t *__restrict__ cand,
+// The sort key of every HSP is written beside it by the kernel that makes it (k_eval_seeds' flush, k_gap_emit): the selection
+// below and the sort then read 8 bytes per HSP instead of its 48-byte record (k_make_keys, which read them all again, is gone).
+__global__ void __launch_bounds__(256) k_select_keys(const uint64_t *__restrict__ hkeys, const uint32_t *__restrict__ counters_in, uint32_t cap_hsps, const uint8_t *__restrict__ cand,
                                                      uint64_t *keys, uint32_t *idx, uint32_t *counters)
 {
     const uint32_t n = counters_in[C_HSPS] <= cap_hsps ? counters_in[C_HSPS] : 0u;
@@ -1548,22 +1554,18 @@ __global__ void __launch_bounds__(256) k_select_keys(const McHsp *__restrict__ h
         bool want = false;
         uint64_t key = 0;
         if (tid < n) {
-            const McHsp &h = hsps[tid];
-            want = cand[h.read] != 0;
-            key = ((uint64_t)h.read << 43) | ((uint64_t)(uint32_t)h.sidx << 28) | (uint64_t)h.chrono;
+            key = hkeys[tid];
+            want = cand[(uint32_t)(key >> 43)] != 0;
         }
         const uint32_t o = mc_block_alloc(&counters[C_HSPS2], want);
         if (want) { keys[o] = key; idx[o] = tid; }
     }
 }
 
-__global__ void k_make_keys(const McHsp *__restrict__ hsps, uint32_t n, uint64_t *keys, uint32_t *idx)
-{
-    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= n) return;
-    const McHsp &h = hsps[tid];
-    keys[tid] = ((uint64_t)h.read << 43) | ((uint64_t)(uint32_t)h.sidx << 28) | (uint64_t)h.chrono;
-    idx[tid] = tid;
+__global__ void k_iota(uint32_t *idx, uint32_t n)
+{   // 0, 1, 2, ...: the values the sort of ALL HSPs carries along (written once per pool)
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < n) idx[tid] = tid;
 }
 // sorted order: copies the HSPs, flags the first HSP of every read, and marks the HSPs that can make their read print
 // anything: log E below the threshold, or a second, DIFFERENT HSP on the same subject (sum statistics may lower the group's E).
@@ -2139,7 +2141,7 @@ struct McCtx {
     uint8_t *d_frames = nullptr, *d_frames_base = nullptr;   // (64 bytes of room in front: k_eval_seeds reads 8 bytes at a time backwards from a seed)
     unsigned long long *d_stats = nullptr;
     McSeedTask *d_tasks = nullptr; McGapTask *d_gaps = nullptr; McHsp *d_hsps = nullptr, *d_sorted = nullptr, *d_v = nullptr, *d_tmp = nullptr;
-    uint64_t *d_k64 = nullptr, *d_k64o = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
+    uint64_t *d_k64 = nullptr, *d_k64o = nullptr, *d_hkeys = nullptr; uint32_t *d_iota = nullptr, *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
     uint32_t *d_counters = nullptr;
     McRow *d_rows = nullptr; uint32_t *d_nrow = nullptr, *d_rowoff = nullptr; McBestHit *d_best = nullptr, *d_bestof = nullptr; uint8_t *d_mark = nullptr, *d_cand = nullptr;
     McGapCell *d_gws_full = nullptr; uint32_t *d_retry = nullptr, *d_retry2 = nullptr; int gap_threads_full = 0;
@@ -2207,7 +2209,7 @@ extern "C" int mc_device_count(void)
 
 static void ctx_free(McCtx &c)
 {
-    void *ptrs[] = {c.d_frames_base, c.d_tasks, c.d_gaps, c.d_hsps, c.d_sorted, c.d_v, c.d_tmp, c.d_k64, c.d_k64o, c.d_idx, c.d_idxo, c.d_heads, c.d_sorttmp, c.d_counters, c.d_rows,
+    void *ptrs[] = {c.d_frames_base, c.d_tasks, c.d_gaps, c.d_hsps, c.d_sorted, c.d_v, c.d_tmp, c.d_k64, c.d_k64o, c.d_hkeys, c.d_iota, c.d_idx, c.d_idxo, c.d_heads, c.d_sorttmp, c.d_counters, c.d_rows,
                     c.d_nrow, c.d_rowoff, c.d_best, c.d_bestof, c.d_mark, c.d_cand, c.d_gws_full, c.d_retry, c.d_retry2, c.d_gtab, c.d_gleader, c.d_fout, c.d_stats};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : {(void *)c.h_c, (void *)c.h_stats, (void *)c.h_best}) if (p) (void)hipHostFree(p);
@@ -2396,7 +2398,7 @@ static int ensure_capacity(mc_handle *h, McCtx &c, int64_t nreads)
     c.gap_threads_full = 16 * 1024;                                 // full-size DP rows for the last-resort launch (460 MB)
     if (dalloc(&c.d_frames_base, (size_t)cap * 6 * h->FP + 128) || dalloc(&c.d_tasks, c.cap_tasks) ||
         dalloc(&c.d_gaps, c.cap_gaps) || dalloc(&c.d_hsps, c.cap_hsps) || dalloc(&c.d_sorted, c.cap_hsps) || dalloc(&c.d_v, c.cap_hsps) ||
-        dalloc(&c.d_tmp, (size_t)c.cap_hsps * 2) || dalloc(&c.d_k64, c.cap_hsps) || dalloc(&c.d_k64o, c.cap_hsps) || dalloc(&c.d_idx, c.cap_hsps) ||
+        dalloc(&c.d_tmp, (size_t)c.cap_hsps * 2) || dalloc(&c.d_k64, c.cap_hsps) || dalloc(&c.d_k64o, c.cap_hsps) || dalloc(&c.d_hkeys, c.cap_hsps) || dalloc(&c.d_iota, c.cap_hsps) || dalloc(&c.d_idx, c.cap_hsps) ||
         dalloc(&c.d_idxo, c.cap_hsps) || dalloc(&c.d_heads, (size_t)cap + 1) || dalloc(&c.d_rows, c.cap_rows) ||
         dalloc(&c.d_mark, (size_t)c.cap_hsps) || dalloc(&c.d_cand, (size_t)cap + 64) || dalloc(&c.d_nrow, (size_t)cap + 1) || dalloc(&c.d_rowoff, (size_t)cap + 1) || dalloc(&c.d_best, (size_t)cap + 1) || dalloc(&c.d_bestof, (size_t)cap + 1) ||
         dalloc(&c.d_gws_full, (size_t)c.gap_threads_full * MC_GAP_W) || dalloc(&c.d_retry, (size_t)c.cap_gaps * 2 + (size_t)cap + 1) || dalloc(&c.d_retry2, (size_t)c.cap_gaps * 2) || dalloc(&c.d_gleader, (size_t)c.cap_gaps) ||
@@ -2404,6 +2406,7 @@ static int ensure_capacity(mc_handle *h, McCtx &c, int64_t nreads)
         return -1;
     c.d_frames = c.d_frames_base + 64;
     HIPCK(hipMemsetAsync(c.d_frames_base, MC_INV, 64, c.stream));
+    k_iota<<<dim3((c.cap_hsps + 255) / 256), dim3(256), 0, c.stream>>>(c.d_iota, c.cap_hsps);
     if (c.h_best) { (void)hipHostFree(c.h_best); c.h_best = nullptr; }
     HIPCK(hipHostMalloc((void **)&c.h_best, sizeof(McBestHit) * ((size_t)cap + 1), hipHostMallocDefault));
     c.h_best_cap = (size_t)cap + 1;
@@ -2516,7 +2519,7 @@ static int stage_a(mc_handle *h, McCtx &c)
     const size_t lds_ev = (size_t)MC_EV_STAGE_H * sizeof(McHsp) + (size_t)MC_EV_STAGE_G * sizeof(McGapTask);   // 51.7 KB: three workgroups per CU
     HIPCK(hipFuncSetAttribute((const void *)k_eval_seeds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ev));
     static const unsigned ev_bpc = getenv("MC_EV_BPC") ? (unsigned)atoi(getenv("MC_EV_BPC")) : (unsigned)MC_EV_BPC;   // (experiments)
-    k_eval_seeds<<<dim3(256u * ev_bpc), dim3(MC_EV_BS), lds_ev, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_tasks, c.d_counters + C_TASKS, c.cap_tasks, c.d_hsps, c.cap_hsps, c.d_gaps, c.cap_gaps, c.d_counters, h->d_P, h->d_fam, h->best_only ? c.d_cand : nullptr);
+    k_eval_seeds<<<dim3(256u * ev_bpc), dim3(MC_EV_BS), lds_ev, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_tasks, c.d_counters + C_TASKS, c.cap_tasks, c.d_hsps, c.cap_hsps, c.d_gaps, c.cap_gaps, c.d_counters, h->d_P, h->d_fam, h->best_only ? c.d_cand : nullptr, c.d_hkeys);
     HIPCK(hipEventRecord(c.ev[3], st));
     return counters_to_host(c);
 }
@@ -2550,11 +2553,11 @@ static int stage_b(mc_handle *h, McCtx &c)
                                                                                                                  c.d_counters + C_RETRY, c.d_retry, gap_refill);
         k_gapped_lds<MC_GAP_WIN2, MC_GAP_LANES2><<<dim3(256u * 4u), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry, c.d_counters + C_RETRY, c.d_fout, c.d_counters + C_RETRY2, c.d_retry2, 1);
         k_gapped<<<dim3(c.gap_threads_full / 128), dim3(128), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry2, c.d_counters + C_RETRY2, c.d_fout, c.d_counters, c.d_gws_full, MC_GAP_W);
-        k_gap_emit<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, L, c.d_gaps, ngaps, c.d_gleader, c.d_fout, c.d_hsps, c.cap_hsps, c.d_counters, h->d_P, h->d_fam, h->best_only ? c.d_cand : nullptr);
+        k_gap_emit<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, L, c.d_gaps, ngaps, c.d_gleader, c.d_fout, c.d_hsps, c.cap_hsps, c.d_counters, h->d_P, h->d_fam, h->best_only ? c.d_cand : nullptr, c.d_hkeys);
     }
     HIPCK(hipEventRecord(c.ev[4], st));
     if (h->best_only)                                             // every HSP exists now: the sort keys of the marked reads' HSPs (their count goes to the host with the other counters)
-        k_select_keys<<<dim3(256u * 8u), dim3(256), 0, st>>>(c.d_hsps, c.d_counters, c.cap_hsps, c.d_cand, c.d_k64, c.d_idx, c.d_counters);
+        k_select_keys<<<dim3(256u * 8u), dim3(256), 0, st>>>(c.d_hkeys, c.d_counters, c.cap_hsps, c.d_cand, c.d_k64, c.d_idx, c.d_counters);
     return counters_to_host(c);
 }
 
@@ -2567,11 +2570,11 @@ static int stage_c(mc_handle *h, McCtx &c)
     const uint32_t nh = c.nh = h->best_only ? c.h_c[C_HSPS2] : c.h_c[C_HSPS];      // HSPs that are ranked
     if (nh) {
         uint32_t *d_flags = c.d_idx, *d_hpos = (uint32_t *)c.d_k64;      // both free once the sort has run
-        if (!h->best_only) k_make_keys<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(c.d_hsps, nh, c.d_k64, c.d_idx);
         size_t bytes = c.sorttmp_bytes;
         int rbits = 1;
         while ((1ll << rbits) < c.n) rbits++;
-        HIPCK(rocprim::radix_sort_pairs(c.d_sorttmp, bytes, c.d_k64, c.d_k64o, c.d_idx, c.d_idxo, (size_t)nh, 0, 43 + rbits, st));
+        // all HSPs: their keys as their kernels wrote them, carrying 0, 1, 2, ...; best hits only: the selected keys and indices
+        HIPCK(rocprim::radix_sort_pairs(c.d_sorttmp, bytes, h->best_only ? c.d_k64 : c.d_hkeys, c.d_k64o, h->best_only ? c.d_idx : c.d_iota, c.d_idxo, (size_t)nh, 0, 43 + rbits, st));
         k_gather<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(c.d_hsps, c.d_idxo, nh, c.d_sorted, d_flags, c.d_mark, h->hT.loge_thr);
         bytes = c.sorttmp_bytes;
         HIPCK(rocprim::exclusive_scan(c.d_sorttmp, bytes, d_flags, d_hpos, 0u, (size_t)nh, rocprim::plus<uint32_t>(), st));
