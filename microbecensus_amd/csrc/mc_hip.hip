@@ -1573,7 +1573,7 @@ __global__ void k_iota(uint32_t *idx, uint32_t n)
 // of them (mc_finish_group's stack), a group of one, printed only if its own log E is below the threshold - so equal neighbours
 // mark nothing, and a subject whose neighbours are all equal is all equal.  A read without a marked HSP prints no row and has no
 // best hit; the finishing kernels never see it.
-__global__ void k_gather(const McHsp *__restrict__ hsps, const uint32_t *__restrict__ idx, uint32_t n, McHsp *out, uint32_t *flags, uint8_t *mark, double loge_thr)
+__global__ void k_gather(const McHsp *__restrict__ hsps, const uint32_t *__restrict__ idx, const uint64_t *__restrict__ skeys, uint32_t n, McHsp *out, uint32_t *flags, uint8_t *mark, double loge_thr)
 {
     uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= n) return;
@@ -1581,9 +1581,14 @@ __global__ void k_gather(const McHsp *__restrict__ hsps, const uint32_t *__restr
     out[tid] = h;
     bool head = true, same_subject = false;
     if (tid > 0) {
-        const McHsp &p = hsps[idx[tid - 1]];
-        head = p.read != h.read;
-        same_subject = !head && p.sidx == h.sidx && !(p.frame == h.frame && p.qaas == h.qaas && p.ds == h.ds && p.qaae == h.qaae && p.de == h.de);
+        // read and subject of the HSP in front are in its sorted key (read 21 | subject 15 | hit order 28): its record - a second
+        // scattered 48-byte read - is only fetched when both are this HSP's
+        const uint64_t pk = skeys[tid - 1];
+        head = (uint32_t)(pk >> 43) != h.read;
+        if (!head && (int32_t)((pk >> 28) & 0x7FFFu) == h.sidx) {
+            const McHsp &p = hsps[idx[tid - 1]];
+            same_subject = !(p.frame == h.frame && p.qaas == h.qaas && p.ds == h.ds && p.qaae == h.qaae && p.de == h.de);
+        }
     }
     flags[tid] = head ? 1u : 0u;
     mark[tid] = (h.loge < loge_thr || same_subject) ? 1 : 0;
@@ -2575,7 +2580,7 @@ static int stage_c(mc_handle *h, McCtx &c)
         while ((1ll << rbits) < c.n) rbits++;
         // all HSPs: their keys as their kernels wrote them, carrying 0, 1, 2, ...; best hits only: the selected keys and indices
         HIPCK(rocprim::radix_sort_pairs(c.d_sorttmp, bytes, h->best_only ? c.d_k64 : c.d_hkeys, c.d_k64o, h->best_only ? c.d_idx : c.d_iota, c.d_idxo, (size_t)nh, 0, 43 + rbits, st));
-        k_gather<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(c.d_hsps, c.d_idxo, nh, c.d_sorted, d_flags, c.d_mark, h->hT.loge_thr);
+        k_gather<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(c.d_hsps, c.d_idxo, c.d_k64o, nh, c.d_sorted, d_flags, c.d_mark, h->hT.loge_thr);
         bytes = c.sorttmp_bytes;
         HIPCK(rocprim::exclusive_scan(c.d_sorttmp, bytes, d_flags, d_hpos, 0u, (size_t)nh, rocprim::plus<uint32_t>(), st));
         HIPCK(hipMemsetAsync(c.d_nrow, 0, ((size_t)c.n + 1) * sizeof(uint32_t), st));
