@@ -44,7 +44,7 @@ extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
         }                                                                                                   \
     } while (0)
 
-enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_HEAVY, C_HEAVY2, C_ITEMS, C_RETRY2, C_HEAVY3, C_LIGHT0, C_LIGHT1, C_LIGHT2, C_LIGHT3, C_HSPS2, C_N = 24 };
+enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_HEAVY, C_HEAVY2, C_ITEMS, C_RETRY2, C_HEAVY3, C_LIGHT0, C_LIGHT1, C_LIGHT2, C_LIGHT3, C_HSPS2, C_HPAD, C_GPAD, C_N = 24 };
 enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_EXACT = 16, S_WILD, S_PAIRS, S_PROBES, S_N = 20 };   // 64-bit algorithmic-traffic counters of k_enumerate; slots 4..: cycle counters of the MC_EXP_TIMING build
 
 // ------------------------------------------------------------------------------------------------
@@ -1131,21 +1131,49 @@ __device__ unsigned long long g_ev_acc[8];           // wave time per phase, sum
 #endif
 #define MC_EV_BS 512         // threads per workgroup
 #define MC_EV_BPC 3          // workgroups per CU
-#define MC_EV_STAGE_H 704    // HSPs staged per workgroup (33 KB)
-#define MC_EV_STAGE_G 640    // gap tasks (17.5 KB)
+#define MC_EV_STAGE_H 88     // HSPs staged per WAVE (4.1 KB)
+#define MC_EV_STAGE_G 80     // gap tasks per wave (2.2 KB)
+#define MC_EV_BLK 256u       // slots of the HSP / gap-task pools a wave reserves at a time (one global atomic per block)
+// A wave's staged records go out when the next 64 hits might not fit: into the wave's current block of the pool, a new block
+// reserved when that one is full (the records of one flush may straddle two blocks).  Returns false after a pool overflow.
+template <class R>
+__device__ __forceinline__ bool mc_ev_flush(const R *st, uint32_t n, R *pool, uint32_t cap, uint32_t *counter, uint32_t &blk_base, uint32_t &blk_used, uint64_t *hkeys, int lane)
+{
+    uint32_t src = 0;
+    while (n > 0) {
+        if (blk_used == MC_EV_BLK) {
+            uint32_t nb = 0;
+            if (lane == 0) nb = atomicAdd(counter, MC_EV_BLK);
+            nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+            if (nb + MC_EV_BLK > cap) return false;
+            blk_base = nb; blk_used = 0;
+        }
+        const uint32_t m = n < MC_EV_BLK - blk_used ? n : MC_EV_BLK - blk_used;
+        const uint32_t *s32 = (const uint32_t *)(st + src);
+        uint32_t *d32 = (uint32_t *)(pool + blk_base + blk_used);
+        for (uint32_t i = (uint32_t)lane; i < m * (uint32_t)(sizeof(R) / 4); i += 64) d32[i] = s32[i];           // (consecutive words: coalesced)
+        if (hkeys) for (uint32_t i = (uint32_t)lane; i < m; i += 64) hkeys[blk_base + blk_used + i] = MC_HSP_KEY(*(const McHsp *)(st + src + i));
+        blk_used += m; src += m; n -= m;
+    }
+    return true;
+}
 __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(MC_EV_BS) k_eval_seeds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
                                                     const McSeedTask *__restrict__ tasks, const uint32_t *__restrict__ ntasks_p, uint32_t cap_tasks, McHsp *hsps, uint32_t cap_hsps,
                                                     McGapTask *gaps, uint32_t cap_gaps, uint32_t *counters, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam, uint8_t *cand, uint64_t *hkeys)
 {
     const uint32_t ntasks = *ntasks_p <= cap_tasks ? *ntasks_p : 0u;   // (device-side count of the seed kernel; after an overflow the host discards the batch)
     __shared__ McHot hot;
-    __shared__ uint32_t fillH, fillG, baseH, baseG;
-    McHsp *stH = (McHsp *)mc_smem;                                // MC_EV_STAGE_H records
-    McGapTask *stG = (McGapTask *)(stH + MC_EV_STAGE_H);          // MC_EV_STAGE_G records
+    const int lane = mc_lane(), wv = threadIdx.x >> 6;
+    // Every wave stages what survives in a pool of its own and flushes it alone - no barrier in the loop: with one pool per
+    // workgroup the eight waves met twice per 512 hits (and a third time, around a global atomic, at every flush), which was 28 %
+    // of the kernel's wave time (cycle counters).  The pools are handed out in blocks of 256 slots per wave; what a wave does not
+    // use of its last block is padded with records the later stages skip (read = MC_TASK_NONE; C_HPAD / C_GPAD count them).
+    McHsp *stH = (McHsp *)(mc_smem + (size_t)wv * (MC_EV_STAGE_H * sizeof(McHsp) + MC_EV_STAGE_G * sizeof(McGapTask)));
+    McGapTask *stG = (McGapTask *)(stH + MC_EV_STAGE_H);
     mc_load_hot(&hot, T);
-    if (threadIdx.x == 0) { fillH = 0; fillG = 0; }
     __syncthreads();
-    const int lane = mc_lane();
+    uint32_t fillH = 0, fillG = 0, hb_base = 0, hb_used = MC_EV_BLK, gb_base = 0, gb_used = MC_EV_BLK;
+    bool over = false;
     const uint32_t nchunks = (ntasks + MC_EV_BS - 1) / MC_EV_BS;
     // The chain of dependent reads of a hit was: its record -> the subject's offsets -> the residue in front of the seed -> the
     // seed's residues, four trips to the L2 before the gate that ends seven hits in ten.  Now: the record of the NEXT chunk is
@@ -1159,30 +1187,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(MC_
     if (blockIdx.x * MC_EV_BS + threadIdx.x < ntasks) tn = tasks[blockIdx.x * MC_EV_BS + threadIdx.x];
     for (uint32_t chunk = blockIdx.x;; chunk += gridDim.x) {
         const bool last = chunk >= nchunks;
-        // flush when the next 256 hits might not fit (or at the end)
-        __syncthreads();                                         // the staging of the previous chunk is complete
-        const uint32_t fh = fillH, fg = fillG;
-        __syncthreads();                                         // everybody has read the fill levels
-        const bool flH = fh != 0 && (last || fh > MC_EV_STAGE_H - MC_EV_BS), flG = fg != 0 && (last || fg > MC_EV_STAGE_G - MC_EV_BS);   // each pool by itself
-        if (flH || flG) {
-            if (threadIdx.x == 0) { if (flH) baseH = atomicAdd(&counters[C_HSPS], fh); if (flG) baseG = atomicAdd(&counters[C_GAPS], fg); }
-            __syncthreads();
-            const uint32_t bH = baseH, bG = baseG;
-            if (flH) {
-                if (bH + fh > cap_hsps) { if (threadIdx.x == 0) counters[C_OVERFLOW] = 2; }
-                else {
-                    for (uint32_t i = threadIdx.x; i < fh * 3; i += MC_EV_BS) ((uint4 *)(hsps + bH))[i] = ((const uint4 *)stH)[i];          // 48-byte records as 16-byte words
-                    for (uint32_t i = threadIdx.x; i < fh; i += MC_EV_BS) hkeys[bH + i] = MC_HSP_KEY(stH[i]);
-                }
-            }
-            if (flG) {
-                if (bG + fg > cap_gaps) { if (threadIdx.x == 0) counters[C_OVERFLOW] = 3; }
-                else for (uint32_t i = threadIdx.x; i < fg * (uint32_t)(sizeof(McGapTask) / 4); i += MC_EV_BS) ((uint32_t *)(gaps + bG))[i] = ((const uint32_t *)stG)[i];
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) { if (flH) fillH = 0; if (flG) fillG = 0; }
-            __syncthreads();
-        }
+        // flush when the next 64 hits might not fit (or at the end)
+        if (fillH != 0 && (last || fillH > MC_EV_STAGE_H - 64)) { mc_wave_sync(); if (!over && !mc_ev_flush(stH, fillH, hsps, cap_hsps, &counters[C_HSPS], hb_base, hb_used, hkeys, lane)) { over = true; if (lane == 0) counters[C_OVERFLOW] = 2; } fillH = 0; mc_wave_sync(); }
+        if (fillG != 0 && (last || fillG > MC_EV_STAGE_G - 64)) { mc_wave_sync(); if (!over && !mc_ev_flush(stG, fillG, gaps, cap_gaps, &counters[C_GAPS], gb_base, gb_used, (uint64_t *)nullptr, lane)) { over = true; if (lane == 0) counters[C_OVERFLOW] = 3; } fillG = 0; mc_wave_sync(); }
         if (last) break;
         MC_EV_TICK(0);
         const uint32_t tid = chunk * MC_EV_BS + threadIdx.x;
@@ -1233,15 +1240,19 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(MC_
             }
         }
         MC_EV_TICK(3);
-        {   // stage: one LDS atomic per wave and kind
+        {   // stage in the wave's own pools
             const unsigned long long mh = __ballot(keep), mg = __ballot(rc == 2);
-            uint32_t oh = 0, og = 0;
-            if (mh) { const int ld = __builtin_ctzll(mh); if (lane == ld) oh = atomicAdd(&fillH, (uint32_t)__popcll(mh)); oh = (uint32_t)__builtin_amdgcn_readlane((int)oh, ld); }
-            if (mg) { const int ld = __builtin_ctzll(mg); if (lane == ld) og = atomicAdd(&fillG, (uint32_t)__popcll(mg)); og = (uint32_t)__builtin_amdgcn_readlane((int)og, ld); }
-            if (keep) stH[oh + (uint32_t)__popcll(mh & ((1ull << lane) - 1))] = h;
-            if (rc == 2) stG[og + (uint32_t)__popcll(mg & ((1ull << lane) - 1))] = g;
+            if (keep) stH[fillH + (uint32_t)__popcll(mh & ((1ull << lane) - 1))] = h;
+            if (rc == 2) stG[fillG + (uint32_t)__popcll(mg & ((1ull << lane) - 1))] = g;
+            fillH += (uint32_t)__popcll(mh); fillG += (uint32_t)__popcll(mg);
         }
         MC_EV_TICK(4);
+    }
+    {   // what the wave did not use of its last blocks: records the later stages skip
+        const uint32_t ph = hb_used < MC_EV_BLK ? MC_EV_BLK - hb_used : 0u, pg = gb_used < MC_EV_BLK ? MC_EV_BLK - gb_used : 0u;
+        for (uint32_t i = (uint32_t)lane; i < ph; i += 64) { hsps[hb_base + hb_used + i].read = MC_TASK_NONE; hkeys[hb_base + hb_used + i] = ~0ull; }
+        for (uint32_t i = (uint32_t)lane; i < pg; i += 64) gaps[gb_base + gb_used + i].read = MC_TASK_NONE;
+        if (lane == 0) { if (ph) atomicAdd(&counters[C_HPAD], ph); if (pg) atomicAdd(&counters[C_GPAD], pg); }
     }
 #ifdef MC_EXP_TIMING
     if (lane == 0) for (int k = 0; k < 5; k++) atomicAdd(&g_ev_acc[k], ev_acc_[k]);
@@ -1310,7 +1321,8 @@ __global__ void __launch_bounds__(256) k_gap_dedupe(McIndex X, int L, const McGa
     uint32_t n = 0;
     McFlank fr, fl;
     bool hr = false, hl = false;
-    if (p < ngaps) {
+    if (p < ngaps && gaps[p].read == MC_TASK_NONE) leader[p] = p;         // (padding of a wave's last block: k_eval_seeds)
+    else if (p < ngaps) {
         const McGapTask g = gaps[p];
         unsigned long long h = ((unsigned long long)g.read << 32) ^ ((unsigned long long)g.sidx << 12) ^ (unsigned long long)(g.chrono >> 25);
         h ^= ((unsigned long long)(uint16_t)(g.qp - g.qbwd) << 48) ^ ((unsigned long long)(uint16_t)(g.dp - g.qbwd) << 20) ^ ((unsigned long long)(uint16_t)(g.qp + g.L + g.qfwd) << 3);
@@ -1348,7 +1360,7 @@ __global__ void __launch_bounds__(256) k_gap_emit(const McTables *__restrict__ T
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     bool keep = false;
     McHsp h;
-    if (p < ngaps) {
+    if (p < ngaps && gaps[p].read != MC_TASK_NONE) {                      // (not the padding of a wave's last block)
         const McGapTask g = gaps[p];
         const uint32_t ld = leader[p];
         const int frame = (int)(g.chrono >> 25), qlen = (L - frame % 3) / 3, dlen = (int)(X.off[g.sidx + 1] - X.off[g.sidx]);
@@ -1555,7 +1567,7 @@ __global__ void __launch_bounds__(256) k_select_keys(const uint64_t *__restrict_
         uint64_t key = 0;
         if (tid < n) {
             key = hkeys[tid];
-            want = cand[(uint32_t)(key >> 43)] != 0;
+            want = key != ~0ull && cand[(uint32_t)(key >> 43)] != 0;       // (~0: padding of a wave's last block)
         }
         const uint32_t o = mc_block_alloc(&counters[C_HSPS2], want);
         if (want) { keys[o] = key; idx[o] = tid; }
@@ -2155,7 +2167,7 @@ struct McCtx {
     uint32_t *h_c = nullptr; unsigned long long *h_stats = nullptr; McBestHit *h_best = nullptr; size_t h_best_cap = 0;
     // the part being processed
     const uint8_t *reads = nullptr; int64_t n = 0, first_read_id = 0;
-    uint32_t ntasks = 0, ngaps = 0, nh = 0, nh_all = 0, nheads = 0, nrows = 0, nbest = 0, nsegs = 0;
+    uint32_t ntasks = 0, ngaps = 0, gpad = 0, nh = 0, nh_all = 0, nheads = 0, nrows = 0, nbest = 0, nsegs = 0;
 };
 
 struct mc_handle {
@@ -2397,8 +2409,9 @@ static int ensure_capacity(mc_handle *h, McCtx &c, int64_t nreads)
     const int64_t L = h->read_len;
     c.cap_reads = 0;                                                // pools are being replaced: nothing is usable until all of them exist
     c.cap_tasks = (uint32_t)std::min<int64_t>(cap * (L + 32) + (1 << 20) + (int64_t)256 * 32 * MC_EN_BLK, 0x7fffffff);
-    c.cap_gaps = (uint32_t)std::min<int64_t>(cap * (L / 8 + 8) + (1 << 18), (1 << 27) - 2);   // (k_gap_dedupe keeps task index + 1 in 27 bits of a table entry: more tasks than that overflow the pool and the range is split)
-    c.cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 2 + 16) + (1 << 20), 0x7fffffff);
+    const int64_t ev_pad = (int64_t)256 * 4 * (MC_EV_BS / 64) * MC_EV_BLK;   // k_eval_seeds hands both pools out in blocks of MC_EV_BLK slots per wave: room for every wave's partly used last block
+    c.cap_gaps = (uint32_t)std::min<int64_t>(cap * (L / 8 + 8) + (1 << 18) + ev_pad, (1 << 27) - 2);   // (k_gap_dedupe keeps task index + 1 in 27 bits of a table entry: more tasks than that overflow the pool and the range is split)
+    c.cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 2 + 16) + (1 << 20) + ev_pad, 0x7fffffff);
     c.cap_rows = (uint32_t)std::min<int64_t>(cap * 48 + (1 << 20), 0x7fffffff);
     c.gap_threads_full = 16 * 1024;                                 // full-size DP rows for the last-resort launch (460 MB)
     if (dalloc(&c.d_frames_base, (size_t)cap * 6 * h->FP + 128) || dalloc(&c.d_tasks, c.cap_tasks) ||
@@ -2462,7 +2475,7 @@ static int stage_a(mc_handle *h, McCtx &c)
     const int L = h->read_len, FP = h->FP;
     hipStream_t st = c.stream;
     McIndex X = dev_index(h);
-    c.ntasks = c.ngaps = c.nh = c.nheads = c.nrows = c.nbest = c.nsegs = 0;
+    c.ntasks = c.ngaps = c.gpad = c.nh = c.nheads = c.nrows = c.nbest = c.nsegs = 0;
     HIPCK(hipMemsetAsync(c.d_counters, 0, sizeof(uint32_t) * C_N, st));
     HIPCK(hipMemsetAsync(c.d_stats, 0, sizeof(unsigned long long) * S_N, st));
     if (h->best_only) HIPCK(hipMemsetAsync(c.d_cand, 0, (size_t)n, st));
@@ -2521,7 +2534,7 @@ static int stage_a(mc_handle *h, McCtx &c)
         k_enumerate<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, X, c.d_frames, FP, L, n, c.d_tasks, c.cap_tasks, c.d_counters, c.d_stats);
     HIPCK(hipEventRecord(c.ev[2], st));
     // the number of seed hits stays on the device: persistent workgroups walk the pool
-    const size_t lds_ev = (size_t)MC_EV_STAGE_H * sizeof(McHsp) + (size_t)MC_EV_STAGE_G * sizeof(McGapTask);   // 51.7 KB: three workgroups per CU
+    const size_t lds_ev = (size_t)(MC_EV_BS / 64) * ((size_t)MC_EV_STAGE_H * sizeof(McHsp) + (size_t)MC_EV_STAGE_G * sizeof(McGapTask));   // a pool pair per wave, 51.7 KB per workgroup: three workgroups per CU
     HIPCK(hipFuncSetAttribute((const void *)k_eval_seeds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ev));
     static const unsigned ev_bpc = getenv("MC_EV_BPC") ? (unsigned)atoi(getenv("MC_EV_BPC")) : (unsigned)MC_EV_BPC;   // (experiments)
     k_eval_seeds<<<dim3(256u * ev_bpc), dim3(MC_EV_BS), lds_ev, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_tasks, c.d_counters + C_TASKS, c.cap_tasks, c.d_hsps, c.cap_hsps, c.d_gaps, c.cap_gaps, c.d_counters, h->d_P, h->d_fam, h->best_only ? c.d_cand : nullptr, c.d_hkeys);
@@ -2537,7 +2550,8 @@ static int stage_b(mc_handle *h, McCtx &c)
     McIndex X = dev_index(h);
     if (c.h_c[C_OVERFLOW]) { g_err = "seed task / HSP / gap task buffer overflow"; return -2; }
     c.ntasks = c.h_c[C_TASKS];
-    const uint32_t ngaps = c.ngaps = c.h_c[C_GAPS];
+    const uint32_t ngaps = c.ngaps = c.h_c[C_GAPS];                 // (slots of the pool: the padding of the waves' last blocks included)
+    c.gpad = c.h_c[C_GPAD];
     if (ngaps) {
         // 1. group the tasks that extend the same ungapped segment and list the flanks of the distinct ones (k_gap_dedupe);
         // 2. order the flanks by DP size (the sort buffers of the HSP sort are idle at this point); 3. extend them with the DP rows
@@ -2571,15 +2585,17 @@ static int stage_c(mc_handle *h, McCtx &c)
 {
     hipStream_t st = c.stream;
     if (c.h_c[C_OVERFLOW]) { g_err = "HSP buffer overflow"; return -2; }
-    c.nh_all = c.h_c[C_HSPS];
-    const uint32_t nh = c.nh = h->best_only ? c.h_c[C_HSPS2] : c.h_c[C_HSPS];      // HSPs that are ranked
+    const uint32_t nslots = c.h_c[C_HSPS];                         // used slots of the pool, the padding of the waves' last blocks included
+    c.nh_all = nslots - c.h_c[C_HPAD];
+    const uint32_t nh = c.nh = h->best_only ? c.h_c[C_HSPS2] : c.nh_all;           // HSPs that are ranked
     if (nh) {
         uint32_t *d_flags = c.d_idx, *d_hpos = (uint32_t *)c.d_k64;      // both free once the sort has run
         size_t bytes = c.sorttmp_bytes;
         int rbits = 1;
         while ((1ll << rbits) < c.n) rbits++;
         // all HSPs: their keys as their kernels wrote them, carrying 0, 1, 2, ...; best hits only: the selected keys and indices
-        HIPCK(rocprim::radix_sort_pairs(c.d_sorttmp, bytes, h->best_only ? c.d_k64 : c.d_hkeys, c.d_k64o, h->best_only ? c.d_idx : c.d_iota, c.d_idxo, (size_t)nh, 0, 43 + rbits, st));
+        // (the keys of the padding are all ones: they sort behind everything and the stages below stop at nh)
+        HIPCK(rocprim::radix_sort_pairs(c.d_sorttmp, bytes, h->best_only ? c.d_k64 : c.d_hkeys, c.d_k64o, h->best_only ? c.d_idx : c.d_iota, c.d_idxo, h->best_only ? (size_t)nh : (size_t)nslots, 0, 43 + rbits, st));
         k_gather<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(c.d_hsps, c.d_idxo, c.d_k64o, nh, c.d_sorted, d_flags, c.d_mark, h->hT.loge_thr);
         bytes = c.sorttmp_bytes;
         HIPCK(rocprim::exclusive_scan(c.d_sorttmp, bytes, d_flags, d_hpos, 0u, (size_t)nh, rocprim::plus<uint32_t>(), st));
@@ -2787,7 +2803,7 @@ static int run_range_once(mc_handle *h, int64_t first, int64_t count, int64_t fi
 #endif
         h->stats.bucket_lookups += (int64_t)c.h_stats[S_LOOKUPS]; h->stats.key_probes += (int64_t)c.h_stats[S_KEYPROBES]; h->stats.seed_tasks += (int64_t)c.h_stats[S_TASKS];
         h->stats.seed_exact_asks += (int64_t)c.h_stats[S_EXACT]; h->stats.seed_wild_asks += (int64_t)c.h_stats[S_WILD]; h->stats.seed_pair_asks += (int64_t)c.h_stats[S_PAIRS]; h->stats.seed_probes += (int64_t)c.h_stats[S_PROBES];
-        h->stats.gap_tasks += c.ngaps; h->stats.hsps += c.nh_all; h->stats.rows += c.nrows; h->stats.reads_with_rows += c.nsegs;
+        h->stats.gap_tasks += c.ngaps - c.gpad; h->stats.hsps += c.nh_all; h->stats.rows += c.nrows; h->stats.reads_with_rows += c.nsegs;
         // kernel times: HIP events on the part's own stream (the parts overlap, so the sums exceed the wall time of the call)
         h->stats.ms_translate += ev_ms(c.ev[0], c.ev[1]); h->stats.ms_seed += ev_ms(c.ev[1], c.ev[2]); h->stats.ms_eval += ev_ms(c.ev[2], c.ev[3]);
         h->stats.ms_gapped += ev_ms(c.ev[3], c.ev[4]); h->stats.ms_sort += ev_ms(c.ev[4], c.ev[5]); h->stats.ms_finish += ev_ms(c.ev[5], c.ev[6]); h->stats.ms_total += ev_ms(c.ev[0], c.ev[6]);
