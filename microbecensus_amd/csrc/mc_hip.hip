@@ -1039,8 +1039,10 @@ __device__ __forceinline__ bool mc_hsp_can_classify(const McTables &T, const McC
 // reference's exit tests, in the same order.  Rows and residue array have room on both sides (what a load reads past a
 // sequence's end is never used: the step that would use it is behind an exit test).
 __device__ __forceinline__ uint64_t mc_ld8(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
-__device__ __forceinline__ int mc_eval_seed_tail_dev(const McHot &T, const uint8_t *q, int qlen, int qpos, const uint8_t *d, int dlen, int dpos, int sidx,
-                                                     int seedlen, int score, int ident, McGapTask *gt, uint64_t q0, uint64_t q2, uint64_t d0, uint64_t d2)
+// growth and gate of a seed hit (mc_eval_seed_tail, mc_core.h): true if the hit goes on to the ungapped X-drop extension, with the
+// grown seed (qp, dp, L), its score and identities
+__device__ __forceinline__ bool mc_ev_gate(const McHot &T, const uint8_t *q, int qlen, int qpos, const uint8_t *d, int dlen, int dpos, int seedlen, int &score, int &ident,
+                                           int &qp_o, int &dp_o, int &L_o, uint64_t q0, uint64_t q2, uint64_t d0, uint64_t d2)
 {
     // growth: residues 9 .. 15 behind the seed's first one and the 8 in front of it are in registers (q2, d2 / q0, d0: the caller's
     // loads); most hits stop growing at once on both sides and reach the gate without another read
@@ -1059,7 +1061,12 @@ __device__ __forceinline__ int mc_eval_seed_tail_dev(const McHot &T, const uint8
         if (qpos - qp == j - 1 && back > 0 && T.grp[a & 31] == T.grp[b & 31]) { qp--; dp--; back--; L++; score += MC_SUB(T, a, b); ident += (a == b); }
     }
     if (qpos - qp == 8) while (back > 0 && T.grp[q[qp - 1]] == T.grp[d[dp - 1]]) { qp--; dp--; back--; L++; int a = q[qp], b = d[dp]; score += MC_SUB(T, a, b); ident += (a == b); }
-    if (!((double)score >= MC_SEED_SCORE && ident >= MC_SEED_IDENT)) return 0;
+    qp_o = qp; dp_o = dp; L_o = L;
+    return (double)score >= MC_SEED_SCORE && ident >= MC_SEED_IDENT;
+}
+// ... and the extension itself, from the grown seed: 1 = ungapped HSP complete, 2 = needs the gapped extension
+__device__ __forceinline__ int mc_ev_xdrop(const McHot &T, const uint8_t *q, int qlen, const uint8_t *d, int dlen, int sidx, int qp, int dp, int L, int score, int ident, McGapTask *gt)
+{
     const double xd = T.xdrop_ungapped;
     int s0 = score, qfwd = 0, qbwd = 0, fgain = 0, bgain = 0;
     { // forward
@@ -1131,32 +1138,28 @@ __device__ unsigned long long g_ev_acc[8];           // wave time per phase, sum
 #endif
 #define MC_EV_BS 512         // threads per workgroup
 #define MC_EV_BPC 3          // workgroups per CU
-#define MC_EV_STAGE_H 88     // HSPs staged per WAVE (4.1 KB)
-#define MC_EV_STAGE_G 80     // gap tasks per wave (2.2 KB)
+#define MC_EV_QCAP 128       // survivors of the gate a wave holds (32 bytes each: 4 KB of LDS per wave)
 #define MC_EV_BLK 256u       // slots of the HSP / gap-task pools a wave reserves at a time (one global atomic per block)
-// A wave's staged records go out when the next 64 hits might not fit: into the wave's current block of the pool, a new block
-// reserved when that one is full (the records of one flush may straddle two blocks).  Returns false after a pool overflow.
-template <class R>
-__device__ __forceinline__ bool mc_ev_flush(const R *st, uint32_t n, R *pool, uint32_t cap, uint32_t *counter, uint32_t &blk_base, uint32_t &blk_used, uint64_t *hkeys, int lane)
+// n consecutive slots for the wave's lanes (lane with rank r < n gets one; n is the same for every lane): from the wave's current
+// block of the pool, continued in a new block when that one is full.  *ok = false after a pool overflow.
+__device__ __forceinline__ uint32_t mc_ev_slots(uint32_t n, uint32_t r, uint32_t cap, uint32_t *counter, uint32_t &blk_base, uint32_t &blk_used, bool *ok, int lane)
 {
-    uint32_t src = 0;
-    while (n > 0) {
-        if (blk_used == MC_EV_BLK) {
-            uint32_t nb = 0;
-            if (lane == 0) nb = atomicAdd(counter, MC_EV_BLK);
-            nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
-            if (nb + MC_EV_BLK > cap) return false;
-            blk_base = nb; blk_used = 0;
-        }
-        const uint32_t m = n < MC_EV_BLK - blk_used ? n : MC_EV_BLK - blk_used;
-        const uint32_t *s32 = (const uint32_t *)(st + src);
-        uint32_t *d32 = (uint32_t *)(pool + blk_base + blk_used);
-        for (uint32_t i = (uint32_t)lane; i < m * (uint32_t)(sizeof(R) / 4); i += 64) d32[i] = s32[i];           // (consecutive words: coalesced)
-        if (hkeys) for (uint32_t i = (uint32_t)lane; i < m; i += 64) hkeys[blk_base + blk_used + i] = MC_HSP_KEY(*(const McHsp *)(st + src + i));
-        blk_used += m; src += m; n -= m;
-    }
-    return true;
+    if (blk_used + n <= MC_EV_BLK) { const uint32_t s = blk_base + blk_used + r; blk_used += n; return s; }
+    const uint32_t rem = MC_EV_BLK - blk_used, old = blk_base + blk_used;
+    uint32_t nb = 0;
+    if (lane == 0) nb = atomicAdd(counter, MC_EV_BLK);
+    nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+    if (nb + MC_EV_BLK > cap) { *ok = false; blk_used = MC_EV_BLK; return 0; }
+    blk_base = nb; blk_used = n - rem;
+    return r < rem ? old + r : nb + (r - rem);
 }
+// Seed hits -> HSPs / gap tasks, in two phases per wave.  Seven hits in ten end at the gate; the three that go on to the
+// ungapped X-drop extension - long loops - used to do so in the lane that met them, 19 lanes of 64 on average.  Now a wave puts
+// the survivors of the gate into a queue of its own in LDS (what the extension needs of them: 32 bytes) and runs the extension,
+// the HSP and the classification mark on 64 survivors at a time - full waves.  No workgroup barrier in the loop and no staging
+// pools: a record goes from its lane straight to the wave's current block of the global pool (blocks of 256 slots, one global
+// atomic each; the records of a turn are consecutive, so the stores of the wave cover whole lines); what a wave does not use of
+// its last block is padded with records the later stages skip (read = MC_TASK_NONE, sort key all ones; C_HPAD / C_GPAD count them).
 __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(MC_EV_BS) k_eval_seeds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
                                                     const McSeedTask *__restrict__ tasks, const uint32_t *__restrict__ ntasks_p, uint32_t cap_tasks, McHsp *hsps, uint32_t cap_hsps,
                                                     McGapTask *gaps, uint32_t cap_gaps, uint32_t *counters, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam, uint8_t *cand, uint64_t *hkeys)
@@ -1164,21 +1167,17 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(MC_
     const uint32_t ntasks = *ntasks_p <= cap_tasks ? *ntasks_p : 0u;   // (device-side count of the seed kernel; after an overflow the host discards the batch)
     __shared__ McHot hot;
     const int lane = mc_lane(), wv = threadIdx.x >> 6;
-    // Every wave stages what survives in a pool of its own and flushes it alone - no barrier in the loop: with one pool per
-    // workgroup the eight waves met twice per 512 hits (and a third time, around a global atomic, at every flush), which was 28 %
-    // of the kernel's wave time (cycle counters).  The pools are handed out in blocks of 256 slots per wave; what a wave does not
-    // use of its last block is padded with records the later stages skip (read = MC_TASK_NONE; C_HPAD / C_GPAD count them).
-    McHsp *stH = (McHsp *)(mc_smem + (size_t)wv * (MC_EV_STAGE_H * sizeof(McHsp) + MC_EV_STAGE_G * sizeof(McGapTask)));
-    McGapTask *stG = (McGapTask *)(stH + MC_EV_STAGE_H);
+    uint4 *Q = (uint4 *)(mc_smem + (size_t)wv * MC_EV_QCAP * 32);    // entry e: words 2 e, 2 e + 1
     mc_load_hot(&hot, T);
     __syncthreads();
-    uint32_t fillH = 0, fillG = 0, hb_base = 0, hb_used = MC_EV_BLK, gb_base = 0, gb_used = MC_EV_BLK;
-    bool over = false;
+    uint32_t qn = 0, hb_base = 0, hb_used = MC_EV_BLK, gb_base = 0, gb_used = MC_EV_BLK;
+    bool ok = true;
+    const unsigned long long lt = (1ull << lane) - 1;
     const uint32_t nchunks = (ntasks + MC_EV_BS - 1) / MC_EV_BS;
     // The chain of dependent reads of a hit was: its record -> the subject's offsets -> the residue in front of the seed -> the
-    // seed's residues, four trips to the L2 before the gate that ends seven hits in ten.  Now: the record of the NEXT chunk is
-    // fetched while this one is evaluated, the record carries the hit's position in the residue array (MC_TASK_W3), and the
-    // subject's end, the residues in front of the seed and the seed's own ten are read together: one trip.
+    // seed's residues, four trips to the L2 before the gate.  Now: the record of the NEXT chunk is fetched while this one is
+    // evaluated, the record carries the hit's position in the residue array (MC_TASK_W3), and the subject's end, the residues in
+    // front of the seed and the seed's own ten are read together: one trip.
 #ifdef MC_EXP_TIMING
     unsigned long long ev_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ev_last_ = __builtin_readcyclecounter();
 #endif
@@ -1187,27 +1186,20 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(MC_
     if (blockIdx.x * MC_EV_BS + threadIdx.x < ntasks) tn = tasks[blockIdx.x * MC_EV_BS + threadIdx.x];
     for (uint32_t chunk = blockIdx.x;; chunk += gridDim.x) {
         const bool last = chunk >= nchunks;
-        // flush when the next 64 hits might not fit (or at the end)
-        if (fillH != 0 && (last || fillH > MC_EV_STAGE_H - 64)) { mc_wave_sync(); if (!over && !mc_ev_flush(stH, fillH, hsps, cap_hsps, &counters[C_HSPS], hb_base, hb_used, hkeys, lane)) { over = true; if (lane == 0) counters[C_OVERFLOW] = 2; } fillH = 0; mc_wave_sync(); }
-        if (fillG != 0 && (last || fillG > MC_EV_STAGE_G - 64)) { mc_wave_sync(); if (!over && !mc_ev_flush(stG, fillG, gaps, cap_gaps, &counters[C_GAPS], gb_base, gb_used, (uint64_t *)nullptr, lane)) { over = true; if (lane == 0) counters[C_OVERFLOW] = 3; } fillG = 0; mc_wave_sync(); }
-        if (last) break;
-        MC_EV_TICK(0);
-        const uint32_t tid = chunk * MC_EV_BS + threadIdx.x;
-        int rc = 0;
-        McGapTask g;
-        McHsp h;
-        bool keep = false;
-        const McSeedTask t = tn;
-        {
-            const uint64_t nx = (uint64_t)(chunk + gridDim.x) * MC_EV_BS + threadIdx.x;
-            tn.read = MC_TASK_NONE;
-            if (nx < ntasks) tn = tasks[nx];
-        }
-        if (tid < ntasks) {
-            if (t.read != MC_TASK_NONE) {                          // (padding of a partly used block of the task pool)
+        if (!last) {   // ---- phase 1: the gate, one hit per lane
+            MC_EV_TICK(0);
+            const uint32_t tid = chunk * MC_EV_BS + threadIdx.x;
+            const McSeedTask t = tn;
+            {
+                const uint64_t nx = (uint64_t)(chunk + gridDim.x) * MC_EV_BS + threadIdx.x;
+                tn.read = MC_TASK_NONE;
+                if (nx < ntasks) tn = tasks[nx];
+            }
+            bool surv = false;
+            uint4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};
+            if (tid < ntasks && t.read != MC_TASK_NONE) {            // (MC_TASK_NONE: padding of a partly used block of the task pool)
                 const int frame = (int)(t.chrono >> 25), pos = (int)((t.chrono >> 17) & 0xff);
                 const int qlen = (L - frame % 3) / 3;
-                g.read = t.read; g.chrono = t.chrono;
                 const uint32_t w3 = t.seedlen_nkey;
                 const int seedlen = (int)((w3 >> 24) & 15u), nkey = (int)(w3 >> 28), dpos = (int)(t.posting & 0x7ffu), sidx = (int)(t.posting >> 11);
                 const uint32_t o0 = (w3 & 0xFFFFFFu) - (uint32_t)dpos;
@@ -1225,34 +1217,63 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(MC_
                         score += MC_SUB(hot, a, b); ident += (a == b);
                     }
                 const bool go = !(dpos + seedlen > dlen) && !(pos != 0 && dpos != 0 && hot.grp[qm1] == hot.grp[dm1] && nkey != 4);
-#ifdef MC_EXP_TIMING
-                if (score == 12345678) rc = 3;                      // (keeps the loads in front of the tick)
-                MC_EV_TICK(1);
-#endif
-                if (go) rc = mc_eval_seed_tail_dev(hot, q, qlen, pos, d, dlen, dpos, sidx, seedlen, score, ident, &g, q0, q2, d0, d2);
+                int qp = 0, dp = 0, Lg = 0;
+                if (go) surv = mc_ev_gate(hot, q, qlen, pos, d, dlen, dpos, seedlen, score, ident, qp, dp, Lg, q0, q2, d0, d2);
+                e0.x = t.read; e0.y = t.chrono; e0.z = o0; e0.w = (uint32_t)sidx;
+                e1.x = (uint32_t)qp | ((uint32_t)dp << 16); e1.y = (uint32_t)Lg | ((uint32_t)(uint16_t)(int16_t)score << 16); e1.z = (uint32_t)ident | ((uint32_t)dlen << 16);
+            }
+            const unsigned long long ms = __ballot(surv);
+            if (surv) { const uint32_t at = qn + (uint32_t)__popcll(ms & lt); Q[2 * at] = e0; Q[2 * at + 1] = e1; }
+            qn += (uint32_t)__popcll(ms);
+            mc_wave_sync();
+            MC_EV_TICK(1);
+        }
+        while (qn >= 64 || (last && qn > 0)) {   // ---- phase 2: the extension, 64 survivors at a time
+            const uint32_t take = qn < 64 ? qn : 64;
+            qn -= take;
+            const bool act = (uint32_t)lane < take;
+            const uint4 e0 = Q[2 * (qn + (act ? (uint32_t)lane : 0u))], e1 = Q[2 * (qn + (act ? (uint32_t)lane : 0u)) + 1];
+            mc_wave_sync();                                          // (read before the next survivors are written over them)
+            int rc = 0;
+            bool keep = false;
+            McGapTask g;
+            McHsp h;
+            if (act) {
+                const uint32_t read = e0.x, chrono = e0.y;
+                const int frame = (int)(chrono >> 25), qlen = (L - frame % 3) / 3, sidx = (int)e0.w;
+                const uint8_t *q = frames + ((int64_t)read * 6 + frame) * FP, *d = X.res + e0.z;
+                g.read = read; g.chrono = chrono;
+                rc = mc_ev_xdrop(hot, q, qlen, d, (int)(e1.z >> 16), sidx, (int)(e1.x & 0xFFFFu), (int)(e1.x >> 16), (int)(e1.y & 0xFFFFu), (int)(int16_t)(e1.y >> 16), (int)(e1.z & 0xFFFFu), &g);
                 MC_EV_TICK(2);
                 if (rc == 1) {
-                    h.read = t.read; h.chrono = t.chrono;
+                    h.read = read; h.chrono = chrono;
                     keep = mc_make_hsp(*T, L, frame, g, g.qfwd, g.qfwd, g.qbwd, g.qbwd, g.score, g.nmatch, g.qfwd + g.L + g.qbwd, 0, 0, &h);
                     if (keep && cand && mc_hsp_can_classify(*T, *P, X, fam, h)) cand[h.read] = 1;
                 }
-                MC_EV_TICK(3);
             }
-        }
-        MC_EV_TICK(3);
-        {   // stage in the wave's own pools
+            MC_EV_TICK(3);
             const unsigned long long mh = __ballot(keep), mg = __ballot(rc == 2);
-            if (keep) stH[fillH + (uint32_t)__popcll(mh & ((1ull << lane) - 1))] = h;
-            if (rc == 2) stG[fillG + (uint32_t)__popcll(mg & ((1ull << lane) - 1))] = g;
-            fillH += (uint32_t)__popcll(mh); fillG += (uint32_t)__popcll(mg);
+            if (mh && ok) {
+                const uint32_t slot = mc_ev_slots((uint32_t)__popcll(mh), (uint32_t)__popcll(mh & lt), cap_hsps, &counters[C_HSPS], hb_base, hb_used, &ok, lane);
+                if (!ok) { if (lane == 0) counters[C_OVERFLOW] = 2; }
+                else if (keep) { hsps[slot] = h; hkeys[slot] = MC_HSP_KEY(h); }
+            }
+            if (mg && ok) {
+                const uint32_t slot = mc_ev_slots((uint32_t)__popcll(mg), (uint32_t)__popcll(mg & lt), cap_gaps, &counters[C_GAPS], gb_base, gb_used, &ok, lane);
+                if (!ok) { if (lane == 0) counters[C_OVERFLOW] = 3; }
+                else if (rc == 2) gaps[slot] = g;
+            }
+            MC_EV_TICK(4);
         }
-        MC_EV_TICK(4);
+        if (last) break;
     }
     {   // what the wave did not use of its last blocks: records the later stages skip
         const uint32_t ph = hb_used < MC_EV_BLK ? MC_EV_BLK - hb_used : 0u, pg = gb_used < MC_EV_BLK ? MC_EV_BLK - gb_used : 0u;
-        for (uint32_t i = (uint32_t)lane; i < ph; i += 64) { hsps[hb_base + hb_used + i].read = MC_TASK_NONE; hkeys[hb_base + hb_used + i] = ~0ull; }
-        for (uint32_t i = (uint32_t)lane; i < pg; i += 64) gaps[gb_base + gb_used + i].read = MC_TASK_NONE;
-        if (lane == 0) { if (ph) atomicAdd(&counters[C_HPAD], ph); if (pg) atomicAdd(&counters[C_GPAD], pg); }
+        if (ok) {
+            for (uint32_t i = (uint32_t)lane; i < ph; i += 64) { hsps[hb_base + hb_used + i].read = MC_TASK_NONE; hkeys[hb_base + hb_used + i] = ~0ull; }
+            for (uint32_t i = (uint32_t)lane; i < pg; i += 64) gaps[gb_base + gb_used + i].read = MC_TASK_NONE;
+            if (lane == 0) { if (ph) atomicAdd(&counters[C_HPAD], ph); if (pg) atomicAdd(&counters[C_GPAD], pg); }
+        }
     }
 #ifdef MC_EXP_TIMING
     if (lane == 0) for (int k = 0; k < 5; k++) atomicAdd(&g_ev_acc[k], ev_acc_[k]);
@@ -2534,7 +2555,7 @@ static int stage_a(mc_handle *h, McCtx &c)
         k_enumerate<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, X, c.d_frames, FP, L, n, c.d_tasks, c.cap_tasks, c.d_counters, c.d_stats);
     HIPCK(hipEventRecord(c.ev[2], st));
     // the number of seed hits stays on the device: persistent workgroups walk the pool
-    const size_t lds_ev = (size_t)(MC_EV_BS / 64) * ((size_t)MC_EV_STAGE_H * sizeof(McHsp) + (size_t)MC_EV_STAGE_G * sizeof(McGapTask));   // a pool pair per wave, 51.7 KB per workgroup: three workgroups per CU
+    const size_t lds_ev = (size_t)(MC_EV_BS / 64) * MC_EV_QCAP * 32;   // a queue of survivors per wave: 32 KB per workgroup
     HIPCK(hipFuncSetAttribute((const void *)k_eval_seeds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ev));
     static const unsigned ev_bpc = getenv("MC_EV_BPC") ? (unsigned)atoi(getenv("MC_EV_BPC")) : (unsigned)MC_EV_BPC;   // (experiments)
     k_eval_seeds<<<dim3(256u * ev_bpc), dim3(MC_EV_BS), lds_ev, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_tasks, c.d_counters + C_TASKS, c.cap_tasks, c.d_hsps, c.cap_hsps, c.d_gaps, c.cap_gaps, c.d_counters, h->d_P, h->d_fam, h->best_only ? c.d_cand : nullptr, c.d_hkeys);
