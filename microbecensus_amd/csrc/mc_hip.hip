@@ -1136,8 +1136,9 @@ __device__ unsigned long long g_ev_acc[8];           // wave time per phase, sum
 #else
 #define MC_EV_TICK(prev) do { } while (0)
 #endif
-#define MC_EV_BS 512         // threads per workgroup
-#define MC_EV_BPC 3          // workgroups per CU
+#define MC_EV_BS 256         // threads per workgroup (the waves are on their own: the size only sets how the LDS is handed out)
+#define MC_EV_BPC 5          // workgroups per CU: 20 waves, 5 per SIMD - 88 registers, nothing spilled (measured per 1 M reads of 150 / 300 bp:
+                             // 7 waves per SIMD and 72 registers with 52 bytes of scratch 3.50 / 7.77 ms, 6 with 80 and 12 bytes 2.82 / 6.41, 5 with 88 2.60 / 6.01, 4: 2.79 / 6.53)
 #define MC_EV_QCAP 128       // survivors of the gate a wave holds (32 bytes each: 4 KB of LDS per wave)
 #define MC_EV_BLK 256u       // slots of the HSP / gap-task pools a wave reserves at a time (one global atomic per block)
 // n consecutive slots for the wave's lanes (lane with rank r < n gets one; n is the same for every lane): from the wave's current
@@ -1160,7 +1161,7 @@ __device__ __forceinline__ uint32_t mc_ev_slots(uint32_t n, uint32_t r, uint32_t
 // pools: a record goes from its lane straight to the wave's current block of the global pool (blocks of 256 slots, one global
 // atomic each; the records of a turn are consecutive, so the stores of the wave cover whole lines); what a wave does not use of
 // its last block is padded with records the later stages skip (read = MC_TASK_NONE, sort key all ones; C_HPAD / C_GPAD count them).
-__global__ void __attribute__((amdgpu_waves_per_eu(6, 6))) __launch_bounds__(MC_EV_BS) k_eval_seeds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
+__global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_EV_BS) k_eval_seeds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
                                                     const McSeedTask *__restrict__ tasks, const uint32_t *__restrict__ ntasks_p, uint32_t cap_tasks, McHsp *hsps, uint32_t cap_hsps,
                                                     McGapTask *gaps, uint32_t cap_gaps, uint32_t *counters, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam, uint8_t *cand, uint64_t *hkeys)
 {
@@ -2430,7 +2431,7 @@ static int ensure_capacity(mc_handle *h, McCtx &c, int64_t nreads)
     const int64_t L = h->read_len;
     c.cap_reads = 0;                                                // pools are being replaced: nothing is usable until all of them exist
     c.cap_tasks = (uint32_t)std::min<int64_t>(cap * (L + 32) + (1 << 20) + (int64_t)256 * 32 * MC_EN_BLK, 0x7fffffff);
-    const int64_t ev_pad = (int64_t)256 * 4 * (MC_EV_BS / 64) * MC_EV_BLK;   // k_eval_seeds hands both pools out in blocks of MC_EV_BLK slots per wave: room for every wave's partly used last block
+    const int64_t ev_pad = (int64_t)256 * 8 * (MC_EV_BS / 64) * MC_EV_BLK;   // k_eval_seeds hands both pools out in blocks of MC_EV_BLK slots per wave: room for every wave's partly used last block
     c.cap_gaps = (uint32_t)std::min<int64_t>(cap * (L / 8 + 8) + (1 << 18) + ev_pad, (1 << 27) - 2);   // (k_gap_dedupe keeps task index + 1 in 27 bits of a table entry: more tasks than that overflow the pool and the range is split)
     c.cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 2 + 16) + (1 << 20) + ev_pad, 0x7fffffff);
     c.cap_rows = (uint32_t)std::min<int64_t>(cap * 48 + (1 << 20), 0x7fffffff);
@@ -2557,7 +2558,7 @@ static int stage_a(mc_handle *h, McCtx &c)
     // the number of seed hits stays on the device: persistent workgroups walk the pool
     const size_t lds_ev = (size_t)(MC_EV_BS / 64) * MC_EV_QCAP * 32;   // a queue of survivors per wave: 32 KB per workgroup
     HIPCK(hipFuncSetAttribute((const void *)k_eval_seeds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ev));
-    static const unsigned ev_bpc = getenv("MC_EV_BPC") ? (unsigned)atoi(getenv("MC_EV_BPC")) : (unsigned)MC_EV_BPC;   // (experiments)
+    static const unsigned ev_bpc = getenv("MC_EV_BPC") ? (unsigned)std::max(1, std::min(8, atoi(getenv("MC_EV_BPC")))) : (unsigned)MC_EV_BPC;   // (experiments)
     k_eval_seeds<<<dim3(256u * ev_bpc), dim3(MC_EV_BS), lds_ev, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_tasks, c.d_counters + C_TASKS, c.cap_tasks, c.d_hsps, c.cap_hsps, c.d_gaps, c.cap_gaps, c.d_counters, h->d_P, h->d_fam, h->best_only ? c.d_cand : nullptr, c.d_hkeys);
     HIPCK(hipEventRecord(c.ev[3], st));
     return counters_to_host(c);
