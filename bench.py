@@ -208,6 +208,24 @@ def ags_abs_error(device):
     return out
 
 
+def usable_cores():
+    """CPUs this process may actually use: the cgroup quota (/sys/fs/cgroup/cpu.max = "quota period"; the GPU boxes show 256 CPUs
+    and grant 16), else the affinity mask, else os.cpu_count()."""
+    n = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, int(round(float(q) / float(per))))
+    except Exception:
+        pass
+    try:
+        a = len(os.sched_getaffinity(0))
+        n = a if n is None else min(n, a)
+    except Exception:
+        pass
+    return n or os.cpu_count() or 1
+
+
 def m8_md5(lines):
     h = hashlib.md5()
     for ln in lines:
@@ -254,12 +272,12 @@ def cpu_baseline(eng, sample_reads, read_len, plan):
                          "m8_md5_equals_gpu": m8_md5(got) == m8_md5(want)})
     head = runs[0]
     return {"value": head["reads_per_s"], "unit": "reads/s", "cores": head["threads"], "kind": kind,
-            "sample": "BOUNDED sample (about 15 s of wall time per run, so that the default bench finishes in minutes): prefixes of the bench workload (%d bp) of %s "
-                      "reads; %s -e 1 -t n -p f -b 0, wall time of the process incl. DB load; headline = first run. On 1,000,000 reads of the same workload "
-                      "(bench.py --cpu-full, profiles/r02_bench_full.json) the same binary ran 14.3 k / 12.7 k / 3.0 k reads/s at -z 256 / 8 / 1" %
+            "sample": "prefixes of the bench workload (%d bp) of %s reads (SURVEY 8(d): >= 1 M reads at -z all usable cores and -z 8; the -z 1 run is bounded to ~15 s); "
+                      "%s -e 1 -t n -p f -b 0, wall time of the process incl. DB load; headline = first run" %
                       (read_len, " / ".join(str(r["reads"]) for r in runs), "rapsearch_Linux_2.15 -z T" if kind == "reference" else "oracle/rs_port (C restatement, 1 thread)"),
-            "note": "'cores' is the -z of the headline run; RAPsearch2 2.15 stops scaling at about 8 threads (see runs), whatever the host has",
-            "host_cores": os.cpu_count(), "runs": runs, "m8_md5_equals_gpu": all(r["m8_md5_equals_gpu"] for r in runs)}
+            "note": "'cores' = the -z of the headline run = the CPUs this process may use (cgroup quota /sys/fs/cgroup/cpu.max, else the affinity mask); host_cores = "
+                    "os.cpu_count(), what the machine shows. RAPsearch2 2.15 stops scaling at about 8 threads (see runs), whatever the host has",
+            "usable_cores": usable_cores(), "host_cores": os.cpu_count(), "runs": runs, "m8_md5_equals_gpu": all(r["m8_md5_equals_gpu"] for r in runs)}
 
 
 def write_fastq(gen, n, L, path, gz):
@@ -353,8 +371,8 @@ def main():
     ap.add_argument("--insert", type=int, default=300, help="fragment length of the paired library (N > 1)")
     ap.add_argument("--workload", choices=["genomes", "orfs"], default="genomes", help="genomes: reads of the 30 real genomes (SURVEY 8d); orfs: round 1's artificial ORF community")
     ap.add_argument("--resident-batches", type=int, default=0, help="distinct batches resident in HBM (0 = one per step: no read is searched twice in the timed region)")
-    ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads of the largest cpu_baseline run (-z all cores)")
-    ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline on >= 1 M reads at -z 1 / 8 / all cores (takes ~20 min)")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads of the cpu_baseline runs at -z <usable cores> and -z 8 (SURVEY 8(d): >= 1 M; ~70 s each); the -z 1 run takes a 75th of it")
+    ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline on the full sample at -z 1 too (~6 min more)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ags-check", action="store_true", help="skip the run_pipeline AGS comparison on the reference's own inputs")
     ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the end-to-end (file -> AGS) measurement (plain FASTQ; a fifth of it, at least 4 M, for .gz); 0 = skip")
@@ -506,12 +524,19 @@ def main():
         dom = max(kseq, key=kseq.get)
         n_batch = args.batch
         hits, hsps, gtasks, rows = acc["seed_tasks"] / K, acc["hsps"] / K, acc["gap_tasks"] / K, acc["rows"] / K
+        # What the seed kernel asks of the index per launch (mc_stats.seed_*, counted by the timed kernel; DESIGN.md 5 "index touches"):
+        # 9-mer filter words (4 B), wildcard filter lines (32 B), pair filter blocks (16 B), bucket record + key group per probe that
+        # survives the filters (32 + 16 B), and per seed hit its posting and the subject's offset (4 + 4 B).
+        asks = {k: acc[k] / K for k in ("seed_exact_asks", "seed_wild_asks", "seed_pair_asks", "seed_probes")}
+        index_touch = 4 * asks["seed_exact_asks"] + 32 * asks["seed_wild_asks"] + 16 * asks["seed_pair_asks"] + 48 * asks["seed_probes"] + 8 * hits
+        # ... and the evaluation kernel of the residues: 24 bytes around the seed in the frame and in the subject, and the subject's end
+        residue_touch = (24 + 24 + 4) * hits
         per_launch = {
-            # ALGORITHMIC bytes per launch = the arrays a kernel must read and write, each once (the index is not counted: it
-            # is resident in L2 / Infinity Cache).  Nothing here is counted by the kernels themselves.
+            # ALGORITHMIC bytes per launch = the arrays a kernel must read and write, each once, plus - for the two kernels that gather
+            # from the index - the items they ask of it, each at its own size.
             "k_translate_seg": n_batch * (L + 6 * (L // 3)),                 # bases in, six frames out
-            "k_enumerate": n_batch * 6 * (L // 3) + 16 * hits,               # frames in, seed hits out (16 B)
-            "k_eval_seeds": 16 * hits + 48 * hsps + 28 * gtasks,             # seed hits in, HSPs (48 B) and gap tasks (28 B) out
+            "k_enumerate": n_batch * 6 * (L // 3) + 16 * hits + index_touch,  # frames in, seed hits out (16 B), index touches
+            "k_eval_seeds": 16 * hits + residue_touch + 48 * hsps + 28 * gtasks,   # seed hits in, residues around them, HSPs (48 B) and gap tasks (28 B) out
             "k_gapped": (28 + 32 + 48) * gtasks,                             # gap tasks in, two flank results (16 B) and an HSP out per task
             "sort": hsps * (48 + 48 + 2 * 12),                               # HSPs in and out in (read, subject, hit order); keys
             "k_finish": hsps * 48 + rows * 64,                               # HSPs in, m8 rows out
@@ -533,12 +558,21 @@ def main():
         traffic_dom = None
         if d_dom and d_dom.get("hbm_bytes_per_launch") is not None and d_dom.get("reads_per_launch"):
             traffic_dom = d_dom["hbm_bytes_per_launch"] * n_batch / d_dom["reads_per_launch"]
+        # north_star's second target: >= 40 % of the HBM roofline on the extension kernel(s) - stated, and missed: both are bound by
+        # VALU issue (integer DP / X-drop loops with 28 - 37 of 64 lanes active), not by bytes
+        ext = {}
+        for k in ("k_eval_seeds", "k_gapped"):
+            if kseq.get(k, 0) > 0:
+                a = per_launch[k] / (kseq[k] * 1e-3) / 1e9
+                ext[k] = {"algorithmic_GBps": round(a, 1), "frac_of_hbm_peak": round(a / HBM_PEAK_GBS, 4), "counter_hbm_frac": (der.get(k) or {}).get("hbm_frac"),
+                          "counter_hbm_frac_lower": (der.get(k) or {}).get("hbm_frac_lower"), "bound": (der.get(k) or {}).get("bound")}
+        ext_best = max([max(v["frac_of_hbm_peak"], v["counter_hbm_frac"] or 0.0) for v in ext.values()] or [0.0])
         out = {
             "metric": METRIC, "value": round(reads_total / dt, 1), "unit": "reads/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32",
             "data": "synthetic",
             "config": {"workload": "%s; %d reads/step/GPU, %d steps, %d distinct reads resident in HBM per GPU" % (wl, n_batch, K, per_rank),
-                       "read_len": L, "batch": n_batch, "parallelism": "reads sharded over %d GPU(s), %s all_reduce of per-family accumulators per step" % (world, "RCCL" if args.backend == "nccl" else "gloo (plumbing test: all ranks on one GPU)"),
+                       "read_len": L, "batch": n_batch, "parallelism": ("1 GPU, no collective" if world == 1 else "reads sharded over %d GPUs, %s all_reduce of per-family accumulators per step" % (world, "RCCL" if args.backend == "nccl" else "gloo (plumbing test: all ranks on one GPU)")),
                        "marker_db": "%d proteins / %d families" % (len(names), len(fams)),
                        "classified_reads": int(tot_hits.sum()), "classified_per_read": round(float(tot_hits.sum()) / reads_total, 6),
                        "rows_per_read": round(job["rows"] / reads_total, 4), "reads_with_rows": round(job["reads_with_rows"] / reads_total, 5),
@@ -554,10 +588,20 @@ def main():
                          "salu_frac": (d_dom or {}).get("salu_frac"), "wait_frac": (d_dom or {}).get("wait_frac"),
                          "valu_lanes_of_64": (d_dom or {}).get("valu_lanes_of_64"), "l2_hit_rate": (d_dom or {}).get("l2_hit_rate"),
                          "kernel_ms_per_step": round(kseq[dom], 3), "algorithmic_bytes_per_read": round(per_launch[dom] / n_batch, 1),
+                         "index_touch_bytes_per_read": round(index_touch / n_batch, 1),
+                         "index_touch_items_per_read": {"filter_words_4B": round(asks["seed_exact_asks"] / n_batch, 2), "wildcard_lines_32B": round(asks["seed_wild_asks"] / n_batch, 2),
+                                                        "pair_blocks_16B": round(asks["seed_pair_asks"] / n_batch, 2), "records_and_key_groups_48B": round(asks["seed_probes"] / n_batch, 2),
+                                                        "postings_and_offsets_8B": round(hits / n_batch, 2)},
+                         "fabric_amplification": (None if traffic_dom is None else round(traffic_dom / per_launch[dom], 2)),
+                         "fabric_amplification_lower": (None if not (d_dom and d_dom.get("hbm_frac_lower") and d_dom.get("hbm_frac")) else round(traffic_dom / per_launch[dom] * d_dom["hbm_frac_lower"] / d_dom["hbm_frac"], 2)),
+                         "extension_kernel_hbm_frac": {"target": 0.40, "met": bool(ext_best >= 0.40), "best": round(ext_best, 4), "kernels": ext,
+                                                       "note": "north_star asks for >= 40 % of the HBM roofline on the extension kernel; the ungapped (k_eval_seeds) and gapped (k_gapped stage) "
+                                                               "extensions are bound by VALU issue, not by bytes: the target is missed"},
                          "profile": (None if prof is None else prof["files"]), "fetch_calibration": (None if prof is None else prof.get("calibration")),
                          "basis": "kernel = the stage with the largest HIP-event time per step. achieved = ALGORITHMIC bytes of one launch (the arrays the kernel "
-                                  "must read and write, each once: DESIGN.md 5 - nothing counted by the kernel itself) / the live HIP-event duration of that "
-                                  "launch; frac = achieved / 8 TB/s. Everything else comes from the committed rocprofv3 profile of THIS read length (profile; null "
+                                  "must read and write, each once, plus the items the seed kernel asks of the index at their own sizes - index_touch_bytes_per_read, "
+                                  "from mc_stats.seed_*: DESIGN.md 5) / the live HIP-event duration of that launch; frac = achieved / 8 TB/s; fabric_amplification = "
+                                  "traffic / those bytes (one 64- or 128-byte line moves per 4 .. 48-byte item). Everything else comes from the committed rocprofv3 profile of THIS read length (profile; null "
                                   "when none is committed - a profile of another length is never scaled): traffic = (fetch_factor x FETCH_SIZE + WRITE_SIZE) KiB x 1024 "
                                   "per profiled launch x (this batch / profiled batch), fetch_factor 2 for streaming reads (MI355X_MICROARCH.md) and the gather "
                                   "calibration's (fetch_calibration) for the seed kernels; hbm_frac = that / profiled duration / 8 TB/s (mostly Infinity-Cache hits: "
@@ -579,11 +623,10 @@ def main():
                                           "value": round(reads_total / dt_only, 1), "unit": "reads/s", "ms_per_step": round(dt_only / K * 1e3, 3),
                                           "kernel_ms_per_step": {k: round(st_only[m] / K, 3) for k, m in SEQ.items()}}
         if world == 1 and not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
-            if args.cpu_full:
-                plan = [(cores, 1_000_000), (8, 1_000_000), (1, 1_000_000)]
-            else:   # bounded: about 10-15 s of wall time per run
-                plan = [(cores, args.cpu_sample), (8, max(1000, args.cpu_sample // 5)), (1, max(1000, args.cpu_sample // 15))]
+            cores = usable_cores()
+            plan = [(cores, args.cpu_sample), (8, args.cpu_sample), (1, args.cpu_sample if args.cpu_full else max(1000, args.cpu_sample // 75))]
+            if cores == 8:
+                plan.pop(1)
             ns = min(max(n for _, n in plan), per_rank)
             out["cpu_baseline"] = cpu_baseline(eng, reads[:ns].cpu().numpy(), L, [(t, min(n, ns)) for t, n in plan])
         if world == 1 and not args.no_ags_check:

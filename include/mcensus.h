@@ -42,6 +42,8 @@ typedef struct mc_stats {
     /* what the seed kernel itself asked its structures (timed form): 9-mer filter words (4 B), wildcard filter lines (32 B),
      * pair filter blocks (16 B), bucket records + key groups searched (32 B + 16 B); seed_tasks postings (4 B) came out */
     int64_t seed_exact_asks, seed_wild_asks, seed_pair_asks, seed_probes;
+    /* how often a range overflowed the pools sized for shotgun reads and was run again in smaller pieces (mc_run_range) */
+    int64_t range_splits;
 } mc_stats;
 
 const char *mc_last_error(void);

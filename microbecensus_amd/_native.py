@@ -27,7 +27,7 @@ class McBestHit(C.Structure):
 class McStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("reads", "seed_tasks", "gap_tasks", "hsps", "rows", "reads_with_rows", "classified", "bucket_lookups", "key_probes")] + \
                [(n, C.c_float) for n in ("ms_translate", "ms_seed", "ms_eval", "ms_gapped", "ms_sort", "ms_finish", "ms_total")] + \
-               [("_pad", C.c_float)] + [(n, C.c_int64) for n in ("seed_exact_asks", "seed_wild_asks", "seed_pair_asks", "seed_probes")]
+               [("_pad", C.c_float)] + [(n, C.c_int64) for n in ("seed_exact_asks", "seed_wild_asks", "seed_pair_asks", "seed_probes", "range_splits")]
 
 
 class McReaderStats(C.Structure):

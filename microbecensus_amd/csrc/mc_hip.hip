@@ -1048,6 +1048,9 @@ __device__ __forceinline__ bool mc_ev_gate(const McHot &T, const uint8_t *q, int
     // loads); most hits stop growing at once on both sides and reach the gate without another read
     int L = seedlen;
     int lim = dlen - dpos; if (lim > qlen - qpos) lim = qlen - qpos;
+    // (seeds shorter than 9 residues - the generic seed kernel of a database whose .info threshold is above 0 emits 6 .. 9 - grow
+    // residue by residue up to the ninth; the marker database's seeds are 9 or 10 long and never enter)
+    while (L < 9 && lim > L && T.grp[q[qpos + L]] == T.grp[d[dpos + L]]) { int a = q[qpos + L], b = d[dpos + L]; score += MC_SUB(T, a, b); ident += (a == b); L++; }
 #pragma unroll
     for (int j = 9; j < 16; j++) {
         const int a = (int)((q2 >> (8 * (j - 8))) & 0xFFu), b = (int)((d2 >> (8 * (j - 8))) & 0xFFu);
@@ -2584,7 +2587,11 @@ static int stage_b(mc_handle *h, McCtx &c)
         uint32_t slots = 1u << 16;
         while (slots < 2 * ngaps) slots <<= 1;
         if (slots > c.gtab_slots) { if (dalloc(&c.d_gtab, (size_t)slots)) return -1; c.gtab_slots = slots; }
-        uint32_t *gk = (uint32_t *)c.d_k64, *gko = gk + 2 * (size_t)ngaps, *gi = c.d_idx, *gio = c.d_idxo;     // (2 ngaps <= cap_hsps: see ensure_capacity)
+        // The flank sort borrows the buffers of the HSP sort: 2 ngaps keys + 2 ngaps sorted keys in d_k64 (8 cap_hsps bytes), 2 ngaps
+        // items in d_idx / d_idxo (4 cap_hsps bytes each).  The pools are sized so that ordinary batches fit (ensure_capacity); a batch
+        // dense in gap tasks that does not is an overflow like any other: the range is run again in halves.
+        if (2 * (uint64_t)ngaps > c.cap_hsps) { g_err = "gap task pool larger than the sort buffers"; return -2; }
+        uint32_t *gk = (uint32_t *)c.d_k64, *gko = gk + 2 * (size_t)ngaps, *gi = c.d_idx, *gio = c.d_idxo;
         HIPCK(hipMemsetAsync(c.d_gtab, 0, (size_t)slots * 8, st));
         HIPCK(hipMemsetAsync(gk, 0, (size_t)ngaps * 8, st));
         k_gap_dedupe<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(X, L, c.d_gaps, ngaps, c.d_gtab, slots - 1, c.d_gleader, gk, gi, c.d_counters);
@@ -2726,6 +2733,7 @@ static void stats_add(mc_stats &tot, const mc_stats &s)
     tot.seed_exact_asks += s.seed_exact_asks; tot.seed_wild_asks += s.seed_wild_asks; tot.seed_pair_asks += s.seed_pair_asks; tot.seed_probes += s.seed_probes;
     tot.ms_translate += s.ms_translate; tot.ms_seed += s.ms_seed; tot.ms_eval += s.ms_eval; tot.ms_gapped += s.ms_gapped;
     tot.ms_sort += s.ms_sort; tot.ms_finish += s.ms_finish; tot.ms_total += s.ms_total;
+    tot.range_splits += s.range_splits;
 }
 
 static int run_range_once(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id);
@@ -2738,11 +2746,12 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
     if (rc != -2 || count <= 1) return rc;
     std::vector<mc_row> &rows = h->split_rows; rows.clear();
     std::vector<mc_best_hit> best; mc_stats tot; memset(&tot, 0, sizeof tot);
+    tot.range_splits = 1;
     int64_t off = 0, step = std::max<int64_t>(1, count / 2);
     while (off < count) {
         const int64_t nb = std::min<int64_t>(step, count - off);
         rc = run_range_once(h, first + off, nb, first_read_id + off);
-        if (rc == -2 && nb > 1) { step = std::max<int64_t>(1, nb / 2); continue; }
+        if (rc == -2 && nb > 1) { step = std::max<int64_t>(1, nb / 2); tot.range_splits++; continue; }
         if (rc) return rc;
         rows_wait(h);
         rows.insert(rows.end(), h->res_rows, h->res_rows + h->n_res_rows);

@@ -109,6 +109,39 @@ def sample_reads(genome, nreads, read_len, seed=1, chunk=1 << 20):
     return out
 
 
+def mutate_reads(reads, read_len, sub_rate=0.02, indel_rate=0.005, seed=1):
+    """Sequencing-error model for parity tests: every base of `reads` (n x >= read_len + slack, error free) is substituted by
+    one of the other three with probability sub_rate, deleted with probability indel_rate / 2, or followed by a random inserted
+    base with probability indel_rate / 2; the result is trimmed to read_len (reads that got too short are padded with `N`).
+    An indel inside a codon shifts the frame: the gapped extension has to bridge between frames' HSPs or stop there."""
+    rng = Counter(seed)
+    n, w = reads.shape
+    u = rng.uniform(n * w).reshape(n, w)
+    pick = rng.integers(n * w, 3).reshape(n, w)
+    ins = rng.integers(n * w, 4).reshape(n, w)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    code = np.zeros(256, dtype=np.int64)
+    for i, c in enumerate(b"ACGT"):
+        code[c] = i
+    out = np.full((n, read_len), ord("N"), dtype=np.uint8)
+    sub = u < sub_rate
+    dele = (u >= sub_rate) & (u < sub_rate + indel_rate / 2)
+    insr = (u >= sub_rate + indel_rate / 2) & (u < sub_rate + indel_rate)
+    subbed = np.where(sub, acgt[(code[reads] + 1 + pick) & 3], reads)
+    for i in range(n):
+        if not (dele[i].any() or insr[i].any()):
+            row = subbed[i]
+        else:
+            keep = ~dele[i]
+            reps = keep.astype(np.int64) + insr[i]
+            row = np.repeat(subbed[i], reps)
+            at = np.cumsum(reps)[insr[i]] - 1              # the copy behind an insertion point becomes the inserted base
+            row[at] = acgt[ins[i][insr[i]]]
+        m = min(read_len, len(row))
+        out[i, :m] = row[:m]
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Reads from the reference's 30 real genomes (SURVEY.md 8(d)); data fixture written by tests/golden/make_genomes_fixture.py
 # ---------------------------------------------------------------------------------------------------------------------

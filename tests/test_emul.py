@@ -41,6 +41,17 @@ def test_device_code_reproduces_reference_m8(emul_bin, markers_faa, tmp_path):
     assert hashlib.md5(out.read_bytes()).hexdigest() == meta["m8_md5"]
 
 
+def test_device_code_on_dirty_reads(emul_bin, markers_faa, tmp_path):
+    """Lower case, IUPAC codes, `*`, `-`, digits, blanks in the reads (golden from the reference's binary,
+    tests/golden/make_dirty_golden.py): the per-thread code the kernels share gives the reference's m8."""
+    meta = json.load(open(os.path.join(GOLD, "dirty_reads.json")))
+    fa = tmp_path / "dirty.fa"
+    fa.write_bytes(gzip.open(os.path.join(GOLD, "dirty_reads.fa.gz"), "rb").read())
+    out = tmp_path / "out.m8"
+    subprocess.check_call([emul_bin, markers_faa, str(fa), str(out)], stderr=subprocess.DEVNULL)
+    assert hashlib.md5(out.read_bytes()).hexdigest() == meta["m8_md5"]
+
+
 def test_index_builder_matches_prerapsearch(emul_bin, markers_faa, ref_dir, tmp_path):
     """Bucket starts, posting order, suffix keys, residue codes, frequency threshold and letter frequencies of
     the product's index builder against the database prerapsearch wrote (oracle/_ref/rapdb_2.15[.info])."""

@@ -1,0 +1,103 @@
+"""GPU parity where the five goldens and the error-free genome reads do not reach: libraries dense in marker genes (the pools
+sized for shotgun reads overflow and mc_run_range runs the range again in halves), and reads with sequencing errors
+(substitutions and indels: frame shifts, gapped DP band growth).  All calls go through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_pipeline import _oracle_rows, _rows, assert_rows_equal
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from microbecensus_amd._native import Engine
+    e = Engine(device=0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def marker_reads():
+    """300,000 reads of 150 bp from a synthetic community made of nothing but (diverged) marker genes: ~290 HSPs and ~100 m8
+    rows per read where a shotgun library has 23 and 1.9."""
+    from microbecensus_amd import _native, synth
+    names, seqs = _native.load_markers()
+    genome = synth.build_genomes(seqs, total_bp=3_000_000, seed=404, marker_gene_fraction=1.0)
+    return synth.sample_reads(genome, 300_000, 150, seed=405)
+
+
+def _fields_equal(a, b):
+    return len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in a.dtype.names)
+
+
+def test_pool_overflow_runs_the_range_in_halves(engine, marker_reads, monkeypatch):
+    """ONE mc_search of a marker-dense library: every batch overflows the HSP / gap-task pools (`C_OVERFLOW`, -2 out of
+    run_range_once) and mc_run_range answers by running the range in halves, and those in halves again.  The rows must be the
+    ones the same reads give in 5,000-read batches (which fit), and the oracle's on a subsample."""
+    from microbecensus_amd import _native
+    model = _native.load_model()
+    fams = model["families"]
+    engine.set_run(150, model["pars"]["150"], fams)
+    rows, best = engine.search(marker_reads)
+    st = engine.stats()
+    print("one call:", st)
+    assert st["range_splits"] > 0, "the batch did not overflow: the test no longer exercises the halving path"
+    assert st["reads"] == len(marker_reads) and st["rows"] == len(rows) and st["classified"] == len(best)
+    assert np.all(np.diff(rows["query"]) >= 0) and np.bincount(rows["query"]).max() <= 500
+    monkeypatch.setenv("MC_STREAM_BATCH", "5000")
+    rows5, best5 = engine.search(marker_reads)
+    st5 = engine.stats()
+    monkeypatch.delenv("MC_STREAM_BATCH")
+    print("5,000-read batches:", st5)
+    assert st5["range_splits"] == 0
+    assert _fields_equal(rows, rows5) and _fields_equal(best, best5)
+    assert (st["hsps"], st["gap_tasks"], st["seed_tasks"]) == (st5["hsps"], st5["gap_tasks"], st5["seed_tasks"])
+    sub = rows[rows["query"] < 5000]
+    assert_rows_equal(_rows(sub), _oracle_rows(marker_reads[:5000]))
+
+
+def test_pool_overflow_through_the_file_pipeline_best_hits_only(engine, marker_reads, tmp_path):
+    """The same library as a FASTA file through mc_search_files with mc_set_best_hits_only (what run_pipeline runs): best hits ==
+    those of the rows path above's algorithm (searched again here), with the halving path taken."""
+    from microbecensus_amd import _native
+    model = _native.load_model()
+    fams = model["families"]
+    fa = tmp_path / "markers_only.fa"
+    with open(fa, "wb") as f:
+        for s in range(0, len(marker_reads), 50000):
+            f.write(b"".join(b">r%d\n%s\n" % (s + i, bytes(r)) for i, r in enumerate(marker_reads[s:s + 50000])))
+    engine.set_run(150, model["pars"]["150"], fams)
+    rd = _native.Reader([str(fa)], 150, 10_000_000, False, 0, -5, -5, 100, False)
+    try:
+        _, best = engine.search_files(rd, keep_rows=False, best_only=True)
+        st = engine.stats()
+        assert rd.stats()["sampled"] == len(marker_reads)
+    finally:
+        rd.close()
+    print("files, best hits only:", st)
+    assert st["range_splits"] > 0
+    _, want = engine.search(marker_reads)
+    assert len(best) > 1000 and _fields_equal(best, want)
+
+
+@pytest.mark.parametrize("L,n,sub,indel", [(150, 6000, 0.01, 0.002), (150, 6000, 0.05, 0.01), (300, 3000, 0.02, 0.005), (300, 3000, 0.05, 0.01), (500, 1500, 0.03, 0.01)])
+def test_reads_with_sequencing_errors_against_oracle(engine, L, n, sub, indel):
+    """1 - 5 % substitutions and 0.2 - 1 % indels at 150 / 300 / 500 bp (synth.mutate_reads): mismatching seeds, frame shifts in
+    the middle of a hit, gapped extensions whose band has to grow (`AlignGapped@0x40a550`) - every m8 row identical to the
+    oracle's."""
+    from microbecensus_amd import _native, synth
+    names, seqs = _native.load_markers()
+    genome = synth.build_genomes(seqs, total_bp=600_000, seed=900 + L, marker_gene_fraction=0.3)
+    clean = synth.sample_reads(genome, n, L + 24, seed=L + 7)
+    reads = synth.mutate_reads(clean, L, sub_rate=sub, indel_rate=indel, seed=L + int(sub * 1000))
+    assert (reads != clean[:, :L]).any(axis=1).mean() > 0.5
+    engine.set_run(L)
+    rows, _ = engine.search(reads)
+    got = _rows(rows)
+    assert_rows_equal(got, _oracle_rows(reads))
+    assert len(rows) > 100 and sum(1 for r in got if r[4] > 0) > 5          # (rows with gap openings among them)

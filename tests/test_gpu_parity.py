@@ -64,6 +64,47 @@ def test_m8_identical_to_reference(case, counting, engine, tmp_path):
     assert (st["bucket_lookups"] > 0 and st["key_probes"] > 0) if counting else (st["bucket_lookups"] == 0 and st["key_probes"] == 0)
 
 
+_DIRTY_WORKER = r"""
+import gzip, hashlib, json, os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from microbecensus_amd import _native
+gold = os.path.join(sys.argv[1], "tests", "golden")
+meta = json.load(open(os.path.join(gold, "dirty_reads.json")))
+seqs = [l.rstrip(b"\r\n") for l in gzip.open(os.path.join(gold, "dirty_reads.fa.gz"), "rb") if not l.startswith(b">")]
+reads = np.frombuffer(b"".join(seqs), dtype=np.uint8).reshape(len(seqs), meta["read_length"])
+eng = _native.Engine(device=0)
+eng.set_run(meta["read_length"])
+res = {}
+for counting in (False, True):
+    eng.set_counting(counting)
+    rows, _ = eng.search(reads)
+    eng.write_m8(sys.argv[2])
+    res["counting" if counting else "filtered"] = [len(rows), hashlib.md5(open(sys.argv[2], "rb").read()).hexdigest()]
+eng.close()
+json.dump(res, open(sys.argv[3], "w"))
+"""
+
+
+@pytest.mark.parametrize("staged", ["1", "0"], ids=["reads_staged_in_lds", "reads_from_global"])
+def test_dirty_reads_identical_to_reference(staged, tmp_path):
+    """Reads that are not clean upper-case ACGT - lower case, IUPAC codes, `*`, `-`, `.`, digits, blanks, `?|~` - as the
+    reference's binary searched them (tests/golden/make_dirty_golden.py; byte tables of `CHashSearch` ctor 0x4169bd-0x416a62,
+    `BuildQHash@0x40b530`): the wave-level base decoding (`mc_nt_code`, packed 4-bit frames of the seed kernel) must give the
+    same m8, for both forms of k_translate_seg (MC_TS_STAGED is read once per process: one child process per form)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    meta = json.load(open(os.path.join(GOLD, "dirty_reads.json")))
+    w = tmp_path / "w.py"
+    w.write_text(_DIRTY_WORKER)
+    env = dict(os.environ, MC_TS_STAGED=staged)
+    subprocess.check_call([sys.executable, str(w), repo, str(tmp_path / "o.m8"), str(tmp_path / "o.json")], env=env, timeout=900)
+    res = json.load(open(tmp_path / "o.json"))
+    for form in ("filtered", "counting"):
+        assert res[form] == [meta["m8_rows"], meta["m8_md5"]], form
+
+
 def test_the_product_library_is_the_one_loaded():
     """The GPU tests must exercise microbecensus_amd/libmcensus_hip.so itself: no MCENSUS_LIB override in the environment, and
     the library mapped into this process is the in-tree one."""

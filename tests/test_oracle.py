@@ -71,3 +71,18 @@ def test_oracle_on_the_small_baseline_configs(case, oracle_bin, ref_dir, tmp_pat
     out = str(tmp_path / "out.m8")
     subprocess.check_call([oracle_bin, os.path.join(ref_dir, "rapdb_2.15"), fa, out])
     assert hashlib.md5(open(out, "rb").read()).hexdigest() == meta["m8_md5"]
+
+
+def test_oracle_on_dirty_reads(oracle_bin, ref_dir, tmp_path):
+    """Reads with lower case, IUPAC codes, `*`, `-`, digits, blanks (tests/golden/make_dirty_golden.py: 3,012 variants of the
+    config-1 reads that hit, searched by the reference's binary): the engine's byte tables (`CHashSearch` ctor
+    0x4169bd-0x416a62, `BuildQHash@0x40b530`) as the oracle restates them."""
+    meta = json.load(open(os.path.join(GOLD, "dirty_reads.json")))
+    fa = tmp_path / "dirty.fa"
+    fa.write_bytes(gzip.open(os.path.join(GOLD, "dirty_reads.fa.gz"), "rb").read())
+    assert hashlib.md5(fa.read_bytes()).hexdigest() == meta["reads_md5"]
+    out = str(tmp_path / "out.m8")
+    subprocess.check_call([oracle_bin, os.path.join(ref_dir, "rapdb_2.15"), str(fa), out])
+    got = open(out, "rb").read()
+    assert got.count(b"\n") == meta["m8_rows"] and hashlib.md5(got).hexdigest() == meta["m8_md5"]
+    assert got == gzip.open(os.path.join(GOLD, "dirty_reads.m8.gz"), "rb").read()
