@@ -44,7 +44,7 @@ extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
         }                                                                                                   \
     } while (0)
 
-enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_HEAVY, C_HEAVY2, C_ITEMS, C_RETRY2, C_HEAVY3, C_LIGHT0, C_LIGHT1, C_LIGHT2, C_LIGHT3, C_HSPS2, C_HPAD, C_GPAD, C_N = 24 };
+enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_HEAVY, C_HEAVY2, C_ITEMS, C_RETRY2, C_HEAVY3, C_LIGHT0, C_LIGHT1, C_LIGHT2, C_LIGHT3, C_HSPS2, C_HPAD, C_GPAD, C_ORDER, C_ORDER2, C_ORDER3, C_OTAKE, C_OTAKE2, C_OTAKE3, C_N = 28 };
 enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_EXACT = 16, S_WILD, S_PAIRS, S_PROBES, S_N = 20 };   // 64-bit algorithmic-traffic counters of k_enumerate; slots 4..: cycle counters of the MC_EXP_TIMING build
 
 // ------------------------------------------------------------------------------------------------
@@ -1016,6 +1016,9 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
 // the reads that have such an HSP (cand), and only THEIR HSPs - all of them: the others still decide the sums, the order and the
 // 500-row cap - are sorted and finished.
 #define MC_HSP_KEY(h) (((uint64_t)(h).read << 43) | ((uint64_t)(uint32_t)(h).sidx << 28) | (uint64_t)(h).chrono)   // (read, subject, hit order)
+// frame and the four coordinates of an HSP in one word (3 + 8 + 8 + 11 + 11 bits: frames of up to 170 residues, markers of up to 1,192):
+// two HSPs of a subject with the same word are one HSP found from several seeds (CalRes 0x4082b0-0x408446 keeps one of them)
+#define MC_HSP_PLACE(h) (((uint64_t)(uint16_t)(h).frame << 38) | ((uint64_t)(uint16_t)(h).qaas << 30) | ((uint64_t)(uint16_t)(h).qaae << 22) | ((uint64_t)(uint16_t)(h).ds << 11) | (uint64_t)(uint16_t)(h).de)
 __device__ __forceinline__ bool mc_hsp_can_classify(const McTables &T, const McClassPars &P, const McIndex &X, const int32_t *fam, const McHsp &h)
 {
     const int f = fam[h.sidx];
@@ -1166,7 +1169,7 @@ __device__ __forceinline__ uint32_t mc_ev_slots(uint32_t n, uint32_t r, uint32_t
 // its last block is padded with records the later stages skip (read = MC_TASK_NONE, sort key all ones; C_HPAD / C_GPAD count them).
 __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_EV_BS) k_eval_seeds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
                                                     const McSeedTask *__restrict__ tasks, const uint32_t *__restrict__ ntasks_p, uint32_t cap_tasks, McHsp *hsps, uint32_t cap_hsps,
-                                                    McGapTask *gaps, uint32_t cap_gaps, uint32_t *counters, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam, uint8_t *cand, uint64_t *hkeys)
+                                                    McGapTask *gaps, uint32_t cap_gaps, uint32_t *counters, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam, uint8_t *cand, uint64_t *hkeys, uint8_t *low, uint64_t *hplace)
 {
     const uint32_t ntasks = *ntasks_p <= cap_tasks ? *ntasks_p : 0u;   // (device-side count of the seed kernel; after an overflow the host discards the batch)
     __shared__ McHot hot;
@@ -1174,6 +1177,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
     uint4 *Q = (uint4 *)(mc_smem + (size_t)wv * MC_EV_QCAP * 32);    // entry e: words 2 e, 2 e + 1
     mc_load_hot(&hot, T);
     __syncthreads();
+    const double hot_loge_thr = T->loge_thr;
     uint32_t qn = 0, hb_base = 0, hb_used = MC_EV_BLK, gb_base = 0, gb_used = MC_EV_BLK;
     bool ok = true;
     const unsigned long long lt = (1ull << lane) - 1;
@@ -1253,6 +1257,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
                     h.read = read; h.chrono = chrono;
                     keep = mc_make_hsp(*T, L, frame, g, g.qfwd, g.qfwd, g.qbwd, g.qbwd, g.score, g.nmatch, g.qfwd + g.L + g.qbwd, 0, 0, &h);
                     if (keep && cand && mc_hsp_can_classify(*T, *P, X, fam, h)) cand[h.read] = 1;
+                    if (keep && h.loge < hot_loge_thr) low[h.read] = 1;      // (the read can print a row: k_order_light)
                 }
             }
             MC_EV_TICK(3);
@@ -1260,7 +1265,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
             if (mh && ok) {
                 const uint32_t slot = mc_ev_slots((uint32_t)__popcll(mh), (uint32_t)__popcll(mh & lt), cap_hsps, &counters[C_HSPS], hb_base, hb_used, &ok, lane);
                 if (!ok) { if (lane == 0) counters[C_OVERFLOW] = 2; }
-                else if (keep) { hsps[slot] = h; hkeys[slot] = MC_HSP_KEY(h); }
+                else if (keep) { hsps[slot] = h; hkeys[slot] = MC_HSP_KEY(h); hplace[slot] = MC_HSP_PLACE(h); }
             }
             if (mg && ok) {
                 const uint32_t slot = mc_ev_slots((uint32_t)__popcll(mg), (uint32_t)__popcll(mg & lt), cap_gaps, &counters[C_GAPS], gb_base, gb_used, &ok, lane);
@@ -1380,7 +1385,7 @@ __global__ void __launch_bounds__(256) k_gap_dedupe(McIndex X, int L, const McGa
 // every gap task -> its HSP, from the flank results of its group's leader
 __global__ void __launch_bounds__(256) k_gap_emit(const McTables *__restrict__ T, McIndex X, int L, const McGapTask *__restrict__ gaps, uint32_t ngaps, const uint32_t *__restrict__ leader,
                                                   const McFlankOut *__restrict__ fout, McHsp *hsps, uint32_t cap_hsps, uint32_t *counters, const McClassPars *__restrict__ P,
-                                                  const int32_t *__restrict__ fam, uint8_t *cand, uint64_t *hkeys)
+                                                  const int32_t *__restrict__ fam, uint8_t *cand, uint64_t *hkeys, uint8_t *low, uint64_t *hplace)
 {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     bool keep = false;
@@ -1402,9 +1407,10 @@ __global__ void __launch_bounds__(256) k_gap_emit(const McTables *__restrict__ T
         h.read = g.read; h.chrono = g.chrono;
         keep = mc_make_hsp(*T, L, frame, g, qfwd, dfwd, qbwd, dbwd, score, nmatch, alnlen, gapopens, gaptotal, &h);
         if (keep && cand && mc_hsp_can_classify(*T, *P, X, fam, h)) cand[h.read] = 1;
+        if (keep && h.loge < T->loge_thr) low[h.read] = 1;
     }
     const uint32_t o = mc_block_alloc(&counters[C_HSPS], keep);
-    if (keep) { if (o < cap_hsps) { hsps[o] = h; hkeys[o] = MC_HSP_KEY(h); } else counters[C_OVERFLOW] = 2; }
+    if (keep) { if (o < cap_hsps) { hsps[o] = h; hkeys[o] = MC_HSP_KEY(h); hplace[o] = MC_HSP_PLACE(h); } else counters[C_OVERFLOW] = 2; }
 }
 
 #define MC_GAP_W 1200   // columns of the full-size DP workspace (markers are <= 1183 aa, checked in mc_open)
@@ -1579,70 +1585,365 @@ __global__ void __launch_bounds__(64) k_gapped_lds(const McTables *__restrict__ 
     }
 }
 
-// sort keys of the HSPs of the marked reads, packed (their count in counters[C_HSPS2]); the HSP count is read on the device
-// The sort key of every HSP is written beside it by the kernel that makes it (k_eval_seeds' flush, k_gap_emit): the selection
-// below and the sort then read 8 bytes per HSP instead of its 48-byte record (k_make_keys, which read them all again, is gone).
-__global__ void __launch_bounds__(256) k_select_keys(const uint64_t *__restrict__ hkeys, const uint32_t *__restrict__ counters_in, uint32_t cap_hsps, const uint8_t *__restrict__ cand,
-                                                     uint64_t *keys, uint32_t *idx, uint32_t *counters)
+// ---- HSPs into per-read segments, ordered by (subject, hit order) ----------------------------------------------------------------
+// The reference keeps a read's HSPs in a multimap keyed by (query, subject) (`CalRes` insert 0x407c70, `PrintRes@0x409310` walks it
+// subject by subject): the finishing kernels need every read's HSPs together, ordered by subject and - inside a subject - by the
+// order in which the reference would have found them (chrono).  Rounds 1 - 3 got there with a 64-bit radix sort of ALL HSPs
+// (rocPRIM, 8 passes over 45 M keys per 2 M reads).  But the producers emit the HSPs of a read close together (a read's seed hits
+// are consecutive in the task pool), nine reads in ten print nothing whatever the order of their HSPs, and a read has 23 HSPs on
+// average.  So: (1) count the HSPs per read and scan the counts (k_bin_count, mc_scan_*), (2) move every HSP's key and pool slot -
+// 12 bytes, not the 48-byte record - to its read's segment (k_bin_scatter; both with ONE atomic per run of consecutive HSPs of the
+// same read in the pool), (3) order each segment by
+// (subject, hit order) - every HSP's rank inside its segment is the number of smaller keys there, counted in LDS - and decide
+// whether the read can print anything: a workgroup per 64 reads for the segments of up to 64 HSPs (k_order_light), a wave per read
+// for the longer ones (k_order_heavy); (4) only the records of the reads that can print are fetched from the pool, in order (k_order_copy).
+// A read is MARKED (nrow_of = 1: the finishing kernels take it) when one of its HSPs has log E below the threshold (low[read], set
+// by the kernel that made the HSP) or two DIFFERENT HSPs lie on one subject (sum statistics may lower the group's E; HSPs of a
+// subject with the same frame and coordinates are one HSP found from several seeds: CalRes keeps the best of them, printed only if
+// its own log E is below the threshold).  Marking more reads than that is harmless (a marked read that prints nothing finishes with
+// 0 rows), only slower.
+// hkeys[slot] = read << 43 | subject << 28 | hit order, written beside every HSP by the kernel that makes it (~0: padding).
+#ifndef MC_BIN_LIGHT
+#define MC_BIN_LIGHT 32                    // segments up to this long are ordered by k_order_light, longer ones by k_order_heavy
+#endif
+__device__ __forceinline__ void mc_bin_runs(bool valid, uint32_t read, int lane, bool &head, int &hl, uint32_t &len)
+{   // consecutive lanes of the wave with the same read form a run: head = its first lane, hl = the head's lane, len = its length (valid lanes only)
+    const uint32_t pr = (uint32_t)__shfl_up((int)read, 1);
+    const bool pv = (bool)__shfl_up((int)valid, 1);
+    head = valid && (lane == 0 || !pv || pr != read);
+    const unsigned long long hm = __ballot(head), sm = __ballot(!valid || head);
+    const unsigned long long below = hm & ((2ull << lane) - 1ull);
+    hl = below ? 63 - __builtin_clzll(below) : 0;
+    const unsigned long long above = lane < 63 ? (sm & ~((2ull << lane) - 1ull)) : 0ull;
+    len = (uint32_t)((above ? __builtin_ctzll(above) : 64) - lane);
+}
+__global__ void __launch_bounds__(256) k_bin_count(const uint64_t *__restrict__ hkeys, const uint32_t *__restrict__ counters_in, uint32_t cap_hsps, const uint8_t *__restrict__ cand, uint32_t *cnt)
 {
     const uint32_t n = counters_in[C_HSPS] <= cap_hsps ? counters_in[C_HSPS] : 0u;
+    const int lane = mc_lane();
     for (uint32_t b0 = blockIdx.x * 256u; b0 < n; b0 += gridDim.x * 256u) {
         const uint32_t tid = b0 + threadIdx.x;
-        bool want = false;
-        uint64_t key = 0;
-        if (tid < n) {
-            key = hkeys[tid];
-            want = key != ~0ull && cand[(uint32_t)(key >> 43)] != 0;       // (~0: padding of a wave's last block)
-        }
-        const uint32_t o = mc_block_alloc(&counters[C_HSPS2], want);
-        if (want) { keys[o] = key; idx[o] = tid; }
+        uint64_t key = ~0ull;
+        if (tid < n) key = hkeys[tid];
+        const uint32_t read = (uint32_t)(key >> 43);
+        const bool valid = key != ~0ull && (!cand || cand[read] != 0);          // (~0: padding of a wave's last block)
+        bool head; int hl; uint32_t len;
+        mc_bin_runs(valid, read, lane, head, hl, len);
+        if (head) atomicAdd(&cnt[read], len);
     }
 }
-
-__global__ void k_iota(uint32_t *idx, uint32_t n)
-{   // 0, 1, 2, ...: the values the sort of ALL HSPs carries along (written once per pool)
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid < n) idx[tid] = tid;
+__global__ void __launch_bounds__(256) k_bin_scatter(const uint64_t *__restrict__ hkeys, const uint32_t *__restrict__ counters_in, uint32_t cap_hsps,
+                                                     const uint8_t *__restrict__ cand, uint32_t *cur, const uint64_t *__restrict__ hplace, uint64_t *keys, uint64_t *places, uint32_t *slots)
+{   // cur[read]: where the read's next HSP goes (in: the exclusive scan of the counts; out: the END of every read's segment = the start of the next read's).
+    // Only the key, the place word and the pool slot of an HSP move (20 bytes): the 48-byte records stay in the pool until k_order_copy fetches those of the marked reads.
+    const uint32_t n = counters_in[C_HSPS] <= cap_hsps ? counters_in[C_HSPS] : 0u;
+    const int lane = mc_lane();
+    for (uint32_t b0 = blockIdx.x * 256u; b0 < n; b0 += gridDim.x * 256u) {
+        const uint32_t tid = b0 + threadIdx.x;
+        uint64_t key = ~0ull;
+        if (tid < n) key = hkeys[tid];
+        const uint32_t read = (uint32_t)(key >> 43);
+        const bool valid = key != ~0ull && (!cand || cand[read] != 0);
+        bool head; int hl; uint32_t len;
+        mc_bin_runs(valid, read, lane, head, hl, len);
+        uint32_t base = 0;
+        if (head) base = atomicAdd(&cur[read], len);
+        base = (uint32_t)__shfl((int)base, hl);
+        if (valid) { const uint32_t dst = base + (uint32_t)(lane - hl); keys[dst] = key; places[dst] = hplace[tid]; slots[dst] = tid; }
+    }
 }
-// sorted order: copies the HSPs, flags the first HSP of every read, and marks the HSPs that can make their read print
-// anything: log E below the threshold, or a second, DIFFERENT HSP on the same subject (sum statistics may lower the group's E).
-// HSPs of a subject that all carry the same frame and coordinates are one HSP found from several seeds: CalRes keeps the best
-// of them (mc_finish_group's stack), a group of one, printed only if its own log E is below the threshold - so equal neighbours
-// mark nothing, and a subject whose neighbours are all equal is all equal.  A read without a marked HSP prints no row and has no
-// best hit; the finishing kernels never see it.
-__global__ void k_gather(const McHsp *__restrict__ hsps, const uint32_t *__restrict__ idx, const uint64_t *__restrict__ skeys, uint32_t n, McHsp *out, uint32_t *flags, uint8_t *mark, double loge_thr)
+// exclusive scan of n 32-bit counts (n <= 2 M + 1): partial sums of blocks of 1024, the scan of those by one workgroup, the blocks again
+#define MC_SCAN_BLK 1024u
+__global__ void __launch_bounds__(256) k_scan_sums(const uint32_t *__restrict__ in, uint32_t n, uint32_t *sums)
 {
-    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= n) return;
-    McHsp h = hsps[idx[tid]];
-    out[tid] = h;
-    bool head = true, same_subject = false;
-    if (tid > 0) {
-        // read and subject of the HSP in front are in its sorted key (read 21 | subject 15 | hit order 28): its record - a second
-        // scattered 48-byte read - is only fetched when both are this HSP's
-        const uint64_t pk = skeys[tid - 1];
-        head = (uint32_t)(pk >> 43) != h.read;
-        if (!head && (int32_t)((pk >> 28) & 0x7FFFu) == h.sidx) {
-            const McHsp &p = hsps[idx[tid - 1]];
-            same_subject = !(p.frame == h.frame && p.qaas == h.qaas && p.ds == h.ds && p.qaae == h.qaae && p.de == h.de);
+    __shared__ uint32_t w[4];
+    const uint32_t i0 = blockIdx.x * MC_SCAN_BLK + threadIdx.x * 4u;
+    uint32_t v = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) if (i0 + k < n) v += in[i0 + k];
+    for (int d = 32; d > 0; d >>= 1) v += (uint32_t)__shfl_down((int)v, d);
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+}
+__global__ void __launch_bounds__(1024) k_scan_top(uint32_t *sums, uint32_t nb)
+{   // one workgroup: exclusive scan of up to 4096 block sums in place (4 per thread)
+    __shared__ uint32_t w[16];
+    const int lane = mc_lane(), wv = threadIdx.x >> 6;
+    uint32_t x[4], t = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) { const uint32_t i = threadIdx.x * 4u + k; x[k] = i < nb ? sums[i] : 0u; t += x[k]; }
+    const uint32_t inc = mc_wave_scan_add(t);
+    if (lane == 63) w[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int k = 0; k < wv; k++) base += w[k];
+    uint32_t run = base + inc - t;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) { const uint32_t i = threadIdx.x * 4u + k; if (i < nb) sums[i] = run; run += x[k]; }
+}
+__global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__ in, uint32_t n, const uint32_t *__restrict__ sums, uint32_t *out)
+{
+    __shared__ uint32_t w[4];
+    const int lane = mc_lane(), wv = threadIdx.x >> 6;
+    const uint32_t i0 = blockIdx.x * MC_SCAN_BLK + threadIdx.x * 4u;
+    uint32_t x[4], t = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) { x[k] = i0 + k < n ? in[i0 + k] : 0u; t += x[k]; }
+    const uint32_t inc = mc_wave_scan_add(t);
+    if (lane == 63) w[wv] = inc;
+    __syncthreads();
+    uint32_t run = sums[blockIdx.x] + inc - t;
+    for (int k = 0; k < wv; k++) run += w[k];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) { if (i0 + k < n) out[i0 + k] = run; run += x[k]; }
+}
+// out[i] = sum of in[0 .. i) for i < n (in and out may be the same array); sums: ceil(n / 1024) + 1 words of scratch
+static int mc_scan_u32(const uint32_t *in, uint32_t n, uint32_t *out, uint32_t *sums, hipStream_t st)
+{
+    if (!n) return 0;
+    const uint32_t nb = (n + MC_SCAN_BLK - 1) / MC_SCAN_BLK;
+    if (nb > 4096) { g_err = "scan of more than 4 M counts"; return -1; }
+    k_scan_sums<<<dim3(nb), dim3(256), 0, st>>>(in, n, sums);
+    k_scan_top<<<dim3(1), dim3(1024), 0, st>>>(sums, nb);
+    k_scan_apply<<<dim3(nb), dim3(256), 0, st>>>(in, n, sums, out);
+    return 0;
+}
+
+__device__ __forceinline__ bool mc_hsp_same_place(const McHsp *a, const McHsp *b)
+{   // frame and the four coordinates: the HSP was found again from another seed (CalRes 0x4082b0-0x408446 keeps one of them)
+    return a->frame == b->frame && a->qaas == b->qaas && a->ds == b->ds && a->qaae == b->qaae && a->de == b->de;
+}
+__device__ __forceinline__ void mc_hsp_copy(McHsp *dst, const McHsp *src)
+{
+    const uint4 *s = (const uint4 *)src; uint4 *d = (uint4 *)dst;
+    const uint4 x0 = s[0], x1 = s[1], x2 = s[2];
+    d[0] = x0; d[1] = x1; d[2] = x2;
+}
+// Light reads (segments of up to MC_BIN_LIGHT HSPs): a workgroup takes 64 consecutive reads - one contiguous stretch of the binned keys -
+// and stages the subjects and the (subject << 28 | hit order) keys of their HSPs in LDS.  Nine reads in ten have no HSP below the
+// threshold: for their HSPs only the question "is there another HSP on my subject, and is it a different one" is asked (a loop over
+// the segment's subjects in LDS; frame and coordinates are compared in global memory, rarely).  The HSPs of the marked reads are
+// then ranked inside their segment by counting the smaller keys and copied to their ranks.  The reads with longer segments are
+// listed for k_order_heavy.
+#define MC_OL_READS 64
+#define MC_ORDER_SMALL 512                 // segments up to this long: a wave per read (two buffers of 4 KB in LDS) ...
+#define MC_ORDER_MID 2048                  // ... up to this long (3 reads in 1,000): a workgroup of four waves (two buffers of 16 KB) ...
+#define MC_ORDER_LDS 8192                  // ... the few longer ones (0.6 in 1,000): a workgroup of sixteen waves (two buffers of 64 KB; beyond that: blocks of 8192, merged in global memory)
+// the reads whose segments are longer than MC_BIN_LIGHT, listed for k_order_heavy (a thread per read)
+__global__ void __launch_bounds__(256) k_order_lists(const uint32_t *__restrict__ heads, uint32_t nreads, uint32_t *counters, uint32_t *heavy, uint32_t *heavy2, uint32_t *heavy3)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t n = r < nreads ? heads[r + 1] - heads[r] : 0u;
+    const bool c1 = n > MC_BIN_LIGHT && n <= MC_ORDER_SMALL, c2 = n > MC_ORDER_SMALL && n <= MC_ORDER_MID, c3 = n > MC_ORDER_MID;
+    const uint32_t o = mc_block_alloc(&counters[C_ORDER], c1);
+    if (c1) heavy[o] = r;
+    const uint32_t o2 = mc_block_alloc(&counters[C_ORDER2], c2);
+    if (c2) heavy2[o2] = r;
+    const uint32_t o3 = mc_block_alloc(&counters[C_ORDER3], c3);
+    if (c3) heavy3[o3] = r;
+}
+#define MC_KEY43 ((1ull << 43) - 1)
+__global__ void __launch_bounds__(256) k_order_light(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ places, const uint32_t *__restrict__ slots, const uint32_t *__restrict__ heads, uint32_t nreads,
+                                                    const uint8_t *__restrict__ low, uint32_t *order, uint32_t *nrow_of)
+{
+    __shared__ uint64_t key[MC_OL_READS * MC_BIN_LIGHT], plc[MC_OL_READS * MC_BIN_LIGHT];
+    __shared__ uint16_t sid[MC_OL_READS * MC_BIN_LIGHT];
+    __shared__ uint8_t qof[MC_OL_READS * MC_BIN_LIGHT];            // the read (0 .. 63) of an LDS slot
+    __shared__ uint32_t lpos[MC_OL_READS + 1], lhead[MC_OL_READS + 1], lcnt[MC_OL_READS];
+    __shared__ uint8_t lmark[MC_OL_READS];
+    const int lane = mc_lane(), wv = threadIdx.x >> 6;
+    const uint32_t r0 = blockIdx.x * MC_OL_READS;
+    if (wv == 0) {
+        const uint32_t r = r0 + (uint32_t)lane;
+        uint32_t a = 0, n = 0;
+        if (r < nreads) { a = heads[r]; n = heads[r + 1] - a; }
+        else a = heads[nreads];
+        const bool light = n > 0 && n <= MC_BIN_LIGHT;
+        const uint32_t m = light ? n : 0u, inc = mc_wave_scan_add(m);
+        lpos[lane] = inc - m; lhead[lane] = a; lcnt[lane] = m;
+        lmark[lane] = (light && low[r] != 0) ? 1 : 0;
+        if (lane == 63) { lpos[64] = inc; lhead[64] = a + n; }
+    }
+    __syncthreads();
+    const uint32_t T = lpos[64];
+    if (T == 0) return;
+    const uint32_t A = lhead[0], B = lhead[64];
+    for (uint32_t p = A + threadIdx.x; p < B; p += 256) {          // subjects and keys into LDS: one coalesced pass over the stretch's keys
+        const uint64_t k = keys[p];
+        const uint32_t q = (uint32_t)(k >> 43) - r0;
+        if (lcnt[q]) { const uint32_t at = lpos[q] + (p - lhead[q]); qof[at] = (uint8_t)q; sid[at] = (uint16_t)((k >> 28) & 0x7FFFu); key[at] = k & MC_KEY43; plc[at] = places[p]; }
+    }
+    __syncthreads();
+    for (uint32_t at = threadIdx.x; at < T; at += 256) {           // reads without an HSP below the threshold: two different HSPs on one subject?
+        const uint32_t q = qof[at];
+        if (lmark[q]) continue;
+        const uint32_t n = lcnt[q], base = lpos[q], me = at - base;
+        const uint32_t s = sid[at];
+        uint32_t same = 0;
+        for (uint32_t j = 0; j < n; j++) same += (sid[base + j] == s) ? 1u : 0u;
+        if (same > 1) {
+            const uint64_t mine = plc[at];
+            for (uint32_t j = 0; j < n; j++)
+                if (sid[base + j] == s && plc[base + j] != mine) { lmark[q] = 1; break; }
+        }
+        (void)me;
+    }
+    __syncthreads();
+    if (threadIdx.x < MC_OL_READS && lmark[threadIdx.x]) nrow_of[r0 + threadIdx.x] = 1u;
+    for (uint32_t at = threadIdx.x; at < T; at += 256) {           // the marked reads: every HSP's rank in its segment
+        const uint32_t q = qof[at];
+        if (!lmark[q]) continue;
+        const uint32_t n = lcnt[q], base = lpos[q], me = at - base;
+        const uint64_t k = key[at];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; j++) { const uint64_t kj = key[base + j]; rank += (kj < k || (kj == k && j < me)) ? 1u : 0u; }
+        order[lhead[q] + rank] = slots[lhead[q] + me];
+    }
+}
+// sorted[i] = the HSP that belongs at place i (order[i]: its pool slot; ~0: the place of an unmarked read's HSP, nobody will look)
+__global__ void __launch_bounds__(256) k_order_copy(const uint32_t *__restrict__ order, const McHsp *__restrict__ hsps, const uint32_t *__restrict__ heads, uint32_t nreads, McHsp *sorted)
+{
+    const uint32_t total = heads[nreads];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const uint32_t sl = order[i];
+        if (sl != ~0u) mc_hsp_copy(sorted + i, hsps + sl);
+    }
+}
+// A wave per read with more HSPs (reads of marker genes: hundreds of HSPs on homologous markers), a workgroup of eight waves for the
+// few with more than 512 (4 reads in 1,000, with a quarter of all HSPs): merge sort of the items (subject << 28 | hit order) << 21 |
+// position in LDS (up to MC_ORDER_LDS; longer segments in global scratch); marked like the light reads.
+template <int NT> __device__ __forceinline__ void mc_group_sync() { if (NT == 64) mc_wave_sync(); else __syncthreads(); }
+__device__ __forceinline__ uint64_t mc_wave_sort64(uint64_t v, int lane)
+{   // bitonic sort of one item per lane, ascending by lane, in registers
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint64_t o = __shfl_xor(v, j);
+            const bool keep_min = ((lane & k) == 0) == ((lane & j) == 0);
+            v = keep_min ? (v < o ? v : o) : (v < o ? o : v);
+        }
+    return v;
+}
+// Merge sort of m items (a power of two >= 64, all different) by NT threads: chunks of 64 in registers, then log2(m / 64) passes in
+// which every item finds its place in the merged run by a binary search in the partner run - a pass is one barrier, where the
+// bitonic network has log2(m) (log2(m) + 1) / 2 of them (78 for the 4096 items of a read of a marker gene with 2,700 HSPs).  A
+// thread searches for four items at a time: the four chains of dependent reads run side by side.
+// One pass: runs of w items of x (sorted) -> runs of 2 w items of y.
+template <int NT, class PTR>
+__device__ __forceinline__ void mc_merge_pass(PTR x, PTR y, uint32_t m, uint32_t w, int tid)
+{
+    for (uint32_t i0 = (uint32_t)tid; i0 < m; i0 += 4 * NT) {
+        uint64_t v[4];
+        uint32_t lo[4], hi[4], pb[4], at[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t i = i0 + (uint32_t)c * NT;
+            const bool ok = i < m;
+            v[c] = ok ? x[i] : 0ull;
+            const uint32_t run = i / w;
+            pb[c] = (run ^ 1u) * w; at[c] = (run >> 1) * 2 * w + (i & (w - 1));
+            lo[c] = 0; hi[c] = ok ? w : 0u;                            // the number of items of the partner run below v
+        }
+        for (uint32_t span = w; span > 0; span >>= 1) {                 // (a range of w + 1 answers: log2(w) + 1 halvings)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (lo[c] < hi[c]) { const uint32_t mid = (lo[c] + hi[c]) >> 1; if (x[pb[c] + mid] < v[c]) lo[c] = mid + 1; else hi[c] = mid; }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) if (i0 + (uint32_t)c * NT < m) y[at[c] + lo[c]] = v[c];
+    }
+}
+// x holds the items, y is a second buffer of the same size; returns the buffer that holds the result.
+template <int NT, class PTR>
+__device__ __forceinline__ PTR mc_group_mergesort(PTR x, PTR y, uint32_t m, int tid)
+{
+    const int lane = tid & 63;
+    for (uint32_t c = (uint32_t)(tid >> 6) * 64u; c < m; c += NT) x[c + lane] = mc_wave_sort64(x[c + lane], lane);
+    mc_group_sync<NT>();
+    for (uint32_t w = 64; w < m; w <<= 1) {
+        mc_merge_pass<NT>(x, y, m, w, tid);
+        mc_group_sync<NT>();
+        PTR t = x; x = y; y = t;
+    }
+    return x;
+}
+#define MC_ITEM_OF(keys, k, n) ((k) < (n) ? (((keys)[k] & MC_KEY43) << 21) | (uint64_t)(k) : (~0ull << 21) | (uint64_t)(k))   // (padding: behind every HSP, all different)
+// the read's order from its sorted items: marks, then the pool slots of its HSPs in order (only if the read is marked)
+template <int NT, class PTR>
+__device__ __forceinline__ void mc_order_heavy_out(PTR x, const uint32_t *__restrict__ slots, const uint64_t *__restrict__ places, uint32_t n, bool marked, uint32_t *__restrict__ order, uint32_t *nrow, int tid, uint32_t *s_diff)
+{
+    if (!marked) {                                                 // no HSP below the threshold: two different HSPs on one subject? (neighbours now)
+        bool diff = false;
+        for (uint32_t k = (uint32_t)tid + 1; k < n && !diff; k += NT) {
+            const uint64_t u = x[k - 1], v = x[k];
+            if ((u >> 49) == (v >> 49)) diff = places[(uint32_t)(u & 0x1FFFFFu)] != places[(uint32_t)(v & 0x1FFFFFu)];
+        }
+        if (NT == 64) marked = __ballot(diff) != 0;
+        else { if (diff) *s_diff = 1; __syncthreads(); marked = *s_diff != 0; }
+    }
+    if (marked) {
+#pragma unroll 4
+        for (uint32_t k = (uint32_t)tid; k < n; k += NT) order[k] = slots[(uint32_t)(x[k] & 0x1FFFFFu)];
+        if (tid == 0) *nrow = 1u;
+    }
+    mc_group_sync<NT>();
+}
+// scratch: 12 64-bit words per HSP (the finishing kernels' tmp): a segment too long for the LDS is sorted there - blocks of CAP
+// items in LDS first, the merge passes above them in global memory (buffers at 12 a and 12 a + 4 n)
+template <int NT, uint32_t CAP>
+__global__ void __launch_bounds__(NT) k_order_heavy(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ places, const uint32_t *__restrict__ slots, const uint32_t *__restrict__ heads,
+                                                    const uint32_t *__restrict__ list, const uint32_t *__restrict__ nlist_p, uint32_t *take, const uint8_t *__restrict__ low, uint32_t *order, uint32_t *nrow_of, uint64_t *scratch)
+{
+    uint64_t *lds = (uint64_t *)mc_smem;                            // 2 x CAP items (dynamic LDS)
+    __shared__ uint32_t s_diff, s_e;
+    const int tid = (int)threadIdx.x;
+    const uint32_t nlist = *nlist_p;
+    uint32_t sub = 0, e0 = 0;
+    for (;;) {
+        // the next read of the list, whoever is free takes it (their sizes differ by orders of magnitude: dealt out in turn, the
+        // workgroup that met the longest ones finished long after the others)
+        // (the many mid-sized reads eight at a time: an atomic on ONE counter runs at the memory side, 125 M/s for the whole GPU)
+        uint32_t e = 0;
+        if (NT == 64) {
+            if ((sub & 7u) == 0) { if (tid == 0) e = atomicAdd(take, 8u); e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e); }
+            e = e0 + (sub++ & 7u);
+        } else { __syncthreads(); if (tid == 0) s_e = atomicAdd(take, 1u); __syncthreads(); e = s_e; }
+        if (e >= nlist) break;
+        const uint32_t r = list[e], a = heads[r], n = heads[r + 1] - a;
+        const bool marked = low[r] != 0;
+        const uint64_t *kk = keys + a;
+        uint32_t m = 64;
+        while (m < n) m <<= 1;
+        if (NT > 64 && tid == 0) s_diff = 0;
+        if (m <= CAP) {
+#pragma unroll 4
+            for (uint32_t k = (uint32_t)tid; k < m; k += NT) lds[k] = MC_ITEM_OF(kk, k, n);
+            mc_group_sync<NT>();
+            uint64_t *x = mc_group_mergesort<NT>(lds, lds + CAP, m, tid);
+            mc_order_heavy_out<NT>(x, slots + a, places + a, n, marked, order + a, nrow_of + r, tid, &s_diff);
+        } else {
+            uint64_t *g = scratch + 12 * (size_t)a, *g2 = g + 4 * (size_t)n;      // (m < 2 n)
+            for (uint32_t b0 = 0; b0 < m; b0 += CAP) {
+#pragma unroll 4
+                for (uint32_t k = (uint32_t)tid; k < CAP; k += NT) lds[k] = MC_ITEM_OF(kk, b0 + k, n);
+                mc_group_sync<NT>();
+                uint64_t *x = mc_group_mergesort<NT>(lds, lds + CAP, CAP, tid);
+                for (uint32_t k = (uint32_t)tid; k < CAP; k += NT) g[b0 + k] = x[k];
+                mc_group_sync<NT>();
+            }
+            __threadfence_block();
+            for (uint32_t w = CAP; w < m; w <<= 1) {
+                mc_merge_pass<NT>(g, g2, m, w, tid);
+                __threadfence_block();
+                mc_group_sync<NT>();
+                uint64_t *t = g; g = g2; g2 = t;
+            }
+            mc_order_heavy_out<NT>(g, slots + a, places + a, n, marked, order + a, nrow_of + r, tid, &s_diff);
         }
     }
-    flags[tid] = head ? 1u : 0u;
-    mark[tid] = (h.loge < loge_thr || same_subject) ? 1 : 0;
 }
-// heads[k] = index of the first HSP of the k-th read that has HSPs (ascending read id); hpos = exclusive scan of flags
-// ... and the reads that have a marked HSP: nrow_of (zeroed by the caller) is set to 1 for them - k_heavy_lists then knows
-// without walking the read's marks, and the finishing kernels overwrite it with the number of rows
-__global__ void k_heads(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ hpos, const uint8_t *__restrict__ mark, uint32_t n, uint32_t *heads, uint32_t *nrow_of, uint32_t *counters)
-{
-    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= n) return;
-    const uint32_t f = flags[tid], hp = hpos[tid];
-    if (f) heads[hp] = tid;
-    if (mark[tid]) nrow_of[hp + f - 1] = 1u;                       // (hpos is the exclusive scan of the flags: the read of HSP tid is hp + f - 1)
-    if (tid == n - 1) counters[C_HEADS] = hp + f;
-}
-
 
 #ifndef MC_FH_MIN
 #define MC_FH_MIN 96
@@ -1663,7 +1964,7 @@ __global__ void __launch_bounds__(256) k_heavy_lists(const uint32_t *__restrict_
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     int cls = -1;                                                // -1 nothing to do, 0..3 light class, 4 heavy
     if (s < nheads) {
-        const uint32_t a = heads[s], b = (s + 1 < nheads) ? heads[s + 1] : nhsps, n = b - a;
+        const uint32_t a = heads[s], b = heads[s + 1], n = b - a;
         const uint32_t any = nrow_of[s];                           // (k_heads: the read has a marked HSP)
         if (!any) best_of[s].family = -1;
         else cls = n > MC_FH_MIN ? 4 : MC_LIGHT_CLASS(n);
@@ -1694,7 +1995,7 @@ __global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, 
     if (idx >= nlight[cl]) return;                                // (the reads of one size class that have something to print: k_heavy_lists)
     const uint32_t s = light[(size_t)cl * light_pitch + idx];
     const uint32_t a = heads[s];
-    const uint32_t b = (s + 1 < nheads) ? heads[s + 1] : nhsps;
+    const uint32_t b = heads[s + 1];
     const int n = (int)(b - a);
     const uint32_t read = sorted[a].read;
     McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
@@ -1864,7 +2165,7 @@ __global__ void __launch_bounds__(64) k_heap_lanes(const uint32_t *__restrict__ 
             if (slot < nheavy) {
                 const uint32_t e = heavy_first[slot];
                 if (e & 0x80000000u) {
-                    const uint32_t s = e & 0x7FFFFFFFu, a = heads[s], b = (s + 1 < nheads) ? heads[s + 1] : nhsps;
+                    const uint32_t s = e & 0x7FFFFFFFu, a = heads[s], b = heads[s + 1];
                     n = (int)nrow_of[s];
                     hw = mc_heavy_words(tmp, a, (int)(b - a));
                 }
@@ -1923,7 +2224,7 @@ __global__ void __launch_bounds__(64) k_heavy_rows(const McTables *__restrict__ 
     for (uint32_t slot = blockIdx.x; slot < nheavy; slot += gridDim.x) {
         const uint32_t e = heavy_first[slot];
         if (!(e & 0x80000000u)) continue;                            // (finished by lane 0 of the last wave kernel)
-        const uint32_t s = e & 0x7FFFFFFFu, a = heads[s], b = (s + 1 < nheads) ? heads[s + 1] : nhsps;
+        const uint32_t s = e & 0x7FFFFFFFu, a = heads[s], b = heads[s + 1];
         const int n = (int)(b - a), nrows = (int)nrow_of[s];
         const int read_id = (int)((int64_t)sorted[a].read + first_read_id);
         const uint32_t *hw = mc_heavy_words(tmp, a, n);
@@ -1971,7 +2272,7 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
     for (uint32_t bi = blockIdx.x; bi < nheavy; bi += gridDim.x) {
         MC_FH_TICK(0);
         const uint32_t slot = CTR == C_HEAVY ? bi : list[bi];        // position in the first list (heavy_first): the later lists hold slots
-        const uint32_t s = heavy_first[slot] & 0x7FFFFFFFu, a = heads[s], b = (s + 1 < nheads) ? heads[s + 1] : nhsps;
+        const uint32_t s = heavy_first[slot] & 0x7FFFFFFFu, a = heads[s], b = heads[s + 1];
         const int n = (int)(b - a);
         const McHsp *in = sorted + a;
         const int read_id = (int)((int64_t)in[0].read + first_read_id);
@@ -2183,9 +2484,9 @@ struct McCtx {
     uint8_t *d_frames = nullptr, *d_frames_base = nullptr;   // (64 bytes of room in front: k_eval_seeds reads 8 bytes at a time backwards from a seed)
     unsigned long long *d_stats = nullptr;
     McSeedTask *d_tasks = nullptr; McGapTask *d_gaps = nullptr; McHsp *d_hsps = nullptr, *d_sorted = nullptr, *d_v = nullptr, *d_tmp = nullptr;
-    uint64_t *d_k64 = nullptr, *d_k64o = nullptr, *d_hkeys = nullptr; uint32_t *d_iota = nullptr, *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
+    uint64_t *d_k64 = nullptr, *d_hkeys = nullptr, *d_hplace = nullptr, *d_places = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr, *d_scan = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
     uint32_t *d_counters = nullptr;
-    McRow *d_rows = nullptr; uint32_t *d_nrow = nullptr, *d_rowoff = nullptr; McBestHit *d_best = nullptr, *d_bestof = nullptr; uint8_t *d_mark = nullptr, *d_cand = nullptr;
+    McRow *d_rows = nullptr; uint32_t *d_nrow = nullptr, *d_rowoff = nullptr; McBestHit *d_best = nullptr, *d_bestof = nullptr; uint8_t *d_low = nullptr, *d_cand = nullptr;
     McGapCell *d_gws_full = nullptr; uint32_t *d_retry = nullptr, *d_retry2 = nullptr; int gap_threads_full = 0;
     unsigned long long *d_gtab = nullptr; uint32_t gtab_slots = 0; uint32_t *d_gleader = nullptr; McFlankOut *d_fout = nullptr;
     // pinned host mirrors
@@ -2251,8 +2552,8 @@ extern "C" int mc_device_count(void)
 
 static void ctx_free(McCtx &c)
 {
-    void *ptrs[] = {c.d_frames_base, c.d_tasks, c.d_gaps, c.d_hsps, c.d_sorted, c.d_v, c.d_tmp, c.d_k64, c.d_k64o, c.d_hkeys, c.d_iota, c.d_idx, c.d_idxo, c.d_heads, c.d_sorttmp, c.d_counters, c.d_rows,
-                    c.d_nrow, c.d_rowoff, c.d_best, c.d_bestof, c.d_mark, c.d_cand, c.d_gws_full, c.d_retry, c.d_retry2, c.d_gtab, c.d_gleader, c.d_fout, c.d_stats};
+    void *ptrs[] = {c.d_frames_base, c.d_tasks, c.d_gaps, c.d_hsps, c.d_sorted, c.d_v, c.d_tmp, c.d_k64, c.d_hkeys, c.d_hplace, c.d_places, c.d_idx, c.d_idxo, c.d_heads, c.d_scan, c.d_sorttmp, c.d_counters, c.d_rows,
+                    c.d_nrow, c.d_rowoff, c.d_best, c.d_bestof, c.d_low, c.d_cand, c.d_gws_full, c.d_retry, c.d_retry2, c.d_gtab, c.d_gleader, c.d_fout, c.d_stats};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : {(void *)c.h_c, (void *)c.h_stats, (void *)c.h_best}) if (p) (void)hipHostFree(p);
     for (auto &e : c.ev) if (e) (void)hipEventDestroy(e);
@@ -2441,24 +2742,19 @@ static int ensure_capacity(mc_handle *h, McCtx &c, int64_t nreads)
     c.gap_threads_full = 16 * 1024;                                 // full-size DP rows for the last-resort launch (460 MB)
     if (dalloc(&c.d_frames_base, (size_t)cap * 6 * h->FP + 128) || dalloc(&c.d_tasks, c.cap_tasks) ||
         dalloc(&c.d_gaps, c.cap_gaps) || dalloc(&c.d_hsps, c.cap_hsps) || dalloc(&c.d_sorted, c.cap_hsps) || dalloc(&c.d_v, c.cap_hsps) ||
-        dalloc(&c.d_tmp, (size_t)c.cap_hsps * 2) || dalloc(&c.d_k64, c.cap_hsps) || dalloc(&c.d_k64o, c.cap_hsps) || dalloc(&c.d_hkeys, c.cap_hsps) || dalloc(&c.d_iota, c.cap_hsps) || dalloc(&c.d_idx, c.cap_hsps) ||
-        dalloc(&c.d_idxo, c.cap_hsps) || dalloc(&c.d_heads, (size_t)cap + 1) || dalloc(&c.d_rows, c.cap_rows) ||
-        dalloc(&c.d_mark, (size_t)c.cap_hsps) || dalloc(&c.d_cand, (size_t)cap + 64) || dalloc(&c.d_nrow, (size_t)cap + 1) || dalloc(&c.d_rowoff, (size_t)cap + 1) || dalloc(&c.d_best, (size_t)cap + 1) || dalloc(&c.d_bestof, (size_t)cap + 1) ||
+        dalloc(&c.d_tmp, (size_t)c.cap_hsps * 2) || dalloc(&c.d_k64, c.cap_hsps) || dalloc(&c.d_hkeys, c.cap_hsps) || dalloc(&c.d_hplace, c.cap_hsps) || dalloc(&c.d_places, c.cap_hsps) || dalloc(&c.d_idx, c.cap_hsps) ||
+        dalloc(&c.d_idxo, c.cap_hsps) || dalloc(&c.d_heads, (size_t)cap + 2) || dalloc(&c.d_scan, (size_t)4100) || dalloc(&c.d_rows, c.cap_rows) ||
+        dalloc(&c.d_low, (size_t)cap + 64) || dalloc(&c.d_cand, (size_t)cap + 64) || dalloc(&c.d_nrow, (size_t)cap + 1) || dalloc(&c.d_rowoff, (size_t)cap + 1) || dalloc(&c.d_best, (size_t)cap + 1) || dalloc(&c.d_bestof, (size_t)cap + 1) ||
         dalloc(&c.d_gws_full, (size_t)c.gap_threads_full * MC_GAP_W) || dalloc(&c.d_retry, (size_t)c.cap_gaps * 2 + (size_t)cap + 1) || dalloc(&c.d_retry2, (size_t)c.cap_gaps * 2) || dalloc(&c.d_gleader, (size_t)c.cap_gaps) ||
         dalloc(&c.d_fout, (size_t)c.cap_gaps * 2))
         return -1;
     c.d_frames = c.d_frames_base + 64;
     HIPCK(hipMemsetAsync(c.d_frames_base, MC_INV, 64, c.stream));
-    k_iota<<<dim3((c.cap_hsps + 255) / 256), dim3(256), 0, c.stream>>>(c.d_iota, c.cap_hsps);
     if (c.h_best) { (void)hipHostFree(c.h_best); c.h_best = nullptr; }
     HIPCK(hipHostMalloc((void **)&c.h_best, sizeof(McBestHit) * ((size_t)cap + 1), hipHostMallocDefault));
     c.h_best_cap = (size_t)cap + 1;
-    size_t bytes = 0, bytes2 = 0;
-    HIPCK(rocprim::radix_sort_pairs(nullptr, bytes, c.d_k64, c.d_k64o, c.d_idx, c.d_idxo, (size_t)c.cap_hsps, 0, 64, c.stream));
-    HIPCK(rocprim::exclusive_scan(nullptr, bytes2, c.d_idx, c.d_idxo, 0u, (size_t)c.cap_hsps, rocprim::plus<uint32_t>(), c.stream));
-    bytes = std::max(bytes, bytes2);
-    HIPCK(rocprim::radix_sort_pairs_desc(nullptr, bytes2, c.d_idx, c.d_idxo, c.d_idx, c.d_idxo, (size_t)c.cap_gaps * 2, 0, 10, c.stream));
-    bytes = std::max(bytes, bytes2);
+    size_t bytes = 0;                                               // (the flank list of the gapped stage is ordered by a 10-bit radix sort)
+    HIPCK(rocprim::radix_sort_pairs_desc(nullptr, bytes, c.d_idx, c.d_idxo, c.d_idx, c.d_idxo, (size_t)c.cap_gaps * 2, 0, 10, c.stream));
     if (c.d_sorttmp) { (void)hipFree(c.d_sorttmp); c.d_sorttmp = nullptr; }
     HIPCK(hipMalloc(&c.d_sorttmp, bytes + 16));
     c.sorttmp_bytes = bytes;
@@ -2504,6 +2800,7 @@ static int stage_a(mc_handle *h, McCtx &c)
     HIPCK(hipMemsetAsync(c.d_counters, 0, sizeof(uint32_t) * C_N, st));
     HIPCK(hipMemsetAsync(c.d_stats, 0, sizeof(unsigned long long) * S_N, st));
     if (h->best_only) HIPCK(hipMemsetAsync(c.d_cand, 0, (size_t)n, st));
+    HIPCK(hipMemsetAsync(c.d_low, 0, (size_t)n, st));
     HIPCK(hipEventRecord(c.ev[0], st));
     const int64_t threads = n * 6;
     const size_t lds_rest = (size_t)MC_TS_NLNF(FP) * 8 + (size_t)MC_TS_THREADS * MC_TS_STRIDE(FP);
@@ -2562,7 +2859,7 @@ static int stage_a(mc_handle *h, McCtx &c)
     const size_t lds_ev = (size_t)(MC_EV_BS / 64) * MC_EV_QCAP * 32;   // a queue of survivors per wave: 32 KB per workgroup
     HIPCK(hipFuncSetAttribute((const void *)k_eval_seeds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ev));
     static const unsigned ev_bpc = getenv("MC_EV_BPC") ? (unsigned)std::max(1, std::min(8, atoi(getenv("MC_EV_BPC")))) : (unsigned)MC_EV_BPC;   // (experiments)
-    k_eval_seeds<<<dim3(256u * ev_bpc), dim3(MC_EV_BS), lds_ev, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_tasks, c.d_counters + C_TASKS, c.cap_tasks, c.d_hsps, c.cap_hsps, c.d_gaps, c.cap_gaps, c.d_counters, h->d_P, h->d_fam, h->best_only ? c.d_cand : nullptr, c.d_hkeys);
+    k_eval_seeds<<<dim3(256u * ev_bpc), dim3(MC_EV_BS), lds_ev, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_tasks, c.d_counters + C_TASKS, c.cap_tasks, c.d_hsps, c.cap_hsps, c.d_gaps, c.cap_gaps, c.d_counters, h->d_P, h->d_fam, h->best_only ? c.d_cand : nullptr, c.d_hkeys, c.d_low, c.d_hplace);
     HIPCK(hipEventRecord(c.ev[3], st));
     return counters_to_host(c);
 }
@@ -2601,38 +2898,63 @@ static int stage_b(mc_handle *h, McCtx &c)
                                                                                                                  c.d_counters + C_RETRY, c.d_retry, gap_refill);
         k_gapped_lds<MC_GAP_WIN2, MC_GAP_LANES2><<<dim3(256u * 4u), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry, c.d_counters + C_RETRY, c.d_fout, c.d_counters + C_RETRY2, c.d_retry2, 1);
         k_gapped<<<dim3(c.gap_threads_full / 128), dim3(128), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry2, c.d_counters + C_RETRY2, c.d_fout, c.d_counters, c.d_gws_full, MC_GAP_W);
-        k_gap_emit<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, L, c.d_gaps, ngaps, c.d_gleader, c.d_fout, c.d_hsps, c.cap_hsps, c.d_counters, h->d_P, h->d_fam, h->best_only ? c.d_cand : nullptr, c.d_hkeys);
+        k_gap_emit<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, L, c.d_gaps, ngaps, c.d_gleader, c.d_fout, c.d_hsps, c.cap_hsps, c.d_counters, h->d_P, h->d_fam, h->best_only ? c.d_cand : nullptr, c.d_hkeys, c.d_low, c.d_hplace);
     }
     HIPCK(hipEventRecord(c.ev[4], st));
-    if (h->best_only)                                             // every HSP exists now: the sort keys of the marked reads' HSPs (their count goes to the host with the other counters)
-        k_select_keys<<<dim3(256u * 8u), dim3(256), 0, st>>>(c.d_hkeys, c.d_counters, c.cap_hsps, c.d_cand, c.d_k64, c.d_idx, c.d_counters);
     return counters_to_host(c);
 }
 
-// C: HSPs into (read, subject, hit order); heads of the reads
+// C: HSPs into per-read segments ordered by (subject, hit order); the reads that can print anything (see k_bin_count)
 static int stage_c(mc_handle *h, McCtx &c)
 {
     hipStream_t st = c.stream;
     if (c.h_c[C_OVERFLOW]) { g_err = "HSP buffer overflow"; return -2; }
     const uint32_t nslots = c.h_c[C_HSPS];                         // used slots of the pool, the padding of the waves' last blocks included
     c.nh_all = nslots - c.h_c[C_HPAD];
-    const uint32_t nh = c.nh = h->best_only ? c.h_c[C_HSPS2] : c.nh_all;           // HSPs that are ranked
-    if (nh) {
-        uint32_t *d_flags = c.d_idx, *d_hpos = (uint32_t *)c.d_k64;      // both free once the sort has run
-        size_t bytes = c.sorttmp_bytes;
-        int rbits = 1;
-        while ((1ll << rbits) < c.n) rbits++;
-        // all HSPs: their keys as their kernels wrote them, carrying 0, 1, 2, ...; best hits only: the selected keys and indices
-        // (the keys of the padding are all ones: they sort behind everything and the stages below stop at nh)
-        HIPCK(rocprim::radix_sort_pairs(c.d_sorttmp, bytes, h->best_only ? c.d_k64 : c.d_hkeys, c.d_k64o, h->best_only ? c.d_idx : c.d_iota, c.d_idxo, h->best_only ? (size_t)nh : (size_t)nslots, 0, 43 + rbits, st));
-        k_gather<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(c.d_hsps, c.d_idxo, c.d_k64o, nh, c.d_sorted, d_flags, c.d_mark, h->hT.loge_thr);
-        bytes = c.sorttmp_bytes;
-        HIPCK(rocprim::exclusive_scan(c.d_sorttmp, bytes, d_flags, d_hpos, 0u, (size_t)nh, rocprim::plus<uint32_t>(), st));
-        HIPCK(hipMemsetAsync(c.d_nrow, 0, ((size_t)c.n + 1) * sizeof(uint32_t), st));
-        k_heads<<<dim3((nh + 255) / 256), dim3(256), 0, st>>>(d_flags, d_hpos, c.d_mark, nh, c.d_heads, c.d_nrow, c.d_counters);
+    c.nh = c.nh_all;                                               // (best hits only: the reads that can be classified are selected on the device - cand)
+    if (c.nh) {
+        const uint32_t n = (uint32_t)c.n;
+        const uint8_t *cand = h->best_only ? c.d_cand : nullptr;
+        uint32_t *cur = c.d_heads + 1;                             // heads[0] = 0; cur[r]: counts -> starts -> ends = heads[r + 1]
+        uint64_t *keys = c.d_k64;                                  // (the gapped stage's sort buffers: free again)
+        uint32_t *slots = c.d_idxo, *order = c.d_idx, *heavy = c.d_retry2, *heavy2 = c.d_retry2 + c.cap_gaps;   // (lists of at most n reads: cap_gaps >= 10 n)
+        static const unsigned bin_blocks = getenv("MC_BIN_BLOCKS") ? (unsigned)std::max(1, atoi(getenv("MC_BIN_BLOCKS"))) : 256u * 8u;   // (experiments)
+        static const bool order_serial = getenv("MC_ORDER_SERIAL") != nullptr;                                                              // (experiments: the three order kernels one after the other)
+        HIPCK(hipMemsetAsync(c.d_heads, 0, ((size_t)n + 2) * sizeof(uint32_t), st));
+        HIPCK(hipMemsetAsync(c.d_nrow, 0, ((size_t)n + 1) * sizeof(uint32_t), st));
+        HIPCK(hipMemsetAsync(order, 0xFF, (size_t)nslots * sizeof(uint32_t), st));
+        k_bin_count<<<dim3(bin_blocks), dim3(256), 0, st>>>(c.d_hkeys, c.d_counters, c.cap_hsps, cand, cur);
+        if (mc_scan_u32(cur, n, cur, c.d_scan, st)) return -1;
+        k_bin_scatter<<<dim3(bin_blocks), dim3(256), 0, st>>>(c.d_hkeys, c.d_counters, c.cap_hsps, cand, cur, c.d_hplace, keys, c.d_places, slots);
+        // the long segments beside the short ones (the few segments of more than 512 HSPs are a long tail on a nearly empty GPU)
+        uint32_t *heavy3 = heavy2 + c.cap_gaps / 2;
+        k_order_lists<<<dim3((n + 255) / 256), dim3(256), 0, st>>>(c.d_heads, n, c.d_counters, heavy, heavy2, heavy3);
+        hipStream_t side = order_serial ? st : c.side;
+        if (!order_serial) { HIPCK(hipEventRecord(c.ev_fork, st)); HIPCK(hipStreamWaitEvent(c.side, c.ev_fork, 0)); }
+        HIPCK(hipFuncSetAttribute((const void *)k_order_heavy<1024, MC_ORDER_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * MC_ORDER_LDS * 8)));
+        k_order_heavy<1024, MC_ORDER_LDS><<<dim3(256u), dim3(1024), 2 * MC_ORDER_LDS * 8, side>>>(keys, c.d_places, slots, c.d_heads, heavy3, c.d_counters + C_ORDER3, c.d_counters + C_OTAKE3, c.d_low, order, c.d_nrow, (uint64_t *)c.d_tmp);
+        k_order_heavy<256, MC_ORDER_MID><<<dim3(256u * 4u), dim3(256), 2 * MC_ORDER_MID * 8, side>>>(keys, c.d_places, slots, c.d_heads, heavy2, c.d_counters + C_ORDER2, c.d_counters + C_OTAKE2, c.d_low, order, c.d_nrow, (uint64_t *)c.d_tmp);
+        if (!order_serial) HIPCK(hipEventRecord(c.ev_join, c.side));
+        k_order_light<<<dim3((n + MC_OL_READS - 1) / MC_OL_READS), dim3(256), 0, st>>>(keys, c.d_places, slots, c.d_heads, n, c.d_low, order, c.d_nrow);
+        k_order_heavy<64, MC_ORDER_SMALL><<<dim3(256u * 16u), dim3(64), 2 * MC_ORDER_SMALL * 8, st>>>(keys, c.d_places, slots, c.d_heads, heavy, c.d_counters + C_ORDER, c.d_counters + C_OTAKE, c.d_low, order, c.d_nrow, (uint64_t *)c.d_tmp);
+        if (!order_serial) HIPCK(hipStreamWaitEvent(st, c.ev_join, 0));
+        k_order_copy<<<dim3(256u * 8u), dim3(256), 0, st>>>(order, c.d_hsps, c.d_heads, n, c.d_sorted);
+        if (getenv("MC_BIN_STATS")) {                                  // (development aid: the sizes of the segments)
+            std::vector<uint32_t> hh((size_t)n + 1);
+            HIPCK(hipStreamSynchronize(st));
+            HIPCK(hipMemcpy(hh.data(), c.d_heads, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+            const uint32_t lim[9] = {16, 32, 64, 128, 512, 2048, 8192, 32768, 0xFFFFFFFFu};
+            uint64_t cnt[9] = {0}, sum[9] = {0};
+            std::vector<uint32_t> top;
+            for (uint32_t r = 0; r < n; r++) { const uint32_t k = hh[r + 1] - hh[r]; if (!k) continue; for (int b = 0; b < 9; b++) if (k <= lim[b]) { cnt[b]++; sum[b] += k; break; } if (k > 2048) top.push_back(k); }
+            std::sort(top.rbegin(), top.rend());
+            fprintf(stderr, "bin-stats segments <=16 32 64 128 512 2048 8192 32768 more: reads"); for (int b = 0; b < 9; b++) fprintf(stderr, " %llu", (unsigned long long)cnt[b]);
+            fprintf(stderr, "; HSPs"); for (int b = 0; b < 9; b++) fprintf(stderr, " %llu", (unsigned long long)sum[b]);
+            fprintf(stderr, "; largest:"); for (size_t i = 0; i < top.size() && i < 12; i++) fprintf(stderr, " %u", top[i]); fprintf(stderr, "\n");
+        }
     }
     HIPCK(hipEventRecord(c.ev[5], st));
-    return counters_to_host(c);
+    return 0;
 }
 
 // D: per-read finishing (linking, ranking, cap, classification), rows into m8 order
@@ -2640,14 +2962,14 @@ static int stage_d(mc_handle *h, McCtx &c)
 {
     hipStream_t st = c.stream;
     McIndex X = dev_index(h);
-    const uint32_t nh = c.nh, nheads = c.nheads = nh ? c.h_c[C_HEADS] : 0u;
+    const uint32_t nh = c.nh, nheads = c.nheads = nh ? (uint32_t)c.n : 0u;   // (every read has a segment, most of them empty or unmarked)
     if (nh) {
         // the thread-per-read kernel (reads with few HSPs) on this stream, the wave-per-read kernels one after the other on a
         // second one (each hands the reads its LDS arrays cannot hold to the next)
         uint32_t *d_heavy = c.d_retry, *d_heavy2 = c.d_retry + c.cap_gaps / 2, *d_heavy3 = c.d_retry + c.cap_gaps;      // (d_retry is free again: the gap tasks are done)
         uint32_t *d_light = c.d_retry + c.cap_gaps + c.cap_gaps / 2;
         const uint32_t light_pitch = (uint32_t)c.cap_reads + 1;
-        k_heavy_lists<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(c.d_heads, nheads, nh, c.d_mark, c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_light, light_pitch);
+        k_heavy_lists<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(c.d_heads, nheads, nh, nullptr, c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_light, light_pitch);
         HIPCK(hipEventRecord(c.ev_fork, st));
         {
             const size_t l1 = (size_t)MC_FH_N1 * 16 + 3 * (size_t)(MC_FH_N1 + 2) * 2, l2 = (size_t)MC_FH_N2 * 16 + 3 * (size_t)(MC_FH_N2 + 2) * 2, l3 = (size_t)MC_FH_N3 * 16 + 3 * (size_t)(MC_FH_N3 + 2) * 2;
@@ -2670,8 +2992,7 @@ static int stage_d(mc_handle *h, McCtx &c)
         k_finish<<<dim3((nheads + 255) / 256, 4), dim3(256), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, c.d_sorted, nh, c.d_heads, nheads, c.d_v, c.d_tmp,
                                                                        c.first_read_id, c.d_nrow, c.d_bestof, d_light, light_pitch, c.d_counters + C_LIGHT0);
         HIPCK(hipStreamWaitEvent(st, c.ev_join, 0));
-        size_t bytes = c.sorttmp_bytes;
-        HIPCK(rocprim::exclusive_scan(c.d_sorttmp, bytes, c.d_nrow, c.d_rowoff, 0u, (size_t)nheads, rocprim::plus<uint32_t>(), st));
+        if (mc_scan_u32(c.d_nrow, nheads, c.d_rowoff, c.d_scan, st)) return -1;
         if (h->rows_ever) HIPCK(hipStreamWaitEvent(st, h->ev_rows, 0));   // (the rows of the run before may still be leaving d_rows)
         k_emit_rows<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(c.d_heads, nheads, c.d_nrow, c.d_rowoff, c.d_tmp, c.d_rows, c.cap_rows, c.d_bestof, c.d_best, c.d_counters, h->best_only ? 0 : 1);
     }
@@ -2788,8 +3109,7 @@ static int run_range_once(mc_handle *h, int64_t first, int64_t count, int64_t fi
 #define MC_ALL(stmt) for (int p = 0; p < np && rc == 0; p++) { McCtx &c = h->ctx[p]; stmt; }
     MC_ALL(rc = stage_a(h, c))
     MC_ALL(if ((rc = stage_wait(c)) == 0) rc = stage_b(h, c))
-    MC_ALL(if ((rc = stage_wait(c)) == 0) rc = stage_c(h, c))
-    MC_ALL(if ((rc = stage_wait(c)) == 0) rc = stage_d(h, c))
+    MC_ALL(if ((rc = stage_wait(c)) == 0 && (rc = stage_c(h, c)) == 0) rc = stage_d(h, c))   // (C leaves its counts on the device: D is issued behind it)
     // E, part by part: as soon as a part's finishing is done its rows start travelling, while the next part is still finishing
     size_t nrows = 0;
     for (int p = 0; p < np && rc == 0; p++) {

@@ -337,9 +337,9 @@ struct Spec {
                 c.ends.push_back(me);
                 t += 8;
                 while (t < end && *t == 0) t++;                          // (zero padding between / behind members)
-                const long h = t < end ? member_header(t, end) : 0;
-                if (t >= end || h == 0) { c.end_bit = (uint64_t)(end - base) * 8; c.at_eof = true; break; }      // end of the data (bytes that are no member are ignored, as zlib does)
-                if (h < 0) return false;
+                if (t >= end) { c.end_bit = (uint64_t)(end - base) * 8; c.at_eof = true; break; }                // end of the data
+                const long h = member_header(t, end);
+                if (h <= 0) return false;                                // (bytes that are no member: gzip.open raises BadGzipFile there - the sequential path reports it)
                 br.init(base, end, (uint64_t)(t + h - base) * 8);
                 mstart = (long)pos;
             }
@@ -434,8 +434,11 @@ inline void decode_known(const uint8_t *base, const uint8_t *end, uint64_t bit, 
             c.ends.push_back(me);
             t += 8;
             while (t < end && *t == 0) t++;
-            const long h = t < end ? member_header(t, end) : 0;
-            if (t >= end || h == 0) { c.end_bit = (uint64_t)(end - base) * 8; c.at_eof = true; break; }
+            if (t >= end) { c.end_bit = (uint64_t)(end - base) * 8; c.at_eof = true; break; }
+            const long h = member_header(t, end);
+            // non-zero bytes behind a member that are no member header: gzip.open raises BadGzipFile("Not a gzipped file") when it gets
+            // there (GzipFile._read_gzip_header), after the zero padding _read_eof skips - what was decoded so far is delivered first
+            if (h == 0) { c.bad = true; c.msg = "Not a gzipped file: bytes behind the last member"; c.end_bit = (uint64_t)(end - base) * 8; break; }
             if (h < 0) { c.bad = true; c.msg = "compressed file ended before the end-of-stream marker was reached"; break; }
             bit = (uint64_t)(t + h - base) * 8;
             window_n = 0;
@@ -445,6 +448,71 @@ inline void decode_known(const uint8_t *base, const uint8_t *end, uint64_t bit, 
     out.resize(pos);
     c.have_bytes = true;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// One inflate stream over the mapped file, with gzip.open's rules for what lies between and behind the members (GzipFile._read_eof /
+// _read_gzip_header): zero padding is skipped, another member goes on, anything else is BadGzipFile - zlib's gzread stops at zero
+// padding and ignores other bytes.  Used where one thread is allowed (-t 1) and for the quality-offset peek; ParallelGz follows
+// the same rules.
+// ------------------------------------------------------------------------------------------------------------------
+class SerialGz {
+public:
+    SerialGz(const uint8_t *data, size_t n) : p_(data), end_(data + n) { memset(&z_, 0, sizeof z_); }
+    ~SerialGz() { if (init_) inflateEnd(&z_); }
+    bool start()
+    {
+        const long h = member_header(p_, end_);
+        if (h <= 0 || inflateInit2(&z_, -15) != Z_OK) return false;
+        init_ = true; p_ += h; in_member_ = true;
+        return true;
+    }
+    // like a file read: < n only at the end of the data; bad: the file is truncated / damaged behind what was delivered
+    int read(uint8_t *dst, int n, bool *bad, std::string *msg)
+    {
+        int got = 0;
+        *bad = false;
+        while (got < n && !done_) {
+            if (!in_member_) {
+                while (p_ < end_ && *p_ == 0) p_++;
+                if (p_ >= end_) { done_ = true; break; }
+                const long h = member_header(p_, end_);
+                if (h == 0) { fail("Not a gzipped file: bytes behind the last member"); break; }
+                if (h < 0) { fail("compressed file ended before the end-of-stream marker was reached"); break; }
+                p_ += h;
+                inflateReset(&z_);
+                crc_ = 0; isize_ = 0; in_member_ = true;
+            }
+            z_.next_in = (Bytef *)p_;
+            z_.avail_in = (uInt)std::min<size_t>((size_t)(end_ - p_), 1u << 30);
+            z_.next_out = dst + got;
+            z_.avail_out = (uInt)(n - got);
+            const int rc = inflate(&z_, Z_NO_FLUSH);
+            const int made = (int)(z_.next_out - (dst + got));
+            crc_ = (uint32_t)crc32(crc_, dst + got, (uInt)made);
+            isize_ += (uint32_t)made;
+            got += made;
+            p_ = z_.next_in;
+            if (rc == Z_STREAM_END) {
+                if (end_ - p_ < 8) { fail("compressed file ended before the end-of-stream marker was reached"); break; }
+                const uint32_t crc = (uint32_t)p_[0] | ((uint32_t)p_[1] << 8) | ((uint32_t)p_[2] << 16) | ((uint32_t)p_[3] << 24);
+                const uint32_t isz = (uint32_t)p_[4] | ((uint32_t)p_[5] << 8) | ((uint32_t)p_[6] << 16) | ((uint32_t)p_[7] << 24);
+                if (crc != crc_) { fail("CRC check failed"); break; }
+                if (isz != isize_) { fail("Incorrect length of data produced"); break; }
+                p_ += 8; in_member_ = false;
+            } else if (rc != Z_OK && rc != Z_BUF_ERROR) { fail(z_.msg ? z_.msg : "invalid deflate data"); break; }
+            else if (made == 0 && p_ >= end_) { fail("compressed file ended before the end-of-stream marker was reached"); break; }
+        }
+        if (failed_) { *bad = true; *msg = err_; }
+        return got;
+    }
+private:
+    void fail(const char *m) { failed_ = true; done_ = true; err_ = m; }
+    const uint8_t *p_, *end_;
+    z_stream z_;
+    bool init_ = false, in_member_ = false, done_ = false, failed_ = false;
+    uint32_t crc_ = 0, isize_ = 0;
+    std::string err_;
+};
 
 // ------------------------------------------------------------------------------------------------------------------
 // the reader: read() delivers the decompressed bytes in order

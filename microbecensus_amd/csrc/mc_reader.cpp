@@ -215,6 +215,7 @@ struct Stream {
     // compressed stream: a producer thread inflates BLK-sized blocks into a ring; the window lives in `buf`
     gzFile gz = nullptr; Bz2File *bz = nullptr;
     mcgz::ParallelGz *pgz = nullptr; const uint8_t *gzmap = nullptr; size_t gzmap_n = 0;   // a regular .gz file: mapped and inflated in parallel (mc_pgzip.h)
+    mcgz::SerialGz *sgz = nullptr;                                                          // ... or by one stream (one thread allowed; the quality-offset peek)
     std::thread th;
     std::mutex mu; std::condition_variable cv;
     std::vector<uint8_t> ring[NBLK]; size_t ring_n[NBLK] = {};
@@ -270,6 +271,21 @@ struct Stream {
                     gzbuffer(gz, 1 << 20);
                 }
                 compressed = true;
+            } else if (has_ext(path, ".gz") && reg && is_gz) {           // one thread allowed, or the quality-offset peek: one inflate stream, gzip.open's rules between the members
+                gzmap_n = (size_t)sb.st_size;
+                void *m = mmap(nullptr, gzmap_n, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m == MAP_FAILED) { ::close(fd); r_err = std::string("cannot map ") + path; return false; }
+                madvise(m, gzmap_n, MADV_SEQUENTIAL);
+                gzmap = (const uint8_t *)m;
+                sgz = new mcgz::SerialGz(gzmap, gzmap_n);
+                if (sgz->start()) ::close(fd);
+                else {                                                   // (a header it does not take: zlib's reader decides)
+                    delete sgz; sgz = nullptr; munmap(m, gzmap_n); gzmap = nullptr;
+                    gz = gzdopen(fd, "rb");
+                    if (!gz) { ::close(fd); r_err = std::string("cannot open ") + path; return false; }
+                    gzbuffer(gz, 1 << 20);
+                }
+                compressed = true;
             } else if (has_ext(path, ".gz") || !reg) {                   // (anything that is not a regular file - a pipe - is read through zlib, which passes plain bytes on)
                 gz = gzdopen(fd, "rb");
                 if (!gz) { ::close(fd); r_err = std::string("cannot open ") + path; return false; }
@@ -303,6 +319,7 @@ struct Stream {
             th.join();
         }
         if (pgz) { delete pgz; pgz = nullptr; }
+        if (sgz) { delete sgz; sgz = nullptr; }
         if (gzmap) { munmap((void *)gzmap, gzmap_n); gzmap = nullptr; }
         if (gz) { gzclose(gz); gz = nullptr; }
         if (bz) { bz->close(); delete bz; bz = nullptr; }
@@ -328,6 +345,8 @@ struct Stream {
             if (peek_blocks > 0) peek_blocks--;
             if (pgz) {
                 n = pgz->read(ring[slot].data(), want, &bad, &msg);
+            } else if (sgz) {
+                n = sgz->read(ring[slot].data(), want, &bad, &msg);
             } else if (gz) {
                 n = gzread(gz, ring[slot].data(), (unsigned)want);
                 if (n < want) {

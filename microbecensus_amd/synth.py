@@ -109,6 +109,30 @@ def sample_reads(genome, nreads, read_len, seed=1, chunk=1 << 20):
     return out
 
 
+def random_proteins(total_residues, seed=20261003, marker_seqs=None, lo=100, hi=600):
+    """A protein database of random ORFs with the marker proteins' amino-acid composition: (names, seqs).  6.5 M residues fill more
+    than half of the 10^6 reduced-alphabet 6-mer buckets, so the database's `.info` threshold (median bucket size) is above 0 and
+    RAPsearch2 lengthens the seeds of frequent buckets by letter frequency (`Searching 0x415ec0-0x415f71`): the generic seed
+    path, which the marker database (threshold 0) never takes."""
+    rng = Counter(seed)
+    comp = np.zeros(20)
+    if marker_seqs is None:
+        comp[:] = [8.6, 5.9, 3.9, 5.4, 0.9, 3.6, 6.9, 7.6, 2.1, 6.6, 9.3, 6.3, 2.5, 3.7, 4.3, 5.6, 5.4, 1.0, 2.9, 7.5]
+    else:
+        sample = "".join(marker_seqs[:: max(1, len(marker_seqs) // 500)])
+        for i, a in enumerate(AA):
+            comp[i] = sample.count(a)
+    cdf = np.cumsum(comp / comp.sum())
+    aa = np.frombuffer(AA.encode(), dtype=np.uint8)
+    names, seqs, n = [], [], 0
+    while n < total_residues:
+        ln = lo + int(rng.integers(1, hi - lo)[0])
+        seqs.append(aa[np.minimum(19, np.searchsorted(cdf, rng.uniform(ln)))].tobytes().decode())
+        names.append("orf%06d" % len(names))
+        n += ln
+    return names, seqs
+
+
 def mutate_reads(reads, read_len, sub_rate=0.02, indel_rate=0.005, seed=1):
     """Sequencing-error model for parity tests: every base of `reads` (n x >= read_len + slack, error free) is substituted by
     one of the other three with probability sub_rate, deleted with probability indel_rate / 2, or followed by a random inserted

@@ -294,6 +294,31 @@ int main(int argc, char **argv)
     // stage 5: sort by (read, subject, chrono)
     std::sort(hsps.begin(), hsps.end(), [](const McHsp &a, const McHsp &b) { if (a.read != b.read) return a.read < b.read; if (a.sidx != b.sidx) return a.sidx < b.sidx; return a.chrono < b.chrono; });
     fprintf(stderr, "hsps kept: %zu\n", hsps.size());
+    if (getenv("MC_HSP_STATS")) {   // how many reads could print anything at all, by criteria that need no sorted order (design aid for the HSP binning)
+        long reads = 0, with_low = 0, with_pair = 0, with_diff = 0, with_rows_possible = 0, h_all = 0, h_low = 0, h_pair = 0, h_diff = 0, dup = 0;
+        for (size_t a = 0; a < hsps.size();) {
+            size_t b = a; while (b < hsps.size() && hsps[b].read == hsps[a].read) b++;
+            bool low = false, pair = false, diff = false;
+            for (size_t i = a; i < b; i++) {
+                if (hsps[i].loge < T.loge_thr) low = true;
+                if (i > a && hsps[i].sidx == hsps[i - 1].sidx) {
+                    pair = true;
+                    const McHsp &p = hsps[i - 1], &h = hsps[i];
+                    if (!(p.frame == h.frame && p.qaas == h.qaas && p.ds == h.ds && p.qaae == h.qaae && p.de == h.de)) diff = true; else dup++;
+                }
+            }
+            { const long n = (long)(b - a); static long hist[8]; static long hh[8]; const long lim[8] = {16, 32, 64, 128, 512, 2048, 8192, 1L << 40};
+              for (int k = 0; k < 8; k++) if (n <= lim[k]) { hist[k]++; hh[k] += n; break; }
+              if (b == hsps.size()) { fprintf(stderr, "hsp-stats segment sizes (<=16, 32, 64, 128, 512, 2048, 8192, more): reads"); for (int k = 0; k < 8; k++) fprintf(stderr, " %ld", hist[k]); fprintf(stderr, "; HSPs"); for (int k = 0; k < 8; k++) fprintf(stderr, " %ld", hh[k]); fprintf(stderr, "\n"); } }
+            reads++; h_all += (long)(b - a);
+            if (low) { with_low++; h_low += (long)(b - a); }
+            if (low || pair) { with_pair++; h_pair += (long)(b - a); }
+            if (low || diff) { with_diff++; h_diff += (long)(b - a); }
+            a = b;
+        }
+        fprintf(stderr, "hsp-stats reads with HSPs %ld (HSPs %ld, duplicates of the HSP in front %ld); with an HSP below the threshold %ld (their HSPs %ld); ... or two HSPs on one subject %ld (%ld); ... or two DIFFERENT HSPs on one subject %ld (%ld)\n",
+                reads, h_all, dup, with_low, h_low, with_pair, h_pair, with_diff, h_diff);
+    }
     // stage 6: per-read finishing
     FILE *o = fopen(argv[3], "w");
     std::vector<McHsp> v, tmp; std::vector<McRow> rows(MC_MAX_M8); std::vector<double> kr(MC_MAX_M8); std::vector<McSortItem> items;

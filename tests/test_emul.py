@@ -52,6 +52,21 @@ def test_device_code_on_dirty_reads(emul_bin, markers_faa, tmp_path):
     assert hashlib.md5(out.read_bytes()).hexdigest() == meta["m8_md5"]
 
 
+def test_device_code_on_a_database_with_a_seed_threshold(emul_bin, tmp_path):
+    """The generic seed enumeration (mc_enumerate_seeds: seeds of 6 .. 9 residues) and the evaluation of short seeds on the second
+    database (`.info` threshold 1, tests/golden/make_generic_db_golden.py): the reference's m8."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import make_generic_db_golden as G
+    meta = json.load(open(os.path.join(GOLD, "generic_db.json")))
+    names, seqs, reads = G.case_inputs()
+    (tmp_path / "db2.faa").write_bytes(G.fasta_bytes(names, seqs))
+    (tmp_path / "reads.fa").write_bytes(b"".join(b">%d\n%s\n" % (i, bytes(r)) for i, r in enumerate(reads)))
+    out = tmp_path / "out.m8"
+    subprocess.check_call([emul_bin, str(tmp_path / "db2.faa"), str(tmp_path / "reads.fa"), str(out)], stderr=subprocess.DEVNULL)
+    assert hashlib.md5(out.read_bytes()).hexdigest() == meta["m8_md5"]
+
+
 def test_index_builder_matches_prerapsearch(emul_bin, markers_faa, ref_dir, tmp_path):
     """Bucket starts, posting order, suffix keys, residue codes, frequency threshold and letter frequencies of
     the product's index builder against the database prerapsearch wrote (oracle/_ref/rapdb_2.15[.info])."""

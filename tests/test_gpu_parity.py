@@ -105,6 +105,35 @@ def test_dirty_reads_identical_to_reference(staged, tmp_path):
         assert res[form] == [meta["m8_rows"], meta["m8_md5"]], form
 
 
+def test_generic_seed_path_on_a_database_with_a_seed_threshold(tmp_path):
+    """A second database whose `.info` threshold is 1 (6.5 M residues of random ORFs; golden from the reference's prerapsearch +
+    rapsearch, tests/golden/make_generic_db_golden.py): mc_open() turns the position-parallel seed kernel off (it is exact only
+    at threshold 0) and k_enumerate emits seeds of 6 .. 9 residues, which k_eval_seeds grows residue by residue
+    (`Searching 0x4153a3-0x4153ce`, `0x415ec0-0x415f71`).  Through mc_open (FASTA) and mc_open_rapdb (the file mc_rapdb_write wrote)."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import make_generic_db_golden as G
+    from microbecensus_amd import _native
+    meta = json.load(open(os.path.join(GOLD, "generic_db.json")))
+    names, seqs, reads = G.case_inputs()
+    assert hashlib.md5(b"".join(b">%d\n%s\n" % (i, bytes(r)) for i, r in enumerate(reads))).hexdigest() == meta["reads_md5"]
+    db = str(tmp_path / "db2")
+    _native.rapdb_write(names, seqs, db)
+    out = str(tmp_path / "out.m8")
+    for how in ("fasta", "rapdb"):
+        eng = _native.Engine(device=0, names=names, seqs=seqs, marker_family=[0] * len(names), nfam=1) if how == "fasta" else _native.Engine.from_rapdb(db, device=0, family_of={n: "all" for n in names}, families=["all"])
+        try:
+            eng.set_run(meta["read_length"])
+            rows, _ = eng.search(reads)
+            eng.write_m8(out)
+            st = eng.stats()
+        finally:
+            eng.close()
+        print(how, st)
+        assert len(rows) == meta["m8_rows"] and hashlib.md5(open(out, "rb").read()).hexdigest() == meta["m8_md5"], how
+        assert st["bucket_lookups"] > 0                  # (the generic kernel counts the reference algorithm's index reads: it is the one that ran)
+
+
 def test_the_product_library_is_the_one_loaded():
     """The GPU tests must exercise microbecensus_amd/libmcensus_hip.so itself: no MCENSUS_LIB override in the environment, and
     the library mapped into this process is the in-tree one."""

@@ -86,3 +86,37 @@ def test_oracle_on_dirty_reads(oracle_bin, ref_dir, tmp_path):
     got = open(out, "rb").read()
     assert got.count(b"\n") == meta["m8_rows"] and hashlib.md5(got).hexdigest() == meta["m8_md5"]
     assert got == gzip.open(os.path.join(GOLD, "dirty_reads.m8.gz"), "rb").read()
+
+
+@pytest.fixture(scope="session")
+def generic_db(tmp_path_factory):
+    """The second database (random ORFs; `.info` threshold 1, tests/golden/make_generic_db_golden.py): FASTA, rapdb written by
+    mc_rapdb_write (byte-identical to prerapsearch's, checked when the golden was made and again by md5 here) and the reads."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import make_generic_db_golden as G
+    from microbecensus_amd import _native
+    meta = json.load(open(os.path.join(GOLD, "generic_db.json")))
+    names, seqs, reads = G.case_inputs()
+    d = tmp_path_factory.mktemp("db2")
+    faa = G.fasta_bytes(names, seqs)
+    assert hashlib.md5(faa).hexdigest() == meta["faa_md5"]
+    (d / "db2.faa").write_bytes(faa)
+    _native.rapdb_write(names, seqs, str(d / "db2"))
+    assert hashlib.md5((d / "db2").read_bytes()).hexdigest() == meta["rapdb_md5"]
+    rfa = b"".join(b">%d\n%s\n" % (i, bytes(r)) for i, r in enumerate(reads))
+    assert hashlib.md5(rfa).hexdigest() == meta["reads_md5"]
+    (d / "reads.fa").write_bytes(rfa)
+    return {"dir": d, "meta": meta, "names": names, "seqs": seqs, "reads": reads}
+
+
+def test_oracle_on_a_database_with_a_seed_threshold(generic_db, oracle_bin, tmp_path):
+    """`.info` threshold 1: seed lengths 6 .. 9 chosen by bucket size and letter frequencies (`Searching 0x4153a3-0x4153ce`,
+    `0x415ec0-0x415f71`) - the branch the marker database never takes.  Golden from the reference's rapsearch on a database its
+    prerapsearch built."""
+    out = str(tmp_path / "out.m8")
+    d, meta = generic_db["dir"], generic_db["meta"]
+    assert meta["info_threshold"] > 0
+    subprocess.check_call([oracle_bin, str(d / "db2"), str(d / "reads.fa"), out])
+    got = open(out, "rb").read()
+    assert got.count(b"\n") == meta["m8_rows"] and hashlib.md5(got).hexdigest() == meta["m8_md5"]

@@ -306,6 +306,44 @@ def test_parallel_gzip_equals_gzip_module(tmp_path, monkeypatch, chunk):
     del want_bases
 
 
+@pytest.mark.parametrize("serial", [False, True], ids=["parallel_inflate", "one_stream"])
+def test_gzip_padding_and_trailing_bytes_as_gzip_open(tmp_path, monkeypatch, serial):
+    """What may lie between and behind gzip members (GzipFile._read_eof / _read_gzip_header, behind the reference's open_file
+    :47-59): zero padding is skipped and the next member read; other bytes raise BadGzipFile once the reader gets there - so
+    run_pipeline fails if the sampler needs them and does not if it stops earlier.  Both native codecs (zlib's own gzread stops at
+    zero padding and ignores other bytes)."""
+    import gzip
+    from microbecensus_amd import _native
+    monkeypatch.setenv("MC_READER_GZ_CHUNK", "20000")
+    if serial:
+        monkeypatch.setenv("MC_READER_SERIAL_GZ", "1")
+    text = _fastq_text(3000, 11)
+    cut = text.index(b"@r1500 ")
+    a, b = gzip.compress(text[:cut], 6), gzip.compress(text[cut:], 6)
+    want, st_want = None, None
+    for name, blob in (("plain", a + b), ("zeros_between", a + b"\0" * 5 + b), ("zeros_behind", a + b + b"\0" * 700)):
+        p = str(tmp_path / (name + ".fq.gz"))
+        open(p, "wb").write(blob)
+        assert gzip.open(p).read() == text
+        got, st = _native.sample_reads([p], 100, 1000000, True, 32, -5, -5, 100, False)
+        if want is None:
+            want, st_want = got, st
+        assert st == st_want and (got == want).all(), name
+        assert st["exhausted"] == 1
+    for name, blob in (("garbage_behind", a + b + b"tail"), ("garbage_behind_zeros", a + b + b"\0\0\0x"), ("garbage_between", a + b"junk" + b)):
+        p = str(tmp_path / (name + ".fq.gz"))
+        open(p, "wb").write(blob)
+        with pytest.raises(gzip.BadGzipFile):
+            gzip.open(p).read()
+        with pytest.raises(_native.ReferenceError_):
+            _native.count_bases([p])
+        with pytest.raises(_native.ReferenceError_):
+            _native.sample_reads([p], 100, 1000000, True, 32, -5, -5, 100, False)
+        # a sampler that has its reads before it gets there never sees the damage (the reference's head-take)
+        got, st = _native.sample_reads([p], 100, 200, True, 32, -5, -5, 100, False)
+        assert st["sampled"] == 200 and (got == want[:200]).all(), name
+
+
 def test_streaming_fetch_equals_run(tmp_path):
     """mc_reader_start / fetch / join hand out the same reads mc_reader_run collects."""
     import ctypes as C
