@@ -93,55 +93,90 @@ MC_HDN double mc_sum_expect(const McTables &T, int n, const double *scores, int 
 
 // CHashSearch::SumEvalue@0x408a50 on v[st, ed); returns the new end (the range may shrink).
 // tmp must hold 2*(ed-st) entries.
+// The reference sorts the subject's HSPs three times (std::sort by frame, per strand std::sort by start and std::stable_sort by
+// log E) and picks a consistent chain.  All of that depends on five small integers per HSP, so it runs on one 64-bit word per HSP
+// (frame | start | end | score | position) - the sequence of comparisons and moves of the sorts depends on the keys only - and the
+// 48-byte records are moved once at the end (a thread walks global memory alone here: sorting the records themselves was the
+// thread-per-read kernel's time).  log E of a single HSP is the table value of its score: a < b in log E <=> a > b in score.
+struct McLinkItem { uint64_t w; };
+#define MC_LK_IDX(x) ((int)((x).w & 0xFFFFFu))                 // position in the subject's stack (20 bits)
+#define MC_LK_SCORE(x) ((int)(((x).w >> 20) & 0xFFFFu))
+#define MC_LK_QAAE(x) ((int)(((x).w >> 36) & 0xFFu))
+#define MC_LK_QAAS(x) ((int)(((x).w >> 44) & 0xFFu))
+#define MC_LK_FRAME(x) ((int)(((x).w >> 52) & 0xFu))             // (bits 62, 63: the HSP carries the log E of its strand's chain)
+MC_HD bool mc_hless(const McLinkItem &a, const McLinkItem &b, int key) { return key == 1 ? MC_LK_FRAME(a) < MC_LK_FRAME(b) : MC_LK_QAAS(a) < MC_LK_QAAS(b); }
 MC_HDN int mc_sum_evalue(const McTables &T, McHsp *v, int st, int ed, int subj_len, McHsp *tmp)
 {
     McHsp *a = v + st;
-    int n = ed - st, part, nres = 0;
+    const int n = ed - st;
+    int part, nres = 0;
     MC_FG_BEGIN;
-    mc_std_sort(a, n, 1);
+    // tmp: n records (the copy the result is gathered from), behind them three arrays of n words
+    McLinkItem *it = (McLinkItem *)(tmp + n), *res = it + n, *chosen = res + n;
+    for (int i = 0; i < n; i++) it[i].w = ((uint64_t)((uint16_t)a[i].frame & 0xFu) << 52) | ((uint64_t)(uint8_t)a[i].qaas << 44) | ((uint64_t)(uint8_t)a[i].qaae << 36) | ((uint64_t)(uint16_t)a[i].score << 20) | (uint64_t)i;
+    mc_std_sort(it, n, 1);
     MC_FG_TICK(1);
-    for (part = 0; part < n && !(a[part].frame > 2); part++) {}
-    if ((n - part) <= 1 && part <= 1) return ed;
-    McHsp *res = tmp, *chosen = tmp + n;
-    for (int pass = 0; pass < 2; pass++) {
-        McHsp *g = pass ? a + part : a;
-        int gn = pass ? n - part : part, nc = 0;
-        if (gn == 0) continue;
-        if (gn == 1) { if (T.loge_thr > g[0].loge) res[nres++] = g[0]; continue; }
-        MC_FG_TICK(5);
-        mc_std_sort(g, gn, 2);
-        mc_stable_sort_loge(g, gn);
-        MC_FG_TICK(2);
-        chosen[nc++] = g[0];
-        for (int i = 1; i < gn; i++) {
-            const McHsp &e = g[i];
-            int ov = (e.qaae + 1 - e.qaas) >> 1;
-            bool ok = true;
-            if (ov > 10) ov = 10;
-            if (e.loge >= 1.0 && !(e.score > 30)) continue;
-            for (int j = 0; j < nc; j++) {
-                const McHsp &c = chosen[j];
-                if (e.qaas <= c.qaae - ov) { if (e.qaae >= c.qaas + ov) { ok = false; break; } }
-                if (e.qaae - ov < c.qaas) continue;
-                if (c.qaae >= ov + e.qaas) { ok = false; break; }
+    for (part = 0; part < n && !(MC_LK_FRAME(it[part]) > 2); part++) {}
+    double le_pass[2] = {0.0, 0.0};
+    const bool link = !((n - part) <= 1 && part <= 1);
+    if (link)
+        for (int pass = 0; pass < 2; pass++) {
+            McLinkItem *g = pass ? it + part : it;
+            int gn = pass ? n - part : part, nc = 0;
+            if (gn == 0) continue;
+            if (gn == 1) { if (T.loge_thr > T.loge_r[MC_LK_SCORE(g[0])]) res[nres++] = g[0]; continue; }
+            MC_FG_TICK(5);
+            mc_std_sort(g, gn, 2);
+            for (long i = 1; i < gn; ++i) {   // std::stable_sort(CompEvalueObj): any stable sort produces the same permutation
+                const McLinkItem val = g[i]; long j = i;
+                while (j > 0 && MC_LK_SCORE(val) > MC_LK_SCORE(g[j - 1])) { g[j] = g[j - 1]; --j; }
+                g[j] = val;
             }
-            if (ok) chosen[nc++] = e;
+            MC_FG_TICK(2);
+            chosen[nc++] = g[0];
+            for (int i = 1; i < gn; i++) {
+                const McLinkItem e = g[i];
+                const int es = MC_LK_QAAS(e), ee = MC_LK_QAAE(e);
+                int ov = (ee + 1 - es) >> 1;
+                bool ok = true;
+                if (ov > 10) ov = 10;
+                if (T.loge_r[MC_LK_SCORE(e)] >= 1.0 && !(MC_LK_SCORE(e) > 30)) continue;
+                for (int j = 0; j < nc; j++) {
+                    const int cs = MC_LK_QAAS(chosen[j]), ce = MC_LK_QAAE(chosen[j]);
+                    if (es <= ce - ov) { if (ee >= cs + ov) { ok = false; break; } }
+                    if (ee - ov < cs) continue;
+                    if (ce >= ov + es) { ok = false; break; }
+                }
+                if (ok) chosen[nc++] = e;
+            }
+            MC_FG_TICK(3);
+            if (nc == 1) { if (T.loge_thr > T.loge_r[MC_LK_SCORE(chosen[0])]) res[nres++] = chosen[0]; }
+            else {
+                double sc[5];
+                int k = nc < 5 ? nc : 5;
+                for (int i = 0; i < k; i++) sc[i] = (double)MC_LK_SCORE(chosen[i]);
+                double E = mc_sum_expect(T, k, sc, subj_len);
+                double le = (E == 0.0) ? -10000.0 : log(E) / 2.302585092994046;
+                le_pass[pass] = le;
+                if (T.loge_thr > le) for (int i = 0; i < nc; i++) { res[nres].w = chosen[i].w | (1ull << (62 + pass)); nres++; }   // (the chain's members carry its log E)
+            }
+            MC_FG_TICK(4);
         }
-        MC_FG_TICK(3);
-        if (nc == 1) { if (T.loge_thr > chosen[0].loge) res[nres++] = chosen[0]; }
-        else {
-            double sc[5];
-            int k = nc < 5 ? nc : 5;
-            for (int i = 0; i < k; i++) sc[i] = (double)chosen[i].score;
-            double E = mc_sum_expect(T, k, sc, subj_len);
-            double le = (E == 0.0) ? -10000.0 : log(E) / 2.302585092994046;
-            if (T.loge_thr > le) for (int i = 0; i < nc; i++) { chosen[i].loge = le; res[nres++] = chosen[i]; }
+    // the records: the chains that stay, or - nothing stays - all of them in the order the sorts left them in
+    const McLinkItem *out = nres > 0 ? res : it;
+    const int nout = nres > 0 ? nres : n;
+    bool moved = nout != n;
+    for (int i = 0; i < n && !moved; i++) moved = MC_LK_IDX(out[i]) != i || (out[i].w >> 62) != 0;
+    if (moved) {
+        for (int i = 0; i < n; i++) tmp[i] = a[i];
+        for (int i = 0; i < nout; i++) {
+            McHsp h = tmp[MC_LK_IDX(out[i])];
+            if (out[i].w >> 62) h.loge = le_pass[(out[i].w >> 63) & 1];
+            a[i] = h;
         }
-        MC_FG_TICK(4);
     }
-    if (nres > 0) { for (int i = 0; i < nres; i++) v[st + i] = res[i]; MC_FG_TICK(5); return st + nres; }
     MC_FG_TICK(5);
-    return ed;
+    return nres > 0 ? st + nres : ed;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -290,51 +325,55 @@ __device__ unsigned long long g_fr_acc[8];           // cycle counters of the ti
 #define MC_FR_TICK(prev) do { } while (0)
 #define MC_FR_END do { } while (0)
 #endif
-MC_HDN int mc_finish_read(const McTables &T, const McIndex &X, const McClassPars &P, const int32_t *marker_family,
-                          int read_id, const McHsp *in, int n, McHsp *v, McHsp *tmp, McRow *rows, double *krows, McSortItem *items, McBestHit *best)
+// The stacks of a read: in[0, n) sorted by (subject, chrono) -> v[0, vn): CalRes' view of every subject (mc_group_stack), subject by
+// subject.  The first record of a subject's stack carries the stack's size in .read (the other records of the stack 0; neither .read
+// nor .chrono is used again).  On the device the ordering kernels (k_order_*) build the same array from the sorted keys.
+MC_HDN int mc_build_stacks(const McHsp *in, int n, McHsp *v)
+{
+    int vn = 0;
+    McHsp cur = in[0];
+    for (int a = 0; a < n;) {
+        const bool lastone = a + 1 >= n;
+        McHsp nxt = cur;
+        if (!lastone) nxt = in[a + 1];
+        if (lastone || nxt.sidx != cur.sidx) { cur.read = 1u; cur.chrono = 1u; v[vn++] = cur; cur = nxt; a++; continue; }   // a subject with ONE HSP (most subjects of most reads)
+        int b = a + 2;
+        const int sidx = cur.sidx;
+        while (b < n && in[b].sidx == sidx) b++;
+        const int k = mc_group_stack(in, a, b, v + vn);
+        for (int j = 1; j < k; j++) v[vn + j].read = 0u;
+        v[vn].read = (uint32_t)k; v[vn].chrono = (uint32_t)k;
+        vn += k;
+        a = b;
+        if (a < n) cur = in[a];
+    }
+    return vn;
+}
+// One read from its stacks (v[0, vn) as mc_build_stacks leaves them; tmp: 2 vn entries of scratch): sum statistics per subject,
+// std::sort by log E, the 500-row cap, MergeRes' order, the rows and the classification.
+MC_HDN int mc_finish_stacked(const McTables &T, const McIndex &X, const McClassPars &P, const int32_t *marker_family,
+                             int read_id, McHsp *v, int vn, McHsp *tmp, McRow *rows, double *krows, McSortItem *items, McBestHit *best)
 {
     MC_FR_BEGIN;
-    // Three passes over the read's subjects.  (1) the stacks, packed into v; a subject with ONE HSP (most subjects of most reads)
-    // goes straight there, the record of the next HSP is read while this one is dealt with.  The first record of a subject's
-    // stack carries the stack's size in .read and what is kept of it in .chrono (neither field is used again).  (2) sum
-    // statistics for the subjects with more than one HSP, in a loop of their own: the threads of a wave that have such a
-    // subject link it AT THE SAME TIME - inside the first loop each thread met its subjects at a different turn and the wave
-    // went through the sorts and logarithms of every one of them separately, which was the light kernel's time (cycle counters).
-    // (3) the kept HSPs moved together, if anything shrank.
-    int vn = 0, nlink = 0;
+    // Sum statistics for the subjects with more than one HSP, in a loop of their own: the threads of a wave that have such a
+    // subject link it AT THE SAME TIME - met one by one while the stacks were built, the wave went through the sorts and logarithms
+    // of every one of them separately, which was the light kernel's time (cycle counters).  Then the kept HSPs are moved together,
+    // if anything shrank.
     {
-        McHsp cur = in[0];
-        for (int a = 0; a < n;) {
-            const bool lastone = a + 1 >= n;
-            McHsp nxt = cur;
-            if (!lastone) nxt = in[a + 1];
-            if (lastone || nxt.sidx != cur.sidx) { cur.read = 1u; cur.chrono = 1u; v[vn++] = cur; cur = nxt; a++; continue; }
-            int b = a + 2;
-            const int sidx = cur.sidx;
-            while (b < n && in[b].sidx == sidx) b++;
-            const int k = mc_group_stack(in, a, b, v + vn);
-            v[vn].read = (uint32_t)k; v[vn].chrono = (uint32_t)k;
-            nlink += k > 1;
-            vn += k;
-            a = b;
-            if (a < n) cur = in[a];
-        }
-    }
-    if (nlink) {
-        bool shrank = false;
-        for (int p = 0;;) {
-            while (p < vn && v[p].read < 2u) p++;                   // (a stack of one is one record: the walk steps by the sizes)
-            if (p >= vn) break;
-            const int k = (int)v[p].read, sidx = v[p].sidx;
+        bool shrank = false, any = false;
+        for (int p = 0; p < vn;) {
+            const int k = (int)v[p].read;
+            if (k < 2) { p++; continue; }                           // (a stack of one is one record: the walk steps by the sizes)
+            const int sidx = v[p].sidx;
             const int kept = mc_sum_evalue(T, v, p, p + k, (int)(X.off[sidx + 1] - X.off[sidx]), tmp) - p;
             v[p].read = (uint32_t)k; v[p].chrono = (uint32_t)kept;
-            shrank |= kept != k;
+            shrank |= kept != k; any = true;
             p += k;
         }
-        if (shrank) {
+        if (any && shrank) {
             int w = 0;
             for (int p = 0; p < vn;) {
-                const int k = (int)v[p].read, kept = (int)v[p].chrono;
+                const int k = (int)v[p].read < 2 ? 1 : (int)v[p].read, kept = (int)v[p].read < 2 ? 1 : (int)v[p].chrono;
                 if (w != p) for (int j = 0; j < kept; j++) v[w + j] = v[p + j];
                 w += kept; p += k;
             }
@@ -371,4 +410,12 @@ MC_HDN int mc_finish_read(const McTables &T, const McIndex &X, const McClassPars
     MC_FR_TICK(6);
     MC_FR_END;
     return nrows;
+}
+// in[0, n): the read's HSPs sorted by (subject, chrono); v: n entries of scratch.  (The test-only emulation's entry; the kernels
+// start from the stacks.)
+MC_HDN int mc_finish_read(const McTables &T, const McIndex &X, const McClassPars &P, const int32_t *marker_family,
+                          int read_id, const McHsp *in, int n, McHsp *v, McHsp *tmp, McRow *rows, double *krows, McSortItem *items, McBestHit *best)
+{
+    const int vn = mc_build_stacks(in, n, v);
+    return mc_finish_stacked(T, X, P, marker_family, read_id, v, vn, tmp, rows, krows, items, best);
 }

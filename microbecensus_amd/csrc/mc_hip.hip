@@ -1018,7 +1018,11 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
 #define MC_HSP_KEY(h) (((uint64_t)(h).read << 43) | ((uint64_t)(uint32_t)(h).sidx << 28) | (uint64_t)(h).chrono)   // (read, subject, hit order)
 // frame and the four coordinates of an HSP in one word (3 + 8 + 8 + 11 + 11 bits: frames of up to 170 residues, markers of up to 1,192):
 // two HSPs of a subject with the same word are one HSP found from several seeds (CalRes 0x4082b0-0x408446 keeps one of them)
-#define MC_HSP_PLACE(h) (((uint64_t)(uint16_t)(h).frame << 38) | ((uint64_t)(uint16_t)(h).qaas << 30) | ((uint64_t)(uint16_t)(h).qaae << 22) | ((uint64_t)(uint16_t)(h).ds << 11) | (uint64_t)(uint16_t)(h).de)
+// ... and above them the score (16 bits): of the HSPs of one place CalRes keeps the one with the smaller log E - the higher score, the
+// first one found on a tie (every HSP's log E is still the table value of its score here: sum statistics come later)
+#define MC_HSP_PLACE(h) (((uint64_t)(uint16_t)(h).score << 41) | ((uint64_t)(uint16_t)(h).frame << 38) | ((uint64_t)(uint16_t)(h).qaas << 30) | ((uint64_t)(uint16_t)(h).qaae << 22) | ((uint64_t)(uint16_t)(h).ds << 11) | (uint64_t)(uint16_t)(h).de)
+#define MC_PLACE_OF(w) ((w) & ((1ull << 41) - 1))
+#define MC_SCORE_OF(w) ((uint32_t)((w) >> 41))
 __device__ __forceinline__ bool mc_hsp_can_classify(const McTables &T, const McClassPars &P, const McIndex &X, const int32_t *fam, const McHsp &h)
 {
     const int f = fam[h.sidx];
@@ -1745,7 +1749,7 @@ __global__ void __launch_bounds__(256) k_order_lists(const uint32_t *__restrict_
 }
 #define MC_KEY43 ((1ull << 43) - 1)
 __global__ void __launch_bounds__(256) k_order_light(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ places, const uint32_t *__restrict__ slots, const uint32_t *__restrict__ heads, uint32_t nreads,
-                                                    const uint8_t *__restrict__ low, uint32_t *order, uint32_t *nrow_of)
+                                                    const uint8_t *__restrict__ low, uint32_t *order, uint32_t *gsz, uint32_t *nv, uint32_t *nrow_of)
 {
     __shared__ uint64_t key[MC_OL_READS * MC_BIN_LIGHT], plc[MC_OL_READS * MC_BIN_LIGHT];
     __shared__ uint16_t sid[MC_OL_READS * MC_BIN_LIGHT];
@@ -1785,29 +1789,69 @@ __global__ void __launch_bounds__(256) k_order_light(const uint64_t *__restrict_
         if (same > 1) {
             const uint64_t mine = plc[at];
             for (uint32_t j = 0; j < n; j++)
-                if (sid[base + j] == s && plc[base + j] != mine) { lmark[q] = 1; break; }
+                if (sid[base + j] == s && MC_PLACE_OF(plc[base + j]) != MC_PLACE_OF(mine)) { lmark[q] = 1; break; }
         }
         (void)me;
     }
     __syncthreads();
-    if (threadIdx.x < MC_OL_READS && lmark[threadIdx.x]) nrow_of[r0 + threadIdx.x] = 1u;
-    for (uint32_t at = threadIdx.x; at < T; at += 256) {           // the marked reads: every HSP's rank in its segment
-        const uint32_t q = qof[at];
-        if (!lmark[q]) continue;
-        const uint32_t n = lcnt[q], base = lpos[q], me = at - base;
-        const uint64_t k = key[at];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < n; j++) { const uint64_t kj = key[base + j]; rank += (kj < k || (kj == k && j < me)) ? 1u : 0u; }
-        order[lhead[q] + rank] = slots[lhead[q] + me];
+    // the marked reads: every HSP's rank in its segment (kept in registers), then keys, place words and positions in order in LDS
+    constexpr int PER = MC_OL_READS * MC_BIN_LIGHT / 256;
+    uint64_t rk[PER], rp[PER];
+    uint32_t rto[PER];
+#pragma unroll
+    for (int it = 0; it < PER; it++) {
+        const uint32_t at = threadIdx.x + 256u * (uint32_t)it;
+        rto[it] = ~0u;
+        if (at < T && lmark[qof[at]]) {
+            const uint32_t q = qof[at], n = lcnt[q], base = lpos[q], me = at - base;
+            const uint64_t k = key[at];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; j++) { const uint64_t kj = key[base + j]; rank += (kj < k || (kj == k && j < me)) ? 1u : 0u; }
+            rk[it] = k; rp[it] = plc[at]; rto[it] = ((base + rank) << 8) | me;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < PER; it++) if (rto[it] != ~0u) { const uint32_t to = rto[it] >> 8; key[to] = rk[it]; plc[to] = rp[it]; sid[to] = (uint16_t)(rto[it] & 0xFFu); }   // (sid: now the HSP's position in its binned segment)
+    __syncthreads();
+    // ... and a thread per marked read walks its HSPs in order: CalRes' stacks (mc_build_stacks, mc_finish.h) - of the consecutive
+    // HSPs of one place the best one, the subject's stack newest first, its size with the first record
+    if (threadIdx.x < MC_OL_READS && lmark[threadIdx.x]) {
+        const uint32_t q = threadIdx.x, n = lcnt[q], base = lpos[q], a = lhead[q];
+        uint32_t out = 0;
+        for (uint32_t gs = 0; gs < n;) {
+            const uint64_t sx = key[base + gs] >> 28;
+            uint32_t ge = gs + 1, kg = 1;
+            while (ge < n && (key[base + ge] >> 28) == sx) { kg += MC_PLACE_OF(plc[base + ge]) != MC_PLACE_OF(plc[base + ge - 1]) ? 1u : 0u; ge++; }
+            uint32_t run = 0;
+            for (uint32_t j = gs; j < ge; run++) {
+                uint32_t bestj = j, j2 = j + 1;
+                while (j2 < ge && MC_PLACE_OF(plc[base + j2]) == MC_PLACE_OF(plc[base + j])) { if (MC_SCORE_OF(plc[base + j2]) > MC_SCORE_OF(plc[base + bestj])) bestj = j2; j2++; }
+                const uint32_t o = a + out + kg - 1 - run;
+                order[o] = slots[a + sid[base + bestj]];
+                gsz[o] = run == kg - 1 ? kg : 0u;
+                j = j2;
+            }
+            out += kg; gs = ge;
+        }
+        nv[r0 + q] = out;
+        nrow_of[r0 + q] = 1u;
     }
 }
-// sorted[i] = the HSP that belongs at place i (order[i]: its pool slot; ~0: the place of an unmarked read's HSP, nobody will look)
-__global__ void __launch_bounds__(256) k_order_copy(const uint32_t *__restrict__ order, const McHsp *__restrict__ hsps, const uint32_t *__restrict__ heads, uint32_t nreads, McHsp *sorted)
+// v[i] = the HSP that belongs at place i of the stacks (order[i]: its pool slot; ~0: nothing - the place of an unmarked read's HSP
+// or of a duplicate), with the size of its subject's stack in .read (0 behind the stack's first record)
+__global__ void __launch_bounds__(256) k_order_copy(const uint32_t *__restrict__ order, const uint32_t *__restrict__ gsz, const McHsp *__restrict__ hsps, const uint32_t *__restrict__ heads, uint32_t nreads, McHsp *v)
 {
     const uint32_t total = heads[nreads];
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
         const uint32_t sl = order[i];
-        if (sl != ~0u) mc_hsp_copy(sorted + i, hsps + sl);
+        if (sl != ~0u) {
+            const uint4 *s4 = (const uint4 *)(hsps + sl); uint4 *d4 = (uint4 *)(v + i);
+            uint4 x0 = s4[0];
+            const uint4 x1 = s4[1], x2 = s4[2];
+            x0.x = gsz[i];                                          // (.read)
+            d4[0] = x0; d4[1] = x1; d4[2] = x2;
+        }
     }
 }
 // A wave per read with more HSPs (reads of marker genes: hundreds of HSPs on homologous markers), a workgroup of eight waves for the
@@ -1870,34 +1914,71 @@ __device__ __forceinline__ PTR mc_group_mergesort(PTR x, PTR y, uint32_t m, int 
     return x;
 }
 #define MC_ITEM_OF(keys, k, n) ((k) < (n) ? (((keys)[k] & MC_KEY43) << 21) | (uint64_t)(k) : (~0ull << 21) | (uint64_t)(k))   // (padding: behind every HSP, all different)
-// the read's order from its sorted items: marks, then the pool slots of its HSPs in order (only if the read is marked)
-template <int NT, class PTR>
-__device__ __forceinline__ void mc_order_heavy_out(PTR x, const uint32_t *__restrict__ slots, const uint64_t *__restrict__ places, uint32_t n, bool marked, uint32_t *__restrict__ order, uint32_t *nrow, int tid, uint32_t *s_diff)
+// From a read's sorted items x (y: the other buffer, R: n counters): is the read marked, and if so CalRes' stacks (mc_build_stacks,
+// mc_finish.h) as pool slots in order[0, runs) with the stack sizes in gsz - a run = consecutive HSPs of one subject with the same
+// place (the best of them stays), a subject's runs newest first.  R[k] = number of runs that start at or in front of item k.
+template <int NT, class PTR, class RPTR>
+__device__ __forceinline__ void mc_order_heavy_out(PTR x, PTR y, RPTR R, const uint32_t *__restrict__ slots, const uint64_t *__restrict__ places, uint32_t n, bool marked,
+                                                   uint32_t *__restrict__ order, uint32_t *__restrict__ gsz, uint32_t *nrow, uint32_t *nv, int tid, uint32_t *s_w)
 {
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll 4
+    for (uint32_t k = (uint32_t)tid; k < n; k += NT) y[k] = places[(uint32_t)(x[k] & 0x1FFFFFu)];
+    if (NT > 64 && tid == 0) s_w[16] = 0;
+    mc_group_sync<NT>();
     if (!marked) {                                                 // no HSP below the threshold: two different HSPs on one subject? (neighbours now)
         bool diff = false;
-        for (uint32_t k = (uint32_t)tid + 1; k < n && !diff; k += NT) {
-            const uint64_t u = x[k - 1], v = x[k];
-            if ((u >> 49) == (v >> 49)) diff = places[(uint32_t)(u & 0x1FFFFFu)] != places[(uint32_t)(v & 0x1FFFFFu)];
-        }
+        for (uint32_t k = (uint32_t)tid + 1; k < n && !diff; k += NT) diff = (x[k - 1] >> 49) == (x[k] >> 49) && MC_PLACE_OF(y[k - 1]) != MC_PLACE_OF(y[k]);
         if (NT == 64) marked = __ballot(diff) != 0;
-        else { if (diff) *s_diff = 1; __syncthreads(); marked = *s_diff != 0; }
+        else { if (diff) s_w[16] = 1; __syncthreads(); marked = s_w[16] != 0; }
+        if (!marked) { mc_group_sync<NT>(); return; }
     }
-    if (marked) {
-#pragma unroll 4
-        for (uint32_t k = (uint32_t)tid; k < n; k += NT) order[k] = slots[(uint32_t)(x[k] & 0x1FFFFFu)];
-        if (tid == 0) *nrow = 1u;
+    uint32_t carry = 0;
+    for (uint32_t k0 = 0; k0 < n; k0 += NT) {
+        const uint32_t k = k0 + (uint32_t)tid;
+        const bool head = k < n && (k == 0 || (x[k] >> 49) != (x[k - 1] >> 49) || MC_PLACE_OF(y[k]) != MC_PLACE_OF(y[k - 1]));
+        const unsigned long long bal = __ballot(head);
+        uint32_t base = 0, tot = (uint32_t)__popcll(bal);
+        if (NT > 64) {
+            if (lane == 0) s_w[wv] = tot;
+            __syncthreads();
+            tot = 0;
+            for (int w = 0; w < NT / 64; w++) { const uint32_t c = s_w[w]; if (w < wv) base += c; tot += c; }
+            __syncthreads();
+        }
+        if (k < n) R[k] = carry + base + (uint32_t)__popcll(bal & ((2ull << lane) - 1ull));
+        carry += tot;
+    }
+    if (tid == 0) { *nv = carry; *nrow = 1u; }
+    mc_group_sync<NT>();
+    for (uint32_t k = (uint32_t)tid; k < n; k += NT) {              // a thread per subject
+        if (k != 0 && (x[k] >> 49) == (x[k - 1] >> 49)) continue;
+        const uint64_t sx = x[k] >> 49;
+        uint32_t ge = k + 1;
+        while (ge < n && (x[ge] >> 49) == sx) ge++;
+        const uint32_t r0 = (uint32_t)R[k], kg = (uint32_t)R[ge - 1] - r0 + 1, ob = r0 - 1;
+        for (uint32_t j = k; j < ge;) {
+            const uint32_t rj = (uint32_t)R[j];
+            uint32_t bestj = j, j2 = j + 1;
+            while (j2 < ge && (uint32_t)R[j2] == rj) { if (MC_SCORE_OF(y[j2]) > MC_SCORE_OF(y[bestj])) bestj = j2; j2++; }
+            const uint32_t run = rj - r0, o = ob + kg - 1 - run;
+            order[o] = slots[(uint32_t)(x[bestj] & 0x1FFFFFu)];
+            gsz[o] = run == kg - 1 ? kg : 0u;
+            j = j2;
+        }
     }
     mc_group_sync<NT>();
 }
 // scratch: 12 64-bit words per HSP (the finishing kernels' tmp): a segment too long for the LDS is sorted there - blocks of CAP
-// items in LDS first, the merge passes above them in global memory (buffers at 12 a and 12 a + 4 n)
+// items in LDS first, the merge passes above them in global memory (buffers at 12 a and 12 a + 4 n, the run counters at 12 a + 8 n)
 template <int NT, uint32_t CAP>
 __global__ void __launch_bounds__(NT) k_order_heavy(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ places, const uint32_t *__restrict__ slots, const uint32_t *__restrict__ heads,
-                                                    const uint32_t *__restrict__ list, const uint32_t *__restrict__ nlist_p, uint32_t *take, const uint8_t *__restrict__ low, uint32_t *order, uint32_t *nrow_of, uint64_t *scratch)
+                                                    const uint32_t *__restrict__ list, const uint32_t *__restrict__ nlist_p, uint32_t *take, const uint8_t *__restrict__ low, uint32_t *order, uint32_t *gsz, uint32_t *nv,
+                                                    uint32_t *nrow_of, uint64_t *scratch)
 {
-    uint64_t *lds = (uint64_t *)mc_smem;                            // 2 x CAP items (dynamic LDS)
-    __shared__ uint32_t s_diff, s_e;
+    uint64_t *lds = (uint64_t *)mc_smem;                            // 2 x CAP items and CAP 16-bit counters (dynamic LDS)
+    uint16_t *ldsR = (uint16_t *)(lds + 2 * CAP);
+    __shared__ uint32_t s_w[17], s_e;
     const int tid = (int)threadIdx.x;
     const uint32_t nlist = *nlist_p;
     uint32_t sub = 0, e0 = 0;
@@ -1916,13 +1997,12 @@ __global__ void __launch_bounds__(NT) k_order_heavy(const uint64_t *__restrict__
         const uint64_t *kk = keys + a;
         uint32_t m = 64;
         while (m < n) m <<= 1;
-        if (NT > 64 && tid == 0) s_diff = 0;
         if (m <= CAP) {
 #pragma unroll 4
             for (uint32_t k = (uint32_t)tid; k < m; k += NT) lds[k] = MC_ITEM_OF(kk, k, n);
             mc_group_sync<NT>();
             uint64_t *x = mc_group_mergesort<NT>(lds, lds + CAP, m, tid);
-            mc_order_heavy_out<NT>(x, slots + a, places + a, n, marked, order + a, nrow_of + r, tid, &s_diff);
+            mc_order_heavy_out<NT>(x, x == lds ? lds + CAP : lds, ldsR, slots + a, places + a, n, marked, order + a, gsz + a, nrow_of + r, nv + r, tid, s_w);
         } else {
             uint64_t *g = scratch + 12 * (size_t)a, *g2 = g + 4 * (size_t)n;      // (m < 2 n)
             for (uint32_t b0 = 0; b0 < m; b0 += CAP) {
@@ -1940,7 +2020,8 @@ __global__ void __launch_bounds__(NT) k_order_heavy(const uint64_t *__restrict__
                 mc_group_sync<NT>();
                 uint64_t *t = g; g = g2; g2 = t;
             }
-            mc_order_heavy_out<NT>(g, slots + a, places + a, n, marked, order + a, nrow_of + r, tid, &s_diff);
+            __threadfence_block();
+            mc_order_heavy_out<NT>(g, g2, (uint32_t *)(scratch + 12 * (size_t)a + 8 * (size_t)n), slots + a, places + a, n, marked, order + a, gsz + a, nrow_of + r, nv + r, tid, s_w);
         }
     }
 }
@@ -1948,7 +2029,12 @@ __global__ void __launch_bounds__(NT) k_order_heavy(const uint64_t *__restrict__
 #ifndef MC_FH_MIN
 #define MC_FH_MIN 96
 #endif
-// MC_FH_MIN: reads with more HSPs than this are finished by a whole wave (k_finish_heavy)
+#ifndef MC_FH_MIN_BEST
+#define MC_FH_MIN_BEST 32
+#endif
+// MC_FH_MIN: reads with more stacked HSPs than this are finished by a whole wave (k_finish_heavy); MC_FH_MIN_BEST: the same with
+// best hits only, where few reads are finished and the longest thread of k_finish decides (per 1 M reads of 150 bp: 96 / 48 / 32 / 16
+// -> finishing 2.36 / 2.64 / 2.65 / 3.80 ms with rows, 2.38 / 1.43 / 1.41 / 1.42 ms with best hits only)
 #define MC_FH_N1 512      // subjects / ranked HSPs a read may have in the first wave kernel (11 KB of LDS per wave) ...
 #define MC_FH_N2 2048     // ... in the second (45 KB) ...
 #define MC_FH_N3 6144     // ... and in the third (135 KB, one wave per CU), where anything larger is finished by lane 0 alone
@@ -1958,16 +2044,15 @@ __global__ void __launch_bounds__(NT) k_order_heavy(const uint64_t *__restrict__
 // The reads with a marked HSP that a single thread finishes (k_finish) are listed by size class as well: a wave of k_finish
 // then holds reads of similar size instead of one read of 90 HSPs among 63 idle lanes.
 #define MC_LIGHT_CLASS(n) ((n) <= 4 ? 0 : (n) <= 16 ? 1 : (n) <= 48 ? 2 : 3)
-__global__ void __launch_bounds__(256) k_heavy_lists(const uint32_t *__restrict__ heads, uint32_t nheads, uint32_t nhsps, const uint8_t *__restrict__ mark, uint32_t *nrow_of,
-                                                     McBestHit *best_of, uint32_t *counters, uint32_t *heavy, uint32_t *light, uint32_t light_pitch)
+__global__ void __launch_bounds__(256) k_heavy_lists(const uint32_t *__restrict__ nv, uint32_t nheads, uint32_t *nrow_of,
+                                                     McBestHit *best_of, uint32_t *counters, uint32_t *heavy, uint32_t *light, uint32_t light_pitch, uint32_t fh_min)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     int cls = -1;                                                // -1 nothing to do, 0..3 light class, 4 heavy
     if (s < nheads) {
-        const uint32_t a = heads[s], b = heads[s + 1], n = b - a;
-        const uint32_t any = nrow_of[s];                           // (k_heads: the read has a marked HSP)
+        const uint32_t any = nrow_of[s];                           // (k_order_*: the read is marked, nv[s] = the size of its stacks)
         if (!any) best_of[s].family = -1;
-        else cls = n > MC_FH_MIN ? 4 : MC_LIGHT_CLASS(n);
+        else { const uint32_t n = nv[s]; cls = n > fh_min ? 4 : MC_LIGHT_CLASS(n); }
     }
     const uint32_t o = mc_block_alloc(&counters[C_HEAVY], cls == 4);
     if (cls == 4) heavy[o] = s;
@@ -1978,12 +2063,12 @@ __global__ void __launch_bounds__(256) k_heavy_lists(const uint32_t *__restrict_
     }
 }
 
-// One thread per read that has HSPs, in ascending read order.  All scratch is addressed by the read's offset into the
-// sorted HSP array (a read never produces more rows than it has HSPs): v = the stacks, tmp = 2 HSP slots per HSP for the
+// One thread per marked read.  All scratch is addressed by the read's offset into the binned HSPs (heads; a read never produces
+// more rows than it has HSPs): v = the stacks (built by the ordering kernels), tmp = 2 HSP slots per HSP for the
 // sum statistics, reused afterwards for the read's rows and their merge keys (64 + 8 bytes per row <= 96).  The rows
 // stay in that scratch; k_emit_rows moves them to their final place once the row counts have been scanned.
 __global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
-                                                const McHsp *__restrict__ sorted, uint32_t nhsps, const uint32_t *__restrict__ heads, uint32_t nheads,
+                                                const uint32_t *__restrict__ nv, const uint32_t *__restrict__ heads, uint32_t nheads,
                                                 McHsp *v, McHsp *tmp, int64_t first_read_id, uint32_t *nrow_of, McBestHit *best,
                                                 const uint32_t *__restrict__ light, uint32_t light_pitch, const uint32_t *__restrict__ nlight)
 {
@@ -1993,16 +2078,14 @@ __global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, 
     const int cl = 3 - (int)blockIdx.y;
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nlight[cl]) return;                                // (the reads of one size class that have something to print: k_heavy_lists)
-    const uint32_t s = light[(size_t)cl * light_pitch + idx];
+    const uint32_t s = light[(size_t)cl * light_pitch + idx];     // the read; its stacks: v[heads[s] ...], nv[s] records (k_order_*)
     const uint32_t a = heads[s];
-    const uint32_t b = heads[s + 1];
-    const int n = (int)(b - a);
-    const uint32_t read = sorted[a].read;
+    const int n = (int)(heads[s + 1] - a);                        // (the scratch of a read is laid out by the size of its segment)
     McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
     double *myk = (double *)(myrows + n);
     McBestHit bh;
     McSortItem *myitems = (McSortItem *)(myk + n);               // 64 n + 8 n + 16 n = 88 n <= 96 n bytes of the read's tmp area
-    const int nr = mc_finish_read(*T, X, *P, fam, (int)((int64_t)read + first_read_id), sorted + a, n, v + a, tmp + 2 * (size_t)a, myrows, myk, myitems, &bh);
+    const int nr = mc_finish_stacked(*T, X, *P, fam, (int)((int64_t)s + first_read_id), v + a, (int)nv[s], tmp + 2 * (size_t)a, myrows, myk, myitems, &bh);
     nrow_of[s] = (uint32_t)nr;
     best[s] = bh;                                                 // per read that has HSPs (family -1: none); k_emit_rows collects them
 }
@@ -2215,7 +2298,7 @@ __global__ void __launch_bounds__(64) k_heap_lanes(const uint32_t *__restrict__ 
 
 // The rows of the heavy reads in their final order, and their classification: one wave per read.
 __global__ void __launch_bounds__(64) k_heavy_rows(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
-                                                   const McHsp *__restrict__ sorted, uint32_t nhsps, const uint32_t *__restrict__ heads, uint32_t nheads,
+                                                   const uint32_t *__restrict__ heads, uint32_t nheads,
                                                    const McHsp *__restrict__ v, McHsp *tmp, int64_t first_read_id, const uint32_t *__restrict__ nrow_of, McBestHit *best_of,
                                                    const uint32_t *__restrict__ counters, const uint32_t *__restrict__ heavy_first)
 {
@@ -2226,7 +2309,7 @@ __global__ void __launch_bounds__(64) k_heavy_rows(const McTables *__restrict__ 
         if (!(e & 0x80000000u)) continue;                            // (finished by lane 0 of the last wave kernel)
         const uint32_t s = e & 0x7FFFFFFFu, a = heads[s], b = heads[s + 1];
         const int n = (int)(b - a), nrows = (int)nrow_of[s];
-        const int read_id = (int)((int64_t)sorted[a].read + first_read_id);
+        const int read_id = (int)((int64_t)s + first_read_id);
         const uint32_t *hw = mc_heavy_words(tmp, a, n);
         McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
         double bbits = -1.0; int bidx = 0x7fffffff, bfam = -1, baln = 0, btl = 0;
@@ -2252,7 +2335,7 @@ __global__ void __launch_bounds__(64) k_heavy_rows(const McTables *__restrict__ 
 
 template <int MAXN, int CTR, int CTR_NEXT>
 __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
-                                                     const McHsp *__restrict__ sorted, uint32_t nhsps, const uint32_t *__restrict__ heads, uint32_t nheads,
+                                                     const uint32_t *__restrict__ nv, const uint32_t *__restrict__ heads, uint32_t nheads,
                                                      McHsp *v, McHsp *tmp, int64_t first_read_id, uint32_t *nrow_of, McBestHit *best_of, uint32_t *counters,
                                                      uint32_t *heavy_first, const uint32_t *__restrict__ list, uint32_t *list_next)
 {
@@ -2273,33 +2356,31 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
         MC_FH_TICK(0);
         const uint32_t slot = CTR == C_HEAVY ? bi : list[bi];        // position in the first list (heavy_first): the later lists hold slots
         const uint32_t s = heavy_first[slot] & 0x7FFFFFFFu, a = heads[s], b = heads[s + 1];
-        const int n = (int)(b - a);
-        const McHsp *in = sorted + a;
-        const int read_id = (int)((int64_t)in[0].read + first_read_id);
-        // subjects: group starts (counted first: a read with more subjects than this kernel's arrays hold moves on)
-        int ng = 0;
-        for (int i0 = 0; i0 < n; i0 += 64) {
-            const int i = i0 + lane;
-            ng += __popcll(__ballot(i < n && (i == 0 || in[i].sidx != in[i - 1].sidx)));
-        }
-        bool punt = ng > MAXN || n > 65535;
-        int vn = 0;
+        const int nseg = (int)(b - a);                              // (the read's scratch is laid out by the size of its segment)
+        const int n = (int)nv[s];                                   // its stacks: v[a, a + n) (k_order_*: the first record of a subject's stack carries the stack's size in .read)
+        McHsp *in = v + a;
+        const int read_id = (int)((int64_t)s + first_read_id);
+        // (a read with more stacked HSPs than this kernel's arrays hold moves on - before anything is changed: the sum statistics
+        // below work in place)
+        bool punt = n > MAXN || n > 65535;
+        int vn = 0, ng = 0;
         if (!punt) {
-            ng = 0;
-            for (int i0 = 0; i0 < n; i0 += 64) {
+            for (int i0 = 0; i0 < n; i0 += 64) {                     // subjects: the starts of their stacks
                 const int i = i0 + lane;
-                const bool st = i < n && (i == 0 || in[i].sidx != in[i - 1].sidx);
+                const bool st = i < n && in[i].read != 0u;
                 const unsigned long long m = __ballot(st);
                 if (st) gst[ng + __popcll(m & lt)] = (uint16_t)i;
                 ng += __popcll(m);
             }
             if (lane == 0) gst[ng] = (uint16_t)n;
             __syncthreads();
-            // per subject: stack, reversal, sum statistics - results stay at the group's own offset of v
+            // per subject: sum statistics - results stay at the group's own offset of v
             MC_FH_TICK(1);
             for (int g = lane; g < ng; g += 64) {
-                const int g0 = gst[g], g1 = gst[g + 1];
-                gkept[g] = (uint16_t)mc_finish_group(*T, X, in, g0, g1, v + a + g0, tmp + 2 * ((size_t)a + g0));
+                const int g0 = gst[g], k = gst[g + 1] - g0;
+                int kept = k;
+                if (k > 1) { const int sidx = in[g0].sidx; kept = mc_sum_evalue(*T, in + g0, 0, k, (int)(X.off[sidx + 1] - X.off[sidx]), tmp + 2 * ((size_t)a + g0)); }
+                gkept[g] = (uint16_t)kept;
             }
             __syncthreads();
             MC_FH_TICK(2);
@@ -2317,16 +2398,15 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
             }
             __syncthreads();
             vn = s_vn;
-            punt = vn > MAXN;                                       // (the groups are recomputed by the next kernel: mc_finish_group only reads `in`)
         }
         if (punt) {
             if (CTR_NEXT >= 0) { if (lane == 0) list_next[atomicAdd(&counters[CTR_NEXT < 0 ? 0 : CTR_NEXT], 1u)] = slot; }
             else if (lane == 0) {                                   // larger than the largest arrays: lane 0 alone, everything in the read's global scratch
                 McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
-                double *myk = (double *)(myrows + n);
-                McSortItem *myitems = (McSortItem *)(myk + n);
+                double *myk = (double *)(myrows + nseg);
+                McSortItem *myitems = (McSortItem *)(myk + nseg);
                 McBestHit bh;
-                nrow_of[s] = (uint32_t)mc_finish_read(*T, X, *P, fam, read_id, in, n, v + a, tmp + 2 * (size_t)a, myrows, myk, myitems, &bh);
+                nrow_of[s] = (uint32_t)mc_finish_stacked(*T, X, *P, fam, read_id, in, n, tmp + 2 * (size_t)a, myrows, myk, myitems, &bh);
                 best_of[s] = bh;
             }
             __syncthreads();
@@ -2359,7 +2439,7 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
         {   // dense ranks of the printed keys -> heap words rank << 16 | index of the HSP in v, into the read's scratch behind the
             // place of its rows (the groups' scratch is dead by now): MergeRes' heap sort and the rows follow in k_heap_lanes and
             // k_heavy_rows
-            uint32_t *ghw = mc_heavy_words(tmp, a, n);
+            uint32_t *ghw = mc_heavy_words(tmp, a, nseg);
             int carry = 0;
             for (int i0 = 0; i0 < nrows; i0 += 64) {
                 const int i = i0 + lane;
@@ -2483,8 +2563,8 @@ struct McCtx {
     uint32_t cap_tasks = 0, cap_gaps = 0, cap_hsps = 0, cap_rows = 0;
     uint8_t *d_frames = nullptr, *d_frames_base = nullptr;   // (64 bytes of room in front: k_eval_seeds reads 8 bytes at a time backwards from a seed)
     unsigned long long *d_stats = nullptr;
-    McSeedTask *d_tasks = nullptr; McGapTask *d_gaps = nullptr; McHsp *d_hsps = nullptr, *d_sorted = nullptr, *d_v = nullptr, *d_tmp = nullptr;
-    uint64_t *d_k64 = nullptr, *d_hkeys = nullptr, *d_hplace = nullptr, *d_places = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr, *d_scan = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
+    McSeedTask *d_tasks = nullptr; McGapTask *d_gaps = nullptr; McHsp *d_hsps = nullptr, *d_v = nullptr, *d_tmp = nullptr;
+    uint64_t *d_k64 = nullptr, *d_hkeys = nullptr, *d_hplace = nullptr, *d_places = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr, *d_scan = nullptr, *d_gsz = nullptr, *d_nv = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
     uint32_t *d_counters = nullptr;
     McRow *d_rows = nullptr; uint32_t *d_nrow = nullptr, *d_rowoff = nullptr; McBestHit *d_best = nullptr, *d_bestof = nullptr; uint8_t *d_low = nullptr, *d_cand = nullptr;
     McGapCell *d_gws_full = nullptr; uint32_t *d_retry = nullptr, *d_retry2 = nullptr; int gap_threads_full = 0;
@@ -2552,7 +2632,7 @@ extern "C" int mc_device_count(void)
 
 static void ctx_free(McCtx &c)
 {
-    void *ptrs[] = {c.d_frames_base, c.d_tasks, c.d_gaps, c.d_hsps, c.d_sorted, c.d_v, c.d_tmp, c.d_k64, c.d_hkeys, c.d_hplace, c.d_places, c.d_idx, c.d_idxo, c.d_heads, c.d_scan, c.d_sorttmp, c.d_counters, c.d_rows,
+    void *ptrs[] = {c.d_frames_base, c.d_tasks, c.d_gaps, c.d_hsps, c.d_v, c.d_tmp, c.d_k64, c.d_hkeys, c.d_hplace, c.d_places, c.d_idx, c.d_idxo, c.d_heads, c.d_scan, c.d_gsz, c.d_nv, c.d_sorttmp, c.d_counters, c.d_rows,
                     c.d_nrow, c.d_rowoff, c.d_best, c.d_bestof, c.d_low, c.d_cand, c.d_gws_full, c.d_retry, c.d_retry2, c.d_gtab, c.d_gleader, c.d_fout, c.d_stats};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : {(void *)c.h_c, (void *)c.h_stats, (void *)c.h_best}) if (p) (void)hipHostFree(p);
@@ -2741,9 +2821,9 @@ static int ensure_capacity(mc_handle *h, McCtx &c, int64_t nreads)
     c.cap_rows = (uint32_t)std::min<int64_t>(cap * 48 + (1 << 20), 0x7fffffff);
     c.gap_threads_full = 16 * 1024;                                 // full-size DP rows for the last-resort launch (460 MB)
     if (dalloc(&c.d_frames_base, (size_t)cap * 6 * h->FP + 128) || dalloc(&c.d_tasks, c.cap_tasks) ||
-        dalloc(&c.d_gaps, c.cap_gaps) || dalloc(&c.d_hsps, c.cap_hsps) || dalloc(&c.d_sorted, c.cap_hsps) || dalloc(&c.d_v, c.cap_hsps) ||
+        dalloc(&c.d_gaps, c.cap_gaps) || dalloc(&c.d_hsps, c.cap_hsps) || dalloc(&c.d_v, c.cap_hsps) ||
         dalloc(&c.d_tmp, (size_t)c.cap_hsps * 2) || dalloc(&c.d_k64, c.cap_hsps) || dalloc(&c.d_hkeys, c.cap_hsps) || dalloc(&c.d_hplace, c.cap_hsps) || dalloc(&c.d_places, c.cap_hsps) || dalloc(&c.d_idx, c.cap_hsps) ||
-        dalloc(&c.d_idxo, c.cap_hsps) || dalloc(&c.d_heads, (size_t)cap + 2) || dalloc(&c.d_scan, (size_t)4100) || dalloc(&c.d_rows, c.cap_rows) ||
+        dalloc(&c.d_idxo, c.cap_hsps) || dalloc(&c.d_heads, (size_t)cap + 2) || dalloc(&c.d_scan, (size_t)4100) || dalloc(&c.d_gsz, c.cap_hsps) || dalloc(&c.d_nv, (size_t)cap + 1) || dalloc(&c.d_rows, c.cap_rows) ||
         dalloc(&c.d_low, (size_t)cap + 64) || dalloc(&c.d_cand, (size_t)cap + 64) || dalloc(&c.d_nrow, (size_t)cap + 1) || dalloc(&c.d_rowoff, (size_t)cap + 1) || dalloc(&c.d_best, (size_t)cap + 1) || dalloc(&c.d_bestof, (size_t)cap + 1) ||
         dalloc(&c.d_gws_full, (size_t)c.gap_threads_full * MC_GAP_W) || dalloc(&c.d_retry, (size_t)c.cap_gaps * 2 + (size_t)cap + 1) || dalloc(&c.d_retry2, (size_t)c.cap_gaps * 2) || dalloc(&c.d_gleader, (size_t)c.cap_gaps) ||
         dalloc(&c.d_fout, (size_t)c.cap_gaps * 2))
@@ -2931,14 +3011,14 @@ static int stage_c(mc_handle *h, McCtx &c)
         k_order_lists<<<dim3((n + 255) / 256), dim3(256), 0, st>>>(c.d_heads, n, c.d_counters, heavy, heavy2, heavy3);
         hipStream_t side = order_serial ? st : c.side;
         if (!order_serial) { HIPCK(hipEventRecord(c.ev_fork, st)); HIPCK(hipStreamWaitEvent(c.side, c.ev_fork, 0)); }
-        HIPCK(hipFuncSetAttribute((const void *)k_order_heavy<1024, MC_ORDER_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * MC_ORDER_LDS * 8)));
-        k_order_heavy<1024, MC_ORDER_LDS><<<dim3(256u), dim3(1024), 2 * MC_ORDER_LDS * 8, side>>>(keys, c.d_places, slots, c.d_heads, heavy3, c.d_counters + C_ORDER3, c.d_counters + C_OTAKE3, c.d_low, order, c.d_nrow, (uint64_t *)c.d_tmp);
-        k_order_heavy<256, MC_ORDER_MID><<<dim3(256u * 4u), dim3(256), 2 * MC_ORDER_MID * 8, side>>>(keys, c.d_places, slots, c.d_heads, heavy2, c.d_counters + C_ORDER2, c.d_counters + C_OTAKE2, c.d_low, order, c.d_nrow, (uint64_t *)c.d_tmp);
+        HIPCK(hipFuncSetAttribute((const void *)k_order_heavy<1024, MC_ORDER_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MC_ORDER_LDS * 18)));
+        k_order_heavy<1024, MC_ORDER_LDS><<<dim3(256u), dim3(1024), MC_ORDER_LDS * 18, side>>>(keys, c.d_places, slots, c.d_heads, heavy3, c.d_counters + C_ORDER3, c.d_counters + C_OTAKE3, c.d_low, order, c.d_gsz, c.d_nv, c.d_nrow, (uint64_t *)c.d_tmp);
+        k_order_heavy<256, MC_ORDER_MID><<<dim3(256u * 4u), dim3(256), MC_ORDER_MID * 18, side>>>(keys, c.d_places, slots, c.d_heads, heavy2, c.d_counters + C_ORDER2, c.d_counters + C_OTAKE2, c.d_low, order, c.d_gsz, c.d_nv, c.d_nrow, (uint64_t *)c.d_tmp);
         if (!order_serial) HIPCK(hipEventRecord(c.ev_join, c.side));
-        k_order_light<<<dim3((n + MC_OL_READS - 1) / MC_OL_READS), dim3(256), 0, st>>>(keys, c.d_places, slots, c.d_heads, n, c.d_low, order, c.d_nrow);
-        k_order_heavy<64, MC_ORDER_SMALL><<<dim3(256u * 16u), dim3(64), 2 * MC_ORDER_SMALL * 8, st>>>(keys, c.d_places, slots, c.d_heads, heavy, c.d_counters + C_ORDER, c.d_counters + C_OTAKE, c.d_low, order, c.d_nrow, (uint64_t *)c.d_tmp);
+        k_order_light<<<dim3((n + MC_OL_READS - 1) / MC_OL_READS), dim3(256), 0, st>>>(keys, c.d_places, slots, c.d_heads, n, c.d_low, order, c.d_gsz, c.d_nv, c.d_nrow);
+        k_order_heavy<64, MC_ORDER_SMALL><<<dim3(256u * 16u), dim3(64), MC_ORDER_SMALL * 18, st>>>(keys, c.d_places, slots, c.d_heads, heavy, c.d_counters + C_ORDER, c.d_counters + C_OTAKE, c.d_low, order, c.d_gsz, c.d_nv, c.d_nrow, (uint64_t *)c.d_tmp);
         if (!order_serial) HIPCK(hipStreamWaitEvent(st, c.ev_join, 0));
-        k_order_copy<<<dim3(256u * 8u), dim3(256), 0, st>>>(order, c.d_hsps, c.d_heads, n, c.d_sorted);
+        k_order_copy<<<dim3(256u * 8u), dim3(256), 0, st>>>(order, c.d_gsz, c.d_hsps, c.d_heads, n, c.d_v);
         if (getenv("MC_BIN_STATS")) {                                  // (development aid: the sizes of the segments)
             std::vector<uint32_t> hh((size_t)n + 1);
             HIPCK(hipStreamSynchronize(st));
@@ -2969,27 +3049,27 @@ static int stage_d(mc_handle *h, McCtx &c)
         uint32_t *d_heavy = c.d_retry, *d_heavy2 = c.d_retry + c.cap_gaps / 2, *d_heavy3 = c.d_retry + c.cap_gaps;      // (d_retry is free again: the gap tasks are done)
         uint32_t *d_light = c.d_retry + c.cap_gaps + c.cap_gaps / 2;
         const uint32_t light_pitch = (uint32_t)c.cap_reads + 1;
-        k_heavy_lists<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(c.d_heads, nheads, nh, nullptr, c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_light, light_pitch);
+        k_heavy_lists<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(c.d_nv, nheads, c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_light, light_pitch, h->best_only ? MC_FH_MIN_BEST : MC_FH_MIN);
         HIPCK(hipEventRecord(c.ev_fork, st));
         {
             const size_t l1 = (size_t)MC_FH_N1 * 16 + 3 * (size_t)(MC_FH_N1 + 2) * 2, l2 = (size_t)MC_FH_N2 * 16 + 3 * (size_t)(MC_FH_N2 + 2) * 2, l3 = (size_t)MC_FH_N3 * 16 + 3 * (size_t)(MC_FH_N3 + 2) * 2;
             HIPCK(hipFuncSetAttribute((const void *)k_finish_heavy<MC_FH_N3, C_HEAVY3, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
             HIPCK(hipStreamWaitEvent(c.side, c.ev_fork, 0));
-            k_finish_heavy<MC_FH_N1, C_HEAVY, C_HEAVY2><<<dim3(256 * 12), dim3(64), l1, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_sorted, nh, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
+            k_finish_heavy<MC_FH_N1, C_HEAVY, C_HEAVY2><<<dim3(256 * 12), dim3(64), l1, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
                                                                                                    c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy, d_heavy2);
-            k_finish_heavy<MC_FH_N2, C_HEAVY2, C_HEAVY3><<<dim3(256 * 3), dim3(64), l2, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_sorted, nh, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
+            k_finish_heavy<MC_FH_N2, C_HEAVY2, C_HEAVY3><<<dim3(256 * 3), dim3(64), l2, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
                                                                                                    c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy2, d_heavy3);
-            k_finish_heavy<MC_FH_N3, C_HEAVY3, -1><<<dim3(256), dim3(64), l3, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_sorted, nh, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
+            k_finish_heavy<MC_FH_N3, C_HEAVY3, -1><<<dim3(256), dim3(64), l3, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
                                                                                          c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy3, nullptr);
             // MergeRes' heap sort of all of them (a lane per read), then their rows (a wave per read)
             const size_t lh = (size_t)(MC_MAX_M8 + 2) * 64 * 4;
             HIPCK(hipFuncSetAttribute((const void *)k_heap_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lh));
             k_heap_lanes<<<dim3(256), dim3(64), lh, c.side>>>(c.d_heads, nheads, nh, c.d_tmp, c.d_nrow, c.d_counters, d_heavy);
-            k_heavy_rows<<<dim3(256 * 12), dim3(64), 0, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_sorted, nh, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id, c.d_nrow, c.d_bestof, c.d_counters, d_heavy);
+            k_heavy_rows<<<dim3(256 * 12), dim3(64), 0, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id, c.d_nrow, c.d_bestof, c.d_counters, d_heavy);
             HIPCK(hipEventRecord(c.ev_join, c.side));
         }
         // the light reads: the four size classes side by side (the counts stay on the device; blocks past a class' count leave at once)
-        k_finish<<<dim3((nheads + 255) / 256, 4), dim3(256), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, c.d_sorted, nh, c.d_heads, nheads, c.d_v, c.d_tmp,
+        k_finish<<<dim3((nheads + 255) / 256, 4), dim3(256), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp,
                                                                        c.first_read_id, c.d_nrow, c.d_bestof, d_light, light_pitch, c.d_counters + C_LIGHT0);
         HIPCK(hipStreamWaitEvent(st, c.ev_join, 0));
         if (mc_scan_u32(c.d_nrow, nheads, c.d_rowoff, c.d_scan, st)) return -1;
