@@ -13,6 +13,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
@@ -33,6 +34,10 @@ static_assert(sizeof(McRow) % 8 == 0 && sizeof(McRow) == sizeof(mc_row) && offse
               "the device row is handed out as the ABI row");
 
 static thread_local std::string g_err;
+// MC_OPEN_TIMING in the environment: where the time of opening an engine and of its first run goes (stderr; development aid)
+static double mc_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+static bool mc_open_timing() { static const bool on = getenv("MC_OPEN_TIMING") != nullptr; return on; }
+#define MC_OT(label, t0) do { if (mc_open_timing()) { const double now_ = mc_now(); fprintf(stderr, "open-timing %-28s %8.1f ms\n", label, (now_ - (t0)) * 1e3); (t0) = now_; } } while (0)
 extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
 
 #define HIPCK(call)                                                                                         \
@@ -2661,6 +2666,7 @@ extern "C" void mc_close(mc_handle *h)
 static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, int32_t device)
 {
     int ndev = 0;
+    double t0 = mc_now();
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device available: libmcensus_hip has no CPU fallback"; return -1; }
     if (device < 0 || device >= ndev) { g_err = "device index out of range"; return -1; }
     if (nfam > 32) { g_err = "at most 32 gene families are supported"; return -1; }
@@ -2670,6 +2676,8 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
     if (marker_family) h->fam.assign(marker_family, marker_family + nseq); else h->fam.assign((size_t)nseq, 0);
     h->nfam = nfam; h->device = device;
     HIPCK(hipSetDevice(device));
+    HIPCK(hipFree(nullptr));
+    MC_OT("  HIP runtime, device", t0);
     for (McCtx &c : h->ctx) {
         HIPCK(hipStreamCreate(&c.stream)); HIPCK(hipStreamCreate(&c.side));
         for (auto &e : c.ev) HIPCK(hipEventCreate(&e));
@@ -2703,6 +2711,7 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
         if (dalloc(&h->d_rec, H.rec.size())) return -1;
         HIPCK(hipMemcpy(h->d_rec, H.rec.data(), H.rec.size() * sizeof(McBucketRec), hipMemcpyHostToDevice));
     }
+    MC_OT("  index upload", t0);
     if (const char *e = getenv("MC_PARTS")) { const int v = atoi(e); if (v >= 1) h->parts = v > MC_NCTX ? MC_NCTX : v; }   // (experiments)
     if (H.max_bucket > 2047) { g_err = "a seed bucket holds more than 2047 postings: the hit-order key cannot index it"; return -1; }
     // the position-parallel seed kernel is exact only when the frequency threshold is 0 and no letter frequency is 0
@@ -2715,8 +2724,11 @@ extern "C" mc_handle *mc_open(const char *const *names, const char *const *seqs,
 {
     mc_handle *h = new mc_handle();
     std::string err;
+    double t0 = mc_now();
     if (!mc_build_index(h->H, names, seqs, nseq, err)) { delete h; g_err = err; return nullptr; }
+    MC_OT("mc_build_index", t0);
     if (open_impl(h, marker_family, nfam, device) != 0) { std::string e = g_err; mc_close(h); g_err = e; return nullptr; }
+    MC_OT("open_impl (device side)", t0);
     return h;
 }
 
@@ -2786,8 +2798,11 @@ extern "C" int mc_set_run(mc_handle *h, int32_t read_len, double loge_thr, const
     if (!h) { g_err = "null handle"; return -1; }
     if (read_len < 18 || read_len > 3 * MC_MAXAA) { g_err = "read_len out of range (18..510)"; return -1; }
     HIPCK(hipSetDevice(h->device));
+    double t0 = mc_now();
     mc_fill_tables(h->hT, h->H, read_len, loge_thr);
+    MC_OT("set_run: tables", t0);
     if (mc_seg_fx_verify(h->hT, nullptr) != 0) { g_err = "internal: the fixed-point SEG tests disagree with the reference arithmetic"; return -1; }
+    MC_OT("set_run: seg_fx_verify", t0);
     memset(&h->hP, 0, sizeof h->hP);
     h->hP.nfam = h->nfam; h->hP.read_len = read_len;
     for (int f = 0; f < h->nfam; f++) { h->hP.min_cov[f] = min_cov[f]; h->hP.min_score[f] = min_score[f]; h->hP.max_aaid[f] = max_aaid[f]; h->hP.aln_stat[f] = aln_stat[f]; }
@@ -2802,12 +2817,14 @@ extern "C" int mc_set_run(mc_handle *h, int32_t read_len, double loge_thr, const
     const int newFP = ((read_len / 3 + 2) + 3) & ~3;
     if (newFP != h->FP || read_len != h->read_len) for (McCtx &c : h->ctx) c.cap_reads = 0;   // pools are sized by read length and frame pitch
     h->read_len = read_len; h->FP = newFP; h->run_set = true;
+    MC_OT("set_run: segtab, uploads", t0);
     return 0;
 }
 
 static int ensure_capacity(mc_handle *h, McCtx &c, int64_t nreads)
 {
     if (nreads <= c.cap_reads) return 0;
+    double t0 = mc_now();
     int64_t cap = nreads;
     if (cap > (1 << 21) - 1) { g_err = "batch larger than 2097151 reads"; return -1; }
     // pool sizes: generous multiples of what shotgun reads produce (75 seed hits, 23 kept HSPs, 5 gapped extensions per 150 bp
@@ -2839,6 +2856,8 @@ static int ensure_capacity(mc_handle *h, McCtx &c, int64_t nreads)
     HIPCK(hipMalloc(&c.d_sorttmp, bytes + 16));
     c.sorttmp_bytes = bytes;
     c.cap_reads = cap;
+    HIPCK(hipStreamSynchronize(c.stream));
+    MC_OT("ensure_capacity (pools)", t0);
     return 0;
 }
 
@@ -3276,6 +3295,7 @@ static int run_stream(mc_handle *h, const std::function<int64_t(uint8_t *, int64
 {
     HIPCK(hipSetDevice(h->device));
     const int64_t BMAX = MC_STREAM_BATCH, B = stream_batch(), L = h->read_len;
+    double t0 = mc_now();
     if (!h->stage_pin[0] || h->stage_len != L) {
         for (int k = 0; k < 2; k++) {
             if (h->stage_pin[k]) { (void)hipHostFree(h->stage_pin[k]); h->stage_pin[k] = nullptr; }
@@ -3285,6 +3305,7 @@ static int run_stream(mc_handle *h, const std::function<int64_t(uint8_t *, int64
         }
         if (!h->copy_stream) HIPCK(hipStreamCreate(&h->copy_stream));
         h->stage_len = (int)L;
+        MC_OT("run_stream: staging buffers", t0);
     }
     McBatchSlot slot[2];
     for (int k = 0; k < 2; k++) { slot[k].pin = h->stage_pin[k]; slot[k].dev = h->stage_dev[k]; }

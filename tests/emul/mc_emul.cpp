@@ -239,6 +239,28 @@ int main(int argc, char **argv)
     std::vector<McSeedTask> tasks; uint64_t lookups = 0, keyprobes = 0;
     for (size_t r = 0; r < rs.size(); r++)
         for (int f = 0; f < 6; f++) { Emit e{&tasks, (uint32_t)r, f, &X}; McSeedCount sc{0, 0, 0}; mc_enumerate_seeds(T, X, &frames[(r * 6 + f) * FP], flen[r * 6 + f], e, &sc); lookups += sc.lookups; keyprobes += sc.keyprobes; }
+    if (getenv("MC_SEG_STATS")) {   // design aid: what would SEG only for the frames with a seed hit save?  
+        std::vector<uint8_t> raw(FP, MC_INV);
+        std::vector<McSeedTask> t2;
+        long frames_n = 0, frames_hit = 0, frames_changed = 0, frames_hit_changed = 0, frames_rawhit = 0, frames_rawhit_changed = 0, raw_tasks = 0, raw_tasks_dropped = 0;
+        std::vector<uint8_t> hit(rs.size() * 6, 0);
+        for (const McSeedTask &t : tasks) hit[(size_t)t.read * 6 + (t.chrono >> 25)] = 1;
+        for (size_t r = 0; r < rs.size(); r++)
+            for (int f = 0; f < 6; f++) {
+                const int n = mc_translate_frame(T, (const uint8_t *)rs[r].data(), read_len, f, raw.data());
+                const uint8_t *m = &frames[(r * 6 + f) * FP];
+                const bool changed = memcmp(raw.data(), m, (size_t)n) != 0;
+                t2.clear();
+                Emit e{&t2, (uint32_t)r, f, &X}; McSeedCount sc{0, 0, 0};
+                mc_enumerate_seeds(T, X, raw.data(), n, e, &sc);
+                long dropped = 0;
+                for (const McSeedTask &t : t2) { const int pos = (int)((t.chrono >> 17) & 0xff), sl = (int)((t.seedlen_nkey >> 24) & 15); bool bad = false; for (int k = 0; k < sl; k++) bad |= m[pos + k] != raw[pos + k]; dropped += bad; }
+                frames_n++; frames_hit += hit[r * 6 + f]; frames_changed += changed; frames_hit_changed += hit[r * 6 + f] && changed;
+                frames_rawhit += !t2.empty(); frames_rawhit_changed += !t2.empty() && changed; raw_tasks += (long)t2.size(); raw_tasks_dropped += dropped;
+            }
+        fprintf(stderr, "seg-stats frames %ld; SEG masks something in %ld; with a seed hit %ld (masked frames), %ld (unmasked frames); with a hit AND masked %ld / %ld; seed hits on unmasked frames %ld, of them on a masked residue %ld (seed hits on masked frames %zu)\n",
+                frames_n, frames_changed, frames_hit, frames_rawhit, frames_hit_changed, frames_rawhit_changed, raw_tasks, raw_tasks_dropped, tasks.size());
+    }
     fprintf(stderr, "seed tasks: %zu (%.1f / read) lookups %.1f / read keyprobes %.1f / read\n", tasks.size(), (double)tasks.size() / std::max<size_t>(1, rs.size()), (double)lookups / std::max<size_t>(1, rs.size()), (double)keyprobes / std::max<size_t>(1, rs.size()));
     // stage 3: seed evaluation (+ ungapped) ; stage 4: gapped
     std::vector<McHsp> hsps; std::vector<McGapTask> gaps;
