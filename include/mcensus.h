@@ -55,6 +55,12 @@ int mc_device_count(void);
 mc_handle *mc_open(const char *const *names, const char *const *seqs, int32_t nseq,
                    const int32_t *marker_family, int32_t nfam, int32_t device);
 void mc_close(mc_handle *h);
+/* mc_open() spends half a second of host time building the index (buckets, suffix keys, filters) - more than the search of the
+ * reference's default run of 1 - 2 M reads (scripts/run_microbe_census.py:31: one run_pipeline per process).  With a cache directory
+ * set (process-wide; NULL or "": none) the built index is kept there in a file named by a hash of the marker names and sequences
+ * and read back by later mc_open() calls; a file that does not match its header, sizes, input hash and checksum is ignored and
+ * rebuilt.  The directory should be writable by the user alone (the Python layer uses ~/.cache/microbecensus_amd, mode 0700). */
+int mc_set_index_cache(const char *dir);
 
 /* The same from a database `prerapsearch` already wrote (the reference ships one as data/rapdb_2.15): residues, buckets,
  * posting order and suffix keys are taken from the file, the GPU-side structures derived from them.  All markers start in
@@ -168,6 +174,8 @@ int mc_reader_start(mc_reader *r);
 int64_t mc_reader_fetch(mc_reader *r, int64_t first, int64_t max_reads, uint8_t *dst);
 int64_t mc_reader_join(mc_reader *r);
 int32_t mc_reader_read_len(const mc_reader *r);
+/* the nreads the reader was opened with: how many reads it delivers at most (mc_search_files sizes its buffers by it) */
+int64_t mc_reader_nreads(const mc_reader *r);
 
 /* process_seqfile() + search_seqs() + classify_reads() in one call (microbe_census.py:328-460): the sampler runs beside the
  * search, batches of accepted reads go through pinned staging memory to the GPU while the batch before is searched.  Results as

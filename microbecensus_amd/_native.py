@@ -56,6 +56,7 @@ def load_library():
     lib.mc_open.restype = C.c_void_p
     lib.mc_open.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32]
     lib.mc_close.argtypes = [C.c_void_p]
+    lib.mc_set_index_cache.argtypes = [C.c_char_p]
     lib.mc_open_rapdb.restype = C.c_void_p
     lib.mc_open_rapdb.argtypes = [C.c_char_p, C.c_int32]
     lib.mc_marker_count.restype = C.c_int32
@@ -103,6 +104,8 @@ def load_library():
     lib.mc_reader_join.argtypes = [C.c_void_p]
     lib.mc_reader_read_len.restype = C.c_int32
     lib.mc_reader_read_len.argtypes = [C.c_void_p]
+    lib.mc_reader_nreads.restype = C.c_int64
+    lib.mc_reader_nreads.argtypes = [C.c_void_p]
     lib.mc_search_files.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.mc_search_files_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int64]
     lib.mc_set_keep_rows.argtypes = [C.c_void_p, C.c_int]
@@ -113,10 +116,10 @@ def load_library():
     return lib
 
 
-EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
+EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_set_index_cache", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
                     "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_set_parts", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8", "mc_write_m8_named",
                     "mc_reader_last_error", "mc_set_host_threads", "mc_reader_open", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_count_bases", "mc_quality_offset",
-                    "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows", "mc_set_best_hits_only", "mc_grid_classify"]
+                    "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_reader_nreads", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows", "mc_set_best_hits_only", "mc_grid_classify"]
 
 
 class ReferenceError_(Exception):
@@ -236,11 +239,44 @@ def load_model(path=None):
 ALN_STAT = {"hits": 0, "cov": 1, "aln": 2}
 
 
+def user_cache_dir():
+    """~/.cache/microbecensus_amd (XDG_CACHE_HOME honoured), created with mode 0700; None when it cannot be made or is not this
+    user's alone (owned by somebody else, or group / world writable) - nothing is cached then."""
+    root = os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "microbecensus_amd")
+    try:
+        os.makedirs(root, mode=0o700, exist_ok=True)
+        st = os.stat(root)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+            return None
+    except OSError:
+        return None
+    return root
+
+
+_index_cache_set = False
+
+
+def use_index_cache():
+    """Points mc_open() at the per-user cache of built indexes (once per process; MC_INDEX_CACHE=0 in the environment: no cache,
+    MC_INDEX_CACHE=<dir>: that directory)."""
+    global _index_cache_set
+    if _index_cache_set:
+        return
+    _index_cache_set = True
+    v = os.environ.get("MC_INDEX_CACHE")
+    if v == "0":
+        return
+    d = v if v else user_cache_dir()
+    if d:
+        load_library().mc_set_index_cache(d.encode())
+
+
 class Engine:
     """One MI355X: marker index resident in HBM + the search/classify pipeline."""
 
     def __init__(self, device=0, names=None, seqs=None, marker_family=None, nfam=None):
         lib = load_library()
+        use_index_cache()
         if names is None:
             names, seqs = load_markers()
             model = load_model()

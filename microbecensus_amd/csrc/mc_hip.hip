@@ -2598,7 +2598,7 @@ struct mc_handle {
     int parts = 1;                        // parts a range is cut into (mc_set_parts): 1 = one kernel at a time; 2 = two halves whose stages alternate
     bool keep_rows = true;                // mc_search / mc_search_files hand out the m8 rows (mc_set_keep_rows)
     bool best_only = false;               // only the reads that can be classified are ranked; no rows (mc_set_best_hits_only)
-    uint8_t *stage_pin[2] = {nullptr, nullptr}, *stage_dev[2] = {nullptr, nullptr}; int stage_len = 0; hipStream_t copy_stream = nullptr;   // run_stream
+    uint8_t *stage_pin[2] = {nullptr, nullptr}, *stage_dev[2] = {nullptr, nullptr}; size_t stage_bytes = 0; hipStream_t copy_stream = nullptr;   // run_stream
     // resident reads
     int64_t nreads = 0, cap_own = 0;
     uint8_t *d_reads = nullptr;
@@ -2720,13 +2720,37 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
     return 0;
 }
 
+// The directory mc_open() keeps built indexes in (mc_set_index_cache; empty: none).  Process-wide, set before the engines are opened.
+static std::mutex g_ixc_mu;
+static std::string g_ixc_dir;
+extern "C" int mc_set_index_cache(const char *dir)
+{
+    std::unique_lock<std::mutex> lk(g_ixc_mu);
+    g_ixc_dir = dir ? dir : "";
+    return 0;
+}
+
 extern "C" mc_handle *mc_open(const char *const *names, const char *const *seqs, int32_t nseq, const int32_t *marker_family, int32_t nfam, int32_t device)
 {
     mc_handle *h = new mc_handle();
     std::string err;
     double t0 = mc_now();
-    if (!mc_build_index(h->H, names, seqs, nseq, err)) { delete h; g_err = err; return nullptr; }
-    MC_OT("mc_build_index", t0);
+    std::string cache;
+    uint64_t ih = 0;
+    { std::unique_lock<std::mutex> lk(g_ixc_mu); cache = g_ixc_dir; }
+    bool loaded = false;
+    if (!cache.empty() && nseq > 0) {
+        ih = mc_ixc_input_hash(names, seqs, nseq);
+        char nm[64]; snprintf(nm, sizeof nm, "/index_%016llx.mcix", (unsigned long long)ih);
+        cache += nm;
+        loaded = mc_index_load(h->H, ih, nseq, cache.c_str());
+        MC_OT(loaded ? "index cache: loaded" : "index cache: none / not usable", t0);
+    }
+    if (!loaded) {
+        if (!mc_build_index(h->H, names, seqs, nseq, err)) { delete h; g_err = err; return nullptr; }
+        MC_OT("mc_build_index", t0);
+        if (!cache.empty()) { (void)mc_index_save(h->H, ih, cache.c_str()); MC_OT("index cache: written", t0); }
+    }
     if (open_impl(h, marker_family, nfam, device) != 0) { std::string e = g_err; mc_close(h); g_err = e; return nullptr; }
     MC_OT("open_impl (device side)", t0);
     return h;
@@ -2834,8 +2858,10 @@ static int ensure_capacity(mc_handle *h, McCtx &c, int64_t nreads)
     c.cap_tasks = (uint32_t)std::min<int64_t>(cap * (L + 32) + (1 << 20) + (int64_t)256 * 32 * MC_EN_BLK, 0x7fffffff);
     const int64_t ev_pad = (int64_t)256 * 8 * (MC_EV_BS / 64) * MC_EV_BLK;   // k_eval_seeds hands both pools out in blocks of MC_EV_BLK slots per wave: room for every wave's partly used last block
     c.cap_gaps = (uint32_t)std::min<int64_t>(cap * (L / 8 + 8) + (1 << 18) + ev_pad, (1 << 27) - 2);   // (k_gap_dedupe keeps task index + 1 in 27 bits of a table entry: more tasks than that overflow the pool and the range is split)
-    c.cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 2 + 16) + (1 << 20) + ev_pad, 0x7fffffff);
-    c.cap_rows = (uint32_t)std::min<int64_t>(cap * 48 + (1 << 20), 0x7fffffff);
+    // (round 4: HSPs L / 3 + 8 per read - 58 at 150 bp, where shotgun reads make 23 - instead of L / 2 + 16, rows 16 per read instead of 48:
+    // allocating the pools of a 1 M-read batch took 0.8 s, most of the wall time of the reference's default run; a denser batch is split)
+    c.cap_hsps = (uint32_t)std::min<int64_t>(cap * (L / 3 + 8) + (1 << 20) + ev_pad, 0x7fffffff);
+    c.cap_rows = (uint32_t)std::min<int64_t>(cap * 16 + (1 << 20), 0x7fffffff);
     c.gap_threads_full = 16 * 1024;                                 // full-size DP rows for the last-resort launch (460 MB)
     if (dalloc(&c.d_frames_base, (size_t)cap * 6 * h->FP + 128) || dalloc(&c.d_tasks, c.cap_tasks) ||
         dalloc(&c.d_gaps, c.cap_gaps) || dalloc(&c.d_hsps, c.cap_hsps) || dalloc(&c.d_v, c.cap_hsps) ||
@@ -3296,17 +3322,25 @@ static int run_stream(mc_handle *h, const std::function<int64_t(uint8_t *, int64
     HIPCK(hipSetDevice(h->device));
     const int64_t BMAX = MC_STREAM_BATCH, B = stream_batch(), L = h->read_len;
     double t0 = mc_now();
-    if (!h->stage_pin[0] || h->stage_len != L) {
+    // The largest batch of this run: a quarter of the reads the caller expects (a power of two between 256 k and 2 M; 2 M when it
+    // does not know).  Staging buffers and pools are sized for it ONCE, before the first batch - pinning 2 x 300 MB and allocating
+    // (then re-allocating, as the batches grew) the pools of ever larger batches was 1 s of the 1.2 - 2 s of the reference's
+    // default run, one run_pipeline of 1 - 2 M reads per process.
+    int64_t bmax_run = B;
+    if (B == BMAX && expect_reads > 0) { bmax_run = 262144; while (bmax_run < BMAX && bmax_run * 4 < expect_reads) bmax_run <<= 1; bmax_run = std::min(bmax_run, BMAX); }
+    const size_t stage_bytes = (size_t)(bmax_run * L + 64);
+    if (!h->stage_pin[0] || h->stage_bytes < stage_bytes) {
         for (int k = 0; k < 2; k++) {
             if (h->stage_pin[k]) { (void)hipHostFree(h->stage_pin[k]); h->stage_pin[k] = nullptr; }
             if (h->stage_dev[k]) { (void)hipFree(h->stage_dev[k]); h->stage_dev[k] = nullptr; }
-            HIPCK(hipHostMalloc((void **)&h->stage_pin[k], (size_t)(BMAX * L + 64), hipHostMallocDefault));
-            HIPCK(hipMalloc((void **)&h->stage_dev[k], (size_t)(BMAX * L + 64)));
+            HIPCK(hipHostMalloc((void **)&h->stage_pin[k], stage_bytes, hipHostMallocDefault));
+            HIPCK(hipMalloc((void **)&h->stage_dev[k], stage_bytes));
         }
-        if (!h->copy_stream) HIPCK(hipStreamCreate(&h->copy_stream));
-        h->stage_len = (int)L;
+        h->stage_bytes = stage_bytes;
         MC_OT("run_stream: staging buffers", t0);
     }
+    if (!h->copy_stream) HIPCK(hipStreamCreate(&h->copy_stream));
+    if (expect_reads > 0 && ensure_capacity(h, h->ctx[0], std::min<int64_t>(bmax_run, expect_reads))) return -1;
     McBatchSlot slot[2];
     for (int k = 0; k < 2; k++) { slot[k].pin = h->stage_pin[k]; slot[k].dev = h->stage_dev[k]; }
     std::mutex mu; std::condition_variable cv;
@@ -3321,7 +3355,7 @@ static int run_stream(mc_handle *h, const std::function<int64_t(uint8_t *, int64
             // The first batches are small - 256 k, 512 k, 1 M reads, then 2 M: the device starts after 4 ms of parsing instead of 33,
             // which is a third of the wall time of the default run (2 M sampled reads); later batches have the full size, where the
             // fixed cost of a range (~1 ms) no longer shows.
-            const int64_t want = B == BMAX ? std::min<int64_t>(B, (int64_t)262144 << std::min(nb, 3)) : B;
+            const int64_t want = B == BMAX ? std::min<int64_t>(bmax_run, (int64_t)262144 << std::min(nb, 3)) : B;
             nb++;
             const int64_t n = fetch(slot[k].pin, want, &at);
             int64_t rc = n;
@@ -3389,6 +3423,8 @@ extern "C" int mc_search_files_multi(mc_handle *const *handles, int32_t n_dev, m
         if (mc_reader_read_len(r) != handles[d]->read_len) { g_err = "the reader trims to another length than mc_set_run() was given"; return -1; }
     }
     if (mc_reader_start(r) != 0) { g_err = mc_reader_last_error(); return -1; }
+    const int64_t cap_reads = mc_reader_nreads(r);                  // the reads the sampler may deliver at most (args['nreads']): per device, what to size for
+    const int64_t expect = cap_reads > 0 && cap_reads < ((int64_t)1 << 40) ? (cap_reads + n_dev - 1) / n_dev : 0;
     std::mutex deal_mu;
     int64_t next = 0;
     bool ended = false;
@@ -3404,7 +3440,7 @@ extern "C" int mc_search_files_multi(mc_handle *const *handles, int32_t n_dev, m
             if (n < max_reads) { std::unique_lock<std::mutex> lk(deal_mu); ended = true; }
             *first = at;
             return n;
-        }, first_read_id);
+        }, first_read_id, expect);
         errs[(size_t)d] = !ferr.empty() ? ferr : std::string(rcs[(size_t)d] ? mc_last_error() : "");
     };
     std::vector<std::thread> th;

@@ -8,6 +8,8 @@
 // libstdc++ (GCC 4.4) introsort is restated here.  tests/test_index.py checks the result entry by entry
 // against a prerapsearch-built database.
 #pragma once
+#include <sys/stat.h>
+#include <unistd.h>
 #include "mc_core.h"
 #include <math.h>
 #include <stdio.h>
@@ -388,6 +390,99 @@ inline bool mc_write_rapdb(const McHostIndex &X, const char *path, std::string &
     f = fopen(ip.c_str(), "wb");
     if (!f || fwrite(b.data(), 1, b.size(), f) != b.size()) { if (f) fclose(f); err = "cannot write " + ip; return false; }
     fclose(f);
+    return true;
+}
+
+// ---- the built index as one file (the per-user cache of mc_open) ------------------------------------------------------------
+// mc_build_index takes half a second of host time per handle (buckets, suffix keys, filters, range table) - more than the search of
+// the reference's default run of 1 - 2 M reads.  The result is a pure function of the marker names and sequences, so it is kept in a
+// file named by a hash of those: header (magic, layout version, the hash, counts), the arrays as they lie in memory, a checksum of
+// the payload.  A file that does not match in every respect is ignored and rebuilt; it is written to a temporary name and renamed.
+#define MC_IXC_MAGIC 0x3158494D434D4D43ull      // "CMMCMIX1"
+#define MC_IXC_VERSION 4u
+inline uint64_t mc_ixc_input_hash(const char *const *names, const char *const *seqs, int nseq)
+{
+    uint64_t h = 0xCBF29CE484222325ull ^ (uint64_t)MC_IXC_VERSION;
+    for (int s = 0; s < nseq; s++) {
+        for (const char *p = names[s]; *p; p++) { h ^= (uint8_t)*p; h *= 0x100000001B3ull; }
+        h ^= 0xFF; h *= 0x100000001B3ull;
+        for (const char *p = seqs[s]; *p; p++) { h ^= (uint8_t)*p; h *= 0x100000001B3ull; }
+        h ^= 0xFE; h *= 0x100000001B3ull;
+    }
+    return h;
+}
+inline uint64_t mc_ixc_sum(const void *p, size_t bytes, uint64_t acc)
+{   // order-dependent sum of 64-bit words (the tail zero-padded): catches truncation and bit rot, not an adversary (the cache directory is the user's own)
+    const uint8_t *b = (const uint8_t *)p;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) { uint64_t w; memcpy(&w, b + i, 8); acc = (acc ^ w) * 0x9E3779B97F4A7C15ull + (acc >> 29); }
+    if (i < bytes) { uint64_t w = 0; memcpy(&w, b + i, bytes - i); acc = (acc ^ w) * 0x9E3779B97F4A7C15ull + (acc >> 29); }
+    return acc;
+}
+struct McIxcHeader { uint64_t magic; uint32_t version, nseq; uint64_t input_hash; uint64_t n[12]; uint32_t rt_mask, max_bucket, freq_thr, pad; double letter_p[10]; int64_t nres; uint64_t names_bytes; };
+#define MC_IXC_ARRAYS(X, F)                                                                                                                   \
+    F(0, (X).res_code) F(1, (X).res) F(2, (X).off) F(3, (X).bstart) F(4, (X).post) F(5, (X).keys) F(6, (X).bitmap) F(7, (X).rec) F(8, (X).filt) \
+    F(9, (X).wild) F(10, (X).pair) F(11, (X).rt)
+inline bool mc_index_save(const McHostIndex &X, uint64_t input_hash, const char *path)
+{
+    McIxcHeader H; memset(&H, 0, sizeof H);
+    H.magic = MC_IXC_MAGIC; H.version = MC_IXC_VERSION; H.nseq = (uint32_t)X.nseq; H.input_hash = input_hash;
+#define MC_F(i, v) H.n[i] = (uint64_t)(v).size();
+    MC_IXC_ARRAYS(X, MC_F)
+#undef MC_F
+    H.rt_mask = X.rt_mask; H.max_bucket = X.max_bucket; H.freq_thr = X.freq_thr; H.nres = X.nres;
+    for (int g = 0; g < 10; g++) H.letter_p[g] = X.letter_p[g];
+    std::string names;
+    for (const std::string &nm : X.names) { names += nm; names.push_back('\0'); }
+    H.names_bytes = names.size();
+    const std::string tmp = std::string(path) + ".tmp" + std::to_string((long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    uint64_t sum = mc_ixc_sum(&H, sizeof H, 0);
+    bool ok = fwrite(&H, sizeof H, 1, f) == 1;
+    ok = ok && (names.empty() || fwrite(names.data(), 1, names.size(), f) == names.size());
+    sum = mc_ixc_sum(names.data(), names.size(), sum);
+#define MC_F(i, v) { const size_t b_ = (v).size() * sizeof((v)[0]); ok = ok && (b_ == 0 || fwrite((v).data(), 1, b_, f) == b_); sum = mc_ixc_sum((v).data(), b_, sum); }
+    MC_IXC_ARRAYS(X, MC_F)
+#undef MC_F
+    ok = ok && fwrite(&sum, 8, 1, f) == 1;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return false; }
+    return true;
+}
+inline bool mc_index_load(McHostIndex &X, uint64_t input_hash, int nseq, const char *path)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    McIxcHeader H;
+    bool ok = fread(&H, sizeof H, 1, f) == 1 && H.magic == MC_IXC_MAGIC && H.version == MC_IXC_VERSION && H.input_hash == input_hash && (int)H.nseq == nseq;
+    if (ok) {   // the sizes must add up to the file's
+        uint64_t want = sizeof H + H.names_bytes + 8;
+        const size_t es[12] = {1, 1, 4, 4, 4, 2, 4, sizeof(McBucketRec), 4, 4, 4, 8};
+        for (int i = 0; i < 12; i++) { if (H.n[i] > (1ull << 32)) ok = false; want += H.n[i] * es[i]; }
+        struct stat sb;
+        ok = ok && fstat(fileno(f), &sb) == 0 && (uint64_t)sb.st_size == want && H.names_bytes < (1ull << 30);
+    }
+    uint64_t sum = 0;
+    std::string names;
+    if (ok) {
+        sum = mc_ixc_sum(&H, sizeof H, 0);
+        names.resize((size_t)H.names_bytes);
+        ok = names.empty() || fread(&names[0], 1, names.size(), f) == names.size();
+        sum = mc_ixc_sum(names.data(), names.size(), sum);
+    }
+#define MC_F(i, v) if (ok) { (v).resize((size_t)H.n[i]); const size_t b_ = (v).size() * sizeof((v)[0]); ok = b_ == 0 || fread((v).data(), 1, b_, f) == b_; sum = mc_ixc_sum((v).data(), b_, sum); }
+    MC_IXC_ARRAYS(X, MC_F)
+#undef MC_F
+    uint64_t stored = 0;
+    ok = ok && fread(&stored, 8, 1, f) == 1 && stored == sum;
+    fclose(f);
+    if (!ok) return false;
+    X.names.clear();
+    for (size_t at = 0; at < names.size();) { const size_t l = strlen(names.c_str() + at); X.names.emplace_back(names.c_str() + at, l); at += l + 1; }
+    if ((int)X.names.size() != nseq) return false;
+    X.nseq = nseq; X.rt_mask = H.rt_mask; X.max_bucket = H.max_bucket; X.freq_thr = H.freq_thr; X.nres = H.nres;
+    for (int g = 0; g < 10; g++) X.letter_p[g] = H.letter_p[g];
     return true;
 }
 

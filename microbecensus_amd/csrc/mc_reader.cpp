@@ -1009,3 +1009,4 @@ extern "C" int64_t mc_reader_join(mc_reader *r)
 }
 
 extern "C" int32_t mc_reader_read_len(const mc_reader *r) { return r ? r->L : 0; }
+extern "C" int64_t mc_reader_nreads(const mc_reader *r) { return r ? r->nreads : 0; }

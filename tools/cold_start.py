@@ -17,7 +17,7 @@ cli = os.path.join(REPO, "scripts", "run_microbe_census.py")
 for rep in range(reps):
     out = os.path.join(td, "out%d.txt" % rep)
     t = time.time()
-    subprocess.check_call([sys.executable, cli, "-n", str(n), fq, out])
+    subprocess.check_call([sys.executable, cli, "-n", str(n), fq, out], env=dict(os.environ, MC_OPEN_TIMING="1") if rep % 2 else None)
     dt = time.time() - t
     ags = [l for l in open(out) if l.startswith("average_genome_size")][0].strip()
     print("cold CLI run %d: %.3f s  (%s)" % (rep, dt, ags), flush=True)
