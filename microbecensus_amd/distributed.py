@@ -82,19 +82,52 @@ def _stream_batch():
     return v if 1000 <= v <= STREAM_BATCH else STREAM_BATCH
 
 
+_stream_seq = [0]
+
+
+def _control_store():
+    """The key-value store of the process group (a TCPStore), under a prefix of this stream's own: the small control messages -
+    batch headers from rank 0, credits from the ranks - travel through it, beside the payloads (RCCL or gloo send / recv).  The
+    store's get blocks until a key exists and its add is an atomic counter: exactly what headers and credits need, from any thread,
+    with nothing posted on the process group that could queue behind (or deadlock with) a GPU transfer.  (gloo's irecv cannot be
+    polled - is_completed() stays false until wait() - so credits cannot be gathered from several ranks with point-to-point messages.)
+    Every rank calls this at the same point of the run."""
+    import torch.distributed as dist
+    from torch.distributed import distributed_c10d as c10d
+    _stream_seq[0] += 1
+    return dist.PrefixStore("mcensus_stream_%d" % _stream_seq[0], c10d._get_default_store())
+
+
+def _store_wait_get(store, key):
+    """store.get that waits as long as it takes (a sampler may take minutes between batches; the store's own time-out raises)"""
+    import datetime
+    while True:
+        try:
+            store.wait([key], datetime.timedelta(seconds=30))
+            return store.get(key)
+        except Exception as e:                                      # noqa: BLE001 - a time-out: ask again
+            if "imeout" not in str(e) and "imed out" not in str(e):
+                raise
+
+
 class _Dealer:
     """Rank 0's side of the streamed multi-GPU pipeline: the native sampler runs on its own thread (mc_reader_start); this
-    thread fetches batches of accepted reads as they appear (mc_reader_fetch, straight into pinned memory) and deals batch k to
-    rank k mod world - over RCCL from a GPU staging buffer, over gloo from host memory; the batches of rank 0 itself go into a
-    local queue.  Nothing waits for the whole library: sampling, dealing and searching overlap, and no rank ever holds more than
-    two batches.  A header (reads in the batch, index of its first read) precedes every batch; (0, n_total) ends the stream,
-    (-1, 0) reports a sampler error."""
+    thread fetches batches of accepted reads as they appear (mc_reader_fetch, straight into pinned memory) and deals every
+    batch to the next rank that is FREE - over RCCL from a GPU staging buffer, over gloo from host memory; the batches of rank 0
+    itself go into a local queue.  A rank is free when it holds a credit: every rank starts with two (its two buffers) and
+    returns one whenever it has finished a batch - a slow rank (a busy GPU, a throttled one) simply asks less often instead of
+    holding up the stream, which dealing round robin (round 3) did.  Nothing waits for the whole library: sampling, dealing and
+    searching overlap, and no rank ever holds more than two batches.  A header (reads in the batch, index of its first read)
+    precedes every batch; (0, n_total) ends the stream, (-1, 0) reports a sampler error.  Headers and credits go through the
+    process group's store (_control_store), payloads over the group itself."""
 
-    def __init__(self, reader, read_len, world, nccl, dev, local_q):
+    def __init__(self, reader, read_len, world, nccl, dev, local_q, store):
         import threading
-        self.rd, self.L, self.world, self.nccl, self.dev, self.q = reader, read_len, world, nccl, dev, local_q
+        self.rd, self.L, self.world, self.nccl, self.dev, self.q, self.store = reader, read_len, world, nccl, dev, local_q, store
         self.error, self.n_total = None, 0
-        self.trace = []                                            # (what, batch, t0, t1): the test of the overlap reads it
+        self.trace = []                                            # (what, batch, t0, t1[, dst]): the tests read it
+        self.local_credit = 2
+        self.lock = threading.Lock()
         self.th = threading.Thread(target=self._run, daemon=True)
 
     def start(self):
@@ -103,6 +136,10 @@ class _Dealer:
     def join(self):
         self.th.join()
 
+    def local_done(self):
+        with self.lock:
+            self.local_credit += 1
+
     def _run(self):
         import ctypes as C
         import threading
@@ -110,22 +147,27 @@ class _Dealer:
         import torch
         import torch.distributed as dist
         lib, r, L, B = self.rd.lib, self.rd.r, self.L, _stream_batch()
+        if self.nccl:
+            torch.cuda.set_device(self.dev)                        # (the current device is per thread: the staging copies and their stream belong to this rank's GPU)
         pin = torch.cuda.is_available()
-        bufs = [torch.empty(B * L, dtype=torch.uint8, pin_memory=pin) for _ in range(2)]
-        stage = [torch.empty(B * L, dtype=torch.uint8, device=self.dev) for _ in range(2)] if self.nccl else None
-        pending = [None, None]                                     # the send that last used buffer i
-        hdr_dev = self.dev if self.nccl else torch.device("cpu")
+        NB = 3
+        bufs = [torch.empty(B * L, dtype=torch.uint8, pin_memory=pin) for _ in range(NB)]
+        stage = [torch.empty(B * L, dtype=torch.uint8, device=self.dev) for _ in range(NB)] if self.nccl else None
+        pending = [None] * NB                                      # what still uses buffer i
+        world, store = self.world, self.store
+        sent = [0] * world                                         # batches dealt to rank w (= headers written for it)
+        last = world - 1
         try:
             if lib.mc_reader_start(r) != 0:
                 raise RuntimeError(lib.mc_reader_last_error().decode())
             at, k = 0, 0
             while True:
-                i = k % 2
+                i = k % NB
                 if pending[i] is not None:
                     for w in pending[i]:
                         w.wait()
                     if self.nccl:
-                        torch.cuda.current_stream().synchronize()
+                        torch.cuda.current_stream(self.dev).synchronize()
                     pending[i] = None
                 t0 = time.time()
                 n = lib.mc_reader_fetch(r, at, B, C.c_void_p(bufs[i].data_ptr()))
@@ -135,20 +177,34 @@ class _Dealer:
                     raise _SamplerError(lib.mc_reader_last_error().decode(), n)
                 if n == 0:
                     break
-                dst = k % self.world
+                dst = -1
+                while dst < 0:                                      # the next free rank, in turn
+                    for j in range(1, world + 1):
+                        w = (last + j) % world
+                        if w == 0:
+                            with self.lock:
+                                if self.local_credit > 0:
+                                    self.local_credit -= 1; dst = 0
+                        elif store.add("c%d" % w, 0) > sent[w]:    # (credits the rank has given so far: 2 + the batches it has finished)
+                            dst = w
+                        if dst >= 0:
+                            break
+                    if dst < 0:
+                        time.sleep(0.0005)
+                last = dst
                 if dst == 0:                                       # rank 0's own batch: searched from the pinned buffer, which comes back with the event
                     done = threading.Event()
                     self.q.put((bufs[i][: n * L].numpy().reshape(n, L), at, done))
                     pending[i] = [done]
                 else:
-                    hdr = torch.tensor([n, at], dtype=torch.int64, device=hdr_dev)
+                    store.set("h%d/%d" % (dst, sent[dst]), "%d,%d" % (n, at))
                     payload = bufs[i][: n * L]
                     if self.nccl:
                         stage[i][: n * L].copy_(payload, non_blocking=True)
                         payload = stage[i][: n * L]
-                    pending[i] = [dist.isend(hdr, dst), dist.isend(payload, dst)]
-                    pending[i].append(_Keep(hdr))
-                self.trace.append(("deal", k, t1, time.time()))
+                    pending[i] = [dist.isend(payload, dst)]
+                    sent[dst] += 1
+                self.trace.append(("deal", k, t1, time.time(), dst))
                 at += n
                 k += 1
             for p in pending:
@@ -159,29 +215,18 @@ class _Dealer:
             if total < 0:
                 raise _SamplerError(lib.mc_reader_last_error().decode(), total)
             self.n_total = int(total)
-            end = [int(0), self.n_total]
+            end = (0, self.n_total)
         except _SamplerError as e:
             self.error = e
-            end = [-1, 0]
+            end = (-1, 0)
         except BaseException as e:                                  # noqa: BLE001 - reported by the main thread
             self.error = e
-            end = [-1, 0]
+            end = (-1, 0)
         try:
-            import torch.distributed as dist2
-            for dst in range(1, self.world):
-                dist2.send(torch.tensor(end, dtype=torch.int64, device=hdr_dev), dst)
+            for dst in range(1, world):
+                store.set("h%d/%d" % (dst, sent[dst]), "%d,%d" % end)
         finally:
             self.q.put(None)
-
-
-class _Keep:
-    """keeps a tensor alive until its asynchronous send has been waited for"""
-
-    def __init__(self, t):
-        self.t = t
-
-    def wait(self):
-        self.t = None
 
 
 class _SamplerError(Exception):
@@ -190,35 +235,117 @@ class _SamplerError(Exception):
         self.code = code
 
 
-def _receive_batches(read_len, nccl, dev, q):
-    """A rank > 0: receives (header, batch) pairs from rank 0 into two buffers in turn and queues them for the searching thread;
-    returns the total number of sampled reads (the end header carries it), or raises what rank 0 reported."""
+def _receive_batches(read_len, nccl, dev, q, store, rank):
+    """A rank > 0: gives rank 0 two credits (its two buffers; the searching thread gives one more whenever it has finished with a
+    buffer), waits for the headers rank 0 writes for it, receives every batch into a free buffer and queues it for the searching
+    thread; returns the total number of sampled reads (the end header carries it), or raises what rank 0 reported."""
+    import threading
     import torch
     import torch.distributed as dist
     B, L = _stream_batch(), read_len
     rdev = dev if nccl else torch.device("cpu")
+    if nccl:
+        torch.cuda.set_device(dev)
     bufs = [torch.empty(B * L, dtype=torch.uint8, device=rdev) for _ in range(2)]
-    free = [None, None]                                             # events the searching thread sets when it is done with buffer i
-    import threading
-    k = 0
+    busy = [None, None]                                             # the event the searching thread sets when it is done with buffer i
+    store.add("c%d" % rank, 2)
+    j = 0
     while True:
-        hdr = torch.empty(2, dtype=torch.int64, device=rdev)
-        dist.recv(hdr, 0)
-        n, first = [int(v) for v in hdr.cpu().tolist()]
+        n, first = [int(v) for v in _store_wait_get(store, "h%d/%d" % (rank, j)).decode().split(",")]
+        j += 1
         if n <= 0:
             q.put(None)
             if n < 0:
                 raise Exception("the sampler on rank 0 failed")
             return first
-        i = k % 2
-        if free[i] is not None:
-            free[i].wait()
+        i = 0 if (busy[0] is None or busy[0].is_set()) else 1       # (rank 0 deals only against credits: a buffer is free)
         dist.recv(bufs[i][: n * L], 0)
         if nccl:
-            torch.cuda.current_stream().synchronize()               # the engine launches on its own streams: the batch must have landed
-        free[i] = threading.Event()
-        q.put((bufs[i][: n * L], first, free[i]))
-        k += 1
+            torch.cuda.current_stream(dev).synchronize()            # the engine launches on its own streams: the batch must have landed
+        busy[i] = threading.Event()
+        q.put((bufs[i][: n * L], first, busy[i]))
+
+
+def stream_batches(reader, read_len, on_batch, device=None):
+    """The streamed dealing by itself: rank 0 samples with `reader` (None on the other ranks) and deals batches to whoever is
+    free; on every rank on_batch(block, first_read_id) is called for the batches it gets - block: (n, read_len) uint8 numpy array
+    (host memory), or with RCCL on ranks > 0 a 1-D uint8 torch tensor in this rank's HBM.  Returns (n_total, dealer trace or None,
+    error or None) - the error already agreed on by all ranks.  run_pipeline_distributed searches the batches; the tests check
+    the dealing with plain checksums (no GPU needed)."""
+    import os
+    import queue
+    import threading
+    import time
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    nccl = dist.is_initialized() and dist.get_backend() == "nccl"
+    dev = torch.device("cuda", device) if nccl else None
+    store = _control_store() if world > 1 else None
+    q = queue.Queue(maxsize=2)
+    errs = []
+    slow = os.environ.get("MC_DIST_SLOW", "")                      # "<rank>:<milliseconds>": that rank dawdles after every batch (tests)
+    slow_s = float(slow.split(":")[1]) / 1e3 if slow and int(slow.split(":")[0]) == rank else 0.0
+    dealer = None
+
+    def loop():
+        while True:
+            item = q.get()
+            if item is None:
+                return
+            try:
+                if not errs:
+                    on_batch(item[0], item[1])
+                    if slow_s:
+                        time.sleep(slow_s)
+            except BaseException as e:                             # noqa: BLE001
+                errs.append(e)
+            finally:                                               # (keep draining so that the dealer / receiver never blocks)
+                item[2].set()
+                if dealer is not None:
+                    dealer.local_done()
+                elif store is not None:
+                    store.add("c%d" % rank, 1)                     # a credit: this rank can take another batch
+
+    worker = threading.Thread(target=loop, daemon=True)
+    n_total, trace, status = 0, None, [0, -1, ""]
+    if rank == 0:
+        dealer = _Dealer(reader, read_len, world, nccl, dev, q, store)
+        worker.start()
+        dealer.start()
+        dealer.join()
+        worker.join()
+        trace = dealer.trace
+        if dealer.error is not None:
+            status = [-1, -1, str(dealer.error)] if isinstance(dealer.error, _SamplerError) and dealer.error.code == -3 else [-2, -1, str(dealer.error)]
+        else:
+            status = [dealer.n_total, 0, ""]
+    else:
+        worker.start()
+        try:
+            _receive_batches(read_len, nccl, dev, q, store, rank)
+        except Exception:
+            pass                                                   # rank 0 broadcasts what happened
+        worker.join()
+    # every rank learns how the stream ended AND whether any rank failed while searching: all raise together (a rank that raised
+    # alone left the others waiting in the all_reduce)
+    if world > 1:
+        dist.broadcast_object_list(status, src=0)
+        flags = [None] * world
+        dist.all_gather_object(flags, str(errs[0]) if errs else "")
+        bad = [f for f in flags if f]
+    else:
+        bad = [str(errs[0])] if errs else []
+    err = None
+    if status[0] == -1:
+        err = Exception(status[2])                                 # the reference raises inside run_pipeline
+    elif status[0] < 0:
+        err = RuntimeError(status[2])
+    elif bad:
+        err = errs[0] if errs else RuntimeError("a rank failed while searching: " + bad[0])
+    n_total = max(0, status[0])
+    return n_total, trace, err
 
 
 def run_pipeline_distributed(args, device=None):
@@ -259,73 +386,43 @@ def run_pipeline_distributed(args, device=None):
         fams = model["families"]
         eng = mc._engine(device)
         eng.set_run(L, model["pars"][str(L)], fams)
-        q = queue.Queue(maxsize=1 if rank else 2)
-        parts, search_err = [], []
+        parts = []
 
-        def search_loop():                                                     # this rank's batches, as they arrive
-            try:
-                eng.lib.mc_set_keep_rows(eng.h, 0)
-                while True:
-                    item = q.get()
-                    if item is None:
-                        return
-                    if search_err:
-                        if len(item) > 2:
-                            item[2].set()
-                        continue                                               # (keep draining so that the dealer / receiver never blocks)
-                    try:
-                        if rank == 0 or not nccl:
-                            blk = item[0] if rank == 0 else item[0].numpy().reshape(-1, L)             # (host memory: rank 0's own batch, or gloo)
-                            eng.search(blk, first_read_id=item[1])
-                        else:                                                  # the batch is already in this GPU's HBM
-                            n = item[0].numel() // L
-                            eng.attach(item[0].data_ptr(), n)
-                            eng.run_range(0, n, first_read_id=item[1])
-                            eng.attach(0, 0)
-                        parts.append(eng.best_hits())
-                    except BaseException as e:                                 # noqa: BLE001
-                        search_err.append(e)
-                    finally:
-                        if len(item) > 2:
-                            item[2].set()
-            finally:
-                eng.lib.mc_set_keep_rows(eng.h, 1)
+        def on_batch(block, first):
+            if isinstance(block, np.ndarray):                                  # host memory: rank 0's own batch
+                eng.search(block, first_read_id=first)
+            elif not nccl:                                                     # gloo: a host tensor
+                eng.search(block.numpy().reshape(-1, L), first_read_id=first)
+            else:                                                              # the batch is already in this GPU's HBM
+                n = block.numel() // L
+                eng.attach(block.data_ptr(), n)
+                try:
+                    eng.run_range(0, n, first_read_id=first)
+                finally:
+                    eng.attach(0, 0)
+            parts.append(eng.best_hits())
 
-        worker = threading.Thread(target=search_loop, daemon=True)
-        worker.start()
-        head = [0, -1, ""]
         rd = None
+        eng.lib.mc_set_keep_rows(eng.h, 0)
         try:
             if rank == 0:
                 rd = _native.Reader(args["seqfiles"], L, args["nreads"], args["file_type"] == "fastq", args.get("quality_offset") or 0,
                                     args["min_quality"], args["mean_quality"], args["max_unknown"], args["filter_dups"])
-                dealer = _Dealer(rd, L, world, nccl, dev, q)
-                dealer.start()
-                dealer.join()
-                worker.join()
-                run_pipeline_distributed.last_trace = dealer.trace
-                if dealer.error is not None:
-                    head = [-1, -1, str(dealer.error)] if isinstance(dealer.error, _SamplerError) and dealer.error.code == -3 else [-2, -1, str(dealer.error)]
-                else:
-                    st = rd.stats()
-                    head = [dealer.n_total, int(st["bases"]) if st.get("exhausted") else -1, ""]
-            else:
-                try:
-                    _receive_batches(L, nccl, dev, q)
-                except Exception:
-                    pass                                                       # rank 0 broadcasts what happened
-                worker.join()
+            n_total, trace, err = stream_batches(rd, L, on_batch, device=device)
+            run_pipeline_distributed.last_trace = trace
+            bases = -1
+            if rank == 0 and err is None:
+                st = rd.stats()
+                bases = int(st["bases"]) if st.get("exhausted") else -1
         finally:
+            eng.lib.mc_set_keep_rows(eng.h, 1)
             if rd is not None:
                 rd.close()
+        if err is not None:
+            raise err
+        head = [n_total, bases]
         if world > 1:
             dist.broadcast_object_list(head, src=0)
-        if head[0] == -1:
-            raise Exception(head[2])                                           # the reference raises inside run_pipeline
-        if head[0] < 0:
-            raise RuntimeError(head[2])
-        if search_err:
-            raise search_err[0]
         n_total = head[0]
         if n_total == 0:
             sys.exit("\nError! No reads remaining after filtering!")

@@ -67,3 +67,60 @@ def test_shard_bounds_cover_everything():
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+DEAL_WORKER = r'''
+import json, os, sys, zlib
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from microbecensus_amd import distributed as D
+from microbecensus_amd import _native
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+path = os.path.join(sys.argv[1], "tests", "golden", "inputs", "metagenome.fa.gz")
+got = []
+def on_batch(block, first):
+    a = block if isinstance(block, np.ndarray) else block.numpy().reshape(-1, 100)
+    got.append((int(first), int(a.shape[0]), zlib.crc32(a.tobytes())))
+rd = _native.Reader([path], 100, 1000000, False, 0, -5, -5, 100, False) if rank == 0 else None
+n_total, trace, err = D.stream_batches(rd, 100, on_batch)
+if rd is not None:
+    rd.close()
+all_got = [None] * world
+dist.all_gather_object(all_got, got)
+if rank == 0:
+    json.dump({"n_total": n_total, "err": None if err is None else str(err), "batches": all_got, "deals": [t[4] for t in trace if t[0] == "deal"]}, open(sys.argv[2], "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_batches_are_dealt_to_free_ranks(tmp_path):
+    """stream_batches with three ranks (gloo, no GPU): rank 0 samples the reference's unit-test metagenome and deals 2,000-read
+    batches to whoever holds a credit; rank 1 dawdles 60 ms after every batch.  Every read arrives exactly once with its global index
+    (the batches tile [0, sampled) and carry the bytes the plain sampler returns), and the slow rank is simply dealt fewer batches
+    than the others instead of holding up the stream (round 3 dealt batch k to rank k mod N)."""
+    import zlib
+    from microbecensus_amd import _native
+    worker = tmp_path / "deal.py"
+    worker.write_text(DEAL_WORKER)
+    out = tmp_path / "deal.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MC_DIST_BATCH="2000", MC_DIST_SLOW="1:60")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                           "--master-port", "29519", str(worker), REPO, str(out)], env=env, timeout=600)
+    res = json.load(open(out))
+    g = json.load(open(os.path.join(GOLD, "unittest_metagenome.json")))
+    assert res["err"] is None and res["n_total"] == g["sampled_reads"]
+    want, st = _native.sample_reads([os.path.join(GOLD, "inputs", "metagenome.fa.gz")], 100, 1000000, False, 0, -5, -5, 100, False)
+    pieces = sorted(tuple(b) for per_rank in res["batches"] for b in per_rank)
+    at = 0
+    for first, n, crc in pieces:                                  # the batches tile the sampled reads, in order, bytes intact
+        assert first == at and crc == zlib.crc32(want[first:first + n].tobytes())
+        at += n
+    assert at == g["sampled_reads"] == len(want)
+    per_rank = [len(b) for b in res["batches"]]
+    assert sum(per_rank) == len(res["deals"]) == -(-g["sampled_reads"] // 2000)
+    assert [res["deals"].count(r) for r in range(3)] == per_rank
+    assert per_rank[1] < per_rank[0] and per_rank[1] < per_rank[2], per_rank      # the slow rank asked less often
+    assert per_rank[1] >= 2                                       # ... but was not starved (it held two credits from the start)

@@ -33,6 +33,61 @@ def _args(case):
     return a
 
 
+# (the RCCL test first: a multi-GPU box that runs this file reaches it whatever happens later)
+def _two_ranks(tmp_path, backend, port):
+    worker = tmp_path / "w.py"
+    worker.write_text(r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+from microbecensus_amd import distributed as D
+backend = sys.argv[3]
+local = int(os.environ["LOCAL_RANK"])
+if backend == "nccl":
+    torch.cuda.set_device(local)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+else:
+    dist.init_process_group(backend="gloo")
+inp = os.path.join(sys.argv[1], "tests", "golden", "inputs")
+est, args = D.run_pipeline_distributed({"seqfiles": [os.path.join(inp, "c4_pair_1.fq.gz"), os.path.join(inp, "c4_pair_2.fq.gz")], "nreads": 20000},
+                                       device=local if backend == "nccl" else 0)
+if dist.get_rank() == 0:
+    tr = D.run_pipeline_distributed.last_trace
+    json.dump({"est": est, "sampled": args["sampled_reads"], "L": args["read_length"], "world": dist.get_world_size(), "backend": dist.get_backend(),
+               "deals": sum(1 for t in tr if t[0] == "deal")}, open(sys.argv[2], "w"))
+dist.barrier()
+dist.destroy_process_group()
+''')
+    out = tmp_path / "o.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MC_DIST_BATCH="3000")   # 20,000 reads dealt in 7 batches
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), str(worker), REPO, str(out), backend], env=env, timeout=900)
+    return json.load(open(out))
+
+
+def test_config4_shape_two_ranks_rccl(tmp_path):
+    """The same over RCCL (backend "nccl") with one GPU per rank: batches dealt GPU to GPU (isend / recv), all_reduce of the
+    per-family sums.  Needs two GPUs."""
+    from microbecensus_amd import _native
+    if _native.load_library().mc_device_count() < 2:              # (asked of the HIP library this process already uses, not of torch)
+        pytest.skip("needs two GPUs (the driver's multi-GPU node)")
+    g = json.load(open(os.path.join(GOLD, "c4_paired.json")))
+    res = _two_ranks(tmp_path, "nccl", 29543)
+    assert res["backend"] == "nccl" and res["world"] == 2 and res["sampled"] == g["sampled_reads"]
+    assert abs(res["est"] - g["est_ags"]) <= 1e-9 * g["est_ags"]
+
+
+def test_config4_shape_two_ranks_gloo(tmp_path):
+    """The paired library given as `a,b` through run_pipeline_distributed with two ranks (both on this box's GPU, gloo): rank 0
+    samples and deals batches to the two ranks while it samples, the reduced per-family sums give the reference's AGS for the same pair."""
+    g = json.load(open(os.path.join(GOLD, "c4_paired.json")))
+    res = _two_ranks(tmp_path, "gloo", 29541)
+    assert res["world"] == 2 and res["sampled"] == g["sampled_reads"] and res["L"] == 150
+    assert res["deals"] == 7                                      # streamed: 3,000-read batches dealt round robin while the sampler runs
+    assert abs(res["est"] - g["est_ags"]) <= 1e-9 * g["est_ags"]
+
+
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_stage_by_stage_against_the_reference(case):
     """sampler -> search -> classification -> aggregation -> estimate: the temp FASTA, the m8 file, the best hits, the
@@ -79,60 +134,6 @@ def test_run_pipeline_over_several_handles_in_one_process(monkeypatch):
     est, out = mc.run_pipeline(args)
     assert out["sampled_reads"] == g["sampled_reads"] and est == g["est_ags"]
     assert sorted(k for k in mc._engines if isinstance(k, tuple)) == [(0, 1), (0, 2)]     # (the extra handles are opened side by side: any order)
-
-
-def _two_ranks(tmp_path, backend, port):
-    worker = tmp_path / "w.py"
-    worker.write_text(r'''
-import json, os, sys
-sys.path.insert(0, sys.argv[1])
-import torch
-import torch.distributed as dist
-from microbecensus_amd import distributed as D
-backend = sys.argv[3]
-local = int(os.environ["LOCAL_RANK"])
-if backend == "nccl":
-    torch.cuda.set_device(local)
-    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-else:
-    dist.init_process_group(backend="gloo")
-inp = os.path.join(sys.argv[1], "tests", "golden", "inputs")
-est, args = D.run_pipeline_distributed({"seqfiles": [os.path.join(inp, "c4_pair_1.fq.gz"), os.path.join(inp, "c4_pair_2.fq.gz")], "nreads": 20000},
-                                       device=local if backend == "nccl" else 0)
-if dist.get_rank() == 0:
-    tr = D.run_pipeline_distributed.last_trace
-    json.dump({"est": est, "sampled": args["sampled_reads"], "L": args["read_length"], "world": dist.get_world_size(), "backend": dist.get_backend(),
-               "deals": sum(1 for t in tr if t[0] == "deal")}, open(sys.argv[2], "w"))
-dist.barrier()
-dist.destroy_process_group()
-''')
-    out = tmp_path / "o.json"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MC_DIST_BATCH="3000")   # 20,000 reads dealt in 7 batches
-    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                           "--master-port", str(port), str(worker), REPO, str(out), backend], env=env, timeout=900)
-    return json.load(open(out))
-
-
-def test_config4_shape_two_ranks_gloo(tmp_path):
-    """The paired library given as `a,b` through run_pipeline_distributed with two ranks (both on this box's GPU, gloo): rank 0
-    samples and deals batches to the two ranks while it samples, the reduced per-family sums give the reference's AGS for the same pair."""
-    g = json.load(open(os.path.join(GOLD, "c4_paired.json")))
-    res = _two_ranks(tmp_path, "gloo", 29541)
-    assert res["world"] == 2 and res["sampled"] == g["sampled_reads"] and res["L"] == 150
-    assert res["deals"] == 7                                      # streamed: 3,000-read batches dealt round robin while the sampler runs
-    assert abs(res["est"] - g["est_ags"]) <= 1e-9 * g["est_ags"]
-
-
-def test_config4_shape_two_ranks_rccl(tmp_path):
-    """The same over RCCL (backend "nccl") with one GPU per rank: batches dealt GPU to GPU (isend / recv), all_reduce of the
-    per-family sums.  Needs two GPUs."""
-    from microbecensus_amd import _native
-    if _native.load_library().mc_device_count() < 2:              # (asked of the HIP library this process already uses, not of torch)
-        pytest.skip("needs two GPUs (the driver's multi-GPU node)")
-    g = json.load(open(os.path.join(GOLD, "c4_paired.json")))
-    res = _two_ranks(tmp_path, "nccl", 29543)
-    assert res["backend"] == "nccl" and res["world"] == 2 and res["sampled"] == g["sampled_reads"]
-    assert abs(res["est"] - g["est_ags"]) <= 1e-9 * g["est_ags"]
 
 
 def test_config2_full_size_batch_split_invariance():
