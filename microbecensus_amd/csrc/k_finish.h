@@ -1,0 +1,478 @@
+// k_finish.h - stage D: per-read finishing (SumEvalue@0x408a50, PrintRes@0x409310, MergeRes@0x40e3b0, classify_reads
+// microbe_census.py:432-460): a thread per read (k_finish) or a wave per read (k_finish_heavy, k_heap_lanes, k_heavy_rows), rows out.
+#pragma once
+#include "mc_hip_common.h"
+
+#ifndef MC_FH_MIN
+#define MC_FH_MIN 96
+#endif
+#ifndef MC_FH_MIN_BEST
+#define MC_FH_MIN_BEST 32
+#endif
+// MC_FH_MIN: reads with more stacked HSPs than this are finished by a whole wave (k_finish_heavy); MC_FH_MIN_BEST: the same with
+// best hits only, where few reads are finished and the longest thread of k_finish decides (per 1 M reads of 150 bp: 96 / 48 / 32 / 16
+// -> finishing 2.36 / 2.64 / 2.65 / 3.80 ms with rows, 2.38 / 1.43 / 1.41 / 1.42 ms with best hits only)
+#define MC_FH_N1 512      // subjects / ranked HSPs a read may have in the first wave kernel (11 KB of LDS per wave) ...
+#define MC_FH_N2 2048     // ... in the second (45 KB) ...
+#define MC_FH_N3 6144     // ... and in the third (135 KB, one wave per CU), where anything larger is finished by lane 0 alone
+
+// The reads that get a wave of their own (k_finish_heavy), collected before the finishing kernels start so that they can run
+// beside the thread-per-read kernel on a second stream.  A read without a marked HSP prints nothing whatever its size.
+// The reads with a marked HSP that a single thread finishes (k_finish) are listed by size class as well: a wave of k_finish
+// then holds reads of similar size instead of one read of 90 HSPs among 63 idle lanes.
+#define MC_LIGHT_CLASS(n) ((n) <= 4 ? 0 : (n) <= 16 ? 1 : (n) <= 48 ? 2 : 3)
+__global__ void __launch_bounds__(256) k_heavy_lists(const uint32_t *__restrict__ nv, uint32_t nheads, uint32_t *nrow_of,
+                                                     McBestHit *best_of, uint32_t *counters, uint32_t *heavy, uint32_t *light, uint32_t light_pitch, uint32_t fh_min)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    int cls = -1;                                                // -1 nothing to do, 0..3 light class, 4 heavy
+    if (s < nheads) {
+        const uint32_t any = nrow_of[s];                           // (k_order_*: the read is marked, nv[s] = the size of its stacks)
+        if (!any) best_of[s].family = -1;
+        else { const uint32_t n = nv[s]; cls = n > fh_min ? 4 : MC_LIGHT_CLASS(n); }
+    }
+    const uint32_t o = mc_block_alloc(&counters[C_HEAVY], cls == 4);
+    if (cls == 4) heavy[o] = s;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t oc = mc_block_alloc(&counters[C_LIGHT0 + c], cls == c);
+        if (cls == c) light[(size_t)c * light_pitch + oc] = s;
+    }
+}
+
+// One thread per marked read.  All scratch is addressed by the read's offset into the binned HSPs (heads; a read never produces
+// more rows than it has HSPs): v = the stacks (built by the ordering kernels), tmp = 2 HSP slots per HSP for the
+// sum statistics, reused afterwards for the read's rows and their merge keys (64 + 8 bytes per row <= 96).  The rows
+// stay in that scratch; k_emit_rows moves them to their final place once the row counts have been scanned.
+__global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
+                                                const uint32_t *__restrict__ nv, const uint32_t *__restrict__ heads, uint32_t nheads,
+                                                McHsp *v, McHsp *tmp, int64_t first_read_id, uint32_t *nrow_of, McBestHit *best,
+                                                const uint32_t *__restrict__ light, uint32_t light_pitch, const uint32_t *__restrict__ nlight)
+{
+    // blockIdx.y = size class, the largest first: the four classes in ONE launch - a thread walks its read alone at the latency of
+    // global memory and the reads that print anything fill a fraction of the GPU, so four launches one after the other took four
+    // times the slowest thread of a class
+    const int cl = 3 - (int)blockIdx.y;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nlight[cl]) return;                                // (the reads of one size class that have something to print: k_heavy_lists)
+    const uint32_t s = light[(size_t)cl * light_pitch + idx];     // the read; its stacks: v[heads[s] ...], nv[s] records (k_order_*)
+    const uint32_t a = heads[s];
+    const int n = (int)(heads[s + 1] - a);                        // (the scratch of a read is laid out by the size of its segment)
+    McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
+    double *myk = (double *)(myrows + n);
+    McBestHit bh;
+    McSortItem *myitems = (McSortItem *)(myk + n);               // 64 n + 8 n + 16 n = 88 n <= 96 n bytes of the read's tmp area
+    const int nr = mc_finish_stacked(*T, X, *P, fam, (int)((int64_t)s + first_read_id), v + a, (int)nv[s], tmp + 2 * (size_t)a, myrows, myk, myitems, &bh);
+    nrow_of[s] = (uint32_t)nr;
+    best[s] = bh;                                                 // per read that has HSPs (family -1: none); k_emit_rows collects them
+}
+// ---- std::sort (libstdc++ 4.4 introsort) replayed by a whole wave -----------------------------------------------------------
+// mc_std_sort (mc_sort_impl.h) is the move-for-move statement; this computes the same permutation with the 64 lanes:
+//  * __unguarded_partition: the left scan stops at the elements that are not < pivot, in order of position (A_0 < A_1 < ...),
+//    the right scan at the elements that are not > pivot, from the right (B_0 > B_1 > ...); both scans only ever see elements
+//    nobody has moved yet, so the k-th swap exchanges A_k and B_k as long as A_k < B_k, and the cut is min(A_K, B_(K-1)) for the
+//    first K that fails (the swapped-in element at B_(K-1) stops the left scan at the latest).  Ranks by ballot + popcount,
+//    all swaps at once.
+//  * the recursion (depth limit, ranges of <= 16 left alone, heap-sort fallback by lane 0) is the reference's own;
+//  * __final_insertion_sort is a stable sort of an array in which no element is further than 15 positions from its place
+//    (ranges of <= 16 between ordered neighbours): place = position - (larger keys among the 15 before) + (smaller keys among
+//    the 15 behind).
+// Checked against mc_std_sort on 200,000 random arrays (ties, sorted, reversed; tests/test_emul.py runs the same formulation).
+__device__ __forceinline__ void mc_wave_std_sort(McSortItem *items, int n, uint16_t *posA, uint16_t *posB, uint16_t *npos, int *stk, int lane)
+{
+    if (n <= 1) return;
+    const unsigned long long lt = (1ull << lane) - 1;
+    int lg = 0;
+    for (int t = n; t > 1; t >>= 1) lg++;
+    int sp = 1;
+    if (lane == 0) { stk[0] = 0; stk[1] = n; stk[2] = 2 * lg; }
+    mc_wave_sync();
+    while (sp > 0) {
+        sp--;
+        int f = stk[3 * sp], l = stk[3 * sp + 1], depth = stk[3 * sp + 2];
+        mc_wave_sync();
+        while (l - f > 16) {
+            if (depth == 0) { if (lane == 0) mc_heapsort_inl(items + f, (long)(l - f), 0); mc_wave_sync(); break; }
+            --depth;
+            const double x = items[f].k, y = items[f + (l - f) / 2].k, z = items[l - 1].k;
+            double p;
+            if (x < y) { if (y < z) p = y; else if (x < z) p = z; else p = x; }
+            else if (x < z) p = x;
+            else if (y < z) p = z;
+            else p = y;
+            int nA = 0, nB = 0;
+            for (int c0 = f; c0 < l; c0 += 64) {
+                const int i = c0 + lane;
+                const bool fa = i < l && !(items[i < l ? i : f].k < p);
+                const unsigned long long m = __ballot(fa);
+                if (fa) posA[nA + __popcll(m & lt)] = (uint16_t)i;
+                nA += __popcll(m);
+            }
+            for (int c0 = l - 1; c0 >= f; c0 -= 64) {
+                const int i = c0 - lane;
+                const bool fb = i >= f && !(p < items[i >= f ? i : f].k);
+                const unsigned long long m = __ballot(fb);
+                if (fb) posB[nB + __popcll(m & lt)] = (uint16_t)i;
+                nB += __popcll(m);
+            }
+            mc_wave_sync();
+            const int mn = nA < nB ? nA : nB;
+            int K = 0;
+            for (int k0 = 0; k0 < mn; k0 += 64) {
+                const int k = k0 + lane;
+                const unsigned long long m = __ballot(k < mn && posA[k < mn ? k : 0] < posB[k < mn ? k : 0]);
+                K += __popcll(m);
+                if (m != ~0ull) break;
+            }
+            for (int k0 = 0; k0 < K; k0 += 64) {
+                const int k = k0 + lane;
+                if (k < K) { const int a = posA[k], b = posB[k]; const McSortItem t1 = items[a], t2 = items[b]; items[a] = t2; items[b] = t1; }
+            }
+            int split;
+            if (K == 0) split = posA[0];
+            else if (K < nA) { const int a = posA[K], b = posB[K - 1]; split = a < b ? a : b; }
+            else split = posB[K - 1];
+            mc_wave_sync();
+            if (lane == 0) { stk[3 * sp] = split; stk[3 * sp + 1] = l; stk[3 * sp + 2] = depth; }
+            sp++;
+            l = split;
+        }
+        mc_wave_sync();
+    }
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int x = c0 + lane;
+        if (x < n) {
+            const double kx = items[x].k;
+            int np = x;
+            const int y0 = x - 15 > 0 ? x - 15 : 0, y1 = x + 15 < n - 1 ? x + 15 : n - 1;
+            for (int yy = y0; yy < x; yy++) np -= (items[yy].k > kx) ? 1 : 0;
+            for (int yy = x + 1; yy <= y1; yy++) np += (items[yy].k < kx) ? 1 : 0;
+            npos[x] = (uint16_t)np;
+        }
+    }
+    mc_wave_sync();
+    McSortItem cur = items[lane < n ? lane : 0];
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int nx = c0 + 64 + lane;
+        const McSortItem nxt = items[nx < n ? nx : 0];            // the next 64 are in registers before anything of this round is written
+        mc_wave_sync();
+        if (c0 + lane < n) items[npos[c0 + lane]] = cur;
+        cur = nxt;
+        mc_wave_sync();
+    }
+}
+
+// ---- MergeRes' heap sort (std::partial_sort over the whole range) on packed words ---------------------------------------------
+// The rows arrive in ascending log E, so their printed keys are non-decreasing: a row's key is replaced by its dense rank
+// (the number of distinct printed keys in front of it) and the heap runs on 32-bit words rank << 16 | position, element e in word
+// e + 1 - the two children of a node then share one aligned 64-bit LDS read.  mc_heapsort (mc_sort_impl.h) move for move.
+__device__ __forceinline__ void mc_heapw_adjust(uint32_t *hw, int hole, int len, uint32_t value)
+{
+    const int top = hole;
+    int sc = hole;
+    while (sc < (len - 1) / 2) {
+        sc = 2 * (sc + 1);
+        const uint2 ch = *(const uint2 *)(hw + sc);                // elements sc - 1 and sc
+        uint32_t pick = ch.y;
+        if ((ch.y >> 16) < (ch.x >> 16)) { sc--; pick = ch.x; }
+        hw[hole + 1] = pick; hole = sc;
+    }
+    if ((len & 1) == 0 && sc == (len - 2) / 2) { sc = 2 * (sc + 1); hw[hole + 1] = hw[sc]; hole = sc - 1; }
+    int parent = (hole - 1) / 2;
+    while (hole > top && (hw[parent + 1] >> 16) < (value >> 16)) { hw[hole + 1] = hw[parent + 1]; hole = parent; parent = (hole - 1) / 2; }
+    hw[hole + 1] = value;
+}
+__device__ __forceinline__ void mc_heapw_sort(uint32_t *hw, int n)
+{
+    if (n >= 2) for (int parent = (n - 2) / 2;; parent--) { mc_heapw_adjust(hw, parent, n, hw[parent + 1]); if (parent == 0) break; }
+    for (int m = n; m > 1;) { m--; const uint32_t v = hw[m + 1]; hw[m + 1] = hw[1]; mc_heapw_adjust(hw, 0, m, v); }
+}
+
+// A read with many HSPs (one that really comes from a marker gene: hundreds of homologous subjects): one wave.
+// Parallel over lanes: the per-subject stacks and sum statistics (mc_finish_group per subject), the (log E, index) items,
+// std::sort by log E (mc_wave_std_sort), the rows and their classification.  Sequential, by lane 0 on packed words in LDS:
+// MergeRes' heap sort by printed log E, which has to replay libstdc++'s exact sequence of moves.
+// Same scratch layout and same results as k_finish.
+#ifdef MC_EXP_TIMING
+__device__ unsigned long long g_fh_acc[8], g_fh_cnt[8];
+#define MC_FH_TICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane == 0) { fh_acc_[fcat_] += now_ - flast_; fh_acc_[8 + fcat_] += 1; } flast_ = now_; fcat_ = (k); } while (0)
+#else
+#define MC_FH_TICK(k) do { } while (0)
+#endif
+// the heap words of a heavy read: in its own scratch, behind the place of its rows (at most n rows of 72 bytes; the area holds 96 n
+// bytes and the words need 4 n + 8)
+static_assert(sizeof(McRow) == 72 && sizeof(McHsp) == 48, "mc_heavy_words: rows of 72 bytes in an area of 2 x 48 bytes per HSP");
+__device__ __forceinline__ uint32_t *mc_heavy_words(McHsp *tmp, uint32_t a, int n) { return (uint32_t *)((uint8_t *)(tmp + 2 * (size_t)a) + (size_t)sizeof(McRow) * n); }
+
+// MergeRes' heap sort for the heavy reads, ONE LANE PER READ: the sort replays libstdc++'s exact sequence of moves and is a chain
+// of dependent LDS accesses - as lane 0 of the read's own wave it was half of the heavy kernels' time (cycle counters), with 63
+// lanes waiting; here 64 reads are replayed side by side.  Words transposed in LDS (word e of lane l at e * 64 + l: lanes on the
+// same word never share a bank), 502 words per lane = 128.5 KB: one wave per CU.
+#define MC_HL_H(e) lds[((e) << 6) + lane]
+__global__ void __launch_bounds__(64) k_heap_lanes(const uint32_t *__restrict__ heads, uint32_t nheads, uint32_t nhsps, McHsp *tmp, const uint32_t *__restrict__ nrow_of,
+                                                   const uint32_t *__restrict__ counters, const uint32_t *__restrict__ heavy_first)
+{
+    uint32_t *lds = (uint32_t *)mc_smem;
+    __shared__ uint32_t s_nr[64];
+    __shared__ uint32_t *s_hw[64];
+    const int lane = mc_lane();
+    const uint32_t nheavy = counters[C_HEAVY];
+    for (uint32_t slot0 = blockIdx.x * 64u; slot0 < nheavy; slot0 += gridDim.x * 64u) {
+        int n = 0;
+        {
+            const uint32_t slot = slot0 + (uint32_t)lane;
+            uint32_t *hw = nullptr;
+            if (slot < nheavy) {
+                const uint32_t e = heavy_first[slot];
+                if (e & 0x80000000u) {
+                    const uint32_t s = e & 0x7FFFFFFFu, a = heads[s], b = heads[s + 1];
+                    n = (int)nrow_of[s];
+                    hw = mc_heavy_words(tmp, a, (int)(b - a));
+                }
+            }
+            if (n < 2) n = 0;                                       // (nothing to sort)
+            s_nr[lane] = (uint32_t)n; s_hw[lane] = hw;
+        }
+        __syncthreads();
+        for (int r = 0; r < 64; r++) {                               // the words of the 64 reads in, read by read (coalesced)
+            const int nr = (int)s_nr[r];
+            const uint32_t *hw = s_hw[r];
+            for (int e = 1 + lane; e <= nr; e += 64) lds[(e << 6) + r] = hw[e];
+        }
+        __syncthreads();
+        if (n >= 2) {   // mc_heapsort (mc_sort_impl.h) move for move, element e in word e + 1; the keys are the upper halves
+#define MC_HL_ADJUST(HOLE, LEN, VALUE)                                                                                             \
+    do {                                                                                                                           \
+        int hole_ = (HOLE), sc_ = hole_;                                                                                           \
+        const int top_ = hole_, len_ = (LEN);                                                                                      \
+        const uint32_t value_ = (VALUE);                                                                                           \
+        while (sc_ < (len_ - 1) / 2) {                                                                                             \
+            sc_ = 2 * (sc_ + 1);                                                                                                   \
+            const uint32_t cx_ = MC_HL_H(sc_), cy_ = MC_HL_H(sc_ + 1);            /* elements sc - 1 and sc */                      \
+            uint32_t pick_ = cy_;                                                                                                  \
+            if ((cy_ >> 16) < (cx_ >> 16)) { sc_--; pick_ = cx_; }                                                                 \
+            MC_HL_H(hole_ + 1) = pick_; hole_ = sc_;                                                                               \
+        }                                                                                                                          \
+        if ((len_ & 1) == 0 && sc_ == (len_ - 2) / 2) { sc_ = 2 * (sc_ + 1); MC_HL_H(hole_ + 1) = MC_HL_H(sc_); hole_ = sc_ - 1; } \
+        int parent_ = (hole_ - 1) / 2;                                                                                             \
+        while (hole_ > top_ && (MC_HL_H(parent_ + 1) >> 16) < (value_ >> 16)) { MC_HL_H(hole_ + 1) = MC_HL_H(parent_ + 1); hole_ = parent_; parent_ = (hole_ - 1) / 2; } \
+        MC_HL_H(hole_ + 1) = value_;                                                                                               \
+    } while (0)
+            for (int parent = (n - 2) / 2;; parent--) { MC_HL_ADJUST(parent, n, MC_HL_H(parent + 1)); if (parent == 0) break; }
+            for (int m = n; m > 1;) { m--; const uint32_t vv = MC_HL_H(m + 1); MC_HL_H(m + 1) = MC_HL_H(1); MC_HL_ADJUST(0, m, vv); }
+#undef MC_HL_ADJUST
+        }
+        __syncthreads();
+        for (int r = 0; r < 64; r++) {
+            const int nr = (int)s_nr[r];
+            uint32_t *hw = s_hw[r];
+            for (int e = 1 + lane; e <= nr; e += 64) hw[e] = lds[(e << 6) + r];
+        }
+        __syncthreads();
+    }
+}
+#undef MC_HL_H
+
+// The rows of the heavy reads in their final order, and their classification: one wave per read.
+__global__ void __launch_bounds__(64) k_heavy_rows(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
+                                                   const uint32_t *__restrict__ heads, uint32_t nheads,
+                                                   const McHsp *__restrict__ v, McHsp *tmp, int64_t first_read_id, const uint32_t *__restrict__ nrow_of, McBestHit *best_of,
+                                                   const uint32_t *__restrict__ counters, const uint32_t *__restrict__ heavy_first)
+{
+    const int lane = mc_lane();
+    const uint32_t nheavy = counters[C_HEAVY];
+    for (uint32_t slot = blockIdx.x; slot < nheavy; slot += gridDim.x) {
+        const uint32_t e = heavy_first[slot];
+        if (!(e & 0x80000000u)) continue;                            // (finished by lane 0 of the last wave kernel)
+        const uint32_t s = e & 0x7FFFFFFFu, a = heads[s], b = heads[s + 1];
+        const int n = (int)(b - a), nrows = (int)nrow_of[s];
+        const int read_id = (int)((int64_t)s + first_read_id);
+        const uint32_t *hw = mc_heavy_words(tmp, a, n);
+        McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
+        double bbits = -1.0; int bidx = 0x7fffffff, bfam = -1, baln = 0, btl = 0;
+        for (int i = lane; i < nrows; i += 64) {
+            McRow r;
+            mc_fill_row(*T, read_id, v[a + (hw[i + 1] & 0xFFFFu)], r);
+            myrows[i] = r;
+            const int f = fam[r.subject], tl = (int)(X.off[r.subject + 1] - X.off[r.subject]);
+            if (mc_row_passes(*P, r, f, tl, r.frame) && (bfam < 0 || bbits < r.bits)) { bbits = r.bits; bidx = i; bfam = f; baln = r.alnlen; btl = tl; }
+        }
+        // classify_reads keeps the first row with the highest bit score: reduce (bits desc, row index asc) over the lanes
+        for (int d = 32; d > 0; d >>= 1) {
+            const double ob = __shfl_down(bbits, d);
+            const int oi = __shfl_down(bidx, d), of = __shfl_down(bfam, d), oa = __shfl_down(baln, d), ot = __shfl_down(btl, d);
+            if (of >= 0 && (bfam < 0 || ob > bbits || (ob == bbits && oi < bidx))) { bbits = ob; bidx = oi; bfam = of; baln = oa; btl = ot; }
+        }
+        if (lane == 0) {
+            McBestHit bh; bh.read = read_id; bh.family = bfam; bh.aln = bfam >= 0 ? baln : 0; bh.target_len = bfam >= 0 ? btl : 0; bh.bits = bfam >= 0 ? bbits : 0.0;
+            best_of[s] = bh;
+        }
+    }
+}
+
+template <int MAXN, int CTR, int CTR_NEXT>
+__global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
+                                                     const uint32_t *__restrict__ nv, const uint32_t *__restrict__ heads, uint32_t nheads,
+                                                     McHsp *v, McHsp *tmp, int64_t first_read_id, uint32_t *nrow_of, McBestHit *best_of, uint32_t *counters,
+                                                     uint32_t *heavy_first, const uint32_t *__restrict__ list, uint32_t *list_next)
+{
+    McSortItem *items = (McSortItem *)mc_smem;                      // MAXN sort items, then three index arrays (dynamic LDS)
+    uint16_t *gst = (uint16_t *)(items + MAXN), *gkept = gst + (MAXN + 2), *gofs = gkept + (MAXN + 2);
+    __shared__ int s_vn, s_nrows;
+    __shared__ int s_stk[3 * 64];
+    const int lane = mc_lane();
+    const unsigned long long lt = (1ull << lane) - 1;
+    const uint32_t nheavy = counters[CTR];
+#ifdef MC_EXP_TIMING
+    __shared__ unsigned long long fh_acc_[16];
+    if (lane < 16) fh_acc_[lane] = 0;
+    __syncthreads();
+    unsigned long long flast_ = __builtin_readcyclecounter(); int fcat_ = 7;   // 0 group starts 1 groups 2 scan, items 3 sort 4 threshold, ranks 5 heap sort 6 rows 7 other
+#endif
+    for (uint32_t bi = blockIdx.x; bi < nheavy; bi += gridDim.x) {
+        MC_FH_TICK(0);
+        const uint32_t slot = CTR == C_HEAVY ? bi : list[bi];        // position in the first list (heavy_first): the later lists hold slots
+        const uint32_t s = heavy_first[slot] & 0x7FFFFFFFu, a = heads[s], b = heads[s + 1];
+        const int nseg = (int)(b - a);                              // (the read's scratch is laid out by the size of its segment)
+        const int n = (int)nv[s];                                   // its stacks: v[a, a + n) (k_order_*: the first record of a subject's stack carries the stack's size in .read)
+        McHsp *in = v + a;
+        const int read_id = (int)((int64_t)s + first_read_id);
+        // (a read with more stacked HSPs than this kernel's arrays hold moves on - before anything is changed: the sum statistics
+        // below work in place)
+        bool punt = n > MAXN || n > 65535;
+        int vn = 0, ng = 0;
+        if (!punt) {
+            for (int i0 = 0; i0 < n; i0 += 64) {                     // subjects: the starts of their stacks
+                const int i = i0 + lane;
+                const bool st = i < n && in[i].read != 0u;
+                const unsigned long long m = __ballot(st);
+                if (st) gst[ng + __popcll(m & lt)] = (uint16_t)i;
+                ng += __popcll(m);
+            }
+            if (lane == 0) gst[ng] = (uint16_t)n;
+            __syncthreads();
+            // per subject: sum statistics - results stay at the group's own offset of v
+            MC_FH_TICK(1);
+            for (int g = lane; g < ng; g += 64) {
+                const int g0 = gst[g], k = gst[g + 1] - g0;
+                int kept = k;
+                if (k > 1) { const int sidx = in[g0].sidx; kept = mc_sum_evalue(*T, in + g0, 0, k, (int)(X.off[sidx + 1] - X.off[sidx]), tmp + 2 * ((size_t)a + g0)); }
+                gkept[g] = (uint16_t)kept;
+            }
+            __syncthreads();
+            MC_FH_TICK(2);
+            // offsets of the groups in the sequence PrintRes sorts (exclusive scan of the kept counts)
+            {
+                int carry = 0;
+                for (int g0 = 0; g0 < ng; g0 += 64) {
+                    const int g = g0 + lane;
+                    int x = g < ng ? gkept[g] : 0, incl = x;
+                    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+                    if (g < ng) gofs[g] = (uint16_t)(carry + incl - x);
+                    carry += __shfl(incl, 63);
+                }
+                if (lane == 0) { gofs[ng] = (uint16_t)carry; s_vn = carry; }
+            }
+            __syncthreads();
+            vn = s_vn;
+        }
+        if (punt) {
+            if (CTR_NEXT >= 0) { if (lane == 0) list_next[atomicAdd(&counters[CTR_NEXT < 0 ? 0 : CTR_NEXT], 1u)] = slot; }
+            else if (lane == 0) {                                   // larger than the largest arrays: lane 0 alone, everything in the read's global scratch
+                McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
+                double *myk = (double *)(myrows + nseg);
+                McSortItem *myitems = (McSortItem *)(myk + nseg);
+                McBestHit bh;
+                nrow_of[s] = (uint32_t)mc_finish_stacked(*T, X, *P, fam, read_id, in, n, tmp + 2 * (size_t)a, myrows, myk, myitems, &bh);
+                best_of[s] = bh;
+            }
+            __syncthreads();
+            continue;
+        }
+        for (int g = lane; g < ng; g += 64) {
+            const int g0 = gst[g], o = gofs[g], k = gkept[g];
+            for (int j = 0; j < k; j++) { McSortItem it; it.k = v[a + g0 + j].loge; it.i = (uint32_t)(g0 + j); it.pad = 0; items[o + j] = it; }
+        }
+        __syncthreads();
+        MC_FH_TICK(3);
+        mc_wave_std_sort(items, vn, gst, gkept, gofs, s_stk, lane);   // std::sort by log E (PrintRes)
+        __syncthreads();
+        MC_FH_TICK(4);
+        // rows: at most 500, log E below the threshold (the items are in ascending log E, so the test is monotone)
+        {
+            const int lim = vn < MC_MAX_M8 ? vn : MC_MAX_M8;
+            int cnt = 0;
+            for (int i0 = 0; i0 < lim; i0 += 64) {
+                const int i = i0 + lane;
+                const bool ok = i < lim && v[a + items[i < lim ? i : 0].i].loge < T->loge_thr;
+                cnt += __popcll(__ballot(ok));
+            }
+            if (lane == 0) s_nrows = cnt;
+        }
+        __syncthreads();
+        const int nrows = s_nrows;
+        for (int i = lane; i < nrows; i += 64) items[i].k = mc_round6(v[a + items[i].i].loge);
+        __syncthreads();
+        {   // dense ranks of the printed keys -> heap words rank << 16 | index of the HSP in v, into the read's scratch behind the
+            // place of its rows (the groups' scratch is dead by now): MergeRes' heap sort and the rows follow in k_heap_lanes and
+            // k_heavy_rows
+            uint32_t *ghw = mc_heavy_words(tmp, a, nseg);
+            int carry = 0;
+            for (int i0 = 0; i0 < nrows; i0 += 64) {
+                const int i = i0 + lane;
+                const bool nw = i < nrows && i > 0 && items[i].k != items[i - 1].k;
+                const unsigned long long m = __ballot(nw);
+                if (i < nrows) ghw[i + 1] = ((uint32_t)(carry + __popcll(m & (lt | (1ull << lane)))) << 16) | items[i].i;
+                carry += __popcll(m);
+            }
+        }
+        if (lane == 0) { nrow_of[s] = (uint32_t)nrows; heavy_first[slot] = s | 0x80000000u; }   // (the flag: heap sort and rows still to come)
+        __syncthreads();
+        MC_FH_TICK(7);
+    }
+#ifdef MC_EXP_TIMING
+    MC_FH_TICK(7);
+    __syncthreads();
+    if (lane < 8) { atomicAdd(&g_fh_acc[lane], fh_acc_[lane]); atomicAdd(&g_fh_cnt[lane], fh_acc_[8 + lane]); }
+#endif
+}
+
+// rows of read s -> rows[rowoff[s] ...]: the m8 order (ascending read, RAPsearch2's order inside a read); the best hits of the
+// reads that have one are collected (any order: the host sorts them by read), the reads with rows counted
+__global__ void __launch_bounds__(256) k_emit_rows(const uint32_t *__restrict__ heads, uint32_t nheads, const uint32_t *__restrict__ nrow_of, const uint32_t *__restrict__ rowoff,
+                                                   const McHsp *__restrict__ tmp, McRow *__restrict__ rows, uint32_t cap_rows, const McBestHit *__restrict__ best_of, McBestHit *best,
+                                                   uint32_t *counters, int copy_rows)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t nr = 0, cp_n = 0;
+    const uint2 *cp_src = nullptr;
+    uint2 *cp_dst = nullptr;
+    McBestHit bh; bh.family = -1;
+    if (s < nheads) {
+        nr = nrow_of[s];
+        bh = best_of[s];
+        const uint32_t off = rowoff[s];
+        if (s == nheads - 1) { counters[C_ROWS] = off + nr; if (copy_rows && off + nr > cap_rows) counters[C_OVERFLOW] = 4; }
+        if (copy_rows && off + nr <= cap_rows && nr > 0) { cp_src = (const uint2 *)(tmp + 2 * (size_t)heads[s]); cp_dst = (uint2 *)(rows + off); cp_n = nr * (uint32_t)(sizeof(McRow) / 8); }
+    }
+    {   // the rows of the block's reads, read by read with all 256 threads (8 bytes each, coalesced: a row is 72 bytes) - one read in twelve prints
+        // anything, 23 rows on average, and a thread copying its read's rows alone moved 64 bytes per turn
+        __shared__ const uint2 *l_src[256];
+        __shared__ uint2 *l_dst[256];
+        __shared__ uint32_t l_n[256], l_cnt;
+        if (threadIdx.x == 0) l_cnt = 0;
+        __syncthreads();
+        if (cp_n) { const uint32_t k = atomicAdd(&l_cnt, 1u); l_src[k] = cp_src; l_dst[k] = cp_dst; l_n[k] = cp_n; }   // (any order: the destinations are disjoint)
+        __syncthreads();
+        const uint32_t cnt = l_cnt;
+        for (uint32_t k = 0; k < cnt; k++) {
+            const uint2 *src = l_src[k];
+            uint2 *dst = l_dst[k];
+            const uint32_t n16 = l_n[k];
+            for (uint32_t i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
+        }
+    }
+    (void)mc_block_alloc(&counters[C_SEGS], nr > 0);
+    const uint32_t o = mc_block_alloc(&counters[C_BEST], bh.family >= 0);
+    if (bh.family >= 0) best[o] = bh;
+}

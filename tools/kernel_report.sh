@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/../microbecensus_amd/csrc" || exit 1
 F=${1:-k_}
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wall -S --cuda-device-only -o /tmp/mc_hip.s mc_hip.hip -Rpass-analysis=kernel-resource-usage 2>&1 \
-  | grep -E "error|Function Name" -A9 | grep -E "error|Function Name|VGPRs:|Spill|ScratchSize|Occupancy" | grep -A6 -E "error|Function Name: .*$F" | sed 's/\[-Rpass.*//; s/mc_hip.hip:[0-9]*:[0-9]*: remark: //'
+  | grep -E "error|Function Name" -A9 | grep -E "error|Function Name|VGPRs:|Spill|ScratchSize|Occupancy" | grep -A6 -E "error|Function Name: .*$F" | sed 's/\[-Rpass.*//; s/[a-z_]*\.[hip]*:[0-9]*:[0-9]*: remark: //'
 python3 - "$F" <<'PY'
 import re, sys
 s = open('/tmp/mc_hip.s').read()
