@@ -44,25 +44,32 @@ __global__ void __launch_bounds__(256) k_heavy_lists(const uint32_t *__restrict_
 // more rows than it has HSPs): v = the stacks (built by the ordering kernels), tmp = 2 HSP slots per HSP for the
 // sum statistics, reused afterwards for the read's rows and their merge keys (64 + 8 bytes per row <= 96).  The rows
 // stay in that scratch; k_emit_rows moves them to their final place once the row counts have been scanned.
-__global__ void __launch_bounds__(256) k_finish(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
+// The (log E, index) items both order-defining sorts work on - std::sort of PrintRes, MergeRes' heap sort: some thousand dependent
+// accesses for a read of 96 stacked HSPs - lie in the thread's own stretch of LDS (round 4; in global scratch every one of those
+// accesses was a trip to the L2 / HBM, and the longest thread of the launch was the launch: 2.1 ms per 1 M reads whether 10,000 or
+// 100,000 reads were finished).  TPB threads per workgroup, ITEMS items per thread; stretches are 4 words apart modulo the 32 banks
+// (a wave reading 16 bytes per lane then meets the minimum of conflicts).  CL0: the first of the two size classes of the launch.
+template <int TPB, int ITEMS, int CL0>
+__global__ void __launch_bounds__(TPB) k_finish(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,
                                                 const uint32_t *__restrict__ nv, const uint32_t *__restrict__ heads, uint32_t nheads,
                                                 McHsp *v, McHsp *tmp, int64_t first_read_id, uint32_t *nrow_of, McBestHit *best,
-                                                const uint32_t *__restrict__ light, uint32_t light_pitch, const uint32_t *__restrict__ nlight)
+                                                const uint32_t *__restrict__ light, uint32_t light_pitch, const uint32_t *__restrict__ nlight, int use_lds)
 {
-    // blockIdx.y = size class, the largest first: the four classes in ONE launch - a thread walks its read alone at the latency of
-    // global memory and the reads that print anything fill a fraction of the GPU, so four launches one after the other took four
-    // times the slowest thread of a class
-    const int cl = 3 - (int)blockIdx.y;
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // blockIdx.y = size class, the larger first: two classes in ONE launch (and the two launches side by side on two streams) - a
+    // thread finishes its read alone and the reads that print anything fill a fraction of the GPU
+    constexpr int STRIDE = ITEMS * 16 + 16;
+    const int cl = CL0 + 1 - (int)blockIdx.y;
+    const uint32_t idx = blockIdx.x * TPB + threadIdx.x;
     if (idx >= nlight[cl]) return;                                // (the reads of one size class that have something to print: k_heavy_lists)
     const uint32_t s = light[(size_t)cl * light_pitch + idx];     // the read; its stacks: v[heads[s] ...], nv[s] records (k_order_*)
     const uint32_t a = heads[s];
-    const int n = (int)(heads[s + 1] - a);                        // (the scratch of a read is laid out by the size of its segment)
+    const int n = (int)(heads[s + 1] - a), vn = (int)nv[s];       // (the scratch of a read is laid out by the size of its segment)
     McRow *myrows = (McRow *)(tmp + 2 * (size_t)a);
     double *myk = (double *)(myrows + n);
     McBestHit bh;
-    McSortItem *myitems = (McSortItem *)(myk + n);               // 64 n + 8 n + 16 n = 88 n <= 96 n bytes of the read's tmp area
-    const int nr = mc_finish_stacked(*T, X, *P, fam, (int)((int64_t)s + first_read_id), v + a, (int)nv[s], tmp + 2 * (size_t)a, myrows, myk, myitems, &bh);
+    int nr;
+    if (use_lds && vn <= ITEMS) nr = mc_finish_stacked_t<McSortsInl>(*T, X, *P, fam, (int)((int64_t)s + first_read_id), v + a, vn, tmp + 2 * (size_t)a, myrows, myk, (McSortItem *)(mc_smem + (size_t)threadIdx.x * STRIDE), &bh);
+    else nr = mc_finish_stacked(*T, X, *P, fam, (int)((int64_t)s + first_read_id), v + a, vn, tmp + 2 * (size_t)a, myrows, myk, (McSortItem *)(myk + n), &bh);   // (64 n + 8 n + 16 n = 88 n <= 96 n bytes of the read's tmp area)
     nrow_of[s] = (uint32_t)nr;
     best[s] = bh;                                                 // per read that has HSPs (family -1: none); k_emit_rows collects them
 }

@@ -351,8 +351,13 @@ MC_HDN int mc_build_stacks(const McHsp *in, int n, McHsp *v)
 }
 // One read from its stacks (v[0, vn) as mc_build_stacks leaves them; tmp: 2 vn entries of scratch): sum statistics per subject,
 // std::sort by log E, the 500-row cap, MergeRes' order, the rows and the classification.
-MC_HDN int mc_finish_stacked(const McTables &T, const McIndex &X, const McClassPars &P, const int32_t *marker_family,
-                             int read_id, McHsp *v, int vn, McHsp *tmp, McRow *rows, double *krows, McSortItem *items, McBestHit *best)
+// (S: the two order-defining sorts - out of line, or forced inline for the kernel that keeps the items in LDS: inlining is what lets
+// the compiler address them as LDS)
+struct McSortsOut { static MC_HD void sort(McSortItem *a, long n) { mc_std_sort(a, n, 0); } static MC_HD void heap(McSortItem *a, long n) { mc_heapsort(a, n, 0); } };
+struct McSortsInl { static MC_HD void sort(McSortItem *a, long n) { mc_std_sort_inl(a, n, 0); } static MC_HD void heap(McSortItem *a, long n) { mc_heapsort_inl(a, n, 0); } };
+template <class S>
+MC_HD int mc_finish_stacked_t(const McTables &T, const McIndex &X, const McClassPars &P, const int32_t *marker_family,
+                              int read_id, McHsp *v, int vn, McHsp *tmp, McRow *rows, double *krows, McSortItem *items, McBestHit *best)
 {
     MC_FR_BEGIN;
     // Sum statistics for the subjects with more than one HSP, in a loop of their own: the threads of a wave that have such a
@@ -383,7 +388,7 @@ MC_HDN int mc_finish_stacked(const McTables &T, const McIndex &X, const McClassP
     MC_FR_TICK(0);
     for (int i = 0; i < vn; i++) { items[i].k = v[i].loge; items[i].i = (uint32_t)i; items[i].pad = 0; }
     MC_FR_TICK(1);
-    mc_std_sort(items, vn, 0);                       // std::sort by log E (PrintRes), on (key, index) items
+    S::sort(items, vn);                              // std::sort by log E (PrintRes), on (key, index) items
     MC_FR_TICK(2);
     int nrows = 0;
     best->read = read_id; best->family = -1; best->aln = 0; best->target_len = 0; best->bits = 0.0;
@@ -392,24 +397,28 @@ MC_HDN int mc_finish_stacked(const McTables &T, const McIndex &X, const McClassP
     // (key, index) items, then the rows are written once, in their final order
     for (int i = 0; i < nrows; i++) items[i].k = mc_round6(v[items[i].i].loge);
     MC_FR_TICK(3);
-    mc_heapsort(items, nrows, 0);
+    S::heap(items, nrows);
     MC_FR_TICK(4);
-    for (int i = 0; i < nrows; i++) {
-        mc_fill_row(T, read_id, v[items[i].i], rows[i]);
-    }
-    MC_FR_TICK(5);
     (void)krows;
-    for (int i = 0; i < nrows; i++) {
-        McRow &r = rows[i];
+    for (int i = 0; i < nrows; i++) {                // the row is written and classified from the same registers (a thread walks global memory alone: reading it back was a trip per row)
+        McRow r;
+        mc_fill_row(T, read_id, v[items[i].i], r);
+        rows[i] = r;
         int fam = marker_family[r.subject], tl = (int)(X.off[r.subject + 1] - X.off[r.subject]);
         int nmatch = r.frame;
         if (mc_row_passes(P, r, fam, tl, nmatch)) {
             if (best->family < 0 || best->bits < r.bits) { best->family = fam; best->aln = r.alnlen; best->target_len = tl; best->bits = r.bits; }
         }
     }
+    MC_FR_TICK(5);
     MC_FR_TICK(6);
     MC_FR_END;
     return nrows;
+}
+MC_HDN int mc_finish_stacked(const McTables &T, const McIndex &X, const McClassPars &P, const int32_t *marker_family,
+                             int read_id, McHsp *v, int vn, McHsp *tmp, McRow *rows, double *krows, McSortItem *items, McBestHit *best)
+{
+    return mc_finish_stacked_t<McSortsOut>(T, X, P, marker_family, read_id, v, vn, tmp, rows, krows, items, best);
 }
 // in[0, n): the read's HSPs sorted by (subject, chrono); v: n entries of scratch.  (The test-only emulation's entry; the kernels
 // start from the stacks.)

@@ -580,8 +580,17 @@ static int stage_d(mc_handle *h, McCtx &c)
             HIPCK(hipEventRecord(c.ev_join, c.side));
         }
         // the light reads: the four size classes side by side (the counts stay on the device; blocks past a class' count leave at once)
-        k_finish<<<dim3((nheads + 255) / 256, 4), dim3(256), 0, st>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp,
-                                                                       c.first_read_id, c.d_nrow, c.d_bestof, d_light, light_pitch, c.d_counters + C_LIGHT0);
+        {   // (size classes 2, 3 - up to 48 / 96 stacked HSPs - with 96 items of LDS per thread, classes 0, 1 - up to 4 / 16 - with 16; the
+            // items are reached through generic pointers - mc_finish_stacked is shared with the host - and a flat access to LDS must stay
+            // below 64 KB of the workgroup's allocation: 32 and 128 threads per workgroup)
+            const size_t lb = 32 * (96 * 16 + 16), ls = 128 * (16 * 16 + 16);
+            static const int fin_lds = getenv("MC_FINISH_GLOBAL") ? 0 : 1;          // (experiments: the items in global scratch, as before round 4)
+            HIPCK(hipFuncSetAttribute((const void *)k_finish<32, 96, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+            k_finish<32, 96, 2><<<dim3((nheads + 31) / 32, 2), dim3(32), lb, st>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp,
+                                                                                 c.first_read_id, c.d_nrow, c.d_bestof, d_light, light_pitch, c.d_counters + C_LIGHT0, fin_lds);
+            k_finish<128, 16, 0><<<dim3((nheads + 127) / 128, 2), dim3(128), ls, st>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp,
+                                                                                     c.first_read_id, c.d_nrow, c.d_bestof, d_light, light_pitch, c.d_counters + C_LIGHT0, fin_lds);
+        }
         HIPCK(hipStreamWaitEvent(st, c.ev_join, 0));
         if (mc_scan_u32(c.d_nrow, nheads, c.d_rowoff, c.d_scan, st)) return -1;
         if (h->rows_ever) HIPCK(hipStreamWaitEvent(st, h->ev_rows, 0));   // (the rows of the run before may still be leaving d_rows)
