@@ -161,6 +161,10 @@ int64_t mc_reader_run(mc_reader *r);
 const uint8_t *mc_reader_reads(mc_reader *r);
 int mc_reader_get_stats(mc_reader *r, mc_reader_stats *out);
 void mc_reader_close(mc_reader *r);
+/* A closed reader leaves its read buffer (touched pages) to the next reader of the process: the second run_pipeline() of a process pays
+ * neither munmap nor page faults.  At most keep_bytes of it are kept (default 4 GB); mc_reader_trim() sets the limit and releases
+ * what is held beyond it (0: everything). */
+void mc_reader_trim(int64_t keep_bytes);
 /* count_bases(): total sequence length over every record of every file. */
 int64_t mc_count_bases(const char *const *paths, int32_t npaths);
 /* auto_detect_quality_offset() (microbe_census.py:175-187): 32 or 64 by the first quality character of the file that decides

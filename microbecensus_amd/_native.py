@@ -93,6 +93,8 @@ def load_library():
     lib.mc_reader_reads.argtypes = [C.c_void_p]
     lib.mc_reader_get_stats.argtypes = [C.c_void_p, C.POINTER(McReaderStats)]
     lib.mc_reader_close.argtypes = [C.c_void_p]
+    lib.mc_reader_trim.restype = None
+    lib.mc_reader_trim.argtypes = [C.c_int64]
     lib.mc_count_bases.restype = C.c_int64
     lib.mc_count_bases.argtypes = [C.POINTER(C.c_char_p), C.c_int32]
     lib.mc_quality_offset.restype = C.c_int32
@@ -118,7 +120,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_set_index_cache", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
                     "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_set_parts", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8", "mc_write_m8_named",
-                    "mc_reader_last_error", "mc_set_host_threads", "mc_reader_open", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_count_bases", "mc_quality_offset",
+                    "mc_reader_last_error", "mc_set_host_threads", "mc_reader_open", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_reader_trim", "mc_count_bases", "mc_quality_offset",
                     "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_reader_nreads", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows", "mc_set_best_hits_only", "mc_grid_classify"]
 
 

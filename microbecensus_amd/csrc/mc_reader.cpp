@@ -803,13 +803,14 @@ struct mc_reader {
     {
         if (run_th.joinable()) run_th.join();
         if (reads) {
-            // The buffer of a closed reader is kept for the next one (one buffer, up to 8 GB): returning gigabytes of pages takes a while
+            // The buffer of a closed reader is kept for the next one (one buffer, up to the limit mc_reader_trim sets - 4 GB unless told
+            // otherwise; a long-lived service is not left holding the 8 GB of one large library): returning gigabytes of pages takes a while
             // (0.17 s for the 3 GB of 20 M reads) and so does faulting them in again - a second run_pipeline() of the same process
             // pays neither.  Anything larger is unmapped, off the caller's time.
             uint8_t *p = reads; const size_t n = reads_cap;
             {
                 std::unique_lock<std::mutex> lk(cache_mu());
-                if (!cache_ptr() && n <= ((size_t)8 << 30) && !getenv("MC_READER_NO_CACHE")) { cache_ptr() = p; cache_cap() = n; p = nullptr; }
+                if (!cache_ptr() && n <= cache_limit() && !getenv("MC_READER_NO_CACHE")) { cache_ptr() = p; cache_cap() = n; p = nullptr; }
             }
             if (p) { if (n >= ((size_t)64 << 20)) std::thread([p, n] { munmap(p, n); }).detach(); else munmap(p, n); }
         }
@@ -817,6 +818,7 @@ struct mc_reader {
     static std::mutex &cache_mu() { static std::mutex m; return m; }
     static uint8_t *&cache_ptr() { static uint8_t *p = nullptr; return p; }
     static size_t &cache_cap() { static size_t n = 0; return n; }
+    static size_t &cache_limit() { static size_t n = (size_t)4 << 30; return n; }   // what a closed reader may leave behind (mc_reader_trim; default 4 GB: 20 M reads of 150 bp and some)
     bool reserve(size_t bytes)
     {
         if (bytes <= reads_cap) return true;
@@ -1008,5 +1010,17 @@ extern "C" int64_t mc_reader_join(mc_reader *r)
     return r->result;
 }
 
+// Releases the buffer a closed reader left for the next one, and sets how large a buffer may be kept from now on (keep_bytes;
+// 0: none is kept).  For long-lived processes that sample a large library once.
+extern "C" void mc_reader_trim(int64_t keep_bytes)
+{
+    uint8_t *p = nullptr; size_t n = 0;
+    {
+        std::unique_lock<std::mutex> lk(mc_reader::cache_mu());
+        mc_reader::cache_limit() = keep_bytes > 0 ? (size_t)keep_bytes : 0;
+        if (mc_reader::cache_ptr() && mc_reader::cache_cap() > mc_reader::cache_limit()) { p = mc_reader::cache_ptr(); n = mc_reader::cache_cap(); mc_reader::cache_ptr() = nullptr; mc_reader::cache_cap() = 0; }
+    }
+    if (p) munmap(p, n);
+}
 extern "C" int32_t mc_reader_read_len(const mc_reader *r) { return r ? r->L : 0; }
 extern "C" int64_t mc_reader_nreads(const mc_reader *r) { return r ? r->nreads : 0; }

@@ -101,3 +101,28 @@ def test_reads_with_sequencing_errors_against_oracle(engine, L, n, sub, indel):
     got = _rows(rows)
     assert_rows_equal(got, _oracle_rows(reads))
     assert len(rows) > 100 and sum(1 for r in got if r[4] > 0) > 5          # (rows with gap openings among them)
+
+
+@pytest.mark.parametrize("thr", [-3.0, 0.0, 2.5])
+def test_log_e_threshold_other_than_one_against_oracle(engine, thr, tmp_path):
+    """`-e` (mc_set_run's loge_thr; scripts/rapsearch_mi355x forwards it): the reference runs `-e 1`, RAPsearch2 takes any threshold - it
+    decides which single HSPs are kept at all (`CalRes 0x4078e4-0x4078f9`), which chains of sum statistics stay (`SumEvalue`), where
+    `PrintRes` stops - and with it which reads the ordering kernels mark.  m8 text of the HIP path == the oracle's (RS_LOGE_THR)."""
+    import hashlib
+    import subprocess
+    from microbecensus_amd import _native, synth
+    names, seqs = _native.load_markers()
+    genome = synth.build_genomes(seqs, total_bp=500_000, seed=71, marker_gene_fraction=0.25)
+    reads = synth.sample_reads(genome, 5000, 150, seed=72)
+    fa = tmp_path / "r.fa"
+    fa.write_bytes(b"".join(b">%d\n%s\n" % (i, bytes(r)) for i, r in enumerate(reads)))
+    engine.set_run(150, loge_thr=thr)
+    try:
+        rows, _ = engine.search(reads)
+        engine.write_m8(str(tmp_path / "gpu.m8"))
+    finally:
+        engine.set_run(150)
+    subprocess.check_call([os.path.join(REPO, "oracle", "rs_port"), os.path.join(REPO, "oracle", "_ref", "rapdb_2.15"), str(fa), str(tmp_path / "cpu.m8")],
+                          env=dict(os.environ, RS_LOGE_THR=repr(thr)))
+    got, want = (tmp_path / "gpu.m8").read_bytes(), (tmp_path / "cpu.m8").read_bytes()
+    assert want.count(b"\n") > 50 and hashlib.md5(got).hexdigest() == hashlib.md5(want).hexdigest(), (len(rows), want.count(b"\n"))
