@@ -145,6 +145,7 @@ typedef struct mc_reader_stats {
     int64_t records;                              /* records parsed before the sampler stopped */
     int64_t bases;                                /* their total sequence length ... */
     int64_t exhausted;                            /* ... which is count_bases() (:573-584) when every file was read to its end (1) */
+    int64_t ragged_end;                           /* the data ended inside a FASTQ record (a truncated file; a byte window that does not end on a record boundary) */
 } mc_reader_stats;
 
 const char *mc_reader_last_error(void);
@@ -155,6 +156,13 @@ void mc_set_host_threads(int32_t n);
  * fasta_out (may be NULL): the temp FASTA process_seqfile writes, ">{id}\n{seq[:L]}\n" per accepted read. */
 mc_reader *mc_reader_open(const char *const *paths, int32_t npaths, int32_t read_len, int64_t nreads, int32_t fastq, int32_t quality_offset,
                           double min_quality, double mean_quality, double max_unknown, int32_t filter_dups, const char *fasta_out);
+/* The same sampler on the byte window [byte_lo, byte_hi) of ONE plain (uncompressed, regular) file: the records that start in it.
+ * Both ends are moved to the first record start behind them by one rule ('@' line whose second next line starts with '+' in a file
+ * that starts with '@'; '>' line in one that starts with '>'), so consecutive windows cut a file into whole records whoever reads
+ * them: the ranks of a multi-GPU run sample their own slices side by side (microbecensus_amd/distributed.py) and reproduce the
+ * head-take of process_seqfile (:337-356) from the per-slice counts.  No duplicate filter (it needs the whole stream in one place). */
+mc_reader *mc_reader_open_range(const char *path, int64_t byte_lo, int64_t byte_hi, int32_t read_len, int64_t nreads, int32_t fastq,
+                                int32_t quality_offset, double min_quality, double mean_quality, double max_unknown);
 /* Runs the sampler: returns args['sampled_reads'] (0 = "No reads remaining after filtering"). */
 int64_t mc_reader_run(mc_reader *r);
 /* sampled x read_len bytes, row i = trimmed read i: exactly what mc_search() / mc_upload() take. Owned by the reader. */

@@ -31,7 +31,7 @@ class McStats(C.Structure):
 
 
 class McReaderStats(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in ("sampled", "too_short", "low_qual", "dups", "records", "bases", "exhausted")]
+    _fields_ = [(n, C.c_int64) for n in ("sampled", "too_short", "low_qual", "dups", "records", "bases", "exhausted", "ragged_end")]
 
 
 ROW_DTYPE = np.dtype([("query", "<i4"), ("subject", "<i4"), ("ident", "<f8"), ("alnlen", "<i4"), ("mismatch", "<i4"),
@@ -87,6 +87,8 @@ def load_library():
     lib.mc_set_host_threads.argtypes = [C.c_int32]
     lib.mc_reader_open.restype = C.c_void_p
     lib.mc_reader_open.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_char_p]
+    lib.mc_reader_open_range.restype = C.c_void_p
+    lib.mc_reader_open_range.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]
     lib.mc_reader_run.restype = C.c_int64
     lib.mc_reader_run.argtypes = [C.c_void_p]
     lib.mc_reader_reads.restype = C.POINTER(C.c_uint8)
@@ -120,7 +122,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_set_index_cache", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
                     "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_set_parts", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8", "mc_write_m8_named",
-                    "mc_reader_last_error", "mc_set_host_threads", "mc_reader_open", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_reader_trim", "mc_count_bases", "mc_quality_offset",
+                    "mc_reader_last_error", "mc_set_host_threads", "mc_reader_open", "mc_reader_open_range", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_reader_trim", "mc_count_bases", "mc_quality_offset",
                     "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_reader_nreads", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows", "mc_set_best_hits_only", "mc_grid_classify"]
 
 
@@ -141,6 +143,20 @@ class Reader:
                                     float(max_unknown), 1 if filter_dups else 0, fasta_out.encode() if fasta_out else None)
         if not self.r:
             raise RuntimeError(lib.mc_reader_last_error().decode())
+
+    @classmethod
+    def on_range(cls, path, byte_lo, byte_hi, read_len, nreads, fastq, quality_offset, min_quality, mean_quality, max_unknown):
+        """The sampler on the records that start in [byte_lo, byte_hi) of one plain file (mc_reader_open_range)."""
+        lib = load_library()
+        self = cls.__new__(cls)
+        self.lib, self.read_len = lib, read_len
+        if nreads is None:
+            nreads = (1 << 63) - 1
+        self.r = lib.mc_reader_open_range(path.encode(), int(byte_lo), int(byte_hi), read_len, nreads, 1 if fastq else 0, int(quality_offset), float(min_quality),
+                                          float(mean_quality), float(max_unknown))
+        if not self.r:
+            raise RuntimeError(lib.mc_reader_last_error().decode())
+        return self
 
     def close(self):
         if getattr(self, "r", None):

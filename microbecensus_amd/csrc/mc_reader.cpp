@@ -63,6 +63,7 @@
 namespace {
 
 thread_local std::string r_err;
+thread_local int64_t t_range_lo = -1, t_range_hi = -1;   // mc_reader_open_range: the byte window of the ONE plain file the reader is opened on (-1: the whole file)
 thread_local bool t_peek = false;   // the caller will most likely stop after a few records (mc_quality_offset): no parallel inflate, small first regions
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -207,11 +208,14 @@ struct Bz2File {
 
 int reader_threads();
 int inflate_threads();
+size_t guess_start(const uint8_t *base, size_t from, size_t e, int max_lines, int kind);
 
 struct Stream {
     enum { NBLK = 16, BLK = 1 << 22, BLK_PEEK = 1 << 16 };
     // plain file: one mapping; the window is a slice of it
     const uint8_t *map = nullptr; size_t map_n = 0;
+    const uint8_t *vend = nullptr;              // end of the part of the mapping that is read (map + map_n, or the end of a byte window: mc_reader_open_range)
+    bool ranged = false;
     // compressed stream: a producer thread inflates BLK-sized blocks into a ring; the window lives in `buf`
     gzFile gz = nullptr; Bz2File *bz = nullptr;
     mcgz::ParallelGz *pgz = nullptr; const uint8_t *gzmap = nullptr; size_t gzmap_n = 0;   // a regular .gz file: mapped and inflated in parallel (mc_pgzip.h)
@@ -300,10 +304,20 @@ struct Stream {
                     map = (const uint8_t *)m;
                 }
                 ::close(fd);
-                win = map; len = 0;
-                if (map_n == 0) at_end = true;
+                win = map; len = 0; vend = map + map_n;
+                if (t_range_lo >= 0 && map_n) {
+                    // A byte window [lo, hi): the records that START in it.  Both ends are moved to the first record start behind them by the
+                    // same rule (an '@' line whose second next line starts with '+', or a '>' line), so the windows [b0, b1), [b1, b2), ...
+                    // of a file cut it into whole records whoever reads them - the ranks of a multi-GPU run, each with its own sampler.
+                    const size_t lo = (size_t)std::min<int64_t>(t_range_lo, (int64_t)map_n), hi = (size_t)std::min<int64_t>(std::max(t_range_hi, t_range_lo), (int64_t)map_n);
+                    const int kind = map[0] == '@' ? '@' : map[0] == '>' ? '>' : 0;
+                    const size_t s0 = lo == 0 ? 0 : guess_start(map, lo, map_n, 1 << 30, kind), s1 = hi >= map_n ? map_n : guess_start(map, hi, map_n, 1 << 30, kind);
+                    win = map + s0; vend = map + std::max(s0, s1); ranged = true;
+                }
+                if (vend == win) at_end = true;
             }
         }
+        if (t_range_lo >= 0 && !ranged) { r_err = std::string("a byte window needs a plain regular file: ") + path; close(); return false; }
         if (compressed) {
             if (t_peek) peek_blocks = 8;
             for (auto &r : ring) r.resize(BLK);
@@ -370,7 +384,7 @@ struct Stream {
     void extend(size_t want)
     {
         if (!compressed) {
-            const size_t have = (size_t)(map + map_n - win);
+            const size_t have = (size_t)(vend - win);
             len = std::min(want, have);
             if (len == have) at_end = true;
             return;
@@ -441,6 +455,7 @@ struct Arena {   // stable storage for records whose sequence spans several line
 struct Piece {
     size_t start = 0, stop = 0, end = 0;               // offsets into the region: first byte, guessed start of the next piece, first unconsumed byte
     bool done = false;                                  // the parser reached its terminal state (the generator returned)
+    bool ragged = false;                                // ... in the middle of a record (the data ended inside its sequence or qualities)
     std::vector<Rec> recs;
     Arena arena;
     int64_t bases = 0;
@@ -569,7 +584,7 @@ void parse_piece(const uint8_t *base, size_t e, bool eof, Piece &pc, const Param
         const uint8_t *seq = nparts <= 1 ? s0 : joined;
         if (!got_next) {                                              // ran out of lines
             if (!eof) { pc.end = hdr_off; return; }                  // unfinished: the next region starts again at its header
-            emit(seq, sn, nullptr, 0, false); pc.end = e; pc.done = true; return;
+            emit(seq, sn, nullptr, 0, false); pc.end = e; pc.done = true; pc.ragged = P.fastq != 0; return;
         }
         const size_t nxn = chomped(nx);
         if (nxn == 0) { emit(seq, sn, nullptr, 0, false); pc.end = e; pc.done = true; return; }   // '' : record goes out, the generator returns
@@ -596,22 +611,25 @@ void parse_piece(const uint8_t *base, size_t e, bool eof, Piece &pc, const Param
         }
         if (complete) { emit(seq, sn, qparts <= 1 ? q0 : qj, qn, true); continue; }
         if (!eof) { pc.end = hdr_off; return; }
-        emit(seq, sn, nullptr, 0, false); pc.end = e; pc.done = true; return;   // the file ends inside the qualities
+        emit(seq, sn, nullptr, 0, false); pc.end = e; pc.done = true; pc.ragged = true; return;   // the file ends inside the qualities
     }
 }
 
 // guessed record start at or behind `from`: offset of a '@' line whose second next line starts with '+', or of a '>' line
-size_t guess_start(const uint8_t *base, size_t from, size_t e)
+// kind: 0 either; '>' / '@': only that kind of record start - the end of a byte window (mc_reader_open_range) must not be taken for
+// a quality line that happens to start with '>' in a FASTQ file (a piece's guess is verified when the pieces are stitched, a
+// window's only by how its parse ends), so there the first byte of the file decides
+size_t guess_start(const uint8_t *base, size_t from, size_t e, int max_lines = 64, int kind = 0)
 {
     size_t pos = from;
     Line ln;
     if (pos > 0) { if (!next_line(base, pos, e, ln)) return e; }     // (skip the line `from` points into)
-    for (int tries = 0; tries < 64; tries++) {
+    for (int tries = 0; tries < max_lines; tries++) {
         const size_t at = pos;
         if (!next_line(base, pos, e, ln)) return e;
         if (ln.n == 0) continue;
-        if (ln.p[0] == '>') return at;
-        if (ln.p[0] == '@') {
+        if (ln.p[0] == '>' && kind != '@') return at;
+        if (ln.p[0] == '@' && kind != '>') {
             size_t p2 = pos; Line a, b;
             if (next_line(base, p2, e, a) && next_line(base, p2, e, b) && b.n > 0 && b.p[0] == '+' && !(a.n > 0 && (a.p[0] == '@' || a.p[0] == '>' || a.p[0] == '+'))) return at;
         }
@@ -790,6 +808,7 @@ struct mc_reader {
     std::vector<std::string> paths;
     int32_t L = 0, fastq = 0, qoff = 0, filter_dups = 0;
     int64_t nreads = 0;
+    int64_t range_lo = -1, range_hi = -1;                          // mc_reader_open_range
     double min_q = 0, mean_q = 0, max_unknown = 0;
     std::string fasta_out;
     uint8_t *reads = nullptr; size_t reads_cap = 0, reads_n = 0;   // anonymous mapping grown with mremap (no copies, no zero fill up front)
@@ -853,6 +872,20 @@ extern "C" mc_reader *mc_reader_open(const char *const *paths, int32_t npaths, i
     return r;
 }
 
+// The sampler on ONE plain (uncompressed, regular) file's byte window [byte_lo, byte_hi): the records that start in it - both ends
+// moved to the first record start behind them by the same rule, so consecutive windows cut the file into whole records whoever
+// reads them.  What the ranks of a multi-GPU run open, each on its own slice (microbecensus_amd/distributed.py); filter_dups needs
+// the whole stream in one place and is not offered.  mc_reader_stats.ragged_end: the window did not end on a record boundary.
+extern "C" mc_reader *mc_reader_open_range(const char *path, int64_t byte_lo, int64_t byte_hi, int32_t read_len, int64_t nreads, int32_t fastq, int32_t quality_offset,
+                                           double min_quality, double mean_quality, double max_unknown)
+{
+    if (!path || byte_lo < 0 || byte_hi < byte_lo) { r_err = "mc_reader_open_range: bad arguments"; return nullptr; }
+    const char *paths[1] = {path};
+    mc_reader *r = mc_reader_open(paths, 1, read_len, nreads, fastq, quality_offset, min_quality, mean_quality, max_unknown, 0, nullptr);
+    if (r) { r->range_lo = byte_lo; r->range_hi = byte_hi; }
+    return r;
+}
+
 extern "C" void mc_reader_close(mc_reader *r) { delete r; }
 
 extern "C" int64_t mc_reader_run(mc_reader *r)
@@ -872,11 +905,13 @@ extern "C" int64_t mc_reader_run(mc_reader *r)
     int64_t kept = 0, rcode = 0;
     char idbuf[32];
     for (const std::string &path : r->paths) {
+        t_range_lo = r->range_lo; t_range_hi = r->range_hi;        // (consumed by Stream::open on this thread)
         const int rc = walk_file(path, P, pool, [&](std::vector<Piece *> &order) -> bool {
             // the sampler's decisions, record by record in file order
             const int64_t kept0 = kept;
             bool full = false;
             for (Piece *pc : order) {
+                if (pc->ragged) r->st.ragged_end = 1;
                 for (Rec &rec : pc->recs) {
                     r->st.records++;
                     r->st.bases += (int64_t)rec.len;
@@ -914,6 +949,7 @@ extern "C" int64_t mc_reader_run(mc_reader *r)
             }
             return !full;
         });
+        t_range_lo = t_range_hi = -1;
         if (rc < 0 && rcode == 0) rcode = rc;
         if (rcode < 0 || kept == r->nreads) break;
     }

@@ -348,6 +348,133 @@ def stream_batches(reader, read_len, on_batch, device=None):
     return n_total, trace, err
 
 
+SLICE_BYTES = 256 << 20     # bytes of a file one rank samples per round (MC_DIST_SLICE in the environment: tests cut small files into many slices)
+
+
+def sharded_sampling_usable(args):
+    """Can every rank sample its own slices of the input?  Without -d (first occurrence wins over the WHOLE stream: that
+    sampler stays on rank 0), on plain regular files (a compressed stream cannot be entered in the middle), and unless
+    MC_DIST_SHARDED=0."""
+    import os
+    if os.environ.get("MC_DIST_SHARDED") == "0" or args.get("filter_dups"):
+        return False
+    for p in args["seqfiles"]:
+        if p.endswith((".gz", ".bz2")) or not os.path.isfile(p):
+            return False
+    return True
+
+
+def stream_batches_sharded(args, on_batch, device=None):
+    """process_seqfile (reference microbe_census.py:328-367) with a sampler on EVERY rank.  One sampler on rank 0 delivers 60 M
+    reads/s of plain FASTQ (9 M/s of .gz) where eight MI355X search 400 M reads/s: file -> AGS could not scale past 1.3 GPUs.
+    The files are walked in rounds of `world` slices of SLICE_BYTES; rank r samples slice r of the round with the native reader
+    on that byte window (mc_reader_open_range: windows cut a file into whole records by one rule, whoever reads them); the
+    ranks exchange their counts of accepted reads; the prefix sum gives every rank the global index of its first read - and the
+    point where the head-take ends: a rank keeps the first nreads - prefix of its reads, the ranks behind it none, and the rounds
+    stop.  on_batch(block, first_read_id) gets the kept reads ((n, L) uint8, host memory).  The sampling of the next round runs
+    beside the search of this one.
+    Returns (n_total, stats, bases, status): stats = the reference's counters (records met before the head-take ended), bases =
+    count_bases() when every file was read to its end (else -1), status 0, or 1 = a window did not end on a record boundary
+    (multi-line FASTQ whose qualities look like headers) or a rank failed: the caller falls back to the sampler on rank 0."""
+    import os
+    import threading
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from . import _native
+    rank, world = dist.get_rank(), dist.get_world_size()
+    nccl = dist.get_backend() == "nccl"
+    tdev = torch.device("cuda", device) if nccl else torch.device("cpu")
+    L, fastq = args["read_length"], args["file_type"] == "fastq"
+    qoff = args.get("quality_offset") or 0
+    nreads = args["nreads"] if args["nreads"] is not None else (1 << 62)
+    try:
+        S = int(os.environ.get("MC_DIST_SLICE", "0")) or SLICE_BYTES
+    except ValueError:
+        S = SLICE_BYTES
+    rounds = []                                                    # (path, lo of rank 0's slice): the same list on every rank
+    for p in args["seqfiles"]:
+        size = os.path.getsize(p)
+        for base in range(0, max(size, 1), S * world):
+            rounds.append((p, base, size))
+
+    def sample(j, cap):
+        p, base, size = rounds[j]
+        lo = min(size, base + rank * S)
+        hi = min(size, lo + S)
+        box = {}
+
+        def work():
+            try:
+                rd = _native.Reader.on_range(p, lo, hi, L, max(1, cap), fastq, qoff, args["min_quality"], args["mean_quality"], args["max_unknown"])
+                box["rd"] = rd
+                box["n"] = rd.run() if hi > lo else 0
+                box["st"] = rd.stats() if hi > lo else {"too_short": 0, "low_qual": 0, "records": 0, "bases": 0, "ragged_end": 0, "exhausted": 1}
+            except BaseException as e:                             # noqa: BLE001
+                box["err"] = e
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        return th, box, (p, lo, hi)
+
+    total, status, cut = 0, 0, False
+    stats = {"too_short": 0, "low_qual": 0, "dups": 0, "records": 0, "bases": 0}
+    err = None
+    cur = sample(0, nreads) if rounds else None
+    for j in range(len(rounds)):
+        th, box, (p, lo, hi) = cur
+        th.join()
+        cur = sample(j + 1, nreads - total) if j + 1 < len(rounds) else None      # (an upper bound of what is still wanted: total only grows)
+        bad = 1 if ("err" in box or (box.get("st") or {}).get("ragged_end")) else 0
+        n_acc = 0 if bad else int(box["n"])
+        mine = torch.tensor([n_acc, bad], dtype=torch.int64, device=tdev)
+        allc = [torch.zeros(2, dtype=torch.int64, device=tdev) for _ in range(world)]
+        dist.all_gather(allc, mine)
+        counts = [int(t[0].item()) for t in allc]
+        if any(int(t[1].item()) for t in allc):
+            status = 1
+            err = box.get("err")
+        else:
+            prefix = total + sum(counts[:rank])
+            keep = max(0, min(n_acc, nreads - prefix))
+            st = box["st"]
+            if keep > 0 and prefix + n_acc >= nreads:              # the head-take ends in this slice: the counters stop with its last read
+                rd2 = _native.Reader.on_range(p, lo, hi, L, keep, fastq, qoff, args["min_quality"], args["mean_quality"], args["max_unknown"])
+                try:
+                    rd2.run()
+                    st = rd2.stats()
+                finally:
+                    rd2.close()
+            if keep > 0 or prefix < nreads:                        # (a slice behind the end of the head-take was never looked at by the reference)
+                for k in ("too_short", "low_qual", "records", "bases"):
+                    stats[k] += int(st[k])
+            if keep > 0:
+                try:
+                    on_batch(box["rd"].reads(n_acc)[:keep], prefix)
+                except BaseException as e:                         # noqa: BLE001 - agreed on below
+                    err = e
+            total += sum(counts)
+            cut = total >= nreads
+        if "rd" in box:
+            box["rd"].close()
+        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int64, device=tdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            status = 1
+        if status or cut:
+            break
+    if cur is not None:                                            # a round sampled ahead and not needed
+        cur[0].join()
+        if "rd" in cur[1]:
+            cur[1]["rd"].close()
+    vec = torch.tensor([stats[k] for k in ("too_short", "low_qual", "records", "bases")], dtype=torch.int64, device=tdev)
+    dist.all_reduce(vec)
+    for k, v in zip(("too_short", "low_qual", "records", "bases"), vec.tolist()):
+        stats[k] = int(v)
+    n_total = min(total, nreads)
+    bases = stats["bases"] if (status == 0 and not cut) else -1
+    return n_total, stats, bases, status
+
+
 def run_pipeline_distributed(args, device=None):
     """run_pipeline() over all ranks of the initialised torch.distributed group (one process per GPU; backend "nccl" = RCCL
     on MI355X, or gloo), STREAMED: rank 0 runs the (sequential, deterministic) sampler on a thread of its own and deals
@@ -404,16 +531,31 @@ def run_pipeline_distributed(args, device=None):
 
         rd = None
         eng.lib.mc_set_keep_rows(eng.h, 0)
+        sharded = None
+        if world > 1 and sharded_sampling_usable(args):                       # a sampler on every rank (plain files, no -d)
+            try:
+                sharded = stream_batches_sharded(args, on_batch, device=device)
+            finally:
+                eng.lib.mc_set_keep_rows(eng.h, 1)
+            if sharded[3] != 0:                                                # a window off a record boundary, or a rank failed: the sampler on rank 0 decides
+                sharded = None
+                del parts[:]
+                eng.lib.mc_set_keep_rows(eng.h, 0)
         try:
-            if rank == 0:
+            if sharded is not None:
+                n_total, trace, err, bases = sharded[0], None, None, sharded[2]
+                run_pipeline_distributed.last_trace = None
+                run_pipeline_distributed.last_stats = sharded[1]
+            elif rank == 0:
                 rd = _native.Reader(args["seqfiles"], L, args["nreads"], args["file_type"] == "fastq", args.get("quality_offset") or 0,
                                     args["min_quality"], args["mean_quality"], args["max_unknown"], args["filter_dups"])
-            n_total, trace, err = stream_batches(rd, L, on_batch, device=device)
-            run_pipeline_distributed.last_trace = trace
-            bases = -1
-            if rank == 0 and err is None:
-                st = rd.stats()
-                bases = int(st["bases"]) if st.get("exhausted") else -1
+            if sharded is None:
+                n_total, trace, err = stream_batches(rd, L, on_batch, device=device)
+                run_pipeline_distributed.last_trace = trace
+                bases = -1
+                if rank == 0 and err is None:
+                    st = rd.stats()
+                    bases = int(st["bases"]) if st.get("exhausted") else -1
         finally:
             eng.lib.mc_set_keep_rows(eng.h, 1)
             if rd is not None:

@@ -8,6 +8,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(REPO, "tests", "golden")
@@ -124,3 +125,76 @@ def test_batches_are_dealt_to_free_ranks(tmp_path):
     assert [res["deals"].count(r) for r in range(3)] == per_rank
     assert per_rank[1] < per_rank[0] and per_rank[1] < per_rank[2], per_rank      # the slow rank asked less often
     assert per_rank[1] >= 2                                       # ... but was not starved (it held two credits from the start)
+
+
+SHARD_WORKER = r'''
+import gzip, json, os, sys, zlib
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from microbecensus_amd import distributed as D
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+cases = json.load(open(sys.argv[2]))
+out = {}
+for name, a in cases.items():
+    got = []
+    def on_batch(block, first):
+        got.append((int(first), int(block.shape[0]), zlib.crc32(np.ascontiguousarray(block).tobytes())))
+    assert D.sharded_sampling_usable(a)
+    n_total, stats, bases, status = D.stream_batches_sharded(a, on_batch)
+    allg = [None] * world
+    dist.all_gather_object(allg, got)
+    out[name] = {"n_total": n_total, "stats": stats, "bases": bases, "status": status, "batches": allg}
+if rank == 0:
+    json.dump(out, open(sys.argv[3], "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_every_rank_samples_its_own_slices(tmp_path, world):
+    """stream_batches_sharded (gloo, no GPU): the reference's inputs as plain files, cut into slices of 150 KB that the ranks sample
+    side by side (mc_reader_open_range) - the kept reads, in the order of their global indices, are exactly the reads of the ONE
+    sequential sampler (process_seqfile :328-367: head-take over the files one after the other), its counters and count_bases
+    included: all reads of the unit-test metagenome; the first 5,000 accepted reads of example.fq (length filter; the take ends
+    inside a slice); the paired library given as two files with the take ending in the second; a -q 20 run of the 300 bp library."""
+    import gzip
+    import zlib
+    from microbecensus_amd import _native
+    inp = os.path.join(GOLD, "inputs")
+    plain = {}
+    for f in ("metagenome.fa.gz", "example.fq.gz", "c4_pair_1.fq.gz", "c4_pair_2.fq.gz", "c5_300bp.fq.gz"):
+        plain[f] = str(tmp_path / f[:-3])
+        open(plain[f], "wb").write(gzip.open(os.path.join(inp, f), "rb").read())
+    base = {"min_quality": -5, "mean_quality": -5, "max_unknown": 100, "filter_dups": False}
+    cases = {
+        "metagenome": dict(base, seqfiles=[plain["metagenome.fa.gz"]], read_length=100, nreads=10**9, file_type="fasta", quality_offset=None),
+        "example_take": dict(base, seqfiles=[plain["example.fq.gz"]], read_length=100, nreads=5000, file_type="fastq", quality_offset=32),
+        "pair_take": dict(base, seqfiles=[plain["c4_pair_1.fq.gz"], plain["c4_pair_2.fq.gz"]], read_length=150, nreads=15000, file_type="fastq", quality_offset=32),
+        "q20": dict(base, seqfiles=[plain["c5_300bp.fq.gz"]], read_length=300, nreads=10**9, file_type="fastq", quality_offset=32, min_quality=20),
+    }
+    cj = tmp_path / "cases.json"
+    cj.write_text(json.dumps(cases))
+    worker = tmp_path / "shard.py"
+    worker.write_text(SHARD_WORKER)
+    out = tmp_path / "shard.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MC_DIST_SLICE="150000")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                           "--master-port", str(29521 + world), str(worker), REPO, str(cj), str(out)], env=env, timeout=900)
+    res = json.load(open(out))
+    for name, a in cases.items():
+        want, st = _native.sample_reads(a["seqfiles"], a["read_length"], a["nreads"], a["file_type"] == "fastq", a["quality_offset"] or 0,
+                                        a["min_quality"], a["mean_quality"], a["max_unknown"], False)
+        r = res[name]
+        assert r["status"] == 0 and r["n_total"] == st["sampled"] == len(want), name
+        at = 0
+        for first, n, crc in sorted(tuple(b) for per_rank in r["batches"] for b in per_rank):
+            assert first == at and crc == zlib.crc32(want[first:first + n].tobytes()), (name, first, at)
+            at += n
+        assert at == len(want), name
+        for k in ("too_short", "low_qual", "records"):
+            assert r["stats"][k] == st[k], (name, k, r["stats"], st)
+        assert r["bases"] == (st["bases"] if st["exhausted"] else -1) or (r["bases"] == -1 and st["sampled"] == a["nreads"]), (name, r["bases"], st)
+        assert sum(1 for per_rank in r["batches"] if per_rank) >= min(world, 2), name      # (more than one rank sampled something)

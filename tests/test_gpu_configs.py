@@ -88,6 +88,39 @@ def test_config4_shape_two_ranks_gloo(tmp_path):
     assert abs(res["est"] - g["est_ags"]) <= 1e-9 * g["est_ags"]
 
 
+def test_sharded_sampling_two_ranks_gloo(tmp_path):
+    """run_pipeline_distributed on a PLAIN file with two ranks (both on this box's GPU, gloo): every rank samples its own slices
+    (mc_reader_open_range; slices of 1 MB here), the head-take and the read indices come from the exchanged counts, one all_reduce of
+    the per-family sums - the reference's AGS for the unit-test metagenome, and nothing dealt by rank 0."""
+    import gzip
+    import subprocess
+    import sys
+    g = json.load(open(os.path.join(GOLD, "unittest_metagenome.json")))
+    fa = tmp_path / "metagenome.fa"
+    fa.write_bytes(gzip.open(os.path.join(INPUTS, "metagenome.fa.gz"), "rb").read())
+    worker = tmp_path / "w.py"
+    worker.write_text(r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from microbecensus_amd import distributed as D
+dist.init_process_group(backend="gloo")
+est, args = D.run_pipeline_distributed({"seqfiles": [sys.argv[3]]}, device=0)
+if dist.get_rank() == 0:
+    json.dump({"est": est, "sampled": args["sampled_reads"], "L": args["read_length"], "dealt": D.run_pipeline_distributed.last_trace is not None,
+               "stats": D.run_pipeline_distributed.last_stats}, open(sys.argv[2], "w"))
+dist.barrier()
+dist.destroy_process_group()
+''')
+    out = tmp_path / "o.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MC_DIST_SLICE="1000000")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29547", str(worker), REPO, str(out), str(fa)], env=env, timeout=900)
+    res = json.load(open(out))
+    assert res["sampled"] == g["sampled_reads"] and res["L"] == 100 and res["dealt"] is False and res["stats"]["records"] == g["sampled_reads"]
+    assert abs(res["est"] - g["est_ags"]) <= 1e-9 * g["est_ags"]
+
+
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_stage_by_stage_against_the_reference(case):
     """sampler -> search -> classification -> aggregation -> estimate: the temp FASTA, the m8 file, the best hits, the
