@@ -347,9 +347,9 @@ def e2e_rate(device, gen, n, L, gz):
 
 
 def e2e_distributed(gen, n, L, rank, world, local, rdev):
-    """File -> AGS over all ranks (microbecensus_amd.distributed.run_pipeline_distributed): rank 0 samples the file and deals batches
-    of 2 M accepted reads to the ranks while it samples; every rank searches what it is dealt; one all_reduce of the per-family sums.
-    Wall time from before the call to after it on every rank, the maximum over the ranks."""
+    """File -> AGS over all ranks (microbecensus_amd.distributed.run_pipeline_distributed) on a plain FASTQ: every rank samples and
+    searches its own slices of the file; one all_reduce of the per-family sums.  Wall time from before the call to after it on every
+    rank, the maximum over the ranks."""
     import contextlib
     import io
     import shutil
@@ -374,8 +374,9 @@ def e2e_distributed(gen, n, L, rank, world, local, rdev):
         walls.append(float(w.item()))
     if rank == 0:
         shutil.rmtree(os.path.dirname(box[0]), ignore_errors=True)
-    return {"what": "run_pipeline_distributed(file -> AGS) over %d ranks: rank 0 samples and deals batches while the ranks search; wall time of the second of two calls, "
-                    "maximum over the ranks" % world, "reads": n, "file": "FASTQ", "wall_s": round(walls[-1], 3), "reads_per_s": round(n / walls[-1], 1),
+    return {"what": "run_pipeline_distributed(file -> AGS) over %d ranks on a plain FASTQ: every rank samples its own slices of the file (mc_reader_open_range) and searches "
+                    "them, the head-take and the read indices come from the exchanged counts, one all_reduce of the per-family sums (a .gz input or -d: rank 0 samples "
+                    "and deals batches to the free ranks); wall time of the second of two calls, maximum over the ranks" % world, "reads": n, "file": "FASTQ", "wall_s": round(walls[-1], 3), "reads_per_s": round(n / walls[-1], 1),
             "first_call_wall_s": round(walls[0], 3), "sampled_reads": int(a["sampled_reads"]), "est_ags": est}
 
 
