@@ -22,17 +22,23 @@
 // then holds reads of similar size instead of one read of 90 HSPs among 63 idle lanes.
 #define MC_LIGHT_CLASS(n) ((n) <= 4 ? 0 : (n) <= 16 ? 1 : (n) <= 48 ? 2 : 3)
 __global__ void __launch_bounds__(256) k_heavy_lists(const uint32_t *__restrict__ nv, uint32_t nheads, uint32_t *nrow_of,
-                                                     McBestHit *best_of, uint32_t *counters, uint32_t *heavy, uint32_t *light, uint32_t light_pitch, uint32_t fh_min)
+                                                     McBestHit *best_of, uint32_t *counters, uint32_t *heavy, uint32_t *light, uint32_t light_pitch, uint32_t fh_min,
+                                                     uint32_t *heavy1, uint32_t *heavy2, uint32_t *heavy3)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    int cls = -1;                                                // -1 nothing to do, 0..3 light class, 4 heavy
+    int cls = -1, hc = 0;                                        // -1 nothing to do, 0..3 light class, 4 heavy (hc: which of the three wave-per-read kernels)
     if (s < nheads) {
         const uint32_t any = nrow_of[s];                           // (k_order_*: the read is marked, nv[s] = the size of its stacks)
         if (!any) best_of[s].family = -1;
-        else { const uint32_t n = nv[s]; cls = n > fh_min ? 4 : MC_LIGHT_CLASS(n); }
+        else { const uint32_t n = nv[s]; cls = n > fh_min ? 4 : MC_LIGHT_CLASS(n); hc = n <= MC_FH_N1 ? 1 : n <= MC_FH_N2 ? 2 : 3; }
     }
     const uint32_t o = mc_block_alloc(&counters[C_HEAVY], cls == 4);
     if (cls == 4) heavy[o] = s;
+    // the heavy reads by the kernel whose arrays hold their stacks - known exactly now that the stacks are built before the finishing:
+    // the three kernels run side by side (they used to hand the reads that did not fit from one to the next)
+    { const uint32_t o1 = mc_block_alloc(&counters[C_HEAVY1], cls == 4 && hc == 1); if (cls == 4 && hc == 1) heavy1[o1] = o; }
+    { const uint32_t o2 = mc_block_alloc(&counters[C_HEAVY2], cls == 4 && hc == 2); if (cls == 4 && hc == 2) heavy2[o2] = o; }
+    { const uint32_t o3 = mc_block_alloc(&counters[C_HEAVY3], cls == 4 && hc == 3); if (cls == 4 && hc == 3) heavy3[o3] = o; }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const uint32_t oc = mc_block_alloc(&counters[C_LIGHT0 + c], cls == c);
@@ -338,7 +344,7 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
 #endif
     for (uint32_t bi = blockIdx.x; bi < nheavy; bi += gridDim.x) {
         MC_FH_TICK(0);
-        const uint32_t slot = CTR == C_HEAVY ? bi : list[bi];        // position in the first list (heavy_first): the later lists hold slots
+        const uint32_t slot = list[bi];                               // position in the list of all heavy reads (heavy_first)
         const uint32_t s = heavy_first[slot] & 0x7FFFFFFFu, a = heads[s], b = heads[s + 1];
         const int nseg = (int)(b - a);                              // (the read's scratch is laid out by the size of its segment)
         const int n = (int)nv[s];                                   // its stacks: v[a, a + n) (k_order_*: the first record of a subject's stack carries the stack's size in .read)

@@ -28,8 +28,8 @@
 // (and the tails of the latency-bound kernels of one part overlap the kernels of the other).
 #define MC_NCTX 2
 struct McCtx {
-    hipStream_t stream = nullptr, side = nullptr;
-    hipEvent_t ev[8] = {}, ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream = nullptr, side = nullptr, side2 = nullptr;
+    hipEvent_t ev[8] = {}, ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     int64_t cap_reads = 0;
     uint32_t cap_tasks = 0, cap_gaps = 0, cap_hsps = 0, cap_rows = 0;
     uint8_t *d_frames = nullptr, *d_frames_base = nullptr;   // (64 bytes of room in front: k_eval_seeds reads 8 bytes at a time backwards from a seed)
@@ -108,8 +108,8 @@ static void ctx_free(McCtx &c)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : {(void *)c.h_c, (void *)c.h_stats, (void *)c.h_best}) if (p) (void)hipHostFree(p);
     for (auto &e : c.ev) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {c.ev_fork, c.ev_join}) if (e) (void)hipEventDestroy(e);
-    for (hipStream_t q : {c.stream, c.side}) if (q) (void)hipStreamDestroy(q);
+    for (hipEvent_t e : {c.ev_fork, c.ev_join, c.ev_join2}) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t q : {c.stream, c.side, c.side2}) if (q) (void)hipStreamDestroy(q);
     c = McCtx();
 }
 
@@ -145,9 +145,10 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
     HIPCK(hipFree(nullptr));
     MC_OT("  HIP runtime, device", t0);
     for (McCtx &c : h->ctx) {
-        HIPCK(hipStreamCreate(&c.stream)); HIPCK(hipStreamCreate(&c.side));
+        HIPCK(hipStreamCreate(&c.stream)); HIPCK(hipStreamCreate(&c.side)); HIPCK(hipStreamCreate(&c.side2));
         for (auto &e : c.ev) HIPCK(hipEventCreate(&e));
         HIPCK(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming)); HIPCK(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&c.ev_join2, hipEventDisableTiming));
         if (dalloc(&c.d_counters, C_N) || dalloc(&c.d_stats, S_N)) return -1;
         HIPCK(hipHostMalloc((void **)&c.h_c, sizeof(uint32_t) * C_N, hipHostMallocDefault));
         HIPCK(hipHostMalloc((void **)&c.h_stats, sizeof(unsigned long long) * S_N, hipHostMallocDefault));
@@ -559,19 +560,25 @@ static int stage_d(mc_handle *h, McCtx &c)
         // second one (each hands the reads its LDS arrays cannot hold to the next)
         uint32_t *d_heavy = c.d_retry, *d_heavy2 = c.d_retry + c.cap_gaps / 2, *d_heavy3 = c.d_retry + c.cap_gaps;      // (d_retry is free again: the gap tasks are done)
         uint32_t *d_light = c.d_retry + c.cap_gaps + c.cap_gaps / 2;
+        uint32_t *d_heavy1 = c.d_retry2;                                // (the ordering kernels' lists: done)
         const uint32_t light_pitch = (uint32_t)c.cap_reads + 1;
-        k_heavy_lists<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(c.d_nv, nheads, c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_light, light_pitch, h->best_only ? MC_FH_MIN_BEST : MC_FH_MIN);
+        k_heavy_lists<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(c.d_nv, nheads, c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_light, light_pitch, h->best_only ? MC_FH_MIN_BEST : MC_FH_MIN,
+                                                                         d_heavy1, d_heavy2, d_heavy3);
         HIPCK(hipEventRecord(c.ev_fork, st));
         {
             const size_t l1 = (size_t)MC_FH_N1 * 16 + 3 * (size_t)(MC_FH_N1 + 2) * 2, l2 = (size_t)MC_FH_N2 * 16 + 3 * (size_t)(MC_FH_N2 + 2) * 2, l3 = (size_t)MC_FH_N3 * 16 + 3 * (size_t)(MC_FH_N3 + 2) * 2;
             HIPCK(hipFuncSetAttribute((const void *)k_finish_heavy<MC_FH_N3, C_HEAVY3, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
             HIPCK(hipStreamWaitEvent(c.side, c.ev_fork, 0));
-            k_finish_heavy<MC_FH_N1, C_HEAVY, C_HEAVY2><<<dim3(256 * 12), dim3(64), l1, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
-                                                                                                   c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy, d_heavy2);
-            k_finish_heavy<MC_FH_N2, C_HEAVY2, C_HEAVY3><<<dim3(256 * 3), dim3(64), l2, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
-                                                                                                   c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy2, d_heavy3);
-            k_finish_heavy<MC_FH_N3, C_HEAVY3, -1><<<dim3(256), dim3(64), l3, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
+            HIPCK(hipStreamWaitEvent(c.side2, c.ev_fork, 0));
+            // the two kernels of the larger reads (few reads, long chains, a fraction of the GPU) beside the first one
+            k_finish_heavy<MC_FH_N2, C_HEAVY2, -1><<<dim3(256 * 3), dim3(64), l2, c.side2>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
+                                                                                            c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy2, nullptr);
+            k_finish_heavy<MC_FH_N3, C_HEAVY3, -1><<<dim3(256), dim3(64), l3, c.side2>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
                                                                                          c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy3, nullptr);
+            HIPCK(hipEventRecord(c.ev_join2, c.side2));
+            k_finish_heavy<MC_FH_N1, C_HEAVY1, -1><<<dim3(256 * 12), dim3(64), l1, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
+                                                                                            c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy1, nullptr);
+            HIPCK(hipStreamWaitEvent(c.side, c.ev_join2, 0));
             // MergeRes' heap sort of all of them (a lane per read), then their rows (a wave per read)
             const size_t lh = (size_t)(MC_MAX_M8 + 2) * 64 * 4;
             HIPCK(hipFuncSetAttribute((const void *)k_heap_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lh));
@@ -580,13 +587,13 @@ static int stage_d(mc_handle *h, McCtx &c)
             HIPCK(hipEventRecord(c.ev_join, c.side));
         }
         // the light reads: the four size classes side by side (the counts stay on the device; blocks past a class' count leave at once)
-        {   // (size classes 2, 3 - up to 48 / 96 stacked HSPs - with 96 items of LDS per thread, classes 0, 1 - up to 4 / 16 - with 16; the
+        {   // (size classes 2, 3 - up to 48 / MC_FH_MIN stacked HSPs - with MC_FH_MIN items of LDS per thread, classes 0, 1 - up to 4 / 16 - with 16; the
             // items are reached through generic pointers - mc_finish_stacked is shared with the host - and a flat access to LDS must stay
             // below 64 KB of the workgroup's allocation: 32 and 128 threads per workgroup)
-            const size_t lb = 32 * (96 * 16 + 16), ls = 128 * (16 * 16 + 16);
+            const size_t lb = 32 * (MC_FH_MIN * 16 + 16), ls = 128 * (16 * 16 + 16);
             static const int fin_lds = getenv("MC_FINISH_GLOBAL") ? 0 : 1;          // (experiments: the items in global scratch, as before round 4)
-            HIPCK(hipFuncSetAttribute((const void *)k_finish<32, 96, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
-            k_finish<32, 96, 2><<<dim3((nheads + 31) / 32, 2), dim3(32), lb, st>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp,
+            HIPCK(hipFuncSetAttribute((const void *)k_finish<32, MC_FH_MIN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+            k_finish<32, MC_FH_MIN, 2><<<dim3((nheads + 31) / 32, 2), dim3(32), lb, st>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp,
                                                                                  c.first_read_id, c.d_nrow, c.d_bestof, d_light, light_pitch, c.d_counters + C_LIGHT0, fin_lds);
             k_finish<128, 16, 0><<<dim3((nheads + 127) / 128, 2), dim3(128), ls, st>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp,
                                                                                      c.first_read_id, c.d_nrow, c.d_bestof, d_light, light_pitch, c.d_counters + C_LIGHT0, fin_lds);
