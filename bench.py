@@ -68,7 +68,7 @@ def spawn_ranks(n, argv):
 STAGE_KERNELS = {   # kernels whose HIP-event time a stage of mc_stats spans (prefixes of the names in the rocprofv3 summaries)
     "k_translate_seg": ["k_translate_seg"], "k_enumerate_t0": ["k_enumerate_t0<"], "k_enumerate": ["k_enumerate_t0<", "k_enumerate"], "k_eval_seeds": ["k_eval_seeds"],
     "k_gapped": ["k_gap_dedupe", "k_gapped_lds", "k_gapped", "k_gap_emit"], "k_finish": ["k_finish", "k_finish_heavy", "k_heap_lanes", "k_heavy_rows", "k_heavy_lists", "k_emit_rows"],
-    "sort": ["k_make_keys", "k_gather", "k_heads"],
+    "sort": ["k_bin_count", "k_bin_scatter", "k_scan_sums", "k_scan_top", "k_scan_apply", "k_order_lists", "k_order_light", "k_order_heavy", "k_order_copy"],
 }
 
 
@@ -557,7 +557,7 @@ def main():
             "k_enumerate": n_batch * 6 * (L // 3) + 16 * hits + index_touch,  # frames in, seed hits out (16 B), index touches
             "k_eval_seeds": 16 * hits + residue_touch + 48 * hsps + 28 * gtasks,   # seed hits in, residues around them, HSPs (48 B) and gap tasks (28 B) out
             "k_gapped": (28 + 32 + 48) * gtasks,                             # gap tasks in, two flank results (16 B) and an HSP out per task
-            "sort": hsps * (48 + 48 + 2 * 12),                               # HSPs in and out in (read, subject, hit order); keys
+            "sort": hsps * (16 + 20 + 20 + 96 * 0.4),                        # stage C: keys and place words in, 20 B binned and read again, the records of the marked reads' HSPs (~40 %) fetched and written
             "k_finish": hsps * 48 + rows * 64,                               # HSPs in, m8 rows out
         }
         prof = load_profile(L)
