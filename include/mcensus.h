@@ -61,6 +61,9 @@ void mc_close(mc_handle *h);
  * and read back by later mc_open() calls; a file that does not match its header, sizes, input hash and checksum is ignored and
  * rebuilt.  The directory should be writable by the user alone (the Python layer uses ~/.cache/microbecensus_amd, mode 0700). */
 int mc_set_index_cache(const char *dir);
+/* Host only (tests; no GPU): builds the index, writes it to dir, reads it back and compares every array, then checks that a file of
+ * other sequences, a damaged and a truncated file are refused.  0 = all of that held. */
+int mc_index_cache_check(const char *const *names, const char *const *seqs, int32_t nseq, const char *dir);
 
 /* The same from a database `prerapsearch` already wrote (the reference ships one as data/rapdb_2.15): residues, buckets,
  * posting order and suffix keys are taken from the file, the GPU-side structures derived from them.  All markers start in

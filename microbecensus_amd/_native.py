@@ -57,6 +57,7 @@ def load_library():
     lib.mc_open.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32]
     lib.mc_close.argtypes = [C.c_void_p]
     lib.mc_set_index_cache.argtypes = [C.c_char_p]
+    lib.mc_index_cache_check.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int32, C.c_char_p]
     lib.mc_open_rapdb.restype = C.c_void_p
     lib.mc_open_rapdb.argtypes = [C.c_char_p, C.c_int32]
     lib.mc_marker_count.restype = C.c_int32
@@ -120,7 +121,7 @@ def load_library():
     return lib
 
 
-EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_set_index_cache", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
+EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_set_index_cache", "mc_index_cache_check", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
                     "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_set_parts", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8", "mc_write_m8_named",
                     "mc_reader_last_error", "mc_set_host_threads", "mc_reader_open", "mc_reader_open_range", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_reader_trim", "mc_count_bases", "mc_quality_offset",
                     "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_reader_nreads", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows", "mc_set_best_hits_only", "mc_grid_classify"]

@@ -197,6 +197,36 @@ extern "C" int mc_set_index_cache(const char *dir)
     return 0;
 }
 
+// Host only (no GPU): does the index cache give back what was built?  Builds the index, writes it to <dir>, reads it back and
+// compares every array; then damages one byte of the file and expects the load to refuse it.  0 = all of that held.
+extern "C" int mc_index_cache_check(const char *const *names, const char *const *seqs, int32_t nseq, const char *dir)
+{
+    McHostIndex A, B, C2;
+    std::string err;
+    if (!dir || !mc_build_index(A, names, seqs, nseq, err)) { g_err = err.empty() ? "bad argument" : err; return -1; }
+    const uint64_t ih = mc_ixc_input_hash(names, seqs, nseq);
+    char nm[64]; snprintf(nm, sizeof nm, "/index_%016llx.mcix", (unsigned long long)ih);
+    const std::string path = std::string(dir) + nm;
+    if (!mc_index_save(A, ih, path.c_str())) { g_err = "cannot write " + path; return -1; }
+    if (!mc_index_load(B, ih, nseq, path.c_str())) { g_err = "the file just written was not accepted"; return 1; }
+    if (!(A.names == B.names && A.res_code == B.res_code && A.res == B.res && A.off == B.off && A.bstart == B.bstart && A.post == B.post && A.keys == B.keys && A.bitmap == B.bitmap &&
+          A.filt == B.filt && A.wild == B.wild && A.pair == B.pair && A.rt == B.rt && A.rec.size() == B.rec.size() &&
+          (A.rec.empty() || memcmp(A.rec.data(), B.rec.data(), A.rec.size() * sizeof(McBucketRec)) == 0) && A.rt_mask == B.rt_mask && A.max_bucket == B.max_bucket &&
+          A.freq_thr == B.freq_thr && A.nres == B.nres && A.nseq == B.nseq && memcmp(A.letter_p, B.letter_p, sizeof A.letter_p) == 0)) { g_err = "the index read back differs from the one built"; return 2; }
+    if (mc_index_load(C2, ih ^ 1, nseq, path.c_str())) { g_err = "a file of other sequences was accepted"; return 3; }
+    {   // one byte of the payload flipped: the checksum must notice
+        FILE *f = fopen(path.c_str(), "r+b");
+        if (!f) { g_err = "cannot reopen " + path; return -1; }
+        fseek(f, 0, SEEK_END); const long sz = ftell(f);
+        fseek(f, sz / 2, SEEK_SET); int c = fgetc(f); fseek(f, sz / 2, SEEK_SET); fputc(c ^ 0x40, f); fclose(f);
+        if (mc_index_load(C2, ih, nseq, path.c_str())) { g_err = "a damaged file was accepted"; return 4; }
+        f = fopen(path.c_str(), "r+b"); fseek(f, sz / 2, SEEK_SET); fputc(c, f); fclose(f);
+        if (truncate(path.c_str(), sz - 9) != 0 || mc_index_load(C2, ih, nseq, path.c_str())) { g_err = "a truncated file was accepted"; return 5; }
+    }
+    remove(path.c_str());
+    return 0;
+}
+
 extern "C" mc_handle *mc_open(const char *const *names, const char *const *seqs, int32_t nseq, const int32_t *marker_family, int32_t nfam, int32_t device)
 {
     mc_handle *h = new mc_handle();

@@ -69,3 +69,17 @@ def test_writer_reproduces_prerapsearch_byte_for_byte(tmp_path):
     _native.rapdb_write(names, seqs, out)
     for suffix in ("", ".info"):
         assert hashlib.md5(open(out + suffix, "rb").read()).hexdigest() == hashlib.md5(open(RAPDB + suffix, "rb").read()).hexdigest(), suffix
+
+
+def test_index_cache_round_trip(tmp_path):
+    """The per-user cache of built indexes (mc_set_index_cache; DESIGN 3, cold start): what mc_open() would read back is, array by
+    array, what mc_build_index built; a file written for other sequences, a file with one flipped byte and a truncated file are
+    refused (and the index rebuilt).  No GPU."""
+    import ctypes as C
+    from microbecensus_amd import _native
+    names, seqs = _native.load_markers()
+    lib = _native.load_library()
+    n = len(names)
+    rc = lib.mc_index_cache_check((C.c_char_p * n)(*[s.encode() for s in names]), (C.c_char_p * n)(*[s.encode() for s in seqs]), n, str(tmp_path).encode())
+    assert rc == 0, lib.mc_last_error().decode()
+    assert not list(tmp_path.iterdir())
