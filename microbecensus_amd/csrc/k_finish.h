@@ -221,9 +221,30 @@ __device__ __forceinline__ uint32_t *mc_heavy_words(McHsp *tmp, uint32_t a, int 
 // of dependent LDS accesses - as lane 0 of the read's own wave it was half of the heavy kernels' time (cycle counters), with 63
 // lanes waiting; here 64 reads are replayed side by side.  Words transposed in LDS (word e of lane l at e * 64 + l: lanes on the
 // same word never share a bank), 502 words per lane = 128.5 KB: one wave per CU.
+// The heavy reads in descending order of their rows (a counting sort by one workgroup): a wave of k_heap_lanes takes as long as the
+// longest of its 64 heap sorts, and the few thousand reads with 400 - 500 rows, spread over the list, sat in nearly every wave - two
+// rounds of waves (one per CU) each as long as a 500-row sort.  Together they fill a fifth of the first round, and the rest is short.
+__global__ void __launch_bounds__(1024) k_heap_order(const uint32_t *__restrict__ heavy_first, const uint32_t *__restrict__ nrow_of, const uint32_t *__restrict__ counters, uint32_t *order)
+{
+    __shared__ uint32_t bin[MC_MAX_M8 + 2];
+    const uint32_t nheavy = counters[C_HEAVY];
+    for (uint32_t i = threadIdx.x; i < MC_MAX_M8 + 2; i += 1024) bin[i] = 0;
+    __syncthreads();
+    auto key = [&](uint32_t slot) -> uint32_t {                   // rows of the read (0: finished already, or nothing to sort)
+        const uint32_t e = heavy_first[slot];
+        if (!(e & 0x80000000u)) return 0u;
+        const uint32_t n = nrow_of[e & 0x7FFFFFFFu];
+        return n > MC_MAX_M8 ? (uint32_t)MC_MAX_M8 : n;
+    };
+    for (uint32_t slot = threadIdx.x; slot < nheavy; slot += 1024) atomicAdd(&bin[key(slot)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int k = MC_MAX_M8; k >= 0; k--) { const uint32_t c = bin[k]; bin[k] = run; run += c; } }
+    __syncthreads();
+    for (uint32_t slot = threadIdx.x; slot < nheavy; slot += 1024) order[atomicAdd(&bin[key(slot)], 1u)] = slot;
+}
 #define MC_HL_H(e) lds[((e) << 6) + lane]
 __global__ void __launch_bounds__(64) k_heap_lanes(const uint32_t *__restrict__ heads, uint32_t nheads, uint32_t nhsps, McHsp *tmp, const uint32_t *__restrict__ nrow_of,
-                                                   const uint32_t *__restrict__ counters, const uint32_t *__restrict__ heavy_first)
+                                                   const uint32_t *__restrict__ counters, const uint32_t *__restrict__ heavy_first, const uint32_t *__restrict__ order)
 {
     uint32_t *lds = (uint32_t *)mc_smem;
     __shared__ uint32_t s_nr[64];
@@ -233,10 +254,10 @@ __global__ void __launch_bounds__(64) k_heap_lanes(const uint32_t *__restrict__ 
     for (uint32_t slot0 = blockIdx.x * 64u; slot0 < nheavy; slot0 += gridDim.x * 64u) {
         int n = 0;
         {
-            const uint32_t slot = slot0 + (uint32_t)lane;
+            const uint32_t at = slot0 + (uint32_t)lane;
             uint32_t *hw = nullptr;
-            if (slot < nheavy) {
-                const uint32_t e = heavy_first[slot];
+            if (at < nheavy) {
+                const uint32_t e = heavy_first[order[at]];
                 if (e & 0x80000000u) {
                     const uint32_t s = e & 0x7FFFFFFFu, a = heads[s], b = heads[s + 1];
                     n = (int)nrow_of[s];

@@ -590,7 +590,7 @@ static int stage_d(mc_handle *h, McCtx &c)
         // second one (each hands the reads its LDS arrays cannot hold to the next)
         uint32_t *d_heavy = c.d_retry, *d_heavy2 = c.d_retry + c.cap_gaps / 2, *d_heavy3 = c.d_retry + c.cap_gaps;      // (d_retry is free again: the gap tasks are done)
         uint32_t *d_light = c.d_retry + c.cap_gaps + c.cap_gaps / 2;
-        uint32_t *d_heavy1 = c.d_retry2;                                // (the ordering kernels' lists: done)
+        uint32_t *d_heavy1 = c.d_retry2, *d_heap_order = c.d_retry2 + c.cap_gaps;   // (the ordering kernels' lists: done)
         const uint32_t light_pitch = (uint32_t)c.cap_reads + 1;
         k_heavy_lists<<<dim3((nheads + 255) / 256), dim3(256), 0, st>>>(c.d_nv, nheads, c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_light, light_pitch, h->best_only ? MC_FH_MIN_BEST : MC_FH_MIN,
                                                                          d_heavy1, d_heavy2, d_heavy3);
@@ -612,7 +612,8 @@ static int stage_d(mc_handle *h, McCtx &c)
             // MergeRes' heap sort of all of them (a lane per read), then their rows (a wave per read)
             const size_t lh = (size_t)(MC_MAX_M8 + 2) * 64 * 4;
             HIPCK(hipFuncSetAttribute((const void *)k_heap_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lh));
-            k_heap_lanes<<<dim3(256), dim3(64), lh, c.side>>>(c.d_heads, nheads, nh, c.d_tmp, c.d_nrow, c.d_counters, d_heavy);
+            k_heap_order<<<dim3(1), dim3(1024), 0, c.side>>>(d_heavy, c.d_nrow, c.d_counters, d_heap_order);
+            k_heap_lanes<<<dim3(256), dim3(64), lh, c.side>>>(c.d_heads, nheads, nh, c.d_tmp, c.d_nrow, c.d_counters, d_heavy, d_heap_order);
             k_heavy_rows<<<dim3(256 * 12), dim3(64), 0, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id, c.d_nrow, c.d_bestof, c.d_counters, d_heavy);
             HIPCK(hipEventRecord(c.ev_join, c.side));
         }
