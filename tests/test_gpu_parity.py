@@ -134,6 +134,35 @@ def test_generic_seed_path_on_a_database_with_a_seed_threshold(tmp_path):
         assert st["bucket_lookups"] > 0                  # (the generic kernel counts the reference algorithm's index reads: it is the one that ran)
 
 
+@pytest.mark.parametrize("case", ["config1_example_fq", "dirty_reads"])
+def test_stage_counts_equal_the_emulation(case, engine, tmp_path):
+    """Stage by stage (a localisation aid beside the end-to-end m8 equality): the number of seed hits the seed kernel
+    emits, of gap tasks and of HSPs the evaluation and the gapped stage keep must be the numbers the CPU emulation of the same
+    per-thread code counts (tests/emul/mc_emul, itself pinned on the reference's m8) - a difference names the stage."""
+    import re
+    import subprocess
+    from microbecensus_amd import _native
+    here = os.path.dirname(os.path.abspath(__file__))
+    repo = os.path.dirname(here)
+    exe = str(tmp_path / "mc_emul")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(here, "emul", "mc_emul.cpp")])
+    faa = tmp_path / "markers.faa"
+    faa.write_bytes(gzip.open(os.path.join(repo, "microbecensus_amd", "data", "markers.faa.gz"), "rb").read())
+    src = os.path.join(GOLD, "dirty_reads.fa.gz" if case == "dirty_reads" else case + ".reads.fa.gz")
+    fa = tmp_path / "reads.fa"
+    fa.write_bytes(gzip.open(src, "rb").read())
+    r = subprocess.run([exe, str(faa), str(fa), str(tmp_path / "e.m8")], stderr=subprocess.PIPE, check=True)
+    err = r.stderr.decode()
+    want = {"seed_tasks": int(re.search(r"seed tasks: (\d+)", err).group(1)), "gap_tasks": int(re.search(r"gapped tasks: (\d+)", err).group(1)),
+            "hsps": int(re.search(r"hsps kept: (\d+)", err).group(1))}
+    seqs = [l.rstrip(b"\r\n") for l in gzip.open(src, "rb") if not l.startswith(b">")]
+    reads = np.frombuffer(b"".join(seqs), dtype=np.uint8).reshape(len(seqs), len(seqs[0]))
+    engine.set_run(reads.shape[1])
+    engine.search(reads)
+    st = engine.stats()
+    assert {k: st[k] for k in want} == want
+
+
 def test_the_product_library_is_the_one_loaded():
     """The GPU tests must exercise microbecensus_amd/libmcensus_hip.so itself: no MCENSUS_LIB override in the environment, and
     the library mapped into this process is the in-tree one."""
