@@ -12,9 +12,11 @@
 // MC_FH_MIN: reads with more stacked HSPs than this are finished by a whole wave (k_finish_heavy); MC_FH_MIN_BEST: the same with
 // best hits only, where few reads are finished and the longest thread of k_finish decides (per 1 M reads of 150 bp: 96 / 48 / 32 / 16
 // -> finishing 2.36 / 2.64 / 2.65 / 3.80 ms with rows, 2.38 / 1.43 / 1.41 / 1.42 ms with best hits only)
+#ifndef MC_FH_N1          // (a test builds the library with small arrays so that ordinary reads take the paths of the largest ones)
 #define MC_FH_N1 512      // subjects / ranked HSPs a read may have in the first wave kernel (11 KB of LDS per wave) ...
 #define MC_FH_N2 2048     // ... in the second (45 KB) ...
 #define MC_FH_N3 6144     // ... and in the third (135 KB, one wave per CU), where anything larger is finished by lane 0 alone
+#endif
 
 // The reads that get a wave of their own (k_finish_heavy), collected before the finishing kernels start so that they can run
 // beside the thread-per-read kernel on a second stream.  A read without a marked HSP prints nothing whatever its size.

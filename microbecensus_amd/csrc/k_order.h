@@ -145,9 +145,11 @@ __device__ __forceinline__ void mc_hsp_copy(McHsp *dst, const McHsp *src)
 // then ranked inside their segment by counting the smaller keys and copied to their ranks.  The reads with longer segments are
 // listed for k_order_heavy.
 #define MC_OL_READS 64
+#ifndef MC_ORDER_SMALL                     // (a test builds the library with small arrays so that ordinary reads take the paths of the longest ones)
 #define MC_ORDER_SMALL 512                 // segments up to this long: a wave per read (two buffers of 4 KB in LDS) ...
 #define MC_ORDER_MID 2048                  // ... up to this long (3 reads in 1,000): a workgroup of four waves (two buffers of 16 KB) ...
 #define MC_ORDER_LDS 8192                  // ... the few longer ones (0.6 in 1,000): a workgroup of sixteen waves (two buffers of 64 KB; beyond that: blocks of 8192, merged in global memory)
+#endif
 // the reads whose segments are longer than MC_BIN_LIGHT, listed for k_order_heavy (a thread per read)
 __global__ void __launch_bounds__(256) k_order_lists(const uint32_t *__restrict__ heads, uint32_t nreads, uint32_t *counters, uint32_t *heavy, uint32_t *heavy2, uint32_t *heavy3)
 {

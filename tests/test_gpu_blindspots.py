@@ -126,3 +126,62 @@ def test_log_e_threshold_other_than_one_against_oracle(engine, thr, tmp_path):
                           env=dict(os.environ, RS_LOGE_THR=repr(thr)))
     got, want = (tmp_path / "gpu.m8").read_bytes(), (tmp_path / "cpu.m8").read_bytes()
     assert want.count(b"\n") > 50 and hashlib.md5(got).hexdigest() == hashlib.md5(want).hexdigest(), (len(rows), want.count(b"\n"))
+
+
+_SMALL_WORKER = r"""
+import gzip, hashlib, json, os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from microbecensus_amd import _native, synth
+gold = os.path.join(sys.argv[1], "tests", "golden")
+out = {}
+eng = _native.Engine(device=0)
+for case, L in (("config1_example_fq", 100), ("unittest_metagenome", 100)):
+    meta = json.load(open(os.path.join(gold, case + ".json")))
+    if os.path.exists(os.path.join(gold, case + ".reads.fa.gz")):
+        seqs = [l.strip() for l in gzip.open(os.path.join(gold, case + ".reads.fa.gz"), "rb") if not l.startswith(b">")]
+    else:
+        recs, seq = [], None
+        for line in gzip.open(os.path.join(gold, "inputs", meta["seqfiles"][0]), "rb"):
+            if line[:1] == b">":
+                if seq is not None: recs.append(b"".join(seq))
+                seq = []
+            else:
+                seq.append(line.strip())
+        recs.append(b"".join(seq))
+        seqs = [s[:L] for s in recs if len(s) >= L]
+    reads = np.frombuffer(b"".join(seqs), dtype=np.uint8).reshape(len(seqs), L)
+    eng.set_run(L)
+    rows, _ = eng.search(reads)
+    eng.write_m8(sys.argv[2])
+    out[case] = [len(rows), hashlib.md5(open(sys.argv[2], "rb").read()).hexdigest(), meta["m8_rows"], meta["m8_md5"]]
+# a read of the genome set with ~200 HSPs nearly all of which print, among copies: the wave kernels and the heap sort
+read = np.frombuffer(b"CCTGGCAATGATGACTCCATCAGAGCAATTGGTTATTACGCAAGAGAAAT", dtype=np.uint8)
+eng.set_run(50)
+rows, _ = eng.search(np.tile(read, (70, 1)))
+out["heavy_read_rows"] = len(rows)
+json.dump(out, open(sys.argv[3], "w"))
+"""
+
+
+def test_ordering_paths_of_the_longest_reads_on_ordinary_reads(tmp_path):
+    """The ordering kernels treat segments by size: up to 32 HSPs ranked by counting, up to 512 merge-sorted by a wave, up to 2048 /
+    8192 by a workgroup, longer ones in blocks merged in global memory (k_order.h) - on the test sets nothing is longer than a few
+    thousand HSPs.  Here the library is built with arrays of 64 / 128 / 256 items, so that ordinary reads of marker genes take
+    every one of those paths, the merge in global memory included - and with finishing kernels of 128 / 192 / 256 stacked HSPs, so
+    that the largest reads are finished by lane 0 in global scratch (k_finish_heavy's last resort): the reference's m8, byte for byte."""
+    import json
+    import subprocess
+    import sys
+    csrc = os.path.join(REPO, "microbecensus_amd", "csrc")
+    lib = str(tmp_path / "libsmall.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                           "-DMC_ORDER_SMALL=64", "-DMC_ORDER_MID=128", "-DMC_ORDER_LDS=256", "-DMC_FH_N1=128", "-DMC_FH_N2=192", "-DMC_FH_N3=256", "-o", lib,
+                           os.path.join(csrc, "mc_hip.hip"), os.path.join(csrc, "mc_reader.cpp"), "-lz", "-ldl", "-pthread"], timeout=900)
+    w = tmp_path / "w.py"
+    w.write_text(_SMALL_WORKER)
+    subprocess.check_call([sys.executable, str(w), REPO, str(tmp_path / "o.m8"), str(tmp_path / "o.json")], env=dict(os.environ, MCENSUS_LIB=lib), timeout=900)
+    res = json.load(open(tmp_path / "o.json"))
+    for case in ("config1_example_fq", "unittest_metagenome"):
+        assert res[case][:2] == res[case][2:], case
+    assert res["heavy_read_rows"] == 198 * 70
