@@ -101,11 +101,24 @@ int mc_run(mc_handle *h, int64_t first_read_id);
 /* runs the pipeline on reads [first, first+count) of the resident set (count <= 2097151). */
 int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id);
 
-/* mc_run_range() can cut its range into `parts` parts (1, the default, or 2) whose pipeline stages are issued alternately on
- * separate HIP streams.  Every kernel of the pipeline fills the GPU by itself and the host's waits between the stages are short
- * (0.3 ms of 46 per 2 M reads), so one part is as fast as two (round 3: 45.6 against 49.5 ms) and is the default; 2 is kept for
- * experiments.  Results do not depend on it. */
+/* Kept for callers of earlier rounds: accepted and ignored (a range is one part; what overlaps ranges is mc_set_pipeline). */
 int mc_set_parts(mc_handle *h, int parts);
+
+/* Two ranges in flight (an option for callers with small ranges; the streaming calls do NOT use it by default).
+ * mc_range_begin() issues a range and returns when its front (translation, seeds, extensions) is done, mc_range_end() completes
+ * the OLDEST range begun: results as after mc_run_range(), valid until the next mc_range_end() / mc_run_range().  At most two
+ * ranges are in flight; begin, begin, end, begin, end, ..., end keeps the ordering / finishing of one beside the front of the
+ * next.  mc_set_pipeline(h, tail_cus) first gives the handle streams with CU masks - the front of a range owns 256 - tail_cus
+ * CUs, its tail the other tail_cus (a divisor of 256, at most 128; 0, the default: ordinary streams).  Measured at 150 bp with
+ * 2 M reads per range: 52.3 M reads/s one range at a time, 53.8 with two in flight on ordinary streams,
+ * 50.9 with tail_cus = 64 - the latency-bound seed kernel loses what the overlap gains.  Either call returns -2 when the range
+ * overflowed a pool: it is then no longer in flight - end the other one and give the range to mc_run_range(), which runs it in
+ * smaller pieces.  mc_run_range() / mc_search*() refuse to run while ranges are in flight.  MC_PIPELINE=<tail_cus> in the
+ * environment makes mc_search() / mc_search_files() pipeline their batches this way.  Results never depend on any of this. */
+int mc_set_pipeline(mc_handle *h, int tail_cus);
+int mc_range_begin(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id);
+int mc_range_end(mc_handle *h);
+int mc_ranges_in_flight(const mc_handle *h);
 
 /* The seed kernel can count the index reads of the reference's algorithm for the batch (mc_stats.bucket_lookups /
  * key_probes: what CHashSearch::Searching@0x415050 / ExtendSeq2Set@0x413b90 would read - bench.py reports the rate at which

@@ -185,3 +185,76 @@ def test_ordering_paths_of_the_longest_reads_on_ordinary_reads(tmp_path):
     for case in ("config1_example_fq", "unittest_metagenome"):
         assert res[case][:2] == res[case][2:], case
     assert res["heavy_read_rows"] == 198 * 70
+
+
+def test_ranges_in_flight_equal_ranges_one_at_a_time(engine, marker_reads, monkeypatch):
+    """mc_set_pipeline + mc_range_begin / mc_range_end (two ranges in flight, the tail of one on CU-masked streams beside the front
+    of the next) against mc_run_range on the same resident reads: rows, best hits and counts equal, range by range - for the masks
+    of three widths; then the streaming call itself (mc_search in 20,000-read batches) with and without MC_PIPELINE; and a
+    range whose pools overflow comes back with -2 from begin or end, leaves nothing in flight, and the stream that meets one
+    still delivers every row in order (the marker-dense library in 150,000-read batches)."""
+    from microbecensus_amd import _native, synth
+    names, seqs = _native.load_markers()
+    model = _native.load_model()
+    genome = synth.build_genomes(seqs, total_bp=2_000_000, seed=21)
+    reads = synth.sample_reads(genome, 240_000, 150, seed=22)
+    engine.set_run(150, model["pars"]["150"], model["families"])
+    engine.upload(reads)
+    n, step = len(reads), 30_000
+    want = []
+    for at in range(0, n, step):
+        engine.run_range(at, step, at)
+        want.append((engine.rows(), engine.best_hits(), engine.stats()))
+    assert sum(len(w[0]) for w in want) > 100_000
+    for cus in (64, 8, 128):
+        engine.set_pipeline(cus)
+        try:
+            got, begun = [], 0
+            for at in range(0, n, step):
+                engine.range_begin(at, step, at)
+                begun += 1
+                if engine.ranges_in_flight() == 2:
+                    engine.range_end()
+                    got.append((engine.rows(), engine.best_hits(), engine.stats()))
+            with pytest.raises(RuntimeError, match="in flight"):
+                engine.run_range(0, step, 0)
+            while engine.ranges_in_flight():
+                engine.range_end()
+                got.append((engine.rows(), engine.best_hits(), engine.stats()))
+            with pytest.raises(RuntimeError, match="no range in flight"):
+                engine.range_end()
+        finally:
+            engine.set_pipeline(0)
+        assert len(got) == len(want) == begun
+        for (r, b, s), (r0, b0, s0) in zip(got, want):
+            assert _fields_equal(r, r0) and _fields_equal(b, b0)
+            assert all(s[k] == s0[k] for k in ("reads", "seed_tasks", "gap_tasks", "hsps", "rows", "reads_with_rows", "classified"))
+    # the streaming call: batches in flight (MC_PIPELINE) against one at a time (the default)
+    monkeypatch.setenv("MC_STREAM_BATCH", "20000")
+    rows_1, best_1 = engine.search(reads)
+    monkeypatch.setenv("MC_PIPELINE", "64")
+    rows_p, best_p = engine.search(reads)
+    assert _fields_equal(rows_p, rows_1) and _fields_equal(best_p, best_1)
+    assert _fields_equal(rows_p, np.concatenate([w[0] for w in want])) and _fields_equal(best_p, np.concatenate([w[1] for w in want]))
+    # overflowing ranges in a pipelined stream: every batch of 150,000 marker-dense reads overflows the pools
+    monkeypatch.delenv("MC_PIPELINE")
+    monkeypatch.setenv("MC_STREAM_BATCH", "5000")
+    rows5, best5 = engine.search(marker_reads)
+    assert engine.stats()["range_splits"] == 0
+    monkeypatch.setenv("MC_PIPELINE", "64")
+    monkeypatch.setenv("MC_STREAM_BATCH", "150000")
+    rows_o, best_o = engine.search(marker_reads)
+    st = engine.stats()
+    assert st["range_splits"] > 0 and st["reads"] == len(marker_reads) and _fields_equal(rows_o, rows5) and _fields_equal(best_o, best5)
+    monkeypatch.delenv("MC_PIPELINE")
+    engine.upload(marker_reads)
+    engine.set_pipeline(64)
+    try:
+        with pytest.raises(RuntimeError, match=r"\(-2\)"):
+            engine.range_begin(0, 150_000, 0)
+            engine.range_end()
+        assert engine.ranges_in_flight() == 0
+        engine.run_range(0, 150_000, 0)
+        assert engine.stats()["range_splits"] > 0 and _fields_equal(engine.rows(), rows5[rows5["query"] < 150_000])
+    finally:
+        engine.set_pipeline(0)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Development aid (GPU box): gapped-extension kernel times for several refill thresholds / occupancies: tools/gap_sweep.sh
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-cd /tmp && export TMPDIR=/tmp MC_PARTS=1
+cd /tmp && export TMPDIR=/tmp
 IFS=";" read -ra CFGS <<< "${GAP_CFGS:-8 5}"
 for L in 150 300; do
   for cfg in "${CFGS[@]}"; do

@@ -2,7 +2,7 @@
 # Per-kernel durations of a short bench run (development aid, run on the GPU box): tools/kernel_trace.sh [read-len] [extra bench args]
 L=${1:-150}; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-cd /tmp && export TMPDIR=/tmp MC_PARTS=1   # MC_PARTS=1: the two parts of a range do not overlap - every kernel alone on the GPU
+cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/ktrace_L$L
 rm -rf $OUT && mkdir -p $OUT
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 4 --warmup 6 --batch 1000000 --resident-batches 2 --read-len $L --no-cpu-baseline --no-ags-check --e2e-reads 0 "$@" > $OUT/trace.log 2>&1

@@ -4,7 +4,7 @@
 K=${1:-k_gapped}
 L=${2:-150}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-cd /tmp && export TMPDIR=/tmp MC_PARTS=1   # MC_PARTS=1: the two parts of a range do not overlap - every kernel alone on the GPU
+cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/focus
 rm -rf $OUT && mkdir -p $OUT
 BENCH="python3 $R/bench.py --steps 3 --warmup 6 --batch 1000000 --resident-batches 1 --read-len $L --no-cpu-baseline --no-ags-check --e2e-reads 0"

@@ -7,7 +7,7 @@
 TAG=${1:-r03}
 L=${2:-150}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-cd /tmp && export TMPDIR=/tmp MC_PARTS=1
+cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_L$L
 rm -rf $OUT && mkdir -p $OUT
 BENCH="python3 $R/bench.py --steps 4 --warmup 6 --batch 1000000 --resident-batches 2 --read-len $L --no-cpu-baseline --no-ags-check --e2e-reads 0 --no-best-only-leg"
