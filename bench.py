@@ -396,9 +396,7 @@ def main():
     ap.add_argument("--no-ags-check", action="store_true", help="skip the run_pipeline AGS comparison on the reference's own inputs")
     ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the end-to-end (file -> AGS) measurement (plain FASTQ; a fifth of it, at least 4 M, for .gz); 0 = skip")
     ap.add_argument("--no-best-only-leg", action="store_true", help="skip the extra timed leg with mc_set_best_hits_only (what run_pipeline runs)")
-    ap.add_argument("--pipeline", type=int, default=0, help="0 (default, what the product runs): one step at a time (mc_run_range). R > 0: step i + 1 is begun before step i is ended "
-                                                             "(mc_range_begin / mc_range_end) on streams with R tail CUs (mc_set_pipeline); -1: the same on ordinary streams - DESIGN.md 5.5: neither pays")
-    ap.add_argument("--no-serial-leg", action="store_true", help="skip the extra timed leg that runs the steps one at a time (N = 1, --pipeline > 0)")
+    ap.add_argument("--one-at-a-time", action="store_true", help="mc_run_range per step (the device idles while the host sums the best hits up) instead of mc_range_end / mc_range_begin / results")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL, one GPU per rank (the measurement); gloo: all ranks on GPU 0, reductions on the host - "
                                                                                "only to exercise the N > 1 code path on a one-GPU box")
     args = ap.parse_args()
@@ -468,16 +466,7 @@ def main():
     nf = len(fams)
     tot_hits = np.zeros(nf, np.int64); tot_aln = np.zeros(nf, np.int64); tot_bylen = np.zeros((nf, mcd.MAX_TARGET_LEN), np.int64)
 
-    def begin(i):
-        b = i % nres
-        if args.pipeline:
-            eng.range_begin(b * args.batch, args.batch, first_read_id=b * args.batch)
-        else:
-            eng.run_range(b * args.batch, args.batch, first_read_id=b * args.batch)
-
-    def finish(collect=True):
-        if args.pipeline:
-            eng.range_end()
+    def collect_results(collect=True):
         best = eng.best_hits(copy=False)    # the rows of the batch are in host memory too (mc_result_rows); the aggregation needs the best hits
         hits, aln, bylen = mcd.family_accumulators(best, nf)
         if world > 1:                       # RCCL: per-family hit counts / alignment sums of this step over all GPUs
@@ -491,21 +480,29 @@ def main():
 
     def run_steps(k, collect=True):
         """k steps.  A step is one batch through the whole path - search, best hits, per-family accumulators (and their all_reduce).
-        With --pipeline (an experiment) step i + 1 is begun before step i is
-        ended: its translation / seed / extension kernels run beside the ordering and finishing of step i (mc_set_pipeline)."""
+        As mc_search / mc_search_files do with their batches, the front of step i + 1 (translation, seeds) is enqueued before the host
+        looks at the results of step i (mc_range_end, mc_range_begin, results): the device does not idle while the host sums up.
+        --one-at-a-time: mc_run_range per step, as rounds 1 - 3 measured."""
         acc = {}
-        for i in range(k):
-            begin(i)
-            if args.pipeline and i == 0:
-                continue
-            for key, v in finish(collect).items():
+        def add(st):
+            for key, v in st.items():
                 acc[key] = acc.get(key, 0) + v
-        if args.pipeline and k:
-            for key, v in finish(collect).items():
-                acc[key] = acc.get(key, 0) + v
+        if args.one_at_a_time:
+            for i in range(k):
+                b = i % nres
+                eng.run_range(b * args.batch, args.batch, first_read_id=b * args.batch)
+                add(collect_results(collect))
+            return acc
+        for i in range(k + 1):
+            if i > 0:
+                eng.range_end()
+            if i < k:
+                b = i % nres
+                eng.range_begin(b * args.batch, args.batch, first_read_id=b * args.batch)
+            if i > 0:
+                add(collect_results(collect))
         return acc
 
-    eng.set_pipeline(max(0, args.pipeline))
     run_steps(args.warmup, collect=False)
     torch.cuda.synchronize()
     if world > 1:
@@ -535,20 +532,6 @@ def main():
             t2 = torch.tensor([dt_only], dtype=torch.float64, device=rdev)
             dist.all_reduce(t2, op=dist.ReduceOp.MAX)
             dt_only = float(t2.item())
-    # ... and, with --pipeline, the timed steps once more ONE AT A TIME on ordinary streams (what rounds 1 - 3 measured)
-    dt_serial, st_serial = None, None
-    if args.pipeline and world == 1 and not args.no_serial_leg:
-        pipe = args.pipeline
-        args.pipeline = 0
-        eng.set_pipeline(0)
-        run_steps(1, collect=False)
-        torch.cuda.synchronize()
-        t1 = time.time()
-        st_serial = run_steps(K, collect=False)
-        torch.cuda.synchronize()
-        dt_serial = time.time() - t1
-        args.pipeline = pipe
-    eng.set_pipeline(0)
     tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -630,8 +613,8 @@ def main():
                        "rows_per_read": round(job["rows"] / reads_total, 4), "reads_with_rows": round(job["reads_with_rows"] / reads_total, 5),
                        "hsps_per_read": round(job["hsps"] / reads_total, 3), "gapped_extensions_per_read": round(job["gap_tasks"] / reads_total, 3),
                        "seed_hits_per_read": round(job["seed_tasks"] / reads_total, 2), "ags_estimate_of_workload": est,
-                       "pipeline": ("two steps in flight (mc_range_begin / mc_range_end), tail CUs %d" % args.pipeline) if args.pipeline else "one step at a time (mc_run_range: what mc_search / mc_search_files run per batch)",
-                       # HIP events on the library's own streams around each stage, timed region (with --pipeline a stage's time includes what it waited for the CUs it shares)
+                       "steps_issued": "mc_run_range per step" if args.one_at_a_time else "mc_range_end(i), mc_range_begin(i + 1), results of i: the front of the next step is enqueued before the host sums up (as mc_search / mc_search_files do with their batches)",
+                       # HIP events on the library's own streams around each stage, timed region (one kernel at a time)
                        "kernel_ms_per_step": {k: round(v / K, 3) for k, v in kern.items()},
                        "sum_kernel_ms_per_step": round(sum(kern.values()) / K, 3)},
             "roofline": {"kernel": dom, "bound": (d_dom or {}).get("bound", "valu_issue"), "nominal_bound": "hbm",
@@ -675,10 +658,6 @@ def main():
                                                   "that have an HSP passing their family's thresholds are sorted and finished, no m8 rows; identical best hits",
                                           "value": round(reads_total / dt_only, 1), "unit": "reads/s", "ms_per_step": round(dt_only / K * 1e3, 3),
                                           "kernel_ms_per_step": {k: round(st_only[m] / K, 3) for k, m in SEQ.items()}}
-        if dt_serial is not None:
-            out["one_step_at_a_time"] = {"what": "the same steps through mc_run_range on ordinary streams (every kernel has all 256 CUs, nothing overlaps: what rounds 1 - 3 reported as value)",
-                                         "value": round(reads_total / dt_serial, 1), "unit": "reads/s", "ms_per_step": round(dt_serial / K * 1e3, 3),
-                                         "kernel_ms_per_step": {k: round(st_serial[m] / K, 3) for k, m in SEQ.items()}}
         if world == 1 and not args.no_cpu_baseline:
             cores = usable_cores()
             plan = [(cores, args.cpu_sample), (8, args.cpu_sample), (1, args.cpu_sample if args.cpu_full else max(1000, args.cpu_sample // 75))]

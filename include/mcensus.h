@@ -101,21 +101,17 @@ int mc_run(mc_handle *h, int64_t first_read_id);
 /* runs the pipeline on reads [first, first+count) of the resident set (count <= 2097151). */
 int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id);
 
-/* Kept for callers of earlier rounds: accepted and ignored (a range is one part; what overlaps ranges is mc_set_pipeline). */
+/* Kept for callers of earlier rounds: accepted and ignored (a range is one part). */
 int mc_set_parts(mc_handle *h, int parts);
 
-/* Two ranges in flight (an option for callers with small ranges; the streaming calls do NOT use it by default).
- * mc_range_begin() issues a range and returns when its front (translation, seeds, extensions) is done, mc_range_end() completes
- * the OLDEST range begun: results as after mc_run_range(), valid until the next mc_range_end() / mc_run_range().  At most two
- * ranges are in flight; begin, begin, end, begin, end, ..., end keeps the ordering / finishing of one beside the front of the
- * next.  mc_set_pipeline(h, tail_cus) first gives the handle streams with CU masks - the front of a range owns 256 - tail_cus
- * CUs, its tail the other tail_cus (a divisor of 256, at most 128; 0, the default: ordinary streams).  Measured at 150 bp with
- * 2 M reads per range: 52.3 M reads/s one range at a time, 53.8 with two in flight on ordinary streams,
- * 50.9 with tail_cus = 64 - the latency-bound seed kernel loses what the overlap gains.  Either call returns -2 when the range
- * overflowed a pool: it is then no longer in flight - end the other one and give the range to mc_run_range(), which runs it in
- * smaller pieces.  mc_run_range() / mc_search*() refuse to run while ranges are in flight.  MC_PIPELINE=<tail_cus> in the
- * environment makes mc_search() / mc_search_files() pipeline their batches this way.  Results never depend on any of this. */
-int mc_set_pipeline(mc_handle *h, int tail_cus);
+/* A stream of ranges without the device waiting for the host.  mc_range_begin() enqueues the FRONT of a range (translation,
+ * seeds, seed evaluation: two thirds of its time) and returns at once; mc_range_end() completes the OLDEST range begun - results
+ * as after mc_run_range(), valid until the next mc_range_end() / mc_run_range().  The order end(i), begin(i + 1), <look at the
+ * results of i>, end(i + 1), ... lets the host collect rows and best hits while the device works on the next front (two
+ * contexts per handle, used in turn; at most two ranges begun).  mc_search() / mc_search_files() run their batches this way,
+ * bench.py its steps.  mc_range_end() returns -2 when the range overflowed a pool: it is then no longer in flight - give it to
+ * mc_run_range(), which runs it in smaller pieces (after ending the other range, if one was begun).  mc_run_range() and
+ * mc_search*() refuse to run while ranges are in flight.  Results never depend on any of this. */
 int mc_range_begin(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id);
 int mc_range_end(mc_handle *h);
 int mc_ranges_in_flight(const mc_handle *h);

@@ -76,7 +76,6 @@ def load_library():
     lib.mc_run_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
     lib.mc_set_counting.argtypes = [C.c_void_p, C.c_int]
     lib.mc_set_parts.argtypes = [C.c_void_p, C.c_int]
-    lib.mc_set_pipeline.argtypes = [C.c_void_p, C.c_int]
     lib.mc_range_begin.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
     lib.mc_range_end.argtypes = [C.c_void_p]
     lib.mc_ranges_in_flight.argtypes = [C.c_void_p]
@@ -126,7 +125,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_set_index_cache", "mc_index_cache_check", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
-                    "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_set_parts", "mc_set_pipeline", "mc_range_begin", "mc_range_end", "mc_ranges_in_flight", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8", "mc_write_m8_named",
+                    "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_set_parts", "mc_range_begin", "mc_range_end", "mc_ranges_in_flight", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8", "mc_write_m8_named",
                     "mc_reader_last_error", "mc_set_host_threads", "mc_reader_open", "mc_reader_open_range", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_reader_trim", "mc_count_bases", "mc_quality_offset",
                     "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_reader_nreads", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows", "mc_set_best_hits_only", "mc_grid_classify"]
 
@@ -409,17 +408,12 @@ class Engine:
         self._check(self.lib.mc_set_counting(self.h, 1 if on else 0), "mc_set_counting")
 
     def set_parts(self, parts):
-        """Accepted and ignored (rounds 2 - 3: a range as two overlapping halves); see set_pipeline."""
+        """Accepted and ignored (rounds 2 - 3: a range as two overlapping halves)."""
         self._check(self.lib.mc_set_parts(self.h, parts), "mc_set_parts")
 
-    def set_pipeline(self, tail_cus):
-        """Streams with CU masks for two ranges in flight (range_begin / range_end): the tail of a range - ordering, finishing - on
-        `tail_cus` CUs beside the front of the next on the others.  0 (default): ordinary streams.  Measured: it does not pay at
-        2 M reads per range (include/mcensus.h)."""
-        self._check(self.lib.mc_set_pipeline(self.h, tail_cus), "mc_set_pipeline")
-
     def range_begin(self, first, count, first_read_id=0):
-        """Issues the range; returns when its front (translation, seeds, extensions) is done.  At most two in flight."""
+        """Enqueues the front of the range (translation, seeds, seed evaluation) and returns at once.  range_end(), range_begin(next),
+        then the results of the range that ended: the device runs the next front while the host looks at them.  At most two begun."""
         self._check(self.lib.mc_range_begin(self.h, first, count, first_read_id), "mc_range_begin")
 
     def range_end(self):

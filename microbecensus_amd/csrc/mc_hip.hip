@@ -27,8 +27,7 @@
 // mc_range_end() take them in turn, so that the tail of one range (ordering, finishing) runs beside the front of the next.
 #define MC_NCTX 2
 struct McCtx {
-    hipStream_t stream = nullptr, side = nullptr, side2 = nullptr, tail = nullptr; hipEvent_t ev_tail = nullptr;   // the streams in use: one of the two sets below (ctx_streams)
-    hipStream_t plain[3] = {}, masked[4] = {}; int masked_R = 0;
+    hipStream_t stream = nullptr, side = nullptr, side2 = nullptr;   // the pipeline of a range, and two side streams of the ordering / finishing kernels
     hipEvent_t ev[8] = {}, ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     int64_t cap_reads = 0;
     uint32_t cap_tasks = 0, cap_gaps = 0, cap_hsps = 0, cap_rows = 0;
@@ -62,11 +61,10 @@ struct mc_handle {
     uint32_t *d_filt = nullptr, *d_wild = nullptr, *d_pair = nullptr; uint64_t *d_segtab = nullptr; unsigned long long *d_rt = nullptr;
     bool fast_enum = false;
     bool count_traffic = false;
-    int pipe_R = 0;                       // mc_set_pipeline: CUs owned by the tail streams (0: no pipelining across ranges)
     int pipe_next = 0, pipe_out[MC_NCTX] = {-1, -1}, pipe_nout = 0;   // mc_range_begin / mc_range_end: the context the next range takes, the ranges in flight (oldest first)
     bool keep_rows = true;                // mc_search / mc_search_files hand out the m8 rows (mc_set_keep_rows)
     bool best_only = false;               // only the reads that can be classified are ranked; no rows (mc_set_best_hits_only)
-    uint8_t *stage_pin[3] = {}, *stage_dev[3] = {}; size_t stage_bytes = 0; int stage_slots = 0; hipStream_t copy_stream = nullptr;   // run_stream
+    uint8_t *stage_pin[2] = {}, *stage_dev[2] = {}; size_t stage_bytes = 0; hipStream_t copy_stream = nullptr;   // run_stream
     // resident reads
     int64_t nreads = 0, cap_own = 0;
     uint8_t *d_reads = nullptr;
@@ -81,6 +79,7 @@ struct mc_handle {
     std::vector<mc_row> all_rows, split_rows;                       // accumulated over the batches of a stream / over the halves of a range that overflowed
     const mc_row *res_rows = nullptr; int64_t n_res_rows = 0;
     std::vector<mc_best_hit> best; mc_stats stats;
+    McCtx *best_from = nullptr;                                    // the context whose best hits (pinned, unordered) are those of the last range: best_materialize
 };
 
 static McIndex dev_index(const mc_handle *h)
@@ -103,33 +102,6 @@ extern "C" int mc_device_count(void)
     return n;
 }
 
-// The streams of a context.  R = 0: three ordinary streams (the pipeline of a range, and two side streams of the ordering / finishing
-// kernels).  R > 0 (mc_set_pipeline): the front of a range (stages A, B: persistent kernels that fill every CU they are given) runs on
-// a stream that owns 256 - R of the CUs, its tail (stages C, D: ordering, finishing) on streams that own the other R (every 256/R-th
-// bit of the mask) - so that the tail of one range can run beside the front of the next (mc_range_begin / mc_range_end).
-static int ctx_streams(McCtx &c, int R)
-{   // (both sets are kept once made: run_stream switches to the masked ones for its duration)
-    for (hipStream_t q : {c.stream, c.side, c.side2, c.tail}) if (q) (void)hipStreamSynchronize(q);
-    if (R > 0) {
-        if (c.masked_R != R) {
-            for (hipStream_t &q : c.masked) if (q) { (void)hipStreamDestroy(q); q = nullptr; }
-            uint32_t front[8], tail[8];
-            for (int w = 0; w < 8; w++) { front[w] = 0xFFFFFFFFu; tail[w] = 0; }
-            const int step = 256 / R;
-            for (int i = 0; i < 256; i += step) { tail[i >> 5] |= 1u << (i & 31); front[i >> 5] &= ~(1u << (i & 31)); }
-            HIPCK(hipExtStreamCreateWithCUMask(&c.masked[0], 8, front));
-            for (int k = 1; k < 4; k++) HIPCK(hipExtStreamCreateWithCUMask(&c.masked[k], 8, tail));
-            if (!c.ev_tail) HIPCK(hipEventCreateWithFlags(&c.ev_tail, hipEventDisableTiming));
-            c.masked_R = R;
-        }
-        c.stream = c.masked[0]; c.side = c.masked[1]; c.side2 = c.masked[2]; c.tail = c.masked[3];
-    } else {
-        for (hipStream_t &q : c.plain) if (!q) HIPCK(hipStreamCreate(&q));
-        c.stream = c.plain[0]; c.side = c.plain[1]; c.side2 = c.plain[2]; c.tail = nullptr;
-    }
-    return 0;
-}
-
 static void ctx_free(McCtx &c)
 {
     void *ptrs[] = {c.d_frames_base, c.d_tasks, c.d_gaps, c.d_hsps, c.d_v, c.d_tmp, c.d_k64, c.d_hkeys, c.d_hplace, c.d_places, c.d_idx, c.d_idxo, c.d_heads, c.d_scan, c.d_gsz, c.d_nv, c.d_sorttmp, c.d_counters, c.d_rows,
@@ -138,9 +110,7 @@ static void ctx_free(McCtx &c)
     for (void *p : {(void *)c.h_c, (void *)c.h_stats, (void *)c.h_best}) if (p) (void)hipHostFree(p);
     for (auto &e : c.ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {c.ev_fork, c.ev_join, c.ev_join2}) if (e) (void)hipEventDestroy(e);
-    for (hipStream_t q : c.plain) if (q) (void)hipStreamDestroy(q);
-    for (hipStream_t q : c.masked) if (q) (void)hipStreamDestroy(q);
-    if (c.ev_tail) (void)hipEventDestroy(c.ev_tail);
+    for (hipStream_t q : {c.stream, c.side, c.side2}) if (q) (void)hipStreamDestroy(q);
     c = McCtx();
 }
 
@@ -151,7 +121,7 @@ extern "C" void mc_close(mc_handle *h)
     void *ptrs[] = {h->d_res_base, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_pair, h->d_rt, h->d_segtab};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (McCtx &c : h->ctx) ctx_free(c);
-    for (int k = 0; k < 3; k++) { if (h->stage_pin[k]) (void)hipHostFree(h->stage_pin[k]); if (h->stage_dev[k]) (void)hipFree(h->stage_dev[k]); }
+    for (int k = 0; k < 2; k++) { if (h->stage_pin[k]) (void)hipHostFree(h->stage_pin[k]); if (h->stage_dev[k]) (void)hipFree(h->stage_dev[k]); }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->rows_stream) { (void)hipStreamSynchronize(h->rows_stream); (void)hipStreamDestroy(h->rows_stream); }
     if (h->ev_rows) (void)hipEventDestroy(h->ev_rows);
@@ -176,7 +146,7 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
     HIPCK(hipFree(nullptr));
     MC_OT("  HIP runtime, device", t0);
     for (McCtx &c : h->ctx) {
-        if (ctx_streams(c, h->pipe_R)) return -1;
+        HIPCK(hipStreamCreate(&c.stream)); HIPCK(hipStreamCreate(&c.side)); HIPCK(hipStreamCreate(&c.side2));
         for (auto &e : c.ev) HIPCK(hipEventCreate(&e));
         HIPCK(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming)); HIPCK(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
         HIPCK(hipEventCreateWithFlags(&c.ev_join2, hipEventDisableTiming));
@@ -559,8 +529,7 @@ static int stage_b(mc_handle *h, McCtx &c)
 // C: HSPs into per-read segments ordered by (subject, hit order); the reads that can print anything (see k_bin_count)
 static int stage_c(mc_handle *h, McCtx &c)
 {
-    hipStream_t st = c.tail ? c.tail : c.stream;
-    if (c.tail) { HIPCK(hipEventRecord(c.ev_tail, c.stream)); HIPCK(hipStreamWaitEvent(c.tail, c.ev_tail, 0)); }
+    hipStream_t st = c.stream;
     if (c.h_c[C_OVERFLOW]) { g_err = "HSP buffer overflow"; return -2; }
     const uint32_t nslots = c.h_c[C_HSPS];                         // used slots of the pool, the padding of the waves' last blocks included
     c.nh_all = nslots - c.h_c[C_HPAD];
@@ -613,7 +582,7 @@ static int stage_c(mc_handle *h, McCtx &c)
 // D: per-read finishing (linking, ranking, cap, classification), rows into m8 order
 static int stage_d(mc_handle *h, McCtx &c)
 {
-    hipStream_t st = c.tail ? c.tail : c.stream;
+    hipStream_t st = c.stream;
     McIndex X = dev_index(h);
     const uint32_t nh = c.nh, nheads = c.nheads = nh ? (uint32_t)c.n : 0u;   // (every read has a segment, most of them empty or unmarked)
     if (nh) {
@@ -698,7 +667,6 @@ static int stage_d(mc_handle *h, McCtx &c)
     }
 #endif
     HIPCK(hipMemcpyAsync(c.h_stats, c.d_stats, sizeof(unsigned long long) * S_N, hipMemcpyDeviceToHost, st));
-    if (c.tail) { HIPCK(hipEventRecord(c.ev_tail, c.tail)); HIPCK(hipStreamWaitEvent(c.stream, c.ev_tail, 0)); }   // (the part's stream is the one that is waited for)
     return counters_to_host(c);
 }
 
@@ -728,6 +696,7 @@ static void stats_add(mc_stats &tot, const mc_stats &s)
 }
 
 static int run_range_once(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id);
+static void best_materialize(mc_handle *h);
 
 // A range whose seed hits / HSPs / rows overflow the pools sized for ordinary shotgun reads (-2 from the pipeline) is run again in
 // halves, and their results joined: the caller sees one range either way.
@@ -747,79 +716,88 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
         if (rc) return rc;
         rows_wait(h);
         rows.insert(rows.end(), h->res_rows, h->res_rows + h->n_res_rows);
+        best_materialize(h);
         best.insert(best.end(), h->best.begin(), h->best.end());
         stats_add(tot, h->stats);
         off += nb;
     }
-    h->res_rows = rows.data(); h->n_res_rows = (int64_t)rows.size(); h->best.swap(best); h->stats = tot;
+    h->res_rows = rows.data(); h->n_res_rows = (int64_t)rows.size(); h->best.swap(best); h->best_from = nullptr; h->stats = tot;
     return 0;
 }
 
-// One range on one context, in two halves: range_begin issues everything up to the end of the finishing (it waits for the counts
-// of stages A and B on the way - the front of the range), range_end waits for the finishing, sends the rows on their way and
-// collects the best hits and the statistics.  Between the two the context's tail runs by itself: with mc_set_pipeline() the next
-// range is begun on the other context meanwhile.
+// One range on one context, in two halves.  range_begin ISSUES the front of the range (stage A: translation, seeds, seed evaluation -
+// two thirds of its time) and returns at once; range_end does everything else: waits for A, issues and waits for B, C + D, sends the
+// rows on their way and fetches the best hits.  mc_run_range is one after the other.  Callers with a stream of ranges (run_stream,
+// bench.py) call end(i), begin(i + 1) and THEN look at the results of range i: the device works on the next front while the host
+// collects rows and best hits (per 2 M reads of 150 bp 0.4 ms to bring the best hits into read order, whatever the caller does with
+// them, and - mc_search with rows - the 270 MB of rows to copy out of the pinned buffer), on two contexts in turn.
 static int range_begin(mc_handle *h, McCtx &c, int64_t first, int64_t count, int64_t first_read_id)
 {
     if (ensure_capacity(h, c, count)) return -1;
     c.reads = h->reads_dev + first * h->read_len; c.n = count; c.first_read_id = first_read_id;
-    int rc = stage_a(h, c);
-    if (rc == 0 && (rc = stage_wait(c)) == 0) rc = stage_b(h, c);
-    if (rc == 0 && (rc = stage_wait(c)) == 0 && (rc = stage_c(h, c)) == 0) rc = stage_d(h, c);   // (C leaves its counts on the device: D is issued behind it)
-    if (rc) { (void)hipStreamSynchronize(c.stream); if (c.tail) (void)hipStreamSynchronize(c.tail); return rc; }
+    const int rc = stage_a(h, c);
+    if (rc) { (void)hipStreamSynchronize(c.stream); return rc; }
     c.busy = true;
     return 0;
+}
+
+// the best hits of the range that ended last, in the order classify_reads meets the reads (input order) - made when somebody asks
+static void best_materialize(mc_handle *h)
+{
+    McCtx *c = h->best_from;
+    if (!c) return;
+    h->best_from = nullptr;
+    std::sort(c->h_best, c->h_best + c->nbest, [](const McBestHit &x, const McBestHit &y) { return x.read < y.read; });
+    h->best.resize(c->nbest);
+    for (uint32_t i = 0; i < c->nbest; i++) { const McBestHit &x = c->h_best[i]; mc_best_hit &o = h->best[i]; o.read = x.read; o.family = x.family; o.aln = x.aln; o.target_len = x.target_len; o.bits = x.bits; }
 }
 
 static int range_end(mc_handle *h, McCtx &c)
 {
     c.busy = false;
     memset(&h->stats, 0, sizeof h->stats);
-    h->res_rows = nullptr; h->n_res_rows = 0; h->best.clear();
-    h->pin_cur ^= 1; h->pin_rows = h->pin_slot[h->pin_cur]; h->pin_cap = h->pin_slot_cap[h->pin_cur];   // (the other slot may still be receiving the rows of the run before)
+    h->res_rows = nullptr; h->n_res_rows = 0; h->best.clear(); h->best_from = nullptr;
     h->stats.reads = c.n;
     int rc = stage_wait(c);
+    if (rc == 0) rc = stage_b(h, c);
+    if (rc == 0 && (rc = stage_wait(c)) == 0 && (rc = stage_c(h, c)) == 0) rc = stage_d(h, c);   // (C leaves its counts on the device: D is issued behind it)
+    if (rc == 0) rc = stage_wait(c);
     if (rc == 0 && c.h_c[C_OVERFLOW]) { g_err = "row buffer overflow"; rc = -2; }
-    if (rc == 0) {
-        c.nrows = (c.nh && !h->best_only) ? c.h_c[C_ROWS] : 0u; c.nsegs = c.h_c[C_SEGS]; c.nbest = c.h_c[C_BEST];
-        if ((size_t)c.nrows > h->pin_cap) {                          // grow the pinned row buffer
-            (void)hipStreamSynchronize(h->rows_stream);                  // (the copy of the run before writes into the other buffer: let it finish before anything is freed)
-            const size_t want = (size_t)c.nrows + c.nrows / 4 + 1024;
-            mc_row *nb = nullptr;
-            if (hipHostMalloc((void **)&nb, want * sizeof(mc_row), hipHostMallocDefault) != hipSuccess) { g_err = "out of pinned host memory for the rows"; rc = -1; }
-            else {
-                if (h->pin_rows) (void)hipHostFree(h->pin_rows);
-                h->pin_rows = nb; h->pin_cap = want; h->pin_slot[h->pin_cur] = nb; h->pin_slot_cap[h->pin_cur] = want;
-                const int other = h->pin_cur ^ 1;                        // the other slot grows with it (pinning 300 MB takes 40 ms: not in the middle of a later run)
-                if (h->pin_slot_cap[other] < want) {
-                    mc_row *ob = nullptr;
-                    if (hipHostMalloc((void **)&ob, want * sizeof(mc_row), hipHostMallocDefault) == hipSuccess) {
-                        if (h->pin_slot[other]) (void)hipHostFree(h->pin_slot[other]);
-                        h->pin_slot[other] = ob; h->pin_slot_cap[other] = want;
-                    }
-                }
+    if (rc) { (void)hipStreamSynchronize(c.stream); return rc; }
+    h->pin_cur ^= 1; h->pin_rows = h->pin_slot[h->pin_cur]; h->pin_cap = h->pin_slot_cap[h->pin_cur];   // (the other slot may still be receiving the rows of the run before)
+    c.nrows = (c.nh && !h->best_only) ? c.h_c[C_ROWS] : 0u; c.nsegs = c.h_c[C_SEGS]; c.nbest = c.h_c[C_BEST];
+    if ((size_t)c.nrows > h->pin_cap) {                          // grow the pinned row buffer
+        (void)hipStreamSynchronize(h->rows_stream);                  // (the copy of the run before writes into the other buffer: let it finish before anything is freed)
+        const size_t want = (size_t)c.nrows + c.nrows / 4 + 1024;
+        mc_row *nb = nullptr;
+        if (hipHostMalloc((void **)&nb, want * sizeof(mc_row), hipHostMallocDefault) != hipSuccess) { g_err = "out of pinned host memory for the rows"; return -1; }
+        if (h->pin_rows) (void)hipHostFree(h->pin_rows);
+        h->pin_rows = nb; h->pin_cap = want; h->pin_slot[h->pin_cur] = nb; h->pin_slot_cap[h->pin_cur] = want;
+        const int other = h->pin_cur ^ 1;                        // the other slot grows with it (pinning 300 MB takes 40 ms: not in the middle of a later run)
+        if (h->pin_slot_cap[other] < want) {
+            mc_row *ob = nullptr;
+            if (hipHostMalloc((void **)&ob, want * sizeof(mc_row), hipHostMallocDefault) == hipSuccess) {
+                if (h->pin_slot[other]) (void)hipHostFree(h->pin_slot[other]);
+                h->pin_slot[other] = ob; h->pin_slot_cap[other] = want;
             }
         }
     }
-    if (rc == 0) rc = stage_e(h, c, 0);
+    rc = stage_e(h, c, 0);
     if (rc) { (void)hipStreamSynchronize(c.stream); (void)hipStreamSynchronize(h->rows_stream); return rc; }
     if (c.nrows) { HIPCK(hipEventRecord(h->ev_rows, h->rows_stream)); h->rows_pending = true; h->rows_ever = true; }
     if ((rc = stage_wait(c)) != 0) return rc;
     h->res_rows = h->pin_rows; h->n_res_rows = (int64_t)c.nrows;
-    // classify_reads meets the reads in input order
-    std::sort(c.h_best, c.h_best + c.nbest, [](const McBestHit &x, const McBestHit &y) { return x.read < y.read; });
-    for (uint32_t i = 0; i < c.nbest; i++) { const McBestHit &x = c.h_best[i]; mc_best_hit o; o.read = x.read; o.family = x.family; o.aln = x.aln; o.target_len = x.target_len; o.bits = x.bits; h->best.push_back(o); }
+    h->best_from = &c;                                           // (mc_result_best_hits / whoever needs them: best_materialize)
 #ifdef MC_EXP_TIMING
     { const char *nm[6] = {"staging/other", "append", "lookup", "push", "setup", "expand"}; for (int k = 0; k < 6; k++) fprintf(stderr, "timing %-14s %8.3f Mcycles/wave-avg  %10llu entries\n", nm[k], (double)c.h_stats[4 + k] / 4096.0 / 1e6, c.h_stats[10 + k]); }
 #endif
     h->stats.bucket_lookups += (int64_t)c.h_stats[S_LOOKUPS]; h->stats.key_probes += (int64_t)c.h_stats[S_KEYPROBES]; h->stats.seed_tasks += (int64_t)c.h_stats[S_TASKS];
     h->stats.seed_exact_asks += (int64_t)c.h_stats[S_EXACT]; h->stats.seed_wild_asks += (int64_t)c.h_stats[S_WILD]; h->stats.seed_pair_asks += (int64_t)c.h_stats[S_PAIRS]; h->stats.seed_probes += (int64_t)c.h_stats[S_PROBES];
     h->stats.gap_tasks += c.ngaps - c.gpad; h->stats.hsps += c.nh_all; h->stats.rows += c.nrows; h->stats.reads_with_rows += c.nsegs;
-    // kernel times: HIP events around the stages (with mc_set_pipeline the tail of a range runs beside the front of the next: its
-    // stage times then include what it waited for CUs)
+    // kernel times: HIP events around the stages
     h->stats.ms_translate += ev_ms(c.ev[0], c.ev[1]); h->stats.ms_seed += ev_ms(c.ev[1], c.ev[2]); h->stats.ms_eval += ev_ms(c.ev[2], c.ev[3]);
     h->stats.ms_gapped += ev_ms(c.ev[3], c.ev[4]); h->stats.ms_sort += ev_ms(c.ev[4], c.ev[5]); h->stats.ms_finish += ev_ms(c.ev[5], c.ev[6]); h->stats.ms_total += ev_ms(c.ev[0], c.ev[6]);
-    h->stats.classified = (int64_t)h->best.size();
+    h->stats.classified = (int64_t)c.nbest;
     return 0;
 }
 
@@ -835,36 +813,20 @@ static int range_check(mc_handle *h, int64_t first, int64_t count)
 static int run_range_once(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id)
 {
     if (range_check(h, first, count)) return -1;
-    if (count == 0) { memset(&h->stats, 0, sizeof h->stats); h->res_rows = nullptr; h->n_res_rows = 0; h->best.clear(); return 0; }
+    if (count == 0) { memset(&h->stats, 0, sizeof h->stats); h->res_rows = nullptr; h->n_res_rows = 0; h->best.clear(); h->best_from = nullptr; return 0; }
     McCtx &c = h->ctx[0];
     const int rc = range_begin(h, c, first, count, first_read_id);
     if (rc) return rc;
     return range_end(h, c);
 }
 
-// ---- ranges in flight: the tail of one beside the front of the next ---------------------------------------------------------------
-// Stages C and D of a range - ordering, finishing - are a fifth of its time, and some of their kernels (the longest reads) leave most
-// of the GPU idle.  mc_range_begin() issues a range on the context that is free and returns when its front is done, mc_range_end()
-// completes the OLDEST range in flight (results as after mc_run_range): begin, begin, end, begin, end, ... keeps two ranges in flight.
-// mc_set_pipeline(h, R) gives the contexts streams with CU masks (ctx_streams) for it.  MEASURED (round 4, 150 bp, 2 M reads per
-// range): one range at a time 52.3 M reads/s; two in flight on ordinary streams 53.8 (best hits only: 54.4 against
-// 59.1), with R = 32 / 64 / 128: 51.2 / 50.9 / 51.0 - the seed kernel is bound by memory latency and anything that runs beside it
-// slows it by as much as the overlap gains (13.0 -> 15.5 - 19.3 ms), and the ordering kernels take 7 - 16 x as long on the masked
-// CUs.  So the streaming calls run their batches one at a time (MC_PIPELINE in the environment turns this on for experiments) and
-// the calls stay in the ABI, parity-tested, for callers whose ranges are small.
-// A range that overflows a pool comes back with -2 from either call: nothing of it stays in flight; run it with mc_run_range (which
-// splits it) once the ranges still in flight have been ended.
-extern "C" int mc_set_pipeline(mc_handle *h, int tail_cus)
-{
-    if (!h || tail_cus < 0 || tail_cus > 128 || (tail_cus && 256 % tail_cus)) { g_err = "mc_set_pipeline: 0, or a divisor of 256 up to 128"; return -1; }
-    if (h->pipe_nout) { g_err = "mc_set_pipeline: ranges are in flight"; return -1; }
-    HIPCK(hipSetDevice(h->device));
-    if (tail_cus == h->pipe_R) return 0;
-    for (McCtx &c : h->ctx) if (ctx_streams(c, tail_cus)) return -1;
-    h->pipe_R = tail_cus;
-    return 0;
-}
-
+// ---- a stream of ranges: the front of the next one issued before the host looks at the results of this one -------------------------
+// mc_range_begin() enqueues the front of a range (on the context that is free) and returns at once; mc_range_end() completes the
+// OLDEST range begun (results as after mc_run_range).  end(i), begin(i + 1), results of i, end(i + 1), ... keeps the device busy
+// while the host works on the results (at most two ranges begun).  A range that overflows a pool comes back with -2 from
+// mc_range_end: it is no longer in flight; run it with mc_run_range (which splits it) once the other one has been ended.
+// (Round 4 also measured the TAIL of a range - ordering, finishing - running beside the front of the next, on ordinary streams, on
+// streams of their own priority and on streams with CU masks: it does not pay)
 extern "C" int mc_range_begin(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id)
 {
     if (range_check(h, first, count)) return -1;
@@ -909,20 +871,14 @@ extern "C" int mc_set_parts(mc_handle *h, int parts)
 extern "C" int mc_run(mc_handle *h, int64_t first_read_id) { return h ? mc_run_range(h, 0, h->nreads, first_read_id) : -1; }
 
 // The streaming form of the pipeline: batches of reads are fetched from a host-side source into pinned staging memory and
-// uploaded by a thread of their own (staging / device buffers in turn) while the calling thread runs the ranges of the batches
-// before - upload and search overlap.  With MC_PIPELINE = R in the environment (an experiment: see mc_set_pipeline, it does not pay) a
-// stream of more than one batch keeps TWO ranges in flight (mc_range_begin / mc_range_end on streams with R tail CUs).
+// uploaded by a thread of their own (two staging / device buffers in turn) while the calling thread runs the ranges of the batches
+// before - upload and search overlap; and the front of batch k + 1 is issued before the results of batch k are collected
+// (range_begin / range_end), so that the device does not wait for the host either.
 #define MC_STREAM_BATCH 2000000
-#define MC_PIPELINE_CUS 0
 static int64_t stream_batch()
 {   // reads per batch of the streaming pipeline (MC_STREAM_BATCH in the environment: tests deal small batches)
     if (const char *e = getenv("MC_STREAM_BATCH")) { const long long v = atoll(e); if (v >= 1000 && v <= MC_STREAM_BATCH) return (int64_t)v; }
     return MC_STREAM_BATCH;
-}
-static int stream_pipeline_cus()
-{
-    if (const char *e = getenv("MC_PIPELINE")) { const int v = atoi(e); if (v == 0 || (v > 0 && v <= 128 && 256 % v == 0)) return v; }
-    return MC_PIPELINE_CUS;
 }
 struct McBatchSlot { uint8_t *pin = nullptr, *dev = nullptr; int64_t n = 0, first = 0; int state = 0; /* 0 free, 1 ready, 2 end / error */ int64_t rc = 0; };
 
@@ -940,41 +896,32 @@ static int run_stream(mc_handle *h, const std::function<int64_t(uint8_t *, int64
     // default run, one run_pipeline of 1 - 2 M reads per process.
     int64_t bmax_run = B;
     if (B == BMAX && expect_reads > 0) { bmax_run = 262144; while (bmax_run < BMAX && bmax_run * 4 < expect_reads) bmax_run <<= 1; bmax_run = std::min(bmax_run, BMAX); }
-    const int saved_R = h->pipe_R;
-    const int R = (expect_reads > 0 && expect_reads <= std::min(bmax_run, B)) ? 0 : stream_pipeline_cus();   // (one batch: nothing to overlap)
-    const int depth = R > 0 ? 2 : 1, NS = depth + 1;
     const size_t stage_bytes = (size_t)(bmax_run * L + 64);
-    if (h->stage_slots < NS || h->stage_bytes < stage_bytes) {
-        const size_t nb = std::max(stage_bytes, h->stage_bytes);
-        for (int k = 0; k < NS; k++) {
-            if (h->stage_pin[k] && h->stage_bytes >= stage_bytes) continue;
+    if (!h->stage_pin[0] || h->stage_bytes < stage_bytes) {
+        for (int k = 0; k < 2; k++) {
             if (h->stage_pin[k]) { (void)hipHostFree(h->stage_pin[k]); h->stage_pin[k] = nullptr; }
             if (h->stage_dev[k]) { (void)hipFree(h->stage_dev[k]); h->stage_dev[k] = nullptr; }
-            HIPCK(hipHostMalloc((void **)&h->stage_pin[k], nb, hipHostMallocDefault));
-            HIPCK(hipMalloc((void **)&h->stage_dev[k], nb));
+            HIPCK(hipHostMalloc((void **)&h->stage_pin[k], stage_bytes, hipHostMallocDefault));
+            HIPCK(hipMalloc((void **)&h->stage_dev[k], stage_bytes));
         }
-        if (h->stage_bytes < stage_bytes) for (int k = NS; k < 3; k++) {   // (a slot of the smaller size left over from a pipelined run)
-            if (h->stage_pin[k]) { (void)hipHostFree(h->stage_pin[k]); h->stage_pin[k] = nullptr; }
-            if (h->stage_dev[k]) { (void)hipFree(h->stage_dev[k]); h->stage_dev[k] = nullptr; }
-        }
-        h->stage_bytes = nb; h->stage_slots = 0;
-        for (int k = 0; k < 3 && h->stage_pin[k]; k++) h->stage_slots = k + 1;
+        h->stage_bytes = stage_bytes;
         MC_OT("run_stream: staging buffers", t0);
     }
     if (!h->copy_stream) HIPCK(hipStreamCreate(&h->copy_stream));
-    if (R != saved_R && mc_set_pipeline(h, R)) return -1;
-    if (expect_reads > 0 && ensure_capacity(h, h->ctx[0], std::min<int64_t>(bmax_run, expect_reads))) return -1;
-    if (expect_reads > 0 && depth == 2 && ensure_capacity(h, h->ctx[1], std::min<int64_t>(bmax_run, expect_reads))) return -1;
+    const bool one_batch = expect_reads > 0 && expect_reads <= std::min(bmax_run, B);   // (nothing to overlap: the second context's pools stay unallocated)
+    const int first_ctx = h->pipe_next;
+    if (expect_reads > 0 && ensure_capacity(h, h->ctx[first_ctx], std::min<int64_t>(bmax_run, expect_reads))) return -1;
     MC_OT("run_stream: pools", t0);
-    McBatchSlot slot[3];
-    for (int k = 0; k < NS; k++) { slot[k].pin = h->stage_pin[k]; slot[k].dev = h->stage_dev[k]; }
+    bool other_sized = one_batch || expect_reads <= 0;             // the other context's pools: allocated while the first batch's front runs
+    McBatchSlot slot[2];
+    for (int k = 0; k < 2; k++) { slot[k].pin = h->stage_pin[k]; slot[k].dev = h->stage_dev[k]; }
     std::mutex mu; std::condition_variable cv;
     bool abort_up = false;
     std::string up_err;
     std::thread uploader([&] {
         (void)hipSetDevice(h->device);
         int nb = 0;
-        for (int k = 0;; k = (k + 1) % NS) {
+        for (int k = 0;; k ^= 1) {
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return slot[k].state == 0 || abort_up; }); if (abort_up) return; }
             int64_t at = 0;
             // The first batches are small - 256 k, 512 k, 1 M reads, then 2 M: the device starts after 4 ms of parsing instead of 33,
@@ -998,72 +945,46 @@ static int run_stream(mc_handle *h, const std::function<int64_t(uint8_t *, int64
     std::vector<mc_row> &all_rows = h->all_rows; all_rows.clear();
     if (h->keep_rows && expect_reads > 0) all_rows.reserve((size_t)expect_reads * 2 + 1024);   // (shotgun reads of real genomes: 1.9 rows per read; untouched pages cost nothing)
     std::vector<mc_best_hit> all_best; mc_stats tot; memset(&tot, 0, sizeof tot);
-    struct Held { std::vector<mc_row> rows; std::vector<mc_best_hit> best; mc_stats st; };
-    auto collect = [&]() {                                           // the results of the range that has just ended -> those of the stream
+    const uint8_t *saved_reads = h->reads_dev; const int64_t saved_n = h->nreads;
+    // the results of the range that ended last -> those of the stream (called while the front of the next batch runs)
+    bool pending = false;
+    auto collect = [&]() {
+        if (!pending) return;
+        pending = false;
         if (h->keep_rows) { rows_wait(h); all_rows.insert(all_rows.end(), h->res_rows, h->res_rows + h->n_res_rows); }
+        best_materialize(h);
         all_best.insert(all_best.end(), h->best.begin(), h->best.end());
         stats_add(tot, h->stats);
     };
     auto release = [&](int k) { std::unique_lock<std::mutex> lk(mu); slot[k].state = 0; cv.notify_all(); };
-    auto run_whole = [&](int k) -> int {                             // one batch by itself (mc_run_range answers a pool overflow with smaller ranges)
-        h->reads_dev = slot[k].dev; h->nreads = slot[k].n;
-        const int r = mc_run_range(h, 0, slot[k].n, first_read_id + slot[k].first);
-        if (r == 0) collect();
-        return r;
-    };
-    int rc = 0;
-    const uint8_t *saved_reads = h->reads_dev; const int64_t saved_n = h->nreads;
-    int flying[2] = {-1, -1}, nfly = 0;                              // the slots whose ranges are in flight, oldest first
-    // the oldest range in flight ends; if a pool of its overflowed (-2) it is run again by itself - after the other range in flight has
-    // been ended too (its results held back, or run again as well): the rows of the stream stay in the order of the reads
-    auto end_oldest = [&]() -> int {
-        const int k = flying[0];
-        flying[0] = flying[1]; nfly--;
+    // batch `k` is in flight: its range ends (a pool overflow is answered by mc_run_range: smaller ranges); its results are pending
+    auto end_batch = [&](int k) -> int {
         int r = mc_range_end(h);
-        if (r == 0) { collect(); release(k); return 0; }
-        if (r != -2) return r;
-        Held held; bool have_held = false; int k2 = -1, r2 = 0;
-        if (nfly) {
-            k2 = flying[0]; nfly = 0;
-            r2 = mc_range_end(h);
-            if (r2 == 0) { rows_wait(h); if (h->keep_rows) held.rows.assign(h->res_rows, h->res_rows + h->n_res_rows); held.best = h->best; held.st = h->stats; have_held = true; }
-            else if (r2 != -2) return r2;
-        }
-        if ((r = run_whole(k)) != 0) return r;
-        release(k);
-        if (k2 >= 0) {
-            if (have_held) { all_rows.insert(all_rows.end(), held.rows.begin(), held.rows.end()); all_best.insert(all_best.end(), held.best.begin(), held.best.end()); stats_add(tot, held.st); }
-            else if ((r = run_whole(k2)) != 0) return r;
-            release(k2);
-        }
+        if (r == -2) { h->reads_dev = slot[k].dev; h->nreads = slot[k].n; r = mc_run_range(h, 0, slot[k].n, first_read_id + slot[k].first); }
+        if (r) return r;
+        pending = true;
+        release(k);                                                  // (the reads of the batch are no longer needed: the uploader may fill the slot)
         return 0;
     };
-    for (int k = 0;; k = (k + 1) % NS) {
+    int rc = 0, flying = -1;
+    for (int k = 0;; k ^= 1) {
         { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return slot[k].state != 0; }); }
         if (slot[k].state == 2) { if (slot[k].rc < 0) { rc = (int)slot[k].rc; if (!up_err.empty()) g_err = up_err; } break; }
-        if (depth == 1) { if ((rc = run_whole(k)) != 0) break; release(k); continue; }
+        if (flying >= 0) { if ((rc = end_batch(flying)) != 0) break; flying = -1; }
         h->reads_dev = slot[k].dev; h->nreads = slot[k].n;
-        rc = mc_range_begin(h, 0, slot[k].n, first_read_id + slot[k].first);
-        if (rc == -2) {                                              // its front overflowed a pool: the range in flight first, then this batch by itself
-            rc = 0;
-            while (nfly && rc == 0) rc = end_oldest();
-            if (rc == 0) rc = run_whole(k);
-            if (rc) break;
-            release(k);
-            continue;
-        }
-        if (rc) break;
-        flying[nfly++] = k;
-        if (nfly == depth && (rc = end_oldest()) != 0) break;
+        if ((rc = mc_range_begin(h, 0, slot[k].n, first_read_id + slot[k].first)) != 0) break;
+        flying = k;
+        if (!other_sized) { other_sized = true; if (ensure_capacity(h, h->ctx[first_ctx ^ 1], std::min<int64_t>(bmax_run, expect_reads))) { rc = -1; break; } }
+        collect();                                                   // the batch before, while the front of this one runs
     }
-    while (rc == 0 && nfly) rc = end_oldest();
+    if (rc == 0 && flying >= 0) { rc = end_batch(flying); flying = -1; }
+    if (rc == 0) collect();
     while (h->pipe_nout) (void)mc_range_end(h);                      // (after an error: nothing stays in flight)
     { std::unique_lock<std::mutex> lk(mu); abort_up = true; cv.notify_all(); }
     uploader.join();
     h->reads_dev = saved_reads; h->nreads = saved_n;
-    if (R != saved_R) { const std::string keep = g_err; if (mc_set_pipeline(h, saved_R) && rc == 0) rc = -1; else g_err = keep; }
     if (rc) return rc;
-    h->res_rows = all_rows.data(); h->n_res_rows = (int64_t)all_rows.size(); h->best.swap(all_best); h->stats = tot;
+    h->res_rows = all_rows.data(); h->n_res_rows = (int64_t)all_rows.size(); h->best.swap(all_best); h->best_from = nullptr; h->stats = tot;
     return 0;
 }
 
@@ -1191,7 +1112,7 @@ extern "C" int mc_set_best_hits_only(mc_handle *h, int on)
 }
 
 extern "C" int64_t mc_result_rows(mc_handle *h, const mc_row **rows) { if (!h) return -1; rows_wait(h); *rows = h->res_rows; return h->n_res_rows; }
-extern "C" int64_t mc_result_best_hits(mc_handle *h, const mc_best_hit **hits) { if (!h) return -1; *hits = h->best.data(); return (int64_t)h->best.size(); }
+extern "C" int64_t mc_result_best_hits(mc_handle *h, const mc_best_hit **hits) { if (!h) return -1; best_materialize(h); *hits = h->best.data(); return (int64_t)h->best.size(); }
 extern "C" int mc_result_stats(mc_handle *h, mc_stats *out) { if (!h) return -1; *out = h->stats; return 0; }
 
 static int write_m8(mc_handle *h, const char *path, int append, const char *const *query_names, int64_t n_names, int64_t first_read_id)

@@ -187,12 +187,12 @@ def test_ordering_paths_of_the_longest_reads_on_ordinary_reads(tmp_path):
     assert res["heavy_read_rows"] == 198 * 70
 
 
-def test_ranges_in_flight_equal_ranges_one_at_a_time(engine, marker_reads, monkeypatch):
-    """mc_set_pipeline + mc_range_begin / mc_range_end (two ranges in flight, the tail of one on CU-masked streams beside the front
-    of the next) against mc_run_range on the same resident reads: rows, best hits and counts equal, range by range - for the masks
-    of three widths; then the streaming call itself (mc_search in 20,000-read batches) with and without MC_PIPELINE; and a
-    range whose pools overflow comes back with -2 from begin or end, leaves nothing in flight, and the stream that meets one
-    still delivers every row in order (the marker-dense library in 150,000-read batches)."""
+def test_stream_of_ranges_equals_ranges_one_at_a_time(engine, marker_reads, monkeypatch):
+    """mc_range_begin / mc_range_end (the front of range i + 1 enqueued before the host looks at the results of range i, two
+    contexts in turn) against mc_run_range on the same resident reads: rows, best hits and counts equal, range by range, in the
+    order end, begin, results and with both ranges begun before the first ends; the misuse errors; a range whose pools overflow
+    comes back with -2 from mc_range_end and leaves nothing in flight; and the streaming call that meets such ranges (mc_search
+    of the marker-dense library in 150,000-read batches) still delivers every row in order."""
     from microbecensus_amd import _native, synth
     names, seqs = _native.load_markers()
     model = _native.load_model()
@@ -206,55 +206,46 @@ def test_ranges_in_flight_equal_ranges_one_at_a_time(engine, marker_reads, monke
         engine.run_range(at, step, at)
         want.append((engine.rows(), engine.best_hits(), engine.stats()))
     assert sum(len(w[0]) for w in want) > 100_000
-    for cus in (64, 8, 128):
-        engine.set_pipeline(cus)
-        try:
-            got, begun = [], 0
-            for at in range(0, n, step):
-                engine.range_begin(at, step, at)
-                begun += 1
-                if engine.ranges_in_flight() == 2:
-                    engine.range_end()
-                    got.append((engine.rows(), engine.best_hits(), engine.stats()))
-            with pytest.raises(RuntimeError, match="in flight"):
-                engine.run_range(0, step, 0)
-            while engine.ranges_in_flight():
-                engine.range_end()
-                got.append((engine.rows(), engine.best_hits(), engine.stats()))
-            with pytest.raises(RuntimeError, match="no range in flight"):
-                engine.range_end()
-        finally:
-            engine.set_pipeline(0)
-        assert len(got) == len(want) == begun
+    starts = list(range(0, n, step))
+    for both_begun in (False, True):
+        got = []
+        engine.range_begin(starts[0], step, starts[0])
+        for i in range(len(starts)):
+            nxt = starts[i + 1] if i + 1 < len(starts) else None
+            if both_begun and nxt is not None:
+                engine.range_begin(nxt, step, nxt)
+                assert engine.ranges_in_flight() == 2
+                with pytest.raises(RuntimeError, match="two ranges are in flight"):
+                    engine.range_begin(0, step, 0)
+                with pytest.raises(RuntimeError, match="in flight"):
+                    engine.run_range(0, step, 0)
+            engine.range_end()
+            if not both_begun and nxt is not None:
+                engine.range_begin(nxt, step, nxt)
+            got.append((engine.rows(), engine.best_hits(), engine.stats()))    # (while the front of the next range runs)
+        assert engine.ranges_in_flight() == 0
+        with pytest.raises(RuntimeError, match="no range in flight"):
+            engine.range_end()
+        assert len(got) == len(want)
         for (r, b, s), (r0, b0, s0) in zip(got, want):
             assert _fields_equal(r, r0) and _fields_equal(b, b0)
             assert all(s[k] == s0[k] for k in ("reads", "seed_tasks", "gap_tasks", "hsps", "rows", "reads_with_rows", "classified"))
-    # the streaming call: batches in flight (MC_PIPELINE) against one at a time (the default)
+    # the streaming call runs its batches the same way
     monkeypatch.setenv("MC_STREAM_BATCH", "20000")
-    rows_1, best_1 = engine.search(reads)
-    monkeypatch.setenv("MC_PIPELINE", "64")
-    rows_p, best_p = engine.search(reads)
-    assert _fields_equal(rows_p, rows_1) and _fields_equal(best_p, best_1)
-    assert _fields_equal(rows_p, np.concatenate([w[0] for w in want])) and _fields_equal(best_p, np.concatenate([w[1] for w in want]))
-    # overflowing ranges in a pipelined stream: every batch of 150,000 marker-dense reads overflows the pools
-    monkeypatch.delenv("MC_PIPELINE")
+    rows_s, best_s = engine.search(reads)
+    assert _fields_equal(rows_s, np.concatenate([w[0] for w in want])) and _fields_equal(best_s, np.concatenate([w[1] for w in want]))
+    # overflowing ranges in a stream: every batch of 150,000 marker-dense reads overflows the pools
     monkeypatch.setenv("MC_STREAM_BATCH", "5000")
     rows5, best5 = engine.search(marker_reads)
     assert engine.stats()["range_splits"] == 0
-    monkeypatch.setenv("MC_PIPELINE", "64")
     monkeypatch.setenv("MC_STREAM_BATCH", "150000")
     rows_o, best_o = engine.search(marker_reads)
     st = engine.stats()
     assert st["range_splits"] > 0 and st["reads"] == len(marker_reads) and _fields_equal(rows_o, rows5) and _fields_equal(best_o, best5)
-    monkeypatch.delenv("MC_PIPELINE")
     engine.upload(marker_reads)
-    engine.set_pipeline(64)
-    try:
-        with pytest.raises(RuntimeError, match=r"\(-2\)"):
-            engine.range_begin(0, 150_000, 0)
-            engine.range_end()
-        assert engine.ranges_in_flight() == 0
-        engine.run_range(0, 150_000, 0)
-        assert engine.stats()["range_splits"] > 0 and _fields_equal(engine.rows(), rows5[rows5["query"] < 150_000])
-    finally:
-        engine.set_pipeline(0)
+    engine.range_begin(0, 150_000, 0)
+    with pytest.raises(RuntimeError, match=r"\(-2\)"):
+        engine.range_end()
+    assert engine.ranges_in_flight() == 0
+    engine.run_range(0, 150_000, 0)
+    assert engine.stats()["range_splits"] > 0 and _fields_equal(engine.rows(), rows5[rows5["query"] < 150_000])
