@@ -75,6 +75,7 @@ struct mc_handle {
     // mc_run_range() returns when the best hits are there; whoever looks at the rows waits for their copy (rows_wait).
     mc_row *pin_slot[2] = {nullptr, nullptr}; size_t pin_slot_cap[2] = {0, 0}; int pin_cur = 0;
     mc_row *pin_rows = nullptr; size_t pin_cap = 0;                // the slot of the current run
+    hipStream_t side = nullptr, side2 = nullptr;                    // shared by the contexts (McCtx::side, side2)
     hipStream_t rows_stream = nullptr; hipEvent_t ev_rows = nullptr; bool rows_pending = false, rows_ever = false;
     std::vector<mc_row> all_rows, split_rows;                       // accumulated over the batches of a stream / over the halves of a range that overflowed
     const mc_row *res_rows = nullptr; int64_t n_res_rows = 0;
@@ -95,6 +96,11 @@ template <class Tp> static int dalloc(Tp **p, size_t n)
     return 0;
 }
 
+// Eight hardware queues for the process instead of HIP's four (see open_impl: streams that share a queue wait for each other): set
+// when the library is loaded - it takes effect if the HIP runtime has not been initialised yet (it reads its settings at the first
+// HIP call), and never overrides what the environment says.
+__attribute__((constructor)) static void mc_hip_init_env() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 extern "C" int mc_device_count(void)
 {
     int n = 0;
@@ -110,7 +116,7 @@ static void ctx_free(McCtx &c)
     for (void *p : {(void *)c.h_c, (void *)c.h_stats, (void *)c.h_best}) if (p) (void)hipHostFree(p);
     for (auto &e : c.ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {c.ev_fork, c.ev_join, c.ev_join2}) if (e) (void)hipEventDestroy(e);
-    for (hipStream_t q : {c.stream, c.side, c.side2}) if (q) (void)hipStreamDestroy(q);
+    if (c.stream) (void)hipStreamDestroy(c.stream);                // (side, side2: the handle's)
     c = McCtx();
 }
 
@@ -123,6 +129,7 @@ extern "C" void mc_close(mc_handle *h)
     for (McCtx &c : h->ctx) ctx_free(c);
     for (int k = 0; k < 2; k++) { if (h->stage_pin[k]) (void)hipHostFree(h->stage_pin[k]); if (h->stage_dev[k]) (void)hipFree(h->stage_dev[k]); }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    for (hipStream_t q : {h->side, h->side2}) if (q) (void)hipStreamDestroy(q);
     if (h->rows_stream) { (void)hipStreamSynchronize(h->rows_stream); (void)hipStreamDestroy(h->rows_stream); }
     if (h->ev_rows) (void)hipEventDestroy(h->ev_rows);
     for (mc_row *p : h->pin_slot) if (p) (void)hipHostFree(p);
@@ -145,8 +152,14 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
     HIPCK(hipSetDevice(device));
     HIPCK(hipFree(nullptr));
     MC_OT("  HIP runtime, device", t0);
+    // Streams: one per context for the pipeline of a range, two side streams for the ordering / finishing kernels of the longest reads
+    // (the handle's: the contexts never run those stages at the same time), one for the rows on their way to the host, one for the
+    // uploads of the streaming calls.  HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the environment
+    // says otherwise) and streams that share one wait for each other: with nine streams the front of a range could land behind the
+    // 5 ms copy of the rows of the range before (measured: 51.2 instead of 53.6 M reads/s) - hence few streams, and mc_hip_init_env().
+    HIPCK(hipStreamCreate(&h->side)); HIPCK(hipStreamCreate(&h->side2));
     for (McCtx &c : h->ctx) {
-        HIPCK(hipStreamCreate(&c.stream)); HIPCK(hipStreamCreate(&c.side)); HIPCK(hipStreamCreate(&c.side2));
+        HIPCK(hipStreamCreate(&c.stream)); c.side = h->side; c.side2 = h->side2;
         for (auto &e : c.ev) HIPCK(hipEventCreate(&e));
         HIPCK(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming)); HIPCK(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
         HIPCK(hipEventCreateWithFlags(&c.ev_join2, hipEventDisableTiming));
