@@ -67,7 +67,7 @@ def spawn_ranks(n, argv):
 
 STAGE_KERNELS = {   # kernels whose HIP-event time a stage of mc_stats spans (prefixes of the names in the rocprofv3 summaries)
     "k_translate_seg": ["k_translate_seg"], "k_enumerate_t0": ["k_enumerate_t0<"], "k_enumerate": ["k_enumerate_t0<", "k_enumerate"], "k_eval_seeds": ["k_eval_seeds"],
-    "k_gapped": ["k_gap_dedupe", "k_gapped_lds", "k_gapped", "k_gap_emit"], "k_finish": ["k_finish", "k_finish_heavy", "k_heap_lanes", "k_heavy_rows", "k_heavy_lists", "k_emit_rows"],
+    "k_gapped": ["k_gap_dedupe", "k_gap_sort_hist", "k_gap_sort_scan", "k_gap_sort_scatter", "k_gapped_lds", "k_gapped", "k_gap_emit"], "k_finish": ["k_finish", "k_finish_heavy", "k_heap_lanes", "k_heavy_rows", "k_heavy_lists", "k_emit_rows"],
     "sort": ["k_bin_count", "k_bin_scatter", "k_scan_sums", "k_scan_top", "k_scan_apply", "k_order_lists", "k_order_light", "k_order_heavy", "k_order_copy"],
 }
 

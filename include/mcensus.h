@@ -116,6 +116,13 @@ int mc_range_begin(mc_handle *h, int64_t first, int64_t count, int64_t first_rea
 int mc_range_end(mc_handle *h);
 int mc_ranges_in_flight(const mc_handle *h);
 
+/* Test aid (tests/test_gpu_parity.py, per-stage parity with the CPU emulation of the kernels' per-thread code): what the stages of
+ * the last mc_run_range() left on the device - what = 0: the six translated, SEG-masked frames of every read (rows of
+ * *record_bytes bytes; BuildQHash@0x40b530, Seg::*), 1: the seed hits (16-byte records; Searching@0x415050), 2: the gap tasks
+ * (28 bytes; ExtendSeq2Set@0x413b90), 3: the HSP pool (48 bytes; CalRes@0x4077a0).  Returns the number of bytes (copied to dst
+ * when they fit cap_bytes; dst may be NULL to ask for the size), -1 on error. */
+int64_t mc_debug_stage(mc_handle *h, int what, void *dst, int64_t cap_bytes, int32_t *record_bytes);
+
 /* The seed kernel can count the index reads of the reference's algorithm for the batch (mc_stats.bucket_lookups /
  * key_probes: what CHashSearch::Searching@0x415050 / ExtendSeq2Set@0x413b90 would read - bench.py reports the rate at which
  * the timed kernel disposes of them).  Off by default: the two fields stay 0 and the kernel answers most one-substitution

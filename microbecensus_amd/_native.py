@@ -75,6 +75,8 @@ def load_library():
     lib.mc_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.mc_run_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
     lib.mc_set_counting.argtypes = [C.c_void_p, C.c_int]
+    lib.mc_debug_stage.restype = C.c_int64
+    lib.mc_debug_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]
     lib.mc_set_parts.argtypes = [C.c_void_p, C.c_int]
     lib.mc_range_begin.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
     lib.mc_range_end.argtypes = [C.c_void_p]
@@ -125,7 +127,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_set_index_cache", "mc_index_cache_check", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
-                    "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_set_parts", "mc_range_begin", "mc_range_end", "mc_ranges_in_flight", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8", "mc_write_m8_named",
+                    "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_debug_stage", "mc_set_parts", "mc_range_begin", "mc_range_end", "mc_ranges_in_flight", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8", "mc_write_m8_named",
                     "mc_reader_last_error", "mc_set_host_threads", "mc_reader_open", "mc_reader_open_range", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_reader_trim", "mc_count_bases", "mc_quality_offset",
                     "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_reader_nreads", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows", "mc_set_best_hits_only", "mc_grid_classify"]
 
@@ -425,6 +427,18 @@ class Engine:
 
     def run_range(self, first, count, first_read_id=0):
         self._check(self.lib.mc_run_range(self.h, first, count, first_read_id), "mc_run_range")
+
+    def debug_stage(self, what):
+        """Test aid: what a stage of the last run_range() left on the device (0 frames, 1 seed hits, 2 gap tasks, 3 HSP pool) as a
+        (records, record_bytes) uint8 array."""
+        rec = C.c_int32(0)
+        n = self.lib.mc_debug_stage(self.h, what, None, 0, C.byref(rec))
+        if n < 0:
+            raise RuntimeError("mc_debug_stage failed: %s" % self.lib.mc_last_error().decode())
+        buf = np.zeros(n, np.uint8)
+        if n and self.lib.mc_debug_stage(self.h, what, buf.ctypes.data_as(C.c_void_p), n, C.byref(rec)) != n:
+            raise RuntimeError("mc_debug_stage failed: %s" % self.lib.mc_last_error().decode())
+        return buf.reshape(-1, rec.value) if rec.value else buf
 
     def rows(self, copy=True):
         """m8 rows of the last run (structured array).  copy=False returns a view of the handle's buffer, valid until the next call."""

@@ -57,7 +57,7 @@ __device__ __forceinline__ uint32_t mc_block_alloc_n(uint32_t *counter, uint32_t
 }
 
 // groups the tasks (leader[p] = first task of p's segment to claim the table slot) and lists the flanks of the leaders with
-// their sort keys (1 + DP rows; the slots behind the list keep key 0 from the memset and sort to the end)
+// their sort keys (1 + DP rows, below 1024)
 __global__ void __launch_bounds__(256) k_gap_dedupe(McIndex X, int L, const McGapTask *__restrict__ gaps, uint32_t ngaps, unsigned long long *tab, uint32_t mask, uint32_t *leader,
                                                     uint32_t *key, uint32_t *item, uint32_t *counters)
 {
@@ -94,6 +94,46 @@ __global__ void __launch_bounds__(256) k_gap_dedupe(McIndex X, int L, const McGa
     uint32_t o = mc_block_alloc_n(&counters[C_ITEMS], n);
     if (hr) { key[o] = 1u + (uint32_t)fr.n1; item[o] = 2 * p; o++; }
     if (hl) { key[o] = 1u + (uint32_t)fl.n1; item[o] = 2 * p + 1; }
+}
+
+// ---- the flanks in descending order of their DP rows (the lanes of a wave of k_gapped_lds then run DPs of similar length) ----------
+// A counting sort over the 10-bit keys, three launches (rounds 1 - 3: rocPRIM's radix sort): a histogram (per workgroup in LDS, then
+// one global atomic per bin it met), the bins' places from the largest key down, and the scatter - a workgroup counts the keys of
+// its own stretch of the list again, reserves its part of every bin with one atomic and deals the places out in LDS.  The order
+// inside a bin is left to the atomics: it decides which lane runs which flank, never a result (a flank's result has its own slot).
+#define MC_GS_BINS 1024u
+__global__ void __launch_bounds__(256) k_gap_sort_hist(const uint32_t *__restrict__ key, const uint32_t *__restrict__ n_p, uint32_t cap, uint32_t *hist)
+{
+    __shared__ uint32_t h[MC_GS_BINS];
+    const uint32_t n = *n_p <= cap ? *n_p : 0u;
+    for (uint32_t b = threadIdx.x; b < MC_GS_BINS; b += 256) h[b] = 0;
+    __syncthreads();
+    const uint32_t per = (n + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&h[key[i] & (MC_GS_BINS - 1)], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < MC_GS_BINS; b += 256) if (h[b]) atomicAdd(&hist[b], h[b]);
+}
+__global__ void __launch_bounds__(1024) k_gap_sort_scan(uint32_t *hist)
+{   // hist[b]: the number of keys b -> the place of the first of them, the largest key first
+    __shared__ uint32_t s[MC_GS_BINS];
+    const uint32_t t = threadIdx.x, v = hist[MC_GS_BINS - 1 - t];
+    s[t] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < MC_GS_BINS; d <<= 1) { const uint32_t y = t >= d ? s[t - d] : 0u; __syncthreads(); s[t] += y; __syncthreads(); }
+    hist[MC_GS_BINS - 1 - t] = s[t] - v;
+}
+__global__ void __launch_bounds__(256) k_gap_sort_scatter(const uint32_t *__restrict__ key, const uint32_t *__restrict__ item, const uint32_t *__restrict__ n_p, uint32_t cap, uint32_t *base, uint32_t *out)
+{
+    __shared__ uint32_t h[MC_GS_BINS], at[MC_GS_BINS];
+    const uint32_t n = *n_p <= cap ? *n_p : 0u;
+    for (uint32_t b = threadIdx.x; b < MC_GS_BINS; b += 256) h[b] = 0;
+    __syncthreads();
+    const uint32_t per = (n + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&h[key[i] & (MC_GS_BINS - 1)], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < MC_GS_BINS; b += 256) { const uint32_t c = h[b]; if (c) at[b] = atomicAdd(&base[b], c); h[b] = 0; }
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) { const uint32_t b = key[i] & (MC_GS_BINS - 1); out[at[b] + atomicAdd(&h[b], 1u)] = item[i]; }
 }
 
 // every gap task -> its HSP, from the flank results of its group's leader

@@ -34,7 +34,7 @@ struct McCtx {
     uint8_t *d_frames = nullptr, *d_frames_base = nullptr;   // (64 bytes of room in front: k_eval_seeds reads 8 bytes at a time backwards from a seed)
     unsigned long long *d_stats = nullptr;
     McSeedTask *d_tasks = nullptr; McGapTask *d_gaps = nullptr; McHsp *d_hsps = nullptr, *d_v = nullptr, *d_tmp = nullptr;
-    uint64_t *d_k64 = nullptr, *d_hkeys = nullptr, *d_hplace = nullptr, *d_places = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr, *d_scan = nullptr, *d_gsz = nullptr, *d_nv = nullptr; void *d_sorttmp = nullptr; size_t sorttmp_bytes = 0;
+    uint64_t *d_k64 = nullptr, *d_hkeys = nullptr, *d_hplace = nullptr, *d_places = nullptr; uint32_t *d_idx = nullptr, *d_idxo = nullptr, *d_heads = nullptr, *d_scan = nullptr, *d_gsz = nullptr, *d_nv = nullptr; uint32_t *d_ghist = nullptr;
     uint32_t *d_counters = nullptr;
     McRow *d_rows = nullptr; uint32_t *d_nrow = nullptr, *d_rowoff = nullptr; McBestHit *d_best = nullptr, *d_bestof = nullptr; uint8_t *d_low = nullptr, *d_cand = nullptr;
     McGapCell *d_gws_full = nullptr; uint32_t *d_retry = nullptr, *d_retry2 = nullptr; int gap_threads_full = 0;
@@ -110,7 +110,7 @@ extern "C" int mc_device_count(void)
 
 static void ctx_free(McCtx &c)
 {
-    void *ptrs[] = {c.d_frames_base, c.d_tasks, c.d_gaps, c.d_hsps, c.d_v, c.d_tmp, c.d_k64, c.d_hkeys, c.d_hplace, c.d_places, c.d_idx, c.d_idxo, c.d_heads, c.d_scan, c.d_gsz, c.d_nv, c.d_sorttmp, c.d_counters, c.d_rows,
+    void *ptrs[] = {c.d_frames_base, c.d_tasks, c.d_gaps, c.d_hsps, c.d_v, c.d_tmp, c.d_k64, c.d_hkeys, c.d_hplace, c.d_places, c.d_idx, c.d_idxo, c.d_heads, c.d_scan, c.d_gsz, c.d_nv, c.d_ghist, c.d_counters, c.d_rows,
                     c.d_nrow, c.d_rowoff, c.d_best, c.d_bestof, c.d_low, c.d_cand, c.d_gws_full, c.d_retry, c.d_retry2, c.d_gtab, c.d_gleader, c.d_fout, c.d_stats};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : {(void *)c.h_c, (void *)c.h_stats, (void *)c.h_best}) if (p) (void)hipHostFree(p);
@@ -163,7 +163,7 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
         for (auto &e : c.ev) HIPCK(hipEventCreate(&e));
         HIPCK(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming)); HIPCK(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
         HIPCK(hipEventCreateWithFlags(&c.ev_join2, hipEventDisableTiming));
-        if (dalloc(&c.d_counters, C_N) || dalloc(&c.d_stats, S_N)) return -1;
+        if (dalloc(&c.d_counters, C_N) || dalloc(&c.d_stats, S_N) || dalloc(&c.d_ghist, (size_t)MC_GS_BINS)) return -1;
         HIPCK(hipHostMalloc((void **)&c.h_c, sizeof(uint32_t) * C_N, hipHostMallocDefault));
         HIPCK(hipHostMalloc((void **)&c.h_stats, sizeof(unsigned long long) * S_N, hipHostMallocDefault));
     }
@@ -386,11 +386,6 @@ static int ensure_capacity(mc_handle *h, McCtx &c, int64_t nreads)
     if (c.h_best) { (void)hipHostFree(c.h_best); c.h_best = nullptr; }
     HIPCK(hipHostMalloc((void **)&c.h_best, sizeof(McBestHit) * ((size_t)cap + 1), hipHostMallocDefault));
     c.h_best_cap = (size_t)cap + 1;
-    size_t bytes = 0;                                               // (the flank list of the gapped stage is ordered by a 10-bit radix sort)
-    HIPCK(rocprim::radix_sort_pairs_desc(nullptr, bytes, c.d_idx, c.d_idxo, c.d_idx, c.d_idxo, (size_t)c.cap_gaps * 2, 0, 10, c.stream));
-    if (c.d_sorttmp) { (void)hipFree(c.d_sorttmp); c.d_sorttmp = nullptr; }
-    HIPCK(hipMalloc(&c.d_sorttmp, bytes + 16));
-    c.sorttmp_bytes = bytes;
     c.cap_reads = cap;
     HIPCK(hipStreamSynchronize(c.stream));
     MC_OT("ensure_capacity (pools)", t0);
@@ -511,7 +506,7 @@ static int stage_b(mc_handle *h, McCtx &c)
     c.gpad = c.h_c[C_GPAD];
     if (ngaps) {
         // 1. group the tasks that extend the same ungapped segment and list the flanks of the distinct ones (k_gap_dedupe);
-        // 2. order the flanks by DP size (the sort buffers of the HSP sort are idle at this point); 3. extend them with the DP rows
+        // 2. order the flanks by DP size (a counting sort, k_gap_sort_*; the ordering kernels' buffers are idle at this point); 3. extend them with the DP rows
         // in LDS, those whose band leaves the window again with a wider one, the rest with full-size rows; 4. every task takes its
         // HSP from its group's flank results.  The counts of 2. - 4. stay on the device.
         static const int gap_refill = getenv("MC_GAP_REFILL") ? std::max(1, std::min(64, atoi(getenv("MC_GAP_REFILL")))) : MC_GAP_REFILL;   // (experiments)
@@ -519,16 +514,17 @@ static int stage_b(mc_handle *h, McCtx &c)
         uint32_t slots = 1u << 16;
         while (slots < 2 * ngaps) slots <<= 1;
         if (slots > c.gtab_slots) { if (dalloc(&c.d_gtab, (size_t)slots)) return -1; c.gtab_slots = slots; }
-        // The flank sort borrows the buffers of the HSP sort: 2 ngaps keys + 2 ngaps sorted keys in d_k64 (8 cap_hsps bytes), 2 ngaps
-        // items in d_idx / d_idxo (4 cap_hsps bytes each).  The pools are sized so that ordinary batches fit (ensure_capacity); a batch
+        // The flank sort borrows the buffers of the HSP ordering: 2 ngaps keys in d_k64 (8 cap_hsps bytes), 2 ngaps items in d_idx /
+        // d_idxo (4 cap_hsps bytes each).  The pools are sized so that ordinary batches fit (ensure_capacity); a batch
         // dense in gap tasks that does not is an overflow like any other: the range is run again in halves.
         if (2 * (uint64_t)ngaps > c.cap_hsps) { g_err = "gap task pool larger than the sort buffers"; return -2; }
-        uint32_t *gk = (uint32_t *)c.d_k64, *gko = gk + 2 * (size_t)ngaps, *gi = c.d_idx, *gio = c.d_idxo;
+        uint32_t *gk = (uint32_t *)c.d_k64, *gi = c.d_idx, *gio = c.d_idxo;
         HIPCK(hipMemsetAsync(c.d_gtab, 0, (size_t)slots * 8, st));
-        HIPCK(hipMemsetAsync(gk, 0, (size_t)ngaps * 8, st));
+        HIPCK(hipMemsetAsync(c.d_ghist, 0, MC_GS_BINS * sizeof(uint32_t), st));
         k_gap_dedupe<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(X, L, c.d_gaps, ngaps, c.d_gtab, slots - 1, c.d_gleader, gk, gi, c.d_counters);
-        size_t gbytes = c.sorttmp_bytes;
-        HIPCK(rocprim::radix_sort_pairs_desc(c.d_sorttmp, gbytes, gk, gko, gi, gio, (size_t)ngaps * 2, 0, 10, st));
+        k_gap_sort_hist<<<dim3(512), dim3(256), 0, st>>>(gk, c.d_counters + C_ITEMS, 2 * ngaps, c.d_ghist);
+        k_gap_sort_scan<<<dim3(1), dim3(1024), 0, st>>>(c.d_ghist);
+        k_gap_sort_scatter<<<dim3(512), dim3(256), 0, st>>>(gk, gi, c.d_counters + C_ITEMS, 2 * ngaps, c.d_ghist, gio);
         k_gapped_lds<MC_GAP_WIN, 64><<<dim3(std::min<uint32_t>((2 * ngaps + 63) / 64, 256u * gap_wpc)), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, gio, c.d_counters + C_ITEMS, c.d_fout,
                                                                                                                  c.d_counters + C_RETRY, c.d_retry, gap_refill);
         k_gapped_lds<MC_GAP_WIN2, MC_GAP_LANES2><<<dim3(256u * 4u), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry, c.d_counters + C_RETRY, c.d_fout, c.d_counters + C_RETRY2, c.d_retry2, 1);
@@ -867,6 +863,27 @@ extern "C" int mc_range_end(mc_handle *h)
 }
 
 extern "C" int mc_ranges_in_flight(const mc_handle *h) { return h ? h->pipe_nout : 0; }
+
+// What the stages of the last mc_run_range() left on the device (the per-stage parity tests compare it with the CPU emulation of
+// the same per-thread code - SURVEY.md 7.2): 0 the six frames of every read (rows of *record_bytes = FP bytes), 1 the seed kernel's
+// hits (McSeedTask, 16 bytes; read = MC_TASK_NONE: padding of a block of the pool), 2 the gap tasks (McGapTask, 28 bytes), 3 the HSP
+// pool (McHsp, 48 bytes: the ungapped HSPs of k_eval_seeds and those of the gapped stage).  Returns the bytes there are (copied if
+// they fit cap_bytes), -1 on error.
+extern "C" int64_t mc_debug_stage(mc_handle *h, int what, void *dst, int64_t cap_bytes, int32_t *record_bytes)
+{
+    if (!h || !h->run_set || what < 0 || what > 3) { g_err = "mc_debug_stage: bad argument"; return -1; }
+    if (h->pipe_nout) { g_err = "mc_debug_stage: ranges are in flight"; return -1; }
+    HIPCK(hipSetDevice(h->device));
+    const McCtx &c = h->ctx[0];
+    const void *src = nullptr; int64_t bytes = 0; int32_t rec = 0;
+    if (what == 0) { src = c.d_frames; rec = h->FP; bytes = c.n * 6 * (int64_t)h->FP; }
+    else if (what == 1) { src = c.d_tasks; rec = (int32_t)sizeof(McSeedTask); bytes = (int64_t)c.ntasks * rec; }
+    else if (what == 2) { src = c.d_gaps; rec = (int32_t)sizeof(McGapTask); bytes = (int64_t)c.ngaps * rec; }
+    else { src = c.d_hsps; rec = (int32_t)sizeof(McHsp); bytes = (int64_t)(c.nh_all + (c.h_c ? c.h_c[C_HPAD] : 0u)) * rec; }
+    if (record_bytes) *record_bytes = rec;
+    if (dst && bytes && bytes <= cap_bytes) { HIPCK(hipStreamSynchronize(c.stream)); HIPCK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost)); }
+    return bytes;
+}
 
 extern "C" int mc_set_counting(mc_handle *h, int on)
 {

@@ -8,7 +8,6 @@
 #include <cstdlib>
 #include <ctime>
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <condition_variable>

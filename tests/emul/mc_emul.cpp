@@ -311,6 +311,14 @@ int main(int argc, char **argv)
         McHsp h; h.read = g.read; h.chrono = g.chrono;
         if (mc_make_hsp(T, read_len, frame, g, qfwd, dfwd, qbwd, dbwd, score, nmatch, alnlen, gapopens, gaptotal, &h)) hsps.push_back(h);
     }
+    if (const char *pre = getenv("MC_DUMP_STAGES")) {   // what every stage made, for the per-stage parity test of the kernels (tests/test_gpu_parity.py)
+        auto dump = [&](const char *name, const void *p, size_t bytes) { const std::string fn = std::string(pre) + name; FILE *d = fopen(fn.c_str(), "wb"); if (!d || (bytes && fwrite(p, 1, bytes, d) != bytes)) { fprintf(stderr, "cannot write %s\n", fn.c_str()); exit(2); } fclose(d); };
+        dump(".frames", frames.data(), frames.size());                 // rows of MC_MAXAA + 2 bytes
+        dump(".tasks", tasks.data(), tasks.size() * sizeof(McSeedTask));
+        dump(".gaps", gaps.data(), gaps.size() * sizeof(McGapTask));
+        dump(".hsps", hsps.data(), hsps.size() * sizeof(McHsp));       // (ungapped and gapped, before any ordering)
+        fprintf(stderr, "stages dumped: FP %d, %zu B per task, %zu per gap task, %zu per HSP\n", FP, sizeof(McSeedTask), sizeof(McGapTask), sizeof(McHsp));
+    }
     fprintf(stderr, "gapped window check (W = %d): %ld flanks, %ld leave the window, %ld differ from the full-size form\n", WIN, win_flanks, win_over, win_bad);
     if (win_bad) return 3;
     // stage 5: sort by (read, subject, chrono)

@@ -135,13 +135,16 @@ def test_generic_seed_path_on_a_database_with_a_seed_threshold(tmp_path):
 
 
 @pytest.mark.parametrize("case", ["config1_example_fq", "dirty_reads"])
-def test_stage_counts_equal_the_emulation(case, engine, tmp_path):
-    """Stage by stage (a localisation aid beside the end-to-end m8 equality): the number of seed hits the seed kernel
-    emits, of gap tasks and of HSPs the evaluation and the gapped stage keep must be the numbers the CPU emulation of the same
-    per-thread code counts (tests/emul/mc_emul, itself pinned on the reference's m8) - a difference names the stage."""
+def test_every_stage_equals_the_emulation(case, engine, tmp_path):
+    """Kernel by kernel (the candidates of every stage against the restatement's - what localises a difference the
+    end-to-end m8 equality only reports): what the stages of mc_run_range leave on the device (mc_debug_stage) against what the
+    CPU emulation of the same per-thread code makes (tests/emul/mc_emul, itself pinned on the reference's m8) -
+    the six translated and SEG-masked frames of every read byte for byte (k_translate_seg; BuildQHash@0x40b530, Seg::*), the
+    multiset of seed hits (k_enumerate_t0; Searching@0x415050) with the positions in the residue array the kernels carry, the
+    multiset of gap tasks and the multiset of HSPs, ungapped and gapped (k_eval_seeds, k_gap_*; ExtendSeq2Set@0x413b90,
+    AlignGapped@0x40a550, CalRes@0x4077a0)."""
     import re
     import subprocess
-    from microbecensus_amd import _native
     here = os.path.dirname(os.path.abspath(__file__))
     repo = os.path.dirname(here)
     exe = str(tmp_path / "mc_emul")
@@ -151,16 +154,60 @@ def test_stage_counts_equal_the_emulation(case, engine, tmp_path):
     src = os.path.join(GOLD, "dirty_reads.fa.gz" if case == "dirty_reads" else case + ".reads.fa.gz")
     fa = tmp_path / "reads.fa"
     fa.write_bytes(gzip.open(src, "rb").read())
-    r = subprocess.run([exe, str(faa), str(fa), str(tmp_path / "e.m8")], stderr=subprocess.PIPE, check=True)
+    pre = str(tmp_path / "emul")
+    r = subprocess.run([exe, str(faa), str(fa), str(tmp_path / "e.m8")], stderr=subprocess.PIPE, check=True, env=dict(os.environ, MC_DUMP_STAGES=pre))
     err = r.stderr.decode()
-    want = {"seed_tasks": int(re.search(r"seed tasks: (\d+)", err).group(1)), "gap_tasks": int(re.search(r"gapped tasks: (\d+)", err).group(1)),
-            "hsps": int(re.search(r"hsps kept: (\d+)", err).group(1))}
+    fp_e = int(re.search(r"stages dumped: FP (\d+)", err).group(1))
     seqs = [l.rstrip(b"\r\n") for l in gzip.open(src, "rb") if not l.startswith(b">")]
     reads = np.frombuffer(b"".join(seqs), dtype=np.uint8).reshape(len(seqs), len(seqs[0]))
-    engine.set_run(reads.shape[1])
-    engine.search(reads)
+    n, L = reads.shape
+    engine.set_run(L)
+    engine.upload(reads)
+    engine.run_range(0, n)
     st = engine.stats()
-    assert {k: st[k] for k in want} == want
+
+    # ---- frames
+    fe = np.fromfile(pre + ".frames", np.uint8).reshape(n, 6, fp_e)
+    fg = engine.debug_stage(0)
+    fg = fg.reshape(n, 6, fg.shape[1])
+    INV = 20
+    for f in range(6):
+        k = (L - f % 3) // 3
+        assert np.array_equal(fg[:, f, :k], fe[:, f, :k]), "frame %d" % f
+        assert (fg[:, f, k:] == INV).all()
+    k0 = L // 3
+    assert (fe[:, 0, :k0] != INV).mean() > 0.5 and (fe[:, 0, :k0] == INV).any()        # (residues, and masked / stop positions among them)
+    # ---- seed hits
+    task_dt = np.dtype([("read", "<u4"), ("chrono", "<u4"), ("posting", "<u4"), ("w3", "<u4")])
+    te = np.fromfile(pre + ".tasks", task_dt)
+    tg = engine.debug_stage(1).reshape(-1).view(task_dt)
+    tg = tg[tg["read"] != 0xFFFFFFFF]                                                   # (padding of the blocks of the pool)
+    assert len(tg) == len(te) == st["seed_tasks"] and len(te) > 1000
+    off = engine.index_view()["off"].astype(np.int64)
+    norm_e = np.stack([te["read"], te["chrono"], te["posting"], te["w3"] & 0xFF, te["w3"] >> 8], 1).astype(np.int64)
+    norm_g = np.stack([tg["read"], tg["chrono"], tg["posting"], (tg["w3"] >> 24) & 15, tg["w3"] >> 28], 1).astype(np.int64)
+    assert np.array_equal(norm_e[np.lexsort(norm_e.T[::-1])], norm_g[np.lexsort(norm_g.T[::-1])])
+    assert np.array_equal((tg["w3"] & 0xFFFFFF).astype(np.int64), off[tg["posting"] >> 11] + (tg["posting"] & 0x7FF))
+    # ---- gap tasks
+    gap_dt = np.dtype({"names": ["read", "chrono", "sidx", "qp", "dp", "L", "qfwd", "qbwd", "score", "nmatch"],
+                       "formats": ["<u4", "<u4", "<u4", "<i2", "<i2", "<i2", "<i2", "<i2", "<i2", "<i2"], "offsets": [0, 4, 8, 12, 14, 16, 18, 20, 22, 24], "itemsize": 28})
+    hsp_dt = np.dtype({"names": ["read", "chrono", "sidx", "score", "frame", "alnlen", "mism", "gaps", "nmatch", "qaas", "qaae", "ds", "de", "qnts", "qnte", "loge"],
+                       "formats": ["<u4", "<u4", "<i4"] + ["<i2"] * 12 + ["<f8"], "offsets": [0, 4, 8] + list(range(12, 36, 2)) + [40], "itemsize": 48})
+
+    def table(a):                                                                       # the named fields (no padding bytes), rows in a canonical order
+        t = np.stack([a[k].astype(np.float64) for k in a.dtype.names], 1)
+        return t[np.lexsort(t.T[::-1])]
+    ge = np.fromfile(pre + ".gaps", gap_dt)
+    gg = engine.debug_stage(2).reshape(-1).view(gap_dt)
+    gg = gg[gg["read"] != 0xFFFFFFFF]
+    assert len(gg) == len(ge) == st["gap_tasks"] and len(ge) > 100
+    assert np.array_equal(table(ge), table(gg))
+    # ---- HSPs
+    he = np.fromfile(pre + ".hsps", hsp_dt)
+    hg = engine.debug_stage(3).reshape(-1).view(hsp_dt)
+    hg = hg[hg["read"] != 0xFFFFFFFF]
+    assert len(hg) == len(he) == st["hsps"] and len(he) > 1000 and (he["gaps"] > 0).any()
+    assert np.array_equal(table(he), table(hg))
 
 
 def test_the_product_library_is_the_one_loaded():
