@@ -105,13 +105,14 @@ int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t first_read_
 int mc_set_parts(mc_handle *h, int parts);
 
 /* A stream of ranges without the device waiting for the host.  mc_range_begin() enqueues the FRONT of a range (translation,
- * seeds, seed evaluation: two thirds of its time) and returns at once; mc_range_end() completes the OLDEST range begun - results
- * as after mc_run_range(), valid until the next mc_range_end() / mc_run_range().  The order end(i), begin(i + 1), <look at the
- * results of i>, end(i + 1), ... lets the host collect rows and best hits while the device works on the next front (two
- * contexts per handle, used in turn; at most two ranges begun).  mc_search() / mc_search_files() run their batches this way,
- * bench.py its steps.  mc_range_end() returns -2 when the range overflowed a pool: it is then no longer in flight - give it to
- * mc_run_range(), which runs it in smaller pieces (after ending the other range, if one was begun).  mc_run_range() and
- * mc_search*() refuse to run while ranges are in flight.  Results never depend on any of this. */
+ * seeds, seed evaluation: two thirds of its time) and returns at once; mc_range_end() completes it - results as after
+ * mc_run_range(), valid until the next mc_range_end() / mc_run_range().  The order end(i), begin(i + 1), <look at the results
+ * of i>, end(i + 1), ... lets the host collect rows and best hits while the device works on the next front (what the host still
+ * reads of range i lies in pinned host memory; the pools on the device are free for range i + 1).  One range at a time is on the
+ * device: a second mc_range_begin() before mc_range_end() is refused.  mc_search() / mc_search_files() run their batches this
+ * way, bench.py its steps.  mc_range_end() returns -2 when the range overflowed a pool: it is then no longer in flight - give
+ * it to mc_run_range(), which runs it in smaller pieces.  mc_run_range() and mc_search*() refuse to run while a range is in
+ * flight.  Results never depend on any of this. */
 int mc_range_begin(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id);
 int mc_range_end(mc_handle *h);
 int mc_ranges_in_flight(const mc_handle *h);

@@ -415,11 +415,11 @@ class Engine:
 
     def range_begin(self, first, count, first_read_id=0):
         """Enqueues the front of the range (translation, seeds, seed evaluation) and returns at once.  range_end(), range_begin(next),
-        then the results of the range that ended: the device runs the next front while the host looks at them.  At most two begun."""
+        then the results of the range that ended: the device runs the next front while the host looks at them.  One range at a time."""
         self._check(self.lib.mc_range_begin(self.h, first, count, first_read_id), "mc_range_begin")
 
     def range_end(self):
-        """Completes the oldest range in flight: rows() / best_hits() / stats() are its results."""
+        """Completes the range in flight: rows() / best_hits() / stats() are its results."""
         self._check(self.lib.mc_range_end(self.h), "mc_range_end")
 
     def ranges_in_flight(self):

@@ -23,9 +23,10 @@
 // ------------------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------------------
-// Everything one range in flight needs.  A handle owns MC_NCTX of them: mc_run_range() uses the first; mc_range_begin() /
-// mc_range_end() take them in turn, so that the tail of one range (ordering, finishing) runs beside the front of the next.
-#define MC_NCTX 2
+// Everything the range in flight needs: streams, events, the pools of the stages, the pinned mirrors of the device counters.  (Rounds 2 - 3
+// had two of them per handle for a range run as two interleaved halves; what overlaps now is the host's work on the results of one
+// range with the front of the next, and that needs no second set of pools - range_begin.)
+#define MC_NCTX 1
 struct McCtx {
     hipStream_t stream = nullptr, side = nullptr, side2 = nullptr;   // the pipeline of a range, and two side streams of the ordering / finishing kernels
     hipEvent_t ev[8] = {}, ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
@@ -61,7 +62,7 @@ struct mc_handle {
     uint32_t *d_filt = nullptr, *d_wild = nullptr, *d_pair = nullptr; uint64_t *d_segtab = nullptr; unsigned long long *d_rt = nullptr;
     bool fast_enum = false;
     bool count_traffic = false;
-    int pipe_next = 0, pipe_out[MC_NCTX] = {-1, -1}, pipe_nout = 0;   // mc_range_begin / mc_range_end: the context the next range takes, the ranges in flight (oldest first)
+    int pipe_nout = 0;                    // mc_range_begin / mc_range_end: 1 while a range has been begun and not ended
     bool keep_rows = true;                // mc_search / mc_search_files hand out the m8 rows (mc_set_keep_rows)
     bool best_only = false;               // only the reads that can be classified are ranked; no rows (mc_set_best_hits_only)
     uint8_t *stage_pin[2] = {}, *stage_dev[2] = {}; size_t stage_bytes = 0; hipStream_t copy_stream = nullptr;   // run_stream
@@ -75,12 +76,12 @@ struct mc_handle {
     // mc_run_range() returns when the best hits are there; whoever looks at the rows waits for their copy (rows_wait).
     mc_row *pin_slot[2] = {nullptr, nullptr}; size_t pin_slot_cap[2] = {0, 0}; int pin_cur = 0;
     mc_row *pin_rows = nullptr; size_t pin_cap = 0;                // the slot of the current run
-    hipStream_t side = nullptr, side2 = nullptr;                    // shared by the contexts (McCtx::side, side2)
+    hipStream_t side = nullptr, side2 = nullptr;                    // (McCtx::side, side2)
     hipStream_t rows_stream = nullptr; hipEvent_t ev_rows = nullptr; bool rows_pending = false, rows_ever = false;
     std::vector<mc_row> all_rows, split_rows;                       // accumulated over the batches of a stream / over the halves of a range that overflowed
     const mc_row *res_rows = nullptr; int64_t n_res_rows = 0;
     std::vector<mc_best_hit> best; mc_stats stats;
-    McCtx *best_from = nullptr;                                    // the context whose best hits (pinned, unordered) are those of the last range: best_materialize
+    McCtx *best_from = nullptr; uint32_t best_count = 0;           // the context whose best hits (pinned, unordered) are those of the last range, and how many: best_materialize
 };
 
 static McIndex dev_index(const mc_handle *h)
@@ -136,6 +137,38 @@ extern "C" void mc_close(mc_handle *h)
     delete h;
 }
 
+// Host arrays -> device through two pinned bounce buffers (a memcpy into one while the other travels).  hipMemcpy from pageable
+// memory pins the caller's pages on the way: the 110 MB of the index took 80 - 150 ms of the engine's 120 - 190 ms warm-cache
+// open that way (the reference's default use is ONE run per process: microbe_census.py:375) - this takes ~25.
+struct McUploader {
+    static constexpr size_t CH = (size_t)8 << 20;
+    uint8_t *pin[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; hipStream_t st = nullptr; int k = 0; bool used[2] = {false, false};
+    int init()
+    {
+        HIPCK(hipStreamCreate(&st));
+        for (int i = 0; i < 2; i++) { HIPCK(hipHostMalloc((void **)&pin[i], CH, hipHostMallocDefault)); HIPCK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming)); }
+        return 0;
+    }
+    int put(void *dst, const void *src, size_t bytes)
+    {
+        for (size_t at = 0; at < bytes; at += CH) {
+            const size_t n = std::min(CH, bytes - at);
+            if (used[k]) HIPCK(hipEventSynchronize(ev[k]));
+            memcpy(pin[k], (const uint8_t *)src + at, n);
+            HIPCK(hipMemcpyAsync((uint8_t *)dst + at, pin[k], n, hipMemcpyHostToDevice, st));
+            HIPCK(hipEventRecord(ev[k], st)); used[k] = true;
+            k ^= 1;
+        }
+        return 0;
+    }
+    int finish() { if (st) HIPCK(hipStreamSynchronize(st)); return 0; }
+    ~McUploader()
+    {
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+        for (int i = 0; i < 2; i++) { if (pin[i]) (void)hipHostFree(pin[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); }
+    }
+};
+
 // h->H holds the host index (built from FASTA or loaded from a rapdb): everything device side
 static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, int32_t device)
 {
@@ -153,7 +186,7 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
     HIPCK(hipFree(nullptr));
     MC_OT("  HIP runtime, device", t0);
     // Streams: one per context for the pipeline of a range, two side streams for the ordering / finishing kernels of the longest reads
-    // (the handle's: the contexts never run those stages at the same time), one for the rows on their way to the host, one for the
+    // (the handle's), one for the rows on their way to the host, one for the
     // uploads of the streaming calls.  HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the environment
     // says otherwise) and streams that share one wait for each other: with nine streams the front of a range could land behind the
     // 5 ms copy of the rows of the range before (measured: 51.2 instead of 53.6 M reads/s) - hence few streams, and mc_hip_init_env().
@@ -174,23 +207,15 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
         dalloc(&h->d_keys, H.keys.size()) || dalloc(&h->d_fam, (size_t)nseq) || dalloc(&h->d_T, 1) || dalloc(&h->d_P, 1)) return -1;
     HIPCK(hipMemset(h->d_res_base, MC_INV, H.res.size() + 128));
     h->d_res = h->d_res_base + 64;                                 // (k_gapped_lds reads 16 bytes at a time around a flank's first residues)
-    HIPCK(hipMemcpy(h->d_res, H.res.data(), H.res.size(), hipMemcpyHostToDevice));
-    HIPCK(hipMemcpy(h->d_off, H.off.data(), H.off.size() * 4, hipMemcpyHostToDevice));
-    HIPCK(hipMemcpy(h->d_bstart, H.bstart.data(), H.bstart.size() * 4, hipMemcpyHostToDevice));
-    HIPCK(hipMemcpy(h->d_post, H.post.data(), H.post.size() * 4, hipMemcpyHostToDevice));
-    HIPCK(hipMemcpy(h->d_keys, H.keys.data(), H.keys.size() * 2, hipMemcpyHostToDevice));
-    HIPCK(hipMemcpy(h->d_fam, h->fam.data(), (size_t)nseq * 4, hipMemcpyHostToDevice));
-    if (dalloc(&h->d_bitmap, H.bitmap.size())) return -1;
-    HIPCK(hipMemcpy(h->d_bitmap, H.bitmap.data(), H.bitmap.size() * 4, hipMemcpyHostToDevice));
-    if (dalloc(&h->d_filt, H.filt.size()) || dalloc(&h->d_wild, H.wild.size()) || dalloc(&h->d_pair, H.pair.size())) return -1;
-    HIPCK(hipMemcpy(h->d_pair, H.pair.data(), H.pair.size() * 4, hipMemcpyHostToDevice));
-    HIPCK(hipMemcpy(h->d_wild, H.wild.data(), H.wild.size() * 4, hipMemcpyHostToDevice));
-    if (dalloc(&h->d_rt, H.rt.size())) return -1;
-    HIPCK(hipMemcpy(h->d_rt, H.rt.data(), H.rt.size() * 8, hipMemcpyHostToDevice));
-    HIPCK(hipMemcpy(h->d_filt, H.filt.data(), H.filt.size() * 4, hipMemcpyHostToDevice));
-    if (!H.rec.empty()) {
-        if (dalloc(&h->d_rec, H.rec.size())) return -1;
-        HIPCK(hipMemcpy(h->d_rec, H.rec.data(), H.rec.size() * sizeof(McBucketRec), hipMemcpyHostToDevice));
+    if (dalloc(&h->d_bitmap, H.bitmap.size()) || dalloc(&h->d_filt, H.filt.size()) || dalloc(&h->d_wild, H.wild.size()) || dalloc(&h->d_pair, H.pair.size()) || dalloc(&h->d_rt, H.rt.size())) return -1;
+    if (!H.rec.empty() && dalloc(&h->d_rec, H.rec.size())) return -1;
+    {
+        McUploader up;
+        if (up.init() || up.put(h->d_res, H.res.data(), H.res.size()) || up.put(h->d_off, H.off.data(), H.off.size() * 4) || up.put(h->d_bstart, H.bstart.data(), H.bstart.size() * 4) ||
+            up.put(h->d_post, H.post.data(), H.post.size() * 4) || up.put(h->d_keys, H.keys.data(), H.keys.size() * 2) || up.put(h->d_fam, h->fam.data(), (size_t)nseq * 4) ||
+            up.put(h->d_bitmap, H.bitmap.data(), H.bitmap.size() * 4) || up.put(h->d_pair, H.pair.data(), H.pair.size() * 4) || up.put(h->d_wild, H.wild.data(), H.wild.size() * 4) ||
+            up.put(h->d_rt, H.rt.data(), H.rt.size() * 8) || up.put(h->d_filt, H.filt.data(), H.filt.size() * 4) ||
+            (!H.rec.empty() && up.put(h->d_rec, H.rec.data(), H.rec.size() * sizeof(McBucketRec))) || up.finish()) return -1;
     }
     MC_OT("  index upload", t0);
     if (H.max_bucket > 2047) { g_err = "a seed bucket holds more than 2047 postings: the hit-order key cannot index it"; return -1; }
@@ -355,9 +380,11 @@ extern "C" int mc_set_run(mc_handle *h, int32_t read_len, double loge_thr, const
     return 0;
 }
 
+static void best_materialize(mc_handle *h);
 static int ensure_capacity(mc_handle *h, McCtx &c, int64_t nreads)
 {
     if (nreads <= c.cap_reads) return 0;
+    if (h->best_from == &c) best_materialize(h);                   // (the best hits of the range before still lie in the pinned buffer that is about to be replaced)
     double t0 = mc_now();
     int64_t cap = nreads;
     if (cap > (1 << 21) - 1) { g_err = "batch larger than 2097151 reads"; return -1; }
@@ -734,12 +761,14 @@ extern "C" int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t 
     return 0;
 }
 
-// One range on one context, in two halves.  range_begin ISSUES the front of the range (stage A: translation, seeds, seed evaluation -
-// two thirds of its time) and returns at once; range_end does everything else: waits for A, issues and waits for B, C + D, sends the
-// rows on their way and fetches the best hits.  mc_run_range is one after the other.  Callers with a stream of ranges (run_stream,
-// bench.py) call end(i), begin(i + 1) and THEN look at the results of range i: the device works on the next front while the host
-// collects rows and best hits (per 2 M reads of 150 bp 0.4 ms to bring the best hits into read order, whatever the caller does with
-// them, and - mc_search with rows - the 270 MB of rows to copy out of the pinned buffer), on two contexts in turn.
+// A range in two halves.  range_begin ISSUES the front of the range (stage A: translation, seeds, seed evaluation - two thirds of
+// its time) and returns at once; range_end does everything else: waits for A, issues and waits for B, C + D, sends the rows on their
+// way and fetches the best hits.  mc_run_range is one after the other.  Callers with a stream of ranges (run_stream, bench.py) call
+// end(i), begin(i + 1) and THEN look at the results of range i: the device works on the next front while the host collects rows
+// and best hits (per 2 M reads of 150 bp 0.4 ms to bring the best hits into read order, whatever the caller does with them, and -
+// mc_search with rows - the 270 MB of rows to copy out of the pinned buffer).  The next front may overwrite every pool of the
+// range before: what the host still reads of it lies in pinned host memory (rows: two buffers in turn; best hits; the counters
+// were taken at range_end), and the rows still leaving the device are waited for by stage D (ev_rows).
 static int range_begin(mc_handle *h, McCtx &c, int64_t first, int64_t count, int64_t first_read_id)
 {
     if (ensure_capacity(h, c, count)) return -1;
@@ -756,9 +785,10 @@ static void best_materialize(mc_handle *h)
     McCtx *c = h->best_from;
     if (!c) return;
     h->best_from = nullptr;
-    std::sort(c->h_best, c->h_best + c->nbest, [](const McBestHit &x, const McBestHit &y) { return x.read < y.read; });
-    h->best.resize(c->nbest);
-    for (uint32_t i = 0; i < c->nbest; i++) { const McBestHit &x = c->h_best[i]; mc_best_hit &o = h->best[i]; o.read = x.read; o.family = x.family; o.aln = x.aln; o.target_len = x.target_len; o.bits = x.bits; }
+    const uint32_t nb = h->best_count;                             // (taken at range_end: the front of the next range has reset the context's counts since)
+    std::sort(c->h_best, c->h_best + nb, [](const McBestHit &x, const McBestHit &y) { return x.read < y.read; });
+    h->best.resize(nb);
+    for (uint32_t i = 0; i < nb; i++) { const McBestHit &x = c->h_best[i]; mc_best_hit &o = h->best[i]; o.read = x.read; o.family = x.family; o.aln = x.aln; o.target_len = x.target_len; o.bits = x.bits; }
 }
 
 static int range_end(mc_handle *h, McCtx &c)
@@ -796,7 +826,7 @@ static int range_end(mc_handle *h, McCtx &c)
     if (c.nrows) { HIPCK(hipEventRecord(h->ev_rows, h->rows_stream)); h->rows_pending = true; h->rows_ever = true; }
     if ((rc = stage_wait(c)) != 0) return rc;
     h->res_rows = h->pin_rows; h->n_res_rows = (int64_t)c.nrows;
-    h->best_from = &c;                                           // (mc_result_best_hits / whoever needs them: best_materialize)
+    h->best_from = &c; h->best_count = c.nbest;                  // (mc_result_best_hits / whoever needs them: best_materialize)
 #ifdef MC_EXP_TIMING
     { const char *nm[6] = {"staging/other", "append", "lookup", "push", "setup", "expand"}; for (int k = 0; k < 6; k++) fprintf(stderr, "timing %-14s %8.3f Mcycles/wave-avg  %10llu entries\n", nm[k], (double)c.h_stats[4 + k] / 4096.0 / 1e6, c.h_stats[10 + k]); }
 #endif
@@ -830,24 +860,20 @@ static int run_range_once(mc_handle *h, int64_t first, int64_t count, int64_t fi
 }
 
 // ---- a stream of ranges: the front of the next one issued before the host looks at the results of this one -------------------------
-// mc_range_begin() enqueues the front of a range (on the context that is free) and returns at once; mc_range_end() completes the
-// OLDEST range begun (results as after mc_run_range).  end(i), begin(i + 1), results of i, end(i + 1), ... keeps the device busy
-// while the host works on the results (at most two ranges begun).  A range that overflows a pool comes back with -2 from
-// mc_range_end: it is no longer in flight; run it with mc_run_range (which splits it) once the other one has been ended.
+// mc_range_begin() enqueues the front of a range and returns at once; mc_range_end() completes it (results as after mc_run_range).
+// end(i), begin(i + 1), results of i, end(i + 1), ... keeps the device busy while the host works on the results.  One range at a
+// time is on the device: a second mc_range_begin() before mc_range_end() is refused.  A range that overflows a pool comes back with
+// -2 from mc_range_end: it is no longer in flight; run it with mc_run_range (which splits it).
 // (Round 4 also measured the TAIL of a range - ordering, finishing - running beside the front of the next, on ordinary streams, on
 // streams of their own priority and on streams with CU masks: it does not pay)
 extern "C" int mc_range_begin(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id)
 {
     if (range_check(h, first, count)) return -1;
     if (count <= 0) { g_err = "mc_range_begin: an empty range"; return -1; }
-    if (h->pipe_nout >= MC_NCTX) { g_err = "mc_range_begin: two ranges are in flight already"; return -1; }
-    const int k = h->pipe_next;
-    McCtx &c = h->ctx[k];
-    if (c.busy) { g_err = "mc_range_begin: internal - the context is busy"; return -1; }
-    const int rc = range_begin(h, c, first, count, first_read_id);
+    if (h->pipe_nout) { g_err = "mc_range_begin: a range is in flight already (mc_range_end first)"; return -1; }
+    const int rc = range_begin(h, h->ctx[0], first, count, first_read_id);
     if (rc) return rc;
-    h->pipe_out[h->pipe_nout++] = k;
-    h->pipe_next = (k + 1) % MC_NCTX;
+    h->pipe_nout = 1;
     return 0;
 }
 
@@ -856,10 +882,8 @@ extern "C" int mc_range_end(mc_handle *h)
     if (!h) { g_err = "null handle"; return -1; }
     if (h->pipe_nout == 0) { g_err = "mc_range_end: no range in flight"; return -1; }
     HIPCK(hipSetDevice(h->device));
-    const int k = h->pipe_out[0];
-    for (int i = 1; i < h->pipe_nout; i++) h->pipe_out[i - 1] = h->pipe_out[i];
-    h->pipe_nout--;
-    return range_end(h, h->ctx[k]);
+    h->pipe_nout = 0;
+    return range_end(h, h->ctx[0]);
 }
 
 extern "C" int mc_ranges_in_flight(const mc_handle *h) { return h ? h->pipe_nout : 0; }
@@ -938,11 +962,8 @@ static int run_stream(mc_handle *h, const std::function<int64_t(uint8_t *, int64
         MC_OT("run_stream: staging buffers", t0);
     }
     if (!h->copy_stream) HIPCK(hipStreamCreate(&h->copy_stream));
-    const bool one_batch = expect_reads > 0 && expect_reads <= std::min(bmax_run, B);   // (nothing to overlap: the second context's pools stay unallocated)
-    const int first_ctx = h->pipe_next;
-    if (expect_reads > 0 && ensure_capacity(h, h->ctx[first_ctx], std::min<int64_t>(bmax_run, expect_reads))) return -1;
+    if (expect_reads > 0 && ensure_capacity(h, h->ctx[0], std::min<int64_t>(bmax_run, expect_reads))) return -1;
     MC_OT("run_stream: pools", t0);
-    bool other_sized = one_batch || expect_reads <= 0;             // the other context's pools: allocated while the first batch's front runs
     McBatchSlot slot[2];
     for (int k = 0; k < 2; k++) { slot[k].pin = h->stage_pin[k]; slot[k].dev = h->stage_dev[k]; }
     std::mutex mu; std::condition_variable cv;
@@ -1004,12 +1025,11 @@ static int run_stream(mc_handle *h, const std::function<int64_t(uint8_t *, int64
         h->reads_dev = slot[k].dev; h->nreads = slot[k].n;
         if ((rc = mc_range_begin(h, 0, slot[k].n, first_read_id + slot[k].first)) != 0) break;
         flying = k;
-        if (!other_sized) { other_sized = true; if (ensure_capacity(h, h->ctx[first_ctx ^ 1], std::min<int64_t>(bmax_run, expect_reads))) { rc = -1; break; } }
         collect();                                                   // the batch before, while the front of this one runs
     }
     if (rc == 0 && flying >= 0) { rc = end_batch(flying); flying = -1; }
     if (rc == 0) collect();
-    while (h->pipe_nout) (void)mc_range_end(h);                      // (after an error: nothing stays in flight)
+    if (h->pipe_nout) (void)mc_range_end(h);                         // (after an error: nothing stays in flight)
     { std::unique_lock<std::mutex> lk(mu); abort_up = true; cv.notify_all(); }
     uploader.join();
     h->reads_dev = saved_reads; h->nreads = saved_n;

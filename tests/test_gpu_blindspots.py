@@ -188,9 +188,9 @@ def test_ordering_paths_of_the_longest_reads_on_ordinary_reads(tmp_path):
 
 
 def test_stream_of_ranges_equals_ranges_one_at_a_time(engine, marker_reads, monkeypatch):
-    """mc_range_begin / mc_range_end (the front of range i + 1 enqueued before the host looks at the results of range i, two
-    contexts in turn) against mc_run_range on the same resident reads: rows, best hits and counts equal, range by range, in the
-    order end, begin, results and with both ranges begun before the first ends; the misuse errors; a range whose pools overflow
+    """mc_range_begin / mc_range_end (the front of range i + 1 enqueued - over the pools of range i - before the host looks at the
+    results of range i) against mc_run_range on the same resident reads: rows, best hits and counts equal, range by range, in the
+    order end, begin, results; the misuse errors; a range whose pools overflow
     comes back with -2 from mc_range_end and leaves nothing in flight; and the streaming call that meets such ranges (mc_search
     of the marker-dense library in 150,000-read batches) still delivers every row in order."""
     from microbecensus_amd import _native, synth
@@ -207,29 +207,26 @@ def test_stream_of_ranges_equals_ranges_one_at_a_time(engine, marker_reads, monk
         want.append((engine.rows(), engine.best_hits(), engine.stats()))
     assert sum(len(w[0]) for w in want) > 100_000
     starts = list(range(0, n, step))
-    for both_begun in (False, True):
-        got = []
-        engine.range_begin(starts[0], step, starts[0])
-        for i in range(len(starts)):
-            nxt = starts[i + 1] if i + 1 < len(starts) else None
-            if both_begun and nxt is not None:
-                engine.range_begin(nxt, step, nxt)
-                assert engine.ranges_in_flight() == 2
-                with pytest.raises(RuntimeError, match="two ranges are in flight"):
-                    engine.range_begin(0, step, 0)
-                with pytest.raises(RuntimeError, match="in flight"):
-                    engine.run_range(0, step, 0)
-            engine.range_end()
-            if not both_begun and nxt is not None:
-                engine.range_begin(nxt, step, nxt)
-            got.append((engine.rows(), engine.best_hits(), engine.stats()))    # (while the front of the next range runs)
-        assert engine.ranges_in_flight() == 0
-        with pytest.raises(RuntimeError, match="no range in flight"):
-            engine.range_end()
-        assert len(got) == len(want)
-        for (r, b, s), (r0, b0, s0) in zip(got, want):
-            assert _fields_equal(r, r0) and _fields_equal(b, b0)
-            assert all(s[k] == s0[k] for k in ("reads", "seed_tasks", "gap_tasks", "hsps", "rows", "reads_with_rows", "classified"))
+    got = []
+    engine.range_begin(starts[0], step, starts[0])
+    with pytest.raises(RuntimeError, match="in flight already"):
+        engine.range_begin(0, step, 0)
+    with pytest.raises(RuntimeError, match="in flight"):
+        engine.run_range(0, step, 0)
+    for i in range(len(starts)):
+        nxt = starts[i + 1] if i + 1 < len(starts) else None
+        engine.range_end()
+        if nxt is not None:
+            engine.range_begin(nxt, step, nxt)
+            assert engine.ranges_in_flight() == 1
+        got.append((engine.rows(), engine.best_hits(), engine.stats()))        # (while the front of the next range overwrites the pools)
+    assert engine.ranges_in_flight() == 0
+    with pytest.raises(RuntimeError, match="no range in flight"):
+        engine.range_end()
+    assert len(got) == len(want)
+    for (r, b, s), (r0, b0, s0) in zip(got, want):
+        assert _fields_equal(r, r0) and _fields_equal(b, b0)
+        assert all(s[k] == s0[k] for k in ("reads", "seed_tasks", "gap_tasks", "hsps", "rows", "reads_with_rows", "classified"))
     # the streaming call runs its batches the same way
     monkeypatch.setenv("MC_STREAM_BATCH", "20000")
     rows_s, best_s = engine.search(reads)
@@ -249,3 +246,31 @@ def test_stream_of_ranges_equals_ranges_one_at_a_time(engine, marker_reads, monk
     assert engine.ranges_in_flight() == 0
     engine.run_range(0, 150_000, 0)
     assert engine.stats()["range_splits"] > 0 and _fields_equal(engine.rows(), rows5[rows5["query"] < 150_000])
+
+
+def test_stream_whose_batches_outgrow_the_pools(tmp_path):
+    """A stream of unknown length (`-n` beyond anything a file holds: mc_search_files cannot size the pools ahead) on a fresh engine:
+    the batches grow (256 k reads, then 512 k), the pools are replaced at the front of the second batch - while the best hits of the
+    first one still lie in the pinned buffer of the old pools.  Best hits == those of the same reads searched from memory."""
+    from microbecensus_amd import _native, synth
+    names, seqs = _native.load_markers()
+    model = _native.load_model()
+    genome = synth.build_genomes(seqs, total_bp=2_000_000, seed=31)
+    reads = synth.sample_reads(genome, 600_000, 100, seed=32)
+    fa = tmp_path / "reads.fa"
+    with open(fa, "wb") as f:
+        for s in range(0, len(reads), 50000):
+            f.write(b"".join(b">r%d\n%s\n" % (s + i, bytes(r)) for i, r in enumerate(reads[s:s + 50000])))
+    eng = _native.Engine(device=0)
+    try:
+        eng.set_run(100, model["pars"]["100"], model["families"])
+        rd = _native.Reader([str(fa)], 100, 1 << 42, False, 0, -5, -5, 100, False)
+        try:
+            _, best = eng.search_files(rd, keep_rows=False, best_only=True)
+            assert rd.stats()["sampled"] == len(reads)
+        finally:
+            rd.close()
+        _, want = eng.search(reads)
+        assert len(want) > 1000 and _fields_equal(best, want)
+    finally:
+        eng.close()

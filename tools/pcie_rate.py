@@ -5,8 +5,8 @@ import numpy as np
 from microbecensus_amd import _native, synth
 names, seqs = _native.load_markers(); model = _native.load_model(); fams = model["families"]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
-genome = synth.build_genomes(seqs, total_bp=8_000_000, seed=20261001)
-reads = synth.sample_reads(genome, n, 150, seed=1000)
+gen = synth.GenomeReads(device="cpu", seed=20261001)          # the bench workload: reads of the reference's 30 genomes
+reads = gen.single(n, 150).numpy()
 eng = _native.Engine(device=0); eng.set_run(150, model["pars"]["150"], fams)
 for it in range(3):
     t = time.time(); eng.lib.mc_search(eng.h, reads.ctypes.data, n, 0); dt = time.time() - t
