@@ -42,10 +42,10 @@ struct McCtx {
     unsigned long long *d_gtab = nullptr; uint32_t gtab_slots = 0; uint32_t *d_gleader = nullptr; McFlankOut *d_fout = nullptr;
     // pinned host mirrors
     uint32_t *h_c = nullptr; unsigned long long *h_stats = nullptr; McBestHit *h_best = nullptr; size_t h_best_cap = 0;
-    // the part being processed
+    // the range being processed
     const uint8_t *reads = nullptr; int64_t n = 0, first_read_id = 0;
     uint32_t ntasks = 0, ngaps = 0, gpad = 0, nh = 0, nh_all = 0, nheads = 0, nrows = 0, nbest = 0, nsegs = 0;
-    bool busy = false;                                             // a range has been begun on this context and not ended
+    bool busy = false;                                             // a range has been begun and not ended
 };
 
 struct mc_handle {
@@ -185,7 +185,7 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
     HIPCK(hipSetDevice(device));
     HIPCK(hipFree(nullptr));
     MC_OT("  HIP runtime, device", t0);
-    // Streams: one per context for the pipeline of a range, two side streams for the ordering / finishing kernels of the longest reads
+    // Streams: one for the pipeline of a range, two side streams for the ordering / finishing kernels of the longest reads
     // (the handle's), one for the rows on their way to the host, one for the
     // uploads of the streaming calls.  HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the environment
     // says otherwise) and streams that share one wait for each other: with nine streams the front of a range could land behind the
@@ -440,7 +440,7 @@ extern "C" int mc_attach(mc_handle *h, const void *device_reads, int64_t nreads)
 
 static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 
-// The pipeline of one part, in five stages.  Each stage only ISSUES work on the part's stream and ends with an asynchronous copy
+// The pipeline of a range, in five stages.  Each stage only ISSUES work on the range's stream and ends with an asynchronous copy
 // of the device counters into pinned host memory; the next stage starts by waiting for that copy (stage_wait) and sizes its
 // launches from it.
 static int stage_wait(McCtx &c) { HIPCK(hipStreamSynchronize(c.stream)); return 0; }
@@ -706,12 +706,11 @@ static int stage_d(mc_handle *h, McCtx &c)
     return counters_to_host(c);
 }
 
-// E: rows (final order and ABI layout: McRow == mc_row) and best hits into pinned host memory; rows_at = where this part's rows
-// go in the handle's row buffer
-static int stage_e(mc_handle *h, McCtx &c, size_t rows_at)
+// E: rows (final order and ABI layout: McRow == mc_row) and best hits into pinned host memory
+static int stage_e(mc_handle *h, McCtx &c)
 {
     hipStream_t st = c.stream;
-    if (c.nrows) HIPCK(hipMemcpyAsync(h->pin_rows + rows_at, c.d_rows, sizeof(McRow) * c.nrows, hipMemcpyDeviceToHost, h->rows_stream));   // (the part's stream has been waited for: d_rows is final)
+    if (c.nrows) HIPCK(hipMemcpyAsync(h->pin_rows, c.d_rows, sizeof(McRow) * c.nrows, hipMemcpyDeviceToHost, h->rows_stream));   // (the range's stream has been waited for: d_rows is final)
     if (c.nbest) HIPCK(hipMemcpyAsync(c.h_best, c.d_best, sizeof(McBestHit) * c.nbest, hipMemcpyDeviceToHost, st));
     return 0;
 }
@@ -821,7 +820,7 @@ static int range_end(mc_handle *h, McCtx &c)
             }
         }
     }
-    rc = stage_e(h, c, 0);
+    rc = stage_e(h, c);
     if (rc) { (void)hipStreamSynchronize(c.stream); (void)hipStreamSynchronize(h->rows_stream); return rc; }
     if (c.nrows) { HIPCK(hipEventRecord(h->ev_rows, h->rows_stream)); h->rows_pending = true; h->rows_ever = true; }
     if ((rc = stage_wait(c)) != 0) return rc;
@@ -917,7 +916,7 @@ extern "C" int mc_set_counting(mc_handle *h, int on)
 }
 
 extern "C" int mc_set_parts(mc_handle *h, int parts)
-{   // (rounds 2 - 3 could cut a range into two parts issued alternately; ranges in flight - mc_set_pipeline - took its place)
+{   // (rounds 2 - 3 could cut a range into two parts issued alternately)
     if (!h || parts < 1) { g_err = "bad argument"; return -1; }
     return 0;
 }
