@@ -279,8 +279,18 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
         for (int i0_ = 0; i0_ < nraw; i0_ += 64)                                                                                 \
             if (i0_ + lane < nraw) __builtin_amdgcn_global_load_lds(gs_ + i0_ + lane, (uint32_t *)raw + i0_, 4, 0, 0);            \
     } while (0)
-    if ((int64_t)blockIdx.x * MC_EN_WAVES + wv < nreads) MC_EN_FETCH((int64_t)blockIdx.x * MC_EN_WAVES + wv);
-    for (int64_t r = (int64_t)blockIdx.x * MC_EN_WAVES + wv; r < nreads; r += nw) {
+    // Which reads a wave takes.  Dealt out in turn (read w, w + nw, ...) a wave's 325 reads of a 2 M batch cost what they cost - a read of
+    // a marker gene tens of times an ordinary one - and the launch lasted as long as its unluckiest wave.  So: chunks of MC_EN_CHUNK
+    // consecutive reads, the first one by the wave's number, every further one from a counter (one atomic per chunk: 250 k per launch).
+#ifndef MC_EN_CHUNK
+#define MC_EN_CHUNK 16
+#endif
+    int64_t r = ((int64_t)blockIdx.x * MC_EN_WAVES + wv) * MC_EN_CHUNK;
+    int left = MC_EN_CHUNK - 1;                                              // reads of the current chunk behind r
+    uint32_t pend = 0;                                                       // lane 0: the number of the chunk after this one
+    static_assert(MC_EN_CHUNK >= 2, "the next chunk is asked for while the last but one read of a chunk is searched");
+    if (r < nreads) MC_EN_FETCH(r);
+    while (r < nreads) {
         int qn = 0, hn = 0, en = 0;
         MC_TICK(0);
         __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0): this read's frames have arrived
@@ -297,7 +307,11 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
             if (lane < 36) { ((uint32_t *)W->setter)[lane] = 0; ((uint32_t *)W->hit)[lane] = 0; }
             mc_wave_sync();
         }
-        if (r + nw < nreads) MC_EN_FETCH(r + nw);
+        int64_t rnext = r + 1;                                               // the read after this one: its frames start their way now
+        if (left == 1 && lane == 0) pend = atomicAdd(&counters[C_ENCHUNK], 1u);   // (the next chunk, asked for one read ahead: the answer is there when it is needed)
+        if (left > 0) left--;
+        else { rnext = (nw + (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pend)) * MC_EN_CHUNK; left = MC_EN_CHUNK - 1; }
+        if (rnext < nreads) MC_EN_FETCH(rnext);
         // What a seed position will do is decided here, once: the 6-mer's bucket and the four key residues (ten codes = 40
         // bits out of three aligned words of the row), whether the bucket holds anything (bitmap gather; those of three sweeps
         // are in flight together), and from that which probes it makes.  The positions of the six frames are numbered through
@@ -551,6 +565,7 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
             }
             mc_wave_sync();
         }
+        r = rnext;
     }
     MC_TICK(0);
 #ifdef MC_EXP_TIMING

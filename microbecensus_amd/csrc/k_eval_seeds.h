@@ -145,6 +145,9 @@ __device__ unsigned long long g_ev_acc[8];           // wave time per phase, sum
                              // 7 waves per SIMD and 72 registers with 52 bytes of scratch 3.50 / 7.77 ms, 6 with 80 and 12 bytes 2.82 / 6.41, 5 with 88 2.60 / 6.01, 4: 2.79 / 6.53)
 #define MC_EV_QCAP 128       // survivors of the gate a wave holds (32 bytes each: 4 KB of LDS per wave)
 #define MC_EV_BLK 256u       // slots of the HSP / gap-task pools a wave reserves at a time (one global atomic per block)
+#ifndef MC_EV_GROUP
+#define MC_EV_GROUP 16u      // chunks of 64 hits a wave takes at a time (one global atomic per group)
+#endif
 // n consecutive slots for the wave's lanes (lane with rank r < n gets one; n is the same for every lane): from the wave's current
 // block of the pool, continued in a new block when that one is full.  *ok = false after a pool overflow.
 __device__ __forceinline__ uint32_t mc_ev_slots(uint32_t n, uint32_t r, uint32_t cap, uint32_t *counter, uint32_t &blk_base, uint32_t &blk_used, bool *ok, int lane)
@@ -179,7 +182,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
     uint32_t qn = 0, hb_base = 0, hb_used = MC_EV_BLK, gb_base = 0, gb_used = MC_EV_BLK;
     bool ok = true;
     const unsigned long long lt = (1ull << lane) - 1;
-    const uint32_t nchunks = (ntasks + MC_EV_BS - 1) / MC_EV_BS;
+    // Which hits a wave takes: groups of MC_EV_GROUP chunks of 64 consecutive hits, the first group by the wave's number, every further
+    // one from a counter (asked for one chunk ahead of need) - dealt out in turn, the launch lasted as long as the wave whose hits
+    // took longest (the same finding as in k_enumerate_t0: reads of marker genes cost many times the average).
+    const uint32_t nchunks = (ntasks + 63u) / 64u, nwaves = gridDim.x * (MC_EV_BS / 64);
+    uint32_t cur = (blockIdx.x * (MC_EV_BS / 64) + (uint32_t)wv) * MC_EV_GROUP, cleft = MC_EV_GROUP - 1, pend = 0;
     // The chain of dependent reads of a hit was: its record -> the subject's offsets -> the residue in front of the seed -> the
     // seed's residues, four trips to the L2 before the gate.  Now: the record of the NEXT chunk is fetched while this one is
     // evaluated, the record carries the hit's position in the residue array (MC_TASK_W3), and the subject's end, the residues in
@@ -189,17 +196,22 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
 #endif
     McSeedTask tn;
     tn.read = MC_TASK_NONE; tn.chrono = 0; tn.posting = 0; tn.seedlen_nkey = 0;
-    if (blockIdx.x * MC_EV_BS + threadIdx.x < ntasks) tn = tasks[blockIdx.x * MC_EV_BS + threadIdx.x];
-    for (uint32_t chunk = blockIdx.x;; chunk += gridDim.x) {
-        const bool last = chunk >= nchunks;
+    if ((uint64_t)cur * 64 + (uint32_t)lane < ntasks) tn = tasks[(uint64_t)cur * 64 + (uint32_t)lane];
+    for (;;) {
+        const bool last = cur >= nchunks;
         if (!last) {   // ---- phase 1: the gate, one hit per lane
             MC_EV_TICK(0);
-            const uint32_t tid = chunk * MC_EV_BS + threadIdx.x;
+            const uint32_t tid = cur * 64u + (uint32_t)lane;
             const McSeedTask t = tn;
             {
-                const uint64_t nx = (uint64_t)(chunk + gridDim.x) * MC_EV_BS + threadIdx.x;
+                uint32_t nxt = cur + 1;
+                if (cleft == 1 && lane == 0) pend = atomicAdd(&counters[C_EVCHUNK], 1u);
+                if (cleft > 0) cleft--;
+                else { nxt = (nwaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)pend)) * MC_EV_GROUP; cleft = MC_EV_GROUP - 1; }
+                const uint64_t nx = (uint64_t)nxt * 64 + (uint32_t)lane;
                 tn.read = MC_TASK_NONE;
                 if (nx < ntasks) tn = tasks[nx];
+                cur = nxt;
             }
             bool surv = false;
             uint4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};
