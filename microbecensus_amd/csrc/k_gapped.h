@@ -250,7 +250,7 @@ struct McGapLds {
 template <int W, int LANES>
 __global__ void __launch_bounds__(64) k_gapped_lds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
                                                    const McGapTask *__restrict__ gaps, const uint32_t *__restrict__ list, const uint32_t *__restrict__ nitems_p, McFlankOut *fout,
-                                                   uint32_t *retry_count, uint32_t *retry, int refill)
+                                                   uint32_t *retry_count, uint32_t *retry, int refill, uint32_t *take)
 {
     __shared__ McHot hot;
     __shared__ uint2 win[W * 64];
@@ -264,10 +264,15 @@ __global__ void __launch_bounds__(64) k_gapped_lds(const McTables *__restrict__ 
     // first LANES lanes of a wave take items, so that the items spread over all the waves the GPU holds
     const bool mine = lane < LANES;
     const uint32_t G = gridDim.x, w0 = blockIdx.x;
-    const uint32_t share = nitems > w0 ? (nitems - w0 + G - 1) / G : 0u;   // items of this wave: list[w0 + G k], k < share
+    // The items of this wave: windows of WS consecutive items of the list (which is in descending order of DP rows), the first one by the
+    // wave's number, every further one from a counter, asked for when half of the window before is used up - longest first, to whoever
+    // is free.  (Dealt out in turn - wave w took items w, w + G, ... - the waves were resident for 85 % of the launch: SQ_WAVE_CYCLES.)
+    constexpr uint32_t WS = (uint32_t)LANES;                       // (the retry launch: as many items as lanes that take them - its few items spread over all the waves)
+    uint32_t wpos = w0 * WS < nitems ? w0 * WS : nitems, wend = wpos + WS < nitems ? wpos + WS : nitems;
+    uint32_t pend = 0;                                             // lane 0: the number of the next window
+    bool asked = false, dry = false;                               // a window has been asked for / there are no more
     const unsigned long long lt = (1ull << lane) - 1;
     const int REFILL = LANES < refill ? 1 : refill;
-    uint32_t taken = 0;
     // the flank being extended
     bool active = false;
     uint32_t it = 0;
@@ -288,7 +293,7 @@ __global__ void __launch_bounds__(64) k_gapped_lds(const McTables *__restrict__ 
         {   // ---- the idle lanes whose next flank is ready start it - MC_GAP_REFILL of them together, or when nothing else is left to do
             const bool ready = mine && !active && nstage == 5;
             const unsigned long long rm = __ballot(ready);
-            if (rm && (__popcll(rm) >= REFILL || taken >= share || __ballot(active) == 0)) {
+            if (rm && (__popcll(rm) >= REFILL || (dry && wpos >= wend) || __ballot(active) == 0)) {
                 if (ready) {
                     it = nit; active = true; nstage = 0; ws.ovf = 0;
                     fin = !mc_gap_begin(hot, S, ns1, ns2, nf.st, nf.n1, nf.n2, ws, W, true, nlo, nhi, (int)nx0);
@@ -322,11 +327,20 @@ __global__ void __launch_bounds__(64) k_gapped_lds(const McTables *__restrict__ 
         {   // claim: the lanes without a next item take the next ones of the wave's share
             const bool want = mine && nstage == 0;
             const unsigned long long cm = __ballot(want);
-            if (cm && taken < share) {
-                const uint32_t k = taken + (uint32_t)__popcll(cm & lt);
-                if (want && k < share) { nit = list[w0 + G * k]; nstage = 1; }
-                taken += (uint32_t)__popcll(cm);
+            if (cm && wpos >= wend && !dry) {                       // the window is used up: on to the next one
+                if (!asked && lane == 0) pend = atomicAdd(take, 1u);
+                const uint32_t base = (G + (uint32_t)__builtin_amdgcn_readfirstlane((int)pend)) * WS;
+                asked = false;
+                if (base >= nitems) { dry = true; wpos = wend = nitems; }
+                else { wpos = base; wend = base + WS < nitems ? base + WS : nitems; }
             }
+            if (cm && wpos < wend) {
+                const uint32_t k = wpos + (uint32_t)__popcll(cm & lt);
+                if (want && k < wend) { nit = list[k]; nstage = 1; }
+                wpos += (uint32_t)__popcll(cm);
+                if (wpos > wend) wpos = wend;
+            }
+            if (!asked && !dry && wend - wpos <= WS / 2) { if (lane == 0) pend = atomicAdd(take, 1u); asked = true; }
         }
         // ---- one DP row of every flank in progress
         if (active && !fin) fin = mc_gap_row(hot, S, ws, W);
@@ -335,6 +349,6 @@ __global__ void __launch_bounds__(64) k_gapped_lds(const McTables *__restrict__ 
         const bool over = fin && S.over != 0;
         const uint32_t ro = mc_wave_alloc(retry_count, over);      // band left the window: the flank is redone with a wider one
         if (over) retry[ro] = it;
-        if (taken >= share && __ballot(active || nstage != 0) == 0) break;
+        if (dry && wpos >= wend && __ballot(active || nstage != 0) == 0) break;
     }
 }

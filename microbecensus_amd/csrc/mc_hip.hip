@@ -553,8 +553,8 @@ static int stage_b(mc_handle *h, McCtx &c)
         k_gap_sort_scan<<<dim3(1), dim3(1024), 0, st>>>(c.d_ghist);
         k_gap_sort_scatter<<<dim3(512), dim3(256), 0, st>>>(gk, gi, c.d_counters + C_ITEMS, 2 * ngaps, c.d_ghist, gio);
         k_gapped_lds<MC_GAP_WIN, 64><<<dim3(std::min<uint32_t>((2 * ngaps + 63) / 64, 256u * gap_wpc)), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, gio, c.d_counters + C_ITEMS, c.d_fout,
-                                                                                                                 c.d_counters + C_RETRY, c.d_retry, gap_refill);
-        k_gapped_lds<MC_GAP_WIN2, MC_GAP_LANES2><<<dim3(256u * 4u), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry, c.d_counters + C_RETRY, c.d_fout, c.d_counters + C_RETRY2, c.d_retry2, 1);
+                                                                                                                 c.d_counters + C_RETRY, c.d_retry, gap_refill, c.d_counters + C_GTAKE);
+        k_gapped_lds<MC_GAP_WIN2, MC_GAP_LANES2><<<dim3(256u * 4u), dim3(64), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry, c.d_counters + C_RETRY, c.d_fout, c.d_counters + C_RETRY2, c.d_retry2, 1, c.d_counters + C_GTAKE2);
         k_gapped<<<dim3(c.gap_threads_full / 128), dim3(128), 0, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_gaps, c.d_retry2, c.d_counters + C_RETRY2, c.d_fout, c.d_counters, c.d_gws_full, MC_GAP_W);
         k_gap_emit<<<dim3((ngaps + 255) / 256), dim3(256), 0, st>>>(h->d_T, X, L, c.d_gaps, ngaps, c.d_gleader, c.d_fout, c.d_hsps, c.cap_hsps, c.d_counters, h->d_P, h->d_fam, h->best_only ? c.d_cand : nullptr, c.d_hkeys, c.d_low, c.d_hplace);
     }

@@ -41,7 +41,7 @@ extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
         }                                                                                                   \
     } while (0)
 
-enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_HEAVY, C_HEAVY2, C_ITEMS, C_RETRY2, C_HEAVY3, C_LIGHT0, C_LIGHT1, C_LIGHT2, C_LIGHT3, C_HSPS2, C_HPAD, C_GPAD, C_ORDER, C_ORDER2, C_ORDER3, C_OTAKE, C_OTAKE2, C_OTAKE3, C_HEAVY1, C_ENCHUNK, C_EVCHUNK, C_N = 30 };
+enum { C_TASKS = 0, C_GAPS, C_HSPS, C_HEADS, C_ROWS, C_OVERFLOW, C_SEGS, C_BEST, C_RETRY, C_HEAVY, C_HEAVY2, C_ITEMS, C_RETRY2, C_HEAVY3, C_LIGHT0, C_LIGHT1, C_LIGHT2, C_LIGHT3, C_HSPS2, C_HPAD, C_GPAD, C_ORDER, C_ORDER2, C_ORDER3, C_OTAKE, C_OTAKE2, C_OTAKE3, C_HEAVY1, C_ENCHUNK, C_EVCHUNK, C_GTAKE, C_GTAKE2, C_N = 32 };
 enum { S_LOOKUPS = 0, S_KEYPROBES, S_TASKS, S_EXACT = 16, S_WILD, S_PAIRS, S_PROBES, S_N = 20 };   // 64-bit algorithmic-traffic counters of k_enumerate; slots 4..: cycle counters of the MC_EXP_TIMING build
 
 extern __shared__ __attribute__((aligned(16))) uint8_t mc_smem[];   // dynamic LDS of the kernels that use it
