@@ -13,7 +13,10 @@ Workload: error-free reads sampled from the reference's 30 real
   N > 1: BASELINE configs[3] in weak-scaling form - a paired library (mate 2 = reverse complement of the fragment end, insert
          --insert), the stream "all of file 1, then all of file 2" cut into contiguous blocks, one per rank, K x batch reads each.
 One "step" is one pass of the whole device pipeline (translate + SEG, seeds, extension, ranking, classification) over one batch;
-the per-family accumulators of every step are summed over the ranks with an RCCL all_reduce.
+the per-family accumulators of every step are summed over the ranks with an RCCL all_reduce.  The steps are issued the way
+mc_search / mc_search_files issue their batches: mc_range_end(i), mc_range_begin(i + 1), then the results of step i - the front
+of the next step is enqueued before the host sums up (--one-at-a-time: mc_run_range per step).  The timed region holds exactly
+K steps, each from its first kernel to its results on the host.
 
 Rank 0 prints ONE JSON line: metric / value (whole-job reads/s), `roofline` for the dominant kernel and, at N = 1, `cpu_baseline`
 (the reference's own RAPsearch2 binary on this host's cores on bounded samples of the same reads, m8 compared by md5) and `e2e`
