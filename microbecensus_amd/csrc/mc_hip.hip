@@ -1018,6 +1018,11 @@ static int run_stream(mc_handle *h, const std::function<int64_t(uint8_t *, int64
     };
     int rc = 0, flying = -1;
     for (int k = 0;; k ^= 1) {
+        {   // the next batch is not there yet (the source is the slower side): nothing to overlap with - finish the range in flight now
+            bool ready;
+            { std::unique_lock<std::mutex> lk(mu); ready = slot[k].state != 0; }
+            if (!ready && flying >= 0) { if ((rc = end_batch(flying)) != 0) break; flying = -1; collect(); }
+        }
         { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return slot[k].state != 0; }); }
         if (slot[k].state == 2) { if (slot[k].rc < 0) { rc = (int)slot[k].rc; if (!up_err.empty()) g_err = up_err; } break; }
         if (flying >= 0) { if ((rc = end_batch(flying)) != 0) break; flying = -1; }
