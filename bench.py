@@ -166,6 +166,11 @@ def derived(prof, stage):
         out["wait_frac"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)
     if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_THREAD_CYCLES_VALU"):
         out["valu_lanes_of_64"] = round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"], 2)
+    if len(c["_kernels"]) == 1 and c.get("SQ_WAVES") and c["SQ_WAVES"] <= 256 * 32 and c.get("GRBM_GUI_ACTIVE") and c.get("SQ_WAVE_CYCLES"):   # (a kernel whose waves are all resident from the start)
+        # a persistent kernel's waves should all live as long as the launch: the share of the launch a wave is resident
+        # (SQ_WAVE_CYCLES counts in units of 4 cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs); what is missing is the tail of the
+        # launch - the waves that got the cheap reads waiting for the one that got the expensive ones
+        out["wave_residency"] = round(c["SQ_WAVE_CYCLES"] * 4.0 / (c["SQ_WAVES"] * c["GRBM_GUI_ACTIVE"] / 8.0), 3)
     if c.get("SQ_LDS_IDX_ACTIVE"):
         out["lds_bank_conflict_frac"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
     if c.get("FETCH_SIZE") is not None and c.get("WRITE_SIZE") is not None:
@@ -624,7 +629,7 @@ def main():
                          "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                          "traffic": (None if traffic_dom is None else round(traffic_dom, 0)),
                          "hbm_frac": (d_dom or {}).get("hbm_frac"), "hbm_frac_lower": (d_dom or {}).get("hbm_frac_lower"), "issue_frac": (d_dom or {}).get("issue_frac"),
-                         "salu_frac": (d_dom or {}).get("salu_frac"), "wait_frac": (d_dom or {}).get("wait_frac"),
+                         "salu_frac": (d_dom or {}).get("salu_frac"), "wait_frac": (d_dom or {}).get("wait_frac"), "wave_residency": (d_dom or {}).get("wave_residency"),
                          "valu_lanes_of_64": (d_dom or {}).get("valu_lanes_of_64"), "l2_hit_rate": (d_dom or {}).get("l2_hit_rate"),
                          "kernel_ms_per_step": round(kseq[dom], 3), "algorithmic_bytes_per_read": round(per_launch[dom] / n_batch, 1),
                          "index_touch_bytes_per_read": round(index_touch / n_batch, 1),
@@ -651,7 +656,7 @@ def main():
                                   "below 0.5 and wait_frac >= 0.6). No kernel of this path is HBM bound: the nominal roofline (nominal_bound) is kept because "
                                   "the metric asks for it.",
                          "all_kernels": {k: dict({"ms_per_step": round(kseq[k], 3), "algorithmic_GBps": round(per_launch[k] / (kseq[k] * 1e-3) / 1e9, 2)},
-                                                 **({} if not der.get(k) else {m: der[k][m] for m in ("bound", "issue_frac", "salu_frac", "wait_frac", "hbm_frac", "hbm_frac_lower", "valu_lanes_of_64", "lds_bank_conflict_frac", "l2_hit_rate", "profiled_ms") if m in der[k]}))
+                                                 **({} if not der.get(k) else {m: der[k][m] for m in ("bound", "issue_frac", "salu_frac", "wait_frac", "wave_residency", "hbm_frac", "hbm_frac_lower", "valu_lanes_of_64", "lds_bank_conflict_frac", "l2_hit_rate", "profiled_ms") if m in der[k]}))
                                          for k in kseq if kseq[k] > 0},
                          "legacy_survey_A": {"bytes_per_read": SURVEY_A.get(L), "pipeline_GBps": (None if pipe_gbs is None else round(pipe_gbs, 2)),
                                              "note": "SURVEY.md 8(d) priced the whole path at A(L) assuming whole-bucket visits the engine does not perform (DESIGN.md 2): kept as a labelled legacy figure, not a fraction of anything"}},
