@@ -172,6 +172,8 @@ __global__ void __launch_bounds__(256) k_order_light(const uint64_t *__restrict_
     __shared__ uint8_t qof[MC_OL_READS * MC_BIN_LIGHT];            // the read (0 .. 63) of an LDS slot
     __shared__ uint32_t lpos[MC_OL_READS + 1], lhead[MC_OL_READS + 1], lcnt[MC_OL_READS];
     __shared__ uint8_t lmark[MC_OL_READS];
+    __shared__ uint32_t gmask[MC_OL_READS], rmask[MC_OL_READS];   // per read: which of its (ordered) HSPs is the first of its subject / of its run
+    static_assert(MC_BIN_LIGHT <= 32, "a segment's HSPs are bits of a word");
     const int lane = mc_lane(), wv = threadIdx.x >> 6;
     const uint32_t r0 = blockIdx.x * MC_OL_READS;
     if (wv == 0) {
@@ -183,6 +185,7 @@ __global__ void __launch_bounds__(256) k_order_light(const uint64_t *__restrict_
         const uint32_t m = light ? n : 0u, inc = mc_wave_scan_add(m);
         lpos[lane] = inc - m; lhead[lane] = a; lcnt[lane] = m;
         lmark[lane] = (light && low[r] != 0) ? 1 : 0;
+        gmask[lane] = 0; rmask[lane] = 0;
         if (lane == 63) { lpos[64] = inc; lhead[64] = a + n; }
     }
     __syncthreads();
@@ -230,28 +233,38 @@ __global__ void __launch_bounds__(256) k_order_light(const uint64_t *__restrict_
 #pragma unroll
     for (int it = 0; it < PER; it++) if (rto[it] != ~0u) { const uint32_t to = rto[it] >> 8; key[to] = rk[it]; plc[to] = rp[it]; sid[to] = (uint16_t)(rto[it] & 0xFFu); }   // (sid: now the HSP's position in its binned segment)
     __syncthreads();
-    // ... and a thread per marked read walks its HSPs in order: CalRes' stacks (mc_build_stacks, mc_finish.h) - of the consecutive
-    // HSPs of one place the best one, the subject's stack newest first, its size with the first record
-    if (threadIdx.x < MC_OL_READS && lmark[threadIdx.x]) {
-        const uint32_t q = threadIdx.x, n = lcnt[q], base = lpos[q], a = lhead[q];
-        uint32_t out = 0;
-        for (uint32_t gs = 0; gs < n;) {
-            const uint64_t sx = key[base + gs] >> 28;
-            uint32_t ge = gs + 1, kg = 1;
-            while (ge < n && (key[base + ge] >> 28) == sx) { kg += MC_PLACE_OF(plc[base + ge]) != MC_PLACE_OF(plc[base + ge - 1]) ? 1u : 0u; ge++; }
-            uint32_t run = 0;
-            for (uint32_t j = gs; j < ge; run++) {
-                uint32_t bestj = j, j2 = j + 1;
-                while (j2 < ge && MC_PLACE_OF(plc[base + j2]) == MC_PLACE_OF(plc[base + j])) { if (MC_SCORE_OF(plc[base + j2]) > MC_SCORE_OF(plc[base + bestj])) bestj = j2; j2++; }
-                const uint32_t o = a + out + kg - 1 - run;
-                order[o] = slots[a + sid[base + bestj]];
-                gsz[o] = run == kg - 1 ? kg : 0u;
-                j = j2;
-            }
-            out += kg; gs = ge;
-        }
-        nv[r0 + q] = out;
-        nrow_of[r0 + q] = 1u;
+    // ... and CalRes' stacks of the marked reads (mc_build_stacks, mc_finish.h): of the consecutive HSPs of one place - a RUN - the best
+    // one, a subject's runs newest first, the stack's size with its first record.  A thread per HSP (a thread per read walking its
+    // HSPs one after the other was 0.39 of the kernel's 1.02 ms per 2 M reads, and the other ordering kernels ran 0.3 ms longer beside
+    // it): every HSP marks in two words of its read whether it starts a subject and whether it starts a run - a segment has at most 32
+    // HSPs -, and the first HSP of every run reads everything it needs off those words with a few bit counts.
+    for (uint32_t at = threadIdx.x; at < T; at += 256) {
+        const uint32_t q = qof[at];
+        if (!lmark[q]) continue;
+        const uint32_t j = at - lpos[q];
+        const bool gh = j == 0 || (key[at] >> 28) != (key[at - 1] >> 28), rh = gh || MC_PLACE_OF(plc[at]) != MC_PLACE_OF(plc[at - 1]);
+        if (gh) atomicOr(&gmask[q], 1u << j);
+        if (rh) atomicOr(&rmask[q], 1u << j);
+    }
+    __syncthreads();
+    for (uint32_t at = threadIdx.x; at < T; at += 256) {
+        const uint32_t q = qof[at];
+        if (!lmark[q]) continue;
+        const uint32_t base = lpos[q], j = at - base, R = rmask[q];
+        if (!((R >> j) & 1u)) continue;                             // (not the first HSP of a run)
+        const uint32_t G = gmask[q], n = lcnt[q], a = lhead[q];
+        const uint32_t upto = (2u << j) - 1u;                      // bits 0 .. j
+        const uint32_t gs = 31u - (uint32_t)__builtin_clz(G & upto);             // the subject's first HSP (bit 0 is always set)
+        const uint32_t Ggt = G & ~upto, Rgt = R & ~upto;
+        const uint32_t ge = Ggt ? (uint32_t)__builtin_ctz(Ggt) : n, j2 = Rgt ? (uint32_t)__builtin_ctz(Rgt) : n;   // the next subject's / the next run's first HSP
+        const uint32_t lt_gs = (1u << gs) - 1u, lt_j = (1u << j) - 1u, lt_ge = ge >= 32u ? 0xFFFFFFFFu : (1u << ge) - 1u;
+        const uint32_t out = (uint32_t)__builtin_popcount(R & lt_gs), run = (uint32_t)__builtin_popcount(R & lt_j & ~lt_gs), kg = (uint32_t)__builtin_popcount(R & lt_ge & ~lt_gs);
+        uint32_t bestj = j;
+        for (uint32_t t = j + 1; t < j2; t++) if (MC_SCORE_OF(plc[base + t]) > MC_SCORE_OF(plc[base + bestj])) bestj = t;
+        const uint32_t o = a + out + kg - 1 - run;
+        order[o] = slots[a + sid[base + bestj]];
+        gsz[o] = run == kg - 1 ? kg : 0u;
+        if (j == 0) { nv[r0 + q] = (uint32_t)__builtin_popcount(R); nrow_of[r0 + q] = 1u; }
     }
 }
 // v[i] = the HSP that belongs at place i of the stacks (order[i]: its pool slot; ~0: nothing - the place of an unmarked read's HSP
