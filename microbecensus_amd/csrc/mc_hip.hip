@@ -587,15 +587,15 @@ static int stage_c(mc_handle *h, McCtx &c)
         // the long segments beside the short ones (the few segments of more than 512 HSPs are a long tail on a nearly empty GPU)
         uint32_t *heavy3 = heavy2 + c.cap_gaps / 2;
         k_order_lists<<<dim3((n + 255) / 256), dim3(256), 0, st>>>(c.d_heads, n, c.d_counters, heavy, heavy2, heavy3);
-        hipStream_t side = order_serial ? st : c.side;
-        if (!order_serial) { HIPCK(hipEventRecord(c.ev_fork, st)); HIPCK(hipStreamWaitEvent(c.side, c.ev_fork, 0)); }
+        hipStream_t side = order_serial ? st : c.side, side2 = order_serial ? st : c.side2;
+        if (!order_serial) { HIPCK(hipEventRecord(c.ev_fork, st)); HIPCK(hipStreamWaitEvent(c.side, c.ev_fork, 0)); HIPCK(hipStreamWaitEvent(c.side2, c.ev_fork, 0)); }
         HIPCK(hipFuncSetAttribute((const void *)k_order_heavy<1024, MC_ORDER_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MC_ORDER_LDS * 18)));
         k_order_heavy<1024, MC_ORDER_LDS><<<dim3(256u), dim3(1024), MC_ORDER_LDS * 18, side>>>(keys, c.d_places, slots, c.d_heads, heavy3, c.d_counters + C_ORDER3, c.d_counters + C_OTAKE3, c.d_low, order, c.d_gsz, c.d_nv, c.d_nrow, (uint64_t *)c.d_tmp);
-        k_order_heavy<256, MC_ORDER_MID><<<dim3(256u * 4u), dim3(256), MC_ORDER_MID * 18, side>>>(keys, c.d_places, slots, c.d_heads, heavy2, c.d_counters + C_ORDER2, c.d_counters + C_OTAKE2, c.d_low, order, c.d_gsz, c.d_nv, c.d_nrow, (uint64_t *)c.d_tmp);
-        if (!order_serial) HIPCK(hipEventRecord(c.ev_join, c.side));
+        k_order_heavy<256, MC_ORDER_MID><<<dim3(256u * 4u), dim3(256), MC_ORDER_MID * 18, side2>>>(keys, c.d_places, slots, c.d_heads, heavy2, c.d_counters + C_ORDER2, c.d_counters + C_OTAKE2, c.d_low, order, c.d_gsz, c.d_nv, c.d_nrow, (uint64_t *)c.d_tmp);
+        if (!order_serial) { HIPCK(hipEventRecord(c.ev_join, c.side)); HIPCK(hipEventRecord(c.ev_join2, c.side2)); }
         k_order_light<<<dim3((n + MC_OL_READS - 1) / MC_OL_READS), dim3(256), 0, st>>>(keys, c.d_places, slots, c.d_heads, n, c.d_low, order, c.d_gsz, c.d_nv, c.d_nrow);
         k_order_heavy<64, MC_ORDER_SMALL><<<dim3(256u * 16u), dim3(64), MC_ORDER_SMALL * 18, st>>>(keys, c.d_places, slots, c.d_heads, heavy, c.d_counters + C_ORDER, c.d_counters + C_OTAKE, c.d_low, order, c.d_gsz, c.d_nv, c.d_nrow, (uint64_t *)c.d_tmp);
-        if (!order_serial) HIPCK(hipStreamWaitEvent(st, c.ev_join, 0));
+        if (!order_serial) { HIPCK(hipStreamWaitEvent(st, c.ev_join, 0)); HIPCK(hipStreamWaitEvent(st, c.ev_join2, 0)); }
         k_order_copy<<<dim3(256u * 8u), dim3(256), 0, st>>>(order, c.d_gsz, c.d_hsps, c.d_heads, n, c.d_v);
         if (getenv("MC_BIN_STATS")) {                                  // (development aid: the sizes of the segments)
             std::vector<uint32_t> hh((size_t)n + 1);
