@@ -587,7 +587,7 @@ static int stage_c(mc_handle *h, McCtx &c)
         // the long segments beside the short ones (the few segments of more than 512 HSPs are a long tail on a nearly empty GPU)
         uint32_t *heavy3 = heavy2 + c.cap_gaps / 2;
         k_order_lists<<<dim3((n + 255) / 256), dim3(256), 0, st>>>(c.d_heads, n, c.d_counters, heavy, heavy2, heavy3);
-        hipStream_t side = order_serial ? st : c.side, side2 = order_serial ? st : c.side2;
+        hipStream_t side = order_serial ? st : c.side, side2 = order_serial ? st : h->best_only ? c.side : c.side2;   // (best hits only: few reads are ordered at all - a third stream only costs)
         if (!order_serial) { HIPCK(hipEventRecord(c.ev_fork, st)); HIPCK(hipStreamWaitEvent(c.side, c.ev_fork, 0)); HIPCK(hipStreamWaitEvent(c.side2, c.ev_fork, 0)); }
         HIPCK(hipFuncSetAttribute((const void *)k_order_heavy<1024, MC_ORDER_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MC_ORDER_LDS * 18)));
         k_order_heavy<1024, MC_ORDER_LDS><<<dim3(256u), dim3(1024), MC_ORDER_LDS * 18, side>>>(keys, c.d_places, slots, c.d_heads, heavy3, c.d_counters + C_ORDER3, c.d_counters + C_OTAKE3, c.d_low, order, c.d_gsz, c.d_nv, c.d_nrow, (uint64_t *)c.d_tmp);
