@@ -34,18 +34,16 @@ __global__ void __launch_bounds__(256) k_heavy_lists(const uint32_t *__restrict_
         if (!any) best_of[s].family = -1;
         else { const uint32_t n = nv[s]; cls = n > fh_min ? 4 : MC_LIGHT_CLASS(n); hc = n <= MC_FH_N1 ? 1 : n <= MC_FH_N2 ? 2 : 3; }
     }
-    const uint32_t o = mc_block_alloc(&counters[C_HEAVY], cls == 4);
-    if (cls == 4) heavy[o] = s;
-    // the heavy reads by the kernel whose arrays hold their stacks - known exactly now that the stacks are built before the finishing:
-    // the three kernels run side by side (they used to hand the reads that did not fit from one to the next)
-    { const uint32_t o1 = mc_block_alloc(&counters[C_HEAVY1], cls == 4 && hc == 1); if (cls == 4 && hc == 1) heavy1[o1] = o; }
-    { const uint32_t o2 = mc_block_alloc(&counters[C_HEAVY2], cls == 4 && hc == 2); if (cls == 4 && hc == 2) heavy2[o2] = o; }
-    { const uint32_t o3 = mc_block_alloc(&counters[C_HEAVY3], cls == 4 && hc == 3); if (cls == 4 && hc == 3) heavy3[o3] = o; }
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const uint32_t oc = mc_block_alloc(&counters[C_LIGHT0 + c], cls == c);
-        if (cls == c) light[(size_t)c * light_pitch + oc] = s;
-    }
+    // the heavy reads, and by the kernel whose arrays hold their stacks - known exactly now that the stacks are built before the finishing:
+    // the three kernels run side by side (they used to hand the reads that did not fit from one to the next); the light reads by size class
+    const int idx[8] = {C_HEAVY, C_HEAVY1, C_HEAVY2, C_HEAVY3, C_LIGHT0, C_LIGHT1, C_LIGHT2, C_LIGHT3};
+    const uint32_t wants = cls == 4 ? (1u | (1u << hc)) : cls >= 0 ? (1u << (4 + cls)) : 0u;
+    uint32_t off[8];
+    mc_block_alloc_multi<8>(counters, idx, wants, off);
+    if (cls == 4) {
+        heavy[off[0]] = s;
+        (hc == 1 ? heavy1 : hc == 2 ? heavy2 : heavy3)[off[hc]] = off[0];
+    } else if (cls >= 0) light[(size_t)cls * light_pitch + off[4 + cls]] = s;
 }
 
 // One thread per marked read.  All scratch is addressed by the read's offset into the binned HSPs (heads; a read never produces
@@ -508,7 +506,8 @@ __global__ void __launch_bounds__(256) k_emit_rows(const uint32_t *__restrict__ 
             for (uint32_t i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
         }
     }
-    (void)mc_block_alloc(&counters[C_SEGS], nr > 0);
-    const uint32_t o = mc_block_alloc(&counters[C_BEST], bh.family >= 0);
-    if (bh.family >= 0) best[o] = bh;
+    const int idx[2] = {C_SEGS, C_BEST};
+    uint32_t off[2];
+    mc_block_alloc_multi<2>(counters, idx, (nr > 0 ? 1u : 0u) | (bh.family >= 0 ? 2u : 0u), off);
+    if (bh.family >= 0) best[off[1]] = bh;
 }

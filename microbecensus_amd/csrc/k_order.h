@@ -156,12 +156,12 @@ __global__ void __launch_bounds__(256) k_order_lists(const uint32_t *__restrict_
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     const uint32_t n = r < nreads ? heads[r + 1] - heads[r] : 0u;
     const bool c1 = n > MC_BIN_LIGHT && n <= MC_ORDER_SMALL, c2 = n > MC_ORDER_SMALL && n <= MC_ORDER_MID, c3 = n > MC_ORDER_MID;
-    const uint32_t o = mc_block_alloc(&counters[C_ORDER], c1);
-    if (c1) heavy[o] = r;
-    const uint32_t o2 = mc_block_alloc(&counters[C_ORDER2], c2);
-    if (c2) heavy2[o2] = r;
-    const uint32_t o3 = mc_block_alloc(&counters[C_ORDER3], c3);
-    if (c3) heavy3[o3] = r;
+    const int idx[3] = {C_ORDER, C_ORDER2, C_ORDER3};
+    uint32_t off[3];
+    mc_block_alloc_multi<3>(counters, idx, (c1 ? 1u : 0u) | (c2 ? 2u : 0u) | (c3 ? 4u : 0u), off);
+    if (c1) heavy[off[0]] = r;
+    if (c2) heavy2[off[1]] = r;
+    if (c3) heavy3[off[2]] = r;
 }
 #define MC_KEY43 ((1ull << 43) - 1)
 __global__ void __launch_bounds__(256) k_order_light(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ places, const uint32_t *__restrict__ slots, const uint32_t *__restrict__ heads, uint32_t nreads,

@@ -93,6 +93,36 @@ __device__ __forceinline__ uint32_t mc_block_alloc(uint32_t *counter, bool want)
     return r;
 }
 
+// ... and slots of up to 8 counters at once (every thread of the 256-thread block calls it; bit k of `wants`: the thread takes a slot of
+// counters[idx[k]], returned in off[k]): the N atomics of a workgroup travel together - called one after the other every one of
+// them is a trip to the memory side that the whole workgroup waits for at a barrier (k_heavy_lists made eight of them).
+template <int N>
+__device__ __forceinline__ void mc_block_alloc_multi(uint32_t *counters, const int *idx, uint32_t wants, uint32_t (&off)[N])
+{
+    static_assert(N <= 8, "eight counters at most");
+    __shared__ uint32_t wcnt[4][8], wbase[4][8];
+    const int lane = mc_lane(), wv = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1;
+    uint32_t rank[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const unsigned long long m = __ballot((wants >> k) & 1u);
+        rank[k] = (uint32_t)__popcll(m & lt);
+        if (lane == 0) wcnt[wv][k] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        const int k = threadIdx.x;
+        const uint32_t c0 = wcnt[0][k], c1 = wcnt[1][k], c2 = wcnt[2][k], c3 = wcnt[3][k], tot = c0 + c1 + c2 + c3;
+        const uint32_t b = tot ? atomicAdd(&counters[idx[k]], tot) : 0u;
+        wbase[0][k] = b; wbase[1][k] = b + c0; wbase[2][k] = b + c0 + c1; wbase[3][k] = b + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; k++) off[k] = wbase[wv][k] + rank[k];
+    __syncthreads();                                             // (the arrays are reused by the next call)
+}
+
 // copies the hot members of the tables into LDS (block-wide; callers __syncthreads() afterwards)
 __device__ __forceinline__ void mc_load_hot(McHot *H, const McTables *T)
 {
