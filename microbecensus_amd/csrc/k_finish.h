@@ -14,7 +14,7 @@
 // -> finishing 2.36 / 2.64 / 2.65 / 3.80 ms with rows, 2.38 / 1.43 / 1.41 / 1.42 ms with best hits only)
 #ifndef MC_FH_N1          // (a test builds the library with small arrays so that ordinary reads take the paths of the largest ones)
 #define MC_FH_N1 512      // subjects / ranked HSPs a read may have in the first wave kernel (11 KB of LDS per wave) ...
-#define MC_FH_N2 2048     // ... in the second (45 KB) ...
+#define MC_FH_N2 1280     // ... in the second (28 KB: five waves per CU; 2048 - 45 KB, three waves - finished 0.1 ms per 2 M reads later) ...
 #define MC_FH_N3 6144     // ... and in the third (135 KB, one wave per CU), where anything larger is finished by lane 0 alone
 #endif
 

@@ -637,7 +637,8 @@ static int stage_d(mc_handle *h, McCtx &c)
             HIPCK(hipStreamWaitEvent(c.side, c.ev_fork, 0));
             HIPCK(hipStreamWaitEvent(c.side2, c.ev_fork, 0));
             // the two kernels of the larger reads (few reads, long chains, a fraction of the GPU) beside the first one
-            k_finish_heavy<MC_FH_N2, C_HEAVY2, -1><<<dim3(256 * 3), dim3(64), l2, c.side2>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
+            const unsigned wpc2 = (unsigned)std::min<size_t>(8, std::max<size_t>(1, (size_t)(158 * 1024) / (l2 + 1024)));   // waves per CU the LDS holds
+            k_finish_heavy<MC_FH_N2, C_HEAVY2, -1><<<dim3(256 * wpc2), dim3(64), l2, c.side2>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
                                                                                             c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy2, nullptr);
             k_finish_heavy<MC_FH_N3, C_HEAVY3, -1><<<dim3(256), dim3(64), l3, c.side2>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
                                                                                          c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy3, nullptr);
