@@ -238,7 +238,14 @@ __global__ void __launch_bounds__(1024) k_heap_order(const uint32_t *__restrict_
     };
     for (uint32_t slot = threadIdx.x; slot < nheavy; slot += 1024) atomicAdd(&bin[key(slot)], 1u);
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t run = 0; for (int k = MC_MAX_M8; k >= 0; k--) { const uint32_t c = bin[k]; bin[k] = run; run += c; } }
+    {   // bin[k]: the reads with k rows -> the place of the first of them, the largest k first (a scan over the 501 bins by 512 threads)
+        __shared__ uint32_t sc[512];
+        const uint32_t t = threadIdx.x, mine = t <= MC_MAX_M8 ? bin[MC_MAX_M8 - t] : 0u;
+        if (t < 512) sc[t] = mine;
+        __syncthreads();
+        for (uint32_t d = 1; d < 512; d <<= 1) { const uint32_t y = (t < 512 && t >= d) ? sc[t - d] : 0u; __syncthreads(); if (t < 512) sc[t] += y; __syncthreads(); }
+        if (t <= MC_MAX_M8) bin[MC_MAX_M8 - t] = sc[t] - mine;
+    }
     __syncthreads();
     for (uint32_t slot = threadIdx.x; slot < nheavy; slot += 1024) order[atomicAdd(&bin[key(slot)], 1u)] = slot;
 }
