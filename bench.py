@@ -33,6 +33,8 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+import microbecensus_amd  # noqa: E402
+microbecensus_amd.configure_process_env()     # bench.py owns its process (and its ranks inherit the environment): GPU_MAX_HW_QUEUES=8 unless set
 
 METRIC = "reads/sec searched vs marker DB + AGS abs-error, 150 bp @ 1/2/4/8 GPU"
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec

@@ -148,6 +148,7 @@ __device__ unsigned long long g_ev_acc[8];           // wave time per phase, sum
 #ifndef MC_EV_GROUP
 #define MC_EV_GROUP 16u      // chunks of 64 hits a wave takes at a time (one global atomic per group)
 #endif
+static_assert(MC_EV_GROUP >= 2, "the next group is asked for while the last but one chunk of a group is evaluated (cleft == 1): with one chunk per group no request is ever made and every wave would walk the same hits");
 // n consecutive slots for the wave's lanes (lane with rank r < n gets one; n is the same for every lane): from the wave's current
 // block of the pool, continued in a new block when that one is full.  *ok = false after a pool overflow.
 __device__ __forceinline__ uint32_t mc_ev_slots(uint32_t n, uint32_t r, uint32_t cap, uint32_t *counter, uint32_t &blk_base, uint32_t &blk_used, bool *ok, int lane)

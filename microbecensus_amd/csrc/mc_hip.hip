@@ -97,10 +97,10 @@ template <class Tp> static int dalloc(Tp **p, size_t n)
     return 0;
 }
 
-// Eight hardware queues for the process instead of HIP's four (see open_impl: streams that share a queue wait for each other): set
-// when the library is loaded - it takes effect if the HIP runtime has not been initialised yet (it reads its settings at the first
-// HIP call), and never overrides what the environment says.
-__attribute__((constructor)) static void mc_hip_init_env() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// (Rounds 3 - 4 had a load-time constructor here that exported GPU_MAX_HW_QUEUES=8: a process-wide side effect on every other HIP
+// user of the host application, dependent on load order, and a setenv() that races with getenv() in other threads - ADVICE r04.  The
+// library no longer touches the environment; the entry points that own their process - scripts/*, bench.py, the tests - set the
+// variable before anything initialises HIP, and INTEGRATION.md section 3 tells an embedding application to do the same.)
 
 extern "C" int mc_device_count(void)
 {
@@ -189,7 +189,8 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
     // (the handle's), one for the rows on their way to the host, one for the
     // uploads of the streaming calls.  HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the environment
     // says otherwise) and streams that share one wait for each other: with nine streams the front of a range could land behind the
-    // 5 ms copy of the rows of the range before (measured: 51.2 instead of 53.6 M reads/s) - hence few streams, and mc_hip_init_env().
+    // 5 ms copy of the rows of the range before (measured: 51.2 instead of 53.6 M reads/s) - hence few streams, and GPU_MAX_HW_QUEUES=8
+    // exported by the entry points (microbecensus_amd.configure_process_env(); never by this library).
     HIPCK(hipStreamCreate(&h->side)); HIPCK(hipStreamCreate(&h->side2));
     for (McCtx &c : h->ctx) {
         HIPCK(hipStreamCreate(&c.stream)); c.side = h->side; c.side2 = h->side2;
@@ -252,6 +253,14 @@ extern "C" int mc_index_cache_check(const char *const *names, const char *const 
           (A.rec.empty() || memcmp(A.rec.data(), B.rec.data(), A.rec.size() * sizeof(McBucketRec)) == 0) && A.rt_mask == B.rt_mask && A.max_bucket == B.max_bucket &&
           A.freq_thr == B.freq_thr && A.nres == B.nres && A.nseq == B.nseq && memcmp(A.letter_p, B.letter_p, sizeof A.letter_p) == 0)) { g_err = "the index read back differs from the one built"; return 2; }
     if (mc_index_load(C2, ih ^ 1, nseq, path.c_str())) { g_err = "a file of other sequences was accepted"; return 3; }
+    if (!mc_index_matches_input(B, names, seqs, nseq)) { g_err = "the index read back does not pass the input comparison"; return 6; }
+    {   // what the checksum cannot see: a well-formed file that is not the index of these sequences (a hash collision, a stale layout)
+        McHostIndex D = B;
+        if (D.nres > 0) { D.res[(size_t)D.nres / 2] ^= 1; if (mc_index_matches_input(D, names, seqs, nseq)) { g_err = "an index with another residue was accepted"; return 7; } D.res[(size_t)D.nres / 2] ^= 1; }
+        if (!D.post.empty()) { const uint32_t keep = D.post[D.post.size() / 2]; D.post[D.post.size() / 2] = ((uint32_t)nseq << 11); if (mc_index_matches_input(D, names, seqs, nseq)) { g_err = "a posting outside the database was accepted"; return 8; } D.post[D.post.size() / 2] = keep; }
+        if (!D.rec.empty()) { D.rec[D.rec.size() / 3].start += 1; if (mc_index_matches_input(D, names, seqs, nseq)) { g_err = "a bucket record outside its bucket was accepted"; return 9; } D.rec[D.rec.size() / 3].start -= 1; }
+        if (nseq > 1) { std::vector<const char *> nm2(names, names + nseq); std::swap(nm2[0], nm2[1]); if (mc_index_matches_input(D, nm2.data(), seqs, nseq)) { g_err = "other marker names were accepted"; return 10; } }
+    }
     {   // one byte of the payload flipped: the checksum must notice
         FILE *f = fopen(path.c_str(), "r+b");
         if (!f) { g_err = "cannot reopen " + path; return -1; }
@@ -279,6 +288,7 @@ extern "C" mc_handle *mc_open(const char *const *names, const char *const *seqs,
         char nm[64]; snprintf(nm, sizeof nm, "/index_%016llx.mcix", (unsigned long long)ih);
         cache += nm;
         loaded = mc_index_load(h->H, ih, nseq, cache.c_str());
+        if (loaded && !mc_index_matches_input(h->H, names, seqs, nseq)) { loaded = false; h->H = McHostIndex(); }   // (not the index of THESE sequences, or offsets out of range: rebuilt)
         MC_OT(loaded ? "index cache: loaded" : "index cache: none / not usable", t0);
     }
     if (!loaded) {

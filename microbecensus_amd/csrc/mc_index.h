@@ -486,6 +486,49 @@ inline bool mc_index_load(McHostIndex &X, uint64_t input_hash, int nseq, const c
     return true;
 }
 
+// A loaded index is only as good as the file it came from: a hash collision of the 64-bit input hash, a forgotten MC_IXC_VERSION bump
+// or a foreign file in MC_INDEX_CACHE=<dir> would hand the kernels arrays they index unchecked.  So after a load the
+// names and residues are compared with what the caller gave (cheap: 3.7 MB), and every offset the kernels follow is range-checked:
+// off[] ascending to nres, bstart[] ascending to post.size(), every posting inside its sequence, every bucket record inside its bucket,
+// the sizes of the fixed-size structures.  Anything off: the file is ignored and the index rebuilt.
+inline bool mc_index_matches_input(const McHostIndex &X, const char *const *names, const char *const *seqs, int nseq)
+{
+    if (X.nseq != nseq || (int)X.names.size() != nseq || X.off.size() != (size_t)nseq + 1 || X.off[0] != 0) return false;
+    if (X.res.size() != (size_t)X.nres || X.res_code.size() != X.res.size() || X.off[(size_t)nseq] != (uint32_t)X.nres) return false;
+    for (int s = 0; s < nseq; s++) {
+        if (X.names[(size_t)s] != names[s]) return false;
+        const size_t l = strlen(seqs[s]);
+        if (l >= 2048 || X.off[(size_t)s] > X.off[(size_t)s + 1] || X.off[(size_t)s + 1] - X.off[(size_t)s] != (uint32_t)l) return false;
+        const uint8_t *r = &X.res[X.off[(size_t)s]], *rc = &X.res_code[X.off[(size_t)s]];
+        for (size_t k = 0; k < l; k++) if (r[k] != (uint8_t)mc_dense_of_char((unsigned char)seqs[s][k]) || rc[k] != (uint8_t)mc_code_of_char((unsigned char)seqs[s][k])) return false;
+    }
+    if (X.bstart.size() != (size_t)MC_NBUCKET + 1 || X.bstart[0] != 0 || X.bstart[MC_NBUCKET] != X.post.size()) return false;
+    if (X.keys.size() != X.post.size() + 64 || X.bitmap.size() != (size_t)(MC_NBUCKET + 31) / 32) return false;
+    uint32_t maxb = 0;
+    for (int b = 0; b < MC_NBUCKET; b++) {
+        if (X.bstart[(size_t)b] > X.bstart[(size_t)b + 1]) return false;
+        const uint32_t n = X.bstart[(size_t)b + 1] - X.bstart[(size_t)b];
+        if (n > maxb) maxb = n;
+        if ((((X.bitmap[(size_t)b >> 5] >> (b & 31)) & 1u) != 0) != (n != 0)) return false;
+    }
+    if (maxb != X.max_bucket) return false;
+    for (size_t i = 0; i < X.post.size(); i++) {
+        const uint32_t sq = X.post[i] >> 11, pos = X.post[i] & 0x7ffu;
+        if (sq >= (uint32_t)nseq || pos + 6 >= X.off[(size_t)sq + 1] - X.off[(size_t)sq]) return false;
+    }
+    if (!X.rec.empty()) {
+        if (X.rec.size() != (size_t)MC_NBUCKET) return false;
+        for (int b = 0; b < MC_NBUCKET; b++) {
+            const McBucketRec &R = X.rec[(size_t)b];
+            if (R.start != X.bstart[(size_t)b] || R.cum[0] != 0 || R.cum[11] != X.bstart[(size_t)b + 1] - X.bstart[(size_t)b]) return false;
+            for (int k = 0; k < 11; k++) if (R.cum[k] > R.cum[k + 1]) return false;
+        }
+    }
+    if (X.filt.size() != (size_t)MC_FILT9_WORDS || X.wild.size() != (size_t)MC_WILD_LINES * 8 || X.pair.size() != (size_t)MC_PAIR_BLOCKS * 4) return false;
+    if (X.rt.size() != (size_t)X.rt_mask + 1 || (X.rt_mask & (X.rt_mask + 1)) != 0) return false;
+    return true;
+}
+
 // Proof obligation of mc_seg_mask_fx: for every composition a window of W residues can have (every partition of every
 // t <= W), the integer tests must decide like Seg::entropy_cal's doubles.  Returns the number of disagreements (0).
 inline int mc_seg_fx_verify(const McTables &T, double *min_margin)

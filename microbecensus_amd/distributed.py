@@ -140,6 +140,18 @@ class _Dealer:
         with self.lock:
             self.local_credit += 1
 
+    @staticmethod
+    def _check_peers(store, world):
+        """A rank whose receiver failed (a broken recv, a store error) says so under the key x<rank>: the stream ends for
+        everybody - that rank returns no more credits, and a batch dealt to it would never be matched."""
+        for w in range(1, world):
+            try:
+                dead = store.check(["x%d" % w])
+            except Exception:                                       # noqa: BLE001 - a store without check(): nothing to look at
+                return
+            if dead:
+                raise RuntimeError("rank %d failed while receiving its batches" % w)
+
     def _run(self):
         import ctypes as C
         import threading
@@ -163,6 +175,7 @@ class _Dealer:
             at, k = 0, 0
             while True:
                 i = k % NB
+                self._check_peers(store, world)
                 if pending[i] is not None:
                     for w in pending[i]:
                         w.wait()
@@ -177,7 +190,7 @@ class _Dealer:
                     raise _SamplerError(lib.mc_reader_last_error().decode(), n)
                 if n == 0:
                     break
-                dst = -1
+                dst, polls = -1, 0
                 while dst < 0:                                      # the next free rank, in turn
                     for j in range(1, world + 1):
                         w = (last + j) % world
@@ -191,18 +204,24 @@ class _Dealer:
                             break
                     if dst < 0:
                         time.sleep(0.0005)
+                        polls += 1
+                        if polls % 2000 == 0:                       # (once a second while nobody is free)
+                            self._check_peers(store, world)
                 last = dst
                 if dst == 0:                                       # rank 0's own batch: searched from the pinned buffer, which comes back with the event
                     done = threading.Event()
                     self.q.put((bufs[i][: n * L].numpy().reshape(n, L), at, done))
                     pending[i] = [done]
                 else:
-                    store.set("h%d/%d" % (dst, sent[dst]), "%d,%d" % (n, at))
                     payload = bufs[i][: n * L]
                     if self.nccl:
                         stage[i][: n * L].copy_(payload, non_blocking=True)
                         payload = stage[i][: n * L]
+                    # The payload is posted BEFORE its header is written: a rank that has read a header always finds its batch on
+                    # the way, and if staging or isend fails no header exists - the end marker below lands on the very key the
+                    # rank is waiting for (header first, then a failure, left the receiver in recv for ever).
                     pending[i] = [dist.isend(payload, dst)]
+                    store.set("h%d/%d" % (dst, sent[dst]), "%d,%d" % (n, at))
                     sent[dst] += 1
                 self.trace.append(("deal", k, t1, time.time(), dst))
                 at += n
@@ -250,20 +269,27 @@ def _receive_batches(read_len, nccl, dev, q, store, rank):
     busy = [None, None]                                             # the event the searching thread sets when it is done with buffer i
     store.add("c%d" % rank, 2)
     j = 0
-    while True:
-        n, first = [int(v) for v in _store_wait_get(store, "h%d/%d" % (rank, j)).decode().split(",")]
-        j += 1
-        if n <= 0:
-            q.put(None)
-            if n < 0:
-                raise Exception("the sampler on rank 0 failed")
-            return first
-        i = 0 if (busy[0] is None or busy[0].is_set()) else 1       # (rank 0 deals only against credits: a buffer is free)
-        dist.recv(bufs[i][: n * L], 0)
-        if nccl:
-            torch.cuda.current_stream(dev).synchronize()            # the engine launches on its own streams: the batch must have landed
-        busy[i] = threading.Event()
-        q.put((bufs[i][: n * L], first, busy[i]))
+    try:
+        while True:
+            key = "h%d/%d" % (rank, j)
+            n, first = [int(v) for v in _store_wait_get(store, key).decode().split(",")]
+            try:
+                store.delete_key(key)                               # (consumed: the store does not grow with the library)
+            except Exception:                                       # noqa: BLE001 - a store without delete_key (FileStore of old versions)
+                pass
+            j += 1
+            if n <= 0:
+                if n < 0:
+                    raise Exception("the sampler on rank 0 failed")
+                return first
+            i = 0 if (busy[0] is None or busy[0].is_set()) else 1   # (rank 0 deals only against credits: a buffer is free)
+            dist.recv(bufs[i][: n * L], 0)
+            if nccl:
+                torch.cuda.current_stream(dev).synchronize()        # the engine launches on its own streams: the batch must have landed
+            busy[i] = threading.Event()
+            q.put((bufs[i][: n * L], first, busy[i]))
+    finally:
+        q.put(None)                                                 # whatever happened here, the searching thread ends (it waited in q.get() for ever)
 
 
 def stream_batches(reader, read_len, on_batch, device=None):
@@ -325,8 +351,13 @@ def stream_batches(reader, read_len, on_batch, device=None):
         worker.start()
         try:
             _receive_batches(read_len, nccl, dev, q, store, rank)
-        except Exception:
-            pass                                                   # rank 0 broadcasts what happened
+        except Exception as e:                                     # noqa: BLE001 - "the sampler on rank 0 failed": rank 0 broadcasts what happened;
+            if "sampler on rank 0" not in str(e):                  # anything else (a failed recv, a store error) is THIS rank's error and travels
+                errs.append(e)                                     # with the flags below, so that all ranks raise together; rank 0 stops dealing
+                try:
+                    store.set("x%d" % rank, "1")
+                except Exception:                                  # noqa: BLE001
+                    pass
         worker.join()
     # every rank learns how the stream ended AND whether any rank failed while searching: all raise together (a rank that raised
     # alone left the others waiting in the all_reduce)
@@ -375,7 +406,9 @@ def stream_batches_sharded(args, on_batch, device=None):
     beside the search of this one.
     Returns (n_total, stats, bases, status): stats = the reference's counters (records met before the head-take ended), bases =
     count_bases() when every file was read to its end (else -1), status 0, or 1 = a window did not end on a record boundary
-    (multi-line FASTQ whose qualities look like headers) or a rank failed: the caller falls back to the sampler on rank 0."""
+    (multi-line FASTQ whose qualities look like headers): the caller falls back to the sampler on rank 0; 2 = a rank failed
+    (its sampler raised, or on_batch - the search - did): stats then carries the agreed message under "error" and the caller
+    raises on every rank instead of searching everything a second time."""
     import os
     import threading
     import numpy as np
@@ -424,14 +457,15 @@ def stream_batches_sharded(args, on_batch, device=None):
         th, box, (p, lo, hi) = cur
         th.join()
         cur = sample(j + 1, nreads - total) if j + 1 < len(rounds) else None      # (an upper bound of what is still wanted: total only grows)
-        bad = 1 if ("err" in box or (box.get("st") or {}).get("ragged_end")) else 0
+        bad = 2 if "err" in box else 1 if (box.get("st") or {}).get("ragged_end") else 0
         n_acc = 0 if bad else int(box["n"])
         mine = torch.tensor([n_acc, bad], dtype=torch.int64, device=tdev)
         allc = [torch.zeros(2, dtype=torch.int64, device=tdev) for _ in range(world)]
         dist.all_gather(allc, mine)
         counts = [int(t[0].item()) for t in allc]
-        if any(int(t[1].item()) for t in allc):
-            status = 1
+        worst = max(int(t[1].item()) for t in allc)
+        if worst:
+            status = worst                                         # 1: a ragged window (fall back); 2: a rank's sampler raised
             err = box.get("err")
         else:
             prefix = total + sum(counts[:rank])
@@ -459,7 +493,7 @@ def stream_batches_sharded(args, on_batch, device=None):
         flag = torch.tensor([1 if err is not None else 0], dtype=torch.int64, device=tdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()):
-            status = 1
+            status = 2
         if status or cut:
             break
     if cur is not None:                                            # a round sampled ahead and not needed
@@ -472,14 +506,20 @@ def stream_batches_sharded(args, on_batch, device=None):
         stats[k] = int(v)
     n_total = min(total, nreads)
     bases = stats["bases"] if (status == 0 and not cut) else -1
+    if status == 2:                                                # every rank learns what went wrong where (the first failing rank's message)
+        msgs = [None] * world
+        dist.all_gather_object(msgs, "" if err is None else "rank %d: %s: %s" % (rank, type(err).__name__, err))
+        stats["error"] = next((m for m in msgs if m), "a rank failed")
     return n_total, stats, bases, status
 
 
 def run_pipeline_distributed(args, device=None):
     """run_pipeline() over all ranks of the initialised torch.distributed group (one process per GPU; backend "nccl" = RCCL
-    on MI355X, or gloo), STREAMED: rank 0 runs the (sequential, deterministic) sampler on a thread of its own and deals
-    batches of 2 M accepted reads round-robin to the ranks as they appear (_Dealer; RCCL: pinned host -> GPU staging -> xGMI);
-    every rank searches the batches it is dealt with global read ids while the next one arrives; the per-family integer
+    on MI355X, or gloo), STREAMED.  Plain files without -d: a sampler on EVERY rank (stream_batches_sharded: byte windows of
+    the files, the head-take agreed on by a prefix sum of the accepted counts).  Compressed inputs, -d, or a window that does not
+    end on a record boundary: rank 0 runs the (sequential, deterministic) sampler on a thread of its own and deals batches of
+    2 M accepted reads to whichever rank holds a credit (_Dealer; RCCL: pinned host -> GPU staging -> xGMI).  Either way
+    every rank searches the batches it gets with global read ids while the next one arrives; the per-family integer
     accumulators are summed with ONE all_reduce at the end, and every rank finishes the estimate from the same sums.  Peak
     memory per rank is two batches, whatever the size of the library.  Returns (est_ags, args) like run_pipeline; hits are
     integers and the 'cov' sums are finished from exact integer sums, so the result does not depend on the number of ranks
@@ -537,7 +577,9 @@ def run_pipeline_distributed(args, device=None):
                 sharded = stream_batches_sharded(args, on_batch, device=device)
             finally:
                 eng.lib.mc_set_keep_rows(eng.h, 1)
-            if sharded[3] != 0:                                                # a window off a record boundary, or a rank failed: the sampler on rank 0 decides
+            if sharded[3] == 2:                                                # a rank failed (sampler or search): all ranks raise the same error
+                raise RuntimeError("sharded sampling failed - " + sharded[1].get("error", ""))
+            if sharded[3] != 0:                                                # a window off a record boundary: the sampler on rank 0 decides
                 sharded = None
                 del parts[:]
                 eng.lib.mc_set_keep_rows(eng.h, 0)

@@ -6,6 +6,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import microbecensus_amd  # noqa: E402
+microbecensus_amd.configure_process_env()     # this program owns its process: eight HIP hardware queues, before anything touches the GPU
 from microbecensus_amd import microbe_census  # noqa: E402
 
 

@@ -6,6 +6,8 @@ import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+import microbecensus_amd  # noqa: E402
+microbecensus_amd.configure_process_env()     # the test process is ours (child processes inherit it): see the function's docstring
 
 
 def pytest_configure(config):

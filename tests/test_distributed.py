@@ -198,3 +198,63 @@ def test_every_rank_samples_its_own_slices(tmp_path, world):
             assert r["stats"][k] == st[k], (name, k, r["stats"], st)
         assert r["bases"] == (st["bases"] if st["exhausted"] else -1) or (r["bases"] == -1 and st["sampled"] == a["nreads"]), (name, r["bases"], st)
         assert sum(1 for per_rank in r["batches"] if per_rank) >= min(world, 2), name      # (more than one rank sampled something)
+
+
+FAIL_WORKER = r'''
+import json, os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from microbecensus_amd import distributed as D, _native
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+a = json.load(open(sys.argv[2]))
+out = {}
+calls = [0]
+def on_batch(block, first):
+    calls[0] += 1
+    if rank == 1 and calls[0] == 2:
+        raise ValueError("search blew up on rank 1")
+# (1) a sampler on every rank, the search of one rank fails: status 2 and ONE message on every rank - no silent second search
+n_total, stats, bases, status = D.stream_batches_sharded(a, on_batch)
+out["sharded"] = {"status": status, "error": stats.get("error")}
+# (2) batches dealt by rank 0, the search of rank 1 fails at its second batch: every rank is handed the error, nobody waits for ever
+calls[0] = 0
+rd = None
+if rank == 0:
+    rd = _native.Reader(a["seqfiles"], a["read_length"], a["nreads"], False, 0, -5, -5, 100, False)
+n_total, trace, err = D.stream_batches(rd, a["read_length"], on_batch)
+if rd is not None:
+    rd.close()
+out["dealt"] = {"err": None if err is None else str(err)}
+allo = [None] * world
+dist.all_gather_object(allo, out)
+if rank == 0:
+    json.dump(allo, open(sys.argv[3], "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_a_failing_rank_is_agreed_on_by_all(tmp_path):
+    """ADVICE r04: (a) stream_batches_sharded tells a failed rank (status 2 + the first failing rank's message, the same on every
+    rank) from a ragged window (status 1: the only case run_pipeline_distributed falls back for); (b) stream_batches with a rank
+    whose search raises ends on every rank with that error - the receiver's sentinel always reaches its searching thread."""
+    import gzip
+    plain = str(tmp_path / "metagenome.fa")
+    open(plain, "wb").write(gzip.open(os.path.join(GOLD, "inputs", "metagenome.fa.gz"), "rb").read())
+    a = {"min_quality": -5, "mean_quality": -5, "max_unknown": 100, "filter_dups": False, "seqfiles": [plain], "read_length": 100,
+         "nreads": 10**9, "file_type": "fasta", "quality_offset": None}
+    cj = tmp_path / "case.json"
+    cj.write_text(json.dumps(a))
+    worker = tmp_path / "fail.py"
+    worker.write_text(FAIL_WORKER)
+    out = tmp_path / "fail.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MC_DIST_SLICE="150000", MC_DIST_BATCH="2000")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29531", str(worker), REPO, str(cj), str(out)], env=env, timeout=600)
+    res = json.load(open(out))
+    assert len(res) == 2
+    for r in res:
+        assert r["sharded"]["status"] == 2 and "rank 1" in r["sharded"]["error"] and "search blew up" in r["sharded"]["error"], r
+        assert r["dealt"]["err"] and "search blew up" in r["dealt"]["err"] or "failed while searching" in (r["dealt"]["err"] or ""), r

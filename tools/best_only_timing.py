@@ -4,6 +4,7 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import microbecensus_amd; microbecensus_amd.configure_process_env()
 from microbecensus_amd import _native, synth
 
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 150

@@ -8,6 +8,7 @@ sys.path.insert(0, REPO)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 import bench
+import microbecensus_amd; microbecensus_amd.configure_process_env()
 from microbecensus_amd import synth
 gen = synth.GenomeReads(device="cpu", seed=20261001)
 td = tempfile.mkdtemp(prefix="mc_cold_")

@@ -4,6 +4,7 @@ import hashlib, os, subprocess, sys, tempfile, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import numpy as np
+import microbecensus_amd; microbecensus_amd.configure_process_env()
 from microbecensus_amd import _native, synth
 
 n150 = int(sys.argv[1]) if len(sys.argv) > 1 else 200000

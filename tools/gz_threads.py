@@ -4,6 +4,7 @@ import contextlib, io, os, subprocess, sys, tempfile, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import bench
+import microbecensus_amd; microbecensus_amd.configure_process_env()
 from microbecensus_amd import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 gen = synth.GenomeReads(device="cpu", seed=20261001)

@@ -1,6 +1,7 @@
 import sys, time
 sys.path.insert(0, "/root/repo")
 t0 = time.time()
+import microbecensus_amd; microbecensus_amd.configure_process_env()
 from microbecensus_amd import _native
 t1 = time.time()
 model = _native.load_model()

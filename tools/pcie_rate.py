@@ -2,6 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import microbecensus_amd; microbecensus_amd.configure_process_env()
 from microbecensus_amd import _native, synth
 names, seqs = _native.load_markers(); model = _native.load_model(); fams = model["families"]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000

@@ -7,6 +7,7 @@ import time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import torch
+import microbecensus_amd; microbecensus_amd.configure_process_env()
 from microbecensus_amd import _native, synth
 from microbecensus_amd import microbe_census as mc
 import bench

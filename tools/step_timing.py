@@ -3,6 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
+import microbecensus_amd; microbecensus_amd.configure_process_env()
 from microbecensus_amd import _native, synth
 names, seqs = _native.load_markers(); model = _native.load_model(); fams = model["families"]
 eng = _native.Engine(device=0); L_ = int(sys.argv[2]) if len(sys.argv) > 2 else 150

@@ -4,6 +4,7 @@ against a single handle with two parts.  python tools/two_engines.py [reads_per_
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import microbecensus_amd; microbecensus_amd.configure_process_env()
 from microbecensus_amd import _native, synth
 import torch
 model = _native.load_model(); fams = model["families"]
