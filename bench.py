@@ -152,9 +152,12 @@ def derived(prof, stage):
     issue_frac = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles) - a wave64 VALU instruction holds its SIMD for 4 cycles;
     salu_frac = SQ_INSTS_SALU / (256 scalar units x kernel cycles) - one scalar issue per CU and cycle (the two run side by side, so
     they are NOT added); kernel cycles = duration x 2.4 GHz (the peak clock: the fractions are lower bounds); wait_frac = SQ_WAIT_ANY /
-    SQ_WAVE_CYCLES; lanes = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64); hbm_bytes = factor x FETCH_SIZE + WRITE_SIZE (KiB as
-    rocprofv3 reports them; factor 2 for streaming reads, the gather calibration's upper bound for the two gather kernels), hbm_frac =
-    hbm_bytes / duration / 8 TB/s; l2_hit = TCC_HIT / (HIT + MISS)."""
+    SQ_WAVE_CYCLES; lanes = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64); issue_roofline = issue_frac x lanes / 64 - the share
+    of the machine's lane-cycles that did work: the fraction of the resource that actually binds these kernels; fabric_bytes = factor x
+    FETCH_SIZE + WRITE_SIZE (KiB as rocprofv3 reports them; factor 2 for streaming reads, the gather calibration's upper bound for
+    the two gather kernels) - what crossed the fabric behind the L2s (L2 misses: Infinity-Cache hits included, so NOT all of it
+    is HBM traffic - the index is 110 MB; rounds 1 - 4 called this hbm_frac), fabric_frac = fabric_bytes / duration / 8 TB/s;
+    l2_hit = TCC_HIT / (HIT + MISS)."""
     c = stage_counters(prof, stage)
     if not c or not c.get("avg_ns"):
         return None
@@ -168,6 +171,8 @@ def derived(prof, stage):
         out["wait_frac"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)
     if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_THREAD_CYCLES_VALU"):
         out["valu_lanes_of_64"] = round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"], 2)
+        if "issue_frac" in out:
+            out["issue_roofline"] = round(out["issue_frac"] * out["valu_lanes_of_64"] / 64.0, 4)
     if len(c["_kernels"]) == 1 and c.get("SQ_WAVES") and c["SQ_WAVES"] <= 256 * 32 and c.get("GRBM_GUI_ACTIVE") and c.get("SQ_WAVE_CYCLES"):   # (a kernel whose waves are all resident from the start)
         # a persistent kernel's waves should all live as long as the launch: the share of the launch a wave is resident
         # (SQ_WAVE_CYCLES counts in units of 4 cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs); what is missing is the tail of the
@@ -180,15 +185,15 @@ def derived(prof, stage):
         f = (prof.get("gather_factor") or FETCH_FACTOR_STREAM) if gather else FETCH_FACTOR_STREAM
         hb = (f * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
         out["fetch_factor"] = f
-        out["hbm_bytes_per_launch"] = round(hb, 0)
-        out["hbm_frac"] = round(hb / (ns * 1e-9) / (HBM_PEAK_GBS * 1e9), 5)
+        out["fabric_bytes_per_launch"] = round(hb, 0)
+        out["fabric_frac"] = round(hb / (ns * 1e-9) / (HBM_PEAK_GBS * 1e9), 5)
         if gather:                                              # (a scattered request moves 64 or 128 bytes: lower bound with factor 1)
-            out["hbm_frac_lower"] = round((1.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / (ns * 1e-9) / (HBM_PEAK_GBS * 1e9), 5)
+            out["fabric_frac_lower"] = round((1.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / (ns * 1e-9) / (HBM_PEAK_GBS * 1e9), 5)
     if c.get("TCC_HIT_sum") is not None and (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)) > 0:
         out["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
     # what binds the kernel, by the counters
     # (for the gather kernels the bytes that certainly moved - the lower bound - decide: the upper bound assumes a whole 128-byte line per item)
-    cand = {"valu_issue": out.get("issue_frac", 0.0), "salu_issue": out.get("salu_frac", 0.0), "hbm": out.get("hbm_frac_lower", out.get("hbm_frac", 0.0))}
+    cand = {"valu_issue": out.get("issue_frac", 0.0), "salu_issue": out.get("salu_frac", 0.0), "fabric": out.get("fabric_frac_lower", out.get("fabric_frac", 0.0))}
     bound = max(cand, key=cand.get)
     if out.get("wait_frac", 0.0) >= 0.6 and cand[bound] < 0.5:
         bound = "latency"
@@ -554,6 +559,38 @@ def main():
     else:
         job = {k: int(acc[k]) for k in ("rows", "reads_with_rows", "hsps", "gap_tasks", "seed_tasks")}
     dt = float(tmax.item())
+    # A yardstick that does not move with the implementation: what the REFERENCE's seed stage would read for one batch -
+    # CHashSearch::Searching@0x415050 looks every seed's bucket up (8 B: start and size), binary-searches the bucket's suffix keys (2 B per
+    # key read: lower_bound / upper_bound, ExtendSeq2Set 0x413bd2-0x414aa1), and reads posting, subject offset and the residues around the
+    # seed of every seed hit (4 + 4 + 12 B); the frames once (6 x L/3 B).  ONE untimed launch of the counting form of the seed kernel
+    # (mc_set_counting: it searches every probe the reference searches instead of asking its filters, and counts) on batch 0.
+    ref_pattern = None
+    if rank == 0:
+        eng.set_counting(True)
+        eng.run_range(0, args.batch, first_read_id=0)
+        cst = eng.stats()
+        eng.set_counting(False)
+        if cst["bucket_lookups"] > 0:
+            rp_bytes = 8 * cst["bucket_lookups"] + 2 * cst["key_probes"] + 20 * cst["seed_tasks"] + 6 * (L // 3) * args.batch
+            ref_pattern = {"bytes_per_read": round(rp_bytes / args.batch, 1), "bucket_lookups_per_read": round(cst["bucket_lookups"] / args.batch, 2),
+                           "key_reads_per_read": round(cst["key_probes"] / args.batch, 2), "seed_hits_per_read": round(cst["seed_tasks"] / args.batch, 2),
+                           "counting_launch_ms": round(cst["ms_seed"], 3), "_bytes_per_launch": rp_bytes,
+                           "formula": "8 B x bucket lookups + 2 B x key reads of the binary searches + 20 B x seed hits + 6 x (L / 3) B of frames, per read; counted by one untimed "
+                                      "launch of k_enumerate_t0<.., true> on batch 0"}
+    rccl = None
+    if world > 1:
+        # evidence that the collective really spanned `world` ranks: every rank contributes rank + 1 to a sum (must be N (N + 1) / 2) and its
+        # LOCAL_RANK's device index to a bit mask; the crc of the reduced per-family vector the estimate is made from
+        import zlib
+        probe = torch.tensor([rank + 1, 1 << local], dtype=torch.int64, device=rdev)
+        dist.all_reduce(probe)
+        ver = None
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None
+        except Exception:
+            pass
+        rccl = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "nccl_version": ver, "rank_sum": int(probe[0].item()), "rank_sum_expected": world * (world + 1) // 2,
+                "device_mask": int(probe[1].item()), "reduced_vector_crc32": zlib.crc32(np.concatenate([tot_hits, tot_aln, tot_bylen.ravel()]).tobytes())}
     e2e_multi = None
     if world > 1 and args.e2e_reads > 0 and gen is not None:
         eng.attach(0, 0)
@@ -586,6 +623,12 @@ def main():
             "sort": hsps * (16 + 20 + 20 + 96 * 0.4),                        # stage C: keys and place words in, 20 B binned and read again, the records of the marked reads' HSPs (~40 %) fetched and written
             "k_finish": hsps * 48 + rows * 64,                               # HSPs in, m8 rows out
         }
+        if ref_pattern is not None and kseq["k_enumerate"] > 0:
+            rp_rate = ref_pattern.pop("_bytes_per_launch") / (kseq["k_enumerate"] * 1e-3) / 1e9
+            ref_pattern.update({"timed_seed_kernel_ms": round(kseq["k_enumerate"], 3), "disposed_GBps": round(rp_rate, 1), "frac_of_hbm_peak": round(rp_rate / HBM_PEAK_GBS, 4),
+                                "own_asks_bytes_per_read": round(per_launch["k_enumerate"] / n_batch, 1),
+                                "note": "disposed_GBps = the reference pattern's bytes of one batch / the TIMED seed kernel's duration: above the HBM peak means the kernel answers "
+                                        "most of what the reference would read from its filters instead (own_asks_bytes_per_read is what it really asks)"})
         prof = load_profile(L)
         der = {k: derived(prof, "k_enumerate_t0" if k == "k_enumerate" else k) for k in kseq}
         d_dom = der.get(dom)
@@ -601,17 +644,18 @@ def main():
         # HBM bytes of the dominant kernel per launch of THIS run's batch: the profile's counters are per launch of its own batch size;
         # the pipeline is linear in the number of reads, so only the reads-per-launch ratio is applied - never another read length
         traffic_dom = None
-        if d_dom and d_dom.get("hbm_bytes_per_launch") is not None and d_dom.get("reads_per_launch"):
-            traffic_dom = d_dom["hbm_bytes_per_launch"] * n_batch / d_dom["reads_per_launch"]
+        if d_dom and d_dom.get("fabric_bytes_per_launch") is not None and d_dom.get("reads_per_launch"):
+            traffic_dom = d_dom["fabric_bytes_per_launch"] * n_batch / d_dom["reads_per_launch"]
         # north_star's second target: >= 40 % of the HBM roofline on the extension kernel(s) - stated, and missed: both are bound by
         # VALU issue (integer DP / X-drop loops with 28 - 37 of 64 lanes active), not by bytes
         ext = {}
         for k in ("k_eval_seeds", "k_gapped"):
             if kseq.get(k, 0) > 0:
                 a = per_launch[k] / (kseq[k] * 1e-3) / 1e9
-                ext[k] = {"algorithmic_GBps": round(a, 1), "frac_of_hbm_peak": round(a / HBM_PEAK_GBS, 4), "counter_hbm_frac": (der.get(k) or {}).get("hbm_frac"),
-                          "counter_hbm_frac_lower": (der.get(k) or {}).get("hbm_frac_lower"), "bound": (der.get(k) or {}).get("bound")}
-        ext_best = max([max(v["frac_of_hbm_peak"], v["counter_hbm_frac"] or 0.0) for v in ext.values()] or [0.0])
+                ext[k] = {"algorithmic_GBps": round(a, 1), "frac_of_hbm_peak": round(a / HBM_PEAK_GBS, 4), "counter_fabric_frac": (der.get(k) or {}).get("fabric_frac"),
+                          "counter_fabric_frac_lower": (der.get(k) or {}).get("fabric_frac_lower"), "bound": (der.get(k) or {}).get("bound"),
+                          "issue_roofline": (der.get(k) or {}).get("issue_roofline")}
+        ext_best = max([v["frac_of_hbm_peak"] for v in ext.values()] or [0.0])
         out = {
             "metric": METRIC, "value": round(reads_total / dt, 1), "unit": "reads/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32",
@@ -630,7 +674,8 @@ def main():
             "roofline": {"kernel": dom, "bound": (d_dom or {}).get("bound", "valu_issue"), "nominal_bound": "hbm",
                          "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                          "traffic": (None if traffic_dom is None else round(traffic_dom, 0)),
-                         "hbm_frac": (d_dom or {}).get("hbm_frac"), "hbm_frac_lower": (d_dom or {}).get("hbm_frac_lower"), "issue_frac": (d_dom or {}).get("issue_frac"),
+                         "fabric_frac": (d_dom or {}).get("fabric_frac"), "fabric_frac_lower": (d_dom or {}).get("fabric_frac_lower"), "issue_frac": (d_dom or {}).get("issue_frac"),
+                         "issue_roofline": (d_dom or {}).get("issue_roofline"), "reference_pattern": ref_pattern,
                          "salu_frac": (d_dom or {}).get("salu_frac"), "wait_frac": (d_dom or {}).get("wait_frac"), "wave_residency": (d_dom or {}).get("wave_residency"),
                          "valu_lanes_of_64": (d_dom or {}).get("valu_lanes_of_64"), "l2_hit_rate": (d_dom or {}).get("l2_hit_rate"),
                          "kernel_ms_per_step": round(kseq[dom], 3), "algorithmic_bytes_per_read": round(per_launch[dom] / n_batch, 1),
@@ -639,7 +684,7 @@ def main():
                                                         "pair_blocks_16B": round(asks["seed_pair_asks"] / n_batch, 2), "records_and_key_groups_48B": round(asks["seed_probes"] / n_batch, 2),
                                                         "postings_and_offsets_8B": round(hits / n_batch, 2)},
                          "fabric_amplification": (None if traffic_dom is None else round(traffic_dom / per_launch[dom], 2)),
-                         "fabric_amplification_lower": (None if not (d_dom and d_dom.get("hbm_frac_lower") and d_dom.get("hbm_frac")) else round(traffic_dom / per_launch[dom] * d_dom["hbm_frac_lower"] / d_dom["hbm_frac"], 2)),
+                         "fabric_amplification_lower": (None if not (d_dom and d_dom.get("fabric_frac_lower") and d_dom.get("fabric_frac")) else round(traffic_dom / per_launch[dom] * d_dom["fabric_frac_lower"] / d_dom["fabric_frac"], 2)),
                          "extension_kernel_hbm_frac": {"target": 0.40, "met": bool(ext_best >= 0.40), "best": round(ext_best, 4), "kernels": ext,
                                                        "note": "north_star asks for >= 40 % of the HBM roofline on the extension kernel; the ungapped (k_eval_seeds) and gapped (k_gapped stage) "
                                                                "extensions are bound by VALU issue, not by bytes: the target is missed"},
@@ -650,15 +695,17 @@ def main():
                                   "traffic / those bytes (one 64- or 128-byte line moves per 4 .. 48-byte item). Everything else comes from the committed rocprofv3 profile of THIS read length (profile; null "
                                   "when none is committed - a profile of another length is never scaled): traffic = (fetch_factor x FETCH_SIZE + WRITE_SIZE) KiB x 1024 "
                                   "per profiled launch x (this batch / profiled batch), fetch_factor 2 for streaming reads (MI355X_MICROARCH.md) and the gather "
-                                  "calibration's (fetch_calibration) for the seed kernels; hbm_frac = that / profiled duration / 8 TB/s (mostly Infinity-Cache hits: "
-                                  "the index is 110 MB; hbm_frac_lower: the same with one 64-byte half line per scattered request); issue_frac = SQ_INSTS_VALU x 4 / "
+                                  "calibration's (fetch_calibration) for the seed kernels; fabric_frac = that / profiled duration / 8 TB/s (L2-miss traffic, mostly Infinity-Cache hits: "
+                                  "the index is 110 MB - rounds 1 - 4 called it hbm_frac; fabric_frac_lower: the same with one 64-byte half line per scattered request); "
+                                  "reference_pattern = what CHashSearch::Searching / ExtendSeq2Set would read for this batch, counted by ONE untimed launch of the counting form of "
+                                  "the seed kernel (mc_set_counting) - a yardstick that does not move with this implementation's filters; issue_roofline = issue_frac x valu_lanes_of_64 / 64; issue_frac = SQ_INSTS_VALU x 4 / "
                                   "(1024 SIMDs x kernel cycles), salu_frac = SQ_INSTS_SALU / (256 scalar units x kernel cycles) - the two issue side by side and are "
                                   "not added -, kernel cycles = profiled duration x 2.4 GHz; wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES; valu_lanes_of_64 = "
-                                  "SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU; bound = the largest of issue_frac, salu_frac and hbm_frac (hbm_frac_lower where there is one; 'latency' when all are "
+                                  "SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU; bound = the largest of issue_frac, salu_frac and fabric_frac (fabric_frac_lower where there is one; 'latency' when all are "
                                   "below 0.5 and wait_frac >= 0.6). No kernel of this path is HBM bound: the nominal roofline (nominal_bound) is kept because "
                                   "the metric asks for it.",
                          "all_kernels": {k: dict({"ms_per_step": round(kseq[k], 3), "algorithmic_GBps": round(per_launch[k] / (kseq[k] * 1e-3) / 1e9, 2)},
-                                                 **({} if not der.get(k) else {m: der[k][m] for m in ("bound", "issue_frac", "salu_frac", "wait_frac", "wave_residency", "hbm_frac", "hbm_frac_lower", "valu_lanes_of_64", "lds_bank_conflict_frac", "l2_hit_rate", "profiled_ms") if m in der[k]}))
+                                                 **({} if not der.get(k) else {m: der[k][m] for m in ("bound", "issue_frac", "issue_roofline", "salu_frac", "wait_frac", "wave_residency", "fabric_frac", "fabric_frac_lower", "valu_lanes_of_64", "lds_bank_conflict_frac", "l2_hit_rate", "profiled_ms") if m in der[k]}))
                                          for k in kseq if kseq[k] > 0},
                          "legacy_survey_A": {"bytes_per_read": SURVEY_A.get(L), "pipeline_GBps": (None if pipe_gbs is None else round(pipe_gbs, 2)),
                                              "note": "SURVEY.md 8(d) priced the whole path at A(L) assuming whole-bucket visits the engine does not perform (DESIGN.md 2): kept as a labelled legacy figure, not a fraction of anything"}},
@@ -683,6 +730,8 @@ def main():
                           "plain": e2e_rate(local, gen, args.e2e_reads, L, gz=False), "gz": e2e_rate(local, gen, max(1, min(args.e2e_reads, max(args.e2e_reads // 5, 4_000_000))), L, gz=True)}
         if e2e_multi is not None:
             out["e2e"] = e2e_multi
+        if rccl is not None:
+            out["rccl"] = rccl
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:

@@ -31,3 +31,39 @@ def write_fastq(path, n=150_000, L=300):
     with open(path, "wb") as f:
         f.write(b"".join(recs))
     return n
+
+
+def write_fastq_chunk(path, chunk, n=150_000, L=300):
+    """Chunk `chunk` of the FULL-SIZE configs[4] file (tests/test_gpu_at_size.py: 14 chunks = 2.1 M records): the same recipe as
+    write_fastq with the chunk's own reads (first = chunk * n), random stream (RandomState(3 + chunk)) and record names; chunk 0 is
+    NOT the file of write_fastq (the names differ) - nothing golden depends on this one, its checks are differential."""
+    from microbecensus_amd import synth
+    gen = synth.GenomeReads(device="cpu", seed=11)
+    r = gen.single(n, L, first=chunk * n).numpy()
+    rng = np.random.RandomState(3 + chunk)
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    qual = (np.clip(np.rint(rng.normal(34, 6, size=(n, L))), 20, 41).astype(np.uint8) + 33)
+    low = rng.rand(n) < 0.05
+    qual[low, rng.randint(0, L, size=int(low.sum()))] = 33 + 10
+    u = rng.rand(n)
+    recs, pool = [], []
+    for i in range(n):
+        sq = bytes(r[i])
+        if b"Y" in sq or b"S" in sq:
+            sq = sq.replace(b"Y", b"N").replace(b"S", b"N")
+        if pool and u[i] < 0.02:
+            sq = pool[rng.randint(len(pool))]
+        elif pool and u[i] < 0.03:
+            sq = pool[rng.randint(len(pool))][::-1].translate(comp)
+        elif len(pool) < 5000:
+            pool.append(sq)
+        recs.append(b"@c%d_%d\n%s\n+\n%s\n" % (chunk, i, sq, bytes(qual[i])))
+    with open(path, "wb") as f:
+        f.write(b"".join(recs))
+    return n
+
+
+if __name__ == "__main__":       # python c5_at_size.py <repo> <out> <chunk> [n [L]]: one chunk, as a process of its own (the GPU tests start several side by side)
+    import sys
+    sys.path.insert(0, sys.argv[1])
+    write_fastq_chunk(sys.argv[2], int(sys.argv[3]), *(int(a) for a in sys.argv[4:6]))
