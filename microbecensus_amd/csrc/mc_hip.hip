@@ -497,7 +497,11 @@ static int stage_a(mc_handle *h, McCtx &c)
     }
 #endif
     if (h->fast_enum) {
-        const size_t per_wave = MC_EN_WAVE_BYTES(h->count_traffic) + MC_EN_WAVE_LDS(FP, L);
+        // k_enumerate_q (round 5: queues that persist across the reads of a chunk) is the kernel of the product path; the counting form
+        // (mc_set_counting: what the reference would read) stays with k_enumerate_t0<.., true>.  MC_EN_OLD=1: k_enumerate_t0<.., false>, for A/B runs.
+        static const bool en_old = getenv("MC_EN_OLD") != nullptr;
+        const bool enq = !h->count_traffic && !en_old;
+        const size_t per_wave = enq ? MC_ENQ_WAVE_LDS(FP, L) : MC_EN_WAVE_BYTES(h->count_traffic) + MC_EN_WAVE_LDS(FP, L);
         // Launch shape: the kernel needs 79 VGPRs (6 waves per SIMD) and is bound by instruction issue with some latency left to
         // hide - measured per 1 M reads of 150 bp: 16 waves per CU 6.77 ms, 20: 6.45, 24 (2 x 12, 3 x 8, 6 x 4 alike): 6.39.
         // So: as many waves per CU as the LDS holds, up to 24, in workgroups of 12 / 8 / 4 / 16 waves.
@@ -516,9 +520,17 @@ static int stage_a(mc_handle *h, McCtx &c)
         k_enumerate_t0<WV, CNT><<<dim3(blocks), dim3(64 * WV), lds2, st>>>(h->d_T, X, h->d_bitmap, c.d_frames, FP, L, n, c.d_tasks, c.cap_tasks, \
                                                                             c.d_counters, c.d_stats);                                             \
     } while (0)
-        if (h->count_traffic) { if (waves == 16) MC_LAUNCH_EN(16, true); else if (waves == 12) MC_LAUNCH_EN(12, true); else if (waves == 8) MC_LAUNCH_EN(8, true); else MC_LAUNCH_EN(4, true); }
+#define MC_LAUNCH_ENQ(WV)                                                                                                                          \
+    do {                                                                                                                                           \
+        HIPCK(hipFuncSetAttribute((const void *)k_enumerate_q<WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                        \
+        k_enumerate_q<WV><<<dim3(blocks), dim3(64 * WV), lds2, st>>>(h->d_T, X, h->d_bitmap, c.d_frames, FP, L, n, c.d_tasks, c.cap_tasks,        \
+                                                                      c.d_counters, c.d_stats);                                                   \
+    } while (0)
+        if (enq) { if (waves == 16) MC_LAUNCH_ENQ(16); else if (waves == 12) MC_LAUNCH_ENQ(12); else if (waves == 8) MC_LAUNCH_ENQ(8); else MC_LAUNCH_ENQ(4); }
+        else if (h->count_traffic) { if (waves == 16) MC_LAUNCH_EN(16, true); else if (waves == 12) MC_LAUNCH_EN(12, true); else if (waves == 8) MC_LAUNCH_EN(8, true); else MC_LAUNCH_EN(4, true); }
         else { if (waves == 16) MC_LAUNCH_EN(16, false); else if (waves == 12) MC_LAUNCH_EN(12, false); else if (waves == 8) MC_LAUNCH_EN(8, false); else MC_LAUNCH_EN(4, false); }
 #undef MC_LAUNCH_EN
+#undef MC_LAUNCH_ENQ
     } else
         k_enumerate<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, X, c.d_frames, FP, L, n, c.d_tasks, c.cap_tasks, c.d_counters, c.d_stats);
     HIPCK(hipEventRecord(c.ev[2], st));
