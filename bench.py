@@ -71,14 +71,14 @@ def spawn_ranks(n, argv):
 
 
 STAGE_KERNELS = {   # kernels whose HIP-event time a stage of mc_stats spans (prefixes of the names in the rocprofv3 summaries)
-    "k_translate_seg": ["k_translate_seg"], "k_enumerate_t0": ["k_enumerate_t0<"], "k_enumerate": ["k_enumerate_t0<", "k_enumerate"], "k_eval_seeds": ["k_eval_seeds"],
+    "k_translate_seg": ["k_translate_seg"], "k_enumerate_t0": ["k_enumerate_q<", "k_enumerate_t0<"], "k_enumerate": ["k_enumerate_q<", "k_enumerate_t0<", "k_enumerate"], "k_eval_seeds": ["k_eval_seeds"],
     "k_gapped": ["k_gap_dedupe", "k_gap_sort_hist", "k_gap_sort_scan", "k_gap_sort_scatter", "k_gapped_lds", "k_gapped", "k_gap_emit"], "k_finish": ["k_finish", "k_finish_heavy", "k_heap_lanes", "k_heavy_rows", "k_heavy_lists", "k_emit_rows"],
     "sort": ["k_bin_count", "k_bin_scatter", "k_scan_sums", "k_scan_top", "k_scan_apply", "k_order_lists", "k_order_light", "k_order_heavy", "k_order_copy"],
 }
 
 
 FETCH_FACTOR_STREAM = 2.0   # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads
-GATHER_KERNELS = ("k_enumerate_t0<", "k_eval_seeds")   # kernels whose global reads are scattered 4..32-byte items
+GATHER_KERNELS = ("k_enumerate_q<", "k_enumerate_t0<", "k_eval_seeds")   # kernels whose global reads are scattered 4..32-byte items
 
 
 def load_profile(L):
@@ -125,7 +125,7 @@ def stage_counters(prof, stage):
     pref = STAGE_KERNELS.get(stage, [stage])
     tot, names, per_pass = {}, [], None
     for k, d in prof["kernels"].items():
-        if k.rstrip().endswith("true>") and k.startswith("k_enumerate"):       # (the counting form of the seed kernel is not the timed one)
+        if (k.rstrip().endswith("true>") and k.startswith("k_enumerate")) or k.startswith("k_enumerate_count"):       # (the counting form of the seed kernel is not the timed one)
             continue
         if not any(k == q or k.startswith(q + "<") or (q.endswith("<") and k.startswith(q)) for q in pref):
             continue
@@ -576,7 +576,7 @@ def main():
                            "key_reads_per_read": round(cst["key_probes"] / args.batch, 2), "seed_hits_per_read": round(cst["seed_tasks"] / args.batch, 2),
                            "counting_launch_ms": round(cst["ms_seed"], 3), "_bytes_per_launch": rp_bytes,
                            "formula": "8 B x bucket lookups + 2 B x key reads of the binary searches + 20 B x seed hits + 6 x (L / 3) B of frames, per read; counted by one untimed "
-                                      "launch of k_enumerate_t0<.., true> on batch 0"}
+                                      "launch of k_enumerate_count on batch 0"}
     rccl = None
     if world > 1:
         # evidence that the collective really spanned `world` ranks: every rank contributes rank + 1 to a sum (must be N (N + 1) / 2) and its

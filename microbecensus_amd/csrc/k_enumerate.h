@@ -1,5 +1,6 @@
 // k_enumerate.h - stage A2: seed enumeration and index probing (CHashSearch::Searching@0x415050): k_enumerate, the generic kernel
-// (any .info threshold, one thread per frame), and k_enumerate_t0, the position-parallel kernel the marker database runs.
+// (any .info threshold, one thread per frame); k_enumerate_q, the position-parallel kernel the marker database runs (threshold 0);
+// k_enumerate_count, its counting form (mc_set_counting: every probe the reference searches is searched and counted - no filters).
 #pragma once
 #include "mc_hip_common.h"
 
@@ -35,7 +36,11 @@ __global__ void __launch_bounds__(256) k_enumerate(const McTables *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_enumerate_t0: position-parallel seed probing for databases whose .info frequency threshold is 0 (the marker DB).
+// k_enumerate_count: position-parallel seed probing for databases whose .info frequency threshold is 0 (the marker DB) - the
+// COUNTING form (mc_set_counting; bench.py's roofline.reference_pattern): it searches every probe the reference's Searching
+// searches, with the reference's binary searches where those decide the count, and reports bucket lookups and key reads.  It is
+// rounds 2 - 4's seed kernel k_enumerate_t0 (one wave per read, queues drained per read) without its filters; the kernel of the
+// product path is k_enumerate_q below, which shares the position pass, the queue items and the append with it.
 //
 // With threshold 0 the seed-length carry of Searching@0x415050 collapses (mc_enumerate_seeds documents the general
 // rule): a position whose own bucket is non-empty always uses a 9-mer (or is skipped), and only positions with an
@@ -44,10 +49,8 @@ __global__ void __launch_bounds__(256) k_enumerate(const McTables *__restrict__ 
 // So a read is handled in two parallel passes: (0) the exact 9-mer probes and the 36 neighbourhood probes of every
 // position whose neighbourhood does not depend on `prev`; (1) the few positions that do.
 //
-// One wave per read, 24 waves per CU.  The kernel is bound by instruction issue (VALU + SALU), not by memory: every stage
-// is arranged so that all 64 lanes work - positions, (position, wildcard offset) pairs and probes are compacted through
-// per-wave LDS queues - and so that a stage costs few instructions per item (filters that answer in one read, packed
-// codes, prefix sums by DPP).  Seed hits are appended to slots from a prefix sum; one global atomic per 2048 slots.
+// One wave per read: positions, (position, wildcard offset) pairs and probes are compacted through per-wave LDS queues so that
+// every stage runs on 64 items.  Seed hits are appended to slots from a prefix sum; one global atomic per 2048 slots.
 // ------------------------------------------------------------------------------------------------
 #define MC_EN_QCAP 128
 #define MC_EN_NCHUNK(L) ((((L) / 3 - 6) + 63) / 64 > 0 ? (((L) / 3 - 6) + 63) / 64 : 1)
@@ -67,9 +70,8 @@ struct McEnWave {
 #ifdef MC_EXP_TIMING
     unsigned long long tacc[6], tcnt[6];
 #endif
-    unsigned long long hq[MC_EN_QCAP];      // probes whose first-residue group is longer than 8 keys (binary search): counting form only - last member, not allocated otherwise
+    unsigned long long hq[MC_EN_QCAP];      // probes whose first-residue group is longer than 8 keys (binary search)
 };
-#define MC_EN_WAVE_BYTES(COUNT) ((COUNT) ? sizeof(McEnWave) : offsetof(McEnWave, hq))
 
 // item: bucket(20) | qk(16)<<20 | pos(8)<<36 | frame(3)<<44 | phase(6)<<47
 // Appends the seed hits of one batch of probes (lane: cnt postings starting at posting index nst of its bucket).
@@ -172,7 +174,6 @@ __device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long
 
 // One batch of (up to 64) probes.  Returns per lane: key reads of the reference (bits 32..), seed hits (bits 8..31);
 // bits 0..7 (uniform): the new fill of the heavy queue.
-template <bool COUNT>
 __device__ __forceinline__ unsigned long long mc_en_process(const McIndex &X, unsigned long long item, bool active, uint32_t read, McEnWave *W, int hn,
                                                          McSeedTask *tasks, uint32_t cap, uint32_t *counters, int lane
 #ifdef MC_EXP_TIMING
@@ -192,14 +193,8 @@ __device__ __forceinline__ unsigned long long mc_en_process(const McIndex &X, un
         start = R->start; c0 = R->cum[k6];
         const int ns = (int)R->cum[k6 + 1] - c0;
         heavy = ns > 8;
-        if (ns > 0 && !heavy) cnt = COUNT ? mc_group_range8(X.keys + start + c0, ns, qk, &lb) : mc_group_match8(X.keys + start + c0, ns, qk, &lb);   // (the counting form wants the lower bound of an empty range too)
-        if (!COUNT && heavy) {                                    // long group: the range table knows the answer (no binary search, no second queue)
-            int nst_b = 0;
-            cnt = mc_rt_lookup(X.rt, X.rt_mask, (uint32_t)bucket, qk, &nst_b);
-            lb = nst_b - c0;
-            heavy = false;
-        }
-        if (COUNT && !heavy) { const int n = R->cum[11]; kp = mc_bsearch_reads(n, c0 + lb) + (cnt > 0 ? mc_bsearch_reads(n, c0 + lb + cnt) : 0u); }
+        if (ns > 0 && !heavy) cnt = mc_group_range8(X.keys + start + c0, ns, qk, &lb);   // (the counting form wants the lower bound of an empty range too)
+        if (!heavy) { const int n = R->cum[11]; kp = mc_bsearch_reads(n, c0 + lb) + (cnt > 0 ? mc_bsearch_reads(n, c0 + lb + cnt) : 0u); }
     }
     const unsigned long long hm = __ballot(heavy);
     if (hm) {
@@ -215,7 +210,6 @@ __device__ __forceinline__ unsigned long long mc_en_process(const McIndex &X, un
 }
 
 // One batch of probes whose group needs the binary searches.
-template <bool COUNT>
 __device__ __forceinline__ unsigned long long mc_en_heavy(const McIndex &X, unsigned long long item, bool active, uint32_t read, McEnWave *W,
                                                        McSeedTask *tasks, uint32_t cap, uint32_t *counters, int lane)
 {
@@ -229,7 +223,7 @@ __device__ __forceinline__ unsigned long long mc_en_heavy(const McIndex &X, unsi
         start = R->start; c0 = R->cum[k6];
         const int ns = (int)R->cum[k6 + 1] - c0;
         cnt = mc_group_range_bs(X.keys + start + c0, ns, qk, &lb);
-        if (COUNT) { const int n = R->cum[11]; kp = mc_bsearch_reads(n, c0 + lb) + (cnt > 0 ? mc_bsearch_reads(n, c0 + lb + cnt) : 0u); }
+        { const int n = R->cum[11]; kp = mc_bsearch_reads(n, c0 + lb) + (cnt > 0 ? mc_bsearch_reads(n, c0 + lb + cnt) : 0u); }
     }
     const uint32_t nt = mc_en_append<McEnWave, false>(X, item, cnt, c0 + lb, start, read, W, tasks, cap, counters, lane);
     return ((unsigned long long)kp << 32) | ((unsigned long long)nt << 8);
@@ -245,16 +239,16 @@ __device__ __forceinline__ unsigned long long mc_en_heavy(const McIndex &X, unsi
 #else
 #define MC_EN_ATTR __attribute__((amdgpu_waves_per_eu(6, 6)))   // 80 VGPRs: the 24 waves per CU of the launch (the allocator stops at 83 by itself)
 #endif
-template <int MC_EN_WAVES, bool COUNT>
-__global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(const McTables *__restrict__ T, McIndex X, const uint32_t *__restrict__ bitmap,
+template <int MC_EN_WAVES>
+__global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_count(const McTables *__restrict__ T, McIndex X, const uint32_t *__restrict__ bitmap,
                                                                    const uint8_t *__restrict__ frames, int FP, int L, int64_t nreads, McSeedTask *tasks,
                                                                    uint32_t cap, uint32_t *counters, unsigned long long *stats)
 {
     uint8_t *smem = mc_smem;
     uint8_t *grp = smem;                                                    // 32-byte group table
     const int lane = mc_lane(), wv = threadIdx.x >> 6;
-    McEnWave *W = (McEnWave *)(smem + 64 + (size_t)wv * MC_EN_WAVE_BYTES(COUNT));
-    uint8_t *fr_all = smem + 64 + (size_t)MC_EN_WAVES * MC_EN_WAVE_BYTES(COUNT);
+    McEnWave *W = (McEnWave *)(smem + 64 + (size_t)wv * sizeof(McEnWave));
+    uint8_t *fr_all = smem + 64 + (size_t)MC_EN_WAVES * sizeof(McEnWave);
     const int FPn = MC_EN_ROW(FP);
     const int ql0 = L / 3, ql1 = (L - 1) / 3, ql2 = (L - 2) / 3;           // frame lengths (frames f and f + 3 alike)
     const int cn0 = ql0 > 6 ? ql0 - 6 : 0, cn1 = ql1 > 6 ? ql1 - 6 : 0, cn2 = ql2 > 6 ? ql2 - 6 : 0;   // seed positions of the frames, and their running sums
@@ -363,7 +357,7 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
                 // when g8, g9 are valid and g6 or g7 is not: those few positions are decided in pass 1.
                 bool live = false, defer = false;
                 if (vd[u] && rest >= 4) { if (occ) live = v6 && v7 && v9; else if (v8 && v9) { if (v6 && v7) live = true; else defer = true; } }
-                if (COUNT && vd[u]) sc.lookups += live0 ? 2 : 1;               // bucket-size probe of the exact seed, and its key-range probe
+                if (vd[u]) sc.lookups += live0 ? 2 : 1;               // bucket-size probe of the exact seed, and its key-range probe
                 if (live0) atomicOr(&W->setter[f][pos >> 5], 1u << (pos & 31));
                 const bool keep = live0 || live || defer;
                 const unsigned long long km = __ballot(keep);
@@ -377,16 +371,13 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
         // offsets 4, 5, 3 of the 6-mer: neighbour buckets; group 3 = offset 6: same bucket, first key residue substituted).
         // Pass 0 sweeps the kept positions 64 at a time and generates both.  Whether a position has a neighbourhood
         // depends, for a few of them (own bucket empty, g8 and g9 valid, g6 or g7 not: ~3 % of the positions), on whether
-        // the nearest earlier exact probe of the frame found a range; those wait in the list dq - with the wildcard
-        // filter's answer, asked in pass 0 - until pass 0 has drained its queues, and are generated in pass 1.
-        // With the counters off, filters decide what is searched:
-        //   exact 9-mer  -> 9-mer Bloom filter -> queue q
-        //   10-mers      -> wildcard filter (one 32-byte line per position answers for its four groups) -> queue eq of
-        //                   (position, group) pairs -> 64 pairs at a time: pair filter (one 16-byte block answers for the
-        //                   ten residues of the pair) -> queue q
-        //   q            -> bucket records: group scan, or the range table for long groups -> seed hits
-        // (the counting form searches every probe; its long groups go through queue hq to the binary searches).
-        // Every stage runs with full waves; the generator is a state machine so that each stage exists once in the kernel.
+        // the nearest earlier exact probe of the frame found a range; those wait in the list dq until pass 0 has drained
+        // its queues, and are generated in pass 1.
+        //   exact 9-mer  -> queue q
+        //   10-mers      -> queue eq of (position, group) pairs -> 64 pairs at a time: the bucket bitmap decides which of the ten
+        //                   probes of a pair are searched -> queue q
+        //   q            -> bucket records: group scan; long groups through queue hq to the reference's binary searches -> seed hits
+        // The generator is a state machine so that each stage exists once in the kernel.
         int dn = 0;                                      // deferred positions (dq)
         for (int pass = 0; pass < 2; pass++) {
             int flat0 = 0, dpos = 0;
@@ -402,7 +393,7 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
                     MC_TICK(1);
                     const int take = hn < 64 ? hn : 64;
                     hn -= take;
-                    const unsigned long long rh = mc_en_heavy<COUNT>(X, (lane < take) ? W->hq[hn + lane] : 0ull, lane < take, (uint32_t)r, W, tasks, cap, counters, lane);
+                    const unsigned long long rh = mc_en_heavy(X, (lane < take) ? W->hq[hn + lane] : 0ull, lane < take, (uint32_t)r, W, tasks, cap, counters, lane);
                     sc.keyprobes += (uint32_t)(rh >> 32); sc.tasks += (uint32_t)(rh >> 8) & 0xFFFFFFu;
                     mc_wave_sync();
                     continue;
@@ -412,7 +403,7 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
                     const int take = qn < 64 ? qn : 64;
                     qn -= take;
                     n_probes += (uint32_t)take;
-                    const unsigned long long ret = mc_en_process<COUNT>(X, (lane < take) ? W->q[qn + lane] : 0ull, lane < take, (uint32_t)r, W, hn, tasks, cap, counters, lane
+                    const unsigned long long ret = mc_en_process(X, (lane < take) ? W->q[qn + lane] : 0ull, lane < take, (uint32_t)r, W, hn, tasks, cap, counters, lane
 #ifdef MC_EXP_TIMING
                                                                              , &tlast, &tcat
 #endif
@@ -451,22 +442,15 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
                     const bool act = lane < take;
                     xi = act ? W->eq[en + lane] : 0ull;
                     const int gl = (int)((xi >> 47) & 3), sd = (int)(xi & 0xFFFFF);
-                    const uint32_t xk = (uint32_t)((xi >> 20) & 0xFFFF);
                     const int st = gl == 0 ? 10 : gl == 1 ? 1 : gl == 2 ? 100 : 0;
                     const int d = (int)((xi >> 53) & 15);                // the position's own residue at the wildcard offset
                     uint32_t ok = 0;
-                    if (COUNT) {
 #pragma unroll
-                        for (int j = 0; j < 10; j++) {
-                            const int v = sd + (j - d) * st;             // st = 0 for the key group: the bucket stays
-                            bool c = act && j != d;
-                            if (c) { sc.lookups++; c = (bitmap[v >> 5] >> (v & 31)) & 1; }   // counting form: bucket occupancy decides, then the search
-                            ok |= (uint32_t)c << j;
-                        }
-                    } else {   // pair filter: one 16-byte block answers for the ten residues (lanes without a pair read block 0)
-                        const uint32_t hp = mc_pair_hash_d((uint32_t)sd, xk, gl, (uint32_t)d);
-                        const uint4 blk = ((const uint4 *)X.pair)[act ? mc_pair_block(hp) : 0u];
-                        ok = act ? (mc_pair_test4(blk.x, blk.y, blk.z, blk.w, hp) & ~(1u << d) & 0x3FFu) : 0u;
+                    for (int j = 0; j < 10; j++) {
+                        const int v = sd + (j - d) * st;                 // st = 0 for the key group: the bucket stays
+                        bool c = act && j != d;
+                        if (c) { sc.lookups++; c = (bitmap[v >> 5] >> (v & 31)) & 1; }   // bucket occupancy decides, then the search
+                        ok |= (uint32_t)c << j;
                     }
                     pm = ok;
                     mc_wave_sync();
@@ -504,44 +488,22 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_t0(co
                         idx = (int)(e & 0x7FFu); wmd = e >> 11;
                     }
                     const unsigned long long pw = pre[here ? idx : 0];
-                    const uint32_t seed = (uint32_t)(pw & 0xFFFFF), qk = (uint32_t)(pw >> 20) & 0xFFFFu;
+                    const uint32_t qk = (uint32_t)(pw >> 20) & 0xFFFFu;
                     const uint32_t d3 = (uint32_t)(pw >> 50) & 15u, d4 = (uint32_t)(pw >> 54) & 15u, d5 = (uint32_t)(pw >> 58) & 15u;   // bucket digits at offsets 3, 4, 5
                     wdig = d4 | (d5 << 4) | (d3 << 8) | ((qk >> 12) << 12);  // the residue at the wildcard offset of groups 0..3
                     wbase = pw & 0x00007FFFFFFFFFFFull;                      // seed | key | position | frame: a queue item without its phase
                     if (pass == 0) {
                         const bool live0 = here && ((pw >> 47) & 1), live = here && ((pw >> 48) & 1);
                         bool defer = here && ((pw >> 49) & 1);
-                        // both filters are asked before either answer is looked at: their reads are in flight together
-                        const bool ask = live || defer;
-                        const unsigned long long m9 = __ballot(live0), mw = __ballot(ask);
-                        const bool any9 = !COUNT && m9, anyw = !COUNT && mw;
+                        const unsigned long long m9 = __ballot(live0), mw = __ballot(live || defer);
                         n_exact += (uint32_t)__popcll(m9); n_wild += (uint32_t)__popcll(mw);
-                        const uint32_t qk0 = (qk & 0xFFF0u) | 0xFu;
-                        uint32_t fw9 = 0, fb9 = 0, wsum = 0;
-                        uint4 q0 = {0, 0, 0, 0}, q1 = {0, 0, 0, 0};
-                        if (any9) {                                      // the exact 9-mer: its own Bloom filter, then straight into q
-                            const uint32_t hh = mc_filter_hash(seed, qk0);
-                            fb9 = mc_filter_bits(hh);
-                            fw9 = X.filt[live0 ? mc_filter9_word(hh) : 0u];
-                        }
-                        if (anyw) {                                      // wildcard filter: one 32-byte line answers for the four groups
-                            const uint32_t ctx = mc_wild_ctx(seed, qk);
-                            const uint4 *ln = (const uint4 *)X.wild + (size_t)(ask ? mc_wild_line(ctx) : 0u) * 2;
-                            q0 = ln[0]; q1 = ln[1];
-                            wsum = mc_wild_sum(ctx, d3, d4, d5, qk >> 12);
-                        }
-                        const bool pr = live0 && (COUNT || (fw9 & fb9) == fb9);
+                        const bool pr = live0;                           // (no filters: every probe the reference searches is searched)
                         const unsigned long long prm = __ballot(pr);
                         if (prm) {
                             if (pr) W->q[qn + __popcll(prm & lt)] = wbase | (0xFull << 20);   // phase 0; key g6 g7 g8 F
                             qn += __popcll(prm);
                         }
-                        uint32_t wmt = 0xFu;                             // counting form: every probe is generated and searched
-                        if (!COUNT) {
-                            wmt = 0;
-                            if (ask) wmt = (mc_wild_test2(q0.x, q0.y, mc_wild_bits_s(wsum, d4, 0)) ? 1u : 0u) | (mc_wild_test2(q0.z, q0.w, mc_wild_bits_s(wsum, d5, 1)) ? 2u : 0u) |
-                                            (mc_wild_test2(q1.x, q1.y, mc_wild_bits_s(wsum, d3, 2)) ? 4u : 0u) | (mc_wild_test2(q1.z, q1.w, mc_wild_bits_s(wsum, qk >> 12, 3)) ? 8u : 0u);
-                        }
+                        const uint32_t wmt = 0xFu;                       // every probe is generated and searched
                         wm = live ? wmt : 0u;
                         defer = defer && wmt != 0;                       // (no group can match: nothing to decide later)
                         const unsigned long long dm = __ballot(defer);
@@ -876,7 +838,7 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_q(con
                 const uint32_t gk = gkv[u];
                 const bool v6 = (gk >> 12) != MC_INVGRP, v7 = ((gk >> 8) & 15u) != MC_INVGRP, v8 = ((gk >> 4) & 15u) != MC_INVGRP, v9 = (gk & 15u) != MC_INVGRP;
                 const bool live0 = vd[u] && occ && rest >= 3 && v6 && v7;        // exact 9-mer probe: it also defines `prev` for the positions behind it
-                bool live = false, defer = false;                                // (see k_enumerate_t0)
+                bool live = false, defer = false;                                // (see k_enumerate_count)
                 if (vd[u] && rest >= 4) { if (occ) live = v6 && v7 && v9; else if (v8 && v9) { if (v6 && v7) live = true; else defer = true; } }
                 if (live0) atomicOr(&setter[f * nw32 + (pos >> 5)], 1u << (pos & 31));
                 const unsigned long long item = (unsigned long long)sdv[u] | ((unsigned long long)gk << 20) | ((unsigned long long)pfv[u] << 36);

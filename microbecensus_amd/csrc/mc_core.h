@@ -955,7 +955,9 @@ MC_HD int mc_key_range_rec(const McBucketRec *rec, const uint16_t *keys, int see
 // probes of a read find nothing, so the seed kernel asks a Bloom filter first: it holds (bucket, k | 0xF) of every posting
 // with at least 3 key residues, 2 bits in one 32-bit word, 2^18 words (1 MB, L2 resident).  No false negatives; a positive
 // goes through the exact range search.  (The one-substitution 10-mer probes have the wildcard and pair filters below.)
+#ifndef MC_FILT9_LOG2W
 #define MC_FILT9_LOG2W 18
+#endif
 #define MC_FILT9_WORDS (1u << MC_FILT9_LOG2W)
 MC_HD uint32_t mc_filter_hash(uint32_t bucket, uint32_t key)
 {
@@ -974,8 +976,11 @@ MC_HD uint32_t mc_filter_bits(uint32_t h) { return (1u << (h & 31)) | (1u << ((h
 // 0-2 and 7-9) pick a 32-byte line, the wildcard position picks one of its four 64-bit parts, the three remaining middle
 // residues pick one bit in each of the part's two words - so the four questions of a position cost ONE 32-byte read and
 // three operations each.  A negative answer is exact (no 10-mer of the group can match); a positive one sends the group
-// to the pair filter.  2^18 lines = 8 MB.
-#define MC_WILD_LOG2L 18
+// to the pair filter.  2^19 lines = 16 MB (rounds 2 - 4: 2^18 - 92 pair filter asks per read of 150 bp, now 77, and those blocks
+// are cache misses all: seed kernel 6.29 -> 6.16 ms per 1 M reads; 2^20 lines: 6.14).
+#ifndef MC_WILD_LOG2L
+#define MC_WILD_LOG2L 19
+#endif
 #define MC_WILD_LINES (1u << MC_WILD_LOG2L)
 #define MC_WILD_LINE_WORDS 8
 MC_HD uint32_t mc_wild_ctx(uint32_t seed, uint32_t key) { return (seed / 1000u) * 4096u + (key & 0xFFFu); }
@@ -1015,7 +1020,9 @@ MC_HD void mc_wild_set(uint32_t q[2], uint32_t bits) { q[0] |= 1u << (bits & 31u
 // offset, and the context picks three of the twelve bits (the same three in every cell).  An index 10-mer sets its three bits
 // in the cell of its own residue, once per offset; a query reads the block and gets the mask of residues that may complete
 // an index 10-mer with a handful of 64-bit operations.  No false negatives; false positives go through the exact search.
+#ifndef MC_PAIR_LOG2B
 #define MC_PAIR_LOG2B 20
+#endif
 #define MC_PAIR_BLOCKS (1u << MC_PAIR_LOG2B)
 // group g: 0 = offset 4 (bucket digit of stride 10), 1 = offset 5 (stride 1), 2 = offset 3 (stride 100), 3 = offset 6 (first key residue)
 MC_HD uint32_t mc_pair_digit(uint32_t seed, uint32_t key, int g) { return g == 0 ? (seed / 10u) % 10u : g == 1 ? seed % 10u : g == 2 ? (seed / 100u) % 10u : key >> 12; }

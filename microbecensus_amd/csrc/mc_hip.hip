@@ -2,7 +2,7 @@
 // (include/mcensus.h names what each entry point replaces in the reference).  One translation unit; the kernels live in
 //   mc_hip_common.h    includes, counters, wave-level helpers
 //   k_translate_seg.h  A1  six-frame translation + SEG: a wave per 10 reads, the trimming search dealt out over the wave
-//   k_enumerate.h      A2  seed enumeration + index probes: a wave per read, a state machine over per-wave LDS queues (k_enumerate_t0)
+//   k_enumerate.h      A2  seed enumeration + index probes: a wave per read, a state machine over per-wave LDS queues that persist across the reads of a chunk (k_enumerate_q)
 //   k_eval_seeds.h     A3  seed gate, growth, ungapped X-drop: persistent waves, gate and extension as two phases of a wave
 //   k_gapped.h         B   gapped X-drop: one DP per distinct segment, a lane per flank, DP rows packed in LDS
 //   k_order.h          C   HSPs binned per read (no global sort), ordered and stacked for the reads that can print
@@ -498,13 +498,11 @@ static int stage_a(mc_handle *h, McCtx &c)
 #endif
     if (h->fast_enum) {
         // k_enumerate_q (round 5: queues that persist across the reads of a chunk) is the kernel of the product path; the counting form
-        // (mc_set_counting: what the reference would read) stays with k_enumerate_t0<.., true>.  MC_EN_OLD=1: k_enumerate_t0<.., false>, for A/B runs.
-        static const bool en_old = getenv("MC_EN_OLD") != nullptr;
-        const bool enq = !h->count_traffic && !en_old;
-        const size_t per_wave = enq ? MC_ENQ_WAVE_LDS(FP, L) : MC_EN_WAVE_BYTES(h->count_traffic) + MC_EN_WAVE_LDS(FP, L);
-        // Launch shape: the kernel needs 79 VGPRs (6 waves per SIMD) and is bound by instruction issue with some latency left to
-        // hide - measured per 1 M reads of 150 bp: 16 waves per CU 6.77 ms, 20: 6.45, 24 (2 x 12, 3 x 8, 6 x 4 alike): 6.39.
-        // So: as many waves per CU as the LDS holds, up to 24, in workgroups of 12 / 8 / 4 / 16 waves.
+        // (mc_set_counting: what the reference would read) is k_enumerate_count (rounds 2 - 4's one-wave-per-read kernel without filters).
+        const bool enq = !h->count_traffic;
+        const size_t per_wave = enq ? MC_ENQ_WAVE_LDS(FP, L) : sizeof(McEnWave) + MC_EN_WAVE_LDS(FP, L);
+        // Launch shape: 80 VGPRs (6 waves per SIMD); as many waves per CU as the LDS holds, up to 24, in workgroups of 12 / 8 / 4 / 16 waves
+        // (measured per 1 M reads of 150 bp, round 2: 16 waves per CU 6.77 ms, 20: 6.45, 24 - 2 x 12, 3 x 8, 6 x 4 alike -: 6.39).
         int waves = 0, bpc = 1;
         {
             static const int shapes[][2] = {{12, 2}, {8, 3}, {4, 6}, {4, 5}, {16, 1}, {8, 2}, {4, 4}, {12, 1}, {4, 3}, {8, 1}, {4, 2}, {4, 1}};
@@ -514,23 +512,15 @@ static int stage_a(mc_handle *h, McCtx &c)
         if (const char *e = getenv("MC_EN_SHAPE")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 16 || a == 12 || a == 8 || a == 4) && b >= 1 && (size_t)b * (64 + a * per_wave) <= 160 * 1024) { waves = a; bpc = b; } }   // (experiments)
         const size_t lds2 = 64 + waves * per_wave;
         const int blocks = (int)std::min<int64_t>((int64_t)256 * bpc, (n + waves - 1) / waves);
-#define MC_LAUNCH_EN(WV, CNT)                                                                                                                      \
+#define MC_LAUNCH_EN(KERNEL, WV)                                                                                                                   \
     do {                                                                                                                                           \
-        HIPCK(hipFuncSetAttribute((const void *)k_enumerate_t0<WV, CNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                  \
-        k_enumerate_t0<WV, CNT><<<dim3(blocks), dim3(64 * WV), lds2, st>>>(h->d_T, X, h->d_bitmap, c.d_frames, FP, L, n, c.d_tasks, c.cap_tasks, \
-                                                                            c.d_counters, c.d_stats);                                             \
+        HIPCK(hipFuncSetAttribute((const void *)KERNEL<WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                               \
+        KERNEL<WV><<<dim3(blocks), dim3(64 * WV), lds2, st>>>(h->d_T, X, h->d_bitmap, c.d_frames, FP, L, n, c.d_tasks, c.cap_tasks, c.d_counters, \
+                                                              c.d_stats);                                                                         \
     } while (0)
-#define MC_LAUNCH_ENQ(WV)                                                                                                                          \
-    do {                                                                                                                                           \
-        HIPCK(hipFuncSetAttribute((const void *)k_enumerate_q<WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                        \
-        k_enumerate_q<WV><<<dim3(blocks), dim3(64 * WV), lds2, st>>>(h->d_T, X, h->d_bitmap, c.d_frames, FP, L, n, c.d_tasks, c.cap_tasks,        \
-                                                                      c.d_counters, c.d_stats);                                                   \
-    } while (0)
-        if (enq) { if (waves == 16) MC_LAUNCH_ENQ(16); else if (waves == 12) MC_LAUNCH_ENQ(12); else if (waves == 8) MC_LAUNCH_ENQ(8); else MC_LAUNCH_ENQ(4); }
-        else if (h->count_traffic) { if (waves == 16) MC_LAUNCH_EN(16, true); else if (waves == 12) MC_LAUNCH_EN(12, true); else if (waves == 8) MC_LAUNCH_EN(8, true); else MC_LAUNCH_EN(4, true); }
-        else { if (waves == 16) MC_LAUNCH_EN(16, false); else if (waves == 12) MC_LAUNCH_EN(12, false); else if (waves == 8) MC_LAUNCH_EN(8, false); else MC_LAUNCH_EN(4, false); }
+        if (enq) { if (waves == 16) MC_LAUNCH_EN(k_enumerate_q, 16); else if (waves == 12) MC_LAUNCH_EN(k_enumerate_q, 12); else if (waves == 8) MC_LAUNCH_EN(k_enumerate_q, 8); else MC_LAUNCH_EN(k_enumerate_q, 4); }
+        else { if (waves == 16) MC_LAUNCH_EN(k_enumerate_count, 16); else if (waves == 12) MC_LAUNCH_EN(k_enumerate_count, 12); else if (waves == 8) MC_LAUNCH_EN(k_enumerate_count, 8); else MC_LAUNCH_EN(k_enumerate_count, 4); }
 #undef MC_LAUNCH_EN
-#undef MC_LAUNCH_ENQ
     } else
         k_enumerate<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(h->d_T, X, c.d_frames, FP, L, n, c.d_tasks, c.cap_tasks, c.d_counters, c.d_stats);
     HIPCK(hipEventRecord(c.ev[2], st));

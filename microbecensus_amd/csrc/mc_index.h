@@ -399,7 +399,7 @@ inline bool mc_write_rapdb(const McHostIndex &X, const char *path, std::string &
 // file named by a hash of those: header (magic, layout version, the hash, counts), the arrays as they lie in memory, a checksum of
 // the payload.  A file that does not match in every respect is ignored and rebuilt; it is written to a temporary name and renamed.
 #define MC_IXC_MAGIC 0x3158494D434D4D43ull      // "CMMCMIX1"
-#define MC_IXC_VERSION 4u
+#define MC_IXC_VERSION 5u
 inline uint64_t mc_ixc_input_hash(const char *const *names, const char *const *seqs, int nseq)
 {
     uint64_t h = 0xCBF29CE484222325ull ^ (uint64_t)MC_IXC_VERSION;

@@ -147,7 +147,7 @@ static const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12
 // what zlib refuses AND what a real compressor never writes (used while guessing block starts).
 inline bool is_text(int c) { return c < 0x80 && (c >= 0x20 || c == '\n' || c == '\r' || c == '\t'); }
 
-inline bool read_dynamic(Bits &br, LitHuff &lit, DistHuff &dist, bool strict, bool *all_text = nullptr)
+inline bool read_dynamic(Bits &br, LitHuff &lit, DistHuff &dist, bool strict, bool *all_text = nullptr, uint8_t *lens_out = nullptr, int *hlit_out = nullptr, int *hdist_out = nullptr)
 {
     if (!br.need(14)) return false;
     const int hlit = (int)br.peek(5) + 257; br.drop(5);
@@ -181,8 +181,80 @@ inline bool read_dynamic(Bits &br, LitHuff &lit, DistHuff &dist, bool strict, bo
     if (dr != 0) return false;
     if (strict) { int used = 0; for (int i = 0; i < hlit; i++) used += lens[i] != 0; if (used < 3) return false; }
     if (all_text) { bool t = true; for (int i = 0; i < 256; i++) if (lens[i] && !is_text(i)) { t = false; break; } *all_text = t; }   // (a compressor gives codes to the bytes that occur)
+    if (lens_out) { memcpy(lens_out, lens, (size_t)total); *hlit_out = hlit; *hdist_out = hdist; }
     return true;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The tables the block loop of the speculative decoder runs on (round 5; the shape of libdeflate's): one 32-bit entry per code says
+// everything the loop needs - what kind of symbol, how many bits the code takes, the literal or the BASE of the length / distance
+// and how many extra bits follow - so that a symbol costs one table read and no second lookup (rounds 3 - 4: symbol table, then
+// kLenBase / kLenExtra / kDistBase / kDistExtra, a refill test in front of every field).  Codes longer than the primary index go
+// through a second-level table behind the primary one (the bit-by-bit walk of Huff::decode stays for the block HEADERS only).
+//   entry: bits 0..7 bits to drop | 8..12 extra bits | 13..15 kind | 16..31 literal / base / offset of the second-level table
+// ------------------------------------------------------------------------------------------------------------------
+enum { FT_BAD = 0, FT_LIT = 1, FT_LEN = 2, FT_EOB = 3, FT_SUB = 4, FT_DIST = 2 };
+#define MC_FT_KIND(e) (((e) >> 13) & 7u)
+template <int PB, int SUBCAP>
+struct FastTab {
+    uint32_t t[(1 << PB) + SUBCAP];
+    // lens[0 .. n): code lengths (a valid, complete or single-code set: Huff::build has seen them); dist: a distance code.  false:
+    // the second-level tables do not fit (the caller declines the chunk; the sequential path decodes anything)
+    bool build(const uint8_t *lens, int n, bool dist)
+    {
+        uint16_t count[16] = {0}, offs[16], sorted[288];
+        for (int i = 0; i < n; i++) count[lens[i]]++;
+        count[0] = 0;
+        offs[1] = 0;
+        for (int len = 1; len < 15; len++) offs[len + 1] = (uint16_t)(offs[len] + count[len]);
+        for (int i = 0; i < n; i++) if (lens[i]) sorted[offs[lens[i]]++] = (uint16_t)i;
+        memset(t, 0, sizeof(uint32_t) << PB);
+        uint8_t subbits[1 << PB];
+        bool anylong = false;
+        for (int len = PB + 1; len <= 15; len++) if (count[len]) anylong = true;
+        auto entry = [&](int sym) -> uint32_t {
+            if (dist) return sym < 30 ? ((uint32_t)kDistBase[sym] << 16) | ((uint32_t)kDistExtra[sym] << 8) | ((uint32_t)FT_DIST << 13) : 0u;
+            if (sym < 256) return ((uint32_t)sym << 16) | ((uint32_t)FT_LIT << 13);
+            if (sym == 256) return (uint32_t)FT_EOB << 13;
+            return sym - 257 < 29 ? ((uint32_t)kLenBase[sym - 257] << 16) | ((uint32_t)kLenExtra[sym - 257] << 8) | ((uint32_t)FT_LEN << 13) : 0u;
+        };
+        auto reverse = [](uint32_t code, int len) -> uint32_t { uint32_t r = 0; for (int b = 0; b < len; b++) r |= ((code >> b) & 1u) << (len - 1 - b); return r; };
+        uint32_t suboff[1 << PB];
+        if (anylong) {                                               // how wide the second-level table of every primary prefix has to be
+            memset(subbits, 0, sizeof subbits);
+            uint32_t code = 0; int idx = 0;
+            for (int len = 1; len <= 15; len++) {
+                for (int k = 0; k < count[len]; k++, idx++, code++)
+                    if (len > PB) { const uint32_t pre = reverse(code, len) & ((1u << PB) - 1); if (subbits[pre] < len - PB) subbits[pre] = (uint8_t)(len - PB); }
+                code <<= 1;
+            }
+            uint32_t next = 1u << PB;
+            for (uint32_t pre = 0; pre < (1u << PB); pre++)
+                if (subbits[pre]) {
+                    if (next + (1u << subbits[pre]) > (uint32_t)((1 << PB) + SUBCAP)) return false;
+                    suboff[pre] = next;
+                    memset(t + next, 0, sizeof(uint32_t) << subbits[pre]);
+                    t[pre] = (next << 16) | ((uint32_t)subbits[pre] << 8) | ((uint32_t)FT_SUB << 13) | (uint32_t)PB;
+                    next += 1u << subbits[pre];
+                }
+        }
+        uint32_t code = 0; int idx = 0;
+        for (int len = 1; len <= 15; len++) {
+            for (int k = 0; k < count[len]; k++, idx++, code++) {
+                const uint32_t rev = reverse(code, len), e = entry(sorted[idx]);
+                if (len <= PB) { for (uint32_t j = rev; j < (1u << PB); j += 1u << len) t[j] = e | (uint32_t)len; }
+                else {
+                    const uint32_t pre = rev & ((1u << PB) - 1), sb = subbits[pre];
+                    for (uint32_t j = rev >> PB; j < (1u << sb); j += 1u << (len - PB)) t[suboff[pre] + j] = e | (uint32_t)(len - PB);
+                }
+            }
+            code <<= 1;
+        }
+        return true;
+    }
+};
+typedef FastTab<11, 2048> FastLit;
+typedef FastTab<9, 1024> FastDist;
 
 inline void fixed_tables(LitHuff &lit, DistHuff &dist)
 {
