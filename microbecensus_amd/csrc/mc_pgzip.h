@@ -31,6 +31,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <deque>
 #include <functional>
 #include <memory>
@@ -40,6 +41,78 @@
 #include <vector>
 
 namespace mcgz {
+
+// ------------------------------------------------------------------------------------------------------------------
+// CRC-32 (gzip's, reflected 0xEDB88320) by carry-less multiplication: four 16-byte lanes folded per turn, then one, then the Barrett
+// reduction (Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ Instruction", Intel 2009; the constants are
+// x^(512+64), x^512, x^(128+64), x^128, x^64 mod P and floor(x^64 / P) in reflected form).  zlib 1.2.11's crc32 runs at 1 GB/s - a
+// quarter of what a worker spent per chunk once the decoder itself got faster; this one at > 10 GB/s.  Chosen at run time (the CPU
+// must have PCLMULQDQ and SSE4.1; checked once against zlib on a test pattern): crc32_any falls back to zlib's otherwise.
+// ------------------------------------------------------------------------------------------------------------------
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("pclmul,sse4.1"))) inline uint32_t crc32_clmul(uint32_t crc0, const uint8_t *buf, size_t len)
+{   // len >= 64 and a multiple of 16; crc0: the running CRC as zlib hands it out (pre- and post-inverted)
+    const __m128i k1k2 = _mm_set_epi64x(0x01c6e41596ll, 0x0154442bd4ll), k3k4 = _mm_set_epi64x(0x00ccaa009ell, 0x01751997d0ll);
+    const __m128i k5k0 = _mm_set_epi64x(0, 0x0163cd6124ll), poly = _mm_set_epi64x(0x01f7011641ll, 0x01db710641ll);
+    __m128i x0, x1, x2, x3, x4, x5, x6, x7, x8, y5, y6, y7, y8;
+    x1 = _mm_loadu_si128((const __m128i *)(buf + 0x00)); x2 = _mm_loadu_si128((const __m128i *)(buf + 0x10));
+    x3 = _mm_loadu_si128((const __m128i *)(buf + 0x20)); x4 = _mm_loadu_si128((const __m128i *)(buf + 0x30));
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)~crc0));
+    x0 = k1k2;
+    buf += 64; len -= 64;
+    while (len >= 64) {
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x6 = _mm_clmulepi64_si128(x2, x0, 0x00); x7 = _mm_clmulepi64_si128(x3, x0, 0x00); x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x2 = _mm_clmulepi64_si128(x2, x0, 0x11); x3 = _mm_clmulepi64_si128(x3, x0, 0x11); x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+        y5 = _mm_loadu_si128((const __m128i *)(buf + 0x00)); y6 = _mm_loadu_si128((const __m128i *)(buf + 0x10));
+        y7 = _mm_loadu_si128((const __m128i *)(buf + 0x20)); y8 = _mm_loadu_si128((const __m128i *)(buf + 0x30));
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5); x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), y7); x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), y8);
+        buf += 64; len -= 64;
+    }
+    x0 = k3k4;                                                       // four lanes into one
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+    while (len >= 16) {
+        x2 = _mm_loadu_si128((const __m128i *)buf);
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+        buf += 16; len -= 16;
+    }
+    x2 = _mm_clmulepi64_si128(x1, x0, 0x10);                         // 128 -> 64 bits
+    x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+    x1 = _mm_srli_si128(x1, 8); x1 = _mm_xor_si128(x1, x2);
+    x0 = _mm_loadl_epi64(&k5k0);
+    x2 = _mm_srli_si128(x1, 4); x1 = _mm_and_si128(x1, x3); x1 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_xor_si128(x1, x2);
+    x0 = poly;                                                       // Barrett: 64 -> 32 bits
+    x2 = _mm_and_si128(x1, x3); x2 = _mm_clmulepi64_si128(x2, x0, 0x10); x2 = _mm_and_si128(x2, x3); x2 = _mm_clmulepi64_si128(x2, x0, 0x00); x1 = _mm_xor_si128(x1, x2);
+    return ~(uint32_t)_mm_extract_epi32(x1, 1);
+}
+inline bool crc32_clmul_usable()
+{
+    static const bool ok = [] {
+        if (!__builtin_cpu_supports("pclmul") || !__builtin_cpu_supports("sse4.1")) return false;
+        uint8_t t[64 * 5 + 48];
+        for (size_t i = 0; i < sizeof t; i++) t[i] = (uint8_t)(i * 131u + (i >> 3) * 17u + 5u);
+        return crc32_clmul(0x1234ABCDu, t, sizeof t) == (uint32_t)::crc32(0x1234ABCDu, t, (uInt)sizeof t) && crc32_clmul(0, t, 64) == (uint32_t)::crc32(0, t, 64);
+    }();
+    return ok;
+}
+#else
+inline bool crc32_clmul_usable() { return false; }
+inline uint32_t crc32_clmul(uint32_t c, const uint8_t *, size_t) { return c; }
+#endif
+// crc32() of zlib for any length: the bulk by crc32_clmul where the CPU has it
+inline uint32_t crc32_any(uint32_t crc, const uint8_t *p, size_t n)
+{
+    if (n >= 256 && crc32_clmul_usable()) {
+        const size_t bulk = n & ~(size_t)15;
+        for (size_t o = 0; o < bulk;) { const size_t k = bulk - o > ((size_t)1 << 30) ? (size_t)1 << 30 : bulk - o; crc = crc32_clmul(crc, p + o, k); o += k; }
+        p += bulk; n -= bulk;
+    }
+    while (n) { const size_t k = n > ((size_t)1 << 30) ? (size_t)1 << 30 : n; crc = (uint32_t)::crc32(crc, p, (uInt)k); p += k; n -= k; }
+    return crc;
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // bit reader over the mapped file (LSB first, as deflate packs its bits)
@@ -192,8 +265,10 @@ inline bool read_dynamic(Bits &br, LitHuff &lit, DistHuff &dist, bool strict, bo
 // kLenBase / kLenExtra / kDistBase / kDistExtra, a refill test in front of every field).  Codes longer than the primary index go
 // through a second-level table behind the primary one (the bit-by-bit walk of Huff::decode stays for the block HEADERS only).
 //   entry: bits 0..7 bits to drop | 8..12 extra bits | 13..15 kind | 16..31 literal / base / offset of the second-level table
+// TWO literals per lookup where both codes fit the primary index together (FT_LIT2: second literal in bits 24..31) - the bases of a
+// FASTQ file have codes of two or three bits, and the chain lookup -> shift -> lookup is what a literal costs.
 // ------------------------------------------------------------------------------------------------------------------
-enum { FT_BAD = 0, FT_LIT = 1, FT_LEN = 2, FT_EOB = 3, FT_SUB = 4, FT_DIST = 2 };
+enum { FT_BAD = 0, FT_LIT = 1, FT_LEN = 2, FT_LIT2 = 3, FT_EOB = 4, FT_SUB = 6, FT_DIST = 2 };   // (the literal kinds are the odd ones)
 #define MC_FT_KIND(e) (((e) >> 13) & 7u)
 template <int PB, int SUBCAP>
 struct FastTab {
@@ -218,7 +293,11 @@ struct FastTab {
             if (sym == 256) return (uint32_t)FT_EOB << 13;
             return sym - 257 < 29 ? ((uint32_t)kLenBase[sym - 257] << 16) | ((uint32_t)kLenExtra[sym - 257] << 8) | ((uint32_t)FT_LEN << 13) : 0u;
         };
-        auto reverse = [](uint32_t code, int len) -> uint32_t { uint32_t r = 0; for (int b = 0; b < len; b++) r |= ((code >> b) & 1u) << (len - 1 - b); return r; };
+        auto reverse = [](uint32_t code, int len) -> uint32_t {      // the low `len` bits of code, in reverse order
+            uint32_t r = ((code & 0x5555u) << 1) | ((code >> 1) & 0x5555u);
+            r = ((r & 0x3333u) << 2) | ((r >> 2) & 0x3333u); r = ((r & 0x0F0Fu) << 4) | ((r >> 4) & 0x0F0Fu); r = ((r & 0x00FFu) << 8) | (r >> 8);
+            return r >> (16 - len);
+        };
         uint32_t suboff[1 << PB];
         if (anylong) {                                               // how wide the second-level table of every primary prefix has to be
             memset(subbits, 0, sizeof subbits);
@@ -250,6 +329,15 @@ struct FastTab {
             }
             code <<= 1;
         }
+        // pairs of literals: entry i = the literal at i followed by the literal at i >> its length, if that one is decided by the bits left
+        // (from the top down: i >> l1 < i, so the entry looked at is still the single one)
+        if (!dist)
+            for (uint32_t i = (1u << PB) - 1; i > 0; i--) {
+                const uint32_t e = t[i];
+                if (MC_FT_KIND(e) != FT_LIT) continue;
+                const uint32_t l1 = e & 0xFFu, e2 = t[i >> l1];
+                if (MC_FT_KIND(e2) == FT_LIT && l1 + (e2 & 0xFFu) <= (uint32_t)PB) t[i] = (e & 0x00FF0000u) | ((e2 & 0x00FF0000u) << 8) | ((uint32_t)FT_LIT2 << 13) | (l1 + (e2 & 0xFFu));
+            }
         return true;
     }
 };
@@ -307,7 +395,8 @@ struct Chunk {
     bool starts_member = false;                                     // start_bit is the first deflate bit of a gzip member (window empty: no markers)
     bool at_eof = false;                                            // the data ended with this chunk (last member complete)
     bool bad = false; std::string msg;                              // damage met while decoding from a KNOWN position
-    SymBuf sym;                                                     // speculative output (markers)
+    SymBuf sym;                                                     // speculative output (markers): the first sym.size() symbols of the chunk
+    size_t total = 0;                                               // ... of `total`: what lies behind them was decoded straight into bytes (Spec::run)
     std::vector<uint8_t> bytes;                                     // final output
     std::vector<MemberEnd> ends;
     std::vector<uint32_t> seg_crc;                                  // crc of bytes between member ends (ends.size() + 1 segments)
@@ -323,10 +412,108 @@ struct Spec {
     const uint8_t *base, *end;                                      // the whole file
     uint64_t data_end_bit;
     LitHuff lit; DistHuff dist;
+    FastLit flit; FastDist fdist;                                   // the tables the block loop runs on (built per block from the same code lengths)
+    bool fixed_ready = false; FastLit fixed_lit; FastDist fixed_dist;
 
-    // Decodes blocks from `bit` until a block starts at or behind stop_bit (or the data ends).  out: 16-bit symbols.  mstart: index in
-    // out where the current member began (-1: it began in front of the chunk: the window is unknown).  Returns false on anything
-    // that cannot be deflate data (or that a text file would not hold, while the window is unknown).
+    // One Huffman block, from behind its header to its end-of-block code.  The bit buffer is refilled ONCE per turn to at least 56
+    // bits - a literal / length code (15), its extra bits (5), a distance code (15) and its extra bits (13) are 48 - so nothing in a
+    // turn tests for input; up to three literals leave per refill.  Near the end of the file the refill takes what is left and the
+    // turn checks afterwards that it did not consume more than there was (cnt < 0).  Matches are copied 16 bytes at a time
+    // (overlapping allowed from that distance on; the buffer has 320 symbols of slack behind pos).
+    // OT = uint16_t: symbols with markers (the window in front of the chunk is unknown; a back-reference may reach up to 32 KB in
+    // front of the chunk); OT = uint8_t: plain bytes - no reference may reach below `floor` (the start of the member, or of the
+    // marker-free 32 KB the caller switched on).  grow(pos): more room behind pos, returns the (new) base.
+    // CHECK_LIT: a fixed-Huffman block met with an unknown window has a code for every byte - every literal is looked at.
+    template <class OT, bool CHECK_LIT, class GROW>
+    inline bool block(Bits &br, OT *&o, size_t &pos, size_t &cap, long floor, GROW &&grow)
+    {
+        const uint32_t *LT = flit.t, *DT = fdist.t;
+        uint64_t buf = br.buf;
+        int cnt = br.cnt;
+        const uint8_t *p = br.p, *const end8 = br.end - 8;
+        constexpr bool MARKERS = sizeof(OT) == 2;
+        constexpr long WORD = 16 / (long)sizeof(OT);                 // symbols per 16-byte move
+        bool ok = false;
+        for (;;) {
+            if (pos + 320 > cap) o = grow(pos, cap);
+#define MC_GZ_REFILL()                                                                                                   \
+    do {                                                                                                                 \
+        if (p <= end8) { uint64_t w_; memcpy(&w_, p, 8); buf |= w_ << cnt; p += (63 - cnt) >> 3; cnt |= 56; }            \
+        else { while (cnt <= 56 && p < br.end) { buf |= (uint64_t)*p++ << cnt; cnt += 8; } }                             \
+    } while (0)
+            MC_GZ_REFILL();
+            uint32_t e = LT[buf & 0x7FFu];
+            if (e & 0x2000u) {                                       // literals: up to three lookups per refill (each takes at most 11 bits), one or two literals per lookup
+#define MC_GZ_PUT()                                                                                                               \
+    do {                                                                                                                          \
+        if (CHECK_LIT && (!is_text((int)((e >> 16) & 0xFFu)) || ((e & 0x4000u) && !is_text((int)(e >> 24))))) goto done;             \
+        if (MARKERS) { const uint32_t two_ = ((e >> 16) & 0xFFu) | ((e >> 24) << 16); memcpy(o + pos, &two_, 4); }                   \
+        else { const uint16_t two_ = (uint16_t)(e >> 16); memcpy(o + pos, &two_, 2); }                                               \
+        pos += 1u + ((e >> 14) & 1u);                                                                                             \
+        buf >>= (e & 0xFFu); cnt -= (int)(e & 0xFFu);                                                                             \
+    } while (0)
+                MC_GZ_PUT();
+                e = LT[buf & 0x7FFu];
+                if (e & 0x2000u) {
+                    MC_GZ_PUT();
+                    e = LT[buf & 0x7FFu];
+                    if (e & 0x2000u) {
+                        MC_GZ_PUT();
+                        if (cnt < 0) break;
+                        continue;
+                    }
+                }
+                if (cnt < 0) break;
+                MC_GZ_REFILL();                                      // the symbol in e has not been consumed: the same bits are still at the bottom
+            }
+            if (MC_FT_KIND(e) == FT_SUB) {                           // a code longer than 11 bits: the second-level table
+                buf >>= 11; cnt -= 11;
+                e = LT[(e >> 16) + (uint32_t)(buf & ((1u << ((e >> 8) & 31u)) - 1u))];
+            }
+            buf >>= (e & 0xFFu); cnt -= (int)(e & 0xFFu);
+            const uint32_t kind = MC_FT_KIND(e);
+            if (kind == FT_LIT) { if (CHECK_LIT && !is_text((int)(e >> 16))) break; o[pos++] = (OT)(e >> 16); if (cnt < 0) break; continue; }   // (from a second-level table: single)
+            if (kind == FT_EOB) { ok = cnt >= 0; break; }
+            if (kind != FT_LEN) break;                               // no such code
+            const int xl = (int)((e >> 8) & 31u);
+            const int len = (int)(e >> 16) + (int)(buf & ((1u << xl) - 1u));
+            buf >>= xl; cnt -= xl;
+            uint32_t de = DT[buf & 0x1FFu];
+            if (MC_FT_KIND(de) == FT_SUB) { buf >>= 9; cnt -= 9; de = DT[(de >> 16) + (uint32_t)(buf & ((1u << ((de >> 8) & 31u)) - 1u))]; }
+            if (MC_FT_KIND(de) != FT_DIST) break;
+            buf >>= (de & 0xFFu); cnt -= (int)(de & 0xFFu);
+            const int xd = (int)((de >> 8) & 31u);
+            const long d = (long)(de >> 16) + (long)(buf & ((1u << xd) - 1u));
+            buf >>= xd; cnt -= xd;
+            if (cnt < 0) break;
+            long src = (long)pos - d;
+            if (src < floor) break;                                  // (markers: floor = -32768)
+            if (!MARKERS || src >= 0) {
+                OT *dst = o + pos;
+                const OT *sp = o + src;
+                if (d >= WORD) { OT *const de_ = dst + len; do { memcpy(dst, sp, 16); dst += WORD; sp += WORD; } while (dst < de_); }
+                else if (!MARKERS && d >= 8) { OT *const de_ = dst + len; do { memcpy(dst, sp, 8); dst += 8; sp += 8; } while (dst < de_); }
+                else for (int i = 0; i < len; i++) dst[i] = sp[i];
+                pos += (size_t)len;
+            } else {
+                for (int i = 0; i < len; i++, src++) o[pos++] = src < 0 ? (OT)(256 + 32768 + src) : o[src];
+            }
+        }
+    done:
+#undef MC_GZ_REFILL
+#undef MC_GZ_PUT
+        br.buf = buf; br.cnt = cnt; br.p = p;
+        return ok;
+    }
+
+    // Decodes blocks from `bit` until a block starts at or behind stop_bit (or the data ends).  Returns false on anything that cannot
+    // be deflate data (or that a text file would not hold, while the window is unknown).
+    // The output starts as 16-bit symbols with markers (c.sym) - the window in front of the chunk is unknown.  It goes on as PLAIN
+    // BYTES, written straight to their final place in c.bytes, as soon as nothing behind can be a marker any more (round 5; rapidgzip
+    // does the same): when a member starts inside the chunk (or the chunk starts with one: a bgzip file never sees a marker), or
+    // when, at a block boundary, the last 32 KB hold no marker - deflate cannot reach further back.  On FASTQ text that is the case
+    // a few hundred KB into a chunk: the rest is decoded at half the memory traffic and needs no marker replacement.
+    // c.sym.size() = the symbols in front of the switch, c.total = the whole output.
     bool run(uint64_t bit, uint64_t stop_bit, bool member_start, Chunk &c)
     {
         SymBuf &out = c.sym;
@@ -335,14 +522,37 @@ struct Spec {
         out.reserve(cap);
         uint16_t *o = out.data();
         size_t pos = 0;
-        long mstart = member_start ? 0 : -1;
+        bool plain = false;                                          // the output has gone over to bytes
+        size_t nsym = 0, bcap = 0, next_scan = 32768;                // symbols in front of the switch; capacity of c.bytes; where the next look for markers pays
+        uint8_t *ob = nullptr;
+        long floor = -32768;                                         // lowest index a back-reference may reach
+        auto grow16 = [&](size_t at, size_t &cp) -> uint16_t * { cp *= 2; out.reserve(cp, at); return out.data(); };
+        auto grow8 = [&](size_t, size_t &cp) -> uint8_t * { cp *= 2; c.bytes.resize(cp); return c.bytes.data(); };   // (size() == capacity in use: nothing is lost)
+        auto to_plain = [&](size_t keep_from) {                      // bytes [keep_from, pos) are marker-free and may be referenced from now on
+            nsym = pos;
+            bcap = std::max<size_t>(std::max<size_t>(c.bytes.capacity(), cap), pos + (1u << 20));
+            c.bytes.resize(bcap);
+            ob = c.bytes.data();
+            for (size_t k = keep_from; k < pos; k++) ob[k] = (uint8_t)o[k];
+            plain = true; floor = (long)keep_from;
+        };
         Bits br;
         br.init(base, end, bit);
         if (br.cnt < 0) return false;
-        uint32_t crc_dummy = 0; (void)crc_dummy;
+        if (member_start) to_plain(0);
         for (;;) {
             const uint64_t here = br.bitpos();
             if (here >= stop_bit && pos > 0) { c.end_bit = here; break; }
+            if (!plain && pos >= next_scan) {                        // a marker in the last 32 KB?  (looked for from the end: the latest one says when to look again)
+                size_t k = pos;
+                const size_t lo = pos - 32768;
+                while (k > lo) {
+                    if (k - lo >= 8) { uint64_t a, b; memcpy(&a, o + k - 8, 8); memcpy(&b, o + k - 4, 8); if (((a | b) & 0xFF00FF00FF00FF00ull) == 0) { k -= 8; continue; } }
+                    if (o[k - 1] >= 256) break;
+                    k--;
+                }
+                if (k == lo) to_plain(lo); else next_scan = k + 32768;
+            }
             if (!br.need(3)) return false;
             const int bfinal = (int)br.peek(1), btype = (int)(br.peek(3) >> 1);
             br.drop(3);
@@ -356,47 +566,31 @@ struct Spec {
                 // the bytes follow byte-aligned: take them from memory
                 const uint8_t *src = base + (br.bitpos() >> 3);
                 if ((uint64_t)(end - src) < len) return false;
-                if (pos + len + 300 > cap) { cap = std::max(cap * 2, pos + len + 65536); out.reserve(cap, pos); o = out.data(); }
-                for (uint32_t i = 0; i < len; i++) o[pos + i] = src[i];
+                if (plain) {
+                    if (pos + len + 320 > bcap) { bcap = std::max(bcap * 2, pos + len + 65536); c.bytes.resize(bcap); ob = c.bytes.data(); }
+                    memcpy(ob + pos, src, len);
+                } else {
+                    if (pos + len + 320 > cap) { cap = std::max(cap * 2, pos + len + 65536); out.reserve(cap, pos); o = out.data(); }
+                    for (uint32_t i = 0; i < len; i++) o[pos + i] = src[i];
+                }
                 pos += len;
                 br.init(base, end, (uint64_t)(src + len - base) * 8);
             } else {
                 bool all_text = false;
-                if (btype == 1) fixed_tables(lit, dist);
-                else if (!read_dynamic(br, lit, dist, false, &all_text)) return false;
-                if (mstart < 0 && btype == 2 && !all_text) return false;       // not text: left to the sequential path
-                const bool check_lit = mstart < 0 && btype == 1;           // (a fixed-Huffman block has a code for every byte: look at each literal)
-                for (;;) {
-                    if (pos + 300 > cap) { cap *= 2; out.reserve(cap, pos); o = out.data(); }
-                    int sym = lit.decode(br);
-                    if (sym < 0) return false;
-                    if (sym < 256) {
-                        if (check_lit && !is_text(sym)) return false;
-                        o[pos++] = (uint16_t)sym;
-                        continue;
-                    }
-                    if (sym == 256) break;
-                    sym -= 257;
-                    if (sym >= 29) return false;
-                    int len = kLenBase[sym];
-                    const int le = kLenExtra[sym];
-                    if (le) { if (!br.need(le)) return false; len += (int)br.peek(le); br.drop(le); }
-                    const int ds = dist.decode(br);
-                    if (ds < 0 || ds >= 30) return false;
-                    long d = kDistBase[ds];
-                    const int de = kDistExtra[ds];
-                    if (de) { if (!br.need(de)) return false; d += (long)br.peek(de); br.drop(de); }
-                    long src = (long)pos - d;
-                    if (mstart >= 0) { if (src < mstart) return false; }
-                    else if (src < -32768) return false;
-                    if (src >= 0) {
-                        if (d >= len) memcpy(o + pos, o + src, (size_t)len * 2);
-                        else for (int i = 0; i < len; i++) o[pos + i] = o[src + i];
-                        pos += (size_t)len;
-                    } else {
-                        for (int i = 0; i < len; i++, src++) o[pos++] = src < 0 ? (uint16_t)(256 + 32768 + src) : o[src];
-                    }
+                const bool check_lit = !plain && btype == 1;               // (a fixed-Huffman block has a code for every byte: look at each literal)
+                if (btype == 1) {
+                    if (!fixed_ready) { uint8_t l[288], d[30]; for (int i = 0; i < 144; i++) l[i] = 8; for (int i = 144; i < 256; i++) l[i] = 9; for (int i = 256; i < 280; i++) l[i] = 7; for (int i = 280; i < 288; i++) l[i] = 8; for (int i = 0; i < 30; i++) d[i] = 5; if (!fixed_lit.build(l, 288, false) || !fixed_dist.build(d, 30, true)) return false; fixed_ready = true; }
+                    memcpy(flit.t, fixed_lit.t, sizeof(uint32_t) << 11); memcpy(fdist.t, fixed_dist.t, sizeof(uint32_t) << 9);   // (all codes of the fixed block fit the primary tables)
+                } else {
+                    uint8_t lens[286 + 30 + 138];
+                    int hlit = 0, hdist = 0;
+                    if (!read_dynamic(br, lit, dist, false, &all_text, lens, &hlit, &hdist)) return false;
+                    if (!plain && !all_text) return false;                  // not text: left to the sequential path
+                    if (!flit.build(lens, hlit, false) || !fdist.build(lens + hlit, hdist, true)) return false;
                 }
+                const bool okb = plain ? block<uint8_t, false>(br, ob, pos, bcap, floor, grow8)
+                                       : check_lit ? block<uint16_t, true>(br, o, pos, cap, floor, grow16) : block<uint16_t, false>(br, o, pos, cap, floor, grow16);
+                if (!okb) return false;
             }
             if (bfinal) {
                 // end of a member: trailer, then either the end of the data or the next member
@@ -413,10 +607,11 @@ struct Spec {
                 const long h = member_header(t, end);
                 if (h <= 0) return false;                                // (bytes that are no member: gzip.open raises BadGzipFile there - the sequential path reports it)
                 br.init(base, end, (uint64_t)(t + h - base) * 8);
-                mstart = (long)pos;
+                if (!plain) to_plain(pos); else floor = (long)pos;       // a new member: nothing in front of it can be referenced
             }
         }
-        out.n = pos;
+        out.n = plain ? nsym : pos;
+        c.total = pos;
         return true;
     }
 
@@ -594,7 +789,12 @@ public:
     // data: the mapped file [data, data + n); threads >= 2
     ParallelGz(const uint8_t *data, size_t n, int threads, size_t chunk_bytes = (size_t)1 << 20)
         : base_(data), end_(data + n), nthreads_(threads), chunk_bytes_(chunk_bytes) {}
-    ~ParallelGz() { stop(); if (getenv("MC_PGZ_DEBUG")) fprintf(stderr, "pgzip: %zu chunks: %zu speculative, %zu sequential (%zu of them had found no start), %zu skipped\n", chunks_.size(), n_spec_, n_seq_, n_notfound_, n_skip_); }
+    ~ParallelGz()
+    {
+        stop();
+        if (getenv("MC_PGZ_DEBUG")) fprintf(stderr, "pgzip: %zu chunks: %zu speculative, %zu sequential (%zu of them had found no start), %zu skipped; %.1f %% of the speculative output decoded as plain bytes; worker seconds: decode %.3f, markers %.3f, crc %.3f; consumer: sequential decode %.3f, stitching %.3f\n",
+                                            chunks_.size(), n_spec_, n_seq_, n_notfound_, n_skip_, 100.0 * (double)b_plain_ / (double)(b_spec_ ? b_spec_ : 1), t_decode_.load() * 1e-9, t_resolve_.load() * 1e-9, t_crc_.load() * 1e-9, t_seq_ * 1e-9, t_stitch_ * 1e-9);
+    }
 
     // false: not a gzip file this reader handles (the caller falls back to gzread)
     bool start()
@@ -649,6 +849,9 @@ private:
     size_t cur_index_ = 0; Chunk *cur_ = nullptr; size_t cur_off_ = 0; bool cur_failed_ = false;
     size_t stitch_next_ = 0, consume_next_ = 0;                     // next chunk to stitch / to hand to the consumer
     size_t n_spec_ = 0, n_seq_ = 0, n_notfound_ = 0, n_skip_ = 0;
+    std::atomic<uint64_t> t_decode_{0}, t_resolve_{0}, t_crc_{0};   // nanoseconds the workers spent (MC_PGZ_DEBUG prints them)
+    uint64_t t_seq_ = 0, t_stitch_ = 0, b_plain_ = 0, b_spec_ = 0;
+    static uint64_t now_ns() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec; }
     // Buffers of finished chunks are kept and handed to the next ones: a fresh 10 MB buffer is 2,500 page faults, and a dozen threads
     // faulting at once queue up in the kernel (the first 65 MB of a file took 0.85 s instead of 0.13 s).
     std::vector<std::unique_ptr<SymBuf>> pool_sym_;
@@ -684,7 +887,9 @@ private:
             Chunk &c = *chunks_[k];
             take_buffers(c, true);
             const uint64_t stop_bit = k + 1 < chunks_.size() ? chunks_[k + 1]->nominal_bit : sp.data_end_bit;
+            const uint64_t t0 = now_ns();
             c.found = sp.find_and_decode(c.nominal_bit, stop_bit, stop_bit, c);
+            t_decode_ += now_ns() - t0;
             if (!c.found) recycle_sym(c);
             { std::unique_lock<std::mutex> lk(mu_); c.state = 1; cv_done_.notify_all(); }
         }
@@ -726,7 +931,7 @@ private:
             const size_t to = s < c.ends.size() ? (size_t)c.ends[s].out_pos : c.bytes.size();
             const size_t n = to - at;
             if (n) {
-                const uint32_t sc = s < c.seg_crc.size() ? c.seg_crc[s] : (uint32_t)crc32(0, c.bytes.data() + at, (uInt)n);
+                const uint32_t sc = s < c.seg_crc.size() ? c.seg_crc[s] : crc32_any(0, c.bytes.data() + at, n);
                 run_crc_ = run_len_ ? (uint32_t)crc32_combine(run_crc_, sc, (z_off_t)n) : sc;
                 run_len_ += n;
             }
@@ -746,7 +951,7 @@ private:
         for (size_t s = 0; s <= c.ends.size(); s++) {
             const size_t to = s < c.ends.size() ? (size_t)c.ends[s].out_pos : c.bytes.size();
             uint32_t v = 0;
-            for (size_t o = at; o < to; o += (size_t)1 << 30) v = (uint32_t)crc32(v, c.bytes.data() + o, (uInt)std::min<size_t>(to - o, (size_t)1 << 30));
+            v = crc32_any(0, c.bytes.data() + at, to - at);
             c.seg_crc.push_back(v);
             at = to;
         }
@@ -766,32 +971,37 @@ private:
         }
     }
 
-    // markers -> bytes for symbols [from, to) of a chunk whose window is w (wn bytes); false: a marker reaches in front of the member
+    // markers -> bytes for symbols [from, to) of a chunk whose window is w (wn bytes); false: a marker reaches in front of the member.
+    // Through a table of all 256 + 32768 symbol values (byte values as themselves, marker k as byte k of the window, 0xFFFF where the
+    // member has no such byte): one load per symbol and no branch.  The repetitive lines of a FASTQ file (qualities, '+', parts of the
+    // names) stay markers for the whole chunk - each is copied from the record before it - so half of all symbols took the
+    // branch of the per-symbol loop rounds 3 - 4 had behind their 16-at-a-time fast path.
     static bool resolve(const uint16_t *s, uint8_t *o, size_t from, size_t to, const uint8_t *w, size_t wn)
     {
-        size_t i = from;
-#if defined(__SSE2__)
-        const __m128i hi = _mm_set1_epi16((short)0xFF00);
-        while (i + 16 <= to) {                                       // 16 symbols at a time while none of them is a marker
-            const __m128i a = _mm_loadu_si128((const __m128i *)(s + i)), b = _mm_loadu_si128((const __m128i *)(s + i + 8));
-            if (_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_and_si128(_mm_or_si128(a, b), hi), _mm_setzero_si128())) != 0xFFFF) {
-                for (size_t e = i + 16; i < e; i++) {
-                    const uint16_t v = s[i];
-                    if (v < 256) o[i] = (uint8_t)v;
-                    else { const size_t j = (size_t)v - 256; if (j + wn < 32768) return false; o[i] = w[j + wn - 32768]; }
-                }
-                continue;
+        if (to - from < 4096) {                                      // (the 32 KB tail in front of a short stretch: not worth a table)
+            for (size_t i = from; i < to; i++) {
+                const uint16_t v = s[i];
+                if (v < 256) o[i] = (uint8_t)v;
+                else { const size_t j = (size_t)v - 256; if (j + wn < 32768) return false; o[i] = w[j + wn - 32768]; }
             }
-            _mm_storeu_si128((__m128i *)(o + i), _mm_packus_epi16(a, b));
-            i += 16;
+            return true;
         }
-#endif
-        for (; i < to; i++) {
-            const uint16_t v = s[i];
-            if (v < 256) o[i] = (uint8_t)v;
-            else { const size_t j = (size_t)v - 256; if (j + wn < 32768) return false; o[i] = w[j + wn - 32768]; }
+        std::unique_ptr<uint16_t[]> lut(new uint16_t[256 + 32768]);
+        for (int v = 0; v < 256; v++) lut[v] = (uint16_t)v;
+        const size_t miss = 32768 - wn;                              // markers below this index point in front of the member
+        for (size_t j = 0; j < miss; j++) lut[256 + j] = 0xFFFF;
+        for (size_t j = miss; j < 32768; j++) lut[256 + j] = w[j - miss];
+        uint32_t bad = 0;
+        size_t i = from;
+        for (; i + 8 <= to; i += 8) {
+            const uint32_t a = lut[s[i]], b = lut[s[i + 1]], c = lut[s[i + 2]], d = lut[s[i + 3]], e = lut[s[i + 4]], f = lut[s[i + 5]], g = lut[s[i + 6]], h = lut[s[i + 7]];
+            bad |= a | b | c | d | e | f | g | h;
+            const uint64_t out8 = (uint64_t)(a & 255u) | ((uint64_t)(b & 255u) << 8) | ((uint64_t)(c & 255u) << 16) | ((uint64_t)(d & 255u) << 24) | ((uint64_t)(e & 255u) << 32) |
+                                  ((uint64_t)(f & 255u) << 40) | ((uint64_t)(g & 255u) << 48) | ((uint64_t)(h & 255u) << 56);
+            memcpy(o + i, &out8, 8);
         }
-        return true;
+        for (; i < to; i++) { const uint32_t a = lut[s[i]]; bad |= a; o[i] = (uint8_t)a; }
+        return (bad >> 8) == 0;
     }
 
     // Stitches the decoded chunks in file order as far as they are ready (at most `ahead` chunks in front of the consumer): checks
@@ -820,12 +1030,12 @@ private:
             if (getenv("MC_PGZ_DEBUG2")) fprintf(stderr, "chunk %zu nominal %llu from %llu found %d start %llu member %d at_member_start %d\n", k, (unsigned long long)c.nominal_bit, (unsigned long long)from, (int)c.found, (unsigned long long)c.start_bit, (int)c.starts_member, (int)at_member_start_);
             if (usable) {
                 // the window behind this chunk needs its last 32 KB only: replaced here; the rest (and the CRC) is a job
-                const size_t n = c.sym.size();
+                const size_t n = c.total, ns = c.sym.size();                 // the first ns symbols may hold markers, the rest are bytes already
                 std::shared_ptr<std::vector<uint8_t>> w(new std::vector<uint8_t>(c.starts_member ? std::vector<uint8_t>() : window_));
                 c.bytes.resize(n);
                 const size_t tail = n > 32768 ? n - 32768 : 0;
                 size_t mfrom = c.ends.empty() ? 0 : (size_t)c.ends.back().out_pos;      // the current member's part of the chunk
-                if (!resolve(c.sym.data(), c.bytes.data(), std::max(tail, mfrom), n, w->data(), w->size())) usable = false;
+                if (std::max(tail, mfrom) < ns && !resolve(c.sym.data(), c.bytes.data(), std::max(tail, mfrom), ns, w->data(), w->size())) usable = false;
                 else {
                     std::vector<uint8_t> nw;
                     if (!c.ends.empty()) window_.clear();
@@ -835,10 +1045,13 @@ private:
                     Chunk *cp = &c;
                     std::unique_lock<std::mutex> lk(mu_);
                     jobs_.push_back([this, cp, w] {
+                        const uint64_t t0 = now_ns();
                         const bool ok = resolve(cp->sym.data(), cp->bytes.data(), 0, cp->sym.size(), w->data(), w->size());
                         recycle_sym(*cp);
                         if (!ok) { cp->bad = true; cp->msg = "invalid distance too far back"; cp->bytes.clear(); cp->ends.clear(); }
+                        const uint64_t t1 = now_ns();
                         seg_crcs(*cp);
+                        t_resolve_ += t1 - t0; t_crc_ += now_ns() - t1;
                         std::unique_lock<std::mutex> lk2(mu_);
                         cp->state = 2;
                         cv_done_.notify_all();
@@ -846,13 +1059,15 @@ private:
                     cv_work_.notify_all();
                 }
             }
-            if (usable) n_spec_++; else { n_seq_++; if (k > 0 && !c.found) n_notfound_++; }
+            if (usable) { n_spec_++; b_spec_ += c.total; b_plain_ += c.total - c.sym.size(); } else { n_seq_++; if (k > 0 && !c.found) n_notfound_++; }
             if (!usable) {                                               // the sequential path: from the known position with the known window
                 recycle_sym(c);
                 if (k == 0) take_buffers(c, false);
                 c.ends.clear(); c.at_eof = false;
+                const uint64_t t0 = now_ns();
                 decode_known(base_, end_, from, stop_bit, at_member_start_ ? nullptr : window_.data(), at_member_start_ ? 0 : window_.size(), c);
                 seg_crcs(c);
+                t_seq_ += now_ns() - t0;
                 update_window(c);
                 std::unique_lock<std::mutex> lk(mu_);
                 c.state = 2;

@@ -318,11 +318,13 @@ struct Stream {
             }
         }
         if (t_range_lo >= 0 && !ranged) { r_err = std::string("a byte window needs a plain regular file: ") + path; close(); return false; }
-        if (compressed) {
+        if (compressed && !pgz) {
             if (t_peek) peek_blocks = 8;
             for (auto &r : ring) r.resize(BLK);
             th = std::thread([this] { produce(); });
         }
+        // (the parallel inflate has its own workers running ahead of the reader: its bytes are taken straight into the window - extend() -
+        // without a producer thread and a ring in between; round 5: one copy of every byte less, a third of the consumer's time)
         return true;
     }
     void close()
@@ -389,7 +391,21 @@ struct Stream {
             if (len == have) at_end = true;
             return;
         }
-        while (len < want && !at_end) {
+        while (pgz && len < want && !at_end) {
+            const double c0 = now();
+            const size_t n = BLK;
+            if (buf_at + len + n > buf.size()) {                         // make room: move the window to the front, grow if needed
+                if (buf_at) { memmove(buf.data(), buf.data() + buf_at, len); buf_at = 0; }
+                if (len + n > buf.size()) buf.resize(std::max(len + n, buf.size() * 2));
+            }
+            bool bad = false;
+            std::string msg;
+            const int got = pgz->read(buf.data() + buf_at + len, (int)n, &bad, &msg);
+            if (got > 0) len += (size_t)got;
+            if (got < (int)n) { at_end = true; failed = bad; prod_err = bad; prod_msg = msg; }
+            t_ext_copy += now() - c0;
+        }
+        while (!pgz && len < want && !at_end) {
             const double w0 = now();
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [this] { return count > 0 || prod_done; });

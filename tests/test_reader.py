@@ -408,3 +408,49 @@ def test_quality_offset_of_a_fasta_record_is_left_to_python(tmp_path):
     from microbecensus_amd import _native
     p = tmp_path / "x.fa"; p.write_text(">a\nACGT\n>b\nACGT\n")
     assert _native.quality_offset(str(p)) is None
+
+
+def test_inflate_tables_and_byte_mode_against_zlib(tmp_path):
+    """The block decoder of the parallel inflate (csrc/mc_pgzip.h, round 5: one-entry-per-code tables with a second level, two
+    literals per lookup, plain-byte output once no marker can follow, CRC-32 by carry-less multiplication) against zlib on streams
+    made to reach its corners - through tools/pgz_bench.cpp, which prints the CRC-32 and the length of what the reader delivers:
+    text over alphabets of 4 .. 90 letters with skewed frequencies (codes of up to 15 bits: second-level tables), every zlib
+    strategy (fixed-Huffman blocks, Huffman only, RLE: distances of 1 .. 7), levels 1 / 6 / 9, members concatenated inside a
+    chunk, repetitive lines whose markers never die out and noisy ones where the output goes over to bytes, at chunk sizes of
+    4 KB .. 1 MB with 1 .. 6 workers."""
+    import gzip
+    import random
+    import subprocess
+    import zlib
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "pgz_bench")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(repo, "tools", "pgz_bench.cpp"), "-lz", "-pthread"])
+    rng = random.Random(20261003)
+    texts = {}
+    for nletters in (4, 20, 90):
+        letters = [chr(33 + i) for i in range(nletters)]
+        weights = [1.0 / (1 + i) ** 2.2 for i in range(nletters)]             # a few frequent letters, a long tail: long codes
+        lines = []
+        for i in range(9000):
+            lines.append("".join(rng.choices(letters, weights, k=rng.randint(20, 160))))
+            if i % 3 == 0:
+                lines.append(lines[-1][: rng.randint(1, 20)] * rng.randint(1, 6))        # repeats at short distances
+            if i % 7 == 0:
+                lines.append("I" * 150)                                          # a line every copy of which is a copy of the one before
+        texts["a%d" % nletters] = ("\n".join(lines) + "\n").encode()
+    texts["fastq"] = _fastq_text(5000, 3)
+    files = {}
+    for name, text in texts.items():
+        for lvl, strat, tag in ((1, zlib.Z_DEFAULT_STRATEGY, "l1"), (6, zlib.Z_DEFAULT_STRATEGY, "l6"), (9, zlib.Z_DEFAULT_STRATEGY, "l9"), (6, zlib.Z_FIXED, "fixed"),
+                                (6, zlib.Z_HUFFMAN_ONLY, "huff"), (6, zlib.Z_RLE, "rle"), (6, zlib.Z_FILTERED, "filt")):
+            co = zlib.compressobj(lvl, zlib.DEFLATED, 31, 8, strat)
+            files["%s_%s" % (name, tag)] = (co.compress(text) + co.flush(), text)
+    both = texts["a20"] + texts["fastq"]                                         # members that begin and end inside the chunks, at changing levels
+    files["members"] = (b"".join(gzip.compress(both[i:i + 70000], 1 + (k % 9)) for k, i in enumerate(range(0, len(both), 70000))), both)
+    for name, (blob, text) in files.items():
+        p = str(tmp_path / (name + ".gz"))
+        open(p, "wb").write(blob)
+        want = "crc32 %08x" % zlib.crc32(text)
+        for threads, chunk in ((1, 4096), (3, 20000), (6, 1 << 20)):
+            out = subprocess.run([exe, p, str(threads), str(chunk), "1"], stdout=subprocess.PIPE, check=True).stdout.decode()
+            assert (" %d bytes " % len(text)) in out and want in out and "BAD" not in out, (name, threads, chunk, out)
