@@ -388,6 +388,32 @@ struct SymBuf {                                                    // 16-bit sym
     void swap(SymBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
 };
 
+// The bytes of a chunk: like std::vector<uint8_t> for what this file does with it, but resize() never writes - a vector zero-fills
+// what it grows by, 5 MB per chunk on the ONE thread that stitches the chunks (the reader's; round 5: that thread, not the
+// workers, bounded the sampling rate of a .gz file beyond 8 workers).
+struct ByteBuf {
+    uint8_t *p = nullptr; size_t n = 0, cap = 0;
+    ByteBuf() {}
+    ~ByteBuf() { free(p); }
+    ByteBuf(const ByteBuf &) = delete;
+    ByteBuf &operator=(const ByteBuf &) = delete;
+    ByteBuf(ByteBuf &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+    uint8_t *data() { return p; }
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+    size_t capacity() const { return cap; }
+    void clear() { n = 0; }
+    void resize(size_t m)                                            // (what lay in [0, min(n, m)) stays)
+    {
+        if (m > cap) { uint8_t *q = (uint8_t *)malloc(m ? m : 1); if (n) memcpy(q, p, n); free(p); p = q; cap = m; }
+        n = m;
+    }
+    void swap(ByteBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
+    void drop() { free(p); p = nullptr; n = cap = 0; }
+    const uint8_t *begin() const { return p; }
+    const uint8_t *end() const { return p + n; }
+};
+
 struct Chunk {
     uint64_t nominal_bit = 0;                                       // where the search for its first block started
     uint64_t start_bit = 0, end_bit = 0;                            // first block decoded / first bit behind the last one
@@ -397,7 +423,7 @@ struct Chunk {
     bool bad = false; std::string msg;                              // damage met while decoding from a KNOWN position
     SymBuf sym;                                                     // speculative output (markers): the first sym.size() symbols of the chunk
     size_t total = 0;                                               // ... of `total`: what lies behind them was decoded straight into bytes (Spec::run)
-    std::vector<uint8_t> bytes;                                     // final output
+    ByteBuf bytes;                                                  // final output
     std::vector<MemberEnd> ends;
     std::vector<uint32_t> seg_crc;                                  // crc of bytes between member ends (ends.size() + 1 segments)
     bool have_bytes = false, skipped = false;                      // skipped: the chunk in front of it covered it entirely
@@ -659,7 +685,7 @@ struct Spec {
 inline void decode_known(const uint8_t *base, const uint8_t *end, uint64_t bit, uint64_t stop_bit, const uint8_t *window, size_t window_n, Chunk &c)
 {
     c.bytes.clear(); c.ends.clear(); c.bad = false; c.at_eof = false;
-    std::vector<uint8_t> &out = c.bytes;
+    ByteBuf &out = c.bytes;
     size_t cap = std::max<size_t>(out.capacity(), 1u << 20);
     out.resize(cap);
     size_t pos = 0;
@@ -855,7 +881,7 @@ private:
     // Buffers of finished chunks are kept and handed to the next ones: a fresh 10 MB buffer is 2,500 page faults, and a dozen threads
     // faulting at once queue up in the kernel (the first 65 MB of a file took 0.85 s instead of 0.13 s).
     std::vector<std::unique_ptr<SymBuf>> pool_sym_;
-    std::vector<std::vector<uint8_t>> pool_bytes_;
+    std::vector<ByteBuf> pool_bytes_;
     bool stitch_stop_ = false;                                      // the data ends (or is damaged) in the last stitched chunk
     uint64_t stitched_end_bit_ = 0;
     bool at_member_start_ = true;                                   // the stitched position is the first deflate bit of a member
@@ -904,7 +930,7 @@ private:
             std::unique_lock<std::mutex> lk(mu_);
             if (pool_bytes_.size() < 4 * (size_t)nthreads_) { pool_bytes_.emplace_back(); pool_bytes_.back().swap(c.bytes); }
         }
-        std::vector<uint8_t>().swap(c.bytes);
+        c.bytes.drop();
     }
     void recycle_sym(Chunk &c)
     {
@@ -1039,7 +1065,7 @@ private:
                 else {
                     std::vector<uint8_t> nw;
                     if (!c.ends.empty()) window_.clear();
-                    if (n - mfrom >= 32768) nw.assign(c.bytes.begin() + (long)(n - 32768), c.bytes.end());
+                    if (n - mfrom >= 32768) nw.assign(c.bytes.begin() + (long)(n - 32768), c.bytes.end());   // (the tail has just been resolved above)
                     else { nw = window_; nw.insert(nw.end(), c.bytes.begin() + (long)mfrom, c.bytes.end()); if (nw.size() > 32768) nw.erase(nw.begin(), nw.end() - 32768); }
                     window_.swap(nw);
                     Chunk *cp = &c;
