@@ -14,8 +14,10 @@ struct DevEmit {
         uint32_t b0 = X->bstart[bucket];
         for (int i = 0; i < cnt; i++) {
             McSeedTask t;
-            t.read = read; t.chrono = MC_CHRONO(frame, pos, phase, nst + i); t.posting = X->post[b0 + nst + i];
-            t.seedlen_nkey = MC_TASK_W3(X->off[t.posting >> 11] + (t.posting & 0x7ff), seedlen, nkey);
+            t.chrono = MC_CHRONO(frame, pos, phase, nst + i); t.posting = X->post[b0 + nst + i];
+            const uint32_t o0 = X->off[t.posting >> 11], o1 = X->off[(t.posting >> 11) + 1], abs = o0 + (t.posting & 0x7ff);
+            t.read = MC_TASK_READ(read, o1 - abs);
+            t.seedlen_nkey = MC_TASK_W3(abs, seedlen, nkey);
             tasks[base + i] = t;
         }
     }
@@ -115,17 +117,19 @@ __device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long
     // markers, and a lane that wrote such a range alone would keep the other 63 waiting.
     if (cnt > 0 && cnt <= MC_EN_SHORT) {
         const uint32_t sn = phase == 0 ? MC_TASK_W3(0, 9, 3) : MC_TASK_W3(0, 10, 4);
-        uint32_t pst[MC_EN_SHORT], ofs[MC_EN_SHORT];   // the postings and the subjects' offsets first, then the stores: a store between two loads orders them (the pointers may alias)
+        uint32_t pst[MC_EN_SHORT];
+        uint2 ofs[MC_EN_SHORT];   // the postings and the subjects' two offsets (one load) first, then the stores: a store between two loads orders them (the pointers may alias)
 #pragma unroll
         for (int i = 0; i < MC_EN_SHORT; i++) pst[i] = X.post[start + (uint32_t)nst + (uint32_t)(i < cnt ? i : 0)];
 #pragma unroll
-        for (int i = 0; i < MC_EN_SHORT; i++) ofs[i] = X.off[pst[i] >> 11];
+        for (int i = 0; i < MC_EN_SHORT; i++) __builtin_memcpy(&ofs[i], X.off + (pst[i] >> 11), 8);
 #pragma unroll
         for (int i = 0; i < MC_EN_SHORT; i++)
             if (i < cnt) {
                 McSeedTask t;
-                t.read = myread; t.chrono = MC_CHRONO(frame, pos, phase, (uint32_t)nst + (uint32_t)i); t.posting = pst[i];
-                t.seedlen_nkey = sn | (ofs[i] + (pst[i] & 0x7ffu));
+                const uint32_t abs = ofs[i].x + (pst[i] & 0x7ffu);
+                t.read = MC_TASK_READ(myread, ofs[i].y - abs); t.chrono = MC_CHRONO(frame, pos, phase, (uint32_t)nst + (uint32_t)i); t.posting = pst[i];
+                t.seedlen_nkey = sn | abs;
                 tasks[base + excl + (uint32_t)i] = t;
             }
     }
@@ -158,7 +162,7 @@ __device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long
                     rd[u] = TAGGED ? read + ((oh >> 25) & 15u) : read;
                 }
 #pragma unroll
-                for (int u = 0; u < 2; u++) snk[u] |= X.off[pst[u] >> 11] + (pst[u] & 0x7ffu);
+                for (int u = 0; u < 2; u++) { uint2 of; __builtin_memcpy(&of, X.off + (pst[u] >> 11), 8); const uint32_t abs = of.x + (pst[u] & 0x7ffu); snk[u] |= abs; rd[u] = MC_TASK_READ(rd[u], of.y - abs); }
 #pragma unroll
                 for (int u = 0; u < 2; u++)
                     if (in[u]) {

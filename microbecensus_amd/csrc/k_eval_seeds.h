@@ -190,8 +190,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
     uint32_t cur = (blockIdx.x * (MC_EV_BS / 64) + (uint32_t)wv) * MC_EV_GROUP, cleft = MC_EV_GROUP - 1, pend = 0;
     // The chain of dependent reads of a hit was: its record -> the subject's offsets -> the residue in front of the seed -> the
     // seed's residues, four trips to the L2 before the gate.  Now: the record of the NEXT chunk is fetched while this one is
-    // evaluated, the record carries the hit's position in the residue array (MC_TASK_W3), and the subject's end, the residues in
-    // front of the seed and the seed's own ten are read together: one trip.
+    // evaluated, the record carries the hit's position in the residue array (MC_TASK_W3) and what is left of the subject behind it
+    // (MC_TASK_READ), and the residues in front of the seed and the seed's own ten are read together: one trip, residues only.
 #ifdef MC_EXP_TIMING
     unsigned long long ev_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ev_last_ = __builtin_readcyclecounter();
 #endif
@@ -221,13 +221,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
                 const int qlen = (L - frame % 3) / 3;
                 const uint32_t w3 = t.seedlen_nkey;
                 const int seedlen = (int)((w3 >> 24) & 15u), nkey = (int)(w3 >> 28), dpos = (int)(t.posting & 0x7ffu), sidx = (int)(t.posting >> 11);
-                const uint32_t o0 = (w3 & 0xFFFFFFu) - (uint32_t)dpos;
-                const uint8_t *q = frames + ((int64_t)t.read * 6 + frame) * FP, *d = X.res + o0;
-                const uint32_t o1 = X.off[sidx + 1];
+                const uint32_t o0 = (w3 & 0xFFFFFFu) - (uint32_t)dpos, rd = MC_TASK_READ_OF(t.read);
+                const uint8_t *q = frames + ((int64_t)rd * 6 + frame) * FP, *d = X.res + o0;
                 // residues pos - 8 .. pos + 15 of the frame and dpos - 8 .. dpos + 15 of the subject: six loads, one trip (rows and residue array have room on both sides)
                 const uint64_t q0 = mc_ld8(q + pos - 8), q1 = mc_ld8(q + pos), q2 = mc_ld8(q + pos + 8), d0 = mc_ld8(d + dpos - 8), d1 = mc_ld8(d + dpos), d2 = mc_ld8(d + dpos + 8);
                 const int qm1 = (int)(q0 >> 56), dm1 = (int)(d0 >> 56);
-                const int dlen = (int)(o1 - o0);
+                const int dlen = dpos + (int)MC_TASK_REM_OF(t.read);          // (the record carries what is left of the subject: no trip to its offsets)
                 int score = 0, ident = 0;
 #pragma unroll
                 for (int k = 0; k < 10; k++)
@@ -238,7 +237,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
                 const bool go = !(dpos + seedlen > dlen) && !(pos != 0 && dpos != 0 && hot.grp[qm1] == hot.grp[dm1] && nkey != 4);
                 int qp = 0, dp = 0, Lg = 0;
                 if (go) surv = mc_ev_gate(hot, q, qlen, pos, d, dlen, dpos, seedlen, score, ident, qp, dp, Lg, q0, q2, d0, d2);
-                e0.x = t.read; e0.y = t.chrono; e0.z = o0; e0.w = (uint32_t)sidx;
+                e0.x = rd; e0.y = t.chrono; e0.z = o0; e0.w = (uint32_t)sidx;
                 e1.x = (uint32_t)qp | ((uint32_t)dp << 16); e1.y = (uint32_t)Lg | ((uint32_t)(uint16_t)(int16_t)score << 16); e1.z = (uint32_t)ident | ((uint32_t)dlen << 16);
             }
             const unsigned long long ms = __ballot(surv);

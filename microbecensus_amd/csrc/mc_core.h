@@ -97,6 +97,13 @@ struct McSeedTask {
 // database has 5.5 M residues; mc_set_db refuses one past 16 M), so that the evaluation reads the subject's residues without
 // first fetching the subject's offset; seed length and number of key residues above it.
 #define MC_TASK_W3(abs, seedlen, nkey) ((uint32_t)(abs) | ((uint32_t)(seedlen) << 24) | ((uint32_t)(nkey) << 28))
+// ... and, in the kernels' records, the upper 11 bits of `read` hold what is left of the subject from the hit's position on (its length
+// minus the position: 1 .. 2047) - the seed kernel has the subject's two offsets in one load, and the evaluation kernel then reads
+// nothing of the index but residues (round 5: one scattered line less per hit; it is bound by the lines its CU's L1 has to fetch)
+#define MC_TASK_READ(r, rem) ((uint32_t)(r) | ((uint32_t)(rem) << 21))
+#define MC_TASK_READ_OF(w) ((w) & 0x1FFFFFu)
+#define MC_TASK_REM_OF(w) ((w) >> 21)
+static_assert(MC_TASK_READ_OF(0xFFFFFFFFu) == 0x1FFFFFu, "the padding record (read = all ones) is no read of a batch: a batch holds at most 2,097,151 reads");
 #define MC_TASK_ABS_LIMIT (1u << 24)
 
 // seed hit whose ungapped score reached the gapped trigger (AlignSeqs 0x4134c8)

@@ -501,12 +501,16 @@ static int stage_a(mc_handle *h, McCtx &c)
         // (mc_set_counting: what the reference would read) is k_enumerate_count (rounds 2 - 4's one-wave-per-read kernel without filters).
         const bool enq = !h->count_traffic;
         const size_t per_wave = enq ? MC_ENQ_WAVE_LDS(FP, L) : sizeof(McEnWave) + MC_EN_WAVE_LDS(FP, L);
-        // Launch shape: 80 VGPRs (6 waves per SIMD); as many waves per CU as the LDS holds, up to 24, in workgroups of 12 / 8 / 4 / 16 waves
-        // (measured per 1 M reads of 150 bp, round 2: 16 waves per CU 6.77 ms, 20: 6.45, 24 - 2 x 12, 3 x 8, 6 x 4 alike -: 6.39).
+        // Launch shape.  k_enumerate_q: SIXTEEN waves per CU (2 workgroups of 8) where the LDS holds them - the kernel is bound by the
+        // scattered lines its CU's vector L1 has to fetch, not by issue or latency, and more resident waves only thrash
+        // that cache: per 1 M reads of 100 / 150 / 300 bp 24 (20 at 300 bp) waves 3.85 / 6.23 / 13.29 ms, 16 waves 3.77 / 6.11 / 13.21.
+        // The counting form (rounds 2 - 4's kernel, issue bound): as many as fit, up to 24 (16 waves 6.77 ms, 20: 6.45, 24: 6.39).
         int waves = 0, bpc = 1;
         {
-            static const int shapes[][2] = {{12, 2}, {8, 3}, {4, 6}, {4, 5}, {16, 1}, {8, 2}, {4, 4}, {12, 1}, {4, 3}, {8, 1}, {4, 2}, {4, 1}};
-            for (const auto &sh : shapes) if (!waves && (size_t)sh[1] * (64 + sh[0] * per_wave) <= 160 * 1024) { waves = sh[0]; bpc = sh[1]; }
+            static const int shapes_q[][2] = {{8, 2}, {4, 4}, {16, 1}, {12, 1}, {4, 3}, {8, 1}, {4, 2}, {4, 1}};
+            static const int shapes_c[][2] = {{12, 2}, {8, 3}, {4, 6}, {4, 5}, {16, 1}, {8, 2}, {4, 4}, {12, 1}, {4, 3}, {8, 1}, {4, 2}, {4, 1}};
+            if (enq) { for (const auto &sh : shapes_q) if (!waves && (size_t)sh[1] * (64 + sh[0] * per_wave) <= 160 * 1024) { waves = sh[0]; bpc = sh[1]; } }
+            else for (const auto &sh : shapes_c) if (!waves && (size_t)sh[1] * (64 + sh[0] * per_wave) <= 160 * 1024) { waves = sh[0]; bpc = sh[1]; }
         }
         if (!waves) { g_err = "reads too long for the seed kernel's LDS layout"; return -1; }
         if (const char *e = getenv("MC_EN_SHAPE")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 16 || a == 12 || a == 8 || a == 4) && b >= 1 && (size_t)b * (64 + a * per_wave) <= 160 * 1024) { waves = a; bpc = b; } }   // (experiments)

@@ -185,9 +185,10 @@ def test_every_stage_equals_the_emulation(case, engine, tmp_path):
     assert len(tg) == len(te) == st["seed_tasks"] and len(te) > 1000
     off = engine.index_view()["off"].astype(np.int64)
     norm_e = np.stack([te["read"], te["chrono"], te["posting"], te["w3"] & 0xFF, te["w3"] >> 8], 1).astype(np.int64)
-    norm_g = np.stack([tg["read"], tg["chrono"], tg["posting"], (tg["w3"] >> 24) & 15, tg["w3"] >> 28], 1).astype(np.int64)
+    norm_g = np.stack([tg["read"] & 0x1FFFFF, tg["chrono"], tg["posting"], (tg["w3"] >> 24) & 15, tg["w3"] >> 28], 1).astype(np.int64)
     assert np.array_equal(norm_e[np.lexsort(norm_e.T[::-1])], norm_g[np.lexsort(norm_g.T[::-1])])
     assert np.array_equal((tg["w3"] & 0xFFFFFF).astype(np.int64), off[tg["posting"] >> 11] + (tg["posting"] & 0x7FF))
+    assert np.array_equal((tg["read"] >> 21).astype(np.int64), off[(tg["posting"] >> 11) + 1] - off[tg["posting"] >> 11] - (tg["posting"] & 0x7FF))   # what is left of the subject (MC_TASK_READ)
     # ---- gap tasks
     gap_dt = np.dtype({"names": ["read", "chrono", "sidx", "qp", "dp", "L", "qfwd", "qbwd", "score", "nmatch"],
                        "formats": ["<u4", "<u4", "<u4", "<i2", "<i2", "<i2", "<i2", "<i2", "<i2", "<i2"], "offsets": [0, 4, 8, 12, 14, 16, 18, 20, 22, 24], "itemsize": 28})
