@@ -411,6 +411,7 @@ def main():
     ap.add_argument("--no-ags-check", action="store_true", help="skip the run_pipeline AGS comparison on the reference's own inputs")
     ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the end-to-end (file -> AGS) measurement (plain FASTQ; a fifth of it, at least 4 M, for .gz); 0 = skip")
     ap.add_argument("--no-best-only-leg", action="store_true", help="skip the extra timed leg with mc_set_best_hits_only (what run_pipeline runs)")
+    ap.add_argument("--no-reference-pattern", action="store_true", help="skip the untimed launch of the counting form of the seed kernel (roofline.reference_pattern); the profiling tools do")
     ap.add_argument("--one-at-a-time", action="store_true", help="mc_run_range per step (the device idles while the host sums the best hits up) instead of mc_range_end / mc_range_begin / results")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL, one GPU per rank (the measurement); gloo: all ranks on GPU 0, reductions on the host - "
                                                                                "only to exercise the N > 1 code path on a one-GPU box")
@@ -565,7 +566,7 @@ def main():
     # seed of every seed hit (4 + 4 + 12 B); the frames once (6 x L/3 B).  ONE untimed launch of the counting form of the seed kernel
     # (mc_set_counting: it searches every probe the reference searches instead of asking its filters, and counts) on batch 0.
     ref_pattern = None
-    if rank == 0:
+    if rank == 0 and not args.no_reference_pattern:
         eng.set_counting(True)
         eng.run_range(0, args.batch, first_read_id=0)
         cst = eng.stats()
