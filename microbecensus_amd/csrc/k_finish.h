@@ -208,6 +208,7 @@ __device__ __forceinline__ void mc_heapw_sort(uint32_t *hw, int n)
 // Same scratch layout and same results as k_finish.
 #ifdef MC_EXP_TIMING
 __device__ unsigned long long g_fh_acc[8], g_fh_cnt[8];
+__device__ unsigned long long g_fh_worst[12];   // the slowest read of the launches: cycles << 20 | stacked HSPs (atomicMax), then its cycles by phase
 #define MC_FH_TICK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane == 0) { fh_acc_[fcat_] += now_ - flast_; fh_acc_[8 + fcat_] += 1; } flast_ = now_; fcat_ = (k); } while (0)
 #else
 #define MC_FH_TICK(k) do { } while (0)
@@ -371,6 +372,11 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
     unsigned long long flast_ = __builtin_readcyclecounter(); int fcat_ = 7;   // 0 group starts 1 groups 2 scan, items 3 sort 4 threshold, ranks 5 heap sort 6 rows 7 other
 #endif
     for (uint32_t bi = blockIdx.x; bi < nheavy; bi += gridDim.x) {
+#ifdef MC_EXP_TIMING
+        unsigned long long rd0_[8];
+        for (int k = 0; k < 8; k++) rd0_[k] = fh_acc_[k];
+        __syncthreads();
+#endif
         MC_FH_TICK(0);
         const uint32_t slot = list[bi];                               // position in the list of all heavy reads (heavy_first)
         const uint32_t s = heavy_first[slot] & 0x7FFFFFFFu, a = heads[s], b = heads[s + 1];
@@ -470,6 +476,15 @@ __global__ void __launch_bounds__(64) k_finish_heavy(const McTables *__restrict_
         if (lane == 0) { nrow_of[s] = (uint32_t)nrows; heavy_first[slot] = s | 0x80000000u; }   // (the flag: heap sort and rows still to come)
         __syncthreads();
         MC_FH_TICK(7);
+#ifdef MC_EXP_TIMING
+        if (lane == 0) {   // the slowest read of the launch decides how long the launch lasts: which one, and where its time went
+            unsigned long long tot = 0;
+            for (int k = 0; k < 8; k++) tot += fh_acc_[k] - rd0_[k];
+            const unsigned long long mine = (tot << 20) | (unsigned long long)(n & 0xFFFFF);
+            if (atomicMax(&g_fh_worst[0], mine) < mine) for (int k = 0; k < 8; k++) g_fh_worst[1 + k] = fh_acc_[k] - rd0_[k];   // (racy among near-equal maxima: a development aid)
+        }
+        __syncthreads();
+#endif
     }
 #ifdef MC_EXP_TIMING
     MC_FH_TICK(7);

@@ -105,9 +105,9 @@ struct McLinkItem { uint64_t w; };
 #define MC_LK_QAAS(x) ((int)(((x).w >> 44) & 0xFFu))
 #define MC_LK_FRAME(x) ((int)(((x).w >> 52) & 0xFu))             // (bits 62, 63: the HSP carries the log E of its strand's chain)
 MC_HD bool mc_hless(const McLinkItem &a, const McLinkItem &b, int key) { return key == 1 ? MC_LK_FRAME(a) < MC_LK_FRAME(b) : MC_LK_QAAS(a) < MC_LK_QAAS(b); }
-MC_HDN int mc_sum_evalue(const McTables &T, McHsp *v, int st, int ed, int subj_len, McHsp *tmp)
+MC_HDN int mc_sum_evalue(const McTables &T, McHsp *v, int st, int ed, int subj_len, McHsp *__restrict__ tmp)
 {
-    McHsp *a = v + st;
+    McHsp *__restrict__ a = v + st;                                 // (v and tmp never overlap: said so, or every copy below waits for the store before it)
     const int n = ed - st;
     int part, nres = 0;
     MC_FG_BEGIN;
@@ -127,10 +127,26 @@ MC_HDN int mc_sum_evalue(const McTables &T, McHsp *v, int st, int ed, int subj_l
             if (gn == 1) { if (T.loge_thr > T.loge_r[MC_LK_SCORE(g[0])]) res[nres++] = g[0]; continue; }
             MC_FG_TICK(5);
             mc_std_sort(g, gn, 2);
-            for (long i = 1; i < gn; ++i) {   // std::stable_sort(CompEvalueObj): any stable sort produces the same permutation
-                const McLinkItem val = g[i]; long j = i;
-                while (j > 0 && MC_LK_SCORE(val) > MC_LK_SCORE(g[j - 1])) { g[j] = g[j - 1]; --j; }
-                g[j] = val;
+            // std::stable_sort(CompEvalueObj): any stable sort produces the same permutation.  Insertion for the short strands; a bottom-up
+            // merge sort (scratch: `chosen`, not in use yet) for the long ones - a subject with 150 HSPs on a strand is 5,600 dependent moves
+            // of an insertion sort for the one lane of k_finish_heavy that has it (round 5)
+            if (gn <= 12) {
+                for (long i = 1; i < gn; ++i) {
+                    const McLinkItem val = g[i]; long j = i;
+                    while (j > 0 && MC_LK_SCORE(val) > MC_LK_SCORE(g[j - 1])) { g[j] = g[j - 1]; --j; }
+                    g[j] = val;
+                }
+            } else {
+                for (int w = 1; w < gn; w *= 2) {
+                    for (int lo = 0; lo < gn; lo += 2 * w) {
+                        const int mid = lo + w < gn ? lo + w : gn, hi = lo + 2 * w < gn ? lo + 2 * w : gn;
+                        int x = lo, y = mid, o = lo;
+                        while (x < mid && y < hi) { if (MC_LK_SCORE(g[y]) > MC_LK_SCORE(g[x])) chosen[o++] = g[y++]; else chosen[o++] = g[x++]; }   // (on a tie the left one first: stable)
+                        while (x < mid) chosen[o++] = g[x++];
+                        while (y < hi) chosen[o++] = g[y++];
+                    }
+                    for (int i = 0; i < gn; i++) g[i] = chosen[i];
+                }
             }
             MC_FG_TICK(2);
             chosen[nc++] = g[0];
@@ -168,8 +184,17 @@ MC_HDN int mc_sum_evalue(const McTables &T, McHsp *v, int st, int ed, int subj_l
     bool moved = nout != n;
     for (int i = 0; i < n && !moved; i++) moved = MC_LK_IDX(out[i]) != i || (out[i].w >> 62) != 0;
     if (moved) {
-        for (int i = 0; i < n; i++) tmp[i] = a[i];
-        for (int i = 0; i < nout; i++) {
+        int i = 0;
+        for (; i + 2 <= n; i += 2) { const McHsp r0 = a[i], r1 = a[i + 1]; tmp[i] = r0; tmp[i + 1] = r1; }   // (two records' loads in flight per turn)
+        for (; i < n; i++) tmp[i] = a[i];
+        for (i = 0; i + 2 <= nout; i += 2) {
+            const uint64_t w0 = out[i].w, w1 = out[i + 1].w;
+            McHsp h0 = tmp[w0 & 0xFFFFFu], h1 = tmp[w1 & 0xFFFFFu];
+            if (w0 >> 62) h0.loge = le_pass[(w0 >> 63) & 1];
+            if (w1 >> 62) h1.loge = le_pass[(w1 >> 63) & 1];
+            a[i] = h0; a[i + 1] = h1;
+        }
+        for (; i < nout; i++) {
             McHsp h = tmp[MC_LK_IDX(out[i])];
             if (out[i].w >> 62) h.loge = le_pass[(out[i].w >> 63) & 1];
             a[i] = h;

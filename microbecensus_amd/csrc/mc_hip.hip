@@ -652,7 +652,10 @@ static int stage_d(mc_handle *h, McCtx &c)
             HIPCK(hipFuncSetAttribute((const void *)k_finish_heavy<MC_FH_N3, C_HEAVY3, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
             HIPCK(hipStreamWaitEvent(c.side, c.ev_fork, 0));
             HIPCK(hipStreamWaitEvent(c.side2, c.ev_fork, 0));
-            // the two kernels of the larger reads (few reads, long chains, a fraction of the GPU) beside the first one
+            // the two kernels of the larger reads (few reads, long chains, a fraction of the GPU) beside the first one.  (Round 5, kernel trace:
+            // second + third, 0.84 ms per 1 M reads, is the longer chain in front of MergeRes' heap sort; the third in front of the thread-per-read
+            // kernels on this stream, or in front of the first on its stream, made the stage 0.1 - 0.2 ms LONGER - whatever runs behind the
+            // third waits for its few long reads, and they hold 135 KB of a CU's LDS each.)
             const unsigned wpc2 = (unsigned)std::min<size_t>(8, std::max<size_t>(1, (size_t)(158 * 1024) / (l2 + 1024)));   // waves per CU the LDS holds
             k_finish_heavy<MC_FH_N2, C_HEAVY2, -1><<<dim3(256 * wpc2), dim3(64), l2, c.side2>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
                                                                                             c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy2, nullptr);
@@ -715,6 +718,15 @@ static int stage_d(mc_handle *h, McCtx &c)
         }
         const char *nm[8] = {"group starts", "groups", "scan, items", "sort", "threshold, ranks", "heap sort", "rows", "other"};
         for (int k = 0; k < 8; k++) fprintf(stderr, "fh-timing %-17s total %9.1f Mcycles %9llu entries\n", nm[k], acc[k] / 1e6, cnt[k]);
+        {
+            unsigned long long w[12];
+            HIPCK(hipMemcpyFromSymbol(w, HIP_SYMBOL(g_fh_worst), sizeof w));
+            fprintf(stderr, "fh-worst read: %llu stacked HSPs, %.3f Mcycles:", w[0] & 0xFFFFF, (double)(w[0] >> 20) / 1e6);
+            for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.3f", nm[k], (double)w[1 + k] / 1e6);
+            fprintf(stderr, "\n");
+            unsigned long long z12[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_fh_worst), z12, sizeof z12));
+        }
         unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_fh_acc), z, sizeof z)); HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_fh_cnt), z, sizeof z));
     }
