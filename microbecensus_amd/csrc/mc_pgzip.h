@@ -440,6 +440,7 @@ struct Spec {
     LitHuff lit; DistHuff dist;
     FastLit flit; FastDist fdist;                                   // the tables the block loop runs on (built per block from the same code lengths)
     bool fixed_ready = false; FastLit fixed_lit; FastDist fixed_dist;
+    bool allow_plain = true;                                        // (tools/pgz_bench.cpp measures the symbol form alone with this off)
 
     // One Huffman block, from behind its header to its end-of-block code.  The bit buffer is refilled ONCE per turn to at least 56
     // bits - a literal / length code (15), its extra bits (5), a distance code (15) and its extra bits (13) are 48 - so nothing in a
@@ -569,7 +570,7 @@ struct Spec {
         for (;;) {
             const uint64_t here = br.bitpos();
             if (here >= stop_bit && pos > 0) { c.end_bit = here; break; }
-            if (!plain && pos >= next_scan) {                        // a marker in the last 32 KB?  (looked for from the end: the latest one says when to look again)
+            if (!plain && allow_plain && pos >= next_scan) {                        // a marker in the last 32 KB?  (looked for from the end: the latest one says when to look again)
                 size_t k = pos;
                 const size_t lo = pos - 32768;
                 while (k > lo) {
@@ -818,8 +819,8 @@ public:
     ~ParallelGz()
     {
         stop();
-        if (getenv("MC_PGZ_DEBUG")) fprintf(stderr, "pgzip: %zu chunks: %zu speculative, %zu sequential (%zu of them had found no start), %zu skipped; %.1f %% of the speculative output decoded as plain bytes; worker seconds: decode %.3f, markers %.3f, crc %.3f; consumer: sequential decode %.3f, stitching %.3f\n",
-                                            chunks_.size(), n_spec_, n_seq_, n_notfound_, n_skip_, 100.0 * (double)b_plain_ / (double)(b_spec_ ? b_spec_ : 1), t_decode_.load() * 1e-9, t_resolve_.load() * 1e-9, t_crc_.load() * 1e-9, t_seq_ * 1e-9, t_stitch_ * 1e-9);
+        if (getenv("MC_PGZ_DEBUG")) fprintf(stderr, "pgzip: %zu chunks: %zu speculative, %zu sequential (%zu of them had found no start), %zu skipped; %.1f %% of the speculative output decoded as plain bytes; worker seconds: decode %.3f, markers %.3f, crc %.3f; consumer: sequential decode %.3f, copies to the reader %.3f, waiting for chunks %.3f\n",
+                                            chunks_.size(), n_spec_, n_seq_, n_notfound_, n_skip_, 100.0 * (double)b_plain_ / (double)(b_spec_ ? b_spec_ : 1), t_decode_.load() * 1e-9, t_resolve_.load() * 1e-9, t_crc_.load() * 1e-9, t_seq_ * 1e-9, t_copy_ * 1e-9, t_wait_ * 1e-9);
     }
 
     // false: not a gzip file this reader handles (the caller falls back to gzread)
@@ -847,7 +848,9 @@ public:
         while (got < n) {
             if (cur_ && cur_off_ < cur_->bytes.size()) {
                 const size_t k = std::min<size_t>((size_t)(n - got), cur_->bytes.size() - cur_off_);
+                const uint64_t t0 = dbg_ ? now_ns() : 0;
                 memcpy(dst + got, cur_->bytes.data() + cur_off_, k);
+                if (dbg_) t_copy_ += now_ns() - t0;
                 cur_off_ += k; got += (int)k;
                 continue;
             }
@@ -876,7 +879,8 @@ private:
     size_t stitch_next_ = 0, consume_next_ = 0;                     // next chunk to stitch / to hand to the consumer
     size_t n_spec_ = 0, n_seq_ = 0, n_notfound_ = 0, n_skip_ = 0;
     std::atomic<uint64_t> t_decode_{0}, t_resolve_{0}, t_crc_{0};   // nanoseconds the workers spent (MC_PGZ_DEBUG prints them)
-    uint64_t t_seq_ = 0, t_stitch_ = 0, b_plain_ = 0, b_spec_ = 0;
+    uint64_t t_seq_ = 0, b_plain_ = 0, b_spec_ = 0, t_copy_ = 0, t_wait_ = 0;
+    const bool dbg_ = getenv("MC_PGZ_DEBUG") != nullptr;
     static uint64_t now_ns() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec; }
     // Buffers of finished chunks are kept and handed to the next ones: a fresh 10 MB buffer is 2,500 page faults, and a dozen threads
     // faulting at once queue up in the kernel (the first 65 MB of a file took 0.85 s instead of 0.13 s).
@@ -1117,7 +1121,7 @@ private:
         }
         stitch(k);
         Chunk &c = *chunks_[k];
-        { std::unique_lock<std::mutex> lk(mu_); cv_done_.wait(lk, [&] { return c.state >= 2; }); }
+        { const uint64_t t0 = dbg_ ? now_ns() : 0; std::unique_lock<std::mutex> lk(mu_); cv_done_.wait(lk, [&] { return c.state >= 2; }); if (dbg_) t_wait_ += now_ns() - t0; }
         consume_next_ = k + 1;
         if (c.skipped) return true;
         const uint64_t data_bits = (uint64_t)(end_ - base_) * 8;
