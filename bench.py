@@ -672,7 +672,11 @@ def main():
                        # HIP events on the library's own streams around each stage, timed region (one kernel at a time)
                        "kernel_ms_per_step": {k: round(v / K, 3) for k, v in kern.items()},
                        "sum_kernel_ms_per_step": round(sum(kern.values()) / K, 3)},
-            "roofline": {"kernel": dom, "bound": (d_dom or {}).get("bound", "valu_issue"), "nominal_bound": "hbm",
+            "roofline": {"kernel": dom, "bound": ("fabric" if dom == "k_enumerate" else (d_dom or {}).get("bound", "valu_issue")), "bound_by_counter_fractions": (d_dom or {}).get("bound"), "nominal_bound": "hbm",
+                         "bound_evidence": ("round 5 (DESIGN.md 5.6): the seed kernel with a fifth fewer instructions (k_enumerate_q: 2.01 G VALU + 1.18 G SALU per 1 M reads against "
+                                            "2.58 G + 1.62 G) runs as long as before; with the whole index in the L2 a quarter shorter; at 16 instead of 24 waves per CU slightly shorter - "
+                                            "it is bound by the scattered cache lines its CUs fetch (about 650 per read of 150 bp; fabric_frac: 0.47 - 0.91 of 8 TB/s of L2-miss traffic), not by "
+                                            "issue (bound_by_counter_fractions is only the largest of the counter fractions) and not by latency" if dom == "k_enumerate" else None),
                          "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                          "traffic": (None if traffic_dom is None else round(traffic_dom, 0)),
                          "fabric_frac": (d_dom or {}).get("fabric_frac"), "fabric_frac_lower": (d_dom or {}).get("fabric_frac_lower"), "issue_frac": (d_dom or {}).get("issue_frac"),
