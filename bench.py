@@ -117,6 +117,59 @@ def load_profile(L):
     return prof
 
 
+def gather_ceiling():
+    """The newest committed calibration of the machine's SCATTERED-LINE rate (profiles/rNN_gather_ceiling.json, made by
+    tools/gather_ceiling.sh on the GPU box): G lines/s by footprint and item width, at 16 waves per CU (the figures do not move with
+    8 or 32 waves per CU, with one or eight asks in flight per lane, or when every ask depends on the one before).  None when absent."""
+    import glob
+    cal = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_gather_ceiling.json")))
+    if not cal:
+        return None
+    try:
+        rows = json.load(open(cal[-1]))["rows"]
+        rate = {(r["footprint"], r["bytes"]): r["g_lines_per_s"] for r in rows if r["kind"] == "gather" and r["waves_per_cu"] == 16}
+        mix = [r["g_lines_per_s"] for r in rows if r["kind"] == "seed_mix_cascade" and r["waves_per_cu"] == 16]
+        return {"file": os.path.basename(cal[-1]), "rate": rate, "mix": (mix[0] if mix else None)}
+    except Exception as e:
+        sys.stderr.write("bench.py: %s unreadable: %s\n" % (cal[-1], e))
+        return None
+
+
+def seed_line_model(cal, L, n_batch, asks, hits, seed_ms):
+    """What the seed kernel's own asks cost at the calibrated scattered-line rates, structure by structure: every ask
+    is one aligned item = one line asked of the level its structure lives in.  items per read x 1 / rate(footprint class, item width),
+    summed, against the kernel's measured duration.  The structures' sizes are those of the marker database (118 MB of index)."""
+    if cal is None or seed_ms <= 0:
+        return None
+    positions = sum(max(0, (L - f) // 3 - 6) for f in (0, 1, 2)) * 2          # seed positions of the six frames: each asks the bucket bitmap once
+    per_read = [   # (structure, footprint class of the calibration, item bytes, asks per read)
+        ("bucket bitmap 125 KB", "128KB", 4, float(positions)),
+        ("9-mer filter 1 MB", "1MB", 4, asks["seed_exact_asks"] / n_batch),
+        ("wildcard filter 16 MB", "16MB", 32, asks["seed_wild_asks"] / n_batch),
+        ("pair filter 16 MB", "16MB", 16, asks["seed_pair_asks"] / n_batch),
+        ("bucket records 32 MB", "32MB", 16, asks["seed_probes"] / n_batch),
+        ("key groups 7 - 11 MB / range table (44 % of the probes: the others find an empty group)", "8MB", 16, 0.44 * asks["seed_probes"] / n_batch),
+        ("postings 14 - 22 MB (at most one line per hit: the postings of a range are consecutive)", "16MB", 4, hits / n_batch),
+        ("subject offsets 67 KB", "128KB", 4, hits / n_batch),
+    ]
+    rows, t = [], 0.0
+    for name, foot, width, n in per_read:
+        r = cal["rate"].get((foot, width))
+        if not r:
+            return None
+        ms = n * n_batch / (r * 1e9) * 1e3
+        t += ms
+        rows.append({"structure": name, "asks_per_read": round(n, 1), "g_lines_per_s_at_that_footprint": r, "ms_per_launch": round(ms, 3)})
+    lines = sum(x[3] for x in per_read)
+    return {"calibration": cal["file"], "lines_asked_per_read": round(lines, 1), "achieved_g_lines_per_s": round(lines * n_batch / (seed_ms * 1e-3) / 1e9, 1),
+            "ceiling_of_the_seed_mix_g_lines_per_s": cal["mix"], "model_ms_per_launch": round(t, 3), "measured_ms_per_launch": round(seed_ms, 3),
+            "frac": round(t / seed_ms, 3), "by_structure": rows,
+            "note": "frac = the time the machine needs for these asks at its measured scattered-line rates (each structure alone in the caches: the optimistic case) / the "
+                    "seed kernel's measured time. About 1 means the kernel runs at the rate the memory system delivers scattered lines at - fewer or more local lines are "
+                    "the only way down, not more lanes, waves or asks in flight (the calibration's rates are the same at 8, 16 and 32 waves per CU, with 1 or 8 asks in "
+                    "flight per lane, and for a chain of dependent asks); above 1: asks of one wave that fall into the same line are counted once each"}
+
+
 def stage_counters(prof, stage):
     """Sums the per-launch counters of the kernels of a stage (one launch of each per pass of the pipeline over the profiled batch;
     a kernel launched several times per pass counts with its number of calls per pass)."""
@@ -681,6 +734,7 @@ def main():
                          "traffic": (None if traffic_dom is None else round(traffic_dom, 0)),
                          "fabric_frac": (d_dom or {}).get("fabric_frac"), "fabric_frac_lower": (d_dom or {}).get("fabric_frac_lower"), "issue_frac": (d_dom or {}).get("issue_frac"),
                          "issue_roofline": (d_dom or {}).get("issue_roofline"), "reference_pattern": ref_pattern,
+                         "scattered_line_ceiling": seed_line_model(gather_ceiling(), L, n_batch, asks, hits, kseq["k_enumerate"]),
                          "salu_frac": (d_dom or {}).get("salu_frac"), "wait_frac": (d_dom or {}).get("wait_frac"), "wave_residency": (d_dom or {}).get("wave_residency"),
                          "valu_lanes_of_64": (d_dom or {}).get("valu_lanes_of_64"), "l2_hit_rate": (d_dom or {}).get("l2_hit_rate"),
                          "kernel_ms_per_step": round(kseq[dom], 3), "algorithmic_bytes_per_read": round(per_launch[dom] / n_batch, 1),

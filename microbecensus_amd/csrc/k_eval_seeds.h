@@ -197,7 +197,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
 #endif
     McSeedTask tn;
     tn.read = MC_TASK_NONE; tn.chrono = 0; tn.posting = 0; tn.seedlen_nkey = 0;
-    if ((uint64_t)cur * 64 + (uint32_t)lane < ntasks) tn = tasks[(uint64_t)cur * 64 + (uint32_t)lane];
+    if ((uint64_t)cur * 64 + (uint32_t)lane < ntasks) tn = mc_load_stream(&tasks[(uint64_t)cur * 64 + (uint32_t)lane]);
     for (;;) {
         const bool last = cur >= nchunks;
         if (!last) {   // ---- phase 1: the gate, one hit per lane
@@ -211,7 +211,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
                 else { nxt = (nwaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)pend)) * MC_EV_GROUP; cleft = MC_EV_GROUP - 1; }
                 const uint64_t nx = (uint64_t)nxt * 64 + (uint32_t)lane;
                 tn.read = MC_TASK_NONE;
-                if (nx < ntasks) tn = tasks[nx];
+                if (nx < ntasks) tn = mc_load_stream(&tasks[nx]);
                 cur = nxt;
             }
             bool surv = false;
@@ -275,12 +275,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
             if (mh && ok) {
                 const uint32_t slot = mc_ev_slots((uint32_t)__popcll(mh), (uint32_t)__popcll(mh & lt), cap_hsps, &counters[C_HSPS], hb_base, hb_used, &ok, lane);
                 if (!ok) { if (lane == 0) counters[C_OVERFLOW] = 2; }
-                else if (keep) { hsps[slot] = h; hkeys[slot] = MC_HSP_KEY(h); hplace[slot] = MC_HSP_PLACE(h); }
+                else if (keep) { mc_store_stream(&hsps[slot], h); __builtin_nontemporal_store(MC_HSP_KEY(h), &hkeys[slot]); __builtin_nontemporal_store(MC_HSP_PLACE(h), &hplace[slot]); }
             }
             if (mg && ok) {
                 const uint32_t slot = mc_ev_slots((uint32_t)__popcll(mg), (uint32_t)__popcll(mg & lt), cap_gaps, &counters[C_GAPS], gb_base, gb_used, &ok, lane);
                 if (!ok) { if (lane == 0) counters[C_OVERFLOW] = 3; }
-                else if (rc == 2) gaps[slot] = g;
+                else if (rc == 2) mc_store_stream(&gaps[slot], g);
             }
             MC_EV_TICK(4);
         }

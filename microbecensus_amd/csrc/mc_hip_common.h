@@ -59,6 +59,36 @@ __device__ __forceinline__ uint32_t mc_wave_scan_add(uint32_t v)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
     return v;
 }
+// Streaming records (read once, or written once for a later kernel) go past the caches' keep lists - "nontemporal" loads and stores -,
+// so that the lines a gather kernel comes back to (the subjects' residues in k_eval_seeds: 3.7 MB, an L2's worth) stay in the L2.
+// Round 5, per 1 M reads of 150 bp: k_eval_seeds 2.50 -> 2.45 ms with the loads of the seed hits alone, 2.45 with the stores of HSPs
+// and gap tasks alone, 2.40 with both; the seed kernel's own stores of the hits: 6.12 -> 6.14 (left as plain stores - its L2 misses
+// are index lines by the hundred per read, the hits are 3 % of its fills).  T: a record of 4-byte words.
+typedef uint32_t mc_u32x4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ void mc_store_stream(T *dst, const T &v)
+{
+    static_assert(sizeof(T) % 4 == 0, "records of 4-byte words");
+    uint32_t w[sizeof(T) / 4];
+    __builtin_memcpy(w, &v, sizeof(T));
+    uint32_t *d = (uint32_t *)dst;
+    if (sizeof(T) % 16 == 0) {
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(T) / 16; i++) { mc_u32x4 x = { w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3] }; __builtin_nontemporal_store(x, (mc_u32x4 *)(d + 4 * i)); }
+    } else {
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(T) / 4; i++) __builtin_nontemporal_store(w[i], d + i);
+    }
+}
+template <typename T> __device__ __forceinline__ T mc_load_stream(const T *src)
+{
+    static_assert(sizeof(T) % 16 == 0, "records of 16-byte words");
+    T v;
+    uint32_t w[sizeof(T) / 4];
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) { const mc_u32x4 x = __builtin_nontemporal_load((const mc_u32x4 *)src + i); w[4 * i] = x.x; w[4 * i + 1] = x.y; w[4 * i + 2] = x.z; w[4 * i + 3] = x.w; }
+    __builtin_memcpy(&v, w, sizeof(T));
+    return v;
+}
 __device__ __forceinline__ void mc_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 // one atomic per wave: the lanes with want == true receive consecutive slots of a global counter
