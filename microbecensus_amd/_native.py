@@ -4,6 +4,7 @@ import ctypes as C
 import gzip
 import json
 import os
+import sys
 
 import numpy as np
 
@@ -42,6 +43,25 @@ BEST_DTYPE = np.dtype([("read", "<i4"), ("family", "<i4"), ("aln", "<i4"), ("tar
 _lib = None
 
 
+def _share_hip_runtime():
+    """One HIP runtime per process.  A PyTorch-ROCm wheel brings its own copy of libamdhip64 (file name libamdhip64.so, SONAME
+    libamdhip64.so.7); this library needs libamdhip64.so.7.  With torch imported first the loader hands this library torch's copy (the
+    SONAME matches) and all is well; the other way round torch asks for "libamdhip64.so", which matches nothing loaded, gets its own
+    copy beside the system's, and the second runtime fails to initialise the GPU.  So: where a torch with a HIP
+    runtime of its own is installed and not yet imported, that copy is loaded first and both use it - in whatever order the application
+    then imports them.  MCENSUS_HIP_RUNTIME=system in the environment: leave it to the loader."""
+    if os.environ.get("MCENSUS_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec is not None and spec.origin else None
+        if cand and os.path.isfile(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:                                   # (no torch, or one without a runtime of its own: the system's it is)
+        pass
+
+
 def load_library():
     """Load libmcensus_hip.so and declare the prototypes of include/mcensus.h."""
     global _lib
@@ -50,6 +70,7 @@ def load_library():
     path = os.environ.get("MCENSUS_LIB", LIB_PATH)      # development: an alternative build of the same library
     if not os.path.isfile(path):
         raise RuntimeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+    _share_hip_runtime()
     lib = C.CDLL(path)
     lib.mc_last_error.restype = C.c_char_p
     lib.mc_device_count.restype = C.c_int

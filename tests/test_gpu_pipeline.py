@@ -339,7 +339,7 @@ def test_best_hits_only_differential_on_genome_reads(engine):
     from microbecensus_amd import _native, synth
     model = _native.load_model()
     fams = model["families"]
-    gen = synth.GenomeReads(device="cpu", seed=20261001)           # (torch's own HIP runtime cannot be initialised beside the engine's in one process)
+    gen = synth.GenomeReads(device="cpu", seed=20261001)           # (generated on the host: the test is about the engine)
     reads = gen.single(1_000_000, 150, first=7_000_000).numpy()
     engine.set_run(150, model["pars"]["150"], fams)
     _, full = engine.search(reads)
@@ -352,3 +352,46 @@ def test_best_hits_only_differential_on_genome_reads(engine):
     assert len(full) > 4000 and len(rows) == 0
     assert only.dtype == full.dtype and len(only) == len(full) and (only == full).all()
     assert st["classified"] == len(full) and st["hsps"] > 10 * len(reads)        # (every HSP is still made and counted; few are ranked)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["engine_first", "torch_first"])
+def test_engine_and_torch_share_one_hip_runtime(order):
+    """The engine and PyTorch-ROCm in one process, in either order of first use (with the engine first, torch's
+    bundled copy of the HIP runtime came up beside the system's and could not initialise the GPU): _native._share_hip_runtime.
+    A fresh process each; the engine's result must be the golden one and torch must compute on the GPU."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import gzip, json, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+order = %r
+def torch_part():
+    import torch
+    x = torch.arange(1024, device="cuda:0", dtype=torch.float32)
+    assert float((x * 2).sum().item()) == 1023.0 * 1024.0
+def engine_part():
+    from microbecensus_amd import _native
+    gold = os.path.join(%r, "tests", "golden")
+    g = json.load(open(os.path.join(gold, "config1_example_fq.json")))
+    seqs = [l.rstrip(b"\r\n") for l in gzip.open(os.path.join(gold, "config1_example_fq.reads.fa.gz"), "rb") if not l.startswith(b">")]
+    reads = np.frombuffer(b"".join(seqs), dtype=np.uint8).reshape(len(seqs), len(seqs[0]))
+    model = _native.load_model()
+    eng = _native.Engine(device=0)
+    eng.set_run(reads.shape[1], model["pars"][str(reads.shape[1])], model["families"])
+    rows, best = eng.search(reads)
+    assert len(rows) == g["m8_rows"], (len(rows), g["m8_rows"])
+    eng.close()
+if order == "engine_first":
+    engine_part(); torch_part(); engine_part()
+else:
+    torch_part(); engine_part(); torch_part()
+maps = open("/proc/self/maps").read()
+copies = sorted({l.split()[-1] for l in maps.splitlines() if "libamdhip64" in l})
+assert len(copies) == 1, copies
+print("OK", copies[0])
+''' % (repo, order, repo)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0 and b"OK" in r.stdout, (r.stdout.decode()[-2000:], r.stderr.decode()[-3000:])
