@@ -2,6 +2,7 @@
 // microbe_census.py:432-460): a thread per read (k_finish) or a wave per read (k_finish_heavy, k_heap_lanes, k_heavy_rows), rows out.
 #pragma once
 #include "mc_hip_common.h"
+#include "mc_heap_words.h"
 
 #ifndef MC_FH_MIN
 #define MC_FH_MIN 96
@@ -250,7 +251,6 @@ __global__ void __launch_bounds__(1024) k_heap_order(const uint32_t *__restrict_
     __syncthreads();
     for (uint32_t slot = threadIdx.x; slot < nheavy; slot += 1024) order[atomicAdd(&bin[key(slot)], 1u)] = slot;
 }
-#define MC_HL_H(e) lds[((e) << 6) + lane]
 __global__ void __launch_bounds__(64) k_heap_lanes(const uint32_t *__restrict__ heads, uint32_t nheads, uint32_t nhsps, McHsp *tmp, const uint32_t *__restrict__ nrow_of,
                                                    const uint32_t *__restrict__ counters, const uint32_t *__restrict__ heavy_first, const uint32_t *__restrict__ order)
 {
@@ -282,27 +282,9 @@ __global__ void __launch_bounds__(64) k_heap_lanes(const uint32_t *__restrict__ 
             for (int e = 1 + lane; e <= nr; e += 64) lds[(e << 6) + r] = hw[e];
         }
         __syncthreads();
-        if (n >= 2) {   // mc_heapsort (mc_sort_impl.h) move for move, element e in word e + 1; the keys are the upper halves
-#define MC_HL_ADJUST(HOLE, LEN, VALUE)                                                                                             \
-    do {                                                                                                                           \
-        int hole_ = (HOLE), sc_ = hole_;                                                                                           \
-        const int top_ = hole_, len_ = (LEN);                                                                                      \
-        const uint32_t value_ = (VALUE);                                                                                           \
-        while (sc_ < (len_ - 1) / 2) {                                                                                             \
-            sc_ = 2 * (sc_ + 1);                                                                                                   \
-            const uint32_t cx_ = MC_HL_H(sc_), cy_ = MC_HL_H(sc_ + 1);            /* elements sc - 1 and sc */                      \
-            uint32_t pick_ = cy_;                                                                                                  \
-            if ((cy_ >> 16) < (cx_ >> 16)) { sc_--; pick_ = cx_; }                                                                 \
-            MC_HL_H(hole_ + 1) = pick_; hole_ = sc_;                                                                               \
-        }                                                                                                                          \
-        if ((len_ & 1) == 0 && sc_ == (len_ - 2) / 2) { sc_ = 2 * (sc_ + 1); MC_HL_H(hole_ + 1) = MC_HL_H(sc_); hole_ = sc_ - 1; } \
-        int parent_ = (hole_ - 1) / 2;                                                                                             \
-        while (hole_ > top_ && (MC_HL_H(parent_ + 1) >> 16) < (value_ >> 16)) { MC_HL_H(hole_ + 1) = MC_HL_H(parent_ + 1); hole_ = parent_; parent_ = (hole_ - 1) / 2; } \
-        MC_HL_H(hole_ + 1) = value_;                                                                                               \
-    } while (0)
-            for (int parent = (n - 2) / 2;; parent--) { MC_HL_ADJUST(parent, n, MC_HL_H(parent + 1)); if (parent == 0) break; }
-            for (int m = n; m > 1;) { m--; const uint32_t vv = MC_HL_H(m + 1); MC_HL_H(m + 1) = MC_HL_H(1); MC_HL_ADJUST(0, m, vv); }
-#undef MC_HL_ADJUST
+        if (n >= 2) {   // mc_heapsort (mc_sort_impl.h) move for move, element e in word e + 1; the keys are the upper halves (mc_heap_words.h, checked on the host by tests/test_emul.py)
+            struct Acc { uint32_t *lds; int lane; __device__ __forceinline__ uint32_t get(int e) const { return lds[((e + 1) << 6) + lane]; } __device__ __forceinline__ void set(int e, uint32_t v) { lds[((e + 1) << 6) + lane] = v; } } acc = { lds, lane };
+            mc_heap_words_sort(acc, n);
         }
         __syncthreads();
         for (int r = 0; r < 64; r++) {
@@ -313,7 +295,6 @@ __global__ void __launch_bounds__(64) k_heap_lanes(const uint32_t *__restrict__ 
         __syncthreads();
     }
 }
-#undef MC_HL_H
 
 // The rows of the heavy reads in their final order, and their classification: one wave per read.
 __global__ void __launch_bounds__(64) k_heavy_rows(const McTables *__restrict__ T, McIndex X, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam,

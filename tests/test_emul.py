@@ -202,3 +202,12 @@ int main(int argc, char **argv) {
     r = subprocess.run([rexe, str(tmp_path / "cut.bin")] + inputs, stderr=subprocess.PIPE)
     err = r.stderr.decode()
     assert r.returncode == 0 and "AddressSanitizer" not in err and "runtime error" not in err, err[-2000:]
+
+
+def test_heap_words_replay_equals_libstdcxx(tmp_path):
+    """MergeRes' heap sort as a lane of k_heap_lanes runs it (csrc/mc_heap_words.h, the text the kernel compiles) == the plain loop of
+    mc_sort_impl.h == libstdc++'s make_heap + sort_heap, word for word, on 200,000 arrays full of ties (MergeRes@0x40e3b0)."""
+    exe = str(tmp_path / "heap_words_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(REPO, "microbecensus_amd", "csrc"), "-o", exe, os.path.join(HERE, "emul", "heap_words_check.cpp")])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert "arrays 200000 differ_from_plain 0 differ_from_libstdcxx 0" in out, out
