@@ -288,6 +288,11 @@ def user_cache_dir():
     """~/.cache/microbecensus_amd (XDG_CACHE_HOME honoured), created with mode 0700; None when it cannot be made or is not this
     user's alone (owned by somebody else, or group / world writable) - nothing is cached then."""
     root = os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "microbecensus_amd")
+    return _private_dir(root)
+
+
+def _private_dir(root):
+    """root, made with mode 0700 if it is not there; None when it cannot be made or is not this user's alone."""
     try:
         os.makedirs(root, mode=0o700, exist_ok=True)
         st = os.stat(root)
@@ -303,7 +308,9 @@ _index_cache_set = False
 
 def use_index_cache():
     """Points mc_open() at the per-user cache of built indexes (once per process; MC_INDEX_CACHE=0 in the environment: no cache,
-    MC_INDEX_CACHE=<dir>: that directory)."""
+    MC_INDEX_CACHE=<dir>: that directory - like the default one only if it is this user's alone: a cached index is
+    read back into device arrays the kernels index, and although mc_open compares it with its inputs and checks its offsets
+    (mc_index_matches_input), a directory others can write is not a place to take it from)."""
     global _index_cache_set
     if _index_cache_set:
         return
@@ -311,7 +318,7 @@ def use_index_cache():
     v = os.environ.get("MC_INDEX_CACHE")
     if v == "0":
         return
-    d = v if v else user_cache_dir()
+    d = _private_dir(v) if v else user_cache_dir()      # (a directory named in the environment passes the same test: this user's, not group / world writable)
     if d:
         load_library().mc_set_index_cache(d.encode())
 

@@ -148,3 +148,27 @@ def test_rapsearch_hook_rejects_other_programs(tmp_path):
     with pytest.raises(SystemExit) as e:
         mc.check_rapsearch(str(fake))
     assert "Incorrect version of rapsearch2" in str(e.value)
+
+
+def test_index_cache_directory_must_be_private(tmp_path, monkeypatch):
+    """MC_INDEX_CACHE=<dir> passes the same test as the default per-user directory: this user's, not group / world
+    writable - else nothing is cached."""
+    from microbecensus_amd import _native
+    good = tmp_path / "mine"
+    assert _native._private_dir(str(good)) == str(good) and (os.stat(good).st_mode & 0o777) == 0o700
+    bad = tmp_path / "shared"
+    bad.mkdir()
+    os.chmod(bad, 0o777)
+    assert _native._private_dir(str(bad)) is None
+    seen = []
+
+    class Lib:
+        def mc_set_index_cache(self, d):
+            seen.append(d)
+    monkeypatch.setattr(_native, "load_library", lambda: Lib())
+    for d, want in ((bad, []), (good, [str(good).encode()])):
+        monkeypatch.setattr(_native, "_index_cache_set", False)
+        monkeypatch.setenv("MC_INDEX_CACHE", str(d))
+        del seen[:]
+        _native.use_index_cache()
+        assert seen == want
