@@ -739,8 +739,12 @@ int inflate_threads()
 
 // One file, region by region.  on_region(pieces) sees the stitched pieces of a region in file order and returns false to stop
 // the file early (sampler full).  Returns 0, or -1 (I/O) / -3 (the reference would have raised).
+static double g_wt[6];   // (MC_READER_TIMING) main-thread seconds: extend, guesses, parse (pool), stitch, on_region, rest
 int walk_file(const std::string &path, const Params &P, Pool &pool, const std::function<bool(std::vector<Piece *> &)> &on_region)
 {
+    const bool wt_on = getenv("MC_READER_TIMING") != nullptr;
+    auto wnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    struct WtPrint { bool on; ~WtPrint() { if (on) fprintf(stderr, "reader main thread: extend %.3f s, guesses %.3f, parse %.3f, stitch %.3f, sampler + copies %.3f\n", g_wt[0], g_wt[1], g_wt[2], g_wt[3], g_wt[4]); for (double &x : g_wt) x = 0; } } wtp{wt_on};
     Stream st;
     if (!st.open(path.c_str())) return st.bad_gzip ? -3 : -1;
     const int T = pool.size();
@@ -752,7 +756,9 @@ int walk_file(const std::string &path, const Params &P, Pool &pool, const std::f
     std::vector<Piece> pieces;
     bool parser_done = false;
     while (!parser_done) {
+        double w0 = wt_on ? wnow() : 0;
         st.extend(region_bytes);
+        if (wt_on) { const double w1 = wnow(); g_wt[0] += w1 - w0; w0 = w1; }
         if (st.len == 0) {
             if (st.failed) { r_err = "EOFError: compressed file ended before the end-of-stream marker was reached (" + path + ": " + st.prod_msg + ")"; return -3; }
             break;
@@ -775,7 +781,9 @@ int walk_file(const std::string &path, const Params &P, Pool &pool, const std::f
         }
         pieces.clear(); pieces.resize(starts.size());
         for (size_t k = 0; k < starts.size(); k++) { pieces[k].start = starts[k]; pieces[k].stop = k + 1 < starts.size() ? starts[k + 1] : e; }
+        if (wt_on) { const double w1 = wnow(); g_wt[1] += w1 - w0; w0 = w1; }
         pool.run((int)pieces.size(), [&](int k) { parse_piece(base, e, eof, pieces[k], P); });
+        if (wt_on) { const double w1 = wnow(); g_wt[2] += w1 - w0; w0 = w1; }
         // stitch in file order: a piece counts only if the parse so far ended exactly at its (guessed) start; where no piece starts,
         // the parser is continued sequentially up to the next guess
         std::vector<Piece *> order;
@@ -798,7 +806,9 @@ int walk_file(const std::string &path, const Params &P, Pool &pool, const std::f
             at = pc->end;
         }
         parser_done = done;
+        if (wt_on) { const double w1 = wnow(); g_wt[3] += w1 - w0; w0 = w1; }
         const bool go_on = on_region(order);
+        if (wt_on) { const double w1 = wnow(); g_wt[4] += w1 - w0; w0 = w1; }
         if (!go_on) return 0;
         if (parser_done) break;
         if (at == 0) {                                               // one record larger than the region: take more
