@@ -59,6 +59,9 @@
 
 #include "../../include/mcensus.h"
 #include "mc_pgzip.h"
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 namespace {
 
@@ -448,7 +451,7 @@ size_t whole_lines(const uint8_t *p, size_t n)
 // ------------------------------------------------------------------------------------------------------------------
 // parse_seqs as a restartable state machine over a region of whole lines, and the per-record evaluation
 // ------------------------------------------------------------------------------------------------------------------
-enum : uint8_t { R_SHORT = 1, R_QUAL = 2, R_RCBAD = 4 };
+enum : uint8_t { R_SHORT = 1, R_QUAL = 2, R_RCBAD = 4, R_PASS = 8, R_LOWQ = 16 };   // (R_PASS / R_LOWQ: the sampler's verdict, where the parser may give it - Params::decide)
 struct Rec {
     const uint8_t *seq; const uint8_t *qual;
     uint32_t len, qlen;
@@ -475,19 +478,41 @@ struct Piece {
     std::vector<Rec> recs;
     Arena arena;
     int64_t bases = 0;
+    // with Params::decide: how many of the piece's records are too short / fail the quality filter / pass, and whether one of them is a
+    // record the sampler would raise an error at (then the region is decided record by record, in file order, as without decide)
+    int64_t n_short = 0, n_lowq = 0, n_pass = 0;
+    bool anomaly = false;
 };
 
 struct Line { const uint8_t *p; size_t n; bool nl; size_t off; };
 // next line of [pos, e): content without terminator; returns false at e
+// first '\n' or '\r' of [b, b + n), or null: ONE pass over the line, 16 bytes at a time (two memchr calls per line - the lines of a FASTQ
+// file are 150 bytes, the calls cost more than the bytes - were half of the parser's time)
+inline const uint8_t *scan_eol(const uint8_t *b, size_t n)
+{
+#if defined(__SSE2__)
+    const __m128i nl = _mm_set1_epi8('\n'), cr = _mm_set1_epi8('\r');
+    size_t i = 0;
+    for (; i + 16 <= n; i += 16) {
+        const __m128i v = _mm_loadu_si128((const __m128i *)(b + i));
+        const int m = _mm_movemask_epi8(_mm_or_si128(_mm_cmpeq_epi8(v, nl), _mm_cmpeq_epi8(v, cr)));
+        if (m) return b + i + __builtin_ctz((unsigned)m);
+    }
+    for (; i < n; i++) if (b[i] == '\n' || b[i] == '\r') return b + i;
+    return nullptr;
+#else
+    const uint8_t *q = (const uint8_t *)memchr(b, '\n', n);
+    const size_t lim = q ? (size_t)(q - b) : n;
+    const uint8_t *c = lim ? (const uint8_t *)memchr(b, '\r', lim) : nullptr;
+    return c ? c : q;
+#endif
+}
 inline bool next_line(const uint8_t *base, size_t &pos, size_t e, Line &ln)
 {
     if (pos >= e) return false;
     const uint8_t *b = base + pos;
     const size_t avail = e - pos;
-    const uint8_t *q = (const uint8_t *)memchr(b, '\n', avail);
-    const size_t lim = q ? (size_t)(q - b) : avail;
-    const uint8_t *c = lim ? (const uint8_t *)memchr(b, '\r', lim) : nullptr;
-    if (c) q = c;
+    const uint8_t *q = scan_eol(b, avail);
     ln.p = b; ln.off = pos;
     if (!q) { ln.n = avail; ln.nl = false; pos = e; return true; }
     ln.n = (size_t)(q - b); ln.nl = true;
@@ -530,7 +555,8 @@ bool h64_rc(const uint8_t *p, size_t n, uint64_t *out)
     return all != 0 || n == 0;
 }
 
-struct Params { size_t L = 0; int fastq = 0, qoff = 0, dups = 0; bool count_only = false; };
+struct Params { size_t L = 0; int fastq = 0, qoff = 0, dups = 0; bool count_only = false;
+                bool decide = false; double max_unknown = 0, mean_q = 0, min_q = 0; };   // decide: the quality filter's verdict per record is given by the parser's threads (no -d: a record's fate depends on nothing but itself)
 
 void evaluate(Rec &r, const Params &P)
 {
@@ -549,6 +575,19 @@ void evaluate(Rec &r, const Params &P)
     }
     if (P.dups) { r.h1 = h64(r.seq, r.len); if (!h64_rc(r.seq, r.len, &r.h2)) r.flags |= R_RCBAD; }
 }
+// quality_filter (reference :269-291) as mc_reader_run's loop states it, for one record that is long enough; false: the sampler
+// would raise at this record
+inline bool decide(Rec &r, const Params &P)
+{
+    bool fail = (double)(100 * (long long)r.ncount) / (double)P.L > P.max_unknown;
+    if (!fail && P.fastq) {
+        if (!(r.flags & R_QUAL) || r.nq == 0) return false;
+        if ((double)r.qsum / (double)r.nq < P.mean_q) fail = true;
+        else if ((double)r.qmin < P.min_q) fail = true;
+    }
+    r.flags |= fail ? R_LOWQ : R_PASS;
+    return true;
+}
 
 // Runs parse_seqs (reference :294-325) over region[start, e) until a header line at an offset >= stop would be consumed (or
 // the region ends).  eof: the region ends the file (else an unfinished record at its end is left for the next region:
@@ -564,6 +603,12 @@ void parse_piece(const uint8_t *base, size_t e, bool eof, Piece &pc, const Param
     auto emit = [&](const uint8_t *s, size_t sn, const uint8_t *q, size_t qn, bool hasq) {
         Rec r; r.seq = s; r.len = (uint32_t)sn; r.qual = hasq ? q : nullptr; r.qlen = hasq ? (uint32_t)qn : 0;
         evaluate(r, P);
+        if (P.decide) {
+            if (r.flags & R_SHORT) pc.n_short++;
+            else if (!decide(r, P)) pc.anomaly = true;
+            else if (r.flags & R_PASS) pc.n_pass++;
+            else pc.n_lowq++;
+        }
         pc.bases += (int64_t)sn;
         pc.recs.push_back(r);
     };
@@ -935,6 +980,7 @@ extern "C" int64_t mc_reader_run(mc_reader *r)
     }
     Pool pool(nparse);
     Params P; P.L = (size_t)r->L; P.fastq = r->fastq; P.qoff = r->qoff; P.dups = r->filter_dups;
+    P.decide = !r->filter_dups && !out; P.max_unknown = r->max_unknown; P.mean_q = r->mean_q; P.min_q = r->min_q;
     SeqSet seen;
     const size_t L = (size_t)r->L;
     int64_t kept = 0, rcode = 0;
@@ -942,9 +988,44 @@ extern "C" int64_t mc_reader_run(mc_reader *r)
     for (const std::string &path : r->paths) {
         t_range_lo = r->range_lo; t_range_hi = r->range_hi;        // (consumed by Stream::open on this thread)
         const int rc = walk_file(path, P, pool, [&](std::vector<Piece *> &order) -> bool {
-            // the sampler's decisions, record by record in file order
             const int64_t kept0 = kept;
             bool full = false;
+            bool anomaly = !P.decide;
+            for (Piece *pc : order) anomaly = anomaly || pc->anomaly;
+            if (!anomaly) {
+                // The verdicts are in (the parser's threads gave them): what is left in file order is the place of every piece's accepted
+                // reads - a running sum over the pieces - and the piece in which the sample gets full, walked record by record.
+                std::vector<int64_t> base(order.size(), 0), take(order.size(), 0);
+                size_t np = 0;
+                for (; np < order.size() && !full; np++) {
+                    Piece *pc = order[np];
+                    if (pc->ragged) r->st.ragged_end = 1;
+                    base[np] = kept - kept0;
+                    if (r->nreads > 0 && kept + pc->n_pass >= r->nreads) {            // the sample gets full inside this piece (or with its last accepted read)
+                        for (Rec &rec : pc->recs) {
+                            r->st.records++; r->st.bases += (int64_t)rec.len;
+                            if (rec.flags & R_SHORT) { r->st.too_short++; continue; }
+                            if (!(rec.flags & R_PASS)) { r->st.low_qual++; continue; }
+                            take[np]++; kept++;
+                            if (kept == r->nreads) { full = true; break; }
+                        }
+                    } else {
+                        r->st.records += (int64_t)pc->recs.size(); r->st.bases += pc->bases; r->st.too_short += pc->n_short; r->st.low_qual += pc->n_lowq;
+                        take[np] = pc->n_pass; kept += pc->n_pass;
+                    }
+                }
+                if (kept > kept0) {
+                    if (!r->reserve((size_t)kept * L)) { r_err = "out of memory for the sampled reads"; rcode = -1; return false; }
+                    uint8_t *dst = r->reads + (size_t)kept0 * L;
+                    pool.run((int)np, [&](int k) {
+                        int64_t j = base[k]; const int64_t stop = j + take[k];
+                        for (const Rec &rec : order[k]->recs) { if (j == stop) break; if (rec.flags & R_PASS) { memcpy(dst + (size_t)j * L, rec.seq, L); j++; } }
+                    });
+                    r->publish(kept);
+                }
+                return !full;
+            }
+            // the sampler's decisions, record by record in file order (-d, a FASTA copy of the sample, or a record to raise an error at)
             for (Piece *pc : order) {
                 if (pc->ragged) r->st.ragged_end = 1;
                 for (Rec &rec : pc->recs) {
