@@ -47,6 +47,29 @@ __global__ void __launch_bounds__(256) k_heavy_lists(const uint32_t *__restrict_
     } else if (cls >= 0) light[(size_t)cls * light_pitch + off[4 + cls]] = s;
 }
 
+// The list of one wave-per-read kernel, LONGEST STACKS FIRST (a counting sort by one workgroup, as k_heap_order).  The kernel's waves
+// take the list in turn (wave b: entries b, b + G, ...): in the order the atomics of k_heavy_lists left, the read that takes longest
+// of all - half a millisecond against a launch of 0.6 - 0.7 - could be the second or third of its wave; the launches' durations
+// moved by 30 % from box to box with it.
+__global__ void __launch_bounds__(1024) k_heavy_order(const uint32_t *__restrict__ list, const uint32_t *__restrict__ count_p, const uint32_t *__restrict__ heavy, const uint32_t *__restrict__ nv,
+                                                      int shift, uint32_t *out)
+{
+    __shared__ uint32_t bin[512], sc[512];
+    const uint32_t n = *count_p, t = threadIdx.x;
+    if (t < 512) bin[t] = 0;
+    __syncthreads();
+    auto key = [&](uint32_t i) -> uint32_t { const uint32_t k = nv[heavy[list[i]] & 0x7FFFFFFFu] >> shift; return 511u - (k > 511u ? 511u : k); };   // (bin 0: the longest)
+    for (uint32_t i = t; i < n; i += 1024) atomicAdd(&bin[key(i)], 1u);
+    __syncthreads();
+    const uint32_t mine = t < 512 ? bin[t] : 0u;
+    if (t < 512) sc[t] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < 512; d <<= 1) { const uint32_t y = (t < 512 && t >= d) ? sc[t - d] : 0u; __syncthreads(); if (t < 512) sc[t] += y; __syncthreads(); }
+    if (t < 512) bin[t] = sc[t] - mine;
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += 1024) out[atomicAdd(&bin[key(i)], 1u)] = list[i];
+}
+
 // One thread per marked read.  All scratch is addressed by the read's offset into the binned HSPs (heads; a read never produces
 // more rows than it has HSPs): v = the stacks (built by the ordering kernels), tmp = 2 HSP slots per HSP for the
 // sum statistics, reused afterwards for the read's rows and their merge keys (64 + 8 bytes per row <= 96).  The rows

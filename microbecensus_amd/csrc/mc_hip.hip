@@ -657,13 +657,18 @@ static int stage_d(mc_handle *h, McCtx &c)
             // kernels on this stream, or in front of the first on its stream, made the stage 0.1 - 0.2 ms LONGER - whatever runs behind the
             // third waits for its few long reads, and they hold 135 KB of a CU's LDS each.)
             const unsigned wpc2 = (unsigned)std::min<size_t>(8, std::max<size_t>(1, (size_t)(158 * 1024) / (l2 + 1024)));   // waves per CU the LDS holds
+            // (the lists of the first two kernels with the longest stacks first - k_heavy_order; the third has a few dozen reads)
+            static const bool fh_sort = !(getenv("MC_FH_SORT") && atoi(getenv("MC_FH_SORT")) == 0);
+            uint32_t *d_sorted1 = c.d_retry2 + c.cap_gaps / 2, *d_sorted2 = c.d_retry2 + c.cap_gaps + c.cap_gaps / 2;      // (lists of at most n reads: cap_gaps >= 10 n)
+            if (fh_sort) k_heavy_order<<<dim3(1), dim3(1024), 0, c.side2>>>(d_heavy2, c.d_counters + C_HEAVY2, d_heavy, c.d_nv, 2, d_sorted2);
             k_finish_heavy<MC_FH_N2, C_HEAVY2, -1><<<dim3(256 * wpc2), dim3(64), l2, c.side2>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
-                                                                                            c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy2, nullptr);
+                                                                                            c.d_nrow, c.d_bestof, c.d_counters, d_heavy, fh_sort ? d_sorted2 : d_heavy2, nullptr);
             k_finish_heavy<MC_FH_N3, C_HEAVY3, -1><<<dim3(256), dim3(64), l3, c.side2>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
                                                                                          c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy3, nullptr);
             HIPCK(hipEventRecord(c.ev_join2, c.side2));
+            if (fh_sort) k_heavy_order<<<dim3(1), dim3(1024), 0, c.side>>>(d_heavy1, c.d_counters + C_HEAVY1, d_heavy, c.d_nv, 0, d_sorted1);
             k_finish_heavy<MC_FH_N1, C_HEAVY1, -1><<<dim3(256 * 12), dim3(64), l1, c.side>>>(h->d_T, X, h->d_P, h->d_fam, c.d_nv, c.d_heads, nheads, c.d_v, c.d_tmp, c.first_read_id,
-                                                                                            c.d_nrow, c.d_bestof, c.d_counters, d_heavy, d_heavy1, nullptr);
+                                                                                            c.d_nrow, c.d_bestof, c.d_counters, d_heavy, fh_sort ? d_sorted1 : d_heavy1, nullptr);
             HIPCK(hipStreamWaitEvent(c.side, c.ev_join2, 0));
             // MergeRes' heap sort of all of them (a lane per read), then their rows (a wave per read)
             const size_t lh = (size_t)(MC_MAX_M8 + 2) * 64 * 4;
