@@ -980,7 +980,8 @@ extern "C" int64_t mc_reader_run(mc_reader *r)
     }
     Pool pool(nparse);
     Params P; P.L = (size_t)r->L; P.fastq = r->fastq; P.qoff = r->qoff; P.dups = r->filter_dups;
-    P.decide = !r->filter_dups && !out; P.max_unknown = r->max_unknown; P.mean_q = r->mean_q; P.min_q = r->min_q;
+    P.decide = !r->filter_dups && !out && !getenv("MC_READER_SERIAL_SAMPLER");   // (the environment variable: tests compare the two forms)
+    P.max_unknown = r->max_unknown; P.mean_q = r->mean_q; P.min_q = r->min_q;
     SeqSet seen;
     const size_t L = (size_t)r->L;
     int64_t kept = 0, rcode = 0;

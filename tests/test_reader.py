@@ -454,3 +454,47 @@ def test_inflate_tables_and_byte_mode_against_zlib(tmp_path):
         for threads, chunk in ((1, 4096), (3, 20000), (6, 1 << 20)):
             out = subprocess.run([exe, p, str(threads), str(chunk), "1"], stdout=subprocess.PIPE, check=True).stdout.decode()
             assert (" %d bytes " % len(text)) in out and want in out and "BAD" not in out, (name, threads, chunk, out)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_parallel_verdicts_equal_the_record_by_record_sampler(seed, tmp_path, monkeypatch):
+    """Without -d the parser's threads give the quality filter's verdicts and the sampler only sums the pieces up (round 5); with
+    MC_READER_SERIAL_SAMPLER it walks the records one by one in file order as before (the form the sampler goldens pinned on the
+    reference's own process_seqfile).  Random FASTQ text - short reads, N runs, low qualities, a sequence over two lines, CR LF -
+    through both, at several head-takes (the sample getting full inside a piece, at a piece's end, never) and piece sizes:
+    the same reads, the same counters."""
+    import random
+    import numpy as np
+    from microbecensus_amd import _native
+    rng = random.Random(seed)
+    L = 60
+    recs = []
+    for i in range(6000):
+        n = rng.choice([L - 7, L, L, L, L + 5, L + 40])
+        seq = "".join(rng.choice("ACGT") for _ in range(n))
+        if rng.random() < 0.15:
+            k = rng.randrange(1, n // 2)
+            at = rng.randrange(0, n - k)
+            seq = seq[:at] + "N" * k + seq[at + k:]
+        lo = rng.choice([2, 2, 20, 30])
+        qual = "".join(chr(33 + rng.randrange(lo, 41)) for _ in range(n))
+        nl = "\r\n" if seed == 3 else "\n"
+        if seed == 4 and i % 97 == 0:
+            recs.append("@r%d%s%s%s%s%s+%s%s%s" % (i, nl, seq[:n // 2], nl, seq[n // 2:], nl, nl, qual, nl))     # a sequence over two lines
+        else:
+            recs.append("@r%d%s%s%s+%s%s%s" % (i, nl, seq, nl, nl, qual, nl))
+    path = tmp_path / "r.fq"
+    path.write_bytes("".join(recs).encode())
+    for piece, region in ((1 << 12, 1 << 16), (1 << 18, 1 << 22)):
+        monkeypatch.setenv("MC_READER_PIECE_BYTES", str(piece))
+        monkeypatch.setenv("MC_READER_REGION_BYTES", str(region))
+        for nreads in (1, 37, 1000, 2500, 100000):
+            for qargs in ((33, -5, -5, 100), (33, 10, 25, 5)):
+                monkeypatch.delenv("MC_READER_SERIAL_SAMPLER", raising=False)
+                a, sa = _native.sample_reads([str(path)], L, nreads, True, qargs[0], qargs[1], qargs[2], qargs[3], False)
+                monkeypatch.setenv("MC_READER_SERIAL_SAMPLER", "1")
+                b, sb = _native.sample_reads([str(path)], L, nreads, True, qargs[0], qargs[1], qargs[2], qargs[3], False)
+                assert sa == sb, (piece, nreads, qargs, sa, sb)
+                assert a.shape == b.shape and (a == b).all()
+                assert sa["sampled"] == min(nreads, sa["sampled"]) and (nreads >= 100000 or sa["sampled"] <= nreads)
+    assert sa["too_short"] > 0 and sa["low_qual"] > 0
