@@ -138,7 +138,9 @@ def gather_ceiling():
 def seed_line_model(cal, L, n_batch, asks, hits, seed_ms):
     """What the seed kernel's own asks cost at the calibrated scattered-line rates, structure by structure: every ask
     is one aligned item = one line asked of the level its structure lives in.  items per read x 1 / rate(footprint class, item width),
-    summed, against the kernel's measured duration.  The structures' sizes are those of the marker database (118 MB of index)."""
+    summed, against the kernel's measured duration.  The structures' sizes are those of the marker database (118 MB of index).
+    (A hit's posting and its subject's offsets - 150 of the lines a read of 150 bp cost the kernel - are no longer asked here: the hit
+    record holds the posting's index and k_eval_seeds, which does not wait for memory, fetches them.)"""
     if cal is None or seed_ms <= 0:
         return None
     positions = sum(max(0, (L - f) // 3 - 6) for f in (0, 1, 2)) * 2          # seed positions of the six frames: each asks the bucket bitmap once
@@ -149,8 +151,6 @@ def seed_line_model(cal, L, n_batch, asks, hits, seed_ms):
         ("pair filter 16 MB", "16MB", 16, asks["seed_pair_asks"] / n_batch),
         ("bucket records 32 MB", "32MB", 16, asks["seed_probes"] / n_batch),
         ("key groups 7 - 11 MB / range table (44 % of the probes: the others find an empty group)", "8MB", 16, 0.44 * asks["seed_probes"] / n_batch),
-        ("postings 14 - 22 MB (at most one line per hit: the postings of a range are consecutive)", "16MB", 4, hits / n_batch),
-        ("subject offsets 67 KB", "128KB", 4, hits / n_batch),
     ]
     rows, t = [], 0.0
     for name, foot, width, n in per_read:
@@ -662,11 +662,13 @@ def main():
         hits, hsps, gtasks, rows = acc["seed_tasks"] / K, acc["hsps"] / K, acc["gap_tasks"] / K, acc["rows"] / K
         # What the seed kernel asks of the index per launch (mc_stats.seed_*, counted by the timed kernel; DESIGN.md 5 "index touches"):
         # 9-mer filter words (4 B), wildcard filter lines (32 B), pair filter blocks (16 B), bucket record + key group per probe that
-        # survives the filters (32 + 16 B), and per seed hit its posting and the subject's offset (4 + 4 B).
+        # survives the filters (32 + 16 B).  (Round 5: a seed hit's posting and its subject's offsets are no longer read here - the hit
+        # record holds the posting's index, k_eval_seeds fetches posting, place in the residue array and rest of the subject in one
+        # 8-byte load: those 8 B per hit moved to residue_touch.)
         asks = {k: acc[k] / K for k in ("seed_exact_asks", "seed_wild_asks", "seed_pair_asks", "seed_probes")}
-        index_touch = 4 * asks["seed_exact_asks"] + 32 * asks["seed_wild_asks"] + 16 * asks["seed_pair_asks"] + 48 * asks["seed_probes"] + 8 * hits
-        # ... and the evaluation kernel of the residues: 24 bytes around the seed in the frame and in the subject, and the subject's end
-        residue_touch = (24 + 24 + 4) * hits
+        index_touch = 4 * asks["seed_exact_asks"] + 32 * asks["seed_wild_asks"] + 16 * asks["seed_pair_asks"] + 48 * asks["seed_probes"]
+        # ... and the evaluation kernel of the residues
+        residue_touch = (24 + 24 + 8) * hits                              # 24 bytes around the seed in the frame and in the subject, the 8-byte posting entry (MC_POST8)
         per_launch = {
             # ALGORITHMIC bytes per launch = the arrays a kernel must read and write, each once, plus - for the two kernels that gather
             # from the index - the items they ask of it, each at its own size.
@@ -741,7 +743,7 @@ def main():
                          "index_touch_bytes_per_read": round(index_touch / n_batch, 1),
                          "index_touch_items_per_read": {"filter_words_4B": round(asks["seed_exact_asks"] / n_batch, 2), "wildcard_lines_32B": round(asks["seed_wild_asks"] / n_batch, 2),
                                                         "pair_blocks_16B": round(asks["seed_pair_asks"] / n_batch, 2), "records_and_key_groups_48B": round(asks["seed_probes"] / n_batch, 2),
-                                                        "postings_and_offsets_8B": round(hits / n_batch, 2)},
+                                                        "postings_and_offsets_8B": 0.0},
                          "fabric_amplification": (None if traffic_dom is None else round(traffic_dom / per_launch[dom], 2)),
                          "fabric_amplification_lower": (None if not (d_dom and d_dom.get("fabric_frac_lower") and d_dom.get("fabric_frac")) else round(traffic_dom / per_launch[dom] * d_dom["fabric_frac_lower"] / d_dom["fabric_frac"], 2)),
                          "extension_kernel_hbm_frac": {"target": 0.40, "met": bool(ext_best >= 0.40), "best": round(ext_best, 4), "kernels": ext,

@@ -117,6 +117,19 @@ __device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long
     // markers, and a lane that wrote such a range alone would keep the other 63 waiting.
     if (cnt > 0 && cnt <= MC_EN_SHORT) {
         const uint32_t sn = phase == 0 ? MC_TASK_W3(0, 9, 3) : MC_TASK_W3(0, 10, 4);
+        if constexpr (TAGGED) {
+            // k_enumerate_q writes the INDEX of a hit's posting (in X.post / X.post8), not the posting: the posting and the subject's offsets of
+            // every hit were 150 of the 810 scattered lines a read of 150 bp cost this kernel, which is bound by such lines;
+            // k_eval_seeds<true>, which is not, fetches posting, position in the residue array and rest of the subject in one 8-byte
+            // load (MC_POST8), asked for a chunk ahead
+#pragma unroll
+            for (int i = 0; i < MC_EN_SHORT; i++)
+                if (i < cnt) {
+                    McSeedTask t;
+                    t.read = myread; t.chrono = MC_CHRONO(frame, pos, phase, (uint32_t)nst + (uint32_t)i); t.posting = start + (uint32_t)nst + (uint32_t)i; t.seedlen_nkey = sn;
+                    tasks[base + excl + (uint32_t)i] = t;
+                }
+        } else {
         uint32_t pst[MC_EN_SHORT];
         uint2 ofs[MC_EN_SHORT];   // the postings and the subjects' two offsets (one load) first, then the stores: a store between two loads orders them (the pointers may alias)
 #pragma unroll
@@ -132,6 +145,7 @@ __device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long
                 t.seedlen_nkey = sn | abs;
                 tasks[base + excl + (uint32_t)i] = t;
             }
+        }
     }
     {   // the long ranges as ONE list of hits, 128 of them per turn whatever range they belong to: lane x finds the range it is in
         // (binary search over the running sums of the lanes, by permute), fetches that lane's fields and writes one hit.  Range
@@ -157,12 +171,12 @@ __device__ __forceinline__ uint32_t mc_en_append(const McIndex &X, unsigned long
                     const uint32_t ofrom = (uint32_t)__shfl((int)from, ol), oex = (uint32_t)__shfl((int)excl, ol), onst = (uint32_t)__shfl(nst, ol);
                     in[u] = x < ltot;
                     const int p2 = (int)((oh >> 4) & 0xFF), f2 = (int)((oh >> 12) & 7), ph2 = (int)((oh >> 15) & 63);
-                    pst[u] = X.post[in[u] ? ofrom + i : 0u];
+                    pst[u] = TAGGED ? ofrom + i : X.post[in[u] ? ofrom + i : 0u];   // (TAGGED: the posting's index - see above)
                     slot[u] = base + oex + i; chr[u] = MC_CHRONO(f2, p2, ph2, onst + i); snk[u] = ph2 == 0 ? MC_TASK_W3(0, 9, 3) : MC_TASK_W3(0, 10, 4);
                     rd[u] = TAGGED ? read + ((oh >> 25) & 15u) : read;
                 }
 #pragma unroll
-                for (int u = 0; u < 2; u++) { uint2 of; __builtin_memcpy(&of, X.off + (pst[u] >> 11), 8); const uint32_t abs = of.x + (pst[u] & 0x7ffu); snk[u] |= abs; rd[u] = MC_TASK_READ(rd[u], of.y - abs); }
+                for (int u = 0; u < 2; u++) if constexpr (!TAGGED) { uint2 of; __builtin_memcpy(&of, X.off + (pst[u] >> 11), 8); const uint32_t abs = of.x + (pst[u] & 0x7ffu); snk[u] |= abs; rd[u] = MC_TASK_READ(rd[u], of.y - abs); }
 #pragma unroll
                 for (int u = 0; u < 2; u++)
                     if (in[u]) {

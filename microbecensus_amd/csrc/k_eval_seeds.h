@@ -169,6 +169,19 @@ __device__ __forceinline__ uint32_t mc_ev_slots(uint32_t n, uint32_t r, uint32_t
 // pools: a record goes from its lane straight to the wave's current block of the global pool (blocks of 256 slots, one global
 // atomic each; the records of a turn are consecutive, so the stores of the wave cover whole lines); what a wave does not use of
 // its last block is padded with records the later stages skip (read = MC_TASK_NONE, sort key all ones; C_HPAD / C_GPAD count them).
+// RANGES (round 5, the product's seed kernel k_enumerate_q; the name is history: ranges of hits per record were built first and cost this
+// kernel more than they saved the other): a record holds the INDEX of its hit's posting instead of the posting, its place in the residue
+// array and the rest of the subject - the seed kernel is bound by the scattered lines its CUs fetch and a hit's posting and
+// offsets were 150 of the 810 lines a read cost it; this kernel does not wait for memory (5.7) and fetches the three in one 8-byte load.
+// the postings with what the evaluation needs beside them (MC_POST8), made once per handle
+__global__ void __launch_bounds__(256) k_post8(const uint32_t *__restrict__ post, const uint32_t *__restrict__ off, uint32_t n, unsigned long long *post8)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pst = post[i], s = pst >> 11, abs = off[s] + (pst & 0x7ffu);
+    post8[i] = MC_POST8(pst, abs, off[s + 1] - abs);
+}
+template <bool RANGES>
 __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_EV_BS) k_eval_seeds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
                                                     const McSeedTask *__restrict__ tasks, const uint32_t *__restrict__ ntasks_p, uint32_t cap_tasks, McHsp *hsps, uint32_t cap_hsps,
                                                     McGapTask *gaps, uint32_t cap_gaps, uint32_t *counters, const McClassPars *__restrict__ P, const int32_t *__restrict__ fam, uint8_t *cand, uint64_t *hkeys, uint8_t *low, uint64_t *hplace)
@@ -183,108 +196,157 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
     uint32_t qn = 0, hb_base = 0, hb_used = MC_EV_BLK, gb_base = 0, gb_used = MC_EV_BLK;
     bool ok = true;
     const unsigned long long lt = (1ull << lane) - 1;
-    // Which hits a wave takes: groups of MC_EV_GROUP chunks of 64 consecutive hits, the first group by the wave's number, every further
+    // Which records a wave takes: groups of MC_EV_GROUP chunks of 64 consecutive records, the first group by the wave's number, every further
     // one from a counter (asked for one chunk ahead of need) - dealt out in turn, the launch lasted as long as the wave whose hits
     // took longest (the same finding as in k_enumerate_t0: reads of marker genes cost many times the average).
     const uint32_t nchunks = (ntasks + 63u) / 64u, nwaves = gridDim.x * (MC_EV_BS / 64);
     uint32_t cur = (blockIdx.x * (MC_EV_BS / 64) + (uint32_t)wv) * MC_EV_GROUP, cleft = MC_EV_GROUP - 1, pend = 0;
     // The chain of dependent reads of a hit was: its record -> the subject's offsets -> the residue in front of the seed -> the
     // seed's residues, four trips to the L2 before the gate.  Now: the record of the NEXT chunk is fetched while this one is
-    // evaluated, the record carries the hit's position in the residue array (MC_TASK_W3) and what is left of the subject behind it
-    // (MC_TASK_READ), and the residues in front of the seed and the seed's own ten are read together: one trip, residues only.
+    // evaluated, and the residues in front of the seed and the seed's own ten are read together.  (!RANGES: the record of a single hit
+    // carries the hit's position in the residue array - MC_TASK_W3 - and what is left of the subject behind it - MC_TASK_READ.)
 #ifdef MC_EXP_TIMING
     unsigned long long ev_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ev_last_ = __builtin_readcyclecounter();
 #endif
+    // ---- phase 1 for one hit per lane: the gate; the survivors into the wave's queue
+    auto gate = [&](bool active, uint32_t rd, uint32_t chrono, uint32_t posting, uint32_t abs, int rem, int seedlen, int nkey) {
+        bool surv = false;
+        uint4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};
+        if (active) {
+            const int frame = (int)(chrono >> 25), pos = (int)((chrono >> 17) & 0xff);
+            const int qlen = (L - frame % 3) / 3;
+            const int dpos = (int)(posting & 0x7ffu), sidx = (int)(posting >> 11);
+            const uint32_t o0 = abs - (uint32_t)dpos;
+            const uint8_t *q = frames + ((int64_t)rd * 6 + frame) * FP, *d = X.res + o0;
+            // residues pos - 8 .. pos + 15 of the frame and dpos - 8 .. dpos + 15 of the subject: six loads, one trip (rows and residue array have room on both sides)
+            const uint64_t q0 = mc_ld8(q + pos - 8), q1 = mc_ld8(q + pos), q2 = mc_ld8(q + pos + 8), d0 = mc_ld8(d + dpos - 8), d1 = mc_ld8(d + dpos), d2 = mc_ld8(d + dpos + 8);
+            const int qm1 = (int)(q0 >> 56), dm1 = (int)(d0 >> 56);
+            const int dlen = dpos + rem;
+            int score = 0, ident = 0;
+#pragma unroll
+            for (int k = 0; k < 10; k++)
+                if (k < seedlen) {
+                    const int a = (int)((k < 8 ? q1 >> (8 * k) : q2 >> (8 * (k - 8))) & 0xFFu), b = (int)((k < 8 ? d1 >> (8 * k) : d2 >> (8 * (k - 8))) & 0xFFu);
+                    score += MC_SUB(hot, a, b); ident += (a == b);
+                }
+            const bool go = !(dpos + seedlen > dlen) && !(pos != 0 && dpos != 0 && hot.grp[qm1] == hot.grp[dm1] && nkey != 4);
+            int qp = 0, dp = 0, Lg = 0;
+            if (go) surv = mc_ev_gate(hot, q, qlen, pos, d, dlen, dpos, seedlen, score, ident, qp, dp, Lg, q0, q2, d0, d2);
+            e0.x = rd; e0.y = chrono; e0.z = o0; e0.w = (uint32_t)sidx;
+            e1.x = (uint32_t)qp | ((uint32_t)dp << 16); e1.y = (uint32_t)Lg | ((uint32_t)(uint16_t)(int16_t)score << 16); e1.z = (uint32_t)ident | ((uint32_t)dlen << 16);
+        }
+        const unsigned long long ms = __ballot(surv);
+        if (surv) { const uint32_t at = qn + (uint32_t)__popcll(ms & lt); Q[2 * at] = e0; Q[2 * at + 1] = e1; }
+        qn += (uint32_t)__popcll(ms);
+        mc_wave_sync();
+    };
+    // ---- phase 2: the extension, up to 64 survivors of the queue
+    auto extend = [&]() {
+        const uint32_t take = qn < 64 ? qn : 64;
+        qn -= take;
+        const bool act = (uint32_t)lane < take;
+        const uint4 e0 = Q[2 * (qn + (act ? (uint32_t)lane : 0u))], e1 = Q[2 * (qn + (act ? (uint32_t)lane : 0u)) + 1];
+        mc_wave_sync();                                          // (read before the next survivors are written over them)
+        int rc = 0;
+        bool keep = false;
+        McGapTask g;
+        McHsp h;
+        if (act) {
+            const uint32_t read = e0.x, chrono = e0.y;
+            const int frame = (int)(chrono >> 25), qlen = (L - frame % 3) / 3, sidx = (int)e0.w;
+            const uint8_t *q = frames + ((int64_t)read * 6 + frame) * FP, *d = X.res + e0.z;
+            g.read = read; g.chrono = chrono;
+            rc = mc_ev_xdrop(hot, q, qlen, d, (int)(e1.z >> 16), sidx, (int)(e1.x & 0xFFFFu), (int)(e1.x >> 16), (int)(e1.y & 0xFFFFu), (int)(int16_t)(e1.y >> 16), (int)(e1.z & 0xFFFFu), &g);
+            MC_EV_TICK(2);
+            if (rc == 1) {
+                h.read = read; h.chrono = chrono;
+                keep = mc_make_hsp(*T, L, frame, g, g.qfwd, g.qfwd, g.qbwd, g.qbwd, g.score, g.nmatch, g.qfwd + g.L + g.qbwd, 0, 0, &h);
+                if (keep && cand && mc_hsp_can_classify(*T, *P, X, fam, h)) cand[h.read] = 1;
+                if (keep && h.loge < hot_loge_thr) low[h.read] = 1;      // (the read can print a row: k_order_light)
+            }
+        }
+        MC_EV_TICK(3);
+        const unsigned long long mh = __ballot(keep), mg = __ballot(rc == 2);
+        if (mh && ok) {
+            const uint32_t slot = mc_ev_slots((uint32_t)__popcll(mh), (uint32_t)__popcll(mh & lt), cap_hsps, &counters[C_HSPS], hb_base, hb_used, &ok, lane);
+            if (!ok) { if (lane == 0) counters[C_OVERFLOW] = 2; }
+            else if (keep) { mc_store_stream(&hsps[slot], h); __builtin_nontemporal_store(MC_HSP_KEY(h), &hkeys[slot]); __builtin_nontemporal_store(MC_HSP_PLACE(h), &hplace[slot]); }
+        }
+        if (mg && ok) {
+            const uint32_t slot = mc_ev_slots((uint32_t)__popcll(mg), (uint32_t)__popcll(mg & lt), cap_gaps, &counters[C_GAPS], gb_base, gb_used, &ok, lane);
+            if (!ok) { if (lane == 0) counters[C_OVERFLOW] = 3; }
+            else if (rc == 2) mc_store_stream(&gaps[slot], g);
+        }
+        MC_EV_TICK(4);
+    };
     McSeedTask tn;
     tn.read = MC_TASK_NONE; tn.chrono = 0; tn.posting = 0; tn.seedlen_nkey = 0;
     if ((uint64_t)cur * 64 + (uint32_t)lane < ntasks) tn = mc_load_stream(&tasks[(uint64_t)cur * 64 + (uint32_t)lane]);
-    for (;;) {
-        const bool last = cur >= nchunks;
-        if (!last) {   // ---- phase 1: the gate, one hit per lane
-            MC_EV_TICK(0);
-            const uint32_t tid = cur * 64u + (uint32_t)lane;
-            const McSeedTask t = tn;
-            {
-                uint32_t nxt = cur + 1;
-                if (cleft == 1 && lane == 0) pend = atomicAdd(&counters[C_EVCHUNK], 1u);
-                if (cleft > 0) cleft--;
-                else { nxt = (nwaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)pend)) * MC_EV_GROUP; cleft = MC_EV_GROUP - 1; }
-                const uint64_t nx = (uint64_t)nxt * 64 + (uint32_t)lane;
-                tn.read = MC_TASK_NONE;
-                if (nx < ntasks) tn = mc_load_stream(&tasks[nx]);
-                cur = nxt;
-            }
-            bool surv = false;
-            uint4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};
-            if (tid < ntasks && t.read != MC_TASK_NONE) {            // (MC_TASK_NONE: padding of a partly used block of the task pool)
-                const int frame = (int)(t.chrono >> 25), pos = (int)((t.chrono >> 17) & 0xff);
-                const int qlen = (L - frame % 3) / 3;
-                const uint32_t w3 = t.seedlen_nkey;
-                const int seedlen = (int)((w3 >> 24) & 15u), nkey = (int)(w3 >> 28), dpos = (int)(t.posting & 0x7ffu), sidx = (int)(t.posting >> 11);
-                const uint32_t o0 = (w3 & 0xFFFFFFu) - (uint32_t)dpos, rd = MC_TASK_READ_OF(t.read);
-                const uint8_t *q = frames + ((int64_t)rd * 6 + frame) * FP, *d = X.res + o0;
-                // residues pos - 8 .. pos + 15 of the frame and dpos - 8 .. dpos + 15 of the subject: six loads, one trip (rows and residue array have room on both sides)
-                const uint64_t q0 = mc_ld8(q + pos - 8), q1 = mc_ld8(q + pos), q2 = mc_ld8(q + pos + 8), d0 = mc_ld8(d + dpos - 8), d1 = mc_ld8(d + dpos), d2 = mc_ld8(d + dpos + 8);
-                const int qm1 = (int)(q0 >> 56), dm1 = (int)(d0 >> 56);
-                const int dlen = dpos + (int)MC_TASK_REM_OF(t.read);          // (the record carries what is left of the subject: no trip to its offsets)
-                int score = 0, ident = 0;
-#pragma unroll
-                for (int k = 0; k < 10; k++)
-                    if (k < seedlen) {
-                        const int a = (int)((k < 8 ? q1 >> (8 * k) : q2 >> (8 * (k - 8))) & 0xFFu), b = (int)((k < 8 ? d1 >> (8 * k) : d2 >> (8 * (k - 8))) & 0xFFu);
-                        score += MC_SUB(hot, a, b); ident += (a == b);
-                    }
-                const bool go = !(dpos + seedlen > dlen) && !(pos != 0 && dpos != 0 && hot.grp[qm1] == hot.grp[dm1] && nkey != 4);
-                int qp = 0, dp = 0, Lg = 0;
-                if (go) surv = mc_ev_gate(hot, q, qlen, pos, d, dlen, dpos, seedlen, score, ident, qp, dp, Lg, q0, q2, d0, d2);
-                e0.x = rd; e0.y = t.chrono; e0.z = o0; e0.w = (uint32_t)sidx;
-                e1.x = (uint32_t)qp | ((uint32_t)dp << 16); e1.y = (uint32_t)Lg | ((uint32_t)(uint16_t)(int16_t)score << 16); e1.z = (uint32_t)ident | ((uint32_t)dlen << 16);
-            }
-            const unsigned long long ms = __ballot(surv);
-            if (surv) { const uint32_t at = qn + (uint32_t)__popcll(ms & lt); Q[2 * at] = e0; Q[2 * at + 1] = e1; }
-            qn += (uint32_t)__popcll(ms);
-            mc_wave_sync();
-            MC_EV_TICK(1);
-        }
-        while (qn >= 64 || (last && qn > 0)) {   // ---- phase 2: the extension, 64 survivors at a time
-            const uint32_t take = qn < 64 ? qn : 64;
-            qn -= take;
-            const bool act = (uint32_t)lane < take;
-            const uint4 e0 = Q[2 * (qn + (act ? (uint32_t)lane : 0u))], e1 = Q[2 * (qn + (act ? (uint32_t)lane : 0u)) + 1];
-            mc_wave_sync();                                          // (read before the next survivors are written over them)
-            int rc = 0;
-            bool keep = false;
-            McGapTask g;
-            McHsp h;
-            if (act) {
-                const uint32_t read = e0.x, chrono = e0.y;
-                const int frame = (int)(chrono >> 25), qlen = (L - frame % 3) / 3, sidx = (int)e0.w;
-                const uint8_t *q = frames + ((int64_t)read * 6 + frame) * FP, *d = X.res + e0.z;
-                g.read = read; g.chrono = chrono;
-                rc = mc_ev_xdrop(hot, q, qlen, d, (int)(e1.z >> 16), sidx, (int)(e1.x & 0xFFFFu), (int)(e1.x >> 16), (int)(e1.y & 0xFFFFu), (int)(int16_t)(e1.y >> 16), (int)(e1.z & 0xFFFFu), &g);
-                MC_EV_TICK(2);
-                if (rc == 1) {
-                    h.read = read; h.chrono = chrono;
-                    keep = mc_make_hsp(*T, L, frame, g, g.qfwd, g.qfwd, g.qbwd, g.qbwd, g.score, g.nmatch, g.qfwd + g.L + g.qbwd, 0, 0, &h);
-                    if (keep && cand && mc_hsp_can_classify(*T, *P, X, fam, h)) cand[h.read] = 1;
-                    if (keep && h.loge < hot_loge_thr) low[h.read] = 1;      // (the read can print a row: k_order_light)
+    // the chunk after the current one: its number, and the request for the group after this one (one chunk ahead of need)
+    auto advance = [&]() -> uint32_t {
+        uint32_t nxt = cur + 1;
+        if (cleft == 1 && lane == 0) pend = atomicAdd(&counters[C_EVCHUNK], 1u);
+        if (cleft > 0) cleft--;
+        else { nxt = (nwaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)pend)) * MC_EV_GROUP; cleft = MC_EV_GROUP - 1; }
+        return nxt;
+    };
+    if constexpr (!RANGES) {
+        for (;;) {
+            const bool last = cur >= nchunks;
+            if (!last) {
+                MC_EV_TICK(0);
+                const uint32_t tid = cur * 64u + (uint32_t)lane;
+                const McSeedTask t = tn;
+                {
+                    const uint32_t nxt = advance();
+                    const uint64_t nx = (uint64_t)nxt * 64 + (uint32_t)lane;
+                    tn.read = MC_TASK_NONE;
+                    if (nx < ntasks) tn = mc_load_stream(&tasks[nx]);
+                    cur = nxt;
                 }
+                const uint32_t w3 = t.seedlen_nkey;
+                gate(tid < ntasks && t.read != MC_TASK_NONE, MC_TASK_READ_OF(t.read), t.chrono, t.posting, w3 & 0xFFFFFFu, (int)MC_TASK_REM_OF(t.read), (int)((w3 >> 24) & 15u), (int)(w3 >> 28));   // (MC_TASK_NONE: padding of a partly used block of the pool)
+                MC_EV_TICK(1);
             }
-            MC_EV_TICK(3);
-            const unsigned long long mh = __ballot(keep), mg = __ballot(rc == 2);
-            if (mh && ok) {
-                const uint32_t slot = mc_ev_slots((uint32_t)__popcll(mh), (uint32_t)__popcll(mh & lt), cap_hsps, &counters[C_HSPS], hb_base, hb_used, &ok, lane);
-                if (!ok) { if (lane == 0) counters[C_OVERFLOW] = 2; }
-                else if (keep) { mc_store_stream(&hsps[slot], h); __builtin_nontemporal_store(MC_HSP_KEY(h), &hkeys[slot]); __builtin_nontemporal_store(MC_HSP_PLACE(h), &hplace[slot]); }
-            }
-            if (mg && ok) {
-                const uint32_t slot = mc_ev_slots((uint32_t)__popcll(mg), (uint32_t)__popcll(mg & lt), cap_gaps, &counters[C_GAPS], gb_base, gb_used, &ok, lane);
-                if (!ok) { if (lane == 0) counters[C_OVERFLOW] = 3; }
-                else if (rc == 2) mc_store_stream(&gaps[slot], g);
-            }
-            MC_EV_TICK(4);
+            while (qn >= 64 || (last && qn > 0)) extend();
+            if (last) break;
         }
-        if (last) break;
+    } else {
+        // The record holds the INDEX of the hit's posting: posting, position in the residue array and rest of the subject come in one 8-byte
+        // load (MC_POST8) - asked for one chunk ahead (the records two chunks ahead), so that a chunk still makes one trip: the residues.
+        McSeedTask tn2;
+        tn2.read = MC_TASK_NONE; tn2.chrono = 0; tn2.posting = 0; tn2.seedlen_nkey = 0;
+        uint32_t tidn = cur * 64u + (uint32_t)lane, tidn2 = 0;       // the hit numbers of tn / tn2 (past the pool: no hit)
+        uint32_t cur2 = cur;
+        bool have_n = cur < nchunks, have_n2 = false;
+        unsigned long long p8n = 0;
+        if (have_n) {
+            cur2 = advance(); have_n2 = cur2 < nchunks; tidn2 = cur2 * 64u + (uint32_t)lane;
+            if (have_n2 && tidn2 < ntasks) tn2 = mc_load_stream(&tasks[tidn2]);
+            p8n = X.post8[(tidn < ntasks && tn.read != MC_TASK_NONE) ? tn.posting : 0u];
+        }
+        for (;;) {
+            const bool last = !have_n;
+            if (!last) {
+                MC_EV_TICK(0);
+                const McSeedTask t = tn;
+                const unsigned long long p8 = p8n;
+                const bool have = tidn < ntasks && t.read != MC_TASK_NONE;   // (MC_TASK_NONE: padding of a partly used block of the pool)
+                // the chunks behind: tn2 (arrived) becomes tn and its postings are asked for; the records of the chunk after it are asked for
+                tn = tn2; tidn = tidn2; have_n = have_n2;
+                if (have_n) {
+                    p8n = X.post8[(tidn < ntasks && tn.read != MC_TASK_NONE) ? tn.posting : 0u];
+                    cur = cur2; cur2 = advance(); have_n2 = cur2 < nchunks; tidn2 = cur2 * 64u + (uint32_t)lane;
+                    tn2.read = MC_TASK_NONE;
+                    if (have_n2 && tidn2 < ntasks) tn2 = mc_load_stream(&tasks[tidn2]);
+                }
+                const uint32_t w3 = t.seedlen_nkey;
+                gate(have, MC_TASK_READ_OF(t.read), t.chrono, (uint32_t)p8 & 0x3FFFFFFu, (uint32_t)(p8 >> 26) & 0xFFFFFFu, (int)(p8 >> 50), (int)((w3 >> 24) & 15u), (int)(w3 >> 28));
+                MC_EV_TICK(1);
+            }
+            while (qn >= 64 || (last && qn > 0)) extend();
+            if (last) break;
+        }
     }
     {   // what the wave did not use of its last blocks: records the later stages skip
         const uint32_t ph = hb_used < MC_EV_BLK ? MC_EV_BLK - hb_used : 0u, pg = gb_used < MC_EV_BLK ? MC_EV_BLK - gb_used : 0u;

@@ -77,6 +77,7 @@ struct McIndex {
     const uint32_t *off;       // nseq+1
     const uint32_t *bstart;    // MC_NBUCKET+1
     const uint32_t *post;      // seqIdx<<11 | pos, in prerapsearch bucket order
+    const unsigned long long *post8;   // (device) the same postings with what the evaluation of a hit needs beside them: posting 26 bits | position in the residue array 24 << 26 | what is left of the subject from there 11 << 50 (MC_POST8)
     const uint16_t *keys;      // 4 reduced residues after the 6-mer, 0xF past the sequence end
     const struct McBucketRec *rec;   // per bucket: start + first-residue group boundaries (NULL when the index cannot use them)
     const uint32_t *wild;      // MC_WILD_LINES x 8 words: wildcard filter (mc_wild_*)
@@ -105,6 +106,7 @@ struct McSeedTask {
 #define MC_TASK_REM_OF(w) ((w) >> 21)
 static_assert(MC_TASK_READ_OF(0xFFFFFFFFu) == 0x1FFFFFu, "the padding record (read = all ones) is no read of a batch: a batch holds at most 2,097,151 reads");
 #define MC_TASK_ABS_LIMIT (1u << 24)
+#define MC_POST8(pst, abs, rem) ((unsigned long long)(pst) | ((unsigned long long)(abs) << 26) | ((unsigned long long)(rem) << 50))   // (posting < 2^26: at most 32,767 sequences of at most 2,047 residues)
 
 // seed hit whose ungapped score reached the gapped trigger (AlignSeqs 0x4134c8)
 struct McGapTask {

@@ -53,7 +53,7 @@ struct mc_handle {
     std::vector<int32_t> fam;
     int nfam = 0, device = 0;
     // device index + tables
-    uint8_t *d_res = nullptr, *d_res_base = nullptr; uint32_t *d_off = nullptr, *d_bstart = nullptr, *d_post = nullptr; uint16_t *d_keys = nullptr; int32_t *d_fam = nullptr;
+    uint8_t *d_res = nullptr, *d_res_base = nullptr; uint32_t *d_off = nullptr, *d_bstart = nullptr, *d_post = nullptr; unsigned long long *d_post8 = nullptr; uint16_t *d_keys = nullptr; int32_t *d_fam = nullptr;
     McTables *d_T = nullptr; McClassPars *d_P = nullptr;
     McTables hT; McClassPars hP;
     int read_len = 0, FP = 0; bool run_set = false;
@@ -86,7 +86,7 @@ struct mc_handle {
 
 static McIndex dev_index(const mc_handle *h)
 {
-    McIndex X; X.res = h->d_res; X.off = h->d_off; X.bstart = h->d_bstart; X.post = h->d_post; X.keys = h->d_keys; X.rec = h->d_rec; X.filt = h->d_filt; X.wild = h->d_wild; X.pair = h->d_pair; X.rt = h->d_rt; X.rt_mask = h->H.rt_mask; X.nseq = h->H.nseq;
+    McIndex X; X.res = h->d_res; X.off = h->d_off; X.bstart = h->d_bstart; X.post = h->d_post; X.post8 = h->d_post8; X.keys = h->d_keys; X.rec = h->d_rec; X.filt = h->d_filt; X.wild = h->d_wild; X.pair = h->d_pair; X.rt = h->d_rt; X.rt_mask = h->H.rt_mask; X.nseq = h->H.nseq;
     return X;
 }
 
@@ -125,7 +125,7 @@ extern "C" void mc_close(mc_handle *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void *ptrs[] = {h->d_res_base, h->d_off, h->d_bstart, h->d_post, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_pair, h->d_rt, h->d_segtab};
+    void *ptrs[] = {h->d_res_base, h->d_off, h->d_bstart, h->d_post, h->d_post8, h->d_keys, h->d_fam, h->d_T, h->d_P, h->d_reads, h->d_bitmap, h->d_rec, h->d_filt, h->d_wild, h->d_pair, h->d_rt, h->d_segtab};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (McCtx &c : h->ctx) ctx_free(c);
     for (int k = 0; k < 2; k++) { if (h->stage_pin[k]) (void)hipHostFree(h->stage_pin[k]); if (h->stage_dev[k]) (void)hipFree(h->stage_dev[k]); }
@@ -204,7 +204,7 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
     HIPCK(hipStreamCreate(&h->rows_stream)); HIPCK(hipEventCreateWithFlags(&h->ev_rows, hipEventDisableTiming));
     const McHostIndex &H = h->H;
     if (H.res.size() >= MC_TASK_ABS_LIMIT) { g_err = "marker database too large: more than 16 M residues (MC_TASK_W3)"; return -1; }
-    if (dalloc(&h->d_res_base, H.res.size() + 128) || dalloc(&h->d_off, H.off.size()) || dalloc(&h->d_bstart, H.bstart.size()) || dalloc(&h->d_post, H.post.size() + 1) ||
+    if (dalloc(&h->d_res_base, H.res.size() + 128) || dalloc(&h->d_off, H.off.size()) || dalloc(&h->d_bstart, H.bstart.size()) || dalloc(&h->d_post, H.post.size() + 1) || dalloc(&h->d_post8, H.post.size() + 1) ||
         dalloc(&h->d_keys, H.keys.size()) || dalloc(&h->d_fam, (size_t)nseq) || dalloc(&h->d_T, 1) || dalloc(&h->d_P, 1)) return -1;
     HIPCK(hipMemset(h->d_res_base, MC_INV, H.res.size() + 128));
     h->d_res = h->d_res_base + 64;                                 // (k_gapped_lds reads 16 bytes at a time around a flank's first residues)
@@ -218,6 +218,9 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
             up.put(h->d_rt, H.rt.data(), H.rt.size() * 8) || up.put(h->d_filt, H.filt.data(), H.filt.size() * 4) ||
             (!H.rec.empty() && up.put(h->d_rec, H.rec.data(), H.rec.size() * sizeof(McBucketRec))) || up.finish()) return -1;
     }
+    if (H.nseq > 32767) { g_err = "marker database too large: more than 32,767 sequences (MC_POST8)"; return -1; }
+    k_post8<<<dim3((unsigned)((H.post.size() + 255) / 256)), dim3(256)>>>(h->d_post, h->d_off, (uint32_t)H.post.size(), h->d_post8);
+    HIPCK(hipDeviceSynchronize());
     MC_OT("  index upload", t0);
     if (H.max_bucket > 2047) { g_err = "a seed bucket holds more than 2047 postings: the hit-order key cannot index it"; return -1; }
     // the position-parallel seed kernel is exact only when the frequency threshold is 0 and no letter frequency is 0
@@ -530,9 +533,11 @@ static int stage_a(mc_handle *h, McCtx &c)
     HIPCK(hipEventRecord(c.ev[2], st));
     // the number of seed hits stays on the device: persistent workgroups walk the pool
     const size_t lds_ev = (size_t)(MC_EV_BS / 64) * MC_EV_QCAP * 32;   // a queue of survivors per wave: 32 KB per workgroup
-    HIPCK(hipFuncSetAttribute((const void *)k_eval_seeds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ev));
+    const bool ranges = h->fast_enum && !h->count_traffic;            // k_enumerate_q writes ranges of hits, the other two seed kernels single hits
+    HIPCK(hipFuncSetAttribute(ranges ? (const void *)k_eval_seeds<true> : (const void *)k_eval_seeds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ev));
     static const unsigned ev_bpc = getenv("MC_EV_BPC") ? (unsigned)std::max(1, std::min(8, atoi(getenv("MC_EV_BPC")))) : (unsigned)MC_EV_BPC;   // (experiments)
-    k_eval_seeds<<<dim3(256u * ev_bpc), dim3(MC_EV_BS), lds_ev, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_tasks, c.d_counters + C_TASKS, c.cap_tasks, c.d_hsps, c.cap_hsps, c.d_gaps, c.cap_gaps, c.d_counters, h->d_P, h->d_fam, h->best_only ? c.d_cand : nullptr, c.d_hkeys, c.d_low, c.d_hplace);
+    if (ranges) k_eval_seeds<true><<<dim3(256u * ev_bpc), dim3(MC_EV_BS), lds_ev, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_tasks, c.d_counters + C_TASKS, c.cap_tasks, c.d_hsps, c.cap_hsps, c.d_gaps, c.cap_gaps, c.d_counters, h->d_P, h->d_fam, h->best_only ? c.d_cand : nullptr, c.d_hkeys, c.d_low, c.d_hplace);
+    else k_eval_seeds<false><<<dim3(256u * ev_bpc), dim3(MC_EV_BS), lds_ev, st>>>(h->d_T, X, c.d_frames, FP, L, c.d_tasks, c.d_counters + C_TASKS, c.cap_tasks, c.d_hsps, c.cap_hsps, c.d_gaps, c.cap_gaps, c.d_counters, h->d_P, h->d_fam, h->best_only ? c.d_cand : nullptr, c.d_hkeys, c.d_low, c.d_hplace);
     HIPCK(hipEventRecord(c.ev[3], st));
     return counters_to_host(c);
 }

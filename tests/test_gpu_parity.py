@@ -140,7 +140,7 @@ def test_every_stage_equals_the_emulation(case, engine, tmp_path):
     end-to-end m8 equality only reports): what the stages of mc_run_range leave on the device (mc_debug_stage) against what the
     CPU emulation of the same per-thread code makes (tests/emul/mc_emul, itself pinned on the reference's m8) -
     the six translated and SEG-masked frames of every read byte for byte (k_translate_seg; BuildQHash@0x40b530, Seg::*), the
-    multiset of seed hits (k_enumerate_t0; Searching@0x415050) with the positions in the residue array the kernels carry, the
+    multiset of seed hits (k_enumerate_q; Searching@0x415050: written with the index of the posting, looked up here), the
     multiset of gap tasks and the multiset of HSPs, ungapped and gapped (k_eval_seeds, k_gap_*; ExtendSeq2Set@0x413b90,
     AlignGapped@0x40a550, CalRes@0x4077a0)."""
     import re
@@ -182,13 +182,14 @@ def test_every_stage_equals_the_emulation(case, engine, tmp_path):
     te = np.fromfile(pre + ".tasks", task_dt)
     tg = engine.debug_stage(1).reshape(-1).view(task_dt)
     tg = tg[tg["read"] != 0xFFFFFFFF]                                                   # (padding of the blocks of the pool)
+    # the product's seed kernel (k_enumerate_q) writes the INDEX of a hit's posting in the index's posting array, not the posting (the
+    # evaluation kernel fetches it with the subject's offsets in one load: MC_POST8)
+    post = engine.index_view()["post"].astype(np.int64)
     assert len(tg) == len(te) == st["seed_tasks"] and len(te) > 1000
-    off = engine.index_view()["off"].astype(np.int64)
+    assert (tg["read"] >> 21 == 0).all() and (tg["w3"] & 0xFFFFFF == 0).all()
     norm_e = np.stack([te["read"], te["chrono"], te["posting"], te["w3"] & 0xFF, te["w3"] >> 8], 1).astype(np.int64)
-    norm_g = np.stack([tg["read"] & 0x1FFFFF, tg["chrono"], tg["posting"], (tg["w3"] >> 24) & 15, tg["w3"] >> 28], 1).astype(np.int64)
+    norm_g = np.stack([tg["read"], tg["chrono"], post[tg["posting"].astype(np.int64)], (tg["w3"] >> 24) & 15, tg["w3"] >> 28], 1).astype(np.int64)
     assert np.array_equal(norm_e[np.lexsort(norm_e.T[::-1])], norm_g[np.lexsort(norm_g.T[::-1])])
-    assert np.array_equal((tg["w3"] & 0xFFFFFF).astype(np.int64), off[tg["posting"] >> 11] + (tg["posting"] & 0x7FF))
-    assert np.array_equal((tg["read"] >> 21).astype(np.int64), off[(tg["posting"] >> 11) + 1] - off[tg["posting"] >> 11] - (tg["posting"] & 0x7FF))   # what is left of the subject (MC_TASK_READ)
     # ---- gap tasks
     gap_dt = np.dtype({"names": ["read", "chrono", "sidx", "qp", "dp", "L", "qfwd", "qbwd", "score", "nmatch"],
                        "formats": ["<u4", "<u4", "<u4", "<i2", "<i2", "<i2", "<i2", "<i2", "<i2", "<i2"], "offsets": [0, 4, 8, 12, 14, 16, 18, 20, 22, 24], "itemsize": 28})
