@@ -143,6 +143,7 @@ __device__ unsigned long long g_ev_acc[8];           // wave time per phase, sum
 #define MC_EV_BS 256         // threads per workgroup (the waves are on their own: the size only sets how the LDS is handed out)
 #define MC_EV_BPC 5          // workgroups per CU: 20 waves, 5 per SIMD - 88 registers, nothing spilled (measured per 1 M reads of 150 / 300 bp:
                              // 7 waves per SIMD and 72 registers with 52 bytes of scratch 3.50 / 7.77 ms, 6 with 80 and 12 bytes 2.82 / 6.41, 5 with 88 2.60 / 6.01, 4: 2.79 / 6.53)
+                             // (again after the postings moved here - <true>, 85 registers: 6 waves per SIMD 2.89 / 6.29, 5: 2.57 / 5.67, 4: 2.66 / 6.06)
 #define MC_EV_QCAP 128       // survivors of the gate a wave holds (32 bytes each: 4 KB of LDS per wave)
 #define MC_EV_BLK 256u       // slots of the HSP / gap-task pools a wave reserves at a time (one global atomic per block)
 #ifndef MC_EV_GROUP
