@@ -451,7 +451,12 @@ size_t whole_lines(const uint8_t *p, size_t n)
 // ------------------------------------------------------------------------------------------------------------------
 // parse_seqs as a restartable state machine over a region of whole lines, and the per-record evaluation
 // ------------------------------------------------------------------------------------------------------------------
-enum : uint8_t { R_SHORT = 1, R_QUAL = 2, R_RCBAD = 4, R_PASS = 8, R_LOWQ = 16 };   // (R_PASS / R_LOWQ: the sampler's verdict, where the parser may give it - Params::decide)
+// R_PASS / R_LOWQ / R_DUP / R_ERR: the sampler's verdict, given off the file-order walk - by the parser's threads (Params::decide: no -d,
+// a record's fate depends on nothing but itself) or by the walkers of the duplicate classes (Params::shards: -d).  R_ERR: the reference
+// raises at this record if its sampler gets that far (err_text)
+enum : uint8_t { R_SHORT = 1, R_QUAL = 2, R_RCBAD = 4, R_PASS = 8, R_LOWQ = 16, R_DUP = 32, R_ERR = 64,
+                 R_STABLE = 128 };                      // the sequence lies in a plain file's mapping, which outlives the sampler's set (no copy kept)
+enum { NSHARD = 64 };                                  // duplicate classes are dealt to this many sets by the top bits of their key (Params::shards)
 struct Rec {
     const uint8_t *seq; const uint8_t *qual;
     uint32_t len, qlen;
@@ -459,7 +464,10 @@ struct Rec {
     uint64_t h1, h2;                                   // hashes of the sequence and of its reverse complement (only with -d)
     uint32_t out;                                      // slot in the output of this region (or ~0)
     uint8_t flags;
+    uint8_t shard;                                     // of the record's duplicate class: top bits of min(h1, h2) - a sequence and its reverse complement share it
 };
+
+struct ShItem { uint64_t h1, h2; const uint8_t *seq; uint32_t len, idx; uint8_t q; };   // q: in - the quality filter's verdict (R_PASS / R_LOWQ / R_ERR) | R_STABLE; out - the sampler's (R_DUP or that verdict)
 
 struct Arena {   // stable storage for records whose sequence spans several lines
     std::vector<std::unique_ptr<uint8_t[]>> blocks; size_t at = 0, cap = 0;
@@ -478,10 +486,19 @@ struct Piece {
     std::vector<Rec> recs;
     Arena arena;
     int64_t bases = 0;
-    // with Params::decide: how many of the piece's records are too short / fail the quality filter / pass, and whether one of them is a
-    // record the sampler would raise an error at (then the region is decided record by record, in file order, as without decide)
-    int64_t n_short = 0, n_lowq = 0, n_pass = 0;
+    // with Params::decide / shards: how many of the piece's records are too short / fail the quality filter / pass / are duplicates, and
+    // whether one of them is a record the sampler would raise an error at (then the piece is walked record by record, in file order)
+    int64_t n_short = 0, n_lowq = 0, n_pass = 0, n_dup = 0;
     bool anomaly = false;
+    // with Params::shards: the piece's long-enough records grouped by the shard of their duplicate class, file order inside a shard -
+    // everything a class's walker needs of a record in one place, read in a stream (the records themselves lie in another core's cache)
+    std::vector<ShItem> sh_items; uint32_t sh_off[NSHARD + 1] = {};
+    // for the next region: the vectors keep their memory (fresh ones are page faults - several times the parse itself in a process's first run)
+    void reset()
+    {
+        start = stop = end = 0; done = ragged = anomaly = false; recs.clear(); sh_items.clear(); if (!arena.blocks.empty()) arena.clear();
+        bases = n_short = n_lowq = n_pass = n_dup = 0;
+    }
 };
 
 struct Line { const uint8_t *p; size_t n; bool nl; size_t off; };
@@ -521,46 +538,98 @@ inline bool next_line(const uint8_t *base, size_t &pos, size_t e, Line &ln)
     return true;
 }
 
+// 64-bit hash of a byte string, and the same hash of its reverse complement read off the string backwards (both only with -d).
+// Four lanes - word i of the string goes to lane i mod 4 - so that four multiplications are in flight instead of one chain of n / 8
+// dependent ones (a 300-base sequence: 38 words; the two hashes were a third of the parser's time with -d).
+#define MC_HMIX(x, w) do { (x) = ((x) ^ (w)) * 0x9FB21C651E98DF25ull; (x) ^= (x) >> 29; } while (0)
+struct H4 {
+    uint64_t a, b, c, d;
+    explicit H4(size_t n)
+    {
+        const uint64_t s = 0x9E3779B97F4A7C15ull ^ (n * 0xff51afd7ed558ccdull);
+        a = s; b = s ^ 0xD6E8FEB86659FD93ull; c = s ^ 0xA0761D6478BD642Full; d = s ^ 0xE7037ED1A0B428DBull;
+    }
+    void lane(unsigned k, uint64_t w) { switch (k & 3) { case 0: MC_HMIX(a, w); break; case 1: MC_HMIX(b, w); break; case 2: MC_HMIX(c, w); break; default: MC_HMIX(d, w); } }
+    uint64_t fin() const
+    {
+        uint64_t h = a;
+        h = (h ^ (b << 21 | b >> 43)) * 0x9FB21C651E98DF25ull; h ^= h >> 29;
+        h = (h ^ (c << 42 | c >> 22)) * 0x9FB21C651E98DF25ull; h ^= h >> 29;
+        h = (h ^ (d << 11 | d >> 53)) * 0x9FB21C651E98DF25ull; h ^= h >> 29;
+        h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 32;
+        return h;
+    }
+};
 uint64_t h64(const uint8_t *p, size_t n)
 {
-    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xff51afd7ed558ccdull);
+    H4 h(n);
     size_t i = 0;
-    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = (h ^ w) * 0x9FB21C651E98DF25ull; h ^= h >> 29; }
-    uint64_t w = 0;
-    if (i < n) { memcpy(&w, p + i, n - i); h = (h ^ w) * 0x9FB21C651E98DF25ull; h ^= h >> 29; }
-    h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 32;
-    return h;
+    for (; i + 32 <= n; i += 32) {
+        uint64_t w0, w1, w2, w3;
+        memcpy(&w0, p + i, 8); memcpy(&w1, p + i + 8, 8); memcpy(&w2, p + i + 16, 8); memcpy(&w3, p + i + 24, 8);
+        MC_HMIX(h.a, w0); MC_HMIX(h.b, w1); MC_HMIX(h.c, w2); MC_HMIX(h.d, w3);
+    }
+    unsigned k = 0;
+    for (; i + 8 <= n; i += 8, k++) { uint64_t w; memcpy(&w, p + i, 8); h.lane(k, w); }
+    if (i < n) { uint64_t w = 0; memcpy(&w, p + i, n - i); h.lane(k, w); }
+    return h.fin();
 }
 struct RcTab { uint8_t t[256]; RcTab() { memset(t, 0, sizeof t); t['A'] = 'T'; t['T'] = 'A'; t['G'] = 'C'; t['C'] = 'G'; t['N'] = 'N'; } };
 const RcTab g_rc;
-// the same hash over the reverse complement, read off the sequence backwards; false: a base outside ACGTN
+// h64 of the reverse complement, read off the sequence backwards; false: a base outside ACGTN (the value is of no use then).
+// 16 bases at a time where SSE2 is there: complement = the byte XOR 0x15 for A / T, XOR 0x04 for C / G, N as it is; a word of the
+// reverse complement is the byte-swapped word of the complement.
 bool h64_rc(const uint8_t *p, size_t n, uint64_t *out)
 {
-    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xff51afd7ed558ccdull);
+    H4 h(n);
     uint8_t all = 0xFF;
     size_t i = 0;
+    unsigned k = 0;                                                  // the next word's lane
     const uint8_t *q = p + n;
-    for (; i + 8 <= n; i += 8) {
+#if defined(__SSE2__)
+    {
+        const __m128i cA = _mm_set1_epi8('A'), cC = _mm_set1_epi8('C'), cG = _mm_set1_epi8('G'), cT = _mm_set1_epi8('T'), cN = _mm_set1_epi8('N');
+        const __m128i xAT = _mm_set1_epi8(0x15), xCG = _mm_set1_epi8(0x04);
+        int ok = 0xFFFF;
+        auto comp16 = [&](const uint8_t *src, uint64_t &first, uint64_t &second) {   // the two words of the reverse complement that 16 bases make
+            const __m128i v = _mm_loadu_si128((const __m128i *)src);
+            const __m128i at = _mm_or_si128(_mm_cmpeq_epi8(v, cA), _mm_cmpeq_epi8(v, cT)), cg = _mm_or_si128(_mm_cmpeq_epi8(v, cC), _mm_cmpeq_epi8(v, cG));
+            ok &= _mm_movemask_epi8(_mm_or_si128(_mm_or_si128(at, cg), _mm_cmpeq_epi8(v, cN)));
+            const __m128i c = _mm_xor_si128(v, _mm_or_si128(_mm_and_si128(at, xAT), _mm_and_si128(cg, xCG)));
+            first = __builtin_bswap64((uint64_t)_mm_cvtsi128_si64(_mm_unpackhi_epi64(c, c))); second = __builtin_bswap64((uint64_t)_mm_cvtsi128_si64(c));
+        };
+        for (; i + 32 <= n; i += 32) {
+            q -= 32;
+            uint64_t w0, w1, w2, w3;
+            comp16(q + 16, w0, w1); comp16(q, w2, w3);
+            MC_HMIX(h.a, w0); MC_HMIX(h.b, w1); MC_HMIX(h.c, w2); MC_HMIX(h.d, w3);
+        }
+        if (i + 16 <= n) { q -= 16; uint64_t w0, w1; comp16(q, w0, w1); h.lane(0, w0); h.lane(1, w1); i += 16; k = 2; }
+        if (ok != 0xFFFF) all = 0;
+    }
+#endif
+    for (; i + 8 <= n; i += 8, k++) {
         uint64_t w = 0;
-        for (int k = 0; k < 8; k++) { const uint8_t d = g_rc.t[*--q]; all &= (uint8_t)(d ? 0xFF : 0); w |= (uint64_t)d << (8 * k); }
-        h = (h ^ w) * 0x9FB21C651E98DF25ull; h ^= h >> 29;
+        for (int j = 0; j < 8; j++) { const uint8_t d = g_rc.t[*--q]; all &= (uint8_t)(d ? 0xFF : 0); w |= (uint64_t)d << (8 * j); }
+        h.lane(k, w);
     }
     if (i < n) {
         uint64_t w = 0;
-        for (int k = 0; i < n; i++, k++) { const uint8_t d = g_rc.t[*--q]; all &= (uint8_t)(d ? 0xFF : 0); w |= (uint64_t)d << (8 * k); }
-        h = (h ^ w) * 0x9FB21C651E98DF25ull; h ^= h >> 29;
+        for (int j = 0; i < n; i++, j++) { const uint8_t d = g_rc.t[*--q]; all &= (uint8_t)(d ? 0xFF : 0); w |= (uint64_t)d << (8 * j); }
+        h.lane(k, w);
     }
-    h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 32;
-    *out = h;
+    *out = h.fin();
     return all != 0 || n == 0;
 }
 
 struct Params { size_t L = 0; int fastq = 0, qoff = 0, dups = 0; bool count_only = false;
-                bool decide = false; double max_unknown = 0, mean_q = 0, min_q = 0; };   // decide: the quality filter's verdict per record is given by the parser's threads (no -d: a record's fate depends on nothing but itself)
+                bool decide = false; double max_unknown = 0, mean_q = 0, min_q = 0;   // decide: the quality filter's verdict per record is given by the parser's threads (no -d: a record's fate depends on nothing but itself)
+                bool shards = false;
+                bool stable = false; };                                               // stable: the file is a mapping that stays until the sampler ends                                               // shards: -d - the parser's threads group their records by duplicate class, the classes' walkers give the verdicts
 
 void evaluate(Rec &r, const Params &P)
 {
-    r.flags = (r.qual ? R_QUAL : 0); r.out = ~0u;
+    r.flags = (r.qual ? R_QUAL : 0); r.out = ~0u; r.shard = 0;
     r.ncount = 0; r.nq = 0; r.qmin = 1 << 30; r.qsum = 0; r.h1 = r.h2 = 0;
     if (P.count_only) return;
     if (r.len < P.L) { r.flags |= R_SHORT; return; }
@@ -573,7 +642,7 @@ void evaluate(Rec &r, const Params &P)
         for (size_t i = 0; i < nq; i++) { const int q = (int)r.qual[i] - P.qoff; sum += q; mn = q < mn ? q : mn; }
         r.nq = (uint32_t)nq; r.qsum = sum; r.qmin = mn;
     }
-    if (P.dups) { r.h1 = h64(r.seq, r.len); if (!h64_rc(r.seq, r.len, &r.h2)) r.flags |= R_RCBAD; }
+    if (P.dups) { r.h1 = h64(r.seq, r.len); if (!h64_rc(r.seq, r.len, &r.h2)) r.flags |= R_RCBAD; r.shard = (uint8_t)((r.h1 < r.h2 ? r.h1 : r.h2) >> 58); }
 }
 // quality_filter (reference :269-291) as mc_reader_run's loop states it, for one record that is long enough; false: the sampler
 // would raise at this record
@@ -592,7 +661,34 @@ inline bool decide(Rec &r, const Params &P)
 // Runs parse_seqs (reference :294-325) over region[start, e) until a header line at an offset >= stop would be consumed (or
 // the region ends).  eof: the region ends the file (else an unfinished record at its end is left for the next region:
 // pc.end = offset of its header line).
+void parse_piece_lines(const uint8_t *base, size_t e, bool eof, Piece &pc, const Params &P);
 void parse_piece(const uint8_t *base, size_t e, bool eof, Piece &pc, const Params &P)
+{
+    parse_piece_lines(base, e, eof, pc, P);
+    if (!P.shards) return;
+    // -d: the piece's long-enough records grouped by the shard of their duplicate class (a counting sort; file order inside a shard),
+    // each with the quality filter's verdict - which counts if the record turns out to be nobody's duplicate.
+    // A record with a base outside ACGTN can be nobody's duplicate - a sequence enters the set only behind its own reverse_complement(),
+    // which raises for such a base - so it has its verdict already: the reference raises there
+    uint32_t cnt[NSHARD] = {};
+    for (Rec &r : pc.recs) {
+        if (r.flags & R_SHORT) continue;
+        if (r.flags & R_RCBAD) { r.flags |= R_ERR; continue; }
+        cnt[r.shard]++;
+    }
+    uint32_t at = 0;
+    for (int s = 0; s < NSHARD; s++) { pc.sh_off[s] = at; at += cnt[s]; cnt[s] = pc.sh_off[s]; }
+    pc.sh_off[NSHARD] = at;
+    pc.sh_items.resize(at);
+    for (size_t i = 0; i < pc.recs.size(); i++) {
+        Rec &r = pc.recs[i];
+        if (r.flags & (R_SHORT | R_RCBAD)) continue;
+        Rec t = r;
+        const uint8_t q = !decide(t, P) ? R_ERR : (t.flags & (R_PASS | R_LOWQ));
+        pc.sh_items[cnt[r.shard]++] = ShItem{r.h1, r.h2, r.seq, r.len, (uint32_t)i, (uint8_t)(q | (r.flags & R_STABLE))};
+    }
+}
+void parse_piece_lines(const uint8_t *base, size_t e, bool eof, Piece &pc, const Params &P)
 {
     size_t pos = pc.start;
     const size_t stop = pc.stop;
@@ -603,9 +699,10 @@ void parse_piece(const uint8_t *base, size_t e, bool eof, Piece &pc, const Param
     auto emit = [&](const uint8_t *s, size_t sn, const uint8_t *q, size_t qn, bool hasq) {
         Rec r; r.seq = s; r.len = (uint32_t)sn; r.qual = hasq ? q : nullptr; r.qlen = hasq ? (uint32_t)qn : 0;
         evaluate(r, P);
+        if (P.stable && s >= base && s < base + e) r.flags |= R_STABLE;   // (not a sequence joined from several lines in the piece's arena)
         if (P.decide) {
             if (r.flags & R_SHORT) pc.n_short++;
-            else if (!decide(r, P)) pc.anomaly = true;
+            else if (!decide(r, P)) { r.flags |= R_ERR; pc.anomaly = true; }
             else if (r.flags & R_PASS) pc.n_pass++;
             else pc.n_lowq++;
         }
@@ -698,46 +795,74 @@ size_t guess_start(const uint8_t *base, size_t from, size_t e, int max_lines = 6
     return e;
 }
 
-// Exact set of the accepted (untrimmed) sequences for -d: the strings live back to back in one arena, an open-addressing
-// table holds (hash, offset) - no allocation per sequence, one cache miss per lookup; equality is decided on the bytes.
+// Anonymous memory by the megabyte, straight from the kernel (null on failure).  (Asked to be backed by huge pages - MADV_HUGEPAGE, one
+// fault per 2 MB - it was SLOWER here: with transparent huge pages' defrag on "madvise" every such fault may compact memory first;
+// sampler + copies of 600 k records 0.04 -> 0.10 - 1.3 s.)
+struct BigPages {
+    static constexpr size_t HP = (size_t)2 << 20;
+    static uint8_t *get(size_t &bytes)
+    {
+        bytes = (bytes + HP - 1) & ~(HP - 1);
+        uint8_t *p = (uint8_t *)mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        return p == (uint8_t *)MAP_FAILED ? nullptr : p;
+    }
+};
+
+// Exact set of the accepted (untrimmed) sequences for -d: the strings live back to back in blocks that never move, an
+// open-addressing table holds (hash, pointer) in one 16-byte slot - no allocation per sequence, one cache miss per lookup (which
+// the walkers of the classes ask for ahead of time: prefetch); equality is decided on the bytes.
 struct SeqSet {
-    std::vector<uint8_t> arena;
-    std::vector<uint64_t> hash, off;             // off: arena offset + 1 (0 = empty slot); the length sits in front of the bytes
+    struct Slot { uint32_t h, len; const uint8_t *p; };             // h: the hash's lower half (its low bits place the slot: tables of up to 2^32 slots); p null = empty slot
+    std::vector<Slot> tab;
+    std::vector<std::pair<uint8_t *, size_t>> blocks; size_t at = 0, cap = 0;
     size_t used = 0;
+    SeqSet() = default;
+    SeqSet(const SeqSet &) = delete;
+    SeqSet &operator=(const SeqSet &) = delete;
+    ~SeqSet() { for (auto &b : blocks) munmap(b.first, b.second); }
     void grow()
     {
-        const size_t cap = hash.empty() ? (1u << 16) : hash.size() * 2;
-        std::vector<uint64_t> nh(cap, 0), no(cap, 0);
-        for (size_t i = 0; i < hash.size(); i++) if (off[i]) { size_t j = hash[i] & (cap - 1); while (no[j]) j = (j + 1) & (cap - 1); nh[j] = hash[i]; no[j] = off[i]; }
-        hash.swap(nh); off.swap(no);
+        const size_t n = tab.empty() ? (1u << 12) : tab.size() * 2;
+        std::vector<Slot> nt(n, Slot{0, 0, nullptr});
+        for (const Slot &sl : tab) if (sl.p) { size_t j = sl.h & (n - 1); while (nt[j].p) j = (j + 1) & (n - 1); nt[j] = sl; }
+        tab.swap(nt);
     }
+    void prefetch(uint64_t h) const { if (!tab.empty()) __builtin_prefetch(&tab[h & (tab.size() - 1)]); }
     // is s (rc = false) or the reverse complement of s (rc = true) in the set?  h = the matching hash
     bool contains(uint64_t h, const uint8_t *s, size_t n, bool rc) const
     {
-        if (hash.empty()) return false;
-        for (size_t j = h & (hash.size() - 1);; j = (j + 1) & (hash.size() - 1)) {
-            if (!off[j]) return false;
-            if (hash[j] == h) {
-                const uint8_t *q = arena.data() + (off[j] - 1);
-                uint64_t len; memcpy(&len, q, 8);
-                if (len == n) {
-                    q += 8;
-                    if (!rc) { if (memcmp(q, s, n) == 0) return true; }
-                    else { size_t i = 0; for (; i < n; i++) if (q[i] != g_rc.t[s[n - 1 - i]]) break; if (i == n) return true; }
-                }
+        if (tab.empty()) return false;
+        const uint32_t hh = (uint32_t)h;
+        for (size_t j = h & (tab.size() - 1);; j = (j + 1) & (tab.size() - 1)) {
+            const uint8_t *q = tab[j].p;
+            if (!q) return false;
+            if (tab[j].h == hh && tab[j].len == n) {
+                if (!rc) { if (memcmp(q, s, n) == 0) return true; }
+                else { size_t i = 0; for (; i < n; i++) if (q[i] != g_rc.t[s[n - 1 - i]]) break; if (i == n) return true; }
             }
         }
     }
-    void insert(uint64_t h, const uint8_t *s, size_t n)              // (the caller has checked that it is not there)
+    // (the caller has checked that it is not there); stable: the bytes outlive the set - no copy; false: out of memory
+    bool insert(uint64_t h, const uint8_t *s, size_t n, bool stable)
     {
-        if ((used + 1) * 2 > hash.size()) grow();
-        const uint64_t len = n;
-        const size_t o = arena.size();
-        arena.resize(o + 8 + n);
-        memcpy(arena.data() + o, &len, 8); memcpy(arena.data() + o + 8, s, n);
-        size_t j = h & (hash.size() - 1);
-        while (off[j]) j = (j + 1) & (hash.size() - 1);
-        hash[j] = h; off[j] = o + 1; used++;
+        if ((used + 1) * 2 > tab.size()) { try { grow(); } catch (const std::bad_alloc &) { return false; } }
+        const uint8_t *o = s;
+        if (!stable) {
+            const size_t need = (n + 7) & ~(size_t)7;
+            if (at + need > cap) {
+                size_t want = std::max<size_t>(need, BigPages::HP);
+                uint8_t *b = BigPages::get(want);
+                if (!b) return false;
+                blocks.emplace_back(b, want); cap = want; at = 0;
+            }
+            uint8_t *w = blocks.back().first + at; at += need;
+            memcpy(w, s, n);
+            o = w;
+        }
+        size_t j = h & (tab.size() - 1);
+        while (tab[j].p) j = (j + 1) & (tab.size() - 1);
+        tab[j] = Slot{(uint32_t)h, (uint32_t)n, o}; used++;
+        return true;
     }
 };
 
@@ -785,13 +910,19 @@ int inflate_threads()
 // One file, region by region.  on_region(pieces) sees the stitched pieces of a region in file order and returns false to stop
 // the file early (sampler full).  Returns 0, or -1 (I/O) / -3 (the reference would have raised).
 static double g_wt[6];   // (MC_READER_TIMING) main-thread seconds: extend, guesses, parse (pool), stitch, on_region, rest
-int walk_file(const std::string &path, const Params &P, Pool &pool, const std::function<bool(std::vector<Piece *> &)> &on_region)
+typedef std::vector<std::pair<const uint8_t *, size_t>> KeptMaps;
+int walk_file(const std::string &path, const Params &P0, Pool &pool, const std::function<bool(std::vector<Piece *> &)> &on_region, KeptMaps *keep = nullptr)
 {
     const bool wt_on = getenv("MC_READER_TIMING") != nullptr;
     auto wnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    struct WtPrint { bool on; ~WtPrint() { if (on) fprintf(stderr, "reader main thread: extend %.3f s, guesses %.3f, parse %.3f, stitch %.3f, sampler + copies %.3f\n", g_wt[0], g_wt[1], g_wt[2], g_wt[3], g_wt[4]); for (double &x : g_wt) x = 0; } } wtp{wt_on};
+    struct WtPrint { bool on; ~WtPrint() { if (on) fprintf(stderr, "reader main thread: extend %.3f s, guesses %.3f, parse %.3f, stitch %.3f, sampler + copies %.3f (of it the walkers of the duplicate classes %.3f)\n", g_wt[0], g_wt[1], g_wt[2], g_wt[3], g_wt[4], g_wt[5]); for (double &x : g_wt) x = 0; } } wtp{wt_on};
     Stream st;
     if (!st.open(path.c_str())) return st.bad_gzip ? -3 : -1;
+    // keep: a plain file's mapping is handed to the caller instead of being unmapped - the sampler's set of accepted sequences (-d) points
+    // into it rather than holding copies
+    struct Keeper { Stream &st; KeptMaps *keep; ~Keeper() { if (keep && st.map) { keep->emplace_back(st.map, st.map_n); st.map = nullptr; } } } keeper{st, keep};
+    Params P = P0;
+    P.stable = keep != nullptr && !st.compressed && st.map != nullptr;
     const int T = pool.size();
     size_t region_bytes = (size_t)std::max(1, std::min(T, 16)) * ((size_t)4 << 20), piece_bytes = (size_t)256 << 10;
     const size_t full_region = region_bytes;
@@ -824,10 +955,12 @@ int walk_file(const std::string &path, const Params &P, Pool &pool, const std::f
             const size_t g = guess_start(base, e / np * k, e);
             if (g < e && g > starts.back()) starts.push_back(g);
         }
-        pieces.clear(); pieces.resize(starts.size());
-        for (size_t k = 0; k < starts.size(); k++) { pieces[k].start = starts[k]; pieces[k].stop = k + 1 < starts.size() ? starts[k + 1] : e; }
+        const size_t npc = starts.size();
+        if (pieces.size() < npc) pieces.resize(npc);
+        for (size_t k = 0; k < npc; k++) pieces[k].reset();
+        for (size_t k = 0; k < npc; k++) { pieces[k].start = starts[k]; pieces[k].stop = k + 1 < npc ? starts[k + 1] : e; }
         if (wt_on) { const double w1 = wnow(); g_wt[1] += w1 - w0; w0 = w1; }
-        pool.run((int)pieces.size(), [&](int k) { parse_piece(base, e, eof, pieces[k], P); });
+        pool.run((int)npc, [&](int k) { parse_piece(base, e, eof, pieces[k], P); });
         if (wt_on) { const double w1 = wnow(); g_wt[2] += w1 - w0; w0 = w1; }
         // stitch in file order: a piece counts only if the parse so far ended exactly at its (guessed) start; where no piece starts,
         // the parser is continued sequentially up to the next guess
@@ -836,13 +969,13 @@ int walk_file(const std::string &path, const Params &P, Pool &pool, const std::f
         size_t at = 0, k = 0;
         bool done = false;
         while (at < e && !done) {
-            while (k < pieces.size() && pieces[k].start < at) k++;      // guesses inside a record that ran over them
+            while (k < npc && pieces[k].start < at) k++;      // guesses inside a record that ran over them
             Piece *pc;
-            if (k < pieces.size() && pieces[k].start == at) pc = &pieces[k++];
+            if (k < npc && pieces[k].start == at) pc = &pieces[k++];
             else {
                 extra.emplace_back(new Piece());
                 pc = extra.back().get();
-                pc->start = at; pc->stop = k < pieces.size() ? pieces[k].start : e;
+                pc->start = at; pc->stop = k < npc ? pieces[k].start : e;
                 parse_piece(base, e, eof, *pc, P);
             }
             done = pc->done;
@@ -980,38 +1113,87 @@ extern "C" int64_t mc_reader_run(mc_reader *r)
     }
     Pool pool(nparse);
     Params P; P.L = (size_t)r->L; P.fastq = r->fastq; P.qoff = r->qoff; P.dups = r->filter_dups;
-    P.decide = !r->filter_dups && !out && !getenv("MC_READER_SERIAL_SAMPLER");   // (the environment variable: tests compare the two forms)
+    const bool serial = getenv("MC_READER_SERIAL_SAMPLER") != nullptr;   // (tests compare the two forms)
+    P.decide = !serial && !r->filter_dups;
+    P.shards = !serial && r->filter_dups;
     P.max_unknown = r->max_unknown; P.mean_q = r->mean_q; P.min_q = r->min_q;
-    SeqSet seen;
+    SeqSet seen;                                                    // the serial form's set
+    std::unique_ptr<SeqSet[]> seen_sh(P.shards ? new SeqSet[NSHARD] : nullptr);
+    struct Maps { KeptMaps v; ~Maps() { for (auto &m : v) munmap((void *)m.first, m.second); } } maps;   // the plain files the sets point into             // the sets of the duplicate classes' walkers
     const size_t L = (size_t)r->L;
     int64_t kept = 0, rcode = 0;
     char idbuf[32];
+    // what the reference raises at a record (R_ERR), in the order its sampler meets the causes: reverse_complement() of the duplicate
+    // test, then the quality filter's rec.phred() of a record without qualities, then mean() of an empty list
+    auto err_text = [&](const Rec &rec) -> const char * {
+        if (r->filter_dups && (rec.flags & R_RCBAD)) return "KeyError: base outside ACGTN in reverse_complement";
+        if (!(rec.flags & R_QUAL)) return "TypeError: record without qualities in a FASTQ run";
+        return "ValueError: empty quality string";
+    };
     for (const std::string &path : r->paths) {
         t_range_lo = r->range_lo; t_range_hi = r->range_hi;        // (consumed by Stream::open on this thread)
         const int rc = walk_file(path, P, pool, [&](std::vector<Piece *> &order) -> bool {
             const int64_t kept0 = kept;
             bool full = false;
-            bool anomaly = !P.decide;
-            for (Piece *pc : order) anomaly = anomaly || pc->anomaly;
-            if (!anomaly) {
-                // The verdicts are in (the parser's threads gave them): what is left in file order is the place of every piece's accepted
-                // reads - a running sum over the pieces - and the piece in which the sample gets full, walked record by record.
+            if (P.shards) {
+                // -d (reference :345, :354): a record is a duplicate when its sequence or the reverse complement of it was ACCEPTED before -
+                // the test comes before the quality filter, only accepted reads enter the set.  So a record's fate depends on nothing but
+                // the earlier records of its own class {s, rc(s)}: in file order inside the class, everything in front of the first record
+                // that passes the quality filter fails it, that one is accepted, everything behind it is a duplicate.  The classes are dealt
+                // to NSHARD sets by their key - min(hash(s), hash(rc(s))), both computed by the parser's threads - and every set walks ITS
+                // records of the region in file order with the very loop of the serial form; the sets live as long as the sampler.  The
+                // head-take (:356) only decides how far the verdicts count: below.
+                std::atomic<bool> oom{false};
+                const double tq0 = Stream::now();
+                pool.run(NSHARD, [&](int sh) {
+                    SeqSet &set = seen_sh[sh];
+                    std::vector<ShItem *> mine;
+                    for (Piece *pc : order) for (uint32_t j = pc->sh_off[sh]; j < pc->sh_off[sh + 1]; j++) mine.push_back(&pc->sh_items[j]);
+                    const size_t n = mine.size(), AHEAD = 8;
+                    for (size_t i = 0; i < n; i++) {
+                        if (i + AHEAD < n) { set.prefetch(mine[i + AHEAD]->h1); set.prefetch(mine[i + AHEAD]->h2); }
+                        ShItem &it = *mine[i];
+                        if (set.contains(it.h1, it.seq, it.len, false) || set.contains(it.h2, it.seq, it.len, true)) { it.q = R_DUP; continue; }
+                        if ((it.q & R_PASS) && !set.insert(it.h1, it.seq, it.len, (it.q & R_STABLE) != 0)) { oom.store(true); return; }
+                        it.q &= (uint8_t)~R_STABLE;
+                    }
+                });
+                if (oom.load()) { r_err = "out of memory for the set of accepted sequences"; rcode = -1; return false; }
+                const double tq1 = Stream::now();
+                g_wt[5] += tq1 - tq0;
+                pool.run((int)order.size(), [&](int k) {
+                    Piece *pc = order[k];
+                    for (const ShItem &it : pc->sh_items) pc->recs[it.idx].flags |= it.q;
+                    for (const Rec &rec : pc->recs) {
+                        if (rec.flags & R_SHORT) pc->n_short++;
+                        else if (rec.flags & R_ERR) pc->anomaly = true;
+                        else if (rec.flags & R_DUP) pc->n_dup++;
+                        else if (rec.flags & R_PASS) pc->n_pass++;
+                        else pc->n_lowq++;
+                    }
+                });
+            }
+            if (P.decide || P.shards) {
+                // The verdicts are in: what is left in file order is the place of every piece's accepted reads - a running sum over the
+                // pieces - and the piece in which the sample gets full (or which holds a record the reference raises at), walked record by record.
                 std::vector<int64_t> base(order.size(), 0), take(order.size(), 0);
                 size_t np = 0;
                 for (; np < order.size() && !full; np++) {
                     Piece *pc = order[np];
                     if (pc->ragged) r->st.ragged_end = 1;
                     base[np] = kept - kept0;
-                    if (r->nreads > 0 && kept + pc->n_pass >= r->nreads) {            // the sample gets full inside this piece (or with its last accepted read)
+                    if (pc->anomaly || (r->nreads > 0 && kept + pc->n_pass >= r->nreads)) {   // the sample gets full inside this piece (or with its last accepted read)
                         for (Rec &rec : pc->recs) {
                             r->st.records++; r->st.bases += (int64_t)rec.len;
                             if (rec.flags & R_SHORT) { r->st.too_short++; continue; }
+                            if (rec.flags & R_DUP) { r->st.dups++; continue; }
+                            if (rec.flags & R_ERR) { r_err = err_text(rec); rcode = -3; return false; }
                             if (!(rec.flags & R_PASS)) { r->st.low_qual++; continue; }
                             take[np]++; kept++;
                             if (kept == r->nreads) { full = true; break; }
                         }
                     } else {
-                        r->st.records += (int64_t)pc->recs.size(); r->st.bases += pc->bases; r->st.too_short += pc->n_short; r->st.low_qual += pc->n_lowq;
+                        r->st.records += (int64_t)pc->recs.size(); r->st.bases += pc->bases; r->st.too_short += pc->n_short; r->st.low_qual += pc->n_lowq; r->st.dups += pc->n_dup;
                         take[np] = pc->n_pass; kept += pc->n_pass;
                     }
                 }
@@ -1022,11 +1204,17 @@ extern "C" int64_t mc_reader_run(mc_reader *r)
                         int64_t j = base[k]; const int64_t stop = j + take[k];
                         for (const Rec &rec : order[k]->recs) { if (j == stop) break; if (rec.flags & R_PASS) { memcpy(dst + (size_t)j * L, rec.seq, L); j++; } }
                     });
+                    if (out) {                                         // the FASTA copy of the sample (reference :352), in order
+                        for (int64_t i = kept0; i < kept; i++) {
+                            const int k = snprintf(idbuf, sizeof idbuf, ">%lld\n", (long long)i);
+                            fwrite(idbuf, 1, (size_t)k, out); fwrite(r->reads + (size_t)i * L, 1, L, out); fputc('\n', out);
+                        }
+                    }
                     r->publish(kept);
                 }
                 return !full;
             }
-            // the sampler's decisions, record by record in file order (-d, a FASTA copy of the sample, or a record to raise an error at)
+            // the serial form (MC_READER_SERIAL_SAMPLER): the sampler's decisions, record by record in file order
             for (Piece *pc : order) {
                 if (pc->ragged) r->st.ragged_end = 1;
                 for (Rec &rec : pc->recs) {
@@ -1052,7 +1240,7 @@ extern "C" int64_t mc_reader_run(mc_reader *r)
                         fwrite(idbuf, 1, (size_t)k, out); fwrite(rec.seq, 1, L, out); fputc('\n', out);
                     }
                     kept++;
-                    if (r->filter_dups) seen.insert(rec.h1, rec.seq, rec.len);
+                    if (r->filter_dups && !seen.insert(rec.h1, rec.seq, rec.len, false)) { r_err = "out of memory for the set of accepted sequences"; rcode = -1; return false; }
                     if (kept == r->nreads) { full = true; break; }
                 }
                 if (full) break;
@@ -1065,7 +1253,7 @@ extern "C" int64_t mc_reader_run(mc_reader *r)
                 r->publish(kept);
             }
             return !full;
-        });
+        }, P.shards ? &maps.v : nullptr);
         t_range_lo = t_range_hi = -1;
         if (rc < 0 && rcode == 0) rcode = rc;
         if (rcode < 0 || kept == r->nreads) break;

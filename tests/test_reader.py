@@ -498,3 +498,118 @@ def test_parallel_verdicts_equal_the_record_by_record_sampler(seed, tmp_path, mo
                 assert a.shape == b.shape and (a == b).all()
                 assert sa["sampled"] == min(nreads, sa["sampled"]) and (nreads >= 100000 or sa["sampled"] <= nreads)
     assert sa["too_short"] > 0 and sa["low_qual"] > 0
+
+
+def _rc(s):
+    return s[::-1].translate(str.maketrans("ACGTN", "TGCAN"))
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_class_sharded_dup_verdicts_equal_the_record_by_record_sampler(seed, tmp_path, monkeypatch):
+    """-d (reference :345 duplicate test before QC, :354 only accepted reads enter the set): the verdicts are given per duplicate
+    class {s, rc(s)} by NSHARD walkers (round 6); MC_READER_SERIAL_SAMPLER keeps the record-by-record walk the goldens were pinned
+    on, and a literal Python loop of process_seqfile is the third voice.  The file is made to hit the rule's corners: exact and
+    reverse-complement repeats whose FIRST occurrence failed the quality filter (so a later one is accepted, and the ones behind
+    it are duplicates), repeats of different untrimmed length (not duplicates), palindromes, repeats across two files, the
+    head-take ending inside a class, and records the reference raises at (a base outside ACGTN) in front of and behind the take."""
+    import random
+    from microbecensus_amd import _native
+    rng = random.Random(seed)
+    L = 50
+    pool_seqs = []
+    recs = []
+    for i in range(9000):
+        u = rng.random()
+        if pool_seqs and u < 0.35:
+            seq = rng.choice(pool_seqs)
+            if rng.random() < 0.5:
+                seq = _rc(seq)
+            if rng.random() < 0.1:
+                seq = seq + "A"                                  # another untrimmed sequence: not a duplicate
+        elif u < 0.38:
+            h = "".join(rng.choice("ACGT") for _ in range(L // 2 + 3))
+            seq = h + _rc(h)                                     # its own reverse complement
+        else:
+            n = rng.choice([L - 5, L, L, L + 3, L + 30, L + rng.randrange(0, 130)])   # (every remainder of the hashes' 32- / 16- / 8-byte steps)
+            seq = "".join(rng.choice("ACGT") for _ in range(n))
+            if rng.random() < 0.1:
+                at = rng.randrange(0, n - 8)
+                seq = seq[:at] + "N" * 8 + seq[at + 8:]
+        pool_seqs.append(seq)
+        lo = rng.choice([2, 2, 25, 30])                          # half of the records fail -q 20 / -m 25
+        qual = "".join(chr(33 + rng.randrange(lo, 41)) for _ in range(len(seq)))
+        recs.append((seq, qual))
+
+    def write(path, rr):
+        with open(path, "w") as f:
+            for i, (s, q) in enumerate(rr):
+                f.write("@r%d\n%s\n+\n%s\n" % (i, s, q))
+
+    def py_sampler(files, nreads, qargs, bad_at=None):
+        # process_seqfile :336-356 stated literally over the record lists
+        seqs, kept, st = set(), [], dict(too_short=0, low_qual=0, dups=0)
+        for rr in files:
+            for (s, q) in rr:
+                if len(s) < L:
+                    st["too_short"] += 1
+                    continue
+                if s in seqs:
+                    st["dups"] += 1
+                    continue
+                if set(s) - set("ACGTN"):
+                    return None, None
+                if _rc(s) in seqs:
+                    st["dups"] += 1
+                    continue
+                t, ph = s[:L], [ord(c) - 33 for c in q[:L]]
+                if 100 * t.count("N") / float(L) > qargs[2] or sum(ph) / float(len(ph)) < qargs[1] or min(ph) < qargs[0]:
+                    st["low_qual"] += 1
+                    continue
+                kept.append(t)
+                seqs.add(s)
+                if len(kept) == nreads:
+                    st["sampled"] = len(kept)
+                    return kept, st
+        st["sampled"] = len(kept)
+        return kept, st
+
+    fa, fb = str(tmp_path / "a.fq"), str(tmp_path / "b.fq")
+    write(fa, recs[:6000])
+    write(fb, recs[6000:])
+    for piece, region in ((1 << 11, 1 << 15), (1 << 18, 1 << 22)):
+        monkeypatch.setenv("MC_READER_PIECE_BYTES", str(piece))
+        monkeypatch.setenv("MC_READER_REGION_BYTES", str(region))
+        for nreads in (1, 50, 777, 2000, 100000):
+            for qargs in ((-5, -5, 100), (20, 25, 10)):
+                want, wst = py_sampler([recs[:6000], recs[6000:]], nreads, qargs)
+                res = []
+                for ser in (False, True):
+                    if ser:
+                        monkeypatch.setenv("MC_READER_SERIAL_SAMPLER", "1")
+                    else:
+                        monkeypatch.delenv("MC_READER_SERIAL_SAMPLER", raising=False)
+                    res.append(_native.sample_reads([fa, fb], L, nreads, True, 33, qargs[0], qargs[1], qargs[2], True))
+                (a, sa), (b, sb) = res
+                assert sa == sb, (piece, nreads, qargs, sa, sb)
+                assert a.shape == b.shape and (a == b).all()
+                assert [bytes(x).decode() for x in a] == want
+                assert {k: sa[k] for k in wst} == wst
+        monkeypatch.delenv("MC_READER_SERIAL_SAMPLER", raising=False)
+    assert wst["dups"] > 500 and wst["low_qual"] > 500 and wst["too_short"] > 0
+    # a record the reference raises at: behind the take nothing happens, in front of it both forms raise
+    bad = list(recs[:6000])
+    bad[3000] = ("ACGTX" * 12, "I" * 60)
+    write(fa, bad)
+    want, wst = py_sampler([bad], 300, (20, 25, 10))
+    assert want is not None and len(want) == 300
+    for ser in (False, True):
+        if ser:
+            monkeypatch.setenv("MC_READER_SERIAL_SAMPLER", "1")
+        else:
+            monkeypatch.delenv("MC_READER_SERIAL_SAMPLER", raising=False)
+        a, sa = _native.sample_reads([fa], L, 300, True, 33, 20, 25, 10, True)
+        assert [bytes(x).decode() for x in a] == want and {k: sa[k] for k in wst} == wst
+        assert py_sampler([bad], 100000, (20, 25, 10))[0] is None
+        with pytest.raises(_native.ReferenceError_) as e:
+            _native.sample_reads([fa], L, 100000, True, 33, 20, 25, 10, True)
+        assert "KeyError" in str(e.value)
