@@ -414,6 +414,83 @@ def e2e_rate(device, gen, n, L, gz):
     return out
 
 
+def write_fastq_c5(gen, n, L, path):
+    """BASELINE configs[4]'s input at size - the recipe of tests/golden/c5_at_size.py, array by array instead of record by record:
+    n reads of L bp of the 30 genomes (the two IUPAC letters the genomes hold become N: reverse_complement knows ACGTN only), phred+33
+    qualities ~ N(34, 6) clipped to [20, 41], 5 % of the records with one base of quality 10, 2 % exact and 1 % reverse-complement
+    copies of one of the first 5,000 records of their block of 150,000.  Returns (file bytes, records that are copies)."""
+    import numpy as np
+    BLOCK, POOL = 150_000, 5_000
+    comp = np.arange(256, dtype=np.uint8)
+    for a, b in zip(b"ACGTN", b"TGCAN"):
+        comp[a] = b
+    w = len(str(n - 1))
+    copies = 0
+    with open(path, "wb") as f:
+        for b0 in range(0, n, BLOCK):
+            m = min(BLOCK, n - b0)
+            rng = np.random.default_rng(3000 + b0 // BLOCK)
+            r = gen.single(m, L, first=(1 << 41) + b0).cpu().numpy().copy()
+            r[(r == ord("Y")) | (r == ord("S"))] = ord("N")
+            u = rng.random(m)
+            idx = np.arange(m)
+            src = (rng.random(m) * np.minimum(idx, POOL)).astype(np.int64)          # an EARLIER record of the block's first 5,000
+            exact = (u < 0.02) & (idx > 0)
+            rc = (u >= 0.02) & (u < 0.03) & (idx > 0)
+            for i in np.nonzero(exact | rc)[0]:                                      # in order: a copy of a copy is a copy of the original (4,500 per block)
+                r[i] = comp[r[src[i]][::-1]] if rc[i] else r[src[i]]
+            copies += int(exact.sum() + rc.sum())
+            q = np.clip(np.rint(rng.standard_normal((m, L), dtype=np.float32) * 6 + 34), 20, 41).astype(np.uint8) + 33
+            low = np.nonzero(rng.random(m) < 0.05)[0]
+            q[low, rng.integers(0, L, size=low.size)] = 33 + 10
+            rec = np.empty((m, 1 + w + 1 + L + 3 + L + 1), dtype=np.uint8)
+            rec[:, 0] = ord("@")
+            ids = b0 + idx
+            for k in range(w):
+                rec[:, w - k] = ord("0") + (ids // 10 ** k) % 10
+            rec[:, 1 + w] = 10
+            rec[:, 2 + w:2 + w + L] = r
+            rec[:, 2 + w + L:5 + w + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+            rec[:, 5 + w + L:5 + w + 2 * L] = q
+            rec[:, -1] = 10
+            f.write(rec.tobytes())
+    return os.path.getsize(path), copies
+
+
+def e2e_c5(device, gen, n, L=300):
+    """BASELINE configs[4] end to end: run_pipeline(file -> AGS) on a plain FASTQ of n records of 300 bp with min_quality 20 and
+    filter_dups (the reference's -q 20 -d; process_seqfile microbe_census.py:328-367 - duplicates are tested before the quality filter,
+    only accepted reads enter the set).  Wall time of the second of two calls, the sampler's own phase timers beside it."""
+    import contextlib
+    import io
+    from microbecensus_amd import microbe_census as mc
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "c5.fq")
+        size, copies = write_fastq_c5(gen, n, L, path)
+        walls, res = [], None
+        for rep in range(2):
+            args = {"seqfiles": [path], "device": device, "nreads": n, "read_length": L, "min_quality": 20, "filter_dups": True}
+            t = time.time()
+            with contextlib.redirect_stdout(io.StringIO()):
+                res = mc.run_pipeline(args)
+            walls.append(time.time() - t)
+            if res is None:
+                return None
+        # the same file without -d and without -q: what the duplicate filter costs the call
+        args = {"seqfiles": [path], "device": device, "nreads": n, "read_length": L}
+        t = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            plain = mc.run_pipeline(args)
+        plain_wall = time.time() - t
+    dt = walls[-1]
+    return {"what": "BASELINE configs[4]: run_pipeline(file -> AGS) on a plain FASTQ of %d records of %d bp (recipe of tests/golden/c5_at_size.py: 5 %% with a base of quality 10, "
+                    "2 %% exact + 1 %% reverse-complement copies) with min_quality=20, filter_dups=True; wall time of the second of two calls" % (n, L),
+            "records": n, "read_len": L, "file_bytes": size, "copies_written": copies, "wall_s": round(dt, 3), "reads_per_s": round(n / dt, 1), "first_call_wall_s": round(walls[0], 3),
+            "sampled_reads": int(res[1]["sampled_reads"]), "est_ags": res[0], "sampler_seconds": res[1].get("_sampler_seconds"),
+            "same_file_without_q_and_d": None if plain is None else {"wall_s": round(plain_wall, 3), "reads_per_s": round(n / plain_wall, 1), "sampled_reads": int(plain[1]["sampled_reads"]),
+                                                                      "sampler_seconds": plain[1].get("_sampler_seconds")}}
+
+
 def e2e_distributed(gen, n, L, rank, world, local, rdev):
     """File -> AGS over all ranks (microbecensus_amd.distributed.run_pipeline_distributed) on a plain FASTQ: every rank samples and
     searches its own slices of the file; one all_reduce of the per-family sums.  Wall time from before the call to after it on every
@@ -463,6 +540,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ags-check", action="store_true", help="skip the run_pipeline AGS comparison on the reference's own inputs")
     ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the end-to-end (file -> AGS) measurement (plain FASTQ; a fifth of it, at least 4 M, for .gz); 0 = skip")
+    ap.add_argument("--c5-reads", type=int, default=2_000_000, help="records of the BASELINE configs[4] leg (e2e.c5: 300 bp FASTQ, -q 20 -d, file -> AGS); 0 = skip")
     ap.add_argument("--no-best-only-leg", action="store_true", help="skip the extra timed leg with mc_set_best_hits_only (what run_pipeline runs)")
     ap.add_argument("--no-reference-pattern", action="store_true", help="skip the untimed launch of the counting form of the seed kernel (roofline.reference_pattern); the profiling tools do")
     ap.add_argument("--one-at-a-time", action="store_true", help="mc_run_range per step (the device idles while the host sums the best hits up) instead of mc_range_end / mc_range_begin / results")
@@ -789,6 +867,8 @@ def main():
             out["e2e"] = {"what": "run_pipeline(file -> AGS): native reader beside the HIP search (mc_search_files), classification, estimate; wall time of the second "
                                   "of two calls on the same file (first_call_wall_s includes the one-time pool allocation); .gz is inflated by several workers (csrc/mc_pgzip.h) as far as the CPUs the process may use allow (cgroup quota)",
                           "plain": e2e_rate(local, gen, args.e2e_reads, L, gz=False), "gz": e2e_rate(local, gen, max(1, min(args.e2e_reads, max(args.e2e_reads // 5, 4_000_000))), L, gz=True)}
+        if world == 1 and args.c5_reads > 0 and gen is not None:
+            out.setdefault("e2e", {})["c5"] = e2e_c5(local, gen, args.c5_reads)
         if e2e_multi is not None:
             out["e2e"] = e2e_multi
         if rccl is not None:

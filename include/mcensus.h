@@ -101,9 +101,6 @@ int mc_run(mc_handle *h, int64_t first_read_id);
 /* runs the pipeline on reads [first, first+count) of the resident set (count <= 2097151). */
 int mc_run_range(mc_handle *h, int64_t first, int64_t count, int64_t first_read_id);
 
-/* Kept for callers of earlier rounds: accepted and ignored (a range is one part). */
-int mc_set_parts(mc_handle *h, int parts);
-
 /* A stream of ranges without the device waiting for the host.  mc_range_begin() enqueues the FRONT of a range (translation,
  * seeds, seed evaluation: two thirds of its time) and returns at once; mc_range_end() completes it - results as after
  * mc_run_range(), valid until the next mc_range_end() / mc_run_range().  The order end(i), begin(i + 1), <look at the results
@@ -188,6 +185,10 @@ int64_t mc_reader_run(mc_reader *r);
 /* sampled x read_len bytes, row i = trimmed read i: exactly what mc_search() / mc_upload() take. Owned by the reader. */
 const uint8_t *mc_reader_reads(mc_reader *r);
 int mc_reader_get_stats(mc_reader *r, mc_reader_stats *out);
+/* Seconds of the last mc_reader_run() by phase, up to n values (returns how many were written): [0] the whole run; on the sampler's own
+ * thread: [1] waiting for input (inflate), [2] guessing the pieces' starts, [3] the parse (all workers), [4] stitching the pieces,
+ * [5] verdicts, places and copies of the accepted reads, [6] of [5]: the walkers of the duplicate classes (-d; process_seqfile :345, :354). */
+int32_t mc_reader_times(const mc_reader *r, double *out, int32_t n);
 void mc_reader_close(mc_reader *r);
 /* A closed reader leaves its read buffer (touched pages) to the next reader of the process: the second run_pipeline() of a process pays
  * neither munmap nor page faults.  At most keep_bytes of it are kept (default 4 GB); mc_reader_trim() sets the limit and releases

@@ -98,7 +98,6 @@ def load_library():
     lib.mc_set_counting.argtypes = [C.c_void_p, C.c_int]
     lib.mc_debug_stage.restype = C.c_int64
     lib.mc_debug_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]
-    lib.mc_set_parts.argtypes = [C.c_void_p, C.c_int]
     lib.mc_range_begin.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
     lib.mc_range_end.argtypes = [C.c_void_p]
     lib.mc_ranges_in_flight.argtypes = [C.c_void_p]
@@ -121,6 +120,8 @@ def load_library():
     lib.mc_reader_reads.restype = C.POINTER(C.c_uint8)
     lib.mc_reader_reads.argtypes = [C.c_void_p]
     lib.mc_reader_get_stats.argtypes = [C.c_void_p, C.POINTER(McReaderStats)]
+    lib.mc_reader_times.restype = C.c_int32
+    lib.mc_reader_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int32]
     lib.mc_reader_close.argtypes = [C.c_void_p]
     lib.mc_reader_trim.restype = None
     lib.mc_reader_trim.argtypes = [C.c_int64]
@@ -148,8 +149,8 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_set_index_cache", "mc_index_cache_check", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
-                    "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_debug_stage", "mc_set_parts", "mc_range_begin", "mc_range_end", "mc_ranges_in_flight", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8", "mc_write_m8_named",
-                    "mc_reader_last_error", "mc_set_host_threads", "mc_reader_open", "mc_reader_open_range", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_close", "mc_reader_trim", "mc_count_bases", "mc_quality_offset",
+                    "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_debug_stage", "mc_range_begin", "mc_range_end", "mc_ranges_in_flight", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8", "mc_write_m8_named",
+                    "mc_reader_last_error", "mc_set_host_threads", "mc_reader_open", "mc_reader_open_range", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_times", "mc_reader_close", "mc_reader_trim", "mc_count_bases", "mc_quality_offset",
                     "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_reader_nreads", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows", "mc_set_best_hits_only", "mc_grid_classify"]
 
 
@@ -210,6 +211,13 @@ class Reader:
         st = McReaderStats()
         self.lib.mc_reader_get_stats(self.r, C.byref(st))
         return {k: getattr(st, k) for k, _ in McReaderStats._fields_}
+
+    def times(self):
+        """Seconds of the last run by phase (mc_reader_times)."""
+        v = (C.c_double * 7)()
+        k = self.lib.mc_reader_times(self.r, v, 7)
+        names = ("run", "input_wait", "guesses", "parse", "stitch", "verdicts_places_copies", "dup_class_walkers")
+        return {names[i]: round(v[i], 4) for i in range(max(k, 0))}
 
     def reads(self, n):
         """(n, read_len) uint8 view of the sampled reads; it keeps the reader alive."""
@@ -436,10 +444,6 @@ class Engine:
     def set_counting(self, on):
         """Turns the seed kernel's algorithmic-traffic counters (stats bucket_lookups / key_probes) on or off."""
         self._check(self.lib.mc_set_counting(self.h, 1 if on else 0), "mc_set_counting")
-
-    def set_parts(self, parts):
-        """Accepted and ignored (rounds 2 - 3: a range as two overlapping halves)."""
-        self._check(self.lib.mc_set_parts(self.h, parts), "mc_set_parts")
 
     def range_begin(self, first, count, first_read_id=0):
         """Enqueues the front of the range (translation, seeds, seed evaluation) and returns at once.  range_end(), range_begin(next),

@@ -954,12 +954,6 @@ extern "C" int mc_set_counting(mc_handle *h, int on)
     return 0;
 }
 
-extern "C" int mc_set_parts(mc_handle *h, int parts)
-{   // (rounds 2 - 3 could cut a range into two parts issued alternately)
-    if (!h || parts < 1) { g_err = "bad argument"; return -1; }
-    return 0;
-}
-
 extern "C" int mc_run(mc_handle *h, int64_t first_read_id) { return h ? mc_run_range(h, 0, h->nreads, first_read_id) : -1; }
 
 // The streaming form of the pipeline: batches of reads are fetched from a host-side source into pinned staging memory and

@@ -909,13 +909,16 @@ int inflate_threads()
 
 // One file, region by region.  on_region(pieces) sees the stitched pieces of a region in file order and returns false to stop
 // the file early (sampler full).  Returns 0, or -1 (I/O) / -3 (the reference would have raised).
-static double g_wt[6];   // (MC_READER_TIMING) main-thread seconds: extend, guesses, parse (pool), stitch, on_region, rest
+// seconds of the sampler's own thread by phase (mc_reader_times): waiting for / inflating input, guessing the pieces' starts, the
+// parse (all workers), stitching, what on_region does (verdicts, places, copies), of it the walkers of the duplicate classes (-d)
+struct WalkTimes { double v[6] = {0, 0, 0, 0, 0, 0}; };
 typedef std::vector<std::pair<const uint8_t *, size_t>> KeptMaps;
-int walk_file(const std::string &path, const Params &P0, Pool &pool, const std::function<bool(std::vector<Piece *> &)> &on_region, KeptMaps *keep = nullptr)
+int walk_file(const std::string &path, const Params &P0, Pool &pool, const std::function<bool(std::vector<Piece *> &)> &on_region, KeptMaps *keep = nullptr, WalkTimes *wt = nullptr)
 {
-    const bool wt_on = getenv("MC_READER_TIMING") != nullptr;
+    const bool wt_on = wt != nullptr;
+    WalkTimes wt_none;
+    double *g_wt = wt ? wt->v : wt_none.v;
     auto wnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    struct WtPrint { bool on; ~WtPrint() { if (on) fprintf(stderr, "reader main thread: extend %.3f s, guesses %.3f, parse %.3f, stitch %.3f, sampler + copies %.3f (of it the walkers of the duplicate classes %.3f)\n", g_wt[0], g_wt[1], g_wt[2], g_wt[3], g_wt[4], g_wt[5]); for (double &x : g_wt) x = 0; } } wtp{wt_on};
     Stream st;
     if (!st.open(path.c_str())) return st.bad_gzip ? -3 : -1;
     // keep: a plain file's mapping is handed to the caller instead of being unmapped - the sampler's set of accepted sequences (-d) points
@@ -1017,6 +1020,7 @@ struct mc_reader {
     std::string fasta_out;
     uint8_t *reads = nullptr; size_t reads_cap = 0, reads_n = 0;   // anonymous mapping grown with mremap (no copies, no zero fill up front)
     mc_reader_stats st{};
+    WalkTimes wt; double wall = 0;                                 // mc_reader_times
     // streaming (mc_reader_start / fetch / join): the sampler runs on a thread of its own and publishes how far it has got
     std::thread run_th;
     std::mutex pmu; std::condition_variable pcv;
@@ -1096,6 +1100,13 @@ extern "C" int64_t mc_reader_run(mc_reader *r)
 {
     if (!r) { r_err = "null reader"; return -1; }
     r->reads_n = 0; memset(&r->st, 0, sizeof r->st);
+    r->wt = WalkTimes(); r->wall = 0;
+    const double run_t0 = Stream::now();
+    struct Wall { mc_reader *r; double t0; ~Wall() {
+        r->wall = Stream::now() - t0;
+        if (getenv("MC_READER_TIMING")) fprintf(stderr, "reader: %.3f s; its own thread: input %.3f, guesses %.3f, parse %.3f, stitch %.3f, verdicts + places + copies %.3f (of it the walkers of the duplicate classes %.3f)\n",
+                                                r->wall, r->wt.v[0], r->wt.v[1], r->wt.v[2], r->wt.v[3], r->wt.v[4], r->wt.v[5]);
+    } } wall_guard{r, run_t0};
     FILE *out = nullptr;
     if (!r->fasta_out.empty()) {
         out = fopen(r->fasta_out.c_str(), "w");
@@ -1160,7 +1171,7 @@ extern "C" int64_t mc_reader_run(mc_reader *r)
                 });
                 if (oom.load()) { r_err = "out of memory for the set of accepted sequences"; rcode = -1; return false; }
                 const double tq1 = Stream::now();
-                g_wt[5] += tq1 - tq0;
+                r->wt.v[5] += tq1 - tq0;
                 pool.run((int)order.size(), [&](int k) {
                     Piece *pc = order[k];
                     for (const ShItem &it : pc->sh_items) pc->recs[it.idx].flags |= it.q;
@@ -1253,7 +1264,7 @@ extern "C" int64_t mc_reader_run(mc_reader *r)
                 r->publish(kept);
             }
             return !full;
-        }, P.shards ? &maps.v : nullptr);
+        }, P.shards ? &maps.v : nullptr, &r->wt);
         t_range_lo = t_range_hi = -1;
         if (rc < 0 && rcode == 0) rcode = rc;
         if (rcode < 0 || kept == r->nreads) break;
@@ -1362,6 +1373,16 @@ extern "C" void mc_reader_trim(int64_t keep_bytes)
         if (mc_reader::cache_ptr() && mc_reader::cache_cap() > mc_reader::cache_limit()) { p = mc_reader::cache_ptr(); n = mc_reader::cache_cap(); mc_reader::cache_ptr() = nullptr; mc_reader::cache_cap() = 0; }
     }
     if (p) munmap(p, n);
+}
+// Seconds of the last mc_reader_run by phase: [0] the whole run; on the sampler's own thread: [1] waiting for input (inflate), [2] guessing the
+// pieces' starts, [3] the parse on all workers, [4] stitching, [5] verdicts + places + copies, [6] of it the walkers of the duplicate classes.
+extern "C" int32_t mc_reader_times(const mc_reader *r, double *out, int32_t n)
+{
+    if (!r || !out) return -1;
+    const double v[7] = {r->wall, r->wt.v[0], r->wt.v[1], r->wt.v[2], r->wt.v[3], r->wt.v[4], r->wt.v[5]};
+    int32_t k = 0;
+    for (; k < n && k < 7; k++) out[k] = v[k];
+    return k;
 }
 extern "C" int32_t mc_reader_read_len(const mc_reader *r) { return r ? r->L : 0; }
 extern "C" int64_t mc_reader_nreads(const mc_reader *r) { return r ? r->nreads : 0; }

@@ -444,6 +444,7 @@ def _sample_search_classify(args, paths):
             clean_up(paths)
             sys.exit("\nDatabase search has exited with the following error:\n%s" % error)
         st = rd.stats()
+        args["_sampler_seconds"] = rd.times()      # (where the host side of the call went: bench.py's e2e legs report it)
         hit_reads = sum(e.stats()["reads_with_rows"] for e in engs)
     finally:
         rd.close()

@@ -20,7 +20,6 @@ eng.attach(reads.data_ptr(), 2 * N)
 import time
 only_modes = (True,) if os.environ.get("MC_BOT_ONLY") else (False, True)      # (tools/best_only_trace.sh: the best-hits-only path alone)
 for parts in ((1,) if os.environ.get("MC_BOT_ONLY") else (1, 2)):
-    eng.set_parts(parts)
     for only in only_modes:
         eng.set_best_hits_only(only)
         for rep in range(3):

@@ -17,7 +17,7 @@ for ne, parts in ((1, 2), (2, 1), (3, 1), (2, 2)):
     engs = [_native.Engine(device=0) for _ in range(ne)]
     for i, e in enumerate(engs):
         e.set_run(L, model["pars"][str(L)], fams); e.lib.mc_set_keep_rows(e.h, 0)
-        e.set_parts(parts); e.attach(reads.data_ptr() + i * n * L, n)
+        e.attach(reads.data_ptr() + i * n * L, n)
         e.run_range(0, n, first_read_id=i * n)                     # warm-up: pools
     def work(e, i):
         for _ in range(reps):
