@@ -19,6 +19,7 @@
 // CRC-32 and ISIZE of every member are verified; a truncated or damaged file delivers what lies in front of the damage and then
 // fails (gzip.open's EOFError / BadGzipFile), like the single-stream reader it replaces.
 #pragma once
+#include <new>
 #include <zlib.h>
 #if defined(__SSE2__)
 #include <emmintrin.h>
@@ -106,7 +107,7 @@ inline uint32_t crc32_clmul(uint32_t c, const uint8_t *, size_t) { return c; }
 inline uint32_t crc32_any(uint32_t crc, const uint8_t *p, size_t n)
 {
     if (n >= 256 && crc32_clmul_usable()) {
-        const size_t bulk = n & ~(size_t)15;
+        const size_t bulk = n & ~(size_t)63;                              // (whole 64-byte blocks: every piece below - the last one too - is at least the 64 bytes crc32_clmul loads before it looks at its length)
         for (size_t o = 0; o < bulk;) { const size_t k = bulk - o > ((size_t)1 << 30) ? (size_t)1 << 30 : bulk - o; crc = crc32_clmul(crc, p + o, k); o += k; }
         p += bulk; n -= bulk;
     }
@@ -405,7 +406,12 @@ struct ByteBuf {
     void clear() { n = 0; }
     void resize(size_t m)                                            // (what lay in [0, min(n, m)) stays)
     {
-        if (m > cap) { uint8_t *q = (uint8_t *)malloc(m ? m : 1); if (n) memcpy(q, p, n); free(p); p = q; cap = m; }
+        if (m > cap) {
+            uint8_t *q = (uint8_t *)malloc(m ? m : 1);
+            if (!q) throw std::bad_alloc();                            // (as the std::vector this replaced: the workers mark their chunk, the reader reports it)
+            if (n) memcpy(q, p, n);
+            free(p); p = q; cap = m;
+        }
         n = m;
     }
     void swap(ByteBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
@@ -554,7 +560,7 @@ struct Spec {
         uint8_t *ob = nullptr;
         long floor = -32768;                                         // lowest index a back-reference may reach
         auto grow16 = [&](size_t at, size_t &cp) -> uint16_t * { cp *= 2; out.reserve(cp, at); return out.data(); };
-        auto grow8 = [&](size_t, size_t &cp) -> uint8_t * { cp *= 2; c.bytes.resize(cp); return c.bytes.data(); };   // (size() == capacity in use: nothing is lost)
+        auto grow8 = [&](size_t at, size_t &cp) -> uint8_t * { cp *= 2; c.bytes.resize(at); c.bytes.resize(cp); return c.bytes.data(); };   // (only the bytes in use are copied)
         auto to_plain = [&](size_t keep_from) {                      // bytes [keep_from, pos) are marker-free and may be referenced from now on
             nsym = pos;
             bcap = std::max<size_t>(std::max<size_t>(c.bytes.capacity(), cap), pos + (1u << 20));
@@ -918,7 +924,8 @@ private:
             take_buffers(c, true);
             const uint64_t stop_bit = k + 1 < chunks_.size() ? chunks_[k + 1]->nominal_bit : sp.data_end_bit;
             const uint64_t t0 = now_ns();
-            c.found = sp.find_and_decode(c.nominal_bit, stop_bit, stop_bit, c);
+            try { c.found = sp.find_and_decode(c.nominal_bit, stop_bit, stop_bit, c); }
+            catch (const std::bad_alloc &) { c.found = false; c.bytes.drop(); }   // (no memory for the speculative output: the chunk is decoded in turn, from its known start)
             t_decode_ += now_ns() - t0;
             if (!c.found) recycle_sym(c);
             { std::unique_lock<std::mutex> lk(mu_); c.state = 1; cv_done_.notify_all(); }
@@ -1080,7 +1087,7 @@ private:
                         recycle_sym(*cp);
                         if (!ok) { cp->bad = true; cp->msg = "invalid distance too far back"; cp->bytes.clear(); cp->ends.clear(); }
                         const uint64_t t1 = now_ns();
-                        seg_crcs(*cp);
+                        try { seg_crcs(*cp); } catch (const std::bad_alloc &) { cp->bad = true; cp->msg = "out of memory"; cp->bytes.clear(); cp->ends.clear(); cp->seg_crc.clear(); }
                         t_resolve_ += t1 - t0; t_crc_ += now_ns() - t1;
                         std::unique_lock<std::mutex> lk2(mu_);
                         cp->state = 2;

@@ -1096,9 +1096,15 @@ extern "C" mc_reader *mc_reader_open_range(const char *path, int64_t byte_lo, in
 
 extern "C" void mc_reader_close(mc_reader *r) { delete r; }
 
+static int64_t reader_run(mc_reader *r);
 extern "C" int64_t mc_reader_run(mc_reader *r)
 {
     if (!r) { r_err = "null reader"; return -1; }
+    try { return reader_run(r); }
+    catch (const std::bad_alloc &) { r_err = "out of memory in the read sampler"; return -1; }
+}
+static int64_t reader_run(mc_reader *r)
+{
     r->reads_n = 0; memset(&r->st, 0, sizeof r->st);
     r->wt = WalkTimes(); r->wall = 0;
     const double run_t0 = Stream::now();
@@ -1283,12 +1289,14 @@ extern "C" int mc_reader_get_stats(mc_reader *r, mc_reader_stats *out) { if (!r 
 extern "C" int64_t mc_count_bases(const char *const *paths, int32_t npaths)
 {
     int64_t total = 0;
-    Pool pool(reader_threads());
-    Params P; P.count_only = true;
-    for (int i = 0; i < npaths; i++) {
-        const int rc = walk_file(paths[i], P, pool, [&](std::vector<Piece *> &order) -> bool { for (Piece *pc : order) total += pc->bases; return true; });
-        if (rc < 0) return rc;
-    }
+    try {
+        Pool pool(reader_threads());
+        Params P; P.count_only = true;
+        for (int i = 0; i < npaths; i++) {
+            const int rc = walk_file(paths[i], P, pool, [&](std::vector<Piece *> &order) -> bool { for (Piece *pc : order) total += pc->bases; return true; });
+            if (rc < 0) return rc;
+        }
+    } catch (const std::bad_alloc &) { r_err = "out of memory in the read sampler"; return -1; }
     return total;
 }
 

@@ -152,6 +152,33 @@ class _Dealer:
             if dead:
                 raise RuntimeError("rank %d failed while receiving its batches" % w)
 
+    def _wait_buffer(self, works):
+        """Waits until nothing uses a staging buffer any more - and keeps looking at the peers while it does: a receiver
+        that dies with one of its batches in flight leaves an isend nobody will ever match, and neither backend lets one ask whether
+        a send is done without waiting for it (gloo's is_completed() stays false until wait(); RCCL's wait() is a stream dependency
+        that the synchronize behind it turns into a host wait).  So the wait itself runs on a helper thread and this one checks the
+        peers once a second; if one has failed the helper is left behind (daemon) and the stream ends for everybody."""
+        import threading
+        done, err = threading.Event(), []
+
+        def waiter():
+            try:
+                import torch
+                for w in works:
+                    w.wait()
+                if self.nccl:
+                    torch.cuda.set_device(self.dev)
+                    torch.cuda.current_stream(self.dev).synchronize()
+            except BaseException as e:                              # noqa: BLE001 - raised by the dealer's thread below
+                err.append(e)
+            finally:
+                done.set()
+        threading.Thread(target=waiter, daemon=True).start()
+        while not done.wait(1.0):
+            self._check_peers(self.store, self.world)
+        if err:
+            raise err[0]
+
     def _run(self):
         import ctypes as C
         import threading
@@ -177,10 +204,7 @@ class _Dealer:
                 i = k % NB
                 self._check_peers(store, world)
                 if pending[i] is not None:
-                    for w in pending[i]:
-                        w.wait()
-                    if self.nccl:
-                        torch.cuda.current_stream(self.dev).synchronize()
+                    self._wait_buffer(pending[i])
                     pending[i] = None
                 t0 = time.time()
                 n = lib.mc_reader_fetch(r, at, B, C.c_void_p(bufs[i].data_ptr()))
@@ -228,8 +252,7 @@ class _Dealer:
                 k += 1
             for p in pending:
                 if p is not None:
-                    for w in p:
-                        w.wait()
+                    self._wait_buffer(p)
             total = lib.mc_reader_join(r)
             if total < 0:
                 raise _SamplerError(lib.mc_reader_last_error().decode(), total)
@@ -309,6 +332,19 @@ def stream_batches(reader, read_len, on_batch, device=None):
     nccl = dist.is_initialized() and dist.get_backend() == "nccl"
     dev = torch.device("cuda", device) if nccl else None
     store = _control_store() if world > 1 else None
+    if world > 1:
+        # The pairs rank 0 <-> rank w meet ONCE before any header logic: on an RCCL group that was initialised lazily
+        # (init_process_group without device_id) the first point-to-point call of a pair creates its communicator and blocks until the
+        # peer enters the matching call - the dealer posts a batch BEFORE it writes the header the receiver waits for, so the first
+        # batch of every rank would wait for a recv that waits for a header.  Here both sides enter unconditionally.
+        tiny = torch.zeros(1, dtype=torch.uint8, device=dev if nccl else torch.device("cpu"))
+        if rank == 0:
+            for w in range(1, world):
+                dist.send(tiny, w)
+        else:
+            dist.recv(tiny, 0)
+        if nccl:
+            torch.cuda.current_stream(dev).synchronize()
     q = queue.Queue(maxsize=2)
     errs = []
     slow = os.environ.get("MC_DIST_SLOW", "")                      # "<rank>:<milliseconds>": that rank dawdles after every batch (tests)
