@@ -820,6 +820,10 @@ def main():
                          "bound_evidence": bound_evidence,
                          "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                          "traffic": (None if traffic_dom is None else round(traffic_dom, 0)),
+                         # flat copies of the nested yardsticks below (a reader that keeps only the scalars of this object keeps these: VERDICT r05 item 7)
+                         "reference_pattern_bytes_per_read": (ref_pattern or {}).get("bytes_per_read"), "reference_pattern_frac_of_hbm_peak": (ref_pattern or {}).get("frac_of_hbm_peak"),
+                         "legacy_survey_A_bytes_per_read": SURVEY_A.get(L), "legacy_survey_A_pipeline_GBps": (None if pipe_gbs is None else round(pipe_gbs, 2)),
+                         "scattered_line_ceiling_frac": (slc or {}).get("frac"), "extension_kernel_hbm_frac_best": round(ext_best, 4),
                          "fabric_frac": (d_dom or {}).get("fabric_frac"), "fabric_frac_lower": (d_dom or {}).get("fabric_frac_lower"), "issue_frac": (d_dom or {}).get("issue_frac"),
                          "issue_roofline": (d_dom or {}).get("issue_roofline"), "reference_pattern": ref_pattern,
                          "scattered_line_ceiling": slc,

@@ -14,6 +14,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+ORACLE_PIECES = ("oracle/_ref/rapdb_2.15", "oracle/_ref/rapdb_2.15.info", "oracle/_ref/rapsearch_Linux_2.15", "oracle/rs_port", "oracle/librapsearch_port.so")
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_runtest_setup(item):
+    """Under -m gpu the checker must be there: a GPU test that cannot find the oracle (oracle/_ref, built once where /root/reference
+    exists and carried to the GPU box; oracle/rs_port and librapsearch_port.so, built by __graft_entry__.build()) FAILS - it never
+    skips, and it never passes without having compared anything."""
+    if item.get_closest_marker("gpu") is None:
+        return
+    missing = [p for p in ORACLE_PIECES if not os.path.exists(os.path.join(REPO, p))]
+    if missing:
+        pytest.fail("the oracle is not built - %s missing: run __graft_entry__.build() where /root/reference exists; GPU parity tests do not run without their checker" % ", ".join(missing), pytrace=False)
+
+
 @pytest.fixture(scope="session")
 def repo():
     return REPO

@@ -24,6 +24,9 @@ CASES = {
     "c2_100bp": {"seqfiles": ["c2_100bp.fa.gz"], "threads": 8},
     "c4_paired": {"seqfiles": ["c4_pair_1.fq.gz", "c4_pair_2.fq.gz"], "threads": 8, "nreads": 20000},
     "c5_300bp_q20_dups": {"seqfiles": ["c5_300bp.fq.gz"], "threads": 8, "min_quality": 20, "filter_dups": True},
+    # a phred+64 FASTQ through the quality filter: the offset is DETECTED here (mc_quality_offset; the first record decides nothing),
+    # as the reference detected it for the golden (tests/golden/make_phred64_golden.py; microbe_census.py:175-187, :265-279)
+    "c1_phred64_q_m": {"seqfiles": ["phred64_110bp.fq.gz"], "threads": 8, "read_length": 100, "min_quality": 10, "mean_quality": 25},
 }
 
 
@@ -317,8 +320,7 @@ def test_read_lengths_off_the_reference_grid_against_the_oracle(tmp_path):
     kernel and both staging forms of k_translate_seg are among them)."""
     from microbecensus_amd import _native, synth
     port, db = os.path.join(REPO, "oracle", "rs_port"), os.path.join(REPO, "oracle", "_ref", "rapdb_2.15")
-    if not (os.path.exists(port) and os.path.exists(db)):
-        pytest.skip("oracle not built")
+    assert os.path.exists(port) and os.path.exists(db), "oracle not built (tests/conftest.py fails every GPU test without it)"
     gen = synth.GenomeReads(device="cpu", seed=77)
     eng = _native.Engine(device=0)
     try:

@@ -55,10 +55,11 @@ def test_oracle_reproduces_reference_m8(case, oracle_bin, ref_dir, tmp_path):
     assert got == want
 
 
-@pytest.mark.parametrize("case", ["c2_100bp", "c4_paired", "c5_300bp_q20_dups"])
+@pytest.mark.parametrize("case", ["c2_100bp", "c4_paired", "c5_300bp_q20_dups", "c1_phred64_q_m"])
 def test_oracle_on_the_small_baseline_configs(case, oracle_bin, ref_dir, tmp_path):
     """Small versions of BASELINE configs[1], [3], [4] (goldens from the reference, tests/golden/make_golden.py): the native
-    sampler re-creates the temp FASTA the reference fed to rapsearch (md5), the oracle its m8 (md5)."""
+    sampler re-creates the temp FASTA the reference fed to rapsearch (md5), the oracle its m8 (md5).  c1_phred64_q_m: a phred+64
+    FASTQ through -q 10 -m 25 (tests/golden/make_phred64_golden.py; the golden's own quality_offset, 64, is what the reference detected)."""
     from microbecensus_amd import _native
     meta = json.load(open(os.path.join(GOLD, case + ".json")))
     a = meta["args"]
