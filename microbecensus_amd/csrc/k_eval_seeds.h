@@ -52,18 +52,40 @@ __device__ __forceinline__ bool mc_ev_gate(const McHot &T, const uint8_t *q, int
     // (seeds shorter than 9 residues - the generic seed kernel of a database whose .info threshold is above 0 emits 6 .. 9 - grow
     // residue by residue up to the ninth; the marker database's seeds are 9 or 10 long and never enter)
     while (L < 9 && lim > L && T.grp[q[qpos + L]] == T.grp[d[dpos + L]]) { int a = q[qpos + L], b = d[dpos + L]; score += MC_SUB(T, a, b); ident += (a == b); L++; }
+#ifdef MC_EV_BRANCHY_GROWTH
 #pragma unroll
     for (int j = 9; j < 16; j++) {
         const int a = (int)((q2 >> (8 * (j - 8))) & 0xFFu), b = (int)((d2 >> (8 * (j - 8))) & 0xFFu);
         if (L == j && lim > L && T.grp[a & 31] == T.grp[b & 31]) { score += MC_SUB(T, a, b); ident += (a == b); L++; }
     }
+#else
+    // (straight-line: the three table bytes of every step are asked for whether the step is taken or not - fifteen independent trips to
+    // the LDS in flight together instead of up to fifteen branches, each waiting for its own; what is taken is decided by L alone)
+#pragma unroll
+    for (int j = 9; j < 16; j++) {
+        const int a = (int)((q2 >> (8 * (j - 8))) & 0xFFu), b = (int)((d2 >> (8 * (j - 8))) & 0xFFu);
+        const int sm = (int)(T.grp[a & 31] == T.grp[b & 31]), sc = MC_SUB(T, a, b);
+        const int take = (int)(L == j) & (int)(lim > L) & sm;
+        score += take ? sc : 0; ident += take & (int)(a == b); L += take;
+    }
+#endif
     if (L == 16) while (lim > L && T.grp[q[qpos + L]] == T.grp[d[dpos + L]]) { int a = q[qpos + L], b = d[dpos + L]; score += MC_SUB(T, a, b); ident += (a == b); L++; }
     int back = qpos < dpos ? qpos : dpos, qp = qpos, dp = dpos;
+#ifdef MC_EV_BRANCHY_GROWTH
 #pragma unroll
     for (int j = 1; j <= 8; j++) {
         const int a = (int)((q0 >> (8 * (8 - j))) & 0xFFu), b = (int)((d0 >> (8 * (8 - j))) & 0xFFu);
         if (qpos - qp == j - 1 && back > 0 && T.grp[a & 31] == T.grp[b & 31]) { qp--; dp--; back--; L++; score += MC_SUB(T, a, b); ident += (a == b); }
     }
+#else
+#pragma unroll
+    for (int j = 1; j <= 8; j++) {
+        const int a = (int)((q0 >> (8 * (8 - j))) & 0xFFu), b = (int)((d0 >> (8 * (8 - j))) & 0xFFu);
+        const int sm = (int)(T.grp[a & 31] == T.grp[b & 31]), sc = MC_SUB(T, a, b);
+        const int take = (int)(qpos - qp == j - 1) & (int)(back > 0) & sm;
+        qp -= take; dp -= take; back -= take; L += take; score += take ? sc : 0; ident += take & (int)(a == b);
+    }
+#endif
     if (qpos - qp == 8) while (back > 0 && T.grp[q[qp - 1]] == T.grp[d[dp - 1]]) { qp--; dp--; back--; L++; int a = q[qp], b = d[dp]; score += MC_SUB(T, a, b); ident += (a == b); }
     qp_o = qp; dp_o = dp; L_o = L;
     return (double)score >= MC_SEED_SCORE && ident >= MC_SEED_IDENT;
@@ -71,7 +93,16 @@ __device__ __forceinline__ bool mc_ev_gate(const McHot &T, const uint8_t *q, int
 // ... and the extension itself, from the grown seed: 1 = ungapped HSP complete, 2 = needs the gapped extension
 __device__ __forceinline__ int mc_ev_xdrop(const McHot &T, const uint8_t *q, int qlen, const uint8_t *d, int dlen, int sidx, int qp, int dp, int L, int score, int ident, McGapTask *gt)
 {
+    // The reference's exit test is `(double)run < (double)best - xdrop` on two integers and a constant that is no integer (8.94 for BLOSUM62's
+    // ungapped lambda; mc_tables_init refuses one that is nearer than 1e-6 to an integer): best - run > xdrop <=> best - run >= floor(xdrop) + 1,
+    // exactly.  (MC_EV_F64_XDROP: the reference's own form - two conversions and an f64 subtraction in the dependent chain of every step.)
+#ifdef MC_EV_F64_XDROP
     const double xd = T.xdrop_ungapped;
+#define MC_EV_DROP(run, best) ((double)(run) < (double)(best) - xd)
+#else
+    const int xdi = (int)floor(T.xdrop_ungapped) + 1;
+#define MC_EV_DROP(run, best) ((best) - (run) >= xdi)
+#endif
     int s0 = score, qfwd = 0, qbwd = 0, fgain = 0, bgain = 0;
     { // forward
         const int n1 = qlen - qp - L, n2 = dlen - dp - L;
@@ -94,7 +125,7 @@ __device__ __forceinline__ int mc_ev_xdrop(const McHot &T, const uint8_t *q, int
                     if (!stop) {
                         run += sc[k]; id += (int)((eq >> k) & 1u); i++;
                         if (run > best) { best = run; bl = i; bi = id; }
-                        stop = !(n2 > i) || n1 <= i || run < -20 || (double)run < (double)best - xd;
+                        stop = !(n2 > i) || n1 <= i || run < -20 || MC_EV_DROP(run, best);
                     }
             } while (!stop);
             fgain = best - s0;
@@ -121,7 +152,7 @@ __device__ __forceinline__ int mc_ev_xdrop(const McHot &T, const uint8_t *q, int
                         run += sc[k]; id += (int)((eq >> k) & 1u); cnt++;
                         if (best < run) { best = run; bl = cnt; bi = id; }
                         a--; b--;
-                        stop = b < 0 || a < 0 || run < -20 || (double)run < (double)best - xd;
+                        stop = b < 0 || a < 0 || run < -20 || MC_EV_DROP(run, best);
                     }
             } while (!stop);
             bgain = best - s0;
