@@ -260,7 +260,7 @@ __device__ __forceinline__ unsigned long long mc_en_heavy(const McIndex &X, unsi
 template <int MC_EN_WAVES>
 __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_count(const McTables *__restrict__ T, McIndex X, const uint32_t *__restrict__ bitmap,
                                                                    const uint8_t *__restrict__ frames, int FP, int L, int64_t nreads, McSeedTask *tasks,
-                                                                   uint32_t cap, uint32_t *counters, unsigned long long *stats)
+                                                                   uint32_t cap, uint32_t *counters, unsigned long long *stats, uint32_t read0, int)
 {
     uint8_t *smem = mc_smem;
     uint8_t *grp = smem;                                                    // 32-byte group table
@@ -411,7 +411,7 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_count
                     MC_TICK(1);
                     const int take = hn < 64 ? hn : 64;
                     hn -= take;
-                    const unsigned long long rh = mc_en_heavy(X, (lane < take) ? W->hq[hn + lane] : 0ull, lane < take, (uint32_t)r, W, tasks, cap, counters, lane);
+                    const unsigned long long rh = mc_en_heavy(X, (lane < take) ? W->hq[hn + lane] : 0ull, lane < take, read0 + (uint32_t)r, W, tasks, cap, counters, lane);
                     sc.keyprobes += (uint32_t)(rh >> 32); sc.tasks += (uint32_t)(rh >> 8) & 0xFFFFFFu;
                     mc_wave_sync();
                     continue;
@@ -421,7 +421,7 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_count
                     const int take = qn < 64 ? qn : 64;
                     qn -= take;
                     n_probes += (uint32_t)take;
-                    const unsigned long long ret = mc_en_process(X, (lane < take) ? W->q[qn + lane] : 0ull, lane < take, (uint32_t)r, W, hn, tasks, cap, counters, lane
+                    const unsigned long long ret = mc_en_process(X, (lane < take) ? W->q[qn + lane] : 0ull, lane < take, read0 + (uint32_t)r, W, hn, tasks, cap, counters, lane
 #ifdef MC_EXP_TIMING
                                                                              , &tlast, &tcat
 #endif
@@ -632,8 +632,13 @@ __device__ __forceinline__ uint32_t mc_enq_process(const McIndex &X, unsigned lo
 template <int MC_EN_WAVES>
 __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_q(const McTables *__restrict__ T, McIndex X, const uint32_t *__restrict__ bitmap,
                                                                   const uint8_t *__restrict__ frames, int FP, int L, int64_t nreads, McSeedTask *tasks,
-                                                                  uint32_t cap, uint32_t *counters, unsigned long long *stats)
+                                                                  uint32_t cap, uint32_t *counters, unsigned long long *stats, uint32_t read0, int prio)
 {
+    // read0: the launch searches reads read0 .. read0 + nreads - 1 of the range (frames points at the first of them) - a range is searched in
+    // parts when the translation of the next part runs beside the search of this one (stage_a); prio: the waves' issue priority (s_setprio):
+    // this kernel waits for scattered lines with two in five issue slots idle, the translation is bound by issue - above it, its waves get
+    // their few instructions out at once and keep their requests in flight, and the translation takes the slots they leave
+    if (prio == 3) __builtin_amdgcn_s_setprio(3); else if (prio == 2) __builtin_amdgcn_s_setprio(2); else if (prio == 1) __builtin_amdgcn_s_setprio(1);
     uint8_t *smem = mc_smem;
     uint8_t *grp = smem;                                                    // 32-byte group table
     const int lane = mc_lane(), wv = threadIdx.x >> 6;
@@ -901,7 +906,7 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_q(con
         // The staged read is decoded and fewer than a batch of everything is left (or, at the end of a chunk, nothing): the next read.
         if (rnext >= nreads) break;
         r = rnext;
-        tag = (uint32_t)(r & (MC_EN_CHUNK - 1)); rbase = (uint32_t)r - tag;
+        tag = (uint32_t)(r & (MC_EN_CHUNK - 1)); rbase = read0 + (uint32_t)r - tag;
         __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0): this read's frames have arrived
         mc_wave_sync();
         {   // stage the six frames of this read as reduced-alphabet codes, two per byte (rows of FPn bytes, padded with the

@@ -52,15 +52,16 @@ __device__ __forceinline__ bool mc_ev_gate(const McHot &T, const uint8_t *q, int
     // (seeds shorter than 9 residues - the generic seed kernel of a database whose .info threshold is above 0 emits 6 .. 9 - grow
     // residue by residue up to the ninth; the marker database's seeds are 9 or 10 long and never enter)
     while (L < 9 && lim > L && T.grp[q[qpos + L]] == T.grp[d[dpos + L]]) { int a = q[qpos + L], b = d[dpos + L]; score += MC_SUB(T, a, b); ident += (a == b); L++; }
-#ifdef MC_EV_BRANCHY_GROWTH
+#ifndef MC_EV_FLAT_GROWTH
 #pragma unroll
     for (int j = 9; j < 16; j++) {
         const int a = (int)((q2 >> (8 * (j - 8))) & 0xFFu), b = (int)((d2 >> (8 * (j - 8))) & 0xFFu);
         if (L == j && lim > L && T.grp[a & 31] == T.grp[b & 31]) { score += MC_SUB(T, a, b); ident += (a == b); L++; }
     }
 #else
-    // (straight-line: the three table bytes of every step are asked for whether the step is taken or not - fifteen independent trips to
-    // the LDS in flight together instead of up to fifteen branches, each waiting for its own; what is taken is decided by L alone)
+    // (MC_EV_FLAT_GROWTH, round 6, measured and not kept: straight-line - the three table bytes of every step asked for whether the step is
+    // taken or not, fifteen independent trips to the LDS in flight together instead of up to fifteen branches - 2.531 -> 2.557 ms per 1 M
+    // reads of 150 bp, 5.591 -> 5.635 at 300 bp: most hits stop growing at once and the branches skip what the straight line executes)
 #pragma unroll
     for (int j = 9; j < 16; j++) {
         const int a = (int)((q2 >> (8 * (j - 8))) & 0xFFu), b = (int)((d2 >> (8 * (j - 8))) & 0xFFu);
@@ -71,7 +72,7 @@ __device__ __forceinline__ bool mc_ev_gate(const McHot &T, const uint8_t *q, int
 #endif
     if (L == 16) while (lim > L && T.grp[q[qpos + L]] == T.grp[d[dpos + L]]) { int a = q[qpos + L], b = d[dpos + L]; score += MC_SUB(T, a, b); ident += (a == b); L++; }
     int back = qpos < dpos ? qpos : dpos, qp = qpos, dp = dpos;
-#ifdef MC_EV_BRANCHY_GROWTH
+#ifndef MC_EV_FLAT_GROWTH
 #pragma unroll
     for (int j = 1; j <= 8; j++) {
         const int a = (int)((q0 >> (8 * (8 - j))) & 0xFFu), b = (int)((d0 >> (8 * (8 - j))) & 0xFFu);

@@ -29,7 +29,7 @@
 #define MC_NCTX 1
 struct McCtx {
     hipStream_t stream = nullptr, side = nullptr, side2 = nullptr;   // the pipeline of a range, and two side streams of the ordering / finishing kernels
-    hipEvent_t ev[8] = {}, ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+    hipEvent_t ev[8] = {}, ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_part[16] = {};
     int64_t cap_reads = 0;
     uint32_t cap_tasks = 0, cap_gaps = 0, cap_hsps = 0, cap_rows = 0;
     uint8_t *d_frames = nullptr, *d_frames_base = nullptr;   // (64 bytes of room in front: k_eval_seeds reads 8 bytes at a time backwards from a seed)
@@ -117,6 +117,7 @@ static void ctx_free(McCtx &c)
     for (void *p : {(void *)c.h_c, (void *)c.h_stats, (void *)c.h_best}) if (p) (void)hipHostFree(p);
     for (auto &e : c.ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {c.ev_fork, c.ev_join, c.ev_join2}) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c.ev_part) if (e) (void)hipEventDestroy(e);
     if (c.stream) (void)hipStreamDestroy(c.stream);                // (side, side2: the handle's)
     c = McCtx();
 }
@@ -479,12 +480,37 @@ static int stage_a(mc_handle *h, McCtx &c)
     const size_t cu_lds = 160 * 1024 - 1024;                      // (static LDS of the kernel and allocation granules)
     const bool staged = ts_force >= 0 ? ts_force != 0 : cu_lds / lds_staged >= cu_lds / lds_direct;   // staging stays while it does not cost a resident workgroup
     const size_t lds = staged ? lds_staged : lds_direct;
-    if (staged) {
-        if (lds > 48 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_translate_seg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_translate_seg<true><<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(MC_TS_THREADS), lds, st>>>(h->d_T, c.reads, L, n, c.d_frames, FP, h->d_segtab);
-    } else {
-        if (lds > 48 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_translate_seg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_translate_seg<false><<<dim3((unsigned)((n + MC_TS_READS - 1) / MC_TS_READS)), dim3(MC_TS_THREADS), lds, st>>>(h->d_T, c.reads, L, n, c.d_frames, FP, h->d_segtab);
+    // The front in PARTS (MC_A_PARTS = P > 1): the translation of part p + 1 on a side stream beside the seed search of
+    // part p.  The translation is bound by VALU issue with the memory system idle, the seed search by scattered lines with two in five issue
+    // slots idle; side by side as equals they took from each other what they gained (a translation wave keeps its SIMD's
+    // issue slots busy and the seed waves beside it stand still) - so the seed kernel's waves run at a higher issue priority (MC_EN_PRIO,
+    // s_setprio) and the translation takes the slots they leave.
+    static const int a_parts = getenv("MC_A_PARTS") ? std::max(1, std::min(16, atoi(getenv("MC_A_PARTS")))) : 1;
+    static const int en_prio = getenv("MC_EN_PRIO") ? std::max(0, std::min(3, atoi(getenv("MC_EN_PRIO")))) : 0;
+    const bool in_parts = a_parts > 1 && h->fast_enum && !h->count_traffic && n >= (int64_t)a_parts * 4096;
+    int64_t part_n = n;
+    if (in_parts) part_n = (((n + a_parts - 1) / a_parts) + 1023) / 1024 * 1024;
+    auto translate = [&](hipStream_t s2, int64_t off, int64_t cnt) -> int {
+        if (staged) {
+            if (lds > 48 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_translate_seg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k_translate_seg<true><<<dim3((unsigned)((cnt + MC_TS_READS - 1) / MC_TS_READS)), dim3(MC_TS_THREADS), lds, s2>>>(h->d_T, c.reads + off * L, L, cnt, c.d_frames + off * 6 * FP, FP, h->d_segtab);
+        } else {
+            if (lds > 48 * 1024) HIPCK(hipFuncSetAttribute((const void *)k_translate_seg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k_translate_seg<false><<<dim3((unsigned)((cnt + MC_TS_READS - 1) / MC_TS_READS)), dim3(MC_TS_THREADS), lds, s2>>>(h->d_T, c.reads + off * L, L, cnt, c.d_frames + off * 6 * FP, FP, h->d_segtab);
+        }
+        return 0;
+    };
+    if (!in_parts) { if (translate(st, 0, n)) return -1; }
+    else {
+        HIPCK(hipEventRecord(c.ev_fork, st));
+        HIPCK(hipStreamWaitEvent(c.side, c.ev_fork, 0));
+        for (int p = 0; (int64_t)p * part_n < n; p++) {
+            if (!c.ev_part[p]) HIPCK(hipEventCreateWithFlags(&c.ev_part[p], hipEventDisableTiming));
+            const int64_t off = (int64_t)p * part_n;
+            if (translate(c.side, off, std::min(part_n, n - off))) return -1;
+            HIPCK(hipEventRecord(c.ev_part[p], c.side));
+        }
+        HIPCK(hipStreamWaitEvent(st, c.ev_part[0], 0));               // (what the stage's first timer sees of the translation: its first part)
     }
     HIPCK(hipEventRecord(c.ev[1], st));
 #ifdef MC_EXP_TIMING
@@ -518,12 +544,16 @@ static int stage_a(mc_handle *h, McCtx &c)
         if (!waves) { g_err = "reads too long for the seed kernel's LDS layout"; return -1; }
         if (const char *e = getenv("MC_EN_SHAPE")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 16 || a == 12 || a == 8 || a == 4) && b >= 1 && (size_t)b * (64 + a * per_wave) <= 160 * 1024) { waves = a; bpc = b; } }   // (experiments)
         const size_t lds2 = 64 + waves * per_wave;
-        const int blocks = (int)std::min<int64_t>((int64_t)256 * bpc, (n + waves - 1) / waves);
 #define MC_LAUNCH_EN(KERNEL, WV)                                                                                                                   \
     do {                                                                                                                                           \
         HIPCK(hipFuncSetAttribute((const void *)KERNEL<WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                               \
-        KERNEL<WV><<<dim3(blocks), dim3(64 * WV), lds2, st>>>(h->d_T, X, h->d_bitmap, c.d_frames, FP, L, n, c.d_tasks, c.cap_tasks, c.d_counters, \
-                                                              c.d_stats);                                                                         \
+        for (int p_ = 0; (int64_t)p_ * part_n < n; p_++) {                                                                                         \
+            const int64_t off_ = (int64_t)p_ * part_n, cnt_ = std::min(part_n, n - off_);                                                          \
+            const int blocks_ = (int)std::min<int64_t>((int64_t)256 * bpc, (cnt_ + WV - 1) / WV);                                                  \
+            if (in_parts) { HIPCK(hipStreamWaitEvent(st, c.ev_part[p_], 0)); if (p_) HIPCK(hipMemsetAsync(c.d_counters + C_ENCHUNK, 0, 4, st)); }  \
+            KERNEL<WV><<<dim3(blocks_), dim3(64 * WV), lds2, st>>>(h->d_T, X, h->d_bitmap, c.d_frames + off_ * 6 * FP, FP, L, cnt_, c.d_tasks, c.cap_tasks, c.d_counters, \
+                                                                   c.d_stats, (uint32_t)off_, en_prio);                                          \
+        }                                                                                                                                          \
     } while (0)
         if (enq) { if (waves == 16) MC_LAUNCH_EN(k_enumerate_q, 16); else if (waves == 12) MC_LAUNCH_EN(k_enumerate_q, 12); else if (waves == 8) MC_LAUNCH_EN(k_enumerate_q, 8); else MC_LAUNCH_EN(k_enumerate_q, 4); }
         else { if (waves == 16) MC_LAUNCH_EN(k_enumerate_count, 16); else if (waves == 12) MC_LAUNCH_EN(k_enumerate_count, 12); else if (waves == 8) MC_LAUNCH_EN(k_enumerate_count, 8); else MC_LAUNCH_EN(k_enumerate_count, 4); }

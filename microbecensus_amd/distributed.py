@@ -649,6 +649,7 @@ def run_pipeline_distributed(args, device=None):
         args["sampled_reads"] = n_total
         if head[1] >= 0:
             mc._bases_cache[tuple(args["seqfiles"])] = head[1]
+        run_pipeline_distributed.last_batches = len(parts)                       # (batches THIS rank searched: the tests look at the dealing)
         best = np.concatenate(parts) if parts else np.zeros(0, _native.BEST_DTYPE)
         acc = family_accumulators(best, len(fams))
         acc = all_reduce_accumulators(*acc, device=dev)

@@ -37,7 +37,7 @@ def _args(case):
 
 
 # (the RCCL test first: a multi-GPU box that runs this file reaches it whatever happens later)
-def _two_ranks(tmp_path, backend, port):
+def _two_ranks(tmp_path, backend, port, world=2, batch="3000"):
     worker = tmp_path / "w.py"
     worker.write_text(r'''
 import json, os, sys
@@ -55,16 +55,18 @@ else:
 inp = os.path.join(sys.argv[1], "tests", "golden", "inputs")
 est, args = D.run_pipeline_distributed({"seqfiles": [os.path.join(inp, "c4_pair_1.fq.gz"), os.path.join(inp, "c4_pair_2.fq.gz")], "nreads": 20000},
                                        device=local if backend == "nccl" else 0)
+got = [None] * dist.get_world_size()
+dist.all_gather_object(got, D.run_pipeline_distributed.last_batches)
 if dist.get_rank() == 0:
     tr = D.run_pipeline_distributed.last_trace
     json.dump({"est": est, "sampled": args["sampled_reads"], "L": args["read_length"], "world": dist.get_world_size(), "backend": dist.get_backend(),
-               "deals": sum(1 for t in tr if t[0] == "deal")}, open(sys.argv[2], "w"))
+               "deals": sum(1 for t in tr if t[0] == "deal"), "batches_per_rank": got}, open(sys.argv[2], "w"))
 dist.barrier()
 dist.destroy_process_group()
 ''')
     out = tmp_path / "o.json"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MC_DIST_BATCH="3000")   # 20,000 reads dealt in 7 batches
-    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MC_DIST_BATCH=batch)   # 20,000 reads dealt in 7 batches of 3,000
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                            "--master-port", str(port), str(worker), REPO, str(out), backend], env=env, timeout=900)
     return json.load(open(out))
 
@@ -89,6 +91,59 @@ def test_config4_shape_two_ranks_gloo(tmp_path):
     assert res["world"] == 2 and res["sampled"] == g["sampled_reads"] and res["L"] == 150
     assert res["deals"] == 7                                      # streamed: 3,000-read batches dealt round robin while the sampler runs
     assert abs(res["est"] - g["est_ags"]) <= 1e-9 * g["est_ags"]
+
+
+def test_config4_shape_eight_ranks_gloo(tmp_path):
+    """World size 8 - what the driver's multi-GPU node runs - before any hardware has it: eight ranks on this box's
+    one GPU (gloo), the reference's paired golden dealt in batches of 1,500 reads: the reference's AGS bit for bit, 14 deals, and every
+    rank searched at least one batch (credits: two per rank, the dealer goes round the ranks)."""
+    g = json.load(open(os.path.join(GOLD, "c4_paired.json")))
+    res = _two_ranks(tmp_path, "gloo", 29551, world=8, batch="1500")
+    assert res["world"] == 8 and res["sampled"] == g["sampled_reads"] and res["L"] == 150
+    assert res["deals"] == 14 and sum(res["batches_per_rank"]) == 14 and min(res["batches_per_rank"]) >= 1, res
+    assert res["est"] == g["est_ags"]
+
+
+def test_bench_eight_ranks_on_one_gpu_equals_one_engine(tmp_path):
+    """bench.py --gpus 8 as the driver will launch it, with gloo and all ranks on this box's GPU: the line's `rccl`
+    object must show eight ranks (rank_sum 36), and the reduced per-family vector - hits, alignment sums, alignment sums per target
+    length, summed over the ranks by the collective - must be the vector ONE engine computes for the same 4 M reads of the paired
+    library (crc32 of the int64 arrays), i.e. no read searched twice or dropped by the sharding, no sum lost in the reduce."""
+    import zlib
+    import numpy as np
+    from microbecensus_amd import _native, distributed as mcd, synth
+    B, K, W, L = 250_000, 2, 8, 150
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(W), "--backend", "gloo", "--batch", str(B), "--steps", str(K), "--warmup", "1",
+                          "--no-cpu-baseline", "--e2e-reads", "2000000", "--c5-reads", "0"], env=env, stdout=subprocess.PIPE, timeout=1500, check=True).stdout.decode()
+    line = json.loads([l for l in out.splitlines() if l.startswith('{"metric"')][-1])
+    r = line["rccl"]
+    assert line["n_gpus"] == W and r["world_size"] == W and r["rank_sum"] == 36 == r["rank_sum_expected"] and r["backend"] == "gloo"
+    assert line["e2e"]["sampled_reads"] == 2_000_000 and line["e2e"]["est_ags"] > 1e6
+    # the same reads through one engine of this process: file 1 (mate 1 of every fragment), then file 2
+    model = _native.load_model()
+    fams = model["families"]
+    nf = len(fams)
+    gen = synth.GenomeReads(device="cuda:0", seed=20261001)
+    F = B * K * W // 2
+    eng = _native.Engine(device=0)
+    try:
+        eng.set_run(L, model["pars"][str(L)], fams)
+        hits, aln, bylen = np.zeros(nf, np.int64), np.zeros(nf, np.int64), np.zeros((nf, mcd.MAX_TARGET_LEN), np.int64)
+        for mate in (0, 1):
+            for lo in range(0, F, 1_000_000):
+                n = min(1_000_000, F - lo)
+                reads = gen.paired(n, L, frag=300, first=lo)[mate]
+                eng.attach(reads.data_ptr(), n)
+                eng.run_range(0, n, first_read_id=0)
+                h, a, b = mcd.family_accumulators(eng.best_hits(), nf)
+                hits += h; aln += a; bylen += b
+                eng.attach(0, 0)
+    finally:
+        eng.close()
+    assert line["config"]["classified_reads"] == int(hits.sum()) > 1000
+    assert r["reduced_vector_crc32"] == zlib.crc32(np.concatenate([hits, aln, bylen.ravel()]).tobytes())
 
 
 def test_sharded_sampling_two_ranks_gloo(tmp_path):

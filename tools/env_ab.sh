@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 L=150; B=2000000
 run() {
-  env $1 timeout 300 python3 bench.py --steps 6 --warmup 3 --batch $B --resident-batches 3 --read-len $L --no-cpu-baseline --no-ags-check --e2e-reads 0 2>/dev/null | python3 -c "
+  env $1 timeout 300 python3 bench.py --steps 6 --warmup 3 --batch $B --resident-batches 3 --read-len $L --no-cpu-baseline --no-ags-check --e2e-reads 0 --c5-reads 0 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
 c=d['classification_only']

@@ -9,7 +9,7 @@ for L in 150 300; do
     export MC_GAP_REFILL=$1 MC_GAP_WPC=$2
     OUT=$R/gpurun_out/gapsweep/L${L}_r$1_w$2
     rm -rf $OUT && mkdir -p $OUT
-    timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 4 --warmup 6 --batch 1000000 --resident-batches 2 --read-len $L --no-cpu-baseline --no-ags-check --e2e-reads 0 > $OUT/trace.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 4 --warmup 6 --batch 1000000 --resident-batches 2 --read-len $L --no-cpu-baseline --no-ags-check --e2e-reads 0 --c5-reads 0 > $OUT/trace.log 2>&1
     echo "== L=$L refill=$1 wpc=$2"
     python3 - $OUT <<'PY'
 import csv, glob, os, sys

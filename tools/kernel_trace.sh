@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/ktrace_L$L
 rm -rf $OUT && mkdir -p $OUT
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 4 --warmup 6 --batch 1000000 --resident-batches 2 --read-len $L --no-cpu-baseline --no-ags-check --no-reference-pattern --e2e-reads 0 "$@" > $OUT/trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 4 --warmup 6 --batch 1000000 --resident-batches 2 --read-len $L --no-cpu-baseline --no-ags-check --no-reference-pattern --e2e-reads 0 --c5-reads 0 "$@" > $OUT/trace.log 2>&1
 python3 - $OUT <<'PY'
 import csv, glob, os, sys
 for f in glob.glob(os.path.join(sys.argv[1], "trace", "*kernel_stats.csv")):

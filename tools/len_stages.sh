@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 L=${1:-300}
-timeout 600 python3 bench.py --steps 6 --warmup 3 --batch ${2:-1000000} --resident-batches 3 --read-len $L --no-cpu-baseline --no-ags-check --e2e-reads 0 2>/dev/null | python3 -c "
+timeout 600 python3 bench.py --steps 6 --warmup 3 --batch ${2:-1000000} --resident-batches 3 --read-len $L --no-cpu-baseline --no-ags-check --e2e-reads 0 --c5-reads 0 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
 c=d['classification_only']

@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 for flag in "--one-at-a-time" ""; do
-  timeout 300 python3 bench.py --steps 8 --warmup 3 --batch ${1:-2000000} --resident-batches 3 $flag --no-cpu-baseline --no-ags-check --e2e-reads 0 2>/dev/null | python3 -c "
+  timeout 300 python3 bench.py --steps 8 --warmup 3 --batch ${1:-2000000} --resident-batches 3 $flag --no-cpu-baseline --no-ags-check --e2e-reads 0 --c5-reads 0 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
 c=d['classification_only']

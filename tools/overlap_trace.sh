@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/otrace
 rm -rf $OUT && mkdir -p $OUT
-timeout 900 rocprofv3 --kernel-trace -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --batch 2000000 --resident-batches 2 --read-len $L --no-cpu-baseline --no-ags-check --e2e-reads 0 > $OUT/trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --batch 2000000 --resident-batches 2 --read-len $L --no-cpu-baseline --no-ags-check --e2e-reads 0 --c5-reads 0 > $OUT/trace.log 2>&1
 python3 - $OUT <<'PY'
 import csv, glob, os, sys
 f = glob.glob(os.path.join(sys.argv[1], "trace", "*kernel_trace.csv"))[0]

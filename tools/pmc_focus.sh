@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/focus
 rm -rf $OUT && mkdir -p $OUT
-BENCH="python3 $R/bench.py --steps 3 --warmup 6 --batch 1000000 --resident-batches 1 --read-len $L --no-cpu-baseline --no-ags-check --no-reference-pattern --e2e-reads 0"
+BENCH="python3 $R/bench.py --steps 3 --warmup 6 --batch 1000000 --resident-batches 1 --read-len $L --no-cpu-baseline --no-ags-check --no-reference-pattern --e2e-reads 0 --c5-reads 0"
 i=0
 if [ -n "$PMC_SETS" ]; then IFS=';' read -ra SETS <<< "$PMC_SETS"; else SETS=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
