@@ -260,7 +260,11 @@ __device__ __forceinline__ unsigned long long mc_en_heavy(const McIndex &X, unsi
 template <int MC_EN_WAVES>
 __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_count(const McTables *__restrict__ T, McIndex X, const uint32_t *__restrict__ bitmap,
                                                                    const uint8_t *__restrict__ frames, int FP, int L, int64_t nreads, McSeedTask *tasks,
-                                                                   uint32_t cap, uint32_t *counters, unsigned long long *stats, uint32_t read0, int)
+                                                                   uint32_t cap, uint32_t *counters, unsigned long long *stats, uint32_t read0, int
+#ifdef MC_EN_FRONT_ONLY
+                                                                   , uint32_t *, uint32_t, uint32_t *
+#endif
+                                                                   )
 {
     uint8_t *smem = mc_smem;
     uint8_t *grp = smem;                                                    // 32-byte group table
@@ -632,13 +636,22 @@ __device__ __forceinline__ uint32_t mc_enq_process(const McIndex &X, unsigned lo
 template <int MC_EN_WAVES>
 __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_q(const McTables *__restrict__ T, McIndex X, const uint32_t *__restrict__ bitmap,
                                                                   const uint8_t *__restrict__ frames, int FP, int L, int64_t nreads, McSeedTask *tasks,
-                                                                  uint32_t cap, uint32_t *counters, unsigned long long *stats, uint32_t read0, int prio)
+                                                                  uint32_t cap, uint32_t *counters, unsigned long long *stats, uint32_t read0, int prio
+#ifdef MC_EN_FRONT_ONLY
+                                                                  , uint32_t *wl_items, uint32_t wl_cap, uint32_t *wl_cursor
+#endif
+                                                                  )
 {
     // read0: the launch searches reads read0 .. read0 + nreads - 1 of the range (frames points at the first of them) - a range is searched in
     // parts when the translation of the next part runs beside the search of this one (stage_a); prio: the waves' issue priority (s_setprio):
     // this kernel waits for scattered lines with two in five issue slots idle, the translation is bound by issue - above it, its waves get
     // their few instructions out at once and keep their requests in flight, and the translation takes the slots they leave
     if (prio == 3) __builtin_amdgcn_s_setprio(3); else if (prio == 2) __builtin_amdgcn_s_setprio(2); else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+#ifdef MC_EN_FRONT_ONLY
+    __shared__ uint32_t fo_all[MC_EN_WAVES][16];
+    uint32_t *fo_base = fo_all[threadIdx.x >> 6], *fo_used = fo_base + 8;
+    if ((threadIdx.x & 63) < 8) { fo_base[threadIdx.x & 63] = 0; fo_used[threadIdx.x & 63] = 256u; }
+#endif
     uint8_t *smem = mc_smem;
     uint8_t *grp = smem;                                                    // 32-byte group table
     const int lane = mc_lane(), wv = threadIdx.x >> 6;
@@ -795,12 +808,46 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_q(con
                 fb9 = mc_filter_bits(hh);
                 fw9 = X.filt[live0 ? mc_filter9_word(hh) : 0u];
             }
+#ifdef MC_EN_FRONT_ONLY
+            // MEASUREMENT BUILD ONLY (the first pass of an XCD-sliced filter cascade priced): the wildcard asks are not made - each
+            // becomes a 12-byte item (seed, key, position, frame, read) in one of eight lists by the top three bits of its filter line, in
+            // blocks of 256 slots per wave and list (one global atomic per block).  The results of such a build are NOT the reference's.
+            if (mw) {
+                const uint32_t ctx = mc_wild_ctx(seed, qk);
+                const uint32_t sl = mc_wild_line(ctx) >> (MC_WILD_LOG2L - 3);
+                const uint32_t rd_ = rbase + tg;
+#pragma unroll 1
+                for (uint32_t s8 = 0; s8 < 8; s8++) {
+                    const unsigned long long m8 = __ballot(live && sl == s8);
+                    if (!m8) continue;
+                    const uint32_t n8 = (uint32_t)__popcll(m8), r8 = (uint32_t)__popcll(m8 & lt);
+                    uint32_t bb = fo_base[s8], bu = fo_used[s8];
+                    mc_wave_sync();
+                    if (bu + n8 > 256u) {
+                        for (uint32_t i = bu + lane; i < 256u; i += 64) wl_items[((size_t)s8 * wl_cap + bb + i) * 3] = 0xFFFFFFFFu;
+                        uint32_t nb = 0;
+                        if (lane == 0) nb = atomicAdd(&wl_cursor[s8 * 32], 256u);
+                        bb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb); bu = 0;
+                        if (bb + 256u > wl_cap) { bb = 0; }                   // (measurement build: wrap instead of failing)
+                    }
+                    if (live && sl == s8) {
+                        uint32_t *it = wl_items + ((size_t)s8 * wl_cap + bb + bu + r8) * 3;
+                        it[0] = seed | ((uint32_t)((pw >> 36) & 0x7FFu) << 20); it[1] = qk; it[2] = rd_;
+                    }
+                    if (lane == 0) { fo_base[s8] = bb; fo_used[s8] = bu + n8; }
+                    mc_wave_sync();
+                }
+            }
+            const bool live_fo = false;
+#define live live_fo
+#else
             if (mw) {
                 const uint32_t ctx = mc_wild_ctx(seed, qk);
                 const uint4 *ln = (const uint4 *)X.wild + (size_t)(live ? mc_wild_line(ctx) : 0u) * 2;
                 q0 = ln[0]; q1 = ln[1];
                 wsum = mc_wild_sum(ctx, d3, d4, d5, qk >> 12);
             }
+#endif
             const bool pr = live0 && (fw9 & fb9) == fb9;
             const unsigned long long prm = __ballot(pr);
             if (prm) {
@@ -810,6 +857,9 @@ __global__ void MC_EN_ATTR __launch_bounds__(64 * MC_EN_WAVES) k_enumerate_q(con
             wm = 0;
             if (live) wm = (mc_wild_test2(q0.x, q0.y, mc_wild_bits_s(wsum, d4, 0)) ? 1u : 0u) | (mc_wild_test2(q0.z, q0.w, mc_wild_bits_s(wsum, d5, 1)) ? 2u : 0u) |
                            (mc_wild_test2(q1.x, q1.y, mc_wild_bits_s(wsum, d3, 2)) ? 4u : 0u) | (mc_wild_test2(q1.z, q1.w, mc_wild_bits_s(wsum, qk >> 12, 3)) ? 8u : 0u);
+#ifdef MC_EN_FRONT_ONLY
+#undef live
+#endif
             for (;;) {   // the groups enter eq at once while it has room (else from the state above)
                 const unsigned long long wmm = __ballot(wm != 0);
                 if (wmm == 0 || en >= 64) break;

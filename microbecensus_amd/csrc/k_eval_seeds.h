@@ -52,41 +52,18 @@ __device__ __forceinline__ bool mc_ev_gate(const McHot &T, const uint8_t *q, int
     // (seeds shorter than 9 residues - the generic seed kernel of a database whose .info threshold is above 0 emits 6 .. 9 - grow
     // residue by residue up to the ninth; the marker database's seeds are 9 or 10 long and never enter)
     while (L < 9 && lim > L && T.grp[q[qpos + L]] == T.grp[d[dpos + L]]) { int a = q[qpos + L], b = d[dpos + L]; score += MC_SUB(T, a, b); ident += (a == b); L++; }
-#ifndef MC_EV_FLAT_GROWTH
 #pragma unroll
     for (int j = 9; j < 16; j++) {
         const int a = (int)((q2 >> (8 * (j - 8))) & 0xFFu), b = (int)((d2 >> (8 * (j - 8))) & 0xFFu);
         if (L == j && lim > L && T.grp[a & 31] == T.grp[b & 31]) { score += MC_SUB(T, a, b); ident += (a == b); L++; }
     }
-#else
-    // (MC_EV_FLAT_GROWTH, round 6, measured and not kept: straight-line - the three table bytes of every step asked for whether the step is
-    // taken or not, fifteen independent trips to the LDS in flight together instead of up to fifteen branches - 2.531 -> 2.557 ms per 1 M
-    // reads of 150 bp, 5.591 -> 5.635 at 300 bp: most hits stop growing at once and the branches skip what the straight line executes)
-#pragma unroll
-    for (int j = 9; j < 16; j++) {
-        const int a = (int)((q2 >> (8 * (j - 8))) & 0xFFu), b = (int)((d2 >> (8 * (j - 8))) & 0xFFu);
-        const int sm = (int)(T.grp[a & 31] == T.grp[b & 31]), sc = MC_SUB(T, a, b);
-        const int take = (int)(L == j) & (int)(lim > L) & sm;
-        score += take ? sc : 0; ident += take & (int)(a == b); L += take;
-    }
-#endif
     if (L == 16) while (lim > L && T.grp[q[qpos + L]] == T.grp[d[dpos + L]]) { int a = q[qpos + L], b = d[dpos + L]; score += MC_SUB(T, a, b); ident += (a == b); L++; }
     int back = qpos < dpos ? qpos : dpos, qp = qpos, dp = dpos;
-#ifndef MC_EV_FLAT_GROWTH
 #pragma unroll
     for (int j = 1; j <= 8; j++) {
         const int a = (int)((q0 >> (8 * (8 - j))) & 0xFFu), b = (int)((d0 >> (8 * (8 - j))) & 0xFFu);
         if (qpos - qp == j - 1 && back > 0 && T.grp[a & 31] == T.grp[b & 31]) { qp--; dp--; back--; L++; score += MC_SUB(T, a, b); ident += (a == b); }
     }
-#else
-#pragma unroll
-    for (int j = 1; j <= 8; j++) {
-        const int a = (int)((q0 >> (8 * (8 - j))) & 0xFFu), b = (int)((d0 >> (8 * (8 - j))) & 0xFFu);
-        const int sm = (int)(T.grp[a & 31] == T.grp[b & 31]), sc = MC_SUB(T, a, b);
-        const int take = (int)(qpos - qp == j - 1) & (int)(back > 0) & sm;
-        qp -= take; dp -= take; back -= take; L += take; score += take ? sc : 0; ident += take & (int)(a == b);
-    }
-#endif
     if (qpos - qp == 8) while (back > 0 && T.grp[q[qp - 1]] == T.grp[d[dp - 1]]) { qp--; dp--; back--; L++; int a = q[qp], b = d[dp]; score += MC_SUB(T, a, b); ident += (a == b); }
     qp_o = qp; dp_o = dp; L_o = L;
     return (double)score >= MC_SEED_SCORE && ident >= MC_SEED_IDENT;
@@ -167,7 +144,7 @@ __device__ __forceinline__ int mc_ev_xdrop(const McHot &T, const uint8_t *q, int
 }
 
 #ifdef MC_EXP_TIMING
-__device__ unsigned long long g_ev_acc[8];           // wave time per phase, summed over the waves: 0 barriers / flush 1 record, first reads, seed score 2 growth, gate, X-drop 3 HSP 4 staging
+__device__ unsigned long long g_ev_acc[8];           // wave time per phase, summed over the waves (lane 0): 0 loop, next records asked for 1 survivors queued 2 X-drop extension (with the read of the queue) 3 HSP, marks 4 records written 5 wait for the residues + seed score 6 redundancy test, growth, gate
 #define MC_EV_TICK(prev) do { const unsigned long long now_ = __builtin_readcyclecounter(); ev_acc_[prev] += now_ - ev_last_; ev_last_ = now_; } while (0)
 #else
 #define MC_EV_TICK(prev) do { } while (0)
@@ -262,9 +239,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
                     const int a = (int)((k < 8 ? q1 >> (8 * k) : q2 >> (8 * (k - 8))) & 0xFFu), b = (int)((k < 8 ? d1 >> (8 * k) : d2 >> (8 * (k - 8))) & 0xFFu);
                     score += MC_SUB(hot, a, b); ident += (a == b);
                 }
+            MC_EV_TICK(5);                                            // (the six residue loads arrive here: their wait, and the seed's score)
             const bool go = !(dpos + seedlen > dlen) && !(pos != 0 && dpos != 0 && hot.grp[qm1] == hot.grp[dm1] && nkey != 4);
             int qp = 0, dp = 0, Lg = 0;
             if (go) surv = mc_ev_gate(hot, q, qlen, pos, d, dlen, dpos, seedlen, score, ident, qp, dp, Lg, q0, q2, d0, d2);
+            MC_EV_TICK(6);                                            // (redundancy test, growth, the gate's thresholds)
             e0.x = rd; e0.y = chrono; e0.z = o0; e0.w = (uint32_t)sidx;
             e1.x = (uint32_t)qp | ((uint32_t)dp << 16); e1.y = (uint32_t)Lg | ((uint32_t)(uint16_t)(int16_t)score << 16); e1.z = (uint32_t)ident | ((uint32_t)dlen << 16);
         }
@@ -390,6 +369,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
         }
     }
 #ifdef MC_EXP_TIMING
-    if (lane == 0) for (int k = 0; k < 5; k++) atomicAdd(&g_ev_acc[k], ev_acc_[k]);
+    if (lane == 0) for (int k = 0; k < 7; k++) atomicAdd(&g_ev_acc[k], ev_acc_[k]);
 #endif
 }

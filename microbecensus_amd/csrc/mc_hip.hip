@@ -29,7 +29,8 @@
 #define MC_NCTX 1
 struct McCtx {
     hipStream_t stream = nullptr, side = nullptr, side2 = nullptr;   // the pipeline of a range, and two side streams of the ordering / finishing kernels
-    hipEvent_t ev[8] = {}, ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_part[16] = {};
+    hipEvent_t ev[8] = {}, ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_part[16] = {}, ev_en[16] = {};
+    hipStream_t tr_stream = nullptr;                               // the translation of the next part of a range beside the seed search of this one (stage_a, MC_A_PARTS)
     int64_t cap_reads = 0;
     uint32_t cap_tasks = 0, cap_gaps = 0, cap_hsps = 0, cap_rows = 0;
     uint8_t *d_frames = nullptr, *d_frames_base = nullptr;   // (64 bytes of room in front: k_eval_seeds reads 8 bytes at a time backwards from a seed)
@@ -118,6 +119,8 @@ static void ctx_free(McCtx &c)
     for (auto &e : c.ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {c.ev_fork, c.ev_join, c.ev_join2}) if (e) (void)hipEventDestroy(e);
     for (auto &e : c.ev_part) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c.ev_en) if (e) (void)hipEventDestroy(e);
+    if (c.tr_stream) (void)hipStreamDestroy(c.tr_stream);
     if (c.stream) (void)hipStreamDestroy(c.stream);                // (side, side2: the handle's)
     c = McCtx();
 }
@@ -502,14 +505,18 @@ static int stage_a(mc_handle *h, McCtx &c)
     };
     if (!in_parts) { if (translate(st, 0, n)) return -1; }
     else {
-        HIPCK(hipEventRecord(c.ev_fork, st));
-        HIPCK(hipStreamWaitEvent(c.side, c.ev_fork, 0));
+        // T0 | E0 + T1 | E1 + T2 | ...: the translation of part p + 1 is released together with the seed search of part p (it waits for the
+        // search of part p - 1; left to itself the side stream would run ALL translations first - their small workgroups take every slot
+        // that frees up before a seed workgroup of 8 waves fits).  A stream of the lowest priority: the seed kernel's workgroups are placed first.
+        if (!c.tr_stream) { int lo = 0, hi = 0; HIPCK(hipDeviceGetStreamPriorityRange(&lo, &hi)); HIPCK(hipStreamCreateWithPriority(&c.tr_stream, hipStreamNonBlocking, lo)); }
         for (int p = 0; (int64_t)p * part_n < n; p++) {
             if (!c.ev_part[p]) HIPCK(hipEventCreateWithFlags(&c.ev_part[p], hipEventDisableTiming));
-            const int64_t off = (int64_t)p * part_n;
-            if (translate(c.side, off, std::min(part_n, n - off))) return -1;
-            HIPCK(hipEventRecord(c.ev_part[p], c.side));
+            if (!c.ev_en[p]) HIPCK(hipEventCreateWithFlags(&c.ev_en[p], hipEventDisableTiming));
         }
+        HIPCK(hipEventRecord(c.ev_fork, st));
+        HIPCK(hipStreamWaitEvent(c.tr_stream, c.ev_fork, 0));
+        if (translate(c.tr_stream, 0, std::min(part_n, n))) return -1;
+        HIPCK(hipEventRecord(c.ev_part[0], c.tr_stream));
         HIPCK(hipStreamWaitEvent(st, c.ev_part[0], 0));               // (what the stage's first timer sees of the translation: its first part)
     }
     HIPCK(hipEventRecord(c.ev[1], st));
@@ -544,15 +551,34 @@ static int stage_a(mc_handle *h, McCtx &c)
         if (!waves) { g_err = "reads too long for the seed kernel's LDS layout"; return -1; }
         if (const char *e = getenv("MC_EN_SHAPE")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 16 || a == 12 || a == 8 || a == 4) && b >= 1 && (size_t)b * (64 + a * per_wave) <= 160 * 1024) { waves = a; bpc = b; } }   // (experiments)
         const size_t lds2 = 64 + waves * per_wave;
+#ifdef MC_EN_FRONT_ONLY   /* measurement build: the lists the front writes its wildcard asks to */
+        static uint32_t *fo_items = nullptr, *fo_cursor = nullptr;
+        const uint32_t fo_cap = 80u << 20;                          /* slots per list: 8 x 80 M x 12 B = 7.7 GB */
+        if (!fo_items) { HIPCK(hipMalloc((void **)&fo_items, (size_t)8 * fo_cap * 12)); HIPCK(hipMalloc((void **)&fo_cursor, 8 * 32 * 4)); }
+        HIPCK(hipMemsetAsync(fo_cursor, 0, 8 * 32 * 4, st));
+#define MC_FO_ARGS , fo_items, fo_cap, fo_cursor
+#else
+#define MC_FO_ARGS
+#endif
 #define MC_LAUNCH_EN(KERNEL, WV)                                                                                                                   \
     do {                                                                                                                                           \
         HIPCK(hipFuncSetAttribute((const void *)KERNEL<WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                               \
         for (int p_ = 0; (int64_t)p_ * part_n < n; p_++) {                                                                                         \
             const int64_t off_ = (int64_t)p_ * part_n, cnt_ = std::min(part_n, n - off_);                                                          \
             const int blocks_ = (int)std::min<int64_t>((int64_t)256 * bpc, (cnt_ + WV - 1) / WV);                                                  \
-            if (in_parts) { HIPCK(hipStreamWaitEvent(st, c.ev_part[p_], 0)); if (p_) HIPCK(hipMemsetAsync(c.d_counters + C_ENCHUNK, 0, 4, st)); }  \
+            if (in_parts) {                                                                                                                        \
+                const int64_t off2_ = off_ + part_n;                                                                                               \
+                if (off2_ < n) {                                                                                                                   \
+                    if (p_ >= 1) HIPCK(hipStreamWaitEvent(c.tr_stream, c.ev_en[p_ - 1], 0));                                                       \
+                    if (translate(c.tr_stream, off2_, std::min(part_n, n - off2_))) return -1;                                                     \
+                    HIPCK(hipEventRecord(c.ev_part[p_ + 1], c.tr_stream));                                                                         \
+                }                                                                                                                                  \
+                HIPCK(hipStreamWaitEvent(st, c.ev_part[p_], 0));                                                                                   \
+                if (p_) HIPCK(hipMemsetAsync(c.d_counters + C_ENCHUNK, 0, 4, st));                                                                 \
+            }                                                                                                                                      \
             KERNEL<WV><<<dim3(blocks_), dim3(64 * WV), lds2, st>>>(h->d_T, X, h->d_bitmap, c.d_frames + off_ * 6 * FP, FP, L, cnt_, c.d_tasks, c.cap_tasks, c.d_counters, \
-                                                                   c.d_stats, (uint32_t)off_, en_prio);                                          \
+                                                                   c.d_stats, (uint32_t)off_, en_prio MC_FO_ARGS);                               \
+            if (in_parts) HIPCK(hipEventRecord(c.ev_en[p_], st));                                                                                  \
         }                                                                                                                                          \
     } while (0)
         if (enq) { if (waves == 16) MC_LAUNCH_EN(k_enumerate_q, 16); else if (waves == 12) MC_LAUNCH_EN(k_enumerate_q, 12); else if (waves == 8) MC_LAUNCH_EN(k_enumerate_q, 8); else MC_LAUNCH_EN(k_enumerate_q, 4); }
@@ -751,8 +777,8 @@ static int stage_d(mc_handle *h, McCtx &c)
         {
             unsigned long long ev[8];
             HIPCK(hipMemcpyFromSymbol(ev, HIP_SYMBOL(g_ev_acc), sizeof ev));
-            const char *en[5] = {"barriers, flush", "record, first reads", "growth, gate, X-drop", "HSP", "staging"};
-            for (int k = 0; k < 5; k++) fprintf(stderr, "ev-timing %-21s total %9.1f Mcycles (lane 0 of every wave)\n", en[k], ev[k] / 1e6);
+            const char *en[7] = {"loop, records asked", "survivors queued", "X-drop extension", "HSP, marks", "records written", "residue wait + seed", "growth, gate"};
+            for (int k = 0; k < 7; k++) fprintf(stderr, "ev-timing %-21s total %9.1f Mcycles (lane 0 of every wave)\n", en[k], ev[k] / 1e6);
             unsigned long long z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_ev_acc), z8, sizeof z8));
         }
