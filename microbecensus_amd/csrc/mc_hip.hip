@@ -1131,6 +1131,7 @@ static int run_stream(mc_handle *h, const std::function<int64_t(uint8_t *, int64
     return 0;
 }
 
+void mc_host_copy(uint8_t *dst, const uint8_t *src, size_t bytes);   // (mc_reader.cpp: a batch copied by several threads)
 extern "C" int mc_search(mc_handle *h, const uint8_t *reads, int64_t nreads, int64_t first_read_id)
 {
     if (!h || !h->run_set) { g_err = "mc_set_run() must be called first"; return -1; }
@@ -1139,7 +1140,7 @@ extern "C" int mc_search(mc_handle *h, const uint8_t *reads, int64_t nreads, int
     int64_t at = 0;
     return run_stream(h, [&](uint8_t *dst, int64_t max_reads, int64_t *first) -> int64_t {
         const int64_t n = std::max<int64_t>(0, std::min(max_reads, nreads - at));
-        if (n > 0) memcpy(dst, reads + at * L, (size_t)(n * L));
+        if (n > 0) mc_host_copy(dst, reads + at * L, (size_t)(n * L));
         *first = at; at += n;
         return n;
     }, first_read_id, nreads);
