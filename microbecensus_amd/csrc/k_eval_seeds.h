@@ -72,7 +72,7 @@ __device__ __forceinline__ bool mc_ev_gate(const McHot &T, const uint8_t *q, int
 __device__ __forceinline__ int mc_ev_xdrop(const McHot &T, const uint8_t *q, int qlen, const uint8_t *d, int dlen, int sidx, int qp, int dp, int L, int score, int ident, McGapTask *gt)
 {
     // The reference's exit test is `(double)run < (double)best - xdrop` on two integers and a constant that is no integer (8.94 for BLOSUM62's
-    // ungapped lambda; mc_tables_init refuses one that is nearer than 1e-6 to an integer): best - run > xdrop <=> best - run >= floor(xdrop) + 1,
+    // ungapped lambda; mc_fill_tables refuses one that is nearer than 1e-6 to an integer): best - run > xdrop <=> best - run >= floor(xdrop) + 1,
     // exactly.  (MC_EV_F64_XDROP: the reference's own form - two conversions and an f64 subtraction in the dependent chain of every step.)
 #ifdef MC_EV_F64_XDROP
     const double xd = T.xdrop_ungapped;

@@ -677,7 +677,7 @@ inline void mc_fill_tables(McTables &T, const McHostIndex &X, int read_len, doub
     // (the kernels test `best - score > xdrop` on integers as `best - score >= floor(xdrop) + 1`: exact unless a threshold sits on an
     // integer, where the reference's double arithmetic would decide - 8.94 and 26.98 are far from one; a change of the constants that
     // moves them there must fail loudly, not drift)
-    for (double x : {T.xdrop_ungapped, T.xdrop_gapped}) if (fabs(x - nearbyint(x)) < 1e-6) { fprintf(stderr, "mc_tables_init: an X-drop threshold on an integer (%.9f): the integer exit tests of the kernels are not exact there\n", x); abort(); }
+    for (double x : {T.xdrop_ungapped, T.xdrop_gapped}) if (fabs(x - nearbyint(x)) < 1e-6) { fprintf(stderr, "mc_fill_tables: an X-drop threshold on an integer (%.9f): the integer exit tests of the kernels are not exact there\n", x); abort(); }
     T.loge_thr = loge_thr;
     T.freq_thr = X.freq_thr;
     for (int g = 0; g < 10; g++) T.letter_p[g] = X.letter_p[g];
