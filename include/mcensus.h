@@ -167,7 +167,7 @@ typedef struct mc_reader_stats {
 
 const char *mc_reader_last_error(void);
 /* Caps the worker threads of the host stages (record parsing, parallel inflate) of every reader opened afterwards: the reference's
- * args['threads'] (-t, microbe_census.py:270, forwarded there to rapsearch -z).  n <= 0: the machine's cores, up to 32 (default). */
+ * args['threads'] (-t, microbe_census.py:270, forwarded there to rapsearch -z).  n <= 0: the CPUs the process may use (cgroup quota), up to 32 (default). */
 void mc_set_host_threads(int32_t n);
 /* fastq: args['file_type'] == 'fastq'; quality_offset: 32 or 64 as auto_detect_quality_offset returns it (:175-187);
  * fasta_out (may be NULL): the temp FASTA process_seqfile writes, ">{id}\n{seq[:L]}\n" per accepted read. */

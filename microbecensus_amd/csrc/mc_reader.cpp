@@ -633,13 +633,41 @@ void evaluate(Rec &r, const Params &P)
     r.ncount = 0; r.nq = 0; r.qmin = 1 << 30; r.qsum = 0; r.h1 = r.h2 = 0;
     if (P.count_only) return;
     if (r.len < P.L) { r.flags |= R_SHORT; return; }
+    // the first L bases: how many are 'N'; the first min(L, qlen) qualities: their sum and their minimum (as ord(c) - offset) - 16 bytes at
+    // a time where SSE2 is there (byte sums by psadbw, the minimum by pminub: the offset comes off at the end), the plain loops elsewhere
     uint32_t nc = 0;
-    for (size_t i = 0; i < P.L; i++) nc += (r.seq[i] == 'N');
+    size_t i = 0;
+#if defined(__SSE2__)
+    {
+        const __m128i cN = _mm_set1_epi8('N'), zero = _mm_setzero_si128();
+        __m128i acc = zero;
+        for (; i + 16 <= P.L; i += 16)
+            acc = _mm_add_epi64(acc, _mm_sad_epu8(_mm_and_si128(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(r.seq + i)), cN), _mm_set1_epi8(1)), zero));
+        nc = (uint32_t)(_mm_cvtsi128_si64(acc) + _mm_cvtsi128_si64(_mm_unpackhi_epi64(acc, acc)));
+    }
+#endif
+    for (; i < P.L; i++) nc += (r.seq[i] == 'N');
     r.ncount = nc;
     if (P.fastq && r.qual) {
         const size_t nq = r.qlen < P.L ? r.qlen : P.L;
         int64_t sum = 0; int mn = 1 << 30;
-        for (size_t i = 0; i < nq; i++) { const int q = (int)r.qual[i] - P.qoff; sum += q; mn = q < mn ? q : mn; }
+        size_t k = 0;
+#if defined(__SSE2__)
+        if (nq >= 16) {
+            const __m128i zero = _mm_setzero_si128();
+            __m128i acc = zero, vmin = _mm_set1_epi8((char)0xFF);
+            for (; k + 16 <= nq; k += 16) {
+                const __m128i v = _mm_loadu_si128((const __m128i *)(r.qual + k));
+                acc = _mm_add_epi64(acc, _mm_sad_epu8(v, zero));
+                vmin = _mm_min_epu8(vmin, v);
+            }
+            sum = (int64_t)(_mm_cvtsi128_si64(acc) + _mm_cvtsi128_si64(_mm_unpackhi_epi64(acc, acc))) - (int64_t)k * P.qoff;
+            vmin = _mm_min_epu8(vmin, _mm_srli_si128(vmin, 8)); vmin = _mm_min_epu8(vmin, _mm_srli_si128(vmin, 4));
+            vmin = _mm_min_epu8(vmin, _mm_srli_si128(vmin, 2)); vmin = _mm_min_epu8(vmin, _mm_srli_si128(vmin, 1));
+            mn = (int)(_mm_cvtsi128_si32(vmin) & 0xFF) - P.qoff;
+        }
+#endif
+        for (; k < nq; k++) { const int q = (int)r.qual[k] - P.qoff; sum += q; mn = q < mn ? q : mn; }
         r.nq = (uint32_t)nq; r.qsum = sum; r.qmin = mn;
     }
     if (P.dups) { r.h1 = h64(r.seq, r.len); if (!h64_rc(r.seq, r.len, &r.h2)) r.flags |= R_RCBAD; r.shard = (uint8_t)((r.h1 < r.h2 ? r.h1 : r.h2) >> 58); }
@@ -867,7 +895,7 @@ struct SeqSet {
 };
 
 // Worker threads of the reader: MC_READER_THREADS in the environment, else the caller's cap (mc_set_host_threads: run_pipeline
-// passes args['threads'], the reference's -t), else the machine's cores up to 32.
+// passes args['threads'], the reference's -t), else the CPUs the process may use (cgroup quota), up to 32.
 std::atomic<int> g_host_threads{0};
 // CPUs this process may actually use: the machine's, or the container's CPU quota when that is smaller (cgroup cpu.max / cfs quota:
 // a box that shows 256 CPUs may be allowed 16 of them - threads beyond the quota only get throttled)
@@ -895,8 +923,11 @@ int reader_threads()
     if (const char *e = getenv("MC_READER_THREADS")) { const int v = atoi(e); if (v >= 1) return v > 256 ? 256 : v; }
     const int cap = g_host_threads.load();
     if (cap >= 1) return cap > 256 ? 256 : cap;
-    const unsigned hc = std::thread::hardware_concurrency();
-    return (int)std::min<unsigned>(hc ? hc : 1, 32);
+    // ... but no more than the CPUs the process may USE (a box that shows 256 CPUs and grants 16 - cgroup quota): the quota throttles every
+    // thread of the process once it is spent, the one that drives the GPU too - with 32 parser threads on 16 granted CPUs the gapped stage of
+    // a streamed range took 63 - 108 ms instead of 47.5 (its launches wait for the host between them) and file -> AGS of a plain FASTQ ran at
+    // 48 - 54 M reads/s instead of 55 - 62 with 16 (round 6, tools/e2e_probe.py)
+    return std::max(1, std::min(effective_cores(), 32));
 }
 // inflate workers of a .gz input: they keep their cores busy all the time (the parser's threads mostly wait), so no more of them
 // than three quarters of the CPUs the process may use

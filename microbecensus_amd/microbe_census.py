@@ -466,7 +466,7 @@ def _sample_search_classify(args, paths):
 
 def _cap_host_threads(threads):
     """args['threads'] is the reference's rapsearch -z (:375); here the search runs on the GPU and the host threads are the
-    native sampler's workers: an explicit value caps them, without one the machine's cores (up to 32) are used."""
+    native sampler's workers: an explicit value caps them, without one the CPUs the process may use (its cgroup quota; up to 32)."""
     try:
         from . import _native
         _native.load_library().mc_set_host_threads(int(threads) if threads and int(threads) > 0 else 0)
