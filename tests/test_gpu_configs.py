@@ -95,13 +95,14 @@ def test_config4_shape_two_ranks_gloo(tmp_path):
 
 def test_config4_shape_eight_ranks_gloo(tmp_path):
     """World size 8 - what the driver's multi-GPU node runs - before any hardware has it: eight ranks on this box's
-    one GPU (gloo), the reference's paired golden dealt in batches of 1,500 reads: the reference's AGS bit for bit, 14 deals, and every
-    rank searched at least one batch (credits: two per rank, the dealer goes round the ranks)."""
+    one GPU (gloo), the reference's paired golden dealt in batches of 1,500 reads: the reference's AGS (the 'cov' sums are finished from
+    exact integer sums in another order than the reference's running sum: 1e-9 relative, as the two-rank test), 14 deals, and every rank
+    searched at least one batch (credits: two per rank, the dealer goes round the ranks)."""
     g = json.load(open(os.path.join(GOLD, "c4_paired.json")))
     res = _two_ranks(tmp_path, "gloo", 29551, world=8, batch="1500")
     assert res["world"] == 8 and res["sampled"] == g["sampled_reads"] and res["L"] == 150
     assert res["deals"] == 14 and sum(res["batches_per_rank"]) == 14 and min(res["batches_per_rank"]) >= 1, res
-    assert res["est"] == g["est_ags"]
+    assert abs(res["est"] - g["est_ags"]) <= 1e-9 * g["est_ags"]
 
 
 def test_bench_eight_ranks_on_one_gpu_equals_one_engine(tmp_path):

@@ -23,7 +23,7 @@ for rep in range(3):
     w.append(time.time() - t)
 print("%%.3f" %% min(w[1:]))
 """ % (REPO, path, n)
-for gz, rd in ((0, 0), (12, 8), (0, 0), (12, 8), (12, 32), (0, 0), (12, 32)):
+for gz, rd in ((0, 0), (12, 8), (12, 4), (12, 3), (13, 3), (14, 2), (11, 5), (10, 6), (12, 6), (0, 0)):
     env = dict(os.environ)
     if gz: env["MC_READER_GZ_THREADS"] = str(gz); env["MC_READER_THREADS"] = str(rd)
     out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode().strip()
