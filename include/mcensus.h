@@ -180,6 +180,21 @@ mc_reader *mc_reader_open(const char *const *paths, int32_t npaths, int32_t read
  * head-take of process_seqfile (:337-356) from the per-slice counts.  No duplicate filter (it needs the whole stream in one place). */
 mc_reader *mc_reader_open_range(const char *path, int64_t byte_lo, int64_t byte_hi, int32_t read_len, int64_t nreads, int32_t fastq,
                                 int32_t quality_offset, double min_quality, double mean_quality, double max_unknown);
+/* -d (filter_dups) with a sampler on every rank.  The duplicate rule of process_seqfile (:345 the test comes before the quality filter,
+ * :354 only accepted reads enter the set) is class-local: a record's fate depends on nothing but the earlier records with the same
+ * sequence or its reverse complement.  So parsing, quality filter and hashing run on every rank's own byte window
+ * (mc_reader_open_range + mc_reader_describe: one 32-byte descriptor per record), the ranks exchange the descriptors, every rank gives
+ * every record of the round its verdict with mc_dupset_walk (same input, same verdicts; sequences are compared on the file's own
+ * mapping) and copies the accepted reads of its own window with mc_reader_take (microbecensus_amd/distributed.py).
+ * flags / verdict bits: 1 too short, 2 has qualities, 4 a base outside ACGTN, 8 accepted, 16 fails the quality filter, 32 duplicate,
+ * 64 the reference raises at this record. */
+typedef struct mc_rec_desc { uint64_t h1, h2; uint64_t seq_off; uint32_t len; uint8_t flags, pad[3]; } mc_rec_desc;
+typedef struct mc_dupset mc_dupset;
+int64_t mc_reader_describe(mc_reader *r, const mc_rec_desc **out);   /* records of the window (array owned by the reader), or < 0; mc_reader_stats.ragged_end: not usable, fall back */
+mc_dupset *mc_dupset_open(void);
+void mc_dupset_close(mc_dupset *s);
+int mc_dupset_walk(mc_dupset *s, const char *path, const mc_rec_desc *d, int64_t n, uint8_t *verdict);   /* n descriptors of `path` in file order -> n verdicts; the set remembers across calls and files */
+int64_t mc_reader_take(mc_reader *r, const uint8_t *verdict, int64_t n, int64_t max_take, uint8_t *dst);   /* accepted reads of the described window (first read_len bases), at most max_take */
 /* Runs the sampler: returns args['sampled_reads'] (0 = "No reads remaining after filtering"). */
 int64_t mc_reader_run(mc_reader *r);
 /* sampled x read_len bytes, row i = trimmed read i: exactly what mc_search() / mc_upload() take. Owned by the reader. */

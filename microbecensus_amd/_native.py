@@ -39,6 +39,7 @@ ROW_DTYPE = np.dtype([("query", "<i4"), ("subject", "<i4"), ("ident", "<f8"), ("
                       ("gapopen", "<i4"), ("qstart", "<i4"), ("qend", "<i4"), ("sstart", "<i4"), ("send", "<i4"),
                       ("loge", "<f8"), ("bits", "<f8"), ("score", "<i4"), ("nmatch", "<i4")], align=True)
 BEST_DTYPE = np.dtype([("read", "<i4"), ("family", "<i4"), ("aln", "<i4"), ("target_len", "<i4"), ("bits", "<f8")], align=True)
+REC_DESC_DTYPE = np.dtype([("h1", "<u8"), ("h2", "<u8"), ("seq_off", "<u8"), ("len", "<u4"), ("flags", "u1"), ("pad", "u1", (3,))])   # mc_rec_desc
 
 _lib = None
 
@@ -120,6 +121,13 @@ def load_library():
     lib.mc_reader_reads.restype = C.POINTER(C.c_uint8)
     lib.mc_reader_reads.argtypes = [C.c_void_p]
     lib.mc_reader_get_stats.argtypes = [C.c_void_p, C.POINTER(McReaderStats)]
+    lib.mc_reader_describe.restype = C.c_int64
+    lib.mc_reader_describe.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.mc_dupset_open.restype = C.c_void_p
+    lib.mc_dupset_close.argtypes = [C.c_void_p]
+    lib.mc_dupset_walk.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mc_reader_take.restype = C.c_int64
+    lib.mc_reader_take.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     lib.mc_reader_times.restype = C.c_int32
     lib.mc_reader_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int32]
     lib.mc_reader_close.argtypes = [C.c_void_p]
@@ -150,8 +158,37 @@ def load_library():
 
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_set_index_cache", "mc_index_cache_check", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
                     "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_debug_stage", "mc_range_begin", "mc_range_end", "mc_ranges_in_flight", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8", "mc_write_m8_named",
-                    "mc_reader_last_error", "mc_set_host_threads", "mc_reader_open", "mc_reader_open_range", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_times", "mc_reader_close", "mc_reader_trim", "mc_count_bases", "mc_quality_offset",
+                    "mc_reader_last_error", "mc_set_host_threads", "mc_reader_open", "mc_reader_open_range", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_times", "mc_reader_describe", "mc_dupset_open", "mc_dupset_close", "mc_dupset_walk", "mc_reader_take", "mc_reader_close", "mc_reader_trim", "mc_count_bases", "mc_quality_offset",
                     "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_reader_nreads", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows", "mc_set_best_hits_only", "mc_grid_classify"]
+
+
+class DupSet:
+    """The sampler's set of accepted sequences for -d, walked over record descriptors (mc_dupset_*): verdicts in file order."""
+
+    def __init__(self):
+        self.lib = load_library()
+        self.s = self.lib.mc_dupset_open()
+        if not self.s:
+            raise RuntimeError(self.lib.mc_reader_last_error().decode())
+
+    def walk(self, path, descs):
+        import numpy as np
+        d = np.ascontiguousarray(descs)
+        v = np.empty(len(d), np.uint8)
+        if self.lib.mc_dupset_walk(self.s, path.encode(), d.ctypes.data, len(d), v.ctypes.data) != 0:
+            raise RuntimeError(self.lib.mc_reader_last_error().decode())
+        return v
+
+    def close(self):
+        if getattr(self, "s", None):
+            self.lib.mc_dupset_close(self.s)
+            self.s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ReferenceError_(Exception):
@@ -211,6 +248,25 @@ class Reader:
         st = McReaderStats()
         self.lib.mc_reader_get_stats(self.r, C.byref(st))
         return {k: getattr(st, k) for k, _ in McReaderStats._fields_}
+
+    def describe(self):
+        """The records of the window of a reader opened with on_range, one 32-byte descriptor each (mc_reader_describe): a numpy
+        structured array (a copy: it travels to the other ranks)."""
+        import numpy as np
+        p = C.c_void_p()
+        n = self.check(self.lib.mc_reader_describe(self.r, C.byref(p)))
+        if n == 0:
+            return np.zeros(0, REC_DESC_DTYPE)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n * REC_DESC_DTYPE.itemsize,)).view(REC_DESC_DTYPE).copy()
+
+    def take(self, verdicts, max_take):
+        """(k, read_len) uint8: the accepted reads of the described window (verdict bit 8), at most max_take (mc_reader_take)."""
+        import numpy as np
+        v = np.ascontiguousarray(verdicts, dtype=np.uint8)
+        k = int(min(max_take, int(np.count_nonzero(v & 8))))
+        out = np.empty((k, self.read_len), np.uint8)
+        got = self.check(self.lib.mc_reader_take(self.r, v.ctypes.data, len(v), k, out.ctypes.data))
+        return out[:got]
 
     def times(self):
         """Seconds of the last run by phase (mc_reader_times)."""

@@ -1052,6 +1052,7 @@ struct mc_reader {
     uint8_t *reads = nullptr; size_t reads_cap = 0, reads_n = 0;   // anonymous mapping grown with mremap (no copies, no zero fill up front)
     mc_reader_stats st{};
     WalkTimes wt; double wall = 0;                                 // mc_reader_times
+    std::vector<mc_rec_desc> descs; KeptMaps desc_maps;            // mc_reader_describe: the window's records, and the file's mapping they point into (kept until the reader closes)
     // streaming (mc_reader_start / fetch / join): the sampler runs on a thread of its own and publishes how far it has got
     std::thread run_th;
     std::mutex pmu; std::condition_variable pcv;
@@ -1060,6 +1061,7 @@ struct mc_reader {
     ~mc_reader()
     {
         if (run_th.joinable()) run_th.join();
+        for (auto &m : desc_maps) munmap((void *)m.first, m.second);
         if (reads) {
             // The buffer of a closed reader is kept for the next one (one buffer, up to the limit mc_reader_trim sets - 4 GB unless told
             // otherwise; a long-lived service is not left holding the 8 GB of one large library): returning gigabytes of pages takes a while
@@ -1331,6 +1333,120 @@ static int64_t reader_run(mc_reader *r)
 
 extern "C" const uint8_t *mc_reader_reads(mc_reader *r) { return r ? r->reads : nullptr; }
 extern "C" int mc_reader_get_stats(mc_reader *r, mc_reader_stats *out) { if (!r || !out) return -1; *out = r->st; return 0; }
+
+// ---- -d across the ranks of a multi-GPU run (microbecensus_amd/distributed.py, stream_batches_sharded_dups) ---------------------------
+// The duplicate rule (process_seqfile :345, :354) is class-local (mc_reader_run), so the expensive part of the sampler - parsing, the
+// quality filter, both hashes - can run on every rank's own byte window; what has to be seen in file order is only a 32-byte descriptor
+// per record.  mc_reader_describe() makes the descriptors of a window; the ranks exchange them; mc_dupset_walk() gives every record of
+// the round its verdict (every rank runs it on the same descriptors: same verdicts everywhere, sequences compared on the file's own
+// mapping); mc_reader_take() copies the accepted reads of the rank's own window.
+extern "C" int64_t mc_reader_describe(mc_reader *r, const mc_rec_desc **out)
+{
+    if (!r || !out) { r_err = "bad argument"; return -1; }
+    if (r->range_lo < 0 || r->paths.size() != 1) { r_err = "mc_reader_describe: the reader must be opened with mc_reader_open_range"; return -1; }
+    try {
+        r->descs.clear(); memset(&r->st, 0, sizeof r->st);
+        for (auto &m : r->desc_maps) munmap((void *)m.first, m.second);
+        r->desc_maps.clear();
+        Pool pool(reader_threads());
+        Params P; P.L = (size_t)r->L; P.fastq = r->fastq; P.qoff = r->qoff; P.dups = 1;
+        P.max_unknown = r->max_unknown; P.mean_q = r->mean_q; P.min_q = r->min_q;
+        bool joined = false;
+        t_range_lo = r->range_lo; t_range_hi = r->range_hi;
+        const int rc = walk_file(r->paths[0], P, pool, [&](std::vector<Piece *> &order) -> bool {
+            for (Piece *pc : order) {
+                if (pc->ragged) r->st.ragged_end = 1;
+                for (const Rec &rec : pc->recs) {
+                    r->st.records++; r->st.bases += (int64_t)rec.len;
+                    mc_rec_desc d; d.h1 = rec.h1; d.h2 = rec.h2; d.seq_off = (uint64_t)(uintptr_t)rec.seq; d.len = rec.len; d.flags = rec.flags & (R_SHORT | R_QUAL | R_RCBAD);
+                    if (!(rec.flags & R_SHORT)) {
+                        if (!(rec.flags & R_STABLE)) joined = true;              // (a sequence over several lines lies in the piece's arena, not in the file)
+                        Rec t = rec;
+                        d.flags |= !decide(t, P) ? R_ERR : (t.flags & (R_PASS | R_LOWQ));
+                    }
+                    r->descs.push_back(d);
+                }
+            }
+            return true;
+        }, &r->desc_maps);
+        t_range_lo = t_range_hi = -1;
+        if (rc < 0) return rc;
+        const uint8_t *base = r->desc_maps.empty() ? nullptr : r->desc_maps[0].first;
+        for (mc_rec_desc &d : r->descs) d.seq_off = (d.flags & R_SHORT) || !base ? 0 : (uint64_t)((const uint8_t *)(uintptr_t)d.seq_off - base);
+        if (joined) r->st.ragged_end = 1;                                        // (the caller falls back to the sampler on one rank, as for a window that does not end on a record boundary)
+        r->st.exhausted = 1;
+        *out = r->descs.data();
+        return (int64_t)r->descs.size();
+    } catch (const std::bad_alloc &) { r_err = "out of memory in the read sampler"; return -1; }
+}
+
+struct mc_dupset {
+    std::unique_ptr<SeqSet[]> sets{new SeqSet[NSHARD]};
+    std::vector<std::pair<std::string, std::pair<const uint8_t *, size_t>>> maps;   // the files the sets point into: mapped until the set closes
+    ~mc_dupset() { for (auto &m : maps) if (m.second.first) munmap((void *)m.second.first, m.second.second); }
+};
+extern "C" mc_dupset *mc_dupset_open(void) { try { return new mc_dupset(); } catch (const std::bad_alloc &) { r_err = "out of memory"; return nullptr; } }
+extern "C" void mc_dupset_close(mc_dupset *s) { delete s; }
+// verdict[i]: the descriptor's R_SHORT | R_QUAL | R_RCBAD bits and ONE of R_SHORT, R_DUP, R_PASS, R_LOWQ, R_ERR - what the reference's sampler
+// would decide at record i given every record walked before (this call's and the earlier calls' on this set), in the order of the array
+extern "C" int mc_dupset_walk(mc_dupset *s, const char *path, const mc_rec_desc *d, int64_t n, uint8_t *verdict)
+{
+    if (!s || !path || (n > 0 && (!d || !verdict)) || n < 0) { r_err = "bad argument"; return -1; }
+    try {
+        const uint8_t *base = nullptr; size_t size = 0;
+        for (auto &m : s->maps) if (m.first == path) { base = m.second.first; size = m.second.second; }
+        if (!base) {
+            const int fd = ::open(path, O_RDONLY);
+            struct stat sb;
+            if (fd < 0 || fstat(fd, &sb) != 0) { if (fd >= 0) ::close(fd); r_err = std::string("cannot open ") + path; return -1; }
+            size = (size_t)sb.st_size;
+            void *m = size ? mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+            ::close(fd);
+            if (size && m == MAP_FAILED) { r_err = std::string("cannot map ") + path; return -1; }
+            base = (const uint8_t *)m;
+            s->maps.emplace_back(path, std::make_pair(base, size));
+        }
+        std::vector<uint32_t> off(NSHARD + 1, 0), idx;
+        auto shard_of = [&](const mc_rec_desc &x) { return (unsigned)((x.h1 < x.h2 ? x.h1 : x.h2) >> 58); };
+        for (int64_t i = 0; i < n; i++) {
+            const uint8_t f = d[i].flags;
+            verdict[i] = f & (R_SHORT | R_QUAL | R_RCBAD);
+            if (f & R_SHORT) continue;
+            if (f & R_RCBAD) { verdict[i] |= R_ERR; continue; }
+            if (d[i].seq_off + d[i].len > size) { r_err = "mc_dupset_walk: a descriptor points outside its file"; return -1; }
+            off[shard_of(d[i]) + 1]++;
+        }
+        for (int k = 0; k < NSHARD; k++) off[k + 1] += off[k];
+        idx.resize(off[NSHARD]);
+        { std::vector<uint32_t> at(off.begin(), off.end() - 1); for (int64_t i = 0; i < n; i++) if (!(d[i].flags & (R_SHORT | R_RCBAD))) idx[at[shard_of(d[i])]++] = (uint32_t)i; }
+        std::atomic<bool> oom{false};
+        Pool pool(reader_threads());
+        pool.run(NSHARD, [&](int sh) {
+            SeqSet &set = s->sets[sh];
+            const uint32_t a = off[sh], b = off[sh + 1], AHEAD = 8;
+            for (uint32_t k = a; k < b; k++) {
+                if (k + AHEAD < b) { set.prefetch(d[idx[k + AHEAD]].h1); set.prefetch(d[idx[k + AHEAD]].h2); }
+                const mc_rec_desc &x = d[idx[k]];
+                const uint8_t *seq = base + x.seq_off;
+                if (set.contains(x.h1, seq, x.len, false) || set.contains(x.h2, seq, x.len, true)) { verdict[idx[k]] |= R_DUP; continue; }
+                verdict[idx[k]] |= x.flags & (R_PASS | R_LOWQ | R_ERR);
+                if ((x.flags & R_PASS) && !set.insert(x.h1, seq, x.len, true)) { oom.store(true); return; }
+            }
+        });
+        if (oom.load()) { r_err = "out of memory for the set of accepted sequences"; return -1; }
+        return 0;
+    } catch (const std::bad_alloc &) { r_err = "out of memory in the read sampler"; return -1; }
+}
+// the first read_len bases of the records of the described window whose verdict is R_PASS, in file order, at most max_take of them -> dst
+extern "C" int64_t mc_reader_take(mc_reader *r, const uint8_t *verdict, int64_t n, int64_t max_take, uint8_t *dst)
+{
+    if (!r || n != (int64_t)r->descs.size() || (n > 0 && !verdict) || max_take < 0) { r_err = "mc_reader_take: the verdicts of the described window, one per record"; return -1; }
+    const uint8_t *base = r->desc_maps.empty() ? nullptr : r->desc_maps[0].first;
+    const size_t L = (size_t)r->L;
+    int64_t k = 0;
+    for (int64_t i = 0; i < n && k < max_take; i++) if (verdict[i] & R_PASS) { if (dst) memcpy(dst + (size_t)k * L, base + r->descs[(size_t)i].seq_off, L); k++; }
+    return k;
+}
 
 extern "C" int64_t mc_count_bases(const char *const *paths, int32_t npaths)
 {

@@ -549,6 +549,150 @@ def stream_batches_sharded(args, on_batch, device=None):
     return n_total, stats, bases, status
 
 
+def sharded_dups_usable(args):
+    """-d with a sampler on every rank (stream_batches_sharded_dups): plain regular files, unless MC_DIST_SHARDED=0."""
+    import os
+    if os.environ.get("MC_DIST_SHARDED") == "0" or not args.get("filter_dups"):
+        return False
+    for p in args["seqfiles"]:
+        if p.endswith((".gz", ".bz2")) or not os.path.isfile(p):
+            return False
+    return True
+
+
+def stream_batches_sharded_dups(args, on_batch, device=None):
+    """process_seqfile WITH -d (reference microbe_census.py:328-367; :345 the duplicate test comes before the quality filter, :354 only
+    accepted reads enter the set) with a sampler on every rank.  The rule is class-local - a record's fate depends on nothing but the
+    earlier records with its sequence or its reverse complement (csrc/mc_reader.cpp) - so what has to be seen in file order is 32 bytes
+    per record, not the record: the files are walked in rounds of `world` slices as in stream_batches_sharded; rank r parses slice r,
+    applies the quality filter and hashes every sequence and its reverse complement (mc_reader_describe); the ranks all_gather the
+    descriptors of the round; EVERY rank walks them in file order through its own copy of the set (mc_dupset_walk: same input, same
+    verdicts - sequences with equal hashes are compared on the file itself, which every rank maps) and so knows every record's
+    verdict, the round's counters, where the head-take ends and the global index of its own first accepted read; it copies the accepted
+    reads of its own slice (mc_reader_take) and searches them.  The next round is parsed beside the search of this one.
+    Returns (n_total, stats, bases, status) as stream_batches_sharded; status 3 = the reference raises at a record the sampler reached
+    (stats["error"] names the exception: every rank raises it)."""
+    import os
+    import threading
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from . import _native
+    rank, world = dist.get_rank(), dist.get_world_size()
+    nccl = dist.get_backend() == "nccl"
+    tdev = torch.device("cuda", device) if nccl else torch.device("cpu")
+    L, fastq = args["read_length"], args["file_type"] == "fastq"
+    qoff = args.get("quality_offset") or 0
+    nreads = args["nreads"] if args["nreads"] is not None else (1 << 62)
+    try:
+        S = int(os.environ.get("MC_DIST_SLICE", "0")) or SLICE_BYTES
+    except ValueError:
+        S = SLICE_BYTES
+    rounds = []
+    for p in args["seqfiles"]:
+        size = os.path.getsize(p)
+        for base in range(0, max(size, 1), S * world):
+            rounds.append((p, base, size))
+    DT = _native.REC_DESC_DTYPE
+
+    def sample(j):
+        p, base, size = rounds[j]
+        lo = min(size, base + rank * S)
+        hi = min(size, lo + S)
+        box = {}
+
+        def work():
+            try:
+                rd = _native.Reader.on_range(p, lo, hi, L, 1 << 62, fastq, qoff, args["min_quality"], args["mean_quality"], args["max_unknown"])
+                box["rd"] = rd
+                box["d"] = rd.describe() if hi > lo else np.zeros(0, DT)
+                box["ragged"] = bool(rd.stats()["ragged_end"]) if hi > lo else False
+            except BaseException as e:                             # noqa: BLE001
+                box["err"] = e
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        return th, box, p
+
+    total, status, cut = 0, 0, False
+    stats = {"too_short": 0, "low_qual": 0, "dups": 0, "records": 0, "bases": 0}
+    err = None
+    dupset = _native.DupSet()
+    cur = sample(0) if rounds else None
+    try:
+        for j in range(len(rounds)):
+            th, box, path = cur
+            th.join()
+            cur = sample(j + 1) if j + 1 < len(rounds) else None
+            bad = 2 if "err" in box else 1 if box.get("ragged") else 0
+            d = box.get("d") if not bad else None
+            n_mine = 0 if d is None else len(d)
+            mine = torch.tensor([n_mine, bad], dtype=torch.int64, device=tdev)
+            allc = [torch.zeros(2, dtype=torch.int64, device=tdev) for _ in range(world)]
+            dist.all_gather(allc, mine)
+            counts = [int(t[0].item()) for t in allc]
+            worst = max(int(t[1].item()) for t in allc)
+            if worst:
+                status = worst
+                err = box.get("err")
+            else:
+                # the round's descriptors in file order: rank 0's slice, rank 1's, ...
+                width = max(counts) * DT.itemsize
+                buf = np.zeros(max(width, 1), np.uint8)
+                if n_mine:
+                    buf[: n_mine * DT.itemsize] = d.view(np.uint8)
+                tm = torch.from_numpy(buf).to(tdev)
+                parts = [torch.empty_like(tm) for _ in range(world)]
+                dist.all_gather(parts, tm)
+                alld = np.concatenate([parts[r][: counts[r] * DT.itemsize].cpu().numpy().view(DT) for r in range(world)]) if sum(counts) else np.zeros(0, DT)
+                v = dupset.walk(path, alld)
+                acc = (v & 8) != 0
+                cum = np.cumsum(acc)
+                want = nreads - total                                # accepted reads still wanted (> 0: the rounds stop when it reaches 0)
+                end = len(v)                                         # records of the round the reference's sampler looks at
+                if len(v) and cum[-1] >= want:
+                    end = int(np.searchsorted(cum, want)) + 1        # ... up to and including the read that fills the sample
+                    cut = True
+                bad_at = np.nonzero((v[:end] & 64) != 0)[0]
+                if len(bad_at):                                      # the reference raises here (every rank sees the same record)
+                    f = int(v[bad_at[0]])
+                    stats["error"] = ("KeyError: base outside ACGTN in reverse_complement" if f & 4 else
+                                      "TypeError: record without qualities in a FASTQ run" if not f & 2 else "ValueError: empty quality string")
+                    status = 3
+                else:
+                    ve = v[:end]
+                    stats["too_short"] += int(np.count_nonzero(ve & 1)); stats["dups"] += int(np.count_nonzero(ve & 32))
+                    stats["low_qual"] += int(np.count_nonzero((ve & 16) != 0)); stats["records"] += end; stats["bases"] += int(alld["len"][:end].sum())
+                    lo_i = sum(counts[:rank]); hi_i = lo_i + n_mine
+                    before = int(cum[lo_i - 1]) if lo_i > 0 else 0   # accepted reads of the round in front of this rank's slice
+                    keep = int(np.count_nonzero(acc[lo_i:min(hi_i, end)]))
+                    if keep > 0:
+                        try:
+                            on_batch(box["rd"].take(v[lo_i:hi_i], keep), total + before)
+                        except BaseException as e:                   # noqa: BLE001 - agreed on below
+                            err = e
+                    total += int(cum[end - 1]) if end > 0 else 0
+            if "rd" in box:
+                box["rd"].close()
+            flag = torch.tensor([1 if err is not None else 0], dtype=torch.int64, device=tdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()) and status == 0:
+                status = 2
+            if status or cut:
+                break
+    finally:
+        if cur is not None:                                          # a round parsed ahead and not needed
+            cur[0].join()
+            if "rd" in cur[1]:
+                cur[1]["rd"].close()
+        dupset.close()
+    bases = stats["bases"] if (status == 0 and not cut) else -1
+    if status == 2:
+        msgs = [None] * world
+        dist.all_gather_object(msgs, "" if err is None else "rank %d: %s: %s" % (rank, type(err).__name__, err))
+        stats["error"] = next((m for m in msgs if m), "a rank failed")
+    return min(total, nreads), stats, bases, status
+
+
 def run_pipeline_distributed(args, device=None):
     """run_pipeline() over all ranks of the initialised torch.distributed group (one process per GPU; backend "nccl" = RCCL
     on MI355X, or gloo), STREAMED.  Plain files without -d: a sampler on EVERY rank (stream_batches_sharded: byte windows of
@@ -608,11 +752,13 @@ def run_pipeline_distributed(args, device=None):
         rd = None
         eng.lib.mc_set_keep_rows(eng.h, 0)
         sharded = None
-        if world > 1 and sharded_sampling_usable(args):                       # a sampler on every rank (plain files, no -d)
+        if world > 1 and (sharded_sampling_usable(args) or sharded_dups_usable(args)):   # a sampler on every rank (plain files; -d: the verdicts from exchanged descriptors)
             try:
-                sharded = stream_batches_sharded(args, on_batch, device=device)
+                sharded = (stream_batches_sharded_dups if args.get("filter_dups") else stream_batches_sharded)(args, on_batch, device=device)
             finally:
                 eng.lib.mc_set_keep_rows(eng.h, 1)
+            if sharded[3] == 3:                                                # the reference raises at a record the sampler reached: run_pipeline prints it and returns None
+                raise Exception(sharded[1]["error"])
             if sharded[3] == 2:                                                # a rank failed (sampler or search): all ranks raise the same error
                 raise RuntimeError("sharded sampling failed - " + sharded[1].get("error", ""))
             if sharded[3] != 0:                                                # a window off a record boundary: the sampler on rank 0 decides

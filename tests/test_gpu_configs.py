@@ -147,6 +147,37 @@ def test_bench_eight_ranks_on_one_gpu_equals_one_engine(tmp_path):
     assert r["reduced_vector_crc32"] == zlib.crc32(np.concatenate([hits, aln, bylen.ravel()]).tobytes())
 
 
+def test_config5_shape_two_ranks_sharded_duplicate_filter_gloo(tmp_path):
+    """BASELINE configs[4]'s shape (300 bp FASTQ, -q 20 -d) through run_pipeline_distributed on a PLAIN file with two ranks (both on this
+    box's GPU, gloo): with -d, too, every rank samples its own slices - descriptors exchanged, the duplicate verdicts walked on every rank
+    (stream_batches_sharded_dups; slices of 400 KB here) - and nothing is dealt by rank 0: the reference's sample size and AGS for the
+    golden made by the reference itself (tests/golden/c5_300bp_q20_dups.json)."""
+    g = json.load(open(os.path.join(GOLD, "c5_300bp_q20_dups.json")))
+    fq = tmp_path / "c5_300bp.fq"
+    fq.write_bytes(gzip.open(os.path.join(INPUTS, "c5_300bp.fq.gz"), "rb").read())
+    worker = tmp_path / "w.py"
+    worker.write_text(r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from microbecensus_amd import distributed as D
+dist.init_process_group(backend="gloo")
+est, args = D.run_pipeline_distributed({"seqfiles": [sys.argv[3]], "min_quality": 20, "filter_dups": True}, device=0)
+if dist.get_rank() == 0:
+    json.dump({"est": est, "sampled": args["sampled_reads"], "L": args["read_length"], "dealt": D.run_pipeline_distributed.last_trace is not None,
+               "stats": D.run_pipeline_distributed.last_stats}, open(sys.argv[2], "w"))
+dist.barrier()
+dist.destroy_process_group()
+''')
+    out = tmp_path / "o.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MC_DIST_SLICE="400000")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29553", str(worker), REPO, str(out), str(fq)], env=env, timeout=900)
+    res = json.load(open(out))
+    assert res["sampled"] == g["sampled_reads"] and res["L"] == 300 and res["dealt"] is False and res["stats"]["dups"] > 0
+    assert abs(res["est"] - g["est_ags"]) <= 1e-9 * g["est_ags"]
+
+
 def test_sharded_sampling_two_ranks_gloo(tmp_path):
     """run_pipeline_distributed on a PLAIN file with two ranks (both on this box's GPU, gloo): every rank samples its own slices
     (mc_reader_open_range; slices of 1 MB here), the head-take and the read indices come from the exchanged counts, one all_reduce of
