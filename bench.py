@@ -408,7 +408,7 @@ def e2e_rate(device, gen, n, L, gz):
                             "per-user index cache, ~/.cache/microbecensus_amd)", "reads": 2_000_000, "wall_s_runs": cw, "wall_s": min(cw), "est_ags": ags}
     dt = walls[-1]
     out = {"reads": n, "file": "FASTQ" + (".gz" if gz else ""), "file_bytes": size, "wall_s": round(dt, 3), "reads_per_s": round(n / dt, 1),
-           "first_call_wall_s": round(walls[0], 3), "sampled_reads": int(res[1]["sampled_reads"]), "est_ags": res[0]}
+           "first_call_wall_s": round(walls[0], 3), "sampled_reads": int(res[1]["sampled_reads"]), "est_ags": res[0], "sampler_seconds": res[1].get("_sampler_seconds")}
     if cold:
         out["cold_cli"] = cold
     return out
