@@ -70,6 +70,24 @@ def aggregate_from_accumulators(hits, aln_sum, aln_by_len, families, optpars):
     return agg
 
 
+def _usable_cores():
+    """CPUs this process may use: the cgroup quota, else the affinity mask, else os.cpu_count()."""
+    import os
+    n = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, int(round(float(q) / float(per))))
+    except Exception:                                               # noqa: BLE001
+        pass
+    try:
+        a = len(os.sched_getaffinity(0))
+        n = a if n is None else min(n, a)
+    except Exception:                                               # noqa: BLE001
+        pass
+    return n or os.cpu_count() or 1
+
+
 STREAM_BATCH = 2000000      # accepted reads per dealt batch (MC_DIST_BATCH in the environment: tests deal small batches)
 
 
@@ -719,7 +737,12 @@ def run_pipeline_distributed(args, device=None):
     paths = mc.get_relative_paths(args)                                        # (mkstemp: every rank has its own temp file)
     mc.check_paths(paths)
     mc.check_input(args)
-    mc._cap_host_threads(args.get("threads"))
+    threads = args.get("threads")
+    if not threads and world > 1:
+        # the ranks of one node share its CPUs (and, in a container, ONE cgroup quota: threads beyond it get every thread of every rank
+        # throttled, the ones that drive the GPUs too - DESIGN.md 3): without an explicit -t each rank's sampler takes its share
+        threads = max(2, _usable_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+    mc._cap_host_threads(threads)
     mc.impute_missing_args(args)
     mc.check_arguments(args)
     args["verbose"] = bool(args.get("verbose")) and rank == 0
