@@ -59,6 +59,7 @@
 
 #include "../../include/mcensus.h"
 #include "mc_pgzip.h"
+#include "mc_pbzip2.h"
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
@@ -167,6 +168,14 @@ struct Bz2File {
     bool live = false, eof_in = false, fresh = true;               // fresh: nothing of the current stream has been decoded yet
     std::vector<char> in;
     bool open(const char *path) { fd = ::open(path, O_RDONLY); in.resize(1 << 20); return fd >= 0; }
+    // ... at a byte offset of the file, behind streams somebody else has decoded (got_any: there were some): mc_pbzip2.h hands over here
+    bool open_at(const char *path, size_t offset, bool got_any)
+    {
+        if (!open(path)) return false;
+        if (lseek(fd, (off_t)offset, SEEK_SET) < 0) return false;
+        got_any_stream = got_any;
+        return true;
+    }
     void close() { if (live) { g_bz2.end(&z); live = false; } if (fd >= 0) { ::close(fd); fd = -1; } }
     int read(uint8_t *dst, int n, bool *bad, std::string *msg)
     {
@@ -223,6 +232,8 @@ struct Stream {
     gzFile gz = nullptr; Bz2File *bz = nullptr;
     mcgz::ParallelGz *pgz = nullptr; const uint8_t *gzmap = nullptr; size_t gzmap_n = 0;   // a regular .gz file: mapped and inflated in parallel (mc_pgzip.h)
     mcgz::SerialGz *sgz = nullptr;                                                          // ... or by one stream (one thread allowed; the quality-offset peek)
+    mcbz::ParallelBz2 *pbz = nullptr; const uint8_t *bzmap = nullptr; size_t bzmap_n = 0;   // a regular .bz2 file: mapped, its well-formed streams decoded block by block in parallel (mc_pbzip2.h)
+    std::string bz_path; uint64_t bz_skip = 0; bool bz_tail = false;                        // ... and what is left for the one-stream decoder
     std::thread th;
     std::mutex mu; std::condition_variable cv;
     std::vector<uint8_t> ring[NBLK]; size_t ring_n[NBLK] = {};
@@ -246,8 +257,25 @@ struct Stream {
         if (has_ext(path, ".bz2")) {
             std::unique_lock<std::mutex> lk(g_bz2_mu);
             if (!g_bz2.load()) { r_err = "cannot load libbz2 for " + std::string(path); return false; }
-            bz = new Bz2File();
-            if (!bz->open(path)) { delete bz; bz = nullptr; r_err = std::string("cannot open ") + path; return false; }
+            bz_path = path;
+            const int bzt = reader_threads();
+            struct stat sb;
+            if (bzt >= 2 && !t_peek && !getenv("MC_READER_SERIAL_BZ2") && stat(path, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size >= 14) {
+                const int fd = ::open(path, O_RDONLY);
+                void *m = fd >= 0 ? mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+                if (fd >= 0) ::close(fd);
+                if (m != MAP_FAILED) {
+                    bzmap = (const uint8_t *)m; bzmap_n = (size_t)sb.st_size;
+                    mcbz::Api api;
+                    api.init = (int (*)(mcbz::BzStreamT *, int, int))g_bz2.init; api.decompress = (int (*)(mcbz::BzStreamT *))g_bz2.decompress; api.end = (int (*)(mcbz::BzStreamT *))g_bz2.end;
+                    pbz = new mcbz::ParallelBz2(bzmap, bzmap_n, api, std::min(bzt, 32));
+                    if (!pbz->start()) { delete pbz; pbz = nullptr; munmap((void *)bzmap, bzmap_n); bzmap = nullptr; }   // (not even the first stream checks out: the one-stream decoder decides)
+                }
+            }
+            if (!pbz) {
+                bz = new Bz2File();
+                if (!bz->open(path)) { delete bz; bz = nullptr; r_err = std::string("cannot open ") + path; return false; }
+            }
             compressed = true;
         } else {
             int fd = ::open(path, O_RDONLY);
@@ -341,8 +369,36 @@ struct Stream {
         if (sgz) { delete sgz; sgz = nullptr; }
         if (gzmap) { munmap((void *)gzmap, gzmap_n); gzmap = nullptr; }
         if (gz) { gzclose(gz); gz = nullptr; }
+        if (pbz) { delete pbz; pbz = nullptr; }
+        if (bzmap) { munmap((void *)bzmap, bzmap_n); bzmap = nullptr; }
         if (bz) { bz->close(); delete bz; bz = nullptr; }
         if (map) { munmap((void *)map, map_n); map = nullptr; }
+    }
+    // .bz2: the blocks of the well-formed streams from the parallel decoder, then - from the first stream that is not, or from the start of
+    // a stream one of whose blocks libbz2 refused - the one-stream decoder with its rules (mc_pbzip2.h)
+    int bz_read(uint8_t *dst, int want, bool *bad, std::string *msg)
+    {
+        *bad = false;
+        int got = 0;
+        if (pbz && !pbz->handover) got = pbz->read(dst, want);
+        if (got < want && pbz && pbz->handover && !bz_tail) {
+            bz_tail = true;
+            bz = new Bz2File();
+            if (!bz->open_at(bz_path.c_str(), pbz->handover_byte, pbz->handover_got_any)) { *bad = true; *msg = "read error"; return got; }
+            bz_skip = pbz->handover_skip;
+        }
+        if (got < want && bz) {
+            std::vector<uint8_t> scratch;
+            while (bz_skip > 0) {                                        // (what the parallel decoder had delivered of this stream already)
+                if (scratch.empty()) scratch.resize(1 << 20);
+                const int k = (int)std::min<uint64_t>(bz_skip, scratch.size());
+                const int r = bz->read(scratch.data(), k, bad, msg);
+                bz_skip -= (uint64_t)r;
+                if (r < k) return got;                                   // the stream ends (or fails) inside what was delivered: nothing more to give
+            }
+            got += bz->read(dst + got, want - got, bad, msg);
+        }
+        return got;
     }
     void produce()
     {
@@ -376,7 +432,7 @@ struct Stream {
                     if (n < 0 || (errnum != Z_OK && errnum != Z_STREAM_END) || !gzeof(gz)) { bad = true; msg = m ? m : "read error"; }
                 }
             } else {
-                n = bz->read(ring[slot].data(), want, &bad, &msg);
+                n = bz_read(ring[slot].data(), want, &bad, &msg);
             }
             t_prod_read += now() - r0;
             std::unique_lock<std::mutex> lk(mu);

@@ -613,3 +613,60 @@ def test_class_sharded_dup_verdicts_equal_the_record_by_record_sampler(seed, tmp
         with pytest.raises(_native.ReferenceError_) as e:
             _native.sample_reads([fa], L, 100000, True, 33, 20, 25, 10, True)
         assert "KeyError" in str(e.value)
+
+
+def test_parallel_bz2_equals_the_one_stream_decoder(tmp_path, monkeypatch):
+    """.bz2 files are decoded block by block on several threads (csrc/mc_pbzip2.h, round 6): the blocks of a stream are independent, each is
+    cut out at its bit offset and decoded as a one-block stream of its own; whatever is not a well-formed stream is left to the one-stream
+    decoder (MC_READER_SERIAL_BZ2 forces it for everything).  Both forms, and Python's bz2 module, on: many small blocks (level 1), several
+    streams, an empty stream in between, trailing bytes that are no stream, a file cut inside a block / between two blocks / inside the
+    end marker, a damaged byte in the middle of a block (the block's CRC fails: back to the stream's start with the one-stream decoder),
+    a damaged block CRC field (the stream no longer checks out: one-stream decoder from there)."""
+    import bz2
+    import random
+    from microbecensus_amd import _native
+    rng = random.Random(99)
+    recs = []
+    for i in range(12000):
+        n = rng.choice([60, 75, 75, 100])
+        recs.append("@r%d\n%s\n+\n%s\n" % (i, "".join(rng.choice("ACGT") for _ in range(n)), "".join(chr(33 + rng.randrange(20, 41)) for _ in range(n))))
+    text = "".join(recs).encode()
+    third = len(text) // 3
+    cut = [text[:third].rfind(b"\n@r") + 1, text[:2 * third].rfind(b"\n@r") + 1]
+    a, b, c = text[:cut[0]], text[cut[0]:cut[1]], text[cut[1]:]
+    one = bz2.compress(text, 1)                                     # ~ 30 blocks of 100 k
+    multi = bz2.compress(a, 1) + bz2.compress(b"") + bz2.compress(b, 9) + bz2.compress(c, 2)
+    blobs = {
+        "one": one, "multi": multi, "trailing": multi + b"this is no stream", "zero_padding": multi + b"\0" * 100,
+        "cut_in_block": one[: len(one) * 2 // 3], "cut_in_end_marker": one[:-6], "cut_multi": multi[:-20],
+    }
+    dmg = bytearray(one); dmg[len(one) // 2] ^= 0x55
+    blobs["damaged_payload"] = bytes(dmg)
+    dmg = bytearray(multi); dmg[len(bz2.compress(a, 1)) + 14 + 4 + 7] ^= 0xFF   # inside the first block header of the third stream (its CRC field)
+    blobs["damaged_crc_field"] = bytes(dmg)
+    monkeypatch.setenv("MC_READER_THREADS", "4")
+    monkeypatch.setenv("MC_READER_REGION_BYTES", str(1 << 16))
+    for name, blob in blobs.items():
+        p = str(tmp_path / (name + ".fq.bz2"))
+        open(p, "wb").write(blob)
+        try:
+            want = bz2.open(p).read()
+            py_err = None
+        except Exception as e:                                     # noqa: BLE001
+            want, py_err = None, type(e).__name__
+        res = []
+        for serial in (False, True):
+            if serial:
+                monkeypatch.setenv("MC_READER_SERIAL_BZ2", "1")
+            else:
+                monkeypatch.delenv("MC_READER_SERIAL_BZ2", raising=False)
+            try:
+                reads, st = _native.sample_reads([p], 60, 10**9, True, 33, -5, -5, 100, False)
+                res.append(("ok", st["records"], st["sampled"], st["bases"], reads.tobytes()))
+            except _native.ReferenceError_ as e:
+                res.append(("raises", str(e).split(":")[0]))
+        assert res[0] == res[1], (name, res[0][:4], res[1][:4])
+        if py_err is None:
+            assert res[0][0] == "ok" and res[0][1] == want.count(b"\n+\n"), (name, res[0][:4])
+        else:
+            assert res[0][0] == "raises", (name, py_err, res[0][:4])
