@@ -195,6 +195,15 @@ mc_dupset *mc_dupset_open(void);
 void mc_dupset_close(mc_dupset *s);
 int mc_dupset_walk(mc_dupset *s, const char *path, const mc_rec_desc *d, int64_t n, uint8_t *verdict);   /* n descriptors of `path` in file order -> n verdicts; the set remembers across calls and files */
 int64_t mc_reader_take(mc_reader *r, const uint8_t *verdict, int64_t n, int64_t max_take, uint8_t *dst);   /* accepted reads of the described window (first read_len bases), at most max_take */
+/* The same sampler on the blocks [block_lo, block_hi) of ONE .bz2 file (open_file :55-58): the records that start in the TEXT of those
+ * blocks, both ends moved to the first record start behind them by the rule of mc_reader_open_range.  The blocks of a bzip2 file are
+ * independent (csrc/mc_pbzip2.h), so the ranks of a multi-GPU run decode and sample their own shares side by side - which a .gz does not
+ * allow.  kind: '@' or '>' (what a record of the file starts with).  mc_bz2_blocks(): the number of blocks of a file all of whose streams
+ * check out from its first to its last byte, or -1 (cut short, damaged, trailing bytes: one sampler reads such a file and reports what the
+ * reference would).  No duplicate filter. */
+mc_reader *mc_reader_open_bz2_part(const char *path, int64_t block_lo, int64_t block_hi, int32_t kind, int32_t read_len, int64_t nreads, int32_t fastq,
+                                   int32_t quality_offset, double min_quality, double mean_quality, double max_unknown);
+int64_t mc_bz2_blocks(const char *path);
 /* Runs the sampler: returns args['sampled_reads'] (0 = "No reads remaining after filtering"). */
 int64_t mc_reader_run(mc_reader *r);
 /* sampled x read_len bytes, row i = trimmed read i: exactly what mc_search() / mc_upload() take. Owned by the reader. */

@@ -121,6 +121,10 @@ def load_library():
     lib.mc_reader_reads.restype = C.POINTER(C.c_uint8)
     lib.mc_reader_reads.argtypes = [C.c_void_p]
     lib.mc_reader_get_stats.argtypes = [C.c_void_p, C.POINTER(McReaderStats)]
+    lib.mc_reader_open_bz2_part.restype = C.c_void_p
+    lib.mc_reader_open_bz2_part.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]
+    lib.mc_bz2_blocks.restype = C.c_int64
+    lib.mc_bz2_blocks.argtypes = [C.c_char_p]
     lib.mc_reader_describe.restype = C.c_int64
     lib.mc_reader_describe.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     lib.mc_dupset_open.restype = C.c_void_p
@@ -158,7 +162,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_set_index_cache", "mc_index_cache_check", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
                     "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_debug_stage", "mc_range_begin", "mc_range_end", "mc_ranges_in_flight", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8", "mc_write_m8_named",
-                    "mc_reader_last_error", "mc_set_host_threads", "mc_reader_open", "mc_reader_open_range", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_times", "mc_reader_describe", "mc_dupset_open", "mc_dupset_close", "mc_dupset_walk", "mc_reader_take", "mc_reader_close", "mc_reader_trim", "mc_count_bases", "mc_quality_offset",
+                    "mc_reader_last_error", "mc_set_host_threads", "mc_reader_open", "mc_reader_open_range", "mc_reader_open_bz2_part", "mc_bz2_blocks", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_times", "mc_reader_describe", "mc_dupset_open", "mc_dupset_close", "mc_dupset_walk", "mc_reader_take", "mc_reader_close", "mc_reader_trim", "mc_count_bases", "mc_quality_offset",
                     "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_reader_nreads", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows", "mc_set_best_hits_only", "mc_grid_classify"]
 
 
@@ -219,6 +223,20 @@ class Reader:
             nreads = (1 << 63) - 1
         self.r = lib.mc_reader_open_range(path.encode(), int(byte_lo), int(byte_hi), read_len, nreads, 1 if fastq else 0, int(quality_offset), float(min_quality),
                                           float(mean_quality), float(max_unknown))
+        if not self.r:
+            raise RuntimeError(lib.mc_reader_last_error().decode())
+        return self
+
+    @classmethod
+    def on_bz2_part(cls, path, block_lo, block_hi, kind, read_len, nreads, fastq, quality_offset, min_quality, mean_quality, max_unknown):
+        """The sampler on the records that start in the text of blocks [block_lo, block_hi) of one .bz2 file (mc_reader_open_bz2_part)."""
+        lib = load_library()
+        self = cls.__new__(cls)
+        self.lib, self.read_len = lib, read_len
+        if nreads is None:
+            nreads = (1 << 63) - 1
+        self.r = lib.mc_reader_open_bz2_part(path.encode(), int(block_lo), int(block_hi), ord(kind), read_len, nreads, 1 if fastq else 0, int(quality_offset),
+                                             float(min_quality), float(mean_quality), float(max_unknown))
         if not self.r:
             raise RuntimeError(lib.mc_reader_last_error().decode())
         return self
@@ -301,6 +319,11 @@ def count_bases(paths):
     if n < 0:
         raise RuntimeError(lib.mc_reader_last_error().decode())
     return n
+
+
+def bz2_blocks(path):
+    """Blocks of a .bz2 file all of whose streams check out (mc_bz2_blocks), or -1."""
+    return int(load_library().mc_bz2_blocks(path.encode()))
 
 
 def quality_offset(path):

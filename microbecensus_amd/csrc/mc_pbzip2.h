@@ -86,6 +86,7 @@ struct ParallelBz2 {
     std::vector<std::thread> workers;
     std::mutex mu; std::condition_variable cv_work, cv_done;
     size_t next_decode = 0, limit_decode = 0, next_consume = 0; size_t cur_off = 0;
+    size_t blk_end = 0;                                             // blocks [first, blk_end) are decoded (start(): all of them; start_part(): a rank's share)
     bool quit = false;
     // what the consumer is told when the parallel part is over
     bool handover = false; size_t handover_byte = 0; uint64_t handover_skip = 0; bool handover_got_any = false;
@@ -98,8 +99,30 @@ struct ParallelBz2 {
         for (auto &t : workers) t.join();
     }
 
+    // after start(false): the workers decode blocks [b0, b1) only (a rank of a multi-GPU run decodes its share of the file: the blocks are
+    // independent); read_block() then hands them over one by one
+    void run_part(size_t b0, size_t b1)
+    {
+        next_decode = next_consume = b0; blk_end = b1; limit_decode = b0 + (size_t)nthreads * 3;
+        for (int t = 0; t < nthreads; t++) workers.emplace_back([this] { work(); });
+    }
+    bool read_block(std::vector<uint8_t> &dst)                       // appends the next block's text; false: it does not decode, or none is left
+    {
+        if (next_consume >= blk_end) return false;
+        Slot &s = *slots[next_consume];
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            if (limit_decode < next_consume + (size_t)nthreads * 3) { limit_decode = next_consume + (size_t)nthreads * 3; cv_work.notify_all(); }
+            cv_done.wait(lk, [&] { return s.state != 0; });
+        }
+        if (s.state == 2) return false;
+        dst.insert(dst.end(), s.out.begin(), s.out.end());
+        std::vector<uint8_t>().swap(s.out);
+        next_consume++;
+        return true;
+    }
     // scans and walks the file; false: not even the first stream is well-formed (the caller uses the one-stream decoder for everything)
-    bool start()
+    bool start(bool run = true)
     {
         if (size < 14 || memcmp(base, "BZh", 3) != 0) return false;
         std::vector<std::vector<Cand>> part((size_t)nthreads);
@@ -145,6 +168,8 @@ struct ParallelBz2 {
         if (streams.empty()) return false;
         slots.resize(blocks.size());
         for (auto &s : slots) s.reset(new Slot());
+        blk_end = blocks.size();
+        if (!run) return true;
         limit_decode = (size_t)nthreads * 3;
         for (int t = 0; t < nthreads; t++) workers.emplace_back([this] { work(); });
         return true;
@@ -198,7 +223,7 @@ struct ParallelBz2 {
             size_t k;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv_work.wait(lk, [&] { return quit || (next_decode < blocks.size() && next_decode < limit_decode); });
+                cv_work.wait(lk, [&] { return quit || (next_decode < blk_end && next_decode < limit_decode); });
                 if (quit) return;
                 k = next_decode++;
             }
@@ -215,7 +240,7 @@ struct ParallelBz2 {
     {
         int got = 0;
         while (got < n && !handover) {
-            if (next_consume >= blocks.size()) { handover = true; handover_byte = tail_byte; handover_skip = 0; handover_got_any = true; break; }
+            if (next_consume >= blk_end) { handover = true; handover_byte = tail_byte; handover_skip = 0; handover_got_any = true; break; }
             Slot &s = *slots[next_consume];
             {
                 std::unique_lock<std::mutex> lk(mu);

@@ -68,6 +68,7 @@ namespace {
 
 thread_local std::string r_err;
 thread_local int64_t t_range_lo = -1, t_range_hi = -1;   // mc_reader_open_range: the byte window of the ONE plain file the reader is opened on (-1: the whole file)
+thread_local int64_t t_bz_b0 = -1, t_bz_b1 = -1; thread_local int t_bz_kind = 0;   // mc_reader_open_bz2_part: the blocks [b0, b1) of the ONE .bz2 file the reader is opened on, and what a record of the file starts with
 thread_local bool t_peek = false;   // the caller will most likely stop after a few records (mc_quality_offset): no parallel inflate, small first regions
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -220,7 +221,7 @@ struct Bz2File {
 
 int reader_threads();
 int inflate_threads();
-size_t guess_start(const uint8_t *base, size_t from, size_t e, int max_lines, int kind);
+size_t guess_start(const uint8_t *base, size_t from, size_t e, int max_lines, int kind, bool skip_first = false);
 
 struct Stream {
     enum { NBLK = 16, BLK = 1 << 22, BLK_PEEK = 1 << 16 };
@@ -234,6 +235,7 @@ struct Stream {
     mcgz::SerialGz *sgz = nullptr;                                                          // ... or by one stream (one thread allowed; the quality-offset peek)
     mcbz::ParallelBz2 *pbz = nullptr; const uint8_t *bzmap = nullptr; size_t bzmap_n = 0;   // a regular .bz2 file: mapped, its well-formed streams decoded block by block in parallel (mc_pbzip2.h)
     std::string bz_path; uint64_t bz_skip = 0; bool bz_tail = false;                        // ... and what is left for the one-stream decoder
+    std::vector<uint8_t> part_text;                                                         // mc_reader_open_bz2_part: the decoded text of the rank's blocks (and of a little behind them), which `map` then points at
     std::thread th;
     std::mutex mu; std::condition_variable cv;
     std::vector<uint8_t> ring[NBLK]; size_t ring_n[NBLK] = {};
@@ -258,6 +260,7 @@ struct Stream {
             std::unique_lock<std::mutex> lk(g_bz2_mu);
             if (!g_bz2.load()) { r_err = "cannot load libbz2 for " + std::string(path); return false; }
             bz_path = path;
+            if (t_bz_b0 >= 0) return open_bz2_part(path);
             const int bzt = reader_threads();
             struct stat sb;
             if (bzt >= 2 && !t_peek && !getenv("MC_READER_SERIAL_BZ2") && stat(path, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size >= 14) {
@@ -349,6 +352,7 @@ struct Stream {
             }
         }
         if (t_range_lo >= 0 && !ranged) { r_err = std::string("a byte window needs a plain regular file: ") + path; close(); return false; }
+        if (t_bz_b0 >= 0) { r_err = std::string("a block range needs a .bz2 file: ") + path; close(); return false; }
         if (compressed && !pgz) {
             if (t_peek) peek_blocks = 8;
             for (auto &r : ring) r.resize(BLK);
@@ -372,7 +376,50 @@ struct Stream {
         if (pbz) { delete pbz; pbz = nullptr; }
         if (bzmap) { munmap((void *)bzmap, bzmap_n); bzmap = nullptr; }
         if (bz) { bz->close(); delete bz; bz = nullptr; }
-        if (map) { munmap((void *)map, map_n); map = nullptr; }
+        if (map && part_text.empty()) munmap((void *)map, map_n);
+        map = nullptr;
+    }
+    // The blocks [b0, b1) of a .bz2 file as a window of its TEXT (mc_reader_open_bz2_part): they are decoded - with two more blocks behind
+    // them - into one buffer, which is then read like the byte window of a plain file: the records that START in the text of the rank's own
+    // blocks, both ends moved to the first record start behind them by the rule of mc_reader_open_range (the line the boundary lies in is
+    // skipped, then the first '@' line whose second next line starts with '+', or the first '>' line) - so consecutive block ranges cut the
+    // file into whole records whoever decodes them.  t_bz_kind: '@' or '>', what a record of this file starts with.
+    bool open_bz2_part(const char *path)
+    {
+        struct stat sb;
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 14) { if (fd >= 0) ::close(fd); r_err = std::string("cannot map ") + path; return false; }
+        void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (m == MAP_FAILED) { r_err = std::string("cannot map ") + path; return false; }
+        bzmap = (const uint8_t *)m; bzmap_n = (size_t)sb.st_size;
+        mcbz::Api api;
+        api.init = (int (*)(mcbz::BzStreamT *, int, int))g_bz2.init; api.decompress = (int (*)(mcbz::BzStreamT *))g_bz2.decompress; api.end = (int (*)(mcbz::BzStreamT *))g_bz2.end;
+        pbz = new mcbz::ParallelBz2(bzmap, bzmap_n, api, std::min(std::max(2, reader_threads()), 32));
+        const size_t b0 = (size_t)t_bz_b0, b1 = (size_t)t_bz_b1, EXTRA = 2;
+        if (!pbz->start(false) || pbz->tail_byte != bzmap_n || b1 > pbz->blocks.size() || b0 >= b1) { r_err = std::string("not a well-formed .bz2 file, or no such blocks: ") + path; return false; }
+        const size_t nb = pbz->blocks.size(), bx = std::min(nb, b1 + EXTRA);
+        pbz->run_part(b0, bx);
+        size_t own = 0;
+        for (size_t k = b0; k < bx; k++) {
+            if (k == b1) own = part_text.size();
+            if (!pbz->read_block(part_text)) { r_err = std::string("a block of the .bz2 file does not decode: ") + path; return false; }
+        }
+        if (bx == b1) own = part_text.size();
+        delete pbz; pbz = nullptr;
+        map_n = part_text.size();
+        if (part_text.empty()) part_text.push_back(0);                 // (owned, even when empty: close() must not unmap it)
+        map = part_text.data();
+        const int kind = t_bz_kind;
+        const size_t s0 = b0 == 0 ? 0 : guess_start(map, 0, map_n, 1 << 30, kind, true);
+        size_t s1 = map_n;
+        if (b1 < nb) {
+            s1 = guess_start(map, own, map_n, 1 << 30, kind, true);
+            if (s1 >= map_n && bx < nb) { r_err = std::string("no record start within two blocks behind the range (a record longer than a block?): ") + path; return false; }
+        }
+        win = map + std::min(s0, map_n); vend = map + std::max(std::min(s0, map_n), s1); len = 0; ranged = true;
+        if (vend == win) at_end = true;
+        return true;
     }
     // .bz2: the blocks of the well-formed streams from the parallel decoder, then - from the first stream that is not, or from the start of
     // a stream one of whose blocks libbz2 refused - the one-stream decoder with its rules (mc_pbzip2.h)
@@ -875,11 +922,11 @@ void parse_piece_lines(const uint8_t *base, size_t e, bool eof, Piece &pc, const
 // kind: 0 either; '>' / '@': only that kind of record start - the end of a byte window (mc_reader_open_range) must not be taken for
 // a quality line that happens to start with '>' in a FASTQ file (a piece's guess is verified when the pieces are stitched, a
 // window's only by how its parse ends), so there the first byte of the file decides
-size_t guess_start(const uint8_t *base, size_t from, size_t e, int max_lines = 64, int kind = 0)
+size_t guess_start(const uint8_t *base, size_t from, size_t e, int max_lines = 64, int kind = 0, bool skip_first)
 {
     size_t pos = from;
     Line ln;
-    if (pos > 0) { if (!next_line(base, pos, e, ln)) return e; }     // (skip the line `from` points into)
+    if (pos > 0 || skip_first) { if (!next_line(base, pos, e, ln)) return e; }     // (skip the line `from` points into; skip_first: also when the buffer begins there - the text of a .bz2 block range)
     for (int tries = 0; tries < max_lines; tries++) {
         const size_t at = pos;
         if (!next_line(base, pos, e, ln)) return e;
@@ -1117,6 +1164,7 @@ struct mc_reader {
     int32_t L = 0, fastq = 0, qoff = 0, filter_dups = 0;
     int64_t nreads = 0;
     int64_t range_lo = -1, range_hi = -1;                          // mc_reader_open_range
+    int64_t bz_b0 = -1, bz_b1 = -1; int bz_kind = 0;               // mc_reader_open_bz2_part
     double min_q = 0, mean_q = 0, max_unknown = 0;
     std::string fasta_out;
     uint8_t *reads = nullptr; size_t reads_cap = 0, reads_n = 0;   // anonymous mapping grown with mremap (no copies, no zero fill up front)
@@ -1212,6 +1260,46 @@ extern "C" mc_reader *mc_reader_open_range(const char *path, int64_t byte_lo, in
     return r;
 }
 
+// The sampler on the blocks [block_lo, block_hi) of ONE .bz2 file that is well-formed from its first to its last byte (mc_bz2_blocks says how
+// many it has): the records that start in the text of those blocks - the blocks of a bzip2 file are independent, so the ranks of a multi-GPU
+// run decode and sample their own shares side by side (microbecensus_amd/distributed.py), which a .gz does not allow.  kind: '@' or '>',
+// what a record of this file starts with (the first byte of its text).
+extern "C" mc_reader *mc_reader_open_bz2_part(const char *path, int64_t block_lo, int64_t block_hi, int32_t kind, int32_t read_len, int64_t nreads, int32_t fastq,
+                                              int32_t quality_offset, double min_quality, double mean_quality, double max_unknown)
+{
+    if (!path || block_lo < 0 || block_hi <= block_lo || (kind != '@' && kind != '>')) { r_err = "mc_reader_open_bz2_part: bad arguments"; return nullptr; }
+    const char *paths[1] = {path};
+    mc_reader *r = mc_reader_open(paths, 1, read_len, nreads, fastq, quality_offset, min_quality, mean_quality, max_unknown, 0, nullptr);
+    if (r) { r->bz_b0 = block_lo; r->bz_b1 = block_hi; r->bz_kind = kind; }
+    return r;
+}
+// blocks of a .bz2 file whose streams all check out (headers, block chain, combined CRCs: mc_pbzip2.h), or -1: cut short, damaged,
+// trailing bytes - such a file is read by one sampler (which reports what the reference would)
+extern "C" int64_t mc_bz2_blocks(const char *path)
+{
+    if (!path) { r_err = "null path"; return -1; }
+    {
+        std::unique_lock<std::mutex> lk(g_bz2_mu);
+        if (!g_bz2.load()) { r_err = std::string("cannot load libbz2 for ") + path; return -1; }
+    }
+    struct stat sb;
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 14) { if (fd >= 0) ::close(fd); r_err = std::string("cannot map ") + path; return -1; }
+    void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED) { r_err = std::string("cannot map ") + path; return -1; }
+    int64_t n = -1;
+    try {
+        mcbz::Api api;
+        api.init = (int (*)(mcbz::BzStreamT *, int, int))g_bz2.init; api.decompress = (int (*)(mcbz::BzStreamT *))g_bz2.decompress; api.end = (int (*)(mcbz::BzStreamT *))g_bz2.end;
+        mcbz::ParallelBz2 pz((const uint8_t *)m, (size_t)sb.st_size, api, std::min(std::max(2, reader_threads()), 32));
+        if (pz.start(false) && pz.tail_byte == (size_t)sb.st_size) n = (int64_t)pz.blocks.size();
+        else r_err = std::string("not a well-formed .bz2 file from its first to its last byte: ") + path;
+    } catch (const std::bad_alloc &) { r_err = "out of memory"; }
+    munmap(m, (size_t)sb.st_size);
+    return n;
+}
+
 extern "C" void mc_reader_close(mc_reader *r) { delete r; }
 
 static int64_t reader_run(mc_reader *r);
@@ -1267,6 +1355,8 @@ static int64_t reader_run(mc_reader *r)
     };
     for (const std::string &path : r->paths) {
         t_range_lo = r->range_lo; t_range_hi = r->range_hi;        // (consumed by Stream::open on this thread)
+        t_bz_b0 = r->bz_b0; t_bz_b1 = r->bz_b1; t_bz_kind = r->bz_kind;
+        struct BzPart { ~BzPart() { t_bz_b0 = t_bz_b1 = -1; } } bz_part_guard;
         const int rc = walk_file(path, P, pool, [&](std::vector<Piece *> &order) -> bool {
             const int64_t kept0 = kept;
             bool full = false;

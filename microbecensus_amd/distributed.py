@@ -437,14 +437,17 @@ SLICE_BYTES = 256 << 20     # bytes of a file one rank samples per round (MC_DIS
 
 
 def sharded_sampling_usable(args):
-    """Can every rank sample its own slices of the input?  Without -d (first occurrence wins over the WHOLE stream: that
-    sampler stays on rank 0), on plain regular files (a compressed stream cannot be entered in the middle), and unless
-    MC_DIST_SHARDED=0."""
+    """Can every rank sample its own slices of the input?  Without -d (with it: stream_batches_sharded_dups), on plain regular files
+    (byte windows) and on .bz2 files all of whose streams check out (block ranges: the blocks of a bzip2 file are independent,
+    csrc/mc_pbzip2.h) - a .gz member cannot be entered in the middle -, and unless MC_DIST_SHARDED=0."""
     import os
+    from . import _native
     if os.environ.get("MC_DIST_SHARDED") == "0" or args.get("filter_dups"):
         return False
     for p in args["seqfiles"]:
-        if p.endswith((".gz", ".bz2")) or not os.path.isfile(p):
+        if p.endswith(".gz") or not os.path.isfile(p):
+            return False
+        if p.endswith(".bz2") and _native.bz2_blocks(p) <= 0:
             return False
     return True
 
@@ -479,26 +482,42 @@ def stream_batches_sharded(args, on_batch, device=None):
         S = int(os.environ.get("MC_DIST_SLICE", "0")) or SLICE_BYTES
     except ValueError:
         S = SLICE_BYTES
-    rounds = []                                                    # (path, lo of rank 0's slice): the same list on every rank
+    # a round = `world` consecutive slices of one file: S bytes each of a plain file, KB blocks each of a .bz2 file (the same list on every rank)
+    KB = max(1, S // 900000)
+    rounds = []
     for p in args["seqfiles"]:
-        size = os.path.getsize(p)
-        for base in range(0, max(size, 1), S * world):
-            rounds.append((p, base, size))
+        if p.endswith(".bz2"):
+            size = _native.bz2_blocks(p)
+            rounds += [(p, base, size, KB) for base in range(0, max(size, 1), KB * world)]
+        else:
+            size = os.path.getsize(p)
+            rounds += [(p, base, size, S) for base in range(0, max(size, 1), S * world)]
+
+    def open_slice(p, lo, hi, cap):
+        if p.endswith(".bz2"):
+            return _native.Reader.on_bz2_part(p, lo, hi, "@" if fastq else ">", L, max(1, cap), fastq, qoff, args["min_quality"], args["mean_quality"], args["max_unknown"])
+        return _native.Reader.on_range(p, lo, hi, L, max(1, cap), fastq, qoff, args["min_quality"], args["mean_quality"], args["max_unknown"])
 
     def sample(j, cap):
-        p, base, size = rounds[j]
-        lo = min(size, base + rank * S)
-        hi = min(size, lo + S)
+        p, base, size, step = rounds[j]
+        lo = min(size, base + rank * step)
+        hi = min(size, lo + step)
         box = {}
 
         def work():
             try:
-                rd = _native.Reader.on_range(p, lo, hi, L, max(1, cap), fastq, qoff, args["min_quality"], args["mean_quality"], args["max_unknown"])
-                box["rd"] = rd
-                box["n"] = rd.run() if hi > lo else 0
-                box["st"] = rd.stats() if hi > lo else {"too_short": 0, "low_qual": 0, "records": 0, "bases": 0, "ragged_end": 0, "exhausted": 1}
+                if hi > lo:
+                    rd = open_slice(p, lo, hi, cap)
+                    box["rd"] = rd
+                    box["n"] = rd.run()
+                    box["st"] = rd.stats()
+                else:
+                    box["n"], box["st"] = 0, {"too_short": 0, "low_qual": 0, "records": 0, "bases": 0, "ragged_end": 0, "exhausted": 1}
             except BaseException as e:                             # noqa: BLE001
-                box["err"] = e
+                if p.endswith(".bz2") and isinstance(e, RuntimeError) and not isinstance(e, _native.ReferenceError_):
+                    box["n"], box["st"] = 0, {"too_short": 0, "low_qual": 0, "records": 0, "bases": 0, "ragged_end": 1, "exhausted": 0}   # (no record start near a block boundary: the sampler on rank 0 decides)
+                else:
+                    box["err"] = e
         th = threading.Thread(target=work, daemon=True)
         th.start()
         return th, box, (p, lo, hi)
@@ -526,7 +545,7 @@ def stream_batches_sharded(args, on_batch, device=None):
             keep = max(0, min(n_acc, nreads - prefix))
             st = box["st"]
             if keep > 0 and prefix + n_acc >= nreads:              # the head-take ends in this slice: the counters stop with its last read
-                rd2 = _native.Reader.on_range(p, lo, hi, L, keep, fastq, qoff, args["min_quality"], args["mean_quality"], args["max_unknown"])
+                rd2 = open_slice(p, lo, hi, keep)
                 try:
                     rd2.run()
                     st = rd2.stats()

@@ -175,6 +175,21 @@ def test_every_rank_samples_its_own_slices(tmp_path, world):
         "pair_take": dict(base, seqfiles=[plain["c4_pair_1.fq.gz"], plain["c4_pair_2.fq.gz"]], read_length=150, nreads=15000, file_type="fastq", quality_offset=32),
         "q20": dict(base, seqfiles=[plain["c5_300bp.fq.gz"]], read_length=300, nreads=10**9, file_type="fastq", quality_offset=32, min_quality=20),
     }
+    # .bz2: the blocks of a bzip2 file are independent, so its block ranges shard like the byte windows of a plain file (round 6): one block per
+    # rank and round here (level 1: 100 KB of text per block), a file of three streams, the take ending in the second file of two
+    import bz2
+    ex = open(plain["example.fq.gz"], "rb").read()
+    cut = ex.rfind(b"\n@", 0, len(ex) // 2) + 1
+    bz = {"example.fq.bz2": bz2.compress(ex, 1), "example3.fq.bz2": bz2.compress(ex[:cut], 1) + bz2.compress(b"") + bz2.compress(ex[cut:], 2),
+          "metagenome.fa.bz2": bz2.compress(open(plain["metagenome.fa.gz"], "rb").read(), 1)}
+    for f, blob in bz.items():
+        plain[f] = str(tmp_path / f)
+        open(plain[f], "wb").write(blob)
+    cases.update({
+        "bz2_all": dict(base, seqfiles=[plain["example.fq.bz2"]], read_length=100, nreads=10**9, file_type="fastq", quality_offset=32),
+        "bz2_streams_take": dict(base, seqfiles=[plain["example3.fq.bz2"]], read_length=100, nreads=6000, file_type="fastq", quality_offset=32),
+        "bz2_and_plain": dict(base, seqfiles=[plain["metagenome.fa.bz2"], plain["metagenome.fa.gz"]], read_length=100, nreads=100000, file_type="fasta", quality_offset=None),
+    })
     cj = tmp_path / "cases.json"
     cj.write_text(json.dumps(cases))
     worker = tmp_path / "shard.py"
