@@ -283,7 +283,31 @@ int main(int argc, char **argv)
     };
     const int WIN = getenv("MC_GAP_WIN") ? atoi(getenv("MC_GAP_WIN")) : 32;
     long win_flanks = 0, win_over = 0, win_bad = 0;
+    // MC_GAP_STATS (design aid): the band of every DP row - what several lanes per flank (a group of G lanes per row, G cells at a
+    // time) would find to do: cells per row, rows per flank, groups of 8 / 16 per row
+    const bool gap_stats = getenv("MC_GAP_STATS") != nullptr;
+    long gs_flanks = 0, gs_rows = 0, gs_cells = 0, gs_g8 = 0, gs_g16 = 0, gs_hist[41] = {0}, gs_rows_hist[8] = {0}, gs_cells_long = 0;
+    auto band_stats = [&](const uint8_t *s1, int st1, const uint8_t *s2, int n1, int n2) {
+        HostWin ws(64);
+        McGapState S;
+        if (!mc_gap_begin(T, S, s1, s2, st1, n1, n2, ws, 64)) return;
+        gs_flanks++;
+        long rows = 0, cells = 0;
+        for (;;) {
+            const int js = S.jStart, je = S.jEnd < n2 ? S.jEnd : n2;
+            const bool end = mc_gap_row(T, S, ws, 64);
+            if (S.over) break;
+            int w = (S.jEnd < je ? S.jEnd : je) - js + 1;            // (the row ran from jStart to its break column, or to the band's end; the right growth is not counted)
+            if (w < 1) w = 1;
+            rows++; cells += w; gs_g8 += (w + 7) / 8; gs_g16 += (w + 15) / 16; gs_hist[w > 40 ? 40 : w]++;
+            if (end) break;
+        }
+        gs_rows += rows; gs_cells += cells;
+        gs_rows_hist[rows >= 64 ? 7 : rows >= 48 ? 6 : rows >= 32 ? 5 : rows >= 24 ? 4 : rows >= 16 ? 3 : rows >= 8 ? 2 : rows >= 4 ? 1 : 0]++;
+        if (rows >= 64) gs_cells_long += cells;
+    };
     auto check_win = [&](const McGapResult &R, const uint8_t *s1, int st1, const uint8_t *s2, int st2, int n1, int n2) {
+        if (gap_stats) band_stats(s1, st1, s2, n1, n2);
         HostWin ws(WIN);
         const McGapResult Q = mc_align_gapped_win(T, s1, st1, s2, st2, n1, n2, ws, WIN);
         win_flanks++;
@@ -318,6 +342,17 @@ int main(int argc, char **argv)
         dump(".gaps", gaps.data(), gaps.size() * sizeof(McGapTask));
         dump(".hsps", hsps.data(), hsps.size() * sizeof(McHsp));       // (ungapped and gapped, before any ordering)
         fprintf(stderr, "stages dumped: FP %d, %zu B per task, %zu per gap task, %zu per HSP\n", FP, sizeof(McSeedTask), sizeof(McGapTask), sizeof(McHsp));
+    }
+    if (gap_stats) {
+        fprintf(stderr, "gap-stats: %ld flanks (every task's two, not deduplicated), %ld rows, %ld cells: %.1f rows per flank, %.2f cells per row; groups per row of 8 lanes %.2f (%.0f %% of the lanes busy), of 16 lanes %.2f (%.0f %%); cells in flanks of >= 64 rows: %.1f %%\n",
+                gs_flanks, gs_rows, gs_cells, (double)gs_rows / (double)(gs_flanks ? gs_flanks : 1), (double)gs_cells / (double)(gs_rows ? gs_rows : 1),
+                (double)gs_g8 / (double)(gs_rows ? gs_rows : 1), 100.0 * (double)gs_cells / (8.0 * (double)(gs_g8 ? gs_g8 : 1)), (double)gs_g16 / (double)(gs_rows ? gs_rows : 1), 100.0 * (double)gs_cells / (16.0 * (double)(gs_g16 ? gs_g16 : 1)),
+                100.0 * (double)gs_cells_long / (double)(gs_cells ? gs_cells : 1));
+        fprintf(stderr, "gap-stats: rows per flank < 4 / 4-7 / 8-15 / 16-23 / 24-31 / 32-47 / 48-63 / >= 64:");
+        for (int k = 0; k < 8; k++) fprintf(stderr, " %ld", gs_rows_hist[k]);
+        fprintf(stderr, "\ngap-stats: cells per row 1 .. 40+:");
+        for (int k = 1; k <= 40; k++) fprintf(stderr, " %ld", gs_hist[k]);
+        fprintf(stderr, "\n");
     }
     fprintf(stderr, "gapped window check (W = %d): %ld flanks, %ld leave the window, %ld differ from the full-size form\n", WIN, win_flanks, win_over, win_bad);
     if (win_bad) return 3;
