@@ -40,6 +40,12 @@ __device__ __forceinline__ bool mc_hsp_can_classify(const McTables &T, const McC
 // reference's exit tests, in the same order.  Rows and residue array have room on both sides (what a load reads past a
 // sequence's end is never used: the step that would use it is behind an exit test).
 __device__ __forceinline__ uint64_t mc_ld8(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+#ifdef MC_EXP_TIMING
+__device__ unsigned long long g_ev_turns[4];         // X-drop loops: lane-turns forward, wave-turns forward, lane-turns backward, wave-turns backward (a turn = 8 residues)
+#define MC_EV_TURN(k) do { const unsigned long long m_ = __ballot(true); if ((int)__builtin_ctzll(m_) == (int)(threadIdx.x & 63)) { atomicAdd(&g_ev_turns[2 * (k)], (unsigned long long)__popcll(m_)); atomicAdd(&g_ev_turns[2 * (k) + 1], 1ull); } } while (0)
+#else
+#define MC_EV_TURN(k) do { } while (0)
+#endif
 // growth and gate of a seed hit (mc_eval_seed_tail, mc_core.h): true if the hit goes on to the ungapped X-drop extension, with the
 // grown seed (qp, dp, L), its score and identities
 __device__ __forceinline__ bool mc_ev_gate(const McHot &T, const uint8_t *q, int qlen, int qpos, const uint8_t *d, int dlen, int dpos, int seedlen, int &score, int &ident,
@@ -90,6 +96,7 @@ __device__ __forceinline__ int mc_ev_xdrop(const McHot &T, const uint8_t *q, int
             int run = s0, best = s0, id = 0, i = 0;
             bool stop = false;
             do {
+                MC_EV_TURN(0);
                 const uint64_t wa = mc_ld8(p1 + i), wb = mc_ld8(p2 + i);
                 int sc[8];
                 uint32_t eq = 0;
@@ -116,6 +123,7 @@ __device__ __forceinline__ int mc_ev_xdrop(const McHot &T, const uint8_t *q, int
             int run = s0, best = s0, id = 0, cnt = 0;
             bool stop = false;
             do {
+                MC_EV_TURN(1);
                 const uint64_t wa = mc_ld8(q + a - 7), wb = mc_ld8(d + b - 7);       // residues a - 7 .. a: step k uses byte 7 - k
                 int sc[8];
                 uint32_t eq = 0;
@@ -149,6 +157,7 @@ __device__ unsigned long long g_ev_acc[8];           // wave time per phase, sum
 #else
 #define MC_EV_TICK(prev) do { } while (0)
 #endif
+
 #define MC_EV_BS 256         // threads per workgroup (the waves are on their own: the size only sets how the LDS is handed out)
 #define MC_EV_BPC 5          // workgroups per CU: 20 waves, 5 per SIMD - 88 registers, nothing spilled (measured per 1 M reads of 150 / 300 bp:
                              // 7 waves per SIMD and 72 registers with 52 bytes of scratch 3.50 / 7.77 ms, 6 with 80 and 12 bytes 2.82 / 6.41, 5 with 88 2.60 / 6.01, 4: 2.79 / 6.53)

@@ -781,6 +781,11 @@ static int stage_d(mc_handle *h, McCtx &c)
             for (int k = 0; k < 7; k++) fprintf(stderr, "ev-timing %-21s total %9.1f Mcycles (lane 0 of every wave)\n", en[k], ev[k] / 1e6);
             unsigned long long z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_ev_acc), z8, sizeof z8));
+            unsigned long long tr[4];
+            HIPCK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_ev_turns), sizeof tr));
+            fprintf(stderr, "ev-turns forward: %.1f M lane-turns in %.2f M wave-turns = %.1f lanes of 64; backward: %.1f M in %.2f M = %.1f lanes\n", tr[0] / 1e6, tr[1] / 1e6, tr[1] ? (double)tr[0] / (double)tr[1] : 0.0,
+                    tr[2] / 1e6, tr[3] / 1e6, tr[3] ? (double)tr[2] / (double)tr[3] : 0.0);
+            HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_ev_turns), z8, sizeof tr));
         }
         const char *nm[8] = {"group starts", "groups", "scan, items", "sort", "threshold, ranks", "heap sort", "rows", "other"};
         for (int k = 0; k < 8; k++) fprintf(stderr, "fh-timing %-17s total %9.1f Mcycles %9llu entries\n", nm[k], acc[k] / 1e6, cnt[k]);
