@@ -204,6 +204,22 @@ int64_t mc_reader_take(mc_reader *r, const uint8_t *verdict, int64_t n, int64_t 
 mc_reader *mc_reader_open_bz2_part(const char *path, int64_t block_lo, int64_t block_hi, int32_t kind, int32_t read_len, int64_t nreads, int32_t fastq,
                                    int32_t quality_offset, double min_quality, double mean_quality, double max_unknown);
 int64_t mc_bz2_blocks(const char *path);
+/* A .gz file across the ranks.  A gzip member cannot be entered in the middle (every block may point 32 KB back) but it can be DECODED
+ * from the middle speculatively (csrc/mc_pgzip.h): the file is cut into slices of chunks, every rank decodes its slice at once, and what
+ * is sequential is a chain of hand-overs - where the slice in front ended and the 32 KB in front of that - after which every rank samples
+ * the records that start in its slice's text (both ends moved to the first record start behind them, as mc_reader_open_range).
+ *   mc_gz_chunks            chunks of chunk_bytes the parallel reader cuts the file into, or -1 (not a gzip file it takes)
+ *   mc_reader_open_gz_part  the sampler on chunks [chunk_lo, chunk_hi); run it with mc_reader_start / mc_reader_join (it waits for the state)
+ *   mc_reader_gz_provide    what mc_reader_gz_end_state of the slice in front returned (n = 0: that slice failed); not needed for chunk_lo = 0
+ *   mc_reader_gz_end_state  waits until the slice is stitched; returns the bytes written (at most 32784), or -1
+ *   mc_reader_gz_finish     after mc_reader_join: checks the CRCs of the members that end in the slice, given CRC (4 bytes) | length (8 bytes) of
+ *                           the open member's bytes in front of it (zeros for the first slice); 0, or -3 = gzip.open's "CRC check failed" */
+int64_t mc_gz_chunks(const char *path, int64_t chunk_bytes);
+mc_reader *mc_reader_open_gz_part(const char *path, int64_t chunk_lo, int64_t chunk_hi, int64_t chunk_bytes, int32_t kind, int32_t read_len, int64_t nreads,
+                                  int32_t fastq, int32_t quality_offset, double min_quality, double mean_quality, double max_unknown);
+int mc_reader_gz_provide(mc_reader *r, const uint8_t *state, int64_t n);
+int64_t mc_reader_gz_end_state(mc_reader *r, uint8_t *out, int64_t cap);
+int mc_reader_gz_finish(mc_reader *r, const uint8_t *crc_in, uint8_t *crc_out);
 /* Runs the sampler: returns args['sampled_reads'] (0 = "No reads remaining after filtering"). */
 int64_t mc_reader_run(mc_reader *r);
 /* sampled x read_len bytes, row i = trimmed read i: exactly what mc_search() / mc_upload() take. Owned by the reader. */

@@ -125,6 +125,14 @@ def load_library():
     lib.mc_reader_open_bz2_part.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]
     lib.mc_bz2_blocks.restype = C.c_int64
     lib.mc_bz2_blocks.argtypes = [C.c_char_p]
+    lib.mc_gz_chunks.restype = C.c_int64
+    lib.mc_gz_chunks.argtypes = [C.c_char_p, C.c_int64]
+    lib.mc_reader_open_gz_part.restype = C.c_void_p
+    lib.mc_reader_open_gz_part.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]
+    lib.mc_reader_gz_provide.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    lib.mc_reader_gz_end_state.restype = C.c_int64
+    lib.mc_reader_gz_end_state.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.mc_reader_gz_finish.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
     lib.mc_reader_describe.restype = C.c_int64
     lib.mc_reader_describe.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     lib.mc_dupset_open.restype = C.c_void_p
@@ -162,7 +170,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ["mc_last_error", "mc_device_count", "mc_open", "mc_close", "mc_set_index_cache", "mc_index_cache_check", "mc_open_rapdb", "mc_marker_count", "mc_marker_name", "mc_set_families", "mc_rapdb_verify", "mc_rapdb_write", "mc_index_view", "mc_set_run", "mc_search",
                     "mc_upload", "mc_attach", "mc_run", "mc_run_range", "mc_set_counting", "mc_debug_stage", "mc_range_begin", "mc_range_end", "mc_ranges_in_flight", "mc_result_rows", "mc_result_best_hits", "mc_result_stats", "mc_write_m8", "mc_write_m8_named",
-                    "mc_reader_last_error", "mc_set_host_threads", "mc_reader_open", "mc_reader_open_range", "mc_reader_open_bz2_part", "mc_bz2_blocks", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_times", "mc_reader_describe", "mc_dupset_open", "mc_dupset_close", "mc_dupset_walk", "mc_reader_take", "mc_reader_close", "mc_reader_trim", "mc_count_bases", "mc_quality_offset",
+                    "mc_reader_last_error", "mc_set_host_threads", "mc_reader_open", "mc_reader_open_range", "mc_reader_open_bz2_part", "mc_bz2_blocks", "mc_gz_chunks", "mc_reader_open_gz_part", "mc_reader_gz_provide", "mc_reader_gz_end_state", "mc_reader_gz_finish", "mc_reader_run", "mc_reader_reads", "mc_reader_get_stats", "mc_reader_times", "mc_reader_describe", "mc_dupset_open", "mc_dupset_close", "mc_dupset_walk", "mc_reader_take", "mc_reader_close", "mc_reader_trim", "mc_count_bases", "mc_quality_offset",
                     "mc_reader_start", "mc_reader_fetch", "mc_reader_join", "mc_reader_read_len", "mc_reader_nreads", "mc_search_files", "mc_search_files_multi", "mc_set_keep_rows", "mc_set_best_hits_only", "mc_grid_classify"]
 
 
@@ -240,6 +248,43 @@ class Reader:
         if not self.r:
             raise RuntimeError(lib.mc_reader_last_error().decode())
         return self
+
+    @classmethod
+    def on_gz_part(cls, path, chunk_lo, chunk_hi, chunk_bytes, kind, read_len, nreads, fastq, quality_offset, min_quality, mean_quality, max_unknown):
+        """The sampler on the records that start in the text of chunks [chunk_lo, chunk_hi) of one .gz file (mc_reader_open_gz_part): start() it,
+        gz_provide() the state of the slice in front (not for chunk 0), gz_end_state() for the next slice's owner, join(), gz_finish()."""
+        lib = load_library()
+        self = cls.__new__(cls)
+        self.lib, self.read_len = lib, read_len
+        if nreads is None:
+            nreads = (1 << 63) - 1
+        self.r = lib.mc_reader_open_gz_part(path.encode(), int(chunk_lo), int(chunk_hi), int(chunk_bytes), ord(kind), read_len, nreads, 1 if fastq else 0, int(quality_offset),
+                                            float(min_quality), float(mean_quality), float(max_unknown))
+        if not self.r:
+            raise RuntimeError(lib.mc_reader_last_error().decode())
+        return self
+
+    def start(self):
+        if self.lib.mc_reader_start(self.r) != 0:
+            raise RuntimeError(self.lib.mc_reader_last_error().decode())
+
+    def join(self):
+        return self.check(self.lib.mc_reader_join(self.r))
+
+    def gz_provide(self, state):
+        self.lib.mc_reader_gz_provide(self.r, state if state else None, len(state) if state else 0)
+
+    def gz_end_state(self):
+        """bytes for the owner of the next slice, or None when this slice failed"""
+        buf = C.create_string_buffer(32768 + 64)
+        n = self.lib.mc_reader_gz_end_state(self.r, buf, len(buf))
+        return None if n < 0 else buf.raw[:n]
+
+    def gz_finish(self, crc_in):
+        """crc_in / result: 12 bytes (CRC | length of the open member's bytes so far); raises ReferenceError_ on a CRC mismatch"""
+        out = C.create_string_buffer(12)
+        self.check(self.lib.mc_reader_gz_finish(self.r, crc_in, out))
+        return out.raw
 
     def close(self):
         if getattr(self, "r", None):
@@ -319,6 +364,11 @@ def count_bases(paths):
     if n < 0:
         raise RuntimeError(lib.mc_reader_last_error().decode())
     return n
+
+
+def gz_chunks(path, chunk_bytes=1 << 20):
+    """Chunks the parallel gzip reader cuts a .gz file into (mc_gz_chunks), or -1."""
+    return int(load_library().mc_gz_chunks(path.encode(), int(chunk_bytes)))
 
 
 def bz2_blocks(path):

@@ -842,7 +842,82 @@ public:
             c->nominal_bit = b;
             chunks_.push_back(std::move(c));
         }
+        lim_ = chunks_.size();
         for (int i = 0; i < nthreads_; i++) workers_.emplace_back([this] { work(); });
+        return true;
+    }
+
+    // ---- a SLICE of the file for one rank of a multi-GPU run (microbecensus_amd/distributed.py): chunks [k0, k1) and one more (the reader's
+    // last record ends in it).  All of them are decoded speculatively at once; stitching - which needs where the chunk in front ended and
+    // the 32 KB in front of that - starts when the owner of the slice in front has told (set_state; slice 0 knows), and tells the owner of
+    // the next slice as soon as it has passed chunk k1 - 1 (end_state) - a chain of 32 KB hand-overs along the ranks while the expensive
+    // part, the decoding, runs on all of them side by side.  The member's CRC is checked at the end, when the CRC of its bytes in front of
+    // the slice is known (finish_crc).
+    struct SliceState { uint64_t end_bit = 0; bool member_start = false, stop = false, bad = false, ready = false; std::vector<uint8_t> window; };
+    struct SegRec { uint32_t crc = 0; uint64_t len = 0; bool has_end = false; uint32_t end_crc = 0, end_isize = 0; };
+    size_t nchunks() const { return chunks_.size(); }
+    bool setup()                                                     // header and chunk table (start() without the workers); false: not a gzip file this reader handles
+    {
+        const long h = member_header(base_, end_);
+        if (h <= 0) return false;
+        first_bit_ = (uint64_t)h * 8;
+        const uint64_t data_bits = (uint64_t)(end_ - base_) * 8;
+        for (uint64_t b = first_bit_; b < data_bits; b += (uint64_t)chunk_bytes_ * 8) { std::unique_ptr<Chunk> c(new Chunk()); c->nominal_bit = b; chunks_.push_back(std::move(c)); }
+        lim_ = chunks_.size();
+        return true;
+    }
+    bool start_slice(size_t k0, size_t k1)
+    {
+        if (!setup() || k0 >= k1 || k1 > chunks_.size()) return false;
+        slice_ = true; slice_end_ = k1; lim_ = std::min(chunks_.size(), k1 + 1);
+        consume_next_ = stitch_next_ = k0; next_decode_ = k0 == 0 ? 1 : k0; limit_decode_ = lim_;
+        state_ready_ = k0 == 0;
+        for (int i = 0; i < nthreads_; i++) workers_.emplace_back([this] { work(); });
+        return true;
+    }
+    void set_state(const SliceState &st)                             // where the slice in front ended
+    {
+        stitched_end_bit_ = st.end_bit; at_member_start_ = st.member_start; window_ = st.window;
+        if (st.stop) { stitch_stop_ = true; finished_ = true; }      // (the data ended in front of this slice: nothing to deliver)
+        state_ready_ = true;
+    }
+    // stitches through the slice's last own chunk (waits for their decoding) and says where it ended; false: damaged data
+    bool end_state(SliceState &out)
+    {
+        if (!state_ready_) return false;
+        while (!end_state_.ready && !stitch_stop_ && stitch_next_ < slice_end_) stitch(slice_end_ - 1);
+        if (!end_state_.ready) {                                     // (the data had ended in front of the slice)
+            end_state_.end_bit = stitched_end_bit_; end_state_.member_start = at_member_start_; end_state_.window = window_; end_state_.stop = true; end_state_.ready = true;
+        }
+        out = end_state_;
+        return !end_state_.bad;
+    }
+    // the slice's own text is [0, own_bytes()) of what read() delivers (the rest: the chunk behind it)
+    // the member CRCs of the slice, given CRC and length of the open member's bytes in front of it; false: a member's CRC or length does not match
+    static bool finish_crc(const std::vector<SegRec> &segs, size_t nsegs_own, uint32_t crc_in, uint64_t len_in, uint32_t *crc_out, uint64_t *len_out)
+    {
+        uint32_t rc = crc_in; uint64_t rl = len_in;
+        for (size_t i = 0; i < nsegs_own && i < segs.size(); i++) {
+            const SegRec &r = segs[i];
+            if (r.len) { rc = rl ? (uint32_t)crc32_combine(rc, r.crc, (z_off_t)r.len) : r.crc; rl += r.len; }
+            if (r.has_end) { if (rc != r.end_crc || (uint32_t)rl != r.end_isize) return false; rc = 0; rl = 0; }
+        }
+        *crc_out = rc; *len_out = rl;
+        return true;
+    }
+    size_t segs() const { return segs_.size(); }
+    const std::vector<SegRec> &seg_list() const { return segs_; }
+    size_t next_chunk_index() const { return consume_next_; }
+    bool slice_failed() const { return failed_; }
+    const std::string &slice_error() const { return err_; }
+    // appends the next chunk's bytes (nothing for a chunk the one in front ran over); false: none left, or the data is damaged (slice_failed)
+    bool read_chunk(std::vector<uint8_t> &dst)
+    {
+        if (cur_) { release(cur_index_); cur_ = nullptr; }
+        if (finished_) return false;
+        if (!next_chunk()) return false;
+        if (cur_ && cur_failed_) return false;
+        if (cur_) dst.insert(dst.end(), cur_->bytes.data(), cur_->bytes.data() + cur_->bytes.size());
         return true;
     }
 
@@ -898,6 +973,8 @@ private:
     std::vector<uint8_t> window_;                                   // last <= 32 KB of the current member in front of the stitched position
     uint32_t run_crc_ = 0; uint64_t run_len_ = 0;                   // CRC / length of the current member so far
     bool finished_ = false, failed_ = false; std::string err_;
+    size_t lim_ = 0;                                                // chunks [.., lim_) are decoded (all of them; a slice: its own and one more)
+    bool slice_ = false, state_ready_ = true; size_t slice_end_ = 0; SliceState end_state_; std::vector<SegRec> segs_;
 
     void stop()
     {
@@ -914,7 +991,7 @@ private:
             size_t k = 0;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_work_.wait(lk, [&] { return quit_ || !jobs_.empty() || (next_decode_ < chunks_.size() && next_decode_ < limit_decode_); });
+                cv_work_.wait(lk, [&] { return quit_ || !jobs_.empty() || (next_decode_ < lim_ && next_decode_ < limit_decode_); });
                 if (quit_) return;
                 if (!jobs_.empty()) { job = std::move(jobs_.front()); jobs_.pop_front(); }
                 else k = next_decode_++;
@@ -961,8 +1038,22 @@ private:
     void fail(const std::string &m) { failed_ = true; finished_ = true; err_ = m; }
 
     // accounts the bytes of a finished chunk to the running member CRC; false on a CRC / length mismatch
+    // (a slice - start_slice - does not know the CRC of the member's bytes in front of it yet: it keeps its segments and checks them
+    // when that arrives, finish_crc)
     bool account(Chunk &c)
     {
+        if (slice_) {
+            size_t at0 = 0;
+            for (size_t s = 0; s <= c.ends.size(); s++) {
+                const size_t to = s < c.ends.size() ? (size_t)c.ends[s].out_pos : c.bytes.size();
+                const size_t n = to - at0;
+                SegRec r; r.crc = n ? (s < c.seg_crc.size() ? c.seg_crc[s] : crc32_any(0, c.bytes.data() + at0, n)) : 0; r.len = n; r.has_end = s < c.ends.size();
+                if (r.has_end) { r.end_crc = c.ends[s].crc; r.end_isize = c.ends[s].isize; }
+                if (n || r.has_end) segs_.push_back(r);
+                at0 = to;
+            }
+            return true;
+        }
         size_t at = 0;
         for (size_t s = 0; s <= c.ends.size(); s++) {
             const size_t to = s < c.ends.size() ? (size_t)c.ends[s].out_pos : c.bytes.size();
@@ -1047,7 +1138,7 @@ private:
     void stitch(size_t wait_for)
     {
         const uint64_t data_bits = (uint64_t)(end_ - base_) * 8;
-        while (stitch_next_ < chunks_.size() && stitch_next_ <= wait_for + (size_t)nthreads_ && !stitch_stop_) {
+        while (stitch_next_ < lim_ && stitch_next_ <= wait_for + (size_t)nthreads_ && !stitch_stop_) {
             const size_t k = stitch_next_;
             Chunk &c = *chunks_[k];
             const uint64_t from = k == 0 ? first_bit_ : stitched_end_bit_;
@@ -1113,6 +1204,10 @@ private:
             at_member_start_ = !c.ends.empty() && (size_t)c.ends.back().out_pos == (usable ? c.bytes.size() : c.bytes.size());
             stitch_next_ = k + 1;
             if (c.bad || c.at_eof || c.end_bit >= data_bits) stitch_stop_ = true;   // nothing behind this chunk
+            if (slice_ && (k + 1 == slice_end_ || stitch_stop_) && !end_state_.ready) {   // (a slice: what the owner of the next one needs - start_slice)
+                end_state_.end_bit = stitched_end_bit_; end_state_.member_start = at_member_start_;
+                end_state_.window = window_; end_state_.stop = stitch_stop_; end_state_.bad = c.bad; end_state_.ready = true;
+            }
         }
     }
 
@@ -1120,7 +1215,7 @@ private:
     bool next_chunk()
     {
         const size_t k = consume_next_;
-        if (k >= chunks_.size() || (stitch_stop_ && k >= stitch_next_)) { finished_ = true; return false; }
+        if (k >= lim_ || (stitch_stop_ && k >= stitch_next_)) { finished_ = true; return false; }
         {   // let the workers run ahead of the consumer (bounded)
             std::unique_lock<std::mutex> lk(mu_);
             limit_decode_ = std::max(limit_decode_, k + 1 + (size_t)nthreads_ * 2);

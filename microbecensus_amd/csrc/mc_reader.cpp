@@ -69,6 +69,15 @@ namespace {
 thread_local std::string r_err;
 thread_local int64_t t_range_lo = -1, t_range_hi = -1;   // mc_reader_open_range: the byte window of the ONE plain file the reader is opened on (-1: the whole file)
 thread_local int64_t t_bz_b0 = -1, t_bz_b1 = -1; thread_local int t_bz_kind = 0;   // mc_reader_open_bz2_part: the blocks [b0, b1) of the ONE .bz2 file the reader is opened on, and what a record of the file starts with
+// mc_reader_open_gz_part: the chunks [k0, k1) of the ONE .gz file the reader is opened on; what it learns from the owner of the slice in front
+// and tells the owner of the next one (mc_reader_gz_provide / mc_reader_gz_end_state), and the member CRCs it checks at the end (mc_reader_gz_finish)
+struct GzPartCtx {
+    std::mutex mu; std::condition_variable cv;
+    bool in_ready = false, in_fail = false, out_ready = false, out_fail = false;
+    mcgz::ParallelGz::SliceState in, out;
+    std::vector<mcgz::ParallelGz::SegRec> segs; size_t nsegs_own = 0;
+};
+thread_local int64_t t_gz_k0 = -1, t_gz_k1 = -1, t_gz_chunk = 0; thread_local int t_gz_kind = 0; thread_local GzPartCtx *t_gz_ctx = nullptr;
 thread_local bool t_peek = false;   // the caller will most likely stop after a few records (mc_quality_offset): no parallel inflate, small first regions
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -280,6 +289,8 @@ struct Stream {
                 if (!bz->open(path)) { delete bz; bz = nullptr; r_err = std::string("cannot open ") + path; return false; }
             }
             compressed = true;
+        } else if (t_gz_k0 >= 0) {
+            return open_gz_part(path);
         } else {
             int fd = ::open(path, O_RDONLY);
             if (fd < 0) { r_err = std::string("cannot open ") + path; return false; }
@@ -378,6 +389,62 @@ struct Stream {
         if (bz) { bz->close(); delete bz; bz = nullptr; }
         if (map && part_text.empty()) munmap((void *)map, map_n);
         map = nullptr;
+    }
+    // The chunks [k0, k1) of a .gz file as a window of its TEXT (mc_reader_open_gz_part; mc_pgzip.h start_slice): all of them - and one
+    // more - are decoded speculatively at once; when the owner of the slice in front has told where it ended and what the 32 KB in front of
+    // that are (slice 0 knows), the chunks are stitched, the owner of the next slice is told the same, and the text is read like the byte
+    // window of a plain file: the records that START in the text of the slice's own chunks, both ends moved to the first record start
+    // behind them by the rule of mc_reader_open_range.
+    bool open_gz_part(const char *path)
+    {
+        GzPartCtx *ctx = t_gz_ctx;
+        auto fail_out = [&](const std::string &m) { r_err = m; if (ctx) { std::unique_lock<std::mutex> lk(ctx->mu); ctx->out_fail = true; ctx->out_ready = true; ctx->cv.notify_all(); } return false; };
+        if (!ctx || !has_ext(path, ".gz")) return fail_out(std::string("a chunk range needs a .gz file: ") + path);
+        struct stat sb;
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 18) { if (fd >= 0) ::close(fd); return fail_out(std::string("cannot map ") + path); }
+        void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (m == MAP_FAILED) return fail_out(std::string("cannot map ") + path);
+        gzmap = (const uint8_t *)m; gzmap_n = (size_t)sb.st_size;
+        const size_t k0 = (size_t)t_gz_k0, k1 = (size_t)t_gz_k1;
+        pgz = new mcgz::ParallelGz(gzmap, gzmap_n, std::min(std::max(2, inflate_threads()), 32), (size_t)t_gz_chunk);
+        if (!pgz->start_slice(k0, k1)) return fail_out(std::string("not a gzip file the parallel reader takes, or no such chunks: ") + path);
+        const size_t nchunks = pgz->nchunks();
+        if (k0 > 0) {                                                  // where the slice in front ended (the decoding of this one is under way meanwhile)
+            std::unique_lock<std::mutex> lk(ctx->mu);
+            ctx->cv.wait(lk, [&] { return ctx->in_ready; });
+            if (ctx->in_fail) { lk.unlock(); return fail_out("the slice in front of this one failed"); }
+            pgz->set_state(ctx->in);
+        }
+        mcgz::ParallelGz::SliceState out;
+        const bool okst = pgz->end_state(out);
+        { std::unique_lock<std::mutex> lk(ctx->mu); ctx->out = out; ctx->out_fail = !okst; ctx->out_ready = true; ctx->cv.notify_all(); }
+        if (!okst) { r_err = std::string("damaged deflate data in ") + path; return false; }
+        size_t own = 0; bool own_set = false;
+        for (;;) {
+            if (!own_set && pgz->next_chunk_index() >= k1) { own = part_text.size(); ctx->nsegs_own = pgz->segs(); own_set = true; }
+            if (!pgz->read_chunk(part_text)) break;
+        }
+        if (!own_set) { own = part_text.size(); ctx->nsegs_own = pgz->segs(); }
+        if (pgz->slice_failed()) { r_err = std::string("EOFError: ") + pgz->slice_error() + " (" + path + ")"; return false; }
+        ctx->segs = pgz->seg_list();
+        delete pgz; pgz = nullptr;
+        munmap((void *)gzmap, gzmap_n); gzmap = nullptr;
+        map_n = part_text.size();
+        if (part_text.empty()) part_text.push_back(0);                 // (owned, even when empty: close() must not unmap it)
+        map = part_text.data();
+        const int kind = t_gz_kind;
+        const bool ends_here = out.stop || k1 >= nchunks;              // the data ends in this slice: its text runs to the end
+        const size_t s0 = k0 == 0 ? 0 : guess_start(map, 0, map_n, 1 << 30, kind, true);
+        size_t s1 = map_n;
+        if (!ends_here) {
+            s1 = guess_start(map, std::min(own, map_n), map_n, 1 << 30, kind, true);
+            if (s1 >= map_n && k1 + 1 < nchunks) { r_err = std::string("no record start within a chunk behind the range (a record longer than a chunk?): ") + path; return false; }
+        }
+        win = map + std::min(s0, map_n); vend = map + std::max(std::min(s0, map_n), s1); len = 0; ranged = true;
+        if (vend == win) at_end = true;
+        return true;
     }
     // The blocks [b0, b1) of a .bz2 file as a window of its TEXT (mc_reader_open_bz2_part): they are decoded - with two more blocks behind
     // them - into one buffer, which is then read like the byte window of a plain file: the records that START in the text of the rank's own
@@ -1165,6 +1232,7 @@ struct mc_reader {
     int64_t nreads = 0;
     int64_t range_lo = -1, range_hi = -1;                          // mc_reader_open_range
     int64_t bz_b0 = -1, bz_b1 = -1; int bz_kind = 0;               // mc_reader_open_bz2_part
+    int64_t gz_k0 = -1, gz_k1 = -1, gz_chunk = 0; int gz_kind = 0; std::unique_ptr<GzPartCtx> gz_ctx;   // mc_reader_open_gz_part
     double min_q = 0, mean_q = 0, max_unknown = 0;
     std::string fasta_out;
     uint8_t *reads = nullptr; size_t reads_cap = 0, reads_n = 0;   // anonymous mapping grown with mremap (no copies, no zero fill up front)
@@ -1300,6 +1368,86 @@ extern "C" int64_t mc_bz2_blocks(const char *path)
     return n;
 }
 
+// ---- a .gz file across the ranks of a multi-GPU run ------------------------------------------------------------------------------------
+// A gzip member cannot be ENTERED in the middle - every block may point 32 KB back - but it can be DECODED from the middle speculatively
+// (mc_pgzip.h: back-references into the unknown become markers).  So the file is cut into slices of chunks; every rank decodes its
+// slice at once; what is sequential is a chain of hand-overs along the slices - where the slice in front ended, and the 32 KB in front of
+// that (33 KB a hop) -, after which every rank replaces its markers and samples the records that start in its slice's text.
+//   mc_gz_chunks(path, chunk_bytes)            chunks of the file (as the parallel reader cuts it), or -1
+//   mc_reader_open_gz_part(path, k0, k1, ...)  the sampler on chunks [k0, k1); run it with mc_reader_start / mc_reader_join
+//   mc_reader_gz_provide(r, state, n)          what mc_reader_gz_end_state of the slice in front returned (n = 0: that slice failed); not for k0 = 0
+//   mc_reader_gz_end_state(r, out, cap)        waits until the slice is stitched; bytes written (<= 33 KB + 16), or -1
+//   mc_reader_gz_finish(r, crc_in, crc_out)    after mc_reader_join: checks the members that end in the slice, given CRC | length (12 bytes) of the
+//                                              open member's bytes in front of it (zeros for slice 0); 0, or -3 (gzip.open's "CRC check failed")
+extern "C" int64_t mc_gz_chunks(const char *path, int64_t chunk_bytes)
+{
+    if (!path || chunk_bytes < 4096) { r_err = "bad argument"; return -1; }
+    struct stat sb;
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 18) { if (fd >= 0) ::close(fd); r_err = std::string("cannot map ") + path; return -1; }
+    void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED) { r_err = std::string("cannot map ") + path; return -1; }
+    int64_t n = -1;
+    { mcgz::ParallelGz pz((const uint8_t *)m, (size_t)sb.st_size, 2, (size_t)chunk_bytes); if (pz.setup()) n = (int64_t)pz.nchunks(); else r_err = std::string("not a gzip file the parallel reader takes: ") + path; }
+    munmap(m, (size_t)sb.st_size);
+    return n;
+}
+extern "C" mc_reader *mc_reader_open_gz_part(const char *path, int64_t chunk_lo, int64_t chunk_hi, int64_t chunk_bytes, int32_t kind, int32_t read_len, int64_t nreads,
+                                             int32_t fastq, int32_t quality_offset, double min_quality, double mean_quality, double max_unknown)
+{
+    if (!path || chunk_lo < 0 || chunk_hi <= chunk_lo || chunk_bytes < 4096 || (kind != '@' && kind != '>')) { r_err = "mc_reader_open_gz_part: bad arguments"; return nullptr; }
+    const char *paths[1] = {path};
+    mc_reader *r = mc_reader_open(paths, 1, read_len, nreads, fastq, quality_offset, min_quality, mean_quality, max_unknown, 0, nullptr);
+    if (r) { r->gz_k0 = chunk_lo; r->gz_k1 = chunk_hi; r->gz_chunk = chunk_bytes; r->gz_kind = kind; r->gz_ctx.reset(new GzPartCtx()); }
+    return r;
+}
+static size_t gz_state_pack(const mcgz::ParallelGz::SliceState &st, uint8_t *out, size_t cap)
+{
+    const size_t need = 16 + st.window.size();
+    if (cap < need) return 0;
+    memcpy(out, &st.end_bit, 8);
+    out[8] = st.member_start; out[9] = st.stop; out[10] = st.bad; out[11] = 0;
+    const uint32_t wl = (uint32_t)st.window.size(); memcpy(out + 12, &wl, 4);
+    if (wl) memcpy(out + 16, st.window.data(), wl);
+    return need;
+}
+extern "C" int mc_reader_gz_provide(mc_reader *r, const uint8_t *state, int64_t n)
+{
+    if (!r || !r->gz_ctx) { r_err = "not a .gz part reader"; return -1; }
+    GzPartCtx &c = *r->gz_ctx;
+    std::unique_lock<std::mutex> lk(c.mu);
+    if (!state || n < 16) c.in_fail = true;
+    else {
+        uint32_t wl = 0; memcpy(&wl, state + 12, 4);
+        if ((int64_t)wl + 16 != n || wl > 32768) c.in_fail = true;
+        else { memcpy(&c.in.end_bit, state, 8); c.in.member_start = state[8] != 0; c.in.stop = state[9] != 0; c.in.bad = state[10] != 0; c.in.window.assign(state + 16, state + 16 + wl); c.in.ready = true; if (c.in.bad) c.in_fail = true; }
+    }
+    c.in_ready = true;
+    c.cv.notify_all();
+    return 0;
+}
+extern "C" int64_t mc_reader_gz_end_state(mc_reader *r, uint8_t *out, int64_t cap)
+{
+    if (!r || !r->gz_ctx || !out) { r_err = "not a .gz part reader"; return -1; }
+    GzPartCtx &c = *r->gz_ctx;
+    std::unique_lock<std::mutex> lk(c.mu);
+    c.cv.wait(lk, [&] { return c.out_ready; });
+    if (c.out_fail) { r_err = "the slice failed"; return -1; }
+    const size_t n = gz_state_pack(c.out, out, (size_t)cap);
+    if (!n) { r_err = "buffer too small"; return -1; }
+    return (int64_t)n;
+}
+extern "C" int mc_reader_gz_finish(mc_reader *r, const uint8_t *crc_in, uint8_t *crc_out)
+{
+    if (!r || !r->gz_ctx || !crc_in || !crc_out) { r_err = "not a .gz part reader"; return -1; }
+    uint32_t ci = 0, co = 0; uint64_t li = 0, lo = 0;
+    memcpy(&ci, crc_in, 4); memcpy(&li, crc_in + 4, 8);
+    if (!mcgz::ParallelGz::finish_crc(r->gz_ctx->segs, r->gz_ctx->nsegs_own, ci, li, &co, &lo)) { r_err = "BadGzipFile: CRC check failed"; return -3; }
+    memcpy(crc_out, &co, 4); memcpy(crc_out + 4, &lo, 8);
+    return 0;
+}
+
 extern "C" void mc_reader_close(mc_reader *r) { delete r; }
 
 static int64_t reader_run(mc_reader *r);
@@ -1356,7 +1504,8 @@ static int64_t reader_run(mc_reader *r)
     for (const std::string &path : r->paths) {
         t_range_lo = r->range_lo; t_range_hi = r->range_hi;        // (consumed by Stream::open on this thread)
         t_bz_b0 = r->bz_b0; t_bz_b1 = r->bz_b1; t_bz_kind = r->bz_kind;
-        struct BzPart { ~BzPart() { t_bz_b0 = t_bz_b1 = -1; } } bz_part_guard;
+        t_gz_k0 = r->gz_k0; t_gz_k1 = r->gz_k1; t_gz_chunk = r->gz_chunk; t_gz_kind = r->gz_kind; t_gz_ctx = r->gz_ctx.get();
+        struct BzPart { ~BzPart() { t_bz_b0 = t_bz_b1 = -1; t_gz_k0 = t_gz_k1 = -1; t_gz_ctx = nullptr; } } bz_part_guard;
         const int rc = walk_file(path, P, pool, [&](std::vector<Piece *> &order) -> bool {
             const int64_t kept0 = kept;
             bool full = false;

@@ -438,18 +438,32 @@ SLICE_BYTES = 256 << 20     # bytes of a file one rank samples per round (MC_DIS
 
 def sharded_sampling_usable(args):
     """Can every rank sample its own slices of the input?  Without -d (with it: stream_batches_sharded_dups), on plain regular files
-    (byte windows) and on .bz2 files all of whose streams check out (block ranges: the blocks of a bzip2 file are independent,
-    csrc/mc_pbzip2.h) - a .gz member cannot be entered in the middle -, and unless MC_DIST_SHARDED=0."""
+    (byte windows), on .bz2 files all of whose streams check out (block ranges: the blocks of a bzip2 file are independent,
+    csrc/mc_pbzip2.h) and on .gz files the parallel reader takes (chunk ranges: a member cannot be entered in the middle, but it can be
+    decoded from the middle speculatively - the ranks hand the 32 KB windows along, csrc/mc_pgzip.h start_slice), and unless
+    MC_DIST_SHARDED=0."""
     import os
     from . import _native
     if os.environ.get("MC_DIST_SHARDED") == "0" or args.get("filter_dups"):
         return False
     for p in args["seqfiles"]:
-        if p.endswith(".gz") or not os.path.isfile(p):
+        if not os.path.isfile(p):
+            return False
+        if p.endswith(".gz") and (os.environ.get("MC_DIST_GZ") == "0" or _native.gz_chunks(p, _gz_chunk_bytes()) <= 0):
             return False
         if p.endswith(".bz2") and _native.bz2_blocks(p) <= 0:
             return False
     return True
+
+
+def _gz_chunk_bytes():
+    """compressed bytes per chunk of a .gz file decoded across the ranks (MC_DIST_GZ_CHUNK: tests cut small files into many)"""
+    import os
+    try:
+        v = int(os.environ.get("MC_DIST_GZ_CHUNK", "0"))
+    except ValueError:
+        v = 0
+    return v if v >= 4096 else (1 << 20)
 
 
 def stream_batches_sharded(args, on_batch, device=None):
@@ -482,40 +496,86 @@ def stream_batches_sharded(args, on_batch, device=None):
         S = int(os.environ.get("MC_DIST_SLICE", "0")) or SLICE_BYTES
     except ValueError:
         S = SLICE_BYTES
-    # a round = `world` consecutive slices of one file: S bytes each of a plain file, KB blocks each of a .bz2 file (the same list on every rank)
+    # a round = `world` consecutive slices of one file: S bytes each of a plain file, KB blocks each of a .bz2 file, KC chunks each of a .gz
+    # file (the same list on every rank)
     KB = max(1, S // 900000)
+    GZC = _gz_chunk_bytes()
+    KC = max(1, min(32, S // GZC))
+    kind = "@" if fastq else ">"
     rounds = []
-    for p in args["seqfiles"]:
+    for fi, p in enumerate(args["seqfiles"]):
         if p.endswith(".bz2"):
             size = _native.bz2_blocks(p)
-            rounds += [(p, base, size, KB) for base in range(0, max(size, 1), KB * world)]
+            rounds += [(p, base, size, KB, fi) for base in range(0, max(size, 1), KB * world)]
+        elif p.endswith(".gz"):
+            size = _native.gz_chunks(p, GZC)
+            rounds += [(p, base, size, KC, fi) for base in range(0, max(size, 1), KC * world)]
         else:
             size = os.path.getsize(p)
-            rounds += [(p, base, size, S) for base in range(0, max(size, 1), S * world)]
+            rounds += [(p, base, size, S, fi) for base in range(0, max(size, 1), S * world)]
+    gz_store = _control_store() if any(p.endswith(".gz") for p in args["seqfiles"]) else None
 
-    def open_slice(p, lo, hi, cap):
+    def run_slice(p, lo, hi, cap, fi=0, state_in=None, publish=True):
+        """(reader, accepted reads, state of the slice in front - .gz only) for slice [lo, hi) of file p"""
+        if p.endswith(".gz"):
+            # the chain of a .gz file: slice i learns from slice i - 1 where that ended (and the 32 KB in front of it), tells slice i + 1 the same
+            # as soon as it knows - through the process group's store, from whichever thread -, and the members' CRCs follow the same way
+            i = lo // KC
+            rd = _native.Reader.on_gz_part(p, lo, hi, GZC, kind, L, max(1, cap), fastq, qoff, args["min_quality"], args["mean_quality"], args["max_unknown"])
+            n, done = 0, False
+            try:
+                rd.start()
+                if lo > 0:
+                    if state_in is None:
+                        state_in = _store_wait_get(gz_store, "s%d/%d" % (fi, i - 1))
+                    rd.gz_provide(state_in)
+                end = rd.gz_end_state()
+                if publish:
+                    gz_store.set("s%d/%d" % (fi, i), end or b"")
+                n = rd.join()
+                if publish:
+                    crc_in = _store_wait_get(gz_store, "c%d/%d" % (fi, i - 1)) if lo > 0 else bytes(12)
+                    if len(crc_in) != 12:
+                        raise RuntimeError("the slice in front of this one failed")
+                    gz_store.set("c%d/%d" % (fi, i), rd.gz_finish(crc_in))
+                done = True
+            finally:
+                if not done and publish:                               # whoever waits for this slice must not wait for ever
+                    for k in ("s%d/%d" % (fi, i), "c%d/%d" % (fi, i)):
+                        try:
+                            if not gz_store.check([k]):
+                                gz_store.set(k, b"")
+                        except Exception:                           # noqa: BLE001
+                            pass
+            return rd, n, state_in
         if p.endswith(".bz2"):
-            return _native.Reader.on_bz2_part(p, lo, hi, "@" if fastq else ">", L, max(1, cap), fastq, qoff, args["min_quality"], args["mean_quality"], args["max_unknown"])
-        return _native.Reader.on_range(p, lo, hi, L, max(1, cap), fastq, qoff, args["min_quality"], args["mean_quality"], args["max_unknown"])
+            rd = _native.Reader.on_bz2_part(p, lo, hi, kind, L, max(1, cap), fastq, qoff, args["min_quality"], args["mean_quality"], args["max_unknown"])
+        else:
+            rd = _native.Reader.on_range(p, lo, hi, L, max(1, cap), fastq, qoff, args["min_quality"], args["mean_quality"], args["max_unknown"])
+        return rd, rd.run(), None
 
     def sample(j, cap):
-        p, base, size, step = rounds[j]
+        p, base, size, step, fi = rounds[j]
         lo = min(size, base + rank * step)
         hi = min(size, lo + step)
-        box = {}
+        box = {"fi": fi}
 
         def work():
             try:
                 if hi > lo:
-                    rd = open_slice(p, lo, hi, cap)
-                    box["rd"] = rd
-                    box["n"] = rd.run()
+                    try:
+                        rd, n, st_in = run_slice(p, lo, hi, cap, fi)
+                    finally:
+                        pass
+                    box["rd"], box["n"], box["state_in"] = rd, n, st_in
                     box["st"] = rd.stats()
                 else:
                     box["n"], box["st"] = 0, {"too_short": 0, "low_qual": 0, "records": 0, "bases": 0, "ragged_end": 0, "exhausted": 1}
             except BaseException as e:                             # noqa: BLE001
-                if p.endswith(".bz2") and isinstance(e, RuntimeError) and not isinstance(e, _native.ReferenceError_):
-                    box["n"], box["st"] = 0, {"too_short": 0, "low_qual": 0, "records": 0, "bases": 0, "ragged_end": 1, "exhausted": 0}   # (no record start near a block boundary: the sampler on rank 0 decides)
+                if p.endswith((".bz2", ".gz")) and (isinstance(e, RuntimeError) or p.endswith(".gz")):
+                    # (no record start near a block / chunk boundary, a slice that does not decode, a CRC that does not match: the sampler on
+                    # rank 0 decides - and reports what the reference would)
+                    box["n"], box["st"] = 0, {"too_short": 0, "low_qual": 0, "records": 0, "bases": 0, "ragged_end": 1, "exhausted": 0}
                 else:
                     box["err"] = e
         th = threading.Thread(target=work, daemon=True)
@@ -545,12 +605,13 @@ def stream_batches_sharded(args, on_batch, device=None):
             keep = max(0, min(n_acc, nreads - prefix))
             st = box["st"]
             if keep > 0 and prefix + n_acc >= nreads:              # the head-take ends in this slice: the counters stop with its last read
-                rd2 = open_slice(p, lo, hi, keep)
+                rd2 = None
                 try:
-                    rd2.run()
+                    rd2, _, _ = run_slice(p, lo, hi, keep, box["fi"], state_in=box.get("state_in"), publish=False)
                     st = rd2.stats()
                 finally:
-                    rd2.close()
+                    if rd2 is not None:
+                        rd2.close()
             if keep > 0 or prefix < nreads:                        # (a slice behind the end of the head-take was never looked at by the reference)
                 for k in ("too_short", "low_qual", "records", "bases"):
                     stats[k] += int(st[k])

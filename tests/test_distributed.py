@@ -190,12 +190,25 @@ def test_every_rank_samples_its_own_slices(tmp_path, world):
         "bz2_streams_take": dict(base, seqfiles=[plain["example3.fq.bz2"]], read_length=100, nreads=6000, file_type="fastq", quality_offset=32),
         "bz2_and_plain": dict(base, seqfiles=[plain["metagenome.fa.bz2"], plain["metagenome.fa.gz"]], read_length=100, nreads=100000, file_type="fasta", quality_offset=None),
     })
+    # .gz: a member cannot be entered in the middle, but it can be decoded from the middle speculatively - every rank decodes its slice of chunks
+    # at once, the 32 KB windows are handed along the slices through the group's store, the members' CRCs follow (round 6).  Chunks of 64 KB
+    # here, two per rank and round: the reference's own example (one member), the paired library with the take in the second file, a file
+    # of three members, the 300 bp library with -q 20
+    gz3 = str(tmp_path / "example3.fq.gz")
+    open(gz3, "wb").write(gzip.compress(ex[:cut], 1) + gzip.compress(b"") + gzip.compress(ex[cut:], 9))
+    cases.update({
+        "gz_all": dict(base, seqfiles=[os.path.join(inp, "example.fq.gz")], read_length=100, nreads=10**9, file_type="fastq", quality_offset=32),
+        "gz_pair_take": dict(base, seqfiles=[os.path.join(inp, "c4_pair_1.fq.gz"), os.path.join(inp, "c4_pair_2.fq.gz")], read_length=150, nreads=15000, file_type="fastq", quality_offset=32),
+        "gz_members_take": dict(base, seqfiles=[gz3], read_length=100, nreads=6000, file_type="fastq", quality_offset=32),
+        "gz_q20": dict(base, seqfiles=[os.path.join(inp, "c5_300bp.fq.gz")], read_length=300, nreads=10**9, file_type="fastq", quality_offset=32, min_quality=20),
+        "gz_and_plain": dict(base, seqfiles=[os.path.join(inp, "metagenome.fa.gz"), plain["metagenome.fa.gz"]], read_length=100, nreads=100000, file_type="fasta", quality_offset=None),
+    })
     cj = tmp_path / "cases.json"
     cj.write_text(json.dumps(cases))
     worker = tmp_path / "shard.py"
     worker.write_text(SHARD_WORKER)
     out = tmp_path / "shard.json"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MC_DIST_SLICE="150000")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MC_DIST_SLICE="150000", MC_DIST_GZ_CHUNK="65536")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                            "--master-port", str(29521 + world), str(worker), REPO, str(cj), str(out)], env=env, timeout=900)
     res = json.load(open(out))

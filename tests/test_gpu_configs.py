@@ -37,7 +37,7 @@ def _args(case):
 
 
 # (the RCCL test first: a multi-GPU box that runs this file reaches it whatever happens later)
-def _two_ranks(tmp_path, backend, port, world=2, batch="3000"):
+def _two_ranks(tmp_path, backend, port, world=2, batch="3000", gz_sharded=False):
     worker = tmp_path / "w.py"
     worker.write_text(r'''
 import json, os, sys
@@ -60,12 +60,15 @@ dist.all_gather_object(got, D.run_pipeline_distributed.last_batches)
 if dist.get_rank() == 0:
     tr = D.run_pipeline_distributed.last_trace
     json.dump({"est": est, "sampled": args["sampled_reads"], "L": args["read_length"], "world": dist.get_world_size(), "backend": dist.get_backend(),
-               "deals": sum(1 for t in tr if t[0] == "deal"), "batches_per_rank": got}, open(sys.argv[2], "w"))
+               "deals": -1 if tr is None else sum(1 for t in tr if t[0] == "deal"), "batches_per_rank": got}, open(sys.argv[2], "w"))
 dist.barrier()
 dist.destroy_process_group()
 ''')
     out = tmp_path / "o.json"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MC_DIST_BATCH=batch)   # 20,000 reads dealt in 7 batches of 3,000
+    # MC_DIST_GZ=0: rank 0 samples the .gz files and DEALS batches (20,000 reads in 7 batches of 3,000); gz_sharded: every rank decodes its own chunks
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MC_DIST_BATCH=batch, MC_DIST_GZ="1" if gz_sharded else "0")
+    if gz_sharded:
+        env.update(MC_DIST_GZ_CHUNK="65536", MC_DIST_SLICE="150000")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                            "--master-port", str(port), str(worker), REPO, str(out), backend], env=env, timeout=900)
     return json.load(open(out))
@@ -90,6 +93,17 @@ def test_config4_shape_two_ranks_gloo(tmp_path):
     res = _two_ranks(tmp_path, "gloo", 29541)
     assert res["world"] == 2 and res["sampled"] == g["sampled_reads"] and res["L"] == 150
     assert res["deals"] == 7                                      # streamed: 3,000-read batches dealt round robin while the sampler runs
+    assert abs(res["est"] - g["est_ags"]) <= 1e-9 * g["est_ags"]
+
+
+def test_config4_shape_two_ranks_gz_decoded_on_both_gloo(tmp_path):
+    """The same paired .gz library with a sampler on EVERY rank (round 6): the ranks decode their own chunks of the gzip members (64 KB chunks,
+    two per rank and round here), hand the 32 KB windows along, sample the records that start in their text - nothing is dealt by rank 0 -
+    and the reduced sums give the reference's AGS."""
+    g = json.load(open(os.path.join(GOLD, "c4_paired.json")))
+    res = _two_ranks(tmp_path, "gloo", 29555, gz_sharded=True)
+    assert res["world"] == 2 and res["sampled"] == g["sampled_reads"] and res["L"] == 150 and res["deals"] == -1
+    assert min(res["batches_per_rank"]) >= 1
     assert abs(res["est"] - g["est_ags"]) <= 1e-9 * g["est_ags"]
 
 
