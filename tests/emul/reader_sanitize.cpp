@@ -62,6 +62,31 @@ int main(int argc, char **argv)
         }
         printf("bz2 parts: blocks %ld accepted %ld\n", nb, tot);
     }
+    {   // a .gz in three slices of chunks: all decode at once, the windows go along the chain, the CRCs at the end
+        const long CB = 65536;
+        long nc = mc_gz_chunks(gz, CB);
+        mc_reader *r[3] = {nullptr, nullptr, nullptr};
+        long tot = 0;
+        int used = 0;
+        for (int w = 0; w < 3 && nc >= 3; w++) {
+            r[w] = mc_reader_open_gz_part(gz, nc * w / 3, nc * (w + 1) / 3, CB, '@', L, 1L << 40, 1, 33, 20, -5, 100);
+            if (!r[w] || mc_reader_start(r[w]) != 0) { printf("gz part %d: %s\n", w, mc_reader_last_error()); break; }
+            used++;
+        }
+        std::vector<uint8_t> st(32768 + 64);
+        for (int w = 0; w + 1 < used; w++) {
+            long n = mc_reader_gz_end_state(r[w], st.data(), (long)st.size());
+            mc_reader_gz_provide(r[w + 1], st.data(), n > 0 ? n : 0);
+        }
+        uint8_t crc[12] = {0}, crc2[12];
+        for (int w = 0; w < used; w++) {
+            long n = mc_reader_join(r[w]); tot += n > 0 ? n : 0;
+            if (mc_reader_gz_finish(r[w], crc, crc2) != 0) printf("gz finish %d: %s\n", w, mc_reader_last_error());
+            for (int i = 0; i < 12; i++) crc[i] = crc2[i];
+        }
+        for (int w = 0; w < 3; w++) if (r[w]) mc_reader_close(r[w]);
+        printf("gz parts: chunks %ld accepted %ld\n", nc, tot);
+    }
     printf("count_bases %ld qoff %d\n", (long)mc_count_bases(p3, 1), mc_quality_offset(gz));
     return 0;
 }
