@@ -86,6 +86,45 @@ def test_config4_shape_two_ranks_rccl(tmp_path):
     assert abs(res["est"] - g["est_ags"]) <= 1e-9 * g["est_ags"]
 
 
+def test_rccl_first_contact_on_one_gpu(tmp_path):
+    """What a one-GPU box can show of RCCL before the driver's node runs the two-rank test above: the library of this image loads in a
+    rank process (HSA_ENABLE_IPC_MODE_LEGACY=0), a communicator of world size 1 forms on the GPU, the all_reduce the product issues -
+    int64 SUM over the per-family accumulator vector, in HBM - returns the vector, and run_pipeline_distributed under backend "nccl"
+    (device tensors, eng.attach path switched on) gives the reference's AGS for the paired library."""
+    worker = tmp_path / "w1.py"
+    worker.write_text(r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch
+import torch.distributed as dist
+from microbecensus_amd import distributed as D, _native
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+nf = len(_native.load_model()["families"])
+rng = np.random.default_rng(5)
+acc = (rng.integers(0, 1 << 40, nf), rng.integers(0, 1 << 50, nf), rng.integers(0, 1 << 40, (nf, D.MAX_TARGET_LEN)))
+flat = np.concatenate([a.ravel() for a in acc]).astype(np.int64)
+t = torch.from_numpy(flat).to("cuda:0")
+dist.all_reduce(t, op=dist.ReduceOp.SUM)
+same = bool((t.cpu().numpy() == flat).all())
+inp = os.path.join(sys.argv[1], "tests", "golden", "inputs")
+est, args = D.run_pipeline_distributed({"seqfiles": [os.path.join(inp, "c4_pair_1.fq.gz"), os.path.join(inp, "c4_pair_2.fq.gz")], "nreads": 20000}, device=0)
+json.dump({"same": same, "words": int(flat.size), "est": est, "sampled": args["sampled_reads"], "backend": dist.get_backend(),
+           "version": ".".join(str(v) for v in torch.cuda.nccl.version())}, open(sys.argv[2], "w"))
+dist.barrier()
+dist.destroy_process_group()
+''')
+    out = tmp_path / "o1.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    subprocess.check_call([sys.executable, str(worker), REPO, str(out)], env=env, timeout=900)
+    res = json.load(open(out))
+    g = json.load(open(os.path.join(GOLD, "c4_paired.json")))
+    assert res["backend"] == "nccl" and res["same"] and res["words"] > 1000, res
+    assert res["sampled"] == g["sampled_reads"] and abs(res["est"] - g["est_ags"]) <= 1e-9 * g["est_ags"]
+    print("RCCL", res["version"])
+
+
 def test_config4_shape_two_ranks_gloo(tmp_path):
     """The paired library given as `a,b` through run_pipeline_distributed with two ranks (both on this box's GPU, gloo): rank 0
     samples and deals batches to the two ranks while it samples, the reduced per-family sums give the reference's AGS for the same pair."""
