@@ -420,6 +420,36 @@ struct ByteBuf {
     const uint8_t *end() const { return p + n; }
 };
 
+// Buffers that outlive one reader: the slices of a file (ParallelGz::start_slice) are read by one reader each, one after the other, and
+// every slice decodes ALL its chunks at once - 33 chunks x 16 MB of fresh pages per slice are 135,000 page faults from a dozen threads
+// that queue up in the kernel.  A reader hands what it holds to the pool when it closes; the pool lives as long as a reader holds it
+// (the next slice's reader is opened before this one's is closed).
+struct SharedBufs {
+    enum { MAX = 160 };
+    std::mutex mu;
+    std::vector<std::unique_ptr<SymBuf>> sym;
+    std::vector<ByteBuf> bytes;
+    ~SharedBufs()
+    {   // (the last reader of a run closes: 160 buffers of 16 MB are 100 ms of munmap on the thread the caller waits for - not there)
+        if (sym.empty() && bytes.empty()) return;
+        auto *a = new std::vector<std::unique_ptr<SymBuf>>(std::move(sym));
+        auto *b = new std::vector<ByteBuf>(std::move(bytes));
+        try { std::thread([a, b] { delete a; delete b; }).detach(); } catch (...) { delete a; delete b; }
+    }
+    static std::shared_ptr<SharedBufs> get()
+    {
+        static std::mutex m; static std::weak_ptr<SharedBufs> w;
+        std::unique_lock<std::mutex> lk(m);
+        std::shared_ptr<SharedBufs> s = w.lock();
+        if (!s) { s = std::make_shared<SharedBufs>(); w = s; }
+        return s;
+    }
+    void give(SymBuf &b) { if (!b.cap) return; std::unique_lock<std::mutex> lk(mu); if (sym.size() < MAX) { sym.emplace_back(new SymBuf()); sym.back()->swap(b); b.n = 0; sym.back()->n = 0; return; } lk.unlock(); b.drop(); }
+    void give(ByteBuf &b) { if (!b.capacity()) return; std::unique_lock<std::mutex> lk(mu); if (bytes.size() < MAX) { bytes.emplace_back(); bytes.back().swap(b); bytes.back().clear(); return; } lk.unlock(); b.drop(); }
+    bool take(SymBuf &b) { std::unique_lock<std::mutex> lk(mu); if (sym.empty()) return false; b.swap(*sym.back()); sym.pop_back(); b.n = 0; return true; }
+    bool take(ByteBuf &b) { std::unique_lock<std::mutex> lk(mu); if (bytes.empty()) return false; b.swap(bytes.back()); bytes.pop_back(); b.clear(); return true; }
+};
+
 struct Chunk {
     uint64_t nominal_bit = 0;                                       // where the search for its first block started
     uint64_t start_bit = 0, end_bit = 0;                            // first block decoded / first bit behind the last one
@@ -825,6 +855,11 @@ public:
     ~ParallelGz()
     {
         stop();
+        if (shared_) {                                                  // (a slice: what this reader holds goes to the next one)
+            for (auto &c : chunks_) { shared_->give(c->sym); shared_->give(c->bytes); }
+            for (auto &b : pool_sym_) shared_->give(*b);
+            for (auto &b : pool_bytes_) shared_->give(b);
+        }
         if (getenv("MC_PGZ_DEBUG")) fprintf(stderr, "pgzip: %zu chunks: %zu speculative, %zu sequential (%zu of them had found no start), %zu skipped; %.1f %% of the speculative output decoded as plain bytes; worker seconds: decode %.3f, markers %.3f, crc %.3f; consumer: sequential decode %.3f, copies to the reader %.3f, waiting for chunks %.3f\n",
                                             chunks_.size(), n_spec_, n_seq_, n_notfound_, n_skip_, 100.0 * (double)b_plain_ / (double)(b_spec_ ? b_spec_ : 1), t_decode_.load() * 1e-9, t_resolve_.load() * 1e-9, t_crc_.load() * 1e-9, t_seq_ * 1e-9, t_copy_ * 1e-9, t_wait_ * 1e-9);
     }
@@ -870,6 +905,7 @@ public:
     {
         if (!setup() || k0 >= k1 || k1 > chunks_.size()) return false;
         slice_ = true; slice_end_ = k1; lim_ = std::min(chunks_.size(), k1 + 1);
+        shared_ = SharedBufs::get();
         consume_next_ = stitch_next_ = k0; next_decode_ = k0 == 0 ? 1 : k0; limit_decode_ = lim_;
         state_ready_ = k0 == 0;
         for (int i = 0; i < nthreads_; i++) workers_.emplace_back([this] { work(); });
@@ -918,6 +954,18 @@ public:
         if (!next_chunk()) return false;
         if (cur_ && cur_failed_) return false;
         if (cur_) dst.insert(dst.end(), cur_->bytes.data(), cur_->bytes.data() + cur_->bytes.size());
+        return true;
+    }
+
+    // the next chunk's bytes where they lie (valid until the next call; n = 0 for a chunk the one in front ran over); false as read_chunk
+    bool next_chunk_view(const uint8_t **p, size_t *n)
+    {
+        if (cur_) { release(cur_index_); cur_ = nullptr; }
+        *p = nullptr; *n = 0;
+        if (finished_) return false;
+        if (!next_chunk()) return false;
+        if (cur_ && cur_failed_) return false;
+        if (cur_) { *p = cur_->bytes.data(); *n = cur_->bytes.size(); }
         return true;
     }
 
@@ -975,6 +1023,7 @@ private:
     bool finished_ = false, failed_ = false; std::string err_;
     size_t lim_ = 0;                                                // chunks [.., lim_) are decoded (all of them; a slice: its own and one more)
     bool slice_ = false, state_ready_ = true; size_t slice_end_ = 0; SliceState end_state_; std::vector<SegRec> segs_;
+    std::shared_ptr<SharedBufs> shared_;
 
     void stop()
     {
@@ -1018,6 +1067,7 @@ private:
             std::unique_lock<std::mutex> lk(mu_);
             if (pool_bytes_.size() < 4 * (size_t)nthreads_) { pool_bytes_.emplace_back(); pool_bytes_.back().swap(c.bytes); }
         }
+        if (shared_) shared_->give(c.bytes);
         c.bytes.drop();
     }
     void recycle_sym(Chunk &c)
@@ -1026,6 +1076,7 @@ private:
         std::unique_lock<std::mutex> lk(mu_);
         if (pool_sym_.size() < 4 * (size_t)nthreads_) { pool_sym_.emplace_back(new SymBuf()); pool_sym_.back()->swap(c.sym); c.sym.n = 0; return; }
         lk.unlock();
+        if (shared_) shared_->give(c.sym);
         c.sym.drop();
     }
     void take_buffers(Chunk &c, bool sym)
@@ -1033,6 +1084,11 @@ private:
         std::unique_lock<std::mutex> lk(mu_);
         if (sym && !c.sym.cap && !pool_sym_.empty()) { c.sym.swap(*pool_sym_.back()); pool_sym_.pop_back(); c.sym.n = 0; }
         if (!c.bytes.capacity() && !pool_bytes_.empty()) { c.bytes.swap(pool_bytes_.back()); pool_bytes_.pop_back(); c.bytes.clear(); }
+        lk.unlock();
+        if (shared_) {
+            if (sym && !c.sym.cap) shared_->take(c.sym);
+            if (!c.bytes.capacity()) shared_->take(c.bytes);
+        }
     }
 
     void fail(const std::string &m) { failed_ = true; finished_ = true; err_ = m; }
@@ -1156,6 +1212,7 @@ private:
             }
             bool usable = k > 0 && c.found && c.start_bit == from && !(c.starts_member && !at_member_start_);
             if (getenv("MC_PGZ_DEBUG2")) fprintf(stderr, "chunk %zu nominal %llu from %llu found %d start %llu member %d at_member_start %d\n", k, (unsigned long long)c.nominal_bit, (unsigned long long)from, (int)c.found, (unsigned long long)c.start_bit, (int)c.starts_member, (int)at_member_start_);
+            const size_t stat_total = c.total, stat_ns = c.sym.size();      // (read here: once the job below is queued, a worker owns the symbols)
             if (usable) {
                 // the window behind this chunk needs its last 32 KB only: replaced here; the rest (and the CRC) is a job
                 const size_t n = c.total, ns = c.sym.size();                 // the first ns symbols may hold markers, the rest are bytes already
@@ -1187,7 +1244,7 @@ private:
                     cv_work_.notify_all();
                 }
             }
-            if (usable) { n_spec_++; b_spec_ += c.total; b_plain_ += c.total - c.sym.size(); } else { n_seq_++; if (k > 0 && !c.found) n_notfound_++; }
+            if (usable) { n_spec_++; b_spec_ += stat_total; b_plain_ += stat_total - stat_ns; } else { n_seq_++; if (k > 0 && !c.found) n_notfound_++; }
             if (!usable) {                                               // the sequential path: from the known position with the known window
                 recycle_sym(c);
                 if (k == 0) take_buffers(c, false);

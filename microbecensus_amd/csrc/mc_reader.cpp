@@ -380,9 +380,15 @@ struct Stream {
             { std::unique_lock<std::mutex> lk(mu); stop = true; cv.notify_all(); }
             th.join();
         }
+        const bool gp_t = gp_on && getenv("MC_READER_TIMING");
+        const double c0 = gp_t ? now() : 0;
+        if (pgz) gz_part_collect();
+        const double c1 = gp_t ? now() : 0;
         if (pgz) { delete pgz; pgz = nullptr; }
+        const double c2 = gp_t ? now() : 0;
         if (sgz) { delete sgz; sgz = nullptr; }
         if (gzmap) { munmap((void *)gzmap, gzmap_n); gzmap = nullptr; }
+        if (gp_t) fprintf(stderr, "gz part [%zu, %zu): rest of the chunks %.3f s, workers joined and buffers handed on %.3f s, unmapped %.3f s\n", gp_k0, gp_k1, c1 - c0, c2 - c1, now() - c2);
         if (gz) { gzclose(gz); gz = nullptr; }
         if (pbz) { delete pbz; pbz = nullptr; }
         if (bzmap) { munmap((void *)bzmap, bzmap_n); bzmap = nullptr; }
@@ -421,30 +427,69 @@ struct Stream {
         const bool okst = pgz->end_state(out);
         { std::unique_lock<std::mutex> lk(ctx->mu); ctx->out = out; ctx->out_fail = !okst; ctx->out_ready = true; ctx->cv.notify_all(); }
         if (!okst) { r_err = std::string("damaged deflate data in ") + path; return false; }
-        size_t own = 0; bool own_set = false;
-        for (;;) {
-            if (!own_set && pgz->next_chunk_index() >= k1) { own = part_text.size(); ctx->nsegs_own = pgz->segs(); own_set = true; }
-            if (!pgz->read_chunk(part_text)) break;
-        }
-        if (!own_set) { own = part_text.size(); ctx->nsegs_own = pgz->segs(); }
-        if (pgz->slice_failed()) { r_err = std::string("EOFError: ") + pgz->slice_error() + " (" + path + ")"; return false; }
-        ctx->segs = pgz->seg_list();
-        delete pgz; pgz = nullptr;
-        munmap((void *)gzmap, gzmap_n); gzmap = nullptr;
-        map_n = part_text.size();
-        if (part_text.empty()) part_text.push_back(0);                 // (owned, even when empty: close() must not unmap it)
-        map = part_text.data();
-        const int kind = t_gz_kind;
-        const bool ends_here = out.stop || k1 >= nchunks;              // the data ends in this slice: its text runs to the end
-        const size_t s0 = k0 == 0 ? 0 : guess_start(map, 0, map_n, 1 << 30, kind, true);
-        size_t s1 = map_n;
-        if (!ends_here) {
-            s1 = guess_start(map, std::min(own, map_n), map_n, 1 << 30, kind, true);
-            if (s1 >= map_n && k1 + 1 < nchunks) { r_err = std::string("no record start within a chunk behind the range (a record longer than a chunk?): ") + path; return false; }
-        }
-        win = map + std::min(s0, map_n); vend = map + std::max(std::min(s0, map_n), s1); len = 0; ranged = true;
-        if (vend == win) at_end = true;
+        // the text is not collected: it is read like any inflated stream (extend -> gz_part_read), the resolve jobs of the workers and
+        // the parser's threads running side by side - from the first record start in the slice's first chunk to the first one in the
+        // chunk behind the slice (both by guess_start on that ONE chunk's text: the neighbour computes the same place from the same bytes)
+        gp_on = true; gp_k0 = k0; gp_k1 = k1; gp_nchunks = nchunks; gp_kind = t_gz_kind; gp_ctx = ctx; gp_path = path;
+        gp_ends_here = out.stop || k1 >= nchunks;                      // the data ends in this slice: its text runs to the end
+        compressed = true;
         return true;
+    }
+    bool gp_on = false, gp_ends_here = false, gp_own_set = false, gp_last = false, gp_done = false, gp_collected = false;
+    size_t gp_k0 = 0, gp_k1 = 0, gp_nchunks = 0; int gp_kind = 0; GzPartCtx *gp_ctx = nullptr; std::string gp_path;
+    const uint8_t *gp_p = nullptr; size_t gp_at = 0, gp_end = 0;
+    bool gz_part_next(bool *bad, std::string *msg)
+    {
+        const size_t idx = pgz->next_chunk_index();
+        if (!gp_own_set && idx >= gp_k1) { gp_ctx->nsegs_own = pgz->segs(); gp_own_set = true; }
+        if (gp_last) { gp_done = true; return false; }
+        size_t n = 0;
+        if (!pgz->next_chunk_view(&gp_p, &n)) {
+            gp_done = true;
+            if (pgz->slice_failed()) { *bad = true; *msg = pgz->slice_error(); }
+            return false;
+        }
+        gp_at = 0; gp_end = n;
+        if (idx == gp_k0 && gp_k0 > 0) {
+            gp_at = std::min(guess_start(gp_p, 0, n, 1 << 30, gp_kind, true), n);
+            if (gp_at >= n && gp_k0 + 1 < gp_nchunks && !gp_ends_here) { gp_done = true; *bad = true; *msg = "no record start within the first chunk of the range (a record longer than a chunk?)"; return false; }
+        }
+        if (idx >= gp_k1) {                                              // the chunk behind the slice: up to the first record start in it
+            gp_last = true;
+            if (!gp_ends_here) {
+                const size_t s1 = guess_start(gp_p, 0, n, 1 << 30, gp_kind, true);
+                if (s1 >= n && gp_k1 + 1 < gp_nchunks) { gp_done = true; *bad = true; *msg = "no record start within a chunk behind the range (a record longer than a chunk?)"; return false; }
+                gp_end = std::min(s1, n);
+            }
+        }
+        return true;
+    }
+    int gz_part_read(uint8_t *dst, int n, bool *bad, std::string *msg)
+    {
+        int got = 0;
+        *bad = false;
+        while (got < n) {
+            if (gp_at < gp_end) {
+                const size_t k = std::min<size_t>((size_t)(n - got), gp_end - gp_at);
+                memcpy(dst + got, gp_p + gp_at, k);
+                gp_at += k; got += (int)k;
+                continue;
+            }
+            if (gp_done || !gz_part_next(bad, msg)) break;
+        }
+        return got;
+    }
+    // after the sampling (which may have stopped early: -n): the rest of the slice's chunks pass by for their CRCs, and the segments go
+    // to where mc_reader_gz_finish finds them
+    void gz_part_collect()
+    {
+        if (!gp_on || gp_collected || !pgz) return;
+        gp_collected = true;
+        bool bad = false; std::string msg;
+        gp_at = gp_end = 0;
+        while (!gp_done && gz_part_next(&bad, &msg)) gp_at = gp_end = 0;
+        if (!gp_own_set) { gp_ctx->nsegs_own = pgz->segs(); gp_own_set = true; }
+        gp_ctx->segs = pgz->seg_list();
     }
     // The blocks [b0, b1) of a .bz2 file as a window of its TEXT (mc_reader_open_bz2_part): they are decoded - with two more blocks behind
     // them - into one buffer, which is then read like the byte window of a plain file: the records that START in the text of the rank's own
@@ -573,7 +618,7 @@ struct Stream {
             }
             bool bad = false;
             std::string msg;
-            const int got = pgz->read(buf.data() + buf_at + len, (int)n, &bad, &msg);
+            const int got = gp_on ? gz_part_read(buf.data() + buf_at + len, (int)n, &bad, &msg) : pgz->read(buf.data() + buf_at + len, (int)n, &bad, &msg);
             if (got > 0) len += (size_t)got;
             if (got < (int)n) { at_end = true; failed = bad; prod_err = bad; prod_msg = msg; }
             t_ext_copy += now() - c0;

@@ -128,6 +128,18 @@ def _store_wait_get(store, key):
                 raise
 
 
+def _store_poll_get(store, key):
+    """The same for a key that several threads of a rank may wait for while others set theirs (the hand-overs of the .gz slices: two rounds
+    are under way at a time): a TCPStore client serves one call at a time, so a thread blocked in wait() would hold up the set() of the
+    thread beside it - whose key the next rank is waiting for - until its time-out.  check() returns at once."""
+    import time
+    nap = 0.0002
+    while not store.check([key]):
+        time.sleep(nap)
+        nap = min(0.002, nap * 1.2)
+    return store.get(key)
+
+
 class _Dealer:
     """Rank 0's side of the streamed multi-GPU pipeline: the native sampler runs on its own thread (mc_reader_start); this
     thread fetches batches of accepted reads as they appear (mc_reader_fetch, straight into pinned memory) and deals every
@@ -481,7 +493,9 @@ def stream_batches_sharded(args, on_batch, device=None):
     (its sampler raised, or on_batch - the search - did): stats then carries the agreed message under "error" and the caller
     raises on every rank instead of searching everything a second time."""
     import os
+    import sys
     import threading
+    import time
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -514,8 +528,9 @@ def stream_batches_sharded(args, on_batch, device=None):
             size = os.path.getsize(p)
             rounds += [(p, base, size, S, fi) for base in range(0, max(size, 1), S * world)]
     gz_store = _control_store() if any(p.endswith(".gz") for p in args["seqfiles"]) else None
+    trace_on, t_zero = bool(os.environ.get("MC_DIST_TRACE")), time.time()
 
-    def run_slice(p, lo, hi, cap, fi=0, state_in=None, publish=True):
+    def run_slice(p, lo, hi, cap, fi=0, state_in=None, publish=True, on_published=None):
         """(reader, accepted reads, state of the slice in front - .gz only) for slice [lo, hi) of file p"""
         if p.endswith(".gz"):
             # the chain of a .gz file: slice i learns from slice i - 1 where that ended (and the 32 KB in front of it), tells slice i + 1 the same
@@ -523,22 +538,30 @@ def stream_batches_sharded(args, on_batch, device=None):
             i = lo // KC
             rd = _native.Reader.on_gz_part(p, lo, hi, GZC, kind, L, max(1, cap), fastq, qoff, args["min_quality"], args["mean_quality"], args["max_unknown"])
             n, done = 0, False
+            tr = [time.time()] if trace_on else None
             try:
                 rd.start()
                 if lo > 0:
                     if state_in is None:
-                        state_in = _store_wait_get(gz_store, "s%d/%d" % (fi, i - 1))
+                        state_in = _store_poll_get(gz_store, "s%d/%d" % (fi, i - 1))
                     rd.gz_provide(state_in)
+                if tr: tr.append(time.time())
                 end = rd.gz_end_state()
                 if publish:
                     gz_store.set("s%d/%d" % (fi, i), end or b"")
+                if tr: tr.append(time.time())
+                if on_published is not None:                       # the slice is decoded, its text is being sampled: the next round's decoding may start beside that
+                    on_published()
                 n = rd.join()
+                if tr: tr.append(time.time())
                 if publish:
-                    crc_in = _store_wait_get(gz_store, "c%d/%d" % (fi, i - 1)) if lo > 0 else bytes(12)
+                    crc_in = _store_poll_get(gz_store, "c%d/%d" % (fi, i - 1)) if lo > 0 else bytes(12)
                     if len(crc_in) != 12:
                         raise RuntimeError("the slice in front of this one failed")
                     gz_store.set("c%d/%d" % (fi, i), rd.gz_finish(crc_in))
                 done = True
+                if tr:                                             # MC_DIST_TRACE: when the slice was opened, had its predecessor's state, was decoded, sampled, checked
+                    sys.stderr.write("gz slice %d rank %d: open %.3f state_in +%.3f decoded +%.3f sampled +%.3f crc +%.3f (%d reads) %s\n" % (i, rank, tr[0] - t_zero, tr[1] - tr[0], tr[2] - tr[1], tr[3] - tr[2], time.time() - tr[3], n, rd.times()))
             finally:
                 if not done and publish:                               # whoever waits for this slice must not wait for ever
                     for k in ("s%d/%d" % (fi, i), "c%d/%d" % (fi, i)):
@@ -554,6 +577,25 @@ def stream_batches_sharded(args, on_batch, device=None):
             rd = _native.Reader.on_range(p, lo, hi, L, max(1, cap), fastq, qoff, args["min_quality"], args["mean_quality"], args["max_unknown"])
         return rd, rd.run(), None
 
+    lock = threading.Lock()
+    started, published, at_round, stopped = {}, set(), [0], [False]
+
+    def ensure(j):
+        with lock:
+            if j < len(rounds) and j not in started and not stopped[0]:
+                started[j] = sample(j, nreads - total)             # (an upper bound of what is still wanted: total only grows)
+
+    def decoded(j):
+        """round j's slice of this rank is decoded (.gz): round j + 1 starts now - its decoding beside the sampling of round j and the
+        search of round j - 1 - unless the main loop is further behind than that (no rank starts a round more than two in front of the
+        one its main loop is at; when the loop ends, the slices of those rounds that this rank never started are published as failed:
+        whoever waits for a hand-over gets an answer)"""
+        with lock:
+            published.add(j)
+            go = at_round[0] >= j - 1
+        if go:
+            ensure(j + 1)
+
     def sample(j, cap):
         p, base, size, step, fi = rounds[j]
         lo = min(size, base + rank * step)
@@ -564,7 +606,7 @@ def stream_batches_sharded(args, on_batch, device=None):
             try:
                 if hi > lo:
                     try:
-                        rd, n, st_in = run_slice(p, lo, hi, cap, fi)
+                        rd, n, st_in = run_slice(p, lo, hi, cap, fi, on_published=lambda: decoded(j))
                     finally:
                         pass
                     box["rd"], box["n"], box["state_in"] = rd, n, st_in
@@ -585,11 +627,18 @@ def stream_batches_sharded(args, on_batch, device=None):
     total, status, cut = 0, 0, False
     stats = {"too_short": 0, "low_qual": 0, "dups": 0, "records": 0, "bases": 0}
     err = None
-    cur = sample(0, nreads) if rounds else None
+    ensure(0)
+    last = -1
     for j in range(len(rounds)):
-        th, box, (p, lo, hi) = cur
+        with lock:
+            at_round[0] = j
+            go = [jj for jj in (j, j + 1) if jj in published]
+        for jj in go:
+            ensure(jj + 1)
+        th, box, (p, lo, hi) = started[j]
         th.join()
-        cur = sample(j + 1, nreads - total) if j + 1 < len(rounds) else None      # (an upper bound of what is still wanted: total only grows)
+        ensure(j + 1)
+        last = j
         bad = 2 if "err" in box else 1 if (box.get("st") or {}).get("ragged_end") else 0
         n_acc = 0 if bad else int(box["n"])
         mine = torch.tensor([n_acc, bad], dtype=torch.int64, device=tdev)
@@ -630,10 +679,22 @@ def stream_batches_sharded(args, on_batch, device=None):
             status = 2
         if status or cut:
             break
-    if cur is not None:                                            # a round sampled ahead and not needed
-        cur[0].join()
-        if "rd" in cur[1]:
-            cur[1]["rd"].close()
+    with lock:
+        stopped[0] = True
+    for jj in range(last + 1, min(len(rounds), last + 4)):         # .gz rounds another rank may have started and this one never will: its slices count as failed
+        p, base, size, step, fi = rounds[jj]
+        if jj not in started and p.endswith(".gz") and min(size, base + rank * step) < size:
+            for key in ("s%d/%d" % (fi, (base + rank * step) // KC), "c%d/%d" % (fi, (base + rank * step) // KC)):
+                try:
+                    if not gz_store.check([key]):
+                        gz_store.set(key, b"")
+                except Exception:                                   # noqa: BLE001
+                    pass
+    for jj in sorted(started):                                     # rounds sampled ahead and not needed
+        if jj > last:
+            started[jj][0].join()
+            if "rd" in started[jj][1]:
+                started[jj][1]["rd"].close()
     vec = torch.tensor([stats[k] for k in ("too_short", "low_qual", "records", "bases")], dtype=torch.int64, device=tdev)
     dist.all_reduce(vec)
     for k, v in zip(("too_short", "low_qual", "records", "bases"), vec.tolist()):

@@ -42,5 +42,7 @@ for W in worlds:
         lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
         if not lines:
             print("world %d MC_DIST_GZ=%s failed: %s" % (W, gz, p.stderr.decode()[-1500:]), flush=True); continue
+        if os.environ.get("MC_DIST_TRACE"):
+            print("\n".join([l for l in p.stderr.decode().splitlines() if l.startswith(("gz slice", "gz part"))][-2 * (n // 550000 + 2):]), flush=True)
         r = json.loads(lines[-1])
         print("world %d  %-34s %.3f s = %5.2f M reads/s  sampled %d  AGS %.3f" % (W, "every rank inflates its slices" if not r["dealt"] else "rank 0 inflates and deals", r["wall"], n / r["wall"] / 1e6, r["sampled"], r["est"]), flush=True)
