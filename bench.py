@@ -348,15 +348,15 @@ def cpu_baseline(eng, sample_reads, read_len, plan):
             "usable_cores": usable_cores(), "host_cores": os.cpu_count(), "runs": runs, "m8_md5_equals_gpu": all(r["m8_md5_equals_gpu"] for r in runs)}
 
 
-def write_fastq(gen, n, L, path, gz):
-    """n reads of the bench workload as a FASTQ file (ids 0 .. n-1, qualities 'I' with a '5' every tenth base: phred+33)."""
+def write_fastq(gen, n, L, path, gz, id0=0, id_width=0):
+    """n reads of the bench workload as a FASTQ file (ids id0 .. id0 + n - 1, qualities 'I' with a '5' every tenth base: phred+33)."""
     import gzip
     import numpy as np
-    reads = gen.single(n, L, first=1 << 40).cpu().numpy()      # (indices far away from the resident set)
-    w = len(str(n - 1))
+    reads = gen.single(n, L, first=(1 << 40) + id0).cpu().numpy()      # (indices far away from the resident set)
+    w = max(id_width, len(str(id0 + n - 1)))
     rec = np.empty((n, 1 + w + 1 + L + 3 + L + 1), dtype=np.uint8)
     rec[:, 0] = ord("@")
-    ids = np.arange(n)
+    ids = np.arange(id0, id0 + n)
     for k in range(w):
         rec[:, w - k] = ord("0") + (ids // 10 ** k) % 10
     rec[:, 1 + w] = 10
@@ -517,12 +517,43 @@ def e2e_distributed(gen, n, L, rank, world, local, rdev):
         w = torch.tensor([time.time() - t], dtype=torch.float64, device=rdev)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         walls.append(float(w.item()))
+    out = {"what": "run_pipeline_distributed(file -> AGS) over %d ranks on a plain FASTQ: every rank samples its own slices of the file (mc_reader_open_range) and searches "
+                   "them, the head-take and the read indices come from the exchanged counts, one all_reduce of the per-family sums; wall time of the second of two "
+                   "calls, maximum over the ranks" % world, "reads": n, "file": "FASTQ", "wall_s": round(walls[-1], 3), "reads_per_s": round(n / walls[-1], 1),
+           "first_call_wall_s": round(walls[0], 3), "sampled_reads": int(a["sampled_reads"]), "est_ags": est}
+    # the same on a FASTQ.gz: every rank inflates its own chunk slices, the 32 KB windows handed along the ranks.  The file is
+    # written by all ranks at once - a gzip member each, concatenated by rank 0 - because one Python gzip writer takes 4 s per 1 M reads
+    ngz = min(n, 2_000_000 * world)
+    share = ngz // world
+    ngz = share * world
+    td = os.path.dirname(box[0])
+    part = os.path.join(td, "part%d.gz" % rank)
+    write_fastq(gen, share, L, part, True, id0=rank * share, id_width=len(str(ngz - 1)))
+    dist.barrier()
+    gzp = os.path.join(td, "reads.fq.gz")
     if rank == 0:
-        shutil.rmtree(os.path.dirname(box[0]), ignore_errors=True)
-    return {"what": "run_pipeline_distributed(file -> AGS) over %d ranks on a plain FASTQ: every rank samples its own slices of the file (mc_reader_open_range) and searches "
-                    "them, the head-take and the read indices come from the exchanged counts, one all_reduce of the per-family sums (a .gz input or -d: rank 0 samples "
-                    "and deals batches to the free ranks); wall time of the second of two calls, maximum over the ranks" % world, "reads": n, "file": "FASTQ", "wall_s": round(walls[-1], 3), "reads_per_s": round(n / walls[-1], 1),
-            "first_call_wall_s": round(walls[0], 3), "sampled_reads": int(a["sampled_reads"]), "est_ags": est}
+        with open(gzp, "wb") as f:
+            for r in range(world):
+                with open(os.path.join(td, "part%d.gz" % r), "rb") as g:
+                    shutil.copyfileobj(g, f, 1 << 24)
+    walls, est = [], None
+    for rep in range(2):
+        dist.barrier()
+        t = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            est, a = mcd.run_pipeline_distributed({"seqfiles": [gzp], "nreads": ngz, "read_length": L}, device=local)
+        dist.barrier()
+        w = torch.tensor([time.time() - t], dtype=torch.float64, device=rdev)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        walls.append(float(w.item()))
+    out["gz"] = {"what": "the same on a FASTQ.gz of %d gzip members: every rank inflates its own slices of 32 chunks of 1 MB, the windows handed along the ranks, "
+                         "and samples the records that start in its text (nothing dealt by rank 0: %s)" % (world, mcd.run_pipeline_distributed.last_trace is None),
+                 "reads": ngz, "file": "FASTQ.gz", "file_bytes": os.path.getsize(gzp) if rank == 0 else None, "wall_s": round(walls[-1], 3), "reads_per_s": round(ngz / walls[-1], 1),
+                 "first_call_wall_s": round(walls[0], 3), "sampled_reads": int(a["sampled_reads"]), "est_ags": est}
+    dist.barrier()
+    if rank == 0:
+        shutil.rmtree(td, ignore_errors=True)
+    return out
 
 
 def main():

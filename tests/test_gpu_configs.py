@@ -175,6 +175,8 @@ def test_bench_eight_ranks_on_one_gpu_equals_one_engine(tmp_path):
     r = line["rccl"]
     assert line["n_gpus"] == W and r["world_size"] == W and r["rank_sum"] == 36 == r["rank_sum_expected"] and r["backend"] == "gloo"
     assert line["e2e"]["sampled_reads"] == 2_000_000 and line["e2e"]["est_ags"] > 1e6
+    gz = line["e2e"]["gz"]                                        # the FASTQ.gz of eight members, inflated by all ranks: every read sampled, nothing dealt
+    assert gz["sampled_reads"] == gz["reads"] == 2_000_000 and "nothing dealt by rank 0: True" in gz["what"] and abs(gz["est_ags"] / line["e2e"]["est_ags"] - 1) < 0.02
     # the same reads through one engine of this process: file 1 (mate 1 of every fragment), then file 2
     model = _native.load_model()
     fams = model["families"]
