@@ -516,14 +516,16 @@ def stream_batches_sharded(args, on_batch, device=None):
     GZC = _gz_chunk_bytes()
     KC = max(1, min(32, S // GZC))
     kind = "@" if fastq else ">"
-    rounds = []
+    rounds, gz_step = [], {}
     for fi, p in enumerate(args["seqfiles"]):
         if p.endswith(".bz2"):
             size = _native.bz2_blocks(p)
             rounds += [(p, base, size, KB, fi) for base in range(0, max(size, 1), KB * world)]
         elif p.endswith(".gz"):
             size = _native.gz_chunks(p, GZC)
-            rounds += [(p, base, size, KC, fi) for base in range(0, max(size, 1), KC * world)]
+            kc = max(min(4, KC), min(KC, -(-size // world)))        # (a file of fewer than `world` full slices: smaller ones, so that every rank has one)
+            gz_step[fi] = kc
+            rounds += [(p, base, size, kc, fi) for base in range(0, max(size, 1), kc * world)]
         else:
             size = os.path.getsize(p)
             rounds += [(p, base, size, S, fi) for base in range(0, max(size, 1), S * world)]
@@ -535,7 +537,7 @@ def stream_batches_sharded(args, on_batch, device=None):
         if p.endswith(".gz"):
             # the chain of a .gz file: slice i learns from slice i - 1 where that ended (and the 32 KB in front of it), tells slice i + 1 the same
             # as soon as it knows - through the process group's store, from whichever thread -, and the members' CRCs follow the same way
-            i = lo // KC
+            i = lo // gz_step[fi]
             rd = _native.Reader.on_gz_part(p, lo, hi, GZC, kind, L, max(1, cap), fastq, qoff, args["min_quality"], args["mean_quality"], args["max_unknown"])
             n, done = 0, False
             tr = [time.time()] if trace_on else None
@@ -684,7 +686,7 @@ def stream_batches_sharded(args, on_batch, device=None):
     for jj in range(last + 1, min(len(rounds), last + 4)):         # .gz rounds another rank may have started and this one never will: its slices count as failed
         p, base, size, step, fi = rounds[jj]
         if jj not in started and p.endswith(".gz") and min(size, base + rank * step) < size:
-            for key in ("s%d/%d" % (fi, (base + rank * step) // KC), "c%d/%d" % (fi, (base + rank * step) // KC)):
+            for key in ("s%d/%d" % (fi, (base + rank * step) // step), "c%d/%d" % (fi, (base + rank * step) // step)):
                 try:
                     if not gz_store.check([key]):
                         gz_store.set(key, b"")
