@@ -228,6 +228,54 @@ def test_every_rank_samples_its_own_slices(tmp_path, world):
         assert sum(1 for per_rank in r["batches"] if per_rank) >= min(world, 2), name      # (more than one rank sampled something)
 
 
+def test_damaged_gz_goes_back_to_the_one_sampler(tmp_path, monkeypatch):
+    """A .gz file the chain of slices cannot finish - the CRC in its trailer is wrong, the file is cut short in the middle of its deflate
+    data, bytes in its middle are damaged - must not hang a rank or give reads the reference would not: every rank agrees (status 1) and
+    the caller reads the file with the ONE sampler on rank 0, which reports what gzip.open would (tests/test_reader.py).  A damaged
+    member BEHIND the head-take is never looked at, as in the reference: status 0 and the reads of the sequential sampler."""
+    import gzip
+    import zlib
+    from microbecensus_amd import _native
+    inp = os.path.join(GOLD, "inputs")
+    ex = gzip.open(os.path.join(inp, "example.fq.gz"), "rb").read()
+    good = gzip.compress(ex, 1)
+    bad_crc = bytearray(good); bad_crc[-8] ^= 0x55
+    cut = good[: len(good) * 2 // 3]
+    hurt = bytearray(good)
+    for k in range(len(good) // 2, len(good) // 2 + 64):
+        hurt[k] ^= 0xA5
+    files = {"crc": bytes(bad_crc), "cut": cut, "hurt": bytes(hurt)}
+    base = {"min_quality": -5, "mean_quality": -5, "max_unknown": 100, "filter_dups": False, "read_length": 100, "file_type": "fastq", "quality_offset": 32}
+    cases = {}
+    for name, blob in files.items():
+        path = str(tmp_path / (name + ".fq.gz"))
+        open(path, "wb").write(blob)
+        cases[name] = dict(base, seqfiles=[path], nreads=10**9)
+    cases["crc_behind_the_take"] = dict(base, seqfiles=[cases["crc"]["seqfiles"][0]], nreads=3000)
+    cj = tmp_path / "cases.json"
+    cj.write_text(json.dumps(cases))
+    worker = tmp_path / "shard.py"
+    worker.write_text(SHARD_WORKER.replace("assert D.sharded_sampling_usable(a)", "pass"))
+    out = tmp_path / "shard.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MC_DIST_SLICE="150000", MC_DIST_GZ_CHUNK="65536")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                           "--master-port", "29529", str(worker), REPO, str(cj), str(out)], env=env, timeout=600)
+    res = json.load(open(out))
+    for name in files:
+        assert res[name]["status"] == 1, (name, res[name]["status"], res[name]["stats"])
+    a = cases["crc_behind_the_take"]
+    monkeypatch.setenv("MC_READER_REGION_BYTES", "200000")       # (the one sampler reads ahead by regions: small ones, so that it stops in front of the trailer too)
+    monkeypatch.setenv("MC_READER_GZ_CHUNK", "65536")
+    want, st = _native.sample_reads(a["seqfiles"], 100, 3000, True, 32, -5, -5, 100, False)
+    r = res["crc_behind_the_take"]
+    assert r["status"] == 0 and r["n_total"] == 3000 == len(want)
+    at = 0
+    for first, n, crc in sorted(tuple(b) for per_rank in r["batches"] for b in per_rank):
+        assert first == at and crc == zlib.crc32(want[first:first + n].tobytes())
+        at += n
+    assert at == 3000 and all(r["stats"][k] == st[k] for k in ("too_short", "low_qual", "records"))
+
+
 FAIL_WORKER = r'''
 import json, os, sys
 import numpy as np
