@@ -537,15 +537,22 @@ def e2e_distributed(gen, n, L, rank, world, local, rdev):
                 with open(os.path.join(td, "part%d.gz" % r), "rb") as g:
                     shutil.copyfileobj(g, f, 1 << 24)
     walls, est = [], None
-    for rep in range(2):
+    try:
+        for rep in range(2):
+            dist.barrier()
+            t = time.time()
+            with contextlib.redirect_stdout(io.StringIO()):
+                est, a = mcd.run_pipeline_distributed({"seqfiles": [gzp], "nreads": ngz, "read_length": L}, device=local)
+            dist.barrier()
+            w = torch.tensor([time.time() - t], dtype=torch.float64, device=rdev)
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            walls.append(float(w.item()))
+    except BaseException as e:                                     # noqa: BLE001 - (run_pipeline_distributed raises on every rank or on none: the line survives a failing leg)
+        out["gz"] = {"error": "%s: %s" % (type(e).__name__, e)}
         dist.barrier()
-        t = time.time()
-        with contextlib.redirect_stdout(io.StringIO()):
-            est, a = mcd.run_pipeline_distributed({"seqfiles": [gzp], "nreads": ngz, "read_length": L}, device=local)
-        dist.barrier()
-        w = torch.tensor([time.time() - t], dtype=torch.float64, device=rdev)
-        dist.all_reduce(w, op=dist.ReduceOp.MAX)
-        walls.append(float(w.item()))
+        if rank == 0:
+            shutil.rmtree(td, ignore_errors=True)
+        return out
     out["gz"] = {"what": "the same on a FASTQ.gz of %d gzip members: every rank inflates its own slices of 32 chunks of 1 MB, the windows handed along the ranks, "
                          "and samples the records that start in its text (nothing dealt by rank 0: %s)" % (world, mcd.run_pipeline_distributed.last_trace is None),
                  "reads": ngz, "file": "FASTQ.gz", "file_bytes": os.path.getsize(gzp) if rank == 0 else None, "wall_s": round(walls[-1], 3), "reads_per_s": round(ngz / walls[-1], 1),
