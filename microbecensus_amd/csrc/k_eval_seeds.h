@@ -75,7 +75,97 @@ __device__ __forceinline__ bool mc_ev_gate(const McHot &T, const uint8_t *q, int
     return (double)score >= MC_SEED_SCORE && ident >= MC_SEED_IDENT;
 }
 // ... and the extension itself, from the grown seed: 1 = ungapped HSP complete, 2 = needs the gapped extension
-__device__ __forceinline__ int mc_ev_xdrop(const McHot &T, const uint8_t *q, int qlen, const uint8_t *d, int dlen, int sidx, int qp, int dp, int L, int score, int ident, McGapTask *gt)
+#ifndef MC_EV_XDROP_STEPWISE
+// One accumulator per walk carries what a step of AlignFwd / AlignBwd updates - the running score, the step's number and the identities
+// so far: P = run * 65536 + (255 - i) * 256 + id (i <= MC_MAXAA steps, id <= i).  A step adds ONE table word to it (sub32[a][b] =
+// score * 65536 - 256 + (a == b), 4 KB of LDS made at the kernel's start), and the best prefix is `max`: P' > Pbest <=> run > best
+// (the low 16 bits are below 65536, and on equal scores the EARLIER step has the larger low part - the reference's `run > best` keeps the
+// first one too).  best, its length and its identities are read off Pbest at the end.  The exit test best - run >= xdi is
+// Pbest - P >= xdi * 65536 exactly (the low parts differ by (i - bl) * 256 - (id - bid) in [0, 65535]: i > bl whenever best > run).
+// `run < -20` cannot fire first: best >= the seed's score >= MC_SEED_SCORE (the gate), so run < -20 has best - run > 31 >= xdi
+// (static_assert below).  The end of the shorter sequence: the bytes of the query's word at and behind it are set to 0xFF - row 31 of the
+// table, which no residue code uses (codes <= MC_INV = 20), holds - 100 * 65536: the step behind the last residue is an exit by the test
+// that is there anyway, with best untouched.  Per step: three instructions for the table's address, one LDS read, add, max, subtract,
+// compare, select - against fifteen and three exit tests (the step-by-step form, -DMC_EV_XDROP_STEPWISE: same results).
+static_assert(MC_MAXAA <= 250 && MC_INV < 31 && MC_SEED_SCORE >= -11.0, "the packed accumulator of mc_ev_xdrop");
+#define MC_EV_POISON (-100 * 65536 - 256)
+#define MC_EV_SUB32(a, b) (*(const int32_t *)((const char *)sub32 + ((((a) << 7) | ((b) << 2)) & 0xFFCu)))      // (the word's byte address straight from the two bytes)
+__device__ __forceinline__ void mc_ev_sub32(int32_t *sub32, const McHot &T)
+{
+    for (int x = (int)threadIdx.x; x < 1024; x += (int)blockDim.x) sub32[x] = (x >> 5) == 31 ? MC_EV_POISON : (int)T.sub[x] * 65536 - 256 + (int)((x >> 5) == (x & 31));
+}
+__device__ __forceinline__ int mc_ev_xdrop(const McHot &T, const int32_t *sub32, const uint8_t *q, int qlen, const uint8_t *d, int dlen, int sidx, int qp, int dp, int L, int score, int ident, McGapTask *gt)
+{
+    const int xdi = (int)floor(T.xdrop_ungapped) + 1;
+    const int32_t TD = xdi * 65536, P0 = score * 65536 + 255 * 256;
+    const int s0 = score;
+    int qfwd = 0, qbwd = 0, fgain = 0, bgain = 0;
+    { // forward
+        const int n1 = qlen - qp - L, n2 = dlen - dp - L, lim = n1 < n2 ? n1 : n2;
+        int32_t bestp = P0;
+        if (lim > 0) {
+            const uint8_t *p1 = q + qp + L, *p2 = d + dp + L;
+            int32_t runp = P0;
+            int i = 0;
+            bool alive = true;
+            do {
+                MC_EV_TURN(0);
+                uint64_t wa = mc_ld8(p1 + i);
+                const uint64_t wb = mc_ld8(p2 + i);
+                const int rem = lim - i;
+                if (rem < 8) wa |= ~0ull << (8 * rem);
+                int32_t e[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) e[k] = MC_EV_SUB32((uint32_t)(wa >> (8 * k)) & 0xFFu, (uint32_t)(wb >> (8 * k)) & 0xFFu);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    runp += e[k];
+                    const int32_t c = bestp > runp ? bestp : runp;
+                    bestp = alive ? c : bestp;
+                    alive = alive && (c - runp < TD);
+                }
+                i += 8;
+            } while (alive && i < lim);
+        }
+        fgain = (bestp >> 16) - s0; qfwd = 255 - ((bestp >> 8) & 255); ident += bestp & 255;
+    }
+    { // backward, restarting from the seed score
+        const int lim = qp < dp ? qp : dp;
+        int32_t bestp = P0;
+        if (lim > 0) {
+            const uint8_t *p1 = q + qp - 8, *p2 = d + dp - 8;                      // residues a - 7 .. a of the step's first residue a = qp - 1 - i: step k uses byte 7 - k
+            int32_t runp = P0;
+            int i = 0;
+            bool alive = true;
+            do {
+                MC_EV_TURN(1);
+                uint64_t wa = mc_ld8(p1 - i);
+                const uint64_t wb = mc_ld8(p2 - i);
+                const int rem = lim - i;
+                if (rem < 8) wa |= ~0ull >> (8 * rem);
+                int32_t e[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) e[k] = MC_EV_SUB32((uint32_t)(wa >> (8 * (7 - k))) & 0xFFu, (uint32_t)(wb >> (8 * (7 - k))) & 0xFFu);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    runp += e[k];
+                    const int32_t c = bestp > runp ? bestp : runp;
+                    bestp = alive ? c : bestp;
+                    alive = alive && (c - runp < TD);
+                }
+                i += 8;
+            } while (alive && i < lim);
+        }
+        bgain = (bestp >> 16) - s0; qbwd = 255 - ((bestp >> 8) & 255); ident += bestp & 255;
+    }
+    score = s0 + bgain + fgain;
+    gt->sidx = (uint32_t)sidx; gt->qp = (int16_t)qp; gt->dp = (int16_t)dp; gt->L = (int16_t)L;
+    gt->qfwd = (int16_t)qfwd; gt->qbwd = (int16_t)qbwd; gt->score = (int16_t)score; gt->nmatch = (int16_t)ident;
+    return (!(T.gap_trigger > (double)score)) ? 2 : 1;
+}
+#else
+__device__ __forceinline__ void mc_ev_sub32(int32_t *, const McHot &) { }
+__device__ __forceinline__ int mc_ev_xdrop(const McHot &T, const int32_t *, const uint8_t *q, int qlen, const uint8_t *d, int dlen, int sidx, int qp, int dp, int L, int score, int ident, McGapTask *gt)
 {
     // The reference's exit test is `(double)run < (double)best - xdrop` on two integers and a constant that is no integer (8.94 for BLOSUM62's
     // ungapped lambda; mc_fill_tables refuses one that is nearer than 1e-6 to an integer): best - run > xdrop <=> best - run >= floor(xdrop) + 1,
@@ -150,6 +240,7 @@ __device__ __forceinline__ int mc_ev_xdrop(const McHot &T, const uint8_t *q, int
     gt->qfwd = (int16_t)qfwd; gt->qbwd = (int16_t)qbwd; gt->score = (int16_t)score; gt->nmatch = (int16_t)ident;
     return (!(T.gap_trigger > (double)score)) ? 2 : 1;
 }
+#endif
 
 #ifdef MC_EXP_TIMING
 __device__ unsigned long long g_ev_acc[8];           // wave time per phase, summed over the waves (lane 0): 0 loop, next records asked for 1 survivors queued 2 X-drop extension (with the read of the queue) 3 HSP, marks 4 records written 5 wait for the residues + seed score 6 redundancy test, growth, gate
@@ -207,9 +298,16 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
 {
     const uint32_t ntasks = *ntasks_p <= cap_tasks ? *ntasks_p : 0u;   // (device-side count of the seed kernel; after an overflow the host discards the batch)
     __shared__ McHot hot;
+#ifndef MC_EV_XDROP_STEPWISE
+    __shared__ int32_t sub32[1024];
+#else
+    int32_t *const sub32 = nullptr;
+#endif
     const int lane = mc_lane(), wv = threadIdx.x >> 6;
     uint4 *Q = (uint4 *)(mc_smem + (size_t)wv * MC_EV_QCAP * 32);    // entry e: words 2 e, 2 e + 1
     mc_load_hot(&hot, T);
+    __syncthreads();
+    mc_ev_sub32(sub32, hot);
     __syncthreads();
     const double hot_loge_thr = T->loge_thr;
     uint32_t qn = 0, hb_base = 0, hb_used = MC_EV_BLK, gb_base = 0, gb_used = MC_EV_BLK;
@@ -277,7 +375,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
             const int frame = (int)(chrono >> 25), qlen = (L - frame % 3) / 3, sidx = (int)e0.w;
             const uint8_t *q = frames + ((int64_t)read * 6 + frame) * FP, *d = X.res + e0.z;
             g.read = read; g.chrono = chrono;
-            rc = mc_ev_xdrop(hot, q, qlen, d, (int)(e1.z >> 16), sidx, (int)(e1.x & 0xFFFFu), (int)(e1.x >> 16), (int)(e1.y & 0xFFFFu), (int)(int16_t)(e1.y >> 16), (int)(e1.z & 0xFFFFu), &g);
+            rc = mc_ev_xdrop(hot, sub32, q, qlen, d, (int)(e1.z >> 16), sidx, (int)(e1.x & 0xFFFFu), (int)(e1.x >> 16), (int)(e1.y & 0xFFFFu), (int)(int16_t)(e1.y >> 16), (int)(e1.z & 0xFFFFu), &g);
             MC_EV_TICK(2);
             if (rc == 1) {
                 h.read = read; h.chrono = chrono;
