@@ -170,6 +170,32 @@ def seed_line_model(cal, L, n_batch, asks, hits, seed_ms):
                     "flight per lane, and for a chain of dependent asks); above 1: asks of one wave that fall into the same line are counted once each"}
 
 
+def eval_line_model(cal, n_batch, hits, survivors, eval_ms, prof_der):
+    """The same pricing for k_eval_seeds: what a seed hit makes the kernel ask of structures that do not fit an L2 - its
+    posting's record (posting, the subject's place and the 24 residues of the subject around the seed: one aligned 32-byte item of a
+    115 MB array; until late in round 6 an 8-byte posting entry AND 24 bytes at a scattered place of the 14 MB residue array, 2.4 lines)
+    and, for the hits that pass the gate, the residue array in front of and behind the grown seed (the two X-drop walks: a line each) -
+    at the calibrated scattered-line rates, against the kernel's measured duration.  (Its records, the frames' rows and its outputs are
+    streams.)  survivors: HSPs + gap tasks per launch - a lower bound (an ungapped HSP below the thresholds leaves no record)."""
+    if cal is None or eval_ms <= 0 or not hits:
+        return None
+    r_rec, r_res = cal["rate"].get(("128MB", 32)), cal["rate"].get(("16MB", 32))
+    if not r_rec or not r_res:
+        return None
+    per_hit = [("posting records 115 MB (32-byte items: posting, place, 24 residues of the subject)", 1.0, r_rec),
+               ("subject residues 14 MB (the X-drop walks of the hits that pass the gate: two lines each)", 2.0 * survivors / hits, r_res)]
+    rows, t = [], 0.0
+    for name, n, r in per_hit:
+        ms = n * hits / (r * 1e9) * 1e3
+        t += ms
+        rows.append({"structure": name, "lines_per_hit": round(n, 2), "g_lines_per_s_at_that_footprint": r, "ms_per_launch": round(ms, 3)})
+    return {"calibration": cal["file"], "hits_per_read": round(hits / n_batch, 2), "model_ms_per_launch": round(t, 3), "measured_ms_per_launch": round(eval_ms, 3), "frac": round(t / eval_ms, 3),
+            "l2_requests_per_hit_of_the_committed_profile": prof_der, "by_structure": rows,
+            "note": "frac near 1: the ungapped extension kernel too takes the time the memory system needs for its scattered lines - halving the instructions of its X-drop "
+                    "loops, 4 to 8 waves per SIMD and loads a turn ahead all left its duration where it was, moving the subject's residues INTO the posting's record (2.4 -> 1 "
+                    "line per hit) took 11 - 15 % off (DESIGN.md 5.8); above 1: hits of one probe have neighbouring records and share lines"}
+
+
 def stage_counters(prof, stage):
     """Sums the per-launch counters of the kernels of a stage (one launch of each per pass of the pipeline over the profiled batch;
     a kernel launched several times per pass counts with its number of calls per pass)."""
@@ -828,6 +854,14 @@ def main():
                           "counter_fabric_frac_lower": (der.get(k) or {}).get("fabric_frac_lower"), "bound": (der.get(k) or {}).get("bound"),
                           "issue_roofline": (der.get(k) or {}).get("issue_roofline")}
         ext_best = max([v["frac_of_hbm_peak"] for v in ext.values()] or [0.0])
+        ev_req = None
+        try:                                                     # (L1 -> L2 read requests per seed hit of the committed profile of this read length: what the model prices)
+            evc = stage_counters(prof, "k_eval_seeds")
+            if evc and evc.get("TCP_TCC_READ_REQ_sum") and (der.get("k_eval_seeds") or {}).get("reads_per_launch"):
+                ev_req = round(evc["TCP_TCC_READ_REQ_sum"] / (hits * der["k_eval_seeds"]["reads_per_launch"] / n_batch), 2)
+        except Exception:                                         # noqa: BLE001
+            ev_req = None
+        elc = eval_line_model(gather_ceiling(), n_batch, hits, hsps + gtasks, kseq["k_eval_seeds"], ev_req)
         # What binds the dominant kernel, from THIS run's measurements (no label or prose that cannot change): the seed kernel is
         # called bound by the fabric's scattered lines when its own ask counters, priced at the machine's calibrated scattered-line rates
         # (profiles/rNN_gather_ceiling.json), account for at least 0.8 of its live duration; otherwise the largest counter fraction of the
@@ -861,10 +895,10 @@ def main():
                          # flat copies of the nested yardsticks below (a reader that keeps only the scalars of this object keeps these: VERDICT r05 item 7)
                          "reference_pattern_bytes_per_read": (ref_pattern or {}).get("bytes_per_read"), "reference_pattern_frac_of_hbm_peak": (ref_pattern or {}).get("frac_of_hbm_peak"),
                          "legacy_survey_A_bytes_per_read": SURVEY_A.get(L), "legacy_survey_A_pipeline_GBps": (None if pipe_gbs is None else round(pipe_gbs, 2)),
-                         "scattered_line_ceiling_frac": (slc or {}).get("frac"), "extension_kernel_hbm_frac_best": round(ext_best, 4),
+                         "scattered_line_ceiling_frac": (slc or {}).get("frac"), "extension_kernel_hbm_frac_best": round(ext_best, 4), "extension_kernel_scattered_line_ceiling_frac": (elc or {}).get("frac"),
                          "fabric_frac": (d_dom or {}).get("fabric_frac"), "fabric_frac_lower": (d_dom or {}).get("fabric_frac_lower"), "issue_frac": (d_dom or {}).get("issue_frac"),
                          "issue_roofline": (d_dom or {}).get("issue_roofline"), "reference_pattern": ref_pattern,
-                         "scattered_line_ceiling": slc,
+                         "scattered_line_ceiling": slc, "extension_kernel_scattered_line_ceiling": elc,
                          "salu_frac": (d_dom or {}).get("salu_frac"), "wait_frac": (d_dom or {}).get("wait_frac"), "wave_residency": (d_dom or {}).get("wave_residency"),
                          "valu_lanes_of_64": (d_dom or {}).get("valu_lanes_of_64"), "l2_hit_rate": (d_dom or {}).get("l2_hit_rate"),
                          "kernel_ms_per_step": round(kseq[dom], 3), "algorithmic_bytes_per_read": round(per_launch[dom] / n_batch, 1),
@@ -876,7 +910,7 @@ def main():
                          "fabric_amplification_lower": (None if not (d_dom and d_dom.get("fabric_frac_lower") and d_dom.get("fabric_frac")) else round(traffic_dom / per_launch[dom] * d_dom["fabric_frac_lower"] / d_dom["fabric_frac"], 2)),
                          "extension_kernel_hbm_frac": {"target": 0.40, "met": bool(ext_best >= 0.40), "best": round(ext_best, 4), "kernels": ext,
                                                        "note": "north_star asks for >= 40 % of the HBM roofline on the extension kernel; the ungapped (k_eval_seeds) and gapped (k_gapped stage) "
-                                                               "extensions are bound by VALU issue, not by bytes: the target is missed"},
+                                                               "extensions are not bound by bytes: k_eval_seeds by the scattered lines of its hits (extension_kernel_scattered_line_ceiling), the gapped stage by VALU issue: the target is missed"},
                          "profile": (None if prof is None else prof["files"]), "fetch_calibration": (None if prof is None else prof.get("calibration")),
                          "basis": "kernel = the stage with the largest HIP-event time per step. achieved = ALGORITHMIC bytes of one launch (the arrays the kernel "
                                   "must read and write, each once, plus the items the seed kernel asks of the index at their own sizes - index_touch_bytes_per_read, "

@@ -108,10 +108,19 @@ __device__ __forceinline__ int mc_ev_xdrop(const McHot &T, const int32_t *sub32,
             int32_t runp = P0;
             int i = 0;
             bool alive = true;
+#ifdef MC_EV_PREFETCH
+            uint64_t na = mc_ld8(p1), nb = mc_ld8(p2);
+#endif
             do {
                 MC_EV_TURN(0);
+#ifdef MC_EV_PREFETCH
+                uint64_t wa = na;
+                const uint64_t wb = nb;
+                na = mc_ld8(p1 + i + 8); nb = mc_ld8(p2 + i + 8);
+#else
                 uint64_t wa = mc_ld8(p1 + i);
                 const uint64_t wb = mc_ld8(p2 + i);
+#endif
                 const int rem = lim - i;
                 if (rem < 8) wa |= ~0ull << (8 * rem);
                 int32_t e[8];
@@ -137,10 +146,19 @@ __device__ __forceinline__ int mc_ev_xdrop(const McHot &T, const int32_t *sub32,
             int32_t runp = P0;
             int i = 0;
             bool alive = true;
+#ifdef MC_EV_PREFETCH
+            uint64_t na = mc_ld8(p1), nb = mc_ld8(p2);
+#endif
             do {
                 MC_EV_TURN(1);
+#ifdef MC_EV_PREFETCH
+                uint64_t wa = na;
+                const uint64_t wb = nb;
+                na = mc_ld8(p1 - i - 8); nb = mc_ld8(p2 - i - 8);
+#else
                 uint64_t wa = mc_ld8(p1 - i);
                 const uint64_t wb = mc_ld8(p2 - i);
+#endif
                 const int rem = lim - i;
                 if (rem < 8) wa |= ~0ull >> (8 * rem);
                 int32_t e[8];
@@ -284,12 +302,23 @@ __device__ __forceinline__ uint32_t mc_ev_slots(uint32_t n, uint32_t r, uint32_t
 // array and the rest of the subject - the seed kernel is bound by the scattered lines its CUs fetch and a hit's posting and
 // offsets were 150 of the 810 lines a read cost it; this kernel does not wait for memory (5.7) and fetches the three in one 8-byte load.
 // the postings with what the evaluation needs beside them (MC_POST8), made once per handle
-__global__ void __launch_bounds__(256) k_post8(const uint32_t *__restrict__ post, const uint32_t *__restrict__ off, uint32_t n, unsigned long long *post8)
+// MC_POST_WORDS = 4 (round 6): the 24 residues of the subject around the posting - dpos - 8 .. dpos + 15, what the gate reads of it - travel
+// WITH it: 32 bytes per posting (115 MB for the marker database instead of 29 + the 14 MB residue array asked at a scattered place), one
+// aligned item = ONE line per hit instead of 2.4, and no second trip (posting -> place -> residues).  The kernel takes the time the memory
+// system needs for its scattered lines (instructions, occupancy and loads ahead of time all left it where it was), so lines are
+// what pays.  The X-drop walks of the three hits in ten that pass the gate still read the residue array.  -DMC_POST_WORDS=1: the 8-byte form.
+#ifndef MC_POST_WORDS
+#define MC_POST_WORDS 4
+#endif
+__global__ void __launch_bounds__(256) k_post8(const uint32_t *__restrict__ post, const uint32_t *__restrict__ off, const uint8_t *__restrict__ res, uint32_t n, unsigned long long *post8)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const uint32_t pst = post[i], s = pst >> 11, abs = off[s] + (pst & 0x7ffu);
-    post8[i] = MC_POST8(pst, abs, off[s + 1] - abs);
+    post8[(size_t)i * MC_POST_WORDS] = MC_POST8(pst, abs, off[s + 1] - abs);
+#if MC_POST_WORDS == 4
+    post8[(size_t)i * 4 + 1] = mc_ld8(res + abs - 8); post8[(size_t)i * 4 + 2] = mc_ld8(res + abs); post8[(size_t)i * 4 + 3] = mc_ld8(res + abs + 8);   // (the residue array has room on both sides)
+#endif
 }
 template <bool RANGES>
 __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_EV_BS) k_eval_seeds(const McTables *__restrict__ T, McIndex X, const uint8_t *__restrict__ frames, int FP, int L,
@@ -326,7 +355,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
     unsigned long long ev_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ev_last_ = __builtin_readcyclecounter();
 #endif
     // ---- phase 1 for one hit per lane: the gate; the survivors into the wave's queue
-    auto gate = [&](bool active, uint32_t rd, uint32_t chrono, uint32_t posting, uint32_t abs, int rem, int seedlen, int nkey) {
+    auto gate = [&](bool active, uint32_t rd, uint32_t chrono, uint32_t posting, uint32_t abs, int rem, int seedlen, int nkey, uint64_t r0, uint64_t r1, uint64_t r2) {
         bool surv = false;
         uint4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};
         if (active) {
@@ -336,7 +365,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
             const uint32_t o0 = abs - (uint32_t)dpos;
             const uint8_t *q = frames + ((int64_t)rd * 6 + frame) * FP, *d = X.res + o0;
             // residues pos - 8 .. pos + 15 of the frame and dpos - 8 .. dpos + 15 of the subject: six loads, one trip (rows and residue array have room on both sides)
-            const uint64_t q0 = mc_ld8(q + pos - 8), q1 = mc_ld8(q + pos), q2 = mc_ld8(q + pos + 8), d0 = mc_ld8(d + dpos - 8), d1 = mc_ld8(d + dpos), d2 = mc_ld8(d + dpos + 8);
+            const uint64_t q0 = mc_ld8(q + pos - 8), q1 = mc_ld8(q + pos), q2 = mc_ld8(q + pos + 8);
+            uint64_t d0 = r0, d1 = r1, d2 = r2;                   // (with the posting's record: MC_POST_WORDS = 4)
+            if (!(RANGES && MC_POST_WORDS == 4)) { d0 = mc_ld8(d + dpos - 8); d1 = mc_ld8(d + dpos); d2 = mc_ld8(d + dpos + 8); }
             const int qm1 = (int)(q0 >> 56), dm1 = (int)(d0 >> 56);
             const int dlen = dpos + rem;
             int score = 0, ident = 0;
@@ -424,7 +455,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
                     cur = nxt;
                 }
                 const uint32_t w3 = t.seedlen_nkey;
-                gate(tid < ntasks && t.read != MC_TASK_NONE, MC_TASK_READ_OF(t.read), t.chrono, t.posting, w3 & 0xFFFFFFu, (int)MC_TASK_REM_OF(t.read), (int)((w3 >> 24) & 15u), (int)(w3 >> 28));   // (MC_TASK_NONE: padding of a partly used block of the pool)
+                gate(tid < ntasks && t.read != MC_TASK_NONE, MC_TASK_READ_OF(t.read), t.chrono, t.posting, w3 & 0xFFFFFFu, (int)MC_TASK_REM_OF(t.read), (int)((w3 >> 24) & 15u), (int)(w3 >> 28), 0, 0, 0);   // (MC_TASK_NONE: padding of a partly used block of the pool)
                 MC_EV_TICK(1);
             }
             while (qn >= 64 || (last && qn > 0)) extend();
@@ -438,29 +469,39 @@ __global__ void __attribute__((amdgpu_waves_per_eu(5, 5))) __launch_bounds__(MC_
         uint32_t tidn = cur * 64u + (uint32_t)lane, tidn2 = 0;       // the hit numbers of tn / tn2 (past the pool: no hit)
         uint32_t cur2 = cur;
         bool have_n = cur < nchunks, have_n2 = false;
-        unsigned long long p8n = 0;
+        unsigned long long p8n = 0, r0n = 0, r1n = 0, r2n = 0;
+        auto fetch = [&](uint32_t idx) {
+#if MC_POST_WORDS == 4
+            const uint4 *rp = (const uint4 *)(X.post8 + (size_t)idx * 4);
+            const uint4 lo = rp[0], hi = rp[1];
+            p8n = (unsigned long long)lo.x | ((unsigned long long)lo.y << 32); r0n = (unsigned long long)lo.z | ((unsigned long long)lo.w << 32);
+            r1n = (unsigned long long)hi.x | ((unsigned long long)hi.y << 32); r2n = (unsigned long long)hi.z | ((unsigned long long)hi.w << 32);
+#else
+            p8n = X.post8[idx];
+#endif
+        };
         if (have_n) {
             cur2 = advance(); have_n2 = cur2 < nchunks; tidn2 = cur2 * 64u + (uint32_t)lane;
             if (have_n2 && tidn2 < ntasks) tn2 = mc_load_stream(&tasks[tidn2]);
-            p8n = X.post8[(tidn < ntasks && tn.read != MC_TASK_NONE) ? tn.posting : 0u];
+            fetch((tidn < ntasks && tn.read != MC_TASK_NONE) ? tn.posting : 0u);
         }
         for (;;) {
             const bool last = !have_n;
             if (!last) {
                 MC_EV_TICK(0);
                 const McSeedTask t = tn;
-                const unsigned long long p8 = p8n;
+                const unsigned long long p8 = p8n, r0 = r0n, r1 = r1n, r2 = r2n;
                 const bool have = tidn < ntasks && t.read != MC_TASK_NONE;   // (MC_TASK_NONE: padding of a partly used block of the pool)
                 // the chunks behind: tn2 (arrived) becomes tn and its postings are asked for; the records of the chunk after it are asked for
                 tn = tn2; tidn = tidn2; have_n = have_n2;
                 if (have_n) {
-                    p8n = X.post8[(tidn < ntasks && tn.read != MC_TASK_NONE) ? tn.posting : 0u];
+                    fetch((tidn < ntasks && tn.read != MC_TASK_NONE) ? tn.posting : 0u);
                     cur = cur2; cur2 = advance(); have_n2 = cur2 < nchunks; tidn2 = cur2 * 64u + (uint32_t)lane;
                     tn2.read = MC_TASK_NONE;
                     if (have_n2 && tidn2 < ntasks) tn2 = mc_load_stream(&tasks[tidn2]);
                 }
                 const uint32_t w3 = t.seedlen_nkey;
-                gate(have, MC_TASK_READ_OF(t.read), t.chrono, (uint32_t)p8 & 0x3FFFFFFu, (uint32_t)(p8 >> 26) & 0xFFFFFFu, (int)(p8 >> 50), (int)((w3 >> 24) & 15u), (int)(w3 >> 28));
+                gate(have, MC_TASK_READ_OF(t.read), t.chrono, (uint32_t)p8 & 0x3FFFFFFu, (uint32_t)(p8 >> 26) & 0xFFFFFFu, (int)(p8 >> 50), (int)((w3 >> 24) & 15u), (int)(w3 >> 28), r0, r1, r2);
                 MC_EV_TICK(1);
             }
             while (qn >= 64 || (last && qn > 0)) extend();

@@ -208,7 +208,7 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
     HIPCK(hipStreamCreate(&h->rows_stream)); HIPCK(hipEventCreateWithFlags(&h->ev_rows, hipEventDisableTiming));
     const McHostIndex &H = h->H;
     if (H.res.size() >= MC_TASK_ABS_LIMIT) { g_err = "marker database too large: more than 16 M residues (MC_TASK_W3)"; return -1; }
-    if (dalloc(&h->d_res_base, H.res.size() + 128) || dalloc(&h->d_off, H.off.size()) || dalloc(&h->d_bstart, H.bstart.size()) || dalloc(&h->d_post, H.post.size() + 1) || dalloc(&h->d_post8, H.post.size() + 1) ||
+    if (dalloc(&h->d_res_base, H.res.size() + 128) || dalloc(&h->d_off, H.off.size()) || dalloc(&h->d_bstart, H.bstart.size()) || dalloc(&h->d_post, H.post.size() + 1) || dalloc(&h->d_post8, (H.post.size() + 1) * MC_POST_WORDS) ||
         dalloc(&h->d_keys, H.keys.size()) || dalloc(&h->d_fam, (size_t)nseq) || dalloc(&h->d_T, 1) || dalloc(&h->d_P, 1)) return -1;
     HIPCK(hipMemset(h->d_res_base, MC_INV, H.res.size() + 128));
     h->d_res = h->d_res_base + 64;                                 // (k_gapped_lds reads 16 bytes at a time around a flank's first residues)
@@ -223,7 +223,7 @@ static int open_impl(mc_handle *h, const int32_t *marker_family, int32_t nfam, i
             (!H.rec.empty() && up.put(h->d_rec, H.rec.data(), H.rec.size() * sizeof(McBucketRec))) || up.finish()) return -1;
     }
     if (H.nseq > 32767) { g_err = "marker database too large: more than 32,767 sequences (MC_POST8)"; return -1; }
-    k_post8<<<dim3((unsigned)((H.post.size() + 255) / 256)), dim3(256)>>>(h->d_post, h->d_off, (uint32_t)H.post.size(), h->d_post8);
+    k_post8<<<dim3((unsigned)((H.post.size() + 255) / 256)), dim3(256)>>>(h->d_post, h->d_off, h->d_res, (uint32_t)H.post.size(), h->d_post8);
     HIPCK(hipDeviceSynchronize());
     MC_OT("  index upload", t0);
     if (H.max_bucket > 2047) { g_err = "a seed bucket holds more than 2047 postings: the hit-order key cannot index it"; return -1; }
