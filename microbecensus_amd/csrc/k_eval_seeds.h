@@ -108,19 +108,10 @@ __device__ __forceinline__ int mc_ev_xdrop(const McHot &T, const int32_t *sub32,
             int32_t runp = P0;
             int i = 0;
             bool alive = true;
-#ifdef MC_EV_PREFETCH
-            uint64_t na = mc_ld8(p1), nb = mc_ld8(p2);
-#endif
             do {
                 MC_EV_TURN(0);
-#ifdef MC_EV_PREFETCH
-                uint64_t wa = na;
-                const uint64_t wb = nb;
-                na = mc_ld8(p1 + i + 8); nb = mc_ld8(p2 + i + 8);
-#else
                 uint64_t wa = mc_ld8(p1 + i);
                 const uint64_t wb = mc_ld8(p2 + i);
-#endif
                 const int rem = lim - i;
                 if (rem < 8) wa |= ~0ull << (8 * rem);
                 int32_t e[8];
@@ -146,19 +137,10 @@ __device__ __forceinline__ int mc_ev_xdrop(const McHot &T, const int32_t *sub32,
             int32_t runp = P0;
             int i = 0;
             bool alive = true;
-#ifdef MC_EV_PREFETCH
-            uint64_t na = mc_ld8(p1), nb = mc_ld8(p2);
-#endif
             do {
                 MC_EV_TURN(1);
-#ifdef MC_EV_PREFETCH
-                uint64_t wa = na;
-                const uint64_t wb = nb;
-                na = mc_ld8(p1 - i - 8); nb = mc_ld8(p2 - i - 8);
-#else
                 uint64_t wa = mc_ld8(p1 - i);
                 const uint64_t wb = mc_ld8(p2 - i);
-#endif
                 const int rem = lim - i;
                 if (rem < 8) wa |= ~0ull >> (8 * rem);
                 int32_t e[8];
