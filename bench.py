@@ -140,7 +140,7 @@ def seed_line_model(cal, L, n_batch, asks, hits, seed_ms):
     is one aligned item = one line asked of the level its structure lives in.  items per read x 1 / rate(footprint class, item width),
     summed, against the kernel's measured duration.  The structures' sizes are those of the marker database (118 MB of index).
     (A hit's posting and its subject's offsets - 150 of the lines a read of 150 bp cost the kernel - are no longer asked here: the hit
-    record holds the posting's index and k_eval_seeds, which does not wait for memory, fetches them.)"""
+    record holds the posting's index and k_eval_seeds fetches them - with the subject's residues, in one 32-byte record: eval_line_model.)"""
     if cal is None or seed_ms <= 0:
         return None
     positions = sum(max(0, (L - f) // 3 - 6) for f in (0, 1, 2)) * 2          # seed positions of the six frames: each asks the bucket bitmap once

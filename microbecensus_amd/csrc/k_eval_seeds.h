@@ -282,7 +282,7 @@ __device__ __forceinline__ uint32_t mc_ev_slots(uint32_t n, uint32_t r, uint32_t
 // RANGES (round 5, the product's seed kernel k_enumerate_q; the name is history: ranges of hits per record were built first and cost this
 // kernel more than they saved the other): a record holds the INDEX of its hit's posting instead of the posting, its place in the residue
 // array and the rest of the subject - the seed kernel is bound by the scattered lines its CUs fetch and a hit's posting and
-// offsets were 150 of the 810 lines a read cost it; this kernel does not wait for memory (5.7) and fetches the three in one 8-byte load.
+// offsets were 150 of the 810 lines a read cost it; this kernel was thought not to wait for memory (5.7; it does: MC_POST_WORDS below) and fetches the three in one 8-byte load.
 // the postings with what the evaluation needs beside them (MC_POST8), made once per handle
 // MC_POST_WORDS = 4 (round 6): the 24 residues of the subject around the posting - dpos - 8 .. dpos + 15, what the gate reads of it - travel
 // WITH it: 32 bytes per posting (115 MB for the marker database instead of 29 + the 14 MB residue array asked at a scattered place), one
