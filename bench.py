@@ -862,6 +862,10 @@ def main():
         except Exception:                                         # noqa: BLE001
             ev_req = None
         elc = eval_line_model(gather_ceiling(), n_batch, hits, hsps + gtasks, kseq["k_eval_seeds"], ev_req)
+        if elc is not None and "k_eval_seeds" in ext:              # (as for the seed kernel: the label follows this run's measurement)
+            ext["k_eval_seeds"]["bound_by_counter_fractions"] = ext["k_eval_seeds"]["bound"]
+            if elc["frac"] >= 0.8:
+                ext["k_eval_seeds"]["bound"] = "fabric"
         # What binds the dominant kernel, from THIS run's measurements (no label or prose that cannot change): the seed kernel is
         # called bound by the fabric's scattered lines when its own ask counters, priced at the machine's calibrated scattered-line rates
         # (profiles/rNN_gather_ceiling.json), account for at least 0.8 of its live duration; otherwise the largest counter fraction of the
