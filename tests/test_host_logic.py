@@ -172,3 +172,22 @@ def test_index_cache_directory_must_be_private(tmp_path, monkeypatch):
         del seen[:]
         _native.use_index_cache()
         assert seen == want
+
+
+def test_bench_line_models_price_asks_at_the_calibrated_rates():
+    """bench.py's two line models (roofline.scattered_line_ceiling / extension_kernel_scattered_line_ceiling): asks x 1 / rate of the committed
+    calibration, summed, over the measured duration - checked on made-up counts against the arithmetic done by hand."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cal = bench.gather_ceiling()
+    assert cal is not None and cal["rate"][("16MB", 32)] > 0 and cal["rate"][("128MB", 32)] > 0
+    n, hits, surv = 1_000_000, 75_000_000, 20_000_000
+    e = bench.eval_line_model(cal, n, hits, surv, 2.0, 2.4)
+    want = hits / (cal["rate"][("128MB", 32)] * 1e9) * 1e3 + 2.0 * surv / (cal["rate"][("16MB", 32)] * 1e9) * 1e3
+    assert abs(e["model_ms_per_launch"] - want) < 2e-3 and abs(e["frac"] - want / 2.0) < 2e-3 and e["hits_per_read"] == 75.0
+    asks = {"seed_exact_asks": 115 * n, "seed_wild_asks": 150 * n, "seed_pair_asks": 77 * n, "seed_probes": 42 * n}
+    s = bench.seed_line_model(cal, 150, n, asks, hits, 5.4)
+    assert s is not None and 0.5 < s["frac"] < 1.5 and abs(sum(r["ms_per_launch"] for r in s["by_structure"]) - s["model_ms_per_launch"]) < 5e-3
+    assert bench.eval_line_model(None, n, hits, surv, 2.0, None) is None and bench.eval_line_model(cal, n, 0, 0, 2.0, None) is None
